@@ -1,0 +1,234 @@
+/*
+ * gfxexp.h -- C ABI of the MI355X-native path-tracing inner loop.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference
+ * interface (file:line under the GfxExp tree) whose job it takes over.  Signatures carry plain
+ * pointers and sizes only; device memory is caller-owned unless stated otherwise
+ * (reference ownership model: restir_di/restir_di_main.cpp:1233-1325).
+ *
+ * All functions return 0 on success, non-zero on failure; gfx_last_error() gives the text
+ * (the reference throws std::runtime_error from CUDADRV_CHECK, utils/cuda_util.cpp:58-69).
+ * Everything is asynchronous with respect to `stream` (a hipStream_t passed as void*), and a
+ * gfx_ctx is not thread-safe (same as the reference: one host thread, restir_di_main.cpp:1705).
+ */
+#ifndef GFXEXP_H
+#define GFXEXP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFX_INVALID_SLOT 0xFFFFFFFFu
+
+typedef struct gfx_ctx gfx_ctx;
+
+/* ---------------------------------------------------------------- POD layouts in HBM -------- */
+
+/* common/common_shared.h:1109-1114 (shared::Vertex, 44 B). */
+typedef struct gfx_vertex {
+    float position[3];
+    float normal[3];
+    float texCoord0Dir[3];
+    float texCoord[2];
+} gfx_vertex;
+
+/* Constant-colour material = what the reference's 1x1 "immediate" textures return from tex2DLod
+ * (common/common_host.cpp:1045-1073,1602-1659).  Values are the *sampled* (linear) values. */
+enum gfx_bsdf_type {
+    GFX_BSDF_LAMBERT = 0,              /* common/common_device.cuh:335-374 */
+    GFX_BSDF_DIFFUSE_AND_SPECULAR = 1, /* common/common_device.cuh:443-765 */
+    GFX_BSDF_SIMPLE_PBR = 2            /* common/common_device.cuh:767-776 */
+};
+typedef struct gfx_material {
+    uint32_t bsdfType;
+    float a[3];          /* lambert reflectance | diffuse | baseColor */
+    float b[3];          /* - | specular F0 | (occlusion, roughness, metallic) */
+    float smoothness;    /* diffuse+specular only */
+    float emittance[3];
+    uint32_t hasEmittance; /* "mat.emittance != 0" in the reference */
+} gfx_material;
+
+/* restir_di/restir_di_shared.h:182-204 -- same element structs, row-major linear arrays. */
+typedef struct gfx_gbuffer0 { uint32_t instSlot, geomInstSlot, primIndex; uint16_t qbcB, qbcC; } gfx_gbuffer0;
+typedef struct gfx_gbuffer1 { float motionVector[2]; } gfx_gbuffer1;
+typedef struct gfx_gbuffer2 { float positionInWorld[3]; uint32_t qGeometricNormal; } gfx_gbuffer2;
+typedef struct gfx_gbuffer3 { uint32_t qShadingNormal, qShadingTangent, qTexCoord, matSlot; } gfx_gbuffer3;
+
+/* restir_di/restir_di_shared.h:89-96,106-139.  Reservoir<LightSample> is 48 B; in HBM it is
+ * stored as THREE planes of 16 B per pixel (plane k starts at k * W*H*16 bytes) so a wavefront's
+ * loads are contiguous:
+ *   plane0 = (emittance.r, emittance.g, emittance.b, position.x)
+ *   plane1 = (position.y, position.z, normal.x, normal.y)
+ *   plane2 = (normal.z, atInfinity as u32 bits, sumWeights, streamLength as u32 bits) */
+typedef struct gfx_reservoir_info { float recPDFEstimate, targetDensity; } gfx_reservoir_info; /* :141-144 */
+
+/* restir_di/restir_di_shared.h:45-60.  orientation is row-major: o[r*3+c]. */
+typedef struct gfx_camera {
+    float aspect;
+    float fovY;
+    float position[3];
+    float orientation[9];
+} gfx_camera;
+
+/* closest-hit record written by gfx_trace (common/common_shared.h:1065-1078 HitObject, compacted). */
+typedef struct gfx_hit {
+    float dist;          /* +inf / tmax on miss */
+    float bcB, bcC;
+    uint32_t triIndex;   /* index into the BVH's triangle records, GFX_INVALID_SLOT on miss */
+} gfx_hit;
+typedef struct gfx_tri_ids { uint32_t instSlot, geomInstSlot, primIndex; } gfx_tri_ids;
+
+/* ---------------------------------------------------------------- context ------------------- */
+
+/* restir_di/restir_di_main.cpp:128-136 (cuInit, cuCtxCreate, optixu::Context::create). */
+int gfx_ctx_create(int device, gfx_ctx** out);
+void gfx_ctx_destroy(gfx_ctx* ctx);
+const char* gfx_last_error(gfx_ctx* ctx);
+/* Library build identification: "gfxexp_amd <version> gfx950". */
+const char* gfx_version(void);
+
+/* ---------------------------------------------------------------- scene --------------------- */
+
+/* common/common_host.cpp:1454-1815 (create*Material) reduced to constant colours. */
+int gfx_material_set(gfx_ctx* ctx, uint32_t matSlot, const gfx_material* mat);
+
+/* common/common_host.cpp:1817-1905 createGeometryInstance: host vertex/triangle arrays in,
+ * geomInstSlot out.  `vertexStride` >= sizeof(gfx_vertex). */
+int gfx_geom_create(gfx_ctx* ctx, const void* vertices, uint32_t vertexStride, uint32_t numVertices,
+                    const uint32_t* triangles, uint32_t numTriangles, uint32_t matSlot,
+                    uint32_t* geomInstSlot);
+/* common/common_host.cpp:2051-2078 createGeometryGroup. */
+int gfx_group_create(gfx_ctx* ctx, const uint32_t* geomInstSlots, uint32_t n, uint32_t* group);
+/* common/common_host.cpp:2582-2656 createInstance: xfm is 3x4 row-major (the float[12] handed to
+ * optixInst.setTransform).  instSlot doubles as the OptiX instance id. */
+int gfx_instance_create(gfx_ctx* ctx, uint32_t group, const float xfm[12], uint32_t* instSlot);
+/* common/common_host.h:798-856 InstanceController::update (per-frame transform + curToPrev). */
+int gfx_instance_set_transform(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12]);
+
+/* common/common_host.h:1027-1100 Scene::updateASs -> OptixTraversableHandle.  Builds the HIP
+ * LBVH -> BVH8 over all instances (world space).  The 64-bit handle fits the reference's
+ * perFramePlp.travHandle field (restir_di_main.cpp:2264). */
+int gfx_accel_build(gfx_ctx* ctx, void* stream, uint64_t* handle);
+/* Build statistics of the last gfx_accel_build: {numTriangles, numNodes, numTriRecords, maxDepth}. */
+int gfx_accel_stats(gfx_ctx* ctx, uint64_t handle, uint32_t stats[4]);
+/* Device pointer to the gfx_tri_ids table of the BVH (indexed by gfx_hit.triIndex). */
+int gfx_accel_tri_ids(gfx_ctx* ctx, uint64_t handle, const void** dTriIds, uint32_t* count);
+
+/* common/common_host.h:1102-1266 setupLightGeomDistributions (once) and
+ * :1268-1359 setupLightInstDistribution (per frame; restir_di_main.cpp:2303-2309). */
+int gfx_lights_build_static(gfx_ctx* ctx, void* stream);
+int gfx_lights_build_instances(gfx_ctx* ctx, void* stream, uint32_t bufferIndex);
+/* Read back the three-level distribution for inspection/tests: level 0 = instances,
+ * 1 = geomInsts of instance `index`, 2 = emitter triangles of geomInst `index`.
+ * weights/cdf may be NULL; returns the element count in *n and the integral in *integral. */
+int gfx_lights_read(gfx_ctx* ctx, uint32_t level, uint32_t index, float* weights, float* cdf,
+                    uint32_t capacity, uint32_t* n, float* integral);
+
+/* ---------------------------------------------------------------- ray queries ---------------- */
+
+/* Replaces optixTrace (utils/optix_util.h:557-603) for wavefront ray queues and the scalar
+ * bvh::traverse (common/bvh_builder.cpp:1272-1649).
+ *   rayOrgTmin[i] = (org.xyz, tmin), rayDirTmax[i] = (dir.xyz, tmax); intervals are exclusive.
+ *   mode CLOSEST: out = gfx_hit[numRays];  mode ANY: out = uint32_t[numRays] (1 = occluded).
+ * counters (optional, device u64[4]): node fetches, triangle fetches, rays, stack spills. */
+enum gfx_trace_mode { GFX_TRACE_CLOSEST = 0, GFX_TRACE_ANY = 1 };
+int gfx_trace(gfx_ctx* ctx, void* stream, uint64_t accel, int mode,
+              const void* dRayOrgTmin, const void* dRayDirTmax, uint32_t numRays,
+              void* dOut, void* dCounters);
+
+/* ---------------------------------------------------------------- ReSTIR DI ------------------ */
+
+/* restir_di/restir_di_shared.h:208-239 StaticPipelineLaunchParameters with surfaces/textures
+ * replaced by plain device pointers (row-major, pixel p = y*W + x). */
+typedef struct gfx_restir_static_params {
+    int32_t imageSizeX, imageSizeY;
+    void* rngBuffer;                 /* uint64_t[W*H]  (PCG32RNG state) */
+    void* gbuffer0[2];
+    void* gbuffer1[2];
+    void* gbuffer2[2];
+    void* gbuffer3[2];
+    void* reservoirBuffer[2];        /* 3 planes x W*H x 16 B */
+    void* reservoirInfoBuffer[2];    /* gfx_reservoir_info[W*H] */
+    void* sampleVisibilityBuffer[2]; /* uint32_t[W*H] (rearchitected only) */
+    const void* spatialNeighborDeltas; /* float2[1024] */
+    void* beautyAccumBuffer;         /* float4[W*H] */
+    void* albedoAccumBuffer;
+    void* normalAccumBuffer;
+    int32_t numTilesX, numTilesY;    /* rearchitected only */
+    void* lightPreSamplingRngs;      /* uint64_t[131072] */
+    void* preSampledLights;          /* 48 B x 131072 */
+    /* environment light (restir_di_shared.h:221-222); NULL = none */
+    const void* envLightTexture;     /* float4[envW*envH], lat-long */
+    int32_t envWidth, envHeight;
+    const void* envRowPDF;           /* float[envH*envW]      conditional PDFs per row */
+    const void* envRowCDF;           /* float[envH*(envW+1)] */
+    const void* envRowIntegrals;     /* float[envH] */
+    const void* envTopPDF;           /* float[envH] */
+    const void* envTopCDF;           /* float[envH+1] */
+    float envTopIntegral;
+} gfx_restir_static_params;
+
+/* restir_di/restir_di_shared.h:241-281 PerFramePipelineLaunchParameters. */
+typedef struct gfx_restir_frame_params {
+    uint64_t travHandle;
+    uint32_t numAccumFrames;
+    uint32_t frameIndex;
+    gfx_camera camera;
+    gfx_camera prevCamera;
+    float envLightPowerCoeff;
+    float envLightRotation;
+    float spatialNeighborRadius;
+    float radiusThresholdForSpatialVisReuse;
+    uint32_t log2NumCandidateSamples;
+    uint32_t numSpatialNeighbors;
+    uint32_t useLowDiscrepancyNeighbors;
+    uint32_t reuseVisibility;
+    uint32_t reuseVisibilityForTemporal;
+    uint32_t reuseVisibilityForSpatiotemporal;
+    uint32_t enableTemporalReuse;
+    uint32_t enableSpatialReuse;
+    uint32_t useUnbiasedEstimator;
+    uint32_t bufferIndex;
+    uint32_t resetFlowBuffer;
+    uint32_t enableJittering;
+    uint32_t enableEnvLight;
+    uint32_t enableBumpMapping;
+} gfx_restir_frame_params;
+
+/* restir_di/restir_di_main.cpp:2350-2359: the three cuMemcpyHtoDAsync of plp/perFramePlp.
+ * currentReservoirIndex is 1 bit, spatialNeighborBaseIndex wraps to 10 bits
+ * (restir_di_shared.h:283-288). */
+int gfx_restir_set_params(gfx_ctx* ctx, void* stream,
+                          const gfx_restir_static_params* s, const gfx_restir_frame_params* f,
+                          uint32_t currentReservoirIndex, uint32_t spatialNeighborBaseIndex);
+
+/* restir_di/restir_di_main.cpp:72-95 entry-point enums; pipeline.launch(stream, plp, W, H, 1)
+ * at :2366-2420. */
+enum gfx_restir_pass {
+    GFX_RESTIR_SETUP_GBUFFERS = 0,                 /* optix_gbuffer_kernels.cu:5-243 */
+    GFX_RESTIR_INITIAL_RIS = 1,                    /* optix_restir_di_kernels.cu:289-291 */
+    GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED = 2,    /* :293-295 */
+    GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED = 3,  /* :297-299 */
+    GFX_RESTIR_SPATIAL_BIASED = 4,                 /* :549-551 */
+    GFX_RESTIR_SPATIAL_UNBIASED = 5,               /* :553-555 */
+    GFX_RESTIR_SHADING = 6,                        /* :559-637 */
+    GFX_RESTIR_NUM_PASSES
+};
+int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height);
+
+/* Per-kernel HIP-event timing of the launches issued since the last reset
+ * (cudau::Timer, utils/cuda_util.h:441-485).  names/ms arrays sized by capacity. */
+int gfx_timing_enable(gfx_ctx* ctx, int enable);
+int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t* calls,
+                       uint32_t capacity, uint32_t* n);
+/* Ray-traversal counters accumulated by the ReSTIR passes (device u64[4], see gfx_trace). */
+int gfx_counters_enable(gfx_ctx* ctx, int enable);
+int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[4], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFXEXP_H */
