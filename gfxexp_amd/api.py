@@ -1,0 +1,436 @@
+"""ctypes bindings of libgfxexp.so (include/gfxexp.h + include/gfxexp_host.h).
+
+The library is the product: hand-written HIP kernels for gfx950 behind a C ABI.  There is no CPU
+fallback -- if the shared object is missing or a call fails, these bindings raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgfxexp.so")
+
+GFX_INVALID_SLOT = 0xFFFFFFFF
+TRACE_CLOSEST, TRACE_ANY = 0, 1
+(PASS_SETUP_GBUFFERS, PASS_INITIAL_RIS, PASS_INITIAL_TEMPORAL_BIASED, PASS_INITIAL_TEMPORAL_UNBIASED,
+ PASS_SPATIAL_BIASED, PASS_SPATIAL_UNBIASED, PASS_SHADING) = range(7)
+RENDERER_BIASED, RENDERER_UNBIASED = 0, 1
+
+
+class GfxError(RuntimeError):
+    pass
+
+
+class GfxMaterial(C.Structure):
+    _fields_ = [("bsdfType", C.c_uint32), ("a", C.c_float * 3), ("b", C.c_float * 3),
+                ("smoothness", C.c_float), ("emittance", C.c_float * 3), ("hasEmittance", C.c_uint32)]
+
+
+class GfxCamera(C.Structure):
+    _fields_ = [("aspect", C.c_float), ("fovY", C.c_float), ("position", C.c_float * 3),
+                ("orientation", C.c_float * 9)]
+
+
+class GfxRestirStaticParams(C.Structure):
+    _fields_ = [
+        ("imageSizeX", C.c_int32), ("imageSizeY", C.c_int32),
+        ("rngBuffer", C.c_void_p),
+        ("gbuffer0", C.c_void_p * 2), ("gbuffer1", C.c_void_p * 2),
+        ("gbuffer2", C.c_void_p * 2), ("gbuffer3", C.c_void_p * 2),
+        ("reservoirBuffer", C.c_void_p * 2), ("reservoirInfoBuffer", C.c_void_p * 2),
+        ("sampleVisibilityBuffer", C.c_void_p * 2),
+        ("spatialNeighborDeltas", C.c_void_p),
+        ("beautyAccumBuffer", C.c_void_p), ("albedoAccumBuffer", C.c_void_p), ("normalAccumBuffer", C.c_void_p),
+        ("numTilesX", C.c_int32), ("numTilesY", C.c_int32),
+        ("lightPreSamplingRngs", C.c_void_p), ("preSampledLights", C.c_void_p),
+        ("envLightTexture", C.c_void_p), ("envWidth", C.c_int32), ("envHeight", C.c_int32),
+        ("envRowPDF", C.c_void_p), ("envRowCDF", C.c_void_p), ("envRowIntegrals", C.c_void_p),
+        ("envTopPDF", C.c_void_p), ("envTopCDF", C.c_void_p), ("envTopIntegral", C.c_float),
+    ]
+
+
+class GfxRestirFrameParams(C.Structure):
+    _fields_ = [
+        ("travHandle", C.c_uint64), ("numAccumFrames", C.c_uint32), ("frameIndex", C.c_uint32),
+        ("camera", GfxCamera), ("prevCamera", GfxCamera),
+        ("envLightPowerCoeff", C.c_float), ("envLightRotation", C.c_float),
+        ("spatialNeighborRadius", C.c_float), ("radiusThresholdForSpatialVisReuse", C.c_float),
+        ("log2NumCandidateSamples", C.c_uint32), ("numSpatialNeighbors", C.c_uint32),
+        ("useLowDiscrepancyNeighbors", C.c_uint32), ("reuseVisibility", C.c_uint32),
+        ("reuseVisibilityForTemporal", C.c_uint32), ("reuseVisibilityForSpatiotemporal", C.c_uint32),
+        ("enableTemporalReuse", C.c_uint32), ("enableSpatialReuse", C.c_uint32),
+        ("useUnbiasedEstimator", C.c_uint32), ("bufferIndex", C.c_uint32),
+        ("resetFlowBuffer", C.c_uint32), ("enableJittering", C.c_uint32),
+        ("enableEnvLight", C.c_uint32), ("enableBumpMapping", C.c_uint32),
+    ]
+
+
+class GfxhStreetParams(C.Structure):
+    _fields_ = [("seed", C.c_uint32), ("groundTess", C.c_uint32), ("numBuildings", C.c_uint32),
+                ("facadeTess", C.c_uint32), ("numProps", C.c_uint32), ("propSubdiv", C.c_uint32),
+                ("numLamps", C.c_uint32), ("numSigns", C.c_uint32), ("extent", C.c_float),
+                ("lampEmittance", C.c_float), ("signEmittance", C.c_float)]
+
+
+class GfxhRestirConfig(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("renderer", C.c_int),
+                ("log2NumCandidateSamples", C.c_uint32), ("enableTemporalReuse", C.c_uint32),
+                ("enableSpatialReuse", C.c_uint32), ("numSpatialReusePasses", C.c_uint32),
+                ("numSpatialNeighbors", C.c_uint32), ("spatialNeighborRadius", C.c_float),
+                ("useLowDiscrepancyNeighbors", C.c_uint32), ("reuseVisibility", C.c_uint32),
+                ("enableAccumulation", C.c_uint32), ("log2MaxNumAccums", C.c_uint32),
+                ("camera", GfxCamera), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32)]
+
+
+HIT_DTYPE = np.dtype([("dist", "<f4"), ("bcB", "<f4"), ("bcC", "<f4"), ("triIndex", "<u4")])
+TRI_IDS_DTYPE = np.dtype([("instSlot", "<u4"), ("geomInstSlot", "<u4"), ("primIndex", "<u4")])
+VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("texCoord0Dir", "<f4", 3),
+                         ("texCoord", "<f4", 2)])
+GBUFFER0_DTYPE = np.dtype([("instSlot", "<u4"), ("geomInstSlot", "<u4"), ("primIndex", "<u4"),
+                           ("qbcB", "<u2"), ("qbcC", "<u2")])
+GBUFFER2_DTYPE = np.dtype([("positionInWorld", "<f4", 3), ("qGeometricNormal", "<u4")])
+GBUFFER3_DTYPE = np.dtype([("qShadingNormal", "<u4"), ("qShadingTangent", "<u4"), ("qTexCoord", "<u4"),
+                           ("matSlot", "<u4")])
+
+# every symbol include/gfxexp.h and include/gfxexp_host.h declare
+C_ABI_SYMBOLS = [
+    "gfx_ctx_create", "gfx_ctx_destroy", "gfx_last_error", "gfx_version", "gfx_material_set", "gfx_geom_create",
+    "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_accel_build",
+    "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
+    "gfx_lights_build_instances", "gfx_lights_read", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
+    "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read",
+]
+HOST_ABI_SYMBOLS = [
+    "gfxh_scene_create", "gfxh_scene_destroy", "gfxh_last_error", "gfxh_scene_add_material_traditional",
+    "gfxh_scene_add_material", "gfxh_scene_add_geom", "gfxh_scene_add_group", "gfxh_scene_add_instance",
+    "gfxh_scene_load_obj", "gfxh_scene_add_rectangle", "gfxh_scene_make_street", "gfxh_scene_counts",
+    "gfxh_scene_get_material", "gfxh_scene_get_geom", "gfxh_scene_get_group", "gfxh_scene_get_instance",
+    "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
+    "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_restir_create",
+    "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera",
+    "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libgfxexp.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GfxError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
+        # libhsa-runtime64.so.1.  Importing torch first makes the loader resolve this library's
+        # NEEDED libamdhip64.so.7 to that already-loaded copy (same SONAME); the other order loads a
+        # second runtime and torch then reports "No HIP GPUs are available".
+        try:
+            import torch  # noqa: F401  (device memory / streams / torch.distributed plumbing)
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        L.gfx_last_error.restype = C.c_char_p
+        L.gfx_version.restype = C.c_char_p
+        L.gfxh_last_error.restype = C.c_char_p
+        L.gfxh_restir_last_error.restype = C.c_char_p
+        L.gfxh_scene_create.restype = C.c_void_p
+        L.gfxh_restir_beauty_buffer.restype = C.c_void_p
+        L.gfxh_restir_accel.restype = C.c_uint64
+        for name in ("gfxh_scene_add_material_traditional", "gfxh_scene_add_material", "gfxh_scene_add_geom",
+                     "gfxh_scene_add_group", "gfxh_scene_add_instance", "gfxh_scene_load_obj", "gfxh_scene_add_rectangle"):
+            getattr(L, name).restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+# ---------------------------------------------------------------- host layer: scenes
+class HostScene:
+    """gfxh_scene: materials / geometry / groups / instances on the host."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.gfxh_scene_create())
+
+    def close(self):
+        if self.h:
+            self.L.gfxh_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_material_traditional(self, diffuse, specular, smoothness, emittance=(0, 0, 0)):
+        return self.L.gfxh_scene_add_material_traditional(self.h, _f3(diffuse), _f3(specular), C.c_float(smoothness),
+                                                          _f3(emittance))
+
+    def add_material(self, mat):
+        return self.L.gfxh_scene_add_material(self.h, C.byref(mat))
+
+    def add_geom(self, vertices, triangles, mat_slot):
+        v = np.ascontiguousarray(vertices)
+        assert v.dtype == VERTEX_DTYPE
+        t = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        return self.L.gfxh_scene_add_geom(self.h, _p(v), C.c_uint32(len(v)), _p(t), C.c_uint32(len(t)), C.c_uint32(mat_slot))
+
+    def add_group(self, geoms):
+        g = np.ascontiguousarray(geoms, np.uint32)
+        return self.L.gfxh_scene_add_group(self.h, _p(g), C.c_uint32(len(g)))
+
+    def add_instance(self, group, xfm12):
+        x = np.ascontiguousarray(xfm12, np.float32).reshape(12)
+        return self.L.gfxh_scene_add_instance(self.h, C.c_uint32(group), _p(x))
+
+    def load_obj(self, path):
+        g = self.L.gfxh_scene_load_obj(self.h, path.encode())
+        if g == GFX_INVALID_SLOT:
+            raise GfxError(self.L.gfxh_last_error().decode())
+        return g
+
+    def add_rectangle(self, width, depth, emittance):
+        return self.L.gfxh_scene_add_rectangle(self.h, C.c_float(width), C.c_float(depth), _f3(emittance))
+
+    def make_street(self, params):
+        if self.L.gfxh_scene_make_street(self.h, C.byref(params)):
+            raise GfxError(self.L.gfxh_last_error().decode())
+
+    def counts(self):
+        c = (C.c_uint32 * 5)()
+        self.L.gfxh_scene_counts(self.h, c)
+        return dict(materials=c[0], geoms=c[1], groups=c[2], insts=c[3], triangles=c[4])
+
+    def bounds(self):
+        b = (C.c_float * 6)()
+        self.L.gfxh_scene_bounds(self.h, b)
+        return np.array(list(b), np.float32)
+
+    def materials(self):
+        out = []
+        for i in range(self.counts()["materials"]):
+            m = GfxMaterial()
+            self.L.gfxh_scene_get_material(self.h, C.c_uint32(i), C.byref(m))
+            out.append(m)
+        return out
+
+    def geoms(self):
+        out = []
+        for i in range(self.counts()["geoms"]):
+            vp, tp = C.c_void_p(), C.c_void_p()
+            nv, nt, mat = C.c_uint32(), C.c_uint32(), C.c_uint32()
+            self.L.gfxh_scene_get_geom(self.h, C.c_uint32(i), C.byref(vp), C.byref(nv), C.byref(tp), C.byref(nt), C.byref(mat))
+            v = np.frombuffer((C.c_char * (44 * nv.value)).from_address(vp.value), dtype=VERTEX_DTYPE).copy()
+            t = np.frombuffer((C.c_char * (12 * nt.value)).from_address(tp.value), dtype=np.uint32).reshape(-1, 3).copy()
+            out.append((v, t, mat.value))
+        return out
+
+    def groups(self):
+        out = []
+        for i in range(self.counts()["groups"]):
+            gp, n = C.c_void_p(), C.c_uint32()
+            self.L.gfxh_scene_get_group(self.h, C.c_uint32(i), C.byref(gp), C.byref(n))
+            out.append(np.frombuffer((C.c_char * (4 * n.value)).from_address(gp.value), dtype=np.uint32).copy())
+        return out
+
+    def instances(self):
+        out = []
+        for i in range(self.counts()["insts"]):
+            g = C.c_uint32()
+            x = (C.c_float * 12)()
+            self.L.gfxh_scene_get_instance(self.h, C.c_uint32(i), C.byref(g), x)
+            out.append((g.value, np.array(list(x), np.float32)))
+        return out
+
+    def upload(self, ctx):
+        if self.L.gfxh_scene_upload(self.h, ctx.h):
+            raise GfxError(self.L.gfxh_last_error().decode())
+
+
+def make_transform(scale=1.0, roll=0.0, pitch=0.0, yaw=0.0, pos=(0, 0, 0)):
+    out = (C.c_float * 12)()
+    lib().gfxh_make_transform(C.c_float(scale), C.c_float(roll), C.c_float(pitch), C.c_float(yaw), _f3(pos), out)
+    return np.array(list(out), np.float32)
+
+
+def make_camera(width, height, pos, roll=0.0, pitch=0.0, yaw=0.0, fov_y_deg=50.0):
+    cam = GfxCamera()
+    cam.aspect = float(width) / float(height)
+    cam.fovY = np.float32(fov_y_deg * np.pi / 180)
+    cam.position = _f3(pos)
+    ori = (C.c_float * 9)()
+    lib().gfxh_make_orientation(C.c_float(roll), C.c_float(pitch), C.c_float(yaw), ori)
+    cam.orientation = ori
+    return cam
+
+
+def seed_rng_states(count, seed):
+    out = np.zeros(count, np.uint64)
+    lib().gfxh_seed_rng_states(_p(out), C.c_uint64(count), C.c_uint64(seed))
+    return out
+
+
+def spatial_neighbor_deltas():
+    out = np.zeros((1024, 2), np.float32)
+    lib().gfxh_spatial_neighbor_deltas(_p(out))
+    return out
+
+
+# ---------------------------------------------------------------- device context
+class Context:
+    """gfx_ctx: scene tables, BVH and kernels on one GPU."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        if self.L.gfx_ctx_create(C.c_int(device), C.byref(h)):
+            raise GfxError("gfx_ctx_create: " + self.L.gfx_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.gfx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise GfxError(self.L.gfx_last_error(self.h).decode())
+
+    def accel_build(self, stream=0, handle=0):
+        hd = C.c_uint64(handle)
+        self._check(self.L.gfx_accel_build(self.h, C.c_void_p(stream), C.byref(hd)))
+        return hd.value
+
+    def accel_set_max_leaf(self, n):
+        self._check(self.L.gfx_accel_set_max_leaf(self.h, C.c_uint32(n)))
+
+    def accel_stats(self, handle):
+        s = (C.c_uint32 * 4)()
+        self._check(self.L.gfx_accel_stats(self.h, C.c_uint64(handle), s))
+        return dict(triangles=s[0], nodes=s[1], triRecords=s[2], maxDepth=s[3])
+
+    def accel_tri_ids_ptr(self, handle):
+        p, n = C.c_void_p(), C.c_uint32()
+        self._check(self.L.gfx_accel_tri_ids(self.h, C.c_uint64(handle), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def lights_build_static(self, stream=0):
+        self._check(self.L.gfx_lights_build_static(self.h, C.c_void_p(stream)))
+
+    def lights_build_instances(self, stream=0, buffer_index=0):
+        self._check(self.L.gfx_lights_build_instances(self.h, C.c_void_p(stream), C.c_uint32(buffer_index)))
+
+    def lights_read(self, level, index=0):
+        n, integ = C.c_uint32(), C.c_float()
+        self._check(self.L.gfx_lights_read(self.h, C.c_uint32(level), C.c_uint32(index), None, None, C.c_uint32(0),
+                                           C.byref(n), C.byref(integ)))
+        w = np.zeros(n.value, np.float32)
+        c = np.zeros(n.value, np.float32)
+        self._check(self.L.gfx_lights_read(self.h, C.c_uint32(level), C.c_uint32(index), _p(w), _p(c), C.c_uint32(n.value),
+                                           C.byref(n), C.byref(integ)))
+        return w, c, integ.value
+
+    def trace(self, accel, mode, d_ray_org, d_ray_dir, num_rays, d_out, d_counters=0, stream=0):
+        self._check(self.L.gfx_trace(self.h, C.c_void_p(stream), C.c_uint64(accel), C.c_int(mode), C.c_void_p(d_ray_org),
+                                     C.c_void_p(d_ray_dir), C.c_uint32(num_rays), C.c_void_p(d_out), C.c_void_p(d_counters)))
+
+    def restir_set_params(self, static_params, frame_params, cur_res_index, base_index, stream=0):
+        self._check(self.L.gfx_restir_set_params(self.h, C.c_void_p(stream),
+                                                 C.byref(static_params) if static_params is not None else None,
+                                                 C.byref(frame_params) if frame_params is not None else None,
+                                                 C.c_uint32(cur_res_index), C.c_uint32(base_index)))
+
+    def restir_launch(self, pass_id, width, height, stream=0):
+        self._check(self.L.gfx_restir_launch(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height)))
+
+    def read_device(self, dptr, nbytes):
+        out = np.zeros(nbytes, np.uint8)
+        self._check(self.L.gfx_read_device(self.h, C.c_void_p(dptr), _p(out), C.c_size_t(nbytes)))
+        return out
+
+    def timing_enable(self, on=True):
+        self._check(self.L.gfx_timing_enable(self.h, C.c_int(1 if on else 0)))
+
+    def timing_collect(self):
+        cap = 64
+        names = ((C.c_char * 48) * cap)()
+        ms = (C.c_float * cap)()
+        calls = (C.c_uint32 * cap)()
+        n = C.c_uint32()
+        self._check(self.L.gfx_timing_collect(self.h, names, ms, calls, C.c_uint32(cap), C.byref(n)))
+        return {names[i].value.decode(): (ms[i], calls[i]) for i in range(min(n.value, cap))}
+
+    def counters_enable(self, on=True):
+        self._check(self.L.gfx_counters_enable(self.h, C.c_int(1 if on else 0)))
+
+    def counters_read(self, reset=True):
+        c = (C.c_uint64 * 4)()
+        self._check(self.L.gfx_counters_read(self.h, c, C.c_int(1 if reset else 0)))
+        return dict(nodeFetches=c[0], triFetches=c[1], rays=c[2], spills=c[3])
+
+
+class RestirRenderer:
+    """gfxh_restir: the headless frame loop of restir_di_main.cpp over the C ABI."""
+
+    def __init__(self, ctx, cfg):
+        self.L = lib()
+        self.ctx = ctx
+        self.cfg = cfg
+        h = C.c_void_p()
+        if self.L.gfxh_restir_create(ctx.h, C.byref(cfg), C.byref(h)):
+            raise GfxError("gfxh_restir_create: " + self.L.gfxh_restir_last_error().decode())
+        self.h = h
+
+    @staticmethod
+    def default_config(width, height, renderer=RENDERER_BIASED):
+        cfg = GfxhRestirConfig()
+        lib().gfxh_restir_default_config(C.byref(cfg), C.c_uint32(width), C.c_uint32(height), C.c_int(renderer))
+        return cfg
+
+    def close(self):
+        if self.h:
+            self.L.gfxh_restir_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_frame(self, stream=0):
+        if self.L.gfxh_restir_render_frame(self.h, C.c_void_p(stream)):
+            raise GfxError("gfxh_restir_render_frame: " + self.L.gfxh_restir_last_error().decode())
+
+    def reset(self):
+        self.L.gfxh_restir_reset(self.h)
+
+    def set_camera(self, cam):
+        self.L.gfxh_restir_set_camera(self.h, C.byref(cam))
+
+    def beauty_ptr(self):
+        return self.L.gfxh_restir_beauty_buffer(self.h)
+
+    def accel(self):
+        return self.L.gfxh_restir_accel(self.h)
+
+    def params(self):
+        s, f = GfxRestirStaticParams(), GfxRestirFrameParams()
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.L.gfxh_restir_get_params(self.h, C.byref(s), C.byref(f), C.byref(a), C.byref(b), C.byref(c))
+        return s, f, a.value, b.value, c.value

@@ -1,0 +1,72 @@
+"""Builds gfxexp_amd/libgfxexp.so in-tree with hipcc for gfx950 (no JIT cache, the .so travels
+with the repository snapshot).  Flags that are part of the numerical contract:
+  -ffp-contract=off                              no fused multiply-add unless written as fmaf
+  -fhip-fp32-correctly-rounded-divide-sqrt       IEEE division / sqrt on the device
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libgfxexp.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+SOURCES = ["capi.cpp", "scene.cpp", "lights.hip", "lbvh.hip", "trace.hip", "restir.hip",
+           "host/scene_builder.cpp", "host/restir_driver.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         "-I" + os.path.join(HERE, "..", "include")]
+
+
+def _deps_hash(src):
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for dp, _, fns in sorted(os.walk(root)):
+            for fn in sorted(fns):
+                if fn.endswith((".h", ".hip", ".cpp")) and (fn.endswith(".h") or os.path.join(dp, fn) == src):
+                    with open(os.path.join(dp, fn), "rb") as f:
+                        h.update(f.read())
+    return h.hexdigest()
+
+
+def _compile(rel):
+    src = os.path.join(CSRC, rel)
+    if not os.path.exists(src):
+        return None
+    obj = os.path.join(OBJ, rel.replace("/", "_") + ".o")
+    stamp = obj + ".stamp"
+    want = _deps_hash(src)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
+        return obj
+    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if rel.endswith(".hip") else []) + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (rel, r.stdout[-4000:], r.stderr[-8000:]))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr[-3000:])
+    with open(stamp, "w") as f:
+        f.write(want)
+    return obj
+
+
+def build(force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for fn in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, fn))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = [o for o in ex.map(_compile, SOURCES) if o]
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,283 @@
+// capi.cpp -- extern "C" entry points declared in include/gfxexp.h.
+// Error model: every HIP failure becomes a non-zero return + gfx_last_error() text (the reference
+// throws std::runtime_error from CUDADRV_CHECK, utils/cuda_util.cpp:58-69; a C++ shim above this
+// ABI can re-throw).
+#include <cstring>
+#include "internal.h"
+
+using namespace gfx;
+
+struct gfx_ctx { Context c; };
+
+static thread_local std::string g_createError;
+
+#define GFX_TRY(ctx) try {
+#define GFX_CATCH(ctx) \
+    return 0; } \
+    catch (const std::exception& e) { (ctx)->c.lastError = e.what(); return 1; } \
+    catch (...) { (ctx)->c.lastError = "unknown error"; return 1; }
+
+extern "C" {
+
+const char* gfx_version(void) { return "gfxexp_amd 0.1 gfx950"; }
+
+int gfx_ctx_create(int device, gfx_ctx** out) {
+    *out = nullptr;
+    try {
+        int count = 0;
+        GFX_HIP(hipGetDeviceCount(&count));
+        if (device < 0 || device >= count) throw HipError("gfx_ctx_create: no such HIP device");
+        GFX_HIP(hipSetDevice(device));
+        gfx_ctx* ctx = new gfx_ctx();
+        ctx->c.device = device;
+        ctx->c.dTraceCounters.reserve(64);
+        GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 64));
+        *out = ctx;
+        return 0;
+    }
+    catch (const std::exception& e) { g_createError = e.what(); return 1; }
+}
+
+void gfx_ctx_destroy(gfx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipDeviceSynchronize();
+    delete ctx;
+}
+
+const char* gfx_last_error(gfx_ctx* ctx) { return ctx ? ctx->c.lastError.c_str() : g_createError.c_str(); }
+
+int gfx_material_set(gfx_ctx* ctx, uint32_t matSlot, const gfx_material* mat) {
+    GFX_TRY(ctx)
+    if (ctx->c.materials.size() <= matSlot) {
+        gfx_material zero; std::memset(&zero, 0, sizeof(zero));
+        ctx->c.materials.resize(matSlot + 1, zero);
+    }
+    ctx->c.materials[matSlot] = *mat;
+    ctx->c.sceneDirty = true;
+    GFX_CATCH(ctx)
+}
+
+int gfx_geom_create(gfx_ctx* ctx, const void* vertices, uint32_t vertexStride, uint32_t numVertices,
+                    const uint32_t* triangles, uint32_t numTriangles, uint32_t matSlot, uint32_t* geomInstSlot) {
+    GFX_TRY(ctx)
+    if (vertexStride < sizeof(gfx_vertex)) throw HipError("gfx_geom_create: vertexStride smaller than gfx_vertex");
+    HostGeom g;
+    g.vertices.resize(numVertices);
+    for (uint32_t i = 0; i < numVertices; ++i) {
+        gfx_vertex v;
+        std::memcpy(&v, static_cast<const uint8_t*>(vertices) + static_cast<size_t>(vertexStride) * i, sizeof(v));
+        DevVertex& d = g.vertices[i];
+        d.px = v.position[0]; d.py = v.position[1]; d.pz = v.position[2];
+        d.nx = v.normal[0]; d.ny = v.normal[1]; d.nz = v.normal[2];
+        d.tx = v.texCoord0Dir[0]; d.ty = v.texCoord0Dir[1]; d.tz = v.texCoord0Dir[2];
+        d.u = v.texCoord[0]; d.v = v.texCoord[1]; d.pad = 0;
+    }
+    g.triangles.assign(triangles, triangles + 3ull * numTriangles);
+    for (uint32_t idx : g.triangles) if (idx >= numVertices) throw HipError("gfx_geom_create: triangle index out of range");
+    g.materialSlot = matSlot;
+    *geomInstSlot = static_cast<uint32_t>(ctx->c.geoms.size());
+    ctx->c.geoms.push_back(std::move(g));
+    ctx->c.sceneDirty = true;
+    GFX_CATCH(ctx)
+}
+
+int gfx_group_create(gfx_ctx* ctx, const uint32_t* geomInstSlots, uint32_t n, uint32_t* group) {
+    GFX_TRY(ctx)
+    for (uint32_t i = 0; i < n; ++i) if (geomInstSlots[i] >= ctx->c.geoms.size()) throw HipError("gfx_group_create: unknown geomInstSlot");
+    *group = static_cast<uint32_t>(ctx->c.groups.size());
+    ctx->c.groups.emplace_back(geomInstSlots, geomInstSlots + n);
+    ctx->c.sceneDirty = true;
+    GFX_CATCH(ctx)
+}
+
+int gfx_instance_create(gfx_ctx* ctx, uint32_t group, const float xfm[12], uint32_t* instSlot) {
+    GFX_TRY(ctx)
+    if (group >= ctx->c.groups.size()) throw HipError("gfx_instance_create: unknown group");
+    HostInstance inst;
+    inst.group = group;
+    std::memcpy(inst.transform, xfm, sizeof(float) * 12);
+    std::memcpy(inst.prevTransform, xfm, sizeof(float) * 12);
+    *instSlot = static_cast<uint32_t>(ctx->c.insts.size());
+    ctx->c.insts.push_back(inst);
+    ctx->c.sceneDirty = true;
+    GFX_CATCH(ctx)
+}
+
+int gfx_instance_set_transform(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12]) {
+    GFX_TRY(ctx)
+    if (instSlot >= ctx->c.insts.size()) throw HipError("gfx_instance_set_transform: unknown instSlot");
+    HostInstance& inst = ctx->c.insts[instSlot];
+    std::memcpy(inst.prevTransform, inst.transform, sizeof(float) * 12);
+    std::memcpy(inst.transform, xfm, sizeof(float) * 12);
+    ctx->c.sceneDirty = true;
+    GFX_CATCH(ctx)
+}
+
+int gfx_accel_build(gfx_ctx* ctx, void* stream, uint64_t* handle) {
+    GFX_TRY(ctx)
+    Accel* a = nullptr;
+    if (*handle != 0 && *handle <= ctx->c.accels.size() && ctx->c.accels[*handle - 1]) a = ctx->c.accels[*handle - 1]; // rebuild in place
+    else { a = new Accel(); ctx->c.accels.push_back(a); *handle = ctx->c.accels.size(); }
+    lbvh_build(ctx->c, static_cast<hipStream_t>(stream), *a);
+    GFX_CATCH(ctx)
+}
+
+static Accel* find_accel(gfx_ctx* ctx, uint64_t handle) {
+    if (handle == 0 || handle > ctx->c.accels.size() || !ctx->c.accels[handle - 1]) throw HipError("invalid accel handle");
+    return ctx->c.accels[handle - 1];
+}
+
+int gfx_accel_stats(gfx_ctx* ctx, uint64_t handle, uint32_t stats[4]) {
+    GFX_TRY(ctx)
+    const Accel* a = find_accel(ctx, handle);
+    stats[0] = a->numInputTris; stats[1] = a->numNodes; stats[2] = a->numTris; stats[3] = a->maxDepth;
+    GFX_CATCH(ctx)
+}
+
+int gfx_accel_tri_ids(gfx_ctx* ctx, uint64_t handle, const void** dTriIds, uint32_t* count) {
+    GFX_TRY(ctx)
+    const Accel* a = find_accel(ctx, handle);
+    *dTriIds = a->triIds.p; *count = a->numTris;
+    GFX_CATCH(ctx)
+}
+
+int gfx_accel_set_max_leaf(gfx_ctx* ctx, uint32_t maxLeafTris) {
+    GFX_TRY(ctx)
+    ctx->c.maxLeafTris = maxLeafTris < 1 ? 1 : (maxLeafTris > 15 ? 15 : maxLeafTris);
+    GFX_CATCH(ctx)
+}
+
+int gfx_lights_build_static(gfx_ctx* ctx, void* stream) {
+    GFX_TRY(ctx)
+    lights_build_static(ctx->c, static_cast<hipStream_t>(stream));
+    GFX_CATCH(ctx)
+}
+
+int gfx_lights_build_instances(gfx_ctx* ctx, void* stream, uint32_t bufferIndex) {
+    GFX_TRY(ctx)
+    lights_build_instances(ctx->c, static_cast<hipStream_t>(stream), bufferIndex);
+    GFX_CATCH(ctx)
+}
+
+int gfx_lights_read(gfx_ctx* ctx, uint32_t level, uint32_t index, float* weights, float* cdf,
+                    uint32_t capacity, uint32_t* n, float* integral) {
+    GFX_TRY(ctx)
+    Context& c = ctx->c;
+    GFX_HIP(hipDeviceSynchronize());
+    uint32_t off = 0xFFFFFFFFu, count = 0;
+    float integ = 0.0f;
+    if (level == 0) {
+        off = c.lightInstDistOffset; count = static_cast<uint32_t>(c.insts.size());
+        GFX_HIP(hipMemcpy(&integ, c.dLightInstIntegral.p, sizeof(float), hipMemcpyDeviceToHost));
+    }
+    else if (level == 1) {
+        if (index >= c.hInsts.size()) throw HipError("gfx_lights_read: bad instance index");
+        DevInstance d;
+        GFX_HIP(hipMemcpy(&d, c.dInsts.as<DevInstance>() + index, sizeof(d), hipMemcpyDeviceToHost));
+        off = d.distOffset; count = off == 0xFFFFFFFFu ? 0 : d.numGeomInsts; integ = d.distIntegral;
+    }
+    else {
+        if (index >= c.hGeomInsts.size()) throw HipError("gfx_lights_read: bad geomInst index");
+        DevGeomInst d;
+        GFX_HIP(hipMemcpy(&d, c.dGeomInsts.as<DevGeomInst>() + index, sizeof(d), hipMemcpyDeviceToHost));
+        off = d.distOffset; count = off == 0xFFFFFFFFu ? 0 : d.distCount; integ = d.distIntegral;
+    }
+    *n = count; *integral = integ;
+    const uint32_t m = count < capacity ? count : capacity;
+    if (m && weights) GFX_HIP(hipMemcpy(weights, c.dLightW.as<float>() + off, sizeof(float) * m, hipMemcpyDeviceToHost));
+    if (m && cdf) GFX_HIP(hipMemcpy(cdf, c.dLightCDF.as<float>() + off, sizeof(float) * m, hipMemcpyDeviceToHost));
+    GFX_CATCH(ctx)
+}
+
+int gfx_trace(gfx_ctx* ctx, void* stream, uint64_t accel, int mode, const void* dRayOrgTmin, const void* dRayDirTmax,
+              uint32_t numRays, void* dOut, void* dCounters) {
+    GFX_TRY(ctx)
+    const Accel* a = find_accel(ctx, accel);
+    TraceLaunch t;
+    t.accel = a->dev();
+    t.rayOrgTmin = static_cast<const float4*>(dRayOrgTmin);
+    t.rayDirTmax = static_cast<const float4*>(dRayDirTmax);
+    t.numRays = numRays; t.numRaysPtr = nullptr; t.out = dOut; t.mode = mode;
+    // explicit counter buffer: count into the caller's u64[4]
+    const bool savedEnabled = ctx->c.countersEnabled;
+    DevBuf saved = ctx->c.dTraceCounters;
+    if (dCounters) { ctx->c.countersEnabled = true; ctx->c.dTraceCounters.p = dCounters; }
+    try { trace_launch(ctx->c, static_cast<hipStream_t>(stream), t); }
+    catch (...) { ctx->c.dTraceCounters = saved; ctx->c.countersEnabled = savedEnabled; throw; }
+    ctx->c.dTraceCounters = saved; ctx->c.countersEnabled = savedEnabled;
+    GFX_CATCH(ctx)
+}
+
+int gfx_restir_set_params(gfx_ctx* ctx, void* /*stream*/, const gfx_restir_static_params* s, const gfx_restir_frame_params* f,
+                          uint32_t currentReservoirIndex, uint32_t spatialNeighborBaseIndex) {
+    GFX_TRY(ctx)
+    // Parameters travel by value in the kernel arguments (the reference copies three structs to
+    // the device with cuMemcpyHtoDAsync per frame, restir_di_main.cpp:2350-2359).
+    if (s) ctx->c.restir.s = *s;
+    if (f) ctx->c.restir.f = *f;
+    ctx->c.restir.currentReservoirIndex = currentReservoirIndex & 1u;
+    ctx->c.restir.spatialNeighborBaseIndex = spatialNeighborBaseIndex & 1023u;
+    ctx->c.restir.valid = true;
+    GFX_CATCH(ctx)
+}
+
+int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height) {
+    GFX_TRY(ctx)
+    restir_launch(ctx->c, static_cast<hipStream_t>(stream), pass, width, height);
+    GFX_CATCH(ctx)
+}
+
+int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes) {
+    GFX_TRY(ctx)
+    GFX_HIP(hipDeviceSynchronize());
+    GFX_HIP(hipMemcpy(hostDst, dSrc, bytes, hipMemcpyDeviceToHost));
+    GFX_CATCH(ctx)
+}
+
+int gfx_timing_enable(gfx_ctx* ctx, int enable) {
+    GFX_TRY(ctx)
+    ctx->c.timingEnabled = enable != 0;
+    GFX_CATCH(ctx)
+}
+
+int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t* calls, uint32_t capacity, uint32_t* n) {
+    GFX_TRY(ctx)
+    Context& c = ctx->c;
+    for (auto& e : c.pendingEvents) {
+        GFX_HIP(hipEventSynchronize(e.second.second));
+        float ms = 0;
+        GFX_HIP(hipEventElapsedTime(&ms, e.second.first, e.second.second));
+        KernelTiming& t = c.timings[e.first];
+        t.ms += ms; ++t.calls;
+        (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second);
+    }
+    c.pendingEvents.clear();
+    uint32_t i = 0;
+    for (const auto& kv : c.timings) {
+        if (i < capacity) {
+            std::memset(names[i], 0, 48);
+            std::strncpy(names[i], kv.first.c_str(), 47);
+            totalMs[i] = static_cast<float>(kv.second.ms); calls[i] = kv.second.calls;
+        }
+        ++i;
+    }
+    *n = i;
+    c.timings.clear();
+    GFX_CATCH(ctx)
+}
+
+int gfx_counters_enable(gfx_ctx* ctx, int enable) {
+    GFX_TRY(ctx)
+    ctx->c.countersEnabled = enable != 0;
+    GFX_CATCH(ctx)
+}
+
+int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[4], int reset) {
+    GFX_TRY(ctx)
+    GFX_HIP(hipDeviceSynchronize());
+    GFX_HIP(hipMemcpy(counters, ctx->c.dTraceCounters.p, 32, hipMemcpyDeviceToHost));
+    if (reset) GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 32));
+    GFX_CATCH(ctx)
+}
+
+} // extern "C"

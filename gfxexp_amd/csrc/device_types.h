@@ -1,0 +1,102 @@
+// device_types.h -- plain structs shared by the host side of the library (capi) and the kernels.
+// They describe how the scene and the BVH sit in HBM.
+#pragma once
+#include <stdint.h>
+#include "../../include/gfxexp.h"
+
+namespace gfx {
+
+// 48-byte vertex record: three aligned 16-byte loads per vertex gather
+// (shared::Vertex is 44 B, common/common_shared.h:1109-1114).
+struct DevVertex {
+    float px, py, pz, nx;
+    float ny, nz, tx, ty;   // t = texCoord0Dir
+    float tz, u, v, pad;
+};
+static_assert(sizeof(DevVertex) == 48, "DevVertex must be 48 bytes");
+
+// shared::GeometryInstanceData (common/common_shared.h:1179-1193) with buffers replaced by offsets
+// into the scene-wide pools.
+struct DevGeomInst {
+    uint32_t vertexOffset;    // into vertex pool
+    uint32_t triangleOffset;  // into triangle pool (uint32 x 3 per triangle)
+    uint32_t numVertices;
+    uint32_t numTriangles;
+    uint32_t materialSlot;
+    uint32_t distOffset;      // emitterPrimDist weights/CDF offset in the light pools (or ~0u)
+    uint32_t distCount;
+    float distIntegral;
+};
+static_assert(sizeof(DevGeomInst) == 32, "DevGeomInst must be 32 bytes");
+
+// shared::InstanceData (common/common_shared.h:1243-1251)
+struct DevInstance {
+    float transform[12];        // 3x4 row-major
+    float curToPrevTransform[12];
+    float normalMatrix[9];      // row-major
+    float uniformScale;
+    uint32_t slotsOffset;       // geomInstSlots offset in the slot pool
+    uint32_t numGeomInsts;
+    uint32_t distOffset;        // lightGeomInstDist offset in the light pools (or ~0u)
+    float distIntegral;
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevInstance) == 160, "DevInstance must be 160 bytes");
+
+// One entry per (instance, geomInst) pair in (instSlot asc, list order) enumeration: the
+// "geometry" list the BVH is built over (bvh::Geometry + preTransform, common/bvh_builder.h:26-36).
+struct DevFlatGeom {
+    uint32_t instSlot;
+    uint32_t geomInstSlot;
+    uint32_t triBegin;   // first flattened triangle index
+    uint32_t numTriangles;
+};
+
+// Everything the shading kernels need to reach the scene.
+struct DevScene {
+    const gfx_material* materials;
+    const DevGeomInst* geomInsts;
+    const DevInstance* insts;
+    const DevVertex* vertices;
+    const uint32_t* triangles;
+    const uint32_t* geomInstSlotPool;
+    const float* lightWeights;
+    const float* lightCDF;
+    const float* lightInstIntegral; // device-resident integral of the level-0 distribution
+    uint32_t lightInstDistOffset;   // level-0 distribution
+    uint32_t numInsts;
+};
+
+// ---------------------------------------------------------------- BVH8 in HBM
+// 64-byte wide node (one aligned half cache line; four dwordx4 loads per visit).
+//   w[0..2]  quantisation origin (fp32)
+//   w[3]     ex | ey << 8 | ez << 16 | imask << 24     (scale_k = 2^(e_k - 127), 6-bit grid)
+//   w[4]     index of the first internal child (children are contiguous, slot order)
+//   w[5]     index of the first triangle record of this node's leaf children (contiguous, slot order)
+//   w[6+s]   child s: qminx | qminy<<6 | qminz<<12 | qmaxx<<18 | qmaxy<<24 | (count & 3) << 30
+//   w[14..15] bytes: child s: qmaxz | (count >> 2) << 6
+// count: number of triangles of a leaf child (1..15), 1 for an internal child, 0 = empty slot.
+// Child slots are assigned so that slot bit k set <=> child lies on the +k side of the node centre
+// (greedy auction as in Ylitie et al. 2017), which lets traversal order children by
+// (slot XOR ray-octant) without sorting.  The reference layout is the 80-byte
+// CompressedInternalNode_T<8> (common/common_shared.h:756-917).
+struct Bvh8Node { uint32_t w[16]; };
+static_assert(sizeof(Bvh8Node) == 64, "Bvh8Node must be 64 bytes");
+
+// 48-byte triangle record = shared::TriangleStorage (common/common_shared.h:1017-1025) with the
+// padding word used for the instance slot.
+struct Bvh8Tri {
+    float ax, ay, az, bx;
+    float by, bz, cx, cy;
+    float cz; uint32_t instSlot, geomInstSlot, primIndex;
+};
+static_assert(sizeof(Bvh8Tri) == 48, "Bvh8Tri must be 48 bytes");
+
+struct DevAccel {
+    const Bvh8Node* nodes;
+    const Bvh8Tri* tris;
+    uint32_t numNodes;
+    uint32_t numTris;
+};
+
+} // namespace gfx

@@ -1,0 +1,211 @@
+// restir_driver.cpp -- headless ReSTIR DI frame driver (include/gfxexp_host.h).
+//
+// Re-creates, on top of the C ABI, the part of restir_di/restir_di_main.cpp that surrounds the hot
+// path: buffer allocation and seeding (:1210-1325), the Halton neighbour table (:1487-1542),
+// launch-parameter defaults (:1560-1631, :1938-1986) and the per-frame sequencing with its index
+// bookkeeping (:1694-1700, :2303-2493): bufferIndex = frameIndex % 2, prevCamera latch, reservoir
+// ping-pong (lastReservoirIndex starts at 1), spatialNeighborBaseIndex growth, newSequence.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../../include/gfxexp_host.h"
+
+namespace {
+thread_local std::string g_driverError;
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    g_driverError = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define DRV_HIP(call) do { if (!hip_ok((call), #call)) return 1; } while (0)
+}
+
+struct gfxh_restir {
+    gfx_ctx* ctx = nullptr;
+    gfxh_restir_config cfg;
+    gfx_restir_static_params sp;
+    gfx_restir_frame_params fp;
+    std::vector<void*> allocations;
+    uint64_t accel = 0;
+    uint32_t frameIndex = 0;
+    uint32_t lastReservoirIndex = 1;            // restir_di_main.cpp:1686
+    uint32_t lastSpatialNeighborBaseIndex = 0;
+    uint32_t numAccumFrames = 0;
+    bool resetRequested = false;
+    gfx_camera camera, prevCamera;
+};
+
+extern "C" {
+
+void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_t height, int renderer) {
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->width = width; cfg->height = height; cfg->renderer = renderer;
+    cfg->log2NumCandidateSamples = 5;                     // ReSTIRConfigs(5, 2, 5) / (5, 1, 3), :1966-1967
+    cfg->enableTemporalReuse = 1; cfg->enableSpatialReuse = 1;
+    cfg->numSpatialReusePasses = renderer == GFXH_ORIGINAL_RESTIR_UNBIASED ? 1 : 2;
+    cfg->numSpatialNeighbors = renderer == GFXH_ORIGINAL_RESTIR_UNBIASED ? 3 : 5;
+    cfg->spatialNeighborRadius = 20.0f;
+    cfg->useLowDiscrepancyNeighbors = 1;
+    cfg->reuseVisibility = 1;
+    cfg->enableAccumulation = 0;
+    cfg->log2MaxNumAccums = 16;
+    cfg->camera.aspect = static_cast<float>(width) / height;
+    cfg->camera.fovY = 50 * 3.14159265358979323846f / 180;   // :1613
+    const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    std::memcpy(cfg->camera.orientation, ident, sizeof(ident));
+}
+
+static int alloc_dev(gfxh_restir* r, void** p, size_t bytes, bool zero) {
+    DRV_HIP(hipMalloc(p, bytes));
+    r->allocations.push_back(*p);
+    if (zero) DRV_HIP(hipMemset(*p, 0, bytes));
+    return 0;
+}
+
+int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir** out) {
+    *out = nullptr;
+    gfxh_restir* r = new gfxh_restir();
+    r->ctx = ctx; r->cfg = *cfg;
+    const size_t n = static_cast<size_t>(cfg->width) * cfg->height;
+    gfx_restir_static_params& sp = r->sp;
+    std::memset(&sp, 0, sizeof(sp));
+    std::memset(&r->fp, 0, sizeof(r->fp));
+    sp.imageSizeX = static_cast<int32_t>(cfg->width); sp.imageSizeY = static_cast<int32_t>(cfg->height);
+    int err = 0;
+    err |= alloc_dev(r, &sp.rngBuffer, 8 * n, false);
+    for (int i = 0; i < 2; ++i) {
+        err |= alloc_dev(r, &sp.gbuffer0[i], sizeof(gfx_gbuffer0) * n, true);
+        err |= alloc_dev(r, &sp.gbuffer1[i], sizeof(gfx_gbuffer1) * n, true);
+        err |= alloc_dev(r, &sp.gbuffer2[i], sizeof(gfx_gbuffer2) * n, true);
+        err |= alloc_dev(r, &sp.gbuffer3[i], sizeof(gfx_gbuffer3) * n, true);
+        err |= alloc_dev(r, &sp.reservoirBuffer[i], 48 * n, true);
+        err |= alloc_dev(r, &sp.reservoirInfoBuffer[i], sizeof(gfx_reservoir_info) * n, true);
+        err |= alloc_dev(r, &sp.sampleVisibilityBuffer[i], 4 * n, true);
+    }
+    err |= alloc_dev(r, &sp.beautyAccumBuffer, 16 * n, true);
+    err |= alloc_dev(r, &sp.albedoAccumBuffer, 16 * n, true);
+    err |= alloc_dev(r, &sp.normalAccumBuffer, 16 * n, true);
+    void* deltas = nullptr;
+    err |= alloc_dev(r, &deltas, 8 * 1024, false);
+    if (err) { gfxh_restir_destroy(r); return 1; }
+    sp.spatialNeighborDeltas = deltas;
+    sp.numTilesX = (cfg->width + 7) / 8; sp.numTilesY = (cfg->height + 7) / 8;
+    {
+        // pixel RNGs: row-major mt19937_64(591842031321323413) (restir_di_main.cpp:1316-1321)
+        std::vector<uint64_t> states(n);
+        gfxh_seed_rng_states(states.data(), n, 591842031321323413ull);
+        if (!hip_ok(hipMemcpy(sp.rngBuffer, states.data(), 8 * n, hipMemcpyHostToDevice), "upload rng states")) { gfxh_restir_destroy(r); return 1; }
+        std::vector<float> d(2048);
+        gfxh_spatial_neighbor_deltas(d.data());
+        if (!hip_ok(hipMemcpy(deltas, d.data(), 8 * 1024, hipMemcpyHostToDevice), "upload neighbour table")) { gfxh_restir_destroy(r); return 1; }
+    }
+    // scene.updateASs + setupLightGeomDistributions (restir_di_main.cpp:1199, 2263-2264)
+    if (gfx_accel_build(ctx, nullptr, &r->accel) || gfx_lights_build_static(ctx, nullptr)) {
+        g_driverError = gfx_last_error(ctx);
+        gfxh_restir_destroy(r);
+        return 1;
+    }
+    r->camera = cfg->camera;
+    r->prevCamera = cfg->camera;
+    *out = r;
+    return 0;
+}
+
+void gfxh_restir_destroy(gfxh_restir* r) {
+    if (!r) return;
+    (void)hipDeviceSynchronize();
+    for (void* p : r->allocations) (void)hipFree(p);
+    delete r;
+}
+
+int gfxh_restir_reset(gfxh_restir* r) { r->resetRequested = true; return 0; }
+int gfxh_restir_set_camera(gfxh_restir* r, const gfx_camera* cam) { r->camera = *cam; return 0; }
+void* gfxh_restir_beauty_buffer(gfxh_restir* r) { return r->sp.beautyAccumBuffer; }
+uint64_t gfxh_restir_accel(gfxh_restir* r) { return r->accel; }
+
+int gfxh_restir_get_params(gfxh_restir* r, gfx_restir_static_params* s, gfx_restir_frame_params* f,
+                           uint32_t* lastReservoirIndex, uint32_t* lastSpatialNeighborBaseIndex, uint32_t* frameIndex) {
+    if (s) *s = r->sp;
+    if (f) *f = r->fp;
+    if (lastReservoirIndex) *lastReservoirIndex = r->lastReservoirIndex;
+    if (lastSpatialNeighborBaseIndex) *lastSpatialNeighborBaseIndex = r->lastSpatialNeighborBaseIndex;
+    if (frameIndex) *frameIndex = r->frameIndex;
+    return 0;
+}
+
+int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
+    gfx_ctx* ctx = r->ctx;
+    const gfxh_restir_config& cfg = r->cfg;
+    const uint32_t frameIndex = r->frameIndex;
+    const uint32_t bufferIndex = frameIndex % 2;                       // :1695
+    gfx_restir_frame_params& fp = r->fp;
+    // prevCamera = camera latched at the top of every frame (:1699), then the camera may move
+    fp.prevCamera = frameIndex == 0 ? r->camera : r->prevCamera;
+    fp.camera = r->camera;
+
+    // scene.setupLightInstDistribution every frame (:2303-2309)
+    if (gfx_lights_build_instances(ctx, stream, bufferIndex)) { g_driverError = gfx_last_error(ctx); return 1; }
+
+    const bool newSequence = frameIndex == 0 || r->resetRequested;     // :2311 (no resize in a headless run)
+    r->resetRequested = false;
+    const bool firstAccumFrame = !cfg.enableAccumulation || newSequence;   // :2312-2313 (no animation / camera motion)
+    if (firstAccumFrame) r->numAccumFrames = 0;
+    else r->numAccumFrames = std::min(r->numAccumFrames + 1, 1u << cfg.log2MaxNumAccums);
+
+    fp.travHandle = r->accel;
+    fp.numAccumFrames = r->numAccumFrames;
+    fp.frameIndex = frameIndex;
+    fp.envLightPowerCoeff = 1.0f;                                      // pow(10, 0) (:2322)
+    fp.envLightRotation = 0.0f;
+    fp.spatialNeighborRadius = cfg.spatialNeighborRadius;
+    fp.radiusThresholdForSpatialVisReuse = 10.0f;
+    fp.log2NumCandidateSamples = cfg.log2NumCandidateSamples;
+    fp.numSpatialNeighbors = cfg.numSpatialNeighbors;
+    fp.useLowDiscrepancyNeighbors = cfg.useLowDiscrepancyNeighbors;
+    fp.reuseVisibility = cfg.reuseVisibility;
+    fp.reuseVisibilityForTemporal = 1;
+    fp.reuseVisibilityForSpatiotemporal = 0;
+    fp.enableTemporalReuse = cfg.enableTemporalReuse;
+    fp.enableSpatialReuse = cfg.enableSpatialReuse;
+    fp.useUnbiasedEstimator = cfg.renderer == GFXH_ORIGINAL_RESTIR_UNBIASED;
+    fp.bufferIndex = bufferIndex;
+    fp.resetFlowBuffer = newSequence;
+    fp.enableJittering = 0;
+    fp.enableEnvLight = r->sp.envLightTexture != nullptr;
+    fp.enableBumpMapping = 0;
+
+    uint32_t currentReservoirIndex = (r->lastReservoirIndex + 1) % 2;  // :2352
+    const uint32_t W = cfg.width, H = cfg.height;
+#define DRV_GFX(call) do { if (call) { g_driverError = gfx_last_error(ctx); return 1; } } while (0)
+    DRV_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, currentReservoirIndex, r->lastSpatialNeighborBaseIndex));
+    DRV_GFX(gfx_restir_launch(ctx, stream, GFX_RESTIR_SETUP_GBUFFERS, W, H));                 // :2366-2367
+
+    int entry = GFX_RESTIR_INITIAL_RIS;                                                        // :2378-2384
+    if (cfg.enableTemporalReuse && !newSequence)
+        entry = fp.useUnbiasedEstimator ? GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED : GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED;
+    DRV_GFX(gfx_restir_launch(ctx, stream, entry, W, H));
+
+    if (cfg.enableSpatialReuse) {                                                              // :2393-2411
+        const int spatial = fp.useUnbiasedEstimator ? GFX_RESTIR_SPATIAL_UNBIASED : GFX_RESTIR_SPATIAL_BIASED;
+        for (uint32_t i = 0; i < cfg.numSpatialReusePasses; ++i) {
+            const uint32_t baseIndex = r->lastSpatialNeighborBaseIndex + cfg.numSpatialNeighbors * i;
+            DRV_GFX(gfx_restir_set_params(ctx, stream, nullptr, nullptr, currentReservoirIndex, baseIndex));
+            DRV_GFX(gfx_restir_launch(ctx, stream, spatial, W, H));
+            currentReservoirIndex = (currentReservoirIndex + 1) % 2;
+        }
+        r->lastSpatialNeighborBaseIndex += cfg.numSpatialNeighbors * cfg.numSpatialReusePasses;
+    }
+    DRV_GFX(gfx_restir_set_params(ctx, stream, nullptr, nullptr, currentReservoirIndex, r->lastSpatialNeighborBaseIndex));
+    DRV_GFX(gfx_restir_launch(ctx, stream, GFX_RESTIR_SHADING, W, H));                        // :2418-2420
+#undef DRV_GFX
+    r->lastReservoirIndex = currentReservoirIndex;                                             // :2493
+    r->prevCamera = r->camera;
+    ++r->frameIndex;
+    return 0;
+}
+
+const char* gfxh_restir_last_error(void) { return g_driverError.c_str(); }
+
+} // extern "C"

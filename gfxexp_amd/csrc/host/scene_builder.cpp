@@ -1,0 +1,600 @@
+// scene_builder.cpp -- host-side scene construction (include/gfxexp_host.h).
+//
+// Mirrors the asset path of the reference host program without assimp / textures:
+//   OBJ + MTL reader          createTriangleMeshes, common/common_host.cpp:2178-2429
+//   immediate material values createImmTexture + sRGB sampler, common_host.cpp:1045-1073, 1602-1659
+//   rectangle light           createRectangleLight, common_host.cpp:2431-2476
+//   instances                 createInstance, common_host.cpp:2582-2656
+// plus a procedural "street" scene standing in for Bistro Exterior (not present offline).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <random>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <vector>
+#include "../../../include/gfxexp_host.h"
+
+namespace {
+
+thread_local std::string g_hostError;
+
+struct Geom { std::vector<gfx_vertex> v; std::vector<uint32_t> t; uint32_t mat; };
+struct Inst { uint32_t group; float xfm[12]; };
+
+} // namespace
+
+struct gfxh_scene {
+    std::vector<gfx_material> materials;
+    std::vector<Geom> geoms;
+    std::vector<std::vector<uint32_t>> groups;
+    std::vector<Inst> insts;
+};
+
+namespace {
+
+struct V3 { float x, y, z; };
+inline V3 operator+(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+inline V3 operator-(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline V3 operator*(V3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+inline V3 cross(V3 a, V3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 normalize(V3 a) { const float l = std::sqrt(dot(a, a)); const float r = 1 / l; return { a.x * r, a.y * r, a.z * r }; }
+
+// makeCoordinateSystem, common/common_host.cpp:2349-2356
+inline V3 tangent_from_normal(V3 n) {
+    const float sign = n.z >= 0 ? 1.0f : -1.0f;
+    const float a = -1 / (sign + n.z);
+    const float b = n.x * n.y * a;
+    return { 1 + sign * n.x * n.x * a, sign * b, -sign * n.x };
+}
+
+inline gfx_vertex make_vertex(V3 p, V3 n, V3 t, float u, float v) {
+    gfx_vertex o;
+    o.position[0] = p.x; o.position[1] = p.y; o.position[2] = p.z;
+    o.normal[0] = n.x; o.normal[1] = n.y; o.normal[2] = n.z;
+    o.texCoord0Dir[0] = t.x; o.texCoord0Dir[1] = t.y; o.texCoord0Dir[2] = t.z;
+    o.texCoord[0] = u; o.texCoord[1] = v;
+    return o;
+}
+
+// 8-bit immediate texture value (common_host.cpp:1045-1073) ...
+inline float quantize8(float v) { const uint32_t q = std::min(static_cast<uint32_t>(255 * v), 255u); return q / 255.0f; }
+// ... read through an sRGB-decoding sampler (basic_types.h:5396-5402 states the formula)
+inline float srgb_degamma(float v) {
+    if (v <= 0.04045f) return v / 12.92f;
+    return std::pow((v + 0.055f) / 1.055f, 2.4f);
+}
+
+void mat3_mul(const double a[9], const double b[9], double o[9]) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) o[r * 3 + c] = a[r * 3 + 0] * b[0 * 3 + c] + a[r * 3 + 1] * b[1 * 3 + c] + a[r * 3 + 2] * b[2 * 3 + c];
+}
+// qFromEulerAngles = Rz(roll) * Ry(yaw) * Rx(pitch), common/basic_types.h:5120-5123
+void euler_matrix(double roll, double pitch, double yaw, double o[9]) {
+    const double cz = std::cos(roll), sz = std::sin(roll), cy = std::cos(yaw), sy = std::sin(yaw), cx = std::cos(pitch), sx = std::sin(pitch);
+    const double Rz[9] = { cz, -sz, 0, sz, cz, 0, 0, 0, 1 };
+    const double Ry[9] = { cy, 0, sy, 0, 1, 0, -sy, 0, cy };
+    const double Rx[9] = { 1, 0, 0, 0, cx, -sx, 0, sx, cx };
+    double t[9];
+    mat3_mul(Rz, Ry, t);
+    mat3_mul(t, Rx, o);
+}
+
+void xfm_point(const float m[12], const float p[3], float o[3]) {
+    for (int r = 0; r < 3; ++r) o[r] = m[r * 4 + 0] * p[0] + m[r * 4 + 1] * p[1] + m[r * 4 + 2] * p[2] + m[r * 4 + 3];
+}
+
+// ---- primitive meshes for the procedural scene
+void add_quad(Geom& g, V3 p0, V3 p1, V3 p2, V3 p3) { // CCW p0..p3
+    const V3 n = normalize(cross(p1 - p0, p3 - p0));
+    const V3 t = normalize(p1 - p0);
+    const uint32_t b = static_cast<uint32_t>(g.v.size());
+    g.v.push_back(make_vertex(p0, n, t, 0, 0));
+    g.v.push_back(make_vertex(p1, n, t, 1, 0));
+    g.v.push_back(make_vertex(p2, n, t, 1, 1));
+    g.v.push_back(make_vertex(p3, n, t, 0, 1));
+    const uint32_t idx[6] = { b, b + 1, b + 2, b, b + 2, b + 3 };
+    g.t.insert(g.t.end(), idx, idx + 6);
+}
+void add_box(Geom& g, V3 lo, V3 hi) {
+    const V3 c[8] = { { lo.x, lo.y, lo.z }, { hi.x, lo.y, lo.z }, { hi.x, hi.y, lo.z }, { lo.x, hi.y, lo.z },
+                      { lo.x, lo.y, hi.z }, { hi.x, lo.y, hi.z }, { hi.x, hi.y, hi.z }, { lo.x, hi.y, hi.z } };
+    add_quad(g, c[1], c[0], c[3], c[2]);  // -z
+    add_quad(g, c[4], c[5], c[6], c[7]);  // +z
+    add_quad(g, c[0], c[4], c[7], c[3]);  // -x
+    add_quad(g, c[5], c[1], c[2], c[6]);  // +x
+    add_quad(g, c[3], c[7], c[6], c[2]);  // +y
+    add_quad(g, c[0], c[1], c[5], c[4]);  // -y
+}
+// grid of quads on the plane spanned by (ex, ey) from origin o, displaced along the normal by h(i,j)
+template <typename H>
+void add_grid(Geom& g, V3 o, V3 ex, V3 ey, uint32_t nx, uint32_t ny, H height) {
+    const V3 n = normalize(cross(ex, ey));
+    const V3 t = normalize(ex);
+    const uint32_t b = static_cast<uint32_t>(g.v.size());
+    for (uint32_t j = 0; j <= ny; ++j)
+        for (uint32_t i = 0; i <= nx; ++i) {
+            const float u = static_cast<float>(i) / nx, v = static_cast<float>(j) / ny;
+            const V3 p = o + ex * u + ey * v + n * height(i, j);
+            g.v.push_back(make_vertex(p, n, t, u, v));
+        }
+    for (uint32_t j = 0; j < ny; ++j)
+        for (uint32_t i = 0; i < nx; ++i) {
+            const uint32_t a = b + j * (nx + 1) + i, c = a + 1, d = a + nx + 1, e = d + 1;
+            const uint32_t idx[6] = { a, c, e, a, e, d };
+            g.t.insert(g.t.end(), idx, idx + 6);
+        }
+}
+void make_icosphere(Geom& g, uint32_t subdiv, float radius) {
+    const float t = (1.0f + std::sqrt(5.0f)) / 2.0f;
+    std::vector<V3> p = { { -1, t, 0 }, { 1, t, 0 }, { -1, -t, 0 }, { 1, -t, 0 }, { 0, -1, t }, { 0, 1, t },
+                          { 0, -1, -t }, { 0, 1, -t }, { t, 0, -1 }, { t, 0, 1 }, { -t, 0, -1 }, { -t, 0, 1 } };
+    for (V3& v : p) v = normalize(v);
+    std::vector<uint32_t> f = { 0, 11, 5, 0, 5, 1, 0, 1, 7, 0, 7, 10, 0, 10, 11, 1, 5, 9, 5, 11, 4, 11, 10, 2, 10, 7, 6, 7, 1, 8,
+                                3, 9, 4, 3, 4, 2, 3, 2, 6, 3, 6, 8, 3, 8, 9, 4, 9, 5, 2, 4, 11, 6, 2, 10, 8, 6, 7, 9, 8, 1 };
+    for (uint32_t s = 0; s < subdiv; ++s) {
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> mid;
+        auto midpoint = [&](uint32_t a, uint32_t b) {
+            const auto key = std::make_pair(std::min(a, b), std::max(a, b));
+            auto it = mid.find(key);
+            if (it != mid.end()) return it->second;
+            p.push_back(normalize((p[a] + p[b]) * 0.5f));
+            const uint32_t idx = static_cast<uint32_t>(p.size() - 1);
+            mid[key] = idx;
+            return idx;
+        };
+        std::vector<uint32_t> nf;
+        for (size_t i = 0; i < f.size(); i += 3) {
+            const uint32_t a = f[i], b = f[i + 1], c = f[i + 2];
+            const uint32_t ab = midpoint(a, b), bc = midpoint(b, c), ca = midpoint(c, a);
+            const uint32_t tri[12] = { a, ab, ca, b, bc, ab, c, ca, bc, ab, bc, ca };
+            nf.insert(nf.end(), tri, tri + 12);
+        }
+        f.swap(nf);
+    }
+    const uint32_t b = static_cast<uint32_t>(g.v.size());
+    for (const V3& n : p) {
+        const V3 tg = normalize(tangent_from_normal(n));
+        const float u = 0.5f + std::atan2(n.z, n.x) / (2 * 3.14159265f), v = 0.5f - std::asin(std::min(1.0f, std::max(-1.0f, n.y))) / 3.14159265f;
+        g.v.push_back(make_vertex(n * radius, n, tg, u, v));
+    }
+    for (uint32_t idx : f) g.t.push_back(b + idx);
+}
+
+struct Rng {
+    std::mt19937 gen;
+    explicit Rng(uint32_t seed) : gen(seed) {}
+    float uni() { return (gen() >> 8) * (1.0f / 16777216.0f); }
+    float range(float a, float b) { return a + (b - a) * uni(); }
+};
+
+} // namespace
+
+extern "C" {
+
+const char* gfxh_last_error(void) { return g_hostError.c_str(); }
+gfxh_scene* gfxh_scene_create(void) { return new gfxh_scene(); }
+void gfxh_scene_destroy(gfxh_scene* s) { delete s; }
+
+uint32_t gfxh_scene_add_material(gfxh_scene* s, const gfx_material* m) {
+    s->materials.push_back(*m);
+    return static_cast<uint32_t>(s->materials.size() - 1);
+}
+
+uint32_t gfxh_scene_add_material_traditional(gfxh_scene* s, const float diffuse[3], const float specular[3],
+                                             float smoothness, const float emittance[3]) {
+    gfx_material m;
+    std::memset(&m, 0, sizeof(m));
+    m.bsdfType = GFX_BSDF_DIFFUSE_AND_SPECULAR;
+    for (int i = 0; i < 3; ++i) {
+        m.a[i] = srgb_degamma(quantize8(diffuse[i]));
+        m.b[i] = srgb_degamma(quantize8(specular[i]));
+        m.emittance[i] = emittance ? emittance[i] : 0.0f;
+    }
+    m.smoothness = quantize8(smoothness);
+    m.hasEmittance = (m.emittance[0] != 0.0f || m.emittance[1] != 0.0f || m.emittance[2] != 0.0f) ? 1u : 0u;
+    return gfxh_scene_add_material(s, &m);
+}
+
+uint32_t gfxh_scene_add_geom(gfxh_scene* s, const gfx_vertex* v, uint32_t nv, const uint32_t* tris, uint32_t nt, uint32_t matSlot) {
+    Geom g;
+    g.v.assign(v, v + nv);
+    g.t.assign(tris, tris + 3ull * nt);
+    g.mat = matSlot;
+    s->geoms.push_back(std::move(g));
+    return static_cast<uint32_t>(s->geoms.size() - 1);
+}
+uint32_t gfxh_scene_add_group(gfxh_scene* s, const uint32_t* geomSlots, uint32_t n) {
+    s->groups.emplace_back(geomSlots, geomSlots + n);
+    return static_cast<uint32_t>(s->groups.size() - 1);
+}
+uint32_t gfxh_scene_add_instance(gfxh_scene* s, uint32_t group, const float xfm[12]) {
+    Inst i;
+    i.group = group;
+    std::memcpy(i.xfm, xfm, sizeof(float) * 12);
+    s->insts.push_back(i);
+    return static_cast<uint32_t>(s->insts.size() - 1);
+}
+
+uint32_t gfxh_scene_load_obj(gfxh_scene* s, const char* path) {
+    std::ifstream in(path);
+    if (!in) { g_hostError = std::string("cannot open ") + path; return 0xFFFFFFFFu; }
+    const std::string dir = std::string(path).substr(0, std::string(path).find_last_of("/\\") + 1);
+    std::vector<V3> pos, nrm;
+    std::vector<std::pair<float, float>> uv;
+    struct MtlDesc { float kd[3] = { 0, 0, 0 }, ks[3] = { 0, 0, 0 }, ke[3] = { 0, 0, 0 }; float ns = 0; };
+    std::map<std::string, MtlDesc> mtl;
+    std::vector<std::string> matOrder;
+    struct Corner { int v, t, n; };
+    std::map<std::string, std::vector<Corner>> facesByMat;   // triangulated corner list per material
+    std::string curMat = "";
+    std::string line;
+    auto parse_mtl = [&](const std::string& file) {
+        std::ifstream m(dir + file);
+        std::string l, cur;
+        while (std::getline(m, l)) {
+            std::istringstream ss(l);
+            std::string k; ss >> k;
+            if (k == "newmtl") { ss >> cur; mtl[cur] = MtlDesc(); }
+            else if (k == "Kd") ss >> mtl[cur].kd[0] >> mtl[cur].kd[1] >> mtl[cur].kd[2];
+            else if (k == "Ks") ss >> mtl[cur].ks[0] >> mtl[cur].ks[1] >> mtl[cur].ks[2];
+            else if (k == "Ke") ss >> mtl[cur].ke[0] >> mtl[cur].ke[1] >> mtl[cur].ke[2];
+            else if (k == "Ns") ss >> mtl[cur].ns;
+        }
+    };
+    while (std::getline(in, line)) {
+        std::istringstream ss(line);
+        std::string k; ss >> k;
+        if (k == "v") { V3 p; ss >> p.x >> p.y >> p.z; pos.push_back(p); }
+        else if (k == "vn") { V3 p; ss >> p.x >> p.y >> p.z; nrm.push_back(p); }
+        else if (k == "vt") { float a = 0, b = 0; ss >> a >> b; uv.push_back({ a, b }); }
+        else if (k == "mtllib") { std::string f; ss >> f; parse_mtl(f); }
+        else if (k == "usemtl") { ss >> curMat; }
+        else if (k == "f") {
+            std::vector<Corner> cs;
+            std::string tok;
+            while (ss >> tok) {
+                Corner c = { 0, 0, 0 };
+                int idx[3] = { 0, 0, 0 };
+                int which = 0; std::string num;
+                for (size_t i = 0; i <= tok.size(); ++i) {
+                    if (i == tok.size() || tok[i] == '/') { if (!num.empty()) idx[which] = std::stoi(num); num.clear(); ++which; if (which > 2) break; }
+                    else num.push_back(tok[i]);
+                }
+                c.v = idx[0] < 0 ? static_cast<int>(pos.size()) + idx[0] : idx[0] - 1;
+                c.t = idx[1] == 0 ? -1 : (idx[1] < 0 ? static_cast<int>(uv.size()) + idx[1] : idx[1] - 1);
+                c.n = idx[2] == 0 ? -1 : (idx[2] < 0 ? static_cast<int>(nrm.size()) + idx[2] : idx[2] - 1);
+                cs.push_back(c);
+            }
+            if (!facesByMat.count(curMat)) matOrder.push_back(curMat);
+            std::vector<Corner>& dst = facesByMat[curMat];
+            for (size_t i = 1; i + 1 < cs.size(); ++i) { dst.push_back(cs[0]); dst.push_back(cs[i]); dst.push_back(cs[i + 1]); }
+        }
+    }
+    std::vector<uint32_t> geomSlots;
+    for (const std::string& name : matOrder) {
+        const MtlDesc d = mtl.count(name) ? mtl[name] : MtlDesc();
+        // smoothness = sqrt(Ns) / 11 (common_host.cpp:2271-2274)
+        const float smoothness = std::sqrt(d.ns) / 11.0f;
+        const uint32_t matSlot = gfxh_scene_add_material_traditional(s, d.kd, d.ks, smoothness, d.ke);
+        const std::vector<Corner>& cs = facesByMat[name];
+        Geom g; g.mat = matSlot;
+        std::map<std::tuple<int, int, int>, uint32_t> dedup;   // aiProcess_JoinIdenticalVertices
+        for (size_t f = 0; f + 2 < cs.size(); f += 3) {
+            V3 fn = { 0, 0, 1 };
+            bool needFaceNormal = cs[f].n < 0 || cs[f + 1].n < 0 || cs[f + 2].n < 0;
+            if (needFaceNormal) fn = normalize(cross(pos[cs[f + 1].v] - pos[cs[f].v], pos[cs[f + 2].v] - pos[cs[f].v]));
+            for (int k = 0; k < 3; ++k) {
+                const Corner c = cs[f + k];
+                const auto key = std::make_tuple(c.v, c.t, needFaceNormal ? -2 - static_cast<int>(f) : c.n);
+                auto it = dedup.find(key);
+                uint32_t vi;
+                if (it != dedup.end()) vi = it->second;
+                else {
+                    const V3 n = normalize(needFaceNormal ? fn : nrm[c.n]);
+                    const V3 tg = normalize(tangent_from_normal(n));
+                    const float u = c.t >= 0 ? uv[c.t].first : 0.0f;
+                    const float v = c.t >= 0 ? 1.0f - uv[c.t].second : 0.0f;   // aiProcess_FlipUVs
+                    g.v.push_back(make_vertex(pos[c.v], n, tg, u, v));
+                    vi = static_cast<uint32_t>(g.v.size() - 1);
+                    dedup[key] = vi;
+                }
+                g.t.push_back(vi);
+            }
+        }
+        s->geoms.push_back(std::move(g));
+        geomSlots.push_back(static_cast<uint32_t>(s->geoms.size() - 1));
+    }
+    if (geomSlots.empty()) { g_hostError = std::string("no faces in ") + path; return 0xFFFFFFFFu; }
+    return gfxh_scene_add_group(s, geomSlots.data(), static_cast<uint32_t>(geomSlots.size()));
+}
+
+uint32_t gfxh_scene_add_rectangle(gfxh_scene* s, float width, float depth, const float emittance[3]) {
+    const float refl[3] = { 0.01f, 0.01f, 0.01f }, spec[3] = { 0, 0, 0 };
+    const uint32_t mat = gfxh_scene_add_material_traditional(s, refl, spec, 0.3f, emittance);
+    const V3 n = { 0, -1, 0 }, t = { 1, 0, 0 };
+    const gfx_vertex v[4] = {
+        make_vertex({ -0.5f * width, 0.0f, -0.5f * depth }, n, t, 0.0f, 1.0f),
+        make_vertex({ 0.5f * width, 0.0f, -0.5f * depth }, n, t, 1.0f, 1.0f),
+        make_vertex({ 0.5f * width, 0.0f, 0.5f * depth }, n, t, 1.0f, 0.0f),
+        make_vertex({ -0.5f * width, 0.0f, 0.5f * depth }, n, t, 0.0f, 0.0f) };
+    const uint32_t tris[6] = { 0, 1, 2, 0, 2, 3 };
+    const uint32_t g = gfxh_scene_add_geom(s, v, 4, tris, 2, mat);
+    return gfxh_scene_add_group(s, &g, 1);
+}
+
+void gfxh_make_transform(float scale, float rollDeg, float pitchDeg, float yawDeg, const float pos[3], float out[12]) {
+    const double d2r = 3.14159265358979323846 / 180.0;
+    double R[9];
+    euler_matrix(rollDeg * d2r, pitchDeg * d2r, yawDeg * d2r, R);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) out[r * 4 + c] = static_cast<float>(R[r * 3 + c] * scale);
+        out[r * 4 + 3] = pos[r];
+    }
+}
+void gfxh_make_orientation(float rollDeg, float pitchDeg, float yawDeg, float out[9]) {
+    const double d2r = 3.14159265358979323846 / 180.0;
+    double R[9];
+    euler_matrix(rollDeg * d2r, pitchDeg * d2r, yawDeg * d2r, R);
+    for (int i = 0; i < 9; ++i) out[i] = static_cast<float>(R[i]);
+}
+
+void gfxh_seed_rng_states(uint64_t* states, uint64_t count, uint64_t seed) {
+    std::mt19937_64 gen(seed);
+    for (uint64_t i = 0; i < count; ++i) states[i] = gen();
+}
+
+int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p) {
+    Rng rng(p->seed);
+    const float E = p->extent;
+    auto mat = [&](float r, float g, float b, float sr, float sm, float e0 = 0, float e1 = 0, float e2 = 0) {
+        const float d[3] = { r, g, b }, sp[3] = { sr, sr, sr }, em[3] = { e0, e1, e2 };
+        return gfxh_scene_add_material_traditional(s, d, sp, sm, em);
+    };
+    const float ident[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    // ---- ground: cobbled street (height noise) as one big static instance
+    {
+        Geom g; g.mat = mat(0.35f, 0.33f, 0.30f, 0.2f, 0.2f);
+        std::mt19937 hgen(p->seed * 7919u + 1);
+        std::vector<float> h((p->groundTess + 1) * (p->groundTess + 1));
+        for (float& v : h) v = ((hgen() >> 8) * (1.0f / 16777216.0f)) * 0.02f;
+        const uint32_t nt = p->groundTess;
+        add_grid(g, { -E, 0, E }, { 2 * E, 0, 0 }, { 0, 0, -2 * E }, nt, nt, [&](uint32_t i, uint32_t j) { return h[j * (nt + 1) + i]; });
+        s->geoms.push_back(std::move(g));
+        const uint32_t gs = static_cast<uint32_t>(s->geoms.size() - 1);
+        gfxh_scene_add_instance(s, gfxh_scene_add_group(s, &gs, 1), ident);
+    }
+    // ---- buildings: a few facade prototypes (wall grid with recessed windows + roof box), instanced
+    const uint32_t numProto = 6;
+    std::vector<uint32_t> protoGroups;
+    std::vector<V3> protoSize;
+    for (uint32_t k = 0; k < numProto; ++k) {
+        const float w = rng.range(6, 14), hgt = rng.range(8, 22), dpt = rng.range(6, 12);
+        Geom wall; wall.mat = mat(rng.range(0.4f, 0.8f), rng.range(0.35f, 0.7f), rng.range(0.3f, 0.6f), 0.04f, 0.1f);
+        Geom glass; glass.mat = mat(0.05f, 0.06f, 0.08f, 0.6f, 0.85f);
+        const uint32_t ft = p->facadeTess;
+        // four facades: displaced grids (window recesses) facing outward
+        const V3 o[4] = { { -w / 2, 0, dpt / 2 }, { w / 2, 0, dpt / 2 }, { w / 2, 0, -dpt / 2 }, { -w / 2, 0, -dpt / 2 } };
+        const V3 ex[4] = { { w, 0, 0 }, { 0, 0, -dpt }, { -w, 0, 0 }, { 0, 0, dpt } };
+        for (int f = 0; f < 4; ++f) {
+            add_grid(wall, o[f], ex[f], { 0, hgt, 0 }, ft, ft, [&](uint32_t i, uint32_t j) {
+                const bool window = (i % 4 == 1 || i % 4 == 2) && (j % 4 == 1 || j % 4 == 2) && j > 3;
+                return window ? -0.25f : 0.0f;
+            });
+        }
+        add_box(wall, { -w / 2, hgt, -dpt / 2 }, { w / 2, hgt + 0.4f, dpt / 2 });
+        // glass panes inside the recesses of the front facade
+        for (uint32_t j = 5; j + 2 < ft; j += 4)
+            for (uint32_t i = 1; i + 2 < ft; i += 4) {
+                const float x0 = -w / 2 + w * (i + 0.1f) / ft, x1 = -w / 2 + w * (i + 1.9f) / ft;
+                const float y0 = hgt * (j + 0.1f) / ft, y1 = hgt * (j + 1.9f) / ft;
+                add_quad(glass, { x0, y0, dpt / 2 - 0.2f }, { x1, y0, dpt / 2 - 0.2f }, { x1, y1, dpt / 2 - 0.2f }, { x0, y1, dpt / 2 - 0.2f });
+            }
+        s->geoms.push_back(std::move(wall));
+        s->geoms.push_back(std::move(glass));
+        const uint32_t gs[2] = { static_cast<uint32_t>(s->geoms.size() - 2), static_cast<uint32_t>(s->geoms.size() - 1) };
+        protoGroups.push_back(gfxh_scene_add_group(s, gs, 2));
+        protoSize.push_back({ w, hgt, dpt });
+    }
+    struct Placed { V3 pos; float yaw; uint32_t proto; };
+    std::vector<Placed> placed;
+    for (uint32_t b = 0; b < p->numBuildings; ++b) {
+        // two rows along the street (z axis), facing the street
+        const bool left = (b & 1) != 0;
+        const float z = -E * 0.9f + (2 * E * 0.9f) * (static_cast<float>(b / 2) + 0.5f) / std::max(1u, (p->numBuildings + 1) / 2);
+        const uint32_t proto = rng.gen() % numProto;
+        const float x = (left ? -1.0f : 1.0f) * (E * 0.35f + protoSize[proto].z * 0.5f);
+        const float yaw = left ? 90.0f : -90.0f;
+        const float pos[3] = { x, 0, z };
+        float xfm[12];
+        gfxh_make_transform(1.0f, 0, 0, yaw, pos, xfm);
+        gfxh_scene_add_instance(s, protoGroups[proto], xfm);
+        placed.push_back({ { x, 0, z }, yaw, proto });
+    }
+    // ---- props: icospheres (planters / bollards) and crates, instanced with random scale
+    {
+        Geom sphere; sphere.mat = mat(0.55f, 0.25f, 0.2f, 0.1f, 0.5f);
+        make_icosphere(sphere, p->propSubdiv, 0.5f);
+        Geom crate; crate.mat = mat(0.45f, 0.32f, 0.18f, 0.03f, 0.2f);
+        add_box(crate, { -0.5f, 0, -0.5f }, { 0.5f, 1, 0.5f });
+        s->geoms.push_back(std::move(sphere));
+        const uint32_t gsph = static_cast<uint32_t>(s->geoms.size() - 1);
+        s->geoms.push_back(std::move(crate));
+        const uint32_t gcr = static_cast<uint32_t>(s->geoms.size() - 1);
+        const uint32_t grpS = gfxh_scene_add_group(s, &gsph, 1), grpC = gfxh_scene_add_group(s, &gcr, 1);
+        for (uint32_t k = 0; k < p->numProps; ++k) {
+            const bool sph = (k % 3) != 0;
+            const float sc = rng.range(0.3f, 1.2f);
+            const float pos[3] = { rng.range(-E * 0.33f, E * 0.33f), sph ? sc * 0.5f : 0.0f, rng.range(-E * 0.95f, E * 0.95f) };
+            float xfm[12];
+            gfxh_make_transform(sc, 0, 0, rng.range(0, 360), pos, xfm);
+            gfxh_scene_add_instance(s, sph ? grpS : grpC, xfm);
+        }
+    }
+    // ---- lamps: pole + small emissive box head; a handful of colour temperatures
+    {
+        Geom pole; pole.mat = mat(0.1f, 0.1f, 0.1f, 0.3f, 0.6f);
+        add_box(pole, { -0.05f, 0, -0.05f }, { 0.05f, 3.5f, 0.05f });
+        s->geoms.push_back(std::move(pole));
+        const uint32_t gpole = static_cast<uint32_t>(s->geoms.size() - 1);
+        std::vector<uint32_t> lampGroups;
+        const float tints[4][3] = { { 1.0f, 0.85f, 0.6f }, { 1.0f, 0.95f, 0.85f }, { 0.8f, 0.9f, 1.0f }, { 1.0f, 0.7f, 0.4f } };
+        for (int k = 0; k < 4; ++k) {
+            Geom head; head.mat = mat(0.01f, 0.01f, 0.01f, 0, 0.3f, p->lampEmittance * tints[k][0], p->lampEmittance * tints[k][1], p->lampEmittance * tints[k][2]);
+            add_box(head, { -0.15f, 3.5f, -0.15f }, { 0.15f, 3.7f, 0.15f });
+            s->geoms.push_back(std::move(head));
+            const uint32_t gs[2] = { gpole, static_cast<uint32_t>(s->geoms.size() - 1) };
+            lampGroups.push_back(gfxh_scene_add_group(s, gs, 2));
+        }
+        for (uint32_t k = 0; k < p->numLamps; ++k) {
+            const float pos[3] = { rng.range(-E * 0.34f, E * 0.34f), 0, rng.range(-E * 0.95f, E * 0.95f) };
+            float xfm[12];
+            gfxh_make_transform(rng.range(0.8f, 1.2f), 0, 0, rng.range(0, 360), pos, xfm);
+            gfxh_scene_add_instance(s, lampGroups[rng.gen() % 4], xfm);
+        }
+    }
+    // ---- signs: emissive quads mounted on facades
+    {
+        std::vector<uint32_t> signGroups;
+        const float cols[5][3] = { { 1, 0.2f, 0.2f }, { 0.2f, 1, 0.3f }, { 0.2f, 0.4f, 1 }, { 1, 0.9f, 0.2f }, { 1, 0.3f, 0.9f } };
+        for (int k = 0; k < 5; ++k) {
+            Geom sign; sign.mat = mat(0.01f, 0.01f, 0.01f, 0, 0.3f, p->signEmittance * cols[k][0], p->signEmittance * cols[k][1], p->signEmittance * cols[k][2]);
+            add_grid(sign, { -0.6f, -0.2f, 0 }, { 1.2f, 0, 0 }, { 0, 0.4f, 0 }, 4, 2, [](uint32_t, uint32_t) { return 0.0f; });
+            s->geoms.push_back(std::move(sign));
+            const uint32_t gs = static_cast<uint32_t>(s->geoms.size() - 1);
+            signGroups.push_back(gfxh_scene_add_group(s, &gs, 1));
+        }
+        for (uint32_t k = 0; k < p->numSigns && !placed.empty(); ++k) {
+            const Placed& b = placed[rng.gen() % placed.size()];
+            const V3 sz = protoSize[b.proto];
+            // local position on the front facade (+z of the prototype), slightly in front of it
+            const float lp[3] = { rng.range(-sz.x * 0.4f, sz.x * 0.4f), rng.range(2.5f, std::max(3.0f, sz.y * 0.8f)), sz.z * 0.5f + 0.05f };
+            float bx[12];
+            const float bpos[3] = { b.pos.x, b.pos.y, b.pos.z };
+            gfxh_make_transform(1.0f, 0, 0, b.yaw, bpos, bx);
+            float wp[3];
+            xfm_point(bx, lp, wp);
+            float xfm[12];
+            gfxh_make_transform(rng.range(0.7f, 1.6f), 0, 0, b.yaw, wp, xfm);
+            gfxh_scene_add_instance(s, signGroups[rng.gen() % 5], xfm);
+        }
+    }
+    return 0;
+}
+
+int gfxh_scene_counts(gfxh_scene* s, uint32_t counts[5]) {
+    counts[0] = static_cast<uint32_t>(s->materials.size());
+    counts[1] = static_cast<uint32_t>(s->geoms.size());
+    counts[2] = static_cast<uint32_t>(s->groups.size());
+    counts[3] = static_cast<uint32_t>(s->insts.size());
+    uint64_t tris = 0;
+    for (const Inst& i : s->insts) for (uint32_t g : s->groups[i.group]) tris += s->geoms[g].t.size() / 3;
+    counts[4] = static_cast<uint32_t>(tris);
+    return 0;
+}
+int gfxh_scene_get_material(gfxh_scene* s, uint32_t i, gfx_material* out) { if (i >= s->materials.size()) return 1; *out = s->materials[i]; return 0; }
+int gfxh_scene_get_geom(gfxh_scene* s, uint32_t i, const gfx_vertex** v, uint32_t* nv, const uint32_t** tris, uint32_t* nt, uint32_t* matSlot) {
+    if (i >= s->geoms.size()) return 1;
+    const Geom& g = s->geoms[i];
+    *v = g.v.data(); *nv = static_cast<uint32_t>(g.v.size()); *tris = g.t.data(); *nt = static_cast<uint32_t>(g.t.size() / 3); *matSlot = g.mat;
+    return 0;
+}
+int gfxh_scene_get_group(gfxh_scene* s, uint32_t i, const uint32_t** geomSlots, uint32_t* n) {
+    if (i >= s->groups.size()) return 1;
+    *geomSlots = s->groups[i].data(); *n = static_cast<uint32_t>(s->groups[i].size());
+    return 0;
+}
+int gfxh_scene_get_instance(gfxh_scene* s, uint32_t i, uint32_t* group, float xfm[12]) {
+    if (i >= s->insts.size()) return 1;
+    *group = s->insts[i].group; std::memcpy(xfm, s->insts[i].xfm, sizeof(float) * 12);
+    return 0;
+}
+int gfxh_scene_bounds(gfxh_scene* s, float bounds[6]) {
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (const Inst& i : s->insts)
+        for (uint32_t g : s->groups[i.group])
+            for (const gfx_vertex& v : s->geoms[g].v) {
+                float w[3];
+                xfm_point(i.xfm, v.position, w);
+                for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], w[k]); hi[k] = std::max(hi[k], w[k]); }
+            }
+    for (int k = 0; k < 3; ++k) { bounds[k] = lo[k]; bounds[3 + k] = hi[k]; }
+    return 0;
+}
+
+int gfxh_scene_upload(gfxh_scene* s, gfx_ctx* ctx) {
+    for (uint32_t i = 0; i < s->materials.size(); ++i)
+        if (gfx_material_set(ctx, i, &s->materials[i])) { g_hostError = gfx_last_error(ctx); return 1; }
+    for (const Geom& g : s->geoms) {
+        uint32_t slot;
+        if (gfx_geom_create(ctx, g.v.data(), sizeof(gfx_vertex), static_cast<uint32_t>(g.v.size()), g.t.data(),
+                            static_cast<uint32_t>(g.t.size() / 3), g.mat, &slot)) { g_hostError = gfx_last_error(ctx); return 1; }
+    }
+    for (const auto& grp : s->groups) {
+        uint32_t slot;
+        if (gfx_group_create(ctx, grp.data(), static_cast<uint32_t>(grp.size()), &slot)) { g_hostError = gfx_last_error(ctx); return 1; }
+    }
+    for (const Inst& i : s->insts) {
+        uint32_t slot;
+        if (gfx_instance_create(ctx, i.group, i.xfm, &slot)) { g_hostError = gfx_last_error(ctx); return 1; }
+    }
+    return 0;
+}
+
+// restir_di_main.cpp:1487-1542 -- Halton(2,3) through the concentric square->disk map.  The host
+// program uses <cmath> cos/sin; here the table goes through the same deterministic sincos as the
+// kernels so any consumer (including a CPU checker) reproduces it bit for bit.
+static void host_sincos(float x, float* s, float* c) {
+    // identical algorithm to gfx::gm_sincos (gm_math.hip.h), host build
+    const float q = std::rint(x * 0.6366197466850281f);
+    float r = std::fma(q, -1.5703125f, x);
+    r = std::fma(q, -0.0004837512969970703f, r);
+    r = std::fma(q, -7.549790126404332e-08f, r);
+    const int n = static_cast<int>(q);
+    const float r2 = r * r;
+    float ps = std::fma(-1.9515295891e-4f, r2, 8.3321608736e-3f);
+    ps = std::fma(ps, r2, -1.6666654611e-1f);
+    const float sr = std::fma(ps * r2, r, r);
+    float pc = std::fma(2.443315711809948e-5f, r2, -1.388731625493765e-3f);
+    pc = std::fma(pc, r2, 4.166664568298827e-2f);
+    const float cr = std::fma(pc * r2, r2, std::fma(-0.5f, r2, 1.0f));
+    const float ss = (n & 1) ? cr : sr, cc = (n & 1) ? sr : cr;
+    *s = (n & 2) ? -ss : ss;
+    *c = ((n + 1) & 2) ? -cc : cc;
+}
+void gfxh_spatial_neighbor_deltas(float* out) {
+    auto halton = [](uint32_t base, uint32_t idx) {
+        const float recBase = 1.0f / base;
+        float ret = 0.0f, scale = 1.0f;
+        while (idx) { scale *= recBase; ret += (idx % base) * scale; idx /= base; }
+        return ret;
+    };
+    for (uint32_t i = 0; i < 1024; ++i) {
+        const float u0 = halton(2, i), u1 = halton(3, i);
+        float dx = 0, dy = 0;
+        const float sx = 2 * u0 - 1, sy = 2 * u1 - 1;
+        if (!(sx == 0 && sy == 0)) {
+            float r, theta;
+            if (sx >= -sy) {
+                if (sx > sy) { r = sx; theta = sy / sx; }
+                else { r = sy; theta = 2 - sx / sy; }
+            }
+            else {
+                if (sx > sy) { r = -sy; theta = 6 + sx / sy; }
+                else { r = -sx; theta = 4 + sy / sx; }
+            }
+            theta *= 3.14159265358979323846f / 4;
+            float s, c;
+            host_sincos(theta, &s, &c);
+            dx = r * c; dy = r * s;
+        }
+        out[2 * i] = dx; out[2 * i + 1] = dy;
+    }
+}
+
+} // extern "C"

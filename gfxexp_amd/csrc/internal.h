@@ -1,0 +1,134 @@
+// internal.h -- host-side state of the library behind include/gfxexp.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "device_types.h"
+
+namespace gfx {
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define GFX_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) \
+    throw ::gfx::HipError(std::string(#call) + ": " + hipGetErrorString(e__)); } while (0)
+
+// Growable device allocation owned by the library (BVH memory, ray queues, scratch).
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void reserve(size_t n) {
+        if (n <= bytes) return;
+        if (p) GFX_HIP(hipFree(p));
+        p = nullptr; bytes = 0;
+        GFX_HIP(hipMalloc(&p, n));
+        bytes = n;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct HostGeom {
+    std::vector<DevVertex> vertices;
+    std::vector<uint32_t> triangles;   // 3 per triangle
+    uint32_t materialSlot = 0;
+};
+struct HostInstance {
+    uint32_t group = 0;
+    float transform[12];
+    float prevTransform[12];
+};
+
+struct Accel {
+    DevBuf nodes, tris, triIds;
+    uint32_t numNodes = 0, numTris = 0, numInputTris = 0, maxDepth = 0;
+    DevAccel dev() const {
+        DevAccel a; a.nodes = nodes.as<Bvh8Node>(); a.tris = tris.as<Bvh8Tri>(); a.numNodes = numNodes; a.numTris = numTris;
+        return a;
+    }
+};
+
+struct KernelTiming { double ms = 0; uint32_t calls = 0; };
+
+struct RestirParams {
+    gfx_restir_static_params s;
+    gfx_restir_frame_params f;
+    uint32_t currentReservoirIndex = 0;
+    uint32_t spatialNeighborBaseIndex = 0;
+    bool valid = false;
+};
+
+struct Context {
+    int device = 0;
+    std::string lastError;
+    // scene (host mirror)
+    std::vector<gfx_material> materials;
+    std::vector<HostGeom> geoms;
+    std::vector<std::vector<uint32_t>> groups;
+    std::vector<HostInstance> insts;
+    bool sceneDirty = true;
+    // scene (device)
+    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightCDF;
+    std::vector<DevGeomInst> hGeomInsts;
+    std::vector<DevInstance> hInsts;
+    std::vector<DevFlatGeom> hFlatGeoms;
+    uint32_t totalTriangles = 0;
+    uint32_t lightPoolSize = 0;
+    uint32_t lightInstDistOffset = 0;
+    DevBuf dLightInstIntegral;       // float[4]; [0] = integral of the instance-level distribution
+    bool lightsStaticBuilt = false;
+    DevScene devScene() const;
+    // accels
+    std::vector<Accel*> accels;
+    uint32_t maxLeafTris = 4;
+    // ray scratch
+    DevBuf rayOrg, rayDir, rayOut, rayHits, spill, pixelRaySlot, shadeScratch, spatialScratch, smallCounters;
+    // build scratch
+    DevBuf bTris, bBoxes, bKeys, bKeysAlt, bVals, bValsAlt, bSortTemp, bNodesLR, bParents, bFlags, bNodeBoxes, bRanges, bQueueA, bQueueB, bCounters;
+    // restir
+    RestirParams restir;
+    // instrumentation
+    bool timingEnabled = false;
+    std::map<std::string, KernelTiming> timings;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pendingEvents;
+    bool countersEnabled = false;
+    DevBuf dTraceCounters;     // u64[4]
+    ~Context();
+};
+
+// Time one kernel launch with HIP events on `stream` when timing is enabled.
+struct ScopedKernelTimer {
+    Context& ctx; hipStream_t stream; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    ScopedKernelTimer(Context& c, hipStream_t s, const char* n) : ctx(c), stream(s), name(n) {
+        if (!ctx.timingEnabled) return;
+        GFX_HIP(hipEventCreate(&a)); GFX_HIP(hipEventCreate(&b));
+        GFX_HIP(hipEventRecord(a, stream));
+    }
+    ~ScopedKernelTimer() {
+        if (!a) return;
+        (void)hipEventRecord(b, stream);
+        ctx.pendingEvents.push_back({ name, { a, b } });
+    }
+};
+
+// ---- scene.cpp
+void scene_upload(Context& ctx, hipStream_t stream);
+// ---- lbvh.hip
+void lbvh_build(Context& ctx, hipStream_t stream, Accel& out);
+// ---- trace.hip
+struct TraceLaunch {
+    DevAccel accel;
+    const float4* rayOrgTmin; const float4* rayDirTmax;
+    uint32_t numRays; const uint32_t* numRaysPtr;   // device-side count overrides numRays when non-null
+    void* out;
+    int mode;
+};
+void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t);
+// ---- lights.hip
+void lights_build_static(Context& ctx, hipStream_t stream);
+void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t bufferIndex);
+// ---- restir.hip
+void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height);
+
+} // namespace gfx

@@ -1,0 +1,475 @@
+// lbvh.hip -- HIP LBVH -> BVH8 builder (replaces the CPU top-down SAH builder
+// common/bvh_builder.cpp:656-1125 and OptiX's GAS/IAS build, common/common_host.h:1027-1100).
+//
+// Pipeline (all on the GPU, one stream):
+//   1. flatten     every (instance, geomInst, triangle) -> world-space 48-byte record (same
+//                  arithmetic as calcTriangleVertices, bvh_builder.cpp:178-209) + scene bounds
+//   2. morton      63-bit Morton code of the triangle-box centre; rocPRIM radix sort (key, index)
+//   3. karras      binary radix tree over the sorted codes (Karras 2012), index tie-break
+//   4. fit         bottom-up AABBs; second arriver at a node continues (agent-scope fences)
+//   5. collapse    top-down, level by level: a wide node repeatedly opens its largest-area child
+//                  until it has 8 (the reference's "split the child with the maximum surface
+//                  area", bvh_builder.cpp:785-888); children with <= maxLeafTris triangles become
+//                  leaves; child boxes are quantised to a 6-bit power-of-two grid, conservatively
+//                  (the reference grid is 8-bit, common_shared.h:814-851); children are placed in
+//                  octant slots by a greedy auction so traversal needs no sorting.
+//   6. triangles of a node's leaf children are copied contiguously behind the node's triBase.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "internal.h"
+#include "shading.hip.h"
+
+namespace gfx {
+
+GFX_DEV uint32_t ordered_from_float(float f) { const uint32_t u = f2bits(f); return u ^ (u < 0x80000000u ? 0x80000000u : 0xFFFFFFFFu); }
+GFX_DEV float float_from_ordered(uint32_t o) { const uint32_t u = o ^ (o >= 0x80000000u ? 0x80000000u : 0xFFFFFFFFu); return bits2f(u); }
+
+struct Box { f3 lo, hi; };
+GFX_DEV Box tri_box(const Bvh8Tri& t) {
+    Box b;
+    b.lo = f3(fminf(fminf(t.ax, t.bx), t.cx), fminf(fminf(t.ay, t.by), t.cy), fminf(fminf(t.az, t.bz), t.cz));
+    b.hi = f3(fmaxf(fmaxf(t.ax, t.bx), t.cx), fmaxf(fmaxf(t.ay, t.by), t.cy), fmaxf(fmaxf(t.az, t.bz), t.cz));
+    return b;
+}
+GFX_DEV Box box_union(const Box& a, const Box& b) {
+    Box r;
+    r.lo = f3(fminf(a.lo.x, b.lo.x), fminf(a.lo.y, b.lo.y), fminf(a.lo.z, b.lo.z));
+    r.hi = f3(fmaxf(a.hi.x, b.hi.x), fmaxf(a.hi.y, b.hi.y), fmaxf(a.hi.z, b.hi.z));
+    return r;
+}
+GFX_DEV float half_area(const Box& b) { const f3 d = b.hi - b.lo; return d.x * d.y + d.y * d.z + d.z * d.x; }
+
+GFX_DEV Bvh8Tri load_tri(const Bvh8Tri* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    const float4 a = q[0], b = q[1], c = q[2];
+    Bvh8Tri t;
+    t.ax = a.x; t.ay = a.y; t.az = a.z; t.bx = a.w; t.by = b.x; t.bz = b.y; t.cx = b.z; t.cy = b.w; t.cz = c.x;
+    t.instSlot = f2bits(c.y); t.geomInstSlot = f2bits(c.z); t.primIndex = f2bits(c.w);
+    return t;
+}
+GFX_DEV void store_tri(Bvh8Tri* p, const Bvh8Tri& t) {
+    float4* q = reinterpret_cast<float4*>(p);
+    q[0] = make_float4(t.ax, t.ay, t.az, t.bx);
+    q[1] = make_float4(t.by, t.bz, t.cx, t.cy);
+    q[2] = make_float4(t.cz, bits2f(t.instSlot), bits2f(t.geomInstSlot), bits2f(t.primIndex));
+}
+
+// ---------------------------------------------------------------- 1. flatten
+__global__ void k_flatten(DevScene sc, const DevFlatGeom* __restrict__ flat, uint32_t numFlat, uint32_t n,
+                          Bvh8Tri* __restrict__ out, uint32_t* __restrict__ bounds /* ordered lo xyz, hi xyz */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    f3 lo(INFINITY), hi(-INFINITY);
+    if (i < n) {
+        // binary search the flattened-geometry list (triBegin ascending)
+        uint32_t a = 0, b = numFlat;
+        while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (flat[m].triBegin <= i) a = m; else b = m; }
+        const DevFlatGeom fg = flat[a];
+        const uint32_t prim = i - fg.triBegin;
+        const DevGeomInst g = sc.geomInsts[fg.geomInstSlot];
+        const uint32_t* tri = sc.triangles + 3ull * (g.triangleOffset + prim);
+        const DevVertex vA = load_vertex(sc.vertices + g.vertexOffset + tri[0]);
+        const DevVertex vB = load_vertex(sc.vertices + g.vertexOffset + tri[1]);
+        const DevVertex vC = load_vertex(sc.vertices + g.vertexOffset + tri[2]);
+        const m34 xfm = load_m34(sc.insts[fg.instSlot].transform);
+        const f3 pA = xfm_point(xfm, f3(vA.px, vA.py, vA.pz));
+        const f3 pB = xfm_point(xfm, f3(vB.px, vB.py, vB.pz));
+        const f3 pC = xfm_point(xfm, f3(vC.px, vC.py, vC.pz));
+        Bvh8Tri t;
+        t.ax = pA.x; t.ay = pA.y; t.az = pA.z; t.bx = pB.x; t.by = pB.y; t.bz = pB.z; t.cx = pC.x; t.cy = pC.y; t.cz = pC.z;
+        t.instSlot = fg.instSlot; t.geomInstSlot = fg.geomInstSlot; t.primIndex = prim;
+        store_tri(out + i, t);
+        const Box bx = tri_box(t);
+        lo = bx.lo; hi = bx.hi;
+    }
+    // wave reduction, then one atomic per wave and component
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo.x = fminf(lo.x, __shfl_xor(lo.x, off)); lo.y = fminf(lo.y, __shfl_xor(lo.y, off)); lo.z = fminf(lo.z, __shfl_xor(lo.z, off));
+        hi.x = fmaxf(hi.x, __shfl_xor(hi.x, off)); hi.y = fmaxf(hi.y, __shfl_xor(hi.y, off)); hi.z = fmaxf(hi.z, __shfl_xor(hi.z, off));
+    }
+    if ((threadIdx.x & 63) == 0 && lo.x <= hi.x) {
+        atomicMin(bounds + 0, ordered_from_float(lo.x)); atomicMin(bounds + 1, ordered_from_float(lo.y)); atomicMin(bounds + 2, ordered_from_float(lo.z));
+        atomicMax(bounds + 3, ordered_from_float(hi.x)); atomicMax(bounds + 4, ordered_from_float(hi.y)); atomicMax(bounds + 5, ordered_from_float(hi.z));
+    }
+}
+
+// ---------------------------------------------------------------- 2. morton
+GFX_DEV uint64_t spread21(uint32_t v) {
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__global__ void k_morton(const Bvh8Tri* __restrict__ tris, uint32_t n, const uint32_t* __restrict__ bounds,
+                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 lo(float_from_ordered(bounds[0]), float_from_ordered(bounds[1]), float_from_ordered(bounds[2]));
+    const f3 hi(float_from_ordered(bounds[3]), float_from_ordered(bounds[4]), float_from_ordered(bounds[5]));
+    const Box b = tri_box(load_tri(tris + i));
+    const f3 c = 0.5f * (b.lo + b.hi);
+    const f3 e = hi - lo;
+    const float sx = e.x > 0 ? (c.x - lo.x) / e.x : 0.0f, sy = e.y > 0 ? (c.y - lo.y) / e.y : 0.0f, sz = e.z > 0 ? (c.z - lo.z) / e.z : 0.0f;
+    const uint32_t qx = min(f2u_sat(sx * 2097152.0f), 2097151u), qy = min(f2u_sat(sy * 2097152.0f), 2097151u), qz = min(f2u_sat(sz * 2097152.0f), 2097151u);
+    keys[i] = (spread21(qx) << 2) | (spread21(qy) << 1) | spread21(qz);
+    vals[i] = i;
+}
+
+// ---------------------------------------------------------------- 3. karras
+// child reference: >= 0 internal node, < 0 leaf ~ref
+GFX_DEV int delta_fn(const uint64_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint64_t x = keys[i] ^ keys[j];
+    if (x == 0) return 64 + __clz(static_cast<uint32_t>(i ^ j));
+    return __clzll(x);
+}
+__global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restrict__ lr, uint32_t* __restrict__ parentInt,
+                         uint32_t* __restrict__ parentLeaf, uint2* __restrict__ ranges) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta_fn(keys, n, i, i + 1) - delta_fn(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta_fn(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta_fn(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta_fn(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta_fn(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta_fn(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int first = min(i, j), last = max(i, j);
+    const int left = (first == gamma) ? ~gamma : gamma;
+    const int right = (last == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    lr[i] = make_int2(left, right);
+    ranges[i] = make_uint2(static_cast<uint32_t>(first), static_cast<uint32_t>(last));
+    if (left >= 0) parentInt[left] = i; else parentLeaf[~left] = i;
+    if (right >= 0) parentInt[right] = i; else parentLeaf[~right] = i;
+    if (i == 0) parentInt[0] = 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------- 4. fit
+__global__ void k_fit(const Bvh8Tri* __restrict__ tris, const uint32_t* __restrict__ sortedIdx, int n,
+                      const int2* __restrict__ lr, const uint32_t* __restrict__ parentInt, const uint32_t* __restrict__ parentLeaf,
+                      uint32_t* __restrict__ flags, float* nodeBoxes /* 8 floats per internal node */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t node = parentLeaf[i];
+    int cameFrom = ~i;
+    Box mine = tri_box(load_tri(tris + sortedIdx[i]));
+    while (true) {
+        // release my subtree's box (internal only; leaf boxes are recomputed from the triangle)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = atomicAdd(flags + node, 1u);
+        if (old == 0) return;                       // first arriver: the sibling finishes this node
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int2 c = lr[node];
+        const int sib = (c.x == cameFrom) ? c.y : c.x;
+        Box sb;
+        if (sib < 0) sb = tri_box(load_tri(tris + sortedIdx[~sib]));
+        else {
+            const float* p = nodeBoxes + 8ull * sib;
+            sb.lo = f3(__hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            sb.hi = f3(__hip_atomic_load(p + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        mine = box_union(mine, sb);
+        float* q = nodeBoxes + 8ull * node;
+        __hip_atomic_store(q + 0, mine.lo.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, mine.lo.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 2, mine.lo.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 4, mine.hi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 5, mine.hi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 6, mine.hi.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (node == 0) return;
+        cameFrom = static_cast<int>(node);
+        node = parentInt[node];
+    }
+}
+
+// ---------------------------------------------------------------- 5./6. collapse
+struct WideChild {
+    int ref;            // binary child reference (>= 0 internal, < 0 leaf)
+    uint32_t first, last;
+    Box box;
+};
+
+GFX_DEV void load_child(int ref, const Bvh8Tri* __restrict__ tris, const uint32_t* __restrict__ sortedIdx,
+                        const float* __restrict__ nodeBoxes, const uint2* __restrict__ ranges, WideChild& c) {
+    c.ref = ref;
+    if (ref < 0) {
+        c.first = c.last = static_cast<uint32_t>(~ref);
+        c.box = tri_box(load_tri(tris + sortedIdx[~ref]));
+    }
+    else {
+        const uint2 r = ranges[ref];
+        c.first = r.x; c.last = r.y;
+        const float* p = nodeBoxes + 8ull * ref;
+        c.box.lo = f3(p[0], p[1], p[2]);
+        c.box.hi = f3(p[4], p[5], p[6]);
+    }
+}
+
+// counters: [0] wide-node allocator, [1] triangle-record allocator, [2 + l] work items of level l
+__global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
+                                 const uint2* __restrict__ queueIn, uint2* __restrict__ queueOut, uint32_t* __restrict__ counters,
+                                 const int2* __restrict__ lr, const uint2* __restrict__ ranges, const float* __restrict__ nodeBoxes,
+                                 const Bvh8Tri* __restrict__ trisIn, const uint32_t* __restrict__ sortedIdx,
+                                 Bvh8Node* __restrict__ nodesOut, Bvh8Tri* __restrict__ trisOut) {
+    const uint32_t numItems = counters[2 + level];
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < numItems; item += gridDim.x * blockDim.x) {
+        const uint2 work = queueIn[item];       // x = binary node, y = wide node index
+        WideChild ch[8];
+        int n = 2;
+        {
+            const int2 c = lr[work.x];
+            load_child(c.x, trisIn, sortedIdx, nodeBoxes, ranges, ch[0]);
+            load_child(c.y, trisIn, sortedIdx, nodeBoxes, ranges, ch[1]);
+        }
+        while (n < 8) {
+            int bestIdx = -1; float bestArea = -INFINITY;
+            for (int k = 0; k < n; ++k) {
+                if (ch[k].ref < 0) continue;
+                const float a = half_area(ch[k].box);
+                if (a > bestArea) { bestArea = a; bestIdx = k; }
+            }
+            if (bestIdx < 0) break;
+            const int2 c = lr[ch[bestIdx].ref];
+            load_child(c.x, trisIn, sortedIdx, nodeBoxes, ranges, ch[bestIdx]);
+            load_child(c.y, trisIn, sortedIdx, nodeBoxes, ranges, ch[n]);
+            ++n;
+        }
+        // node frame
+        Box nb = ch[0].box;
+        for (int k = 1; k < n; ++k) nb = box_union(nb, ch[k].box);
+        const f3 origin = nb.lo;
+        uint32_t ex[3];
+        float scale[3];
+        {
+            const float ext[3] = { nb.hi.x - nb.lo.x, nb.hi.y - nb.lo.y, nb.hi.z - nb.lo.z };
+            const float org[3] = { origin.x, origin.y, origin.z };
+            const float top[3] = { nb.hi.x, nb.hi.y, nb.hi.z };
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t us = f2bits(ext[a] / 63.0f);
+                uint32_t e = (us >> 23) + ((us & 0x7FFFFFu) ? 1u : 0u);
+                // the decoded far end origin + 63 * scale must not round below the true maximum
+                while (e < 254u && org[a] + 63.0f * bits2f(e << 23) < top[a]) ++e;
+                ex[a] = e; scale[a] = bits2f(e << 23);
+            }
+        }
+        // octant slots by greedy auction: maximise sum of dot(child centre - node centre, slot sign)
+        const f3 nc = 0.5f * (nb.lo + nb.hi);
+        int slotOf[8];
+        {
+            float cost[8][8];
+            for (int k = 0; k < n; ++k) {
+                const f3 cc = 0.5f * (ch[k].box.lo + ch[k].box.hi) - nc;
+                for (int s = 0; s < 8; ++s)
+                    cost[k][s] = ((s & 1) ? cc.x : -cc.x) + ((s & 2) ? cc.y : -cc.y) + ((s & 4) ? cc.z : -cc.z);
+            }
+            uint32_t freeSlots = 0xFFu, freeKids = (1u << n) - 1u;
+            for (int it = 0; it < n; ++it) {
+                float best = -INFINITY; int bk = 0, bs = 0;
+                for (int k = 0; k < n; ++k) {
+                    if (!((freeKids >> k) & 1u)) continue;
+                    for (int s = 0; s < 8; ++s) {
+                        if (!((freeSlots >> s) & 1u)) continue;
+                        if (cost[k][s] > best) { best = cost[k][s]; bk = k; bs = s; }
+                    }
+                }
+                slotOf[bk] = bs;
+                freeKids &= ~(1u << bk); freeSlots &= ~(1u << bs);
+            }
+        }
+        int kidAt[8];
+        for (int s = 0; s < 8; ++s) kidAt[s] = -1;
+        for (int k = 0; k < n; ++k) kidAt[slotOf[k]] = k;
+
+        uint32_t imask = 0, numInternal = 0, numLeafTris = 0;
+        for (int s = 0; s < 8; ++s) {
+            const int k = kidAt[s];
+            if (k < 0) continue;
+            const uint32_t cnt = ch[k].last - ch[k].first + 1;
+            if (cnt > maxLeafTris) { imask |= 1u << s; ++numInternal; }
+            else numLeafTris += cnt;
+        }
+        const uint32_t childBase = numInternal ? atomicAdd(counters + 0, numInternal) : 0xFFFFFFFFu;
+        const uint32_t triBase = numLeafTris ? atomicAdd(counters + 1, numLeafTris) : 0xFFFFFFFFu;
+        const uint32_t qBase = numInternal ? atomicAdd(counters + 2 + level + 1, numInternal) : 0u;
+
+        Bvh8Node node;
+        node.w[0] = f2bits(origin.x); node.w[1] = f2bits(origin.y); node.w[2] = f2bits(origin.z);
+        node.w[3] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);
+        node.w[4] = childBase; node.w[5] = triBase;
+        node.w[14] = 0; node.w[15] = 0;
+        uint32_t internalRank = 0, triOff = 0;
+        const float org[3] = { origin.x, origin.y, origin.z };
+        for (int s = 0; s < 8; ++s) {
+            const int k = kidAt[s];
+            if (k < 0) { node.w[6 + s] = 0; continue; }
+            const float lo[3] = { ch[k].box.lo.x, ch[k].box.lo.y, ch[k].box.lo.z };
+            const float hi[3] = { ch[k].box.hi.x, ch[k].box.hi.y, ch[k].box.hi.z };
+            uint32_t qlo[3], qhi[3];
+            for (int a = 0; a < 3; ++a) {
+                uint32_t l = 0, h = 1;
+                if (scale[a] > 0.0f) {
+                    l = min(f2u_sat((lo[a] - org[a]) / scale[a]), 63u);
+                    h = min(f2u_sat((hi[a] - org[a]) / scale[a]) + 1u, 63u);
+                }
+                // make the DECODED box (origin + q * scale, as traversal computes it) contain the child
+                while (l > 0 && org[a] + static_cast<float>(l) * scale[a] > lo[a]) --l;
+                while (h < 63 && org[a] + static_cast<float>(h) * scale[a] < hi[a]) ++h;
+                qlo[a] = l; qhi[a] = h;
+            }
+            const uint32_t cnt = ch[k].last - ch[k].first + 1;
+            const bool internal = (imask >> s) & 1u;
+            const uint32_t count = internal ? 1u : cnt;
+            node.w[6 + s] = qlo[0] | (qlo[1] << 6) | (qlo[2] << 12) | (qhi[0] << 18) | (qhi[1] << 24) | ((count & 3u) << 30);
+            node.w[14 + (s >> 2)] |= (qhi[2] | ((count >> 2) << 6)) << ((s & 3) * 8);
+            if (internal) {
+                queueOut[qBase + internalRank] = make_uint2(static_cast<uint32_t>(ch[k].ref), childBase + internalRank);
+                ++internalRank;
+            }
+            else {
+                for (uint32_t t = 0; t < cnt; ++t)
+                    store_tri(trisOut + triBase + triOff + t, load_tri(trisIn + sortedIdx[ch[k].first + t]));
+                triOff += cnt;
+            }
+        }
+        uint4* dst = reinterpret_cast<uint4*>(nodesOut + work.y);
+        dst[0] = make_uint4(node.w[0], node.w[1], node.w[2], node.w[3]);
+        dst[1] = make_uint4(node.w[4], node.w[5], node.w[6], node.w[7]);
+        dst[2] = make_uint4(node.w[8], node.w[9], node.w[10], node.w[11]);
+        dst[3] = make_uint4(node.w[12], node.w[13], node.w[14], node.w[15]);
+    }
+}
+
+// single-triangle scene: one node, one leaf child in slot 0
+__global__ void k_single_tri_root(const Bvh8Tri* __restrict__ trisIn, Bvh8Node* __restrict__ nodesOut, Bvh8Tri* __restrict__ trisOut) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const Bvh8Tri t = load_tri(trisIn);
+    const Box b = tri_box(t);
+    Bvh8Node node;
+    for (int i = 0; i < 16; ++i) node.w[i] = 0;
+    node.w[0] = f2bits(b.lo.x); node.w[1] = f2bits(b.lo.y); node.w[2] = f2bits(b.lo.z);
+    uint32_t ex[3];
+    const float ext[3] = { b.hi.x - b.lo.x, b.hi.y - b.lo.y, b.hi.z - b.lo.z };
+    const float org[3] = { b.lo.x, b.lo.y, b.lo.z };
+    const float top[3] = { b.hi.x, b.hi.y, b.hi.z };
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t us = f2bits(ext[a] / 63.0f);
+        uint32_t e = (us >> 23) + ((us & 0x7FFFFFu) ? 1u : 0u);
+        while (e < 254u && org[a] + 63.0f * bits2f(e << 23) < top[a]) ++e;
+        ex[a] = e;
+    }
+    node.w[3] = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+    node.w[4] = 0xFFFFFFFFu; node.w[5] = 0;
+    node.w[6] = 0u | (63u << 18) | (63u << 24) | (1u << 30);   // whole frame, count = 1
+    node.w[14] = 63u;
+    uint4* dst = reinterpret_cast<uint4*>(nodesOut);
+    dst[0] = make_uint4(node.w[0], node.w[1], node.w[2], node.w[3]);
+    dst[1] = make_uint4(node.w[4], node.w[5], node.w[6], node.w[7]);
+    dst[2] = make_uint4(node.w[8], node.w[9], node.w[10], node.w[11]);
+    dst[3] = make_uint4(node.w[12], node.w[13], node.w[14], node.w[15]);
+    store_tri(trisOut, t);
+}
+
+__global__ void k_tri_ids(const Bvh8Tri* __restrict__ tris, uint32_t n, gfx_tri_ids* __restrict__ ids) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Bvh8Tri* t = tris + i;
+    gfx_tri_ids o; o.instSlot = t->instSlot; o.geomInstSlot = t->geomInstSlot; o.primIndex = t->primIndex;
+    ids[i] = o;
+}
+
+constexpr uint32_t kMaxCollapseLevels = 96;
+
+void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
+    scene_upload(ctx, stream);
+    const uint32_t n = ctx.totalTriangles;
+    out.numInputTris = n;
+    out.numNodes = 0; out.numTris = 0; out.maxDepth = 0;
+    if (n == 0) return;
+    const uint32_t numFlat = static_cast<uint32_t>(ctx.hFlatGeoms.size());
+    const dim3 blk(256), grd((n + 255) / 256);
+
+    ctx.bTris.reserve(sizeof(Bvh8Tri) * static_cast<size_t>(n));
+    ctx.bKeys.reserve(8ull * n); ctx.bKeysAlt.reserve(8ull * n);
+    ctx.bVals.reserve(4ull * n); ctx.bValsAlt.reserve(4ull * n);
+    ctx.bNodesLR.reserve(8ull * n); ctx.bParents.reserve(8ull * n + 16); ctx.bFlags.reserve(4ull * n);
+    ctx.bNodeBoxes.reserve(32ull * n); ctx.bRanges.reserve(8ull * n);
+    ctx.bQueueA.reserve(8ull * n + 16); ctx.bQueueB.reserve(8ull * n + 16);
+    ctx.bCounters.reserve(4 * (2 + kMaxCollapseLevels + 2) + 64);
+    out.nodes.reserve(sizeof(Bvh8Node) * static_cast<size_t>(n));
+    out.tris.reserve(sizeof(Bvh8Tri) * static_cast<size_t>(n));
+    out.triIds.reserve(sizeof(gfx_tri_ids) * static_cast<size_t>(n));
+
+    uint32_t* counters = ctx.bCounters.as<uint32_t>();
+    uint32_t* bounds = counters + 2 + kMaxCollapseLevels + 2;
+    {
+        std::vector<uint32_t> init(2 + kMaxCollapseLevels + 2 + 6, 0u);
+        init[0] = 1;                     // root wide node is index 0
+        init[2] = 1;                     // one work item at level 0
+        for (int k = 0; k < 3; ++k) { init[2 + kMaxCollapseLevels + 2 + k] = 0xFFFFFFFFu; init[2 + kMaxCollapseLevels + 2 + 3 + k] = 0u; }
+        GFX_HIP(hipMemcpyAsync(counters, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice, stream));
+        GFX_HIP(hipStreamSynchronize(stream));
+    }
+    hipLaunchKernelGGL(k_flatten, grd, blk, 0, stream, ctx.devScene(), ctx.dFlatGeoms.as<DevFlatGeom>(), numFlat, n,
+                       ctx.bTris.as<Bvh8Tri>(), bounds);
+    if (n == 1) {
+        hipLaunchKernelGGL(k_single_tri_root, dim3(1), dim3(64), 0, stream, ctx.bTris.as<Bvh8Tri>(), out.nodes.as<Bvh8Node>(), out.tris.as<Bvh8Tri>());
+        out.numNodes = 1; out.numTris = 1; out.maxDepth = 1;
+    }
+    else {
+        hipLaunchKernelGGL(k_morton, grd, blk, 0, stream, ctx.bTris.as<Bvh8Tri>(), n, bounds, ctx.bKeys.as<uint64_t>(), ctx.bVals.as<uint32_t>());
+        size_t tempBytes = 0;
+        GFX_HIP(rocprim::radix_sort_pairs(nullptr, tempBytes, ctx.bKeys.as<uint64_t>(), ctx.bKeysAlt.as<uint64_t>(),
+                                          ctx.bVals.as<uint32_t>(), ctx.bValsAlt.as<uint32_t>(), n, 0, 63, stream));
+        ctx.bSortTemp.reserve(std::max<size_t>(tempBytes, 16));
+        GFX_HIP(rocprim::radix_sort_pairs(ctx.bSortTemp.p, tempBytes, ctx.bKeys.as<uint64_t>(), ctx.bKeysAlt.as<uint64_t>(),
+                                          ctx.bVals.as<uint32_t>(), ctx.bValsAlt.as<uint32_t>(), n, 0, 63, stream));
+        const uint64_t* keys = ctx.bKeysAlt.as<uint64_t>();
+        const uint32_t* sortedIdx = ctx.bValsAlt.as<uint32_t>();
+        uint32_t* parentInt = ctx.bParents.as<uint32_t>();
+        uint32_t* parentLeaf = parentInt + n;
+        hipLaunchKernelGGL(k_karras, grd, blk, 0, stream, keys, static_cast<int>(n), ctx.bNodesLR.as<int2>(), parentInt, parentLeaf,
+                           ctx.bRanges.as<uint2>());
+        GFX_HIP(hipMemsetAsync(ctx.bFlags.p, 0, 4ull * n, stream));
+        hipLaunchKernelGGL(k_fit, grd, blk, 0, stream, ctx.bTris.as<Bvh8Tri>(), sortedIdx, static_cast<int>(n), ctx.bNodesLR.as<int2>(),
+                           parentInt, parentLeaf, ctx.bFlags.as<uint32_t>(), ctx.bNodeBoxes.as<float>());
+        // level 0 work item: binary root 0 -> wide node 0
+        const uint2 rootItem = make_uint2(0u, 0u);
+        GFX_HIP(hipMemcpyAsync(ctx.bQueueA.p, &rootItem, sizeof(rootItem), hipMemcpyHostToDevice, stream));
+        const uint32_t gridC = std::min<uint32_t>((n + 255) / 256, 2048u);
+        for (uint32_t level = 0; level < kMaxCollapseLevels; ++level) {
+            uint2* qin = (level & 1) ? ctx.bQueueB.as<uint2>() : ctx.bQueueA.as<uint2>();
+            uint2* qout = (level & 1) ? ctx.bQueueA.as<uint2>() : ctx.bQueueB.as<uint2>();
+            hipLaunchKernelGGL(k_collapse_level, dim3(gridC), dim3(256), 0, stream, level, ctx.maxLeafTris, qin, qout, counters,
+                               ctx.bNodesLR.as<int2>(), ctx.bRanges.as<uint2>(), ctx.bNodeBoxes.as<float>(),
+                               ctx.bTris.as<Bvh8Tri>(), sortedIdx, out.nodes.as<Bvh8Node>(), out.tris.as<Bvh8Tri>());
+        }
+        GFX_HIP(hipGetLastError());
+        std::vector<uint32_t> h(2 + kMaxCollapseLevels + 2);
+        GFX_HIP(hipMemcpyAsync(h.data(), counters, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost, stream));
+        GFX_HIP(hipStreamSynchronize(stream));
+        out.numNodes = h[0]; out.numTris = h[1];
+        for (uint32_t l = 0; l < kMaxCollapseLevels; ++l) if (h[2 + l]) out.maxDepth = l + 1;
+        if (h[2 + kMaxCollapseLevels] != 0) throw HipError("lbvh_build: tree deeper than kMaxCollapseLevels");
+        if (out.numTris != n) throw HipError("lbvh_build: triangle count mismatch after collapse");
+    }
+    hipLaunchKernelGGL(k_tri_ids, dim3((out.numTris + 255) / 256), blk, 0, stream, out.tris.as<Bvh8Tri>(), out.numTris, out.triIds.as<gfx_tri_ids>());
+    GFX_HIP(hipGetLastError());
+    GFX_HIP(hipStreamSynchronize(stream));
+}
+
+} // namespace gfx

@@ -1,0 +1,140 @@
+// lights.hip -- emitter importance and the three-level light distribution.
+//
+// Reference: common/gpu_kernels/compute_light_probs.cu:22-46 (triangle importance),
+// :86-93 (geomInst importance), :134-142 (instance importance), :206-212 (finalize) and the cubd
+// exclusive scans sequenced by common/common_host.h:1102-1359.
+//
+// Contract: a CDF is the SERIAL left-to-right exclusive prefix sum of its weights (the order a CPU
+// loop produces).  cub::DeviceScan leaves the association order unspecified, so the reference's
+// own CDFs are only defined up to fp32 rounding; fixing the serial order makes the sampled
+// triangle indices reproducible.  One thread scans one distribution; the scene has many small
+// distributions (one per emitter geomInst / instance), so the work is still parallel.
+#include "internal.h"
+#include "shading.hip.h"
+
+namespace gfx {
+
+__global__ void k_triangle_importance(DevScene sc, uint32_t numGeomInsts, float* __restrict__ weights) {
+    // one block row per geomInst (blockIdx.y), threads over its triangles
+    const uint32_t gi = blockIdx.y;
+    if (gi >= numGeomInsts) return;
+    const DevGeomInst g = sc.geomInsts[gi];
+    if (g.distOffset == 0xFFFFFFFFu) return;
+    const gfx_material& mat = sc.materials[g.materialSlot];
+    const f3 e(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < g.numTriangles; t += gridDim.x * blockDim.x) {
+        const uint32_t* tri = sc.triangles + 3ull * (g.triangleOffset + t);
+        const DevVertex v0 = load_vertex(sc.vertices + g.vertexOffset + tri[0]);
+        const DevVertex v1 = load_vertex(sc.vertices + g.vertexOffset + tri[1]);
+        const DevVertex v2 = load_vertex(sc.vertices + g.vertexOffset + tri[2]);
+        const f3 p0(v0.px, v0.py, v0.pz), p1(v1.px, v1.py, v1.pz), p2(v2.px, v2.py, v2.pz);
+        const f3 n = cross(p1 - p0, p2 - p0);
+        const float area = 0.5f * len(n);
+        // mean of the emittance at the three vertices (constant texture -> the same value thrice)
+        f3 est = f3(0.0f) + e;
+        est = est + e;
+        est = est + e;
+        est = est / 3.0f;
+        weights[g.distOffset + t] = luminance_srgb(est) * area;
+    }
+}
+
+// Serial exclusive scan of one distribution per thread; writes the integral into the owning table.
+__global__ void k_scan_geom_dists(DevGeomInst* __restrict__ geomInsts, uint32_t numGeomInsts,
+                                  const float* __restrict__ weights, float* __restrict__ cdf) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= numGeomInsts) return;
+    DevGeomInst g = geomInsts[gi];
+    if (g.distOffset == 0xFFFFFFFFu) return;
+    float acc = 0.0f, last = 0.0f, lastW = 0.0f;
+    for (uint32_t i = 0; i < g.distCount; ++i) {
+        const float w = weights[g.distOffset + i];
+        cdf[g.distOffset + i] = acc;
+        last = acc; lastW = w;
+        acc += w;
+    }
+    geomInsts[gi].distIntegral = g.distCount ? last + lastW : 0.0f;   // CDF[n-1] + w[n-1]
+}
+
+__global__ void k_inst_geom_dists(DevInstance* __restrict__ insts, uint32_t numInsts,
+                                  const DevGeomInst* __restrict__ geomInsts, const uint32_t* __restrict__ slotPool,
+                                  float* __restrict__ weights, float* __restrict__ cdf) {
+    const uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ii >= numInsts) return;
+    DevInstance* inst = insts + ii;
+    if (inst->distOffset == 0xFFFFFFFFu) { inst->distIntegral = 0.0f; return; }
+    float acc = 0.0f, last = 0.0f, lastW = 0.0f;
+    for (uint32_t i = 0; i < inst->numGeomInsts; ++i) {
+        const float w = geomInsts[slotPool[inst->slotsOffset + i]].distIntegral;   // compute_light_probs.cu:86-93
+        weights[inst->distOffset + i] = w;
+        cdf[inst->distOffset + i] = acc;
+        last = acc; lastW = w;
+        acc += w;
+    }
+    inst->distIntegral = inst->numGeomInsts ? last + lastW : 0.0f;
+}
+
+__global__ void k_inst_importance(const DevInstance* __restrict__ insts, uint32_t numInsts, uint32_t off, float* __restrict__ weights) {
+    const uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ii >= numInsts) return;
+    const DevInstance* inst = insts + ii;
+    // Matrix4x4::decompose: scale.x = length of column 0 (common/basic_types.h:4643-4646)
+    const float sx = sqrtf(inst->transform[0] * inst->transform[0] + inst->transform[4] * inst->transform[4] +
+                           inst->transform[8] * inst->transform[8]);
+    weights[off + ii] = sq(sx) * inst->distIntegral;
+}
+
+__global__ void k_scan_inst_dist(uint32_t numInsts, uint32_t off, const float* __restrict__ weights, float* __restrict__ cdf,
+                                 float* __restrict__ integralOut) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float acc = 0.0f, last = 0.0f, lastW = 0.0f;
+    for (uint32_t i = 0; i < numInsts; ++i) {
+        const float w = weights[off + i];
+        cdf[off + i] = acc;
+        last = acc; lastW = w;
+        acc += w;
+    }
+    *integralOut = numInsts ? last + lastW : 0.0f;
+}
+
+void lights_build_static(Context& ctx, hipStream_t stream) {
+    scene_upload(ctx, stream);
+    const uint32_t ng = static_cast<uint32_t>(ctx.geoms.size());
+    const uint32_t ni = static_cast<uint32_t>(ctx.insts.size());
+    if (ng) {
+        uint32_t maxTris = 1;
+        for (const DevGeomInst& g : ctx.hGeomInsts) if (g.distOffset != 0xFFFFFFFFu) maxTris = std::max(maxTris, g.numTriangles);
+        const dim3 grid(std::min<uint32_t>((maxTris + 255) / 256, 64), ng);
+        hipLaunchKernelGGL(k_triangle_importance, grid, dim3(256), 0, stream, ctx.devScene(), ng, ctx.dLightW.as<float>());
+        hipLaunchKernelGGL(k_scan_geom_dists, dim3((ng + 63) / 64), dim3(64), 0, stream,
+                           ctx.dGeomInsts.as<DevGeomInst>(), ng, ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>());
+    }
+    if (ni)
+        hipLaunchKernelGGL(k_inst_geom_dists, dim3((ni + 63) / 64), dim3(64), 0, stream,
+                           ctx.dInsts.as<DevInstance>(), ni, ctx.dGeomInsts.as<DevGeomInst>(), ctx.dSlotPool.as<uint32_t>(),
+                           ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>());
+    GFX_HIP(hipGetLastError());
+    // keep the host mirrors of the integrals current (read by gfx_lights_read and the launch params)
+    GFX_HIP(hipMemcpyAsync(ctx.hGeomInsts.data(), ctx.dGeomInsts.p, sizeof(DevGeomInst) * ng, hipMemcpyDeviceToHost, stream));
+    GFX_HIP(hipMemcpyAsync(ctx.hInsts.data(), ctx.dInsts.p, sizeof(DevInstance) * ni, hipMemcpyDeviceToHost, stream));
+    GFX_HIP(hipStreamSynchronize(stream));
+    ctx.lightsStaticBuilt = true;
+}
+
+void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t /*bufferIndex*/) {
+    if (!ctx.lightsStaticBuilt) lights_build_static(ctx, stream);
+    const uint32_t ni = static_cast<uint32_t>(ctx.insts.size());
+    // The integral stays device resident (like the DiscreteDistribution1D inside the reference's
+    // static launch parameters, restir_di_main.cpp:2303-2309): no host round trip per frame.
+    float* dIntegral = ctx.dLightInstIntegral.as<float>();
+    if (ni) {
+        hipLaunchKernelGGL(k_inst_importance, dim3((ni + 63) / 64), dim3(64), 0, stream,
+                           ctx.dInsts.as<DevInstance>(), ni, ctx.lightInstDistOffset, ctx.dLightW.as<float>());
+        hipLaunchKernelGGL(k_scan_inst_dist, dim3(1), dim3(64), 0, stream, ni, ctx.lightInstDistOffset,
+                           ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>(), dIntegral);
+        GFX_HIP(hipGetLastError());
+    }
+    else GFX_HIP(hipMemsetAsync(dIntegral, 0, sizeof(float), stream));
+}
+
+} // namespace gfx

@@ -1,0 +1,814 @@
+// restir.hip -- the original ReSTIR DI passes as a wavefront pipeline of HIP kernels.
+//
+// The reference runs each pass as one OptiX ray-generation megakernel that traces inline
+// (restir_di/gpu_kernels/optix_gbuffer_kernels.cu, optix_restir_di_kernels.cu).  Here every
+// optixTrace becomes: producer kernel -> dense ray queue (ballot/mbcnt compaction, one atomic per
+// wave) -> trace.hip -> consumer kernel.  Per-pixel arithmetic and RNG draw order are those of the
+// reference, so reservoirs match the CPU restatement bit for bit.
+//
+//   pass (gfx_restir_pass)          kernels
+//   SETUP_GBUFFERS                  k_primary_rays -> trace closest -> k_gbuffer_resolve
+//   INITIAL_RIS / +TEMPORAL_*       k_initial_candidates -> trace any -> k_temporal<mode>
+//   SPATIAL_BIASED                  k_spatial<false>
+//   SPATIAL_UNBIASED                k_spatial<true> (select + emit MIS rays) -> trace any -> k_spatial_mis_finish
+//   SHADING                         k_shade_prepare -> trace any -> k_shade_finish
+#include "internal.h"
+#include "shading.hip.h"
+
+namespace gfx {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kSlotSkipped = 0xFFFFFFFEu;   // SpatialSlot.raySlot: neighbour not evaluated
+
+struct SpatialSlot {            // per (pixel, k): k = 0 self, 1..N neighbours (unbiased MIS denominators)
+    float targetDensity;        // unshadowed target of the selected sample at that pixel
+    uint32_t streamLength;
+    uint32_t raySlot;           // GFX_INVALID_SLOT: no ray needed
+};
+
+struct RestirArgs {
+    DevScene scene;
+    gfx_restir_static_params s;
+    gfx_restir_frame_params f;
+    uint32_t curRes, baseIdx;
+    float4* rayOrg; float4* rayDir;
+    uint32_t* rayCount;
+    uint32_t* pixelRaySlot;
+    const uint32_t* occluded;
+    const gfx_hit* hits;
+    const Bvh8Tri* tris;
+    float4* shadeScratch;
+    SpatialSlot* spatialScratch;
+};
+
+struct Camera { f3 pos; m33 ori; float aspect, fovY; };
+GFX_DEV Camera load_camera(const gfx_camera& c) {
+    Camera r;
+    r.pos = f3(c.position[0], c.position[1], c.position[2]);
+    r.ori.r0 = f3(c.orientation[0], c.orientation[1], c.orientation[2]);
+    r.ori.r1 = f3(c.orientation[3], c.orientation[4], c.orientation[5]);
+    r.ori.r2 = f3(c.orientation[6], c.orientation[7], c.orientation[8]);
+    r.aspect = c.aspect; r.fovY = c.fovY;
+    return r;
+}
+GFX_DEV EnvMap load_env(const gfx_restir_static_params& s) {
+    EnvMap e;
+    e.texels = static_cast<const float4*>(s.envLightTexture);
+    e.rowPDF = static_cast<const float*>(s.envRowPDF); e.rowCDF = static_cast<const float*>(s.envRowCDF);
+    e.topPDF = static_cast<const float*>(s.envTopPDF); e.topCDF = static_cast<const float*>(s.envTopCDF);
+    e.w = s.envWidth; e.h = s.envHeight;
+    return e;
+}
+
+// ---------------------------------------------------------------- reservoir planes
+struct Reservoir {
+    LightSample sample;
+    float sumWeights;
+    uint32_t streamLength;
+    GFX_DEV void reset() {
+        sample.emittance = f3(0.0f); sample.position = f3(0.0f); sample.normal = f3(0.0f); sample.atInfinity = 0;
+        sumWeights = 0; streamLength = 0;
+    }
+    GFX_DEV bool update(const LightSample& s, float weight, float u) {   // restir_di_shared.h:118-125
+        sumWeights += weight;
+        const bool accepted = u < weight / sumWeights;
+        if (accepted) sample = s;
+        ++streamLength;
+        return accepted;
+    }
+};
+GFX_DEV Reservoir load_reservoir(const void* buf, size_t numPixels, size_t p) {
+    const float4* b = static_cast<const float4*>(buf);
+    const float4 a = b[p], c = b[numPixels + p], d = b[2 * numPixels + p];
+    Reservoir r;
+    r.sample.emittance = f3(a.x, a.y, a.z);
+    r.sample.position = f3(a.w, c.x, c.y);
+    r.sample.normal = f3(c.z, c.w, d.x);
+    r.sample.atInfinity = f2bits(d.y) & 1u;
+    r.sumWeights = d.z;
+    r.streamLength = f2bits(d.w);
+    return r;
+}
+GFX_DEV void store_reservoir(void* buf, size_t numPixels, size_t p, const Reservoir& r) {
+    float4* b = static_cast<float4*>(buf);
+    b[p] = make_float4(r.sample.emittance.x, r.sample.emittance.y, r.sample.emittance.z, r.sample.position.x);
+    b[numPixels + p] = make_float4(r.sample.position.y, r.sample.position.z, r.sample.normal.x, r.sample.normal.y);
+    b[2 * numPixels + p] = make_float4(r.sample.normal.z, bits2f(r.sample.atInfinity & 1u), r.sumWeights, bits2f(r.streamLength));
+}
+
+// Dense ray-queue append for the lanes with want == true; every lane of the wave must call it.
+GFX_DEV uint32_t emit_ray(bool want, f3 org, f3 dir, float tmin, float tmax, const RestirArgs& a) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return GFX_INVALID_SLOT;
+    const int lane = threadIdx.x & 63;
+    const int leader = __builtin_ctzll(mask);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(a.rayCount, static_cast<uint32_t>(__popcll(mask)));
+    base = __shfl(base, leader);
+    if (!want) return GFX_INVALID_SLOT;
+    const uint32_t slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+    a.rayOrg[slot] = make_float4(org.x, org.y, org.z, tmin);
+    a.rayDir[slot] = make_float4(dir.x, dir.y, dir.z, tmax);
+    return slot;
+}
+
+// Shading point re-derived from the quantised G-buffer (every pass does this).
+struct ShadingPoint {
+    f3 pos;        // offset ray origin
+    f3 vOutLocal;
+    float dist;
+    Frame frame;
+    Bsdf bsdf;
+};
+// normalizeFirst = false: vOut = cam - p; frontHit from the unnormalised vector; vOut /= |vOut|
+//                         (optix_restir_di_kernels.cu:41-46, 320-325)
+// normalizeFirst = true : vOut = normalize(cam - p); frontHit from the unit vector (:230-232, 574-577)
+GFX_DEV void make_shading_point(const RestirArgs& a, uint32_t bufIdx, size_t p, f3 camPos, bool normalizeFirst, ShadingPoint& sp) {
+    const float4 g2 = static_cast<const float4*>(a.s.gbuffer2[bufIdx])[p];
+    const uint4 g3 = static_cast<const uint4*>(a.s.gbuffer3[bufIdx])[p];
+    f3 pos(g2.x, g2.y, g2.z);
+    const f3 ng = decode_dir(f2bits(g2.w));
+    f3 vOut = camPos - pos;
+    float frontHit;
+    if (normalizeFirst) {
+        vOut = unit(vOut);
+        sp.dist = 0;
+        frontHit = dot(vOut, ng) >= 0.0f ? 1.0f : -1.0f;
+    }
+    else {
+        frontHit = dot(vOut, ng) >= 0.0f ? 1.0f : -1.0f;
+        sp.dist = len(vOut);
+        vOut = vOut / sp.dist;
+    }
+    sp.pos = offset_ray_origin(pos, frontHit * ng);
+    sp.frame = Frame(decode_dir(g3.x), decode_dir(g3.y));
+    sp.vOutLocal = sp.frame.to_local(vOut);
+    sp.bsdf.setup(a.scene.materials[g3.w]);
+}
+
+// restir_di_shared.h:747-771
+GFX_DEV bool test_neighbor(const RestirArgs& a, bool testGeometry, uint32_t nbBuf, int nx, int ny, float dist, f3 normal, f3 camPos) {
+    if (nx < 0 || nx >= a.s.imageSizeX || ny < 0 || ny >= a.s.imageSizeY) return false;
+    const size_t np = static_cast<size_t>(ny) * a.s.imageSizeX + nx;
+    const uint32_t nbInst = static_cast<const uint4*>(a.s.gbuffer0[nbBuf])[np].x;
+    if (nbInst == 0xFFFFFFFFu) return false;
+    if (testGeometry) {
+        const float4 g2 = static_cast<const float4*>(a.s.gbuffer2[nbBuf])[np];
+        const uint32_t qn = static_cast<const uint4*>(a.s.gbuffer3[nbBuf])[np].x;
+        const f3 nbNormal = decode_dir(qn);
+        const float nbDist = len(camPos - f3(g2.x, g2.y, g2.z));
+        if (fabsf(nbDist - dist) / dist > 0.1f || dot(normal, nbNormal) < 0.9f) return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- SETUP_GBUFFERS
+// ray generation of optix_gbuffer_kernels.cu:5-27
+__global__ __launch_bounds__(kBlock) void k_primary_rays(RestirArgs a) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= numPixels) return;
+    const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
+    const Camera cam = load_camera(a.f.camera);
+    float jx = 0.5f, jy = 0.5f;
+    if (a.f.enableJittering) {
+        uint64_t* rngBuf = static_cast<uint64_t*>(a.s.rngBuffer);
+        Pcg32 rng; rng.state = rngBuf[p];
+        jx = rng.uniform();
+        jy = rng.uniform();
+        rngBuf[p] = rng.state;
+    }
+    const float fx = (x + jx) / a.s.imageSizeX;
+    const float fy = (y + jy) / a.s.imageSizeY;
+    const float vh = 2 * gm_tan(cam.fovY * 0.5f);
+    const float vw = cam.aspect * vh;
+    const f3 dir = unit(mul(cam.ori, f3(vw * (0.5f - fx), vh * (0.5f - fy), 1)));
+    a.rayOrg[p] = make_float4(cam.pos.x, cam.pos.y, cam.pos.z, 0.0f);
+    a.rayDir[p] = make_float4(dir.x, dir.y, dir.z, 3.402823466e+38f);
+}
+
+// PerspectiveCamera::calcScreenPosition, restir_di_shared.h:51-59
+GFX_DEV void calc_screen_position(const Camera& cam, f3 pw, float& sx, float& sy) {
+    const m33 invOri = inverse(cam.ori);
+    const f3 pv = mul(invOri, pw - cam.pos);
+    const float ax = pv.x / pv.z, ay = pv.y / pv.z;
+    const float h = 2 * gm_tan(cam.fovY / 2);
+    const float w = cam.aspect * h;
+    sx = 1 - (ax + 0.5f * w) / w;
+    sy = 1 - (ay + 0.5f * h) / h;
+}
+
+// closest-hit / miss programs + the tail of the ray-generation program (optix_gbuffer_kernels.cu:56-243)
+__global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= numPixels) return;
+    const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
+    const uint32_t bufIdx = a.f.bufferIndex;
+    const gfx_hit h = a.hits[p];
+    const float4 rd = a.rayDir[p];
+    const f3 direction(rd.x, rd.y, rd.z);
+
+    f3 albedo(0.0f);
+    const float qnan = bits2f(0x7FC00000u);
+    f3 positionInWorld(qnan), prevPositionInWorld(qnan), shadingNormalInWorld(qnan);
+    uint32_t qGeomNormal = 0, qTangent = 0, qTexCoord = 0;
+    uint32_t matSlot = 0xFFFFFFFFu, instSlot = 0xFFFFFFFFu, geomInstSlot = 0xFFFFFFFFu, primIndex = 0xFFFFFFFFu;
+    uint32_t qbcB = 0, qbcC = 0;
+
+    if (h.triIndex != GFX_INVALID_SLOT) {
+        const Bvh8Tri* tr = a.tris + h.triIndex;
+        instSlot = tr->instSlot; geomInstSlot = tr->geomInstSlot; primIndex = tr->primIndex;
+        const DevInstance* inst = a.scene.insts + instSlot;
+        const DevGeomInst g = a.scene.geomInsts[geomInstSlot];
+        matSlot = g.materialSlot;
+        const uint32_t* tri = a.scene.triangles + 3ull * (g.triangleOffset + primIndex);
+        const DevVertex vA = load_vertex(a.scene.vertices + g.vertexOffset + tri[0]);
+        const DevVertex vB = load_vertex(a.scene.vertices + g.vertexOffset + tri[1]);
+        const DevVertex vC = load_vertex(a.scene.vertices + g.vertexOffset + tri[2]);
+        const float bcB = h.bcB, bcC = h.bcC;
+        const float bcA = 1 - (bcB + bcC);
+        qbcB = encode_bc(bcB);
+        qbcC = encode_bc(bcC);
+        const f3 pAo(vA.px, vA.py, vA.pz), pBo(vB.px, vB.py, vB.pz), pCo(vC.px, vC.py, vC.pz);
+        const f3 positionInObj = bcA * pAo + bcB * pBo + bcC * pCo;
+        const f3 shadingNormalInObj = bcA * f3(vA.nx, vA.ny, vA.nz) + bcB * f3(vB.nx, vB.ny, vB.nz) + bcC * f3(vC.nx, vC.ny, vC.nz);
+        const f3 tc0DirInObj = bcA * f3(vA.tx, vA.ty, vA.tz) + bcB * f3(vB.tx, vB.ty, vB.tz) + bcC * f3(vC.tx, vC.ty, vC.tz);
+        const float tu = bcA * vA.u + bcB * vB.u + bcC * vC.u;
+        const float tv = bcA * vA.v + bcB * vB.v + bcC * vC.v;
+        const f3 geomNormalInObj = cross(pBo - pAo, pCo - pAo);
+        const m34 xfm = load_m34(inst->transform);
+        const m33 nrm = load_m33(inst->normalMatrix);
+        positionInWorld = xfm_point(xfm, positionInObj);
+        prevPositionInWorld = xfm_point(load_m34(inst->curToPrevTransform), positionInWorld);
+        f3 geomNormalInWorld = unit(mul(nrm, geomNormalInObj));
+        shadingNormalInWorld = unit(mul(nrm, shadingNormalInObj));
+        f3 tc0DirInWorld = xfm_vector(xfm, tc0DirInObj);
+        tc0DirInWorld = unit(tc0DirInWorld - dot(shadingNormalInWorld, tc0DirInWorld) * shadingNormalInWorld);
+        if (!all_finite(shadingNormalInWorld)) {
+            geomNormalInWorld = f3(0, 0, 1);
+            shadingNormalInWorld = f3(0, 0, 1);
+            tc0DirInWorld = f3(1, 0, 0);
+        }
+        qGeomNormal = encode_dir(geomNormalInWorld);
+        qTexCoord = encode_uv(tu, tv);
+        Bsdf bsdf; bsdf.setup(a.scene.materials[matSlot]);
+        const Frame frame(shadingNormalInWorld, tc0DirInWorld);
+        const f3 vOutLocal = frame.to_local(unit(-direction));
+        qTangent = encode_dir(frame.t);
+        albedo = bsdf.dh_reflectance_estimate(vOutLocal);
+    }
+    else {
+        const f3 vOut = -direction;
+        const f3 pp = -vOut;
+        float posPhi, posTheta;
+        to_polar_yup(pp, posPhi, posTheta);
+        const float phi = posPhi + a.f.envLightRotation;
+        float u = phi / (2 * kPi);
+        u -= floorf(u);
+        const float v = posTheta / kPi;
+        positionInWorld = pp;
+        prevPositionInWorld = pp;
+        qGeomNormal = encode_dir(vOut);
+        shadingNormalInWorld = vOut;
+        qTangent = encode_dir(f3(-gm_cos(posPhi), 0, -gm_sin(posPhi)));
+        qTexCoord = encode_uv(u, v);
+        qbcB = encode_bc(u);
+        qbcC = encode_bc(v);
+    }
+
+    const Camera prevCam = load_camera(a.f.prevCamera);
+    float sx, sy;
+    calc_screen_position(prevCam, prevPositionInWorld, sx, sy);
+    float mvx = (x + 0.5f) - sx * a.s.imageSizeX;
+    float mvy = (y + 0.5f) - sy * a.s.imageSizeY;
+    if (a.f.resetFlowBuffer || prevPositionInWorld.x != prevPositionInWorld.x) { mvx = 0.0f; mvy = 0.0f; }
+
+    static_cast<uint4*>(a.s.gbuffer0[bufIdx])[p] = make_uint4(instSlot, geomInstSlot, primIndex, qbcB | (qbcC << 16));
+    static_cast<float2*>(a.s.gbuffer1[bufIdx])[p] = make_float2(mvx, mvy);
+    static_cast<float4*>(a.s.gbuffer2[bufIdx])[p] = make_float4(positionInWorld.x, positionInWorld.y, positionInWorld.z, bits2f(qGeomNormal));
+    static_cast<uint4*>(a.s.gbuffer3[bufIdx])[p] = make_uint4(encode_dir(shadingNormalInWorld), qTangent, qTexCoord, matSlot);
+
+    float4* albedoAcc = static_cast<float4*>(a.s.albedoAccumBuffer) + p;
+    float4* normalAcc = static_cast<float4*>(a.s.normalAccumBuffer) + p;
+    f3 prevAlbedo(0.0f), prevNormal(0.0f);
+    if (a.f.numAccumFrames > 0) {
+        const float4 pa = *albedoAcc, pn = *normalAcc;
+        prevAlbedo = f3(pa.x, pa.y, pa.z);
+        prevNormal = f3(pn.x, pn.y, pn.z);
+    }
+    const float curWeight = 1.0f / (1 + a.f.numAccumFrames);
+    const f3 albedoResult = (1 - curWeight) * prevAlbedo + curWeight * albedo;
+    const f3 normalResult = (1 - curWeight) * prevNormal + curWeight * shadingNormalInWorld;
+    *albedoAcc = make_float4(albedoResult.x, albedoResult.y, albedoResult.z, 1.0f);
+    *normalAcc = make_float4(normalResult.x, normalResult.y, normalResult.z, 1.0f);
+}
+
+// ---------------------------------------------------------------- INITIAL (+ TEMPORAL)
+// candidate loop + visibility-ray emission: optix_restir_di_kernels.cu:57-133
+__global__ __launch_bounds__(kBlock) void k_initial_candidates(RestirArgs a) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const uint32_t bufIdx = a.f.bufferIndex;
+    bool surface = false;
+    if (p < numPixels) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
+
+    bool wantRay = false;
+    f3 rayO(0.0f), rayD(0.0f);
+    float rayTmax = 0;
+    if (surface) {
+        const Camera cam = load_camera(a.f.camera);
+        const EnvMap env = load_env(a.s);
+        const bool envEnabled = env.present() && a.f.enableEnvLight;
+        ShadingPoint sp;
+        make_shading_point(a, bufIdx, p, cam.pos, false, sp);
+        uint64_t* rngBuf = static_cast<uint64_t*>(a.s.rngBuffer);
+        Pcg32 rng; rng.state = rngBuf[p];
+
+        Reservoir reservoir;
+        reservoir.reset();
+        float selectedTarget = 0.0f;
+        const uint32_t numCandidates = 1u << a.f.log2NumCandidateSamples;
+        for (uint32_t i = 0; i < numCandidates; ++i) {
+            float ul = rng.uniform();
+            float probCurType = 1.0f;
+            bool sampleEnv = false;
+            if (envEnabled) {
+                if (*a.scene.lightInstIntegral > 0.0f) {
+                    const float prob = fmin2(fmax2(0.25f * numCandidates - i, 0.0f), 1.0f);
+                    if (ul < prob) { probCurType = 0.25f; ul = ul / prob; sampleEnv = true; }
+                    else { probCurType = 1.0f - 0.25f; ul = (ul - prob) / (1 - prob); }
+                }
+                else sampleEnv = true;
+            }
+            LightSample ls;
+            ls.emittance = f3(0.0f); ls.position = f3(0.0f); ls.normal = f3(0.0f); ls.atInfinity = 0;
+            float pd;
+            const float u0 = rng.uniform();
+            const float u1 = rng.uniform();
+            sample_light(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
+            const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
+            pd *= probCurType;
+            const float target = target_weight(cont);
+            const float weight = target / pd;
+            if (reservoir.update(ls, weight, rng.uniform())) selectedTarget = target;
+        }
+        float recPDF = reservoir.sumWeights / (selectedTarget * reservoir.streamLength);
+        if (!is_finite(recPDF)) { recPDF = 0.0f; selectedTarget = 0.0f; }
+
+        if (a.f.reuseVisibility && selectedTarget > 0.0f) {
+            const ShadowRay sr = shadow_ray(sp.pos, reservoir.sample);
+            wantRay = true; rayO = sp.pos; rayD = sr.dir; rayTmax = sr.tmax;
+        }
+        rngBuf[p] = rng.state;
+        store_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p, reservoir);
+        static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes])[p] = make_float2(recPDF, selectedTarget);
+    }
+    const uint32_t slot = emit_ray(wantRay, rayO, rayD, 0.0f, rayTmax, a);
+    if (p < numPixels) a.pixelRaySlot[p] = slot;
+}
+
+// visibility application + temporal reuse: optix_restir_di_kernels.cu:128-286
+// MODE 0: performInitialRIS, 1: ...TemporalRISBiased, 2: ...TemporalRISUnbiased
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_temporal(RestirArgs a) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= numPixels) return;
+    const uint32_t bufIdx = a.f.bufferIndex;
+    if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x == 0xFFFFFFFFu) return;
+    const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
+
+    float2* infoBuf = static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes]);
+    float2 info = infoBuf[p];
+    float recPDF = info.x, selectedTarget = info.y;
+    const uint32_t slot = a.pixelRaySlot[p];
+    if (slot != GFX_INVALID_SLOT && a.occluded[slot]) { recPDF = 0.0f; selectedTarget = 0.0f; }
+    if (MODE == 0) {
+        infoBuf[p] = make_float2(recPDF, selectedTarget);
+        return;
+    }
+    constexpr bool unbiased = MODE == 2;
+    const Camera cam = load_camera(a.f.camera);
+    ShadingPoint sp;
+    make_shading_point(a, bufIdx, p, cam.pos, false, sp);
+    uint64_t* rngBuf = static_cast<uint64_t*>(a.s.rngBuffer);
+    Pcg32 rng; rng.state = rngBuf[p];
+    Reservoir reservoir = load_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p);
+
+    const uint32_t prevBuf = (bufIdx + 1) % 2;
+    const uint32_t prevRes = (a.curRes + 1) % 2;
+    bool neighborIsSelected = false;
+    const uint32_t selfStreamLength = reservoir.streamLength;
+    if (recPDF == 0.0f) reservoir.reset();
+    uint32_t combinedStreamLength = selfStreamLength;
+    const uint32_t maxPrevStreamLength = 20 * selfStreamLength;
+    const float2 mv = static_cast<const float2*>(a.s.gbuffer1[bufIdx])[p];
+    const int nbx = f2i_sat(x + 0.5f - mv.x);
+    const int nby = f2i_sat(y + 0.5f - mv.y);
+    const bool accepted = test_neighbor(a, !unbiased, prevBuf, nbx, nby, sp.dist, sp.frame.n, cam.pos);
+    size_t np = 0;
+    Reservoir neighbor;
+    if (accepted) {
+        np = static_cast<size_t>(nby) * a.s.imageSizeX + nbx;
+        neighbor = load_reservoir(a.s.reservoirBuffer[prevRes], numPixels, np);
+        const float2 nbInfo = static_cast<const float2*>(a.s.reservoirInfoBuffer[prevRes])[np];
+        const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, neighbor.sample);
+        const float target = target_weight(cont);
+        const uint32_t nbStreamLength = min(neighbor.streamLength, maxPrevStreamLength);
+        const float weight = target * nbInfo.x * nbStreamLength;
+        if (reservoir.update(neighbor.sample, weight, rng.uniform())) {
+            selectedTarget = target;
+            if (unbiased) neighborIsSelected = true;
+        }
+        combinedStreamLength += nbStreamLength;
+    }
+    reservoir.streamLength = combinedStreamLength;
+
+    float weightForEstimate;
+    if (unbiased) {
+        const LightSample selected = reservoir.sample;
+        float numWeight, denomWeight;
+        {
+            const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, selected);
+            const float targetSelf = target_weight(cont);
+            numWeight = targetSelf;                          // useMIS_RIS = true (:10, 210-213)
+            denomWeight = targetSelf * selfStreamLength;
+        }
+        if (accepted) {
+            const Camera prevCam = load_camera(a.f.prevCamera);
+            ShadingPoint nsp;
+            make_shading_point(a, prevBuf, np, prevCam.pos, true, nsp);
+            const f3 cont = direct_lighting(nsp.pos, nsp.vOutLocal, nsp.frame, nsp.bsdf, selected);
+            const float nbTarget = target_weight(cont);
+            const uint32_t nbStreamLength = min(neighbor.streamLength, maxPrevStreamLength);
+            denomWeight += nbTarget * nbStreamLength;
+            if (neighborIsSelected) numWeight = nbTarget;
+        }
+        weightForEstimate = numWeight / denomWeight;
+    }
+    else weightForEstimate = 1.0f / reservoir.streamLength;
+
+    recPDF = weightForEstimate * reservoir.sumWeights / selectedTarget;
+    if (!is_finite(recPDF)) { recPDF = 0.0f; selectedTarget = 0.0f; }
+
+    rngBuf[p] = rng.state;
+    store_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p, reservoir);
+    infoBuf[p] = make_float2(recPDF, selectedTarget);
+}
+
+// ---------------------------------------------------------------- SPATIAL
+GFX_DEV void spatial_neighbor(const RestirArgs& a, Pcg32& rng, uint32_t nIdx, int x, int y, int& nbx, int& nby) {
+    float radius = a.f.spatialNeighborRadius;
+    float dx, dy;
+    if (a.f.useLowDiscrepancyNeighbors) {
+        const float2 d = static_cast<const float2*>(a.s.spatialNeighborDeltas)[(a.baseIdx + nIdx) % 1024];
+        dx = radius * d.x;
+        dy = radius * d.y;
+    }
+    else {
+        radius *= sqrtf(rng.uniform());
+        const float angle = 2 * kPi * rng.uniform();
+        float s, c;
+        gm_sincos(angle, s, c);
+        dx = radius * c;
+        dy = radius * s;
+    }
+    nbx = f2i_sat(x + 0.5f + dx);
+    nby = f2i_sat(y + 0.5f + dy);
+}
+
+// optix_restir_di_kernels.cu:303-547.  UNBIASED: combines, then emits the MIS-denominator rays.
+template <bool UNBIASED>
+__global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const uint32_t bufIdx = a.f.bufferIndex;
+    const uint32_t numNb = a.f.numSpatialNeighbors;
+    bool surface = false;
+    if (p < numPixels) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
+    const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
+    const uint32_t srcRes = a.curRes, dstRes = (a.curRes + 1) % 2;
+    const Camera cam = load_camera(a.f.camera);
+
+    ShadingPoint sp;
+    Pcg32 rng; rng.state = 0;
+    Reservoir combined;
+    combined.reset();
+    float selectedTarget = 0.0f;
+    int32_t selectedNeighborIndex = -1;
+    uint32_t selfStreamLength = 0;
+    uint64_t* rngBuf = static_cast<uint64_t*>(a.s.rngBuffer);
+    if (surface) {
+        make_shading_point(a, bufIdx, p, cam.pos, false, sp);
+        rng.state = rngBuf[p];
+        const Reservoir self = load_reservoir(a.s.reservoirBuffer[srcRes], numPixels, p);
+        const float2 selfInfo = static_cast<const float2*>(a.s.reservoirInfoBuffer[srcRes])[p];
+        if (selfInfo.x > 0.0f) { combined = self; selectedTarget = selfInfo.y; }
+        selfStreamLength = self.streamLength;
+        uint32_t combinedStreamLength = self.streamLength;
+        for (uint32_t nIdx = 0; nIdx < numNb; ++nIdx) {
+            int nbx, nby;
+            spatial_neighbor(a, rng, nIdx, x, y, nbx, nby);
+            const bool accepted = test_neighbor(a, !UNBIASED, bufIdx, nbx, nby, sp.dist, sp.frame.n, cam.pos) && (nbx != x || nby != y);
+            if (accepted) {
+                const size_t np = static_cast<size_t>(nby) * a.s.imageSizeX + nbx;
+                const Reservoir neighbor = load_reservoir(a.s.reservoirBuffer[srcRes], numPixels, np);
+                const float2 nbInfo = static_cast<const float2*>(a.s.reservoirInfoBuffer[srcRes])[np];
+                const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, neighbor.sample);
+                const float target = target_weight(cont);
+                const uint32_t nbStreamLength = neighbor.streamLength;
+                const float weight = target * nbInfo.x * nbStreamLength;
+                if (combined.update(neighbor.sample, weight, rng.uniform())) {
+                    selectedTarget = target;
+                    if (UNBIASED) selectedNeighborIndex = static_cast<int32_t>(nIdx);
+                }
+                combinedStreamLength += nbStreamLength;
+            }
+        }
+        combined.streamLength = combinedStreamLength;
+    }
+
+    if (!UNBIASED) {
+        if (!surface) return;
+        const float weightForEstimate = 1.0f / combined.streamLength;
+        float recPDF = weightForEstimate * combined.sumWeights / selectedTarget;
+        float target = selectedTarget;
+        if (!is_finite(recPDF)) { recPDF = 0.0f; target = 0.0f; }
+        rngBuf[p] = rng.state;
+        store_reservoir(a.s.reservoirBuffer[dstRes], numPixels, p, combined);
+        static_cast<float2*>(a.s.reservoirInfoBuffer[dstRes])[p] = make_float2(recPDF, target);
+        return;
+    }
+
+    // ---- unbiased: targets of the selected sample at self and at every neighbour, rays where needed
+    const bool needMis = surface && selectedTarget > 0.0f;
+    const LightSample selected = combined.sample;
+    SpatialSlot* slots = a.spatialScratch + (p < numPixels ? p * (numNb + 1) : 0);
+    {
+        float targetSelf = 0.0f;
+        bool want = false;
+        f3 ro(0.0f), rd(0.0f); float tmax = 0;
+        if (needMis) {
+            const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, selected);
+            targetSelf = target_weight(cont);
+            if (a.f.reuseVisibility && targetSelf > 0.0f) {
+                const ShadowRay sr = shadow_ray(sp.pos, selected);
+                want = true; ro = sp.pos; rd = sr.dir; tmax = sr.tmax;
+            }
+        }
+        const uint32_t slot = emit_ray(want, ro, rd, 0.0f, tmax, a);
+        if (p < numPixels) { SpatialSlot s; s.targetDensity = targetSelf; s.streamLength = selfStreamLength; s.raySlot = slot; slots[0] = s; }
+    }
+    const Camera prevCam = load_camera(a.f.prevCamera);
+    for (uint32_t nIdx = 0; nIdx < numNb; ++nIdx) {
+        float nbTarget = 0.0f;
+        uint32_t nbStreamLength = 0;
+        bool want = false, evaluated = false;
+        f3 ro(0.0f), rd(0.0f); float tmax = 0;
+        if (needMis) {
+            int nbx, nby;
+            spatial_neighbor(a, rng, nIdx, x, y, nbx, nby);
+            const bool accepted = (nbx >= 0 && nbx < a.s.imageSizeX && nby >= 0 && nby < a.s.imageSizeY) && (nbx != x || nby != y);
+            if (accepted) {
+                const size_t np = static_cast<size_t>(nby) * a.s.imageSizeX + nbx;
+                if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[np].x != 0xFFFFFFFFu) {
+                    ShadingPoint nsp;
+                    make_shading_point(a, bufIdx, np, prevCam.pos, true, nsp);   // prevCamera as in the reference (:487)
+                    const Reservoir neighbor = load_reservoir(a.s.reservoirBuffer[srcRes], numPixels, np);
+                    const f3 cont = direct_lighting(nsp.pos, nsp.vOutLocal, nsp.frame, nsp.bsdf, selected);
+                    nbTarget = target_weight(cont);
+                    nbStreamLength = neighbor.streamLength;
+                    evaluated = true;
+                    if (a.f.reuseVisibility && nbTarget > 0.0f) {
+                        const ShadowRay sr = shadow_ray(nsp.pos, selected);
+                        want = true; ro = nsp.pos; rd = sr.dir; tmax = sr.tmax;
+                    }
+                }
+            }
+        }
+        uint32_t slot = emit_ray(want, ro, rd, 0.0f, tmax, a);
+        if (!evaluated) slot = kSlotSkipped;   // out of bounds / self / background: the reference `continue`s
+        if (p < numPixels) { SpatialSlot s; s.targetDensity = nbTarget; s.streamLength = nbStreamLength; s.raySlot = slot; slots[1 + nIdx] = s; }
+    }
+    if (!surface) return;
+    rngBuf[p] = rng.state;
+    store_reservoir(a.s.reservoirBuffer[dstRes], numPixels, p, combined);
+    // stash (selectedNeighborIndex, selectedTarget) for the finishing kernel
+    static_cast<float2*>(a.s.reservoirInfoBuffer[dstRes])[p] = make_float2(bits2f(static_cast<uint32_t>(selectedNeighborIndex)), selectedTarget);
+}
+
+// MIS weights of the unbiased spatial pass once the rays are back: optix_restir_di_kernels.cu:413-546
+__global__ __launch_bounds__(kBlock) void k_spatial_mis_finish(RestirArgs a) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= numPixels) return;
+    const uint32_t bufIdx = a.f.bufferIndex;
+    if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x == 0xFFFFFFFFu) return;
+    const uint32_t numNb = a.f.numSpatialNeighbors;
+    const uint32_t dstRes = (a.curRes + 1) % 2;
+    float2* infoBuf = static_cast<float2*>(a.s.reservoirInfoBuffer[dstRes]);
+    const float2 stash = infoBuf[p];
+    const int32_t selectedNeighborIndex = static_cast<int32_t>(f2bits(stash.x));
+    const float selectedTarget = stash.y;
+    const float sumWeights = static_cast<const float4*>(a.s.reservoirBuffer[dstRes])[2 * numPixels + p].z;
+    const SpatialSlot* slots = a.spatialScratch + p * (numNb + 1);
+
+    float weightForEstimate = 0.0f;
+    if (selectedTarget > 0.0f) {
+        bool visibility = true;
+        float numWeight, denomWeight;
+        {
+            const SpatialSlot s = slots[0];
+            float targetSelf = s.targetDensity;
+            if (s.raySlot != GFX_INVALID_SLOT && a.occluded[s.raySlot]) targetSelf = 0.0f;
+            if (a.f.reuseVisibility) visibility = targetSelf > 0.0f;
+            numWeight = targetSelf;
+            denomWeight = targetSelf * s.streamLength;
+        }
+        for (uint32_t nIdx = 0; nIdx < numNb; ++nIdx) {
+            const SpatialSlot s = slots[1 + nIdx];
+            if (s.raySlot == kSlotSkipped) continue;
+            float nbTarget = s.targetDensity;
+            if (s.raySlot != GFX_INVALID_SLOT && a.occluded[s.raySlot]) nbTarget = 0.0f;
+            denomWeight += nbTarget * s.streamLength;
+            if (static_cast<int32_t>(nIdx) == selectedNeighborIndex) numWeight = nbTarget;
+        }
+        weightForEstimate = numWeight / denomWeight;
+        if (a.f.reuseVisibility && !visibility) weightForEstimate = 0.0f;
+    }
+    float recPDF = weightForEstimate * sumWeights / selectedTarget;
+    float target = selectedTarget;
+    if (!is_finite(recPDF)) { recPDF = 0.0f; target = 0.0f; }
+    infoBuf[p] = make_float2(recPDF, target);
+}
+
+// ---------------------------------------------------------------- SHADING
+// optix_restir_di_kernels.cu:559-629 up to the final shadow ray
+__global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const uint32_t bufIdx = a.f.bufferIndex;
+    bool want = false;
+    f3 ro(0.0f), rd(0.0f); float tmax = 0;
+    f3 contribution(0.01f, 0.01f, 0.01f);
+    f3 direct(0.0f);
+    float recPDF = 0.0f;
+    if (p < numPixels) {
+        const uint32_t instSlot = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x;
+        const uint4 g3 = static_cast<const uint4*>(a.s.gbuffer3[bufIdx])[p];
+        if (instSlot != 0xFFFFFFFFu) {
+            const Camera cam = load_camera(a.f.camera);
+            ShadingPoint sp;
+            make_shading_point(a, bufIdx, p, cam.pos, true, sp);
+            const gfx_material& mat = a.scene.materials[g3.w];
+            const Reservoir reservoir = load_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p);
+            recPDF = static_cast<const float2*>(a.s.reservoirInfoBuffer[a.curRes])[p].x;
+            contribution = f3(0.0f);
+            if (sp.vOutLocal.z > 0) {
+                f3 e(0.0f);
+                if (mat.hasEmittance) e = f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+                contribution = contribution + e / kPi;
+            }
+            if (recPDF > 0 && is_finite(recPDF)) {
+                const bool visDone = a.f.reuseVisibility && (!a.f.enableTemporalReuse || (a.f.enableSpatialReuse && a.f.useUnbiasedEstimator));
+                direct = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, reservoir.sample);
+                if (!visDone) {
+                    // performDirectLighting<.., true> traces unconditionally; the result only matters
+                    // when the unshadowed term is non-zero
+                    if (direct.x != 0.0f || direct.y != 0.0f || direct.z != 0.0f) {
+                        const ShadowRay sr = shadow_ray(sp.pos, reservoir.sample);
+                        want = true; ro = sp.pos; rd = sr.dir; tmax = sr.tmax;
+                    }
+                }
+            }
+        }
+        else {
+            const EnvMap env = load_env(a.s);
+            if (env.present() && a.f.enableEnvLight) {
+                const float u = (g3.z & 0xFFFF) / 65535.0f, v = (g3.z >> 16) / 65535.0f;
+                contribution = a.f.envLightPowerCoeff * env.fetch(u, v);
+            }
+        }
+    }
+    const uint32_t slot = emit_ray(want, ro, rd, 0.0f, tmax, a);
+    if (p < numPixels) {
+        a.shadeScratch[2 * p] = make_float4(contribution.x, contribution.y, contribution.z, bits2f(slot));
+        a.shadeScratch[2 * p + 1] = make_float4(direct.x, direct.y, direct.z, recPDF);
+    }
+}
+
+// contribution += recPDFEstimate * directCont; running mean (optix_restir_di_kernels.cu:619-636)
+__global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= numPixels) return;
+    const float4 c0 = a.shadeScratch[2 * p], c1 = a.shadeScratch[2 * p + 1];
+    f3 contribution(c0.x, c0.y, c0.z);
+    const uint32_t bufIdx = a.f.bufferIndex;
+    if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu) {
+        f3 direct(c1.x, c1.y, c1.z);
+        const uint32_t slot = f2bits(c0.w);
+        if (slot != GFX_INVALID_SLOT && a.occluded[slot]) direct = f3(0.0f);
+        contribution = contribution + c1.w * direct;
+    }
+    float4* beauty = static_cast<float4*>(a.s.beautyAccumBuffer) + p;
+    f3 prev(0.0f);
+    if (a.f.numAccumFrames > 0) { const float4 b = *beauty; prev = f3(b.x, b.y, b.z); }
+    const float curWeight = 1.0f / (1 + a.f.numAccumFrames);
+    const f3 result = (1 - curWeight) * prev + curWeight * contribution;
+    *beauty = make_float4(result.x, result.y, result.z, 1.0f);
+}
+
+// ---------------------------------------------------------------- host sequencing
+static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height) {
+    const RestirParams& rp = ctx.restir;
+    if (!rp.valid) throw HipError("gfx_restir_launch: gfx_restir_set_params has not been called");
+    if (static_cast<uint32_t>(rp.s.imageSizeX) != width || static_cast<uint32_t>(rp.s.imageSizeY) != height)
+        throw HipError("gfx_restir_launch: launch size differs from imageSize in the static parameters");
+    const uint64_t h = rp.f.travHandle;
+    if (h == 0 || h > ctx.accels.size() || !ctx.accels[h - 1]) throw HipError("gfx_restir_launch: invalid travHandle");
+    const size_t numPixels = static_cast<size_t>(width) * height;
+    const size_t maxRays = numPixels * (1 + rp.f.numSpatialNeighbors);
+    ctx.rayOrg.reserve(16 * maxRays); ctx.rayDir.reserve(16 * maxRays);
+    ctx.rayOut.reserve(4 * maxRays);
+    ctx.rayHits.reserve(sizeof(gfx_hit) * numPixels);
+    ctx.pixelRaySlot.reserve(4 * numPixels);
+    ctx.shadeScratch.reserve(32 * numPixels);
+    ctx.spatialScratch.reserve(sizeof(SpatialSlot) * maxRays);
+    ctx.smallCounters.reserve(256);
+    RestirArgs a;
+    a.scene = ctx.devScene();
+    a.s = rp.s; a.f = rp.f;
+    a.curRes = rp.currentReservoirIndex & 1u;
+    a.baseIdx = rp.spatialNeighborBaseIndex & 1023u;   // 10-bit bitfield (restir_di_shared.h:287)
+    a.rayOrg = ctx.rayOrg.as<float4>(); a.rayDir = ctx.rayDir.as<float4>();
+    a.rayCount = ctx.smallCounters.as<uint32_t>() + 4;
+    a.pixelRaySlot = ctx.pixelRaySlot.as<uint32_t>();
+    a.occluded = ctx.rayOut.as<uint32_t>();
+    a.hits = ctx.rayHits.as<gfx_hit>();
+    a.tris = ctx.accels[h - 1]->tris.as<Bvh8Tri>();
+    a.shadeScratch = ctx.shadeScratch.as<float4>();
+    a.spatialScratch = ctx.spatialScratch.as<SpatialSlot>();
+    return a;
+}
+
+template <typename K>
+static void launch_pixels(Context& ctx, hipStream_t stream, const char* name, K kernel, const RestirArgs& a) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const uint32_t grid = static_cast<uint32_t>((numPixels + kBlock - 1) / kBlock);
+    ScopedKernelTimer timer(ctx, stream, name);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+    GFX_HIP(hipGetLastError());
+}
+
+static void trace_queue(Context& ctx, hipStream_t stream, const RestirArgs& a, int mode, uint32_t fixedCount, bool useCounter, void* out) {
+    TraceLaunch t;
+    t.accel = ctx.accels[ctx.restir.f.travHandle - 1]->dev();
+    t.rayOrgTmin = a.rayOrg; t.rayDirTmax = a.rayDir;
+    t.numRays = fixedCount; t.numRaysPtr = useCounter ? a.rayCount : nullptr;
+    t.out = out; t.mode = mode;
+    trace_launch(ctx, stream, t);
+}
+
+void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height) {
+    RestirArgs a = make_args(ctx, width, height);
+    const uint32_t numPixels = width * height;
+    auto reset_queue = [&]() { GFX_HIP(hipMemsetAsync(a.rayCount, 0, sizeof(uint32_t), stream)); };
+    switch (pass) {
+    case GFX_RESTIR_SETUP_GBUFFERS:
+        launch_pixels(ctx, stream, "primary_rays", k_primary_rays, a);
+        trace_queue(ctx, stream, a, GFX_TRACE_CLOSEST, numPixels, false, ctx.rayHits.p);
+        launch_pixels(ctx, stream, "gbuffer_resolve", k_gbuffer_resolve, a);
+        break;
+    case GFX_RESTIR_INITIAL_RIS:
+    case GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED:
+    case GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED:
+        reset_queue();
+        launch_pixels(ctx, stream, "initial_candidates", k_initial_candidates, a);
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
+        if (pass == GFX_RESTIR_INITIAL_RIS) launch_pixels(ctx, stream, "temporal_none", k_temporal<0>, a);
+        else if (pass == GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED) launch_pixels(ctx, stream, "temporal_biased", k_temporal<1>, a);
+        else launch_pixels(ctx, stream, "temporal_unbiased", k_temporal<2>, a);
+        break;
+    case GFX_RESTIR_SPATIAL_BIASED:
+        launch_pixels(ctx, stream, "spatial_biased", k_spatial<false>, a);
+        break;
+    case GFX_RESTIR_SPATIAL_UNBIASED:
+        reset_queue();
+        launch_pixels(ctx, stream, "spatial_unbiased_select", k_spatial<true>, a);
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
+        launch_pixels(ctx, stream, "spatial_unbiased_finish", k_spatial_mis_finish, a);
+        break;
+    case GFX_RESTIR_SHADING:
+        reset_queue();
+        launch_pixels(ctx, stream, "shade_prepare", k_shade_prepare, a);
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
+        launch_pixels(ctx, stream, "shade_finish", k_shade_finish, a);
+        break;
+    default:
+        throw HipError("gfx_restir_launch: unknown pass");
+    }
+}
+
+} // namespace gfx

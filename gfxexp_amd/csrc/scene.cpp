@@ -1,0 +1,133 @@
+// scene.cpp -- flattens the host-side scene mirror into the HBM tables the kernels read.
+// Reference: Scene slot buffers and createInstance (common/common_host.h:862-969,
+// common/common_host.cpp:1817-1905, 2582-2656).
+#include <cmath>
+#include <cstring>
+#include "internal.h"
+
+namespace gfx {
+
+Context::~Context() {
+    for (Accel* a : accels) { if (a) { a->nodes.release(); a->tris.release(); a->triIds.release(); delete a; } }
+    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dLightW, &dLightCDF,
+                      &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
+                      &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
+                      &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral };
+    for (DevBuf* b : all) b->release();
+    for (auto& e : pendingEvents) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+}
+
+DevScene Context::devScene() const {
+    DevScene s;
+    s.materials = dMaterials.as<gfx_material>();
+    s.geomInsts = dGeomInsts.as<DevGeomInst>();
+    s.insts = dInsts.as<DevInstance>();
+    s.vertices = dVertices.as<DevVertex>();
+    s.triangles = dTriangles.as<uint32_t>();
+    s.geomInstSlotPool = dSlotPool.as<uint32_t>();
+    s.lightWeights = dLightW.as<float>();
+    s.lightCDF = dLightCDF.as<float>();
+    s.lightInstIntegral = dLightInstIntegral.as<float>();
+    s.lightInstDistOffset = lightInstDistOffset;
+    s.numInsts = static_cast<uint32_t>(insts.size());
+    return s;
+}
+
+// normalMatrix = transpose(invert(upper-left 3x3)); Matrix3x3::invert is determinant + adjugate
+// scaled by 1/det (common/basic_types.h:4118-4157).  Written out so every product/sum happens in
+// the same order as in the kernels' gfx::inverse.
+static void normal_matrix(const float x[12], float out[9]) {
+    const float a = x[0], b = x[1], c = x[2], d = x[4], e = x[5], f = x[6], g = x[8], h = x[9], i = x[10];
+    const float det = a * e * i + b * f * g + c * d * h - c * e * g - b * d * i - a * f * h;
+    const float r = 1 / det;
+    const float inv[9] = {
+        (e * i - f * h) * r, -(b * i - c * h) * r, (b * f - c * e) * r,
+        -(d * i - f * g) * r, (a * i - c * g) * r, -(a * f - c * d) * r,
+        (d * h - e * g) * r, -(a * h - b * g) * r, (a * e - b * d) * r };
+    for (int rr = 0; rr < 3; ++rr)
+        for (int cc = 0; cc < 3; ++cc) out[rr * 3 + cc] = inv[cc * 3 + rr];
+}
+
+template <typename T>
+static void upload(DevBuf& b, const std::vector<T>& v, hipStream_t stream) {
+    b.reserve(std::max<size_t>(sizeof(T) * v.size(), 16));
+    if (!v.empty()) GFX_HIP(hipMemcpyAsync(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, stream));
+}
+
+void scene_upload(Context& ctx, hipStream_t stream) {
+    if (!ctx.sceneDirty) return;
+    // pools
+    std::vector<DevVertex> vertices;
+    std::vector<uint32_t> triangles;
+    std::vector<uint32_t> slotPool;
+    ctx.hGeomInsts.assign(ctx.geoms.size(), DevGeomInst());
+    uint32_t lightPool = 0;
+    for (size_t gi = 0; gi < ctx.geoms.size(); ++gi) {
+        const HostGeom& g = ctx.geoms[gi];
+        DevGeomInst& d = ctx.hGeomInsts[gi];
+        d.vertexOffset = static_cast<uint32_t>(vertices.size());
+        d.triangleOffset = static_cast<uint32_t>(triangles.size() / 3);
+        d.numVertices = static_cast<uint32_t>(g.vertices.size());
+        d.numTriangles = static_cast<uint32_t>(g.triangles.size() / 3);
+        d.materialSlot = g.materialSlot;
+        const bool emitter = g.materialSlot < ctx.materials.size() && ctx.materials[g.materialSlot].hasEmittance;
+        d.distOffset = emitter ? lightPool : 0xFFFFFFFFu;   // only emitters own a distribution
+        d.distCount = emitter ? d.numTriangles : 0;
+        d.distIntegral = 0;
+        if (emitter) lightPool += d.numTriangles;
+        vertices.insert(vertices.end(), g.vertices.begin(), g.vertices.end());
+        triangles.insert(triangles.end(), g.triangles.begin(), g.triangles.end());
+    }
+    ctx.hInsts.assign(ctx.insts.size(), DevInstance());
+    ctx.hFlatGeoms.clear();
+    uint32_t triCursor = 0;
+    for (size_t ii = 0; ii < ctx.insts.size(); ++ii) {
+        const HostInstance& hi = ctx.insts[ii];
+        DevInstance& d = ctx.hInsts[ii];
+        std::memcpy(d.transform, hi.transform, sizeof(float) * 12);
+        // curToPrevTransform: identity for static instances (common_host.cpp:2631)
+        const float ident[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+        std::memcpy(d.curToPrevTransform, ident, sizeof(ident));
+        normal_matrix(hi.transform, d.normalMatrix);
+        d.uniformScale = std::sqrt(hi.transform[0] * hi.transform[0] + hi.transform[4] * hi.transform[4] + hi.transform[8] * hi.transform[8]);
+        const std::vector<uint32_t>& slots = ctx.groups[hi.group];
+        d.slotsOffset = static_cast<uint32_t>(slotPool.size());
+        d.numGeomInsts = static_cast<uint32_t>(slots.size());
+        bool hasEmitter = false;
+        for (uint32_t s : slots) {
+            slotPool.push_back(s);
+            if (ctx.hGeomInsts[s].distOffset != 0xFFFFFFFFu) hasEmitter = true;
+            DevFlatGeom fg; fg.instSlot = static_cast<uint32_t>(ii); fg.geomInstSlot = s; fg.triBegin = triCursor;
+            fg.numTriangles = ctx.hGeomInsts[s].numTriangles;
+            triCursor += fg.numTriangles;
+            ctx.hFlatGeoms.push_back(fg);
+        }
+        d.distOffset = hasEmitter ? lightPool : 0xFFFFFFFFu;
+        d.distIntegral = 0;
+        if (hasEmitter) lightPool += d.numGeomInsts;
+        d.pad[0] = d.pad[1] = 0;
+    }
+    ctx.totalTriangles = triCursor;
+    ctx.lightInstDistOffset = lightPool;
+    lightPool += static_cast<uint32_t>(ctx.insts.size());
+    ctx.lightPoolSize = lightPool;
+    ctx.lightsStaticBuilt = false;
+    ctx.dLightInstIntegral.reserve(16);
+    GFX_HIP(hipMemsetAsync(ctx.dLightInstIntegral.p, 0, 16, stream));
+
+    upload(ctx.dMaterials, ctx.materials, stream);
+    upload(ctx.dGeomInsts, ctx.hGeomInsts, stream);
+    upload(ctx.dInsts, ctx.hInsts, stream);
+    upload(ctx.dVertices, vertices, stream);
+    upload(ctx.dTriangles, triangles, stream);
+    upload(ctx.dSlotPool, slotPool, stream);
+    upload(ctx.dFlatGeoms, ctx.hFlatGeoms, stream);
+    ctx.dLightW.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
+    ctx.dLightCDF.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
+    GFX_HIP(hipMemsetAsync(ctx.dLightW.p, 0, ctx.dLightW.bytes, stream));
+    GFX_HIP(hipMemsetAsync(ctx.dLightCDF.p, 0, ctx.dLightCDF.bytes, stream));
+    GFX_HIP(hipStreamSynchronize(stream));   // host vectors above go out of scope
+    ctx.sceneDirty = false;
+}
+
+} // namespace gfx

@@ -1,0 +1,474 @@
+// shading.hip.h -- device shading library of the ReSTIR / path-tracing kernels.
+//
+// What each block computes and where the reference defines it:
+//   Pcg32                     common/common_shared.h:116-138 (PCG32RNG; LCG increment is literally 1)
+//   discrete_sample           common/common_shared.h:209-247 (DiscreteDistribution1D::sample)
+//   polar quantisers          common/common_device.cuh:14-79
+//   offset_ray_origin         common/common_device.cuh:112-140
+//   Frame                     common/common_device.cuh:149-174 (ReferenceFrame)
+//   Bsdf                      common/common_device.cuh:335-374 (Lambert), :443-765 (DiffuseAndSpecular),
+//                             :767-776 (SimplePBR), setup :376-385,778-826
+//   sample_light              restir_di/restir_di_shared.h:320-516 (sampleLight<false>)
+//   direct_lighting           restir_di/restir_di_shared.h:518-557 (performDirectLighting, unshadowed part)
+// Arithmetic follows the reference operation by operation (fp32, no contraction); rng() calls
+// passed as two function arguments in the reference are drawn left to right here.
+#pragma once
+#include "device_types.h"
+#include "gm_math.hip.h"
+
+namespace gfx {
+
+struct Pcg32 {
+    uint64_t state;
+    GFX_DEV uint32_t next() {
+        const uint64_t old = state;
+        state = old * 6364136223846793005ULL + 1;
+        const uint32_t xs = static_cast<uint32_t>(((old >> 18u) ^ old) >> 27u);
+        const uint32_t rot = static_cast<uint32_t>(old >> 59u);
+        return (xs >> rot) | (xs << ((0u - rot) & 31u));
+    }
+    GFX_DEV float uniform() { return bits2f((next() >> 9) | 0x3f800000u) - 1.0f; }
+};
+
+GFX_DEV uint32_t next_pow2(uint32_t x) { return x <= 1 ? x : 1u << (32 - __clz(x - 1)); }
+
+// Branch-light binary search over an exclusive-prefix CDF.
+GFX_DEV uint32_t discrete_sample(const float* __restrict__ weights, const float* __restrict__ cdf,
+                                 float integral, uint32_t n, float u, float& prob, float* remapped) {
+    u *= integral;
+    int idx = 0;
+    for (int d = static_cast<int>(next_pow2(n) >> 1); d >= 1; d >>= 1) {
+        if (idx + d >= static_cast<int>(n)) continue;
+        if (cdf[idx + d] <= u) idx += d;
+    }
+    if (remapped) {
+        const float lo = cdf[idx];
+        float hi = integral;
+        if (idx < static_cast<int>(n) - 1) hi = cdf[idx + 1];
+        *remapped = (u - lo) / (hi - lo);
+    }
+    prob = weights[idx] / integral;
+    return static_cast<uint32_t>(idx);
+}
+
+// ---------------------------------------------------------------- quantisers
+GFX_DEV f3 from_polar_yup(float phi, float theta) {
+    float sp, cp, st, ct;
+    gm_sincos(phi, sp, cp);
+    gm_sincos(theta, st, ct);
+    return f3(-sp * st, ct, cp * st);
+}
+GFX_DEV void to_polar_yup(f3 v, float& phi, float& theta) {
+    theta = gm_acos(fmin2(fmax2(v.y, -1.0f), 1.0f));
+    const float a = gm_atan2(-v.x, v.z) + kTwoPi;   // in [pi, 3pi]: fmod(a, 2pi) is one exact subtraction
+    phi = a >= kTwoPi ? a - kTwoPi : a;
+}
+GFX_DEV uint32_t q16(float x01) { const uint32_t q = f2u_sat(x01 * 65535u); return q > 65535u ? 65535u : q; }
+GFX_DEV uint32_t encode_dir(f3 v) {
+    float phi, theta;
+    to_polar_yup(v, phi, theta);
+    return (q16(theta / kPi) << 16) | q16(phi / kTwoPi);
+}
+GFX_DEV f3 decode_dir(uint32_t q) {
+    const float phi = kTwoPi * ((q & 0xFFFF) / 65535.0f);
+    const float theta = kPi * ((q >> 16) / 65535.0f);
+    return from_polar_yup(phi, theta);
+}
+GFX_DEV uint32_t encode_bc(float bc) { return q16(bc); }
+GFX_DEV float decode_bc(uint32_t q) { return q / 65535.0f; }
+GFX_DEV uint32_t encode_uv(float u, float v) { return (q16(v - floorf(v)) << 16) | q16(u - floorf(u)); }
+
+GFX_DEV f3 offset_ray_origin(f3 p, f3 ng) {
+    constexpr float kOrigin = 1.0f / 32.0f, kFloatScale = 1.0f / 65536.0f, kIntScale = 256.0f;
+    const int32_t ox = f2i_sat(kIntScale * ng.x), oy = f2i_sat(kIntScale * ng.y), oz = f2i_sat(kIntScale * ng.z);
+    const f3 pi(__int_as_float(__float_as_int(p.x) + (p.x < 0 ? -1 : 1) * ox),
+                __int_as_float(__float_as_int(p.y) + (p.y < 0 ? -1 : 1) * oy),
+                __int_as_float(__float_as_int(p.z) + (p.z < 0 ? -1 : 1) * oz));
+    const f3 pf = p + kFloatScale * ng;
+    return f3(fabsf(p.x) < kOrigin ? pf.x : pi.x, fabsf(p.y) < kOrigin ? pf.y : pi.y, fabsf(p.z) < kOrigin ? pf.z : pi.z);
+}
+
+struct Frame {
+    f3 t, b, n;
+    GFX_DEV Frame() {}
+    GFX_DEV Frame(f3 normal, f3 tangent) : t(tangent), n(normal) { b = cross(n, t); }
+    GFX_DEV f3 to_local(f3 v) const { return f3(dot(t, v), dot(b, v), dot(n, v)); }
+    GFX_DEV f3 from_local(f3 v) const {
+        return f3(dot(f3(t.x, b.x, n.x), v), dot(f3(t.y, b.y, n.y), v), dot(f3(t.z, b.z, n.z), v));
+    }
+};
+
+GFX_DEV void concentric_disk(float u0, float u1, float& dx, float& dy) { // common_device.cuh:285-318
+    const float sx = 2 * u0 - 1, sy = 2 * u1 - 1;
+    if (sx == 0 && sy == 0) { dx = 0; dy = 0; return; }
+    float r, theta;
+    if (sx >= -sy) {
+        if (sx > sy) { r = sx; theta = sy / sx; }
+        else { r = sy; theta = 2 - sx / sy; }
+    }
+    else {
+        if (sx > sy) { r = -sy; theta = 6 + sx / sy; }
+        else { r = -sx; theta = 4 + sy / sx; }
+    }
+    theta *= kPi / 4;
+    float s, c;
+    gm_sincos(theta, s, c);
+    dx = r * c;
+    dy = r * s;
+}
+GFX_DEV f3 cosine_hemisphere(float u0, float u1) {
+    float x, y;
+    concentric_disk(u0, u1, x, y);
+    return f3(x, y, sqrtf(fmax2(0.0f, 1.0f - x * x - y * y)));
+}
+
+// ---------------------------------------------------------------- BSDF
+struct Bsdf {
+    uint32_t type;
+    f3 diffuse;      // Lambert: reflectance
+    f3 specularF0;
+    float roughness;
+
+    GFX_DEV void setup(const gfx_material& m) {
+        type = m.bsdfType;
+        diffuse = f3(m.a[0], m.a[1], m.a[2]);
+        specularF0 = f3(0.0f);
+        roughness = 1.0f;
+        if (type == GFX_BSDF_DIFFUSE_AND_SPECULAR) {
+            specularF0 = f3(m.b[0], m.b[1], m.b[2]);
+            roughness = 1 - fmin2(m.smoothness, 0.999f);
+        }
+        else if (type == GFX_BSDF_SIMPLE_PBR) {
+            const f3 base = diffuse;
+            const float smoothness = fmin2(1.0f - m.b[1], 0.999f);
+            const float metallic = m.b[2];
+            diffuse = base * (1 - metallic);
+            specularF0 = f3(0.16f * sq(0.5f) * (1 - metallic)) + base * metallic;
+            roughness = 1 - smoothness;
+        }
+    }
+
+    static GFX_DEV float ggx_d(float ag, f3 m) {
+        if (m.z <= 0.0f) return 0.0f;
+        const float t = sq(m.x) + sq(m.y) + sq(m.z * ag);
+        return sq(ag) / (kPi * sq(t));
+    }
+    static GFX_DEV float ggx_g1(float ag, f3 v, f3 m) {
+        if (dot(v, m) * v.z <= 0) return 0.0f;
+        const float t = sq(ag) * (sq(v.x) + sq(v.y)) / sq(v.z);
+        return 2 / (1 + sqrtf(1 + t));
+    }
+    static GFX_DEV float ggx_g_height_correlated(float ag, f3 v1, f3 v2, f3 m) {
+        const float a1 = sq(ag) * (sq(v1.x) + sq(v1.y)) / sq(v1.z);
+        const float a2 = sq(ag) * (sq(v2.x) + sq(v2.y)) / sq(v2.z);
+        const float l1 = (-1 + sqrtf(1 + a1)) / 2;
+        const float l2 = (-1 + sqrtf(1 + a2)) / 2;
+        const float c1 = (dot(v1, m) / v1.z) > 0 ? 1.0f : 0.0f;
+        const float c2 = (dot(v2, m) / v2.z) > 0 ? 1.0f : 0.0f;
+        return c1 * c2 / (1 + l1 + l2);
+    }
+    static GFX_DEV float ggx_pdf(float ag, f3 v, f3 m) {
+        return ggx_g1(ag, v, m) * fabsf(dot(v, m)) * ggx_d(ag, m) / fabsf(v.z);
+    }
+    static GFX_DEV float ggx_sample(float ag, f3 v, float u0, float u1, f3& m, float& mPdf) {
+        const f3 sv = unit(f3(ag * v.x, ag * v.y, v.z));
+        const float d2 = sqrtf(sv.x * sv.x + sv.y * sv.y);
+        const float rd2 = 1.0f / d2;
+        const f3 T1 = (sv.z < 0.9999f) ? f3(sv.y * rd2, -sv.x * rd2, 0) : f3(1, 0, 0);
+        const f3 T2(T1.y * sv.z, -T1.x * sv.z, d2);
+        const float a = 1.0f / (1.0f + sv.z);
+        const float r = sqrtf(u0);
+        const float phi = kPi * ((u1 < a) ? u1 / a : 1 + (u1 - a) / (1.0f - a));
+        float sp, cp;
+        gm_sincos(phi, sp, cp);
+        const float P1 = r * cp;
+        const float P2 = r * sp * ((u1 < a) ? 1.0f : sv.z);
+        m = P1 * T1 + P2 * T2 + sqrtf(1.0f - P1 * P1 - P2 * P2) * sv;
+        m = unit(f3(ag * m.x, ag * m.y, m.z));
+        const float D = ggx_d(ag, m);
+        mPdf = ggx_g1(ag, v, m) * fabsf(dot(v, m)) * D / fabsf(v.z);
+        return D;
+    }
+
+    // shared tail of evaluate / sampleThroughput: f = diffuse lobe + specular lobe
+    GFX_DEV f3 lobes(f3 dirL, f3 dirV, f3 m, float dotLH, float D, float oneMinusDotVN5) const {
+        const float ag = roughness * roughness;
+        const float oneMinusDotLH5 = pow5(1 - dotLH);
+        const float G = ggx_g_height_correlated(ag, dirL, dirV, m);
+        const f3 F = mix3(specularF0, f3(1.0f), oneMinusDotLH5);
+        const float denom = 4 * dirL.z * dirV.z;
+        f3 spec = F * ((D * G) / denom);
+        if (G == 0) spec = f3(0.0f);
+        const float F_D90 = 0.5f * roughness + 2 * roughness * dotLH * dotLH;
+        const float oneMinusDotLN5 = pow5(1 - dirL.z);
+        const float fOut = mixf(1.0f, F_D90, oneMinusDotVN5);
+        const float fIn = mixf(1.0f, F_D90, oneMinusDotLN5);
+        const f3 diff = diffuse * (fOut * fIn * mixf(1.0f, 1.0f / 1.51f, roughness) / kPi);
+        return diff + spec;
+    }
+
+    GFX_DEV f3 evaluate(f3 vGiven, f3 vSampled) const {
+        if (type == GFX_BSDF_LAMBERT)
+            return vGiven.z * vSampled.z > 0 ? diffuse / kPi : f3(0.0f);
+        if (vSampled.z * vGiven.z <= 0) return f3(0.0f);
+        const bool entering = vGiven.z >= 0.0f;
+        const f3 dirV = entering ? vGiven : -vGiven;
+        const f3 dirL = entering ? vSampled : -vSampled;
+        const f3 m = unit(dirL + dirV);
+        const float dotLH = dot(dirL, m);
+        const float D = ggx_d(roughness * roughness, m);
+        return lobes(dirL, dirV, m, dotLH, D, pow5(1 - dirV.z));
+    }
+
+    GFX_DEV void lobe_weights(f3 vGiven, f3 dirV, float& wDiff, float& wSpec) const {
+        const float eF_D90 = 0.5f * roughness + 2 * roughness * vGiven.z * vGiven.z;
+        const float oneMinusDotVN5 = pow5(1 - dirV.z);
+        const float eDiffFresnel = mixf(1.0f, eF_D90, oneMinusDotVN5);
+        wDiff = luminance_srgb(diffuse) * sq(eDiffFresnel) * mixf(1.0f, 1.0f / 1.51f, roughness);
+        const float eOneMinusDotVH5 = pow5(1 - dirV.z);
+        wSpec = mixf(luminance_srgb(specularF0), 1.0f, eOneMinusDotVH5);
+    }
+
+    GFX_DEV f3 sample_throughput(f3 vGiven, float u0, float u1, f3& vSampled, float& pdf) const {
+        if (type == GFX_BSDF_LAMBERT) {
+            vSampled = cosine_hemisphere(u0, u1);
+            pdf = vSampled.z / kPi;
+            if (vGiven.z <= 0.0f) vSampled.z *= -1;
+            return diffuse;
+        }
+        const float ag = roughness * roughness;
+        const bool entering = vGiven.z >= 0.0f;
+        const f3 dirV = entering ? vGiven : -vGiven;
+        const float oneMinusDotVN5 = pow5(1 - dirV.z);
+        float wDiff, wSpec;
+        lobe_weights(vGiven, dirV, wDiff, wSpec);
+        const float sumW = wDiff + wSpec;
+        if (sumW == 0.0f) { pdf = 0.0f; return f3(0.0f); }
+        const float uComp = u1;
+        f3 dirL, m;
+        float pdfDiff, pdfSpec, dotLH, D;
+        if (sumW * uComp < wDiff) {
+            u1 = (sumW * uComp - 0) / wDiff;
+            dirL = cosine_hemisphere(u0, u1);
+            pdfDiff = dirL.z / kPi;
+            m = unit(dirL + dirV);
+            dotLH = fmin2(dot(dirL, m), 1.0f);
+            const float common = 1.0f / (4 * dotLH);
+            pdfSpec = common * ggx_pdf(ag, dirV, m);
+            D = ggx_d(ag, m);
+        }
+        else {
+            u1 = (sumW * uComp - wDiff) / wSpec;
+            float mPdf;
+            D = ggx_sample(ag, dirV, u0, u1, m, mPdf);
+            const float dotVH = fmin2(dot(dirV, m), 1.0f);
+            dotLH = dotVH;
+            dirL = 2 * dotVH * m - dirV;
+            if (dirL.z * dirV.z <= 0) { pdf = 0.0f; return f3(0.0f); }
+            const float common = 1.0f / (4 * dotLH);
+            pdfSpec = common * mPdf;
+            pdfDiff = dirL.z / kPi;
+        }
+        f3 ret = lobes(dirL, dirV, m, dotLH, D, oneMinusDotVN5);
+        vSampled = entering ? dirL : -dirL;
+        pdf = (pdfDiff * wDiff + pdfSpec * wSpec) / sumW;
+        ret = ret * (dirL.z / pdf);
+        return ret;
+    }
+
+    GFX_DEV float evaluate_pdf(f3 vGiven, f3 vSampled) const {
+        if (type == GFX_BSDF_LAMBERT)
+            return vGiven.z * vSampled.z > 0 ? fabsf(vSampled.z) / kPi : 0.0f;
+        const float ag = roughness * roughness;
+        const bool entering = vGiven.z >= 0.0f;
+        const f3 dirV = entering ? vGiven : -vGiven;
+        const f3 dirL = entering ? vSampled : -vSampled;
+        const f3 m = unit(dirL + dirV);
+        const float dotLH = dot(dirL, m);
+        const float common = 1.0f / (4 * dotLH);
+        float wDiff, wSpec;
+        lobe_weights(vGiven, dirV, wDiff, wSpec);
+        const float sumW = wDiff + wSpec;
+        if (sumW == 0.0f) return 0.0f;
+        const float pdfDiff = dirL.z / kPi;
+        const float pdfSpec = common * ggx_pdf(ag, dirV, m);
+        return (pdfDiff * wDiff + pdfSpec * wSpec) / sumW;
+    }
+
+    GFX_DEV f3 dh_reflectance_estimate(f3 vGiven) const {
+        if (type == GFX_BSDF_LAMBERT) return diffuse;
+        const f3 dirV = vGiven.z >= 0.0f ? vGiven : -vGiven;
+        const float eF_D90 = 0.5f * roughness + 2 * roughness * sq(dirV.z);
+        const float oneMinusDotVN5 = pow5(1 - dirV.z);
+        const float eDiffFGiven = mixf(1.0f, eF_D90, oneMinusDotVN5);
+        const f3 diffuseDHR = diffuse * eDiffFGiven * 1.0f * mixf(1.0f, 1.0f / 1.51f, roughness);
+        const float eOneMinusDotVH5 = pow5(1 - dirV.z) * (1 - roughness);
+        const f3 specularDHR = mix3(specularF0, f3(1.0f), eOneMinusDotVH5);
+        return min3(diffuseDHR + specularDHR, f3(1.0f));
+    }
+};
+
+// ---------------------------------------------------------------- light sampling
+struct LightSample {
+    f3 emittance;
+    f3 position;
+    f3 normal;
+    uint32_t atInfinity;
+};
+
+struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
+    const float4* texels;
+    const float* rowPDF; const float* rowCDF; const float* topPDF; const float* topCDF;
+    int32_t w, h;
+    GFX_DEV bool present() const { return texels != nullptr; }
+    GFX_DEV f3 fetch(float u, float v) const { // nearest texel (the build's tex2DLod contract)
+        uint32_t x = f2u_sat(u * w); if (x > static_cast<uint32_t>(w - 1)) x = w - 1;
+        uint32_t y = f2u_sat(v * h); if (y > static_cast<uint32_t>(h - 1)) y = h - 1;
+        const float4 t = texels[static_cast<size_t>(y) * w + x];
+        return f3(t.x, t.y, t.z);
+    }
+    static GFX_DEV float sample1d(const float* pdf, const float* cdf, uint32_t n, float u, float& p) {
+        int idx = 0;
+        for (int d = static_cast<int>(next_pow2(n) >> 1); d >= 1; d >>= 1) {
+            if (idx + d >= static_cast<int>(n)) continue;
+            if (cdf[idx + d] <= u) idx += d;
+        }
+        const float t = (u - cdf[idx]) / (cdf[idx + 1] - cdf[idx]);
+        p = pdf[idx];
+        return (idx + t) / n;
+    }
+    GFX_DEV void sample(float u0, float u1, float& d0, float& d1, float& p) const { // common_shared.h:372-379
+        float topP;
+        d1 = sample1d(topPDF, topCDF, h, u1, topP);
+        uint32_t row = f2u_sat(d1 * h); if (row > static_cast<uint32_t>(h - 1)) row = h - 1;
+        d0 = sample1d(rowPDF + static_cast<size_t>(row) * w, rowCDF + static_cast<size_t>(row) * (w + 1), w, u0, p);
+        p *= topP;
+    }
+};
+
+GFX_DEV DevVertex load_vertex(const DevVertex* __restrict__ v) {
+    const float4* p = reinterpret_cast<const float4*>(v);
+    const float4 a = p[0], b = p[1], c = p[2];
+    DevVertex r;
+    r.px = a.x; r.py = a.y; r.pz = a.z; r.nx = a.w;
+    r.ny = b.x; r.nz = b.y; r.tx = b.z; r.ty = b.w;
+    r.tz = c.x; r.u = c.y; r.v = c.z; r.pad = 0;
+    return r;
+}
+GFX_DEV m34 load_m34(const float* __restrict__ p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    const float4 a = q[0], b = q[1], c = q[2];
+    m34 m;
+    m.m[0] = a.x; m.m[1] = a.y; m.m[2] = a.z; m.m[3] = a.w;
+    m.m[4] = b.x; m.m[5] = b.y; m.m[6] = b.z; m.m[7] = b.w;
+    m.m[8] = c.x; m.m[9] = c.y; m.m[10] = c.z; m.m[11] = c.w;
+    return m;
+}
+GFX_DEV m33 load_m33(const float* __restrict__ p) {
+    m33 m;
+    m.r0 = f3(p[0], p[1], p[2]); m.r1 = f3(p[3], p[4], p[5]); m.r2 = f3(p[6], p[7], p[8]);
+    return m;
+}
+
+// sampleLight<false>.  Returns the area density; sample left untouched past an early out exactly
+// like the reference (the caller starts from a default-constructed LightSample).
+GFX_DEV void sample_light(const DevScene& sc, const EnvMap& env, float envRotation, float envPowerCoeff,
+                          float ul, bool sampleEnv, float u0, float u1, LightSample& ls, float& areaPDensity) {
+    if (sampleEnv) {
+        float u, v, uvPDF;
+        env.sample(u0, u1, u, v, uvPDF);
+        const float phi = 2 * kPi * u;
+        const float theta = kPi * v;
+        float posPhi = phi - envRotation;
+        posPhi = posPhi - floorf(posPhi / (2 * kPi)) * 2 * kPi;
+        const f3 dir = from_polar_yup(posPhi, theta);
+        ls.position = dir;
+        ls.atInfinity = 1;
+        ls.normal = -dir;
+        const float sinTheta = gm_sin(theta);
+        if (sinTheta == 0.0f) { areaPDensity = 0.0f; return; }
+        areaPDensity = uvPDF / (2 * kPi * kPi * sinTheta);
+        ls.emittance = f3(kPi * envPowerCoeff) * env.fetch(u, v);
+        return;
+    }
+    float lightProb = 1.0f;
+    float instProb, uGeomInst;
+    const uint32_t instSlot = discrete_sample(sc.lightWeights + sc.lightInstDistOffset, sc.lightCDF + sc.lightInstDistOffset,
+                                              *sc.lightInstIntegral, sc.numInsts, ul, instProb, &uGeomInst);
+    lightProb *= instProb;
+    if (instProb == 0.0f) { areaPDensity = 0.0f; return; }
+    const DevInstance* inst = sc.insts + instSlot;
+
+    float geomInstProb, uPrim;
+    const uint32_t gi = discrete_sample(sc.lightWeights + inst->distOffset, sc.lightCDF + inst->distOffset,
+                                        inst->distIntegral, inst->numGeomInsts, uGeomInst, geomInstProb, &uPrim);
+    const uint32_t geomInstSlot = sc.geomInstSlotPool[inst->slotsOffset + gi];
+    lightProb *= geomInstProb;
+    if (geomInstProb == 0.0f) { areaPDensity = 0.0f; return; }
+    const DevGeomInst g = sc.geomInsts[geomInstSlot];
+
+    float primProb;
+    const uint32_t prim = discrete_sample(sc.lightWeights + g.distOffset, sc.lightCDF + g.distOffset,
+                                          g.distIntegral, g.distCount, uPrim, primProb, nullptr);
+    lightProb *= primProb;
+
+    const uint32_t* tri = sc.triangles + 3ull * (g.triangleOffset + prim);
+    const DevVertex vA = load_vertex(sc.vertices + g.vertexOffset + tri[0]);
+    const DevVertex vB = load_vertex(sc.vertices + g.vertexOffset + tri[1]);
+    const DevVertex vC = load_vertex(sc.vertices + g.vertexOffset + tri[2]);
+    const m34 xfm = load_m34(inst->transform);
+    const f3 pA = xfm_point(xfm, f3(vA.px, vA.py, vA.pz));
+    const f3 pB = xfm_point(xfm, f3(vB.px, vB.py, vB.pz));
+    const f3 pC = xfm_point(xfm, f3(vC.px, vC.py, vC.pz));
+    const f3 ng = cross(pB - pA, pC - pA);
+
+    float bcA = 0.5f * u0;
+    float bcB = 0.5f * u1;
+    const float off = bcB - bcA;
+    if (off > 0) bcB += off;
+    else bcA -= off;
+    const float bcC = 1 - (bcA + bcB);
+    areaPDensity = lightProb * (2.0f / len(ng));
+
+    ls.position = bcA * pA + bcB * pB + bcC * pC;
+    ls.atInfinity = 0;
+    const f3 n = bcA * f3(vA.nx, vA.ny, vA.nz) + bcB * f3(vB.nx, vB.ny, vB.nz) + bcC * f3(vC.nx, vC.ny, vC.nz);
+    ls.normal = unit(mul(load_m33(inst->normalMatrix), n));
+    const gfx_material& mat = sc.materials[g.materialSlot];
+    f3 e(0.0f);
+    if (mat.hasEmittance) e = f3(1.0f) * f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+    ls.emittance = e;
+}
+
+// Geometry of a shadow ray toward a light sample (restir_di_shared.h:524-545, 564-581).
+struct ShadowRay { f3 dir; float dist2; float tmax; };
+GFX_DEV ShadowRay shadow_ray(f3 shadingPoint, const LightSample& ls) {
+    f3 d = ls.atInfinity ? ls.position : (ls.position - shadingPoint);
+    ShadowRay r;
+    r.dist2 = len2(d);
+    float dist = sqrtf(r.dist2);
+    r.dir = d / dist;
+    if (ls.atInfinity) dist = 1e+10f;
+    r.tmax = dist * 0.9999f;
+    return r;
+}
+
+// Unshadowed contribution f * Le * G (performDirectLighting<.., false>); the visibility factor of
+// the <.., true> form is applied by the caller from the traced occlusion bit.
+GFX_DEV f3 direct_lighting(f3 shadingPoint, f3 vOutLocal, const Frame& frame, const Bsdf& bsdf, const LightSample& ls) {
+    const ShadowRay sr = shadow_ray(shadingPoint, ls);
+    const f3 dirLocal = frame.to_local(sr.dir);
+    const float lpCos = dot(-sr.dir, ls.normal);
+    const float spCos = dirLocal.z;
+    if (lpCos > 0) {
+        const f3 Le = ls.emittance / kPi;
+        const f3 fs = bsdf.evaluate(vOutLocal, dirLocal);
+        const float G = lpCos * fabsf(spCos) / sr.dist2;
+        return fs * Le * G;
+    }
+    return f3(0.0f);
+}
+
+GFX_DEV float target_weight(f3 c) { return (c.x + c.y + c.z) / 3; } // convertToWeight, restir_di_shared.h:82-85
+
+} // namespace gfx

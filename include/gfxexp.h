@@ -112,6 +112,9 @@ int gfx_instance_set_transform(gfx_ctx* ctx, uint32_t instSlot, const float xfm[
  * LBVH -> BVH8 over all instances (world space).  The 64-bit handle fits the reference's
  * perFramePlp.travHandle field (restir_di_main.cpp:2264). */
 int gfx_accel_build(gfx_ctx* ctx, void* stream, uint64_t* handle);
+/* Leaf size limit of the collapse step, 1..15 (default 4); GeometryBVHBuildConfig::maxNumPrimsPerLeaf,
+ * common/bvh_builder.h:38-44. */
+int gfx_accel_set_max_leaf(gfx_ctx* ctx, uint32_t maxLeafTris);
 /* Build statistics of the last gfx_accel_build: {numTriangles, numNodes, numTriRecords, maxDepth}. */
 int gfx_accel_stats(gfx_ctx* ctx, uint64_t handle, uint32_t stats[4]);
 /* Device pointer to the gfx_tri_ids table of the BVH (indexed by gfx_hit.triIndex). */
@@ -218,6 +221,10 @@ enum gfx_restir_pass {
     GFX_RESTIR_NUM_PASSES
 };
 int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height);
+
+/* Blocking device-to-host copy of library- or caller-owned device memory (TypedBuffer::read,
+ * utils/cuda_util.h; used for pick info at restir_di_main.cpp:2010). */
+int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes);
 
 /* Per-kernel HIP-event timing of the launches issued since the last reset
  * (cudau::Timer, utils/cuda_util.h:441-485).  names/ms arrays sized by capacity. */

@@ -1,0 +1,134 @@
+/*
+ * gfxexp_host.h -- host layer above the C ABI of gfxexp.h: scene construction and the headless
+ * ReSTIR DI frame driver.  It mirrors what the reference's host program does around the hot path
+ * (restir_di/restir_di_main.cpp) without the window / ImGui / OptiX parts:
+ *   scene building      createTriangleMeshes / createRectangleLight / createInstance
+ *                       (common/common_host.cpp:2178-2429, 2431-2476, 2582-2656)
+ *   material constants  immediate 1x1 textures, 8-bit + sRGB decode (common_host.cpp:1045-1073,
+ *                       1602-1659; basic_types.h:5396-5402)
+ *   frame loop          buffer allocation + seeding (restir_di_main.cpp:1210-1325), Halton disk table
+ *                       (:1487-1542), per-frame sequencing and index bookkeeping (:2311-2493)
+ * Everything here is plain C ABI as well so tests and bench.py drive it through ctypes.
+ */
+#ifndef GFXEXP_HOST_H
+#define GFXEXP_HOST_H
+
+#include "gfxexp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gfxh_scene gfxh_scene;
+
+gfxh_scene* gfxh_scene_create(void);
+void gfxh_scene_destroy(gfxh_scene* s);
+const char* gfxh_last_error(void);
+
+/* createDiffuseAndSpecularMaterial with immediate values (common_host.cpp:1560-1700): diffuse and
+ * specular go through 8-bit quantisation + sRGB decode, smoothness through 8-bit quantisation,
+ * emittance is kept as float; hasEmittance = any(emittance != 0). Returns the material slot. */
+uint32_t gfxh_scene_add_material_traditional(gfxh_scene* s, const float diffuse[3], const float specular[3],
+                                             float smoothness, const float emittance[3]);
+/* Raw material (values as sampled). */
+uint32_t gfxh_scene_add_material(gfxh_scene* s, const gfx_material* m);
+
+/* Geometry / groups / instances (return slot indices). */
+uint32_t gfxh_scene_add_geom(gfxh_scene* s, const gfx_vertex* v, uint32_t nv, const uint32_t* tris, uint32_t nt, uint32_t matSlot);
+uint32_t gfxh_scene_add_group(gfxh_scene* s, const uint32_t* geomSlots, uint32_t n);
+uint32_t gfxh_scene_add_instance(gfxh_scene* s, uint32_t group, const float xfm[12]);
+
+/* OBJ + MTL reader ("-obj <path> <scale> trad"): one geometry instance per material, one group.
+ * Returns the group index or 0xFFFFFFFF on failure.  The scale belongs to the instance transform
+ * (the reference passes it as the mesh pre-transform, restir_di_main.cpp:1119-1124). */
+uint32_t gfxh_scene_load_obj(gfxh_scene* s, const char* path);
+/* createRectangleLight (common_host.cpp:2431-2476): XZ rectangle facing -Y. Returns the group. */
+uint32_t gfxh_scene_add_rectangle(gfxh_scene* s, float width, float depth, const float emittance[3]);
+
+/* Procedural "street" stand-in for Bistro Exterior (the asset is not redistributable / absent):
+ * tessellated ground, facade blocks with window grids, instanced props, and many small emitters. */
+typedef struct gfxh_street_params {
+    uint32_t seed;
+    uint32_t groundTess;        /* ground is groundTess x groundTess quads */
+    uint32_t numBuildings;
+    uint32_t facadeTess;        /* window grid resolution per facade */
+    uint32_t numProps;          /* instanced icospheres / crates */
+    uint32_t propSubdiv;        /* icosphere subdivision level (0..5) */
+    uint32_t numLamps;          /* small box emitters on poles */
+    uint32_t numSigns;          /* emissive quads on facades */
+    float extent;               /* half size of the street block in metres */
+    float lampEmittance;
+    float signEmittance;
+} gfxh_street_params;
+int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p);
+
+/* Enumeration (to feed the same arrays to another consumer, e.g. the test oracle). */
+int gfxh_scene_counts(gfxh_scene* s, uint32_t counts[5]); /* materials, geoms, groups, insts, triangles(total over instances) */
+int gfxh_scene_get_material(gfxh_scene* s, uint32_t i, gfx_material* out);
+int gfxh_scene_get_geom(gfxh_scene* s, uint32_t i, const gfx_vertex** v, uint32_t* nv, const uint32_t** tris, uint32_t* nt, uint32_t* matSlot);
+int gfxh_scene_get_group(gfxh_scene* s, uint32_t i, const uint32_t** geomSlots, uint32_t* n);
+int gfxh_scene_get_instance(gfxh_scene* s, uint32_t i, uint32_t* group, float xfm[12]);
+/* World-space bounds of all instances: {minx,miny,minz,maxx,maxy,maxz}. */
+int gfxh_scene_bounds(gfxh_scene* s, float bounds[6]);
+
+/* Push the scene through gfx_material_set / gfx_geom_create / gfx_group_create / gfx_instance_create. */
+int gfxh_scene_upload(gfxh_scene* s, gfx_ctx* ctx);
+
+/* 3x4 row-major transform from scale, yaw/pitch/roll (degrees, the reference's CLI convention) and
+ * translation: T * R * S. */
+void gfxh_make_transform(float scale, float rollDeg, float pitchDeg, float yawDeg, const float pos[3], float out[12]);
+/* Camera orientation from roll/pitch/yaw in degrees (restir_di_main.cpp:2667-2676 qFromEulerAngles), row-major 3x3. */
+void gfxh_make_orientation(float rollDeg, float pitchDeg, float yawDeg, float out[9]);
+
+/* restir_di_main.cpp:1316-1321 / :1217: PCG32 states from std::mt19937_64(seed). */
+void gfxh_seed_rng_states(uint64_t* states, uint64_t count, uint64_t seed);
+/* restir_di_main.cpp:1487-1542: 1024 Halton(2,3) samples mapped to the unit disk (float2 x 1024). */
+void gfxh_spatial_neighbor_deltas(float* out2x1024);
+
+/* ---------------------------------------------------------------- headless ReSTIR DI renderer */
+typedef struct gfxh_restir gfxh_restir;
+
+enum gfxh_renderer {
+    GFXH_ORIGINAL_RESTIR_BIASED = 0,   /* restir_di_main.cpp:1958-1977 Renderer enum */
+    GFXH_ORIGINAL_RESTIR_UNBIASED = 1
+};
+typedef struct gfxh_restir_config {
+    uint32_t width, height;
+    int renderer;
+    uint32_t log2NumCandidateSamples;   /* 5 */
+    uint32_t enableTemporalReuse;       /* 1 */
+    uint32_t enableSpatialReuse;        /* 1 */
+    uint32_t numSpatialReusePasses;     /* 2 biased / 1 unbiased */
+    uint32_t numSpatialNeighbors;       /* 5 biased / 3 unbiased */
+    float spatialNeighborRadius;        /* 20 */
+    uint32_t useLowDiscrepancyNeighbors;/* 1 */
+    uint32_t reuseVisibility;           /* 1 */
+    uint32_t enableAccumulation;        /* 0 */
+    uint32_t log2MaxNumAccums;          /* 16 */
+    gfx_camera camera;                  /* fovY = 50 deg in the reference (:1613) */
+    /* rows [rowBegin, rowEnd) owned by this process when a frame is split across GPUs; 0,0 = all.
+     * (reserved for the tile-split driver) */
+    uint32_t rowBegin, rowEnd;
+} gfxh_restir_config;
+
+void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_t height, int renderer);
+/* Allocates every per-pixel buffer (hipMalloc), seeds the RNG buffer, uploads the Halton table,
+ * builds BVH and light distributions for the uploaded scene. */
+int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir** out);
+void gfxh_restir_destroy(gfxh_restir* r);
+/* One frame: light-instance distribution, G-buffer, initial(+temporal) RIS, spatial passes, shading. */
+int gfxh_restir_render_frame(gfxh_restir* r, void* stream);
+/* Restart the sequence (newSequence, restir_di_main.cpp:2311). */
+int gfxh_restir_reset(gfxh_restir* r);
+int gfxh_restir_set_camera(gfxh_restir* r, const gfx_camera* cam);
+/* Device pointer of the float4 beauty accumulation buffer (W*H). */
+void* gfxh_restir_beauty_buffer(gfxh_restir* r);
+/* Copies of the static parameters (device pointers) and of the last frame parameters. */
+int gfxh_restir_get_params(gfxh_restir* r, gfx_restir_static_params* s, gfx_restir_frame_params* f,
+                           uint32_t* lastReservoirIndex, uint32_t* lastSpatialNeighborBaseIndex, uint32_t* frameIndex);
+uint64_t gfxh_restir_accel(gfxh_restir* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFXEXP_HOST_H */

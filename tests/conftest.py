@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libgfxexp.so must exist (built by __graft_entry__.build()); never fall back."""
+    from gfxexp_amd import api
+    if not os.path.exists(api.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return api.lib()
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import oracle
+    return oracle.lib()

@@ -1,0 +1,145 @@
+"""-m gpu: the ReSTIR DI passes (G-buffer, initial + temporal RIS, spatial RIS, shading), pass by
+pass, against the CPU oracle on identical scenes, seeds and parameters.
+
+Bar (north_star): reservoir sample selection bit-exact -- here EVERY per-pixel buffer is compared
+bit for bit (RNG state, G-buffers, reservoirs, ReservoirInfo, beauty/albedo/normal).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gfxexp_amd import api
+from oracle import oracle as O
+from tests import util
+
+
+def _cam_for(hs, width, height):
+    b = hs.bounds()
+    centre = 0.5 * (b[:3] + b[3:])
+    return centre
+
+
+def default_camera(scene_kind, width, height):
+    if scene_kind == "bunny":
+        return api.make_camera(width, height, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+    return api.make_camera(width, height, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
+
+
+def run_sequence_both(hs, width, height, frames=2, renderer=api.RENDERER_BIASED, scene_kind="bunny",
+                      low_discrepancy=True, reuse_visibility=True, camera=None, stop_after=None, threads=None):
+    """Run `frames` frames with the sequencing of restir_di_main.cpp:2311-2493 on the GPU (through
+    the C ABI) and in the oracle, comparing all buffers after every pass.  Returns a list of
+    mismatch descriptions (empty = bit-identical)."""
+    import torch
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    ctx.lights_build_static()
+    osc = util.feed_oracle(hs, threads=threads)
+    cam = camera if camera is not None else default_camera(scene_kind, width, height)
+    ocam = util.copy_struct(O.GfxCamera, cam)
+
+    pb_gpu_init = util.PixelBuffers(width, height)
+    dev = util.DeviceBuffers(pb_gpu_init)
+    pb_cpu = util.PixelBuffers(width, height)
+    s_gpu = dev.static_params()
+    s_cpu = pb_cpu.host_static_params()
+
+    unbiased = renderer == api.RENDERER_UNBIASED
+    num_passes = 1 if unbiased else 2
+    num_nb = 3 if unbiased else 5
+    last_res, last_base = 1, 0
+    diffs = []
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def compare(tag):
+        got = dev.download()
+        want = pb_cpu.arrays()
+        for k in want:
+            a = np.ascontiguousarray(got[k]).view(np.uint8).reshape(-1)
+            b = np.ascontiguousarray(want[k]).view(np.uint8).reshape(-1)
+            if not np.array_equal(a, b):
+                item = want[k].dtype.itemsize
+                nbad = len(np.unique(np.nonzero(a != b)[0] // item))
+                diffs.append(f"{tag}: {k}: {nbad} of {want[k].size} elements differ")
+
+    for frame in range(frames):
+        buffer_index = frame % 2
+        new_sequence = frame == 0
+        kw = dict(frameIndex=frame, bufferIndex=buffer_index, resetFlowBuffer=int(new_sequence), numAccumFrames=0,
+                  numSpatialNeighbors=num_nb, useUnbiasedEstimator=int(unbiased),
+                  useLowDiscrepancyNeighbors=int(low_discrepancy), reuseVisibility=int(reuse_visibility))
+        f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, width, height, cam, travHandle=accel, **kw)
+        f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, width, height, ocam, travHandle=0, **kw)
+        ctx.lights_build_instances(stream)
+        cur = (last_res + 1) % 2
+
+        def both(pass_id, cur_res, base, tag):
+            ctx.restir_set_params(s_gpu, f_gpu, cur_res, base, stream)
+            ctx.restir_launch(pass_id, width, height, stream)
+            osc.restir_launch(s_cpu, f_cpu, cur_res, base, pass_id)
+            compare(f"frame {frame} {tag}")
+
+        both(api.PASS_SETUP_GBUFFERS, cur, last_base, "gbuffer")
+        if stop_after == "gbuffer":
+            break
+        entry = api.PASS_INITIAL_RIS
+        if not new_sequence:
+            entry = api.PASS_INITIAL_TEMPORAL_UNBIASED if unbiased else api.PASS_INITIAL_TEMPORAL_BIASED
+        both(entry, cur, last_base, "initial/temporal")
+        for i in range(num_passes):
+            both(api.PASS_SPATIAL_UNBIASED if unbiased else api.PASS_SPATIAL_BIASED, cur, last_base + num_nb * i, f"spatial {i}")
+            cur = (cur + 1) % 2
+        last_base += num_nb * num_passes
+        both(api.PASS_SHADING, cur, last_base, "shading")
+        last_res = cur
+    run_sequence_both.last_beauty = pb_cpu.beauty.copy()
+    run_sequence_both.last_gb0 = pb_cpu.gb0[(frames - 1) % 2].copy()
+    return diffs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("renderer", [api.RENDERER_BIASED, api.RENDERER_UNBIASED])
+def test_bunny_sequence_bit_exact(built_lib, renderer):
+    diffs = run_sequence_both(util.bunny_scene(), 160, 96, frames=3, renderer=renderer)
+    assert not diffs, "\n".join(diffs)
+    beauty = run_sequence_both.last_beauty
+    surf = run_sequence_both.last_gb0["instSlot"] != 0xFFFFFFFF
+    assert surf.mean() > 0.3
+    assert np.isfinite(beauty).all() and beauty[surf, :3].mean() > 1e-3
+
+
+@pytest.mark.gpu
+def test_street_sequence_bit_exact(built_lib):
+    diffs = run_sequence_both(util.small_street(), 192, 108, frames=2, renderer=api.RENDERER_BIASED, scene_kind="street")
+    assert not diffs, "\n".join(diffs)
+
+
+@pytest.mark.gpu
+def test_random_neighbours_and_no_visibility_reuse(built_lib):
+    diffs = run_sequence_both(util.bunny_scene(), 128, 80, frames=2, renderer=api.RENDERER_UNBIASED,
+                              low_discrepancy=False, reuse_visibility=False)
+    assert not diffs, "\n".join(diffs)
+
+
+@pytest.mark.gpu
+def test_headless_driver_matches_pass_by_pass(built_lib):
+    """gfxh_restir_render_frame (the C++ frame loop) produces the same beauty buffer as the
+    oracle sequenced by the test harness."""
+    import torch
+    width, height, frames = 128, 72, 3
+    hs = util.bunny_scene()
+    diffs = run_sequence_both(hs, width, height, frames=frames, renderer=api.RENDERER_BIASED)
+    assert not diffs, "\n".join(diffs)
+    want = run_sequence_both.last_beauty
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    cfg = api.RestirRenderer.default_config(width, height, api.RENDERER_BIASED)
+    cfg.camera = default_camera("bunny", width, height)
+    r = api.RestirRenderer(ctx, cfg)
+    for _ in range(frames):
+        r.render_frame()
+    torch.cuda.synchronize()
+    out = ctx.read_device(r.beauty_ptr(), width * height * 16).view(np.float32).reshape(-1, 4)
+    util.assert_same_bits("driver beauty", out, want)

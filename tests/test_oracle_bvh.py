@@ -1,0 +1,80 @@
+"""CPU: the oracle's restatement of the reference SAH BVH8 builder + compressed-stack traversal
+(common/bvh_builder.cpp) pinned against brute force on the two meshes the reference's own
+(disabled) testBvhBuilder harness names: stanford_bunny_309_faces.obj and teapot.obj
+(nrtdsm/nrtdsm_sandbox.cpp:3118-3146), with its build config {0.3, 1.2, 1.0, 1, 128} (:3179-3184)."""
+import numpy as np
+import pytest
+
+from tests import util
+
+
+def _rays_around(hs, res, seed=0):
+    b = hs.bounds()
+    centre = 0.5 * (b[:3] + b[3:])
+    ext = np.linalg.norm(b[3:] - b[:3])
+    return util.pinhole_rays(res, res, centre + np.array([0.3, 0.35, 0.9]) * ext, centre)
+
+
+@pytest.mark.parametrize("name,res", [("bunny", 256), ("teapot", 96)])
+def test_reference_traversal_equals_brute_force(built_lib, name, res):
+    hs = util.bunny_scene(with_light=False, with_ground=False) if name == "bunny" else util.teapot_scene()
+    osc = util.feed_oracle(hs, config=[0.3, 1.2, 1.0, 1, 128])
+    stats = osc.accel_stats()
+    assert stats[0] == hs.counts()["triangles"]
+    assert stats[2] >= stats[0]                       # spatial splits may duplicate references
+    assert stats[2] <= int(1.3 * stats[0]) + 1        # splittingBudget 0.3
+    assert osc.accel_validate() == 0
+    org, dirs = _rays_around(hs, res)
+    brute = osc.trace(2, org, dirs)
+    ref, st = osc.trace(3, org, dirs, want_stats=True)      # verbatim reference traversal
+    canon = osc.trace(0, org, dirs)                          # + canonical tie-break
+    hit_b = brute["triIndex"] != 0xFFFFFFFF
+    assert hit_b.mean() > 0.05
+    assert np.array_equal(hit_b, ref["triIndex"] != 0xFFFFFFFF)
+    util.assert_same_bits("dist", ref["dist"], brute["dist"])
+    util.assert_same_bits("canonical", canon, brute)
+    # the verbatim traversal may only differ from brute force where two triangles tie exactly
+    differs = ref["triIndex"] != brute["triIndex"]
+    assert differs.sum() <= max(2, len(org) // 2000)
+    assert st[0] > 0 and st[1] > 0 and st[3] >= st[0]
+
+
+def test_any_hit_equals_brute_force(built_lib):
+    hs = util.bunny_scene(with_light=True)
+    osc = util.feed_oracle(hs)
+    rng = np.random.default_rng(1)
+    n = 20000
+    p0 = rng.uniform((-8, 0.01, -8), (8, 12, 8), (n, 3)).astype(np.float32)
+    p1 = rng.uniform((-8, 0.01, -8), (8, 12, 8), (n, 3)).astype(np.float32)
+    d = p1 - p0
+    dist = np.linalg.norm(d, axis=1).astype(np.float32)
+    org = np.zeros((n, 4), np.float32); org[:, :3] = p0
+    dirs = np.zeros((n, 4), np.float32); dirs[:, :3] = d / dist[:, None]; dirs[:, 3] = dist * np.float32(0.9999)
+    occ = osc.trace(1, org, dirs)
+    brute = osc.trace(2, org, dirs)
+    assert np.array_equal(occ, (brute["triIndex"] != 0xFFFFFFFF).astype(np.uint32))
+
+
+def test_light_distributions_follow_compute_light_probs(built_lib):
+    hs = util.bunny_scene(with_light=True)
+    osc = util.feed_oracle(hs)
+    w, cdf, integral = osc.lights_read(0)
+    # two rectangle lights (instances 2, 3): luminance(emittance) * area * scale^2
+    lum = lambda e: 0.2126729 * e[0] + 0.7151522 * e[1] + 0.0721750 * e[2]
+    np.testing.assert_allclose(w, [0, 0, lum((50, 50, 50)) * 1.0, lum((10, 20, 40)) * 2.0], rtol=1e-5)
+    assert cdf[0] == 0 and np.all(np.diff(cdf) >= 0)
+    assert integral == np.float32(cdf[-1] + w[-1])
+    wg, _, ig = osc.lights_read(1, 2)
+    wt, ct, it = osc.lights_read(2, 2)          # geomInst 2 = first rectangle: two triangles of area 0.5
+    np.testing.assert_allclose(wt, [lum((50, 50, 50)) * 0.5] * 2, rtol=1e-5)
+    assert np.float32(ig) == np.float32(it) == np.float32(ct[-1] + wt[-1]) and wg[0] == np.float32(it)
+    # area density integrates to one over the emitters: E[1/pdf] = total emitter area (MC)
+    u = np.random.default_rng(2).random((200000, 3)).astype(np.float32)
+    ls, pd = osc.sample_light((0, 1, 0), u)
+    assert np.all(pd > 0)
+    np.testing.assert_allclose(np.mean(1.0 / pd.astype(np.float64)), 1.0 + 2.0, rtol=0.03)
+    # samples lie on the emitters' planes, normals unit length
+    np.testing.assert_allclose(np.linalg.norm(ls[:, 6:9], axis=1), 1.0, atol=1e-5)
+    on_first = np.isclose(ls[:, 4], 12.0, atol=1e-4)
+    frac = on_first.mean()
+    assert abs(frac - w[2] / (w[2] + w[3])) < 0.01

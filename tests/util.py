@@ -1,0 +1,253 @@
+"""Helpers shared by the tests: build the same scene in the product (gfxexp_amd, through the C ABI)
+and in the CPU oracle, allocate ReSTIR pixel buffers on either side, compare buffers."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from gfxexp_amd import api
+from oracle import oracle as O
+
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets")
+PIXEL_RNG_SEED = 591842031321323413  # restir_di/restir_di_main.cpp:1317
+
+
+def to_oracle_material(m):
+    om = O.GfxMaterial()
+    C.memmove(C.byref(om), C.byref(m), C.sizeof(om))
+    return om
+
+
+def feed_oracle(host_scene, threads=None, brute_force=False, config=None):
+    """Push every array of a HostScene into an OracleScene (same slots, same order)."""
+    osc = O.OracleScene(threads=threads)
+    for i, m in enumerate(host_scene.materials()):
+        osc.set_material(i, to_oracle_material(m))
+    for v, t, mat in host_scene.geoms():
+        osc.add_geom(v, t, mat)
+    for g in host_scene.groups():
+        osc.add_group(g)
+    for g, x in host_scene.instances():
+        osc.add_instance(g, x)
+    secs = osc.commit(brute_force=brute_force, config=config)
+    osc.build_seconds = secs
+    return osc
+
+
+def bunny_scene(with_light=True, with_ground=True):
+    """BASELINE config 2: bunny (scale 0.1) + rectangle light + ground quad."""
+    s = api.HostScene()
+    g = s.load_obj(os.path.join(ASSETS, "stanford_bunny_309_faces.obj"))
+    s.add_instance(g, api.make_transform(scale=0.1))
+    if with_ground:
+        mat = s.add_material_traditional((0.7, 0.7, 0.7), (0.04, 0.04, 0.04), 0.1)
+        v = np.zeros(4, api.VERTEX_DTYPE)
+        v["position"] = [(-20, 0, -20), (20, 0, -20), (20, 0, 20), (-20, 0, 20)]
+        v["normal"] = (0, 1, 0)
+        v["texCoord0Dir"] = (1, 0, 0)
+        v["texCoord"] = [(0, 0), (1, 0), (1, 1), (0, 1)]
+        geom = s.add_geom(v, [(0, 2, 1), (0, 3, 2)], mat)
+        s.add_instance(s.add_group([geom]), api.make_transform())
+    if with_light:
+        r = s.add_rectangle(1.0, 1.0, (50, 50, 50))
+        s.add_instance(r, api.make_transform(pos=(0.0, 12.0, 2.0)))
+        r2 = s.add_rectangle(2.0, 1.0, (10, 20, 40))
+        s.add_instance(r2, api.make_transform(pitch=-60.0, pos=(-6.0, 6.0, 6.0)))
+    return s
+
+
+def teapot_scene(emissive=False):
+    s = api.HostScene()
+    g = s.load_obj(os.path.join(ASSETS, "teapot.obj"))
+    if emissive:
+        # config 1 plumbing: every teapot triangle emits RGB(1,1,1)
+        for m in s.materials():
+            pass
+    s.add_instance(g, api.make_transform())
+    return s
+
+
+def small_street(seed=7, scale=1):
+    p = api.GfxhStreetParams()
+    p.seed = seed
+    p.groundTess = 24 * scale
+    p.numBuildings = 8
+    p.facadeTess = 12 * scale
+    p.numProps = 30 * scale
+    p.propSubdiv = 1
+    p.numLamps = 24 * scale
+    p.numSigns = 12 * scale
+    p.extent = 30.0
+    p.lampEmittance = 40.0
+    p.signEmittance = 8.0
+    s = api.HostScene()
+    s.make_street(p)
+    return s
+
+
+def bench_street(seed=2024):
+    """The Bistro-Exterior stand-in used by bench.py (about 2.8 M instanced triangles)."""
+    p = api.GfxhStreetParams()
+    p.seed = seed
+    p.groundTess = 512
+    p.numBuildings = 44
+    p.facadeTess = 64
+    p.numProps = 600
+    p.propSubdiv = 3
+    p.numLamps = 1500
+    p.numSigns = 600
+    p.extent = 60.0
+    p.lampEmittance = 60.0
+    p.signEmittance = 10.0
+    s = api.HostScene()
+    s.make_street(p)
+    return s
+
+
+def pinhole_rays(width, height, cam_pos, look_at, fov_y_deg=45.0, tmax=np.float32(3.0e38)):
+    """Pinhole camera rays (the shape of the reference's testBvhBuilder harness, nrtdsm_sandbox.cpp:3376-3410)."""
+    cam_pos = np.asarray(cam_pos, np.float64)
+    fwd = np.asarray(look_at, np.float64) - cam_pos
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, (0, 1, 0))
+    right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    h = 2 * np.tan(np.radians(fov_y_deg) / 2)
+    w = h * width / height
+    xs = ((np.arange(width) + 0.5) / width - 0.5) * w
+    ys = (0.5 - (np.arange(height) + 0.5) / height) * h
+    X, Y = np.meshgrid(xs, ys)
+    d = fwd[None, None, :] + X[..., None] * right + Y[..., None] * up
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    n = width * height
+    org = np.zeros((n, 4), np.float32)
+    org[:, :3] = cam_pos
+    dirs = np.zeros((n, 4), np.float32)
+    dirs[:, :3] = d.reshape(n, 3)
+    dirs[:, 3] = tmax
+    return org, dirs
+
+
+class PixelBuffers:
+    """Host-side (numpy) copies of every ReSTIR per-pixel buffer in the ABI layouts."""
+
+    def __init__(self, width, height, seed=PIXEL_RNG_SEED):
+        n = width * height
+        self.w, self.h, self.n = width, height, n
+        self.rng = O.seed_rngs(n, seed)
+        self.gb0 = [np.zeros(n, api.GBUFFER0_DTYPE) for _ in range(2)]
+        self.gb1 = [np.zeros((n, 2), np.float32) for _ in range(2)]
+        self.gb2 = [np.zeros(n, api.GBUFFER2_DTYPE) for _ in range(2)]
+        self.gb3 = [np.zeros(n, api.GBUFFER3_DTYPE) for _ in range(2)]
+        self.res = [np.zeros((3, n, 4), np.float32) for _ in range(2)]
+        self.info = [np.zeros((n, 2), np.float32) for _ in range(2)]
+        self.vis = [np.zeros(n, np.uint32) for _ in range(2)]
+        self.beauty = np.zeros((n, 4), np.float32)
+        self.albedo = np.zeros((n, 4), np.float32)
+        self.normal = np.zeros((n, 4), np.float32)
+        self.deltas = O.spatial_neighbor_deltas()
+
+    def arrays(self):
+        out = {"rng": self.rng, "beauty": self.beauty, "albedo": self.albedo, "normal": self.normal}
+        for i in range(2):
+            out.update({f"gb0_{i}": self.gb0[i], f"gb1_{i}": self.gb1[i], f"gb2_{i}": self.gb2[i], f"gb3_{i}": self.gb3[i],
+                        f"res_{i}": self.res[i], f"info_{i}": self.info[i]})
+        return out
+
+    def static_params(self, cls, ptr):
+        s = cls()
+        s.imageSizeX, s.imageSizeY = self.w, self.h
+        s.rngBuffer = ptr(self.rng)
+        for i in range(2):
+            s.gbuffer0[i] = ptr(self.gb0[i]); s.gbuffer1[i] = ptr(self.gb1[i])
+            s.gbuffer2[i] = ptr(self.gb2[i]); s.gbuffer3[i] = ptr(self.gb3[i])
+            s.reservoirBuffer[i] = ptr(self.res[i]); s.reservoirInfoBuffer[i] = ptr(self.info[i])
+            s.sampleVisibilityBuffer[i] = ptr(self.vis[i])
+        s.spatialNeighborDeltas = ptr(self.deltas)
+        s.beautyAccumBuffer = ptr(self.beauty); s.albedoAccumBuffer = ptr(self.albedo); s.normalAccumBuffer = ptr(self.normal)
+        s.numTilesX, s.numTilesY = (self.w + 7) // 8, (self.h + 7) // 8
+        return s
+
+    def host_static_params(self):
+        return self.static_params(O.GfxRestirStaticParams, lambda a: a.ctypes.data)
+
+
+class DeviceBuffers:
+    """torch-allocated device mirrors of a PixelBuffers (PyTorch = device memory plumbing only)."""
+
+    def __init__(self, pb):
+        import torch
+        self.torch = torch
+        self.pb = pb
+        self.t = {}
+        for k, a in pb.arrays().items():
+            self.t[k] = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda()
+        self.t["deltas"] = torch.from_numpy(pb.deltas.view(np.uint8).reshape(-1).copy()).cuda()
+        for i in range(2):
+            self.t[f"vis_{i}"] = torch.zeros(pb.n * 4, dtype=torch.uint8, device="cuda")
+
+    def static_params(self):
+        pb, t = self.pb, self.t
+        s = api.GfxRestirStaticParams()
+        s.imageSizeX, s.imageSizeY = pb.w, pb.h
+        s.rngBuffer = t["rng"].data_ptr()
+        for i in range(2):
+            s.gbuffer0[i] = t[f"gb0_{i}"].data_ptr(); s.gbuffer1[i] = t[f"gb1_{i}"].data_ptr()
+            s.gbuffer2[i] = t[f"gb2_{i}"].data_ptr(); s.gbuffer3[i] = t[f"gb3_{i}"].data_ptr()
+            s.reservoirBuffer[i] = t[f"res_{i}"].data_ptr(); s.reservoirInfoBuffer[i] = t[f"info_{i}"].data_ptr()
+            s.sampleVisibilityBuffer[i] = t[f"vis_{i}"].data_ptr()
+        s.spatialNeighborDeltas = t["deltas"].data_ptr()
+        s.beautyAccumBuffer = t["beauty"].data_ptr(); s.albedoAccumBuffer = t["albedo"].data_ptr()
+        s.normalAccumBuffer = t["normal"].data_ptr()
+        s.numTilesX, s.numTilesY = (pb.w + 7) // 8, (pb.h + 7) // 8
+        return s
+
+    def download(self):
+        """Return {name: numpy array} with the dtypes/shapes of PixelBuffers.arrays()."""
+        self.torch.cuda.synchronize()
+        out = {}
+        for k, a in self.pb.arrays().items():
+            raw = self.t[k].cpu().numpy()
+            out[k] = raw.view(a.dtype).reshape(a.shape)
+        return out
+
+
+def frame_params(cls_frame, cls_cam, width, height, cam, prev_cam=None, **kw):
+    f = cls_frame()
+    C.memmove(C.byref(f.camera), C.byref(cam), C.sizeof(cam))
+    pc = prev_cam if prev_cam is not None else cam
+    C.memmove(C.byref(f.prevCamera), C.byref(pc), C.sizeof(pc))
+    f.envLightPowerCoeff = 1.0
+    f.spatialNeighborRadius = 20.0
+    f.radiusThresholdForSpatialVisReuse = 10.0
+    f.log2NumCandidateSamples = 5
+    f.numSpatialNeighbors = 5
+    f.useLowDiscrepancyNeighbors = 1
+    f.reuseVisibility = 1
+    f.reuseVisibilityForTemporal = 1
+    f.enableTemporalReuse = 1
+    f.enableSpatialReuse = 1
+    for k, v in kw.items():
+        setattr(f, k, v)
+    return f
+
+
+def copy_struct(dst_cls, src):
+    d = dst_cls()
+    assert C.sizeof(d) == C.sizeof(src)
+    C.memmove(C.byref(d), C.byref(src), C.sizeof(src))
+    return d
+
+
+def assert_same_bits(name, a, b):
+    """Bit-exact comparison with a helpful message (NaNs with equal payload compare equal)."""
+    a8 = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    b8 = np.ascontiguousarray(b).view(np.uint8).reshape(-1)
+    assert a8.shape == b8.shape, f"{name}: shape {a8.shape} vs {b8.shape}"
+    if not np.array_equal(a8, b8):
+        item = np.ascontiguousarray(a).dtype.itemsize if np.ascontiguousarray(a).dtype.fields is None else 1
+        bad = np.nonzero(a8 != b8)[0]
+        first = bad[0] // max(item, 1)
+        raise AssertionError(f"{name}: {len(bad)} differing bytes, first at element {first}: "
+                             f"{np.ascontiguousarray(a).reshape(-1)[first] if item > 1 else a8[bad[0]]} vs "
+                             f"{np.ascontiguousarray(b).reshape(-1)[first] if item > 1 else b8[bad[0]]}")
