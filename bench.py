@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""bench.py -- ReSTIR DI (original, biased) on the Bistro-Exterior stand-in, 1920x1080, 1 spp.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one steady-state frame (frameIndex >= 1: temporal reuse active, static camera, no
+accumulation): light-instance distribution, G-buffer, initial+temporal RIS, 2 spatial passes x 5
+neighbours, shading -- exactly the span of the reference's GPUTimer.frame minus denoise/display
+(restir_di/restir_di_main.cpp:2245-2422).  1 path = 1 pixel sample, so
+    Mpaths/s = W*H*K / t / 1e6.
+Inputs (scene, BVH, per-pixel state) are resident in HBM before the timed region starts.
+
+N > 1 splits the frame into N row bands (multiples of 8 rows), one process per GPU; every rank
+renders its band plus the halo the reuse passes read, and the HDR bands are all-gathered over
+RCCL/xGMI once per frame ("strong" scaling: total work fixed).
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--mse-ref-spp", type=int, default=512, help="frames of plain-NEE reference accumulated in fp64 for the MSE figure (0 = skip)")
+    ap.add_argument("--cpu-sample", type=str, default="240x135", help="resolution of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from gfxexp_amd import api
+    from gfxexp_amd import tilesplit
+    from tests import util
+
+    W, H = args.width, args.height
+    t0 = time.time()
+    hs = util.bench_street()
+    counts = hs.counts()
+    ctx = api.Context(local_rank)
+    hs.upload(ctx)
+    cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
+    cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
+    cfg.camera = cam
+    band = tilesplit.band_for_rank(H, world, rank)
+    cfg.rowBegin, cfg.rowEnd = band
+    renderer = api.RestirRenderer(ctx, cfg)
+    accel_stats = ctx.accel_stats(renderer.accel())
+    setup_s = time.time() - t0
+    stream = torch.cuda.current_stream().cuda_stream
+
+    gather = None
+    if world > 1:
+        gather = tilesplit.BandGather(_device_view(renderer.beauty_ptr(), W * H * 4), W, H, world, rank, dist)
+
+    def frame():
+        renderer.render_frame(stream)
+        if gather is not None:
+            gather.all_gather()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # frame 0 starts the sequence (no temporal reuse); it is part of the untimed warm-up
+    for _ in range(max(1, args.warmup)):
+        frame()
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    mpaths = W * H * args.steps / elapsed / 1e6
+
+    result = {
+        "metric": "Mpaths/s, ReSTIR DI (original, biased) 1920x1080 1 spp, Bistro-Exterior stand-in",
+        "value": round(mpaths, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[2]: ReSTIR DI biased, procedural street stand-in for Bistro Exterior "
+                               f"({counts['triangles']} instanced triangles, {counts['insts']} instances, "
+                               "2100 emitter instances), 32 candidates, temporal + 2x5 spatial reuse, radius 20, visibility reuse",
+                   "width": W, "height": H, "spp": 1, "parallelism": f"row-bands x{world}" if world > 1 else "single GPU",
+                   "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]}},
+        "setup_s": round(setup_s, 2),
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            result["roofline"], result["kernels_ms_per_frame"] = roofline(ctx, renderer, stream, args.steps, W, H)
+        if args.mse_ref_spp > 0:
+            result["mse"] = mse_vs_reference(ctx, hs, renderer, cam, W, H, args.mse_ref_spp)
+        if args.cpu_sample not in ("0", ""):
+            result["cpu_baseline"] = cpu_baseline(hs, cam, args.cpu_sample, W, H)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline(ctx, renderer, stream, steps, W, H):
+    """Dominant kernel by GPU time; achieved = algorithmic bytes per launch / mean launch duration.
+    Durations: HIP events on the launch stream around every kernel (gfx_timing_*), live in this run.
+    Algorithmic bytes of the traversal kernels: node fetches x 64 B + triangle fetches x 48 B +
+    rays x (32 B in + result out), counted by the counting instantiation of the same kernel."""
+    import torch
+    ctx.timing_enable(True)
+    n = max(4, min(steps, 16))
+    for _ in range(n):
+        renderer.render_frame(stream)
+    torch.cuda.synchronize()
+    timings = ctx.timing_collect()
+    ctx.timing_enable(False)
+    ctx.counters_enable(True)
+    ctx.counters_read(reset=True)
+    renderer.render_frame(stream)
+    torch.cuda.synchronize()
+    c = ctx.counters_read(reset=True)
+    ctx.counters_enable(False)
+    per_frame = {k: round(ms / n, 4) for k, (ms, calls) in sorted(timings.items(), key=lambda kv: -kv[1][0])}
+    trav_ms = sum(ms for k, (ms, calls) in timings.items() if k.startswith("trace_")) / n
+    trav_launches = sum(calls for k, (ms, calls) in timings.items() if k.startswith("trace_")) / n
+    # one frame = 1 closest launch (16 B out) + 2 any-hit launches (4 B out); counters cover all of them
+    rays_closest = W * H
+    rays_any = c["rays"] - rays_closest
+    bytes_frame = c["nodeFetches"] * 64 + c["triFetches"] * 48 + rays_closest * (32 + 16) + rays_any * (32 + 4)
+    achieved = bytes_frame / (trav_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "k_trace<closest|any> (software BVH8 traversal; 3 launches per frame)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": int(bytes_frame / max(trav_launches, 1)),
+            "avg_launch_ms": round(trav_ms / max(trav_launches, 1), 4),
+            "per_frame": {"node_fetches": int(c["nodeFetches"]), "tri_fetches": int(c["triFetches"]), "rays": int(c["rays"]),
+                          "stack_spills": int(c["spills"])}}
+    return roof, per_frame
+
+
+def mse_vs_reference(ctx, hs, renderer, cam, W, H, ref_spp):
+    """MSE / relMSE of one 1-spp ReSTIR frame against an fp64 accumulation of `ref_spp` frames of
+    plain RIS/NEE (temporal + spatial reuse off), same scene and camera."""
+    import torch
+    from gfxexp_amd import api
+    n = W * H
+    test = torch.from_numpy(ctx.read_device(renderer.beauty_ptr(), n * 16).view(np.float32).reshape(n, 4).copy())[:, :3].double()
+    cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_UNBIASED)
+    cfg.camera = cam
+    cfg.enableTemporalReuse = 0
+    cfg.enableSpatialReuse = 0
+    ref_r = api.RestirRenderer(ctx, cfg)
+    acc = torch.zeros(n * 4, dtype=torch.float64, device="cuda")
+    view = None
+    for _ in range(ref_spp):
+        ref_r.render_frame()
+        torch.cuda.synchronize()
+        if view is None:
+            view = _device_view(ref_r.beauty_ptr(), n * 4)
+        acc += view.double()
+    ref = (acc / ref_spp).view(n, 4)[:, :3].cpu()
+    ref_r.close()
+    err = (test - ref) ** 2
+    return {"mse": float(err.mean()), "rel_mse": float((err / (ref ** 2 + 1e-2)).mean()), "ref_spp": ref_spp,
+            "ref_estimator": "RIS/NEE 32 candidates + visibility, no reuse, fp64 accumulation"}
+
+
+def _device_view(ptr, num_floats):
+    """Wrap a raw device pointer as a torch tensor (no copy) through the CUDA array interface."""
+    import torch
+
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (num_floats,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device="cuda")
+
+
+def cpu_baseline(hs, cam, sample, W, H):
+    """The CPU restatement (oracle/, test infrastructure) timed on this host: same scene, same
+    camera, same settings, steady-state frames on a reduced pixel count, one thread."""
+    import ctypes as C
+    from oracle import oracle as O
+    from tests import util
+    sw, sh = [int(x) for x in sample.lower().split("x")]
+    osc = util.feed_oracle(hs, threads=1)
+    ocam = util.copy_struct(O.GfxCamera, cam)
+    ocam.aspect = float(sw) / float(sh)
+    pb = util.PixelBuffers(sw, sh)
+    s = pb.host_static_params()
+    last_res, last_base = 1, 0
+    times = []
+    frames = 3
+    for frame in range(frames):
+        kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=0)
+        f = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, sw, sh, ocam, **kw)
+        cur = (last_res + 1) % 2
+        t0 = time.perf_counter()
+        osc.restir_launch(s, f, cur, last_base, 0)
+        osc.restir_launch(s, f, cur, last_base, 1 if frame == 0 else 2)
+        for i in range(2):
+            osc.restir_launch(s, f, cur, last_base + 5 * i, 4)
+            cur = (cur + 1) % 2
+        last_base += 10
+        osc.restir_launch(s, f, cur, last_base, 6)
+        last_res = cur
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": round(sw * sh / t / 1e6, 5), "unit": "Mpaths/s", "cores": 1, "kind": "port",
+            "sample": f"{sw}x{sh} pixels ({sw * sh / (W * H):.4f} of the frame), {frames - 1} steady-state frames, same scene/camera/settings, "
+                      f"scalar C++ restatement (oracle/), SAH BVH8 build {osc.build_seconds:.1f} s untimed",
+            "seconds_per_sample_frame": round(t, 3), "host_threads_available": O.lib().orc_max_threads()}
+
+
+if __name__ == "__main__":
+    main()
