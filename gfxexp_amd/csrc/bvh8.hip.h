@@ -30,12 +30,11 @@ struct RayHit {
 
 GFX_DEV uint32_t bfe(uint32_t v, uint32_t off, uint32_t bits) { return (v >> off) & ((1u << bits) - 1u); }
 
-// Ray vs triangle, common/bvh_builder.cpp:1251-1270 (same operations, same order); the distMax
-// comparison is left to the caller (it also handles exact ties).
-GFX_DEV bool ray_triangle(f3 org, f3 dir, float tmin, f3 pA, f3 pB, f3 pC, float& t, float& bcB, float& bcC) {
-    const f3 eAB = pB - pA;
-    const f3 eCA = pA - pC;
-    const f3 n = cross(eCA, eAB);
+// Ray vs triangle, common/bvh_builder.cpp:1251-1270 (same operations, same order).  The edge
+// vectors eAB = pB - pA, eCA = pA - pC and the normal n = cross(eCA, eAB) are ray independent and
+// are stored in the 64-byte record by the builder (same fp32 operations, so the same bits); the
+// distMax comparison is left to the caller (it also handles exact ties).
+GFX_DEV bool ray_triangle(f3 org, f3 dir, float tmin, f3 pA, f3 eAB, f3 eCA, f3 n, float& t, float& bcB, float& bcC) {
     const f3 e = (1.0f / dot(n, dir)) * (pA - org);
     const f3 i = cross(dir, e);
     bcB = dot(i, eCA);
@@ -58,38 +57,62 @@ struct LaneStack {
     }
 };
 
-// Per-lane traversal state: one ray in flight.  step() performs one group pop + node visit
-// (including the triangle tests of the node's hit leaf children) and returns false once the ray
-// has finished, so a persistent wave can refill finished lanes between steps.
+constexpr uint32_t kItemNone = 0xFFFFFFFFu;   // nothing to fetch
+constexpr uint32_t kItemTri = 0x80000000u;    // item code: bit 31 = triangle record, low bits = index
+
+// Per-lane traversal state: one ray in flight.  Each iteration of the wave loop a lane asks for ONE
+// 64-byte item -- the next node of its current group, or the next pending triangle of the node it
+// visited last -- the wave fetches all 64 items cooperatively (trace.hip), and the lane then
+// processes its item.  A lane never waits inside another lane's per-child or per-triangle loop.
+//
+// Slab test in the node's quantised frame: plane t = A_k + q * B_k with A_k = (origin_k - org_k) /
+// dir_k, B_k = scale_k / dir_k (one fmaf per plane).  The builder guarantees that the fp32 DECODED
+// box origin + q * scale contains the child; the fmaf form differs from that decode by a few
+// roundings, bounded by 1.5 * 2^-22 * |1/dir_k| * (max |plane coordinate| + |org_k|); slabs are
+// widened by 2^-21 of that magnitude, so no box the exact test keeps is ever culled.
 struct Traversal {
     f3 org, dir, inv;
     float tmin;
     RayHit hit;
     uint2 grp;
     uint32_t oct;
+    uint32_t triBase, triMask;
+    uint32_t offNx, offFx, offNy, offFy;   // bit offsets of the near / far plane fields per axis
+    bool zNeg;
     bool active;
 
     GFX_DEV void begin(f3 o, f3 d, float t0, float t1, LaneStack& stack, bool hasNodes) {
         org = o; dir = d; tmin = t0;
-        inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        // |dir_k| below 1e-20 behaves like an axis-parallel ray without producing inf / NaN
+        const float dx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
+        const float dy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
+        const float dz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
+        inv = f3(1.0f / dx, 1.0f / dy, 1.0f / dz);
         hit.t = t1; hit.bcB = 0; hit.bcC = 0; hit.tri = GFX_INVALID_SLOT;
         // octant mask: bit k set when the ray travels toward -k, so (slot ^ oct) ascending = near to far
-        oct = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+        oct = (dx < 0 ? 1u : 0u) | (dy < 0 ? 2u : 0u) | (dz < 0 ? 4u : 0u);
+        offNx = dx < 0 ? 18u : 0u; offFx = dx < 0 ? 0u : 18u;
+        offNy = dy < 0 ? 24u : 6u; offFy = dy < 0 ? 6u : 24u;
+        zNeg = dz < 0;
         // current group: x = index of the first internal child; y = hit bits | imask << 8.
         // Hit bit p stands for child slot (p ^ oct).  The root is a one-child group: slot 0
         // (bit 0 ^ oct), empty imask -> node index 0.
         grp = make_uint2(0u, 1u << oct);
+        triBase = 0; triMask = 0;
         stack.sp = 0;
         active = hasNodes;
     }
 
-    template <bool ANY_HIT, bool COUNT>
-    GFX_DEV bool step(const DevAccel& acc, LaneStack& stack, TraceCounters& cnt) {
-        const Bvh8Node* __restrict__ nodes = acc.nodes;
-        const Bvh8Tri* __restrict__ tris = acc.tris;
+    // Which 64-byte item does this lane need next?  kItemNone = the ray has finished.
+    GFX_DEV uint32_t next_item(LaneStack& stack) {
+        if (triMask) {
+            const uint32_t bit = __builtin_ctz(triMask);
+            triMask &= triMask - 1u;
+            return kItemTri | (triBase + bit);
+        }
         uint32_t hits = grp.y & 0xFFu;
         if (hits == 0) {
-            if (stack.sp == 0) { active = false; return false; }
+            if (stack.sp == 0) { active = false; return kItemNone; }
             grp = stack.pop();
             hits = grp.y & 0xFFu;
         }
@@ -97,78 +120,82 @@ struct Traversal {
         grp.y &= ~(1u << pos);
         const uint32_t slot = pos ^ oct;
         const uint32_t imaskG = (grp.y >> 8) & 0xFFu;
-        const uint32_t nodeIdx = grp.x + __builtin_popcount(imaskG & ((1u << slot) - 1u));
+        return grp.x + __builtin_popcount(imaskG & ((1u << slot) - 1u));
+    }
 
-        const uint4* np = reinterpret_cast<const uint4*>(nodes + nodeIdx);
-        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    // One triangle record (device_types.h Bvh8Tri).  Returns false when an any-hit ray is done.
+    template <bool ANY_HIT, bool COUNT>
+    GFX_DEV bool process_triangle(uint32_t ti, uint4 q0, uint4 q1, uint4 q2, uint4 q3, const Bvh8Tri* __restrict__ tris, TraceCounters& cnt) {
+        if (COUNT) ++cnt.tris;
+        const f3 pA(bits2f(q0.x), bits2f(q0.y), bits2f(q0.z));
+        const f3 eAB(bits2f(q0.w), bits2f(q1.x), bits2f(q1.y));
+        const f3 eCA(bits2f(q1.z), bits2f(q1.w), bits2f(q2.x));
+        const f3 n(bits2f(q2.y), bits2f(q2.z), bits2f(q2.w));
+        float t, bb, cc;
+        if (!ray_triangle(org, dir, tmin, pA, eAB, eCA, n, t, bb, cc)) return true;
+        bool take = t < hit.t;
+        if (!ANY_HIT && !take && t == hit.t && hit.tri != GFX_INVALID_SLOT) {
+            // exact tie: lowest (instSlot, geomInstSlot, primIndex) wins
+            const Bvh8Tri* o = tris + hit.tri;
+            take = q3.x < o->instSlot || (q3.x == o->instSlot && (q3.y < o->geomInstSlot ||
+                   (q3.y == o->geomInstSlot && q3.z < o->primIndex)));
+        }
+        if (take) {
+            hit.t = t; hit.bcB = bb; hit.bcC = cc; hit.tri = ti;
+            if (ANY_HIT) { active = false; return false; }
+        }
+        return true;
+    }
+
+    // One node (device_types.h Bvh8Node): 8 slab tests, leaf hits -> triangle mask, node hits -> group.
+    template <bool COUNT>
+    GFX_DEV void process_node(uint4 n0, uint4 n1, uint4 n2, uint4 n3, LaneStack& stack, TraceCounters& cnt) {
         if (COUNT) ++cnt.nodes;
         const f3 origin(bits2f(n0.x), bits2f(n0.y), bits2f(n0.z));
         const f3 scale(bits2f(bfe(n0.w, 0, 8) << 23), bits2f(bfe(n0.w, 8, 8) << 23), bits2f(bfe(n0.w, 16, 8) << 23));
         const uint32_t imask = n0.w >> 24;
-        const uint32_t triBase = n1.y;
         const uint32_t cw[8] = { n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y };
         const uint32_t zb[2] = { n3.z, n3.w };
 
+        const f3 B = scale * inv;
+        const f3 A = (origin - org) * inv;
+        const f3 m(fmaxf(fabsf(origin.x), fabsf(origin.x + 63.0f * scale.x)) + fabsf(org.x),
+                   fmaxf(fabsf(origin.y), fabsf(origin.y + 63.0f * scale.y)) + fabsf(org.y),
+                   fmaxf(fabsf(origin.z), fabsf(origin.z + 63.0f * scale.z)) + fabsf(org.z));
+        const f3 slack(m.x * fabsf(inv.x) * 4.76837158203125e-07f, m.y * fabsf(inv.y) * 4.76837158203125e-07f,
+                       m.z * fabsf(inv.z) * 4.76837158203125e-07f);
+        const f3 An = A - slack, Af = A + slack;
+
         uint32_t nodeHits = 0;     // hit internal children, bit (slot ^ oct)
+        uint32_t leafMask = 0;     // triangles of hit leaf children, bit = offset from triBase
         uint32_t triOff = 0;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const uint32_t w = cw[s];
             const uint32_t zc = bfe(zb[s >> 2], (s & 3) * 8, 8);
             const uint32_t count = (w >> 30) | ((zc >> 6) << 2);
-            if (count == 0) continue;
             const bool internal = (imask >> s) & 1u;
-            // dequantise: origin + q * scale (q * scale is exact, one rounding per coordinate)
-            const f3 lo(origin.x + static_cast<float>(bfe(w, 0, 6)) * scale.x,
-                        origin.y + static_cast<float>(bfe(w, 6, 6)) * scale.y,
-                        origin.z + static_cast<float>(bfe(w, 12, 6)) * scale.z);
-            const f3 hi(origin.x + static_cast<float>(bfe(w, 18, 6)) * scale.x,
-                        origin.y + static_cast<float>(bfe(w, 24, 6)) * scale.y,
-                        origin.z + static_cast<float>(zc & 63u) * scale.z);
-            const f3 t0 = (lo - org) * inv, t1 = (hi - org) * inv;
-            // fminf/fmaxf drop NaNs (0 * inf when the ray origin lies in a slab plane)
-            float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
-            float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
-            // conservative slabs: widen by a few ulp so rounding never culls a box the exact test keeps
-            tn = tn * (tn > 0 ? 0.9999995f : 1.0000005f);
-            tf = tf * (tf > 0 ? 1.0000005f : 0.9999995f);
-            tn = fmaxf(tn, tmin);
-            tf = fminf(tf, hit.t);
-            const bool boxHit = tn <= tf;
-            if (internal) {
-                if (boxHit) nodeHits |= 1u << (s ^ oct);
-                continue;
-            }
+            const uint32_t zlo = bfe(w, 12, 6), zhi = zc & 63u;
+            const float tnx = fmaf(static_cast<float>((w >> offNx) & 63u), B.x, An.x);
+            const float tny = fmaf(static_cast<float>((w >> offNy) & 63u), B.y, An.y);
+            const float tnz = fmaf(static_cast<float>(zNeg ? zhi : zlo), B.z, An.z);
+            const float tfx = fmaf(static_cast<float>((w >> offFx) & 63u), B.x, Af.x);
+            const float tfy = fmaf(static_cast<float>((w >> offFy) & 63u), B.y, Af.y);
+            const float tfz = fmaf(static_cast<float>(zNeg ? zlo : zhi), B.z, Af.z);
+            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, hit.t));
+            const bool boxHit = (tn <= tf) && count != 0;
             if (boxHit) {
-                for (uint32_t k = 0; k < count; ++k) {
-                    const uint32_t ti = triBase + triOff + k;
-                    const float4* tp = reinterpret_cast<const float4*>(tris + ti);
-                    const float4 a = tp[0], b = tp[1], c = tp[2];
-                    if (COUNT) ++cnt.tris;
-                    float t, bb, cc;
-                    if (!ray_triangle(org, dir, tmin, f3(a.x, a.y, a.z), f3(a.w, b.x, b.y), f3(b.z, b.w, c.x), t, bb, cc))
-                        continue;
-                    bool take = t < hit.t;
-                    if (!ANY_HIT && !take && t == hit.t && hit.tri != GFX_INVALID_SLOT) {
-                        // exact tie: lowest (instSlot, geomInstSlot, primIndex) wins
-                        const Bvh8Tri* o = tris + hit.tri;
-                        const uint32_t ni = __float_as_uint(c.y), ng = __float_as_uint(c.z), npm = __float_as_uint(c.w);
-                        take = ni < o->instSlot || (ni == o->instSlot && (ng < o->geomInstSlot ||
-                               (ng == o->geomInstSlot && npm < o->primIndex)));
-                    }
-                    if (take) {
-                        hit.t = t; hit.bcB = bb; hit.bcC = cc; hit.tri = ti;
-                        if (ANY_HIT) { active = false; return false; }
-                    }
-                }
+                if (internal) nodeHits |= 1u << (s ^ oct);
+                else leafMask |= ((1u << count) - 1u) << triOff;
             }
-            triOff += count;
+            triOff += internal ? 0u : count;
         }
+        if (leafMask) { triMask = leafMask; triBase = n1.y; }
         if (nodeHits) {
             if (grp.y & 0xFFu) stack.push(grp, cnt, COUNT);
             grp = make_uint2(n1.x, nodeHits | (imask << 8));
         }
-        return true;
     }
 };
 

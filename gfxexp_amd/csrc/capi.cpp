@@ -143,7 +143,7 @@ int gfx_accel_tri_ids(gfx_ctx* ctx, uint64_t handle, const void** dTriIds, uint3
 
 int gfx_accel_set_max_leaf(gfx_ctx* ctx, uint32_t maxLeafTris) {
     GFX_TRY(ctx)
-    ctx->c.maxLeafTris = maxLeafTris < 1 ? 1 : (maxLeafTris > 15 ? 15 : maxLeafTris);
+    ctx->c.maxLeafTris = maxLeafTris < 1 ? 1 : (maxLeafTris > 4 ? 4 : maxLeafTris);   // 8 children x 4 = one 32-bit triangle mask
     GFX_CATCH(ctx)
 }
 

@@ -75,7 +75,8 @@ struct DevScene {
 //   w[5]     index of the first triangle record of this node's leaf children (contiguous, slot order)
 //   w[6+s]   child s: qminx | qminy<<6 | qminz<<12 | qmaxx<<18 | qmaxy<<24 | (count & 3) << 30
 //   w[14..15] bytes: child s: qmaxz | (count >> 2) << 6
-// count: number of triangles of a leaf child (1..15), 1 for an internal child, 0 = empty slot.
+// count: number of triangles of a leaf child (1..4; the field has room for 15), 1 for an internal
+// child, 0 = empty slot.  A node's leaf triangles total <= 32 so traversal tracks them in one mask.
 // Child slots are assigned so that slot bit k set <=> child lies on the +k side of the node centre
 // (greedy auction as in Ylitie et al. 2017), which lets traversal order children by
 // (slot XOR ray-octant) without sorting.  The reference layout is the 80-byte
@@ -83,14 +84,25 @@ struct DevScene {
 struct Bvh8Node { uint32_t w[16]; };
 static_assert(sizeof(Bvh8Node) == 64, "Bvh8Node must be 64 bytes");
 
-// 48-byte triangle record = shared::TriangleStorage (common/common_shared.h:1017-1025) with the
-// padding word used for the instance slot.
+// 64-byte triangle record: shared::TriangleStorage (common/common_shared.h:1017-1025, 48 B) plus
+// the ray-independent terms of the reference's ray/triangle test (bvh_builder.cpp:1256-1258),
+// precomputed by the builder with the same fp32 operations: one aligned 64-byte fetch per test,
+// the same size as a node, so a wave can fetch nodes and triangles with one cooperative pattern.
 struct Bvh8Tri {
+    float ax, ay, az, eABx;          // pA, eAB = pB - pA
+    float eABy, eABz, eCAx, eCAy;    // eCA = pA - pC
+    float eCAz, nx, ny, nz;          // n = cross(eCA, eAB)
+    uint32_t instSlot, geomInstSlot, primIndex, pad;
+};
+static_assert(sizeof(Bvh8Tri) == 64, "Bvh8Tri must be 64 bytes");
+
+// 48-byte world-space triangle used inside the builder (vertices + ids).
+struct BuildTri {
     float ax, ay, az, bx;
     float by, bz, cx, cy;
     float cz; uint32_t instSlot, geomInstSlot, primIndex;
 };
-static_assert(sizeof(Bvh8Tri) == 48, "Bvh8Tri must be 48 bytes");
+static_assert(sizeof(BuildTri) == 48, "BuildTri must be 48 bytes");
 
 struct DevAccel {
     const Bvh8Node* nodes;

@@ -25,7 +25,7 @@ GFX_DEV uint32_t ordered_from_float(float f) { const uint32_t u = f2bits(f); ret
 GFX_DEV float float_from_ordered(uint32_t o) { const uint32_t u = o ^ (o >= 0x80000000u ? 0x80000000u : 0xFFFFFFFFu); return bits2f(u); }
 
 struct Box { f3 lo, hi; };
-GFX_DEV Box tri_box(const Bvh8Tri& t) {
+GFX_DEV Box tri_box(const BuildTri& t) {
     Box b;
     b.lo = f3(fminf(fminf(t.ax, t.bx), t.cx), fminf(fminf(t.ay, t.by), t.cy), fminf(fminf(t.az, t.bz), t.cz));
     b.hi = f3(fmaxf(fmaxf(t.ax, t.bx), t.cx), fmaxf(fmaxf(t.ay, t.by), t.cy), fmaxf(fmaxf(t.az, t.bz), t.cz));
@@ -39,24 +39,37 @@ GFX_DEV Box box_union(const Box& a, const Box& b) {
 }
 GFX_DEV float half_area(const Box& b) { const f3 d = b.hi - b.lo; return d.x * d.y + d.y * d.z + d.z * d.x; }
 
-GFX_DEV Bvh8Tri load_tri(const Bvh8Tri* p) {
+GFX_DEV BuildTri load_tri(const BuildTri* p) {
     const float4* q = reinterpret_cast<const float4*>(p);
     const float4 a = q[0], b = q[1], c = q[2];
-    Bvh8Tri t;
+    BuildTri t;
     t.ax = a.x; t.ay = a.y; t.az = a.z; t.bx = a.w; t.by = b.x; t.bz = b.y; t.cx = b.z; t.cy = b.w; t.cz = c.x;
     t.instSlot = f2bits(c.y); t.geomInstSlot = f2bits(c.z); t.primIndex = f2bits(c.w);
     return t;
 }
-GFX_DEV void store_tri(Bvh8Tri* p, const Bvh8Tri& t) {
+GFX_DEV void store_tri(BuildTri* p, const BuildTri& t) {
     float4* q = reinterpret_cast<float4*>(p);
     q[0] = make_float4(t.ax, t.ay, t.az, t.bx);
     q[1] = make_float4(t.by, t.bz, t.cx, t.cy);
     q[2] = make_float4(t.cz, bits2f(t.instSlot), bits2f(t.geomInstSlot), bits2f(t.primIndex));
 }
+// Final 64-byte traversal record: pA and the ray-independent terms of testRayVsTriangle
+// (common/bvh_builder.cpp:1256-1258), computed with exactly those fp32 operations.
+GFX_DEV void store_final_tri(Bvh8Tri* p, const BuildTri& t) {
+    const f3 pA(t.ax, t.ay, t.az), pB(t.bx, t.by, t.bz), pC(t.cx, t.cy, t.cz);
+    const f3 eAB = pB - pA;
+    const f3 eCA = pA - pC;
+    const f3 n = cross(eCA, eAB);
+    float4* q = reinterpret_cast<float4*>(p);
+    q[0] = make_float4(pA.x, pA.y, pA.z, eAB.x);
+    q[1] = make_float4(eAB.y, eAB.z, eCA.x, eCA.y);
+    q[2] = make_float4(eCA.z, n.x, n.y, n.z);
+    q[3] = make_float4(bits2f(t.instSlot), bits2f(t.geomInstSlot), bits2f(t.primIndex), 0.0f);
+}
 
 // ---------------------------------------------------------------- 1. flatten
 __global__ void k_flatten(DevScene sc, const DevFlatGeom* __restrict__ flat, uint32_t numFlat, uint32_t n,
-                          Bvh8Tri* __restrict__ out, uint32_t* __restrict__ bounds /* ordered lo xyz, hi xyz */) {
+                          BuildTri* __restrict__ out, uint32_t* __restrict__ bounds /* ordered lo xyz, hi xyz */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     f3 lo(INFINITY), hi(-INFINITY);
     if (i < n) {
@@ -74,7 +87,7 @@ __global__ void k_flatten(DevScene sc, const DevFlatGeom* __restrict__ flat, uin
         const f3 pA = xfm_point(xfm, f3(vA.px, vA.py, vA.pz));
         const f3 pB = xfm_point(xfm, f3(vB.px, vB.py, vB.pz));
         const f3 pC = xfm_point(xfm, f3(vC.px, vC.py, vC.pz));
-        Bvh8Tri t;
+        BuildTri t;
         t.ax = pA.x; t.ay = pA.y; t.az = pA.z; t.bx = pB.x; t.by = pB.y; t.bz = pB.z; t.cx = pC.x; t.cy = pC.y; t.cz = pC.z;
         t.instSlot = fg.instSlot; t.geomInstSlot = fg.geomInstSlot; t.primIndex = prim;
         store_tri(out + i, t);
@@ -102,7 +115,7 @@ GFX_DEV uint64_t spread21(uint32_t v) {
     x = (x | x << 2) & 0x1249249249249249ull;
     return x;
 }
-__global__ void k_morton(const Bvh8Tri* __restrict__ tris, uint32_t n, const uint32_t* __restrict__ bounds,
+__global__ void k_morton(const BuildTri* __restrict__ tris, uint32_t n, const uint32_t* __restrict__ bounds,
                          uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -155,7 +168,7 @@ __global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restr
 }
 
 // ---------------------------------------------------------------- 4. fit
-__global__ void k_fit(const Bvh8Tri* __restrict__ tris, const uint32_t* __restrict__ sortedIdx, int n,
+__global__ void k_fit(const BuildTri* __restrict__ tris, const uint32_t* __restrict__ sortedIdx, int n,
                       const int2* __restrict__ lr, const uint32_t* __restrict__ parentInt, const uint32_t* __restrict__ parentLeaf,
                       uint32_t* __restrict__ flags, float* nodeBoxes /* 8 floats per internal node */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,7 +217,7 @@ struct WideChild {
     Box box;
 };
 
-GFX_DEV void load_child(int ref, const Bvh8Tri* __restrict__ tris, const uint32_t* __restrict__ sortedIdx,
+GFX_DEV void load_child(int ref, const BuildTri* __restrict__ tris, const uint32_t* __restrict__ sortedIdx,
                         const float* __restrict__ nodeBoxes, const uint2* __restrict__ ranges, WideChild& c) {
     c.ref = ref;
     if (ref < 0) {
@@ -224,7 +237,7 @@ GFX_DEV void load_child(int ref, const Bvh8Tri* __restrict__ tris, const uint32_
 __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
                                  const uint2* __restrict__ queueIn, uint2* __restrict__ queueOut, uint32_t* __restrict__ counters,
                                  const int2* __restrict__ lr, const uint2* __restrict__ ranges, const float* __restrict__ nodeBoxes,
-                                 const Bvh8Tri* __restrict__ trisIn, const uint32_t* __restrict__ sortedIdx,
+                                 const BuildTri* __restrict__ trisIn, const uint32_t* __restrict__ sortedIdx,
                                  Bvh8Node* __restrict__ nodesOut, Bvh8Tri* __restrict__ trisOut) {
     const uint32_t numItems = counters[2 + level];
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < numItems; item += gridDim.x * blockDim.x) {
@@ -342,7 +355,7 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
             }
             else {
                 for (uint32_t t = 0; t < cnt; ++t)
-                    store_tri(trisOut + triBase + triOff + t, load_tri(trisIn + sortedIdx[ch[k].first + t]));
+                    store_final_tri(trisOut + triBase + triOff + t, load_tri(trisIn + sortedIdx[ch[k].first + t]));
                 triOff += cnt;
             }
         }
@@ -355,9 +368,9 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
 }
 
 // single-triangle scene: one node, one leaf child in slot 0
-__global__ void k_single_tri_root(const Bvh8Tri* __restrict__ trisIn, Bvh8Node* __restrict__ nodesOut, Bvh8Tri* __restrict__ trisOut) {
+__global__ void k_single_tri_root(const BuildTri* __restrict__ trisIn, Bvh8Node* __restrict__ nodesOut, Bvh8Tri* __restrict__ trisOut) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const Bvh8Tri t = load_tri(trisIn);
+    const BuildTri t = load_tri(trisIn);
     const Box b = tri_box(t);
     Bvh8Node node;
     for (int i = 0; i < 16; ++i) node.w[i] = 0;
@@ -381,7 +394,7 @@ __global__ void k_single_tri_root(const Bvh8Tri* __restrict__ trisIn, Bvh8Node* 
     dst[1] = make_uint4(node.w[4], node.w[5], node.w[6], node.w[7]);
     dst[2] = make_uint4(node.w[8], node.w[9], node.w[10], node.w[11]);
     dst[3] = make_uint4(node.w[12], node.w[13], node.w[14], node.w[15]);
-    store_tri(trisOut, t);
+    store_final_tri(trisOut, t);
 }
 
 __global__ void k_tri_ids(const Bvh8Tri* __restrict__ tris, uint32_t n, gfx_tri_ids* __restrict__ ids) {
@@ -403,7 +416,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
     const uint32_t numFlat = static_cast<uint32_t>(ctx.hFlatGeoms.size());
     const dim3 blk(256), grd((n + 255) / 256);
 
-    ctx.bTris.reserve(sizeof(Bvh8Tri) * static_cast<size_t>(n));
+    ctx.bTris.reserve(sizeof(BuildTri) * static_cast<size_t>(n));
     ctx.bKeys.reserve(8ull * n); ctx.bKeysAlt.reserve(8ull * n);
     ctx.bVals.reserve(4ull * n); ctx.bValsAlt.reserve(4ull * n);
     ctx.bNodesLR.reserve(8ull * n); ctx.bParents.reserve(8ull * n + 16); ctx.bFlags.reserve(4ull * n);
@@ -425,13 +438,13 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
         GFX_HIP(hipStreamSynchronize(stream));
     }
     hipLaunchKernelGGL(k_flatten, grd, blk, 0, stream, ctx.devScene(), ctx.dFlatGeoms.as<DevFlatGeom>(), numFlat, n,
-                       ctx.bTris.as<Bvh8Tri>(), bounds);
+                       ctx.bTris.as<BuildTri>(), bounds);
     if (n == 1) {
-        hipLaunchKernelGGL(k_single_tri_root, dim3(1), dim3(64), 0, stream, ctx.bTris.as<Bvh8Tri>(), out.nodes.as<Bvh8Node>(), out.tris.as<Bvh8Tri>());
+        hipLaunchKernelGGL(k_single_tri_root, dim3(1), dim3(64), 0, stream, ctx.bTris.as<BuildTri>(), out.nodes.as<Bvh8Node>(), out.tris.as<Bvh8Tri>());
         out.numNodes = 1; out.numTris = 1; out.maxDepth = 1;
     }
     else {
-        hipLaunchKernelGGL(k_morton, grd, blk, 0, stream, ctx.bTris.as<Bvh8Tri>(), n, bounds, ctx.bKeys.as<uint64_t>(), ctx.bVals.as<uint32_t>());
+        hipLaunchKernelGGL(k_morton, grd, blk, 0, stream, ctx.bTris.as<BuildTri>(), n, bounds, ctx.bKeys.as<uint64_t>(), ctx.bVals.as<uint32_t>());
         size_t tempBytes = 0;
         GFX_HIP(rocprim::radix_sort_pairs(nullptr, tempBytes, ctx.bKeys.as<uint64_t>(), ctx.bKeysAlt.as<uint64_t>(),
                                           ctx.bVals.as<uint32_t>(), ctx.bValsAlt.as<uint32_t>(), n, 0, 63, stream));
@@ -445,7 +458,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
         hipLaunchKernelGGL(k_karras, grd, blk, 0, stream, keys, static_cast<int>(n), ctx.bNodesLR.as<int2>(), parentInt, parentLeaf,
                            ctx.bRanges.as<uint2>());
         GFX_HIP(hipMemsetAsync(ctx.bFlags.p, 0, 4ull * n, stream));
-        hipLaunchKernelGGL(k_fit, grd, blk, 0, stream, ctx.bTris.as<Bvh8Tri>(), sortedIdx, static_cast<int>(n), ctx.bNodesLR.as<int2>(),
+        hipLaunchKernelGGL(k_fit, grd, blk, 0, stream, ctx.bTris.as<BuildTri>(), sortedIdx, static_cast<int>(n), ctx.bNodesLR.as<int2>(),
                            parentInt, parentLeaf, ctx.bFlags.as<uint32_t>(), ctx.bNodeBoxes.as<float>());
         // level 0 work item: binary root 0 -> wide node 0
         const uint2 rootItem = make_uint2(0u, 0u);
@@ -456,7 +469,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
             uint2* qout = (level & 1) ? ctx.bQueueA.as<uint2>() : ctx.bQueueB.as<uint2>();
             hipLaunchKernelGGL(k_collapse_level, dim3(gridC), dim3(256), 0, stream, level, ctx.maxLeafTris, qin, qout, counters,
                                ctx.bNodesLR.as<int2>(), ctx.bRanges.as<uint2>(), ctx.bNodeBoxes.as<float>(),
-                               ctx.bTris.as<Bvh8Tri>(), sortedIdx, out.nodes.as<Bvh8Node>(), out.tris.as<Bvh8Tri>());
+                               ctx.bTris.as<BuildTri>(), sortedIdx, out.nodes.as<Bvh8Node>(), out.tris.as<Bvh8Tri>());
         }
         GFX_HIP(hipGetLastError());
         std::vector<uint32_t> h(2 + kMaxCollapseLevels + 2);

@@ -7,13 +7,15 @@
 // kRefillThreshold lanes are idle and the queue is not exhausted, the wave takes one atomic ticket
 // for exactly popcount(idle) rays (ballot + mbcnt compaction) and the idle lanes start new rays
 // while the others keep traversing -- the SIMT analogue of OptiX's hardware ray scheduling.
+#include <cstdlib>
 #include "bvh8.hip.h"
 #include "internal.h"
 
 namespace gfx {
 
 constexpr int kTraceBlock = 256;
-constexpr int kRefillThreshold = 16;
+constexpr int kRefillThreshold = 8;
+constexpr int kTicketBatch = 64;   // rays bought per device atomic (tuned: 32 and 128 are slower)
 
 struct TraceArgs {
     DevAccel accel;
@@ -25,13 +27,48 @@ struct TraceArgs {
     uint32_t* ticket;           // queue head (zeroed before the launch)
     uint2* spill;               // kSpillStackDepth entries per thread of the grid
     unsigned long long* counters; // optional: node fetches, triangle fetches, rays, spills
+    int refillThreshold;        // refill when at least this many lanes are idle
+    int ticketBatch;            // rays bought per device atomic
 };
+
+// Cooperative fetch of one 64-byte item (node or triangle record) per lane.
+// A per-lane gather of 64 B costs four dwordx4 instructions whose 64 lanes all touch different
+// cache lines: 256 line requests per wave-iteration, and the CU's texture-addresser (one line
+// request per clock) is what the kernel was bound by (profiles/r01b: same time at 2 and 6 blocks
+// per CU).  Here four neighbouring lanes fetch the four 16-byte quarters of ONE item with a
+// global->LDS DMA (global_load_lds_dwordx4, no VGPR round trip), so each instruction issues 16
+// line requests instead of 64, and every lane then reads its own item back from LDS with four
+// ds_read_b128.  LDS-DMA writes lane-linearly (base + lane * 16), so the quarter a lane fetches is
+// XOR-swizzled with (item >> 2) & 3 to make those reads bank-conflict free.
+GFX_DEV void fetch_items(uint32_t code, const DevAccel& acc, uint4* waveBuf /* 256 x 16 B, wave-private */, int lane,
+                         uint4& q0, uint4& q1, uint4& q2, uint4& q3) {
+    const char* nodeBase = reinterpret_cast<const char*>(acc.nodes);
+    const char* triBase = reinterpret_cast<const char*>(acc.tris);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int item = 16 * k + (lane >> 2);              // whose item this lane helps to fetch
+        const uint32_t c = __shfl(code, item);
+        if (c != kItemNone) {
+            const uint32_t quarter = (lane & 3) ^ ((item >> 2) & 3);
+            const char* src = ((c & kItemTri) ? triBase : nodeBase) + (static_cast<size_t>(c & 0x7FFFFFFFu) << 6) + (quarter << 4);
+            typedef const __attribute__((address_space(1))) void* GlobalPtr;
+            typedef __attribute__((address_space(3))) void* LdsPtr;
+            __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)(waveBuf + 64 * k), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int sw = (lane >> 2) & 3;
+    const uint4* mine = waveBuf + 4 * lane;
+    q0 = mine[0 ^ sw]; q1 = mine[1 ^ sw]; q2 = mine[2 ^ sw]; q3 = mine[3 ^ sw];
+}
 
 template <bool ANY_HIT, bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kTraceBlock];
+    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[kTraceBlock * 4];   // 4 KiB per wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    uint4* waveBuf = fetchBuf + 256 * (tid >> 6);
     LaneStack stack;
     stack.lds = ldsStack + tid;
     stack.ldsStride = kTraceBlock;
@@ -44,48 +81,66 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
     tr.active = false;
     uint32_t rayIdx = 0;
     bool exhausted = false;           // wave-uniform: the queue has no more rays
+    uint32_t waveNext = 0, waveEnd = 0; // wave-uniform: rays [waveNext, waveEnd) already ticketed for this wave
     TraceCounters cnt = { 0, 0, 0 };
     uint32_t raysDone = 0;
+
+    auto write_result = [&]() {
+        if (ANY_HIT) static_cast<uint32_t*>(a.out)[rayIdx] = tr.hit.tri != GFX_INVALID_SLOT ? 1u : 0u;
+        else {
+            gfx_hit h; h.dist = tr.hit.t; h.bcB = tr.hit.bcB; h.bcC = tr.hit.bcC; h.triIndex = tr.hit.tri;
+            static_cast<gfx_hit*>(a.out)[rayIdx] = h;
+        }
+        if (COUNT) ++raysDone;
+    };
 
     while (true) {
         const unsigned long long idleMask = __ballot(!tr.active);
         const int numIdle = __popcll(idleMask);
-        if (!exhausted && numIdle >= kRefillThreshold) {
-            uint32_t base = 0;
-            if (lane == __builtin_ctzll(idleMask)) base = atomicAdd(a.ticket, static_cast<uint32_t>(numIdle));
-            base = __shfl(base, __builtin_ctzll(idleMask));
-            if (base + numIdle >= n) exhausted = true;
+        if (!exhausted && numIdle >= a.refillThreshold) {
+            // wave-local ticket range: one device atomic buys a batch of rays, bought on demand
+            // (buying ahead of need strands rays in waves that finish late; measured slower)
+            if (waveNext == waveEnd) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.ticket, static_cast<uint32_t>(a.ticketBatch));
+                base = __shfl(base, 0);
+                if (base >= n) exhausted = true;
+                else { waveNext = base; waveEnd = min(base + static_cast<uint32_t>(a.ticketBatch), n); }
+            }
+            const uint32_t take = min(static_cast<uint32_t>(numIdle), waveEnd - waveNext);
             if (!tr.active) {
                 const uint32_t rank = __popcll(idleMask & ((1ull << lane) - 1ull));
-                const uint32_t i = base + rank;
-                if (i < n) {
+                if (rank < take) {
+                    const uint32_t i = waveNext + rank;
                     const float4 o = a.rayOrgTmin[i];
                     const float4 d = a.rayDirTmax[i];
                     rayIdx = i;
                     tr.begin(f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, d.w, stack, hasNodes);
                     if (!hasNodes || !(d.w > o.w)) {   // empty interval or empty scene: immediate miss
                         tr.active = false;
-                        if (ANY_HIT) static_cast<uint32_t*>(a.out)[i] = 0u;
-                        else { gfx_hit h; h.dist = d.w; h.bcB = 0; h.bcC = 0; h.triIndex = GFX_INVALID_SLOT; static_cast<gfx_hit*>(a.out)[i] = h; }
-                        if (COUNT) ++raysDone;
+                        write_result();
                     }
                 }
             }
+            waveNext += take;
         }
         if (__ballot(tr.active) == 0ull) {
             if (exhausted) break;
             continue;
         }
+        uint32_t code = kItemNone;
         if (tr.active) {
-            const bool more = tr.template step<ANY_HIT, COUNT>(a.accel, stack, cnt);
-            if (!more) {
-                if (ANY_HIT) static_cast<uint32_t*>(a.out)[rayIdx] = tr.hit.tri != GFX_INVALID_SLOT ? 1u : 0u;
-                else {
-                    gfx_hit h; h.dist = tr.hit.t; h.bcB = tr.hit.bcB; h.bcC = tr.hit.bcC; h.triIndex = tr.hit.tri;
-                    static_cast<gfx_hit*>(a.out)[rayIdx] = h;
-                }
-                if (COUNT) ++raysDone;
+            code = tr.next_item(stack);
+            if (code == kItemNone) write_result();          // traversal finished
+        }
+        uint4 q0, q1, q2, q3;
+        fetch_items(code, a.accel, waveBuf, lane, q0, q1, q2, q3);
+        if (code != kItemNone) {
+            if (code & kItemTri) {
+                if (!tr.template process_triangle<ANY_HIT, COUNT>(code & 0x7FFFFFFFu, q0, q1, q2, q3, a.accel.tris, cnt))
+                    write_result();                         // any-hit ray found its occluder
             }
+            else tr.template process_node<COUNT>(q0, q1, q2, q3, stack, cnt);
         }
     }
     if (COUNT && a.counters) {
@@ -106,7 +161,13 @@ static uint32_t persistent_grid(Context& ctx) {
         GFX_HIP(hipGetDeviceProperties(&prop, ctx.device));
         numCUs = prop.multiProcessorCount;
     }
-    return static_cast<uint32_t>(numCUs) * 4u;   // 4 blocks of 256 per CU (LDS: 4 x 24 KiB)
+    static int blocksPerCU = 0;
+    if (!blocksPerCU) {
+        const char* e = getenv("GFX_TRACE_BLOCKS_PER_CU");   // tuning knob; default 4 blocks of 256 per CU (LDS: 4 x 40 KiB)
+        blocksPerCU = e ? atoi(e) : 4;
+        if (blocksPerCU < 1 || blocksPerCU > 8) blocksPerCU = 4;
+    }
+    return static_cast<uint32_t>(numCUs) * static_cast<uint32_t>(blocksPerCU);
 }
 
 void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
@@ -121,6 +182,12 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     a.numRaysPtr = t.numRaysPtr; a.numRays = t.numRays;
     a.out = t.out; a.ticket = ticket; a.spill = ctx.spill.as<uint2>();
     a.counters = ctx.countersEnabled ? ctx.dTraceCounters.as<unsigned long long>() : nullptr;
+    static int refill = 0;
+    if (!refill) { const char* e = getenv("GFX_TRACE_REFILL"); refill = e ? atoi(e) : kRefillThreshold; if (refill < 1 || refill > 64) refill = kRefillThreshold; }
+    a.refillThreshold = refill;
+    static int batch = 0;
+    if (!batch) { const char* e = getenv("GFX_TRACE_BATCH"); batch = e ? atoi(e) : kTicketBatch; if (batch < 1 || batch > 65536) batch = kTicketBatch; }
+    a.ticketBatch = batch;
     const bool any = t.mode == GFX_TRACE_ANY;
     ScopedKernelTimer timer(ctx, stream, any ? "trace_any" : "trace_closest");
     if (ctx.countersEnabled) {

@@ -112,7 +112,7 @@ int gfx_instance_set_transform(gfx_ctx* ctx, uint32_t instSlot, const float xfm[
  * LBVH -> BVH8 over all instances (world space).  The 64-bit handle fits the reference's
  * perFramePlp.travHandle field (restir_di_main.cpp:2264). */
 int gfx_accel_build(gfx_ctx* ctx, void* stream, uint64_t* handle);
-/* Leaf size limit of the collapse step, 1..15 (default 4); GeometryBVHBuildConfig::maxNumPrimsPerLeaf,
+/* Leaf size limit of the collapse step, 1..4 (default 4; a node's leaf triangles fit one 32-bit mask); GeometryBVHBuildConfig::maxNumPrimsPerLeaf,
  * common/bvh_builder.h:38-44. */
 int gfx_accel_set_max_leaf(gfx_ctx* ctx, uint32_t maxLeafTris);
 /* Build statistics of the last gfx_accel_build: {numTriangles, numNodes, numTriRecords, maxDepth}. */
