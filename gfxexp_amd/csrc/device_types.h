@@ -33,15 +33,40 @@ static_assert(sizeof(DevGeomInst) == 32, "DevGeomInst must be 32 bytes");
 struct DevInstance {
     float transform[12];        // 3x4 row-major
     float curToPrevTransform[12];
-    float normalMatrix[9];      // row-major
-    float uniformScale;
-    uint32_t slotsOffset;       // geomInstSlots offset in the slot pool
-    uint32_t numGeomInsts;
+    float normalMatrix[12];     // 3 rows padded to float4 (three aligned 16-byte loads)
+    // ---- one aligned 16-byte chunk: everything sample_light needs after the instance search
     uint32_t distOffset;        // lightGeomInstDist offset in the light pools (or ~0u)
+    uint32_t numGeomInsts;
     float distIntegral;
+    uint32_t slotsOffset;       // geomInstSlots offset in the slot pool
+    float uniformScale;
+    uint32_t pad[3];
+};
+static_assert(sizeof(DevInstance) == 176, "DevInstance must be 176 bytes");
+
+// Per (instance, geomInst-in-instance) entry, parallel to the instance's lightGeomInstDist slice of
+// the light pools: what sample_light needs once the geometry instance has been chosen.
+struct LightGeomRef {
+    uint32_t recBase;           // first EmitterRec of this (instance, geomInst) or ~0u
+    uint32_t distOffset;        // emitterPrimDist slice in the light pools
+    uint32_t distCount;
+    float distIntegral;
+};
+static_assert(sizeof(LightGeomRef) == 16, "LightGeomRef must be 16 bytes");
+
+// Pre-transformed emitter triangle (one per emissive triangle per instance), 96 B = six aligned
+// 16-byte loads instead of the ~30 scattered loads of triangle -> 3 vertices -> transform -> material:
+// world positions are inst.transform * v.position computed ONCE with the same fp32 operations
+// sampleLight performs per candidate (restir_di_shared.h:412-414); normals stay in object space
+// (the normal matrix is applied to the interpolated normal, :501-502).
+struct EmitterRec {
+    float pA[3], pB[3], pC[3];
+    float nA[3], nB[3], nC[3];
+    float emittance[3];
+    uint32_t instSlot;
     uint32_t pad[2];
 };
-static_assert(sizeof(DevInstance) == 160, "DevInstance must be 160 bytes");
+static_assert(sizeof(EmitterRec) == 96, "EmitterRec must be 96 bytes");
 
 // One entry per (instance, geomInst) pair in (instSlot asc, list order) enumeration: the
 // "geometry" list the BVH is built over (bvh::Geometry + preTransform, common/bvh_builder.h:26-36).
@@ -62,6 +87,8 @@ struct DevScene {
     const uint32_t* geomInstSlotPool;
     const float* lightWeights;
     const float* lightCDF;
+    const LightGeomRef* lightGeomRefs;   // indexed like the light pools (inst.distOffset + i)
+    const EmitterRec* emitterRecs;
     const float* lightInstIntegral; // device-resident integral of the level-0 distribution
     uint32_t lightInstDistOffset;   // level-0 distribution
     uint32_t numInsts;

@@ -69,7 +69,9 @@ struct Context {
     std::vector<HostInstance> insts;
     bool sceneDirty = true;
     // scene (device)
-    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightCDF;
+    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightCDF, dLightRefs, dEmitterRecs;
+    std::vector<LightGeomRef> hLightRefs;
+    uint32_t numEmitterRecs = 0;
     std::vector<DevGeomInst> hGeomInsts;
     std::vector<DevInstance> hInsts;
     std::vector<DevFlatGeom> hFlatGeoms;

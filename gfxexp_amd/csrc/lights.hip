@@ -74,6 +74,47 @@ __global__ void k_inst_geom_dists(DevInstance* __restrict__ insts, uint32_t numI
     inst->distIntegral = inst->numGeomInsts ? last + lastW : 0.0f;
 }
 
+// Per (instance, geomInst): copy the emitter distribution's integral next to its offsets and
+// pre-transform the emitter triangles (EmitterRec, device_types.h).  One block per instance.
+__global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* __restrict__ refs, EmitterRec* __restrict__ recs) {
+    const uint32_t ii = blockIdx.x;
+    if (ii >= numInsts) return;
+    const DevInstance* inst = sc.insts + ii;
+    if (inst->distOffset == 0xFFFFFFFFu) return;
+    const m34 xfm = load_m34(inst->transform);
+    for (uint32_t k = 0; k < inst->numGeomInsts; ++k) {
+        const DevGeomInst g = sc.geomInsts[sc.geomInstSlotPool[inst->slotsOffset + k]];
+        LightGeomRef* ref = refs + inst->distOffset + k;
+        if (threadIdx.x == 0) ref->distIntegral = g.distIntegral;
+        const uint32_t recBase = ref->recBase;
+        if (recBase == 0xFFFFFFFFu) continue;
+        const gfx_material& mat = sc.materials[g.materialSlot];
+        for (uint32_t t = threadIdx.x; t < g.numTriangles; t += blockDim.x) {
+            const uint32_t* tri = sc.triangles + 3ull * (g.triangleOffset + t);
+            const DevVertex vA = load_vertex(sc.vertices + g.vertexOffset + tri[0]);
+            const DevVertex vB = load_vertex(sc.vertices + g.vertexOffset + tri[1]);
+            const DevVertex vC = load_vertex(sc.vertices + g.vertexOffset + tri[2]);
+            const f3 pA = xfm_point(xfm, f3(vA.px, vA.py, vA.pz));
+            const f3 pB = xfm_point(xfm, f3(vB.px, vB.py, vB.pz));
+            const f3 pC = xfm_point(xfm, f3(vC.px, vC.py, vC.pz));
+            EmitterRec r;
+            r.pA[0] = pA.x; r.pA[1] = pA.y; r.pA[2] = pA.z;
+            r.pB[0] = pB.x; r.pB[1] = pB.y; r.pB[2] = pB.z;
+            r.pC[0] = pC.x; r.pC[1] = pC.y; r.pC[2] = pC.z;
+            r.nA[0] = vA.nx; r.nA[1] = vA.ny; r.nA[2] = vA.nz;
+            r.nB[0] = vB.nx; r.nB[1] = vB.ny; r.nB[2] = vB.nz;
+            r.nC[0] = vC.nx; r.nC[1] = vC.ny; r.nC[2] = vC.nz;
+            // emittance = RGB(1) * texel for an emitter material (restir_di_shared.h:504-514)
+            const f3 e = mat.hasEmittance ? f3(1.0f) * f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]) : f3(0.0f);
+            r.emittance[0] = e.x; r.emittance[1] = e.y; r.emittance[2] = e.z;
+            r.instSlot = ii; r.pad[0] = r.pad[1] = 0;
+            float4* dst = reinterpret_cast<float4*>(recs + recBase + t);
+            const float4* src = reinterpret_cast<const float4*>(&r);
+            for (int q = 0; q < 6; ++q) dst[q] = src[q];
+        }
+    }
+}
+
 __global__ void k_inst_importance(const DevInstance* __restrict__ insts, uint32_t numInsts, uint32_t off, float* __restrict__ weights) {
     const uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
     if (ii >= numInsts) return;
@@ -113,6 +154,9 @@ void lights_build_static(Context& ctx, hipStream_t stream) {
         hipLaunchKernelGGL(k_inst_geom_dists, dim3((ni + 63) / 64), dim3(64), 0, stream,
                            ctx.dInsts.as<DevInstance>(), ni, ctx.dGeomInsts.as<DevGeomInst>(), ctx.dSlotPool.as<uint32_t>(),
                            ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>());
+    if (ni)
+        hipLaunchKernelGGL(k_emitter_records, dim3(ni), dim3(64), 0, stream, ctx.devScene(), ni,
+                           ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>());
     GFX_HIP(hipGetLastError());
     // keep the host mirrors of the integrals current (read by gfx_lights_read and the launch params)
     GFX_HIP(hipMemcpyAsync(ctx.hGeomInsts.data(), ctx.dGeomInsts.p, sizeof(DevGeomInst) * ng, hipMemcpyDeviceToHost, stream));

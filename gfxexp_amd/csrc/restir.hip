@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
         const float tv = bcA * vA.v + bcB * vB.v + bcC * vC.v;
         const f3 geomNormalInObj = cross(pBo - pAo, pCo - pAo);
         const m34 xfm = load_m34(inst->transform);
-        const m33 nrm = load_m33(inst->normalMatrix);
+        const m33 nrm = load_m33_rows(inst->normalMatrix);
         positionInWorld = xfm_point(xfm, positionInObj);
         prevPositionInWorld = xfm_point(load_m34(inst->curToPrevTransform), positionInWorld);
         f3 geomNormalInWorld = unit(mul(nrm, geomNormalInObj));
@@ -306,7 +306,19 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
 
 // ---------------------------------------------------------------- INITIAL (+ TEMPORAL)
 // candidate loop + visibility-ray emission: optix_restir_di_kernels.cu:57-133
+// The instance-level CDF (searched 32 times per pixel, log2(numInsts) dependent loads each) is
+// staged in LDS once per block when it fits (LDS_DIST); larger scenes search it in global memory.
+template <bool LDS_DIST>
 __global__ __launch_bounds__(kBlock) void k_initial_candidates(RestirArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ldsDist[];   // weights[numInsts] | CDF[numInsts]
+    const float* instWeights = a.scene.lightWeights + a.scene.lightInstDistOffset;
+    const float* instCDF = a.scene.lightCDF + a.scene.lightInstDistOffset;
+    if (LDS_DIST) {
+        const uint32_t ni = a.scene.numInsts;
+        for (uint32_t i = threadIdx.x; i < ni; i += kBlock) { ldsDist[i] = instWeights[i]; ldsDist[ni + i] = instCDF[i]; }
+        __syncthreads();
+        instWeights = ldsDist; instCDF = ldsDist + ni;
+    }
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     const uint32_t bufIdx = a.f.bufferIndex;
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_initial_candidates(RestirArgs a) {
             float pd;
             const float u0 = rng.uniform();
             const float u1 = rng.uniform();
-            sample_light(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
+            sample_light(a.scene, instWeights, instCDF, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
             const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
             pd *= probCurType;
             const float target = target_weight(cont);
@@ -785,7 +797,15 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     case GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED:
     case GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED:
         reset_queue();
-        launch_pixels(ctx, stream, "initial_candidates", k_initial_candidates, a);
+        {
+            const size_t numPx = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+            const uint32_t grid = static_cast<uint32_t>((numPx + kBlock - 1) / kBlock);
+            const size_t ldsBytes = 8ull * a.scene.numInsts;
+            ScopedKernelTimer timer(ctx, stream, "initial_candidates");
+            if (ldsBytes <= 64 * 1024) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), ldsBytes, stream, a);
+            else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);
+            GFX_HIP(hipGetLastError());
+        }
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
         if (pass == GFX_RESTIR_INITIAL_RIS) launch_pixels(ctx, stream, "temporal_none", k_temporal<0>, a);
         else if (pass == GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED) launch_pixels(ctx, stream, "temporal_biased", k_temporal<1>, a);

@@ -9,7 +9,7 @@ namespace gfx {
 
 Context::~Context() {
     for (Accel* a : accels) { if (a) { a->nodes.release(); a->tris.release(); a->triIds.release(); delete a; } }
-    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dLightW, &dLightCDF,
+    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dLightW, &dLightCDF, &dLightRefs, &dEmitterRecs,
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
                       &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral };
@@ -27,6 +27,8 @@ DevScene Context::devScene() const {
     s.geomInstSlotPool = dSlotPool.as<uint32_t>();
     s.lightWeights = dLightW.as<float>();
     s.lightCDF = dLightCDF.as<float>();
+    s.lightGeomRefs = dLightRefs.as<LightGeomRef>();
+    s.emitterRecs = dEmitterRecs.as<EmitterRec>();
     s.lightInstIntegral = dLightInstIntegral.as<float>();
     s.lightInstDistOffset = lightInstDistOffset;
     s.numInsts = static_cast<uint32_t>(insts.size());
@@ -36,7 +38,7 @@ DevScene Context::devScene() const {
 // normalMatrix = transpose(invert(upper-left 3x3)); Matrix3x3::invert is determinant + adjugate
 // scaled by 1/det (common/basic_types.h:4118-4157).  Written out so every product/sum happens in
 // the same order as in the kernels' gfx::inverse.
-static void normal_matrix(const float x[12], float out[9]) {
+static void normal_matrix(const float x[12], float out[12]) {
     const float a = x[0], b = x[1], c = x[2], d = x[4], e = x[5], f = x[6], g = x[8], h = x[9], i = x[10];
     const float det = a * e * i + b * f * g + c * d * h - c * e * g - b * d * i - a * f * h;
     const float r = 1 / det;
@@ -44,8 +46,10 @@ static void normal_matrix(const float x[12], float out[9]) {
         (e * i - f * h) * r, -(b * i - c * h) * r, (b * f - c * e) * r,
         -(d * i - f * g) * r, (a * i - c * g) * r, -(a * f - c * d) * r,
         (d * h - e * g) * r, -(a * h - b * g) * r, (a * e - b * d) * r };
-    for (int rr = 0; rr < 3; ++rr)
-        for (int cc = 0; cc < 3; ++cc) out[rr * 3 + cc] = inv[cc * 3 + rr];
+    for (int rr = 0; rr < 3; ++rr) {
+        for (int cc = 0; cc < 3; ++cc) out[rr * 4 + cc] = inv[cc * 3 + rr];
+        out[rr * 4 + 3] = 0.0f;
+    }
 }
 
 template <typename T>
@@ -105,9 +109,23 @@ void scene_upload(Context& ctx, hipStream_t stream) {
         d.distOffset = hasEmitter ? lightPool : 0xFFFFFFFFu;
         d.distIntegral = 0;
         if (hasEmitter) lightPool += d.numGeomInsts;
-        d.pad[0] = d.pad[1] = 0;
+        d.pad[0] = d.pad[1] = d.pad[2] = 0;
     }
     ctx.totalTriangles = triCursor;
+    // per (instance, geomInst) light references + pre-transformed emitter triangle records
+    ctx.hLightRefs.assign(lightPool + ctx.insts.size(), LightGeomRef{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0.0f });
+    uint32_t recCursor = 0;
+    for (size_t ii = 0; ii < ctx.insts.size(); ++ii) {
+        const DevInstance& d = ctx.hInsts[ii];
+        if (d.distOffset == 0xFFFFFFFFu) continue;
+        for (uint32_t k = 0; k < d.numGeomInsts; ++k) {
+            const DevGeomInst& g = ctx.hGeomInsts[slotPool[d.slotsOffset + k]];
+            LightGeomRef& r = ctx.hLightRefs[d.distOffset + k];
+            r.distOffset = g.distOffset; r.distCount = g.distCount; r.distIntegral = 0.0f;
+            if (g.distOffset != 0xFFFFFFFFu) { r.recBase = recCursor; recCursor += g.numTriangles; }
+        }
+    }
+    ctx.numEmitterRecs = recCursor;
     ctx.lightInstDistOffset = lightPool;
     lightPool += static_cast<uint32_t>(ctx.insts.size());
     ctx.lightPoolSize = lightPool;
@@ -122,6 +140,8 @@ void scene_upload(Context& ctx, hipStream_t stream) {
     upload(ctx.dTriangles, triangles, stream);
     upload(ctx.dSlotPool, slotPool, stream);
     upload(ctx.dFlatGeoms, ctx.hFlatGeoms, stream);
+    upload(ctx.dLightRefs, ctx.hLightRefs, stream);
+    ctx.dEmitterRecs.reserve(std::max<size_t>(sizeof(EmitterRec) * ctx.numEmitterRecs, 16));
     ctx.dLightW.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
     ctx.dLightCDF.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
     GFX_HIP(hipMemsetAsync(ctx.dLightW.p, 0, ctx.dLightW.bytes, stream));

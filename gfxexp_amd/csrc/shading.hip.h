@@ -364,15 +364,19 @@ GFX_DEV m34 load_m34(const float* __restrict__ p) {
     m.m[8] = c.x; m.m[9] = c.y; m.m[10] = c.z; m.m[11] = c.w;
     return m;
 }
-GFX_DEV m33 load_m33(const float* __restrict__ p) {
+GFX_DEV m33 load_m33_rows(const float* __restrict__ p) {   // 3 rows padded to float4
+    const float4* q = reinterpret_cast<const float4*>(p);
+    const float4 a = q[0], b = q[1], c = q[2];
     m33 m;
-    m.r0 = f3(p[0], p[1], p[2]); m.r1 = f3(p[3], p[4], p[5]); m.r2 = f3(p[6], p[7], p[8]);
+    m.r0 = f3(a.x, a.y, a.z); m.r1 = f3(b.x, b.y, b.z); m.r2 = f3(c.x, c.y, c.z);
     return m;
 }
 
 // sampleLight<false>.  Returns the area density; sample left untouched past an early out exactly
 // like the reference (the caller starts from a default-constructed LightSample).
-GFX_DEV void sample_light(const DevScene& sc, const EnvMap& env, float envRotation, float envPowerCoeff,
+// instWeights / instCDF: the instance-level distribution (level 0), usually an LDS copy.
+GFX_DEV void sample_light(const DevScene& sc, const float* instWeights, const float* instCDF,
+                          const EnvMap& env, float envRotation, float envPowerCoeff,
                           float ul, bool sampleEnv, float u0, float u1, LightSample& ls, float& areaPDensity) {
     if (sampleEnv) {
         float u, v, uvPDF;
@@ -393,33 +397,27 @@ GFX_DEV void sample_light(const DevScene& sc, const EnvMap& env, float envRotati
     }
     float lightProb = 1.0f;
     float instProb, uGeomInst;
-    const uint32_t instSlot = discrete_sample(sc.lightWeights + sc.lightInstDistOffset, sc.lightCDF + sc.lightInstDistOffset,
-                                              *sc.lightInstIntegral, sc.numInsts, ul, instProb, &uGeomInst);
+    const uint32_t instSlot = discrete_sample(instWeights, instCDF, *sc.lightInstIntegral, sc.numInsts, ul, instProb, &uGeomInst);
     lightProb *= instProb;
     if (instProb == 0.0f) { areaPDensity = 0.0f; return; }
     const DevInstance* inst = sc.insts + instSlot;
+    // (distOffset, numGeomInsts, distIntegral, slotsOffset) in one 16-byte load
+    const uint4 ih = *reinterpret_cast<const uint4*>(&inst->distOffset);
 
     float geomInstProb, uPrim;
-    const uint32_t gi = discrete_sample(sc.lightWeights + inst->distOffset, sc.lightCDF + inst->distOffset,
-                                        inst->distIntegral, inst->numGeomInsts, uGeomInst, geomInstProb, &uPrim);
-    const uint32_t geomInstSlot = sc.geomInstSlotPool[inst->slotsOffset + gi];
+    const uint32_t gi = discrete_sample(sc.lightWeights + ih.x, sc.lightCDF + ih.x, bits2f(ih.z), ih.y, uGeomInst, geomInstProb, &uPrim);
     lightProb *= geomInstProb;
     if (geomInstProb == 0.0f) { areaPDensity = 0.0f; return; }
-    const DevGeomInst g = sc.geomInsts[geomInstSlot];
+    const uint4 gr = *reinterpret_cast<const uint4*>(sc.lightGeomRefs + ih.x + gi);   // LightGeomRef
 
     float primProb;
-    const uint32_t prim = discrete_sample(sc.lightWeights + g.distOffset, sc.lightCDF + g.distOffset,
-                                          g.distIntegral, g.distCount, uPrim, primProb, nullptr);
+    const uint32_t prim = discrete_sample(sc.lightWeights + gr.y, sc.lightCDF + gr.y, bits2f(gr.w), gr.z, uPrim, primProb, nullptr);
     lightProb *= primProb;
 
-    const uint32_t* tri = sc.triangles + 3ull * (g.triangleOffset + prim);
-    const DevVertex vA = load_vertex(sc.vertices + g.vertexOffset + tri[0]);
-    const DevVertex vB = load_vertex(sc.vertices + g.vertexOffset + tri[1]);
-    const DevVertex vC = load_vertex(sc.vertices + g.vertexOffset + tri[2]);
-    const m34 xfm = load_m34(inst->transform);
-    const f3 pA = xfm_point(xfm, f3(vA.px, vA.py, vA.pz));
-    const f3 pB = xfm_point(xfm, f3(vB.px, vB.py, vB.pz));
-    const f3 pC = xfm_point(xfm, f3(vC.px, vC.py, vC.pz));
+    const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + gr.x + prim);
+    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
+    const f3 pA(r0.x, r0.y, r0.z), pB(r0.w, r1.x, r1.y), pC(r1.z, r1.w, r2.x);
+    const f3 nA(r2.y, r2.z, r2.w), nB(r3.x, r3.y, r3.z), nC(r3.w, r4.x, r4.y);
     const f3 ng = cross(pB - pA, pC - pA);
 
     float bcA = 0.5f * u0;
@@ -432,12 +430,9 @@ GFX_DEV void sample_light(const DevScene& sc, const EnvMap& env, float envRotati
 
     ls.position = bcA * pA + bcB * pB + bcC * pC;
     ls.atInfinity = 0;
-    const f3 n = bcA * f3(vA.nx, vA.ny, vA.nz) + bcB * f3(vB.nx, vB.ny, vB.nz) + bcC * f3(vC.nx, vC.ny, vC.nz);
-    ls.normal = unit(mul(load_m33(inst->normalMatrix), n));
-    const gfx_material& mat = sc.materials[g.materialSlot];
-    f3 e(0.0f);
-    if (mat.hasEmittance) e = f3(1.0f) * f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
-    ls.emittance = e;
+    const f3 n = bcA * nA + bcB * nB + bcC * nC;
+    ls.normal = unit(mul(load_m33_rows(inst->normalMatrix), n));
+    ls.emittance = f3(r4.z, r4.w, r5.x);
 }
 
 // Geometry of a shadow ray toward a light sample (restir_di_shared.h:524-545, 564-581).
