@@ -82,14 +82,17 @@ def main():
     setup_s = time.time() - t0
     stream = torch.cuda.current_stream().cuda_stream
 
-    gather = None
+    gather = exchange = None
     if world > 1:
-        gather = tilesplit.BandGather(_device_view(renderer.beauty_ptr(), W * H * 4), W, H, world, rank, dist)
+        state = tilesplit.renderer_state_views(renderer, W, H)
+        gather = tilesplit.BandGather(state["beauty"], W, H, world, rank, dist)
+        exchange = tilesplit.HaloExchange(state, renderer.band_plan(), W, H, rank, world, dist)
 
     def frame():
         renderer.render_frame(stream)
-        if gather is not None:
-            gather.all_gather()
+        if exchange is not None:
+            exchange.exchange(renderer.params()[2])   # final reservoirs + RNG of the halo rows, from their owners
+            gather.all_gather()                       # float4 HDR bands -> full frame on every rank
 
     def barrier():
         torch.cuda.synchronize()

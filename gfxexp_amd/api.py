@@ -83,6 +83,13 @@ class GfxhRestirConfig(C.Structure):
                 ("camera", GfxCamera), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32)]
 
 
+class GfxhBandPlan(C.Structure):
+    _fields_ = [("bandBegin", C.c_uint32), ("bandEnd", C.c_uint32), ("haloRows", C.c_uint32),
+                ("gbufferRows", C.c_uint32 * 2), ("initialRows", C.c_uint32 * 2), ("spatialRows", (C.c_uint32 * 2) * 8),
+                ("shadingRows", C.c_uint32 * 2), ("recvAbove", C.c_uint32 * 2), ("sendAbove", C.c_uint32 * 2),
+                ("recvBelow", C.c_uint32 * 2), ("sendBelow", C.c_uint32 * 2)]
+
+
 HIT_DTYPE = np.dtype([("dist", "<f4"), ("bcB", "<f4"), ("bcC", "<f4"), ("triIndex", "<u4")])
 TRI_IDS_DTYPE = np.dtype([("instSlot", "<u4"), ("geomInstSlot", "<u4"), ("primIndex", "<u4")])
 VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("texCoord0Dir", "<f4", 3),
@@ -99,6 +106,7 @@ C_ABI_SYMBOLS = [
     "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_accel_build",
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
+    "gfx_restir_launch_rows",
     "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read",
 ]
 HOST_ABI_SYMBOLS = [
@@ -107,7 +115,8 @@ HOST_ABI_SYMBOLS = [
     "gfxh_scene_load_obj", "gfxh_scene_add_rectangle", "gfxh_scene_make_street", "gfxh_scene_counts",
     "gfxh_scene_get_material", "gfxh_scene_get_geom", "gfxh_scene_get_group", "gfxh_scene_get_instance",
     "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
-    "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_restir_create",
+    "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
+    "gfxh_restir_band_plan", "gfxh_restir_create",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
 ]
@@ -273,6 +282,13 @@ def make_camera(width, height, pos, roll=0.0, pitch=0.0, yaw=0.0, fov_y_deg=50.0
     return cam
 
 
+def band_plan(height, band_begin, band_end, radius_rows, num_spatial_passes, max_motion_rows=0):
+    plan = GfxhBandPlan()
+    lib().gfxh_band_plan_compute(C.c_uint32(height), C.c_uint32(band_begin), C.c_uint32(band_end), C.c_uint32(radius_rows),
+                                 C.c_uint32(num_spatial_passes), C.c_uint32(max_motion_rows), C.byref(plan))
+    return plan
+
+
 def seed_rng_states(count, seed):
     out = np.zeros(count, np.uint64)
     lib().gfxh_seed_rng_states(_p(out), C.c_uint64(count), C.c_uint64(seed))
@@ -355,6 +371,10 @@ class Context:
                                                  C.byref(frame_params) if frame_params is not None else None,
                                                  C.c_uint32(cur_res_index), C.c_uint32(base_index)))
 
+    def restir_launch_rows(self, pass_id, width, height, row_begin, row_end, stream=0):
+        self._check(self.L.gfx_restir_launch_rows(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height),
+                                                  C.c_uint32(row_begin), C.c_uint32(row_end)))
+
     def restir_launch(self, pass_id, width, height, stream=0):
         self._check(self.L.gfx_restir_launch(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height)))
 
@@ -412,6 +432,11 @@ class RestirRenderer:
             self.close()
         except Exception:
             pass
+
+    def band_plan(self):
+        plan = GfxhBandPlan()
+        self.L.gfxh_restir_band_plan(self.h, C.byref(plan))
+        return plan
 
     def render_frame(self, stream=0):
         if self.L.gfxh_restir_render_frame(self.h, C.c_void_p(stream)):

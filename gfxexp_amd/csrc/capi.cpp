@@ -223,7 +223,13 @@ int gfx_restir_set_params(gfx_ctx* ctx, void* /*stream*/, const gfx_restir_stati
 
 int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height) {
     GFX_TRY(ctx)
-    restir_launch(ctx->c, static_cast<hipStream_t>(stream), pass, width, height);
+    restir_launch(ctx->c, static_cast<hipStream_t>(stream), pass, width, height, 0, height);
+    GFX_CATCH(ctx)
+}
+
+int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {
+    GFX_TRY(ctx)
+    restir_launch(ctx->c, static_cast<hipStream_t>(stream), pass, width, height, rowBegin, rowEnd);
     GFX_CATCH(ctx)
 }
 

@@ -6,6 +6,7 @@
 // bookkeeping (:1694-1700, :2303-2493): bufferIndex = frameIndex % 2, prevCamera latch, reservoir
 // ping-pong (lastReservoirIndex starts at 1), spatialNeighborBaseIndex growth, newSequence.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -55,6 +56,30 @@ void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_
     cfg->camera.fovY = 50 * 3.14159265358979323846f / 180;   // :1613
     const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
     std::memcpy(cfg->camera.orientation, ident, sizeof(ident));
+}
+
+void gfxh_band_plan_compute(uint32_t height, uint32_t bandBegin, uint32_t bandEnd, uint32_t radiusRows,
+                            uint32_t numSpatialPasses, uint32_t maxMotionRows, gfxh_band_plan* out) {
+    std::memset(out, 0, sizeof(*out));
+    if (numSpatialPasses > 8) numSpatialPasses = 8;
+    const uint32_t b = bandBegin, e = bandEnd;
+    const uint32_t halo = radiusRows * numSpatialPasses + maxMotionRows;
+    auto lo = [&](uint32_t rows) { return b > rows ? b - rows : 0u; };
+    auto hi = [&](uint32_t rows) { return std::min(height, e + rows); };
+    out->bandBegin = b; out->bandEnd = e; out->haloRows = halo;
+    out->gbufferRows[0] = lo(halo); out->gbufferRows[1] = hi(halo);
+    out->initialRows[0] = lo(halo); out->initialRows[1] = hi(halo);
+    for (uint32_t i = 0; i < numSpatialPasses; ++i) {
+        const uint32_t rows = radiusRows * (numSpatialPasses - 1 - i);
+        out->spatialRows[i][0] = lo(rows); out->spatialRows[i][1] = hi(rows);
+    }
+    out->shadingRows[0] = b; out->shadingRows[1] = e;
+    out->recvAbove[0] = lo(halo); out->recvAbove[1] = b;
+    out->recvBelow[0] = e; out->recvBelow[1] = hi(halo);
+    out->sendAbove[0] = b; out->sendAbove[1] = std::min(e, b + halo);     // what rank-1 receives "below" its band
+    out->sendBelow[0] = e > halo ? std::max(b, e - halo) : b; out->sendBelow[1] = e;
+    if (b == 0) { out->sendAbove[0] = out->sendAbove[1] = 0; }
+    if (e >= height) { out->sendBelow[0] = out->sendBelow[1] = e; }
 }
 
 static int alloc_dev(gfxh_restir* r, void** p, size_t bytes, bool zero) {
@@ -120,6 +145,15 @@ void gfxh_restir_destroy(gfxh_restir* r) {
     delete r;
 }
 
+int gfxh_restir_band_plan(gfxh_restir* r, gfxh_band_plan* out) {
+    const gfxh_restir_config& cfg = r->cfg;
+    const bool whole = cfg.rowBegin == 0 && cfg.rowEnd == 0;
+    const uint32_t passes = cfg.enableSpatialReuse ? cfg.numSpatialReusePasses : 0;
+    gfxh_band_plan_compute(cfg.height, whole ? 0 : cfg.rowBegin, whole ? cfg.height : cfg.rowEnd,
+                           static_cast<uint32_t>(std::ceil(cfg.spatialNeighborRadius)), passes, 0, out);
+    return 0;
+}
+
 int gfxh_restir_reset(gfxh_restir* r) { r->resetRequested = true; return 0; }
 int gfxh_restir_set_camera(gfxh_restir* r, const gfx_camera* cam) { r->camera = *cam; return 0; }
 void* gfxh_restir_beauty_buffer(gfxh_restir* r) { return r->sp.beautyAccumBuffer; }
@@ -178,27 +212,29 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
 
     uint32_t currentReservoirIndex = (r->lastReservoirIndex + 1) % 2;  // :2352
     const uint32_t W = cfg.width, H = cfg.height;
+    gfxh_band_plan plan;
+    gfxh_restir_band_plan(r, &plan);
 #define DRV_GFX(call) do { if (call) { g_driverError = gfx_last_error(ctx); return 1; } } while (0)
     DRV_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, currentReservoirIndex, r->lastSpatialNeighborBaseIndex));
-    DRV_GFX(gfx_restir_launch(ctx, stream, GFX_RESTIR_SETUP_GBUFFERS, W, H));                 // :2366-2367
+    DRV_GFX(gfx_restir_launch_rows(ctx, stream, GFX_RESTIR_SETUP_GBUFFERS, W, H, plan.gbufferRows[0], plan.gbufferRows[1]));   // :2366-2367
 
     int entry = GFX_RESTIR_INITIAL_RIS;                                                        // :2378-2384
     if (cfg.enableTemporalReuse && !newSequence)
         entry = fp.useUnbiasedEstimator ? GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED : GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED;
-    DRV_GFX(gfx_restir_launch(ctx, stream, entry, W, H));
+    DRV_GFX(gfx_restir_launch_rows(ctx, stream, entry, W, H, plan.initialRows[0], plan.initialRows[1]));
 
     if (cfg.enableSpatialReuse) {                                                              // :2393-2411
         const int spatial = fp.useUnbiasedEstimator ? GFX_RESTIR_SPATIAL_UNBIASED : GFX_RESTIR_SPATIAL_BIASED;
         for (uint32_t i = 0; i < cfg.numSpatialReusePasses; ++i) {
             const uint32_t baseIndex = r->lastSpatialNeighborBaseIndex + cfg.numSpatialNeighbors * i;
             DRV_GFX(gfx_restir_set_params(ctx, stream, nullptr, nullptr, currentReservoirIndex, baseIndex));
-            DRV_GFX(gfx_restir_launch(ctx, stream, spatial, W, H));
+            DRV_GFX(gfx_restir_launch_rows(ctx, stream, spatial, W, H, plan.spatialRows[i][0], plan.spatialRows[i][1]));
             currentReservoirIndex = (currentReservoirIndex + 1) % 2;
         }
         r->lastSpatialNeighborBaseIndex += cfg.numSpatialNeighbors * cfg.numSpatialReusePasses;
     }
     DRV_GFX(gfx_restir_set_params(ctx, stream, nullptr, nullptr, currentReservoirIndex, r->lastSpatialNeighborBaseIndex));
-    DRV_GFX(gfx_restir_launch(ctx, stream, GFX_RESTIR_SHADING, W, H));                        // :2418-2420
+    DRV_GFX(gfx_restir_launch_rows(ctx, stream, GFX_RESTIR_SHADING, W, H, plan.shadingRows[0], plan.shadingRows[1]));   // :2418-2420
 #undef DRV_GFX
     r->lastReservoirIndex = currentReservoirIndex;                                             // :2493
     r->prevCamera = r->camera;

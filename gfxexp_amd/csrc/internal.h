@@ -131,6 +131,6 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t);
 void lights_build_static(Context& ctx, hipStream_t stream);
 void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t bufferIndex);
 // ---- restir.hip
-void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height);
+void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd);
 
 } // namespace gfx

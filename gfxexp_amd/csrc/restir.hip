@@ -31,6 +31,7 @@ struct RestirArgs {
     gfx_restir_static_params s;
     gfx_restir_frame_params f;
     uint32_t curRes, baseIdx;
+    size_t pixelBegin, pixelEnd;   // the launch covers pixels [pixelBegin, pixelEnd) (whole rows)
     float4* rayOrg; float4* rayDir;
     uint32_t* rayCount;
     uint32_t* pixelRaySlot;
@@ -166,8 +167,8 @@ GFX_DEV bool test_neighbor(const RestirArgs& a, bool testGeometry, uint32_t nbBu
 // ray generation of optix_gbuffer_kernels.cu:5-27
 __global__ __launch_bounds__(kBlock) void k_primary_rays(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= numPixels) return;
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= a.pixelEnd) return;
     const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
     const Camera cam = load_camera(a.f.camera);
     float jx = 0.5f, jy = 0.5f;
@@ -183,8 +184,8 @@ __global__ __launch_bounds__(kBlock) void k_primary_rays(RestirArgs a) {
     const float vh = 2 * gm_tan(cam.fovY * 0.5f);
     const float vw = cam.aspect * vh;
     const f3 dir = unit(mul(cam.ori, f3(vw * (0.5f - fx), vh * (0.5f - fy), 1)));
-    a.rayOrg[p] = make_float4(cam.pos.x, cam.pos.y, cam.pos.z, 0.0f);
-    a.rayDir[p] = make_float4(dir.x, dir.y, dir.z, 3.402823466e+38f);
+    a.rayOrg[p - a.pixelBegin] = make_float4(cam.pos.x, cam.pos.y, cam.pos.z, 0.0f);
+    a.rayDir[p - a.pixelBegin] = make_float4(dir.x, dir.y, dir.z, 3.402823466e+38f);
 }
 
 // PerspectiveCamera::calcScreenPosition, restir_di_shared.h:51-59
@@ -201,12 +202,12 @@ GFX_DEV void calc_screen_position(const Camera& cam, f3 pw, float& sx, float& sy
 // closest-hit / miss programs + the tail of the ray-generation program (optix_gbuffer_kernels.cu:56-243)
 __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= numPixels) return;
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= a.pixelEnd) return;
     const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
     const uint32_t bufIdx = a.f.bufferIndex;
-    const gfx_hit h = a.hits[p];
-    const float4 rd = a.rayDir[p];
+    const gfx_hit h = a.hits[p - a.pixelBegin];
+    const float4 rd = a.rayDir[p - a.pixelBegin];
     const f3 direction(rd.x, rd.y, rd.z);
 
     f3 albedo(0.0f);
@@ -320,10 +321,10 @@ __global__ __launch_bounds__(kBlock) void k_initial_candidates(RestirArgs a) {
         instWeights = ldsDist; instCDF = ldsDist + ni;
     }
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     const uint32_t bufIdx = a.f.bufferIndex;
     bool surface = false;
-    if (p < numPixels) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
+    if (p < a.pixelEnd) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
 
     bool wantRay = false;
     f3 rayO(0.0f), rayD(0.0f);
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_initial_candidates(RestirArgs a) {
         static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes])[p] = make_float2(recPDF, selectedTarget);
     }
     const uint32_t slot = emit_ray(wantRay, rayO, rayD, 0.0f, rayTmax, a);
-    if (p < numPixels) a.pixelRaySlot[p] = slot;
+    if (p < a.pixelEnd) a.pixelRaySlot[p] = slot;
 }
 
 // visibility application + temporal reuse: optix_restir_di_kernels.cu:128-286
@@ -385,8 +386,8 @@ __global__ __launch_bounds__(kBlock) void k_initial_candidates(RestirArgs a) {
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_temporal(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= numPixels) return;
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= a.pixelEnd) return;
     const uint32_t bufIdx = a.f.bufferIndex;
     if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x == 0xFFFFFFFFu) return;
     const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
@@ -494,11 +495,11 @@ GFX_DEV void spatial_neighbor(const RestirArgs& a, Pcg32& rng, uint32_t nIdx, in
 template <bool UNBIASED>
 __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     const uint32_t bufIdx = a.f.bufferIndex;
     const uint32_t numNb = a.f.numSpatialNeighbors;
     bool surface = false;
-    if (p < numPixels) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
+    if (p < a.pixelEnd) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
     const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
     const uint32_t srcRes = a.curRes, dstRes = (a.curRes + 1) % 2;
     const Camera cam = load_camera(a.f.camera);
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
     // ---- unbiased: targets of the selected sample at self and at every neighbour, rays where needed
     const bool needMis = surface && selectedTarget > 0.0f;
     const LightSample selected = combined.sample;
-    SpatialSlot* slots = a.spatialScratch + (p < numPixels ? p * (numNb + 1) : 0);
+    SpatialSlot* slots = a.spatialScratch + (p < a.pixelEnd ? p * (numNb + 1) : 0);
     {
         float targetSelf = 0.0f;
         bool want = false;
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
             }
         }
         const uint32_t slot = emit_ray(want, ro, rd, 0.0f, tmax, a);
-        if (p < numPixels) { SpatialSlot s; s.targetDensity = targetSelf; s.streamLength = selfStreamLength; s.raySlot = slot; slots[0] = s; }
+        if (p < a.pixelEnd) { SpatialSlot s; s.targetDensity = targetSelf; s.streamLength = selfStreamLength; s.raySlot = slot; slots[0] = s; }
     }
     const Camera prevCam = load_camera(a.f.prevCamera);
     for (uint32_t nIdx = 0; nIdx < numNb; ++nIdx) {
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
         }
         uint32_t slot = emit_ray(want, ro, rd, 0.0f, tmax, a);
         if (!evaluated) slot = kSlotSkipped;   // out of bounds / self / background: the reference `continue`s
-        if (p < numPixels) { SpatialSlot s; s.targetDensity = nbTarget; s.streamLength = nbStreamLength; s.raySlot = slot; slots[1 + nIdx] = s; }
+        if (p < a.pixelEnd) { SpatialSlot s; s.targetDensity = nbTarget; s.streamLength = nbStreamLength; s.raySlot = slot; slots[1 + nIdx] = s; }
     }
     if (!surface) return;
     rngBuf[p] = rng.state;
@@ -613,8 +614,8 @@ __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
 // MIS weights of the unbiased spatial pass once the rays are back: optix_restir_di_kernels.cu:413-546
 __global__ __launch_bounds__(kBlock) void k_spatial_mis_finish(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= numPixels) return;
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= a.pixelEnd) return;
     const uint32_t bufIdx = a.f.bufferIndex;
     if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x == 0xFFFFFFFFu) return;
     const uint32_t numNb = a.f.numSpatialNeighbors;
@@ -659,14 +660,14 @@ __global__ __launch_bounds__(kBlock) void k_spatial_mis_finish(RestirArgs a) {
 // optix_restir_di_kernels.cu:559-629 up to the final shadow ray
 __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     const uint32_t bufIdx = a.f.bufferIndex;
     bool want = false;
     f3 ro(0.0f), rd(0.0f); float tmax = 0;
     f3 contribution(0.01f, 0.01f, 0.01f);
     f3 direct(0.0f);
     float recPDF = 0.0f;
-    if (p < numPixels) {
+    if (p < a.pixelEnd) {
         const uint32_t instSlot = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x;
         const uint4 g3 = static_cast<const uint4*>(a.s.gbuffer3[bufIdx])[p];
         if (instSlot != 0xFFFFFFFFu) {
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
         }
     }
     const uint32_t slot = emit_ray(want, ro, rd, 0.0f, tmax, a);
-    if (p < numPixels) {
+    if (p < a.pixelEnd) {
         a.shadeScratch[2 * p] = make_float4(contribution.x, contribution.y, contribution.z, bits2f(slot));
         a.shadeScratch[2 * p + 1] = make_float4(direct.x, direct.y, direct.z, recPDF);
     }
@@ -713,8 +714,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
 // contribution += recPDFEstimate * directCont; running mean (optix_restir_di_kernels.cu:619-636)
 __global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= numPixels) return;
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= a.pixelEnd) return;
     const float4 c0 = a.shadeScratch[2 * p], c1 = a.shadeScratch[2 * p + 1];
     f3 contribution(c0.x, c0.y, c0.z);
     const uint32_t bufIdx = a.f.bufferIndex;
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
 }
 
 // ---------------------------------------------------------------- host sequencing
-static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height) {
+static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {
     const RestirParams& rp = ctx.restir;
     if (!rp.valid) throw HipError("gfx_restir_launch: gfx_restir_set_params has not been called");
     if (static_cast<uint32_t>(rp.s.imageSizeX) != width || static_cast<uint32_t>(rp.s.imageSizeY) != height)
@@ -762,12 +763,16 @@ static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height) {
     a.tris = ctx.accels[h - 1]->tris.as<Bvh8Tri>();
     a.shadeScratch = ctx.shadeScratch.as<float4>();
     a.spatialScratch = ctx.spatialScratch.as<SpatialSlot>();
+    if (rowEnd > height || rowBegin > rowEnd) throw HipError("gfx_restir_launch_rows: row range outside the image");
+    a.pixelBegin = static_cast<size_t>(rowBegin) * width;
+    a.pixelEnd = static_cast<size_t>(rowEnd) * width;
     return a;
 }
 
 template <typename K>
 static void launch_pixels(Context& ctx, hipStream_t stream, const char* name, K kernel, const RestirArgs& a) {
-    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const size_t numPixels = a.pixelEnd - a.pixelBegin;
+    if (numPixels == 0) return;
     const uint32_t grid = static_cast<uint32_t>((numPixels + kBlock - 1) / kBlock);
     ScopedKernelTimer timer(ctx, stream, name);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a);
@@ -783,9 +788,10 @@ static void trace_queue(Context& ctx, hipStream_t stream, const RestirArgs& a, i
     trace_launch(ctx, stream, t);
 }
 
-void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height) {
-    RestirArgs a = make_args(ctx, width, height);
-    const uint32_t numPixels = width * height;
+void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {
+    RestirArgs a = make_args(ctx, width, height, rowBegin, rowEnd);
+    const uint32_t numPixels = static_cast<uint32_t>(a.pixelEnd - a.pixelBegin);
+    if (numPixels == 0) return;
     auto reset_queue = [&]() { GFX_HIP(hipMemsetAsync(a.rayCount, 0, sizeof(uint32_t), stream)); };
     switch (pass) {
     case GFX_RESTIR_SETUP_GBUFFERS:
@@ -798,7 +804,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     case GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED:
         reset_queue();
         {
-            const size_t numPx = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+            const size_t numPx = a.pixelEnd - a.pixelBegin;
             const uint32_t grid = static_cast<uint32_t>((numPx + kBlock - 1) / kBlock);
             const size_t ldsBytes = 8ull * a.scene.numInsts;
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");

@@ -66,3 +66,69 @@ class BandGather:
             m = (re - rb) * self.w * 4
             self.beauty[rb * self.w * 4:re * self.w * 4].copy_(self.recv[r * slab:r * slab + m])
         return self.beauty
+
+
+class HaloExchange:
+    """Per-frame refresh of the halo rows' FINAL temporal state from their owners (gfxh_band_plan).
+
+    `state` maps names to flat torch tensors viewing this rank's full-frame buffers:
+        "rng"   int64  [H*W]          PCG32 state per pixel
+        "info0" "info1"  float32 [H*W*2]   ReservoirInfo ping-pong
+        "res0"  "res1"   float32 [3*H*W*4] reservoir planes ping-pong
+    Only the buffers of `last_res_index` (the frame's final reservoirs) and the RNG are exchanged:
+    64 bytes per halo pixel per neighbour (~4.9 MB per neighbour at 1080p, 40 halo rows).
+    Works with any torch.distributed backend (RCCL on the GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, state, plan, width, height, rank, world, dist):
+        self.state, self.plan, self.w, self.h = state, plan, width, height
+        self.rank, self.world, self.dist = rank, world, dist
+
+    def _slices(self, rows, last):
+        b, e = int(rows[0]), int(rows[1])
+        if e <= b:
+            return []
+        n = self.w * self.h
+        out = [self.state["rng"][b * self.w:e * self.w], self.state["info%d" % last][b * self.w * 2:e * self.w * 2]]
+        res = self.state["res%d" % last]
+        for plane in range(3):
+            out.append(res[plane * n * 4 + b * self.w * 4:plane * n * 4 + e * self.w * 4])
+        return out
+
+    def exchange(self, last_res_index):
+        dist, ops = self.dist, []
+        p = self.plan
+        if self.rank > 0:
+            for t in self._slices(p.sendAbove, last_res_index):
+                ops.append(dist.P2POp(dist.isend, t, self.rank - 1))
+            for t in self._slices(p.recvAbove, last_res_index):
+                ops.append(dist.P2POp(dist.irecv, t, self.rank - 1))
+        if self.rank < self.world - 1:
+            for t in self._slices(p.sendBelow, last_res_index):
+                ops.append(dist.P2POp(dist.isend, t, self.rank + 1))
+            for t in self._slices(p.recvBelow, last_res_index):
+                ops.append(dist.P2POp(dist.irecv, t, self.rank + 1))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+
+def device_view(ptr, count, typestr="<f4"):
+    """Wrap a raw device pointer as a flat torch tensor without copying (CUDA array interface)."""
+    import torch
+
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device="cuda")
+
+
+def renderer_state_views(renderer, width, height):
+    """Tensor views of a gfxexp RestirRenderer's device buffers for HaloExchange / BandGather."""
+    s, _, _, _, _ = renderer.params()
+    n = width * height
+    state = {"rng": device_view(s.rngBuffer, n, "<i8"), "beauty": device_view(s.beautyAccumBuffer, n * 4)}
+    for i in range(2):
+        state["info%d" % i] = device_view(s.reservoirInfoBuffer[i], n * 2)
+        state["res%d" % i] = device_view(s.reservoirBuffer[i], n * 12)
+    return state

@@ -221,6 +221,11 @@ enum gfx_restir_pass {
     GFX_RESTIR_NUM_PASSES
 };
 int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height);
+/* The same pass restricted to image rows [rowBegin, rowEnd): the unit of the multi-GPU row-band split
+ * (no reference counterpart -- restir_di_main.cpp is single GPU, :130-133).  Buffers keep their
+ * full-frame size and indexing. */
+int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height,
+                           uint32_t rowBegin, uint32_t rowEnd);
 
 /* Blocking device-to-host copy of library- or caller-owned device memory (TypedBuffer::read,
  * utils/cuda_util.h; used for pick info at restir_di_main.cpp:2010). */

@@ -106,12 +106,31 @@ typedef struct gfxh_restir_config {
     uint32_t enableAccumulation;        /* 0 */
     uint32_t log2MaxNumAccums;          /* 16 */
     gfx_camera camera;                  /* fovY = 50 deg in the reference (:1613) */
-    /* rows [rowBegin, rowEnd) owned by this process when a frame is split across GPUs; 0,0 = all.
-     * (reserved for the tile-split driver) */
+    /* rows [rowBegin, rowEnd) owned by this process when a frame is split across GPUs; 0,0 = all. */
     uint32_t rowBegin, rowEnd;
 } gfxh_restir_config;
 
 void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_t height, int renderer);
+
+/* Row-band plan of one rank for one frame.  A band [bandBegin, bandEnd) owns its rows;
+ * every reuse pass reads neighbours up to `radiusRows` away, so earlier passes run on a halo that
+ * shrinks by radiusRows per spatial pass:
+ *   G-buffer + initial/temporal RIS : band +- (radiusRows * numSpatialPasses + maxMotionRows)
+ *   spatial pass i                  : band +- radiusRows * (numSpatialPasses - 1 - i)
+ *   shading                         : band
+ * Within a frame halo pixels reproduce bit for bit what their owner computes (per-pixel RNG, same
+ * inputs).  Across frames the owner's FINAL reservoir / ReservoirInfo / RNG state of the halo rows
+ * must be refreshed once per frame: recv* are the row ranges to receive from the rank above
+ * (rank - 1) / below (rank + 1), send* the own rows those ranks need.  All ranges are [begin, end). */
+typedef struct gfxh_band_plan {
+    uint32_t bandBegin, bandEnd, haloRows;
+    uint32_t gbufferRows[2], initialRows[2], spatialRows[8][2], shadingRows[2];
+    uint32_t recvAbove[2], sendAbove[2], recvBelow[2], sendBelow[2];
+} gfxh_band_plan;
+void gfxh_band_plan_compute(uint32_t height, uint32_t bandBegin, uint32_t bandEnd, uint32_t radiusRows,
+                            uint32_t numSpatialPasses, uint32_t maxMotionRows, gfxh_band_plan* out);
+/* The plan the renderer uses (band from cfg.rowBegin/rowEnd; whole frame when both are 0). */
+int gfxh_restir_band_plan(gfxh_restir* r, gfxh_band_plan* out);
 /* Allocates every per-pixel buffer (hipMalloc), seeds the RNG buffer, uploads the Halton table,
  * builds BVH and light distributions for the uploaded scene. */
 int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir** out);

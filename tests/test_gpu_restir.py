@@ -143,3 +143,55 @@ def test_headless_driver_matches_pass_by_pass(built_lib):
     torch.cuda.synchronize()
     out = ctx.read_device(r.beauty_ptr(), width * height * 16).view(np.float32).reshape(-1, 4)
     util.assert_same_bits("driver beauty", out, want)
+
+
+@pytest.mark.gpu
+def test_row_band_renderers_match_full_frame(built_lib):
+    """Two band-limited renderers on one GPU (bands 0 and 1 of a 2-way split), halo rows refreshed by
+    device copies exactly as HaloExchange would send them, reproduce the full-frame renderer bit for bit."""
+    import torch
+    from gfxexp_amd import tilesplit
+    width, height, frames = 128, 96, 3
+    hs = util.bunny_scene()
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    cam = default_camera("bunny", width, height)
+
+    def make(band):
+        cfg = api.RestirRenderer.default_config(width, height, api.RENDERER_BIASED)
+        cfg.camera = cam
+        cfg.spatialNeighborRadius = 6.0
+        cfg.rowBegin, cfg.rowEnd = band
+        return api.RestirRenderer(ctx, cfg)
+
+    full = make((0, 0))
+    bands = tilesplit.band_rows(height, 2)
+    parts = [make(b) for b in bands]
+    views = [tilesplit.renderer_state_views(r, width, height) for r in parts]
+    plans = [r.band_plan() for r in parts]
+    assert plans[0].haloRows == 12 and list(plans[0].recvBelow) == [48, 60] and list(plans[1].recvAbove) == [36, 48]
+    n = width * height
+
+    def rows(state, key, r, planes=1, comps=1):
+        b, e = int(r[0]), int(r[1])
+        return [state[key][pl * n * comps + b * width * comps: pl * n * comps + e * width * comps] for pl in range(planes)]
+
+    for _ in range(frames):
+        full.render_frame()
+        for r in parts:
+            r.render_frame()
+        torch.cuda.synchronize()
+        last = parts[0].params()[2]
+        assert last == parts[1].params()[2] == full.params()[2]
+        # rank 0 -> rank 1 (rank 1's recvAbove = rank 0's sendBelow) and back
+        for src, dst, send, recv in ((0, 1, plans[0].sendBelow, plans[1].recvAbove), (1, 0, plans[1].sendAbove, plans[0].recvBelow)):
+            assert int(send[1]) - int(send[0]) == int(recv[1]) - int(recv[0])
+            for key, planes, comps in (("rng", 1, 1), (f"info{last}", 1, 2), (f"res{last}", 3, 4)):
+                for s_t, d_t in zip(rows(views[src], key, send, planes, comps), rows(views[dst], key, recv, planes, comps)):
+                    d_t.copy_(s_t)
+        torch.cuda.synchronize()
+    want = ctx.read_device(full.beauty_ptr(), n * 16).view(np.float32).reshape(height, width, 4)
+    for r, (b, e) in zip(parts, bands):
+        got = ctx.read_device(r.beauty_ptr(), n * 16).view(np.float32).reshape(height, width, 4)
+        util.assert_same_bits(f"band {b}:{e}", got[b:e], want[b:e])
+    assert np.abs(want[..., :3]).sum() > 0

@@ -1,0 +1,128 @@
+"""CPU, world_size 2, gloo: the row-band split (band plan + per-frame halo refresh + HDR all-gather)
+reproduces the single-process frame BIT FOR BIT.  The per-rank renderer here is the CPU oracle driven
+with the same gfxh_band_plan row ranges the GPU driver uses, and the communication code is the
+production code (gfxexp_amd/tilesplit.py) on the gloo backend."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H, FRAMES, RADIUS, PASSES, NB = 64, 48, 3, 5.0, 2, 3
+
+
+def _sequence(osc, pb, plan, cam, frames, exchange=None, gather=None):
+    from gfxexp_amd import api
+    from oracle import oracle as O
+    from tests import util
+    s = pb.host_static_params()
+    ocam = util.copy_struct(O.GfxCamera, cam)
+    last_res, last_base = 1, 0
+    for frame in range(frames):
+        kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=0,
+                  numSpatialNeighbors=NB, spatialNeighborRadius=RADIUS)
+        f = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, W, H, ocam, **kw)
+        cur = (last_res + 1) % 2
+
+        def rows(r):
+            return (0, int(r[0]), W, int(r[1]))
+        osc.restir_launch(s, f, cur, last_base, api.PASS_SETUP_GBUFFERS, rect=rows(plan.gbufferRows))
+        osc.restir_launch(s, f, cur, last_base, api.PASS_INITIAL_RIS if frame == 0 else api.PASS_INITIAL_TEMPORAL_BIASED,
+                          rect=rows(plan.initialRows))
+        for i in range(PASSES):
+            osc.restir_launch(s, f, cur, last_base + NB * i, api.PASS_SPATIAL_BIASED, rect=rows(plan.spatialRows[i]))
+            cur = (cur + 1) % 2
+        last_base += NB * PASSES
+        osc.restir_launch(s, f, cur, last_base, api.PASS_SHADING, rect=rows(plan.shadingRows))
+        last_res = cur
+        if exchange is not None:
+            exchange.exchange(last_res)
+        if gather is not None:
+            gather.all_gather()
+    return last_res
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from gfxexp_amd import api, tilesplit
+    from tests import util
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    hs = util.bunny_scene()
+    osc = util.feed_oracle(hs, threads=2)
+    pb = util.PixelBuffers(W, H)
+    b, e = tilesplit.band_for_rank(H, world, rank)
+    plan = api.band_plan(H, b, e, int(np.ceil(RADIUS)), PASSES)
+    assert e - b >= plan.haloRows
+    state = {"rng": torch.from_numpy(pb.rng.view(np.int64)), "beauty": torch.from_numpy(pb.beauty.reshape(-1))}
+    for i in range(2):
+        state[f"info{i}"] = torch.from_numpy(pb.info[i].reshape(-1))
+        state[f"res{i}"] = torch.from_numpy(pb.res[i].reshape(-1))
+    exchange = tilesplit.HaloExchange(state, plan, W, H, rank, world, dist)
+    gather = tilesplit.BandGather(state["beauty"], W, H, world, rank, dist)
+    cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+    last = _sequence(osc, pb, plan, cam, FRAMES, exchange, gather)
+    np.save(os.path.join(out_dir, f"beauty_{rank}.npy"), pb.beauty)
+    np.save(os.path.join(out_dir, f"res_{rank}.npy"), pb.res[last])
+    np.save(os.path.join(out_dir, f"band_{rank}.npy"), np.array([b, e]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_band_rows_are_tile_aligned_and_cover_the_frame():
+    from gfxexp_amd import tilesplit
+    for h in (1080, 48, 720, 1081):
+        for world in (1, 2, 4, 8):
+            bands = tilesplit.band_rows(h, world)
+            assert bands[0][0] == 0 and bands[-1][1] == h
+            for (b0, e0), (b1, e1) in zip(bands, bands[1:]):
+                assert e0 == b1 and b0 % 8 == 0 and b1 % 8 == 0
+    assert tilesplit.band_rows(1080, 8)[0] == (0, 136) and tilesplit.band_rows(1080, 8)[-1] == (952, 1080)
+
+
+def test_band_plan_ranges(built_lib):
+    from gfxexp_amd import api
+    p = api.band_plan(1080, 136, 272, 20, 2)
+    assert p.haloRows == 40
+    assert list(p.gbufferRows) == [96, 312] and list(p.initialRows) == [96, 312]
+    assert list(p.spatialRows[0]) == [116, 292] and list(p.spatialRows[1]) == [136, 272]
+    assert list(p.shadingRows) == [136, 272]
+    assert list(p.recvAbove) == [96, 136] and list(p.sendAbove) == [136, 176]
+    assert list(p.recvBelow) == [272, 312] and list(p.sendBelow) == [232, 272]
+    top = api.band_plan(1080, 0, 136, 20, 2)
+    assert list(top.gbufferRows) == [0, 176] and list(top.recvAbove) == [0, 0] and top.sendAbove[0] == top.sendAbove[1]
+    bottom = api.band_plan(1080, 952, 1080, 20, 1)
+    assert list(bottom.gbufferRows) == [932, 1080] and bottom.recvBelow[0] == bottom.recvBelow[1] == 1080
+
+
+def test_two_rank_band_split_is_bit_exact(built_lib):
+    import torch.multiprocessing as mp
+    from gfxexp_amd import api
+    from tests import util
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    with tempfile.TemporaryDirectory() as out_dir:
+        mp.spawn(_worker, args=(2, port, out_dir), nprocs=2, join=True)
+        gathered = [np.load(os.path.join(out_dir, f"beauty_{r}.npy")) for r in range(2)]
+        res = [np.load(os.path.join(out_dir, f"res_{r}.npy")) for r in range(2)]
+        bands = [np.load(os.path.join(out_dir, f"band_{r}.npy")) for r in range(2)]
+    # single process, whole frame
+    hs = util.bunny_scene()
+    osc = util.feed_oracle(hs, threads=4)
+    pb = util.PixelBuffers(W, H)
+    plan = api.band_plan(H, 0, H, int(np.ceil(RADIUS)), PASSES)
+    cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+    last = _sequence(osc, pb, plan, cam, FRAMES)
+    assert np.abs(pb.beauty[:, :3]).sum() > 0
+    for r in range(2):
+        util.assert_same_bits(f"rank {r} gathered HDR frame", gathered[r], pb.beauty)
+        b, e = bands[r]
+        want = pb.res[last].reshape(3, H, W, 4)[:, b:e]
+        util.assert_same_bits(f"rank {r} final reservoirs of its band", res[r].reshape(3, H, W, 4)[:, b:e], want)
