@@ -117,6 +117,7 @@ HOST_ABI_SYMBOLS = [
     "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
     "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
     "gfxh_restir_band_plan", "gfxh_restir_create",
+    "gfxh_env_build_importance", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
 ]
@@ -289,6 +290,22 @@ def band_plan(height, band_begin, band_end, radius_rows, num_spatial_passes, max
     return plan
 
 
+def env_make_sky(w, h, sun_elevation=35.0, sun_azimuth=40.0, sun_radiance=400.0):
+    t = np.zeros((h * w, 4), np.float32)
+    lib().gfxh_env_make_sky(C.c_uint32(w), C.c_uint32(h), C.c_float(sun_elevation), C.c_float(sun_azimuth), C.c_float(sun_radiance), _p(t))
+    return t
+
+
+def env_build_importance(texels, w, h):
+    out = dict(rowPDF=np.zeros(h * w, np.float32), rowCDF=np.zeros(h * (w + 1), np.float32), rowIntegrals=np.zeros(h, np.float32),
+               topPDF=np.zeros(h, np.float32), topCDF=np.zeros(h + 1, np.float32))
+    integ = C.c_float()
+    lib().gfxh_env_build_importance(_p(texels), C.c_uint32(w), C.c_uint32(h), _p(out["rowPDF"]), _p(out["rowCDF"]),
+                                    _p(out["rowIntegrals"]), _p(out["topPDF"]), _p(out["topCDF"]), C.byref(integ))
+    out["topIntegral"] = integ.value
+    return out
+
+
 def seed_rng_states(count, seed):
     out = np.zeros(count, np.uint64)
     lib().gfxh_seed_rng_states(_p(out), C.c_uint64(count), C.c_uint64(seed))
@@ -444,6 +461,11 @@ class RestirRenderer:
 
     def reset(self):
         self.L.gfxh_restir_reset(self.h)
+
+    def set_env(self, texels, w, h, power_coeff=1.0, rotation=0.0):
+        t = np.ascontiguousarray(texels, np.float32)
+        if self.L.gfxh_restir_set_env(self.h, _p(t), C.c_uint32(w), C.c_uint32(h), C.c_float(power_coeff), C.c_float(rotation)):
+            raise GfxError("gfxh_restir_set_env: " + self.L.gfxh_restir_last_error().decode())
 
     def set_camera(self, cam):
         self.L.gfxh_restir_set_camera(self.h, C.byref(cam))

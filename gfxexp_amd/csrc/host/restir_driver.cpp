@@ -36,6 +36,7 @@ struct gfxh_restir {
     uint32_t numAccumFrames = 0;
     bool resetRequested = false;
     gfx_camera camera, prevCamera;
+    float envPowerCoeff = 1.0f, envRotation = 0.0f;
 };
 
 extern "C" {
@@ -155,6 +156,33 @@ int gfxh_restir_band_plan(gfxh_restir* r, gfxh_band_plan* out) {
 }
 
 int gfxh_restir_reset(gfxh_restir* r) { r->resetRequested = true; return 0; }
+
+int gfxh_restir_set_env(gfxh_restir* r, float* texels, uint32_t w, uint32_t h, float powerCoeff, float rotation) {
+    const size_t n = static_cast<size_t>(w) * h;
+    std::vector<float> rowPDF(n), rowCDF(static_cast<size_t>(h) * (w + 1)), rowInt(h), topPDF(h), topCDF(h + 1);
+    float topIntegral = 0;
+    gfxh_env_build_importance(texels, w, h, rowPDF.data(), rowCDF.data(), rowInt.data(), topPDF.data(), topCDF.data(), &topIntegral);
+    gfx_restir_static_params& sp = r->sp;
+    auto up = [&](const void** dst, const void* src, size_t bytes) {
+        void* p = nullptr;
+        if (alloc_dev(r, &p, bytes, false)) return 1;
+        if (!hip_ok(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice), "upload env")) return 1;
+        *dst = p;
+        return 0;
+    };
+    int err = 0;
+    err |= up(&sp.envLightTexture, texels, 16 * n);
+    err |= up(&sp.envRowPDF, rowPDF.data(), 4 * rowPDF.size());
+    err |= up(&sp.envRowCDF, rowCDF.data(), 4 * rowCDF.size());
+    err |= up(&sp.envRowIntegrals, rowInt.data(), 4 * rowInt.size());
+    err |= up(&sp.envTopPDF, topPDF.data(), 4 * topPDF.size());
+    err |= up(&sp.envTopCDF, topCDF.data(), 4 * topCDF.size());
+    if (err) return 1;
+    sp.envWidth = static_cast<int32_t>(w); sp.envHeight = static_cast<int32_t>(h); sp.envTopIntegral = topIntegral;
+    r->envPowerCoeff = powerCoeff; r->envRotation = rotation;
+    r->resetRequested = true;
+    return 0;
+}
 int gfxh_restir_set_camera(gfxh_restir* r, const gfx_camera* cam) { r->camera = *cam; return 0; }
 void* gfxh_restir_beauty_buffer(gfxh_restir* r) { return r->sp.beautyAccumBuffer; }
 uint64_t gfxh_restir_accel(gfxh_restir* r) { return r->accel; }
@@ -191,8 +219,8 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     fp.travHandle = r->accel;
     fp.numAccumFrames = r->numAccumFrames;
     fp.frameIndex = frameIndex;
-    fp.envLightPowerCoeff = 1.0f;                                      // pow(10, 0) (:2322)
-    fp.envLightRotation = 0.0f;
+    fp.envLightPowerCoeff = r->envPowerCoeff;                          // pow(10, log10EnvLightPowerCoeff) (:2322)
+    fp.envLightRotation = r->envRotation;
     fp.spatialNeighborRadius = cfg.spatialNeighborRadius;
     fp.radiusThresholdForSpatialVisReuse = 10.0f;
     fp.log2NumCandidateSamples = cfg.log2NumCandidateSamples;

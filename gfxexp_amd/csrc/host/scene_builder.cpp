@@ -567,6 +567,61 @@ static void host_sincos(float x, float* s, float* c) {
     *s = (n & 2) ? -ss : ss;
     *c = ((n + 1) & 2) ? -cc : cc;
 }
+// RegularConstantContinuousDistribution1D::initialize, common/common_host.cpp:292-316 (Kahan sums)
+static float build_rccd1d(const float* values, uint32_t n, float* pdf, float* cdf) {
+    float result = 0.0f, comp = 0.0f;   // CompensatedSum_T, common/basic_types.h:5428-5452
+    for (uint32_t i = 0; i < n; ++i) {
+        cdf[i] = result;
+        const float input = values[i] / n - comp;
+        const float t = result + input;
+        comp = (t - result) - input;
+        result = t;
+    }
+    const float integral = result;
+    for (uint32_t i = 0; i < n; ++i) { pdf[i] = values[i] / integral; cdf[i] /= integral; }
+    cdf[n] = 1.0f;
+    return integral;
+}
+
+int gfxh_env_build_importance(float* texels, uint32_t w, uint32_t h, float* rowPDF, float* rowCDF,
+                              float* rowIntegrals, float* topPDF, float* topCDF, float* topIntegral) {
+    std::vector<float> importance(static_cast<size_t>(w) * h);
+    for (uint32_t y = 0; y < h; ++y) {
+        const float theta = 3.14159265358979323846f * (y + 0.5f) / h;
+        float sinTheta, cosTheta;
+        host_sincos(theta, &sinTheta, &cosTheta);
+        for (uint32_t x = 0; x < w; ++x) {
+            float* t = texels + 4 * (static_cast<size_t>(y) * w + x);
+            for (int c = 0; c < 3; ++c) t[c] = std::min(std::max(t[c], 0.0f), 65504.0f);
+            importance[static_cast<size_t>(y) * w + x] = (0.2126729f * t[0] + 0.7151522f * t[1] + 0.0721750f * t[2]) * sinTheta;
+        }
+    }
+    for (uint32_t y = 0; y < h; ++y)
+        rowIntegrals[y] = build_rccd1d(importance.data() + static_cast<size_t>(y) * w, w, rowPDF + static_cast<size_t>(y) * w,
+                                       rowCDF + static_cast<size_t>(y) * (w + 1));
+    *topIntegral = build_rccd1d(rowIntegrals, h, topPDF, topCDF);
+    return 0;
+}
+
+void gfxh_env_make_sky(uint32_t w, uint32_t h, float sunElevationDeg, float sunAzimuthDeg, float sunRadiance, float* texels) {
+    const float d2r = 3.14159265358979323846f / 180.0f;
+    const float se = sunElevationDeg * d2r, sa = sunAzimuthDeg * d2r;
+    const V3 sun = { -std::sin(sa) * std::cos(se), std::sin(se), std::cos(sa) * std::cos(se) };
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            const float theta = 3.14159265358979323846f * (y + 0.5f) / h, phi = 2 * 3.14159265358979323846f * (x + 0.5f) / w;
+            const V3 d = { -std::sin(phi) * std::sin(theta), std::cos(theta), std::cos(phi) * std::sin(theta) };   // fromPolarYUp
+            const float up = std::max(d.y, 0.0f);
+            float r = 0.25f + 0.5f * (1 - up), g = 0.35f + 0.45f * (1 - up), b = 0.7f + 0.2f * (1 - up);
+            if (d.y < 0) { r = g = b = 0.05f; }
+            const float c = dot(d, sun);
+            if (c > 0.9995f) { r += sunRadiance; g += sunRadiance * 0.95f; b += sunRadiance * 0.85f; }
+            else if (c > 0.99f) { const float k = (c - 0.99f) / 0.0095f; r += 4 * k; g += 3.6f * k; b += 3 * k; }
+            float* t = texels + 4 * (static_cast<size_t>(y) * w + x);
+            t[0] = r; t[1] = g; t[2] = b; t[3] = 1.0f;
+        }
+}
+
 void gfxh_spatial_neighbor_deltas(float* out) {
     auto halton = [](uint32_t base, uint32_t idx) {
         const float recBase = 1.0f / base;

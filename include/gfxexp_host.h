@@ -85,6 +85,16 @@ void gfxh_seed_rng_states(uint64_t* states, uint64_t count, uint64_t seed);
 /* restir_di_main.cpp:1487-1542: 1024 Halton(2,3) samples mapped to the unit disk (float2 x 1024). */
 void gfxh_spatial_neighbor_deltas(float* out2x1024);
 
+/* Environment light (loadEnvironmentalTexture, common/common_host.cpp:2658-2711 and the
+ * RegularConstantContinuousDistribution2D build, :204-357): importance = luminance * sin(theta) per
+ * texel of a lat-long float4 image; per-row piecewise-constant PDFs/CDFs (Kahan sums) and the
+ * marginal over rows.  texels are clamped to [0, 65504] in place like the reference.  Output sizes:
+ * rowPDF h*w, rowCDF h*(w+1), rowIntegrals h, topPDF h, topCDF h+1. */
+int gfxh_env_build_importance(float* texels4, uint32_t w, uint32_t h, float* rowPDF, float* rowCDF,
+                              float* rowIntegrals, float* topPDF, float* topCDF, float* topIntegral);
+/* Synthetic lat-long sky (gradient + sun disc) used as the stand-in environment map. */
+void gfxh_env_make_sky(uint32_t w, uint32_t h, float sunElevationDeg, float sunAzimuthDeg, float sunRadiance, float* texels4);
+
 /* ---------------------------------------------------------------- headless ReSTIR DI renderer */
 typedef struct gfxh_restir gfxh_restir;
 
@@ -139,6 +149,9 @@ void gfxh_restir_destroy(gfxh_restir* r);
 int gfxh_restir_render_frame(gfxh_restir* r, void* stream);
 /* Restart the sequence (newSequence, restir_di_main.cpp:2311). */
 int gfxh_restir_reset(gfxh_restir* r);
+/* "-env-texture": upload a lat-long float4 environment map (host pointer) + its importance map and
+ * enable environment lighting with the given power coefficient and rotation (restir_di_main.cpp:1188-1197). */
+int gfxh_restir_set_env(gfxh_restir* r, float* texels4, uint32_t w, uint32_t h, float powerCoeff, float rotation);
 int gfxh_restir_set_camera(gfxh_restir* r, const gfx_camera* cam);
 /* Device pointer of the float4 beauty accumulation buffer (W*H). */
 void* gfxh_restir_beauty_buffer(gfxh_restir* r);

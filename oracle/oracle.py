@@ -302,3 +302,24 @@ def reservoir_stream(weights, us):
     sl = np.zeros(K, np.uint32)
     lib().orc_reservoir_stream(_p(w), _p(u), C.c_uint32(M), C.c_uint32(K), _p(sel), _p(sw), _p(sl))
     return sel, sw, sl
+
+
+def env_build(texels, w, h):
+    """-> dict(rowPDF,rowCDF,rowIntegrals,topPDF,topCDF,topIntegral); texels (h*w,4) float32 clamped in place."""
+    t = texels
+    assert t.dtype == np.float32 and t.flags.c_contiguous
+    out = dict(rowPDF=np.zeros(h * w, np.float32), rowCDF=np.zeros(h * (w + 1), np.float32), rowIntegrals=np.zeros(h, np.float32),
+               topPDF=np.zeros(h, np.float32), topCDF=np.zeros(h + 1, np.float32))
+    integ = C.c_float()
+    lib().orc_env_build(_p(t), C.c_uint32(w), C.c_uint32(h), _p(out["rowPDF"]), _p(out["rowCDF"]), _p(out["rowIntegrals"]),
+                        _p(out["topPDF"]), _p(out["topCDF"]), C.byref(integ))
+    out["topIntegral"] = integ.value
+    return out
+
+
+def env_sample(env, w, h, u2):
+    u = np.ascontiguousarray(u2, np.float32).reshape(-1, 2)
+    out = np.zeros((len(u), 3), np.float32)
+    lib().orc_env_sample(_p(env["rowPDF"]), _p(env["rowCDF"]), _p(env["rowIntegrals"]), _p(env["topPDF"]), _p(env["topCDF"]),
+                         C.c_float(env["topIntegral"]), C.c_uint32(w), C.c_uint32(h), _p(u), C.c_uint32(len(u)), _p(out))
+    return out

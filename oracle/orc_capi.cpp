@@ -387,6 +387,43 @@ void orc_reservoir_stream(const float* weights, const float* us, uint32_t M, uin
     }
 }
 
+// Environment importance map: loadEnvironmentalTexture (common/common_host.cpp:2675-2691) +
+// RegularConstantContinuousDistribution1D/2D::initialize (:292-357), CompensatedSum_T
+// (common/basic_types.h:5428-5452).  sin(theta) goes through the math contract (gm_sin).
+static float orc_rccd1d(const float* values, uint32_t n, float* PDF, float* CDF) {
+    struct Kahan { float result = 0, comp = 0; void add(float v) { const float c = v - comp; const float t = result + c; comp = (t - result) - c; result = t; } } sum;
+    for (uint32_t i = 0; i < n; ++i) { PDF[i] = values[i]; CDF[i] = sum.result; sum.add(PDF[i] / n); }
+    const float integral = sum.result;
+    for (uint32_t i = 0; i < n; ++i) { PDF[i] /= integral; CDF[i] /= integral; }
+    CDF[n] = 1.0f;
+    return integral;
+}
+void orc_env_build(float* texels, uint32_t w, uint32_t h, float* rowPDF, float* rowCDF, float* rowIntegrals,
+                   float* topPDF, float* topCDF, float* topIntegral) {
+    std::vector<float> importance(static_cast<size_t>(w) * h);
+    for (uint32_t y = 0; y < h; ++y) {
+        const float theta = kPi * (y + 0.5f) / h;
+        const float sinTheta = gm_sin(theta);
+        for (uint32_t x = 0; x < w; ++x) {
+            float* t = texels + 4 * (static_cast<size_t>(y) * w + x);
+            for (int c = 0; c < 3; ++c) t[c] = fmin2(fmax2(t[c], 0.0f), 65504.0f);
+            importance[static_cast<size_t>(y) * w + x] = sRGB_calcLuminance(RGB(t[0], t[1], t[2])) * sinTheta;
+        }
+    }
+    for (uint32_t y = 0; y < h; ++y)
+        rowIntegrals[y] = orc_rccd1d(importance.data() + static_cast<size_t>(y) * w, w, rowPDF + static_cast<size_t>(y) * w,
+                                     rowCDF + static_cast<size_t>(y) * (w + 1));
+    *topIntegral = orc_rccd1d(rowIntegrals, h, topPDF, topCDF);
+}
+// RegularConstantContinuousDistribution2D::sample on host arrays (common_shared.h:372-379)
+void orc_env_sample(const float* rowPDF, const float* rowCDF, const float* rowIntegrals, const float* topPDF, const float* topCDF,
+                    float topIntegral, uint32_t w, uint32_t h, const float* u2, uint32_t n, float* out3) {
+    RegularConstantContinuousDistribution2D d;
+    d.rowPDF = rowPDF; d.rowCDF = rowCDF; d.rowIntegrals = rowIntegrals; d.w = w; d.h = h;
+    d.top.PDF = topPDF; d.top.CDF = topCDF; d.top.integralValue = topIntegral; d.top.numValues = h;
+    for (uint32_t i = 0; i < n; ++i) d.sample(u2[2 * i], u2[2 * i + 1], &out3[3 * i], &out3[3 * i + 1], &out3[3 * i + 2]);
+}
+
 const char* orc_version() { return "gfxexp oracle (CPU restatement) 1"; }
 
 } // extern "C"

@@ -1,0 +1,48 @@
+"""CPU: environment-light importance map: the product's host builder
+(gfxh_env_build_importance) against the oracle's independent restatement of
+common/common_host.cpp:204-357, 2675-2691, and sampling invariants."""
+import numpy as np
+
+from gfxexp_amd import api
+from oracle import oracle as O
+from tests import util
+
+
+def test_importance_map_builders_agree_bit_for_bit(built_lib):
+    w, h = 96, 48
+    sky = api.env_make_sky(w, h)
+    a_tex, b_tex = sky.copy(), sky.copy()
+    a = api.env_build_importance(a_tex, w, h)
+    b = O.env_build(b_tex, w, h)
+    util.assert_same_bits("clamped texels", a_tex, b_tex)
+    for k in ("rowPDF", "rowCDF", "rowIntegrals", "topPDF", "topCDF"):
+        util.assert_same_bits(k, a[k], b[k])
+    assert np.float32(a["topIntegral"]) == np.float32(b["topIntegral"])
+    # piecewise-constant densities integrate to one; CDFs are monotone and end at 1
+    np.testing.assert_allclose(a["rowPDF"].reshape(h, w).mean(axis=1), 1.0, rtol=1e-5)
+    np.testing.assert_allclose(a["topPDF"].mean(), 1.0, rtol=1e-5)
+    cdf = a["rowCDF"].reshape(h, w + 1)
+    assert np.all(np.diff(cdf, axis=1) >= 0) and np.all(cdf[:, -1] == 1.0) and np.all(cdf[:, 0] == 0.0)
+
+
+def test_sampling_follows_luminance_times_sin_theta(built_lib):
+    w, h = 64, 32
+    sky = api.env_make_sky(w, h, sun_radiance=50.0)
+    env = O.env_build(sky.copy(), w, h)
+    u = np.random.default_rng(4).random((400000, 2)).astype(np.float32)
+    s = O.env_sample(env, w, h, u)
+    assert s[:, 0].min() >= 0 and s[:, 0].max() < 1 and s[:, 1].min() >= 0 and s[:, 1].max() < 1
+    x = np.minimum((s[:, 0] * w).astype(int), w - 1)
+    y = np.minimum((s[:, 1] * h).astype(int), h - 1)
+    hist = np.zeros((h, w))
+    np.add.at(hist, (y, x), 1)
+    lum = sky.reshape(h, w, 4)[..., :3] @ np.array([0.2126729, 0.7151522, 0.0721750])
+    theta = np.pi * (np.arange(h) + 0.5) / h
+    imp = lum * np.sin(theta)[:, None]
+    expect = imp / imp.sum()
+    got = hist / hist.sum()
+    assert np.abs(got - expect).max() < 4 * np.sqrt(expect.max() / len(u)) + 1e-4
+    # returned density == pdf(u,v) of the piecewise-constant map
+    pdf = (env["rowPDF"].reshape(h, w) * env["topPDF"][:, None])[y, x]
+    # (a sample that lands exactly on a cell border may be binned into the neighbouring cell here)
+    assert np.mean(np.abs(s[:, 2] - pdf) <= 1e-5 * pdf) > 0.999

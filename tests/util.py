@@ -146,6 +146,23 @@ class PixelBuffers:
         self.albedo = np.zeros((n, 4), np.float32)
         self.normal = np.zeros((n, 4), np.float32)
         self.deltas = O.spatial_neighbor_deltas()
+        self.env = None
+
+    def set_env(self, texels, w, h):
+        """Attach a lat-long environment map; the importance map comes from the product's host builder
+        (the oracle's own restatement of it is compared separately in test_env_light.py)."""
+        t = np.ascontiguousarray(texels, np.float32).copy()
+        e = api.env_build_importance(t, w, h)
+        e.update(texels=t, w=w, h=h)
+        self.env = e
+
+    def _fill_env(self, s, ptr):
+        if self.env is None:
+            return
+        e = self.env
+        s.envLightTexture = ptr(e["texels"]); s.envWidth, s.envHeight = e["w"], e["h"]
+        s.envRowPDF = ptr(e["rowPDF"]); s.envRowCDF = ptr(e["rowCDF"]); s.envRowIntegrals = ptr(e["rowIntegrals"])
+        s.envTopPDF = ptr(e["topPDF"]); s.envTopCDF = ptr(e["topCDF"]); s.envTopIntegral = e["topIntegral"]
 
     def arrays(self):
         out = {"rng": self.rng, "beauty": self.beauty, "albedo": self.albedo, "normal": self.normal}
@@ -166,6 +183,7 @@ class PixelBuffers:
         s.spatialNeighborDeltas = ptr(self.deltas)
         s.beautyAccumBuffer = ptr(self.beauty); s.albedoAccumBuffer = ptr(self.albedo); s.normalAccumBuffer = ptr(self.normal)
         s.numTilesX, s.numTilesY = (self.w + 7) // 8, (self.h + 7) // 8
+        self._fill_env(s, ptr)
         return s
 
     def host_static_params(self):
@@ -185,6 +203,10 @@ class DeviceBuffers:
         self.t["deltas"] = torch.from_numpy(pb.deltas.view(np.uint8).reshape(-1).copy()).cuda()
         for i in range(2):
             self.t[f"vis_{i}"] = torch.zeros(pb.n * 4, dtype=torch.uint8, device="cuda")
+        self.env_t = {}
+        if pb.env is not None:
+            for k in ("texels", "rowPDF", "rowCDF", "rowIntegrals", "topPDF", "topCDF"):
+                self.env_t[k] = torch.from_numpy(pb.env[k].reshape(-1)).cuda()
 
     def static_params(self):
         pb, t = self.pb, self.t
@@ -200,6 +222,12 @@ class DeviceBuffers:
         s.beautyAccumBuffer = t["beauty"].data_ptr(); s.albedoAccumBuffer = t["albedo"].data_ptr()
         s.normalAccumBuffer = t["normal"].data_ptr()
         s.numTilesX, s.numTilesY = (pb.w + 7) // 8, (pb.h + 7) // 8
+        if pb.env is not None:
+            e, et = pb.env, self.env_t
+            s.envLightTexture = et["texels"].data_ptr(); s.envWidth, s.envHeight = e["w"], e["h"]
+            s.envRowPDF = et["rowPDF"].data_ptr(); s.envRowCDF = et["rowCDF"].data_ptr()
+            s.envRowIntegrals = et["rowIntegrals"].data_ptr()
+            s.envTopPDF = et["topPDF"].data_ptr(); s.envTopCDF = et["topCDF"].data_ptr(); s.envTopIntegral = e["topIntegral"]
         return s
 
     def download(self):
