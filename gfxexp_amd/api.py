@@ -15,7 +15,8 @@ GFX_INVALID_SLOT = 0xFFFFFFFF
 TRACE_CLOSEST, TRACE_ANY = 0, 1
 (PASS_SETUP_GBUFFERS, PASS_INITIAL_RIS, PASS_INITIAL_TEMPORAL_BIASED, PASS_INITIAL_TEMPORAL_UNBIASED,
  PASS_SPATIAL_BIASED, PASS_SPATIAL_UNBIASED, PASS_SHADING) = range(7)
-RENDERER_BIASED, RENDERER_UNBIASED = 0, 1
+RENDERER_BIASED, RENDERER_UNBIASED, RENDERER_PATH_TRACE = 0, 1, 2
+PT_SETUP_GBUFFERS, PT_PATH_TRACE_BASELINE = 0, 1
 
 
 class GfxError(RuntimeError):
@@ -80,7 +81,8 @@ class GfxhRestirConfig(C.Structure):
                 ("numSpatialNeighbors", C.c_uint32), ("spatialNeighborRadius", C.c_float),
                 ("useLowDiscrepancyNeighbors", C.c_uint32), ("reuseVisibility", C.c_uint32),
                 ("enableAccumulation", C.c_uint32), ("log2MaxNumAccums", C.c_uint32),
-                ("camera", GfxCamera), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32)]
+                ("camera", GfxCamera), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32),
+                ("maxPathLength", C.c_uint32), ("enableJittering", C.c_uint32)]
 
 
 class GfxhBandPlan(C.Structure):
@@ -106,7 +108,7 @@ C_ABI_SYMBOLS = [
     "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_accel_build",
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
-    "gfx_restir_launch_rows",
+    "gfx_restir_launch_rows", "gfx_pt_launch",
     "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read",
 ]
 HOST_ABI_SYMBOLS = [
@@ -394,6 +396,10 @@ class Context:
 
     def restir_launch(self, pass_id, width, height, stream=0):
         self._check(self.L.gfx_restir_launch(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height)))
+
+    def pt_launch(self, pass_id, width, height, max_path_length, row_begin=0, row_end=0, stream=0):
+        self._check(self.L.gfx_pt_launch(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height),
+                                         C.c_uint32(max_path_length), C.c_uint32(row_begin), C.c_uint32(row_end)))
 
     def read_device(self, dptr, nbytes):
         out = np.zeros(nbytes, np.uint8)

@@ -233,6 +233,14 @@ int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width,
     GFX_CATCH(ctx)
 }
 
+int gfx_pt_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height, uint32_t maxPathLength,
+                  uint32_t rowBegin, uint32_t rowEnd) {
+    GFX_TRY(ctx)
+    if (rowEnd == 0 && rowBegin == 0) rowEnd = height;
+    pathtrace_launch(ctx->c, static_cast<hipStream_t>(stream), pass, width, height, maxPathLength, rowBegin, rowEnd);
+    GFX_CATCH(ctx)
+}
+
 int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes) {
     GFX_TRY(ctx)
     GFX_HIP(hipDeviceSynchronize());

@@ -53,6 +53,8 @@ void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_
     cfg->reuseVisibility = 1;
     cfg->enableAccumulation = 0;
     cfg->log2MaxNumAccums = 16;
+    cfg->maxPathLength = 5;                                // path_tracing_main.cpp:1519
+    cfg->enableJittering = 0;
     cfg->camera.aspect = static_cast<float>(width) / height;
     cfg->camera.fovY = 50 * 3.14159265358979323846f / 180;   // :1613
     const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
@@ -234,7 +236,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     fp.useUnbiasedEstimator = cfg.renderer == GFXH_ORIGINAL_RESTIR_UNBIASED;
     fp.bufferIndex = bufferIndex;
     fp.resetFlowBuffer = newSequence;
-    fp.enableJittering = 0;
+    fp.enableJittering = cfg.enableJittering;
     fp.enableEnvLight = r->sp.envLightTexture != nullptr;
     fp.enableBumpMapping = 0;
 
@@ -244,6 +246,15 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     gfxh_restir_band_plan(r, &plan);
 #define DRV_GFX(call) do { if (call) { g_driverError = gfx_last_error(ctx); return 1; } } while (0)
     DRV_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, currentReservoirIndex, r->lastSpatialNeighborBaseIndex));
+    if (cfg.renderer == GFXH_PATH_TRACE_BASELINE) {
+        // path_tracing_main.cpp:2068-2093: G-buffer pipeline, then pathTraceBaseline.  A band needs no
+        // halo: paths never read a neighbour's pixel state.
+        DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, plan.bandBegin, plan.bandEnd));
+        DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_BASELINE, W, H, cfg.maxPathLength, plan.bandBegin, plan.bandEnd));
+        r->prevCamera = r->camera;
+        ++r->frameIndex;
+        return 0;
+    }
     DRV_GFX(gfx_restir_launch_rows(ctx, stream, GFX_RESTIR_SETUP_GBUFFERS, W, H, plan.gbufferRows[0], plan.gbufferRows[1]));   // :2366-2367
 
     int entry = GFX_RESTIR_INITIAL_RIS;                                                        // :2378-2384

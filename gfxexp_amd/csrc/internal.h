@@ -86,6 +86,8 @@ struct Context {
     uint32_t maxLeafTris = 4;
     // ray scratch
     DevBuf rayOrg, rayDir, rayOut, rayHits, spill, pixelRaySlot, shadeScratch, spatialScratch, smallCounters;
+    // path tracer scratch (pathtrace.hip)
+    DevBuf ptPending, ptExtOrg, ptExtDir, ptExtOwner, ptState;
     // build scratch
     DevBuf bTris, bBoxes, bKeys, bKeysAlt, bVals, bValsAlt, bSortTemp, bNodesLR, bParents, bFlags, bNodeBoxes, bRanges, bQueueA, bQueueB, bCounters;
     // restir
@@ -132,5 +134,8 @@ void lights_build_static(Context& ctx, hipStream_t stream);
 void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t bufferIndex);
 // ---- restir.hip
 void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd);
+// ---- pathtrace.hip
+void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height,
+                      uint32_t maxPathLength, uint32_t rowBegin, uint32_t rowEnd);
 
 } // namespace gfx

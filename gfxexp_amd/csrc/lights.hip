@@ -125,17 +125,38 @@ __global__ void k_inst_importance(const DevInstance* __restrict__ insts, uint32_
     weights[off + ii] = sq(sx) * inst->distIntegral;
 }
 
-__global__ void k_scan_inst_dist(uint32_t numInsts, uint32_t off, const float* __restrict__ weights, float* __restrict__ cdf,
-                                 float* __restrict__ integralOut) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    float acc = 0.0f, last = 0.0f, lastW = 0.0f;
-    for (uint32_t i = 0; i < numInsts; ++i) {
-        const float w = weights[off + i];
-        cdf[off + i] = acc;
-        last = acc; lastW = w;
-        acc += w;
+// Serial-order exclusive scan of the instance-level distribution (runs every frame,
+// restir_di_main.cpp:2303-2309).  The summation order is the contract, so one lane adds -- but out of
+// LDS: the block stages the weights with coalesced loads, lane 0 scans chunk by chunk in LDS
+// (~10 cycles per element instead of a dependent global load + store), and the block writes the
+// CDF back coalesced.
+constexpr int kScanChunk = 4096;
+__global__ __launch_bounds__(256) void k_scan_inst_dist(uint32_t numInsts, uint32_t off, const float* __restrict__ weights,
+                                                        float* __restrict__ cdf, float* __restrict__ integralOut) {
+    __shared__ float buf[kScanChunk];
+    __shared__ float carry[2];   // running sum, last weight
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0) { carry[0] = 0.0f; carry[1] = 0.0f; }
+    float lastCdf = 0.0f;
+    for (uint32_t base = 0; base < numInsts; base += kScanChunk) {
+        const uint32_t m = min(static_cast<uint32_t>(kScanChunk), numInsts - base);
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) buf[i] = weights[off + base + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float acc = carry[0];
+            for (uint32_t i = 0; i < m; ++i) {
+                const float w = buf[i];
+                buf[i] = acc;
+                lastCdf = acc; carry[1] = w;
+                acc += w;
+            }
+            carry[0] = acc;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) cdf[off + base + i] = buf[i];
+        __syncthreads();
     }
-    *integralOut = numInsts ? last + lastW : 0.0f;
+    if (threadIdx.x == 0) *integralOut = numInsts ? lastCdf + carry[1] : 0.0f;   // CDF[n-1] + w[n-1]
 }
 
 void lights_build_static(Context& ctx, hipStream_t stream) {
@@ -174,7 +195,7 @@ void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t /*bufferI
     if (ni) {
         hipLaunchKernelGGL(k_inst_importance, dim3((ni + 63) / 64), dim3(64), 0, stream,
                            ctx.dInsts.as<DevInstance>(), ni, ctx.lightInstDistOffset, ctx.dLightW.as<float>());
-        hipLaunchKernelGGL(k_scan_inst_dist, dim3(1), dim3(64), 0, stream, ni, ctx.lightInstDistOffset,
+        hipLaunchKernelGGL(k_scan_inst_dist, dim3(1), dim3(256), 0, stream, ni, ctx.lightInstDistOffset,
                            ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>(), dIntegral);
         GFX_HIP(hipGetLastError());
     }

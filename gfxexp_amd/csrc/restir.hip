@@ -14,6 +14,7 @@
 //   SHADING                         k_shade_prepare -> trace any -> k_shade_finish
 #include "internal.h"
 #include "shading.hip.h"
+#include "pass_common.hip.h"
 
 namespace gfx {
 
@@ -41,25 +42,6 @@ struct RestirArgs {
     float4* shadeScratch;
     SpatialSlot* spatialScratch;
 };
-
-struct Camera { f3 pos; m33 ori; float aspect, fovY; };
-GFX_DEV Camera load_camera(const gfx_camera& c) {
-    Camera r;
-    r.pos = f3(c.position[0], c.position[1], c.position[2]);
-    r.ori.r0 = f3(c.orientation[0], c.orientation[1], c.orientation[2]);
-    r.ori.r1 = f3(c.orientation[3], c.orientation[4], c.orientation[5]);
-    r.ori.r2 = f3(c.orientation[6], c.orientation[7], c.orientation[8]);
-    r.aspect = c.aspect; r.fovY = c.fovY;
-    return r;
-}
-GFX_DEV EnvMap load_env(const gfx_restir_static_params& s) {
-    EnvMap e;
-    e.texels = static_cast<const float4*>(s.envLightTexture);
-    e.rowPDF = static_cast<const float*>(s.envRowPDF); e.rowCDF = static_cast<const float*>(s.envRowCDF);
-    e.topPDF = static_cast<const float*>(s.envTopPDF); e.topCDF = static_cast<const float*>(s.envTopCDF);
-    e.w = s.envWidth; e.h = s.envHeight;
-    return e;
-}
 
 // ---------------------------------------------------------------- reservoir planes
 struct Reservoir {
@@ -97,20 +79,8 @@ GFX_DEV void store_reservoir(void* buf, size_t numPixels, size_t p, const Reserv
     b[2 * numPixels + p] = make_float4(r.sample.normal.z, bits2f(r.sample.atInfinity & 1u), r.sumWeights, bits2f(r.streamLength));
 }
 
-// Dense ray-queue append for the lanes with want == true; every lane of the wave must call it.
 GFX_DEV uint32_t emit_ray(bool want, f3 org, f3 dir, float tmin, float tmax, const RestirArgs& a) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return GFX_INVALID_SLOT;
-    const int lane = threadIdx.x & 63;
-    const int leader = __builtin_ctzll(mask);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(a.rayCount, static_cast<uint32_t>(__popcll(mask)));
-    base = __shfl(base, leader);
-    if (!want) return GFX_INVALID_SLOT;
-    const uint32_t slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-    a.rayOrg[slot] = make_float4(org.x, org.y, org.z, tmin);
-    a.rayDir[slot] = make_float4(dir.x, dir.y, dir.z, tmax);
-    return slot;
+    return queue_append(want, org, dir, tmin, tmax, a.rayOrg, a.rayDir, a.rayCount);
 }
 
 // Shading point re-derived from the quantised G-buffer (every pass does this).

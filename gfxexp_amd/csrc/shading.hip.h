@@ -88,6 +88,14 @@ GFX_DEV f3 offset_ray_origin(f3 p, f3 ng) {
     return f3(fabsf(p.x) < kOrigin ? pf.x : pi.x, fabsf(p.y) < kOrigin ? pf.y : pi.y, fabsf(p.z) < kOrigin ? pf.z : pi.z);
 }
 
+GFX_DEV void make_coordinate_system(f3 normal, f3& tangent, f3& bitangent) { // common_shared.h:92-100
+    const float sign = normal.z >= 0 ? 1.0f : -1.0f;
+    const float a = -1 / (sign + normal.z);
+    const float b = normal.x * normal.y * a;
+    tangent = f3(1 + sign * normal.x * normal.x * a, sign * b, -sign * normal.x);
+    bitangent = f3(b, sign + normal.y * normal.y * a, -normal.y);
+}
+
 struct Frame {
     f3 t, b, n;
     GFX_DEV Frame() {}
@@ -336,6 +344,11 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
         const float t = (u - cdf[idx]) / (cdf[idx + 1] - cdf[idx]);
         p = pdf[idx];
         return (idx + t) / n;
+    }
+    GFX_DEV float evaluate_pdf(float d0, float d1) const { // common_shared.h:344-348, 380-383
+        uint32_t row = f2u_sat(d1 * h); if (row > static_cast<uint32_t>(h - 1)) row = h - 1;
+        uint32_t col = f2u_sat(d0 * w); if (col > static_cast<uint32_t>(w - 1)) col = w - 1;
+        return topPDF[row] * rowPDF[static_cast<size_t>(row) * w + col];
     }
     GFX_DEV void sample(float u0, float u1, float& d0, float& d1, float& p) const { // common_shared.h:372-379
         float topP;

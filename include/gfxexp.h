@@ -227,6 +227,24 @@ int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint
 int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height,
                            uint32_t rowBegin, uint32_t rowEnd);
 
+/* ---------------------------------------------------------------- path tracing ---------------- */
+
+/* The baseline path tracer (path_tracing/path_tracing_main.cpp:2068-2093: G-buffer pipeline, then
+ * the pathTraceBaseline pipeline; kernels path_tracing/gpu_kernels/optix_pathtracing_kernels.cu:74-341:
+ * NEE + BSDF sampling with power-heuristic MIS, Russian roulette, implicit light hits).
+ * Parameters are the ones set by gfx_restir_set_params: path_tracing_shared.h:137-173 is the subset
+ * {imageSize, rngBuffer, GBuffer0/1, beauty/albedo/normal accumulation, env light} of the static block
+ * and {travHandle, numAccumFrames, camera, prevCamera, envLightPowerCoeff/Rotation, bufferIndex,
+ * resetFlowBuffer, enableJittering, enableEnvLight} of the per-frame block; maxPathLength
+ * (path_tracing_shared.h:165, 4-bit field, UI range 2..15, default 5 at path_tracing_main.cpp:1519)
+ * is passed here.  Rows [rowBegin, rowEnd) as in gfx_restir_launch_rows; rowEnd == 0 -> whole frame. */
+enum gfx_pt_pass {
+    GFX_PT_SETUP_GBUFFERS = 0,        /* path_tracing/gpu_kernels/optix_gbuffer_kernels.cu */
+    GFX_PT_PATH_TRACE_BASELINE = 1    /* optix_pathtracing_kernels.cu:298-341 (pathTraceBaseline RG/CH/MS) */
+};
+int gfx_pt_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height,
+                  uint32_t maxPathLength, uint32_t rowBegin, uint32_t rowEnd);
+
 /* Blocking device-to-host copy of library- or caller-owned device memory (TypedBuffer::read,
  * utils/cuda_util.h; used for pick info at restir_di_main.cpp:2010). */
 int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes);

@@ -100,7 +100,8 @@ typedef struct gfxh_restir gfxh_restir;
 
 enum gfxh_renderer {
     GFXH_ORIGINAL_RESTIR_BIASED = 0,   /* restir_di_main.cpp:1958-1977 Renderer enum */
-    GFXH_ORIGINAL_RESTIR_UNBIASED = 1
+    GFXH_ORIGINAL_RESTIR_UNBIASED = 1,
+    GFXH_PATH_TRACE_BASELINE = 2       /* path_tracing/path_tracing_main.cpp:2068-2093 frame loop */
 };
 typedef struct gfxh_restir_config {
     uint32_t width, height;
@@ -118,6 +119,8 @@ typedef struct gfxh_restir_config {
     gfx_camera camera;                  /* fovY = 50 deg in the reference (:1613) */
     /* rows [rowBegin, rowEnd) owned by this process when a frame is split across GPUs; 0,0 = all. */
     uint32_t rowBegin, rowEnd;
+    uint32_t maxPathLength;             /* GFXH_PATH_TRACE_BASELINE only; 5 (path_tracing_main.cpp:1519) */
+    uint32_t enableJittering;           /* 0 (path_tracing_main.cpp:1515, restir_di_main.cpp) */
 } gfxh_restir_config;
 
 void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_t height, int renderer);

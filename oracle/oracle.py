@@ -193,6 +193,11 @@ class OracleScene:
                                  C.c_uint32(cur_res_index), C.c_uint32(base_index), C.c_int(pass_id),
                                  C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1))
 
+    def pt_launch(self, static_params, frame_params, pass_id, max_path_length, rect=None):
+        x0, y0, x1, y1 = rect if rect else (0, 0, 0, 0)
+        self.L.orc_pt_launch(self.h, C.byref(static_params), C.byref(frame_params), C.c_int(pass_id),
+                             C.c_uint32(max_path_length), C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1))
+
     def sample_light(self, shading_point, u3):
         u = np.ascontiguousarray(u3, dtype=np.float32).reshape(-1, 3)
         sp = np.ascontiguousarray(shading_point, dtype=np.float32)

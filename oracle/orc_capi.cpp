@@ -10,6 +10,7 @@
 #include <random>
 #include <string>
 #include "orc_restir.h"
+#include "orc_pathtrace.h"
 
 using namespace orc;
 
@@ -286,6 +287,25 @@ int orc_restir_launch(orc_scene* s, const gfx_restir_static_params* sp, const gf
             default: break;
             }
         }
+    return 0;
+}
+
+// Baseline path tracer (path_tracing/path_tracing_main.cpp:2068-2093: G-buffer pass, then the
+// pathTraceBaseline pipeline).  pass 0 = setupGBuffers (same program text as ReSTIR's), 1 = path trace.
+int orc_pt_launch(orc_scene* s, const gfx_restir_static_params* sp, const gfx_restir_frame_params* fp,
+                  int pass, uint32_t maxPathLength, int x0, int y0, int x1, int y1) {
+    orc_env_set(s, sp);
+    if (pass == 0)
+        return orc_restir_launch(s, sp, fp, 0, 0, GFX_RESTIR_SETUP_GBUFFERS, x0, y0, x1, y1);
+    PathTraceParams p;
+    p.scene = &s->scene; p.accel = &s->accel; p.s = sp; p.f = fp;
+    p.camera = toCamera(fp->camera);
+    p.maxPathLength = maxPathLength & 15u; // 4-bit bitfield, path_tracing_shared.h:165
+    if (x1 <= 0) x1 = sp->imageSizeX;
+    if (y1 <= 0) y1 = sp->imageSizeY;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(s->numThreads)
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) pathTracePixel(p, x, y);
     return 0;
 }
 

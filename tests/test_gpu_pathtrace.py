@@ -1,0 +1,92 @@
+"""-m gpu: the baseline path tracer (BASELINE.json config 2) through the C ABI against the CPU
+oracle: RNG states, G-buffers and the accumulated beauty buffer are compared bit for bit after
+every frame."""
+import numpy as np
+import pytest
+
+from gfxexp_amd import api
+from oracle import oracle as O
+from tests import util
+
+
+def run_pt_both(hs, width, height, frames=2, max_len=5, camera=None, env=None, jitter=0, env_rotation=0.0, rows=None):
+    import torch
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    ctx.lights_build_static()
+    osc = util.feed_oracle(hs)
+    cam = camera if camera is not None else api.make_camera(width, height, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+    ocam = util.copy_struct(O.GfxCamera, cam)
+    pb_gpu_init = util.PixelBuffers(width, height)
+    pb_cpu = util.PixelBuffers(width, height)
+    if env is not None:
+        pb_gpu_init.set_env(*env)
+        pb_cpu.set_env(*env)
+    dev = util.DeviceBuffers(pb_gpu_init)
+    s_gpu = dev.static_params()
+    s_cpu = pb_cpu.host_static_params()
+    stream = torch.cuda.current_stream().cuda_stream
+    diffs = []
+    for frame in range(frames):
+        kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=frame,
+                  enableJittering=jitter, enableEnvLight=int(env is not None), envLightRotation=env_rotation)
+        f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, width, height, cam, travHandle=accel, **kw)
+        f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, width, height, ocam, travHandle=0, **kw)
+        ctx.lights_build_instances(stream)
+        ctx.restir_set_params(s_gpu, f_gpu, 0, 0, stream)
+        bands = rows if rows else [(0, 0)]
+        for pass_id in (api.PT_SETUP_GBUFFERS, api.PT_PATH_TRACE_BASELINE):
+            for (rb, re) in bands:
+                ctx.pt_launch(pass_id, width, height, max_len, rb, re, stream)
+            osc.pt_launch(s_cpu, f_cpu, pass_id, max_len)
+        got, want = dev.download(), pb_cpu.arrays()
+        for k in ("rng", "beauty", f"gb0_{frame % 2}", f"gb1_{frame % 2}", "albedo", "normal"):
+            a = np.ascontiguousarray(got[k]).view(np.uint8).reshape(-1)
+            b = np.ascontiguousarray(want[k]).view(np.uint8).reshape(-1)
+            if not np.array_equal(a, b):
+                item = want[k].dtype.itemsize
+                nbad = len(np.unique(np.nonzero(a != b)[0] // item))
+                diffs.append(f"frame {frame}: {k}: {nbad} of {want[k].size} elements differ")
+    run_pt_both.last_beauty = pb_cpu.beauty.copy()
+    return diffs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_len", [2, 5, 15])
+def test_bunny_path_tracer_bit_exact(built_lib, max_len):
+    diffs = run_pt_both(util.bunny_scene(), 128, 96, frames=2, max_len=max_len)
+    assert not diffs, "\n".join(diffs)
+    b = run_pt_both.last_beauty
+    assert np.all(np.isfinite(b)) and b[:, :3].max() > 0.0
+
+
+@pytest.mark.gpu
+def test_path_tracer_config2_resolution_bit_exact(built_lib):
+    """BASELINE.json configs[1]: bunny-class scene, 512x512, max path length 5."""
+    diffs = run_pt_both(util.bunny_scene(), 512, 512, frames=1, max_len=5, jitter=1,
+                        camera=api.make_camera(512, 512, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0))
+    assert not diffs, "\n".join(diffs)
+
+
+@pytest.mark.gpu
+def test_path_tracer_env_light_bit_exact(built_lib):
+    w, h = 64, 32
+    sky = api.env_make_sky(w, h)
+    diffs = run_pt_both(util.bunny_scene(), 96, 64, frames=2, max_len=4, env=(sky, w, h), env_rotation=0.7)
+    assert not diffs, "\n".join(diffs)
+
+
+@pytest.mark.gpu
+def test_path_tracer_street_instances_bit_exact(built_lib):
+    hs = util.small_street()
+    cam = api.make_camera(96, 64, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
+    diffs = run_pt_both(hs, 96, 64, frames=2, max_len=5, camera=cam)
+    assert not diffs, "\n".join(diffs)
+
+
+@pytest.mark.gpu
+def test_path_tracer_row_bands_equal_full_frame(built_lib):
+    """Row bands (the multi-GPU unit) launched one after the other reproduce the full frame."""
+    diffs = run_pt_both(util.bunny_scene(), 96, 64, frames=2, max_len=5, rows=[(0, 24), (24, 64)])
+    assert not diffs, "\n".join(diffs)
