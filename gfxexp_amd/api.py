@@ -15,7 +15,19 @@ GFX_INVALID_SLOT = 0xFFFFFFFF
 TRACE_CLOSEST, TRACE_ANY = 0, 1
 (PASS_SETUP_GBUFFERS, PASS_INITIAL_RIS, PASS_INITIAL_TEMPORAL_BIASED, PASS_INITIAL_TEMPORAL_UNBIASED,
  PASS_SPATIAL_BIASED, PASS_SPATIAL_UNBIASED, PASS_SHADING) = range(7)
-RENDERER_BIASED, RENDERER_UNBIASED, RENDERER_PATH_TRACE = 0, 1, 2
+# rearchitected ReSTIR: trace-shadow-rays / shade-and-resample entry points in the order of
+# RearchitectedReSTIREntryPoint (restir_di_main.cpp:83-95)
+PASS_LIGHT_PRESAMPLING, PASS_PER_PIXEL_RIS, PASS_TRACE_SHADOW_RAYS = 7, 8, 9
+PASS_SHADE_AND_RESAMPLE = 16
+
+
+def rearch_passes(temporal, spatial, unbiased, new_sequence):
+    """(traceShadowRays pass, shadeAndResample pass) as restir_di_main.cpp:2446-2484 selects them."""
+    if new_sequence or not (temporal or spatial):
+        return PASS_TRACE_SHADOW_RAYS, PASS_SHADE_AND_RESAMPLE
+    k = (1 if temporal and not spatial else 2 if spatial and not temporal else 3)
+    return PASS_TRACE_SHADOW_RAYS + k + (3 if unbiased else 0), PASS_SHADE_AND_RESAMPLE + k
+RENDERER_BIASED, RENDERER_UNBIASED, RENDERER_REARCH_BIASED, RENDERER_REARCH_UNBIASED, RENDERER_PATH_TRACE = 0, 1, 2, 3, 4
 PT_SETUP_GBUFFERS, PT_PATH_TRACE_BASELINE = 0, 1
 
 

@@ -46,8 +46,8 @@ void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_
     cfg->width = width; cfg->height = height; cfg->renderer = renderer;
     cfg->log2NumCandidateSamples = 5;                     // ReSTIRConfigs(5, 2, 5) / (5, 1, 3), :1966-1967
     cfg->enableTemporalReuse = 1; cfg->enableSpatialReuse = 1;
-    cfg->numSpatialReusePasses = renderer == GFXH_ORIGINAL_RESTIR_UNBIASED ? 1 : 2;
-    cfg->numSpatialNeighbors = renderer == GFXH_ORIGINAL_RESTIR_UNBIASED ? 3 : 5;
+    cfg->numSpatialReusePasses = renderer == GFXH_ORIGINAL_RESTIR_BIASED ? 2 : 1;
+    cfg->numSpatialNeighbors = renderer == GFXH_ORIGINAL_RESTIR_BIASED ? 5 : renderer == GFXH_ORIGINAL_RESTIR_UNBIASED ? 3 : 1;
     cfg->spatialNeighborRadius = 20.0f;
     cfg->useLowDiscrepancyNeighbors = 1;
     cfg->reuseVisibility = 1;
@@ -117,6 +117,12 @@ int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir*
     err |= alloc_dev(r, &sp.normalAccumBuffer, 16 * n, true);
     void* deltas = nullptr;
     err |= alloc_dev(r, &deltas, 8 * 1024, false);
+    const bool rearch = cfg->renderer == GFXH_REARCHITECTED_RESTIR_BIASED || cfg->renderer == GFXH_REARCHITECTED_RESTIR_UNBIASED;
+    constexpr size_t numPreSampledLights = 128 * 1024;     // numLightSubsets * lightSubsetSize, restir_di_shared.h:8-9
+    if (rearch) {
+        err |= alloc_dev(r, &sp.lightPreSamplingRngs, 8 * numPreSampledLights, false);
+        err |= alloc_dev(r, &sp.preSampledLights, 48 * numPreSampledLights, true);
+    }
     if (err) { gfxh_restir_destroy(r); return 1; }
     sp.spatialNeighborDeltas = deltas;
     sp.numTilesX = (cfg->width + 7) / 8; sp.numTilesY = (cfg->height + 7) / 8;
@@ -125,6 +131,11 @@ int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir*
         std::vector<uint64_t> states(n);
         gfxh_seed_rng_states(states.data(), n, 591842031321323413ull);
         if (!hip_ok(hipMemcpy(sp.rngBuffer, states.data(), 8 * n, hipMemcpyHostToDevice), "upload rng states")) { gfxh_restir_destroy(r); return 1; }
+        if (rearch) {   // restir_di_main.cpp:1216-1219
+            std::vector<uint64_t> pre(numPreSampledLights);
+            gfxh_seed_rng_states(pre.data(), numPreSampledLights, 894213312210ull);
+            if (!hip_ok(hipMemcpy(sp.lightPreSamplingRngs, pre.data(), 8 * numPreSampledLights, hipMemcpyHostToDevice), "upload pre-sampling rng states")) { gfxh_restir_destroy(r); return 1; }
+        }
         std::vector<float> d(2048);
         gfxh_spatial_neighbor_deltas(d.data());
         if (!hip_ok(hipMemcpy(deltas, d.data(), 8 * 1024, hipMemcpyHostToDevice), "upload neighbour table")) { gfxh_restir_destroy(r); return 1; }
@@ -233,7 +244,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     fp.reuseVisibilityForSpatiotemporal = 0;
     fp.enableTemporalReuse = cfg.enableTemporalReuse;
     fp.enableSpatialReuse = cfg.enableSpatialReuse;
-    fp.useUnbiasedEstimator = cfg.renderer == GFXH_ORIGINAL_RESTIR_UNBIASED;
+    fp.useUnbiasedEstimator = cfg.renderer == GFXH_ORIGINAL_RESTIR_UNBIASED || cfg.renderer == GFXH_REARCHITECTED_RESTIR_UNBIASED;
     fp.bufferIndex = bufferIndex;
     fp.resetFlowBuffer = newSequence;
     fp.enableJittering = cfg.enableJittering;
@@ -256,6 +267,24 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
         return 0;
     }
     DRV_GFX(gfx_restir_launch_rows(ctx, stream, GFX_RESTIR_SETUP_GBUFFERS, W, H, plan.gbufferRows[0], plan.gbufferRows[1]));   // :2366-2367
+
+    if (cfg.renderer == GFXH_REARCHITECTED_RESTIR_BIASED || cfg.renderer == GFXH_REARCHITECTED_RESTIR_UNBIASED) {
+        // restir_di_main.cpp:2423-2487; whole-frame only (the previous frame's reservoirs, sample
+        // visibility and G-buffers of halo rows are not exchanged for this renderer yet)
+        const bool T = cfg.enableTemporalReuse && !newSequence, S = cfg.enableSpatialReuse && !newSequence;
+        const int k = (T && S) ? 3 : T ? 1 : S ? 2 : 0;
+        const int trace = GFX_RESTIR_TRACE_SHADOW_RAYS + (k == 0 ? 0 : k + (fp.useUnbiasedEstimator ? 3 : 0));
+        const int shade = GFX_RESTIR_SHADE_AND_RESAMPLE + k;
+        DRV_GFX(gfx_restir_launch(ctx, stream, GFX_RESTIR_LIGHT_PRESAMPLING, W, H));
+        DRV_GFX(gfx_restir_launch(ctx, stream, GFX_RESTIR_PER_PIXEL_RIS, W, H));
+        DRV_GFX(gfx_restir_launch(ctx, stream, trace, W, H));
+        DRV_GFX(gfx_restir_launch(ctx, stream, shade, W, H));
+        ++r->lastSpatialNeighborBaseIndex;                                                     // :2486
+        r->lastReservoirIndex = currentReservoirIndex;
+        r->prevCamera = r->camera;
+        ++r->frameIndex;
+        return 0;
+    }
 
     int entry = GFX_RESTIR_INITIAL_RIS;                                                        // :2378-2384
     if (cfg.enableTemporalReuse && !newSequence)

@@ -88,6 +88,7 @@ struct Context {
     DevBuf rayOrg, rayDir, rayOut, rayHits, spill, pixelRaySlot, shadeScratch, spatialScratch, smallCounters;
     // path tracer scratch (pathtrace.hip)
     DevBuf ptPending, ptExtOrg, ptExtDir, ptExtOwner, ptState;
+    DevBuf rearchSlots;
     // build scratch
     DevBuf bTris, bBoxes, bKeys, bKeysAlt, bVals, bValsAlt, bSortTemp, bNodesLR, bParents, bFlags, bNodeBoxes, bRanges, bQueueA, bQueueB, bCounters;
     // restir

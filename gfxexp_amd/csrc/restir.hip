@@ -15,123 +15,10 @@
 #include "internal.h"
 #include "shading.hip.h"
 #include "pass_common.hip.h"
+#include "restir_common.hip.h"
+#include "restir_rearch.hip.h"
 
 namespace gfx {
-
-constexpr int kBlock = 256;
-constexpr uint32_t kSlotSkipped = 0xFFFFFFFEu;   // SpatialSlot.raySlot: neighbour not evaluated
-
-struct SpatialSlot {            // per (pixel, k): k = 0 self, 1..N neighbours (unbiased MIS denominators)
-    float targetDensity;        // unshadowed target of the selected sample at that pixel
-    uint32_t streamLength;
-    uint32_t raySlot;           // GFX_INVALID_SLOT: no ray needed
-};
-
-struct RestirArgs {
-    DevScene scene;
-    gfx_restir_static_params s;
-    gfx_restir_frame_params f;
-    uint32_t curRes, baseIdx;
-    size_t pixelBegin, pixelEnd;   // the launch covers pixels [pixelBegin, pixelEnd) (whole rows)
-    float4* rayOrg; float4* rayDir;
-    uint32_t* rayCount;
-    uint32_t* pixelRaySlot;
-    const uint32_t* occluded;
-    const gfx_hit* hits;
-    const Bvh8Tri* tris;
-    float4* shadeScratch;
-    SpatialSlot* spatialScratch;
-};
-
-// ---------------------------------------------------------------- reservoir planes
-struct Reservoir {
-    LightSample sample;
-    float sumWeights;
-    uint32_t streamLength;
-    GFX_DEV void reset() {
-        sample.emittance = f3(0.0f); sample.position = f3(0.0f); sample.normal = f3(0.0f); sample.atInfinity = 0;
-        sumWeights = 0; streamLength = 0;
-    }
-    GFX_DEV bool update(const LightSample& s, float weight, float u) {   // restir_di_shared.h:118-125
-        sumWeights += weight;
-        const bool accepted = u < weight / sumWeights;
-        if (accepted) sample = s;
-        ++streamLength;
-        return accepted;
-    }
-};
-GFX_DEV Reservoir load_reservoir(const void* buf, size_t numPixels, size_t p) {
-    const float4* b = static_cast<const float4*>(buf);
-    const float4 a = b[p], c = b[numPixels + p], d = b[2 * numPixels + p];
-    Reservoir r;
-    r.sample.emittance = f3(a.x, a.y, a.z);
-    r.sample.position = f3(a.w, c.x, c.y);
-    r.sample.normal = f3(c.z, c.w, d.x);
-    r.sample.atInfinity = f2bits(d.y) & 1u;
-    r.sumWeights = d.z;
-    r.streamLength = f2bits(d.w);
-    return r;
-}
-GFX_DEV void store_reservoir(void* buf, size_t numPixels, size_t p, const Reservoir& r) {
-    float4* b = static_cast<float4*>(buf);
-    b[p] = make_float4(r.sample.emittance.x, r.sample.emittance.y, r.sample.emittance.z, r.sample.position.x);
-    b[numPixels + p] = make_float4(r.sample.position.y, r.sample.position.z, r.sample.normal.x, r.sample.normal.y);
-    b[2 * numPixels + p] = make_float4(r.sample.normal.z, bits2f(r.sample.atInfinity & 1u), r.sumWeights, bits2f(r.streamLength));
-}
-
-GFX_DEV uint32_t emit_ray(bool want, f3 org, f3 dir, float tmin, float tmax, const RestirArgs& a) {
-    return queue_append(want, org, dir, tmin, tmax, a.rayOrg, a.rayDir, a.rayCount);
-}
-
-// Shading point re-derived from the quantised G-buffer (every pass does this).
-struct ShadingPoint {
-    f3 pos;        // offset ray origin
-    f3 vOutLocal;
-    float dist;
-    Frame frame;
-    Bsdf bsdf;
-};
-// normalizeFirst = false: vOut = cam - p; frontHit from the unnormalised vector; vOut /= |vOut|
-//                         (optix_restir_di_kernels.cu:41-46, 320-325)
-// normalizeFirst = true : vOut = normalize(cam - p); frontHit from the unit vector (:230-232, 574-577)
-GFX_DEV void make_shading_point(const RestirArgs& a, uint32_t bufIdx, size_t p, f3 camPos, bool normalizeFirst, ShadingPoint& sp) {
-    const float4 g2 = static_cast<const float4*>(a.s.gbuffer2[bufIdx])[p];
-    const uint4 g3 = static_cast<const uint4*>(a.s.gbuffer3[bufIdx])[p];
-    f3 pos(g2.x, g2.y, g2.z);
-    const f3 ng = decode_dir(f2bits(g2.w));
-    f3 vOut = camPos - pos;
-    float frontHit;
-    if (normalizeFirst) {
-        vOut = unit(vOut);
-        sp.dist = 0;
-        frontHit = dot(vOut, ng) >= 0.0f ? 1.0f : -1.0f;
-    }
-    else {
-        frontHit = dot(vOut, ng) >= 0.0f ? 1.0f : -1.0f;
-        sp.dist = len(vOut);
-        vOut = vOut / sp.dist;
-    }
-    sp.pos = offset_ray_origin(pos, frontHit * ng);
-    sp.frame = Frame(decode_dir(g3.x), decode_dir(g3.y));
-    sp.vOutLocal = sp.frame.to_local(vOut);
-    sp.bsdf.setup(a.scene.materials[g3.w]);
-}
-
-// restir_di_shared.h:747-771
-GFX_DEV bool test_neighbor(const RestirArgs& a, bool testGeometry, uint32_t nbBuf, int nx, int ny, float dist, f3 normal, f3 camPos) {
-    if (nx < 0 || nx >= a.s.imageSizeX || ny < 0 || ny >= a.s.imageSizeY) return false;
-    const size_t np = static_cast<size_t>(ny) * a.s.imageSizeX + nx;
-    const uint32_t nbInst = static_cast<const uint4*>(a.s.gbuffer0[nbBuf])[np].x;
-    if (nbInst == 0xFFFFFFFFu) return false;
-    if (testGeometry) {
-        const float4 g2 = static_cast<const float4*>(a.s.gbuffer2[nbBuf])[np];
-        const uint32_t qn = static_cast<const uint4*>(a.s.gbuffer3[nbBuf])[np].x;
-        const f3 nbNormal = decode_dir(qn);
-        const float nbDist = len(camPos - f3(g2.x, g2.y, g2.z));
-        if (fabsf(nbDist - dist) / dist > 0.1f || dot(normal, nbNormal) < 0.9f) return false;
-    }
-    return true;
-}
 
 // ---------------------------------------------------------------- SETUP_GBUFFERS
 // ray generation of optix_gbuffer_kernels.cu:5-27
@@ -704,7 +591,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
 }
 
 // ---------------------------------------------------------------- host sequencing
-static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {
+static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd, bool rearch) {
     const RestirParams& rp = ctx.restir;
     if (!rp.valid) throw HipError("gfx_restir_launch: gfx_restir_set_params has not been called");
     if (static_cast<uint32_t>(rp.s.imageSizeX) != width || static_cast<uint32_t>(rp.s.imageSizeY) != height)
@@ -712,7 +599,7 @@ static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint3
     const uint64_t h = rp.f.travHandle;
     if (h == 0 || h > ctx.accels.size() || !ctx.accels[h - 1]) throw HipError("gfx_restir_launch: invalid travHandle");
     const size_t numPixels = static_cast<size_t>(width) * height;
-    const size_t maxRays = numPixels * (1 + rp.f.numSpatialNeighbors);
+    const size_t maxRays = numPixels * std::max<size_t>(1 + rp.f.numSpatialNeighbors, rearch ? kRearchRayKinds : 1);
     ctx.rayOrg.reserve(16 * maxRays); ctx.rayDir.reserve(16 * maxRays);
     ctx.rayOut.reserve(4 * maxRays);
     ctx.rayHits.reserve(sizeof(gfx_hit) * numPixels);
@@ -733,6 +620,11 @@ static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint3
     a.tris = ctx.accels[h - 1]->tris.as<Bvh8Tri>();
     a.shadeScratch = ctx.shadeScratch.as<float4>();
     a.spatialScratch = ctx.spatialScratch.as<SpatialSlot>();
+    a.rearchSlots = nullptr;
+    if (rearch) {
+        ctx.rearchSlots.reserve(sizeof(uint32_t) * kRearchRayKinds * numPixels);
+        a.rearchSlots = ctx.rearchSlots.as<uint32_t>();
+    }
     if (rowEnd > height || rowBegin > rowEnd) throw HipError("gfx_restir_launch_rows: row range outside the image");
     a.pixelBegin = static_cast<size_t>(rowBegin) * width;
     a.pixelEnd = static_cast<size_t>(rowEnd) * width;
@@ -759,7 +651,8 @@ static void trace_queue(Context& ctx, hipStream_t stream, const RestirArgs& a, i
 }
 
 void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {
-    RestirArgs a = make_args(ctx, width, height, rowBegin, rowEnd);
+    const bool rearch = pass >= GFX_RESTIR_LIGHT_PRESAMPLING;
+    RestirArgs a = make_args(ctx, width, height, rowBegin, rowEnd, rearch);
     const uint32_t numPixels = static_cast<uint32_t>(a.pixelEnd - a.pixelBegin);
     if (numPixels == 0) return;
     auto reset_queue = [&]() { GFX_HIP(hipMemsetAsync(a.rayCount, 0, sizeof(uint32_t), stream)); };
@@ -802,6 +695,51 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
         launch_pixels(ctx, stream, "shade_finish", k_shade_finish, a);
         break;
+    case GFX_RESTIR_LIGHT_PRESAMPLING: {
+        if (!a.s.lightPreSamplingRngs || !a.s.preSampledLights) throw HipError("gfx_restir_launch: light pre-sampling buffers are not set");
+        ScopedKernelTimer timer(ctx, stream, "light_presample");
+        hipLaunchKernelGGL(k_light_presample, dim3(kNumPreSampledLights / kBlock), dim3(kBlock), 0, stream, a);
+        GFX_HIP(hipGetLastError());
+        break;
+    }
+    case GFX_RESTIR_PER_PIXEL_RIS: {
+        if (rowBegin % 8 != 0) throw HipError("gfx_restir_launch_rows: per-pixel RIS bands must start on an 8-row tile boundary");
+        const uint32_t tilesX = (width + 7) / 8, tileRows = (rowEnd + 7) / 8 - rowBegin / 8;
+        const uint32_t numTiles = tilesX * tileRows;
+        ScopedKernelTimer timer(ctx, stream, "per_pixel_ris");
+        hipLaunchKernelGGL(k_per_pixel_ris, dim3((numTiles + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, stream, a);
+        GFX_HIP(hipGetLastError());
+        break;
+    }
+    case GFX_RESTIR_TRACE_SHADOW_RAYS:
+    case GFX_RESTIR_TRACE_SHADOW_RAYS_TEMPORAL_BIASED:
+    case GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIAL_BIASED:
+    case GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIOTEMPORAL_BIASED:
+    case GFX_RESTIR_TRACE_SHADOW_RAYS_TEMPORAL_UNBIASED:
+    case GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIAL_UNBIASED:
+    case GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIOTEMPORAL_UNBIASED: {
+        reset_queue();
+        void (*emit)(RestirArgs) = nullptr; void (*finish)(RestirArgs) = nullptr;
+        switch (pass) {
+#define GFX_REARCH_CASE(PASS, T, S, U) case PASS: emit = k_rearch_emit<T, S, U>; finish = k_rearch_vis_finish<T, S, U>; break;
+        GFX_REARCH_CASE(GFX_RESTIR_TRACE_SHADOW_RAYS, false, false, false)
+        GFX_REARCH_CASE(GFX_RESTIR_TRACE_SHADOW_RAYS_TEMPORAL_BIASED, true, false, false)
+        GFX_REARCH_CASE(GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIAL_BIASED, false, true, false)
+        GFX_REARCH_CASE(GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIOTEMPORAL_BIASED, true, true, false)
+        GFX_REARCH_CASE(GFX_RESTIR_TRACE_SHADOW_RAYS_TEMPORAL_UNBIASED, true, false, true)
+        GFX_REARCH_CASE(GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIAL_UNBIASED, false, true, true)
+        GFX_REARCH_CASE(GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIOTEMPORAL_UNBIASED, true, true, true)
+#undef GFX_REARCH_CASE
+        }
+        launch_pixels(ctx, stream, "rearch_emit", emit, a);
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
+        launch_pixels(ctx, stream, "rearch_vis_finish", finish, a);
+        break;
+    }
+    case GFX_RESTIR_SHADE_AND_RESAMPLE: launch_pixels(ctx, stream, "rearch_shade", k_rearch_shade<false, false>, a); break;
+    case GFX_RESTIR_SHADE_AND_RESAMPLE_TEMPORAL: launch_pixels(ctx, stream, "rearch_shade_t", k_rearch_shade<true, false>, a); break;
+    case GFX_RESTIR_SHADE_AND_RESAMPLE_SPATIAL: launch_pixels(ctx, stream, "rearch_shade_s", k_rearch_shade<false, true>, a); break;
+    case GFX_RESTIR_SHADE_AND_RESAMPLE_SPATIOTEMPORAL: launch_pixels(ctx, stream, "rearch_shade_st", k_rearch_shade<true, true>, a); break;
     default:
         throw HipError("gfx_restir_launch: unknown pass");
     }

@@ -218,6 +218,25 @@ enum gfx_restir_pass {
     GFX_RESTIR_SPATIAL_BIASED = 4,                 /* :549-551 */
     GFX_RESTIR_SPATIAL_UNBIASED = 5,               /* :553-555 */
     GFX_RESTIR_SHADING = 6,                        /* :559-637 */
+    /* Rearchitected ReSTIR (restir_di_main.cpp:2423-2487).  preSampledLights = 131072 x 48 B
+     * ([emittance.rgb, position.x] [position.yz, normal.xy] [normal.z, atInfinity, areaPDensity, 0]),
+     * lightPreSamplingRngs = 131072 x u64 seeded from mt19937_64(894213312210) (:1216-1219),
+     * sampleVisibilityBuffer = the SampleVisibility bit union of restir_di_shared.h:146-164. */
+    GFX_RESTIR_LIGHT_PRESAMPLING = 7,              /* per_pixel_ris.cu:6-40 */
+    GFX_RESTIR_PER_PIXEL_RIS = 8,                  /* per_pixel_ris.cu:44-128 (8x8 tiles) */
+    /* optix_restir_di_rearch_kernels.cu:227-253, in the order of RearchitectedReSTIREntryPoint
+     * (restir_di_main.cpp:83-95) */
+    GFX_RESTIR_TRACE_SHADOW_RAYS = 9,
+    GFX_RESTIR_TRACE_SHADOW_RAYS_TEMPORAL_BIASED = 10,
+    GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIAL_BIASED = 11,
+    GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIOTEMPORAL_BIASED = 12,
+    GFX_RESTIR_TRACE_SHADOW_RAYS_TEMPORAL_UNBIASED = 13,
+    GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIAL_UNBIASED = 14,
+    GFX_RESTIR_TRACE_SHADOW_RAYS_SPATIOTEMPORAL_UNBIASED = 15,
+    GFX_RESTIR_SHADE_AND_RESAMPLE = 16,            /* :649-663 */
+    GFX_RESTIR_SHADE_AND_RESAMPLE_TEMPORAL = 17,
+    GFX_RESTIR_SHADE_AND_RESAMPLE_SPATIAL = 18,
+    GFX_RESTIR_SHADE_AND_RESAMPLE_SPATIOTEMPORAL = 19,
     GFX_RESTIR_NUM_PASSES
 };
 int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height);

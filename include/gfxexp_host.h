@@ -101,7 +101,9 @@ typedef struct gfxh_restir gfxh_restir;
 enum gfxh_renderer {
     GFXH_ORIGINAL_RESTIR_BIASED = 0,   /* restir_di_main.cpp:1958-1977 Renderer enum */
     GFXH_ORIGINAL_RESTIR_UNBIASED = 1,
-    GFXH_PATH_TRACE_BASELINE = 2       /* path_tracing/path_tracing_main.cpp:2068-2093 frame loop */
+    GFXH_REARCHITECTED_RESTIR_BIASED = 2,   /* frame loop :2423-2487, configs (5, 1, 1) :1966-1969 */
+    GFXH_REARCHITECTED_RESTIR_UNBIASED = 3,
+    GFXH_PATH_TRACE_BASELINE = 4       /* path_tracing/path_tracing_main.cpp:2068-2093 frame loop */
 };
 typedef struct gfxh_restir_config {
     uint32_t width, height;

@@ -11,6 +11,7 @@
 #include <string>
 #include "orc_restir.h"
 #include "orc_pathtrace.h"
+#include "orc_restir_rearch.h"
 
 using namespace orc;
 
@@ -273,6 +274,33 @@ int orc_restir_launch(orc_scene* s, const gfx_restir_static_params* sp, const gf
     p.prevCamera = toCamera(fp->prevCamera);
     if (x1 <= 0) x1 = sp->imageSizeX;
     if (y1 <= 0) y1 = sp->imageSizeY;
+    if (pass == GFX_RESTIR_LIGHT_PRESAMPLING) {
+#pragma omp parallel for schedule(static) num_threads(s->numThreads)
+        for (int i = 0; i < static_cast<int>(kNumLightSubsets * kLightSubsetSize); ++i) lightPreSamplingThread(p, static_cast<uint32_t>(i));
+        return 0;
+    }
+    if (pass == GFX_RESTIR_PER_PIXEL_RIS) {
+        const int tx0 = x0 / kTileSizeX, ty0 = y0 / kTileSizeY;
+        const int tx1 = (x1 + kTileSizeX - 1) / kTileSizeX, ty1 = (y1 + kTileSizeY - 1) / kTileSizeY;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(s->numThreads)
+        for (int ty = ty0; ty < ty1; ++ty)
+            for (int tx = tx0; tx < tx1; ++tx) perPixelRISTile(p, tx, ty);
+        return 0;
+    }
+    if (pass >= GFX_RESTIR_TRACE_SHADOW_RAYS && pass <= GFX_RESTIR_SHADE_AND_RESAMPLE_SPATIOTEMPORAL) {
+        // RearchitectedReSTIREntryPoint order (restir_di_main.cpp:83-95)
+        static const bool kT[11] = { false, true, false, true, true, false, true, false, true, false, true };
+        static const bool kS[11] = { false, false, true, true, false, true, true, false, false, true, true };
+        static const bool kU[11] = { false, false, false, false, true, true, true, false, false, false, false };
+        const int e = pass - GFX_RESTIR_TRACE_SHADOW_RAYS;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(s->numThreads)
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                if (e < 7) traceShadowRaysPixel(p, kT[e], kS[e], kU[e], x, y);
+                else shadeAndResamplePixel(p, kT[e], kS[e], x, y);
+            }
+        return 0;
+    }
 #pragma omp parallel for schedule(dynamic, 4) num_threads(s->numThreads)
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {

@@ -90,3 +90,27 @@ def test_path_tracer_row_bands_equal_full_frame(built_lib):
     """Row bands (the multi-GPU unit) launched one after the other reproduce the full frame."""
     diffs = run_pt_both(util.bunny_scene(), 96, 64, frames=2, max_len=5, rows=[(0, 24), (24, 64)])
     assert not diffs, "\n".join(diffs)
+
+
+@pytest.mark.gpu
+def test_headless_driver_path_trace_mode_with_accumulation(built_lib):
+    """gfxh_restir with renderer = GFXH_PATH_TRACE_BASELINE (the frame loop of path_tracing_main.cpp)
+    accumulating 3 frames equals the oracle sequenced by the harness."""
+    import torch
+    width, height, frames = 96, 64, 3
+    hs = util.bunny_scene()
+    diffs = run_pt_both(hs, width, height, frames=frames, max_len=5)
+    assert not diffs, "\n".join(diffs)
+    want = run_pt_both.last_beauty
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    cfg = api.RestirRenderer.default_config(width, height, api.RENDERER_PATH_TRACE)
+    assert cfg.maxPathLength == 5
+    cfg.enableAccumulation = 1
+    cfg.camera = api.make_camera(width, height, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+    r = api.RestirRenderer(ctx, cfg)
+    for _ in range(frames):
+        r.render_frame()
+    torch.cuda.synchronize()
+    out = ctx.read_device(r.beauty_ptr(), width * height * 16).view(np.float32).reshape(-1, 4)
+    util.assert_same_bits("driver beauty", out, want)

@@ -128,6 +128,9 @@ def pinhole_rays(width, height, cam_pos, look_at, fov_y_deg=45.0, tmax=np.float3
     return org, dirs
 
 
+PRESAMPLED_LIGHTS = 128 * 1024   # numLightSubsets * lightSubsetSize, restir_di_shared.h:8-9
+
+
 class PixelBuffers:
     """Host-side (numpy) copies of every ReSTIR per-pixel buffer in the ABI layouts."""
 
@@ -147,6 +150,9 @@ class PixelBuffers:
         self.normal = np.zeros((n, 4), np.float32)
         self.deltas = O.spatial_neighbor_deltas()
         self.env = None
+        # rearchitected ReSTIR: restir_di_main.cpp:1210-1222 (mt19937_64(894213312210))
+        self.presample_rngs = O.seed_rngs(PRESAMPLED_LIGHTS, 894213312210)
+        self.presampled = np.zeros((PRESAMPLED_LIGHTS, 12), np.float32)
 
     def set_env(self, texels, w, h):
         """Attach a lat-long environment map; the importance map comes from the product's host builder
@@ -165,8 +171,10 @@ class PixelBuffers:
         s.envTopPDF = ptr(e["topPDF"]); s.envTopCDF = ptr(e["topCDF"]); s.envTopIntegral = e["topIntegral"]
 
     def arrays(self):
-        out = {"rng": self.rng, "beauty": self.beauty, "albedo": self.albedo, "normal": self.normal}
+        out = {"rng": self.rng, "beauty": self.beauty, "albedo": self.albedo, "normal": self.normal,
+               "presample_rngs": self.presample_rngs, "presampled": self.presampled}
         for i in range(2):
+            out[f"vis_{i}"] = self.vis[i]
             out.update({f"gb0_{i}": self.gb0[i], f"gb1_{i}": self.gb1[i], f"gb2_{i}": self.gb2[i], f"gb3_{i}": self.gb3[i],
                         f"res_{i}": self.res[i], f"info_{i}": self.info[i]})
         return out
@@ -183,6 +191,7 @@ class PixelBuffers:
         s.spatialNeighborDeltas = ptr(self.deltas)
         s.beautyAccumBuffer = ptr(self.beauty); s.albedoAccumBuffer = ptr(self.albedo); s.normalAccumBuffer = ptr(self.normal)
         s.numTilesX, s.numTilesY = (self.w + 7) // 8, (self.h + 7) // 8
+        s.lightPreSamplingRngs = ptr(self.presample_rngs); s.preSampledLights = ptr(self.presampled)
         self._fill_env(s, ptr)
         return s
 
@@ -201,8 +210,6 @@ class DeviceBuffers:
         for k, a in pb.arrays().items():
             self.t[k] = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda()
         self.t["deltas"] = torch.from_numpy(pb.deltas.view(np.uint8).reshape(-1).copy()).cuda()
-        for i in range(2):
-            self.t[f"vis_{i}"] = torch.zeros(pb.n * 4, dtype=torch.uint8, device="cuda")
         self.env_t = {}
         if pb.env is not None:
             for k in ("texels", "rowPDF", "rowCDF", "rowIntegrals", "topPDF", "topCDF"):
@@ -222,6 +229,7 @@ class DeviceBuffers:
         s.beautyAccumBuffer = t["beauty"].data_ptr(); s.albedoAccumBuffer = t["albedo"].data_ptr()
         s.normalAccumBuffer = t["normal"].data_ptr()
         s.numTilesX, s.numTilesY = (pb.w + 7) // 8, (pb.h + 7) // 8
+        s.lightPreSamplingRngs = t["presample_rngs"].data_ptr(); s.preSampledLights = t["presampled"].data_ptr()
         if pb.env is not None:
             e, et = pb.env, self.env_t
             s.envLightTexture = et["texels"].data_ptr(); s.envWidth, s.envHeight = e["w"], e["h"]
