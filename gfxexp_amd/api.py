@@ -28,7 +28,8 @@ def rearch_passes(temporal, spatial, unbiased, new_sequence):
     k = (1 if temporal and not spatial else 2 if spatial and not temporal else 3)
     return PASS_TRACE_SHADOW_RAYS + k + (3 if unbiased else 0), PASS_SHADE_AND_RESAMPLE + k
 RENDERER_BIASED, RENDERER_UNBIASED, RENDERER_REARCH_BIASED, RENDERER_REARCH_UNBIASED, RENDERER_PATH_TRACE = 0, 1, 2, 3, 4
-PT_SETUP_GBUFFERS, PT_PATH_TRACE_BASELINE = 0, 1
+(PT_SETUP_GBUFFERS, PT_PATH_TRACE_BASELINE, PT_REGIR_BUILD_CELLS, PT_REGIR_BUILD_CELLS_TEMPORAL,
+ PT_PATH_TRACE_REGIR, PT_REGIR_UPDATE_LAST_ACCESS) = range(6)
 
 
 class GfxError(RuntimeError):
@@ -79,6 +80,14 @@ class GfxRestirFrameParams(C.Structure):
     ]
 
 
+class GfxRegirParams(C.Structure):
+    _fields_ = [("reservoirs", C.c_void_p * 2), ("reservoirInfos", C.c_void_p * 2), ("lightSlotRngs", C.c_void_p),
+                ("perCellNumAccesses", C.c_void_p), ("lastAccessFrameIndices", C.c_void_p),
+                ("numActiveCells", C.c_void_p * 2), ("gridOrigin", C.c_float * 3), ("gridCellSize", C.c_float * 3),
+                ("gridDimension", C.c_uint32 * 3), ("log2NumCandidatesPerLightSlot", C.c_uint32),
+                ("log2NumCandidatesPerCell", C.c_uint32), ("enableCellRandomization", C.c_uint32)]
+
+
 class GfxhStreetParams(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("groundTess", C.c_uint32), ("numBuildings", C.c_uint32),
                 ("facadeTess", C.c_uint32), ("numProps", C.c_uint32), ("propSubdiv", C.c_uint32),
@@ -120,7 +129,7 @@ C_ABI_SYMBOLS = [
     "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_accel_build",
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
-    "gfx_restir_launch_rows", "gfx_pt_launch",
+    "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
     "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read",
 ]
 HOST_ABI_SYMBOLS = [
@@ -408,6 +417,9 @@ class Context:
 
     def restir_launch(self, pass_id, width, height, stream=0):
         self._check(self.L.gfx_restir_launch(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height)))
+
+    def regir_set_params(self, params):
+        self._check(self.L.gfx_regir_set_params(self.h, C.byref(params)))
 
     def pt_launch(self, pass_id, width, height, max_path_length, row_begin=0, row_end=0, stream=0):
         self._check(self.L.gfx_pt_launch(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height),

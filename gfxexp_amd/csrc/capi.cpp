@@ -233,6 +233,15 @@ int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width,
     GFX_CATCH(ctx)
 }
 
+int gfx_regir_set_params(gfx_ctx* ctx, const gfx_regir_params* p) {
+    GFX_TRY(ctx)
+    if (!p) throw HipError("gfx_regir_set_params: null parameters");
+    if (!p->gridDimension[0] || !p->gridDimension[1] || !p->gridDimension[2]) throw HipError("gfx_regir_set_params: empty grid");
+    ctx->c.regir = *p;
+    ctx->c.regirValid = true;
+    GFX_CATCH(ctx)
+}
+
 int gfx_pt_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height, uint32_t maxPathLength,
                   uint32_t rowBegin, uint32_t rowEnd) {
     GFX_TRY(ctx)

@@ -93,6 +93,8 @@ struct Context {
     DevBuf bTris, bBoxes, bKeys, bKeysAlt, bVals, bValsAlt, bSortTemp, bNodesLR, bParents, bFlags, bNodeBoxes, bRanges, bQueueA, bQueueB, bCounters;
     // restir
     RestirParams restir;
+    gfx_regir_params regir;
+    bool regirValid = false;
     // instrumentation
     bool timingEnabled = false;
     std::map<std::string, KernelTiming> timings;

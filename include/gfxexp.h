@@ -259,8 +259,35 @@ int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width,
  * is passed here.  Rows [rowBegin, rowEnd) as in gfx_restir_launch_rows; rowEnd == 0 -> whole frame. */
 enum gfx_pt_pass {
     GFX_PT_SETUP_GBUFFERS = 0,        /* path_tracing/gpu_kernels/optix_gbuffer_kernels.cu */
-    GFX_PT_PATH_TRACE_BASELINE = 1    /* optix_pathtracing_kernels.cu:298-341 (pathTraceBaseline RG/CH/MS) */
+    GFX_PT_PATH_TRACE_BASELINE = 1,   /* optix_pathtracing_kernels.cu:298-341 (pathTraceBaseline RG/CH/MS) */
+    /* ReGIR (regir/regir_main.cpp:2031-2066); need gfx_regir_set_params */
+    GFX_PT_REGIR_BUILD_CELL_RESERVOIRS = 2,           /* regir/gpu_kernels/build_cell_reservoirs.cu:221-223 */
+    GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL = 3,  /* :225-227 */
+    GFX_PT_PATH_TRACE_REGIR = 4,                      /* regir/gpu_kernels/optix_pathtracing_kernels.cu:425-433 */
+    GFX_PT_REGIR_UPDATE_LAST_ACCESS = 5               /* build_cell_reservoirs.cu:229-243 */
 };
+
+/* The ReGIR members of regir/regir_shared.h:200-263 (grid of cells x 512 light slots).  Light-slot
+ * reservoirs use the three-plane layout of the pixel reservoirs: plane k of buffer b at
+ * reservoirs[b] + 16 * (k * numLightSlots + slot), numLightSlots = cells * 512.
+ * lightSlotRngs are seeded row-major from mt19937_64(591842031321323413) (regir_main.cpp:1086-1092),
+ * lastAccessFrameIndices start at 0xFFFFFFFF (regir_main.cpp:1096, 1112: fill(-1)).
+ * The build passes read frame.frameIndex and frame.bufferIndex. */
+typedef struct gfx_regir_params {
+    void* reservoirs[2];
+    void* reservoirInfos[2];         /* gfx_reservoir_info[numLightSlots] */
+    void* lightSlotRngs;             /* uint64_t[numLightSlots] */
+    void* perCellNumAccesses;        /* uint32_t[numCells] */
+    void* lastAccessFrameIndices;    /* uint32_t[numCells] */
+    void* numActiveCells[2];         /* uint32_t each (statistics) */
+    float gridOrigin[3];
+    float gridCellSize[3];
+    uint32_t gridDimension[3];       /* 32 x 8 x 32 in the reference (regir_main.cpp:1112) */
+    uint32_t log2NumCandidatesPerLightSlot;   /* 3 (regir_main.cpp:1733) */
+    uint32_t log2NumCandidatesPerCell;        /* 2 (:1734) */
+    uint32_t enableCellRandomization;         /* 1 (:1736) */
+} gfx_regir_params;
+int gfx_regir_set_params(gfx_ctx* ctx, const gfx_regir_params* p);
 int gfx_pt_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height,
                   uint32_t maxPathLength, uint32_t rowBegin, uint32_t rowEnd);
 

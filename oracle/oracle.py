@@ -65,6 +65,14 @@ class GfxRestirFrameParams(C.Structure):
     ]
 
 
+class GfxRegirParams(C.Structure):
+    _fields_ = [("reservoirs", C.c_void_p * 2), ("reservoirInfos", C.c_void_p * 2), ("lightSlotRngs", C.c_void_p),
+                ("perCellNumAccesses", C.c_void_p), ("lastAccessFrameIndices", C.c_void_p),
+                ("numActiveCells", C.c_void_p * 2), ("gridOrigin", C.c_float * 3), ("gridCellSize", C.c_float * 3),
+                ("gridDimension", C.c_uint32 * 3), ("log2NumCandidatesPerLightSlot", C.c_uint32),
+                ("log2NumCandidatesPerCell", C.c_uint32), ("enableCellRandomization", C.c_uint32)]
+
+
 GFX_HIT_DTYPE = np.dtype([("dist", "<f4"), ("bcB", "<f4"), ("bcC", "<f4"), ("triIndex", "<u4")])
 GFX_TRI_IDS_DTYPE = np.dtype([("instSlot", "<u4"), ("geomInstSlot", "<u4"), ("primIndex", "<u4")])
 GFX_VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("texCoord0Dir", "<f4", 3),
@@ -192,6 +200,9 @@ class OracleScene:
         self.L.orc_restir_launch(self.h, C.byref(static_params), C.byref(frame_params),
                                  C.c_uint32(cur_res_index), C.c_uint32(base_index), C.c_int(pass_id),
                                  C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1))
+
+    def regir_set_params(self, params):
+        self.L.orc_regir_set_params(self.h, C.byref(params))
 
     def pt_launch(self, static_params, frame_params, pass_id, max_path_length, rect=None):
         x0, y0, x1, y1 = rect if rect else (0, 0, 0, 0)

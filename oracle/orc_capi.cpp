@@ -318,17 +318,53 @@ int orc_restir_launch(orc_scene* s, const gfx_restir_static_params* sp, const gf
     return 0;
 }
 
-// Baseline path tracer (path_tracing/path_tracing_main.cpp:2068-2093: G-buffer pass, then the
-// pathTraceBaseline pipeline).  pass 0 = setupGBuffers (same program text as ReSTIR's), 1 = path trace.
+// Path tracers (path_tracing/path_tracing_main.cpp:2068-2093, regir/regir_main.cpp:2021-2066).
+// pass = gfx_pt_pass.
+static gfx_regir_params g_regirParams;
+static bool g_regirValid = false;
+int orc_regir_set_params(orc_scene*, const gfx_regir_params* p) { g_regirParams = *p; g_regirValid = true; return 0; }
+
 int orc_pt_launch(orc_scene* s, const gfx_restir_static_params* sp, const gfx_restir_frame_params* fp,
                   int pass, uint32_t maxPathLength, int x0, int y0, int x1, int y1) {
     orc_env_set(s, sp);
-    if (pass == 0)
+    if (pass == GFX_PT_SETUP_GBUFFERS)
         return orc_restir_launch(s, sp, fp, 0, 0, GFX_RESTIR_SETUP_GBUFFERS, x0, y0, x1, y1);
+    RegirState rs; rs.g = &g_regirParams;
+    Params rp; rp.scene = &s->scene; rp.accel = &s->accel; rp.s = sp; rp.f = fp;
+    rp.currentReservoirIndex = 0; rp.spatialNeighborBaseIndex = 0;
+    rp.camera = toCamera(fp->camera); rp.prevCamera = toCamera(fp->prevCamera);
+    if (pass == GFX_PT_REGIR_BUILD_CELL_RESERVOIRS || pass == GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL) {
+        if (!g_regirValid) return 1;
+        const uint32_t numCells = rs.numCells();
+        *static_cast<uint32_t*>(g_regirParams.numActiveCells[fp->bufferIndex]) = 0;
+        // the kernel zeroes the access counter of every cell before the activity test (:76-78)
+        std::memset(g_regirParams.perCellNumAccesses, 0, sizeof(uint32_t) * numCells);
+        const bool temporal = pass == GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL;
+#pragma omp parallel for schedule(dynamic, 512) num_threads(s->numThreads)
+        for (long long i = 0; i < static_cast<long long>(rs.numLightSlots()); ++i)
+            buildCellReservoirThread(rp, rs, temporal, static_cast<uint32_t>(i));
+        return 0;
+    }
+    if (pass == GFX_PT_REGIR_UPDATE_LAST_ACCESS) {
+        if (!g_regirValid) return 1;
+        const uint32_t numCells = rs.numCells();
+        const uint32_t* acc = static_cast<const uint32_t*>(g_regirParams.perCellNumAccesses);
+        uint32_t* last = static_cast<uint32_t*>(g_regirParams.lastAccessFrameIndices);
+        uint32_t active = 0;
+        for (uint32_t c = 0; c < numCells; ++c)
+            if (acc[c] > 0) { last[c] = fp->frameIndex; ++active; }
+        *static_cast<uint32_t*>(g_regirParams.numActiveCells[fp->bufferIndex]) += active;
+        return 0;
+    }
     PathTraceParams p;
     p.scene = &s->scene; p.accel = &s->accel; p.s = sp; p.f = fp;
     p.camera = toCamera(fp->camera);
     p.maxPathLength = maxPathLength & 15u; // 4-bit bitfield, path_tracing_shared.h:165
+    if (pass == GFX_PT_PATH_TRACE_REGIR) {
+        if (!g_regirValid) return 1;
+        p.regir = &rs;
+    }
+    else if (pass != GFX_PT_PATH_TRACE_BASELINE) return 1;
     if (x1 <= 0) x1 = sp->imageSizeX;
     if (y1 <= 0) y1 = sp->imageSizeY;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(s->numThreads)

@@ -10,6 +10,7 @@
 //                                restir_di/restir_di_shared.h:584-721)
 #pragma once
 #include "orc_restir.h"
+#include "orc_regir.h"
 
 namespace orc {
 
@@ -93,6 +94,7 @@ struct PathTraceParams {
     const gfx_restir_static_params* s; const gfx_restir_frame_params* f;
     PerspectiveCamera camera;
     uint32_t maxPathLength;
+    const RegirState* regir = nullptr;   // non-null: pathTraceReGIR (regir/gpu_kernels/optix_pathtracing_kernels.cu:425-433)
     bool envEnabled() const { return s->envLightTexture != nullptr && f->enableEnvLight; }
 };
 
@@ -106,6 +108,18 @@ static inline RGB performNextEventEstimation(const PathTraceParams& p, const Vis
                                              const ReferenceFrame& shadingFrame, const BSDF& bsdf, PCG32RNG& rng) {
     const Scene& scene = *p.scene;
     RGB ret(0.0f);
+    if (p.regir) { // regir/gpu_kernels/optix_pathtracing_kernels.cu:90-102
+        Params rp; rp.scene = p.scene; rp.accel = p.accel; rp.s = p.s; rp.f = p.f;
+        LightSample lightSample;
+        float recProbDensityEstimate;
+        const RGB unshadowedContribution = sampleFromCell(rp, *p.regir, shadingPoint, vOutLocal, shadingFrame, bsdf, rng,
+                                                          &lightSample, &recProbDensityEstimate);
+        if (recProbDensityEstimate > 0.0f) {
+            const float visibility = evaluateVisibility(visFn, shadingPoint, lightSample) ? 1.0f : 0.0f;
+            ret = unshadowedContribution * (visibility * recProbDensityEstimate);
+        }
+        return ret;
+    }
     float uLight = rng.getFloat0cTo1o();
     bool selectEnvLight = false;
     float probToSampleCurLightType = 1.0f;
@@ -192,9 +206,15 @@ static inline void pathTracePixel(const PathTraceParams& p, int x, int y) {
             if (!isValidSampling) break;
             ++pathLength;
             const bool maxLengthTerminate = pathLength >= p.maxPathLength;
+            if (p.regir) { // useReGIR: regir/gpu_kernels/optix_pathtracing_kernels.cu:247-256
+                if (maxLengthTerminate) break;
+                const float continueProb = std::fmin(sRGB_calcLuminance(alpha) / initImportance, 1.0f);
+                if (rng.getFloat0cTo1o() >= continueProb) break;
+                alpha /= continueProb;
+            }
             const bvh::HitObject h = closestHitCanonical(*p.accel, rayOrg, rayDir, 0.0f, 3.402823466e+38f);
-            if (!h.isHit()) { // miss program
-                if (useEnvLight) {
+            if (!h.isHit()) { // miss program (the ReGIR ray type has an empty miss program, regir_main.cpp:250)
+                if (useEnvLight && !p.regir) {
                     const V3 rd = normalize(rayDir);
                     float posPhi, theta;
                     toPolarYUp(rd, &posPhi, &theta);
@@ -217,6 +237,10 @@ static inline void pathTracePixel(const PathTraceParams& p, int x, int y) {
             const GeometryInstanceData& hg = scene.geomInsts[hGeom];
             V3 pos, sn, tc0, gn; V2 tc; float hypAreaPDensity;
             computeSurfacePointCH(scene, useEnvLight, hInst, hi, hg, h.primIndex, h.bcB, h.bcC, &pos, &sn, &tc0, &gn, &tc, &hypAreaPDensity);
+            // pathTraceReGIR instantiates computeSurfacePoint<false, ..> and then READS hypAreaPDensity
+            // uninitialised (regir/.../optix_pathtracing_kernels.cu:323-330, :356-361): undefined in the
+            // reference; this build defines it as 0 (MIS weight 1 for implicit light hits).
+            if (p.regir) hypAreaPDensity = 0.0f;
             const MaterialData& mat = scene.materials[hg.materialSlot];
             const V3 vOut = normalize(-rayDir);
             const float frontHit = dot(vOut, gn) >= 0.0f ? 1.0f : -1.0f;

@@ -287,3 +287,55 @@ def assert_same_bits(name, a, b):
         raise AssertionError(f"{name}: {len(bad)} differing bytes, first at element {first}: "
                              f"{np.ascontiguousarray(a).reshape(-1)[first] if item > 1 else a8[bad[0]]} vs "
                              f"{np.ascontiguousarray(b).reshape(-1)[first] if item > 1 else b8[bad[0]]}")
+
+
+class RegirBuffers:
+    """Host (numpy) ReGIR grid state in the ABI layout; device mirrors via to_device()."""
+
+    def __init__(self, bounds, dims=(8, 4, 8), log2_slot=3, log2_cell=2, randomize=1):
+        self.dims = tuple(int(d) for d in dims)
+        self.cells = self.dims[0] * self.dims[1] * self.dims[2]
+        self.slots = self.cells * 512
+        lo, hi = np.asarray(bounds[:3], np.float32), np.asarray(bounds[3:], np.float32)
+        self.origin = lo
+        self.cell_size = ((hi - lo) / np.asarray(self.dims, np.float32)).astype(np.float32)   # regir_main.cpp:1079
+        self.res = [np.zeros((3, self.slots, 4), np.float32) for _ in range(2)]
+        self.info = [np.zeros((self.slots, 2), np.float32) for _ in range(2)]
+        self.rngs = O.seed_rngs(self.slots, PIXEL_RNG_SEED)                                 # regir_main.cpp:1086-1092
+        self.accesses = np.zeros(self.cells, np.uint32)
+        self.last_access = np.full(self.cells, 0xFFFFFFFF, np.uint32)                       # fill(-1), :1096, :1112
+        self.active = [np.zeros(1, np.uint32) for _ in range(2)]
+        self.cfg = (log2_slot, log2_cell, randomize)
+        self.t = None
+
+    def arrays(self):
+        out = {"regir_rngs": self.rngs, "regir_accesses": self.accesses, "regir_last_access": self.last_access}
+        for i in range(2):
+            out.update({f"regir_res_{i}": self.res[i], f"regir_info_{i}": self.info[i], f"regir_active_{i}": self.active[i]})
+        return out
+
+    def _params(self, cls, ptr):
+        g = cls()
+        for i in range(2):
+            g.reservoirs[i] = ptr(f"regir_res_{i}"); g.reservoirInfos[i] = ptr(f"regir_info_{i}")
+            g.numActiveCells[i] = ptr(f"regir_active_{i}")
+        g.lightSlotRngs = ptr("regir_rngs"); g.perCellNumAccesses = ptr("regir_accesses")
+        g.lastAccessFrameIndices = ptr("regir_last_access")
+        for k in range(3):
+            g.gridOrigin[k] = float(self.origin[k]); g.gridCellSize[k] = float(self.cell_size[k]); g.gridDimension[k] = self.dims[k]
+        g.log2NumCandidatesPerLightSlot, g.log2NumCandidatesPerCell, g.enableCellRandomization = self.cfg
+        return g
+
+    def host_params(self):
+        arrs = self.arrays()
+        return self._params(O.GfxRegirParams, lambda k: arrs[k].ctypes.data)
+
+    def device_params(self):
+        import torch
+        self.t = {k: torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda() for k, a in self.arrays().items()}
+        return self._params(api.GfxRegirParams, lambda k: self.t[k].data_ptr())
+
+    def download(self):
+        import torch
+        torch.cuda.synchronize()
+        return {k: self.t[k].cpu().numpy().view(a.dtype).reshape(a.shape) for k, a in self.arrays().items()}
