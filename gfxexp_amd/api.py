@@ -130,6 +130,8 @@ C_ABI_SYMBOLS = [
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
     "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
+    "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
+    "gfx_nrc_get_params",
     "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read",
 ]
 HOST_ABI_SYMBOLS = [
@@ -449,6 +451,51 @@ class Context:
         c = (C.c_uint64 * 4)()
         self._check(self.L.gfx_counters_read(self.h, c, C.c_int(1 if reset else 0)))
         return dict(nodeFetches=c[0], triFetches=c[1], rays=c[2], spills=c[3])
+
+
+NRC_TRIANGLE_WAVE, NRC_HASH_GRID = 0, 1
+
+
+class NeuralRadianceCache:
+    """gfx_nrc_*: the network behind NeuralRadianceCache (network_interface.h:14-28).  Inputs and
+    outputs are device pointers to column-major fp32 [14, N] / [3, N] (torch tensors of shape [N, 14] /
+    [N, 3], contiguous)."""
+
+    def __init__(self, ctx, position_encoding=NRC_HASH_GRID, num_hidden_layers=2, learning_rate=1e-2):
+        self.ctx, self.L = ctx, lib()
+        h = C.c_uint64()
+        ctx._check(self.L.gfx_nrc_create(ctx.h, C.c_int(position_encoding), C.c_uint32(num_hidden_layers),
+                                         C.c_float(learning_rate), C.byref(h)))
+        self.h = h.value
+
+    def close(self):
+        if self.h:
+            self.L.gfx_nrc_destroy(self.ctx.h, C.c_uint64(self.h))
+            self.h = 0
+
+    def num_params(self):
+        n = C.c_uint32()
+        self.ctx._check(self.L.gfx_nrc_num_params(self.ctx.h, C.c_uint64(self.h), C.byref(n)))
+        return n.value
+
+    def set_params(self, params):
+        p = np.ascontiguousarray(params, np.float32)
+        self.ctx._check(self.L.gfx_nrc_set_params(self.ctx.h, C.c_uint64(self.h), _p(p), C.c_uint32(p.size)))
+
+    def get_params(self, which=0):
+        out = np.zeros(self.num_params(), np.float32)
+        self.ctx._check(self.L.gfx_nrc_get_params(self.ctx.h, C.c_uint64(self.h), C.c_int(which), _p(out), C.c_uint32(out.size)))
+        return out
+
+    def infer(self, d_inputs, num_data, d_predictions, stream=0):
+        self.ctx._check(self.L.gfx_nrc_infer(self.ctx.h, C.c_void_p(stream), C.c_uint64(self.h), C.c_void_p(d_inputs),
+                                             C.c_uint32(num_data), C.c_void_p(d_predictions)))
+
+    def train(self, d_inputs, d_targets, num_data, want_loss=False, stream=0):
+        loss = C.c_float(0.0)
+        self.ctx._check(self.L.gfx_nrc_train(self.ctx.h, C.c_void_p(stream), C.c_uint64(self.h), C.c_void_p(d_inputs),
+                                             C.c_void_p(d_targets), C.c_uint32(num_data), C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
 
 
 class RestirRenderer:

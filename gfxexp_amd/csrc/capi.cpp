@@ -250,6 +250,50 @@ int gfx_pt_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t
     GFX_CATCH(ctx)
 }
 
+static NrcNet* nrc_of(gfx_ctx* ctx, uint64_t handle) {
+    if (handle == 0 || handle > ctx->c.nrcNets.size() || !ctx->c.nrcNets[handle - 1]) throw HipError("gfx_nrc: invalid network handle");
+    return ctx->c.nrcNets[handle - 1];
+}
+int gfx_nrc_create(gfx_ctx* ctx, int positionEncoding, uint32_t numHiddenLayers, float learningRate, uint64_t* outHandle) {
+    GFX_TRY(ctx)
+    ctx->c.nrcNets.push_back(nrc_create(ctx->c, positionEncoding, numHiddenLayers, learningRate));
+    *outHandle = ctx->c.nrcNets.size();
+    GFX_CATCH(ctx)
+}
+int gfx_nrc_destroy(gfx_ctx* ctx, uint64_t handle) {
+    GFX_TRY(ctx)
+    NrcNet* net = nrc_of(ctx, handle);
+    GFX_HIP(hipDeviceSynchronize());
+    nrc_destroy(net);
+    ctx->c.nrcNets[handle - 1] = nullptr;
+    GFX_CATCH(ctx)
+}
+int gfx_nrc_infer(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInputData, uint32_t numData, void* dPredictionData) {
+    GFX_TRY(ctx)
+    nrc_infer(ctx->c, static_cast<hipStream_t>(stream), nrc_of(ctx, handle), static_cast<const float*>(dInputData), numData, static_cast<float*>(dPredictionData));
+    GFX_CATCH(ctx)
+}
+int gfx_nrc_train(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInputData, const void* dTargetData, uint32_t numData, float* lossOnCPU) {
+    GFX_TRY(ctx)
+    nrc_train(ctx->c, static_cast<hipStream_t>(stream), nrc_of(ctx, handle), static_cast<const float*>(dInputData), static_cast<const float*>(dTargetData), numData, lossOnCPU);
+    GFX_CATCH(ctx)
+}
+int gfx_nrc_num_params(gfx_ctx* ctx, uint64_t handle, uint32_t* outCount) {
+    GFX_TRY(ctx)
+    *outCount = nrc_num_params(nrc_of(ctx, handle));
+    GFX_CATCH(ctx)
+}
+int gfx_nrc_set_params(gfx_ctx* ctx, uint64_t handle, const float* hostParams, uint32_t count) {
+    GFX_TRY(ctx)
+    nrc_set_params(ctx->c, nullptr, nrc_of(ctx, handle), hostParams, count);
+    GFX_CATCH(ctx)
+}
+int gfx_nrc_get_params(gfx_ctx* ctx, uint64_t handle, int which, float* hostOut, uint32_t count) {
+    GFX_TRY(ctx)
+    nrc_get_params(nrc_of(ctx, handle), which, hostOut, count);
+    GFX_CATCH(ctx)
+}
+
 int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes) {
     GFX_TRY(ctx)
     GFX_HIP(hipDeviceSynchronize());

@@ -59,6 +59,8 @@ struct RestirParams {
     bool valid = false;
 };
 
+struct NrcNet;
+
 struct Context {
     int device = 0;
     std::string lastError;
@@ -94,6 +96,7 @@ struct Context {
     // restir
     RestirParams restir;
     gfx_regir_params regir;
+    std::vector<NrcNet*> nrcNets;
     bool regirValid = false;
     // instrumentation
     bool timingEnabled = false;
@@ -137,6 +140,15 @@ void lights_build_static(Context& ctx, hipStream_t stream);
 void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t bufferIndex);
 // ---- restir.hip
 void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd);
+// ---- nrc.hip
+struct NrcNet;
+NrcNet* nrc_create(Context& ctx, int posEnc, uint32_t numHiddenLayers, float learningRate);
+void nrc_destroy(NrcNet* net);
+uint32_t nrc_num_params(const NrcNet* net);
+void nrc_set_params(Context& ctx, hipStream_t stream, NrcNet* net, const float* hostParams, uint32_t count);
+void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count);
+void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions);
+void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, const float* dTargets, uint32_t numData, float* lossOnCPU);
 // ---- pathtrace.hip
 void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height,
                       uint32_t maxPathLength, uint32_t rowBegin, uint32_t rowEnd);

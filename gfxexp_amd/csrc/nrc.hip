@@ -1,0 +1,715 @@
+// nrc.hip -- the neural radiance cache network: input encoding + fully fused 64-wide MLP on the
+// MFMA units (v_mfma_f32_32x32x16_bf16), training step (forward, relative-L2-luminance loss,
+// backward, Adam + EMA) and the C ABI behind NeuralRadianceCache
+// (neural_radiance_caching/network_interface.h:14-28, network_interface.cu:48-157).
+//
+// tiny-cuda-nn is not vendored in the reference (ext/tiny-cuda-nn is an empty submodule), so the
+// arithmetic follows the published algorithms as restated in oracle/nrc_net.py (parity unpinned).
+//
+// Formulation.  Every layer is computed transposed, H_out^T [64 x batch] = W [64 x 64] . H_in^T [64 x batch]:
+// the weight tile is the MFMA A operand (M = out feature, K = in feature), the activations are the
+// B operand (K = in feature, N = batch column).  With the 32x32x16 shape a wave owns 64 batch
+// columns (two N tiles); lane (n = lane & 31, h = lane >> 5) holds, for batch column n of each tile,
+// the 16 accumulator rows (reg & 3) + 8 * (reg >> 2) + 4 * h of each 32-row M tile.  The B operand
+// of the NEXT layer wants 8 consecutive K slots per lane -- instead of shuffling, the K order of
+// every weight matrix is permuted once when it is packed: K slot (s, h, i) carries feature
+//     f(s, h, i) = 16 s + 8 (i >> 2) + 4 h + (i & 3),
+// which is exactly accumulator register 8 (s & 1) + i of M tile s >> 1.  Activations therefore stay
+// in registers from the encoding to the output with no LDS round trip and no cross-lane traffic;
+// LDS holds the packed bf16 weight fragments (one ds_read_b128 per fragment per lane).
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "internal.h"
+#include "gm_math.hip.h"
+
+#define GFX_HOSTDEV __host__ __device__
+
+namespace gfx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kNrcIn = 14, kNrcOut = 3, kNrcOutPad = 16;
+constexpr int kHashLevels = 16, kLog2Hashmap = 15, kBaseRes = 16;
+constexpr int kTriFreqs = 12;
+constexpr int kMaxHidden = 5;
+constexpr int kFragElems = 64 * 8;                 // bf16 per (mt, s) fragment: 64 lanes x 8
+constexpr int kMatFwdElems = 2 * 4 * kFragElems;   // 64 x 64 matrix, forward image (8 KiB)
+constexpr int kOutFwdElems = 1 * 4 * kFragElems;   // 16(32) x 64 output matrix, forward image
+constexpr int kOutBwdElems = 2 * 2 * kFragElems;   // 64 x 16(32) transposed output matrix
+constexpr float kLossScale = 128.0f;
+constexpr int kTStride = 72;                       // bf16 per row of the [feature][batch] LDS images (144 B)
+
+struct NrcLevel { float scale; uint32_t res; uint32_t entries; uint32_t offset; };
+
+struct NrcDev {
+    int posEnc;                 // 1 = hash grid, 0 = triangle wave
+    int numHidden;              // hidden layers (2 or 5): W0 + (numHidden - 1) hidden matrices + Wout
+    uint32_t gridOff;           // fp32 element offset of the grid inside the parameter blob
+    uint32_t total;             // parameters
+    NrcLevel levels[kHashLevels];
+};
+
+GFX_DEV uint32_t to_bf16_bits(float x) {            // round to nearest even
+    const uint32_t u = f2bits(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+GFX_DEV float from_bf16_bits(uint32_t b) { return bits2f(b << 16); }
+GFX_HOSTDEV inline int nrc_feature_of_slot(int s, int h, int i) { return 16 * s + 8 * (i >> 2) + 4 * h + (i & 3); }
+
+// ---------------------------------------------------------------- weight packing
+// fp32 parameters -> bf16 MFMA fragments.  Forward image of W [out][in]: fragment (mt, s), lane (m, h),
+// element i = W[32 mt + m][f(s, h, i)]; transposed image (backward): fragment (mt, s) = W[f(s, h, i)][32 mt + m].
+__global__ void k_nrc_pack(NrcDev d, const float* __restrict__ params, uint16_t* __restrict__ fwd, uint16_t* __restrict__ bwd,
+                           uint32_t* __restrict__ gridOut) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t numMats = d.numHidden;                       // 64 x 64 matrices
+    const uint32_t fwdTotal = numMats * kMatFwdElems + kOutFwdElems;
+    if (t < fwdTotal) {
+        const bool isOut = t >= numMats * kMatFwdElems;
+        const uint32_t mat = isOut ? numMats : t / kMatFwdElems;
+        const uint32_t r = isOut ? t - numMats * kMatFwdElems : t % kMatFwdElems;
+        const uint32_t frag = r / kFragElems, lane = (r % kFragElems) / 8, i = r % 8;
+        const uint32_t mt = isOut ? 0 : frag / 4, s = frag % 4;
+        const uint32_t m = lane & 31, h = lane >> 5;
+        const uint32_t row = 32 * mt + m, col = nrc_feature_of_slot(s, h, i);
+        float v = 0.0f;
+        if (!isOut || row < static_cast<uint32_t>(kNrcOutPad)) v = params[mat * 4096 + row * 64 + col];
+        fwd[t] = static_cast<uint16_t>(to_bf16_bits(v));
+    }
+    if (bwd) {
+        const uint32_t bwdTotal = numMats * kMatFwdElems + kOutBwdElems;
+        if (t < bwdTotal) {
+            const bool isOut = t >= numMats * kMatFwdElems;
+            const uint32_t mat = isOut ? numMats : t / kMatFwdElems;
+            const uint32_t r = isOut ? t - numMats * kMatFwdElems : t % kMatFwdElems;
+            const uint32_t frag = r / kFragElems, lane = (r % kFragElems) / 8, i = r % 8;
+            const uint32_t mt = isOut ? frag / 2 : frag / 4, s = isOut ? frag % 2 : frag % 4;
+            const uint32_t m = lane & 31, h = lane >> 5;
+            const uint32_t inF = 32 * mt + m, outF = nrc_feature_of_slot(s, h, i);
+            float v = 0.0f;
+            if (!isOut || outF < static_cast<uint32_t>(kNrcOutPad)) v = params[mat * 4096 + outF * 64 + inF];
+            bwd[t] = static_cast<uint16_t>(to_bf16_bits(v));
+        }
+    }
+    if (d.posEnc == 1) {
+        const uint32_t entries = (d.total - d.gridOff) / 2;
+        for (uint32_t e = t; e < entries; e += gridDim.x * blockDim.x) {
+            const float a = params[d.gridOff + 2 * e], b = params[d.gridOff + 2 * e + 1];
+            gridOut[e] = to_bf16_bits(a) | (to_bf16_bits(b) << 16);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- encoding
+GFX_DEV float quartic_cdf(float x, float invRadius) {
+    const float u = x * invRadius;
+    const float u2 = u * u;
+    const float u4 = u2 * u2;
+    const float v = (15.0f / 16.0f) * u * (1 - (2.0f / 3.0f) * u2 + (1.0f / 5.0f) * u4) + 0.5f;
+    return fmin2(fmax2(v, 0.0f), 1.0f);
+}
+GFX_DEV void oneblob4(float x, float out[4]) {
+    float cdf[5];
+#pragma unroll
+    for (int b = 0; b <= 4; ++b) {
+        const float left = b * 0.25f;
+        cdf[b] = quartic_cdf(left - x, 4.0f) + quartic_cdf(left - x - 1.0f, 4.0f) + quartic_cdf(left - x + 1.0f, 4.0f);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) out[b] = cdf[b + 1] - cdf[b];
+}
+GFX_DEV uint32_t grid_index(const NrcLevel& lv, uint32_t ix, uint32_t iy, uint32_t iz) {
+    const unsigned long long dense = static_cast<unsigned long long>(lv.res) * lv.res * lv.res;
+    if (dense <= lv.entries) {
+        const unsigned long long idx = ix + static_cast<unsigned long long>(iy) * lv.res + static_cast<unsigned long long>(iz) * lv.res * lv.res;
+        return static_cast<uint32_t>(idx % lv.entries);
+    }
+    const uint32_t hsh = (ix * 1u) ^ (iy * 2654435761u) ^ (iz * 805459861u);
+    return hsh % lv.entries;
+}
+// corner c of level lv for position p: table index (level offset included) and trilinear weight
+GFX_DEV void grid_corner(const NrcLevel& lv, float px, float py, float pz, int c, uint32_t& idx, float& w) {
+    const float x = px * lv.scale + 0.5f, y = py * lv.scale + 0.5f, z = pz * lv.scale + 0.5f;
+    const float bx = floorf(x), by = floorf(y), bz = floorf(z);
+    const float fx = x - bx, fy = y - by, fz = z - bz;
+    const int ox = c & 1, oy = (c >> 1) & 1, oz = (c >> 2) & 1;
+    const uint32_t ix = static_cast<uint32_t>(static_cast<long long>(bx) + ox);
+    const uint32_t iy = static_cast<uint32_t>(static_cast<long long>(by) + oy);
+    const uint32_t iz = static_cast<uint32_t>(static_cast<long long>(bz) + oz);
+    idx = lv.offset + grid_index(lv, ix, iy, iz);
+    w = 1.0f;
+    w = w * (ox ? fx : 1 - fx);
+    w = w * (oy ? fy : 1 - fy);
+    w = w * (oz ? fz : 1 - fz);
+}
+
+// The 32 canonical features a lane (half h) supplies for one batch column, in K-slot order
+// out[s * 8 + i] = feature f(s, h, i).  Canonical order: [position 32|36] [one-blob 20] [identity 6] [ones].
+GFX_DEV void encode_half(const NrcDev& d, const uint32_t* __restrict__ grid, const float x[kNrcIn], int h, float out[32]) {
+    // groups of 4 consecutive canonical features: group g = 4 g .. 4 g + 3; this half owns groups with (g & 1) == h
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                 // q-th owned group -> slots [4 q, 4 q + 4): s = q >> 1, i = 4 (q & 1) + r
+        const int g = 2 * q + h;
+        float v[4];
+        const int f0 = 4 * g;
+        if (d.posEnc == 1 && f0 < 32) {           // two hash-grid levels: 2 g, 2 g + 1
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const NrcLevel lv = d.levels[2 * g + k];
+                float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t idx; float w;
+                    grid_corner(lv, x[0], x[1], x[2], c, idx, w);
+                    const uint32_t e = grid[idx];
+                    a0 = a0 + w * from_bf16_bits(e & 0xFFFFu);
+                    a1 = a1 + w * from_bf16_bits(e >> 16);
+                }
+                v[2 * k] = a0; v[2 * k + 1] = a1;
+            }
+        }
+        else {
+            const int posFeatures = d.posEnc == 1 ? 32 : 3 * kTriFreqs;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = f0 + r;
+                float val = 1.0f;                                       // padding
+                if (f < posFeatures) {                                  // triangle wave: feature 12 dim + freq
+                    const int dim = f / kTriFreqs, freq = f % kTriFreqs;
+                    const float xs = ldexpf(x[dim], freq - 1);
+                    val = fabsf(xs - floorf(xs) - 0.5f) * 4 - 1;
+                }
+                else if (f < posFeatures + 20) {
+                    const int o = f - posFeatures;
+                    float ob[4];
+                    oneblob4(x[3 + (o >> 2)], ob);
+                    val = ob[o & 3];
+                }
+                else if (f < posFeatures + 26) val = x[8 + (f - posFeatures - 20)];
+                v[r] = val;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[4 * q + r] = v[r];
+    }
+}
+
+GFX_DEV uint4 pack8(const float v[8]) {
+    uint4 r;
+    r.x = to_bf16_bits(v[0]) | (to_bf16_bits(v[1]) << 16);
+    r.y = to_bf16_bits(v[2]) | (to_bf16_bits(v[3]) << 16);
+    r.z = to_bf16_bits(v[4]) | (to_bf16_bits(v[5]) << 16);
+    r.w = to_bf16_bits(v[6]) | (to_bf16_bits(v[7]) << 16);
+    return r;
+}
+GFX_DEV void unpack8(uint4 p, float v[8]) {
+    v[0] = from_bf16_bits(p.x & 0xFFFFu); v[1] = from_bf16_bits(p.x >> 16);
+    v[2] = from_bf16_bits(p.y & 0xFFFFu); v[3] = from_bf16_bits(p.y >> 16);
+    v[4] = from_bf16_bits(p.z & 0xFFFFu); v[5] = from_bf16_bits(p.z >> 16);
+    v[6] = from_bf16_bits(p.w & 0xFFFFu); v[7] = from_bf16_bits(p.w >> 16);
+}
+
+// B operand (4 K steps) of one batch column from 32 slot-ordered fp32 values
+GFX_DEV void to_operand(const float v[32], uint4 b[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[s] = pack8(v + 8 * s);
+}
+// accumulators of a 64-row layer (two M tiles) -> ReLU -> next B operand
+GFX_DEV void relu_to_operand(const f32x16 acc[2], uint4 b[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmax2(acc[s >> 1][8 * (s & 1) + i], 0.0f);
+        b[s] = pack8(v);
+    }
+}
+
+// one 64 x 64 layer for one N tile: acc[mt] = sum_s A(mt, s) . B(s); `frags` = the matrix' fragment image
+template <typename FragPtr>
+GFX_DEV void layer64(FragPtr frags, int lane, const uint4 b[4], f32x16 acc[2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint4 a = frags[(mt * 4 + s) * 64 + lane];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[s]), c, 0, 0, 0);
+        }
+        acc[mt] = c;
+    }
+}
+
+// ---------------------------------------------------------------- inference
+// inputs [14, N] column-major fp32, predictions [3, N] column-major fp32 (network_interface.cu:141-147)
+constexpr int kInferBlock = 256;
+__global__ __launch_bounds__(kInferBlock) void k_nrc_infer(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_t* __restrict__ grid,
+                                                           const float* __restrict__ inputs, uint32_t numData, float* __restrict__ predictions) {
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsW[];
+    const uint32_t fwdElems = d.numHidden * kMatFwdElems + kOutFwdElems;
+    for (uint32_t i = threadIdx.x; i < fwdElems / 8; i += kInferBlock) ldsW[i] = reinterpret_cast<const uint4*>(fwd)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    const uint32_t wave = blockIdx.x * (kInferBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t numWaves = gridDim.x * (kInferBlock / 64);
+    const uint32_t numTiles = (numData + 63) / 64;
+    for (uint32_t tile = wave; tile < numTiles; tile += numWaves) {
+        uint4 b[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const uint32_t col = tile * 64 + 32 * nt + n;
+            float x[kNrcIn];
+#pragma unroll
+            for (int k = 0; k < kNrcIn; ++k) x[k] = col < numData ? inputs[static_cast<size_t>(col) * kNrcIn + k] : 0.0f;
+            float enc[32];
+            encode_half(d, grid, x, h, enc);
+            to_operand(enc, b[nt]);
+        }
+        for (int layer = 0; layer < d.numHidden; ++layer) {
+            const uint4* frags = ldsW + layer * (kMatFwdElems / 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x16 acc[2];
+                layer64(frags, lane, b[nt], acc);
+                relu_to_operand(acc, b[nt]);
+            }
+        }
+        const uint4* fragsOut = ldsW + d.numHidden * (kMatFwdElems / 8);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fragsOut[s * 64 + lane]),
+                                                            __builtin_bit_cast(bf16x8, b[nt][s]), c, 0, 0, 0);
+            const uint32_t col = tile * 64 + 32 * nt + n;
+            if (h == 0 && col < numData) {       // rows 0..2 live in registers 0..2 of the h == 0 lanes
+                float* o = predictions + static_cast<size_t>(col) * kNrcOut;
+                o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- training step
+// One wave per block, 64 batch columns per block.  Weight fragments are read straight from the packed
+// global images (each is used once per block); LDS keeps every layer's activations twice: in operand
+// order (ReLU masks) and as a [feature][batch] matrix (the K = batch contraction of dL/dW).
+struct NrcTrainArgs {
+    NrcDev d;
+    const uint16_t* fwd; const uint16_t* bwd; const uint32_t* grid;
+    const float* inputs; const float* targets; uint32_t numData;
+    float* gradPartials;      // [numBlocks][mlpParams]
+    float* gridGrad;          // [gridParams] (atomics)
+    float* lossSum;
+};
+GFX_DEV void store_transposed(uint16_t* ldsT, int nt, int n, int h, const uint4 b[4]) {   // operand -> [feature][batch]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t w[4] = { b[s].x, b[s].y, b[s].z, b[s].w };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = nrc_feature_of_slot(s, h, i);
+            ldsT[f * kTStride + 32 * nt + n] = static_cast<uint16_t>((w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+        }
+    }
+}
+// dW [outRows x 64] of one layer: A = delta^T (M = out feature, K = batch), B = act^T (K = batch, N = in feature)
+GFX_DEV void weight_gradient(const uint16_t* ldsDelta, const uint16_t* ldsAct, int lane, int outTiles, int outRows, float* gradOut) {
+    const int m = lane & 31, h = lane >> 5;
+    for (int mt = 0; mt < outTiles; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 a = *reinterpret_cast<const uint4*>(ldsDelta + (32 * mt + m) * kTStride + 16 * ks + 8 * h);
+                const uint4 b = *reinterpret_cast<const uint4*>(ldsAct + (32 * nt + m) * kTStride + 16 * ks + 8 * h);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < outRows) gradOut[row * 64 + 32 * nt + m] = c[r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsT4[];
+    const NrcDev& d = a.d;
+    const int numLayers = d.numHidden + 1;                       // activation sets: encoded input + hidden outputs
+    uint4* ldsOp = ldsT4;                                        // [numLayers][nt][s][lane] operand order
+    uint16_t* ldsActT = reinterpret_cast<uint16_t*>(ldsOp + numLayers * 2 * 4 * 64);   // [numLayers][64][kTStride]
+    uint16_t* ldsDeltaT = ldsActT + numLayers * 64 * kTStride;   // [64][kTStride]
+    const int lane = threadIdx.x, h = lane >> 5, n = lane & 31;
+    const uint32_t tile = blockIdx.x;
+    const uint4* fwd4 = reinterpret_cast<const uint4*>(a.fwd);
+    const uint4* bwd4 = reinterpret_cast<const uint4*>(a.bwd);
+    const uint32_t mlpParams = d.numHidden * 4096 + kNrcOutPad * 64;
+    float* gradOut = a.gradPartials + static_cast<size_t>(tile) * mlpParams;
+
+    // ---- forward
+    uint4 b[2][4];
+    float xpos[2][3];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const uint32_t col = tile * 64 + 32 * nt + n;
+        float x[kNrcIn];
+#pragma unroll
+        for (int k = 0; k < kNrcIn; ++k) x[k] = col < a.numData ? a.inputs[static_cast<size_t>(col) * kNrcIn + k] : 0.0f;
+        xpos[nt][0] = x[0]; xpos[nt][1] = x[1]; xpos[nt][2] = x[2];
+        float enc[32];
+        encode_half(d, a.grid, x, h, enc);
+        to_operand(enc, b[nt]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ldsOp[((0 * 2 + nt) * 4 + s) * 64 + lane] = b[nt][s];
+        store_transposed(ldsActT, nt, n, h, b[nt]);
+    }
+    for (int layer = 0; layer < d.numHidden; ++layer) {
+        const uint4* frags = fwd4 + layer * (kMatFwdElems / 8);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 acc[2];
+            layer64(frags, lane, b[nt], acc);
+            relu_to_operand(acc, b[nt]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ldsOp[(((layer + 1) * 2 + nt) * 4 + s) * 64 + lane] = b[nt][s];
+            store_transposed(ldsActT + (layer + 1) * 64 * kTStride, nt, n, h, b[nt]);
+        }
+    }
+    // ---- output layer + loss gradient (RelativeL2Luminance)
+    uint4 delta[2][4];
+    float lossLocal = 0.0f;
+    {
+        const uint4* fragsOut = fwd4 + d.numHidden * (kMatFwdElems / 8);
+        const float nTotal = static_cast<float>(a.numData) * kNrcOut;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fragsOut[s * 64 + lane]),
+                                                            __builtin_bit_cast(bf16x8, b[nt][s]), c, 0, 0, 0);
+            float dv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            const uint32_t col = tile * 64 + 32 * nt + n;
+            if (h == 0 && col < a.numData) {
+                const float* t = a.targets + static_cast<size_t>(col) * kNrcOut;
+                const float lum = 0.299f * c[0] + 0.587f * c[1] + 0.114f * c[2];
+                const float denom = lum * lum + 0.01f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float diff = c[k] - t[k];
+                    lossLocal += (diff * diff / denom) / nTotal;
+                    dv[k] = kLossScale * 2 * diff / denom / nTotal;
+                }
+            }
+            delta[nt][0] = pack8(dv);                        // features 0..2 = slots (s 0, h 0, i 0..2)
+            delta[nt][1] = make_uint4(0, 0, 0, 0); delta[nt][2] = make_uint4(0, 0, 0, 0); delta[nt][3] = make_uint4(0, 0, 0, 0);
+            store_transposed(ldsDeltaT, nt, n, h, delta[nt]);
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) lossLocal += __shfl_xor(lossLocal, off);
+    if (lane == 0) atomicAdd(a.lossSum, lossLocal);
+    __syncthreads();
+
+    // ---- backward
+    // output matrix: dWout = delta_out . h_last^T; delta_last = (Wout^T . delta_out) * relu'(h_last)
+    weight_gradient(ldsDeltaT, ldsActT + d.numHidden * 64 * kTStride, lane, 1, kNrcOutPad, gradOut + d.numHidden * 4096);
+    __syncthreads();
+    {
+        const uint4* fragsT = bwd4 + d.numHidden * (kMatFwdElems / 8);     // WoutT: fragments (mt, s), s in {0, 1}
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fragsT[(mt * 2 + s) * 64 + lane]),
+                                                                __builtin_bit_cast(bf16x8, delta[nt][s]), c, 0, 0, 0);
+                acc[mt] = c;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float act[8], v[8];
+                unpack8(ldsOp[((d.numHidden * 2 + nt) * 4 + s) * 64 + lane], act);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = act[i] > 0.0f ? acc[s >> 1][8 * (s & 1) + i] : 0.0f;
+                delta[nt][s] = pack8(v);
+            }
+            store_transposed(ldsDeltaT, nt, n, h, delta[nt]);
+        }
+    }
+    __syncthreads();
+    for (int layer = d.numHidden - 1; layer >= 0; --layer) {
+        // dW_layer = delta_{layer+1} . act_layer^T
+        weight_gradient(ldsDeltaT, ldsActT + layer * 64 * kTStride, lane, 2, 64, gradOut + layer * 4096);
+        __syncthreads();
+        if (layer == 0 && d.posEnc != 1) break;
+        const uint4* fragsT = bwd4 + layer * (kMatFwdElems / 8);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 acc[2];
+            layer64(fragsT, lane, delta[nt], acc);
+            if (layer > 0) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float act[8], v[8];
+                    unpack8(ldsOp[((layer * 2 + nt) * 4 + s) * 64 + lane], act);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = act[i] > 0.0f ? acc[s >> 1][8 * (s & 1) + i] : 0.0f;
+                    delta[nt][s] = pack8(v);
+                }
+                store_transposed(ldsDeltaT, nt, n, h, delta[nt]);
+            }
+            else {
+                // dL/d(encoded input), fp32: scatter the hash-grid part.  Owned group q < 4 (canonical
+                // features 8 q + 4 h .. + 3 = levels 2 g, 2 g + 1 with g = 2 q + h) sits in M tile 0,
+                // registers 8 (q >> 1) + 4 (q & 1) + r.
+                const uint32_t col = tile * 64 + 32 * nt + n;
+                if (col < a.numData) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int g = 2 * q + h;
+                        const int base = 8 * (q >> 1) + 4 * (q & 1);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const NrcLevel lv = d.levels[2 * g + k];
+                            const float d0 = acc[0][base + 2 * k], d1 = acc[0][base + 2 * k + 1];
+                            if (d0 == 0.0f && d1 == 0.0f) continue;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                uint32_t idx; float w;
+                                grid_corner(lv, xpos[nt][0], xpos[nt][1], xpos[nt][2], c, idx, w);
+                                atomicAdd(a.gridGrad + 2ull * idx, w * d0);
+                                atomicAdd(a.gridGrad + 2ull * idx + 1, w * d1);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- optimizer: Adam + EMA
+struct NrcOptArgs {
+    NrcDev d;
+    float* params; float* adamM; float* adamV; float* ema;
+    const float* gradPartials; uint32_t numPartials; uint32_t mlpParams;
+    float* gridGrad;
+    float lrT, beta1, beta2, eps, l2Reg, emaDecay, debiasOld, debiasNew;
+};
+__global__ void k_nrc_optimizer(NrcOptArgs a) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.d.total) return;
+    const bool isGrid = p >= a.d.gridOff;
+    float g;
+    if (isGrid) { g = a.gridGrad[p - a.d.gridOff]; a.gridGrad[p - a.d.gridOff] = 0.0f; }
+    else {
+        g = 0.0f;
+        for (uint32_t k = 0; k < a.numPartials; ++k) g += a.gradPartials[static_cast<size_t>(k) * a.mlpParams + p];
+    }
+    float grad = g / kLossScale;
+    float w = a.params[p];
+    if (!(isGrid && grad == 0.0f)) {       // untouched hash-grid entries keep their moments
+        if (!isGrid) grad = grad + a.l2Reg * w;
+        const float m = a.beta1 * a.adamM[p] + (1 - a.beta1) * grad;
+        const float v = a.beta2 * a.adamV[p] + (1 - a.beta2) * grad * grad;
+        a.adamM[p] = m; a.adamV[p] = v;
+        w = w - a.lrT * m / (sqrtf(v) + a.eps);
+        a.params[p] = w;
+    }
+    a.ema[p] = ((1 - a.emaDecay) * w + a.emaDecay * a.debiasOld * a.ema[p]) * a.debiasNew;
+}
+
+// ---------------------------------------------------------------- host side
+struct NrcNet {
+    NrcDev d;
+    float learningRate;
+    uint32_t step = 0;
+    uint32_t mlpParams = 0, gridParams = 0;
+    DevBuf params, adamM, adamV, ema, gradPartials, gridGrad, lossSum;
+    DevBuf packTrainFwd, packTrainBwd, packInferFwd, gridTrain, gridInfer;
+    uint32_t partialCapacity = 0;
+};
+
+static void nrc_levels(NrcDev& d) {
+    uint32_t offset = 0;
+    for (int l = 0; l < kHashLevels; ++l) {
+        const float scale = exp2f(static_cast<float>(l) * log2f(2.0f)) * kBaseRes - 1.0f;
+        const uint32_t res = static_cast<uint32_t>(ceilf(scale)) + 1;
+        unsigned long long n = static_cast<unsigned long long>(res) * res * res;
+        n = (n + 7) / 8 * 8;
+        if (n > (1ull << kLog2Hashmap)) n = 1ull << kLog2Hashmap;
+        d.levels[l] = NrcLevel{ scale, res, static_cast<uint32_t>(n), offset };
+        offset += static_cast<uint32_t>(n);
+    }
+    d.total = d.gridOff + (d.posEnc == 1 ? offset * 2 : 0);
+}
+
+static void nrc_pack(Context& ctx, hipStream_t stream, NrcNet& net, bool training) {
+    const uint32_t fwdElems = net.d.numHidden * kMatFwdElems + kOutFwdElems;
+    const uint32_t bwdElems = net.d.numHidden * kMatFwdElems + kOutBwdElems;
+    const uint32_t threads = std::max(fwdElems, bwdElems);
+    const float* src = training ? net.params.as<float>() : net.ema.as<float>();
+    uint16_t* fwd = training ? net.packTrainFwd.as<uint16_t>() : net.packInferFwd.as<uint16_t>();
+    uint16_t* bwd = training ? net.packTrainBwd.as<uint16_t>() : nullptr;
+    uint32_t* grid = training ? net.gridTrain.as<uint32_t>() : net.gridInfer.as<uint32_t>();
+    ScopedKernelTimer timer(ctx, stream, "nrc_pack");
+    hipLaunchKernelGGL(k_nrc_pack, dim3((threads + 255) / 256), dim3(256), 0, stream, net.d, src, fwd, bwd, grid);
+    GFX_HIP(hipGetLastError());
+}
+
+void nrc_set_params(Context& ctx, hipStream_t stream, NrcNet* net, const float* hostParams, uint32_t count);
+
+NrcNet* nrc_create(Context& ctx, int posEnc, uint32_t numHiddenLayers, float learningRate) {
+    if (numHiddenLayers < 1 || numHiddenLayers > kMaxHidden) throw HipError("gfx_nrc_create: numHiddenLayers must be 1..5");
+    if (posEnc != 0 && posEnc != 1) throw HipError("gfx_nrc_create: unknown position encoding");
+    NrcNet* net = new NrcNet();
+    std::memset(&net->d, 0, sizeof(net->d));
+    net->d.posEnc = posEnc; net->d.numHidden = static_cast<int>(numHiddenLayers);
+    net->learningRate = learningRate;
+    net->mlpParams = numHiddenLayers * 4096 + kNrcOutPad * 64;
+    net->d.gridOff = net->mlpParams;
+    nrc_levels(net->d);
+    net->gridParams = net->d.total - net->d.gridOff;
+    const size_t bytes = sizeof(float) * net->d.total;
+    net->params.reserve(bytes); net->adamM.reserve(bytes); net->adamV.reserve(bytes); net->ema.reserve(bytes);
+    net->gridGrad.reserve(sizeof(float) * std::max<uint32_t>(net->gridParams, 4));
+    net->lossSum.reserve(16);
+    const uint32_t fwdElems = numHiddenLayers * kMatFwdElems + kOutFwdElems;
+    const uint32_t bwdElems = numHiddenLayers * kMatFwdElems + kOutBwdElems;
+    net->packTrainFwd.reserve(2 * fwdElems); net->packInferFwd.reserve(2 * fwdElems); net->packTrainBwd.reserve(2 * bwdElems);
+    net->gridTrain.reserve(std::max<uint32_t>(2 * net->gridParams, 16)); net->gridInfer.reserve(std::max<uint32_t>(2 * net->gridParams, 16));
+    GFX_HIP(hipMemset(net->adamM.p, 0, bytes)); GFX_HIP(hipMemset(net->adamV.p, 0, bytes));
+    GFX_HIP(hipMemset(net->params.p, 0, bytes)); GFX_HIP(hipMemset(net->ema.p, 0, bytes));
+    GFX_HIP(hipMemset(net->gridGrad.p, 0, sizeof(float) * std::max<uint32_t>(net->gridParams, 4)));
+    // default initialisation: Xavier-uniform MLP weights, U(-1e-4, 1e-4) grid features from one PCG32
+    // stream (state 1337, increment 1) -- the same stream as oracle/nrc_net.py init_params
+    std::vector<float> init(net->d.total);
+    uint64_t state = 1337;
+    auto uniform = [&state]() {
+        const uint64_t old = state;
+        state = old * 6364136223846793005ull + 1ull;
+        const uint32_t xorshifted = static_cast<uint32_t>(((old >> 18u) ^ old) >> 27u);
+        const uint32_t rot = static_cast<uint32_t>(old >> 59u);
+        const uint32_t v = (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31u));
+        const uint32_t bits = (v >> 9) | 0x3F800000u;
+        float f; std::memcpy(&f, &bits, 4);
+        return f - 1.0f;
+    };
+    for (uint32_t mat = 0; mat <= numHiddenLayers; ++mat) {
+        const uint32_t rows = mat == numHiddenLayers ? kNrcOutPad : 64;
+        const float bound = static_cast<float>(std::sqrt(6.0 / (64 + rows)));
+        for (uint32_t k = 0; k < rows * 64; ++k) init[mat * 4096 + k] = (uniform() * 2.0f - 1.0f) * bound;
+    }
+    for (uint32_t k = net->d.gridOff; k < net->d.total; ++k) init[k] = (uniform() * 2.0f - 1.0f) * 1e-4f;
+    nrc_set_params(ctx, nullptr, net, init.data(), net->d.total);
+    return net;
+}
+
+void nrc_destroy(NrcNet* net) { delete net; }
+uint32_t nrc_num_params(const NrcNet* net) { return net->d.total; }
+
+// which: 0 = training parameters (also resets the EMA copy, the Adam moments and the step counter), 1 = EMA
+void nrc_set_params(Context& ctx, hipStream_t stream, NrcNet* net, const float* hostParams, uint32_t count) {
+    if (count != net->d.total) throw HipError("gfx_nrc_set_params: parameter count mismatch");
+    const size_t bytes = sizeof(float) * count;
+    GFX_HIP(hipMemcpyAsync(net->params.p, hostParams, bytes, hipMemcpyHostToDevice, stream));
+    GFX_HIP(hipMemcpyAsync(net->ema.p, hostParams, bytes, hipMemcpyHostToDevice, stream));
+    GFX_HIP(hipMemsetAsync(net->adamM.p, 0, bytes, stream));
+    GFX_HIP(hipMemsetAsync(net->adamV.p, 0, bytes, stream));
+    net->step = 0;
+    nrc_pack(ctx, stream, *net, true);
+    nrc_pack(ctx, stream, *net, false);
+    GFX_HIP(hipStreamSynchronize(stream));
+}
+void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count) {
+    if (count != net->d.total) throw HipError("gfx_nrc_get_params: parameter count mismatch");
+    GFX_HIP(hipDeviceSynchronize());
+    const DevBuf& src = which == 0 ? net->params : which == 1 ? net->ema : which == 2 ? net->adamM : net->adamV;
+    GFX_HIP(hipMemcpy(hostOut, src.p, sizeof(float) * count, hipMemcpyDeviceToHost));
+}
+
+void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions) {
+    if (numData & 0x7F) throw HipError("gfx_nrc_infer: numData must be a multiple of 128");   // network_interface.cu:143
+    if (numData == 0) return;
+    static int numCUs = 0;
+    if (!numCUs) { hipDeviceProp_t prop; GFX_HIP(hipGetDeviceProperties(&prop, ctx.device)); numCUs = prop.multiProcessorCount; }
+    const uint32_t numTiles = numData / 64;
+    const uint32_t wavesPerBlock = kInferBlock / 64;
+    uint32_t grid = std::min<uint32_t>((numTiles + wavesPerBlock - 1) / wavesPerBlock, static_cast<uint32_t>(numCUs) * 4);
+    const size_t lds = 2ull * (net->d.numHidden * kMatFwdElems + kOutFwdElems);
+    ScopedKernelTimer timer(ctx, stream, "nrc_infer");
+    hipLaunchKernelGGL(k_nrc_infer, dim3(grid), dim3(kInferBlock), lds, stream, net->d, net->packInferFwd.as<uint16_t>(),
+                       net->gridInfer.as<uint32_t>(), dInputs, numData, dPredictions);
+    GFX_HIP(hipGetLastError());
+}
+
+void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, const float* dTargets, uint32_t numData, float* lossOnCPU) {
+    if (numData & 0x7F) throw HipError("gfx_nrc_train: numData must be a multiple of 128");   // network_interface.cu:151
+    if (numData == 0) return;
+    const uint32_t numBlocks = numData / 64;
+    net->gradPartials.reserve(sizeof(float) * static_cast<size_t>(numBlocks) * net->mlpParams);
+    GFX_HIP(hipMemsetAsync(net->lossSum.p, 0, sizeof(float), stream));
+    NrcTrainArgs a;
+    a.d = net->d;
+    a.fwd = net->packTrainFwd.as<uint16_t>(); a.bwd = net->packTrainBwd.as<uint16_t>(); a.grid = net->gridTrain.as<uint32_t>();
+    a.inputs = dInputs; a.targets = dTargets; a.numData = numData;
+    a.gradPartials = net->gradPartials.as<float>(); a.gridGrad = net->gridGrad.as<float>(); a.lossSum = net->lossSum.as<float>();
+    const int numLayers = net->d.numHidden + 1;
+    const size_t lds = static_cast<size_t>(numLayers) * 2 * 4 * 64 * 16 + (static_cast<size_t>(numLayers) + 1) * 64 * kTStride * 2;
+    static size_t ldsConfigured = 0;
+    if (lds > ldsConfigured) {
+        GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_train), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        ldsConfigured = lds;
+    }
+    {
+        ScopedKernelTimer timer(ctx, stream, "nrc_train_fwd_bwd");
+        hipLaunchKernelGGL(k_nrc_train, dim3(numBlocks), dim3(64), lds, stream, a);
+        GFX_HIP(hipGetLastError());
+    }
+    // Adam (beta1 0.9, beta2 0.99, l2_reg 1e-6) inside EMA(0.99): network_interface.cu:53-64, 91, 118
+    ++net->step;
+    NrcOptArgs o;
+    o.d = net->d;
+    o.params = net->params.as<float>(); o.adamM = net->adamM.as<float>(); o.adamV = net->adamV.as<float>(); o.ema = net->ema.as<float>();
+    o.gradPartials = net->gradPartials.as<float>(); o.numPartials = numBlocks; o.mlpParams = net->mlpParams;
+    o.gridGrad = net->gridGrad.as<float>();
+    o.beta1 = 0.9f; o.beta2 = 0.99f; o.l2Reg = 1e-6f; o.emaDecay = 0.99f;
+    o.eps = net->d.posEnc == 1 ? 1e-15f : 1e-8f;
+    const double t = net->step;
+    o.lrT = static_cast<float>(static_cast<double>(net->learningRate) * std::sqrt(1.0 - std::pow(static_cast<double>(o.beta2), t)) /
+                               (1.0 - std::pow(static_cast<double>(o.beta1), t)));
+    o.debiasOld = static_cast<float>(1.0 - std::pow(static_cast<double>(o.emaDecay), t - 1.0));
+    o.debiasNew = static_cast<float>(1.0 / (1.0 - std::pow(static_cast<double>(o.emaDecay), t)));
+    {
+        ScopedKernelTimer timer(ctx, stream, "nrc_optimizer");
+        hipLaunchKernelGGL(k_nrc_optimizer, dim3((net->d.total + 255) / 256), dim3(256), 0, stream, o);
+        GFX_HIP(hipGetLastError());
+    }
+    nrc_pack(ctx, stream, *net, true);
+    nrc_pack(ctx, stream, *net, false);
+    if (lossOnCPU) {
+        GFX_HIP(hipStreamSynchronize(stream));
+        GFX_HIP(hipMemcpy(lossOnCPU, net->lossSum.p, sizeof(float), hipMemcpyDeviceToHost));
+    }
+}
+
+} // namespace gfx

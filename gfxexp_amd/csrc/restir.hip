@@ -23,7 +23,6 @@ namespace gfx {
 // ---------------------------------------------------------------- SETUP_GBUFFERS
 // ray generation of optix_gbuffer_kernels.cu:5-27
 __global__ __launch_bounds__(kBlock) void k_primary_rays(RestirArgs a) {
-    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (p >= a.pixelEnd) return;
     const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
@@ -58,7 +57,6 @@ GFX_DEV void calc_screen_position(const Camera& cam, f3 pw, float& sx, float& sy
 
 // closest-hit / miss programs + the tail of the ray-generation program (optix_gbuffer_kernels.cu:56-243)
 __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
-    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (p >= a.pixelEnd) return;
     const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
@@ -570,7 +568,6 @@ __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
 
 // contribution += recPDFEstimate * directCont; running mean (optix_restir_di_kernels.cu:619-636)
 __global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
-    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (p >= a.pixelEnd) return;
     const float4 c0 = a.shadeScratch[2 * p], c1 = a.shadeScratch[2 * p + 1];

@@ -291,6 +291,33 @@ int gfx_regir_set_params(gfx_ctx* ctx, const gfx_regir_params* p);
 int gfx_pt_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height,
                   uint32_t maxPathLength, uint32_t rowBegin, uint32_t rowEnd);
 
+/* ---------------------------------------------------------------- neural radiance cache -------- */
+
+/* NeuralRadianceCache (neural_radiance_caching/network_interface.h:14-28): the tiny-cuda-nn network of
+ * network_interface.cu:48-132 -- Composite{HashGrid | TriangleWave (3 dims), OneBlob 4 bins (5 dims),
+ * Identity (6 dims)} -> fully fused MLP, 64 neurons, numHiddenLayers (2 or 5), ReLU; loss
+ * RelativeL2Luminance; optimizer EMA(0.99) o Adam(lr, 0.9, 0.99, l2_reg 1e-6).  Here: bf16 MFMA,
+ * fp32 accumulation and fp32 master parameters.
+ *   gfx_nrc_create    = initialize(posEnc, numHiddenLayers, learningRate)      network_interface.cu:48-132
+ *   gfx_nrc_destroy   = finalize()                                            :134-139
+ *   gfx_nrc_infer     = infer(stream, inputData, numData, predictionData)     :141-147
+ *   gfx_nrc_train     = train(stream, inputData, targetData, numData, lossOnCPU)   :149-157
+ * inputData: device fp32 [14, numData] column-major (RadianceQuery, neural_radiance_caching_shared.h:118-127),
+ * predictionData / targetData: device fp32 [3, numData]; numData must be a multiple of 128 (:143, :151).
+ * Parameter blob (fp32): W0 [64][64], W1.. [64][64] x (numHiddenLayers - 1), Wout [16][64] (rows >= 3
+ * unused), then the hash grid (level tables back to back, 2 features per entry); W[out][in] with `in`
+ * in the canonical feature order [position | one-blob 4 x 5 | identity 6 | ones].
+ * get_params which: 0 training weights, 1 EMA (inference) weights, 2 Adam first moment, 3 second moment. */
+enum gfx_nrc_position_encoding { GFX_NRC_TRIANGLE_WAVE = 0, GFX_NRC_HASH_GRID = 1 };   /* network_interface.h:5-8 */
+int gfx_nrc_create(gfx_ctx* ctx, int positionEncoding, uint32_t numHiddenLayers, float learningRate, uint64_t* outHandle);
+int gfx_nrc_destroy(gfx_ctx* ctx, uint64_t handle);
+int gfx_nrc_infer(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInputData, uint32_t numData, void* dPredictionData);
+int gfx_nrc_train(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInputData, const void* dTargetData,
+                  uint32_t numData, float* lossOnCPU);
+int gfx_nrc_num_params(gfx_ctx* ctx, uint64_t handle, uint32_t* outCount);
+int gfx_nrc_set_params(gfx_ctx* ctx, uint64_t handle, const float* hostParams, uint32_t count);
+int gfx_nrc_get_params(gfx_ctx* ctx, uint64_t handle, int which, float* hostOut, uint32_t count);
+
 /* Blocking device-to-host copy of library- or caller-owned device memory (TypedBuffer::read,
  * utils/cuda_util.h; used for pick info at restir_di_main.cpp:2010). */
 int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes);
