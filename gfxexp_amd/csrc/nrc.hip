@@ -120,29 +120,38 @@ GFX_DEV void oneblob4(float x, float out[4]) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) out[b] = cdf[b + 1] - cdf[b];
 }
-GFX_DEV uint32_t grid_index(const NrcLevel& lv, uint32_t ix, uint32_t iy, uint32_t iz) {
-    const unsigned long long dense = static_cast<unsigned long long>(lv.res) * lv.res * lv.res;
-    if (dense <= lv.entries) {
-        const unsigned long long idx = ix + static_cast<unsigned long long>(iy) * lv.res + static_cast<unsigned long long>(iz) * lv.res * lv.res;
-        return static_cast<uint32_t>(idx % lv.entries);
-    }
-    const uint32_t hsh = (ix * 1u) ^ (iy * 2654435761u) ^ (iz * 805459861u);
-    return hsh % lv.entries;
-}
-// corner c of level lv for position p: table index (level offset included) and trilinear weight
-GFX_DEV void grid_corner(const NrcLevel& lv, float px, float py, float pz, int c, uint32_t& idx, float& w) {
+// Table indices (level offset included) and trilinear weights of the 8 corners of one level.
+// Hashed levels: x ^ y * 2654435761 ^ z * 805459861 (uint32) modulo the table size; dense levels:
+// x + y res + z res^2 modulo the table size.  Table sizes are powers of two for the configuration
+// the reference uses (4096, 32768), where the modulo is a mask.
+GFX_DEV void grid_corners(const NrcLevel& lv, float px, float py, float pz, uint32_t idx[8], float w[8]) {
     const float x = px * lv.scale + 0.5f, y = py * lv.scale + 0.5f, z = pz * lv.scale + 0.5f;
     const float bx = floorf(x), by = floorf(y), bz = floorf(z);
     const float fx = x - bx, fy = y - by, fz = z - bz;
-    const int ox = c & 1, oy = (c >> 1) & 1, oz = (c >> 2) & 1;
-    const uint32_t ix = static_cast<uint32_t>(static_cast<long long>(bx) + ox);
-    const uint32_t iy = static_cast<uint32_t>(static_cast<long long>(by) + oy);
-    const uint32_t iz = static_cast<uint32_t>(static_cast<long long>(bz) + oz);
-    idx = lv.offset + grid_index(lv, ix, iy, iz);
-    w = 1.0f;
-    w = w * (ox ? fx : 1 - fx);
-    w = w * (oy ? fy : 1 - fy);
-    w = w * (oz ? fz : 1 - fz);
+    const uint32_t ix = static_cast<uint32_t>(static_cast<int32_t>(bx));
+    const uint32_t iy = static_cast<uint32_t>(static_cast<int32_t>(by));
+    const uint32_t iz = static_cast<uint32_t>(static_cast<int32_t>(bz));
+    const bool dense = static_cast<unsigned long long>(lv.res) * lv.res * lv.res <= lv.entries;
+    const bool pow2 = (lv.entries & (lv.entries - 1)) == 0;
+    uint32_t tx[2], ty[2], tz[2];
+    if (dense) {
+        tx[0] = ix; tx[1] = ix + 1;
+        ty[0] = iy * lv.res; ty[1] = (iy + 1) * lv.res;
+        tz[0] = iz * lv.res * lv.res; tz[1] = (iz + 1) * lv.res * lv.res;
+    }
+    else {
+        tx[0] = ix; tx[1] = ix + 1;
+        ty[0] = iy * 2654435761u; ty[1] = (iy + 1) * 2654435761u;
+        tz[0] = iz * 805459861u; tz[1] = (iz + 1) * 805459861u;
+    }
+    const float wx[2] = { 1 - fx, fx }, wy[2] = { 1 - fy, fy }, wz[2] = { 1 - fz, fz };
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ox = c & 1, oy = (c >> 1) & 1, oz = (c >> 2) & 1;
+        const uint32_t raw = dense ? tx[ox] + ty[oy] + tz[oz] : tx[ox] ^ ty[oy] ^ tz[oz];
+        idx[c] = lv.offset + (pow2 ? raw & (lv.entries - 1) : raw % lv.entries);
+        w[c] = wx[ox] * wy[oy] * wz[oz];
+    }
 }
 
 // The 32 canonical features a lane (half h) supplies for one batch column, in K-slot order
@@ -158,14 +167,15 @@ GFX_DEV void encode_half(const NrcDev& d, const uint32_t* __restrict__ grid, con
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const NrcLevel lv = d.levels[2 * g + k];
+                uint32_t idx[8]; float w[8]; uint32_t e[8];
+                grid_corners(lv, x[0], x[1], x[2], idx, w);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) e[c] = grid[idx[c]];
                 float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    uint32_t idx; float w;
-                    grid_corner(lv, x[0], x[1], x[2], c, idx, w);
-                    const uint32_t e = grid[idx];
-                    a0 = a0 + w * from_bf16_bits(e & 0xFFFFu);
-                    a1 = a1 + w * from_bf16_bits(e >> 16);
+                    a0 = a0 + w[c] * from_bf16_bits(e[c] & 0xFFFFu);
+                    a1 = a1 + w[c] * from_bf16_bits(e[c] >> 16);
                 }
                 v[2 * k] = a0; v[2 * k + 1] = a1;
             }
@@ -491,12 +501,12 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
                             const NrcLevel lv = d.levels[2 * g + k];
                             const float d0 = acc[0][base + 2 * k], d1 = acc[0][base + 2 * k + 1];
                             if (d0 == 0.0f && d1 == 0.0f) continue;
+                            uint32_t idx[8]; float w[8];
+                            grid_corners(lv, xpos[nt][0], xpos[nt][1], xpos[nt][2], idx, w);
 #pragma unroll
                             for (int c = 0; c < 8; ++c) {
-                                uint32_t idx; float w;
-                                grid_corner(lv, xpos[nt][0], xpos[nt][1], xpos[nt][2], c, idx, w);
-                                atomicAdd(a.gridGrad + 2ull * idx, w * d0);
-                                atomicAdd(a.gridGrad + 2ull * idx + 1, w * d1);
+                                atomicAdd(a.gridGrad + 2ull * idx[c], w[c] * d0);
+                                atomicAdd(a.gridGrad + 2ull * idx[c] + 1, w[c] * d1);
                             }
                         }
                     }
