@@ -29,7 +29,8 @@ def rearch_passes(temporal, spatial, unbiased, new_sequence):
     return PASS_TRACE_SHADOW_RAYS + k + (3 if unbiased else 0), PASS_SHADE_AND_RESAMPLE + k
 RENDERER_BIASED, RENDERER_UNBIASED, RENDERER_REARCH_BIASED, RENDERER_REARCH_UNBIASED, RENDERER_PATH_TRACE = 0, 1, 2, 3, 4
 (PT_SETUP_GBUFFERS, PT_PATH_TRACE_BASELINE, PT_REGIR_BUILD_CELLS, PT_REGIR_BUILD_CELLS_TEMPORAL,
- PT_PATH_TRACE_REGIR, PT_REGIR_UPDATE_LAST_ACCESS) = range(6)
+ PT_PATH_TRACE_REGIR, PT_REGIR_UPDATE_LAST_ACCESS, PT_NRC_PREPROCESS, PT_PATH_TRACE_NRC, PT_NRC_ACCUMULATE,
+ PT_NRC_PROPAGATE, PT_NRC_SHUFFLE, PT_NRC_VISUALIZE_PREDICTION) = range(12)
 
 
 class GfxError(RuntimeError):
@@ -88,6 +89,19 @@ class GfxRegirParams(C.Structure):
                 ("log2NumCandidatesPerCell", C.c_uint32), ("enableCellRandomization", C.c_uint32)]
 
 
+class GfxNrcParams(C.Structure):
+    _fields_ = [("sceneAabbMin", C.c_float * 3), ("sceneAabbMax", C.c_float * 3), ("maxNumTrainingSuffixes", C.c_uint32),
+                ("numTrainingData", C.c_void_p * 2), ("tileSize", C.c_void_p * 2), ("targetMinMax", C.c_void_p * 2),
+                ("targetAvg", C.c_void_p * 2), ("offsetToSelectUnbiasedTile", C.c_void_p),
+                ("offsetToSelectTrainingPath", C.c_void_p), ("inferenceRadianceQueryBuffer", C.c_void_p),
+                ("inferenceTerminalInfoBuffer", C.c_void_p), ("inferredRadianceBuffer", C.c_void_p),
+                ("perFrameContributionBuffer", C.c_void_p), ("trainRadianceQueryBuffer", C.c_void_p * 2),
+                ("trainTargetBuffer", C.c_void_p * 2), ("trainVertexInfoBuffer", C.c_void_p),
+                ("trainSuffixTerminalInfoBuffer", C.c_void_p), ("dataShufflerBuffer", C.c_void_p),
+                ("radianceScale", C.c_float), ("preprocessOffsetToSelectUnbiasedTile", C.c_uint32),
+                ("preprocessOffsetToSelectTrainingPath", C.c_uint32), ("isNewSequence", C.c_uint32)]
+
+
 class GfxhStreetParams(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("groundTess", C.c_uint32), ("numBuildings", C.c_uint32),
                 ("facadeTess", C.c_uint32), ("numProps", C.c_uint32), ("propSubdiv", C.c_uint32),
@@ -131,7 +145,7 @@ C_ABI_SYMBOLS = [
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
     "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
-    "gfx_nrc_get_params",
+    "gfx_nrc_get_params", "gfx_nrc_set_render_params",
     "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read",
 ]
 HOST_ABI_SYMBOLS = [
@@ -419,6 +433,9 @@ class Context:
 
     def restir_launch(self, pass_id, width, height, stream=0):
         self._check(self.L.gfx_restir_launch(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height)))
+
+    def nrc_set_render_params(self, params):
+        self._check(self.L.gfx_nrc_set_render_params(self.h, C.byref(params)))
 
     def regir_set_params(self, params):
         self._check(self.L.gfx_regir_set_params(self.h, C.byref(params)))

@@ -242,6 +242,14 @@ int gfx_regir_set_params(gfx_ctx* ctx, const gfx_regir_params* p) {
     GFX_CATCH(ctx)
 }
 
+int gfx_nrc_set_render_params(gfx_ctx* ctx, const gfx_nrc_params* p) {
+    GFX_TRY(ctx)
+    if (!p) throw HipError("gfx_nrc_set_render_params: null parameters");
+    ctx->c.nrcRender = *p;
+    ctx->c.nrcRenderValid = true;
+    GFX_CATCH(ctx)
+}
+
 int gfx_pt_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height, uint32_t maxPathLength,
                   uint32_t rowBegin, uint32_t rowEnd) {
     GFX_TRY(ctx)

@@ -66,6 +66,20 @@ GFX_DEV float gm_sin(float x) { float s, c; gm_sincos(x, s, c); return s; }
 GFX_DEV float gm_cos(float x) { float s, c; gm_sincos(x, s, c); return c; }
 GFX_DEV float gm_tan(float x) { float s, c; gm_sincos(x, s, c); return s / c; }
 
+// exp(x), |x| < 80: Cody-Waite ln2 split + degree-6 polynomial + exponent insertion
+GFX_DEV float gm_exp(float x) {
+    const float n = floorf(x * 1.44269504088896341f + 0.5f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float y = fmaf(p, r * r, r) + 1.0f;
+    return y * bits2f(static_cast<uint32_t>(static_cast<int32_t>(n) + 127) << 23);
+}
+
 GFX_DEV float gm_asin_core(float x) {
     const float z = x * x;
     float p = fmaf(4.2163199048e-2f, z, 2.4181311049e-2f);

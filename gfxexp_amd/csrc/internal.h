@@ -91,12 +91,15 @@ struct Context {
     // path tracer scratch (pathtrace.hip)
     DevBuf ptPending, ptExtOrg, ptExtDir, ptExtOwner, ptState;
     DevBuf rearchSlots;
+    DevBuf nrcState, neeTrainIdx;
     // build scratch
     DevBuf bTris, bBoxes, bKeys, bKeysAlt, bVals, bValsAlt, bSortTemp, bNodesLR, bParents, bFlags, bNodeBoxes, bRanges, bQueueA, bQueueB, bCounters;
     // restir
     RestirParams restir;
     gfx_regir_params regir;
     std::vector<NrcNet*> nrcNets;
+    gfx_nrc_params nrcRender;
+    bool nrcRenderValid = false;
     bool regirValid = false;
     // instrumentation
     bool timingEnabled = false;

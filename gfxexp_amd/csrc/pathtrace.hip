@@ -50,6 +50,10 @@ struct PtArgs {
     float4* state;                // per pixel: [2p] = alpha.rgb, prevDirPDensity; [2p+1] = contribution.rgb
     gfx_regir_params g;           // ReGIR grid (REGIR kernels only)
     uint32_t nextMaxLengthTerminate;   // pathLength + 1 >= maxPathLength (ReGIR loop head)
+    gfx_nrc_params nrc;           // NRC render state (NRC kernels only)
+    float4* nrcState;             // per pixel: [2p] = prevLocalThroughput.rgb, primaryPathSpread;
+                                  //            [2p+1] = curSqrtPathSpread, prevTrainDataIndex, flags, -
+    uint32_t* neeTrainIdx;        // per NEE slot: training record initialised with that NEE estimate (or invalid)
 };
 
 // ---------------------------------------------------------------- ReGIR
@@ -130,6 +134,9 @@ GFX_DEV f3 regir_sample_from_cell(const PtArgs& a, bool active, f3 pos, f3 vOutL
 struct PtVertexOut {              // what one shaded vertex hands to the queues
     bool wantNee; f3 neeDir; float neeTmax; f3 pending;
     bool wantExt; f3 extDir;
+    f3 neeRet;                    // unshadowed NEE estimate (NRC: initial training target)
+    f3 localThroughput;           // BSDF sampling throughput of this vertex
+    uint32_t trainIdx;            // NRC: training record tied to the NEE ray
 };
 
 // performNextEventEstimation (optix_pathtracing_kernels.cu:18-72) without the trace: returns the
@@ -182,12 +189,14 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
     o.wantNee = ret.x != 0.0f || ret.y != 0.0f || ret.z != 0.0f;
     o.neeDir = sr.dir; o.neeTmax = sr.tmax;
     o.pending = alpha * ret;
+    o.neeRet = ret;
     if (!o.wantNee) contribution = contribution + o.pending;   // nothing to trace: the add happens here
 
     f3 vInLocal;
     const float b0 = rng.uniform();
     const float b1 = rng.uniform();
-    alpha = alpha * bsdf.sample_throughput(vOutLocal, b0, b1, vInLocal, dirPDensity);
+    o.localThroughput = bsdf.sample_throughput(vOutLocal, b0, b1, vInLocal, dirPDensity);
+    alpha = alpha * o.localThroughput;
     o.extDir = frame.from_local(vInLocal);
     // loop head of the ray-generation program (:163-166): only valid samples are extended
     o.wantExt = dirPDensity > 0.0f && is_finite(dirPDensity);
@@ -203,7 +212,10 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
 
 GFX_DEV void push_vertex(const PtArgs& a, uint32_t pixel, f3 pos, const PtVertexOut& o) {
     const uint32_t ns = queue_append(o.wantNee, pos, o.neeDir, 0.0f, o.neeTmax, a.neeOrg, a.neeDir, a.neeCount);
-    if (o.wantNee) a.neePending[ns] = make_float4(o.pending.x, o.pending.y, o.pending.z, bits2f(pixel));
+    if (o.wantNee) {
+        a.neePending[ns] = make_float4(o.pending.x, o.pending.y, o.pending.z, bits2f(pixel));
+        if (a.neeTrainIdx) a.neeTrainIdx[ns] = o.trainIdx;
+    }
     const uint32_t es = queue_append(o.wantExt, pos, o.extDir, 0.0f, 3.402823466e+38f, a.extOrgOut, a.extDirOut, a.extCountOut);
     if (o.wantExt) a.extOwnerOut[es] = pixel;
 }
@@ -215,6 +227,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_first(PtArgs a) {
     const uint32_t bufIdx = a.f.bufferIndex;
     PtVertexOut o;
     o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
+    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = 0x007FFFFFu;
     f3 pos(0.0f), vOutLocal(0.0f);
     Frame frame(f3(0, 0, 1), f3(1, 0, 0));
     Bsdf bsdf;
@@ -284,7 +297,16 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_apply_nee(PtArgs a) {
     const float4 pend = a.neePending[i];
     const uint32_t pixel = f2bits(pend.w);
     f3 add(pend.x, pend.y, pend.z);
-    if (a.occluded[i]) add = add * 0.0f;      // alpha * RGB(0): zero unless the throughput is not finite
+    if (a.occluded[i]) {
+        add = add * 0.0f;                     // alpha * RGB(0): zero unless the throughput is not finite
+        if (a.neeTrainIdx) {                  // NRC: the record's initial target is the SHADOWED estimate
+            const uint32_t t = a.neeTrainIdx[i];
+            if (t != 0x007FFFFFu) {
+                float* tgt = static_cast<float*>(a.nrc.trainTargetBuffer[0]) + 3ull * t;
+                tgt[0] = 0.0f; tgt[1] = 0.0f; tgt[2] = 0.0f;
+            }
+        }
+    }
     float4* c = a.state + 2ull * pixel + 1;
     const float4 cur = *c;
     *c = make_float4(cur.x + add.x, cur.y + add.y, cur.z + add.z, 0.0f);
@@ -298,6 +320,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_bounce(PtArgs a) {
     const uint32_t count = *a.extCountIn;
     PtVertexOut o;
     o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
+    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = 0x007FFFFFu;
     f3 pos(0.0f), vOutLocal(0.0f);
     Frame frame(f3(0, 0, 1), f3(1, 0, 0));
     Bsdf bsdf;
@@ -545,6 +568,546 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_finish(PtArgs a) {
     *beauty = make_float4(result.x, result.y, result.z, 1.0f);
 }
 
+// ---------------------------------------------------------------- neural radiance caching (render side)
+// neural_radiance_caching/gpu_kernels/optix_pathtracing_kernels.cu + nrc_setup_kernels.cu on the
+// same wavefront pipeline.  Training-record indices come from one wave-aggregated atomicAdd per
+// kernel wave (the reference's per-thread atomicAdd order is unspecified as well); the initial
+// target of a record is the NEE estimate of its vertex, so the apply kernel zeroes it when the
+// shadow ray turns out occluded.
+constexpr uint32_t kInvalidVertexDataIndex = 0x007FFFFFu;     // neural_radiance_caching_shared.h:146
+constexpr uint32_t kNumTrainingDataPerFrame = 1u << 16, kTrainBufferSize = 2u << 16;   // :8-9
+constexpr uint32_t kNrcFlagRenderEnds = 1u, kNrcFlagSuffixEnds = 2u;
+
+GFX_DEV uint32_t nrc_terminal_bits(bool hasQuery, uint32_t pathLength, bool training, bool unbiased) {
+    return (hasQuery ? 1u : 0u) | ((pathLength & 0xFFu) << 1) | ((training ? 1u : 0u) << 9) | ((unbiased ? 1u : 0u) << 10);
+}
+GFX_DEV uint32_t nrc_suffix_bits(uint32_t prevIdx, bool hasQuery, uint32_t pathLength) {
+    return (prevIdx & 0x7FFFFFu) | ((hasQuery ? 1u : 0u) << 23) | ((pathLength & 0xFFu) << 24);
+}
+struct NrcTile { uint32_t linearTileIndex; bool training, unbiased; };
+GFX_DEV NrcTile nrc_tile_of(const PtArgs& a, uint32_t pixel) {   // optix_pathtracing_kernels.cu:107-131
+    const uint32_t W = static_cast<uint32_t>(a.s.imageSizeX);
+    const uint32_t x = pixel % W, y = pixel / W;
+    const uint2 ts = *static_cast<const uint2*>(a.nrc.tileSize[a.f.bufferIndex]);
+    const uint32_t local = (y % ts.y) * ts.x + (x % ts.x);
+    NrcTile t;
+    t.training = (local + *static_cast<const uint32_t*>(a.nrc.offsetToSelectTrainingPath)) % (ts.x * ts.y) == 0;
+    const uint32_t numTilesX = (W + ts.x - 1) / ts.x;
+    const uint32_t tx = x / ts.x, ty = y / ts.y;
+    t.linearTileIndex = ty * numTilesX + tx;
+    t.unbiased = ((ty % 4) * 4 + (tx % 4) + *static_cast<const uint32_t*>(a.nrc.offsetToSelectUnbiasedTile)) % 16 == 0;
+    return t;
+}
+struct NrcQuery { float v[14]; };
+GFX_DEV NrcQuery nrc_make_query(const PtArgs& a, f3 pos, f3 normal, f3 vOut, const Bsdf& bsdf) {   // :12-32
+    NrcQuery q;
+    const float* lo = a.nrc.sceneAabbMin; const float* hi = a.nrc.sceneAabbMax;
+    const float p[3] = { pos.x, pos.y, pos.z };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float den = hi[k] - lo[k]; q.v[k] = den != 0 ? (p[k] - lo[k]) / den : 0.0f; }
+    q.v[4] = gm_acos(fmin2(fmax2(normal.z, -1.0f), 1.0f)); q.v[3] = gm_atan2(normal.y, normal.x);
+    q.v[6] = gm_acos(fmin2(fmax2(vOut.z, -1.0f), 1.0f)); q.v[5] = gm_atan2(vOut.y, vOut.x);
+    q.v[7] = 1 - gm_exp(-bsdf.roughness);
+    q.v[8] = bsdf.diffuse.x; q.v[9] = bsdf.diffuse.y; q.v[10] = bsdf.diffuse.z;
+    q.v[11] = bsdf.specularF0.x; q.v[12] = bsdf.specularF0.y; q.v[13] = bsdf.specularF0.z;
+    return q;
+}
+GFX_DEV void nrc_store_query(void* buf, size_t idx, const NrcQuery& q) {
+    float2* dst = reinterpret_cast<float2*>(static_cast<float*>(buf) + 14 * idx);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) dst[k] = make_float2(q.v[2 * k], q.v[2 * k + 1]);
+}
+// trainDataIndex = atomicAdd(numTrainingData, 1) for the lanes with want, one atomic per wave
+GFX_DEV uint32_t nrc_alloc_train_index(uint32_t* counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return kInvalidVertexDataIndex;
+    const int lane = threadIdx.x & 63;
+    const int leader = __builtin_ctzll(mask);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(mask)));
+    base = __shfl(base, leader);
+    return base + __popcll(mask & ((1ull << lane) - 1ull));
+}
+GFX_DEV void nrc_write_train_vertex(const PtArgs& a, uint32_t idx, const NrcQuery& q, f3 localThroughput, uint32_t prevIdx,
+                                    uint32_t pathLength, f3 target) {
+    nrc_store_query(a.nrc.trainRadianceQueryBuffer[0], idx, q);
+    static_cast<float4*>(a.nrc.trainVertexInfoBuffer)[idx] =
+        make_float4(localThroughput.x, localThroughput.y, localThroughput.z, bits2f((prevIdx & 0x7FFFFFu) | ((pathLength & 0xFFu) << 23)));
+    float* t = static_cast<float*>(a.nrc.trainTargetBuffer[0]) + 3ull * idx;
+    t[0] = target.x; t[1] = target.y; t[2] = target.z;
+}
+// tail of the ray-generation program for a path that stops here (:339-373)
+GFX_DEV void nrc_end_path(const PtArgs& a, uint32_t pixel, const NrcTile& tile, uint32_t flags, uint32_t prevTrainIdx, uint32_t pathLength) {
+    if (tile.training && !(flags & kNrcFlagSuffixEnds))
+        static_cast<uint32_t*>(a.nrc.trainSuffixTerminalInfoBuffer)[tile.linearTileIndex] = nrc_suffix_bits(prevTrainIdx, false, pathLength);
+    if (!(flags & kNrcFlagRenderEnds))
+        static_cast<float4*>(a.nrc.inferenceTerminalInfoBuffer)[pixel] =
+            make_float4(0.0f, 0.0f, 0.0f, bits2f(nrc_terminal_bits(false, pathLength, tile.training, tile.unbiased)));
+}
+
+// preprocessNRC, nrc_setup_kernels.cu:6-49
+__global__ __launch_bounds__(kPtBlock) void k_nrc_preprocess(PtArgs a) {
+    const uint32_t i = blockIdx.x * kPtBlock + threadIdx.x;
+    if (i >= a.nrc.maxNumTrainingSuffixes) return;
+    const uint32_t bufIdx = a.f.bufferIndex, prevBufIdx = (a.f.bufferIndex + 1) % 2;
+    if (i == 0) {
+        uint32_t nx = 8, ny = 8;
+        if (!a.nrc.isNewSequence) {
+            const uint32_t prevNum = *static_cast<const uint32_t*>(a.nrc.numTrainingData[prevBufIdx]);
+            const float r = sqrtf(static_cast<float>(prevNum) / kNumTrainingDataPerFrame);
+            const uint2 cur = *static_cast<const uint2*>(a.nrc.tileSize[prevBufIdx]);
+            nx = f2u_sat(cur.x * r); ny = f2u_sat(cur.y * r);
+            nx = nx < 4u ? 4u : (nx > 128u ? 128u : nx);
+            ny = ny < 4u ? 4u : (ny > 128u ? 128u : ny);
+        }
+        *static_cast<uint2*>(a.nrc.tileSize[bufIdx]) = make_uint2(nx, ny);
+        *static_cast<uint32_t*>(a.nrc.numTrainingData[bufIdx]) = 0;
+        *static_cast<uint32_t*>(a.nrc.offsetToSelectUnbiasedTile) = a.nrc.preprocessOffsetToSelectUnbiasedTile;
+        *static_cast<uint32_t*>(a.nrc.offsetToSelectTrainingPath) = a.nrc.preprocessOffsetToSelectTrainingPath;
+        int32_t* mm = static_cast<int32_t*>(a.nrc.targetMinMax[bufIdx]);
+        mm[0] = mm[1] = mm[2] = 0x7F800000;                         // floatToOrderedInt(+inf)
+        mm[3] = mm[4] = mm[5] = static_cast<int32_t>(0xFF800000u) ^ 0x7FFFFFFF;   // floatToOrderedInt(-inf)
+        float* avg = static_cast<float*>(a.nrc.targetAvg[bufIdx]);
+        avg[0] = avg[1] = avg[2] = 0.0f;
+    }
+    static_cast<uint32_t*>(a.nrc.trainSuffixTerminalInfoBuffer)[i] = nrc_suffix_bits(kInvalidVertexDataIndex, false, 0);
+}
+
+// pathTrace_raygen_generic<true> up to the path extension loop (:133-318)
+__global__ __launch_bounds__(kPtBlock) void k_nrc_pt_first(PtArgs a) {
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
+    const uint32_t bufIdx = a.f.bufferIndex;
+    PtVertexOut o;
+    o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
+    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = kInvalidVertexDataIndex;
+    f3 pos(0.0f), vOutLocal(0.0f), vOut(0.0f);
+    Frame frame(f3(0, 0, 1), f3(1, 0, 0));
+    Bsdf bsdf; bsdf.type = 0; bsdf.diffuse = f3(0.0f); bsdf.specularF0 = f3(0.0f); bsdf.roughness = 1.0f;
+    Pcg32 rng; rng.state = 0;
+    const EnvMap env = load_env(a.s);
+    const bool envEnabled = env.present() && a.f.enableEnvLight;
+    f3 contribution(0.001f, 0.001f, 0.001f);
+    f3 alpha(1.0f);
+    float dirPDensity = 0.0f, primaryPathSpread = 0.0f;
+    const bool inImage = p < a.pixelEnd;
+    uint4 g0 = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+    if (inImage) g0 = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p];
+    const bool surface = g0.x != 0xFFFFFFFFu;
+    NrcTile tile; tile.linearTileIndex = 0; tile.training = false; tile.unbiased = false;
+    if (inImage) tile = nrc_tile_of(a, static_cast<uint32_t>(p));
+    if (surface) {
+        const float bcB = decode_bc(g0.w & 0xFFFF), bcC = decode_bc(g0.w >> 16);
+        const DevInstance* inst = a.scene.insts + g0.x;
+        const DevGeomInst g = a.scene.geomInsts[g0.y];
+        const uint32_t* tri = a.scene.triangles + 3ull * (g.triangleOffset + g0.z);
+        const DevVertex vA = load_vertex(a.scene.vertices + g.vertexOffset + tri[0]);
+        const DevVertex vB = load_vertex(a.scene.vertices + g.vertexOffset + tri[1]);
+        const DevVertex vC = load_vertex(a.scene.vertices + g.vertexOffset + tri[2]);
+        const float bcA = 1 - (bcB + bcC);
+        const f3 pAo(vA.px, vA.py, vA.pz), pBo(vB.px, vB.py, vB.pz), pCo(vC.px, vC.py, vC.pz);
+        const m34 xfm = load_m34(inst->transform);
+        const m33 nrm = load_m33_rows(inst->normalMatrix);
+        pos = xfm_point(xfm, bcA * pAo + bcB * pBo + bcC * pCo);
+        f3 ng = unit(mul(nrm, cross(pBo - pAo, pCo - pAo)));
+        const f3 nsObj = bcA * f3(vA.nx, vA.ny, vA.nz) + bcB * f3(vB.nx, vB.ny, vB.nz) + bcC * f3(vC.nx, vC.ny, vC.nz);
+        const f3 tcObj = bcA * f3(vA.tx, vA.ty, vA.tz) + bcB * f3(vB.tx, vB.ty, vB.tz) + bcC * f3(vC.tx, vC.ty, vC.tz);
+        f3 ns = unit(mul(nrm, nsObj));
+        f3 tc0 = xfm_vector(xfm, tcObj);
+        tc0 = unit(tc0 - dot(ns, tc0) * ns);
+        if (!all_finite(ns)) { ng = f3(0, 0, 1); ns = f3(0, 0, 1); tc0 = f3(1, 0, 0); }
+        if (!all_finite(tc0)) { f3 bt; make_coordinate_system(ns, tc0, bt); }
+        const Camera cam = load_camera(a.f.camera);
+        rng.state = static_cast<const uint64_t*>(a.s.rngBuffer)[p];
+        const gfx_material& mat = a.scene.materials[g.materialSlot];
+        vOut = cam.pos - pos;
+        const float primaryDist2 = len2(vOut);
+        vOut = vOut / sqrtf(primaryDist2);
+        const float primaryDotVN = dot(vOut, ng);
+        const float frontHit = primaryDotVN >= 0.0f ? 1.0f : -1.0f;
+        pos = offset_ray_origin(pos, frontHit * ng);
+        primaryPathSpread = primaryDist2 / (4 * kPi * fabsf(primaryDotVN));
+        frame = Frame(ns, tc0);
+        vOutLocal = frame.to_local(vOut);
+        contribution = f3(0.0f);
+        if (vOutLocal.z > 0 && mat.hasEmittance)
+            contribution = contribution + alpha * f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]) / kPi;
+        bsdf.setup(mat);
+    }
+    else if (inImage && envEnabled) {
+        contribution = a.f.envLightPowerCoeff * env.fetch(decode_bc(g0.w & 0xFFFF), decode_bc(g0.w >> 16));
+    }
+    shade_vertex<false>(a, surface, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
+    // training record of the first vertex (:238-277)
+    uint32_t trainIdx = nrc_alloc_train_index(static_cast<uint32_t*>(a.nrc.numTrainingData[bufIdx]), surface && tile.training);
+    if (surface && tile.training) {
+        if (trainIdx < kTrainBufferSize)
+            nrc_write_train_vertex(a, trainIdx, nrc_make_query(a, pos, frame.n, vOut, bsdf), o.localThroughput, kInvalidVertexDataIndex, 1, o.neeRet);
+        else trainIdx = kInvalidVertexDataIndex;
+    }
+    else trainIdx = kInvalidVertexDataIndex;   // (never read for non-training paths)
+    o.trainIdx = trainIdx;
+    if (surface) static_cast<uint64_t*>(a.s.rngBuffer)[p] = rng.state;
+    if (inImage) {
+        a.state[2 * p] = make_float4(alpha.x, alpha.y, alpha.z, dirPDensity);
+        a.state[2 * p + 1] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+        a.nrcState[2 * p] = make_float4(o.localThroughput.x, o.localThroughput.y, o.localThroughput.z, primaryPathSpread);
+        a.nrcState[2 * p + 1] = make_float4(0.0f, bits2f(trainIdx), bits2f(0u), 0.0f);
+        if (!o.wantExt) {
+            NrcTile t = tile;
+            if (!surface) t.training = false;      // the suffix terminal is only written inside the surface branch (:344-350)
+            nrc_end_path(a, static_cast<uint32_t>(p), t, 0u, trainIdx, 1);
+            if (!surface)   // ... but the terminal info of a background pixel still records the tile flags (:365-372)
+                static_cast<float4*>(a.nrc.inferenceTerminalInfoBuffer)[p] =
+                    make_float4(0.0f, 0.0f, 0.0f, bits2f(nrc_terminal_bits(false, 1, tile.training, tile.unbiased)));
+        }
+    }
+    push_vertex(a, static_cast<uint32_t>(p), pos, o);
+}
+
+// pathTrace_closestHit_generic<true> / pathTrace_miss_generic<true> for one extension ray, then the
+// loop head and, when the path stops, the tail of the ray-generation program (:380-677, :320-373)
+__global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
+    const uint32_t i = blockIdx.x * kPtBlock + threadIdx.x;
+    const uint32_t count = *a.extCountIn;
+    const uint32_t bufIdx = a.f.bufferIndex;
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    PtVertexOut o;
+    o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
+    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = kInvalidVertexDataIndex;
+    f3 pos(0.0f), vOutLocal(0.0f), vOut(0.0f);
+    Frame frame(f3(0, 0, 1), f3(1, 0, 0));
+    Bsdf bsdf; bsdf.type = 0; bsdf.diffuse = f3(0.0f); bsdf.specularF0 = f3(0.0f); bsdf.roughness = 1.0f;
+    Pcg32 rng; rng.state = 0;
+    const EnvMap env = load_env(a.s);
+    const bool envEnabled = env.present() && a.f.enableEnvLight;
+    f3 alpha(0.0f), contribution(0.0f), prevLocalThroughput(0.0f);
+    float dirPDensity = 0.0f, primaryPathSpread = 0.0f, curSqrtPathSpread = 0.0f;
+    uint32_t pixel = 0, prevTrainIdx = kInvalidVertexDataIndex, flags = 0;
+    NrcTile tile; tile.linearTileIndex = 0; tile.training = false; tile.unbiased = false;
+    const uint32_t pathLength = a.pathLength;
+    bool active = i < count, hitSurface = false, shade = false;
+    if (active) {
+        pixel = a.extOwnerIn[i];
+        tile = nrc_tile_of(a, pixel);
+        const gfx_hit h = a.hits[i];
+        const float4 ro4 = a.extOrgIn[i], rd4 = a.extDirIn[i];
+        const f3 rayOrg(ro4.x, ro4.y, ro4.z), rayDir(rd4.x, rd4.y, rd4.z);
+        const float4 s0 = a.state[2ull * pixel], s1 = a.state[2ull * pixel + 1];
+        const float4 n0 = a.nrcState[2ull * pixel], n1 = a.nrcState[2ull * pixel + 1];
+        alpha = f3(s0.x, s0.y, s0.z);
+        const float prevDirPDensity = s0.w;
+        dirPDensity = prevDirPDensity;
+        contribution = f3(s1.x, s1.y, s1.z);
+        prevLocalThroughput = f3(n0.x, n0.y, n0.z); primaryPathSpread = n0.w;
+        curSqrtPathSpread = n1.x; prevTrainIdx = f2bits(n1.y); flags = f2bits(n1.z);
+        float* prevTarget = static_cast<float*>(a.nrc.trainTargetBuffer[0]) + 3ull * prevTrainIdx;
+        const bool linkPrev = tile.training && prevTrainIdx != kInvalidVertexDataIndex;
+        if (h.triIndex == GFX_INVALID_SLOT) {
+            if (envEnabled) {
+                const f3 rd = unit(rayDir);
+                float posPhi, theta;
+                to_polar_yup(rd, posPhi, theta);
+                float phi = posPhi + a.f.envLightRotation;
+                phi = phi - floorf(phi / (2 * kPi)) * 2 * kPi;
+                const float tu = phi / (2 * kPi), tv = theta / kPi;
+                const f3 luminance = a.f.envLightPowerCoeff * env.fetch(tu, tv);
+                const float uvPDF = env.evaluate_pdf(tu, tv);
+                const float hypAreaPDensity = uvPDF / (2 * kPi * kPi * gm_sin(theta));
+                const float lightPDensity = 0.25f * hypAreaPDensity;
+                const float misWeight = (prevDirPDensity * prevDirPDensity) / (prevDirPDensity * prevDirPDensity + lightPDensity * lightPDensity);
+                const f3 implicit = misWeight * luminance;
+                contribution = contribution + alpha * implicit;
+                if (linkPrev) {
+                    const f3 add = prevLocalThroughput * implicit;
+                    prevTarget[0] += add.x; prevTarget[1] += add.y; prevTarget[2] += add.z;
+                }
+            }
+        }
+        else {
+            hitSurface = true;
+            const Bvh8Tri* tr = a.tris + h.triIndex;
+            const uint32_t instSlot = tr->instSlot, geomInstSlot = tr->geomInstSlot, primIndex = tr->primIndex;
+            const DevInstance* inst = a.scene.insts + instSlot;
+            const DevGeomInst g = a.scene.geomInsts[geomInstSlot];
+            const uint32_t* tri = a.scene.triangles + 3ull * (g.triangleOffset + primIndex);
+            const DevVertex vA = load_vertex(a.scene.vertices + g.vertexOffset + tri[0]);
+            const DevVertex vB = load_vertex(a.scene.vertices + g.vertexOffset + tri[1]);
+            const DevVertex vC = load_vertex(a.scene.vertices + g.vertexOffset + tri[2]);
+            const m34 xfm = load_m34(inst->transform);
+            const m33 nrm = load_m33_rows(inst->normalMatrix);
+            const f3 pA = xfm_point(xfm, f3(vA.px, vA.py, vA.pz));
+            const f3 pB = xfm_point(xfm, f3(vB.px, vB.py, vB.pz));
+            const f3 pC = xfm_point(xfm, f3(vC.px, vC.py, vC.pz));
+            const float bcB = h.bcB, bcC = h.bcC;
+            const float bcA = 1 - (bcB + bcC);
+            pos = bcA * pA + bcB * pB + bcC * pC;
+            const f3 nsObj = bcA * f3(vA.nx, vA.ny, vA.nz) + bcB * f3(vB.nx, vB.ny, vB.nz) + bcC * f3(vC.nx, vC.ny, vC.nz);
+            const f3 tcObj = bcA * f3(vA.tx, vA.ty, vA.tz) + bcB * f3(vB.tx, vB.ty, vB.tz) + bcC * f3(vC.tx, vC.ty, vC.tz);
+            f3 ng = cross(pB - pA, pC - pA);
+            const float area = 0.5f * len(ng);
+            ng = ng / (2 * area);
+            f3 ns = unit(mul(nrm, nsObj));
+            f3 tc0 = unit(xfm_vector(xfm, tcObj));
+            if (!all_finite(ns)) { ns = f3(0, 0, 1); tc0 = f3(1, 0, 0); }
+            if (!all_finite(tc0)) { f3 bt; make_coordinate_system(ns, tc0, bt); }
+            float hypAreaPDensity = 0.0f;
+            {
+                float lightProb = 1.0f;
+                if (envEnabled) lightProb *= (1 - 0.25f);
+                const float instImportance = inst->distIntegral;
+                lightProb *= (inst->uniformScale * inst->uniformScale * instImportance) / *a.scene.lightInstIntegral;
+                lightProb *= g.distIntegral / instImportance;
+                if (is_finite(lightProb)) {
+                    float pmf = 0.0f;
+                    if (g.distOffset != 0xFFFFFFFFu && g.distIntegral != 0.0f) pmf = a.scene.lightWeights[g.distOffset + primIndex] / g.distIntegral;
+                    lightProb *= pmf;
+                    hypAreaPDensity = lightProb / area;
+                }
+            }
+            const gfx_material& mat = a.scene.materials[g.materialSlot];
+            vOut = unit(-rayDir);
+            const float frontHit = dot(vOut, ng) >= 0.0f ? 1.0f : -1.0f;
+            frame = Frame(ns, tc0);
+            pos = offset_ray_origin(pos, frontHit * ng);
+            vOutLocal = frame.to_local(vOut);
+            const float dist2 = len2(rayOrg - pos);
+            curSqrtPathSpread += sqrtf(dist2 / (prevDirPDensity * fabsf(vOutLocal.z)));
+            if (vOutLocal.z > 0 && mat.hasEmittance) {
+                const f3 emittance(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+                const float lightPDensity = hypAreaPDensity * dist2 / vOutLocal.z;
+                const float misWeight = (prevDirPDensity * prevDirPDensity) / (prevDirPDensity * prevDirPDensity + lightPDensity * lightPDensity);
+                const f3 implicit = emittance * (misWeight / kPi);
+                contribution = contribution + alpha * implicit;
+                if (linkPrev) {
+                    const f3 add = prevLocalThroughput * implicit;
+                    prevTarget[0] += add.x; prevTarget[1] += add.y; prevTarget[2] += add.z;
+                }
+            }
+            rng.state = static_cast<const uint64_t*>(a.s.rngBuffer)[pixel];
+            // Russian roulette (:455-474)
+            bool performRR = true, terminatedByRR = false, stop = false;
+            float recContinueProb = 1.0f;
+            if (tile.training) performRR = pathLength > 2;
+            const bool unbiasedSuffix = (flags & kNrcFlagRenderEnds) && tile.training && tile.unbiased;
+            if (performRR) {
+                const float continueProb = fminf(luminance_srgb(alpha) / luminance_srgb(f3(1.0f)), 1.0f);
+                if (rng.uniform() >= continueProb || a.maxLengthTerminate) {
+                    if (unbiasedSuffix) stop = true;
+                    terminatedByRR = true;
+                }
+                recContinueProb = 1.0f / continueProb;
+            }
+            bsdf.setup(mat);
+            if (!stop) {   // cache termination heuristic (:479-538)
+                bool endsWithCache = curSqrtPathSpread * curSqrtPathSpread > 0.01f * primaryPathSpread;
+                if (unbiasedSuffix) endsWithCache = false;
+                if (endsWithCache) {
+                    const NrcQuery q = nrc_make_query(a, pos, frame.n, vOut, bsdf);
+                    if (!(flags & kNrcFlagRenderEnds)) {
+                        nrc_store_query(a.nrc.inferenceRadianceQueryBuffer, pixel, q);
+                        static_cast<float4*>(a.nrc.inferenceTerminalInfoBuffer)[pixel] =
+                            make_float4(alpha.x, alpha.y, alpha.z, bits2f(nrc_terminal_bits(true, pathLength, tile.training, tile.unbiased)));
+                        flags |= kNrcFlagRenderEnds;
+                        if (tile.training) curSqrtPathSpread = 0;
+                        else stop = true;
+                    }
+                    else {
+                        if (!(flags & kNrcFlagSuffixEnds)) {
+                            nrc_store_query(a.nrc.inferenceRadianceQueryBuffer, numPixels + tile.linearTileIndex, q);
+                            static_cast<uint32_t*>(a.nrc.trainSuffixTerminalInfoBuffer)[tile.linearTileIndex] = nrc_suffix_bits(prevTrainIdx, true, pathLength);
+                            flags |= kNrcFlagSuffixEnds;
+                        }
+                        stop = true;
+                    }
+                }
+            }
+            if (!stop && terminatedByRR) stop = true;
+            if (!stop) {
+                alpha = alpha * recContinueProb;
+                if (linkPrev) {
+                    float4* vi = static_cast<float4*>(a.nrc.trainVertexInfoBuffer) + prevTrainIdx;
+                    float4 v = *vi;
+                    v.x *= recContinueProb; v.y *= recContinueProb; v.z *= recContinueProb;
+                    *vi = v;
+                }
+                shade = true;
+            }
+        }
+    }
+    shade_vertex<false>(a, shade, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
+    // training record of this vertex (:574-631)
+    const bool wantRecord = shade && tile.training && !(flags & kNrcFlagSuffixEnds);
+    uint32_t trainIdx = nrc_alloc_train_index(static_cast<uint32_t*>(a.nrc.numTrainingData[bufIdx]), wantRecord);
+    if (wantRecord) {
+        const NrcQuery q = nrc_make_query(a, pos, frame.n, vOut, bsdf);
+        if (trainIdx < kTrainBufferSize) {
+            nrc_write_train_vertex(a, trainIdx, q, o.localThroughput, prevTrainIdx, pathLength, o.neeRet);
+            prevTrainIdx = trainIdx;
+            o.trainIdx = trainIdx;
+        }
+        else {
+            nrc_store_query(a.nrc.inferenceRadianceQueryBuffer, numPixels + tile.linearTileIndex, q);
+            static_cast<uint32_t*>(a.nrc.trainSuffixTerminalInfoBuffer)[tile.linearTileIndex] = nrc_suffix_bits(prevTrainIdx, true, pathLength);
+            flags |= kNrcFlagSuffixEnds;
+        }
+    }
+    if (shade) prevLocalThroughput = o.localThroughput;
+    if (active) {
+        if (hitSurface) {
+            static_cast<uint64_t*>(a.s.rngBuffer)[pixel] = rng.state;
+            a.state[2ull * pixel] = make_float4(alpha.x, alpha.y, alpha.z, dirPDensity);
+        }
+        a.state[2ull * pixel + 1] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+        a.nrcState[2ull * pixel] = make_float4(prevLocalThroughput.x, prevLocalThroughput.y, prevLocalThroughput.z, primaryPathSpread);
+        a.nrcState[2ull * pixel + 1] = make_float4(curSqrtPathSpread, bits2f(prevTrainIdx), bits2f(flags), 0.0f);
+        if (!o.wantExt) nrc_end_path(a, pixel, tile, flags, prevTrainIdx, pathLength);
+    }
+    push_vertex(a, pixel, pos, o);
+}
+
+// perFrameContributionBuffer = contribution (:375)
+__global__ __launch_bounds__(kPtBlock) void k_nrc_pt_finish(PtArgs a) {
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
+    if (p >= a.pixelEnd) return;
+    const float4 c = a.state[2 * p + 1];
+    float* dst = static_cast<float*>(a.nrc.perFrameContributionBuffer) + 3 * p;
+    dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
+}
+
+GFX_DEV f3 nrc_scaled_prediction(const PtArgs& a, size_t entry) {
+    const float* r = static_cast<const float*>(a.nrc.inferredRadianceBuffer) + 3 * entry;
+    f3 radiance(fmax2(r[0], 0.0f), fmax2(r[1], 0.0f), fmax2(r[2], 0.0f));
+    if (a.nrc.radianceScale > 0) radiance = radiance / a.nrc.radianceScale;
+    const float* q = static_cast<const float*>(a.nrc.inferenceRadianceQueryBuffer) + 14 * entry;
+    return radiance * f3(q[8] + q[11], q[9] + q[12], q[10] + q[13]);
+}
+
+// accumulateInferredRadianceValues, nrc_setup_kernels.cu:51-93
+__global__ __launch_bounds__(kPtBlock) void k_nrc_accumulate(PtArgs a) {
+    const size_t p = static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
+    if (p >= static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY) return;
+    const float4 t = static_cast<const float4*>(a.nrc.inferenceTerminalInfoBuffer)[p];
+    const float* d = static_cast<const float*>(a.nrc.perFrameContributionBuffer) + 3 * p;
+    const f3 directCont(d[0], d[1], d[2]);
+    f3 radiance(0.0f);
+    if (f2bits(t.w) & 1u) radiance = nrc_scaled_prediction(a, p);
+    const f3 contribution = directCont + f3(t.x, t.y, t.z) * radiance;
+    float4* beauty = static_cast<float4*>(a.s.beautyAccumBuffer) + p;
+    f3 prev(0.0f);
+    if (a.f.numAccumFrames > 0) { const float4 b = *beauty; prev = f3(b.x, b.y, b.z); }
+    const float curWeight = 1.0f / (1 + a.f.numAccumFrames);
+    const f3 result = (1 - curWeight) * prev + curWeight * contribution;
+    *beauty = make_float4(result.x, result.y, result.z, 1.0f);
+}
+
+// propagateRadianceValues, nrc_setup_kernels.cu:95-137
+__global__ __launch_bounds__(kPtBlock) void k_nrc_propagate(PtArgs a) {
+    const uint32_t i = blockIdx.x * kPtBlock + threadIdx.x;
+    if (i >= a.nrc.maxNumTrainingSuffixes) return;
+    const uint32_t bits = static_cast<const uint32_t*>(a.nrc.trainSuffixTerminalInfoBuffer)[i];
+    uint32_t last = bits & 0x7FFFFFu;
+    if (last == kInvalidVertexDataIndex) return;
+    f3 contribution(0.0f);
+    if ((bits >> 23) & 1u) contribution = nrc_scaled_prediction(a, static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY + i);
+    while (last != kInvalidVertexDataIndex) {
+        const float4 vi = static_cast<const float4*>(a.nrc.trainVertexInfoBuffer)[last];
+        float* t = static_cast<float*>(a.nrc.trainTargetBuffer[0]) + 3ull * last;
+        contribution = f3(t[0], t[1], t[2]) + f3(vi.x, vi.y, vi.z) * contribution;
+        const float* q = static_cast<const float*>(a.nrc.trainRadianceQueryBuffer[0]) + 14ull * last;
+        const f3 ref(q[8] + q[11], q[9] + q[12], q[10] + q[13]);
+        t[0] = ref.x != 0 ? contribution.x / ref.x : 0.0f;
+        t[1] = ref.y != 0 ? contribution.y / ref.y : 0.0f;
+        t[2] = ref.z != 0 ? contribution.z / ref.z : 0.0f;
+        last = f2bits(vi.w) & 0x7FFFFFu;
+    }
+}
+
+GFX_DEV int32_t float_to_ordered_int(float f) { const int32_t i = static_cast<int32_t>(f2bits(f)); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+
+// shuffleTrainingData, nrc_setup_kernels.cu:139-216 (one thread per destination candidate, 65536 threads)
+__global__ __launch_bounds__(kPtBlock) void k_nrc_shuffle(PtArgs a) {
+    const uint32_t i = blockIdx.x * kPtBlock + threadIdx.x;
+    const uint32_t bufIdx = a.f.bufferIndex;
+    const uint32_t numTrainingData = *static_cast<const uint32_t*>(a.nrc.numTrainingData[bufIdx]);
+    float* dstQ = static_cast<float*>(a.nrc.trainRadianceQueryBuffer[1]);
+    float* dstT = static_cast<float*>(a.nrc.trainTargetBuffer[1]);
+    if (numTrainingData == 0) {
+        for (int k = 0; k < 14; ++k) dstQ[14ull * i + k] = 0.0f;
+        dstT[3ull * i] = 0.0f; dstT[3ull * i + 1] = 0.0f; dstT[3ull * i + 2] = 0.0f;
+        return;
+    }
+    uint32_t* shuffler = static_cast<uint32_t*>(a.nrc.dataShufflerBuffer) + i;
+    const uint32_t state = (*shuffler * 1103515245u + 12345u) % (1u << 31);    // LinearCongruentialGenerator, :164-181
+    *shuffler = state;
+    const uint32_t dstIdx = state % kNumTrainingDataPerFrame;
+    const uint32_t srcIdx = i % numTrainingData;
+    const float* sq = static_cast<const float*>(a.nrc.trainRadianceQueryBuffer[0]) + 14ull * srcIdx;
+    const float* st = static_cast<const float*>(a.nrc.trainTargetBuffer[0]) + 3ull * srcIdx;
+    float q[14];
+    bool valid = true;
+#pragma unroll
+    for (int k = 0; k < 14; ++k) { q[k] = sq[k]; valid = valid && is_finite(q[k]); }
+    if (!valid) for (int k = 0; k < 14; ++k) q[k] = 0.0f;
+    f3 target(st[0], st[1], st[2]);
+    if (!all_finite(target)) target = f3(0.0f);
+    // statistics (min / max exact; the average accumulates in arrival order)
+    int32_t* mm = static_cast<int32_t*>(a.nrc.targetMinMax[bufIdx]);
+    float* avg = static_cast<float*>(a.nrc.targetAvg[bufIdx]);
+    const float c[3] = { target.x, target.y, target.z };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int32_t lo = float_to_ordered_int(c[k]), hi = lo;
+        float sum = c[k] / kNumTrainingDataPerFrame;
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); sum += __shfl_xor(sum, off);
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(mm + k, lo); atomicMax(mm + 3 + k, hi); atomicAdd(avg + k, sum); }
+    }
+    if (a.nrc.radianceScale > 0) target = target * a.nrc.radianceScale;
+    target = f3(fmin2(target.x, 1e+6f), fmin2(target.y, 1e+6f), fmin2(target.z, 1e+6f));
+#pragma unroll
+    for (int k = 0; k < 14; ++k) dstQ[14ull * dstIdx + k] = q[k];
+    dstT[3ull * dstIdx] = target.x; dstT[3ull * dstIdx + 1] = target.y; dstT[3ull * dstIdx + 2] = target.z;
+}
+
+// visualizePrediction ray generation, optix_pathtracing_kernels.cu:705-778
+__global__ __launch_bounds__(kPtBlock) void k_nrc_visualize(PtArgs a) {
+    const size_t p = static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
+    if (p >= static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY) return;
+    const uint4 g0 = static_cast<const uint4*>(a.s.gbuffer0[a.f.bufferIndex])[p];
+    const bool surface = g0.x != 0xFFFFFFFFu;
+    if (surface) {
+        const float bcB = decode_bc(g0.w & 0xFFFF), bcC = decode_bc(g0.w >> 16);
+        const DevInstance* inst = a.scene.insts + g0.x;
+        const DevGeomInst g = a.scene.geomInsts[g0.y];
+        const uint32_t* tri = a.scene.triangles + 3ull * (g.triangleOffset + g0.z);
+        const DevVertex vA = load_vertex(a.scene.vertices + g.vertexOffset + tri[0]);
+        const DevVertex vB = load_vertex(a.scene.vertices + g.vertexOffset + tri[1]);
+        const DevVertex vC = load_vertex(a.scene.vertices + g.vertexOffset + tri[2]);
+        const float bcA = 1 - (bcB + bcC);
+        const f3 pAo(vA.px, vA.py, vA.pz), pBo(vB.px, vB.py, vB.pz), pCo(vC.px, vC.py, vC.pz);
+        const m34 xfm = load_m34(inst->transform);
+        const m33 nrm = load_m33_rows(inst->normalMatrix);
+        f3 pos = xfm_point(xfm, bcA * pAo + bcB * pBo + bcC * pCo);
+        f3 ng = unit(mul(nrm, cross(pBo - pAo, pCo - pAo)));
+        const f3 nsObj = bcA * f3(vA.nx, vA.ny, vA.nz) + bcB * f3(vB.nx, vB.ny, vB.nz) + bcC * f3(vC.nx, vC.ny, vC.nz);
+        const f3 tcObj = bcA * f3(vA.tx, vA.ty, vA.tz) + bcB * f3(vB.tx, vB.ty, vB.tz) + bcC * f3(vC.tx, vC.ty, vC.tz);
+        f3 ns = unit(mul(nrm, nsObj));
+        f3 tc0 = xfm_vector(xfm, tcObj);
+        tc0 = unit(tc0 - dot(ns, tc0) * ns);
+        if (!all_finite(ns)) { ng = f3(0, 0, 1); ns = f3(0, 0, 1); tc0 = f3(1, 0, 0); }
+        if (!all_finite(tc0)) { f3 bt; make_coordinate_system(ns, tc0, bt); }
+        const Camera cam = load_camera(a.f.camera);
+        f3 vOut = cam.pos - pos;
+        vOut = vOut / sqrtf(len2(vOut));
+        const float frontHit = dot(vOut, ng) >= 0.0f ? 1.0f : -1.0f;
+        pos = offset_ray_origin(pos, frontHit * ng);
+        Bsdf bsdf; bsdf.setup(a.scene.materials[g.materialSlot]);
+        nrc_store_query(a.nrc.inferenceRadianceQueryBuffer, p, nrc_make_query(a, pos, ns, vOut, bsdf));
+    }
+    static_cast<float4*>(a.nrc.inferenceTerminalInfoBuffer)[p] = make_float4(1.0f, 1.0f, 1.0f, bits2f(nrc_terminal_bits(surface, 1, false, false)));
+}
+
 // ---------------------------------------------------------------- host sequencing
 void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height,
                       uint32_t maxPathLength, uint32_t rowBegin, uint32_t rowEnd) {
@@ -557,12 +1120,28 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     const RestirParams& rp = ctx.restir;
     if (!rp.valid) throw HipError("gfx_pt_launch: gfx_restir_set_params has not been called");
     const bool regirPass = pass >= GFX_PT_REGIR_BUILD_CELL_RESERVOIRS && pass <= GFX_PT_REGIR_UPDATE_LAST_ACCESS;
-    if (!regirPass && pass != GFX_PT_PATH_TRACE_BASELINE) throw HipError("gfx_pt_launch: unknown pass");
+    const bool nrcPass = pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_VISUALIZE_PREDICTION;
+    if (!regirPass && !nrcPass && pass != GFX_PT_PATH_TRACE_BASELINE) throw HipError("gfx_pt_launch: unknown pass");
     if (regirPass && !ctx.regirValid) throw HipError("gfx_pt_launch: gfx_regir_set_params has not been called");
+    if (nrcPass && !ctx.nrcRenderValid) throw HipError("gfx_pt_launch: gfx_nrc_set_render_params has not been called");
     PtArgs a;
     std::memset(&a, 0, sizeof(a));
     a.scene = ctx.devScene();
     a.s = rp.s; a.f = rp.f;
+    if (nrcPass) {
+        a.nrc = ctx.nrcRender;
+        const size_t np = static_cast<size_t>(rp.s.imageSizeX) * rp.s.imageSizeY;
+        auto simple = [&](const char* name, void (*kernel)(PtArgs), size_t threads) {
+            ScopedKernelTimer timer(ctx, stream, name);
+            hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>((threads + kPtBlock - 1) / kPtBlock)), dim3(kPtBlock), 0, stream, a);
+            GFX_HIP(hipGetLastError());
+        };
+        if (pass == GFX_PT_NRC_PREPROCESS) { simple("nrc_preprocess", k_nrc_preprocess, a.nrc.maxNumTrainingSuffixes); return; }
+        if (pass == GFX_PT_NRC_ACCUMULATE) { simple("nrc_accumulate", k_nrc_accumulate, np); return; }
+        if (pass == GFX_PT_NRC_PROPAGATE) { simple("nrc_propagate", k_nrc_propagate, a.nrc.maxNumTrainingSuffixes); return; }
+        if (pass == GFX_PT_NRC_SHUFFLE) { simple("nrc_shuffle", k_nrc_shuffle, kNumTrainingDataPerFrame); return; }
+        if (pass == GFX_PT_NRC_VISUALIZE_PREDICTION) { simple("nrc_visualize", k_nrc_visualize, np); return; }
+    }
     if (regirPass) a.g = ctx.regir;
     if (pass == GFX_PT_REGIR_BUILD_CELL_RESERVOIRS || pass == GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL) {
         const size_t numLightSlots = static_cast<size_t>(a.g.gridDimension[0]) * a.g.gridDimension[1] * a.g.gridDimension[2] * kNumLightSlotsPerCell;
@@ -581,6 +1160,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         return;
     }
     const bool regir = pass == GFX_PT_PATH_TRACE_REGIR;
+    const bool nrc = pass == GFX_PT_PATH_TRACE_NRC;
     if (static_cast<uint32_t>(rp.s.imageSizeX) != width || static_cast<uint32_t>(rp.s.imageSizeY) != height)
         throw HipError("gfx_pt_launch: launch size differs from imageSize in the static parameters");
     const uint64_t h = rp.f.travHandle;
@@ -596,6 +1176,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     ctx.ptPending.reserve(16 * bandPixels);
     ctx.ptExtOrg.reserve(2 * 16 * bandPixels); ctx.ptExtDir.reserve(2 * 16 * bandPixels); ctx.ptExtOwner.reserve(2 * 4 * bandPixels);
     ctx.ptState.reserve(32 * numPixels);
+    if (nrc) { ctx.nrcState.reserve(32 * numPixels); ctx.neeTrainIdx.reserve(4 * numPixels); }
     ctx.smallCounters.reserve(256);
     uint32_t* counters = ctx.smallCounters.as<uint32_t>() + 8;   // [0] nee, [1] ext ping, [2] ext pong
     GFX_HIP(hipMemsetAsync(counters, 0, 3 * sizeof(uint32_t), stream));
@@ -608,6 +1189,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     a.hits = ctx.rayHits.as<gfx_hit>();
     a.tris = ctx.accels[h - 1]->tris.as<Bvh8Tri>();
     a.state = ctx.ptState.as<float4>();
+    if (nrc) { a.nrcState = ctx.nrcState.as<float4>(); a.neeTrainIdx = ctx.neeTrainIdx.as<uint32_t>(); }
     float4* extOrg[2] = { ctx.ptExtOrg.as<float4>(), ctx.ptExtOrg.as<float4>() + bandPixels };
     float4* extDir[2] = { ctx.ptExtDir.as<float4>(), ctx.ptExtDir.as<float4>() + bandPixels };
     uint32_t* extOwner[2] = { ctx.ptExtOwner.as<uint32_t>(), ctx.ptExtOwner.as<uint32_t>() + bandPixels };
@@ -632,25 +1214,40 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     set_queues(1, cur);
     a.pathLength = 1; a.maxLengthTerminate = 0;
     a.nextMaxLengthTerminate = 2 >= maxPathLength ? 1u : 0u;
-    launch("pt_first", regir ? k_pt_first<true> : k_pt_first<false>);
+    if (nrc) launch("nrc_pt_first", k_nrc_pt_first);
+    else launch("pt_first", regir ? k_pt_first<true> : k_pt_first<false>);
     // while (true) { ++pathLength; trace; }.  Baseline: at least one extension even when maxPathLength < 2,
     // the terminal vertex (implicit light only) emits no NEE ray.  ReGIR: the loop head breaks before the
-    // trace at the length limit, so the last vertex's NEE ray is resolved after the loop.
+    // trace at the length limit, so the last vertex's NEE ray is resolved after the loop.  NRC:
+    // maxPathLength == 0 means unlimited bounces (neural_radiance_caching_main.cpp:2246) -- the live
+    // path count is read back every fourth bounce to stop (the 6-bit pathLength field caps it at 63).
     for (uint32_t pathLength = 2;; ++pathLength) {
         trace(GFX_TRACE_ANY, a.neeOrg, a.neeDir, a.neeCount, ctx.rayOut.p);
         launch("pt_apply_nee", k_pt_apply_nee);
         if (regir && pathLength >= maxPathLength) break;
+        // NRC: training paths skip Russian roulette (and with it the length test) at pathLength 2 (:459-462),
+        // so the last vertex that can exist is max(maxPathLength, 3)
+        if (nrc && maxPathLength > 0 && pathLength > (maxPathLength > 3 ? maxPathLength : 3)) break;
+        if (nrc && pathLength >= 63) break;
+        if (nrc && maxPathLength == 0 && pathLength > 2 && (pathLength & 3u) == 2u) {
+            uint32_t live = 0;
+            GFX_HIP(hipMemcpyAsync(&live, counters + 1 + cur, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            GFX_HIP(hipStreamSynchronize(stream));
+            if (live == 0) break;
+        }
         trace(GFX_TRACE_CLOSEST, extOrg[cur], extDir[cur], counters + 1 + cur, ctx.rayHits.p);
         GFX_HIP(hipMemsetAsync(counters, 0, sizeof(uint32_t), stream));
         GFX_HIP(hipMemsetAsync(counters + 1 + (cur ^ 1), 0, sizeof(uint32_t), stream));
         set_queues(cur, cur ^ 1);
         a.pathLength = pathLength;
-        a.maxLengthTerminate = pathLength >= maxPathLength ? 1u : 0u;
+        a.maxLengthTerminate = (pathLength >= maxPathLength && (!nrc || maxPathLength > 0)) ? 1u : 0u;
         a.nextMaxLengthTerminate = pathLength + 1 >= maxPathLength ? 1u : 0u;
-        launch("pt_bounce", regir ? k_pt_bounce<true> : k_pt_bounce<false>);
+        if (nrc) launch("nrc_pt_bounce", k_nrc_pt_bounce);
+        else launch("pt_bounce", regir ? k_pt_bounce<true> : k_pt_bounce<false>);
         cur ^= 1;
-        if (!regir && a.maxLengthTerminate) break;
+        if (!regir && !nrc && a.maxLengthTerminate) break;
     }
+    if (nrc) { launch("nrc_pt_finish", k_nrc_pt_finish); return; }
     launch("pt_finish", k_pt_finish);
 }
 

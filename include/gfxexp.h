@@ -264,7 +264,15 @@ enum gfx_pt_pass {
     GFX_PT_REGIR_BUILD_CELL_RESERVOIRS = 2,           /* regir/gpu_kernels/build_cell_reservoirs.cu:221-223 */
     GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL = 3,  /* :225-227 */
     GFX_PT_PATH_TRACE_REGIR = 4,                      /* regir/gpu_kernels/optix_pathtracing_kernels.cu:425-433 */
-    GFX_PT_REGIR_UPDATE_LAST_ACCESS = 5               /* build_cell_reservoirs.cu:229-243 */
+    GFX_PT_REGIR_UPDATE_LAST_ACCESS = 5,              /* build_cell_reservoirs.cu:229-243 */
+    /* Neural radiance caching (neural_radiance_caching_main.cpp:2270-2370); need gfx_nrc_set_render_params.
+     * The network calls between them are gfx_nrc_infer / gfx_nrc_train. */
+    GFX_PT_NRC_PREPROCESS = 6,                        /* nrc_setup_kernels.cu:6-49 */
+    GFX_PT_PATH_TRACE_NRC = 7,                        /* neural_radiance_caching/gpu_kernels/optix_pathtracing_kernels.cu:693-703 */
+    GFX_PT_NRC_ACCUMULATE = 8,                        /* nrc_setup_kernels.cu:51-93 */
+    GFX_PT_NRC_PROPAGATE = 9,                         /* :95-137 */
+    GFX_PT_NRC_SHUFFLE = 10,                          /* :139-216 */
+    GFX_PT_NRC_VISUALIZE_PREDICTION = 11              /* optix_pathtracing_kernels.cu:705-778 */
 };
 
 /* The ReGIR members of regir/regir_shared.h:200-263 (grid of cells x 512 light slots).  Light-slot
@@ -290,6 +298,40 @@ typedef struct gfx_regir_params {
 int gfx_regir_set_params(gfx_ctx* ctx, const gfx_regir_params* p);
 int gfx_pt_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height,
                   uint32_t maxPathLength, uint32_t rowBegin, uint32_t rowEnd);
+
+/* NRC render-side state: the NRC members of neural_radiance_caching_shared.h:229-265 (+ radianceScale of
+ * the per-frame block, :277, and the three arguments of preprocessNRC, nrc_setup_kernels.cu:6-9).
+ *   RadianceQuery              14 floats = one column of the network input (:118-137)
+ *   TerminalInfo               float3 alpha + u32 {hasQuery:1, pathLength:8, isTrainingPixel:1, isUnbiasedTile:1}
+ *   TrainingVertexInfo         float3 localThroughput + u32 {prevVertexDataIndex:23, pathLength:8}
+ *   TrainingSuffixTerminalInfo u32 {prevVertexDataIndex:23, hasQuery:1, pathLength:8}
+ *   dataShuffler               u32 LCG state; entry i = state after i + 1 steps from 471313181
+ *                              (neural_radiance_caching_main.cpp:1186-1194)
+ * numPixels = W*H; maxNumTrainingSuffixes = W*H/16 (:1150); train buffers hold 131072 records (:9). */
+typedef struct gfx_nrc_params {
+    float sceneAabbMin[3], sceneAabbMax[3];
+    uint32_t maxNumTrainingSuffixes;
+    void* numTrainingData[2];            /* uint32_t */
+    void* tileSize[2];                   /* uint32_t[2], initialised to 8 x 8 */
+    void* targetMinMax[2];               /* int32_t[6] ordered-int min rgb, max rgb */
+    void* targetAvg[2];                  /* float[3] */
+    void* offsetToSelectUnbiasedTile;    /* uint32_t */
+    void* offsetToSelectTrainingPath;    /* uint32_t */
+    void* inferenceRadianceQueryBuffer;  /* 56 B x (numPixels + maxNumTrainingSuffixes, rounded up to 256) */
+    void* inferenceTerminalInfoBuffer;   /* 16 B x numPixels */
+    void* inferredRadianceBuffer;        /* float3 x (numPixels + maxNumTrainingSuffixes, rounded up to 256) */
+    void* perFrameContributionBuffer;    /* float3 x numPixels */
+    void* trainRadianceQueryBuffer[2];   /* 56 B x 131072 */
+    void* trainTargetBuffer[2];          /* float3 x 131072 */
+    void* trainVertexInfoBuffer;         /* 16 B x 131072 */
+    void* trainSuffixTerminalInfoBuffer; /* uint32_t x maxNumTrainingSuffixes */
+    void* dataShufflerBuffer;            /* uint32_t x 65536 */
+    float radianceScale;
+    uint32_t preprocessOffsetToSelectUnbiasedTile;   /* perFrameRng() draws, :2276-2277 (mt19937(72139121)) */
+    uint32_t preprocessOffsetToSelectTrainingPath;
+    uint32_t isNewSequence;
+} gfx_nrc_params;
+int gfx_nrc_set_render_params(gfx_ctx* ctx, const gfx_nrc_params* p);
 
 /* ---------------------------------------------------------------- neural radiance cache -------- */
 

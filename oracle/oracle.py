@@ -73,6 +73,19 @@ class GfxRegirParams(C.Structure):
                 ("log2NumCandidatesPerCell", C.c_uint32), ("enableCellRandomization", C.c_uint32)]
 
 
+class GfxNrcParams(C.Structure):
+    _fields_ = [("sceneAabbMin", C.c_float * 3), ("sceneAabbMax", C.c_float * 3), ("maxNumTrainingSuffixes", C.c_uint32),
+                ("numTrainingData", C.c_void_p * 2), ("tileSize", C.c_void_p * 2), ("targetMinMax", C.c_void_p * 2),
+                ("targetAvg", C.c_void_p * 2), ("offsetToSelectUnbiasedTile", C.c_void_p),
+                ("offsetToSelectTrainingPath", C.c_void_p), ("inferenceRadianceQueryBuffer", C.c_void_p),
+                ("inferenceTerminalInfoBuffer", C.c_void_p), ("inferredRadianceBuffer", C.c_void_p),
+                ("perFrameContributionBuffer", C.c_void_p), ("trainRadianceQueryBuffer", C.c_void_p * 2),
+                ("trainTargetBuffer", C.c_void_p * 2), ("trainVertexInfoBuffer", C.c_void_p),
+                ("trainSuffixTerminalInfoBuffer", C.c_void_p), ("dataShufflerBuffer", C.c_void_p),
+                ("radianceScale", C.c_float), ("preprocessOffsetToSelectUnbiasedTile", C.c_uint32),
+                ("preprocessOffsetToSelectTrainingPath", C.c_uint32), ("isNewSequence", C.c_uint32)]
+
+
 GFX_HIT_DTYPE = np.dtype([("dist", "<f4"), ("bcB", "<f4"), ("bcC", "<f4"), ("triIndex", "<u4")])
 GFX_TRI_IDS_DTYPE = np.dtype([("instSlot", "<u4"), ("geomInstSlot", "<u4"), ("primIndex", "<u4")])
 GFX_VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("texCoord0Dir", "<f4", 3),
@@ -200,6 +213,9 @@ class OracleScene:
         self.L.orc_restir_launch(self.h, C.byref(static_params), C.byref(frame_params),
                                  C.c_uint32(cur_res_index), C.c_uint32(base_index), C.c_int(pass_id),
                                  C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1))
+
+    def nrc_set_render_params(self, params):
+        self.L.orc_nrc_set_render_params(self.h, C.byref(params))
 
     def regir_set_params(self, params):
         self.L.orc_regir_set_params(self.h, C.byref(params))

@@ -12,6 +12,7 @@
 #include "orc_restir.h"
 #include "orc_pathtrace.h"
 #include "orc_restir_rearch.h"
+#include "orc_nrc.h"
 
 using namespace orc;
 
@@ -324,6 +325,10 @@ static gfx_regir_params g_regirParams;
 static bool g_regirValid = false;
 int orc_regir_set_params(orc_scene*, const gfx_regir_params* p) { g_regirParams = *p; g_regirValid = true; return 0; }
 
+static gfx_nrc_params g_nrcParams;
+static bool g_nrcValid = false;
+int orc_nrc_set_render_params(orc_scene*, const gfx_nrc_params* p) { g_nrcParams = *p; g_nrcValid = true; return 0; }
+
 int orc_pt_launch(orc_scene* s, const gfx_restir_static_params* sp, const gfx_restir_frame_params* fp,
                   int pass, uint32_t maxPathLength, int x0, int y0, int x1, int y1) {
     orc_env_set(s, sp);
@@ -360,6 +365,31 @@ int orc_pt_launch(orc_scene* s, const gfx_restir_static_params* sp, const gfx_re
     p.scene = &s->scene; p.accel = &s->accel; p.s = sp; p.f = fp;
     p.camera = toCamera(fp->camera);
     p.maxPathLength = maxPathLength & 15u; // 4-bit bitfield, path_tracing_shared.h:165
+    if (pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_VISUALIZE_PREDICTION) {
+        if (!g_nrcValid) return 1;
+        NrcState ns; ns.n = &g_nrcParams;
+        const int W = sp->imageSizeX, H = sp->imageSizeY;
+        switch (pass) {
+        case GFX_PT_NRC_PREPROCESS: preprocessNRC(ns, *fp); break;
+        case GFX_PT_PATH_TRACE_NRC: {
+            // one thread, row-major: the training-record order (an atomicAdd race in the reference) is defined
+            uint32_t* counter = ns.numTrainingData(fp->bufferIndex);
+            for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) nrcPathTracePixel(p, ns, counter, x, y);
+            break;
+        }
+        case GFX_PT_NRC_ACCUMULATE:
+            for (size_t i = 0; i < static_cast<size_t>(W) * H; ++i) accumulateInferredRadiancePixel(ns, *sp, *fp, i);
+            break;
+        case GFX_PT_NRC_PROPAGATE:
+            for (uint32_t i = 0; i < g_nrcParams.maxNumTrainingSuffixes; ++i) propagateRadianceSuffix(ns, *sp, i);
+            break;
+        case GFX_PT_NRC_SHUFFLE: shuffleTrainingData(ns, *fp); break;
+        case GFX_PT_NRC_VISUALIZE_PREDICTION:
+            for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) visualizePredictionPixel(p, ns, x, y);
+            break;
+        }
+        return 0;
+    }
     if (pass == GFX_PT_PATH_TRACE_REGIR) {
         if (!g_regirValid) return 1;
         p.regir = &rs;

@@ -75,6 +75,21 @@ static inline float gm_sin(float x) { float s, c; gm_sincos(x, &s, &c); return s
 static inline float gm_cos(float x) { float s, c; gm_sincos(x, &s, &c); return c; }
 static inline float gm_tan(float x) { float s, c; gm_sincos(x, &s, &c); return s / c; }
 
+// exp(x) for |x| < 80: n = round(x / ln2), Cody-Waite r = x - n ln2 (hi + lo), degree-6 kernel, 2^n by bits
+static inline float gm_exp(float x) {
+    const float n = std::floor(x * 1.44269504088896341f + 0.5f);
+    float r = std::fma(n, -0.693359375f, x);
+    r = std::fma(n, 2.12194440e-4f, r);
+    float p = std::fma(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = std::fma(p, r, 8.3334519073e-3f);
+    p = std::fma(p, r, 4.1665795894e-2f);
+    p = std::fma(p, r, 1.6666665459e-1f);
+    p = std::fma(p, r, 5.0000001201e-1f);
+    const float y = std::fma(p, r * r, r) + 1.0f;
+    const int32_t e = static_cast<int32_t>(n);
+    return y * bits2f(static_cast<uint32_t>(e + 127) << 23);
+}
+
 static inline float gm_asin_kernel(float x) { // |x| <= 0.5
     const float z = x * x;
     float p = std::fma(4.2163199048e-2f, z, 2.4181311049e-2f);

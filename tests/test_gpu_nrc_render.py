@@ -1,0 +1,143 @@
+"""-m gpu: the NRC render side (tile/training-path selection, NRC path tracer, radiance queries,
+terminal infos, training chains, accumulate / propagate / shuffle) through the C ABI against the CPU
+oracle.  Per-pixel buffers are bit-exact; training records are compared in a canonical form (per
+tile, along the chain) because the reference allocates their indices with an unordered atomicAdd."""
+import numpy as np
+import pytest
+
+from gfxexp_amd import api
+from oracle import oracle as O
+from tests import util
+
+
+def _setup(hs, width, height, env=None, radiance_scale=1.0):
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    ctx.lights_build_static()
+    osc = util.feed_oracle(hs, threads=1)
+    pb_gpu_init, pb_cpu = util.PixelBuffers(width, height), util.PixelBuffers(width, height)
+    if env is not None:
+        pb_gpu_init.set_env(*env); pb_cpu.set_env(*env)
+    dev = util.DeviceBuffers(pb_gpu_init)
+    nb_gpu, nb_cpu = util.NrcBuffers(width, height, hs.bounds(), radiance_scale), util.NrcBuffers(width, height, hs.bounds(), radiance_scale)
+    nb_gpu.to_device()
+    return ctx, accel, osc, dev, pb_cpu, nb_gpu, nb_cpu
+
+
+def _compare_exact(diffs, tag, got, want, keys):
+    for k in keys:
+        a = np.ascontiguousarray(got[k]).view(np.uint8).reshape(-1)
+        b = np.ascontiguousarray(want[k]).view(np.uint8).reshape(-1)
+        if not np.array_equal(a, b):
+            item = want[k].dtype.itemsize
+            diffs.append(f"{tag}: {k}: {len(np.unique(np.nonzero(a != b)[0] // item))} of {want[k].size} elements differ")
+
+
+def run_nrc_both(hs, width, height, frames, max_len, env=None, camera=None, radiance_scale=1.0):
+    import torch
+    ctx, accel, osc, dev, pb_cpu, nb_gpu, nb_cpu = _setup(hs, width, height, env, radiance_scale)
+    cam = camera if camera is not None else api.make_camera(width, height, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+    ocam = util.copy_struct(O.GfxCamera, cam)
+    s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(7)
+    offsets = np.random.default_rng(72139121)
+    diffs = []
+    n = width * height
+    for frame in range(frames):
+        kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=frame,
+                  enableEnvLight=int(env is not None))
+        f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, width, height, cam, travHandle=accel, **kw)
+        f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, width, height, ocam, travHandle=0, **kw)
+        ou, ot = int(offsets.integers(0, 1 << 31)), int(offsets.integers(0, 1 << 31))
+        ctx.lights_build_instances(stream)
+        ctx.restir_set_params(s_gpu, f_gpu, 0, 0, stream)
+        ctx.nrc_set_render_params(nb_gpu.device_params(ou, ot, frame == 0))
+        osc.nrc_set_render_params(nb_cpu.host_params(ou, ot, frame == 0))
+        b = frame % 2
+        for pass_id in (api.PT_SETUP_GBUFFERS, api.PT_NRC_PREPROCESS, api.PT_PATH_TRACE_NRC):
+            ctx.pt_launch(pass_id, width, height, max_len, 0, 0, stream)
+            osc.pt_launch(s_cpu, f_cpu, pass_id, max_len)
+        got, want = dev.download(), pb_cpu.arrays()
+        got.update(nb_gpu.download()); want.update(nb_cpu.arrays())
+        tag = f"frame {frame} path trace"
+        _compare_exact(diffs, tag, got, want, ["rng", f"gb0_{b}", "nrc_contribution", "nrc_terminal", f"nrc_num_{b}", f"nrc_tile_{b}",
+                                               "nrc_off_unbiased", "nrc_off_training"])
+        # inference queries: pixel entries of paths that ended in the cache, suffix entries with a query
+        hq = (want["nrc_terminal"][:, 3].view(np.uint32) & 1) == 1
+        if not np.array_equal(got["nrc_queries"][:n][hq].view(np.uint32), want["nrc_queries"][:n][hq].view(np.uint32)):
+            diffs.append(f"{tag}: rendering-path queries differ")
+        sq = ((want["nrc_suffix"] >> 23) & 1) == 1
+        if not np.array_equal((got["nrc_suffix"] >> 23), (want["nrc_suffix"] >> 23)):
+            diffs.append(f"{tag}: suffix terminal flags / path lengths differ")
+        if not np.array_equal(got["nrc_queries"][n:n + len(sq)][sq].view(np.uint32), want["nrc_queries"][n:n + len(sq)][sq].view(np.uint32)):
+            diffs.append(f"{tag}: suffix queries differ")
+        cg, cw = util.nrc_chains(got), util.nrc_chains(want)
+        if cg != cw:
+            bad = [t for t in cw if cg.get(t) != cw[t]]
+            diffs.append(f"{tag}: training chains differ in {len(bad)} of {len(cw)} tiles (gpu has {len(cg)})")
+        assert int(want[f"nrc_num_{b}"][0]) > 0
+
+        # identical predictions and identical record order on both sides for the network-dependent kernels
+        pred = (rng.random(nb_cpu.a["nrc_inferred"].shape).astype(np.float32) - 0.1) * 2
+        nb_cpu.a["nrc_inferred"][:] = pred
+        nb_gpu.upload("nrc_inferred", pred)
+        for k in ("nrc_trainq_0", "nrc_traint_0", "nrc_vertex", "nrc_suffix"):
+            nb_gpu.upload(k, nb_cpu.a[k])
+        for tag, pass_id, keys in (("accumulate", api.PT_NRC_ACCUMULATE, ["beauty"]),
+                                   ("propagate", api.PT_NRC_PROPAGATE, ["nrc_traint_0"]),
+                                   ("shuffle", api.PT_NRC_SHUFFLE, ["nrc_trainq_1", "nrc_traint_1", "nrc_shuffler", f"nrc_minmax_{b}"])):
+            ctx.pt_launch(pass_id, width, height, max_len, 0, 0, stream)
+            osc.pt_launch(s_cpu, f_cpu, pass_id, max_len)
+            got, want = dev.download(), pb_cpu.arrays()
+            got.update(nb_gpu.download()); want.update(nb_cpu.arrays())
+            _compare_exact(diffs, f"frame {frame} {tag}", got, want, keys)
+        if not np.allclose(got[f"nrc_avg_{b}"], want[f"nrc_avg_{b}"], rtol=2e-3, atol=1e-6):
+            diffs.append(f"frame {frame}: target average differs: {got[f'nrc_avg_{b}']} vs {want[f'nrc_avg_{b}']}")
+    return diffs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_len", [5, 2])
+def test_nrc_render_bunny(built_lib, max_len):
+    diffs = run_nrc_both(util.bunny_scene(), 128, 96, 2, max_len, radiance_scale=2.5)
+    assert not diffs, "\n".join(diffs[:12])
+
+
+@pytest.mark.gpu
+def test_nrc_render_unlimited_bounces(built_lib):
+    diffs = run_nrc_both(util.bunny_scene(), 96, 64, 2, 0)
+    assert not diffs, "\n".join(diffs[:12])
+
+
+@pytest.mark.gpu
+def test_nrc_render_street_with_env_light(built_lib):
+    w, h = 64, 32
+    sky = api.env_make_sky(w, h)
+    cam = api.make_camera(96, 64, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
+    diffs = run_nrc_both(util.small_street(), 96, 64, 2, 5, env=(sky, w, h), camera=cam)
+    assert not diffs, "\n".join(diffs[:12])
+
+
+@pytest.mark.gpu
+def test_nrc_visualize_prediction_queries(built_lib):
+    import torch
+    hs = util.bunny_scene()
+    w, h = 96, 64
+    ctx, accel, osc, dev, pb_cpu, nb_gpu, nb_cpu = _setup(hs, w, h)
+    cam = api.make_camera(w, h, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+    s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
+    f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, w, h, cam, travHandle=accel, resetFlowBuffer=1)
+    f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, w, h, util.copy_struct(O.GfxCamera, cam), resetFlowBuffer=1)
+    ctx.lights_build_instances(0)
+    ctx.restir_set_params(s_gpu, f_gpu, 0, 0, 0)
+    ctx.nrc_set_render_params(nb_gpu.device_params(0, 0, True))
+    osc.nrc_set_render_params(nb_cpu.host_params(0, 0, True))
+    for pass_id in (api.PT_SETUP_GBUFFERS, api.PT_NRC_VISUALIZE_PREDICTION):
+        ctx.pt_launch(pass_id, w, h, 5)
+        osc.pt_launch(s_cpu, f_cpu, pass_id, 5)
+    got, want = nb_gpu.download(), nb_cpu.arrays()
+    util.assert_same_bits("terminal infos", got["nrc_terminal"], want["nrc_terminal"])
+    hq = (want["nrc_terminal"][:, 3].view(np.uint32) & 1) == 1
+    util.assert_same_bits("queries", got["nrc_queries"][:w * h][hq], want["nrc_queries"][:w * h][hq])

@@ -1,0 +1,128 @@
+"""CPU checks of the NRC render-side restatement (oracle/orc_nrc.h): tile bookkeeping, training
+chains, target propagation against the recursive definition, shuffling."""
+import numpy as np
+
+from gfxexp_amd import api
+from oracle import oracle as O
+from tests import util
+
+
+def _camera(width, height):
+    return api.make_camera(width, height, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+
+
+def run_frame(osc, hs, pb, nb, width, height, frame, max_len=5, off=(3, 5), predictions=None):
+    s = pb.host_static_params()
+    cam = util.copy_struct(O.GfxCamera, _camera(width, height))
+    f = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, width, height, cam, frameIndex=frame, bufferIndex=frame % 2,
+                          resetFlowBuffer=int(frame == 0), numAccumFrames=0)
+    osc.nrc_set_render_params(nb.host_params(off[0], off[1], frame == 0))
+    for pass_id in (api.PT_SETUP_GBUFFERS, api.PT_NRC_PREPROCESS, api.PT_PATH_TRACE_NRC):
+        osc.pt_launch(s, f, pass_id, max_len)
+    if predictions is not None:
+        nb.a["nrc_inferred"][:] = predictions
+    return s, f
+
+
+def test_tiles_training_paths_and_chain_structure():
+    hs = util.bunny_scene()
+    osc = util.feed_oracle(hs, threads=1)
+    w, h = 64, 48
+    pb, nb = util.PixelBuffers(w, h), util.NrcBuffers(w, h, hs.bounds())
+    run_frame(osc, hs, pb, nb, w, h, 0)
+    a = nb.arrays()
+    assert list(a["nrc_tile_0"]) == [8, 8] and a["nrc_off_unbiased"][0] == 3 and a["nrc_off_training"][0] == 5
+    term = a["nrc_terminal"][:, 3].view(np.uint32)
+    training = (term >> 9) & 1
+    assert training.sum() == (w // 8) * (h // 8)                # one training path per 8x8 tile
+    unbiased_tiles = ((term >> 10) & 1).reshape(h, w)[::8, ::8]
+    assert unbiased_tiles.sum() == (w // 8) * (h // 8) // 16 or unbiased_tiles.sum() >= 1
+    n = int(a["nrc_num_0"][0])
+    assert 0 < n < 1 << 17
+    chains = util.nrc_chains(a)
+    assert len(chains) > 0
+    total = sum(len(c[1]) for c in chains.values())
+    assert total == n                                           # every record belongs to exactly one chain
+    for tile, (hdr, chain) in chains.items():
+        lengths = [c[3] for c in chain]
+        assert lengths == sorted(lengths, reverse=True) and lengths[-1] == 1     # path length decreases to the first vertex
+    # rendering paths that ended in the cache carry a query and a non-negative throughput
+    has_query = (term & 1) == 1
+    assert has_query.any()
+    assert np.all(np.isfinite(a["nrc_queries"][:w * h][has_query]))
+    assert np.all(a["nrc_terminal"][has_query, :3] >= 0)
+    q = a["nrc_queries"][:w * h][has_query]
+    assert q[:, :3].min() >= -1e-3 and q[:, :3].max() <= 1 + 1e-3   # positions normalised by the scene box
+    assert np.all((q[:, 7] >= 0) & (q[:, 7] < 1))                   # 1 - exp(-roughness)
+
+
+def test_propagation_equals_the_recursive_definition():
+    hs = util.bunny_scene()
+    osc = util.feed_oracle(hs, threads=1)
+    w, h = 64, 48
+    pb, nb = util.PixelBuffers(w, h), util.NrcBuffers(w, h, hs.bounds(), radiance_scale=2.0)
+    rng = np.random.default_rng(2)
+    pred = rng.random(nb.a["nrc_inferred"].shape).astype(np.float32) - 0.2      # some negative predictions
+    s, f = run_frame(osc, hs, pb, nb, w, h, 0, predictions=pred)
+    a = nb.arrays()
+    before_t, vinfo, trainq = a["nrc_traint_0"].copy(), a["nrc_vertex"].copy(), a["nrc_trainq_0"].copy()
+    suffix = a["nrc_suffix"].copy()
+    osc.pt_launch(s, f, api.PT_NRC_PROPAGATE, 5)
+    after_t = a["nrc_traint_0"]
+    checked = 0
+    for tile in np.nonzero((suffix & 0x7FFFFF) != 0x7FFFFF)[0]:
+        bits = int(suffix[tile])
+        contribution = np.zeros(3, np.float32)
+        if (bits >> 23) & 1:
+            e = w * h + tile
+            q = a["nrc_queries"][e]
+            contribution = np.maximum(pred[e], 0) / np.float32(2.0) * (q[8:11] + q[11:14])
+        last = bits & 0x7FFFFF
+        while last != 0x7FFFFF:
+            vb = int(vinfo[last, 3].view(np.uint32))
+            contribution = before_t[last] + vinfo[last, :3] * contribution
+            ref = trainq[last, 8:11] + trainq[last, 11:14]
+            want = np.where(ref != 0, contribution / np.where(ref != 0, ref, 1), 0)
+            assert np.allclose(after_t[last], want, rtol=2e-5, atol=1e-7)
+            last = vb & 0x7FFFFF
+            checked += 1
+    assert checked == int(a["nrc_num_0"][0])
+    # accumulate: beauty = direct + alpha * scaled prediction
+    osc.pt_launch(s, f, api.PT_NRC_ACCUMULATE, 5)
+    term = a["nrc_terminal"]
+    hq = (term[:, 3].view(np.uint32) & 1) == 1
+    q = a["nrc_queries"][:w * h]
+    rad = np.maximum(pred[:w * h], 0) / np.float32(2.0) * (q[:, 8:11] + q[:, 11:14])
+    want = a["nrc_contribution"] + np.where(hq[:, None], term[:, :3] * rad, 0)
+    assert np.allclose(pb.beauty[:, :3], want, rtol=2e-5, atol=1e-7)
+
+
+def test_shuffle_is_a_scatter_of_every_source_record_and_tile_size_adapts():
+    hs = util.bunny_scene()
+    osc = util.feed_oracle(hs, threads=1)
+    w, h = 64, 48
+    pb, nb = util.PixelBuffers(w, h), util.NrcBuffers(w, h, hs.bounds(), radiance_scale=3.0)
+    s, f = run_frame(osc, hs, pb, nb, w, h, 0)
+    a = nb.arrays()
+    n = int(a["nrc_num_0"][0])
+    osc.pt_launch(s, f, api.PT_NRC_PROPAGATE, 5)
+    src_t = a["nrc_traint_0"][:n].copy()
+    osc.pt_launch(s, f, api.PT_NRC_SHUFFLE, 5)
+    sh = util.lcg_shufflers()
+    nxt = (sh.astype(np.uint64) * 1103515245 + 12345) % (1 << 31)
+    assert np.array_equal(a["nrc_shuffler"], nxt.astype(np.uint32))
+    dst = (nxt % (1 << 16)).astype(np.int64)
+    # the LAST writer of every destination wins (thread order = index order in the restatement)
+    winners = {int(d): i for i, d in enumerate(dst)}
+    some = list(winners.items())[:2000]
+    for d, i in some:
+        want = np.minimum(src_t[i % n] * np.float32(3.0), np.float32(1e6))
+        assert np.array_equal(a["nrc_traint_1"][d], want)
+        assert np.array_equal(a["nrc_trainq_1"][d], a["nrc_trainq_0"][i % n])
+    lo = a["nrc_minmax_0"][:3]; hi = a["nrc_minmax_0"][3:]
+    assert np.all(lo <= hi)
+    assert np.allclose(a["nrc_avg_0"], np.stack([src_t[i % n] for i in range(1 << 16)]).mean(axis=0), rtol=1e-3, atol=1e-6)
+    # next frame: tile size follows sqrt(n / 65536) of the previous frame, clamped to [4, 128]
+    run_frame(osc, hs, pb, nb, w, h, 1)
+    r = np.sqrt(np.float32(n) / np.float32(65536))
+    assert list(a["nrc_tile_1"]) == [max(4, min(128, int(np.float32(8) * r)))] * 2

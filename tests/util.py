@@ -339,3 +339,107 @@ class RegirBuffers:
         import torch
         torch.cuda.synchronize()
         return {k: self.t[k].cpu().numpy().view(a.dtype).reshape(a.shape) for k, a in self.arrays().items()}
+
+
+def lcg_shufflers():
+    """dataShufflerBuffer initialisation, neural_radiance_caching_main.cpp:1186-1194."""
+    out = np.zeros(1 << 16, np.uint32)
+    state = 471313181
+    for i in range(1 << 16):
+        state = (state * 1103515245 + 12345) % (1 << 31)
+        out[i] = state
+    return out
+
+
+class NrcBuffers:
+    """Host (numpy) NRC render-side state in the ABI layout (gfx_nrc_params); device mirrors on demand."""
+    TRAIN = 1 << 17
+
+    def __init__(self, width, height, bounds, radiance_scale=1.0):
+        n = width * height
+        self.n, self.suffixes = n, n // 16
+        cap = ((n + self.suffixes + 255) // 256) * 256
+        self.bounds = np.asarray(bounds, np.float32)
+        self.radiance_scale = radiance_scale
+        a = {}
+        for i in range(2):
+            a[f"nrc_num_{i}"] = np.zeros(1, np.uint32)
+            a[f"nrc_tile_{i}"] = np.full(2, 8, np.uint32)
+            a[f"nrc_minmax_{i}"] = np.zeros(6, np.int32)
+            a[f"nrc_avg_{i}"] = np.zeros(3, np.float32)
+            a[f"nrc_trainq_{i}"] = np.zeros((self.TRAIN, 14), np.float32)
+            a[f"nrc_traint_{i}"] = np.zeros((self.TRAIN, 3), np.float32)
+        a["nrc_off_unbiased"] = np.zeros(1, np.uint32)
+        a["nrc_off_training"] = np.zeros(1, np.uint32)
+        a["nrc_queries"] = np.zeros((cap, 14), np.float32)
+        a["nrc_terminal"] = np.zeros((n, 4), np.float32)
+        a["nrc_inferred"] = np.zeros((cap, 3), np.float32)
+        a["nrc_contribution"] = np.zeros((n, 3), np.float32)
+        a["nrc_vertex"] = np.zeros((self.TRAIN, 4), np.float32)
+        a["nrc_suffix"] = np.zeros(self.suffixes, np.uint32)
+        a["nrc_shuffler"] = lcg_shufflers()
+        self.a = a
+        self.t = None
+
+    def arrays(self):
+        return self.a
+
+    def _params(self, cls, ptr, off_unbiased, off_training, new_sequence):
+        g = cls()
+        for k in range(3):
+            g.sceneAabbMin[k] = float(self.bounds[k]); g.sceneAabbMax[k] = float(self.bounds[3 + k])
+        g.maxNumTrainingSuffixes = self.suffixes
+        for i in range(2):
+            g.numTrainingData[i] = ptr(f"nrc_num_{i}"); g.tileSize[i] = ptr(f"nrc_tile_{i}")
+            g.targetMinMax[i] = ptr(f"nrc_minmax_{i}"); g.targetAvg[i] = ptr(f"nrc_avg_{i}")
+            g.trainRadianceQueryBuffer[i] = ptr(f"nrc_trainq_{i}"); g.trainTargetBuffer[i] = ptr(f"nrc_traint_{i}")
+        g.offsetToSelectUnbiasedTile = ptr("nrc_off_unbiased"); g.offsetToSelectTrainingPath = ptr("nrc_off_training")
+        g.inferenceRadianceQueryBuffer = ptr("nrc_queries"); g.inferenceTerminalInfoBuffer = ptr("nrc_terminal")
+        g.inferredRadianceBuffer = ptr("nrc_inferred"); g.perFrameContributionBuffer = ptr("nrc_contribution")
+        g.trainVertexInfoBuffer = ptr("nrc_vertex"); g.trainSuffixTerminalInfoBuffer = ptr("nrc_suffix")
+        g.dataShufflerBuffer = ptr("nrc_shuffler")
+        g.radianceScale = self.radiance_scale
+        g.preprocessOffsetToSelectUnbiasedTile, g.preprocessOffsetToSelectTrainingPath = off_unbiased, off_training
+        g.isNewSequence = int(new_sequence)
+        return g
+
+    def host_params(self, off_unbiased, off_training, new_sequence):
+        return self._params(O.GfxNrcParams, lambda k: self.a[k].ctypes.data, off_unbiased, off_training, new_sequence)
+
+    def to_device(self):
+        import torch
+        self.t = {k: torch.from_numpy(v.view(np.uint8).reshape(-1).copy()).cuda() for k, v in self.a.items()}
+
+    def device_params(self, off_unbiased, off_training, new_sequence):
+        if self.t is None:
+            self.to_device()
+        return self._params(api.GfxNrcParams, lambda k: self.t[k].data_ptr(), off_unbiased, off_training, new_sequence)
+
+    def download(self):
+        import torch
+        torch.cuda.synchronize()
+        return {k: self.t[k].cpu().numpy().view(v.dtype).reshape(v.shape) for k, v in self.a.items()}
+
+    def upload(self, name, array):
+        import torch
+        self.t[name].copy_(torch.from_numpy(np.ascontiguousarray(array).view(np.uint8).reshape(-1)))
+
+
+def nrc_chains(arrays, buf_idx=0):
+    """Canonical form of the training records: {tile: (suffix bits without the index, [(query, target,
+    localThroughput, pathLength), ...] from the suffix end to the first vertex)} -- independent of the
+    order in which records were allocated."""
+    out = {}
+    suffix = arrays["nrc_suffix"]
+    vinfo = arrays["nrc_vertex"]
+    q, t = arrays["nrc_trainq_0"], arrays["nrc_traint_0"]
+    for tile in np.nonzero((suffix & 0x7FFFFF) != 0x7FFFFF)[0]:
+        bits = int(suffix[tile])
+        last = bits & 0x7FFFFF
+        chain = []
+        while last != 0x7FFFFF and len(chain) < 256:
+            vb = int(vinfo[last, 3].view(np.uint32))
+            chain.append((q[last].tobytes(), t[last].tobytes(), vinfo[last, :3].tobytes(), vb >> 23))
+            last = vb & 0x7FFFFF
+        out[int(tile)] = (bits >> 23, chain)
+    return out
