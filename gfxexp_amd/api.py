@@ -159,6 +159,8 @@ HOST_ABI_SYMBOLS = [
     "gfxh_env_build_importance", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
+    "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_beauty_buffer",
+    "gfxh_nrc_network", "gfxh_nrc_stats",
 ]
 
 _lib = None
@@ -513,6 +515,55 @@ class NeuralRadianceCache:
         self.ctx._check(self.L.gfx_nrc_train(self.ctx.h, C.c_void_p(stream), C.c_uint64(self.h), C.c_void_p(d_inputs),
                                              C.c_void_p(d_targets), C.c_uint32(num_data), C.byref(loss) if want_loss else None))
         return loss.value if want_loss else None
+
+
+class GfxhNrcConfig(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("positionEncoding", C.c_int), ("numHiddenLayers", C.c_uint32),
+                ("learningRate", C.c_float), ("maxPathLength", C.c_uint32), ("radianceScale", C.c_float), ("train", C.c_uint32),
+                ("enableAccumulation", C.c_uint32), ("camera", GfxCamera), ("sceneAabbMin", C.c_float * 3),
+                ("sceneAabbMax", C.c_float * 3)]
+
+
+class NrcRenderer:
+    """gfxh_nrc: the headless frame loop of neural_radiance_caching_main.cpp over the C ABI."""
+
+    def __init__(self, ctx, cfg):
+        self.L, self.ctx, self.cfg = lib(), ctx, cfg
+        self.L.gfxh_nrc_last_error.restype = C.c_char_p
+        self.L.gfxh_nrc_beauty_buffer.restype = C.c_void_p
+        self.L.gfxh_nrc_network.restype = C.c_uint64
+        h = C.c_void_p()
+        if self.L.gfxh_nrc_create(ctx.h, C.byref(cfg), C.byref(h)):
+            raise GfxError("gfxh_nrc_create: " + self.L.gfxh_nrc_last_error().decode())
+        self.h = h
+
+    @staticmethod
+    def default_config(width, height, bounds):
+        cfg = GfxhNrcConfig()
+        lib().gfxh_nrc_default_config(C.byref(cfg), C.c_uint32(width), C.c_uint32(height))
+        for k in range(3):
+            cfg.sceneAabbMin[k] = float(bounds[k]); cfg.sceneAabbMax[k] = float(bounds[3 + k])
+        return cfg
+
+    def close(self):
+        if self.h:
+            self.L.gfxh_nrc_destroy(self.h)
+            self.h = None
+
+    def render_frame(self, stream=0, want_loss=False):
+        loss = C.c_float(0.0)
+        if self.L.gfxh_nrc_render_frame(self.h, C.c_void_p(stream), C.byref(loss) if want_loss else None):
+            raise GfxError("gfxh_nrc_render_frame: " + self.L.gfxh_nrc_last_error().decode())
+        return loss.value if want_loss else None
+
+    def beauty_ptr(self):
+        return self.L.gfxh_nrc_beauty_buffer(self.h)
+
+    def stats(self):
+        n, q = C.c_uint32(), C.c_uint32()
+        t = (C.c_uint32 * 2)()
+        self.L.gfxh_nrc_stats(self.h, C.byref(n), t, C.byref(q))
+        return dict(numTrainingData=n.value, tileSize=(t[0], t[1]), numInferenceQueries=q.value)
 
 
 class RestirRenderer:

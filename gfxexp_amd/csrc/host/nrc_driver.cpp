@@ -1,0 +1,193 @@
+// nrc_driver.cpp -- headless neural-radiance-caching frame driver (include/gfxexp_host.h).
+//
+// Re-creates the part of neural_radiance_caching/neural_radiance_caching_main.cpp that surrounds the
+// hot path: NRC buffer allocation and the LCG shuffler table (:1145-1200), per-frame offsets from
+// mt19937(72139121) (:1602, :2276-2277), and the frame sequencing (:2225-2370).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+#include "../../../include/gfxexp_host.h"
+
+namespace {
+thread_local std::string g_nrcError;
+bool nrc_hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    g_nrcError = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define NRC_HIP(call) do { if (!nrc_hip_ok((call), #call)) return 1; } while (0)
+#define NRC_GFX(call) do { if (call) { g_nrcError = gfx_last_error(r->ctx); return 1; } } while (0)
+constexpr uint32_t kNumTrainingDataPerFrame = 1u << 16;   // neural_radiance_caching_shared.h:8
+constexpr uint32_t kTrainBufferSize = 2u << 16;            // :9
+}
+
+struct gfxh_nrc {
+    gfx_ctx* ctx = nullptr;
+    gfxh_nrc_config cfg;
+    gfx_restir_static_params sp;
+    gfx_restir_frame_params fp;
+    gfx_nrc_params np;
+    std::vector<void*> allocations;
+    uint64_t accel = 0, network = 0;
+    uint32_t frameIndex = 0, numAccumFrames = 0;
+    std::mt19937 perFrameRng{ 72139121 };                  // main:1602
+    gfx_camera prevCamera;
+    uint32_t lastNumTrainingData = 0, lastTileSize[2] = { 8, 8 }, lastNumInferenceQueries = 0;
+};
+
+static int nrc_alloc(gfxh_nrc* r, void** p, size_t bytes) {
+    NRC_HIP(hipMalloc(p, bytes));
+    r->allocations.push_back(*p);
+    NRC_HIP(hipMemset(*p, 0, bytes));
+    return 0;
+}
+
+extern "C" {
+
+void gfxh_nrc_default_config(gfxh_nrc_config* cfg, uint32_t width, uint32_t height) {
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->width = width; cfg->height = height;
+    cfg->positionEncoding = GFX_NRC_HASH_GRID; cfg->numHiddenLayers = 2; cfg->learningRate = 1e-2f;
+    cfg->maxPathLength = 5; cfg->radianceScale = 1.0f; cfg->train = 1; cfg->enableAccumulation = 0;
+    cfg->camera.aspect = static_cast<float>(width) / height;
+    cfg->camera.fovY = 50 * 3.14159265358979323846f / 180;
+    const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    std::memcpy(cfg->camera.orientation, ident, sizeof(ident));
+}
+
+void gfxh_nrc_destroy(gfxh_nrc* r) {
+    if (!r) return;
+    (void)hipDeviceSynchronize();
+    if (r->network) (void)gfx_nrc_destroy(r->ctx, r->network);
+    for (void* p : r->allocations) (void)hipFree(p);
+    delete r;
+}
+
+int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out) {
+    *out = nullptr;
+    gfxh_nrc* r = new gfxh_nrc();
+    r->ctx = ctx; r->cfg = *cfg;
+    const size_t n = static_cast<size_t>(cfg->width) * cfg->height;
+    gfx_restir_static_params& sp = r->sp; gfx_nrc_params& np = r->np;
+    std::memset(&sp, 0, sizeof(sp)); std::memset(&r->fp, 0, sizeof(r->fp)); std::memset(&np, 0, sizeof(np));
+    sp.imageSizeX = static_cast<int32_t>(cfg->width); sp.imageSizeY = static_cast<int32_t>(cfg->height);
+    int err = 0;
+    err |= nrc_alloc(r, &sp.rngBuffer, 8 * n);
+    for (int i = 0; i < 2; ++i) {
+        err |= nrc_alloc(r, &sp.gbuffer0[i], sizeof(gfx_gbuffer0) * n);
+        err |= nrc_alloc(r, &sp.gbuffer1[i], sizeof(gfx_gbuffer1) * n);
+        err |= nrc_alloc(r, &sp.gbuffer2[i], sizeof(gfx_gbuffer2) * n);
+        err |= nrc_alloc(r, &sp.gbuffer3[i], sizeof(gfx_gbuffer3) * n);
+    }
+    err |= nrc_alloc(r, &sp.beautyAccumBuffer, 16 * n);
+    err |= nrc_alloc(r, &sp.albedoAccumBuffer, 16 * n);
+    err |= nrc_alloc(r, &sp.normalAccumBuffer, 16 * n);
+    // main:1150-1185
+    np.maxNumTrainingSuffixes = static_cast<uint32_t>(n / 16);
+    const size_t cap = (n + np.maxNumTrainingSuffixes + 255) / 256 * 256;
+    for (int i = 0; i < 2; ++i) {
+        err |= nrc_alloc(r, &np.numTrainingData[i], 4);
+        err |= nrc_alloc(r, &np.tileSize[i], 8);
+        err |= nrc_alloc(r, &np.targetMinMax[i], 24);
+        err |= nrc_alloc(r, &np.targetAvg[i], 12);
+        err |= nrc_alloc(r, &np.trainRadianceQueryBuffer[i], 56ull * kTrainBufferSize);
+        err |= nrc_alloc(r, &np.trainTargetBuffer[i], 12ull * kTrainBufferSize);
+    }
+    err |= nrc_alloc(r, &np.offsetToSelectUnbiasedTile, 4);
+    err |= nrc_alloc(r, &np.offsetToSelectTrainingPath, 4);
+    err |= nrc_alloc(r, &np.inferenceRadianceQueryBuffer, 56 * cap);
+    err |= nrc_alloc(r, &np.inferenceTerminalInfoBuffer, 16 * n);
+    err |= nrc_alloc(r, &np.inferredRadianceBuffer, 12 * cap);
+    err |= nrc_alloc(r, &np.perFrameContributionBuffer, 12 * n);
+    err |= nrc_alloc(r, &np.trainVertexInfoBuffer, 16ull * kTrainBufferSize);
+    err |= nrc_alloc(r, &np.trainSuffixTerminalInfoBuffer, 4ull * np.maxNumTrainingSuffixes);
+    err |= nrc_alloc(r, &np.dataShufflerBuffer, 4ull * kNumTrainingDataPerFrame);
+    if (err) { gfxh_nrc_destroy(r); return 1; }
+    {
+        std::vector<uint64_t> states(n);
+        gfxh_seed_rng_states(states.data(), n, 591842031321323413ull);
+        const uint32_t tile[2] = { 8, 8 };
+        std::vector<uint32_t> shufflers(kNumTrainingDataPerFrame);
+        uint32_t lcg = 471313181u;                                             // main:1188
+        for (uint32_t i = 0; i < kNumTrainingDataPerFrame; ++i) { lcg = (lcg * 1103515245u + 12345u) % (1u << 31); shufflers[i] = lcg; }
+        bool ok = nrc_hip_ok(hipMemcpy(sp.rngBuffer, states.data(), 8 * n, hipMemcpyHostToDevice), "upload rng states");
+        for (int i = 0; i < 2 && ok; ++i) ok = nrc_hip_ok(hipMemcpy(np.tileSize[i], tile, 8, hipMemcpyHostToDevice), "upload tile size");
+        ok = ok && nrc_hip_ok(hipMemcpy(np.dataShufflerBuffer, shufflers.data(), 4ull * kNumTrainingDataPerFrame, hipMemcpyHostToDevice), "upload shufflers");
+        if (!ok) { gfxh_nrc_destroy(r); return 1; }
+    }
+    std::memcpy(np.sceneAabbMin, cfg->sceneAabbMin, 12); std::memcpy(np.sceneAabbMax, cfg->sceneAabbMax, 12);
+    if (gfx_accel_build(ctx, nullptr, &r->accel) || gfx_lights_build_static(ctx, nullptr) ||
+        gfx_nrc_create(ctx, cfg->positionEncoding, cfg->numHiddenLayers, cfg->learningRate, &r->network)) {
+        g_nrcError = gfx_last_error(ctx);
+        gfxh_nrc_destroy(r);
+        return 1;
+    }
+    r->prevCamera = cfg->camera;
+    *out = r;
+    return 0;
+}
+
+int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
+    gfx_ctx* ctx = r->ctx;
+    const gfxh_nrc_config& cfg = r->cfg;
+    const uint32_t W = cfg.width, H = cfg.height;
+    const uint32_t frameIndex = r->frameIndex, bufferIndex = frameIndex % 2;
+    gfx_restir_frame_params& fp = r->fp;
+    NRC_GFX(gfx_lights_build_instances(ctx, stream, bufferIndex));
+    const bool newSequence = frameIndex == 0;                                       // main:2228
+    if (!cfg.enableAccumulation || newSequence) r->numAccumFrames = 0;
+    else r->numAccumFrames = std::min(r->numAccumFrames + 1, 1u << 16);
+    fp.travHandle = r->accel; fp.numAccumFrames = r->numAccumFrames; fp.frameIndex = frameIndex;
+    fp.prevCamera = frameIndex == 0 ? cfg.camera : r->prevCamera;
+    fp.camera = cfg.camera;
+    fp.envLightPowerCoeff = 1.0f; fp.envLightRotation = 0.0f;
+    fp.bufferIndex = bufferIndex; fp.resetFlowBuffer = newSequence; fp.enableJittering = 0; fp.enableEnvLight = 0; fp.enableBumpMapping = 0;
+    r->np.radianceScale = cfg.radianceScale;
+    r->np.preprocessOffsetToSelectUnbiasedTile = static_cast<uint32_t>(r->perFrameRng());   // main:2276-2277
+    r->np.preprocessOffsetToSelectTrainingPath = static_cast<uint32_t>(r->perFrameRng());
+    r->np.isNewSequence = newSequence;
+    NRC_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, 0, 0));
+    NRC_GFX(gfx_nrc_set_render_params(ctx, &r->np));
+    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, 0, 0));
+    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_PREPROCESS, W, H, cfg.maxPathLength, 0, 0));
+    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_NRC, W, H, cfg.maxPathLength, 0, 0));
+    // main:2293-2303: the inference batch size needs the tile size of this frame
+    NRC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    NRC_HIP(hipMemcpy(&r->lastNumTrainingData, r->np.numTrainingData[bufferIndex], 4, hipMemcpyDeviceToHost));
+    NRC_HIP(hipMemcpy(r->lastTileSize, r->np.tileSize[bufferIndex], 8, hipMemcpyDeviceToHost));
+    const uint32_t tilesX = (W + r->lastTileSize[0] - 1) / r->lastTileSize[0], tilesY = (H + r->lastTileSize[1] - 1) / r->lastTileSize[1];
+    uint32_t numInferenceQueries = W * H + tilesX * tilesY;
+    numInferenceQueries = (numInferenceQueries + 127) / 128 * 128;
+    r->lastNumInferenceQueries = numInferenceQueries;
+    NRC_GFX(gfx_nrc_infer(ctx, stream, r->network, r->np.inferenceRadianceQueryBuffer, numInferenceQueries, r->np.inferredRadianceBuffer));
+    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_ACCUMULATE, W, H, cfg.maxPathLength, 0, 0));
+    if (cfg.train) {
+        NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_PROPAGATE, W, H, cfg.maxPathLength, 0, 0));
+        NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_SHUFFLE, W, H, cfg.maxPathLength, 0, 0));
+        constexpr uint32_t batchSize = kNumTrainingDataPerFrame / 4;                 // main:2350
+        for (uint32_t step = 0; step < 4; ++step) {
+            const char* q = static_cast<const char*>(r->np.trainRadianceQueryBuffer[1]) + 56ull * step * batchSize;
+            const char* t = static_cast<const char*>(r->np.trainTargetBuffer[1]) + 12ull * step * batchSize;
+            NRC_GFX(gfx_nrc_train(ctx, stream, r->network, q, t, batchSize, (lossOut && step == 3) ? lossOut : nullptr));
+        }
+    }
+    r->prevCamera = cfg.camera;
+    ++r->frameIndex;
+    return 0;
+}
+
+void* gfxh_nrc_beauty_buffer(gfxh_nrc* r) { return r->sp.beautyAccumBuffer; }
+uint64_t gfxh_nrc_network(gfxh_nrc* r) { return r->network; }
+int gfxh_nrc_stats(gfxh_nrc* r, uint32_t* numTrainingData, uint32_t tileSize[2], uint32_t* numInferenceQueries) {
+    if (numTrainingData) *numTrainingData = r->lastNumTrainingData;
+    if (tileSize) { tileSize[0] = r->lastTileSize[0]; tileSize[1] = r->lastTileSize[1]; }
+    if (numInferenceQueries) *numInferenceQueries = r->lastNumInferenceQueries;
+    return 0;
+}
+const char* gfxh_nrc_last_error(void) { return g_nrcError.c_str(); }
+
+} // extern "C"

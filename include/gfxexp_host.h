@@ -165,6 +165,34 @@ int gfxh_restir_get_params(gfxh_restir* r, gfx_restir_static_params* s, gfx_rest
                            uint32_t* lastReservoirIndex, uint32_t* lastSpatialNeighborBaseIndex, uint32_t* frameIndex);
 uint64_t gfxh_restir_accel(gfxh_restir* r);
 
+/* ---------------------------------------------------------------- headless NRC renderer -------- */
+/* The frame loop of neural_radiance_caching_main.cpp:2225-2370 over the C ABI: G-buffer, preprocessNRC,
+ * pathTraceNRC, infer (W*H + #tiles queries rounded up to 128), accumulate, and -- when training --
+ * propagate, shuffle, 4 training steps of 16 384 records.  Like the reference it reads the tile size
+ * back from the device once per frame to size the inference batch (:2293-2303). */
+typedef struct gfxh_nrc gfxh_nrc;
+typedef struct gfxh_nrc_config {
+    uint32_t width, height;
+    int positionEncoding;        /* gfx_nrc_position_encoding; HashGrid (main:458) */
+    uint32_t numHiddenLayers;    /* 2 (main:459) */
+    float learningRate;          /* 1e-2 (main:460) */
+    uint32_t maxPathLength;      /* 5; 0 = unlimited bounces (main:1860-1861, 2246) */
+    float radianceScale;         /* pow(10, log10RadianceScale) (main:2240) */
+    uint32_t train;              /* 1 */
+    uint32_t enableAccumulation; /* 0 */
+    gfx_camera camera;
+    float sceneAabbMin[3], sceneAabbMax[3];   /* scene.initialSceneAabb (main:1139) */
+} gfxh_nrc_config;
+void gfxh_nrc_default_config(gfxh_nrc_config* cfg, uint32_t width, uint32_t height);
+int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out);
+void gfxh_nrc_destroy(gfxh_nrc* r);
+/* lossOut (optional): the loss of the fourth training step (main:2363). */
+int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut);
+void* gfxh_nrc_beauty_buffer(gfxh_nrc* r);
+uint64_t gfxh_nrc_network(gfxh_nrc* r);
+int gfxh_nrc_stats(gfxh_nrc* r, uint32_t* numTrainingData, uint32_t tileSize[2], uint32_t* numInferenceQueries);
+const char* gfxh_nrc_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,3 +141,54 @@ def test_nrc_visualize_prediction_queries(built_lib):
     util.assert_same_bits("terminal infos", got["nrc_terminal"], want["nrc_terminal"])
     hq = (want["nrc_terminal"][:, 3].view(np.uint32) & 1) == 1
     util.assert_same_bits("queries", got["nrc_queries"][:w * h][hq], want["nrc_queries"][:w * h][hq])
+
+
+@pytest.mark.gpu
+def test_headless_nrc_renderer_learns_the_indirect_light(built_lib):
+    """End to end through gfxh_nrc (C++ frame loop + network): after a few dozen training frames the
+    cache-terminated image (short paths + predicted tail) is closer to a long-path reference than the
+    same short paths with an untrained cache, the tile size adapts, and the loss stays finite."""
+    import torch
+    hs = util.bunny_scene()
+    w, h = 160, 96
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    cam = api.make_camera(w, h, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+
+    # long-path reference: baseline path tracer, 15 bounces, 96 accumulated frames
+    cfg_ref = api.RestirRenderer.default_config(w, h, api.RENDERER_PATH_TRACE)
+    cfg_ref.maxPathLength = 15; cfg_ref.enableAccumulation = 1; cfg_ref.camera = cam
+    ref = api.RestirRenderer(ctx, cfg_ref)
+    for _ in range(96):
+        ref.render_frame()
+    torch.cuda.synchronize()
+    ref_img = ctx.read_device(ref.beauty_ptr(), w * h * 16).view(np.float32).reshape(-1, 4)[:, :3].copy()
+
+    def mean_image(renderer, frames):
+        acc = np.zeros((w * h, 3), np.float64)
+        for _ in range(frames):
+            renderer.render_frame()
+            torch.cuda.synchronize()
+            acc += ctx.read_device(renderer.beauty_ptr(), w * h * 16).view(np.float32).reshape(-1, 4)[:, :3]
+        return acc / frames
+
+    cfg = api.NrcRenderer.default_config(w, h, hs.bounds())
+    cfg.camera = cam
+    cfg.train = 0
+    untrained = api.NrcRenderer(ctx, cfg)
+    img_untrained = mean_image(untrained, 24)
+    st = untrained.stats()
+    assert st["numInferenceQueries"] % 128 == 0 and st["numInferenceQueries"] >= w * h
+    untrained.close()
+
+    cfg.train = 1
+    nrc = api.NrcRenderer(ctx, cfg)
+    losses = [nrc.render_frame(want_loss=True) for _ in range(48)]
+    assert np.all(np.isfinite(losses))
+    st = nrc.stats()
+    assert st["numTrainingData"] > 0 and 4 <= st["tileSize"][0] <= 128
+    img_trained = mean_image(nrc, 24)
+    assert np.all(np.isfinite(img_trained))
+    err_untrained = np.abs(img_untrained.mean(axis=0) - ref_img.mean(axis=0)).sum()
+    err_trained = np.abs(img_trained.mean(axis=0) - ref_img.mean(axis=0)).sum()
+    assert err_trained < 0.6 * err_untrained, (err_trained, err_untrained, ref_img.mean(axis=0), img_trained.mean(axis=0))
