@@ -161,6 +161,7 @@ def roofline(ctx, renderer, stream, steps, W, H):
     renderer.render_frame(stream)
     torch.cuda.synchronize()
     c = ctx.counters_read(reset=True)
+    diag = ctx.trace_diag_read(reset=True)
     ctx.counters_enable(False)
     per_frame = {k: round(ms / n, 4) for k, (ms, calls) in sorted(timings.items(), key=lambda kv: -kv[1][0])}
     trav_ms = sum(ms for k, (ms, calls) in timings.items() if k.startswith("trace_")) / n
@@ -173,6 +174,9 @@ def roofline(ctx, renderer, stream, steps, W, H):
     roof = {"bound": "hbm", "kernel": "k_trace<closest|any> (software BVH8 traversal; 3 launches per frame)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
+            "scheduling": {"wave_iterations": diag["iterations"], "lane_occupancy": round(diag["itemLanes"] / max(1, 64 * diag["iterations"]), 4),
+                           "drain_iteration_share": round(diag["drainIterations"] / max(1, diag["iterations"]), 4),
+                           "drain_lane_occupancy": round(diag["drainItemLanes"] / max(1, 64 * diag["drainIterations"]), 4)},
             "algorithmic_bytes_per_launch": int(bytes_frame / max(trav_launches, 1)),
             "avg_launch_ms": round(trav_ms / max(trav_launches, 1), 4),
             "per_frame": {"node_fetches": int(c["nodeFetches"]), "tri_fetches": int(c["triFetches"]), "rays": int(c["rays"]),

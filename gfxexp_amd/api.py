@@ -146,7 +146,7 @@ C_ABI_SYMBOLS = [
     "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
     "gfx_nrc_get_params", "gfx_nrc_set_render_params",
-    "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read",
+    "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read", "gfx_trace_diag_read",
 ]
 HOST_ABI_SYMBOLS = [
     "gfxh_scene_create", "gfxh_scene_destroy", "gfxh_last_error", "gfxh_scene_add_material_traditional",
@@ -465,6 +465,11 @@ class Context:
 
     def counters_enable(self, on=True):
         self._check(self.L.gfx_counters_enable(self.h, C.c_int(1 if on else 0)))
+
+    def trace_diag_read(self, reset=True):
+        c = (C.c_uint64 * 8)()
+        self._check(self.L.gfx_trace_diag_read(self.h, c, C.c_int(1 if reset else 0)))
+        return dict(iterations=c[0], itemLanes=c[1], drainIterations=c[2], drainItemLanes=c[3])
 
     def counters_read(self, reset=True):
         c = (C.c_uint64 * 4)()

@@ -347,6 +347,17 @@ int gfx_counters_enable(gfx_ctx* ctx, int enable) {
     GFX_CATCH(ctx)
 }
 
+int gfx_trace_diag_read(gfx_ctx* ctx, uint64_t diag[8], int reset) {
+    GFX_TRY(ctx)
+    GFX_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 8; ++i) diag[i] = 0;
+    if (ctx->c.dTraceDiag.p) {
+        GFX_HIP(hipMemcpy(diag, ctx->c.dTraceDiag.p, 64, hipMemcpyDeviceToHost));
+        if (reset) GFX_HIP(hipMemset(ctx->c.dTraceDiag.p, 0, 64));
+    }
+    GFX_CATCH(ctx)
+}
+
 int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[4], int reset) {
     GFX_TRY(ctx)
     GFX_HIP(hipDeviceSynchronize());

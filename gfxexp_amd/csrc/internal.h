@@ -107,6 +107,7 @@ struct Context {
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pendingEvents;
     bool countersEnabled = false;
     DevBuf dTraceCounters;     // u64[4]
+    DevBuf dTraceDiag;         // u64[8] scheduling diagnostics of counting launches
     ~Context();
 };
 

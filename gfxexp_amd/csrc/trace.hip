@@ -27,6 +27,7 @@ struct TraceArgs {
     uint32_t* ticket;           // queue head (zeroed before the launch)
     uint2* spill;               // kSpillStackDepth entries per thread of the grid
     unsigned long long* counters; // optional: node fetches, triangle fetches, rays, spills
+    unsigned long long* diag;     // optional (counting launches): wave iterations, item-lanes, drain iterations, drain item-lanes
     int refillThreshold;        // refill when at least this many lanes are idle
     int ticketBatch;            // rays bought per device atomic
 };
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
     uint32_t waveNext = 0, waveEnd = 0; // wave-uniform: rays [waveNext, waveEnd) already ticketed for this wave
     TraceCounters cnt = { 0, 0, 0 };
     uint32_t raysDone = 0;
+    uint32_t diagIter = 0, diagLanes = 0, diagDrainIter = 0, diagDrainLanes = 0;   // wave-uniform (COUNT only)
 
     auto write_result = [&]() {
         if (ANY_HIT) static_cast<uint32_t*>(a.out)[rayIdx] = tr.hit.tri != GFX_INVALID_SLOT ? 1u : 0u;
@@ -133,6 +135,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
             code = tr.next_item(stack);
             if (code == kItemNone) write_result();          // traversal finished
         }
+        if (COUNT) {
+            const int held = __popcll(__ballot(code != kItemNone));
+            ++diagIter; diagLanes += held;
+            if (exhausted) { ++diagDrainIter; diagDrainLanes += held; }
+        }
         uint4 q0, q1, q2, q3;
         fetch_items(code, a.accel, waveBuf, lane, q0, q1, q2, q3);
         if (code != kItemNone) {
@@ -142,6 +149,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
             }
             else tr.template process_node<COUNT>(q0, q1, q2, q3, stack, cnt);
         }
+    }
+    if (COUNT && a.diag && lane == 0) {
+        atomicAdd(a.diag + 0, static_cast<unsigned long long>(diagIter)); atomicAdd(a.diag + 1, static_cast<unsigned long long>(diagLanes));
+        atomicAdd(a.diag + 2, static_cast<unsigned long long>(diagDrainIter)); atomicAdd(a.diag + 3, static_cast<unsigned long long>(diagDrainLanes));
     }
     if (COUNT && a.counters) {
         // wave-level reduction, one atomic per wave and counter
@@ -182,6 +193,11 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     a.numRaysPtr = t.numRaysPtr; a.numRays = t.numRays;
     a.out = t.out; a.ticket = ticket; a.spill = ctx.spill.as<uint2>();
     a.counters = ctx.countersEnabled ? ctx.dTraceCounters.as<unsigned long long>() : nullptr;
+    a.diag = nullptr;
+    if (ctx.countersEnabled) {
+        if (!ctx.dTraceDiag.p) { ctx.dTraceDiag.reserve(64); GFX_HIP(hipMemsetAsync(ctx.dTraceDiag.p, 0, 64, stream)); }
+        a.diag = ctx.dTraceDiag.as<unsigned long long>();
+    }
     static int refill = 0;
     if (!refill) { const char* e = getenv("GFX_TRACE_REFILL"); refill = e ? atoi(e) : kRefillThreshold; if (refill < 1 || refill > 64) refill = kRefillThreshold; }
     a.refillThreshold = refill;

@@ -372,6 +372,9 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
 /* Ray-traversal counters accumulated by the ReSTIR passes (device u64[4], see gfx_trace). */
 int gfx_counters_enable(gfx_ctx* ctx, int enable);
 int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[4], int reset);
+/* Scheduling diagnostics of the counting trace launches: [0] wave iterations, [1] lanes that held an
+ * item summed over iterations, [2] / [3] the same after the ray queue ran dry (drain phase). */
+int gfx_trace_diag_read(gfx_ctx* ctx, uint64_t diag[8], int reset);
 
 #ifdef __cplusplus
 }
