@@ -33,6 +33,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def _profiled_traffic():
+    """HBM bytes per traversal launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
+    inside this process); None when the file is missing."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,7 +184,7 @@ def roofline(ctx, renderer, stream, steps, W, H):
     achieved = bytes_frame / (trav_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": "k_trace<closest|any> (software BVH8 traversal; 3 launches per frame)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": _profiled_traffic(),
             "scheduling": {"wave_iterations": diag["iterations"], "lane_occupancy": round(diag["itemLanes"] / max(1, 64 * diag["iterations"]), 4),
                            "drain_iteration_share": round(diag["drainIterations"] / max(1, diag["iterations"]), 4),
                            "drain_lane_occupancy": round(diag["drainItemLanes"] / max(1, 64 * diag["drainIterations"]), 4)},
