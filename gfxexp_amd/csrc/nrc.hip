@@ -634,7 +634,13 @@ NrcNet* nrc_create(Context& ctx, int posEnc, uint32_t numHiddenLayers, float lea
     return net;
 }
 
-void nrc_destroy(NrcNet* net) { delete net; }
+void nrc_destroy(NrcNet* net) {
+    if (!net) return;
+    DevBuf* all[] = { &net->params, &net->adamM, &net->adamV, &net->ema, &net->gradPartials, &net->gridGrad, &net->lossSum,
+                      &net->packTrainFwd, &net->packTrainBwd, &net->packInferFwd, &net->gridTrain, &net->gridInfer };
+    for (DevBuf* b : all) b->release();
+    delete net;
+}
 uint32_t nrc_num_params(const NrcNet* net) { return net->d.total; }
 
 // which: 0 = training parameters (also resets the EMA copy, the Adam moments and the step counter), 1 = EMA

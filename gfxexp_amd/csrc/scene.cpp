@@ -12,7 +12,10 @@ Context::~Context() {
     DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dLightW, &dLightCDF, &dLightRefs, &dEmitterRecs,
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
-                      &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral };
+                      &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral,
+                      &dTraceDiag, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
+                      &rearchSlots, &nrcState, &neeTrainIdx };
+    for (NrcNet* net : nrcNets) if (net) nrc_destroy(net);
     for (DevBuf* b : all) b->release();
     for (auto& e : pendingEvents) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
 }
