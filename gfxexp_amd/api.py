@@ -27,7 +27,7 @@ def rearch_passes(temporal, spatial, unbiased, new_sequence):
         return PASS_TRACE_SHADOW_RAYS, PASS_SHADE_AND_RESAMPLE
     k = (1 if temporal and not spatial else 2 if spatial and not temporal else 3)
     return PASS_TRACE_SHADOW_RAYS + k + (3 if unbiased else 0), PASS_SHADE_AND_RESAMPLE + k
-RENDERER_BIASED, RENDERER_UNBIASED, RENDERER_REARCH_BIASED, RENDERER_REARCH_UNBIASED, RENDERER_PATH_TRACE = 0, 1, 2, 3, 4
+RENDERER_BIASED, RENDERER_UNBIASED, RENDERER_REARCH_BIASED, RENDERER_REARCH_UNBIASED, RENDERER_PATH_TRACE, RENDERER_PATH_TRACE_REGIR = 0, 1, 2, 3, 4, 5
 (PT_SETUP_GBUFFERS, PT_PATH_TRACE_BASELINE, PT_REGIR_BUILD_CELLS, PT_REGIR_BUILD_CELLS_TEMPORAL,
  PT_PATH_TRACE_REGIR, PT_REGIR_UPDATE_LAST_ACCESS, PT_NRC_PREPROCESS, PT_PATH_TRACE_NRC, PT_NRC_ACCUMULATE,
  PT_NRC_PROPAGATE, PT_NRC_SHUFFLE, PT_NRC_VISUALIZE_PREDICTION) = range(12)
@@ -117,7 +117,10 @@ class GfxhRestirConfig(C.Structure):
                 ("useLowDiscrepancyNeighbors", C.c_uint32), ("reuseVisibility", C.c_uint32),
                 ("enableAccumulation", C.c_uint32), ("log2MaxNumAccums", C.c_uint32),
                 ("camera", GfxCamera), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32),
-                ("maxPathLength", C.c_uint32), ("enableJittering", C.c_uint32)]
+                ("maxPathLength", C.c_uint32), ("enableJittering", C.c_uint32),
+                ("regirAabbMin", C.c_float * 3), ("regirAabbMax", C.c_float * 3), ("regirGridDimension", C.c_uint32 * 3),
+                ("regirLog2CandidatesPerLightSlot", C.c_uint32), ("regirLog2CandidatesPerCell", C.c_uint32),
+                ("regirEnableTemporalReuse", C.c_uint32), ("regirEnableCellRandomization", C.c_uint32)]
 
 
 class GfxhBandPlan(C.Structure):

@@ -37,6 +37,7 @@ struct gfxh_restir {
     bool resetRequested = false;
     gfx_camera camera, prevCamera;
     float envPowerCoeff = 1.0f, envRotation = 0.0f;
+    gfx_regir_params regir;
 };
 
 extern "C" {
@@ -54,6 +55,9 @@ void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_
     cfg->enableAccumulation = 0;
     cfg->log2MaxNumAccums = 16;
     cfg->maxPathLength = 5;                                // path_tracing_main.cpp:1519
+    cfg->regirGridDimension[0] = 32; cfg->regirGridDimension[1] = 8; cfg->regirGridDimension[2] = 32;   // regir_main.cpp:1112
+    cfg->regirLog2CandidatesPerLightSlot = 3; cfg->regirLog2CandidatesPerCell = 2;                       // :1733-1734
+    cfg->regirEnableTemporalReuse = 1; cfg->regirEnableCellRandomization = 1;                             // :1735-1736
     cfg->enableJittering = 0;
     cfg->camera.aspect = static_cast<float>(width) / height;
     cfg->camera.fovY = 50 * 3.14159265358979323846f / 180;   // :1613
@@ -122,6 +126,35 @@ int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir*
     if (rearch) {
         err |= alloc_dev(r, &sp.lightPreSamplingRngs, 8 * numPreSampledLights, false);
         err |= alloc_dev(r, &sp.preSampledLights, 48 * numPreSampledLights, true);
+    }
+    if (cfg->renderer == GFXH_PATH_TRACE_REGIR) {          // regir_main.cpp:1071-1097
+        gfx_regir_params& g = r->regir;
+        std::memset(&g, 0, sizeof(g));
+        const uint32_t* d = cfg->regirGridDimension;
+        const size_t numCells = static_cast<size_t>(d[0]) * d[1] * d[2], numSlots = numCells * 512;
+        if (numCells == 0) { g_driverError = "gfxh_restir_create: empty ReGIR grid"; gfxh_restir_destroy(r); return 1; }
+        for (int i = 0; i < 2; ++i) {
+            err |= alloc_dev(r, &g.reservoirs[i], 48 * numSlots, true);
+            err |= alloc_dev(r, &g.reservoirInfos[i], 8 * numSlots, true);
+            err |= alloc_dev(r, &g.numActiveCells[i], 4, true);
+        }
+        err |= alloc_dev(r, &g.lightSlotRngs, 8 * numSlots, false);
+        err |= alloc_dev(r, &g.perCellNumAccesses, 4 * numCells, true);
+        err |= alloc_dev(r, &g.lastAccessFrameIndices, 4 * numCells, false);
+        if (!err) {
+            std::vector<uint64_t> states(numSlots);
+            gfxh_seed_rng_states(states.data(), numSlots, 591842031321323413ull);
+            if (!hip_ok(hipMemcpy(g.lightSlotRngs, states.data(), 8 * numSlots, hipMemcpyHostToDevice), "upload light-slot rng states") ||
+                !hip_ok(hipMemset(g.lastAccessFrameIndices, 0xFF, 4 * numCells), "fill lastAccessFrameIndices")) err = 1;
+        }
+        for (int k = 0; k < 3; ++k) {
+            g.gridOrigin[k] = cfg->regirAabbMin[k];
+            g.gridCellSize[k] = (cfg->regirAabbMax[k] - cfg->regirAabbMin[k]) / static_cast<float>(d[k]);
+            g.gridDimension[k] = d[k];
+        }
+        g.log2NumCandidatesPerLightSlot = cfg->regirLog2CandidatesPerLightSlot;
+        g.log2NumCandidatesPerCell = cfg->regirLog2CandidatesPerCell;
+        g.enableCellRandomization = cfg->regirEnableCellRandomization;
     }
     if (err) { gfxh_restir_destroy(r); return 1; }
     sp.spatialNeighborDeltas = deltas;
@@ -257,6 +290,19 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     gfxh_restir_band_plan(r, &plan);
 #define DRV_GFX(call) do { if (call) { g_driverError = gfx_last_error(ctx); return 1; } } while (0)
     DRV_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, currentReservoirIndex, r->lastSpatialNeighborBaseIndex));
+    if (cfg.renderer == GFXH_PATH_TRACE_REGIR) {
+        // regir_main.cpp:2021-2066: G-buffer, cell reservoirs (+ temporal reuse unless a new sequence), ReGIR path
+        // tracing, last-access update.  Whole frame (the grid is shared state).
+        DRV_GFX(gfx_regir_set_params(ctx, &r->regir));
+        DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, 0, 0));
+        const int build = (cfg.regirEnableTemporalReuse && !newSequence) ? GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL : GFX_PT_REGIR_BUILD_CELL_RESERVOIRS;
+        DRV_GFX(gfx_pt_launch(ctx, stream, build, W, H, cfg.maxPathLength, 0, 0));
+        DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_REGIR, W, H, cfg.maxPathLength, 0, 0));
+        DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_REGIR_UPDATE_LAST_ACCESS, W, H, cfg.maxPathLength, 0, 0));
+        r->prevCamera = r->camera;
+        ++r->frameIndex;
+        return 0;
+    }
     if (cfg.renderer == GFXH_PATH_TRACE_BASELINE) {
         // path_tracing_main.cpp:2068-2093: G-buffer pipeline, then pathTraceBaseline.  A band needs no
         // halo: paths never read a neighbour's pixel state.

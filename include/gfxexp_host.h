@@ -103,7 +103,8 @@ enum gfxh_renderer {
     GFXH_ORIGINAL_RESTIR_UNBIASED = 1,
     GFXH_REARCHITECTED_RESTIR_BIASED = 2,   /* frame loop :2423-2487, configs (5, 1, 1) :1966-1969 */
     GFXH_REARCHITECTED_RESTIR_UNBIASED = 3,
-    GFXH_PATH_TRACE_BASELINE = 4       /* path_tracing/path_tracing_main.cpp:2068-2093 frame loop */
+    GFXH_PATH_TRACE_BASELINE = 4,      /* path_tracing/path_tracing_main.cpp:2068-2093 frame loop */
+    GFXH_PATH_TRACE_REGIR = 5          /* regir/regir_main.cpp:2021-2066 frame loop (grid 32 x 8 x 32 over the scene box) */
 };
 typedef struct gfxh_restir_config {
     uint32_t width, height;
@@ -123,6 +124,13 @@ typedef struct gfxh_restir_config {
     uint32_t rowBegin, rowEnd;
     uint32_t maxPathLength;             /* GFXH_PATH_TRACE_BASELINE only; 5 (path_tracing_main.cpp:1519) */
     uint32_t enableJittering;           /* 0 (path_tracing_main.cpp:1515, restir_di_main.cpp) */
+    /* GFXH_PATH_TRACE_REGIR only (regir_main.cpp:1112, 1733-1736) */
+    float regirAabbMin[3], regirAabbMax[3];   /* scene.initialSceneAabb */
+    uint32_t regirGridDimension[3];           /* 32 x 8 x 32 */
+    uint32_t regirLog2CandidatesPerLightSlot; /* 3 */
+    uint32_t regirLog2CandidatesPerCell;      /* 2 */
+    uint32_t regirEnableTemporalReuse;        /* 1 */
+    uint32_t regirEnableCellRandomization;    /* 1 */
 } gfxh_restir_config;
 
 void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_t height, int renderer);

@@ -87,3 +87,40 @@ def test_regir_street_with_env_light(built_lib):
     cam = api.make_camera(96, 64, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
     diffs = run_regir_both(util.small_street(), 96, 64, 3, 5, env=(sky, w, h), camera=cam, dims=(8, 2, 8))
     assert not diffs, "\n".join(diffs[:12])
+
+
+@pytest.mark.gpu
+def test_headless_driver_regir_mode(built_lib):
+    """gfxh_restir with renderer = GFXH_PATH_TRACE_REGIR (frame loop of regir_main.cpp:2021-2066)
+    reproduces the oracle sequenced by the harness."""
+    import torch
+    hs = util.bunny_scene()
+    width, height, frames, dims = 96, 64, 3, (8, 4, 8)
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    cam = api.make_camera(width, height, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+    cfg = api.RestirRenderer.default_config(width, height, api.RENDERER_PATH_TRACE_REGIR)
+    assert list(cfg.regirGridDimension) == [32, 8, 32] and cfg.regirLog2CandidatesPerLightSlot == 3
+    cfg.camera = cam
+    b = hs.bounds()
+    for k in range(3):
+        cfg.regirAabbMin[k] = float(b[k]); cfg.regirAabbMax[k] = float(b[3 + k]); cfg.regirGridDimension[k] = dims[k]
+    r = api.RestirRenderer(ctx, cfg)
+    for _ in range(frames):
+        r.render_frame()
+    torch.cuda.synchronize()
+    out = ctx.read_device(r.beauty_ptr(), width * height * 16).view(np.float32).reshape(-1, 4)
+
+    osc = util.feed_oracle(hs)
+    pb = util.PixelBuffers(width, height)
+    rb = util.RegirBuffers(hs.bounds(), dims)
+    s = pb.host_static_params()
+    osc.regir_set_params(rb.host_params())
+    ocam = util.copy_struct(O.GfxCamera, cam)
+    for frame in range(frames):
+        f = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, width, height, ocam, frameIndex=frame, bufferIndex=frame % 2,
+                              resetFlowBuffer=int(frame == 0), numAccumFrames=0)
+        build = api.PT_REGIR_BUILD_CELLS_TEMPORAL if frame > 0 else api.PT_REGIR_BUILD_CELLS
+        for pass_id in (api.PT_SETUP_GBUFFERS, build, api.PT_PATH_TRACE_REGIR, api.PT_REGIR_UPDATE_LAST_ACCESS):
+            osc.pt_launch(s, f, pass_id, 5)
+    util.assert_same_bits("driver beauty", out, pb.beauty)

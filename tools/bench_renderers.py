@@ -1,0 +1,85 @@
+"""Frame times of the other renderers behind the same C ABI (secondary numbers; the driver's metric
+is bench.py).  One JSON line per renderer.
+
+    python tools/bench_renderers.py [--steps K]
+
+  path_trace   BASELINE.json configs[1]: bunny-class scene, 512x512, 1 spp, max path length 5
+  rearch       rearchitected ReSTIR (biased / unbiased) on the configs[2] street stand-in, 1920x1080
+  regir        ReGIR path tracer on the street stand-in, 1920x1080, grid 32 x 8 x 32
+  nrc          NRC frame on the street stand-in, 1920x1080 (path trace + inference + 4 training steps)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gfxexp_amd import api  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def timed(ctx, renderer, steps, warmup):
+    import torch
+    for _ in range(warmup):
+        renderer.render_frame()
+    torch.cuda.synchronize()
+    ctx.timing_enable(True)
+    ctx.timing_collect()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        renderer.render_frame()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kernels = {k: round(v[0] / steps, 4) for k, v in sorted(ctx.timing_collect().items(), key=lambda kv: -kv[1][0])}
+    ctx.timing_enable(False)
+    return dt, kernels
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    args = ap.parse_args()
+
+    # configs[1]
+    hs = util.bunny_scene()
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    w = h = 512
+    cfg = api.RestirRenderer.default_config(w, h, api.RENDERER_PATH_TRACE)
+    cfg.camera = api.make_camera(w, h, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+    dt, k = timed(ctx, api.RestirRenderer(ctx, cfg), args.steps * 5, args.warmup)
+    print(json.dumps({"renderer": "path_trace", "workload": "configs[1]: bunny + rectangle light + ground, 512x512, 1 spp, max path length 5",
+                      "ms_per_frame": round(dt * 1e3, 4), "Mpaths_per_s": round(w * h / dt / 1e6, 2), "kernels_ms_per_frame": k}))
+
+    hs = util.bench_street()
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    w, h = 1920, 1080
+    cam = api.make_camera(w, h, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
+    for name, rid in (("rearch_biased", api.RENDERER_REARCH_BIASED), ("rearch_unbiased", api.RENDERER_REARCH_UNBIASED),
+                      ("path_trace_street", api.RENDERER_PATH_TRACE), ("regir", api.RENDERER_PATH_TRACE_REGIR)):
+        cfg = api.RestirRenderer.default_config(w, h, rid)
+        cfg.camera = cam
+        if rid == api.RENDERER_PATH_TRACE_REGIR:
+            b = hs.bounds()
+            for i in range(3):
+                cfg.regirAabbMin[i] = float(b[i]); cfg.regirAabbMax[i] = float(b[3 + i])
+        r = api.RestirRenderer(ctx, cfg)
+        dt, k = timed(ctx, r, args.steps, args.warmup)
+        r.close()
+        print(json.dumps({"renderer": name, "workload": "street stand-in (2.55 M triangles), 1920x1080, 1 spp, reference defaults",
+                          "ms_per_frame": round(dt * 1e3, 4), "Mpaths_per_s": round(w * h / dt / 1e6, 2), "kernels_ms_per_frame": k}))
+    cfg = api.NrcRenderer.default_config(w, h, hs.bounds())
+    cfg.camera = cam
+    r = api.NrcRenderer(ctx, cfg)
+    dt, k = timed(ctx, r, args.steps, args.warmup)
+    print(json.dumps({"renderer": "nrc", "workload": "configs[3] stand-in: street, 1920x1080, hash grid, 2 hidden layers, training on",
+                      "ms_per_frame": round(dt * 1e3, 4), "Mpaths_per_s": round(w * h / dt / 1e6, 2), "stats": r.stats(), "kernels_ms_per_frame": k}))
+
+
+if __name__ == "__main__":
+    main()
