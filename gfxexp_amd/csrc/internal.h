@@ -93,7 +93,7 @@ struct Context {
     DevBuf rearchSlots;
     DevBuf nrcState, neeTrainIdx;
     // build scratch
-    DevBuf bTris, bBoxes, bKeys, bKeysAlt, bVals, bValsAlt, bSortTemp, bNodesLR, bParents, bFlags, bNodeBoxes, bRanges, bQueueA, bQueueB, bCounters;
+    DevBuf bTris, bBoxes, bKeys, bKeysAlt, bVals, bValsAlt, bSortTemp, bNodesLR, bParents, bFlags, bNodeBoxes, bRanges, bQueueA, bQueueB, bCounters, bCosts, bDec;
     // restir
     RestirParams restir;
     gfx_regir_params regir;

@@ -14,6 +14,7 @@
 //                  (the reference grid is 8-bit, common_shared.h:814-851); children are placed in
 //                  octant slots by a greedy auction so traversal needs no sorting.
 //   6. triangles of a node's leaf children are copied contiguously behind the node's triBase.
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "internal.h"
@@ -167,26 +168,78 @@ __global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restr
     if (i == 0) parentInt[0] = 0xFFFFFFFFu;
 }
 
-// ---------------------------------------------------------------- 4. fit
+// ---------------------------------------------------------------- 4. fit + wide-node DP
+// Bottom-up AABBs, and in the same pass the dynamic program of Ylitie, Karras & Laine 2017 (sec. 3)
+// that decides how the binary tree is cut into 8-wide nodes: cost(n, i) = cheapest SAH cost of
+// representing the subtree of n with at most i roots (i = 1..7),
+//   cost(n, 1) = min(leaf: A(n) * cPrim * tris(n) if tris(n) <= maxLeafTris,
+//                    node: A(n) * cNode + distribute(n, 8))
+//   cost(n, i) = min(distribute(n, i), cost(n, i - 1)),   distribute(n, j) = min_k cost(l, k) + cost(r, j - k).
+// dec[n]: nibble i (1..7) = k chosen for distribute(n, i) or 0 = "same as i - 1"; nibble 0 = k of
+// distribute(n, 8); bit 31 = n is cheaper as a leaf.  The collapse follows these decisions top-down.
+constexpr float kCostNode = 1.0f;
+constexpr float kCostPrimDefault = 1.0f;     // a triangle test occupies a lane for one wave iteration, like a node visit
+
+GFX_DEV void dp_leaf_table(float area, float kCostPrim, float c[8]) {
+#pragma unroll
+    for (int i = 1; i <= 7; ++i) c[i] = area * kCostPrim;
+}
+// combine the tables of the two children of a binary node
+GFX_DEV uint32_t dp_combine(const float l[8], const float r[8], float area, uint32_t numTris, uint32_t maxLeafTris, float kCostPrim, float out[8]) {
+    uint32_t dec = 0;
+    float dist[9];
+#pragma unroll
+    for (int j = 2; j <= 8; ++j) {
+        float best = INFINITY; int bk = 1;
+#pragma unroll
+        for (int k = 1; k < j; ++k) {
+            if (k > 7 || j - k > 7) continue;
+            const float v = l[k] + r[j - k];
+            if (v < best) { best = v; bk = k; }
+        }
+        dist[j] = best;
+        if (j == 8) dec |= static_cast<uint32_t>(bk);
+        else dec |= static_cast<uint32_t>(bk) << (4 * j);
+    }
+    const float asNode = area * kCostNode + dist[8];
+    const float asLeaf = numTris <= maxLeafTris ? area * kCostPrim * static_cast<float>(numTris) : INFINITY;
+    out[1] = fminf(asLeaf, asNode);
+    if (asLeaf <= asNode) dec |= 0x80000000u;
+#pragma unroll
+    for (int i = 2; i <= 7; ++i) {
+        if (out[i - 1] <= dist[i]) { out[i] = out[i - 1]; dec &= ~(0xFu << (4 * i)); }
+        else out[i] = dist[i];
+    }
+    return dec;
+}
+
 __global__ void k_fit(const BuildTri* __restrict__ tris, const uint32_t* __restrict__ sortedIdx, int n,
                       const int2* __restrict__ lr, const uint32_t* __restrict__ parentInt, const uint32_t* __restrict__ parentLeaf,
-                      uint32_t* __restrict__ flags, float* nodeBoxes /* 8 floats per internal node */) {
+                      uint32_t* __restrict__ flags, float* nodeBoxes /* 8 floats per internal node */,
+                      const uint2* __restrict__ ranges, uint32_t maxLeafTris, float kCostPrim, float* costs /* 8 floats per internal node */, uint32_t* __restrict__ dec) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t node = parentLeaf[i];
     int cameFrom = ~i;
     Box mine = tri_box(load_tri(tris + sortedIdx[i]));
+    float myCost[8];
+    dp_leaf_table(half_area(mine), kCostPrim, myCost);
     while (true) {
-        // release my subtree's box (internal only; leaf boxes are recomputed from the triangle)
+        // release my subtree's box and cost table (internal only; leaf data is recomputed from the triangle)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t old = atomicAdd(flags + node, 1u);
         if (old == 0) return;                       // first arriver: the sibling finishes this node
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const int2 c = lr[node];
-        const int sib = (c.x == cameFrom) ? c.y : c.x;
+        const bool fromLeft = c.x == cameFrom;
+        const int sib = fromLeft ? c.y : c.x;
         Box sb;
-        if (sib < 0) sb = tri_box(load_tri(tris + sortedIdx[~sib]));
+        float sibCost[8];
+        if (sib < 0) {
+            sb = tri_box(load_tri(tris + sortedIdx[~sib]));
+            dp_leaf_table(half_area(sb), kCostPrim, sibCost);
+        }
         else {
             const float* p = nodeBoxes + 8ull * sib;
             sb.lo = f3(__hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
@@ -195,8 +248,18 @@ __global__ void k_fit(const BuildTri* __restrict__ tris, const uint32_t* __restr
             sb.hi = f3(__hip_atomic_load(p + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                        __hip_atomic_load(p + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                        __hip_atomic_load(p + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const float* q = costs + 8ull * sib;
+#pragma unroll
+            for (int k = 1; k <= 7; ++k) sibCost[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         mine = box_union(mine, sb);
+        const uint2 rg = ranges[node];
+        float merged[8];
+        const uint32_t d = fromLeft ? dp_combine(myCost, sibCost, half_area(mine), rg.y - rg.x + 1, maxLeafTris, kCostPrim, merged)
+                                    : dp_combine(sibCost, myCost, half_area(mine), rg.y - rg.x + 1, maxLeafTris, kCostPrim, merged);
+#pragma unroll
+        for (int k = 1; k <= 7; ++k) myCost[k] = merged[k];
+        dec[node] = d;
         float* q = nodeBoxes + 8ull * node;
         __hip_atomic_store(q + 0, mine.lo.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(q + 1, mine.lo.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -204,6 +267,9 @@ __global__ void k_fit(const BuildTri* __restrict__ tris, const uint32_t* __restr
         __hip_atomic_store(q + 4, mine.hi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(q + 5, mine.hi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(q + 6, mine.hi.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float* cq = costs + 8ull * node;
+#pragma unroll
+        for (int k = 1; k <= 7; ++k) __hip_atomic_store(cq + k, myCost[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (node == 0) return;
         cameFrom = static_cast<int>(node);
         node = parentInt[node];
@@ -237,30 +303,56 @@ GFX_DEV void load_child(int ref, const BuildTri* __restrict__ tris, const uint32
 __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
                                  const uint2* __restrict__ queueIn, uint2* __restrict__ queueOut, uint32_t* __restrict__ counters,
                                  const int2* __restrict__ lr, const uint2* __restrict__ ranges, const float* __restrict__ nodeBoxes,
+                                 const uint32_t* __restrict__ dec, int useDp,
                                  const BuildTri* __restrict__ trisIn, const uint32_t* __restrict__ sortedIdx,
                                  Bvh8Node* __restrict__ nodesOut, Bvh8Tri* __restrict__ trisOut) {
     const uint32_t numItems = counters[2 + level];
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < numItems; item += gridDim.x * blockDim.x) {
         const uint2 work = queueIn[item];       // x = binary node, y = wide node index
         WideChild ch[8];
-        int n = 2;
-        {
+        bool asLeaf[8];
+        int n = 0;
+        if (useDp) {
+            // expand distribute(work.x, 8) along the DP decisions: (ref, i) = "ref gets at most i roots"
+            int stRef[8]; int stI[8]; int sp = 0;
+            {
+                const int2 c = lr[work.x];
+                const int k = static_cast<int>(dec[work.x] & 0xFu);
+                stRef[sp] = c.y; stI[sp] = 8 - k; ++sp;
+                stRef[sp] = c.x; stI[sp] = k; ++sp;
+            }
+            while (sp > 0) {
+                --sp;
+                const int ref = stRef[sp]; int i = stI[sp];
+                if (ref < 0) { load_child(ref, trisIn, sortedIdx, nodeBoxes, ranges, ch[n]); asLeaf[n] = true; ++n; continue; }
+                const uint32_t d = dec[ref];
+                int k = 0;
+                while (i > 1 && (k = static_cast<int>((d >> (4 * i)) & 0xFu)) == 0) --i;   // "same as i - 1"
+                if (i == 1) { load_child(ref, trisIn, sortedIdx, nodeBoxes, ranges, ch[n]); asLeaf[n] = (d >> 31) != 0; ++n; continue; }
+                const int2 c = lr[ref];
+                stRef[sp] = c.y; stI[sp] = i - k; ++sp;
+                stRef[sp] = c.x; stI[sp] = k; ++sp;
+            }
+        }
+        else {
+            n = 2;
             const int2 c = lr[work.x];
             load_child(c.x, trisIn, sortedIdx, nodeBoxes, ranges, ch[0]);
             load_child(c.y, trisIn, sortedIdx, nodeBoxes, ranges, ch[1]);
-        }
-        while (n < 8) {
-            int bestIdx = -1; float bestArea = -INFINITY;
-            for (int k = 0; k < n; ++k) {
-                if (ch[k].ref < 0) continue;
-                const float a = half_area(ch[k].box);
-                if (a > bestArea) { bestArea = a; bestIdx = k; }
+            while (n < 8) {
+                int bestIdx = -1; float bestArea = -INFINITY;
+                for (int k = 0; k < n; ++k) {
+                    if (ch[k].ref < 0) continue;
+                    const float a = half_area(ch[k].box);
+                    if (a > bestArea) { bestArea = a; bestIdx = k; }
+                }
+                if (bestIdx < 0) break;
+                const int2 c2 = lr[ch[bestIdx].ref];
+                load_child(c2.x, trisIn, sortedIdx, nodeBoxes, ranges, ch[bestIdx]);
+                load_child(c2.y, trisIn, sortedIdx, nodeBoxes, ranges, ch[n]);
+                ++n;
             }
-            if (bestIdx < 0) break;
-            const int2 c = lr[ch[bestIdx].ref];
-            load_child(c.x, trisIn, sortedIdx, nodeBoxes, ranges, ch[bestIdx]);
-            load_child(c.y, trisIn, sortedIdx, nodeBoxes, ranges, ch[n]);
-            ++n;
+            for (int k = 0; k < n; ++k) asLeaf[k] = ch[k].last - ch[k].first + 1 <= maxLeafTris;
         }
         // node frame
         Box nb = ch[0].box;
@@ -313,7 +405,7 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
             const int k = kidAt[s];
             if (k < 0) continue;
             const uint32_t cnt = ch[k].last - ch[k].first + 1;
-            if (cnt > maxLeafTris) { imask |= 1u << s; ++numInternal; }
+            if (!asLeaf[k]) { imask |= 1u << s; ++numInternal; }
             else numLeafTris += cnt;
         }
         const uint32_t childBase = numInternal ? atomicAdd(counters + 0, numInternal) : 0xFFFFFFFFu;
@@ -458,8 +550,14 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
         hipLaunchKernelGGL(k_karras, grd, blk, 0, stream, keys, static_cast<int>(n), ctx.bNodesLR.as<int2>(), parentInt, parentLeaf,
                            ctx.bRanges.as<uint2>());
         GFX_HIP(hipMemsetAsync(ctx.bFlags.p, 0, 4ull * n, stream));
+        ctx.bCosts.reserve(32ull * n); ctx.bDec.reserve(4ull * n);
+        static float costPrim = -1.0f;
+        if (costPrim < 0) { const char* e = getenv("GFX_BVH_CPRIM"); costPrim = e ? static_cast<float>(atof(e)) : kCostPrimDefault; if (!(costPrim > 0)) costPrim = kCostPrimDefault; }
         hipLaunchKernelGGL(k_fit, grd, blk, 0, stream, ctx.bTris.as<BuildTri>(), sortedIdx, static_cast<int>(n), ctx.bNodesLR.as<int2>(),
-                           parentInt, parentLeaf, ctx.bFlags.as<uint32_t>(), ctx.bNodeBoxes.as<float>());
+                           parentInt, parentLeaf, ctx.bFlags.as<uint32_t>(), ctx.bNodeBoxes.as<float>(),
+                           ctx.bRanges.as<uint2>(), ctx.maxLeafTris, costPrim, ctx.bCosts.as<float>(), ctx.bDec.as<uint32_t>());
+        static int useDp = -1;   // GFX_BVH_COLLAPSE=greedy: open the largest-area child until 8 (the reference's rule)
+        if (useDp < 0) { const char* e = getenv("GFX_BVH_COLLAPSE"); useDp = (e && std::strcmp(e, "greedy") == 0) ? 0 : 1; }
         // level 0 work item: binary root 0 -> wide node 0
         const uint2 rootItem = make_uint2(0u, 0u);
         GFX_HIP(hipMemcpyAsync(ctx.bQueueA.p, &rootItem, sizeof(rootItem), hipMemcpyHostToDevice, stream));
@@ -469,6 +567,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
             uint2* qout = (level & 1) ? ctx.bQueueA.as<uint2>() : ctx.bQueueB.as<uint2>();
             hipLaunchKernelGGL(k_collapse_level, dim3(gridC), dim3(256), 0, stream, level, ctx.maxLeafTris, qin, qout, counters,
                                ctx.bNodesLR.as<int2>(), ctx.bRanges.as<uint2>(), ctx.bNodeBoxes.as<float>(),
+                               ctx.bDec.as<uint32_t>(), useDp,
                                ctx.bTris.as<BuildTri>(), sortedIdx, out.nodes.as<Bvh8Node>(), out.tris.as<Bvh8Tri>());
         }
         GFX_HIP(hipGetLastError());

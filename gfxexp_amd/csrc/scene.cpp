@@ -13,7 +13,7 @@ Context::~Context() {
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
                       &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral,
-                      &dTraceDiag, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
+                      &dTraceDiag, &bCosts, &bDec, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
                       &rearchSlots, &nrcState, &neeTrainIdx };
     for (NrcNet* net : nrcNets) if (net) nrc_destroy(net);
     for (DevBuf* b : all) b->release();
