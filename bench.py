@@ -180,7 +180,7 @@ def roofline(ctx, renderer, stream, steps, W, H):
     # one frame = 1 closest launch (16 B out) + 2 any-hit launches (4 B out); counters cover all of them
     rays_closest = W * H
     rays_any = c["rays"] - rays_closest
-    bytes_frame = c["nodeFetches"] * 64 + c["triFetches"] * 64 + rays_closest * (32 + 16) + rays_any * (32 + 4)
+    bytes_frame = c["nodeFetches"] * (64 + 16) + c["triFetches"] * 64 + rays_closest * (32 + 16) + rays_any * (32 + 4)   # node = 64-B record + 16-B link
     achieved = bytes_frame / (trav_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": "k_trace<closest|any> (software BVH8 traversal; 3 launches per frame)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

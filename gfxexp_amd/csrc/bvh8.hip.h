@@ -5,7 +5,8 @@
 // (common/bvh_builder.cpp:1251-1270, bit-identical arithmetic so hits agree with the CPU oracle),
 // exclusive (tmin, tmax) intervals, and the idea of 2-dword "group" stack entries.  What is
 // different, by design for wave64 SIMT:
-//   * 64-byte nodes with 6-bit child boxes (device_types.h) -> 4 aligned dwordx4 loads per visit;
+//   * 64-byte nodes with 8-bit child boxes, one byte per plane value (device_types.h) + a 16-byte
+//     link record -> five aligned dwordx4 loads per visit, one v_cvt_f32_ubyteN per plane;
 //   * children visited in (slot XOR ray-octant) order -- no per-node sorting network;
 //   * the stack lives in LDS, one 8-byte column per lane ([depth][lane] => conflict-free
 //     ds_read/write_b64), spilling to a per-lane HBM area past kLdsStackDepth entries;
@@ -77,8 +78,7 @@ struct Traversal {
     uint2 grp;
     uint32_t oct;
     uint32_t triBase, triMask;
-    uint32_t offNx, offFx, offNy, offFy;   // bit offsets of the near / far plane fields per axis
-    bool zNeg;
+    bool xNeg, yNeg, zNeg;                 // the ray travels toward -k: near plane = hi, far plane = lo
     bool active;
 
     GFX_DEV void begin(f3 o, f3 d, float t0, float t1, LaneStack& stack, bool hasNodes) {
@@ -91,9 +91,7 @@ struct Traversal {
         hit.t = t1; hit.bcB = 0; hit.bcC = 0; hit.tri = GFX_INVALID_SLOT;
         // octant mask: bit k set when the ray travels toward -k, so (slot ^ oct) ascending = near to far
         oct = (dx < 0 ? 1u : 0u) | (dy < 0 ? 2u : 0u) | (dz < 0 ? 4u : 0u);
-        offNx = dx < 0 ? 18u : 0u; offFx = dx < 0 ? 0u : 18u;
-        offNy = dy < 0 ? 24u : 6u; offFy = dy < 0 ? 6u : 24u;
-        zNeg = dz < 0;
+        xNeg = dx < 0; yNeg = dy < 0; zNeg = dz < 0;
         // current group: x = index of the first internal child; y = hit bits | imask << 8.
         // Hit bit p stands for child slot (p ^ oct).  The root is a one-child group: slot 0
         // (bit 0 ^ oct), empty imask -> node index 0.
@@ -147,21 +145,24 @@ struct Traversal {
         return true;
     }
 
-    // One node (device_types.h Bvh8Node): 8 slab tests, leaf hits -> triangle mask, node hits -> group.
+    // One node (device_types.h Bvh8Node + Bvh8Link): 8 slab tests, leaf hits -> triangle mask, node hits -> group.
     template <bool COUNT>
-    GFX_DEV void process_node(uint4 n0, uint4 n1, uint4 n2, uint4 n3, LaneStack& stack, TraceCounters& cnt) {
+    GFX_DEV void process_node(uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint4 link, LaneStack& stack, TraceCounters& cnt) {
         if (COUNT) ++cnt.nodes;
         const f3 origin(bits2f(n0.x), bits2f(n0.y), bits2f(n0.z));
         const f3 scale(bits2f(bfe(n0.w, 0, 8) << 23), bits2f(bfe(n0.w, 8, 8) << 23), bits2f(bfe(n0.w, 16, 8) << 23));
         const uint32_t imask = n0.w >> 24;
-        const uint32_t cw[8] = { n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y };
-        const uint32_t zb[2] = { n3.z, n3.w };
+        const uint32_t valid = link.z;
+        // plane bytes: lo.x = n1.xy, lo.y = n1.zw, lo.z = n2.xy, hi.x = n2.zw, hi.y = n3.xy, hi.z = n3.zw
+        const uint32_t nx[2] = { xNeg ? n2.z : n1.x, xNeg ? n2.w : n1.y }, fx[2] = { xNeg ? n1.x : n2.z, xNeg ? n1.y : n2.w };
+        const uint32_t ny[2] = { yNeg ? n3.x : n1.z, yNeg ? n3.y : n1.w }, fy[2] = { yNeg ? n1.z : n3.x, yNeg ? n1.w : n3.y };
+        const uint32_t nz[2] = { zNeg ? n3.z : n2.x, zNeg ? n3.w : n2.y }, fz[2] = { zNeg ? n2.x : n3.z, zNeg ? n2.y : n3.w };
 
         const f3 B = scale * inv;
         const f3 A = (origin - org) * inv;
-        const f3 m(fmaxf(fabsf(origin.x), fabsf(origin.x + 63.0f * scale.x)) + fabsf(org.x),
-                   fmaxf(fabsf(origin.y), fabsf(origin.y + 63.0f * scale.y)) + fabsf(org.y),
-                   fmaxf(fabsf(origin.z), fabsf(origin.z + 63.0f * scale.z)) + fabsf(org.z));
+        const f3 m(fmaxf(fabsf(origin.x), fabsf(origin.x + 255.0f * scale.x)) + fabsf(org.x),
+                   fmaxf(fabsf(origin.y), fabsf(origin.y + 255.0f * scale.y)) + fabsf(org.y),
+                   fmaxf(fabsf(origin.z), fabsf(origin.z + 255.0f * scale.z)) + fabsf(org.z));
         const f3 slack(m.x * fabsf(inv.x) * 4.76837158203125e-07f, m.y * fabsf(inv.y) * 4.76837158203125e-07f,
                        m.z * fabsf(inv.z) * 4.76837158203125e-07f);
         const f3 An = A - slack, Af = A + slack;
@@ -171,30 +172,27 @@ struct Traversal {
         uint32_t triOff = 0;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const uint32_t w = cw[s];
-            const uint32_t zc = bfe(zb[s >> 2], (s & 3) * 8, 8);
-            const uint32_t count = (w >> 30) | ((zc >> 6) << 2);
+            const int w = s >> 2, sh = (s & 3) * 8;
             const bool internal = (imask >> s) & 1u;
-            const uint32_t zlo = bfe(w, 12, 6), zhi = zc & 63u;
-            const float tnx = fmaf(static_cast<float>((w >> offNx) & 63u), B.x, An.x);
-            const float tny = fmaf(static_cast<float>((w >> offNy) & 63u), B.y, An.y);
-            const float tnz = fmaf(static_cast<float>(zNeg ? zhi : zlo), B.z, An.z);
-            const float tfx = fmaf(static_cast<float>((w >> offFx) & 63u), B.x, Af.x);
-            const float tfy = fmaf(static_cast<float>((w >> offFy) & 63u), B.y, Af.y);
-            const float tfz = fmaf(static_cast<float>(zNeg ? zlo : zhi), B.z, Af.z);
+            const float tnx = fmaf(static_cast<float>((nx[w] >> sh) & 0xFFu), B.x, An.x);
+            const float tny = fmaf(static_cast<float>((ny[w] >> sh) & 0xFFu), B.y, An.y);
+            const float tnz = fmaf(static_cast<float>((nz[w] >> sh) & 0xFFu), B.z, An.z);
+            const float tfx = fmaf(static_cast<float>((fx[w] >> sh) & 0xFFu), B.x, Af.x);
+            const float tfy = fmaf(static_cast<float>((fy[w] >> sh) & 0xFFu), B.y, Af.y);
+            const float tfz = fmaf(static_cast<float>((fz[w] >> sh) & 0xFFu), B.z, Af.z);
             const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
             const float tf = fminf(fminf(tfx, tfy), fminf(tfz, hit.t));
-            const bool boxHit = (tn <= tf) && count != 0;
-            if (boxHit) {
+            const bool present = (valid >> s) & 1u;
+            if ((tn <= tf) && present) {
                 if (internal) nodeHits |= 1u << (s ^ oct);
-                else leafMask |= ((1u << count) - 1u) << triOff;
+                else leafMask |= 1u << triOff;
             }
-            triOff += internal ? 0u : count;
+            triOff += (present && !internal) ? 1u : 0u;
         }
-        if (leafMask) { triMask = leafMask; triBase = n1.y; }
+        if (leafMask) { triMask = leafMask; triBase = link.y; }
         if (nodeHits) {
             if (grp.y & 0xFFu) stack.push(grp, cnt, COUNT);
-            grp = make_uint2(n1.x, nodeHits | (imask << 8));
+            grp = make_uint2(link.x, nodeHits | (imask << 8));
         }
     }
 };

@@ -95,20 +95,24 @@ struct DevScene {
 };
 
 // ---------------------------------------------------------------- BVH8 in HBM
-// 64-byte wide node (one aligned half cache line; four dwordx4 loads per visit).
-//   w[0..2]  quantisation origin (fp32)
-//   w[3]     ex | ey << 8 | ez << 16 | imask << 24     (scale_k = 2^(e_k - 127), 6-bit grid)
-//   w[4]     index of the first internal child (children are contiguous, slot order)
-//   w[5]     index of the first triangle record of this node's leaf children (contiguous, slot order)
-//   w[6+s]   child s: qminx | qminy<<6 | qminz<<12 | qmaxx<<18 | qmaxy<<24 | (count & 3) << 30
-//   w[14..15] bytes: child s: qmaxz | (count >> 2) << 6
-// count: number of triangles of a leaf child (1..4; the field has room for 15), 1 for an internal
-// child, 0 = empty slot.  A node's leaf triangles total <= 32 so traversal tracks them in one mask.
+// 64-byte wide node (one aligned half cache line, fetched cooperatively by four lanes) + a 16-byte
+// link record in a parallel array (one extra dwordx4 per visit).
+//   w[0..2]   quantisation origin (fp32)
+//   w[3]      ex | ey << 8 | ez << 16 | imask << 24     (scale_k = 2^(e_k - 127), 8-bit grid)
+//   w[4..15]  48 plane bytes, one byte per (plane, child): lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8];
+//             child s of plane p = byte (s & 3) of dword 4 + 2 p + (s >> 2), so every plane value is one
+//             v_cvt_f32_ubyteN away from a float (the 6-bit packing this replaces cost a bfe + cvt pair).
+//   link      { first internal child (children are contiguous, slot order),
+//               first triangle record of the leaf children (contiguous, slot order), valid-slot mask, 0 }
+// A leaf child holds exactly one triangle (the SAH dynamic program of the builder fills all eight
+// slots before it would ever pack triangles together), so there is no per-child count.
 // Child slots are assigned so that slot bit k set <=> child lies on the +k side of the node centre
 // (greedy auction as in Ylitie et al. 2017), which lets traversal order children by
 // (slot XOR ray-octant) without sorting.  The reference layout is the 80-byte
 // CompressedInternalNode_T<8> (common/common_shared.h:756-917).
 struct Bvh8Node { uint32_t w[16]; };
+struct Bvh8Link { uint32_t childBase, triBase, valid, pad; };
+static_assert(sizeof(Bvh8Link) == 16, "Bvh8Link must be 16 bytes");
 static_assert(sizeof(Bvh8Node) == 64, "Bvh8Node must be 64 bytes");
 
 // 64-byte triangle record: shared::TriangleStorage (common/common_shared.h:1017-1025, 48 B) plus
@@ -133,6 +137,7 @@ static_assert(sizeof(BuildTri) == 48, "BuildTri must be 48 bytes");
 
 struct DevAccel {
     const Bvh8Node* nodes;
+    const Bvh8Link* links;   // per node
     const Bvh8Tri* tris;
     uint32_t numNodes;
     uint32_t numTris;

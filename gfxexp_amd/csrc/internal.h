@@ -41,10 +41,10 @@ struct HostInstance {
 };
 
 struct Accel {
-    DevBuf nodes, tris, triIds;
+    DevBuf nodes, links, tris, triIds;
     uint32_t numNodes = 0, numTris = 0, numInputTris = 0, maxDepth = 0;
     DevAccel dev() const {
-        DevAccel a; a.nodes = nodes.as<Bvh8Node>(); a.tris = tris.as<Bvh8Tri>(); a.numNodes = numNodes; a.numTris = numTris;
+        DevAccel a; a.nodes = nodes.as<Bvh8Node>(); a.links = links.as<Bvh8Link>(); a.tris = tris.as<Bvh8Tri>(); a.numNodes = numNodes; a.numTris = numTris;
         return a;
     }
 };

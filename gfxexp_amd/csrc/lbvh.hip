@@ -305,7 +305,7 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
                                  const int2* __restrict__ lr, const uint2* __restrict__ ranges, const float* __restrict__ nodeBoxes,
                                  const uint32_t* __restrict__ dec, int useDp,
                                  const BuildTri* __restrict__ trisIn, const uint32_t* __restrict__ sortedIdx,
-                                 Bvh8Node* __restrict__ nodesOut, Bvh8Tri* __restrict__ trisOut) {
+                                 Bvh8Node* __restrict__ nodesOut, Bvh8Link* __restrict__ linksOut, Bvh8Tri* __restrict__ trisOut) {
     const uint32_t numItems = counters[2 + level];
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < numItems; item += gridDim.x * blockDim.x) {
         const uint2 work = queueIn[item];       // x = binary node, y = wide node index
@@ -352,7 +352,7 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
                 load_child(c2.y, trisIn, sortedIdx, nodeBoxes, ranges, ch[n]);
                 ++n;
             }
-            for (int k = 0; k < n; ++k) asLeaf[k] = ch[k].last - ch[k].first + 1 <= maxLeafTris;
+            for (int k = 0; k < n; ++k) asLeaf[k] = ch[k].last == ch[k].first;
         }
         // node frame
         Box nb = ch[0].box;
@@ -365,10 +365,10 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
             const float org[3] = { origin.x, origin.y, origin.z };
             const float top[3] = { nb.hi.x, nb.hi.y, nb.hi.z };
             for (int a = 0; a < 3; ++a) {
-                const uint32_t us = f2bits(ext[a] / 63.0f);
+                const uint32_t us = f2bits(ext[a] / 255.0f);
                 uint32_t e = (us >> 23) + ((us & 0x7FFFFFu) ? 1u : 0u);
-                // the decoded far end origin + 63 * scale must not round below the true maximum
-                while (e < 254u && org[a] + 63.0f * bits2f(e << 23) < top[a]) ++e;
+                // the decoded far end origin + 255 * scale must not round below the true maximum
+                while (e < 254u && org[a] + 255.0f * bits2f(e << 23) < top[a]) ++e;
                 ex[a] = e; scale[a] = bits2f(e << 23);
             }
         }
@@ -404,9 +404,8 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
         for (int s = 0; s < 8; ++s) {
             const int k = kidAt[s];
             if (k < 0) continue;
-            const uint32_t cnt = ch[k].last - ch[k].first + 1;
             if (!asLeaf[k]) { imask |= 1u << s; ++numInternal; }
-            else numLeafTris += cnt;
+            else numLeafTris += 1;
         }
         const uint32_t childBase = numInternal ? atomicAdd(counters + 0, numInternal) : 0xFFFFFFFFu;
         const uint32_t triBase = numLeafTris ? atomicAdd(counters + 1, numLeafTris) : 0xFFFFFFFFu;
@@ -415,42 +414,43 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
         Bvh8Node node;
         node.w[0] = f2bits(origin.x); node.w[1] = f2bits(origin.y); node.w[2] = f2bits(origin.z);
         node.w[3] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);
-        node.w[4] = childBase; node.w[5] = triBase;
-        node.w[14] = 0; node.w[15] = 0;
-        uint32_t internalRank = 0, triOff = 0;
+        // empty slots: inverted box (lo 255 / hi 0); the valid mask of the link record is what traversal trusts
+        for (int k = 4; k < 10; ++k) node.w[k] = 0xFFFFFFFFu;
+        for (int k = 10; k < 16; ++k) node.w[k] = 0u;
+        uint32_t internalRank = 0, triOff = 0, validMask = 0;
         const float org[3] = { origin.x, origin.y, origin.z };
         for (int s = 0; s < 8; ++s) {
             const int k = kidAt[s];
-            if (k < 0) { node.w[6 + s] = 0; continue; }
+            if (k < 0) continue;
+            validMask |= 1u << s;
             const float lo[3] = { ch[k].box.lo.x, ch[k].box.lo.y, ch[k].box.lo.z };
             const float hi[3] = { ch[k].box.hi.x, ch[k].box.hi.y, ch[k].box.hi.z };
-            uint32_t qlo[3], qhi[3];
             for (int a = 0; a < 3; ++a) {
                 uint32_t l = 0, h = 1;
                 if (scale[a] > 0.0f) {
-                    l = min(f2u_sat((lo[a] - org[a]) / scale[a]), 63u);
-                    h = min(f2u_sat((hi[a] - org[a]) / scale[a]) + 1u, 63u);
+                    l = min(f2u_sat((lo[a] - org[a]) / scale[a]), 254u);
+                    h = min(f2u_sat((hi[a] - org[a]) / scale[a]) + 1u, 255u);
                 }
                 // make the DECODED box (origin + q * scale, as traversal computes it) contain the child
                 while (l > 0 && org[a] + static_cast<float>(l) * scale[a] > lo[a]) --l;
-                while (h < 63 && org[a] + static_cast<float>(h) * scale[a] < hi[a]) ++h;
-                qlo[a] = l; qhi[a] = h;
+                while (h < 255 && org[a] + static_cast<float>(h) * scale[a] < hi[a]) ++h;
+                const uint32_t shift = (s & 3) * 8;
+                uint32_t& wl = node.w[4 + 2 * a + (s >> 2)];
+                uint32_t& wh = node.w[10 + 2 * a + (s >> 2)];
+                wl = (wl & ~(0xFFu << shift)) | (l << shift);
+                wh = (wh & ~(0xFFu << shift)) | (h << shift);
             }
-            const uint32_t cnt = ch[k].last - ch[k].first + 1;
             const bool internal = (imask >> s) & 1u;
-            const uint32_t count = internal ? 1u : cnt;
-            node.w[6 + s] = qlo[0] | (qlo[1] << 6) | (qlo[2] << 12) | (qhi[0] << 18) | (qhi[1] << 24) | ((count & 3u) << 30);
-            node.w[14 + (s >> 2)] |= (qhi[2] | ((count >> 2) << 6)) << ((s & 3) * 8);
             if (internal) {
                 queueOut[qBase + internalRank] = make_uint2(static_cast<uint32_t>(ch[k].ref), childBase + internalRank);
                 ++internalRank;
             }
             else {
-                for (uint32_t t = 0; t < cnt; ++t)
-                    store_final_tri(trisOut + triBase + triOff + t, load_tri(trisIn + sortedIdx[ch[k].first + t]));
-                triOff += cnt;
+                store_final_tri(trisOut + triBase + triOff, load_tri(trisIn + sortedIdx[ch[k].first]));
+                ++triOff;
             }
         }
+        reinterpret_cast<uint4*>(linksOut)[work.y] = make_uint4(childBase, triBase, validMask, 0u);
         uint4* dst = reinterpret_cast<uint4*>(nodesOut + work.y);
         dst[0] = make_uint4(node.w[0], node.w[1], node.w[2], node.w[3]);
         dst[1] = make_uint4(node.w[4], node.w[5], node.w[6], node.w[7]);
@@ -460,32 +460,32 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
 }
 
 // single-triangle scene: one node, one leaf child in slot 0
-__global__ void k_single_tri_root(const BuildTri* __restrict__ trisIn, Bvh8Node* __restrict__ nodesOut, Bvh8Tri* __restrict__ trisOut) {
+__global__ void k_single_tri_root(const BuildTri* __restrict__ trisIn, Bvh8Node* __restrict__ nodesOut, Bvh8Link* __restrict__ linksOut, Bvh8Tri* __restrict__ trisOut) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const BuildTri t = load_tri(trisIn);
     const Box b = tri_box(t);
     Bvh8Node node;
-    for (int i = 0; i < 16; ++i) node.w[i] = 0;
     node.w[0] = f2bits(b.lo.x); node.w[1] = f2bits(b.lo.y); node.w[2] = f2bits(b.lo.z);
     uint32_t ex[3];
     const float ext[3] = { b.hi.x - b.lo.x, b.hi.y - b.lo.y, b.hi.z - b.lo.z };
     const float org[3] = { b.lo.x, b.lo.y, b.lo.z };
     const float top[3] = { b.hi.x, b.hi.y, b.hi.z };
     for (int a = 0; a < 3; ++a) {
-        const uint32_t us = f2bits(ext[a] / 63.0f);
+        const uint32_t us = f2bits(ext[a] / 255.0f);
         uint32_t e = (us >> 23) + ((us & 0x7FFFFFu) ? 1u : 0u);
-        while (e < 254u && org[a] + 63.0f * bits2f(e << 23) < top[a]) ++e;
+        while (e < 254u && org[a] + 255.0f * bits2f(e << 23) < top[a]) ++e;
         ex[a] = e;
     }
     node.w[3] = ex[0] | (ex[1] << 8) | (ex[2] << 16);
-    node.w[4] = 0xFFFFFFFFu; node.w[5] = 0;
-    node.w[6] = 0u | (63u << 18) | (63u << 24) | (1u << 30);   // whole frame, count = 1
-    node.w[14] = 63u;
+    for (int k = 4; k < 10; ++k) node.w[k] = 0xFFFFFF00u;      // slot 0: lo = 0 on every axis; other slots empty
+    for (int k = 10; k < 16; ++k) node.w[k] = 0x000000FFu;     // slot 0: hi = 255 (the whole frame)
+    for (int a = 0; a < 3; ++a) { node.w[5 + 2 * a] = 0xFFFFFFFFu; node.w[11 + 2 * a] = 0u; }
     uint4* dst = reinterpret_cast<uint4*>(nodesOut);
     dst[0] = make_uint4(node.w[0], node.w[1], node.w[2], node.w[3]);
     dst[1] = make_uint4(node.w[4], node.w[5], node.w[6], node.w[7]);
     dst[2] = make_uint4(node.w[8], node.w[9], node.w[10], node.w[11]);
     dst[3] = make_uint4(node.w[12], node.w[13], node.w[14], node.w[15]);
+    reinterpret_cast<uint4*>(linksOut)[0] = make_uint4(0xFFFFFFFFu, 0u, 1u, 0u);
     store_final_tri(trisOut, t);
 }
 
@@ -516,6 +516,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
     ctx.bQueueA.reserve(8ull * n + 16); ctx.bQueueB.reserve(8ull * n + 16);
     ctx.bCounters.reserve(4 * (2 + kMaxCollapseLevels + 2) + 64);
     out.nodes.reserve(sizeof(Bvh8Node) * static_cast<size_t>(n));
+    out.links.reserve(sizeof(Bvh8Link) * static_cast<size_t>(n));
     out.tris.reserve(sizeof(Bvh8Tri) * static_cast<size_t>(n));
     out.triIds.reserve(sizeof(gfx_tri_ids) * static_cast<size_t>(n));
 
@@ -532,7 +533,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
     hipLaunchKernelGGL(k_flatten, grd, blk, 0, stream, ctx.devScene(), ctx.dFlatGeoms.as<DevFlatGeom>(), numFlat, n,
                        ctx.bTris.as<BuildTri>(), bounds);
     if (n == 1) {
-        hipLaunchKernelGGL(k_single_tri_root, dim3(1), dim3(64), 0, stream, ctx.bTris.as<BuildTri>(), out.nodes.as<Bvh8Node>(), out.tris.as<Bvh8Tri>());
+        hipLaunchKernelGGL(k_single_tri_root, dim3(1), dim3(64), 0, stream, ctx.bTris.as<BuildTri>(), out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>(), out.tris.as<Bvh8Tri>());
         out.numNodes = 1; out.numTris = 1; out.maxDepth = 1;
     }
     else {
@@ -555,7 +556,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
         if (costPrim < 0) { const char* e = getenv("GFX_BVH_CPRIM"); costPrim = e ? static_cast<float>(atof(e)) : kCostPrimDefault; if (!(costPrim > 0)) costPrim = kCostPrimDefault; }
         hipLaunchKernelGGL(k_fit, grd, blk, 0, stream, ctx.bTris.as<BuildTri>(), sortedIdx, static_cast<int>(n), ctx.bNodesLR.as<int2>(),
                            parentInt, parentLeaf, ctx.bFlags.as<uint32_t>(), ctx.bNodeBoxes.as<float>(),
-                           ctx.bRanges.as<uint2>(), ctx.maxLeafTris, costPrim, ctx.bCosts.as<float>(), ctx.bDec.as<uint32_t>());
+                           ctx.bRanges.as<uint2>(), 1u /* one triangle per leaf slot */, costPrim, ctx.bCosts.as<float>(), ctx.bDec.as<uint32_t>());
         static int useDp = -1;   // GFX_BVH_COLLAPSE=greedy: open the largest-area child until 8 (the reference's rule)
         if (useDp < 0) { const char* e = getenv("GFX_BVH_COLLAPSE"); useDp = (e && std::strcmp(e, "greedy") == 0) ? 0 : 1; }
         // level 0 work item: binary root 0 -> wide node 0
@@ -568,7 +569,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
             hipLaunchKernelGGL(k_collapse_level, dim3(gridC), dim3(256), 0, stream, level, ctx.maxLeafTris, qin, qout, counters,
                                ctx.bNodesLR.as<int2>(), ctx.bRanges.as<uint2>(), ctx.bNodeBoxes.as<float>(),
                                ctx.bDec.as<uint32_t>(), useDp,
-                               ctx.bTris.as<BuildTri>(), sortedIdx, out.nodes.as<Bvh8Node>(), out.tris.as<Bvh8Tri>());
+                               ctx.bTris.as<BuildTri>(), sortedIdx, out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>(), out.tris.as<Bvh8Tri>());
         }
         GFX_HIP(hipGetLastError());
         std::vector<uint32_t> h(2 + kMaxCollapseLevels + 2);

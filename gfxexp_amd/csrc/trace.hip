@@ -140,6 +140,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
             ++diagIter; diagLanes += held;
             if (exhausted) { ++diagDrainIter; diagDrainLanes += held; }
         }
+        uint4 link = make_uint4(0u, 0u, 0u, 0u);
+        if (code != kItemNone && !(code & kItemTri)) link = reinterpret_cast<const uint4*>(a.accel.links)[code];   // in flight with the item fetch
         uint4 q0, q1, q2, q3;
         fetch_items(code, a.accel, waveBuf, lane, q0, q1, q2, q3);
         if (code != kItemNone) {
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
                 if (!tr.template process_triangle<ANY_HIT, COUNT>(code & 0x7FFFFFFFu, q0, q1, q2, q3, a.accel.tris, cnt))
                     write_result();                         // any-hit ray found its occluder
             }
-            else tr.template process_node<COUNT>(q0, q1, q2, q3, stack, cnt);
+            else tr.template process_node<COUNT>(q0, q1, q2, q3, link, stack, cnt);
         }
     }
     if (COUNT && a.diag && lane == 0) {
