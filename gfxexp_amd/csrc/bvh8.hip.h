@@ -102,12 +102,17 @@ struct Traversal {
     }
 
     // Which 64-byte item does this lane need next?  kItemNone = the ray has finished.
-    GFX_DEV uint32_t next_item(LaneStack& stack) {
-        if (triMask) {
-            const uint32_t bit = __builtin_ctz(triMask);
+    // Triangle items are numbered behind the nodes (item = triItemOffset + triangle index): one base
+    // address serves both kinds.
+    GFX_DEV uint32_t next_item(LaneStack& stack, uint32_t triItemOffset) {
+        if (triMask & 0xFFu) {
+            // triMask: bits 0-7 hit leaf slots still to test, bits 8-15 all leaf slots of that node;
+            // the triangles of a node's leaf children sit behind triBase in slot order
+            const uint32_t slot = __builtin_ctz(triMask);
             triMask &= triMask - 1u;
-            return kItemTri | (triBase + bit);
+            return kItemTri | (triItemOffset + triBase + __builtin_popcount((triMask >> 8) & ((1u << slot) - 1u)));
         }
+        triMask = 0;
         uint32_t hits = grp.y & 0xFFu;
         if (hits == 0) {
             if (stack.sp == 0) { active = false; return kItemNone; }
@@ -167,13 +172,11 @@ struct Traversal {
                        m.z * fabsf(inv.z) * 4.76837158203125e-07f);
         const f3 An = A - slack, Af = A + slack;
 
-        uint32_t nodeHits = 0;     // hit internal children, bit (slot ^ oct)
-        uint32_t leafMask = 0;     // triangles of hit leaf children, bit = offset from triBase
-        uint32_t triOff = 0;
+        // branch-free: one bit per hit SLOT, classified after the loop
+        uint32_t hitSlots = 0;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int w = s >> 2, sh = (s & 3) * 8;
-            const bool internal = (imask >> s) & 1u;
             const float tnx = fmaf(static_cast<float>((nx[w] >> sh) & 0xFFu), B.x, An.x);
             const float tny = fmaf(static_cast<float>((ny[w] >> sh) & 0xFFu), B.y, An.y);
             const float tnz = fmaf(static_cast<float>((nz[w] >> sh) & 0xFFu), B.z, An.z);
@@ -182,13 +185,18 @@ struct Traversal {
             const float tfz = fmaf(static_cast<float>((fz[w] >> sh) & 0xFFu), B.z, Af.z);
             const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
             const float tf = fminf(fminf(tfx, tfy), fminf(tfz, hit.t));
-            const bool present = (valid >> s) & 1u;
-            if ((tn <= tf) && present) {
-                if (internal) nodeHits |= 1u << (s ^ oct);
-                else leafMask |= 1u << triOff;
-            }
-            triOff += (present && !internal) ? 1u : 0u;
+            hitSlots |= (tn <= tf) ? (1u << s) : 0u;
         }
+        hitSlots &= valid;
+        // internal children in (slot ^ oct) order: XOR-permute the 8 bit positions with three conditional swaps
+        uint32_t nodeHits = hitSlots & imask;
+        nodeHits = (oct & 1u) ? (((nodeHits & 0x55u) << 1) | ((nodeHits & 0xAAu) >> 1)) : nodeHits;
+        nodeHits = (oct & 2u) ? (((nodeHits & 0x33u) << 2) | ((nodeHits & 0xCCu) >> 2)) : nodeHits;
+        nodeHits = (oct & 4u) ? (((nodeHits & 0x0Fu) << 4) | ((nodeHits & 0xF0u) >> 4)) : nodeHits;
+        // leaf children: keep the hit slots and the node's leaf-slot set; the rank (= triangle offset) is
+        // taken when the triangle is fetched (next_item)
+        const uint32_t leafBits = valid & ~imask;
+        const uint32_t leafMask = (hitSlots & leafBits) ? ((hitSlots & leafBits) | (leafBits << 8)) : 0u;
         if (leafMask) { triMask = leafMask; triBase = link.y; }
         if (nodeHits) {
             if (grp.y & 0xFFu) stack.push(grp, cnt, COUNT);

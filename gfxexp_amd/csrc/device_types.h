@@ -141,6 +141,7 @@ struct DevAccel {
     const Bvh8Tri* tris;
     uint32_t numNodes;
     uint32_t numTris;
+    uint32_t triItemOffset;  // tris == reinterpret_cast<const Bvh8Tri*>(nodes + triItemOffset)
 };
 
 } // namespace gfx

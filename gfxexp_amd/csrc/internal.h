@@ -41,10 +41,15 @@ struct HostInstance {
 };
 
 struct Accel {
-    DevBuf nodes, links, tris, triIds;
+    // nodes and triangle records are both 64-byte items and live in ONE allocation (nodes first, triangle
+    // records from item `triItemOffset`), so the traversal kernel fetches any item as base + (index << 6)
+    DevBuf nodes, links, triIds;
+    uint32_t triItemOffset = 0;
     uint32_t numNodes = 0, numTris = 0, numInputTris = 0, maxDepth = 0;
+    Bvh8Tri* trisPtr() const { return reinterpret_cast<Bvh8Tri*>(nodes.as<Bvh8Node>() + triItemOffset); }
     DevAccel dev() const {
-        DevAccel a; a.nodes = nodes.as<Bvh8Node>(); a.links = links.as<Bvh8Link>(); a.tris = tris.as<Bvh8Tri>(); a.numNodes = numNodes; a.numTris = numTris;
+        DevAccel a; a.nodes = nodes.as<Bvh8Node>(); a.links = links.as<Bvh8Link>(); a.tris = trisPtr(); a.numNodes = numNodes; a.numTris = numTris;
+        a.triItemOffset = triItemOffset;
         return a;
     }
 };

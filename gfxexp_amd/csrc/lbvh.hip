@@ -515,9 +515,9 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
     ctx.bNodeBoxes.reserve(32ull * n); ctx.bRanges.reserve(8ull * n);
     ctx.bQueueA.reserve(8ull * n + 16); ctx.bQueueB.reserve(8ull * n + 16);
     ctx.bCounters.reserve(4 * (2 + kMaxCollapseLevels + 2) + 64);
-    out.nodes.reserve(sizeof(Bvh8Node) * static_cast<size_t>(n));
+    out.nodes.reserve(sizeof(Bvh8Node) * 2 * static_cast<size_t>(n));   // n node slots + n triangle records
+    out.triItemOffset = n;
     out.links.reserve(sizeof(Bvh8Link) * static_cast<size_t>(n));
-    out.tris.reserve(sizeof(Bvh8Tri) * static_cast<size_t>(n));
     out.triIds.reserve(sizeof(gfx_tri_ids) * static_cast<size_t>(n));
 
     uint32_t* counters = ctx.bCounters.as<uint32_t>();
@@ -533,7 +533,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
     hipLaunchKernelGGL(k_flatten, grd, blk, 0, stream, ctx.devScene(), ctx.dFlatGeoms.as<DevFlatGeom>(), numFlat, n,
                        ctx.bTris.as<BuildTri>(), bounds);
     if (n == 1) {
-        hipLaunchKernelGGL(k_single_tri_root, dim3(1), dim3(64), 0, stream, ctx.bTris.as<BuildTri>(), out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>(), out.tris.as<Bvh8Tri>());
+        hipLaunchKernelGGL(k_single_tri_root, dim3(1), dim3(64), 0, stream, ctx.bTris.as<BuildTri>(), out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>(), out.trisPtr());
         out.numNodes = 1; out.numTris = 1; out.maxDepth = 1;
     }
     else {
@@ -569,7 +569,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
             hipLaunchKernelGGL(k_collapse_level, dim3(gridC), dim3(256), 0, stream, level, ctx.maxLeafTris, qin, qout, counters,
                                ctx.bNodesLR.as<int2>(), ctx.bRanges.as<uint2>(), ctx.bNodeBoxes.as<float>(),
                                ctx.bDec.as<uint32_t>(), useDp,
-                               ctx.bTris.as<BuildTri>(), sortedIdx, out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>(), out.tris.as<Bvh8Tri>());
+                               ctx.bTris.as<BuildTri>(), sortedIdx, out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>(), out.trisPtr());
         }
         GFX_HIP(hipGetLastError());
         std::vector<uint32_t> h(2 + kMaxCollapseLevels + 2);
@@ -580,7 +580,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
         if (h[2 + kMaxCollapseLevels] != 0) throw HipError("lbvh_build: tree deeper than kMaxCollapseLevels");
         if (out.numTris != n) throw HipError("lbvh_build: triangle count mismatch after collapse");
     }
-    hipLaunchKernelGGL(k_tri_ids, dim3((out.numTris + 255) / 256), blk, 0, stream, out.tris.as<Bvh8Tri>(), out.numTris, out.triIds.as<gfx_tri_ids>());
+    hipLaunchKernelGGL(k_tri_ids, dim3((out.numTris + 255) / 256), blk, 0, stream, out.trisPtr(), out.numTris, out.triIds.as<gfx_tri_ids>());
     GFX_HIP(hipGetLastError());
     GFX_HIP(hipStreamSynchronize(stream));
 }

@@ -1187,7 +1187,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     a.neeCount = counters;
     a.occluded = ctx.rayOut.as<uint32_t>();
     a.hits = ctx.rayHits.as<gfx_hit>();
-    a.tris = ctx.accels[h - 1]->tris.as<Bvh8Tri>();
+    a.tris = ctx.accels[h - 1]->trisPtr();
     a.state = ctx.ptState.as<float4>();
     if (nrc) { a.nrcState = ctx.nrcState.as<float4>(); a.neeTrainIdx = ctx.neeTrainIdx.as<uint32_t>(); }
     float4* extOrg[2] = { ctx.ptExtOrg.as<float4>(), ctx.ptExtOrg.as<float4>() + bandPixels };

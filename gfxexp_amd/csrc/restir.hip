@@ -614,7 +614,7 @@ static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint3
     a.pixelRaySlot = ctx.pixelRaySlot.as<uint32_t>();
     a.occluded = ctx.rayOut.as<uint32_t>();
     a.hits = ctx.rayHits.as<gfx_hit>();
-    a.tris = ctx.accels[h - 1]->tris.as<Bvh8Tri>();
+    a.tris = ctx.accels[h - 1]->trisPtr();
     a.shadeScratch = ctx.shadeScratch.as<float4>();
     a.spatialScratch = ctx.spatialScratch.as<SpatialSlot>();
     a.rearchSlots = nullptr;

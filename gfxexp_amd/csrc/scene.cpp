@@ -8,7 +8,7 @@
 namespace gfx {
 
 Context::~Context() {
-    for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->tris.release(); a->triIds.release(); delete a; } }
+    for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->triIds.release(); delete a; } }
     DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dLightW, &dLightCDF, &dLightRefs, &dEmitterRecs,
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,

@@ -43,15 +43,15 @@ struct TraceArgs {
 // XOR-swizzled with (item >> 2) & 3 to make those reads bank-conflict free.
 GFX_DEV void fetch_items(uint32_t code, const DevAccel& acc, uint4* waveBuf /* 256 x 16 B, wave-private */, int lane,
                          uint4& q0, uint4& q1, uint4& q2, uint4& q3) {
-    const char* nodeBase = reinterpret_cast<const char*>(acc.nodes);
-    const char* triBase = reinterpret_cast<const char*>(acc.tris);
+    // nodes and triangle records share one allocation (internal.h Accel): item = code & 0x7FFFFFFF
+    const char* itemBase = reinterpret_cast<const char*>(acc.nodes);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int item = 16 * k + (lane >> 2);              // whose item this lane helps to fetch
         const uint32_t c = __shfl(code, item);
         if (c != kItemNone) {
             const uint32_t quarter = (lane & 3) ^ ((item >> 2) & 3);
-            const char* src = ((c & kItemTri) ? triBase : nodeBase) + (static_cast<size_t>(c & 0x7FFFFFFFu) << 6) + (quarter << 4);
+            const char* src = itemBase + (static_cast<size_t>(c & 0x7FFFFFFFu) << 6) + (quarter << 4);
             typedef const __attribute__((address_space(1))) void* GlobalPtr;
             typedef __attribute__((address_space(3))) void* LdsPtr;
             __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)(waveBuf + 64 * k), 16, 0, 0);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
         }
         uint32_t code = kItemNone;
         if (tr.active) {
-            code = tr.next_item(stack);
+            code = tr.next_item(stack, a.accel.triItemOffset);
             if (code == kItemNone) write_result();          // traversal finished
         }
         if (COUNT) {
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
         fetch_items(code, a.accel, waveBuf, lane, q0, q1, q2, q3);
         if (code != kItemNone) {
             if (code & kItemTri) {
-                if (!tr.template process_triangle<ANY_HIT, COUNT>(code & 0x7FFFFFFFu, q0, q1, q2, q3, a.accel.tris, cnt))
+                if (!tr.template process_triangle<ANY_HIT, COUNT>((code & 0x7FFFFFFFu) - a.accel.triItemOffset, q0, q1, q2, q3, a.accel.tris, cnt))
                     write_result();                         // any-hit ray found its occluder
             }
             else tr.template process_node<COUNT>(q0, q1, q2, q3, link, stack, cnt);
