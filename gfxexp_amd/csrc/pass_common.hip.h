@@ -24,10 +24,37 @@ GFX_DEV EnvMap load_env(const gfx_restir_static_params& s) {
     return e;
 }
 
-// Dense ray-queue append for the lanes with want == true; every lane of the wave must call it.
-// One atomic per wave (ballot + popcount); returns the slot or GFX_INVALID_SLOT.
+// Dense ray-queue append for the threads with want == true.  EVERY thread of the block must call it
+// (block-uniform control flow): the waves' counts are combined in LDS and the block takes ONE atomic
+// on the queue head -- with one atomic per wave the 32 k waves of a full-HD launch serialise on that
+// single address (profiles/r01f: k_shade_prepare 0.38 -> 0.1x ms).  Returns the slot or GFX_INVALID_SLOT.
 GFX_DEV uint32_t queue_append(bool want, f3 org, f3 dir, float tmin, float tmax,
                               float4* rayOrg, float4* rayDir, uint32_t* rayCount) {
+    __shared__ uint32_t qa[1 + 16];                       // [0] block base, [1 + w] count of wave w
+    const unsigned long long mask = __ballot(want);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, numWaves = (blockDim.x + 63) >> 6;
+    if (lane == 0) qa[1 + wave] = static_cast<uint32_t>(__popcll(mask));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < numWaves; ++w) total += qa[1 + w];
+        qa[0] = total ? atomicAdd(rayCount, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = qa[0];
+    for (int w = 0; w < wave; ++w) base += qa[1 + w];
+    __syncthreads();                                      // qa is reused by the next append of this block
+    if (!want) return GFX_INVALID_SLOT;
+    const uint32_t slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+    rayOrg[slot] = make_float4(org.x, org.y, org.z, tmin);
+    rayDir[slot] = make_float4(dir.x, dir.y, dir.z, tmax);
+    return slot;
+}
+
+// Wave-level variant (one atomic per wave, no barrier): for long kernels whose waves finish at very
+// different times, where holding a block back at a barrier costs more than the spread-out atomics.
+GFX_DEV uint32_t queue_append_wave(bool want, f3 org, f3 dir, float tmin, float tmax,
+                                   float4* rayOrg, float4* rayDir, uint32_t* rayCount) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0ull) return GFX_INVALID_SLOT;
     const int lane = threadIdx.x & 63;

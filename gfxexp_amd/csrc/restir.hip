@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void k_initial_candidates(RestirArgs a) {
         store_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p, reservoir);
         static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes])[p] = make_float2(recPDF, selectedTarget);
     }
-    const uint32_t slot = emit_ray(wantRay, rayO, rayD, 0.0f, rayTmax, a);
+    const uint32_t slot = queue_append_wave(wantRay, rayO, rayD, 0.0f, rayTmax, a.rayOrg, a.rayDir, a.rayCount);
     if (p < a.pixelEnd) a.pixelRaySlot[p] = slot;
 }
 
