@@ -64,7 +64,8 @@ struct EmitterRec {
     float nA[3], nB[3], nC[3];
     float emittance[3];
     uint32_t instSlot;
-    uint32_t pad[2];
+    float twoOverLenNg;   // 2 / |cross(pB - pA, pC - pA)|: the per-triangle factor of the area density
+    float primProb;       // weight / integral inside the owning geometry instance's distribution
 };
 static_assert(sizeof(EmitterRec) == 96, "EmitterRec must be 96 bytes");
 
@@ -86,10 +87,14 @@ struct DevScene {
     const uint32_t* triangles;
     const uint32_t* geomInstSlotPool;
     const float* lightWeights;
+    const float* lightProbs;             // weight / integral of the owning distribution, same indexing
     const float* lightCDF;
     const LightGeomRef* lightGeomRefs;   // indexed like the light pools (inst.distOffset + i)
     const EmitterRec* emitterRecs;
-    const float* lightInstIntegral; // device-resident integral of the level-0 distribution
+    const float* lightInstIntegral; // device float[4]: [0] integral of the level-0 distribution,
+                                    // [1] guide-table scale (cells / integral), [2] guide valid (uint32)
+    const uint16_t* lightInstGuide; // guide table of the level-0 distribution (see lights.hip)
+    uint32_t lightInstGuideCells;
     uint32_t lightInstDistOffset;   // level-0 distribution
     uint32_t numInsts;
 };

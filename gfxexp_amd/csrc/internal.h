@@ -76,7 +76,7 @@ struct Context {
     std::vector<HostInstance> insts;
     bool sceneDirty = true;
     // scene (device)
-    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightCDF, dLightRefs, dEmitterRecs;
+    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightP, dLightCDF, dLightRefs, dEmitterRecs;
     std::vector<LightGeomRef> hLightRefs;
     uint32_t numEmitterRecs = 0;
     std::vector<DevGeomInst> hGeomInsts;
@@ -85,7 +85,9 @@ struct Context {
     uint32_t totalTriangles = 0;
     uint32_t lightPoolSize = 0;
     uint32_t lightInstDistOffset = 0;
-    DevBuf dLightInstIntegral;       // float[4]; [0] = integral of the instance-level distribution
+    DevBuf dLightInstIntegral;       // float[4]; [0] = integral of the instance-level distribution, [1..2] guide header
+    DevBuf dLightInstGuide;          // uint16[lightInstGuideCells]
+    uint32_t lightInstGuideCells = 0;
     bool lightsStaticBuilt = false;
     DevScene devScene() const;
     // accels

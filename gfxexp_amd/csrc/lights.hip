@@ -41,7 +41,7 @@ __global__ void k_triangle_importance(DevScene sc, uint32_t numGeomInsts, float*
 
 // Serial exclusive scan of one distribution per thread; writes the integral into the owning table.
 __global__ void k_scan_geom_dists(DevGeomInst* __restrict__ geomInsts, uint32_t numGeomInsts,
-                                  const float* __restrict__ weights, float* __restrict__ cdf) {
+                                  const float* __restrict__ weights, float* __restrict__ cdf, float* __restrict__ probs) {
     const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
     if (gi >= numGeomInsts) return;
     DevGeomInst g = geomInsts[gi];
@@ -53,12 +53,15 @@ __global__ void k_scan_geom_dists(DevGeomInst* __restrict__ geomInsts, uint32_t 
         last = acc; lastW = w;
         acc += w;
     }
-    geomInsts[gi].distIntegral = g.distCount ? last + lastW : 0.0f;   // CDF[n-1] + w[n-1]
+    const float integral = g.distCount ? last + lastW : 0.0f;   // CDF[n-1] + w[n-1]
+    geomInsts[gi].distIntegral = integral;
+    // the division DiscreteDistribution1D::sample/evaluatePMF performs per call, done once
+    for (uint32_t i = 0; i < g.distCount; ++i) probs[g.distOffset + i] = weights[g.distOffset + i] / integral;
 }
 
 __global__ void k_inst_geom_dists(DevInstance* __restrict__ insts, uint32_t numInsts,
                                   const DevGeomInst* __restrict__ geomInsts, const uint32_t* __restrict__ slotPool,
-                                  float* __restrict__ weights, float* __restrict__ cdf) {
+                                  float* __restrict__ weights, float* __restrict__ cdf, float* __restrict__ probs) {
     const uint32_t ii = blockIdx.x * blockDim.x + threadIdx.x;
     if (ii >= numInsts) return;
     DevInstance* inst = insts + ii;
@@ -71,7 +74,9 @@ __global__ void k_inst_geom_dists(DevInstance* __restrict__ insts, uint32_t numI
         last = acc; lastW = w;
         acc += w;
     }
-    inst->distIntegral = inst->numGeomInsts ? last + lastW : 0.0f;
+    const float integral = inst->numGeomInsts ? last + lastW : 0.0f;
+    inst->distIntegral = integral;
+    for (uint32_t i = 0; i < inst->numGeomInsts; ++i) probs[inst->distOffset + i] = weights[inst->distOffset + i] / integral;
 }
 
 // Per (instance, geomInst): copy the emitter distribution's integral next to its offsets and
@@ -107,7 +112,9 @@ __global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* 
             // emittance = RGB(1) * texel for an emitter material (restir_di_shared.h:504-514)
             const f3 e = mat.hasEmittance ? f3(1.0f) * f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]) : f3(0.0f);
             r.emittance[0] = e.x; r.emittance[1] = e.y; r.emittance[2] = e.z;
-            r.instSlot = ii; r.pad[0] = r.pad[1] = 0;
+            r.instSlot = ii;
+            r.twoOverLenNg = 2.0f / len(cross(pB - pA, pC - pA));
+            r.primProb = sc.lightWeights[g.distOffset + t] / g.distIntegral;
             float4* dst = reinterpret_cast<float4*>(recs + recBase + t);
             const float4* src = reinterpret_cast<const float4*>(&r);
             for (int q = 0; q < 6; ++q) dst[q] = src[q];
@@ -132,7 +139,8 @@ __global__ void k_inst_importance(const DevInstance* __restrict__ insts, uint32_
 // CDF back coalesced.
 constexpr int kScanChunk = 4096;
 __global__ __launch_bounds__(256) void k_scan_inst_dist(uint32_t numInsts, uint32_t off, const float* __restrict__ weights,
-                                                        float* __restrict__ cdf, float* __restrict__ integralOut) {
+                                                        float* __restrict__ cdf, float* __restrict__ probs,
+                                                        float* __restrict__ integralOut, uint32_t guideCells) {
     __shared__ float buf[kScanChunk];
     __shared__ float carry[2];   // running sum, last weight
     if (blockIdx.x != 0) return;
@@ -156,7 +164,42 @@ __global__ __launch_bounds__(256) void k_scan_inst_dist(uint32_t numInsts, uint3
         for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) cdf[off + base + i] = buf[i];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *integralOut = numInsts ? lastCdf + carry[1] : 0.0f;   // CDF[n-1] + w[n-1]
+    if (threadIdx.x == 0) carry[0] = numInsts ? lastCdf + carry[1] : 0.0f;   // CDF[n-1] + w[n-1]
+    __syncthreads();
+    const float integral = carry[0];
+    for (uint32_t i = threadIdx.x; i < numInsts; i += blockDim.x) probs[off + i] = weights[off + i] / integral;
+    if (threadIdx.x == 0) {
+        integralOut[0] = integral;
+        // guide header: scale and "usable" flag (k_inst_guide clears the flag if the CDF is not monotone)
+        const float scale = static_cast<float>(guideCells) / integral;
+        const bool usable = numInsts > 0 && numInsts <= 65536 && integral > 0.0f && integral < INFINITY && scale > 0.0f && scale < INFINITY;
+        integralOut[1] = usable ? scale : 0.0f;
+        reinterpret_cast<uint32_t*>(integralOut)[2] = usable ? 1u : 0u;
+    }
+}
+
+// Guide table over the instance-level CDF.  cell(x) = min(cells - 1, uint(x * scale)) is monotone in x,
+// so with guide[k] = largest i with cell(CDF[i]) <= k a sample u in cell k has its answer (the largest i
+// with CDF[i] <= u, what the reference's 12-step binary search finds, common_shared.h:209-247) inside
+// [guide[k-1], guide[k]]: CDF[guide[k-1]] lies in an earlier cell, hence below u, and nothing past guide[k]
+// can be <= u.  The bracket is typically one or two entries wide.  All of this leans on the CDF being
+// monotone, which a sum of non-negative weights is; the kernel checks it anyway and withdraws the table
+// (samplers fall back to the plain search) if it ever is not.
+__global__ __launch_bounds__(256) void k_inst_guide(uint32_t numInsts, uint32_t off, const float* __restrict__ cdfPool,
+                                                    float* __restrict__ header, uint16_t* __restrict__ guide, uint32_t cells) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* cdf = cdfPool + off;
+    if (reinterpret_cast<const uint32_t*>(header)[2] == 0u) return;
+    const float scale = header[1];
+    if (t + 1 < numInsts && !(cdf[t] <= cdf[t + 1])) atomicAnd(reinterpret_cast<uint32_t*>(header) + 2, 0u);
+    if (t == 0 && !(cdf[0] == 0.0f)) atomicAnd(reinterpret_cast<uint32_t*>(header) + 2, 0u);
+    if (t >= cells) return;
+    uint32_t idx = 0;
+    for (uint32_t d = next_pow2(numInsts) >> 1; d >= 1; d >>= 1) {
+        if (idx + d >= numInsts) continue;
+        if (guide_cell(cdf[idx + d], scale, cells) <= t) idx += d;
+    }
+    guide[t] = static_cast<uint16_t>(idx);
 }
 
 void lights_build_static(Context& ctx, hipStream_t stream) {
@@ -169,12 +212,12 @@ void lights_build_static(Context& ctx, hipStream_t stream) {
         const dim3 grid(std::min<uint32_t>((maxTris + 255) / 256, 64), ng);
         hipLaunchKernelGGL(k_triangle_importance, grid, dim3(256), 0, stream, ctx.devScene(), ng, ctx.dLightW.as<float>());
         hipLaunchKernelGGL(k_scan_geom_dists, dim3((ng + 63) / 64), dim3(64), 0, stream,
-                           ctx.dGeomInsts.as<DevGeomInst>(), ng, ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>());
+                           ctx.dGeomInsts.as<DevGeomInst>(), ng, ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>(), ctx.dLightP.as<float>());
     }
     if (ni)
         hipLaunchKernelGGL(k_inst_geom_dists, dim3((ni + 63) / 64), dim3(64), 0, stream,
                            ctx.dInsts.as<DevInstance>(), ni, ctx.dGeomInsts.as<DevGeomInst>(), ctx.dSlotPool.as<uint32_t>(),
-                           ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>());
+                           ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>(), ctx.dLightP.as<float>());
     if (ni)
         hipLaunchKernelGGL(k_emitter_records, dim3(ni), dim3(64), 0, stream, ctx.devScene(), ni,
                            ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>());
@@ -196,10 +239,13 @@ void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t /*bufferI
         hipLaunchKernelGGL(k_inst_importance, dim3((ni + 63) / 64), dim3(64), 0, stream,
                            ctx.dInsts.as<DevInstance>(), ni, ctx.lightInstDistOffset, ctx.dLightW.as<float>());
         hipLaunchKernelGGL(k_scan_inst_dist, dim3(1), dim3(256), 0, stream, ni, ctx.lightInstDistOffset,
-                           ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>(), dIntegral);
+                           ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>(), ctx.dLightP.as<float>(), dIntegral, ctx.lightInstGuideCells);
+        const uint32_t guideThreads = std::max(ni, ctx.lightInstGuideCells);
+        hipLaunchKernelGGL(k_inst_guide, dim3((guideThreads + 255) / 256), dim3(256), 0, stream, ni, ctx.lightInstDistOffset,
+                           ctx.dLightCDF.as<float>(), dIntegral, ctx.dLightInstGuide.as<uint16_t>(), ctx.lightInstGuideCells);
         GFX_HIP(hipGetLastError());
     }
-    else GFX_HIP(hipMemsetAsync(dIntegral, 0, sizeof(float), stream));
+    else GFX_HIP(hipMemsetAsync(dIntegral, 0, 4 * sizeof(float), stream));
 }
 
 } // namespace gfx

@@ -157,8 +157,7 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
     }
     else {
         if (!active) return;
-        const float* instWeights = a.scene.lightWeights + a.scene.lightInstDistOffset;
-        const float* instCDF = a.scene.lightCDF + a.scene.lightInstDistOffset;
+        const InstDist instDist = inst_dist_global(a.scene);
         float ul = rng.uniform();
         bool selectEnv = false;
         float probCurType = 1.0f;
@@ -172,7 +171,7 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
         float areaPDensity;
         const float u0 = rng.uniform();
         const float u1 = rng.uniform();
-        sample_light(a.scene, instWeights, instCDF, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, selectEnv, u0, u1, ls, areaPDensity);
+        sample_light(a.scene, instDist, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, selectEnv, u0, u1, ls, areaPDensity);
         areaPDensity *= probCurType;
         const ShadowRay sr = shadow_ray(pos, ls);
         float misWeight;
@@ -485,8 +484,7 @@ __global__ __launch_bounds__(kPtBlock) void k_regir_build(PtArgs a) {
     Pcg32 rng; rng.state = rngs[i];
     const EnvMap env = load_env(a.s);
     const bool envEnabled = env.present() && a.f.enableEnvLight;
-    const float* instWeights = a.scene.lightWeights + a.scene.lightInstDistOffset;
-    const float* instCDF = a.scene.lightCDF + a.scene.lightInstDistOffset;
+    const InstDist instDist = inst_dist_global(a.scene);
     float selectedTarget = 0.0f;
     Reservoir reservoir;
     reservoir.reset();
@@ -508,7 +506,7 @@ __global__ __launch_bounds__(kPtBlock) void k_regir_build(PtArgs a) {
         float pd;
         const float u0 = rng.uniform();
         const float u1 = rng.uniform();
-        sample_light(a.scene, instWeights, instCDF, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
+        sample_light(a.scene, instDist, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
         const f3 cont = regir_sample_intensity(ls, cellCenter, halfCellSize, minSquaredDistance);
         pd *= probCurType;
         const float target = target_weight(cont);

@@ -166,14 +166,20 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
 // staged in LDS once per block when it fits (LDS_DIST); larger scenes search it in global memory.
 template <bool LDS_DIST>
 __global__ __launch_bounds__(kBlock) void k_initial_candidates(RestirArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float ldsDist[];   // weights[numInsts] | CDF[numInsts]
-    const float* instWeights = a.scene.lightWeights + a.scene.lightInstDistOffset;
-    const float* instCDF = a.scene.lightCDF + a.scene.lightInstDistOffset;
+    extern __shared__ __attribute__((aligned(16))) float ldsDist[];   // probs | CDF | guide table of the instance level
+    InstDist instDist = inst_dist_global(a.scene);
     if (LDS_DIST) {
+        // probs[ni] | CDF[ni] | guide[cells] (uint16)
         const uint32_t ni = a.scene.numInsts;
-        for (uint32_t i = threadIdx.x; i < ni; i += kBlock) { ldsDist[i] = instWeights[i]; ldsDist[ni + i] = instCDF[i]; }
+        for (uint32_t i = threadIdx.x; i < ni; i += kBlock) { ldsDist[i] = instDist.probs[i]; ldsDist[ni + i] = instDist.cdf[i]; }
+        uint32_t* ldsGuide = reinterpret_cast<uint32_t*>(ldsDist + 2 * ni);
+        if (instDist.guide) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(instDist.guide);
+            for (uint32_t i = threadIdx.x; i < instDist.guideCells / 2; i += kBlock) ldsGuide[i] = src[i];
+            instDist.guide = reinterpret_cast<const uint16_t*>(ldsGuide);
+        }
         __syncthreads();
-        instWeights = ldsDist; instCDF = ldsDist + ni;
+        instDist.probs = ldsDist; instDist.cdf = ldsDist + ni;
     }
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void k_initial_candidates(RestirArgs a) {
             float pd;
             const float u0 = rng.uniform();
             const float u1 = rng.uniform();
-            sample_light(a.scene, instWeights, instCDF, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
+            sample_light(a.scene, instDist, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
             const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
             pd *= probCurType;
             const float target = target_weight(cont);
@@ -666,7 +672,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         {
             const size_t numPx = a.pixelEnd - a.pixelBegin;
             const uint32_t grid = static_cast<uint32_t>((numPx + kBlock - 1) / kBlock);
-            const size_t ldsBytes = 8ull * a.scene.numInsts;
+            const size_t ldsBytes = 8ull * a.scene.numInsts + 2ull * a.scene.lightInstGuideCells;
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
             if (ldsBytes <= 64 * 1024) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), ldsBytes, stream, a);
             else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);

@@ -9,10 +9,10 @@ namespace gfx {
 
 Context::~Context() {
     for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->triIds.release(); delete a; } }
-    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dLightW, &dLightCDF, &dLightRefs, &dEmitterRecs,
+    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs,
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
-                      &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral,
+                      &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide,
                       &dTraceDiag, &bCosts, &bDec, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
                       &rearchSlots, &nrcState, &neeTrainIdx };
     for (NrcNet* net : nrcNets) if (net) nrc_destroy(net);
@@ -29,10 +29,13 @@ DevScene Context::devScene() const {
     s.triangles = dTriangles.as<uint32_t>();
     s.geomInstSlotPool = dSlotPool.as<uint32_t>();
     s.lightWeights = dLightW.as<float>();
+    s.lightProbs = dLightP.as<float>();
     s.lightCDF = dLightCDF.as<float>();
     s.lightGeomRefs = dLightRefs.as<LightGeomRef>();
     s.emitterRecs = dEmitterRecs.as<EmitterRec>();
     s.lightInstIntegral = dLightInstIntegral.as<float>();
+    s.lightInstGuide = dLightInstGuide.as<uint16_t>();
+    s.lightInstGuideCells = lightInstGuideCells;
     s.lightInstDistOffset = lightInstDistOffset;
     s.numInsts = static_cast<uint32_t>(insts.size());
     return s;
@@ -134,6 +137,12 @@ void scene_upload(Context& ctx, hipStream_t stream) {
     ctx.lightPoolSize = lightPool;
     ctx.lightsStaticBuilt = false;
     ctx.dLightInstIntegral.reserve(16);
+    {   // guide table: about one cell per instance, power of two, small enough to sit in LDS next to the CDF
+        uint32_t cells = 256;
+        while (cells < ctx.insts.size() && cells < 8192) cells *= 2;
+        ctx.lightInstGuideCells = cells;
+        ctx.dLightInstGuide.reserve(sizeof(uint16_t) * cells);
+    }
     GFX_HIP(hipMemsetAsync(ctx.dLightInstIntegral.p, 0, 16, stream));
 
     upload(ctx.dMaterials, ctx.materials, stream);
@@ -147,7 +156,9 @@ void scene_upload(Context& ctx, hipStream_t stream) {
     ctx.dEmitterRecs.reserve(std::max<size_t>(sizeof(EmitterRec) * ctx.numEmitterRecs, 16));
     ctx.dLightW.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
     ctx.dLightCDF.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
+    ctx.dLightP.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
     GFX_HIP(hipMemsetAsync(ctx.dLightW.p, 0, ctx.dLightW.bytes, stream));
+    GFX_HIP(hipMemsetAsync(ctx.dLightP.p, 0, ctx.dLightP.bytes, stream));
     GFX_HIP(hipMemsetAsync(ctx.dLightCDF.p, 0, ctx.dLightCDF.bytes, stream));
     GFX_HIP(hipStreamSynchronize(stream));   // host vectors above go out of scope
     ctx.sceneDirty = false;

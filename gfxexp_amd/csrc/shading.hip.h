@@ -32,9 +32,10 @@ struct Pcg32 {
 
 GFX_DEV uint32_t next_pow2(uint32_t x) { return x <= 1 ? x : 1u << (32 - __clz(x - 1)); }
 
-// Branch-light binary search over an exclusive-prefix CDF.
-GFX_DEV uint32_t discrete_sample(const float* __restrict__ weights, const float* __restrict__ cdf,
-                                 float integral, uint32_t n, float u, float& prob, float* remapped) {
+// Branch-light binary search over an exclusive-prefix CDF.  probs[i] = weight[i] / integral, the quotient
+// the reference forms per call, is tabulated by the light-distribution build (lights.hip); prob may be null.
+GFX_DEV uint32_t discrete_sample(const float* __restrict__ probs, const float* __restrict__ cdf,
+                                 float integral, uint32_t n, float u, float* prob, float* remapped) {
     u *= integral;
     int idx = 0;
     for (int d = static_cast<int>(next_pow2(n) >> 1); d >= 1; d >>= 1) {
@@ -47,7 +48,45 @@ GFX_DEV uint32_t discrete_sample(const float* __restrict__ weights, const float*
         if (idx < static_cast<int>(n) - 1) hi = cdf[idx + 1];
         *remapped = (u - lo) / (hi - lo);
     }
-    prob = weights[idx] / integral;
+    if (prob) *prob = probs[idx];
+    return static_cast<uint32_t>(idx);
+}
+
+// Instance-level (level 0) distribution plus its guide table (lights.hip, k_inst_guide).  guide == nullptr
+// selects the plain search.
+struct InstDist {
+    const float* probs;
+    const float* cdf;
+    const uint16_t* guide;
+    float guideScale;
+    uint32_t guideCells;
+};
+
+GFX_DEV uint32_t guide_cell(float x, float scale, uint32_t cells) {
+    return min(cells - 1u, static_cast<uint32_t>(x * scale));
+}
+
+// Same result as discrete_sample (largest idx with cdf[idx] <= u) for a monotone CDF, found inside the
+// bracket the guide table gives instead of by log2(n) dependent loads.
+GFX_DEV uint32_t discrete_sample_guided(const InstDist& d, float integral, uint32_t n, float u, float& prob, float* remapped) {
+    if (!d.guide) return discrete_sample(d.probs, d.cdf, integral, n, u, &prob, remapped);
+    u *= integral;
+    const uint32_t k = guide_cell(u, d.guideScale, d.guideCells);
+    int hi = d.guide[k];
+    int lo = k ? d.guide[k - 1] : 0;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (d.cdf[mid] <= u) lo = mid;
+        else hi = mid - 1;
+    }
+    const int idx = lo;
+    if (remapped) {
+        const float l = d.cdf[idx];
+        float h = integral;
+        if (idx < static_cast<int>(n) - 1) h = d.cdf[idx + 1];
+        *remapped = (u - l) / (h - l);
+    }
+    prob = d.probs[idx];
     return static_cast<uint32_t>(idx);
 }
 
@@ -387,8 +426,19 @@ GFX_DEV m33 load_m33_rows(const float* __restrict__ p) {   // 3 rows padded to f
 
 // sampleLight<false>.  Returns the area density; sample left untouched past an early out exactly
 // like the reference (the caller starts from a default-constructed LightSample).
-// instWeights / instCDF: the instance-level distribution (level 0), usually an LDS copy.
-GFX_DEV void sample_light(const DevScene& sc, const float* instWeights, const float* instCDF,
+// instDist: the instance-level distribution (level 0), usually an LDS copy.
+GFX_DEV InstDist inst_dist_global(const DevScene& sc) {
+    InstDist d;
+    d.probs = sc.lightProbs + sc.lightInstDistOffset;
+    d.cdf = sc.lightCDF + sc.lightInstDistOffset;
+    const bool usable = reinterpret_cast<const uint32_t*>(sc.lightInstIntegral)[2] != 0u;
+    d.guide = usable ? sc.lightInstGuide : nullptr;
+    d.guideScale = sc.lightInstIntegral[1];
+    d.guideCells = sc.lightInstGuideCells;
+    return d;
+}
+
+GFX_DEV void sample_light(const DevScene& sc, const InstDist& instDist,
                           const EnvMap& env, float envRotation, float envPowerCoeff,
                           float ul, bool sampleEnv, float u0, float u1, LightSample& ls, float& areaPDensity) {
     if (sampleEnv) {
@@ -410,7 +460,7 @@ GFX_DEV void sample_light(const DevScene& sc, const float* instWeights, const fl
     }
     float lightProb = 1.0f;
     float instProb, uGeomInst;
-    const uint32_t instSlot = discrete_sample(instWeights, instCDF, *sc.lightInstIntegral, sc.numInsts, ul, instProb, &uGeomInst);
+    const uint32_t instSlot = discrete_sample_guided(instDist, *sc.lightInstIntegral, sc.numInsts, ul, instProb, &uGeomInst);
     lightProb *= instProb;
     if (instProb == 0.0f) { areaPDensity = 0.0f; return; }
     const DevInstance* inst = sc.insts + instSlot;
@@ -418,20 +468,19 @@ GFX_DEV void sample_light(const DevScene& sc, const float* instWeights, const fl
     const uint4 ih = *reinterpret_cast<const uint4*>(&inst->distOffset);
 
     float geomInstProb, uPrim;
-    const uint32_t gi = discrete_sample(sc.lightWeights + ih.x, sc.lightCDF + ih.x, bits2f(ih.z), ih.y, uGeomInst, geomInstProb, &uPrim);
+    const uint32_t gi = discrete_sample(sc.lightProbs + ih.x, sc.lightCDF + ih.x, bits2f(ih.z), ih.y, uGeomInst, &geomInstProb, &uPrim);
     lightProb *= geomInstProb;
     if (geomInstProb == 0.0f) { areaPDensity = 0.0f; return; }
     const uint4 gr = *reinterpret_cast<const uint4*>(sc.lightGeomRefs + ih.x + gi);   // LightGeomRef
 
-    float primProb;
-    const uint32_t prim = discrete_sample(sc.lightWeights + gr.y, sc.lightCDF + gr.y, bits2f(gr.w), gr.z, uPrim, primProb, nullptr);
-    lightProb *= primProb;
+    const uint32_t prim = discrete_sample(nullptr, sc.lightCDF + gr.y, bits2f(gr.w), gr.z, uPrim, nullptr, nullptr);
 
+    // EmitterRec: world-space triangle, 2 / |ng| and the primitive's probability tabulated at build time
     const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + gr.x + prim);
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
     const f3 pA(r0.x, r0.y, r0.z), pB(r0.w, r1.x, r1.y), pC(r1.z, r1.w, r2.x);
     const f3 nA(r2.y, r2.z, r2.w), nB(r3.x, r3.y, r3.z), nC(r3.w, r4.x, r4.y);
-    const f3 ng = cross(pB - pA, pC - pA);
+    lightProb *= r5.w;
 
     float bcA = 0.5f * u0;
     float bcB = 0.5f * u1;
@@ -439,7 +488,7 @@ GFX_DEV void sample_light(const DevScene& sc, const float* instWeights, const fl
     if (off > 0) bcB += off;
     else bcA -= off;
     const float bcC = 1 - (bcA + bcB);
-    areaPDensity = lightProb * (2.0f / len(ng));
+    areaPDensity = lightProb * r5.z;
 
     ls.position = bcA * pA + bcB * pB + bcC * pC;
     ls.atInfinity = 0;
