@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
 // The instance-level CDF (searched 32 times per pixel, log2(numInsts) dependent loads each) is
 // staged in LDS once per block when it fits (LDS_DIST); larger scenes search it in global memory.
 template <bool LDS_DIST>
-__global__ __launch_bounds__(kBlock) void k_initial_candidates(RestirArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_initial_candidates(RestirArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ldsDist[];   // probs | CDF | guide table of the instance level
     InstDist instDist = inst_dist_global(a.scene);
     if (LDS_DIST) {

@@ -210,8 +210,11 @@ struct Bsdf {
         const float a2 = sq(ag) * (sq(v2.x) + sq(v2.y)) / sq(v2.z);
         const float l1 = (-1 + sqrtf(1 + a1)) / 2;
         const float l2 = (-1 + sqrtf(1 + a2)) / 2;
-        const float c1 = (dot(v1, m) / v1.z) > 0 ? 1.0f : 0.0f;
-        const float c2 = (dot(v2, m) / v2.z) > 0 ? 1.0f : 0.0f;
+        // chi+(dot(v, m) / v.z) without the division: v.z is a non-zero component of a unit vector (|v.z| < 2),
+        // so the quotient of a non-zero numerator cannot round to zero and its sign is the sign pair's.
+        const float d1 = dot(v1, m), d2 = dot(v2, m);
+        const float c1 = ((d1 > 0 && v1.z > 0) || (d1 < 0 && v1.z < 0)) ? 1.0f : 0.0f;
+        const float c2 = ((d2 > 0 && v2.z > 0) || (d2 < 0 && v2.z < 0)) ? 1.0f : 0.0f;
         return c1 * c2 / (1 + l1 + l2);
     }
     static GFX_DEV float ggx_pdf(float ag, f3 v, f3 m) {
