@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <stdexcept>
 #include "internal.h"
 #include "shading.hip.h"
 
@@ -505,6 +506,8 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
     out.numInputTris = n;
     out.numNodes = 0; out.numTris = 0; out.maxDepth = 0;
     if (n == 0) return;
+    // the traversal kernel addresses items (n node slots + n triangle records, 64 B each) with 32-bit byte offsets
+    if (n >= (1u << 25)) throw std::runtime_error("gfx: acceleration structure limited to 2^25 triangles");
     const uint32_t numFlat = static_cast<uint32_t>(ctx.hFlatGeoms.size());
     const dim3 blk(256), grd((n + 255) / 256);
 

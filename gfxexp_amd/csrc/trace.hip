@@ -43,18 +43,21 @@ struct TraceArgs {
 // XOR-swizzled with (item >> 2) & 3 to make those reads bank-conflict free.
 GFX_DEV void fetch_items(uint32_t code, const DevAccel& acc, uint4* waveBuf /* 256 x 16 B, wave-private */, int lane,
                          uint4& q0, uint4& q1, uint4& q2, uint4& q3) {
-    // nodes and triangle records share one allocation (internal.h Accel): item = code & 0x7FFFFFFF
+    // nodes and triangle records share one allocation (internal.h Accel): item = code & 0x7FFFFFFF.  The builder
+    // keeps the item count below 2^26, so the byte offset fits 32 bits and the loads use the scalar-base form.
     const char* itemBase = reinterpret_cast<const char*>(acc.nodes);
+    // item 16 k + (lane >> 2) of round k: its swizzle ((item >> 2) & 3) = (lane >> 4) & 3 does not depend on k
+    const uint32_t quarterOff = static_cast<uint32_t>((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    uint32_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = __shfl(code, 16 * k + (lane >> 2));   // whose item this lane helps to fetch
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int item = 16 * k + (lane >> 2);              // whose item this lane helps to fetch
-        const uint32_t c = __shfl(code, item);
-        if (c != kItemNone) {
-            const uint32_t quarter = (lane & 3) ^ ((item >> 2) & 3);
-            const char* src = itemBase + (static_cast<size_t>(c & 0x7FFFFFFFu) << 6) + (quarter << 4);
+        if (c[k] != kItemNone) {
+            const uint32_t off = (c[k] << 6) | quarterOff;   // the tag bit (bit 31) falls off the top
             typedef const __attribute__((address_space(1))) void* GlobalPtr;
             typedef __attribute__((address_space(3))) void* LdsPtr;
-            __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)(waveBuf + 64 * k), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((GlobalPtr)(itemBase + off), (LdsPtr)(waveBuf + 64 * k), 16, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[kTraceBlock * 4];   // 4 KiB per wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    uint4* waveBuf = fetchBuf + 256 * (tid >> 6);
+    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, kept scalar
     LaneStack stack;
     stack.lds = ldsStack + tid;
     stack.ldsStride = kTraceBlock;
