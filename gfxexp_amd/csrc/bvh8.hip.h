@@ -10,8 +10,9 @@
 //   * children visited in (slot XOR ray-octant) order -- no per-node sorting network;
 //   * the stack lives in LDS, one 8-byte column per lane ([depth][lane] => conflict-free
 //     ds_read/write_b64), spilling to a per-lane HBM area past kLdsStackDepth entries;
-//   * closest-hit ties (equal t) resolve to the lowest (instSlot, geomInstSlot, primIndex), so the
-//     result does not depend on traversal order.
+//   * closest-hit ties (equal t) resolve to the triangle that comes first in the flattened triangle list
+//     (instance slot ascending, group list order, primitive index), so the result does not depend on
+//     traversal order.
 #pragma once
 #include "device_types.h"
 #include "gm_math.hip.h"
@@ -138,10 +139,8 @@ struct Traversal {
         if (!ray_triangle(org, dir, tmin, pA, eAB, eCA, n, t, bb, cc)) return true;
         bool take = t < hit.t;
         if (!ANY_HIT && !take && t == hit.t && hit.tri != GFX_INVALID_SLOT) {
-            // exact tie: lowest (instSlot, geomInstSlot, primIndex) wins
-            const Bvh8Tri* o = tris + hit.tri;
-            take = q3.x < o->instSlot || (q3.x == o->instSlot && (q3.y < o->geomInstSlot ||
-                   (q3.y == o->geomInstSlot && q3.z < o->primIndex)));
+            // exact tie: the triangle that comes first in the flattened triangle list wins
+            take = q3.w < tris[hit.tri].flatIndex;
         }
         if (take) {
             hit.t = t; hit.bcB = bb; hit.bcC = cc; hit.tri = ti;

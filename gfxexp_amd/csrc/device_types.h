@@ -128,7 +128,8 @@ struct Bvh8Tri {
     float ax, ay, az, eABx;          // pA, eAB = pB - pA
     float eABy, eABz, eCAx, eCAy;    // eCA = pA - pC
     float eCAz, nx, ny, nz;          // n = cross(eCA, eAB)
-    uint32_t instSlot, geomInstSlot, primIndex, pad;
+    uint32_t instSlot, geomInstSlot, primIndex;
+    uint32_t flatIndex;              // position in the flattened triangle list (instance slot asc, group list order, primitive)
 };
 static_assert(sizeof(Bvh8Tri) == 64, "Bvh8Tri must be 64 bytes");
 

@@ -57,7 +57,7 @@ GFX_DEV void store_tri(BuildTri* p, const BuildTri& t) {
 }
 // Final 64-byte traversal record: pA and the ray-independent terms of testRayVsTriangle
 // (common/bvh_builder.cpp:1256-1258), computed with exactly those fp32 operations.
-GFX_DEV void store_final_tri(Bvh8Tri* p, const BuildTri& t) {
+GFX_DEV void store_final_tri(Bvh8Tri* p, const BuildTri& t, uint32_t flatIndex) {
     const f3 pA(t.ax, t.ay, t.az), pB(t.bx, t.by, t.bz), pC(t.cx, t.cy, t.cz);
     const f3 eAB = pB - pA;
     const f3 eCA = pA - pC;
@@ -66,7 +66,7 @@ GFX_DEV void store_final_tri(Bvh8Tri* p, const BuildTri& t) {
     q[0] = make_float4(pA.x, pA.y, pA.z, eAB.x);
     q[1] = make_float4(eAB.y, eAB.z, eCA.x, eCA.y);
     q[2] = make_float4(eCA.z, n.x, n.y, n.z);
-    q[3] = make_float4(bits2f(t.instSlot), bits2f(t.geomInstSlot), bits2f(t.primIndex), 0.0f);
+    q[3] = make_float4(bits2f(t.instSlot), bits2f(t.geomInstSlot), bits2f(t.primIndex), bits2f(flatIndex));
 }
 
 // ---------------------------------------------------------------- 1. flatten
@@ -447,7 +447,7 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
                 ++internalRank;
             }
             else {
-                store_final_tri(trisOut + triBase + triOff, load_tri(trisIn + sortedIdx[ch[k].first]));
+                store_final_tri(trisOut + triBase + triOff, load_tri(trisIn + sortedIdx[ch[k].first]), sortedIdx[ch[k].first]);
                 ++triOff;
             }
         }
@@ -487,7 +487,7 @@ __global__ void k_single_tri_root(const BuildTri* __restrict__ trisIn, Bvh8Node*
     dst[2] = make_uint4(node.w[8], node.w[9], node.w[10], node.w[11]);
     dst[3] = make_uint4(node.w[12], node.w[13], node.w[14], node.w[15]);
     reinterpret_cast<uint4*>(linksOut)[0] = make_uint4(0xFFFFFFFFu, 0u, 1u, 0u);
-    store_final_tri(trisOut, t);
+    store_final_tri(trisOut, t, 0u);
 }
 
 __global__ void k_tri_ids(const Bvh8Tri* __restrict__ tris, uint32_t n, gfx_tri_ids* __restrict__ ids) {
