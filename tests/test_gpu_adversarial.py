@@ -1,0 +1,55 @@
+"""-m gpu: every renderer on a scene built to break things (tests/util.py pathological_light_scene):
+emitter importance over ~12 decades, runs of non-emissive instances, groups listing coplanar geometry
+out of slot order (exact closest-hit ties), emissive geometry first / middle / last in a group.
+All buffers bit for bit against the oracle after every pass."""
+import numpy as np
+import pytest
+
+from gfxexp_amd import api
+from tests import util
+from tests.test_gpu_nrc_render import run_nrc_both
+from tests.test_gpu_pathtrace import run_pt_both
+from tests.test_gpu_regir import run_regir_both
+from tests.test_gpu_restir import run_sequence_both
+
+pytestmark = pytest.mark.gpu
+W, H = 48, 32
+
+
+def _cam():
+    return api.make_camera(W, H, pos=(0.0, 9.0, 38.0), pitch=10.0, yaw=180.0)
+
+
+@pytest.mark.parametrize("renderer", [api.RENDERER_BIASED, api.RENDERER_UNBIASED])
+def test_original_restir(built_lib, renderer):
+    diffs = run_sequence_both(util.pathological_light_scene(), W, H, frames=3, renderer=renderer, camera=_cam())
+    assert not diffs, "\n".join(diffs[:12])
+
+
+def test_path_tracer(built_lib):
+    diffs = run_pt_both(util.pathological_light_scene(), W, H, frames=2, max_len=6, camera=_cam())
+    assert not diffs, "\n".join(diffs[:12])
+
+
+def test_regir(built_lib):
+    diffs = run_regir_both(util.pathological_light_scene(), W, H, frames=3, max_len=4, camera=_cam())
+    assert not diffs, "\n".join(diffs[:12])
+
+
+def test_nrc_render(built_lib):
+    diffs = run_nrc_both(util.pathological_light_scene(), W, H, frames=2, max_len=5, camera=_cam())
+    assert not diffs, "\n".join(diffs[:12])
+
+
+def test_closest_hit_ties_follow_the_flattened_order(built_lib):
+    from tests.test_gpu_trace import _compare_closest, _gpu_trace, _tri_ids
+    hs = util.pathological_light_scene()
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    org, dirs = util.pinhole_rays(160, 96, (0.0, 9.0, 38.0), (0.0, 3.0, 0.0), 50.0)
+    gpu = _gpu_trace(ctx, accel, api.TRACE_CLOSEST, org, dirs)
+    ids = _tri_ids(ctx, accel)
+    for brute in (False, True):
+        osc = util.feed_oracle(hs, brute_force=brute)
+        _compare_closest(gpu, ids, osc.trace(api.TRACE_CLOSEST, org, dirs), osc.tri_ids(), f"brute={brute}")

@@ -131,56 +131,10 @@ def test_headless_driver_rearchitected_renderers(built_lib, renderer, unbiased):
     util.assert_same_bits("driver beauty", out, pb.beauty)
 
 
-def pathological_light_scene(seed=11, instances=420):
-    """Emitters whose importance spans ~12 decades, runs of non-emissive instances between them, and groups
-    with the emissive geometry first / last / in the middle: the instance-level guide table gets crowded
-    and empty cells, and the geometry-instance search sees zero-weight entries on either side."""
-    rng = np.random.default_rng(seed)
-    s = api.HostScene()
-
-    def quad(mat, n=1):
-        # n x n grid of two-triangle cells in the xz plane, 1 x 1 overall
-        m = n + 1
-        v = np.zeros(m * m, api.VERTEX_DTYPE)
-        xs, zs = np.meshgrid(np.linspace(-0.5, 0.5, m), np.linspace(-0.5, 0.5, m))
-        v["position"] = np.stack([xs.ravel(), np.zeros(m * m), zs.ravel()], 1)
-        v["normal"] = (0, 1, 0)
-        v["texCoord0Dir"] = (1, 0, 0)
-        v["texCoord"] = np.stack([xs.ravel() + 0.5, zs.ravel() + 0.5], 1)
-        t = []
-        for j in range(n):
-            for i in range(n):
-                a = j * m + i
-                t += [(a, a + m + 1, a + 1), (a, a + m, a + m + 1)]
-        return s.add_geom(v, t, mat)
-
-    dark = s.add_material_traditional((0.6, 0.6, 0.6), (0.04, 0.04, 0.04), 0.2)
-    lit = [s.add_material_traditional((0.01, 0.01, 0.01), (0, 0, 0), 0.3, e)
-           for e in ((30, 20, 10), (0.5, 2, 8), (1e-3, 1e-3, 1e-3), (400, 400, 380))]
-    g_dark, g_dark5 = quad(dark), quad(dark, 5)
-    g_lit = [quad(m, n) for m, n in zip(lit, (1, 3, 2, 7))]
-    groups = [s.add_group([g_lit[0]]), s.add_group([g_dark]), s.add_group([g_dark5, g_lit[1]]),
-              s.add_group([g_lit[2], g_dark]), s.add_group([g_dark, g_lit[3], g_dark5]),
-              s.add_group([g_lit[1], g_lit[0], g_lit[3]]), s.add_group([g_dark5])]
-    ground = s.add_group([quad(dark, 8)])
-    s.add_instance(ground, api.make_transform(scale=60.0))
-    i = 0
-    while i < instances:
-        run = int(rng.integers(1, 40))                     # runs of one kind: long stretches of zero weight
-        kind = int(rng.integers(0, len(groups)))
-        for _ in range(min(run, instances - i)):
-            scale = float(10.0 ** rng.uniform(-2.5, 1.2))
-            pos = (float(rng.uniform(-25, 25)), float(rng.uniform(0.5, 12)), float(rng.uniform(-25, 25)))
-            s.add_instance(groups[kind], api.make_transform(scale=scale, roll=float(rng.uniform(0, 360)),
-                                                            pitch=float(rng.uniform(0, 360)), yaw=float(rng.uniform(0, 360)), pos=pos))
-            i += 1
-    return s
-
-
 @pytest.mark.gpu
 def test_light_sampling_pathological_distribution(built_lib):
     """131072 pre-sampled lights + per-pixel RIS + shading on a scene built to stress the light-distribution
     tables (guide table brackets, tabulated probabilities, zero-weight runs), bit for bit."""
-    hs = pathological_light_scene()
+    hs = util.pathological_light_scene()
     cam = api.make_camera(48, 32, pos=(0.0, 9.0, 38.0), pitch=10.0, yaw=180.0)
     assert run_rearch_both(hs, 48, 32, 2, temporal=True, spatial=False, unbiased=False, camera=cam) == []
