@@ -53,3 +53,32 @@ def test_closest_hit_ties_follow_the_flattened_order(built_lib):
     for brute in (False, True):
         osc = util.feed_oracle(hs, brute_force=brute)
         _compare_closest(gpu, ids, osc.trace(api.TRACE_CLOSEST, org, dirs), osc.tri_ids(), f"brute={brute}")
+
+
+def _odd_transform_scene():
+    """Non-uniformly scaled, sheared and mirrored (negative determinant) instances of emitters and receivers."""
+    rng = np.random.default_rng(5)
+    s = util.bunny_scene(with_light=False)
+    lights = [s.add_rectangle(1.0, 0.6, e) for e in ((40, 30, 20), (5, 10, 30))]
+    for k in range(10):
+        m = np.eye(3) + rng.uniform(-0.45, 0.45, (3, 3))
+        m *= rng.uniform(0.4, 2.5, 3)[None, :]
+        if k % 2:
+            m[:, 0] = -m[:, 0]                      # mirror
+        x = np.zeros((3, 4), np.float32)
+        x[:, :3] = m
+        x[:, 3] = (rng.uniform(-8, 8), rng.uniform(4, 11), rng.uniform(-6, 8))
+        s.add_instance(lights[k % 2], x.reshape(12))
+    g = s.load_obj(__import__("os").path.join(util.ASSETS, "teapot.obj"))
+    x = np.zeros((3, 4), np.float32)
+    x[:, :3] = np.array([[0.9, 0.3, 0.0], [0.0, -1.4, 0.2], [0.1, 0.0, 0.6]])
+    x[:, 3] = (5.0, 3.0, 2.0)
+    s.add_instance(g, x.reshape(12))
+    return s
+
+
+def test_sheared_and_mirrored_instances(built_lib):
+    cam = api.make_camera(W, H, pos=(1.5, 6.0, 18.0), pitch=12.0, yaw=186.0)
+    diffs = run_sequence_both(_odd_transform_scene(), W, H, frames=2, renderer=api.RENDERER_UNBIASED, camera=cam)
+    diffs += run_pt_both(_odd_transform_scene(), W, H, frames=1, max_len=5, camera=cam)
+    assert not diffs, "\n".join(diffs[:12])
