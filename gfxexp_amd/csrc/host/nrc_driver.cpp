@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -37,6 +38,13 @@ struct gfxh_nrc {
     std::mt19937 perFrameRng{ 72139121 };                  // main:1602
     gfx_camera prevCamera;
     uint32_t lastNumTrainingData = 0, lastTileSize[2] = { 8, 8 }, lastNumInferenceQueries = 0;
+    // The four training steps of frame N only feed the inference of frame N + 1, so they run on their own
+    // stream underneath the G-buffer / path-tracing kernels of frame N + 1 (a training step is ~300 single-wave
+    // blocks: it leaves most of the chip idle on its own).  evData: shuffled training data ready;
+    // evTrained: weights of the last step packed.
+    hipStream_t trainStream = nullptr;
+    hipEvent_t evData = nullptr, evTrained = nullptr;
+    bool trainPending = false, overlapTraining = true;
 };
 
 static int nrc_alloc(gfxh_nrc* r, void** p, size_t bytes) {
@@ -62,6 +70,9 @@ void gfxh_nrc_default_config(gfxh_nrc_config* cfg, uint32_t width, uint32_t heig
 void gfxh_nrc_destroy(gfxh_nrc* r) {
     if (!r) return;
     (void)hipDeviceSynchronize();
+    if (r->evData) (void)hipEventDestroy(r->evData);
+    if (r->evTrained) (void)hipEventDestroy(r->evTrained);
+    if (r->trainStream) (void)hipStreamDestroy(r->trainStream);
     if (r->network) (void)gfx_nrc_destroy(r->ctx, r->network);
     for (void* p : r->allocations) (void)hipFree(p);
     delete r;
@@ -127,6 +138,17 @@ int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out) {
         return 1;
     }
     r->prevCamera = cfg->camera;
+    {
+        const char* e = std::getenv("GFX_NRC_SERIAL_TRAINING");   // debugging aid: train on the caller's stream
+        r->overlapTraining = !(e && e[0] == '1');
+        // non-blocking: the caller's stream may be the legacy default stream, which would serialise a blocking one
+        if (!nrc_hip_ok(hipStreamCreateWithFlags(&r->trainStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
+            !nrc_hip_ok(hipEventCreateWithFlags(&r->evData, hipEventDisableTiming), "hipEventCreate") ||
+            !nrc_hip_ok(hipEventCreateWithFlags(&r->evTrained, hipEventDisableTiming), "hipEventCreate")) {
+            gfxh_nrc_destroy(r);
+            return 1;
+        }
+    }
     *out = r;
     return 0;
 }
@@ -163,16 +185,30 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     uint32_t numInferenceQueries = W * H + tilesX * tilesY;
     numInferenceQueries = (numInferenceQueries + 127) / 128 * 128;
     r->lastNumInferenceQueries = numInferenceQueries;
+    if (r->trainPending) {   // the weights this frame infers with come from the previous frame's training
+        NRC_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), r->evTrained, 0));
+        r->trainPending = false;
+    }
     NRC_GFX(gfx_nrc_infer(ctx, stream, r->network, r->np.inferenceRadianceQueryBuffer, numInferenceQueries, r->np.inferredRadianceBuffer));
     NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_ACCUMULATE, W, H, cfg.maxPathLength, 0, 0));
     if (cfg.train) {
         NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_PROPAGATE, W, H, cfg.maxPathLength, 0, 0));
         NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_SHUFFLE, W, H, cfg.maxPathLength, 0, 0));
         constexpr uint32_t batchSize = kNumTrainingDataPerFrame / 4;                 // main:2350
+        void* ts = stream;
+        if (r->overlapTraining) {
+            NRC_HIP(hipEventRecord(r->evData, static_cast<hipStream_t>(stream)));
+            NRC_HIP(hipStreamWaitEvent(r->trainStream, r->evData, 0));
+            ts = r->trainStream;
+        }
         for (uint32_t step = 0; step < 4; ++step) {
             const char* q = static_cast<const char*>(r->np.trainRadianceQueryBuffer[1]) + 56ull * step * batchSize;
             const char* t = static_cast<const char*>(r->np.trainTargetBuffer[1]) + 12ull * step * batchSize;
-            NRC_GFX(gfx_nrc_train(ctx, stream, r->network, q, t, batchSize, (lossOut && step == 3) ? lossOut : nullptr));
+            NRC_GFX(gfx_nrc_train(ctx, ts, r->network, q, t, batchSize, (lossOut && step == 3) ? lossOut : nullptr));
+        }
+        if (r->overlapTraining) {
+            NRC_HIP(hipEventRecord(r->evTrained, r->trainStream));
+            r->trainPending = true;
         }
     }
     r->prevCamera = cfg.camera;
@@ -181,7 +217,10 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
 }
 
 void* gfxh_nrc_beauty_buffer(gfxh_nrc* r) { return r->sp.beautyAccumBuffer; }
-uint64_t gfxh_nrc_network(gfxh_nrc* r) { return r->network; }
+uint64_t gfxh_nrc_network(gfxh_nrc* r) {
+    if (r->trainStream) (void)hipStreamSynchronize(r->trainStream);   // whoever asks for the network sees it trained
+    return r->network;
+}
 int gfxh_nrc_stats(gfxh_nrc* r, uint32_t* numTrainingData, uint32_t tileSize[2], uint32_t* numInferenceQueries) {
     if (numTrainingData) *numTrainingData = r->lastNumTrainingData;
     if (tileSize) { tileSize[0] = r->lastTileSize[0]; tileSize[1] = r->lastTileSize[1]; }
