@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,6 +39,14 @@ struct gfxh_restir {
     gfx_camera camera, prevCamera;
     float envPowerCoeff = 1.0f, envRotation = 0.0f;
     gfx_regir_params regir;
+    // Frame pipelining: the G-buffer pass of frame N + 1 (primary rays, closest-hit traversal, resolve) depends on
+    // nothing frame N computes, only on frame N being done with the G-buffer it overwrites (the "previous" one,
+    // last read by the temporal pass).  It runs on gbStream underneath the rest of frame N; the context keeps
+    // a separate scratch set for it.  evPrevRead: frame N no longer reads the previous G-buffer;
+    // evGbuffer: the G-buffer of the frame is complete.
+    hipStream_t gbStream = nullptr;
+    hipEvent_t evPrevRead = nullptr, evGbuffer = nullptr;
+    bool prevReadPending = false, pipelineFrames = true;
 };
 
 extern "C" {
@@ -181,6 +190,16 @@ int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir*
     }
     r->camera = cfg->camera;
     r->prevCamera = cfg->camera;
+    {
+        const char* e = std::getenv("GFX_SERIAL_FRAMES");   // debugging aid: everything on the caller's stream
+        r->pipelineFrames = !(e && e[0] == '1');
+        if (!hip_ok(hipStreamCreateWithFlags(&r->gbStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evPrevRead, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evGbuffer, hipEventDisableTiming), "hipEventCreate")) {
+            gfxh_restir_destroy(r);
+            return 1;
+        }
+    }
     *out = r;
     return 0;
 }
@@ -188,6 +207,9 @@ int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir*
 void gfxh_restir_destroy(gfxh_restir* r) {
     if (!r) return;
     (void)hipDeviceSynchronize();
+    if (r->evPrevRead) (void)hipEventDestroy(r->evPrevRead);
+    if (r->evGbuffer) (void)hipEventDestroy(r->evGbuffer);
+    if (r->gbStream) (void)hipStreamDestroy(r->gbStream);
     for (void* p : r->allocations) (void)hipFree(p);
     delete r;
 }
@@ -289,12 +311,38 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     gfxh_band_plan plan;
     gfxh_restir_band_plan(r, &plan);
 #define DRV_GFX(call) do { if (call) { g_driverError = gfx_last_error(ctx); return 1; } } while (0)
+    // G-buffer pass, pipelined under the previous frame when nothing forbids it: jittering advances the pixel
+    // RNGs the previous frame's passes are still drawing from, and a band renderer's halo exchange has its own
+    // ordering with the caller's stream.
+    hipStream_t main = static_cast<hipStream_t>(stream);
+    const bool wholeFrame = cfg.rowBegin == 0 && cfg.rowEnd == 0;
+    const bool pipelined = r->pipelineFrames && !cfg.enableJittering && wholeFrame;
+    auto gbuffer_pass = [&](bool pathTraceEntry, uint32_t rowBegin, uint32_t rowEnd) -> int {
+        hipStream_t s = main;
+        if (pipelined) {
+            s = r->gbStream;
+            if (r->prevReadPending) DRV_HIP(hipStreamWaitEvent(s, r->evPrevRead, 0));
+            else { DRV_HIP(hipEventRecord(r->evPrevRead, main)); DRV_HIP(hipStreamWaitEvent(s, r->evPrevRead, 0)); }   // first frame: after whatever the caller queued
+        }
+        if (pathTraceEntry) DRV_GFX(gfx_pt_launch(ctx, s, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, rowBegin, rowEnd));
+        else DRV_GFX(gfx_restir_launch_rows(ctx, s, GFX_RESTIR_SETUP_GBUFFERS, W, H, rowBegin, rowEnd));
+        if (pipelined) {
+            DRV_HIP(hipEventRecord(r->evGbuffer, s));
+            DRV_HIP(hipStreamWaitEvent(main, r->evGbuffer, 0));
+        }
+        return 0;
+    };
+    // call once the frame has queued its last pass that reads the previous frame's G-buffer
+    auto prev_gbuffer_released = [&]() -> int {
+        if (pipelined) { DRV_HIP(hipEventRecord(r->evPrevRead, main)); r->prevReadPending = true; }
+        return 0;
+    };
     DRV_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, currentReservoirIndex, r->lastSpatialNeighborBaseIndex));
     if (cfg.renderer == GFXH_PATH_TRACE_REGIR) {
         // regir_main.cpp:2021-2066: G-buffer, cell reservoirs (+ temporal reuse unless a new sequence), ReGIR path
         // tracing, last-access update.  Whole frame (the grid is shared state).
         DRV_GFX(gfx_regir_set_params(ctx, &r->regir));
-        DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, 0, 0));
+        if (gbuffer_pass(true, 0, 0) || prev_gbuffer_released()) return 1;
         const int build = (cfg.regirEnableTemporalReuse && !newSequence) ? GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL : GFX_PT_REGIR_BUILD_CELL_RESERVOIRS;
         DRV_GFX(gfx_pt_launch(ctx, stream, build, W, H, cfg.maxPathLength, 0, 0));
         DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_REGIR, W, H, cfg.maxPathLength, 0, 0));
@@ -306,13 +354,13 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     if (cfg.renderer == GFXH_PATH_TRACE_BASELINE) {
         // path_tracing_main.cpp:2068-2093: G-buffer pipeline, then pathTraceBaseline.  A band needs no
         // halo: paths never read a neighbour's pixel state.
-        DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, plan.bandBegin, plan.bandEnd));
+        if (gbuffer_pass(true, plan.bandBegin, plan.bandEnd) || prev_gbuffer_released()) return 1;
         DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_BASELINE, W, H, cfg.maxPathLength, plan.bandBegin, plan.bandEnd));
         r->prevCamera = r->camera;
         ++r->frameIndex;
         return 0;
     }
-    DRV_GFX(gfx_restir_launch_rows(ctx, stream, GFX_RESTIR_SETUP_GBUFFERS, W, H, plan.gbufferRows[0], plan.gbufferRows[1]));   // :2366-2367
+    if (gbuffer_pass(false, plan.gbufferRows[0], plan.gbufferRows[1])) return 1;                  // :2366-2367
 
     if (cfg.renderer == GFXH_REARCHITECTED_RESTIR_BIASED || cfg.renderer == GFXH_REARCHITECTED_RESTIR_UNBIASED) {
         // restir_di_main.cpp:2423-2487; whole-frame only (the previous frame's reservoirs, sample
@@ -325,6 +373,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
         DRV_GFX(gfx_restir_launch(ctx, stream, GFX_RESTIR_PER_PIXEL_RIS, W, H));
         DRV_GFX(gfx_restir_launch(ctx, stream, trace, W, H));
         DRV_GFX(gfx_restir_launch(ctx, stream, shade, W, H));
+        if (prev_gbuffer_released()) return 1;   // shadeAndResample reads the previous G-buffer and sample visibility
         ++r->lastSpatialNeighborBaseIndex;                                                     // :2486
         r->lastReservoirIndex = currentReservoirIndex;
         r->prevCamera = r->camera;
@@ -336,6 +385,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     if (cfg.enableTemporalReuse && !newSequence)
         entry = fp.useUnbiasedEstimator ? GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED : GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED;
     DRV_GFX(gfx_restir_launch_rows(ctx, stream, entry, W, H, plan.initialRows[0], plan.initialRows[1]));
+    if (prev_gbuffer_released()) return 1;   // only the temporal pass reads the previous frame's G-buffer
 
     if (cfg.enableSpatialReuse) {                                                              // :2393-2411
         const int spatial = fp.useUnbiasedEstimator ? GFX_RESTIR_SPATIAL_UNBIASED : GFX_RESTIR_SPATIAL_BIASED;

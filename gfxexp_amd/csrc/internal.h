@@ -95,6 +95,9 @@ struct Context {
     uint32_t maxLeafTris = 4;
     // ray scratch
     DevBuf rayOrg, rayDir, rayOut, rayHits, spill, pixelRaySlot, shadeScratch, spatialScratch, smallCounters;
+    // The G-buffer pass has its own ray queue / hit / stack-spill / ticket scratch, so a driver may run the next
+    // frame's G-buffer pass on a second stream underneath the tail of the current frame (restir_driver.cpp).
+    DevBuf gbRayOrg, gbRayDir, gbRayHits, gbSpill, gbCounters;
     // path tracer scratch (pathtrace.hip)
     DevBuf ptPending, ptExtOrg, ptExtDir, ptExtOwner, ptState;
     DevBuf rearchSlots;
@@ -144,6 +147,8 @@ struct TraceLaunch {
     uint32_t numRays; const uint32_t* numRaysPtr;   // device-side count overrides numRays when non-null
     void* out;
     int mode;
+    DevBuf* spill = nullptr;        // stack-spill area / ticket word; null = the context's shared ones
+    DevBuf* counters = nullptr;
 };
 void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t);
 // ---- lights.hip

@@ -660,11 +660,24 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     if (numPixels == 0) return;
     auto reset_queue = [&]() { GFX_HIP(hipMemsetAsync(a.rayCount, 0, sizeof(uint32_t), stream)); };
     switch (pass) {
-    case GFX_RESTIR_SETUP_GBUFFERS:
+    case GFX_RESTIR_SETUP_GBUFFERS: {
+        // own scratch set (internal.h): this pass may overlap other passes of the previous frame
+        const size_t framePixels = static_cast<size_t>(width) * height;
+        ctx.gbRayOrg.reserve(16 * framePixels); ctx.gbRayDir.reserve(16 * framePixels);
+        ctx.gbRayHits.reserve(sizeof(gfx_hit) * framePixels);
+        a.rayOrg = ctx.gbRayOrg.as<float4>(); a.rayDir = ctx.gbRayDir.as<float4>();
+        a.hits = ctx.gbRayHits.as<gfx_hit>();
         launch_pixels(ctx, stream, "primary_rays", k_primary_rays, a);
-        trace_queue(ctx, stream, a, GFX_TRACE_CLOSEST, numPixels, false, ctx.rayHits.p);
+        TraceLaunch t;
+        t.accel = ctx.accels[ctx.restir.f.travHandle - 1]->dev();
+        t.rayOrgTmin = a.rayOrg; t.rayDirTmax = a.rayDir;
+        t.numRays = numPixels; t.numRaysPtr = nullptr;
+        t.out = ctx.gbRayHits.p; t.mode = GFX_TRACE_CLOSEST;
+        t.spill = &ctx.gbSpill; t.counters = &ctx.gbCounters;
+        trace_launch(ctx, stream, t);
         launch_pixels(ctx, stream, "gbuffer_resolve", k_gbuffer_resolve, a);
         break;
+    }
     case GFX_RESTIR_INITIAL_RIS:
     case GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED:
     case GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED:

@@ -10,7 +10,7 @@ namespace gfx {
 Context::~Context() {
     for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->triIds.release(); delete a; } }
     DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs,
-                      &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
+                      &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
                       &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide,
                       &dTraceDiag, &bCosts, &bDec, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,

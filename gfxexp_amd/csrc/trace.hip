@@ -188,15 +188,17 @@ static uint32_t persistent_grid(Context& ctx) {
 
 void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     const uint32_t grid = persistent_grid(ctx);
-    ctx.spill.reserve(sizeof(uint2) * static_cast<size_t>(grid) * kTraceBlock * kSpillStackDepth);
-    ctx.smallCounters.reserve(256);
-    uint32_t* ticket = ctx.smallCounters.as<uint32_t>();
+    DevBuf& spill = t.spill ? *t.spill : ctx.spill;
+    DevBuf& small = t.counters ? *t.counters : ctx.smallCounters;
+    spill.reserve(sizeof(uint2) * static_cast<size_t>(grid) * kTraceBlock * kSpillStackDepth);
+    small.reserve(256);
+    uint32_t* ticket = small.as<uint32_t>();
     GFX_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream));
     TraceArgs a;
     a.accel = t.accel;
     a.rayOrgTmin = t.rayOrgTmin; a.rayDirTmax = t.rayDirTmax;
     a.numRaysPtr = t.numRaysPtr; a.numRays = t.numRays;
-    a.out = t.out; a.ticket = ticket; a.spill = ctx.spill.as<uint2>();
+    a.out = t.out; a.ticket = ticket; a.spill = spill.as<uint2>();
     a.counters = ctx.countersEnabled ? ctx.dTraceCounters.as<unsigned long long>() : nullptr;
     a.diag = nullptr;
     if (ctx.countersEnabled) {
