@@ -1,3 +1,4 @@
+# rocprofv3 PMC passes used for profiles/r01g_initial_candidates_experiments.txt (TA / TCP / TCC view of k_initial_candidates).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 B="python bench.py --steps 6 --warmup 2 --mse-ref-spp 0 --cpu-sample 0"

@@ -1,3 +1,4 @@
+# rocprofv3 PMC passes over tools/bench_nrc.py for k_nrc_train (profiles/r01c_nrc_network.txt).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 B="python tools/bench_nrc.py --steps 5"
