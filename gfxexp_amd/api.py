@@ -143,7 +143,8 @@ GBUFFER3_DTYPE = np.dtype([("qShadingNormal", "<u4"), ("qShadingTangent", "<u4")
 # every symbol include/gfxexp.h and include/gfxexp_host.h declare
 C_ABI_SYMBOLS = [
     "gfx_ctx_create", "gfx_ctx_destroy", "gfx_last_error", "gfx_version", "gfx_material_set", "gfx_geom_create",
-    "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_accel_build",
+    "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_instance_set_transform_and_normal_matrix",
+    "gfx_accel_build",
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
     "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
@@ -160,7 +161,7 @@ HOST_ABI_SYMBOLS = [
     "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
     "gfxh_restir_band_plan", "gfxh_restir_create",
     "gfxh_env_build_importance", "gfxh_env_make_sky", "gfxh_restir_set_env",
-    "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera",
+    "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
     "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_beauty_buffer",
     "gfxh_nrc_network", "gfxh_nrc_stats",
@@ -387,6 +388,16 @@ class Context:
     def _check(self, rc):
         if rc:
             raise GfxError(self.L.gfx_last_error(self.h).decode())
+
+    def instance_set_transform(self, inst_slot, xfm12, normal_matrix9=None):
+        """InstanceController::update for one instance (previous matrix kept for the motion vectors).  Rebuild the
+        acceleration structure (accel_build with the old handle) before the next trace / frame."""
+        x = np.ascontiguousarray(xfm12, np.float32).reshape(12)
+        if normal_matrix9 is None:
+            self._check(self.L.gfx_instance_set_transform(self.h, C.c_uint32(inst_slot), _p(x)))
+        else:
+            nm = np.ascontiguousarray(normal_matrix9, np.float32).reshape(9)
+            self._check(self.L.gfx_instance_set_transform_and_normal_matrix(self.h, C.c_uint32(inst_slot), _p(x), _p(nm)))
 
     def accel_build(self, stream=0, handle=0):
         hd = C.c_uint64(handle)
@@ -622,6 +633,11 @@ class RestirRenderer:
 
     def set_camera(self, cam):
         self.L.gfxh_restir_set_camera(self.h, C.byref(cam))
+
+    def rebuild_accel(self, stream=0):
+        """After Context.instance_set_transform: rebuild this renderer's BVH in place (Scene::updateASs)."""
+        if self.L.gfxh_restir_rebuild_accel(self.h, C.c_void_p(stream)):
+            raise GfxError("gfxh_restir_rebuild_accel: " + self.L.gfxh_restir_last_error().decode())
 
     def beauty_ptr(self):
         return self.L.gfxh_restir_beauty_buffer(self.h)

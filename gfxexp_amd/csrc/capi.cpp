@@ -103,13 +103,27 @@ int gfx_instance_create(gfx_ctx* ctx, uint32_t group, const float xfm[12], uint3
     GFX_CATCH(ctx)
 }
 
-int gfx_instance_set_transform(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12]) {
-    GFX_TRY(ctx)
+static void instance_update(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12], const float* normalMatrix) {
     if (instSlot >= ctx->c.insts.size()) throw HipError("gfx_instance_set_transform: unknown instSlot");
     HostInstance& inst = ctx->c.insts[instSlot];
     std::memcpy(inst.prevTransform, inst.transform, sizeof(float) * 12);
     std::memcpy(inst.transform, xfm, sizeof(float) * 12);
+    instance_cur_to_prev(inst.prevTransform, inst.transform, inst.curToPrev);
+    inst.animated = true;
+    inst.hasNormalMatrix = normalMatrix != nullptr;
+    if (normalMatrix) std::memcpy(inst.normalMatrix, normalMatrix, sizeof(float) * 9);
     ctx->c.sceneDirty = true;
+}
+
+int gfx_instance_set_transform(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12]) {
+    GFX_TRY(ctx)
+    instance_update(ctx, instSlot, xfm, nullptr);
+    GFX_CATCH(ctx)
+}
+
+int gfx_instance_set_transform_and_normal_matrix(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12], const float normalMatrix[9]) {
+    GFX_TRY(ctx)
+    instance_update(ctx, instSlot, xfm, normalMatrix);
     GFX_CATCH(ctx)
 }
 

@@ -252,6 +252,15 @@ int gfxh_restir_set_env(gfxh_restir* r, float* texels, uint32_t w, uint32_t h, f
     return 0;
 }
 int gfxh_restir_set_camera(gfxh_restir* r, const gfx_camera* cam) { r->camera = *cam; return 0; }
+int gfxh_restir_rebuild_accel(gfxh_restir* r, void* stream) {
+    // in place: the handle stays valid.  Ordered after everything queued on `stream`; the pipelined G-buffer pass
+    // of the last frame was joined into that stream before its later passes were queued.
+    if (gfx_accel_build(r->ctx, stream, &r->accel)) { g_driverError = gfx_last_error(r->ctx); return 1; }
+    // the next frame's pipelined G-buffer pass must not start before the build
+    if (r->evPrevRead && !hip_ok(hipEventRecord(r->evPrevRead, static_cast<hipStream_t>(stream)), "hipEventRecord")) return 1;
+    r->prevReadPending = r->evPrevRead != nullptr;
+    return 0;
+}
 void* gfxh_restir_beauty_buffer(gfxh_restir* r) { return r->sp.beautyAccumBuffer; }
 uint64_t gfxh_restir_accel(gfxh_restir* r) { return r->accel; }
 

@@ -38,7 +38,13 @@ struct HostInstance {
     uint32_t group = 0;
     float transform[12];
     float prevTransform[12];
+    // set by gfx_instance_set_transform (InstanceController::update): curToPrevTransform = prev * invert(cur),
+    // optional caller-supplied normal matrix (row-major 3x3)
+    bool animated = false, hasNormalMatrix = false;
+    float curToPrev[12];
+    float normalMatrix[9];
 };
+void instance_cur_to_prev(const float prev[12], const float cur[12], float out[12]);   // scene.cpp
 
 struct Accel {
     // nodes and triangle records are both 64-byte items and live in ONE allocation (nodes first, triangle

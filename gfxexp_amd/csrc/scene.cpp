@@ -58,6 +58,32 @@ static void normal_matrix(const float x[12], float out[12]) {
     }
 }
 
+// curToPrevTransform = prevTransform * invert(matM2W) (common/common_host.h:851), rows 0..2 of the 4x4 product.
+// Matrix4x4::invert (basic_types.h:4597-4626) is the cofactor expansion: entry (i, j) of the inverse = +/- the
+// 3x3 minor without row j and column i, its six triple products summed in the order
+//   (r0c0 r1c1 r2c2) - (r2c0 r1c1 r0c2) + (r1c0 r2c1 r0c2) - (r0c0 r2c1 r1c2) + (r2c0 r0c1 r1c2) - (r1c0 r0c1 r2c2)
+// over the remaining rows r0 < r1 < r2 / columns c0 < c1 < c2, times 1 / det with det expanded along column 0;
+// the matrix product is row-of-left . column-of-right, x y z w in that order (:4552-4559).
+void instance_cur_to_prev(const float prev[12], const float cur[12], float out[12]) {
+    float a[16], inv[16];   // row-major 4x4
+    for (int k = 0; k < 12; ++k) a[k] = cur[k];
+    a[12] = 0.0f; a[13] = 0.0f; a[14] = 0.0f; a[15] = 1.0f;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            int rows[3], cols[3], nr = 0, nc = 0;
+            for (int k = 0; k < 4; ++k) { if (k != j) rows[nr++] = k; if (k != i) cols[nc++] = k; }
+            auto e = [&](int r, int c) { return a[4 * rows[r] + cols[c]]; };
+            const float minor = (e(0, 0) * e(1, 1) * e(2, 2)) - (e(2, 0) * e(1, 1) * e(0, 2)) + (e(1, 0) * e(2, 1) * e(0, 2)) -
+                                (e(0, 0) * e(2, 1) * e(1, 2)) + (e(2, 0) * e(0, 1) * e(1, 2)) - (e(1, 0) * e(0, 1) * e(2, 2));
+            inv[4 * i + j] = ((i + j) % 2) ? -minor : minor;
+        }
+    const float recDet = 1.0f / (a[0] * inv[0] + a[4] * inv[1] + a[8] * inv[2] + a[12] * inv[3]);
+    for (int k = 0; k < 16; ++k) inv[k] *= recDet;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j)
+            out[4 * i + j] = prev[4 * i + 0] * inv[0 + j] + prev[4 * i + 1] * inv[4 + j] + prev[4 * i + 2] * inv[8 + j] + prev[4 * i + 3] * inv[12 + j];
+}
+
 template <typename T>
 static void upload(DevBuf& b, const std::vector<T>& v, hipStream_t stream) {
     b.reserve(std::max<size_t>(sizeof(T) * v.size(), 16));
@@ -95,10 +121,15 @@ void scene_upload(Context& ctx, hipStream_t stream) {
         const HostInstance& hi = ctx.insts[ii];
         DevInstance& d = ctx.hInsts[ii];
         std::memcpy(d.transform, hi.transform, sizeof(float) * 12);
-        // curToPrevTransform: identity for static instances (common_host.cpp:2631)
+        // curToPrevTransform: identity for static instances (common_host.cpp:2631), prev * invert(cur) once moved
         const float ident[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
-        std::memcpy(d.curToPrevTransform, ident, sizeof(ident));
-        normal_matrix(hi.transform, d.normalMatrix);
+        std::memcpy(d.curToPrevTransform, hi.animated ? hi.curToPrev : ident, sizeof(ident));
+        if (hi.hasNormalMatrix)
+            for (int rr = 0; rr < 3; ++rr) {
+                for (int cc = 0; cc < 3; ++cc) d.normalMatrix[rr * 4 + cc] = hi.normalMatrix[rr * 3 + cc];
+                d.normalMatrix[rr * 4 + 3] = 0.0f;
+            }
+        else normal_matrix(hi.transform, d.normalMatrix);
         d.uniformScale = std::sqrt(hi.transform[0] * hi.transform[0] + hi.transform[4] * hi.transform[4] + hi.transform[8] * hi.transform[8]);
         const std::vector<uint32_t>& slots = ctx.groups[hi.group];
         d.slotsOffset = static_cast<uint32_t>(slotPool.size());

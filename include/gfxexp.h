@@ -105,8 +105,16 @@ int gfx_group_create(gfx_ctx* ctx, const uint32_t* geomInstSlots, uint32_t n, ui
 /* common/common_host.cpp:2582-2656 createInstance: xfm is 3x4 row-major (the float[12] handed to
  * optixInst.setTransform).  instSlot doubles as the OptiX instance id. */
 int gfx_instance_create(gfx_ctx* ctx, uint32_t group, const float xfm[12], uint32_t* instSlot);
-/* common/common_host.h:798-856 InstanceController::update (per-frame transform + curToPrev). */
+/* common/common_host.h:837-855 InstanceController::update, the InstanceData part: xfm becomes the instance's
+ * object-to-world matrix and curToPrevTransform = (previous matrix) * invert(xfm), so the next G-buffer pass
+ * writes motion vectors for the instance (optix_gbuffer_kernels.cu:132).  Like the reference's controllers, call
+ * it every frame for an animated instance (a frame without a call keeps the last curToPrevTransform), then
+ * gfx_accel_build again (Scene::updateASs, restir_di_main.cpp:2263-2264); the emitter distributions and
+ * records are rebuilt by the next gfx_lights_build_instances.  The normal matrix is recomputed as
+ * transpose(invert(upper-left 3x3)) like at creation; ..._and_normal_matrix takes the controller's own
+ * matRot / curScale (row-major 3x3, common_host.h:843) for a bit-exact shim. */
 int gfx_instance_set_transform(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12]);
+int gfx_instance_set_transform_and_normal_matrix(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12], const float normalMatrix[9]);
 
 /* common/common_host.h:1027-1100 Scene::updateASs -> OptixTraversableHandle.  Builds the HIP
  * LBVH -> BVH8 over all instances (world space).  The 64-bit handle fits the reference's

@@ -166,6 +166,10 @@ int gfxh_restir_reset(gfxh_restir* r);
  * enable environment lighting with the given power coefficient and rotation (restir_di_main.cpp:1188-1197). */
 int gfxh_restir_set_env(gfxh_restir* r, float* texels4, uint32_t w, uint32_t h, float powerCoeff, float rotation);
 int gfxh_restir_set_camera(gfxh_restir* r, const gfx_camera* cam);
+/* Scene::updateASs of an animated frame (restir_di_main.cpp:2258-2264): call after gfx_instance_set_transform on
+ * the renderer's context and before the next gfxh_restir_render_frame; rebuilds the renderer's BVH in place
+ * (same handle) on `stream`. */
+int gfxh_restir_rebuild_accel(gfxh_restir* r, void* stream);
 /* Device pointer of the float4 beauty accumulation buffer (W*H). */
 void* gfxh_restir_beauty_buffer(gfxh_restir* r);
 /* Copies of the static parameters (device pointers) and of the last frame parameters. */

@@ -158,6 +158,13 @@ class OracleScene:
         self.L.orc_instance_create(self.h, C.c_uint32(group), _p(x), C.byref(out))
         return out.value
 
+    def set_instance_transform(self, inst_slot, xfm12, normal_matrix9=None):
+        """InstanceController::update for one instance; call commit() again before tracing / rendering."""
+        x = np.ascontiguousarray(xfm12, dtype=np.float32).reshape(12)
+        nm = None if normal_matrix9 is None else _p(np.ascontiguousarray(normal_matrix9, dtype=np.float32).reshape(9))
+        if self.L.orc_instance_set_transform(self.h, C.c_uint32(inst_slot), _p(x), nm):
+            raise RuntimeError("orc_instance_set_transform failed")
+
     def commit(self, brute_force=False, config=None):
         secs = C.c_double()
         cfg = None

@@ -78,6 +78,26 @@ int orc_instance_create(orc_scene* s, uint32_t group, const float xfm[12], uint3
     return 0;
 }
 
+// common/common_host.h:837-855 InstanceController::update, the InstanceData part: the new object-to-world
+// matrix replaces the old one, curToPrevTransform = prevTransform * invert(matM2W).  normalMatrix9: the
+// controller's matRot / curScale (row-major 3x3) or NULL for transpose(invert(upper-left 3x3)) as at creation.
+// orc_scene_commit must run again afterwards (updateASs + the light distributions, restir_di_main.cpp:2263-2264).
+int orc_instance_set_transform(orc_scene* s, uint32_t instSlot, const float xfm[12], const float* normalMatrix9) {
+    if (instSlot >= s->scene.insts.size()) return 1;
+    InstanceData& inst = s->scene.insts[instSlot];
+    const M34 cur = toM34(xfm);
+    inst.curToPrevTransform = curToPrev(inst.transform, cur);
+    inst.transform = cur;
+    if (normalMatrix9) {
+        inst.normalMatrix.r0 = V3(normalMatrix9[0], normalMatrix9[1], normalMatrix9[2]);
+        inst.normalMatrix.r1 = V3(normalMatrix9[3], normalMatrix9[4], normalMatrix9[5]);
+        inst.normalMatrix.r2 = V3(normalMatrix9[6], normalMatrix9[7], normalMatrix9[8]);
+    }
+    else inst.normalMatrix = transpose(invert(upperLeft(inst.transform)));
+    inst.uniformScale = length(V3(xfm[0], xfm[4], xfm[8]));
+    return 0;
+}
+
 // Build the emitter distributions and the world-space BVH (SAH builder restatement).
 // config: {splittingBudget, intNodeTravCost, primIntersectCost, minLeaf, maxLeaf} or NULL for the
 // nrtdsm defaults {0.3, 1.2, 1.0, 1, 128} (nrtdsm/nrtdsm_main.cpp:811-816).

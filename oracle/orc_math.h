@@ -206,6 +206,41 @@ static inline V3 xfmVector(const M34& a, V3 v) {
               a.m[4] * v.x + a.m[5] * v.y + a.m[6] * v.z + a.m[7] * 0.0f,
               a.m[8] * v.x + a.m[9] * v.y + a.m[10] * v.z + a.m[11] * 0.0f);
 }
+// prevTransform * invert(matM2W) of InstanceController::update (common/common_host.h:851), rows 0..2.
+// Matrix4x4::invert (basic_types.h:4597-4626): element (row i, column j) of the inverse is the signed 3x3
+// minor of the matrix without row j and column i, expanded in the reference's term order
+//   m[r0][c0] m[r1][c1] m[r2][c2] - m[r2][c0] m[r1][c1] m[r0][c2] + m[r1][c0] m[r2][c1] m[r0][c2]
+// - m[r0][c0] m[r2][c1] m[r1][c2] + m[r2][c0] m[r0][c1] m[r1][c2] - m[r1][c0] m[r0][c1] m[r2][c2],
+// all sixteen scaled by recDet = 1 / (m00 inv00 + m10 inv01 + m20 inv02 + m30 inv03);
+// the product is Matrix4x4::operator*= (:4552-4559): dot4(row of the left, column of the right).
+static inline void invert44(const float m[4][4], float inv[4][4]) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            int r[3], c[3], nr = 0, nc = 0;
+            for (int k = 0; k < 4; ++k) { if (k != j) r[nr++] = k; if (k != i) c[nc++] = k; }
+            const float v = (m[r[0]][c[0]] * m[r[1]][c[1]] * m[r[2]][c[2]]) - (m[r[2]][c[0]] * m[r[1]][c[1]] * m[r[0]][c[2]]) +
+                            (m[r[1]][c[0]] * m[r[2]][c[1]] * m[r[0]][c[2]]) - (m[r[0]][c[0]] * m[r[2]][c[1]] * m[r[1]][c[2]]) +
+                            (m[r[2]][c[0]] * m[r[0]][c[1]] * m[r[1]][c[2]]) - (m[r[1]][c[0]] * m[r[0]][c[1]] * m[r[2]][c[2]]);
+            inv[i][j] = ((i + j) & 1) ? -v : v;
+        }
+    const float recDet = 1.0f / (m[0][0] * inv[0][0] + m[1][0] * inv[0][1] + m[2][0] * inv[0][2] + m[3][0] * inv[0][3]);
+    for (int j = 0; j < 4; ++j)          // the reference scales its column-major array in order
+        for (int i = 0; i < 4; ++i) inv[i][j] *= recDet;
+}
+static inline void toM44(const float a[12], float m[4][4]) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) m[i][j] = a[4 * i + j];
+    m[3][0] = 0.0f; m[3][1] = 0.0f; m[3][2] = 0.0f; m[3][3] = 1.0f;
+}
+static inline M34 curToPrev(const M34& prev, const M34& cur) {
+    float p[4][4], c[4][4], inv[4][4];
+    toM44(prev.m, p); toM44(cur.m, c);
+    invert44(c, inv);
+    M34 out;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j)
+            out.m[4 * i + j] = p[i][0] * inv[0][j] + p[i][1] * inv[1][j] + p[i][2] * inv[2][j] + p[i][3] * inv[3][j];
+    return out;
+}
 static inline M3 upperLeft(const M34& a) {
     M3 m;
     m.r0 = V3(a.m[0], a.m[1], a.m[2]);
