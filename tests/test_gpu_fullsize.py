@@ -1,0 +1,118 @@
+"""-m gpu: BASELINE configs[2] at its full size (1920x1080, the 2.5 M-triangle street stand-in of bench.py).
+
+The CPU oracle cannot render the whole frame in seconds, so parity at this size is established by
+  * an oracle run restricted to a window of the frame (plus the margin the reuse passes read), compared
+    bit for bit with the same pixels of the full-frame GPU run after every pass of two frames, and
+  * properties that do not depend on the size: run-to-run determinism (ray-queue slots are handed out by
+    atomics in a different order every run), pipelined == serial frame loop, band split == full frame.
+"""
+import numpy as np
+import pytest
+
+from gfxexp_amd import api
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+W, H = 1920, 1080
+CAM = dict(pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)        # bench.py's camera
+
+
+def _window_mask(x0, y0, x1, y1):
+    m = np.zeros((H, W), bool)
+    m[y0:y1, x0:x1] = True
+    return m.reshape(-1)
+
+
+def _pick(arr, mask, n):
+    a = np.asarray(arr)
+    if a.ndim >= 2 and a.shape[0] == 3 and a.shape[1] == n:      # reservoir planes [3][n][4]
+        return a[:, mask]
+    return a[mask]
+
+
+def test_window_of_the_full_frame_matches_the_oracle(built_lib):
+    import torch
+    hs = util.bench_street()
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    ctx.lights_build_static()
+    osc = util.feed_oracle(hs)
+    cam = api.make_camera(W, H, **CAM)
+    ocam = util.copy_struct(O.GfxCamera, cam)
+    pb_init, pb_cpu = util.PixelBuffers(W, H), util.PixelBuffers(W, H)
+    dev = util.DeviceBuffers(pb_init)
+    s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
+    stream = torch.cuda.current_stream().cuda_stream
+    n = W * H
+    inner = (900, 560, 980, 600)                       # street level, left of the frame centre: lamps, facades, props
+    radius, passes, nb = 20, 2, 5
+    # margins: a frame's final reservoirs are exact `radius * passes` pixels inside the region its first passes
+    # covered, and the next frame's temporal pass reads them -- so frame 0 starts 40 pixels wider than frame 1
+    pads = [2 * radius * passes + 8, radius * passes + 8]
+
+    def grow(r, d):
+        return (max(0, r[0] - d), max(0, r[1] - d), min(W, r[2] + d), min(H, r[3] + d))
+
+    diffs = []
+    last_res, last_base = 1, 0
+    for frame in range(2):
+        kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=0,
+                  numSpatialNeighbors=nb, useUnbiasedEstimator=0, useLowDiscrepancyNeighbors=1, reuseVisibility=1)
+        f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, W, H, cam, travHandle=accel, **kw)
+        f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, W, H, ocam, travHandle=0, **kw)
+        ctx.lights_build_instances(stream)
+        cur = (last_res + 1) % 2
+        pad = pads[frame]
+        plan = [(api.PASS_SETUP_GBUFFERS, 0, pad), (api.PASS_INITIAL_RIS if frame == 0 else api.PASS_INITIAL_TEMPORAL_BIASED, 0, pad),
+                (api.PASS_SPATIAL_BIASED, 0, pad - radius), (api.PASS_SPATIAL_BIASED, nb, pad - 2 * radius),
+                (api.PASS_SHADING, 2 * nb, pad - 2 * radius)]
+        for k, (pass_id, base_off, margin) in enumerate(plan):
+            base = last_base + (base_off if pass_id != api.PASS_SHADING else nb * passes)
+            ctx.restir_set_params(s_gpu, f_gpu, cur, base, stream)
+            ctx.restir_launch(pass_id, W, H, stream)
+            osc.restir_launch(s_cpu, f_cpu, cur, base, pass_id, rect=grow(inner, margin))
+            if pass_id == api.PASS_SPATIAL_BIASED:
+                cur = (cur + 1) % 2
+        last_base += nb * passes
+        last_res = cur
+        got, want = dev.download(), pb_cpu.arrays()
+        mask = _window_mask(*inner)
+        for key in ("rng", "beauty", "albedo", "normal", f"gb0_{frame % 2}", f"gb1_{frame % 2}", f"gb2_{frame % 2}", f"gb3_{frame % 2}",
+                    f"res_{cur}", f"info_{cur}"):
+            a = np.ascontiguousarray(_pick(got[key].reshape(want[key].shape), mask, n)).view(np.uint8)
+            b = np.ascontiguousarray(_pick(want[key], mask, n)).view(np.uint8)
+            if not np.array_equal(a, b):
+                diffs.append(f"frame {frame}: {key}: {np.count_nonzero(a != b)} bytes differ inside the window")
+    assert not diffs, "\n".join(diffs)
+    beauty = pb_cpu.beauty.reshape(H, W, 4)[inner[1]:inner[3], inner[0]:inner[2], :3]
+    assert np.isfinite(beauty).all() and beauty.mean() > 1e-4     # the window is lit, not background
+
+
+def _render(frames, serial=False, band=None, monkeypatch=None):
+    import torch
+    ctx = api.Context(0)
+    util.bench_street().upload(ctx)
+    cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
+    cfg.camera = api.make_camera(W, H, **CAM)
+    if band is not None:
+        cfg.rowBegin, cfg.rowEnd = band
+    if monkeypatch is not None:
+        monkeypatch.setenv("GFX_SERIAL_FRAMES", "1" if serial else "0")
+    r = api.RestirRenderer(ctx, cfg)
+    for _ in range(frames):
+        r.render_frame()
+    torch.cuda.synchronize()
+    out = ctx.read_device(r.beauty_ptr(), W * H * 16).view(np.float32).reshape(-1, 4).copy()
+    return out, ctx, r
+
+
+def test_full_size_frames_are_deterministic_and_pipelining_changes_nothing(built_lib, monkeypatch):
+    a, ctx_a, ra = _render(3, serial=False, monkeypatch=monkeypatch)
+    b, ctx_b, rb = _render(3, serial=False, monkeypatch=monkeypatch)
+    util.assert_same_bits("run-to-run", a, b)
+    del ctx_b, rb
+    c, ctx_c, rc = _render(3, serial=True, monkeypatch=monkeypatch)
+    util.assert_same_bits("pipelined vs serial frame loop", a, c)
+    assert np.isfinite(a).all() and a[:, :3].mean() > 1e-3
