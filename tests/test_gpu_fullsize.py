@@ -116,3 +116,42 @@ def test_full_size_frames_are_deterministic_and_pipelining_changes_nothing(built
     c, ctx_c, rc = _render(3, serial=True, monkeypatch=monkeypatch)
     util.assert_same_bits("pipelined vs serial frame loop", a, c)
     assert np.isfinite(a).all() and a[:, :3].mean() > 1e-3
+
+
+def test_path_tracer_window_of_the_full_frame_matches_the_oracle(built_lib):
+    """Baseline path tracer (max path length 5) on the bench scene at 1920x1080: paths never read a neighbour's
+    state, so the oracle's window needs no margin; two frames with accumulation."""
+    import torch
+    hs = util.bench_street()
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    ctx.lights_build_static()
+    osc = util.feed_oracle(hs)
+    cam = api.make_camera(W, H, **CAM)
+    ocam = util.copy_struct(O.GfxCamera, cam)
+    pb_init, pb_cpu = util.PixelBuffers(W, H), util.PixelBuffers(W, H)
+    dev = util.DeviceBuffers(pb_init)
+    s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
+    stream = torch.cuda.current_stream().cuda_stream
+    window = (880, 540, 1008, 604)
+    mask = _window_mask(*window)
+    diffs = []
+    for frame in range(2):
+        kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=frame)
+        f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, W, H, cam, travHandle=accel, **kw)
+        f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, W, H, ocam, travHandle=0, **kw)
+        ctx.lights_build_instances(stream)
+        ctx.restir_set_params(s_gpu, f_gpu, 0, 0, stream)
+        for pass_id in (api.PT_SETUP_GBUFFERS, api.PT_PATH_TRACE_BASELINE):
+            ctx.pt_launch(pass_id, W, H, 5, 0, 0, stream)
+            osc.pt_launch(s_cpu, f_cpu, pass_id, 5, rect=window)
+        got, want = dev.download(), pb_cpu.arrays()
+        for key in ("rng", "beauty", "albedo", "normal", f"gb0_{frame % 2}", f"gb1_{frame % 2}"):
+            a = np.ascontiguousarray(_pick(got[key].reshape(want[key].shape), mask, W * H)).view(np.uint8)
+            b = np.ascontiguousarray(_pick(want[key], mask, W * H)).view(np.uint8)
+            if not np.array_equal(a, b):
+                diffs.append(f"frame {frame}: {key}: {np.count_nonzero(a != b)} bytes differ inside the window")
+    assert not diffs, "\n".join(diffs)
+    beauty = pb_cpu.beauty.reshape(H, W, 4)[window[1]:window[3], window[0]:window[2], :3]
+    assert np.isfinite(beauty).all() and beauty.mean() > 1e-4
