@@ -31,8 +31,10 @@ def _pick(arr, mask, n):
     return a[mask]
 
 
-def test_window_of_the_full_frame_matches_the_oracle(built_lib):
+@pytest.mark.parametrize("config", ["configs[2]: biased", "configs[5]: unbiased + 2048x1024 environment map"])
+def test_window_of_the_full_frame_matches_the_oracle(built_lib, config):
     import torch
+    unbiased = "unbiased" in config
     hs = util.bench_street()
     ctx = api.Context(0)
     hs.upload(ctx)
@@ -42,14 +44,23 @@ def test_window_of_the_full_frame_matches_the_oracle(built_lib):
     cam = api.make_camera(W, H, **CAM)
     ocam = util.copy_struct(O.GfxCamera, cam)
     pb_init, pb_cpu = util.PixelBuffers(W, H), util.PixelBuffers(W, H)
+    env_kw = {}
+    if unbiased:
+        ew, eh = 2048, 1024                            # analytic sky + sun, lat-long
+        sky = api.env_make_sky(ew, eh)
+        pb_init.set_env(sky, ew, eh)
+        pb_cpu.set_env(sky, ew, eh)
+        env_kw = dict(enableEnvLight=1, envLightPowerCoeff=0.6, envLightRotation=0.4)
     dev = util.DeviceBuffers(pb_init)
     s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
     stream = torch.cuda.current_stream().cuda_stream
     n = W * H
     inner = (900, 560, 980, 600)                       # street level, left of the frame centre: lamps, facades, props
-    radius, passes, nb = 20, 2, 5
+    radius = 20
+    passes, nb = (1, 3) if unbiased else (2, 5)        # restir_di_main.cpp:1965-1967
+    spatial = api.PASS_SPATIAL_UNBIASED if unbiased else api.PASS_SPATIAL_BIASED
     # margins: a frame's final reservoirs are exact `radius * passes` pixels inside the region its first passes
-    # covered, and the next frame's temporal pass reads them -- so frame 0 starts 40 pixels wider than frame 1
+    # covered, and the next frame's temporal pass reads them -- so frame 0 starts that much wider than frame 1
     pads = [2 * radius * passes + 8, radius * passes + 8]
 
     def grow(r, d):
@@ -59,21 +70,24 @@ def test_window_of_the_full_frame_matches_the_oracle(built_lib):
     last_res, last_base = 1, 0
     for frame in range(2):
         kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=0,
-                  numSpatialNeighbors=nb, useUnbiasedEstimator=0, useLowDiscrepancyNeighbors=1, reuseVisibility=1)
+                  numSpatialNeighbors=nb, useUnbiasedEstimator=int(unbiased), useLowDiscrepancyNeighbors=1, reuseVisibility=1, **env_kw)
         f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, W, H, cam, travHandle=accel, **kw)
         f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, W, H, ocam, travHandle=0, **kw)
         ctx.lights_build_instances(stream)
         cur = (last_res + 1) % 2
         pad = pads[frame]
-        plan = [(api.PASS_SETUP_GBUFFERS, 0, pad), (api.PASS_INITIAL_RIS if frame == 0 else api.PASS_INITIAL_TEMPORAL_BIASED, 0, pad),
-                (api.PASS_SPATIAL_BIASED, 0, pad - radius), (api.PASS_SPATIAL_BIASED, nb, pad - 2 * radius),
-                (api.PASS_SHADING, 2 * nb, pad - 2 * radius)]
-        for k, (pass_id, base_off, margin) in enumerate(plan):
-            base = last_base + (base_off if pass_id != api.PASS_SHADING else nb * passes)
+        entry = api.PASS_INITIAL_RIS
+        if frame > 0:
+            entry = api.PASS_INITIAL_TEMPORAL_UNBIASED if unbiased else api.PASS_INITIAL_TEMPORAL_BIASED
+        plan = [(api.PASS_SETUP_GBUFFERS, 0, pad), (entry, 0, pad)]
+        plan += [(spatial, nb * i, pad - radius * (i + 1)) for i in range(passes)]
+        plan += [(api.PASS_SHADING, nb * passes, pad - radius * passes)]
+        for pass_id, base_off, margin in plan:
+            base = last_base + base_off
             ctx.restir_set_params(s_gpu, f_gpu, cur, base, stream)
             ctx.restir_launch(pass_id, W, H, stream)
             osc.restir_launch(s_cpu, f_cpu, cur, base, pass_id, rect=grow(inner, margin))
-            if pass_id == api.PASS_SPATIAL_BIASED:
+            if pass_id == spatial:
                 cur = (cur + 1) % 2
         last_base += nb * passes
         last_res = cur
