@@ -62,6 +62,7 @@ class GfxRestirStaticParams(C.Structure):
         ("envLightTexture", C.c_void_p), ("envWidth", C.c_int32), ("envHeight", C.c_int32),
         ("envRowPDF", C.c_void_p), ("envRowCDF", C.c_void_p), ("envRowIntegrals", C.c_void_p),
         ("envTopPDF", C.c_void_p), ("envTopCDF", C.c_void_p), ("envTopIntegral", C.c_float),
+        ("envRowGuide", C.c_void_p), ("envTopGuide", C.c_void_p),
     ]
 
 
@@ -160,7 +161,7 @@ HOST_ABI_SYMBOLS = [
     "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
     "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
     "gfxh_restir_band_plan", "gfxh_restir_create",
-    "gfxh_env_build_importance", "gfxh_env_make_sky", "gfxh_restir_set_env",
+    "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
     "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_beauty_buffer",
@@ -348,6 +349,9 @@ def env_build_importance(texels, w, h):
     lib().gfxh_env_build_importance(_p(texels), C.c_uint32(w), C.c_uint32(h), _p(out["rowPDF"]), _p(out["rowCDF"]),
                                     _p(out["rowIntegrals"]), _p(out["topPDF"]), _p(out["topCDF"]), C.byref(integ))
     out["topIntegral"] = integ.value
+    out["rowGuide"], out["topGuide"] = np.zeros(h * w, np.uint16), np.zeros(h, np.uint16)
+    out["guidesUsable"] = bool(lib().gfxh_env_build_guides(_p(out["rowCDF"]), _p(out["topCDF"]), C.c_uint32(w), C.c_uint32(h),
+                                                           _p(out["rowGuide"]), _p(out["topGuide"])))
     return out
 
 

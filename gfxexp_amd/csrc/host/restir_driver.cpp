@@ -245,6 +245,14 @@ int gfxh_restir_set_env(gfxh_restir* r, float* texels, uint32_t w, uint32_t h, f
     err |= up(&sp.envRowIntegrals, rowInt.data(), 4 * rowInt.size());
     err |= up(&sp.envTopPDF, topPDF.data(), 4 * topPDF.size());
     err |= up(&sp.envTopCDF, topCDF.data(), 4 * topCDF.size());
+    sp.envRowGuide = nullptr; sp.envTopGuide = nullptr;
+    {
+        std::vector<uint16_t> rowGuide(n), topGuide(h);
+        if (gfxh_env_build_guides(rowCDF.data(), topCDF.data(), w, h, rowGuide.data(), topGuide.data())) {
+            err |= up(&sp.envRowGuide, rowGuide.data(), 2 * rowGuide.size());
+            err |= up(&sp.envTopGuide, topGuide.data(), 2 * topGuide.size());
+        }
+    }
     if (err) return 1;
     sp.envWidth = static_cast<int32_t>(w); sp.envHeight = static_cast<int32_t>(h); sp.envTopIntegral = topIntegral;
     r->envPowerCoeff = powerCoeff; r->envRotation = rotation;

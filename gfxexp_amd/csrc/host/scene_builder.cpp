@@ -603,6 +603,28 @@ int gfxh_env_build_importance(float* texels, uint32_t w, uint32_t h, float* rowP
     return 0;
 }
 
+// guide[k] = largest index i in [0, n) with cell(cdf[i]) <= k, cell(x) = min(n - 1, uint(x * n)): the device
+// samplers (shading.hip.h, EnvMap::sample1d) bracket the search for u with guide[cell(u) - 1] .. guide[cell(u)].
+static bool build_guide(const float* cdf, uint32_t n, uint16_t* guide) {
+    if (n == 0 || n > 65536u) return false;
+    if (!(cdf[0] == 0.0f)) return false;
+    for (uint32_t i = 0; i + 1 < n; ++i) if (!(cdf[i] <= cdf[i + 1])) return false;
+    auto cell = [n](float x) { return std::min<uint32_t>(n - 1u, static_cast<uint32_t>(x * static_cast<float>(n))); };
+    uint32_t idx = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        while (idx + 1 < n && cell(cdf[idx + 1]) <= k) ++idx;
+        guide[k] = static_cast<uint16_t>(idx);
+    }
+    return true;
+}
+
+int gfxh_env_build_guides(const float* rowCDF, const float* topCDF, uint32_t w, uint32_t h, uint16_t* rowGuide, uint16_t* topGuide) {
+    if (!build_guide(topCDF, h, topGuide)) return 0;
+    for (uint32_t y = 0; y < h; ++y)
+        if (!build_guide(rowCDF + static_cast<size_t>(y) * (w + 1), w, rowGuide + static_cast<size_t>(y) * w)) return 0;
+    return 1;
+}
+
 void gfxh_env_make_sky(uint32_t w, uint32_t h, float sunElevationDeg, float sunAzimuthDeg, float sunRadiance, float* texels) {
     const float d2r = 3.14159265358979323846f / 180.0f;
     const float se = sunElevationDeg * d2r, sa = sunAzimuthDeg * d2r;

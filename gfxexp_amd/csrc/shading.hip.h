@@ -369,6 +369,7 @@ struct LightSample {
 struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
     const float4* texels;
     const float* rowPDF; const float* rowCDF; const float* topPDF; const float* topCDF;
+    const uint16_t* rowGuide; const uint16_t* topGuide;   // optional guide tables (gfxh_env_build_guides), or null
     int32_t w, h;
     GFX_DEV bool present() const { return texels != nullptr; }
     GFX_DEV f3 fetch(float u, float v) const { // nearest texel (the build's tex2DLod contract)
@@ -377,8 +378,22 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
         const float4 t = texels[static_cast<size_t>(y) * w + x];
         return f3(t.x, t.y, t.z);
     }
-    static GFX_DEV float sample1d(const float* pdf, const float* cdf, uint32_t n, float u, float& p) {
+    static GFX_DEV float sample1d(const float* pdf, const float* cdf, uint32_t n, float u, float& p, const uint16_t* guide) {
         int idx = 0;
+        if (guide) {
+            // largest idx with cdf[idx] <= u, inside the bracket of u's cell: cdf[guide[k - 1]] lies in an earlier
+            // cell (so below u), nothing past guide[k] can be <= u (cell() is monotone, the builder checked the CDF)
+            const uint32_t k = min(n - 1u, static_cast<uint32_t>(u * static_cast<float>(n)));
+            int hi = guide[k];
+            int lo = k ? guide[k - 1] : 0;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (cdf[mid] <= u) lo = mid;
+                else hi = mid - 1;
+            }
+            idx = lo;
+        }
+        else
         for (int d = static_cast<int>(next_pow2(n) >> 1); d >= 1; d >>= 1) {
             if (idx + d >= static_cast<int>(n)) continue;
             if (cdf[idx + d] <= u) idx += d;
@@ -394,9 +409,10 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
     }
     GFX_DEV void sample(float u0, float u1, float& d0, float& d1, float& p) const { // common_shared.h:372-379
         float topP;
-        d1 = sample1d(topPDF, topCDF, h, u1, topP);
+        d1 = sample1d(topPDF, topCDF, h, u1, topP, topGuide);
         uint32_t row = f2u_sat(d1 * h); if (row > static_cast<uint32_t>(h - 1)) row = h - 1;
-        d0 = sample1d(rowPDF + static_cast<size_t>(row) * w, rowCDF + static_cast<size_t>(row) * (w + 1), w, u0, p);
+        d0 = sample1d(rowPDF + static_cast<size_t>(row) * w, rowCDF + static_cast<size_t>(row) * (w + 1), w, u0, p,
+                      rowGuide ? rowGuide + static_cast<size_t>(row) * w : nullptr);
         p *= topP;
     }
 };

@@ -180,6 +180,11 @@ typedef struct gfx_restir_static_params {
     const void* envTopPDF;           /* float[envH] */
     const void* envTopCDF;           /* float[envH+1] */
     float envTopIntegral;
+    /* Optional guide tables over the environment CDFs (gfxh_env_build_guides; NULL = plain binary search, same
+     * results): uint16_t[envH*envW] / uint16_t[envH], entry k = largest index whose CDF value lies in cell <= k
+     * of envW (envH) equal cells of [0,1). */
+    const void* envRowGuide;
+    const void* envTopGuide;
 } gfx_restir_static_params;
 
 /* restir_di/restir_di_shared.h:241-281 PerFramePipelineLaunchParameters. */

@@ -92,6 +92,10 @@ void gfxh_spatial_neighbor_deltas(float* out2x1024);
  * rowPDF h*w, rowCDF h*(w+1), rowIntegrals h, topPDF h, topCDF h+1. */
 int gfxh_env_build_importance(float* texels4, uint32_t w, uint32_t h, float* rowPDF, float* rowCDF,
                               float* rowIntegrals, float* topPDF, float* topCDF, float* topIntegral);
+/* Guide tables for the CDFs gfxh_env_build_importance produced (gfx_restir_static_params::envRowGuide / envTopGuide):
+ * the samplers' log2(n)-step searches become a table lookup plus a one- or two-entry bracket search with identical
+ * results.  Returns 1 when the tables are usable (every CDF monotone, w and h <= 65536), 0 otherwise (pass NULL). */
+int gfxh_env_build_guides(const float* rowCDF, const float* topCDF, uint32_t w, uint32_t h, uint16_t* rowGuide, uint16_t* topGuide);
 /* Synthetic lat-long sky (gradient + sun disc) used as the stand-in environment map. */
 void gfxh_env_make_sky(uint32_t w, uint32_t h, float sunElevationDeg, float sunAzimuthDeg, float sunRadiance, float* texels4);
 

@@ -46,3 +46,38 @@ def test_sampling_follows_luminance_times_sin_theta(built_lib):
     pdf = (env["rowPDF"].reshape(h, w) * env["topPDF"][:, None])[y, x]
     # (a sample that lands exactly on a cell border may be binned into the neighbouring cell here)
     assert np.mean(np.abs(s[:, 2] - pdf) <= 1e-5 * pdf) > 0.999
+
+
+def test_guide_tables_bracket_every_search(built_lib):
+    """gfxh_env_build_guides: for any u, the reference's search result (largest i with CDF[i] <= u) lies inside
+    [guide[cell(u) - 1], guide[cell(u)]] and the CDF entry at the lower end is <= u -- what the device sampler
+    relies on (shading.hip.h, EnvMap::sample1d)."""
+    w, h = 256, 128
+    sky = api.env_make_sky(w, h, sun_radiance=5000.0)          # a very peaked map: crowded and empty cells
+    e = api.env_build_importance(sky.copy(), w, h)
+    assert e["guidesUsable"]
+    rng = np.random.default_rng(9)
+
+    def check(cdf, guide, n):
+        u = np.concatenate([rng.random(4000).astype(np.float32), cdf[:n].astype(np.float32),      # exact knots too
+                            np.nextafter(cdf[1:n + 1].astype(np.float32), np.float32(0))])
+        u = u[(u >= 0) & (u < 1)]
+        want = np.searchsorted(cdf[:n], u, side="right") - 1    # largest i with cdf[i] <= u (cdf[0] = 0)
+        k = np.minimum(n - 1, (u * np.float32(n)).astype(np.uint32))
+        hi = guide[k].astype(np.int64)
+        lo = np.where(k > 0, guide[np.maximum(k, 1) - 1], 0).astype(np.int64)
+        assert np.all(lo <= want) and np.all(want <= hi)
+        assert np.all(cdf[lo] <= u)
+
+    check(e["topCDF"], e["topGuide"], h)
+    rows = e["rowCDF"].reshape(h, w + 1)
+    guides = e["rowGuide"].reshape(h, w)
+    for y in (0, 17, h // 2, h - 1):
+        check(rows[y], guides[y], w)
+    # a non-monotone CDF is refused (the samplers then use the plain search)
+    bad = e["topCDF"].copy()
+    bad[5], bad[6] = bad[6], bad[5] + np.float32(1e-3)
+    import ctypes as C
+    ok = api.lib().gfxh_env_build_guides(e["rowCDF"].ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p), C.c_uint32(w), C.c_uint32(h),
+                                         np.zeros(h * w, np.uint16).ctypes.data_as(C.c_void_p), np.zeros(h, np.uint16).ctypes.data_as(C.c_void_p))
+    assert ok == 0

@@ -260,6 +260,9 @@ class DeviceBuffers:
         if pb.env is not None:
             for k in ("texels", "rowPDF", "rowCDF", "rowIntegrals", "topPDF", "topCDF"):
                 self.env_t[k] = torch.from_numpy(pb.env[k].reshape(-1)).cuda()
+            if pb.env.get("guidesUsable") and getattr(pb, "use_env_guides", True):
+                for k in ("rowGuide", "topGuide"):      # uint16 tables (torch has no uint16: ship the bytes)
+                    self.env_t[k] = torch.from_numpy(pb.env[k].view(np.uint8).reshape(-1).copy()).cuda()
 
     def static_params(self):
         pb, t = self.pb, self.t
@@ -282,6 +285,8 @@ class DeviceBuffers:
             s.envRowPDF = et["rowPDF"].data_ptr(); s.envRowCDF = et["rowCDF"].data_ptr()
             s.envRowIntegrals = et["rowIntegrals"].data_ptr()
             s.envTopPDF = et["topPDF"].data_ptr(); s.envTopCDF = et["topCDF"].data_ptr(); s.envTopIntegral = e["topIntegral"]
+            if "rowGuide" in et:
+                s.envRowGuide = et["rowGuide"].data_ptr(); s.envTopGuide = et["topGuide"].data_ptr()
         return s
 
     def download(self):
