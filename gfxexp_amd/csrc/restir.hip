@@ -210,7 +210,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             if (envEnabled) {
                 if (*a.scene.lightInstIntegral > 0.0f) {
                     const float prob = fmin2(fmax2(0.25f * numCandidates - i, 0.0f), 1.0f);
-                    if (ul < prob) { probCurType = 0.25f; ul = ul / prob; sampleEnv = true; }
+                    // prob is 0 or 1 for every candidate count >= 4: x / 1 and (x - 0) / (1 - 0) are x, no division needed
+                    if (prob == 1.0f) { probCurType = 0.25f; sampleEnv = true; }
+                    else if (prob == 0.0f) probCurType = 1.0f - 0.25f;
+                    else if (ul < prob) { probCurType = 0.25f; ul = ul / prob; sampleEnv = true; }
                     else { probCurType = 1.0f - 0.25f; ul = (ul - prob) / (1 - prob); }
                 }
                 else sampleEnv = true;
