@@ -161,7 +161,8 @@ def test_headless_driver_matches_pass_by_pass(built_lib):
 
 
 @pytest.mark.gpu
-def test_row_band_renderers_match_full_frame(built_lib):
+@pytest.mark.parametrize("renderer,with_env", [(api.RENDERER_BIASED, False), (api.RENDERER_UNBIASED, True)])
+def test_row_band_renderers_match_full_frame(built_lib, renderer, with_env):
     """Two band-limited renderers on one GPU (bands 0 and 1 of a 2-way split), halo rows refreshed by
     device copies exactly as HaloExchange would send them, reproduce the full-frame renderer bit for bit."""
     import torch
@@ -172,19 +173,25 @@ def test_row_band_renderers_match_full_frame(built_lib):
     hs.upload(ctx)
     cam = default_camera("bunny", width, height)
 
+    sky = api.env_make_sky(64, 32) if with_env else None     # BASELINE configs[5]: unbiased + environment map, row bands
+
     def make(band):
-        cfg = api.RestirRenderer.default_config(width, height, api.RENDERER_BIASED)
+        cfg = api.RestirRenderer.default_config(width, height, renderer)
         cfg.camera = cam
         cfg.spatialNeighborRadius = 6.0
         cfg.rowBegin, cfg.rowEnd = band
-        return api.RestirRenderer(ctx, cfg)
+        r = api.RestirRenderer(ctx, cfg)
+        if sky is not None:
+            r.set_env(sky.copy(), 64, 32, 0.7, 0.6)
+        return r
 
     full = make((0, 0))
     bands = tilesplit.band_rows(height, 2)
     parts = [make(b) for b in bands]
     views = [tilesplit.renderer_state_views(r, width, height) for r in parts]
     plans = [r.band_plan() for r in parts]
-    assert plans[0].haloRows == 12 and list(plans[0].recvBelow) == [48, 60] and list(plans[1].recvAbove) == [36, 48]
+    halo = 12 if renderer == api.RENDERER_BIASED else 6      # radius 6 x spatial passes (2 / 1)
+    assert plans[0].haloRows == halo and list(plans[0].recvBelow) == [48, 48 + halo] and list(plans[1].recvAbove) == [48 - halo, 48]
     n = width * height
 
     def rows(state, key, r, planes=1, comps=1):
