@@ -144,7 +144,7 @@ GBUFFER3_DTYPE = np.dtype([("qShadingNormal", "<u4"), ("qShadingTangent", "<u4")
 # every symbol include/gfxexp.h and include/gfxexp_host.h declare
 C_ABI_SYMBOLS = [
     "gfx_ctx_create", "gfx_ctx_destroy", "gfx_last_error", "gfx_version", "gfx_material_set", "gfx_geom_create",
-    "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_instance_set_transform_and_normal_matrix",
+    "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_instance_set_transform_and_normal_matrix", "gfx_instance_set_dynamic",
     "gfx_accel_build",
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
@@ -402,6 +402,9 @@ class Context:
         else:
             nm = np.ascontiguousarray(normal_matrix9, np.float32).reshape(9)
             self._check(self.L.gfx_instance_set_transform_and_normal_matrix(self.h, C.c_uint32(inst_slot), _p(x), _p(nm)))
+
+    def instance_set_dynamic(self, inst_slot, dynamic=True):
+        self._check(self.L.gfx_instance_set_dynamic(self.h, C.c_uint32(inst_slot), C.c_int(int(dynamic))))
 
     def accel_build(self, stream=0, handle=0):
         hd = C.c_uint64(handle)

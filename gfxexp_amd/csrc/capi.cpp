@@ -112,7 +112,24 @@ static void instance_update(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12]
     inst.animated = true;
     inst.hasNormalMatrix = normalMatrix != nullptr;
     if (normalMatrix) std::memcpy(inst.normalMatrix, normalMatrix, sizeof(float) * 9);
-    ctx->c.sceneDirty = true;
+    if (inst.dynamic && !ctx->c.sceneDirty) {       // already in the animated subtree: transform-only update
+        ctx->c.transformsDirty = true;
+        ctx->c.movedInsts.push_back(instSlot);
+    }
+    else {                                          // first move: the instance changes subtree, full rebuild once
+        inst.dynamic = true;
+        ctx->c.sceneDirty = true;
+    }
+}
+
+int gfx_instance_set_dynamic(gfx_ctx* ctx, uint32_t instSlot, int dynamic) {
+    GFX_TRY(ctx)
+    if (instSlot >= ctx->c.insts.size()) throw HipError("gfx_instance_set_dynamic: unknown instSlot");
+    if (ctx->c.insts[instSlot].dynamic != (dynamic != 0)) {
+        ctx->c.insts[instSlot].dynamic = dynamic != 0;
+        ctx->c.sceneDirty = true;
+    }
+    GFX_CATCH(ctx)
 }
 
 int gfx_instance_set_transform(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12]) {
@@ -132,7 +149,7 @@ int gfx_accel_build(gfx_ctx* ctx, void* stream, uint64_t* handle) {
     Accel* a = nullptr;
     if (*handle != 0 && *handle <= ctx->c.accels.size() && ctx->c.accels[*handle - 1]) a = ctx->c.accels[*handle - 1]; // rebuild in place
     else { a = new Accel(); ctx->c.accels.push_back(a); *handle = ctx->c.accels.size(); }
-    lbvh_build(ctx->c, static_cast<hipStream_t>(stream), *a);
+    if (!lbvh_update_dynamic(ctx->c, static_cast<hipStream_t>(stream), *a)) lbvh_build(ctx->c, static_cast<hipStream_t>(stream), *a);
     GFX_CATCH(ctx)
 }
 

@@ -78,6 +78,15 @@ struct DevFlatGeom {
     uint32_t numTriangles;
 };
 
+// Build-time view of one flattened geometry inside a BVH subtree's triangle list (static or animated
+// instances): localBegin = first triangle inside that subtree's list, globalBegin = DevFlatGeom::triBegin.
+struct SubsetGeom {
+    uint32_t instSlot;
+    uint32_t geomInstSlot;
+    uint32_t localBegin;
+    uint32_t globalBegin;
+};
+
 // Everything the shading kernels need to reach the scene.
 struct DevScene {
     const gfx_material* materials;

@@ -41,6 +41,9 @@ struct HostInstance {
     // set by gfx_instance_set_transform (InstanceController::update): curToPrevTransform = prev * invert(cur),
     // optional caller-supplied normal matrix (row-major 3x3)
     bool animated = false, hasNormalMatrix = false;
+    // lives in the animated subtree of the BVH (gfx_instance_set_dynamic, or implied by the first
+    // gfx_instance_set_transform): later transform updates rebuild only that subtree
+    bool dynamic = false;
     float curToPrev[12];
     float normalMatrix[9];
 };
@@ -52,6 +55,11 @@ struct Accel {
     DevBuf nodes, links, triIds;
     uint32_t triItemOffset = 0;
     uint32_t numNodes = 0, numTris = 0, numInputTris = 0, maxDepth = 0;
+    // split tree (static + animated subtree under a two-child root, lbvh.hip): world boxes of the two subtree
+    // roots (2 x 8 floats, device), triangle count and node range of the static part
+    bool split = false;
+    DevBuf rootBoxes;
+    uint32_t numStaticTris = 0, staticNodeEnd = 0;
     Bvh8Tri* trisPtr() const { return reinterpret_cast<Bvh8Tri*>(nodes.as<Bvh8Node>() + triItemOffset); }
     DevAccel dev() const {
         DevAccel a; a.nodes = nodes.as<Bvh8Node>(); a.links = links.as<Bvh8Link>(); a.tris = trisPtr(); a.numNodes = numNodes; a.numTris = numTris;
@@ -89,6 +97,14 @@ struct Context {
     std::vector<DevInstance> hInsts;
     std::vector<DevFlatGeom> hFlatGeoms;
     uint32_t totalTriangles = 0;
+    // the flattened geometry list split by HostInstance::dynamic: [0] static, [1] animated (lbvh.hip builds one
+    // subtree over each when both exist); instances whose transform changed since the last upload
+    std::vector<SubsetGeom> hSubset[2];
+    DevBuf dSubset[2];
+    uint32_t subsetTris[2] = { 0, 0 };
+    bool transformsDirty = false;
+    std::vector<uint32_t> movedInsts;
+    bool emitterRecsDirty = false;
     uint32_t lightPoolSize = 0;
     uint32_t lightInstDistOffset = 0;
     DevBuf dLightInstIntegral;       // float[4]; [0] = integral of the instance-level distribution, [1..2] guide header
@@ -109,7 +125,7 @@ struct Context {
     DevBuf rearchSlots;
     DevBuf nrcState, neeTrainIdx;
     // build scratch
-    DevBuf bTris, bBoxes, bKeys, bKeysAlt, bVals, bValsAlt, bSortTemp, bNodesLR, bParents, bFlags, bNodeBoxes, bRanges, bQueueA, bQueueB, bCounters, bCosts, bDec;
+    DevBuf bTris, bBoxes, bKeys, bKeysAlt, bVals, bValsAlt, bSortTemp, bNodesLR, bParents, bFlags, bNodeBoxes, bRanges, bQueueA, bQueueB, bCounters, bCosts, bDec, bFlatIdx;
     // restir
     RestirParams restir;
     gfx_regir_params regir;
@@ -144,8 +160,10 @@ struct ScopedKernelTimer {
 
 // ---- scene.cpp
 void scene_upload(Context& ctx, hipStream_t stream);
+void transforms_upload(Context& ctx, hipStream_t stream);   // moved instances only (scene.cpp)
 // ---- lbvh.hip
 void lbvh_build(Context& ctx, hipStream_t stream, Accel& out);
+bool lbvh_update_dynamic(Context& ctx, hipStream_t stream, Accel& out);   // false: a full lbvh_build is needed
 // ---- trace.hip
 struct TraceLaunch {
     DevAccel accel;

@@ -70,16 +70,17 @@ GFX_DEV void store_final_tri(Bvh8Tri* p, const BuildTri& t, uint32_t flatIndex) 
 }
 
 // ---------------------------------------------------------------- 1. flatten
-__global__ void k_flatten(DevScene sc, const DevFlatGeom* __restrict__ flat, uint32_t numFlat, uint32_t n,
-                          BuildTri* __restrict__ out, uint32_t* __restrict__ bounds /* ordered lo xyz, hi xyz */) {
+__global__ void k_flatten(DevScene sc, const SubsetGeom* __restrict__ flat, uint32_t numFlat, uint32_t n,
+                          BuildTri* __restrict__ out, uint32_t* __restrict__ flatIndexOut, uint32_t* __restrict__ bounds /* ordered lo xyz, hi xyz */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     f3 lo(INFINITY), hi(-INFINITY);
     if (i < n) {
-        // binary search the flattened-geometry list (triBegin ascending)
+        // binary search the subtree's geometry list (localBegin ascending)
         uint32_t a = 0, b = numFlat;
-        while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (flat[m].triBegin <= i) a = m; else b = m; }
-        const DevFlatGeom fg = flat[a];
-        const uint32_t prim = i - fg.triBegin;
+        while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (flat[m].localBegin <= i) a = m; else b = m; }
+        const SubsetGeom fg = flat[a];
+        const uint32_t prim = i - fg.localBegin;
+        flatIndexOut[i] = fg.globalBegin + prim;   // position in the whole scene's flattened triangle list (closest-hit tie rule)
         const DevGeomInst g = sc.geomInsts[fg.geomInstSlot];
         const uint32_t* tri = sc.triangles + 3ull * (g.triangleOffset + prim);
         const DevVertex vA = load_vertex(sc.vertices + g.vertexOffset + tri[0]);
@@ -305,7 +306,7 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
                                  const uint2* __restrict__ queueIn, uint2* __restrict__ queueOut, uint32_t* __restrict__ counters,
                                  const int2* __restrict__ lr, const uint2* __restrict__ ranges, const float* __restrict__ nodeBoxes,
                                  const uint32_t* __restrict__ dec, int useDp,
-                                 const BuildTri* __restrict__ trisIn, const uint32_t* __restrict__ sortedIdx,
+                                 const BuildTri* __restrict__ trisIn, const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ flatIndex,
                                  Bvh8Node* __restrict__ nodesOut, Bvh8Link* __restrict__ linksOut, Bvh8Tri* __restrict__ trisOut) {
     const uint32_t numItems = counters[2 + level];
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < numItems; item += gridDim.x * blockDim.x) {
@@ -447,7 +448,7 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
                 ++internalRank;
             }
             else {
-                store_final_tri(trisOut + triBase + triOff, load_tri(trisIn + sortedIdx[ch[k].first]), sortedIdx[ch[k].first]);
+                store_final_tri(trisOut + triBase + triOff, load_tri(trisIn + sortedIdx[ch[k].first]), flatIndex[sortedIdx[ch[k].first]]);
                 ++triOff;
             }
         }
@@ -460,132 +461,245 @@ __global__ void k_collapse_level(uint32_t level, uint32_t maxLeafTris,
     }
 }
 
-// single-triangle scene: one node, one leaf child in slot 0
-__global__ void k_single_tri_root(const BuildTri* __restrict__ trisIn, Bvh8Node* __restrict__ nodesOut, Bvh8Link* __restrict__ linksOut, Bvh8Tri* __restrict__ trisOut) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const BuildTri t = load_tri(trisIn);
-    const Box b = tri_box(t);
-    Bvh8Node node;
-    node.w[0] = f2bits(b.lo.x); node.w[1] = f2bits(b.lo.y); node.w[2] = f2bits(b.lo.z);
-    uint32_t ex[3];
-    const float ext[3] = { b.hi.x - b.lo.x, b.hi.y - b.lo.y, b.hi.z - b.lo.z };
-    const float org[3] = { b.lo.x, b.lo.y, b.lo.z };
-    const float top[3] = { b.hi.x, b.hi.y, b.hi.z };
+// Node frame (origin + power-of-two scale exponents) of a box, and the 8-bit quantisation of a child box inside
+// it -- the same rules as k_collapse_level: the DECODED box must contain the child.
+GFX_DEV void node_frame(const Box& nb, uint32_t ex[3], float scale[3]) {
+    const float ext[3] = { nb.hi.x - nb.lo.x, nb.hi.y - nb.lo.y, nb.hi.z - nb.lo.z };
+    const float org[3] = { nb.lo.x, nb.lo.y, nb.lo.z };
+    const float top[3] = { nb.hi.x, nb.hi.y, nb.hi.z };
     for (int a = 0; a < 3; ++a) {
         const uint32_t us = f2bits(ext[a] / 255.0f);
         uint32_t e = (us >> 23) + ((us & 0x7FFFFFu) ? 1u : 0u);
         while (e < 254u && org[a] + 255.0f * bits2f(e << 23) < top[a]) ++e;
-        ex[a] = e;
+        ex[a] = e; scale[a] = bits2f(e << 23);
     }
-    node.w[3] = ex[0] | (ex[1] << 8) | (ex[2] << 16);
-    for (int k = 4; k < 10; ++k) node.w[k] = 0xFFFFFF00u;      // slot 0: lo = 0 on every axis; other slots empty
-    for (int k = 10; k < 16; ++k) node.w[k] = 0x000000FFu;     // slot 0: hi = 255 (the whole frame)
-    for (int a = 0; a < 3; ++a) { node.w[5 + 2 * a] = 0xFFFFFFFFu; node.w[11 + 2 * a] = 0u; }
-    uint4* dst = reinterpret_cast<uint4*>(nodesOut);
-    dst[0] = make_uint4(node.w[0], node.w[1], node.w[2], node.w[3]);
-    dst[1] = make_uint4(node.w[4], node.w[5], node.w[6], node.w[7]);
-    dst[2] = make_uint4(node.w[8], node.w[9], node.w[10], node.w[11]);
-    dst[3] = make_uint4(node.w[12], node.w[13], node.w[14], node.w[15]);
-    reinterpret_cast<uint4*>(linksOut)[0] = make_uint4(0xFFFFFFFFu, 0u, 1u, 0u);
-    store_final_tri(trisOut, t, 0u);
+}
+GFX_DEV void put_child_box(uint32_t w[16], int slot, const Box& nb, const float scale[3], const Box& child) {
+    const float org[3] = { nb.lo.x, nb.lo.y, nb.lo.z };
+    const float lo[3] = { child.lo.x, child.lo.y, child.lo.z };
+    const float hi[3] = { child.hi.x, child.hi.y, child.hi.z };
+    for (int a = 0; a < 3; ++a) {
+        uint32_t l = 0, h = 1;
+        if (scale[a] > 0.0f) {
+            l = min(f2u_sat((lo[a] - org[a]) / scale[a]), 254u);
+            h = min(f2u_sat((hi[a] - org[a]) / scale[a]) + 1u, 255u);
+        }
+        while (l > 0 && org[a] + static_cast<float>(l) * scale[a] > lo[a]) --l;
+        while (h < 255 && org[a] + static_cast<float>(h) * scale[a] < hi[a]) ++h;
+        const uint32_t shift = (slot & 3) * 8;
+        uint32_t& wl = w[4 + 2 * a + (slot >> 2)];
+        uint32_t& wh = w[10 + 2 * a + (slot >> 2)];
+        wl = (wl & ~(0xFFu << shift)) | (l << shift);
+        wh = (wh & ~(0xFFu << shift)) | (h << shift);
+    }
+}
+GFX_DEV void store_node(Bvh8Node* nodes, Bvh8Link* links, uint32_t index, const Box& nb, const uint32_t ex[3], uint32_t imask,
+                        const uint32_t w[16], uint32_t childBase, uint32_t triBase, uint32_t validMask) {
+    uint4* dst = reinterpret_cast<uint4*>(nodes + index);
+    dst[0] = make_uint4(f2bits(nb.lo.x), f2bits(nb.lo.y), f2bits(nb.lo.z), ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24));
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    dst[2] = make_uint4(w[8], w[9], w[10], w[11]);
+    dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
+    reinterpret_cast<uint4*>(links)[index] = make_uint4(childBase, triBase, validMask, 0u);
 }
 
-__global__ void k_tri_ids(const Bvh8Tri* __restrict__ tris, uint32_t n, gfx_tri_ids* __restrict__ ids) {
+// Subtree of at most eight triangles (a lone scene triangle; the usual animated set: a rectangle light or two):
+// one wide node whose children are the triangles, written by one thread.  rootBox: {lo, hi} of the subtree.
+__global__ void k_small_subtree(const BuildTri* __restrict__ trisIn, const uint32_t* __restrict__ flatIndex, uint32_t n,
+                                uint32_t nodeIndex, uint32_t triBase,
+                                Bvh8Node* __restrict__ nodesOut, Bvh8Link* __restrict__ linksOut, Bvh8Tri* __restrict__ trisOut,
+                                float* __restrict__ rootBox) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Box boxes[8];
+    Box nb;
+    for (uint32_t k = 0; k < n; ++k) {
+        boxes[k] = tri_box(load_tri(trisIn + k));
+        nb = k ? box_union(nb, boxes[k]) : boxes[k];
+    }
+    uint32_t ex[3]; float scale[3];
+    node_frame(nb, ex, scale);
+    uint32_t w[16];
+    for (int k = 4; k < 10; ++k) w[k] = 0xFFFFFFFFu;      // empty slots: inverted box
+    for (int k = 10; k < 16; ++k) w[k] = 0u;
+    for (uint32_t k = 0; k < n; ++k) {
+        put_child_box(w, static_cast<int>(k), nb, scale, boxes[k]);
+        store_final_tri(trisOut + triBase + k, load_tri(trisIn + k), flatIndex[k]);
+    }
+    store_node(nodesOut, linksOut, nodeIndex, nb, ex, 0u, w, 0xFFFFFFFFu, triBase, (1u << n) - 1u);
+    if (rootBox) { rootBox[0] = nb.lo.x; rootBox[1] = nb.lo.y; rootBox[2] = nb.lo.z; rootBox[3] = nb.hi.x; rootBox[4] = nb.hi.y; rootBox[5] = nb.hi.z; }
+}
+
+// Root of a split tree: node 0 with two internal children, the static subtree's root (node 1, slot 0) and the
+// animated subtree's root (node 2, slot 1).  rootBoxes: 2 x {lo, hi}.
+__global__ void k_super_root(const float* __restrict__ rootBoxes, Bvh8Node* __restrict__ nodesOut, Bvh8Link* __restrict__ linksOut) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Box b[2];
+    for (int k = 0; k < 2; ++k) {
+        b[k].lo = f3(rootBoxes[8 * k + 0], rootBoxes[8 * k + 1], rootBoxes[8 * k + 2]);
+        b[k].hi = f3(rootBoxes[8 * k + 3], rootBoxes[8 * k + 4], rootBoxes[8 * k + 5]);
+    }
+    const Box nb = box_union(b[0], b[1]);
+    uint32_t ex[3]; float scale[3];
+    node_frame(nb, ex, scale);
+    uint32_t w[16];
+    for (int k = 4; k < 10; ++k) w[k] = 0xFFFFFFFFu;
+    for (int k = 10; k < 16; ++k) w[k] = 0u;
+    put_child_box(w, 0, nb, scale, b[0]);
+    put_child_box(w, 1, nb, scale, b[1]);
+    store_node(nodesOut, linksOut, 0u, nb, ex, 0x3u, w, 1u, 0xFFFFFFFFu, 0x3u);
+}
+// the binary root's box of a general build -> rootBoxes slot
+__global__ void k_copy_root_box(const float* __restrict__ nodeBoxes, float* __restrict__ rootBox) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    rootBox[0] = nodeBoxes[0]; rootBox[1] = nodeBoxes[1]; rootBox[2] = nodeBoxes[2];
+    rootBox[3] = nodeBoxes[4]; rootBox[4] = nodeBoxes[5]; rootBox[5] = nodeBoxes[6];
+}
+
+__global__ void k_tri_ids(const Bvh8Tri* __restrict__ tris, uint32_t first, uint32_t n, gfx_tri_ids* __restrict__ ids) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Bvh8Tri* t = tris + i;
+    const Bvh8Tri* t = tris + first + i;
     gfx_tri_ids o; o.instSlot = t->instSlot; o.geomInstSlot = t->geomInstSlot; o.primIndex = t->primIndex;
-    ids[i] = o;
+    ids[first + i] = o;
 }
 
 constexpr uint32_t kMaxCollapseLevels = 96;
+constexpr uint32_t kSmallSubtreeTris = 8;
 
-void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
-    scene_upload(ctx, stream);
-    const uint32_t n = ctx.totalTriangles;
-    out.numInputTris = n;
-    out.numNodes = 0; out.numTris = 0; out.maxDepth = 0;
-    if (n == 0) return;
-    // the traversal kernel addresses items (n node slots + n triangle records, 64 B each) with 32-bit byte offsets
-    if (n >= (1u << 25)) throw std::runtime_error("gfx: acceleration structure limited to 2^25 triangles");
-    const uint32_t numFlat = static_cast<uint32_t>(ctx.hFlatGeoms.size());
+// One subtree over the triangles of ctx.hSubset[subset]: its root wide node at `rootWide`, further nodes
+// allocated from `nodeAllocStart`, triangle records from `triAllocStart`.  Returns {next free node, depth}.
+struct SubtreeResult { uint32_t nodeEnd; uint32_t depth; };
+static SubtreeResult build_subtree(Context& ctx, hipStream_t stream, Accel& out, int subset, uint32_t rootWide,
+                                   uint32_t nodeAllocStart, uint32_t triAllocStart, float* rootBoxOut) {
+    const uint32_t n = ctx.subsetTris[subset];
+    const uint32_t numFlat = static_cast<uint32_t>(ctx.hSubset[subset].size());
     const dim3 blk(256), grd((n + 255) / 256);
-
     ctx.bTris.reserve(sizeof(BuildTri) * static_cast<size_t>(n));
+    ctx.bFlatIdx.reserve(4ull * n);
+    ctx.bCounters.reserve(4 * (2 + kMaxCollapseLevels + 2) + 64);
+    uint32_t* counters = ctx.bCounters.as<uint32_t>();
+    uint32_t* bounds = counters + 2 + kMaxCollapseLevels + 2;
+    if (n <= kSmallSubtreeTris) {   // no sort, no allocator, no host round trip (the scene-box atomics of k_flatten go unused)
+        hipLaunchKernelGGL(k_flatten, grd, blk, 0, stream, ctx.devScene(), ctx.dSubset[subset].as<SubsetGeom>(), numFlat, n,
+                           ctx.bTris.as<BuildTri>(), ctx.bFlatIdx.as<uint32_t>(), bounds);
+        hipLaunchKernelGGL(k_small_subtree, dim3(1), dim3(64), 0, stream, ctx.bTris.as<BuildTri>(), ctx.bFlatIdx.as<uint32_t>(), n,
+                           rootWide, triAllocStart, out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>(), out.trisPtr(), rootBoxOut);
+        GFX_HIP(hipGetLastError());
+        return { nodeAllocStart, 1u };
+    }
+    {
+        std::vector<uint32_t> init(2 + kMaxCollapseLevels + 2 + 6, 0u);
+        init[0] = nodeAllocStart;        // next free wide node
+        init[1] = triAllocStart;         // next free triangle record
+        init[2] = 1;                     // one work item at level 0
+        for (int k = 0; k < 3; ++k) { init[2 + kMaxCollapseLevels + 2 + k] = 0xFFFFFFFFu; init[2 + kMaxCollapseLevels + 2 + 3 + k] = 0u; }
+        GFX_HIP(hipMemcpyAsync(counters, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice, stream));
+        GFX_HIP(hipStreamSynchronize(stream));   // init goes out of scope
+    }
+    hipLaunchKernelGGL(k_flatten, grd, blk, 0, stream, ctx.devScene(), ctx.dSubset[subset].as<SubsetGeom>(), numFlat, n,
+                       ctx.bTris.as<BuildTri>(), ctx.bFlatIdx.as<uint32_t>(), bounds);
     ctx.bKeys.reserve(8ull * n); ctx.bKeysAlt.reserve(8ull * n);
     ctx.bVals.reserve(4ull * n); ctx.bValsAlt.reserve(4ull * n);
     ctx.bNodesLR.reserve(8ull * n); ctx.bParents.reserve(8ull * n + 16); ctx.bFlags.reserve(4ull * n);
     ctx.bNodeBoxes.reserve(32ull * n); ctx.bRanges.reserve(8ull * n);
     ctx.bQueueA.reserve(8ull * n + 16); ctx.bQueueB.reserve(8ull * n + 16);
-    ctx.bCounters.reserve(4 * (2 + kMaxCollapseLevels + 2) + 64);
-    out.nodes.reserve(sizeof(Bvh8Node) * 2 * static_cast<size_t>(n));   // n node slots + n triangle records
-    out.triItemOffset = n;
-    out.links.reserve(sizeof(Bvh8Link) * static_cast<size_t>(n));
-    out.triIds.reserve(sizeof(gfx_tri_ids) * static_cast<size_t>(n));
-
-    uint32_t* counters = ctx.bCounters.as<uint32_t>();
-    uint32_t* bounds = counters + 2 + kMaxCollapseLevels + 2;
-    {
-        std::vector<uint32_t> init(2 + kMaxCollapseLevels + 2 + 6, 0u);
-        init[0] = 1;                     // root wide node is index 0
-        init[2] = 1;                     // one work item at level 0
-        for (int k = 0; k < 3; ++k) { init[2 + kMaxCollapseLevels + 2 + k] = 0xFFFFFFFFu; init[2 + kMaxCollapseLevels + 2 + 3 + k] = 0u; }
-        GFX_HIP(hipMemcpyAsync(counters, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice, stream));
-        GFX_HIP(hipStreamSynchronize(stream));
+    hipLaunchKernelGGL(k_morton, grd, blk, 0, stream, ctx.bTris.as<BuildTri>(), n, bounds, ctx.bKeys.as<uint64_t>(), ctx.bVals.as<uint32_t>());
+    size_t tempBytes = 0;
+    GFX_HIP(rocprim::radix_sort_pairs(nullptr, tempBytes, ctx.bKeys.as<uint64_t>(), ctx.bKeysAlt.as<uint64_t>(),
+                                      ctx.bVals.as<uint32_t>(), ctx.bValsAlt.as<uint32_t>(), n, 0, 63, stream));
+    ctx.bSortTemp.reserve(std::max<size_t>(tempBytes, 16));
+    GFX_HIP(rocprim::radix_sort_pairs(ctx.bSortTemp.p, tempBytes, ctx.bKeys.as<uint64_t>(), ctx.bKeysAlt.as<uint64_t>(),
+                                      ctx.bVals.as<uint32_t>(), ctx.bValsAlt.as<uint32_t>(), n, 0, 63, stream));
+    const uint64_t* keys = ctx.bKeysAlt.as<uint64_t>();
+    const uint32_t* sortedIdx = ctx.bValsAlt.as<uint32_t>();
+    uint32_t* parentInt = ctx.bParents.as<uint32_t>();
+    uint32_t* parentLeaf = parentInt + n;
+    hipLaunchKernelGGL(k_karras, grd, blk, 0, stream, keys, static_cast<int>(n), ctx.bNodesLR.as<int2>(), parentInt, parentLeaf,
+                       ctx.bRanges.as<uint2>());
+    GFX_HIP(hipMemsetAsync(ctx.bFlags.p, 0, 4ull * n, stream));
+    ctx.bCosts.reserve(32ull * n); ctx.bDec.reserve(4ull * n);
+    static float costPrim = -1.0f;
+    if (costPrim < 0) { const char* e = getenv("GFX_BVH_CPRIM"); costPrim = e ? static_cast<float>(atof(e)) : kCostPrimDefault; if (!(costPrim > 0)) costPrim = kCostPrimDefault; }
+    hipLaunchKernelGGL(k_fit, grd, blk, 0, stream, ctx.bTris.as<BuildTri>(), sortedIdx, static_cast<int>(n), ctx.bNodesLR.as<int2>(),
+                       parentInt, parentLeaf, ctx.bFlags.as<uint32_t>(), ctx.bNodeBoxes.as<float>(),
+                       ctx.bRanges.as<uint2>(), 1u /* one triangle per leaf slot */, costPrim, ctx.bCosts.as<float>(), ctx.bDec.as<uint32_t>());
+    if (rootBoxOut) hipLaunchKernelGGL(k_copy_root_box, dim3(1), dim3(64), 0, stream, ctx.bNodeBoxes.as<float>(), rootBoxOut);
+    static int useDp = -1;   // GFX_BVH_COLLAPSE=greedy: open the largest-area child until 8 (the reference's rule)
+    if (useDp < 0) { const char* e = getenv("GFX_BVH_COLLAPSE"); useDp = (e && std::strcmp(e, "greedy") == 0) ? 0 : 1; }
+    // level 0 work item: binary root 0 -> wide node rootWide
+    const uint2 rootItem = make_uint2(0u, rootWide);
+    GFX_HIP(hipMemcpyAsync(ctx.bQueueA.p, &rootItem, sizeof(rootItem), hipMemcpyHostToDevice, stream));
+    const uint32_t gridC = std::min<uint32_t>((n + 255) / 256, 2048u);
+    for (uint32_t level = 0; level < kMaxCollapseLevels; ++level) {
+        uint2* qin = (level & 1) ? ctx.bQueueB.as<uint2>() : ctx.bQueueA.as<uint2>();
+        uint2* qout = (level & 1) ? ctx.bQueueA.as<uint2>() : ctx.bQueueB.as<uint2>();
+        hipLaunchKernelGGL(k_collapse_level, dim3(gridC), dim3(256), 0, stream, level, ctx.maxLeafTris, qin, qout, counters,
+                           ctx.bNodesLR.as<int2>(), ctx.bRanges.as<uint2>(), ctx.bNodeBoxes.as<float>(),
+                           ctx.bDec.as<uint32_t>(), useDp,
+                           ctx.bTris.as<BuildTri>(), sortedIdx, ctx.bFlatIdx.as<uint32_t>(), out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>(), out.trisPtr());
     }
-    hipLaunchKernelGGL(k_flatten, grd, blk, 0, stream, ctx.devScene(), ctx.dFlatGeoms.as<DevFlatGeom>(), numFlat, n,
-                       ctx.bTris.as<BuildTri>(), bounds);
-    if (n == 1) {
-        hipLaunchKernelGGL(k_single_tri_root, dim3(1), dim3(64), 0, stream, ctx.bTris.as<BuildTri>(), out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>(), out.trisPtr());
-        out.numNodes = 1; out.numTris = 1; out.maxDepth = 1;
+    GFX_HIP(hipGetLastError());
+    std::vector<uint32_t> h(2 + kMaxCollapseLevels + 2);
+    GFX_HIP(hipMemcpyAsync(h.data(), counters, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost, stream));
+    GFX_HIP(hipStreamSynchronize(stream));
+    uint32_t depth = 0;
+    for (uint32_t l = 0; l < kMaxCollapseLevels; ++l) if (h[2 + l]) depth = l + 1;
+    if (h[2 + kMaxCollapseLevels] != 0) throw HipError("lbvh_build: tree deeper than kMaxCollapseLevels");
+    if (h[1] - triAllocStart != n) throw HipError("lbvh_build: triangle count mismatch after collapse");
+    return { h[0], depth };
+}
+
+// Tree layouts.  No animated instances (or only animated ones): one tree, root = node 0.  Both kinds: node 0 is a
+// two-child root over the static subtree (root node 1, nodes from 3, triangle records [0, nStatic)) and the animated
+// subtree (root node 2, nodes behind the static ones, triangle records [nStatic, n)); a transform update of the
+// animated instances then rebuilds only the second subtree and node 0 (lbvh_update_dynamic).
+void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
+    scene_upload(ctx, stream);
+    transforms_upload(ctx, stream);
+    const uint32_t n = ctx.totalTriangles;
+    out.numInputTris = n;
+    out.numNodes = 0; out.numTris = 0; out.maxDepth = 0; out.split = false;
+    if (n == 0) return;
+    // the traversal kernel addresses items (node slots + triangle records, 64 B each) with 32-bit byte offsets
+    if (n >= (1u << 25) - 4u) throw std::runtime_error("gfx: acceleration structure limited to 2^25 triangles");
+    const uint32_t nodeSlots = n + 4;
+    out.nodes.reserve(sizeof(Bvh8Node) * (static_cast<size_t>(nodeSlots) + n));   // node slots + n triangle records
+    out.triItemOffset = nodeSlots;
+    out.links.reserve(sizeof(Bvh8Link) * static_cast<size_t>(nodeSlots));
+    out.triIds.reserve(sizeof(gfx_tri_ids) * static_cast<size_t>(n));
+    out.rootBoxes.reserve(sizeof(float) * 16);
+    const uint32_t nStatic = ctx.subsetTris[0], nDynamic = ctx.subsetTris[1];
+    if (nStatic == 0 || nDynamic == 0) {
+        const SubtreeResult r = build_subtree(ctx, stream, out, nStatic ? 0 : 1, 0u, 1u, 0u, nullptr);
+        out.numNodes = r.nodeEnd; out.maxDepth = r.depth;
     }
     else {
-        hipLaunchKernelGGL(k_morton, grd, blk, 0, stream, ctx.bTris.as<BuildTri>(), n, bounds, ctx.bKeys.as<uint64_t>(), ctx.bVals.as<uint32_t>());
-        size_t tempBytes = 0;
-        GFX_HIP(rocprim::radix_sort_pairs(nullptr, tempBytes, ctx.bKeys.as<uint64_t>(), ctx.bKeysAlt.as<uint64_t>(),
-                                          ctx.bVals.as<uint32_t>(), ctx.bValsAlt.as<uint32_t>(), n, 0, 63, stream));
-        ctx.bSortTemp.reserve(std::max<size_t>(tempBytes, 16));
-        GFX_HIP(rocprim::radix_sort_pairs(ctx.bSortTemp.p, tempBytes, ctx.bKeys.as<uint64_t>(), ctx.bKeysAlt.as<uint64_t>(),
-                                          ctx.bVals.as<uint32_t>(), ctx.bValsAlt.as<uint32_t>(), n, 0, 63, stream));
-        const uint64_t* keys = ctx.bKeysAlt.as<uint64_t>();
-        const uint32_t* sortedIdx = ctx.bValsAlt.as<uint32_t>();
-        uint32_t* parentInt = ctx.bParents.as<uint32_t>();
-        uint32_t* parentLeaf = parentInt + n;
-        hipLaunchKernelGGL(k_karras, grd, blk, 0, stream, keys, static_cast<int>(n), ctx.bNodesLR.as<int2>(), parentInt, parentLeaf,
-                           ctx.bRanges.as<uint2>());
-        GFX_HIP(hipMemsetAsync(ctx.bFlags.p, 0, 4ull * n, stream));
-        ctx.bCosts.reserve(32ull * n); ctx.bDec.reserve(4ull * n);
-        static float costPrim = -1.0f;
-        if (costPrim < 0) { const char* e = getenv("GFX_BVH_CPRIM"); costPrim = e ? static_cast<float>(atof(e)) : kCostPrimDefault; if (!(costPrim > 0)) costPrim = kCostPrimDefault; }
-        hipLaunchKernelGGL(k_fit, grd, blk, 0, stream, ctx.bTris.as<BuildTri>(), sortedIdx, static_cast<int>(n), ctx.bNodesLR.as<int2>(),
-                           parentInt, parentLeaf, ctx.bFlags.as<uint32_t>(), ctx.bNodeBoxes.as<float>(),
-                           ctx.bRanges.as<uint2>(), 1u /* one triangle per leaf slot */, costPrim, ctx.bCosts.as<float>(), ctx.bDec.as<uint32_t>());
-        static int useDp = -1;   // GFX_BVH_COLLAPSE=greedy: open the largest-area child until 8 (the reference's rule)
-        if (useDp < 0) { const char* e = getenv("GFX_BVH_COLLAPSE"); useDp = (e && std::strcmp(e, "greedy") == 0) ? 0 : 1; }
-        // level 0 work item: binary root 0 -> wide node 0
-        const uint2 rootItem = make_uint2(0u, 0u);
-        GFX_HIP(hipMemcpyAsync(ctx.bQueueA.p, &rootItem, sizeof(rootItem), hipMemcpyHostToDevice, stream));
-        const uint32_t gridC = std::min<uint32_t>((n + 255) / 256, 2048u);
-        for (uint32_t level = 0; level < kMaxCollapseLevels; ++level) {
-            uint2* qin = (level & 1) ? ctx.bQueueB.as<uint2>() : ctx.bQueueA.as<uint2>();
-            uint2* qout = (level & 1) ? ctx.bQueueA.as<uint2>() : ctx.bQueueB.as<uint2>();
-            hipLaunchKernelGGL(k_collapse_level, dim3(gridC), dim3(256), 0, stream, level, ctx.maxLeafTris, qin, qout, counters,
-                               ctx.bNodesLR.as<int2>(), ctx.bRanges.as<uint2>(), ctx.bNodeBoxes.as<float>(),
-                               ctx.bDec.as<uint32_t>(), useDp,
-                               ctx.bTris.as<BuildTri>(), sortedIdx, out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>(), out.trisPtr());
-        }
-        GFX_HIP(hipGetLastError());
-        std::vector<uint32_t> h(2 + kMaxCollapseLevels + 2);
-        GFX_HIP(hipMemcpyAsync(h.data(), counters, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost, stream));
-        GFX_HIP(hipStreamSynchronize(stream));
-        out.numNodes = h[0]; out.numTris = h[1];
-        for (uint32_t l = 0; l < kMaxCollapseLevels; ++l) if (h[2 + l]) out.maxDepth = l + 1;
-        if (h[2 + kMaxCollapseLevels] != 0) throw HipError("lbvh_build: tree deeper than kMaxCollapseLevels");
-        if (out.numTris != n) throw HipError("lbvh_build: triangle count mismatch after collapse");
+        out.split = true;
+        out.numStaticTris = nStatic;
+        const SubtreeResult rs = build_subtree(ctx, stream, out, 0, 1u, 3u, 0u, out.rootBoxes.as<float>());
+        out.staticNodeEnd = std::max(rs.nodeEnd, 3u);
+        const SubtreeResult rd = build_subtree(ctx, stream, out, 1, 2u, out.staticNodeEnd, nStatic, out.rootBoxes.as<float>() + 8);
+        hipLaunchKernelGGL(k_super_root, dim3(1), dim3(64), 0, stream, out.rootBoxes.as<float>(), out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>());
+        out.numNodes = rd.nodeEnd; out.maxDepth = std::max(rs.depth, rd.depth) + 1;
     }
-    hipLaunchKernelGGL(k_tri_ids, dim3((out.numTris + 255) / 256), blk, 0, stream, out.trisPtr(), out.numTris, out.triIds.as<gfx_tri_ids>());
+    out.numTris = n;
+    hipLaunchKernelGGL(k_tri_ids, dim3((n + 255) / 256), dim3(256), 0, stream, out.trisPtr(), 0u, n, out.triIds.as<gfx_tri_ids>());
     GFX_HIP(hipGetLastError());
     GFX_HIP(hipStreamSynchronize(stream));
+}
+
+// Animated instances moved, nothing else changed: rebuild their subtree and the two-child root.  For the usual
+// handful of triangles this is a few small kernels and no host round trip.
+bool lbvh_update_dynamic(Context& ctx, hipStream_t stream, Accel& out) {
+    if (ctx.sceneDirty || !out.split || out.numInputTris != ctx.totalTriangles || out.numStaticTris != ctx.subsetTris[0]) return false;
+    transforms_upload(ctx, stream);
+    const uint32_t nStatic = ctx.subsetTris[0], nDynamic = ctx.subsetTris[1];
+    const SubtreeResult rd = build_subtree(ctx, stream, out, 1, 2u, out.staticNodeEnd, nStatic, out.rootBoxes.as<float>() + 8);
+    hipLaunchKernelGGL(k_super_root, dim3(1), dim3(64), 0, stream, out.rootBoxes.as<float>(), out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>());
+    hipLaunchKernelGGL(k_tri_ids, dim3((nDynamic + 255) / 256), dim3(256), 0, stream, out.trisPtr(), nStatic, nDynamic, out.triIds.as<gfx_tri_ids>());
+    GFX_HIP(hipGetLastError());
+    out.numNodes = rd.nodeEnd;
+    return true;
 }
 
 } // namespace gfx

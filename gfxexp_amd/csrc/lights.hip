@@ -231,6 +231,16 @@ void lights_build_static(Context& ctx, hipStream_t stream) {
 
 void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t /*bufferIndex*/) {
     if (!ctx.lightsStaticBuilt) lights_build_static(ctx, stream);
+    transforms_upload(ctx, stream);
+    if (ctx.emitterRecsDirty) {
+        // animated instances moved: their emitter triangles are stored in world space
+        const uint32_t numInsts = static_cast<uint32_t>(ctx.insts.size());
+        if (numInsts)
+            hipLaunchKernelGGL(k_emitter_records, dim3(numInsts), dim3(64), 0, stream, ctx.devScene(), numInsts,
+                               ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>());
+        GFX_HIP(hipGetLastError());
+        ctx.emitterRecsDirty = false;
+    }
     const uint32_t ni = static_cast<uint32_t>(ctx.insts.size());
     // The integral stays device resident (like the DiscreteDistribution1D inside the reference's
     // static launch parameters, restir_di_main.cpp:2303-2309): no host round trip per frame.

@@ -8,12 +8,12 @@
 namespace gfx {
 
 Context::~Context() {
-    for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->triIds.release(); delete a; } }
-    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs,
+    for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->triIds.release(); a->rootBoxes.release(); delete a; } }
+    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dSubset[0], &dSubset[1], &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs,
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
                       &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide,
-                      &dTraceDiag, &bCosts, &bDec, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
+                      &dTraceDiag, &bCosts, &bDec, &bFlatIdx, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
                       &rearchSlots, &nrcState, &neeTrainIdx };
     for (NrcNet* net : nrcNets) if (net) nrc_destroy(net);
     for (DevBuf* b : all) b->release();
@@ -84,6 +84,36 @@ void instance_cur_to_prev(const float prev[12], const float cur[12], float out[1
             out[4 * i + j] = prev[4 * i + 0] * inv[0 + j] + prev[4 * i + 1] * inv[4 + j] + prev[4 * i + 2] * inv[8 + j] + prev[4 * i + 3] * inv[12 + j];
 }
 
+// transform, curToPrevTransform, normal matrix and uniform scale of a DevInstance from the host instance
+static void fill_instance_transform(const HostInstance& hi, DevInstance& d) {
+    std::memcpy(d.transform, hi.transform, sizeof(float) * 12);
+    // curToPrevTransform: identity for static instances (common_host.cpp:2631), prev * invert(cur) once moved
+    const float ident[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    std::memcpy(d.curToPrevTransform, hi.animated ? hi.curToPrev : ident, sizeof(ident));
+    if (hi.hasNormalMatrix)
+        for (int rr = 0; rr < 3; ++rr) {
+            for (int cc = 0; cc < 3; ++cc) d.normalMatrix[rr * 4 + cc] = hi.normalMatrix[rr * 3 + cc];
+            d.normalMatrix[rr * 4 + 3] = 0.0f;
+        }
+    else normal_matrix(hi.transform, d.normalMatrix);
+    d.uniformScale = std::sqrt(hi.transform[0] * hi.transform[0] + hi.transform[4] * hi.transform[4] + hi.transform[8] * hi.transform[8]);
+}
+
+// Transform-only update (gfx_instance_set_transform on instances that already live in the animated subtree): the
+// pools, the distributions' layout and the static subtree stay; only the moved DevInstance entries go to the device.
+// The emitter records (world-space triangles) are refreshed by the next lights_build_instances.
+void transforms_upload(Context& ctx, hipStream_t stream) {
+    if (!ctx.transformsDirty) return;
+    for (uint32_t slot : ctx.movedInsts) {
+        DevInstance& d = ctx.hInsts[slot];
+        fill_instance_transform(ctx.insts[slot], d);
+        GFX_HIP(hipMemcpyAsync(ctx.dInsts.as<DevInstance>() + slot, &d, sizeof(DevInstance), hipMemcpyHostToDevice, stream));
+    }
+    ctx.movedInsts.clear();
+    ctx.transformsDirty = false;
+    ctx.emitterRecsDirty = true;
+}
+
 template <typename T>
 static void upload(DevBuf& b, const std::vector<T>& v, hipStream_t stream) {
     b.reserve(std::max<size_t>(sizeof(T) * v.size(), 16));
@@ -116,21 +146,13 @@ void scene_upload(Context& ctx, hipStream_t stream) {
     }
     ctx.hInsts.assign(ctx.insts.size(), DevInstance());
     ctx.hFlatGeoms.clear();
+    ctx.hSubset[0].clear(); ctx.hSubset[1].clear();
+    ctx.subsetTris[0] = ctx.subsetTris[1] = 0;
     uint32_t triCursor = 0;
     for (size_t ii = 0; ii < ctx.insts.size(); ++ii) {
         const HostInstance& hi = ctx.insts[ii];
         DevInstance& d = ctx.hInsts[ii];
-        std::memcpy(d.transform, hi.transform, sizeof(float) * 12);
-        // curToPrevTransform: identity for static instances (common_host.cpp:2631), prev * invert(cur) once moved
-        const float ident[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
-        std::memcpy(d.curToPrevTransform, hi.animated ? hi.curToPrev : ident, sizeof(ident));
-        if (hi.hasNormalMatrix)
-            for (int rr = 0; rr < 3; ++rr) {
-                for (int cc = 0; cc < 3; ++cc) d.normalMatrix[rr * 4 + cc] = hi.normalMatrix[rr * 3 + cc];
-                d.normalMatrix[rr * 4 + 3] = 0.0f;
-            }
-        else normal_matrix(hi.transform, d.normalMatrix);
-        d.uniformScale = std::sqrt(hi.transform[0] * hi.transform[0] + hi.transform[4] * hi.transform[4] + hi.transform[8] * hi.transform[8]);
+        fill_instance_transform(hi, d);
         const std::vector<uint32_t>& slots = ctx.groups[hi.group];
         d.slotsOffset = static_cast<uint32_t>(slotPool.size());
         d.numGeomInsts = static_cast<uint32_t>(slots.size());
@@ -142,6 +164,9 @@ void scene_upload(Context& ctx, hipStream_t stream) {
             fg.numTriangles = ctx.hGeomInsts[s].numTriangles;
             triCursor += fg.numTriangles;
             ctx.hFlatGeoms.push_back(fg);
+            const int sub = hi.dynamic ? 1 : 0;
+            ctx.hSubset[sub].push_back(SubsetGeom{ fg.instSlot, fg.geomInstSlot, ctx.subsetTris[sub], fg.triBegin });
+            ctx.subsetTris[sub] += fg.numTriangles;
         }
         d.distOffset = hasEmitter ? lightPool : 0xFFFFFFFFu;
         d.distIntegral = 0;
@@ -183,6 +208,9 @@ void scene_upload(Context& ctx, hipStream_t stream) {
     upload(ctx.dTriangles, triangles, stream);
     upload(ctx.dSlotPool, slotPool, stream);
     upload(ctx.dFlatGeoms, ctx.hFlatGeoms, stream);
+    upload(ctx.dSubset[0], ctx.hSubset[0], stream);
+    upload(ctx.dSubset[1], ctx.hSubset[1], stream);
+    ctx.transformsDirty = false; ctx.movedInsts.clear(); ctx.emitterRecsDirty = false;
     upload(ctx.dLightRefs, ctx.hLightRefs, stream);
     ctx.dEmitterRecs.reserve(std::max<size_t>(sizeof(EmitterRec) * ctx.numEmitterRecs, 16));
     ctx.dLightW.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));

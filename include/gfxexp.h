@@ -115,6 +115,11 @@ int gfx_instance_create(gfx_ctx* ctx, uint32_t group, const float xfm[12], uint3
  * matRot / curScale (row-major 3x3, common_host.h:843) for a bit-exact shim. */
 int gfx_instance_set_transform(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12]);
 int gfx_instance_set_transform_and_normal_matrix(gfx_ctx* ctx, uint32_t instSlot, const float xfm[12], const float normalMatrix[9]);
+/* Declares an instance animated before the first gfx_accel_build.  Animated instances live in their own BVH
+ * subtree under a two-child root; gfx_instance_set_transform on them followed by gfx_accel_build (same handle)
+ * rebuilds only that subtree -- a few small kernels for a light or two -- instead of the whole tree.  An instance
+ * that was not declared becomes animated at its first gfx_instance_set_transform (one full rebuild). */
+int gfx_instance_set_dynamic(gfx_ctx* ctx, uint32_t instSlot, int dynamic);
 
 /* common/common_host.h:1027-1100 Scene::updateASs -> OptixTraversableHandle.  Builds the HIP
  * LBVH -> BVH8 over all instances (world space).  The 64-bit handle fits the reference's
