@@ -144,3 +144,41 @@ def test_degenerate_inputs(built_lib):
     osc = util.feed_oracle(hs, brute_force=True)
     _compare_closest(_gpu_trace(ctx2, accel2, api.TRACE_CLOSEST, org, dirs), _tri_ids(ctx2, accel2),
                      osc.trace(2, org, dirs), osc.tri_ids(), "single triangle")
+
+
+def test_split_tree_static_plus_animated_subtree(built_lib):
+    """A declared-animated rectangle light (2 triangles: single-kernel subtree) and a declared-animated teapot
+    (general builder) next to a static street: after every transform update the in-place rebuild touches only the
+    animated subtree, and closest / any hits still equal the oracle's (rebuilt from scratch each time)."""
+    hs = util.small_street()
+    light = hs.add_rectangle(2.0, 1.0, (30, 30, 30))
+    light_slot = hs.add_instance(light, api.make_transform(pos=(0.0, 6.0, 0.0)))
+    pot = hs.load_obj(__import__("os").path.join(util.ASSETS, "teapot.obj"))
+    pot_slot = hs.add_instance(pot, api.make_transform(scale=0.4, pos=(3.0, 0.0, 2.0)))
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    ctx.instance_set_dynamic(light_slot)
+    accel = ctx.accel_build()
+    nodes_before = ctx.accel_stats(accel)["nodes"]
+    osc = util.feed_oracle(hs)
+    b = hs.bounds()
+    centre = 0.5 * (b[:3] + b[3:])
+    org, dirs = util.pinhole_rays(192, 128, centre + np.array([0.1, 0.25, 0.7]) * np.linalg.norm(b[3:] - b[:3]), centre)
+    shadow_o = org.copy(); shadow_d = dirs.copy()
+    shadow_d[:, 3] = 40.0                                   # finite tmax: any-hit within 40 units
+    for step in range(4):
+        t = step / 3.0
+        moves = [(light_slot, api.make_transform(pos=(-4.0 + 8.0 * t, 6.0 - 2.0 * t, 1.0), roll=35.0 * t))]
+        if step >= 1:                                        # the teapot joins the animated set at step 1 (one full rebuild)
+            moves.append((pot_slot, api.make_transform(scale=0.4, yaw=90.0 * t, pos=(3.0 - 2.0 * t, 0.5 * t, 2.0))))
+        for slot, xfm in moves:
+            ctx.instance_set_transform(slot, xfm)
+            osc.set_instance_transform(slot, xfm)
+        assert ctx.accel_build(handle=accel) == accel
+        osc.commit()
+        gpu = _gpu_trace(ctx, accel, api.TRACE_CLOSEST, org, dirs)
+        _compare_closest(gpu, _tri_ids(ctx, accel), osc.trace(0, org, dirs), osc.tri_ids(), f"step {step}")
+        occ = _gpu_trace(ctx, accel, api.TRACE_ANY, shadow_o, shadow_d)
+        assert np.array_equal(occ != 0, osc.trace(1, shadow_o, shadow_d) != 0), f"step {step}: any-hit"
+    assert ctx.accel_stats(accel)["triRecords"] == hs.counts()["triangles"]
+    assert nodes_before > 0
