@@ -164,7 +164,7 @@ HOST_ABI_SYMBOLS = [
     "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
-    "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_beauty_buffer",
+    "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_rebuild_accel", "gfxh_nrc_beauty_buffer",
     "gfxh_nrc_network", "gfxh_nrc_stats",
 ]
 
@@ -575,6 +575,10 @@ class NrcRenderer:
         if self.h:
             self.L.gfxh_nrc_destroy(self.h)
             self.h = None
+
+    def rebuild_accel(self, stream=0):
+        if self.L.gfxh_nrc_rebuild_accel(self.h, C.c_void_p(stream)):
+            raise GfxError("gfxh_nrc_rebuild_accel: " + self.L.gfxh_nrc_last_error().decode())
 
     def render_frame(self, stream=0, want_loss=False):
         loss = C.c_float(0.0)

@@ -216,6 +216,10 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     return 0;
 }
 
+int gfxh_nrc_rebuild_accel(gfxh_nrc* r, void* stream) {
+    if (gfx_accel_build(r->ctx, stream, &r->accel)) { g_nrcError = gfx_last_error(r->ctx); return 1; }
+    return 0;
+}
 void* gfxh_nrc_beauty_buffer(gfxh_nrc* r) { return r->sp.beautyAccumBuffer; }
 uint64_t gfxh_nrc_network(gfxh_nrc* r) {
     if (r->trainStream) (void)hipStreamSynchronize(r->trainStream);   // whoever asks for the network sees it trained

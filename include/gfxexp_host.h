@@ -204,6 +204,8 @@ int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out);
 void gfxh_nrc_destroy(gfxh_nrc* r);
 /* lossOut (optional): the loss of the fourth training step (main:2363). */
 int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut);
+/* Scene::updateASs of an animated frame: rebuild the renderer's BVH in place after gfx_instance_set_transform. */
+int gfxh_nrc_rebuild_accel(gfxh_nrc* r, void* stream);
 void* gfxh_nrc_beauty_buffer(gfxh_nrc* r);
 uint64_t gfxh_nrc_network(gfxh_nrc* r);
 int gfxh_nrc_stats(gfxh_nrc* r, uint32_t* numTrainingData, uint32_t tileSize[2], uint32_t* numInferenceQueries);
