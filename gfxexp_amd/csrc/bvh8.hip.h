@@ -74,6 +74,7 @@ constexpr uint32_t kItemTri = 0x80000000u;    // item code: bit 31 = triangle re
 // widened by 2^-21 of that magnitude, so no box the exact test keeps is ever culled.
 struct Traversal {
     f3 org, dir, inv;
+    f3 slackScale, slackOrg;               // 2^-21 |1/dir_k| and 2^-21 |org_k / dir_k|: per-ray factors of the slab widening
     float tmin;
     RayHit hit;
     uint2 grp;
@@ -89,6 +90,8 @@ struct Traversal {
         const float dy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
         const float dz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
         inv = f3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+        slackScale = f3(fabsf(inv.x) * 4.76837158203125e-07f, fabsf(inv.y) * 4.76837158203125e-07f, fabsf(inv.z) * 4.76837158203125e-07f);
+        slackOrg = f3(fabsf(o.x) * slackScale.x, fabsf(o.y) * slackScale.y, fabsf(o.z) * slackScale.z);
         hit.t = t1; hit.bcB = 0; hit.bcC = 0; hit.tri = GFX_INVALID_SLOT;
         // octant mask: bit k set when the ray travels toward -k, so (slot ^ oct) ascending = near to far
         oct = (dx < 0 ? 1u : 0u) | (dy < 0 ? 2u : 0u) | (dz < 0 ? 4u : 0u);
@@ -164,11 +167,11 @@ struct Traversal {
 
         const f3 B = scale * inv;
         const f3 A = (origin - org) * inv;
-        const f3 m(fmaxf(fabsf(origin.x), fabsf(origin.x + 255.0f * scale.x)) + fabsf(org.x),
-                   fmaxf(fabsf(origin.y), fabsf(origin.y + 255.0f * scale.y)) + fabsf(org.y),
-                   fmaxf(fabsf(origin.z), fabsf(origin.z + 255.0f * scale.z)) + fabsf(org.z));
-        const f3 slack(m.x * fabsf(inv.x) * 4.76837158203125e-07f, m.y * fabsf(inv.y) * 4.76837158203125e-07f,
-                       m.z * fabsf(inv.z) * 4.76837158203125e-07f);
+        // widening: 2^-21 |1/dir_k| (|origin_k| + 255 scale_k + |org_k|), an upper bound of the magnitude the header
+        // comment asks for (|origin + 255 scale| <= |origin| + 255 scale), two FMAs per axis
+        const f3 slack(fmaf(fmaf(255.0f, scale.x, fabsf(origin.x)), slackScale.x, slackOrg.x),
+                       fmaf(fmaf(255.0f, scale.y, fabsf(origin.y)), slackScale.y, slackOrg.y),
+                       fmaf(fmaf(255.0f, scale.z, fabsf(origin.z)), slackScale.z, slackOrg.z));
         const f3 An = A - slack, Af = A + slack;
 
         // branch-free: one bit per hit SLOT, classified after the loop
