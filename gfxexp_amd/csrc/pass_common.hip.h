@@ -52,6 +52,50 @@ GFX_DEV uint32_t queue_append(bool want, f3 org, f3 dir, float tmin, float tmax,
     return slot;
 }
 
+// Several appends of one block at once: every thread asks for up to K slots (want[k]); the block takes ONE atomic
+// for all of them and two barriers instead of three per kind.  The block's chunk of the queue is laid out kind by
+// kind (all rays of kind 0, then kind 1, ...), so consecutive entries are still the same kind of ray from
+// neighbouring pixels.  EVERY thread of the block must call it.  slot[k] = GFX_INVALID_SLOT where !want[k]; the
+// caller writes the rays (queue_write).
+template <int K>
+GFX_DEV void queue_reserve(const bool (&want)[K], uint32_t* rayCount, uint32_t (&slot)[K]) {
+    __shared__ uint32_t qr[1 + K + 16 * K];               // [0] block base, [1 + k] block total of kind k, then [wave][kind]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, numWaves = (blockDim.x + 63) >> 6;
+    unsigned long long mask[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        mask[k] = __ballot(want[k]);
+        if (lane == 0) qr[1 + K + wave * K + k] = static_cast<uint32_t>(__popcll(mask[k]));
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        uint32_t total = 0;
+        for (int w = 0; w < numWaves; ++w) total += qr[1 + K + w * K + threadIdx.x];
+        qr[1 + threadIdx.x] = total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int k = 0; k < K; ++k) total += qr[1 + k];
+        qr[0] = total ? atomicAdd(rayCount, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t kindBase = qr[0];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        uint32_t base = kindBase;
+        for (int w = 0; w < wave; ++w) base += qr[1 + K + w * K + k];
+        slot[k] = want[k] ? base + static_cast<uint32_t>(__popcll(mask[k] & ((1ull << lane) - 1ull))) : GFX_INVALID_SLOT;
+        kindBase += qr[1 + k];
+    }
+    __syncthreads();                                      // qr is reused by the next call of this block
+}
+GFX_DEV void queue_write(uint32_t slot, f3 org, f3 dir, float tmin, float tmax, float4* rayOrg, float4* rayDir) {
+    if (slot == GFX_INVALID_SLOT) return;
+    rayOrg[slot] = make_float4(org.x, org.y, org.z, tmin);
+    rayDir[slot] = make_float4(dir.x, dir.y, dir.z, tmax);
+}
+
 // Wave-level variant (one atomic per wave, no barrier): for long kernels whose waves finish at very
 // different times, where holding a block back at a barrier costs more than the spread-out atomics.
 GFX_DEV uint32_t queue_append_wave(bool want, f3 org, f3 dir, float tmin, float tmax,

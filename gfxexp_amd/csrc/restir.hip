@@ -422,27 +422,23 @@ __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
     const bool needMis = surface && selectedTarget > 0.0f;
     const LightSample selected = combined.sample;
     SpatialSlot* slots = a.spatialScratch + (p < a.pixelEnd ? p * (numNb + 1) : 0);
-    {
-        float targetSelf = 0.0f;
-        bool want = false;
-        f3 ro(0.0f), rd(0.0f); float tmax = 0;
+    const Camera prevCam = load_camera(a.f.prevCamera);
+    // MIS term k (0 = self, 1 + nIdx = neighbour): target density, stream length, and the visibility ray it needs
+    struct MisTerm { float target; uint32_t streamLength; bool want, evaluated; f3 ro, rd; float tmax; };
+    auto self_term = [&]() {
+        MisTerm t; t.target = 0.0f; t.streamLength = selfStreamLength; t.want = false; t.evaluated = true; t.ro = f3(0.0f); t.rd = f3(0.0f); t.tmax = 0;
         if (needMis) {
             const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, selected);
-            targetSelf = target_weight(cont);
-            if (a.f.reuseVisibility && targetSelf > 0.0f) {
+            t.target = target_weight(cont);
+            if (a.f.reuseVisibility && t.target > 0.0f) {
                 const ShadowRay sr = shadow_ray(sp.pos, selected);
-                want = true; ro = sp.pos; rd = sr.dir; tmax = sr.tmax;
+                t.want = true; t.ro = sp.pos; t.rd = sr.dir; t.tmax = sr.tmax;
             }
         }
-        const uint32_t slot = emit_ray(want, ro, rd, 0.0f, tmax, a);
-        if (p < a.pixelEnd) { SpatialSlot s; s.targetDensity = targetSelf; s.streamLength = selfStreamLength; s.raySlot = slot; slots[0] = s; }
-    }
-    const Camera prevCam = load_camera(a.f.prevCamera);
-    for (uint32_t nIdx = 0; nIdx < numNb; ++nIdx) {
-        float nbTarget = 0.0f;
-        uint32_t nbStreamLength = 0;
-        bool want = false, evaluated = false;
-        f3 ro(0.0f), rd(0.0f); float tmax = 0;
+        return t;
+    };
+    auto neighbor_term = [&](uint32_t nIdx) {
+        MisTerm t; t.target = 0.0f; t.streamLength = 0; t.want = false; t.evaluated = false; t.ro = f3(0.0f); t.rd = f3(0.0f); t.tmax = 0;
         if (needMis) {
             int nbx, nby;
             spatial_neighbor(a, rng, nIdx, x, y, nbx, nby);
@@ -454,19 +450,51 @@ __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
                     make_shading_point(a, bufIdx, np, prevCam.pos, true, nsp);   // prevCamera as in the reference (:487)
                     const Reservoir neighbor = load_reservoir(a.s.reservoirBuffer[srcRes], numPixels, np);
                     const f3 cont = direct_lighting(nsp.pos, nsp.vOutLocal, nsp.frame, nsp.bsdf, selected);
-                    nbTarget = target_weight(cont);
-                    nbStreamLength = neighbor.streamLength;
-                    evaluated = true;
-                    if (a.f.reuseVisibility && nbTarget > 0.0f) {
+                    t.target = target_weight(cont);
+                    t.streamLength = neighbor.streamLength;
+                    t.evaluated = true;
+                    if (a.f.reuseVisibility && t.target > 0.0f) {
                         const ShadowRay sr = shadow_ray(nsp.pos, selected);
-                        want = true; ro = nsp.pos; rd = sr.dir; tmax = sr.tmax;
+                        t.want = true; t.ro = nsp.pos; t.rd = sr.dir; t.tmax = sr.tmax;
                     }
                 }
             }
         }
-        uint32_t slot = emit_ray(want, ro, rd, 0.0f, tmax, a);
-        if (!evaluated) slot = kSlotSkipped;   // out of bounds / self / background: the reference `continue`s
-        if (p < a.pixelEnd) { SpatialSlot s; s.targetDensity = nbTarget; s.streamLength = nbStreamLength; s.raySlot = slot; slots[1 + nIdx] = s; }
+        return t;
+    };
+    auto store_term = [&](uint32_t k, const MisTerm& t, uint32_t slot) {
+        if (!t.evaluated) slot = kSlotSkipped;   // out of bounds / self / background: the reference `continue`s
+        if (p < a.pixelEnd) { SpatialSlot s; s.targetDensity = t.target; s.streamLength = t.streamLength; s.raySlot = slot; slots[k] = s; }
+    };
+    constexpr int kBatch = 4;                    // self + the reference's three neighbours: one queue reservation
+    if (numNb + 1 <= static_cast<uint32_t>(kBatch)) {
+        MisTerm terms[kBatch];
+        bool want[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if (k == 0) terms[k] = self_term();
+            else if (static_cast<uint32_t>(k) <= numNb) terms[k] = neighbor_term(static_cast<uint32_t>(k) - 1);
+            else { terms[k].want = false; terms[k].evaluated = false; }
+            want[k] = terms[k].want;
+        }
+        uint32_t raySlots[kBatch];
+        queue_reserve<kBatch>(want, a.rayCount, raySlots);
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if (static_cast<uint32_t>(k) > numNb) continue;
+            queue_write(raySlots[k], terms[k].ro, terms[k].rd, 0.0f, terms[k].tmax, a.rayOrg, a.rayDir);
+            store_term(static_cast<uint32_t>(k), terms[k], raySlots[k]);
+        }
+    }
+    else {
+        {
+            const MisTerm t = self_term();
+            store_term(0, t, emit_ray(t.want, t.ro, t.rd, 0.0f, t.tmax, a));
+        }
+        for (uint32_t nIdx = 0; nIdx < numNb; ++nIdx) {
+            const MisTerm t = neighbor_term(nIdx);
+            store_term(1 + nIdx, t, emit_ray(t.want, t.ro, t.rd, 0.0f, t.tmax, a));
+        }
     }
     if (!surface) return;
     rngBuf[p] = rng.state;

@@ -263,15 +263,20 @@ __global__ __launch_bounds__(kBlock) void k_rearch_emit(RestirArgs a) {
     // kind -> (origin, sample); every lane of the wave takes part in every append
     const f3* orgs[kRearchRayKinds] = { &pos, &pos, &tPos, &pos, &stPos, &stPos, &tPos };
     const LightSample* smps[kRearchRayKinds] = { &newS, &tS, &newS, &stS, &newS, &tS, &stS };
+    // kinds this instantiation never emits stay want = false; one reservation for all seven kinds
+    uint32_t slots[kRearchRayKinds];
+    queue_reserve<kRearchRayKinds>(want, a.rayCount, slots);
 #pragma unroll
     for (int k = 0; k < kRearchRayKinds; ++k) {
         if (k == 1 && !TEMPORAL) continue;
         if ((k == 2 || k == 5 || k == 6) && !(TEMPORAL && UNBIASED)) continue;
         if (k == 3 && !SPATIAL) continue;
         if ((k == 4 || k == 5 || k == 6) && !(SPATIAL && UNBIASED)) continue;
-        const ShadowRay sr = shadow_ray(*orgs[k], *smps[k]);
-        const uint32_t slot = emit_ray(want[k], *orgs[k], sr.dir, 0.0f, sr.tmax, a);
-        if (p < a.pixelEnd) a.rearchSlots[static_cast<size_t>(k) * numPixels + p] = slot;
+        if (slots[k] != GFX_INVALID_SLOT) {
+            const ShadowRay sr = shadow_ray(*orgs[k], *smps[k]);
+            queue_write(slots[k], *orgs[k], sr.dir, 0.0f, sr.tmax, a.rayOrg, a.rayDir);
+        }
+        if (p < a.pixelEnd) a.rearchSlots[static_cast<size_t>(k) * numPixels + p] = slots[k];
     }
     if (p < a.pixelEnd) a.pixelRaySlot[p] = sv;
 }
