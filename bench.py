@@ -75,11 +75,11 @@ def main():
 
     from gfxexp_amd import api
     from gfxexp_amd import tilesplit
-    from tests import util
+    from gfxexp_amd import scenes            # the measured path imports nothing from tests/ or oracle/
 
     W, H = args.width, args.height
     t0 = time.time()
-    hs = util.bench_street()
+    hs = scenes.bench_street()
     counts = hs.counts()
     ctx = api.Context(local_rank)
     hs.upload(ctx)

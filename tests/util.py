@@ -34,26 +34,7 @@ def feed_oracle(host_scene, threads=None, brute_force=False, config=None):
     return osc
 
 
-def bunny_scene(with_light=True, with_ground=True):
-    """BASELINE config 2: bunny (scale 0.1) + rectangle light + ground quad."""
-    s = api.HostScene()
-    g = s.load_obj(os.path.join(ASSETS, "stanford_bunny_309_faces.obj"))
-    s.add_instance(g, api.make_transform(scale=0.1))
-    if with_ground:
-        mat = s.add_material_traditional((0.7, 0.7, 0.7), (0.04, 0.04, 0.04), 0.1)
-        v = np.zeros(4, api.VERTEX_DTYPE)
-        v["position"] = [(-20, 0, -20), (20, 0, -20), (20, 0, 20), (-20, 0, 20)]
-        v["normal"] = (0, 1, 0)
-        v["texCoord0Dir"] = (1, 0, 0)
-        v["texCoord"] = [(0, 0), (1, 0), (1, 1), (0, 1)]
-        geom = s.add_geom(v, [(0, 2, 1), (0, 3, 2)], mat)
-        s.add_instance(s.add_group([geom]), api.make_transform())
-    if with_light:
-        r = s.add_rectangle(1.0, 1.0, (50, 50, 50))
-        s.add_instance(r, api.make_transform(pos=(0.0, 12.0, 2.0)))
-        r2 = s.add_rectangle(2.0, 1.0, (10, 20, 40))
-        s.add_instance(r2, api.make_transform(pitch=-60.0, pos=(-6.0, 6.0, 6.0)))
-    return s
+from gfxexp_amd.scenes import bunny_scene  # noqa: E402,F401
 
 
 def teapot_scene(emissive=False):
@@ -67,41 +48,7 @@ def teapot_scene(emissive=False):
     return s
 
 
-def small_street(seed=7, scale=1):
-    p = api.GfxhStreetParams()
-    p.seed = seed
-    p.groundTess = 24 * scale
-    p.numBuildings = 8
-    p.facadeTess = 12 * scale
-    p.numProps = 30 * scale
-    p.propSubdiv = 1
-    p.numLamps = 24 * scale
-    p.numSigns = 12 * scale
-    p.extent = 30.0
-    p.lampEmittance = 40.0
-    p.signEmittance = 8.0
-    s = api.HostScene()
-    s.make_street(p)
-    return s
-
-
-def bench_street(seed=2024):
-    """The Bistro-Exterior stand-in used by bench.py (about 2.8 M instanced triangles)."""
-    p = api.GfxhStreetParams()
-    p.seed = seed
-    p.groundTess = 512
-    p.numBuildings = 44
-    p.facadeTess = 64
-    p.numProps = 600
-    p.propSubdiv = 3
-    p.numLamps = 1500
-    p.numSigns = 600
-    p.extent = 60.0
-    p.lampEmittance = 60.0
-    p.signEmittance = 10.0
-    s = api.HostScene()
-    s.make_street(p)
-    return s
+from gfxexp_amd.scenes import bench_street, small_street  # noqa: E402,F401  (scene definitions live with the product)
 
 
 def pathological_light_scene(seed=11, instances=420):

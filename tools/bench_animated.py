@@ -9,7 +9,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gfxexp_amd import api  # noqa: E402
-from tests import util  # noqa: E402
+from gfxexp_amd import scenes  # noqa: E402
 
 
 def light_transform(t_seconds):
@@ -21,7 +21,7 @@ def light_transform(t_seconds):
 def run(animated, steps=40, declare=True):
     import torch
     W, H = 1920, 1080
-    hs = util.bench_street()
+    hs = scenes.bench_street()
     light = hs.add_rectangle(1.5, 1.5, (60, 60, 60))
     slot = hs.add_instance(light, light_transform(0.0))
     ctx = api.Context(0)

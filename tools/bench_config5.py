@@ -7,14 +7,14 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gfxexp_amd import api  # noqa: E402
-from tests import util  # noqa: E402
+from gfxexp_amd import scenes  # noqa: E402
 
 
 def main():
     import torch
     W, H = 1920, 1080
     ctx = api.Context(0)
-    util.bench_street().upload(ctx)
+    scenes.bench_street().upload(ctx)
     cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_UNBIASED)
     cfg.camera = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
     r = api.RestirRenderer(ctx, cfg)

@@ -18,7 +18,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gfxexp_amd import api  # noqa: E402
-from tests import util  # noqa: E402
+from gfxexp_amd import scenes  # noqa: E402
 
 
 def timed(ctx, renderer, steps, warmup):
@@ -45,7 +45,7 @@ def main():
     args = ap.parse_args()
 
     # configs[1]
-    hs = util.bunny_scene()
+    hs = scenes.bunny_scene()
     ctx = api.Context(0)
     hs.upload(ctx)
     w = h = 512
@@ -55,7 +55,7 @@ def main():
     print(json.dumps({"renderer": "path_trace", "workload": "configs[1]: bunny + rectangle light + ground, 512x512, 1 spp, max path length 5",
                       "ms_per_frame": round(dt * 1e3, 4), "Mpaths_per_s": round(w * h / dt / 1e6, 2), "kernels_ms_per_frame": k}))
 
-    hs = util.bench_street()
+    hs = scenes.bench_street()
     ctx = api.Context(0)
     hs.upload(ctx)
     w, h = 1920, 1080
