@@ -165,7 +165,7 @@ HOST_ABI_SYMBOLS = [
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
     "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_rebuild_accel", "gfxh_nrc_beauty_buffer",
-    "gfxh_nrc_network", "gfxh_nrc_stats",
+    "gfxh_nrc_network", "gfxh_nrc_stats", "gfxh_save_image_sdr", "gfxh_save_image_hdr", "gfxh_tonemap_sdr",
 ]
 
 _lib = None
@@ -334,6 +334,35 @@ def band_plan(height, band_begin, band_end, radius_rows, num_spatial_passes, max
     lib().gfxh_band_plan_compute(C.c_uint32(height), C.c_uint32(band_begin), C.c_uint32(band_end), C.c_uint32(radius_rows),
                                  C.c_uint32(num_spatial_passes), C.c_uint32(max_motion_rows), C.byref(plan))
     return plan
+
+
+class GfxhSdrConfig(C.Structure):
+    _fields_ = [("alphaForOverride", C.c_float), ("brightnessScale", C.c_float), ("applyToneMap", C.c_uint32),
+                ("apply_sRGB_gammaCorrection", C.c_uint32), ("flipY", C.c_uint32)]
+
+
+def sdr_config(brightness=1.0, tone_map=True, gamma=True, flip_y=False):
+    return GfxhSdrConfig(-1.0, brightness, int(tone_map), int(gamma), int(flip_y))
+
+
+def tonemap_sdr(rgba, width, height, cfg):
+    """8-bit pixels (R | G << 8 | B << 16 | A << 24) of a float4 image: saveImage's tone map + sRGB gamma."""
+    src = np.ascontiguousarray(rgba, np.float32).reshape(-1)
+    out = np.zeros(width * height, np.uint32)
+    lib().gfxh_tonemap_sdr(C.c_uint32(width), C.c_uint32(height), _p(src), C.byref(cfg), _p(out))
+    return out.reshape(height, width)
+
+
+def save_image_sdr(path, rgba, width, height, cfg):
+    src = np.ascontiguousarray(rgba, np.float32).reshape(-1)
+    if lib().gfxh_save_image_sdr(path.encode(), C.c_uint32(width), C.c_uint32(height), _p(src), C.byref(cfg)):
+        raise GfxError(lib().gfxh_last_error().decode())
+
+
+def save_image_hdr(path, rgba, width, height, brightness=1.0, flip_y=False):
+    src = np.ascontiguousarray(rgba, np.float32).reshape(-1)
+    if lib().gfxh_save_image_hdr(path.encode(), C.c_uint32(width), C.c_uint32(height), C.c_float(brightness), _p(src), C.c_int(int(flip_y))):
+        raise GfxError(lib().gfxh_last_error().decode())
 
 
 def env_make_sky(w, h, sun_elevation=35.0, sun_azimuth=40.0, sun_radiance=400.0):

@@ -675,3 +675,79 @@ void gfxh_spatial_neighbor_deltas(float* out) {
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------- output chain
+// saveImage(float4 -> 8-bit) of common/common_host.cpp:2859-2897: tone map on the luminance, sRGB gamma, quantise.
+extern "C" void gfxh_tonemap_sdr(uint32_t width, uint32_t height, const float* rgba, const gfxh_sdr_config* cfg, uint32_t* out) {
+    for (uint32_t y = 0; y < height; ++y) {
+        const uint32_t sy = cfg->flipY ? (height - 1 - y) : y;
+        for (uint32_t x = 0; x < width; ++x) {
+            const float* src = rgba + 4 * (static_cast<size_t>(sy) * width + x);
+            float r = src[0], g = src[1], b = src[2], a = src[3];
+            if (cfg->alphaForOverride >= 0.0f) a = cfg->alphaForOverride;
+            if (cfg->applyToneMap) {
+                if (!(std::isfinite(r) && std::isfinite(g) && std::isfinite(b))) { r = 0.0f; g = 0.0f; b = 0.0f; }
+                const float lum = 0.2126729f * r + 0.7151522f * g + 0.0721750f * b;      // sRGB_calcLuminance
+                const float lumT = 1 - std::exp(-(cfg->brightnessScale * lum));           // simpleToneMap_s
+                const float s = lum > 0.0f ? lumT / lum : 0.0f;
+                r *= s; g *= s; b *= s;
+            }
+            if (cfg->apply_sRGB_gammaCorrection) {                                        // sRGB_gamma_s
+                auto gamma = [](float v) { return v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1 / 2.4f) - 0.055f; };
+                r = gamma(r); g = gamma(g); b = gamma(b);
+            }
+            auto q = [](float v) { return v > 0.0f ? std::min<uint32_t>(static_cast<uint32_t>(std::min(v * 255, 4.0e9f)), 255u) : 0u; };
+            out[static_cast<size_t>(y) * width + x] = q(r) | (q(g) << 8) | (q(b) << 16) | (q(a) << 24);
+        }
+    }
+}
+
+static bool has_ext(const char* path, const char* ext) {
+    const size_t n = std::strlen(path), m = std::strlen(ext);
+    return n >= m && std::strcmp(path + n - m, ext) == 0;
+}
+
+extern "C" int gfxh_save_image_sdr(const char* path, uint32_t width, uint32_t height, const float* rgba, const gfxh_sdr_config* cfg) {
+    std::vector<uint32_t> px(static_cast<size_t>(width) * height);
+    gfxh_tonemap_sdr(width, height, rgba, cfg, px.data());
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { g_hostError = std::string("cannot open ") + path; return 1; }
+    if (has_ext(path, ".ppm")) {
+        std::fprintf(f, "P6\n%u %u\n255\n", width, height);
+        for (uint32_t p : px) { const unsigned char c[3] = { static_cast<unsigned char>(p), static_cast<unsigned char>(p >> 8), static_cast<unsigned char>(p >> 16) }; std::fwrite(c, 1, 3, f); }
+    }
+    else if (has_ext(path, ".bmp")) {
+        const uint32_t rowBytes = (3 * width + 3) & ~3u, dataBytes = rowBytes * height;
+        unsigned char hdr[54] = { 'B', 'M' };
+        auto put32 = [&](int o, uint32_t v) { hdr[o] = v & 255; hdr[o + 1] = (v >> 8) & 255; hdr[o + 2] = (v >> 16) & 255; hdr[o + 3] = (v >> 24) & 255; };
+        put32(2, 54 + dataBytes); put32(10, 54); put32(14, 40); put32(18, width); put32(22, height);
+        hdr[26] = 1; hdr[28] = 24; put32(34, dataBytes);
+        std::fwrite(hdr, 1, 54, f);
+        std::vector<unsigned char> row(rowBytes, 0);
+        for (uint32_t y = 0; y < height; ++y) {                       // bottom-up, BGR
+            const uint32_t* src = px.data() + static_cast<size_t>(height - 1 - y) * width;
+            for (uint32_t x = 0; x < width; ++x) { row[3 * x] = (src[x] >> 16) & 255; row[3 * x + 1] = (src[x] >> 8) & 255; row[3 * x + 2] = src[x] & 255; }
+            std::fwrite(row.data(), 1, rowBytes, f);
+        }
+    }
+    else { std::fclose(f); g_hostError = "gfxh_save_image_sdr: .bmp or .ppm"; return 1; }
+    std::fclose(f);
+    return 0;
+}
+
+extern "C" int gfxh_save_image_hdr(const char* path, uint32_t width, uint32_t height, float brightnessScale, const float* rgba, int flipY) {
+    if (!has_ext(path, ".pfm")) { g_hostError = "gfxh_save_image_hdr: .pfm"; return 1; }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { g_hostError = std::string("cannot open ") + path; return 1; }
+    std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height);              // little endian, rows bottom to top
+    std::vector<float> row(3 * static_cast<size_t>(width));
+    for (uint32_t y = 0; y < height; ++y) {
+        const uint32_t top = height - 1 - y;                            // the image row this file row holds
+        const uint32_t sy = flipY ? (height - 1 - top) : top;
+        for (uint32_t x = 0; x < width; ++x)
+            for (int c = 0; c < 3; ++c) row[3 * x + c] = brightnessScale * rgba[4 * (static_cast<size_t>(sy) * width + x) + c];
+        std::fwrite(row.data(), sizeof(float), row.size(), f);
+    }
+    std::fclose(f);
+    return 0;
+}

@@ -211,6 +211,21 @@ uint64_t gfxh_nrc_network(gfxh_nrc* r);
 int gfxh_nrc_stats(gfxh_nrc* r, uint32_t* numTrainingData, uint32_t tileSize[2], uint32_t* numInferenceQueries);
 const char* gfxh_nrc_last_error(void);
 
+/* ---- output chain (common/common_host.cpp:2725-2922 saveImage / saveImageHDR) -------------------------------------
+ * rgba: host copy of a float4 accumulation buffer (gfx_read_device of the beauty buffer), row-major, top row first.
+ * SDR: optional tone map on the luminance (1 - exp(-brightnessScale * Y), chroma kept), optional sRGB gamma, 8 bits
+ * per channel as min(uint(v * 255), 255); written as 24-bit .bmp or binary .ppm by extension.  HDR: the fp32 values
+ * times brightnessScale as a .pfm (the reference writes the same numbers as an OpenEXR file through tinyexr). */
+typedef struct gfxh_sdr_config {
+    float alphaForOverride;              /* kept for layout parity with SDRImageSaverConfig (common_host.h:1520-1532); unused */
+    float brightnessScale;
+    uint32_t applyToneMap, apply_sRGB_gammaCorrection, flipY;
+} gfxh_sdr_config;
+int gfxh_save_image_sdr(const char* path, uint32_t width, uint32_t height, const float* rgba, const gfxh_sdr_config* cfg);
+int gfxh_save_image_hdr(const char* path, uint32_t width, uint32_t height, float brightnessScale, const float* rgba, int flipY);
+/* The 8-bit pixels gfxh_save_image_sdr would write (R | G << 8 | B << 16 | A << 24, common_host.cpp:2886-2890). */
+void gfxh_tonemap_sdr(uint32_t width, uint32_t height, const float* rgba, const gfxh_sdr_config* cfg, uint32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

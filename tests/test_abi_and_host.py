@@ -96,3 +96,40 @@ def test_street_scene_statistics(built_lib):
     osc = util.feed_oracle(s)
     w, cdf, integral = osc.lights_read(0)
     assert (w > 0).sum() == 24 + 12 and integral > 0
+
+
+def test_output_chain_tone_map_and_files(built_lib, tmp_path):
+    """saveImage's SDR conversion (common_host.cpp:2859-2897) against a numpy restatement, and the file writers."""
+    rng = np.random.default_rng(3)
+    w, h = 37, 19
+    img = (rng.random((h, w, 4)) ** 4 * 20).astype(np.float32)
+    img[0, 0, :3] = np.nan; img[1, 1, :3] = 0.0; img[2, 2, :3] = (np.inf, 1.0, 1.0)
+    cfg = api.sdr_config(brightness=0.7, tone_map=True, gamma=True, flip_y=True)
+    got = api.tonemap_sdr(img, w, h, cfg)
+    src = img[::-1].astype(np.float32).copy()
+    rgb = src[..., :3].copy()
+    bad = ~np.isfinite(rgb).all(axis=2)
+    rgb[bad] = 0
+    lum = (np.float32(0.2126729) * rgb[..., 0] + np.float32(0.7151522) * rgb[..., 1] + np.float32(0.0721750) * rgb[..., 2]).astype(np.float32)
+    lum_t = (1 - np.exp(-(np.float32(0.7) * lum))).astype(np.float32)
+    s = np.where(lum > 0, lum_t / np.where(lum > 0, lum, 1), 0).astype(np.float32)
+    rgb = rgb * s[..., None]
+    gamma = np.where(rgb <= 0.0031308, 12.92 * rgb, 1.055 * np.power(np.maximum(rgb, 0), 1 / 2.4) - 0.055)
+    q = np.minimum((np.maximum(gamma, 0) * 255).astype(np.uint32), 255)
+    ref = q[..., 0] | (q[..., 1] << 8) | (q[..., 2] << 16)
+    diff = np.abs(((got & 0xFFFFFF).astype(np.int64) >> np.array([0, 8, 16])[:, None, None] & 255) -
+                  ((ref.astype(np.int64) >> np.array([0, 8, 16])[:, None, None]) & 255))
+    assert diff.max() <= 1                                  # float32 vs float64 pow at a quantisation step
+    assert (got >> 24).min() >= 0
+    api.save_image_sdr(str(tmp_path / "a.bmp"), img, w, h, cfg)
+    api.save_image_sdr(str(tmp_path / "a.ppm"), img, w, h, cfg)
+    api.save_image_hdr(str(tmp_path / "a.pfm"), img, w, h, 2.0)
+    bmp = (tmp_path / "a.bmp").read_bytes()
+    assert bmp[:2] == b"BM" and len(bmp) == 54 + ((3 * w + 3) & ~3) * h
+    ppm = (tmp_path / "a.ppm").read_bytes()
+    assert ppm.startswith(b"P6\n37 19\n255\n") and len(ppm) == len(b"P6\n37 19\n255\n") + 3 * w * h
+    pfm = (tmp_path / "a.pfm").read_bytes()
+    head = b"PF\n37 19\n-1.0\n"
+    assert pfm.startswith(head)
+    data = np.frombuffer(pfm[len(head):], np.float32).reshape(h, w, 3)
+    assert np.array_equal(data[::-1][3:, 3:], (np.float32(2.0) * img[3:, 3:, :3]))      # finite region, bottom-up rows
