@@ -217,9 +217,12 @@ def mse_vs_reference(ctx, hs, renderer, cam, W, H, ref_spp):
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
     ref = (acc / ref_spp).view(n, 4)[:, :3].cpu()
+    one_ref_frame = view.double().view(n, 4)[:, :3].cpu()      # the last frame of the reference estimator, for scale
     ref_r.close()
     err = (test - ref) ** 2
+    err_plain = (one_ref_frame - ref) ** 2
     return {"mse": float(err.mean()), "rel_mse": float((err / (ref ** 2 + 1e-2)).mean()), "ref_spp": ref_spp,
+            "mse_of_one_reference_frame": float(err_plain.mean()), "rel_mse_of_one_reference_frame": float((err_plain / (ref ** 2 + 1e-2)).mean()),
             "ref_estimator": "RIS/NEE 32 candidates + visibility, no reuse, fp64 accumulation", "ref_seconds": round(seconds, 1),
             "note": "the metric names a 64k-spp reference: --mse-ref-spp 65536 (about 3 minutes on one MI355X)"}
 
