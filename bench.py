@@ -103,7 +103,7 @@ def main():
         renderer.render_frame(stream)
         if exchange is not None:
             exchange.exchange(renderer.params()[2])   # final reservoirs + RNG of the halo rows, from their owners
-            gather.all_gather()                       # float4 HDR bands -> full frame on every rank
+            gather.all_gather()                       # float4 HDR bands -> full frame on every rank (asynchronous, see BandGather)
 
     def barrier():
         torch.cuda.synchronize()
@@ -118,6 +118,8 @@ def main():
     t_start = time.perf_counter()
     for _ in range(args.steps):
         frame()
+    if gather is not None:
+        gather.finish()                               # the last frame's bands are in place on every rank
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:

@@ -40,7 +40,8 @@ class BandGather:
 
     Bands can differ by 8 rows, so every rank contributes a max-band-sized slab and the slabs are
     scattered back to their rows.  One collective per frame: W*H*16 bytes total (33 MB at 1080p),
-    4.15 MB per rank at 8 ranks -- far below one xGMI link's per-frame budget."""
+    4.15 MB per rank at 8 ranks.  The collective is asynchronous: nothing of the next frame depends on the other
+    ranks' pixels, so it overlaps that frame's rendering."""
 
     def __init__(self, beauty_view, width, height, world, rank, dist):
         import torch
@@ -55,10 +56,24 @@ class BandGather:
         self.recv = torch.zeros(world * self.max_rows * width * 4, dtype=torch.float32, device=device)
 
     def all_gather(self):
+        """Issue this frame's collective and return: it runs on the communicator's stream underneath the next
+        frame's kernels.  The received bands of the PREVIOUS call are put into place first (`finish`), so every
+        rank holds the complete frame one call later -- or right after `finish()`."""
+        self.finish()
         b, e = self.bands[self.rank]
         n = (e - b) * self.w * 4
         self.send[:n].copy_(self.beauty[b * self.w * 4:e * self.w * 4])
-        self.dist.all_gather_into_tensor(self.recv, self.send)
+        self.work = self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+        return self.work
+
+    def finish(self):
+        """Wait (stream-ordered on RCCL, blocking on gloo) for the outstanding collective and scatter the other
+        ranks' bands into the full-frame buffer.  Call once after the last frame."""
+        work = getattr(self, "work", None)
+        if work is None:
+            return self.beauty
+        work.wait()
+        self.work = None
         slab = self.max_rows * self.w * 4
         for r, (rb, re) in enumerate(self.bands):
             if r == self.rank:

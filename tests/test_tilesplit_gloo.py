@@ -68,6 +68,7 @@ def _worker(rank, world, port, out_dir):
     gather = tilesplit.BandGather(state["beauty"], W, H, world, rank, dist)
     cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
     last = _sequence(osc, pb, plan, cam, FRAMES, exchange, gather)
+    gather.finish()
     np.save(os.path.join(out_dir, f"beauty_{rank}.npy"), pb.beauty)
     np.save(os.path.join(out_dir, f"res_{rank}.npy"), pb.res[last])
     np.save(os.path.join(out_dir, f"band_{rank}.npy"), np.array([b, e]))
