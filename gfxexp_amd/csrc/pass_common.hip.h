@@ -90,6 +90,32 @@ GFX_DEV void queue_reserve(const bool (&want)[K], uint32_t* rayCount, uint32_t (
     }
     __syncthreads();                                      // qr is reused by the next call of this block
 }
+// Same idea for K different queues (one counter each): K threads take the K atomics side by side, two barriers.
+template <int K>
+GFX_DEV void queue_reserve_each(const bool (&want)[K], uint32_t* const (&counters)[K], uint32_t (&slot)[K]) {
+    __shared__ uint32_t qe[K + 16 * K];                   // [k] base of queue k for this block, then [wave][kind]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, numWaves = (blockDim.x + 63) >> 6;
+    unsigned long long mask[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        mask[k] = __ballot(want[k]);
+        if (lane == 0) qe[K + wave * K + k] = static_cast<uint32_t>(__popcll(mask[k]));
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        uint32_t total = 0;
+        for (int w = 0; w < numWaves; ++w) total += qe[K + w * K + threadIdx.x];
+        qe[threadIdx.x] = total ? atomicAdd(counters[threadIdx.x], total) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        uint32_t base = qe[k];
+        for (int w = 0; w < wave; ++w) base += qe[K + w * K + k];
+        slot[k] = want[k] ? base + static_cast<uint32_t>(__popcll(mask[k] & ((1ull << lane) - 1ull))) : GFX_INVALID_SLOT;
+    }
+    __syncthreads();                                      // qe is reused by the next call of this block
+}
 GFX_DEV void queue_write(uint32_t slot, f3 org, f3 dir, float tmin, float tmax, float4* rayOrg, float4* rayDir) {
     if (slot == GFX_INVALID_SLOT) return;
     rayOrg[slot] = make_float4(org.x, org.y, org.z, tmin);

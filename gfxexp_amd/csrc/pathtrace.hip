@@ -210,12 +210,18 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
 }
 
 GFX_DEV void push_vertex(const PtArgs& a, uint32_t pixel, f3 pos, const PtVertexOut& o) {
-    const uint32_t ns = queue_append(o.wantNee, pos, o.neeDir, 0.0f, o.neeTmax, a.neeOrg, a.neeDir, a.neeCount);
+    // the vertex's NEE (any-hit) ray and extension (closest-hit) ray: both queue heads in one block-level step
+    const bool want[2] = { o.wantNee, o.wantExt };
+    uint32_t* const counters[2] = { a.neeCount, a.extCountOut };
+    uint32_t slots[2];
+    queue_reserve_each<2>(want, counters, slots);
+    const uint32_t ns = slots[0], es = slots[1];
+    queue_write(ns, pos, o.neeDir, 0.0f, o.neeTmax, a.neeOrg, a.neeDir);
     if (o.wantNee) {
         a.neePending[ns] = make_float4(o.pending.x, o.pending.y, o.pending.z, bits2f(pixel));
         if (a.neeTrainIdx) a.neeTrainIdx[ns] = o.trainIdx;
     }
-    const uint32_t es = queue_append(o.wantExt, pos, o.extDir, 0.0f, 3.402823466e+38f, a.extOrgOut, a.extDirOut, a.extCountOut);
+    queue_write(es, pos, o.extDir, 0.0f, 3.402823466e+38f, a.extOrgOut, a.extDirOut);
     if (o.wantExt) a.extOwnerOut[es] = pixel;
 }
 
