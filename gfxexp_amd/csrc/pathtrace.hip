@@ -467,8 +467,11 @@ GFX_DEV f3 regir_sample_intensity(const LightSample& ls, f3 cellCenter, f3 halfC
 }
 
 // buildCellReservoirsAndTemporalReuse<TEMPORAL>, build_cell_reservoirs.cu:70-219: one thread per light slot
-template <bool TEMPORAL>
+// LDS_DIST: the instance-level distribution (probabilities, CDF, guide table; searched once per candidate)
+// staged in LDS like in k_initial_candidates, when it fits.
+template <bool TEMPORAL, bool LDS_DIST>
 __global__ __launch_bounds__(kPtBlock) void k_regir_build(PtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ldsDist[];
     const gfx_regir_params& g = a.g;
     const uint32_t numCells = g.gridDimension[0] * g.gridDimension[1] * g.gridDimension[2];
     const size_t numLightSlots = static_cast<size_t>(numCells) * kNumLightSlotsPerCell;
@@ -479,7 +482,20 @@ __global__ __launch_bounds__(kPtBlock) void k_regir_build(PtArgs a) {
     const uint32_t lastAccess = static_cast<const uint32_t*>(g.lastAccessFrameIndices)[cell];
     if (i == 0) *static_cast<uint32_t*>(g.numActiveCells[bufferIndex]) = 0;
     if (i % kNumLightSlotsPerCell == 0) static_cast<uint32_t*>(g.perCellNumAccesses)[cell] = 0;
-    if (a.f.frameIndex - lastAccess > 8) return;
+    if (a.f.frameIndex - lastAccess > 8) return;      // block-uniform: a cell owns 512 = 2 x kPtBlock consecutive slots
+    InstDist instDist = inst_dist_global(a.scene);
+    if (LDS_DIST) {
+        const uint32_t ni = a.scene.numInsts;
+        for (uint32_t k = threadIdx.x; k < ni; k += kPtBlock) { ldsDist[k] = instDist.probs[k]; ldsDist[ni + k] = instDist.cdf[k]; }
+        uint32_t* ldsGuide = reinterpret_cast<uint32_t*>(ldsDist + 2 * ni);
+        if (instDist.guide) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(instDist.guide);
+            for (uint32_t k = threadIdx.x; k < instDist.guideCells / 2; k += kPtBlock) ldsGuide[k] = src[k];
+            instDist.guide = reinterpret_cast<const uint16_t*>(ldsGuide);
+        }
+        __syncthreads();
+        instDist.probs = ldsDist; instDist.cdf = ldsDist + ni;
+    }
     const uint32_t gx = g.gridDimension[0], gy = g.gridDimension[1];
     const uint32_t iz = cell / (gx * gy), iy = (cell % (gx * gy)) / gx, ix = cell % gx;
     const f3 cs(g.gridCellSize[0], g.gridCellSize[1], g.gridCellSize[2]);
@@ -490,7 +506,6 @@ __global__ __launch_bounds__(kPtBlock) void k_regir_build(PtArgs a) {
     Pcg32 rng; rng.state = rngs[i];
     const EnvMap env = load_env(a.s);
     const bool envEnabled = env.present() && a.f.enableEnvLight;
-    const InstDist instDist = inst_dist_global(a.scene);
     float selectedTarget = 0.0f;
     Reservoir reservoir;
     reservoir.reset();
@@ -1154,8 +1169,14 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         const size_t numLightSlots = static_cast<size_t>(a.g.gridDimension[0]) * a.g.gridDimension[1] * a.g.gridDimension[2] * kNumLightSlotsPerCell;
         ScopedKernelTimer timer(ctx, stream, "regir_build_cells");
         const dim3 grid(static_cast<uint32_t>((numLightSlots + kPtBlock - 1) / kPtBlock));
-        if (pass == GFX_PT_REGIR_BUILD_CELL_RESERVOIRS) hipLaunchKernelGGL(k_regir_build<false>, grid, dim3(kPtBlock), 0, stream, a);
-        else hipLaunchKernelGGL(k_regir_build<true>, grid, dim3(kPtBlock), 0, stream, a);
+        const size_t distBytes = 8ull * a.scene.numInsts + 2ull * a.scene.lightInstGuideCells;
+        const bool temporal = pass != GFX_PT_REGIR_BUILD_CELL_RESERVOIRS;
+        if (distBytes <= 60 * 1024) {
+            if (temporal) hipLaunchKernelGGL((k_regir_build<true, true>), grid, dim3(kPtBlock), distBytes, stream, a);
+            else hipLaunchKernelGGL((k_regir_build<false, true>), grid, dim3(kPtBlock), distBytes, stream, a);
+        }
+        else if (temporal) hipLaunchKernelGGL((k_regir_build<true, false>), grid, dim3(kPtBlock), 0, stream, a);
+        else hipLaunchKernelGGL((k_regir_build<false, false>), grid, dim3(kPtBlock), 0, stream, a);
         GFX_HIP(hipGetLastError());
         return;
     }
