@@ -2,6 +2,8 @@
 emitter importance over ~12 decades, runs of non-emissive instances, groups listing coplanar geometry
 out of slot order (exact closest-hit ties), emissive geometry first / middle / last in a group.
 All buffers bit for bit against the oracle after every pass."""
+import os
+
 import numpy as np
 import pytest
 
@@ -81,4 +83,54 @@ def test_sheared_and_mirrored_instances(built_lib):
     cam = api.make_camera(W, H, pos=(1.5, 6.0, 18.0), pitch=12.0, yaw=186.0)
     diffs = run_sequence_both(_odd_transform_scene(), W, H, frames=2, renderer=api.RENDERER_UNBIASED, camera=cam)
     diffs += run_pt_both(_odd_transform_scene(), W, H, frames=1, max_len=5, camera=cam)
+    assert not diffs, "\n".join(diffs[:12])
+
+
+def _all_bsdf_scene(seed=21):
+    """Lambert, DiffuseAndSpecular and SimplePBR receivers (rough, mirror-like, metallic) under two lights: every
+    BSDF type's evaluate / sampleThroughput / evaluatePDF / albedo estimate runs on the GPU."""
+    rng = np.random.default_rng(seed)
+    s = api.HostScene()
+
+    def material(kind, a, b, smoothness=0.0):
+        m = api.GfxMaterial()
+        m.bsdfType = kind
+        m.a[:] = a
+        m.b[:] = b
+        m.smoothness = smoothness
+        return s.add_material(m)
+
+    mats = [material(0, (0.7, 0.6, 0.5), (0, 0, 0)),                        # Lambert
+            material(1, (0.5, 0.1, 0.1), (0.04, 0.04, 0.04), 0.3),          # DiffuseAndSpecular, rough
+            material(1, (0.05, 0.05, 0.05), (0.9, 0.8, 0.3), 0.995),        # ... almost a mirror (smoothness clamps at 0.999)
+            material(2, (0.8, 0.8, 0.9), (1.0, 0.4, 0.0)),                  # SimplePBR: (occlusion, roughness, metallic) dielectric
+            material(2, (0.95, 0.7, 0.3), (1.0, 0.15, 1.0)),                # SimplePBR metal, smooth
+            material(2, (0.3, 0.9, 0.4), (1.0, 1.0, 0.5))]                  # SimplePBR, fully rough, half metallic
+    obj = os.path.join(util.ASSETS, "stanford_bunny_309_faces.obj")
+    ground = np.zeros(4, api.VERTEX_DTYPE)
+    ground["position"] = [(-15, 0, -15), (15, 0, -15), (15, 0, 15), (-15, 0, 15)]
+    ground["normal"] = (0, 1, 0); ground["texCoord0Dir"] = (1, 0, 0); ground["texCoord"] = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    s.add_instance(s.add_group([s.add_geom(ground, [(0, 2, 1), (0, 3, 2)], mats[0])]), api.make_transform())
+    bunny = s.load_obj(obj)                                                 # its own material (DiffuseAndSpecular)
+    s.add_instance(bunny, api.make_transform(scale=0.08, pos=(-5.0, 0.0, 0.0)))
+    # slabs of every material, tilted at random
+    slab = np.zeros(4, api.VERTEX_DTYPE)
+    slab["position"] = [(-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1)]
+    slab["normal"] = (0, 1, 0); slab["texCoord0Dir"] = (1, 0, 0); slab["texCoord"] = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    for k, m in enumerate(mats):
+        g = s.add_group([s.add_geom(slab, [(0, 2, 1), (0, 3, 2)], m)])
+        for j in range(2):
+            s.add_instance(g, api.make_transform(scale=float(rng.uniform(1.0, 2.2)), pitch=float(rng.uniform(-50, 50)), roll=float(rng.uniform(-40, 40)),
+                                                 yaw=float(rng.uniform(0, 360)), pos=(-6.0 + 2.6 * k + 0.8 * j, float(rng.uniform(0.6, 3.0)), float(rng.uniform(-4, 4)))))
+    s.add_instance(s.add_rectangle(1.5, 1.5, (60, 55, 50)), api.make_transform(pos=(0.0, 9.0, 1.0)))
+    s.add_instance(s.add_rectangle(1.0, 2.0, (5, 15, 40)), api.make_transform(pitch=-70.0, pos=(5.0, 5.0, 7.0)))
+    return s
+
+
+def test_every_bsdf_type(built_lib):
+    cam = api.make_camera(W, H, pos=(0.5, 6.0, 17.0), pitch=14.0, yaw=182.0)
+    diffs = run_sequence_both(_all_bsdf_scene(), W, H, frames=2, renderer=api.RENDERER_UNBIASED, camera=cam)
+    diffs += run_pt_both(_all_bsdf_scene(), W, H, frames=2, max_len=7, camera=cam)
+    diffs += run_regir_both(_all_bsdf_scene(), W, H, frames=2, max_len=4, camera=cam)
+    diffs += run_nrc_both(_all_bsdf_scene(), W, H, frames=1, max_len=5, camera=cam)
     assert not diffs, "\n".join(diffs[:12])
