@@ -30,7 +30,7 @@ def write_png(path, px, width, height):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="street")
-    ap.add_argument("--renderer", type=int, default=api.RENDERER_BIASED)
+    ap.add_argument("--renderer", type=int, default=api.RENDERER_BIASED, help="0-5 = gfxh_renderer, 6 = NRC path tracer")
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--height", type=int, default=540)
@@ -46,12 +46,21 @@ def main():
     else:
         scenes.bunny_scene().upload(ctx)
         cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
-    cfg = api.RestirRenderer.default_config(W, H, args.renderer)
-    cfg.camera = cam
-    cfg.enableAccumulation = 1
-    r = api.RestirRenderer(ctx, cfg)
-    for _ in range(args.frames):
-        r.render_frame()
+    if args.renderer == 6:     # neural radiance cache: --warm frames of training without accumulation, then accumulate
+        hs_bounds = (scenes.bench_street() if args.scene == "street" else scenes.bunny_scene()).bounds()
+        cfg = api.NrcRenderer.default_config(W, H, hs_bounds)
+        cfg.camera = cam
+        cfg.enableAccumulation = 1
+        r = api.NrcRenderer(ctx, cfg)
+        losses = [r.render_frame(want_loss=(k % 32 == 31)) for k in range(args.frames)]
+        print({"loss_every_32_frames": [round(x, 5) for x in losses if x is not None]})
+    else:
+        cfg = api.RestirRenderer.default_config(W, H, args.renderer)
+        cfg.camera = cam
+        cfg.enableAccumulation = 1
+        r = api.RestirRenderer(ctx, cfg)
+        for _ in range(args.frames):
+            r.render_frame()
     torch.cuda.synchronize()
     img = ctx.read_device(r.beauty_ptr(), W * H * 16).view(np.float32).reshape(H, W, 4)
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
