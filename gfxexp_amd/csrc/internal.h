@@ -105,6 +105,7 @@ struct Context {
     bool transformsDirty = false;
     std::vector<uint32_t> movedInsts;
     bool emitterRecsDirty = false;
+    bool instDistValid = false;      // the instance-level distribution on the device matches the current transforms
     uint32_t lightPoolSize = 0;
     uint32_t lightInstDistOffset = 0;
     DevBuf dLightInstIntegral;       // float[4]; [0] = integral of the instance-level distribution, [1..2] guide header

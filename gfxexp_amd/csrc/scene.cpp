@@ -112,6 +112,7 @@ void transforms_upload(Context& ctx, hipStream_t stream) {
     ctx.movedInsts.clear();
     ctx.transformsDirty = false;
     ctx.emitterRecsDirty = true;
+    ctx.instDistValid = false;
 }
 
 template <typename T>
@@ -210,7 +211,7 @@ void scene_upload(Context& ctx, hipStream_t stream) {
     upload(ctx.dFlatGeoms, ctx.hFlatGeoms, stream);
     upload(ctx.dSubset[0], ctx.hSubset[0], stream);
     upload(ctx.dSubset[1], ctx.hSubset[1], stream);
-    ctx.transformsDirty = false; ctx.movedInsts.clear(); ctx.emitterRecsDirty = false;
+    ctx.transformsDirty = false; ctx.movedInsts.clear(); ctx.emitterRecsDirty = false; ctx.instDistValid = false;
     upload(ctx.dLightRefs, ctx.hLightRefs, stream);
     ctx.dEmitterRecs.reserve(std::max<size_t>(sizeof(EmitterRec) * ctx.numEmitterRecs, 16));
     ctx.dLightW.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
