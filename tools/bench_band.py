@@ -1,0 +1,48 @@
+"""Frame time of ONE rank's row band on one GPU (no communication): what the halo recompute costs when the
+1920x1080 bench frame is split N ways (tilesplit.band_rows), as a bound on strong scaling.  The halo rows' temporal
+state is not refreshed here (no neighbour rank), which does not change the amount of work.  One JSON line."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gfxexp_amd import api, scenes, tilesplit  # noqa: E402
+
+
+def band_ms(ctx, cam, W, H, band, steps=30):
+    import torch
+    cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
+    cfg.camera = cam
+    cfg.rowBegin, cfg.rowEnd = band
+    r = api.RestirRenderer(ctx, cfg)
+    for _ in range(5):
+        r.render_frame()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.render_frame()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps * 1e3
+    r.close()
+    return dt
+
+
+def main():
+    W, H = 1920, 1080
+    ctx = api.Context(0)
+    scenes.bench_street().upload(ctx)
+    cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
+    full = band_ms(ctx, cam, W, H, (0, 0))
+    out = {"workload": "bench frame, one rank's band rendered alone on one GPU (compute only)", "full_frame_ms": round(full, 4), "bands": {}}
+    for n in (2, 4, 8):
+        bands = tilesplit.band_rows(H, n)
+        ms = [band_ms(ctx, cam, W, H, b) for b in (bands[0], bands[n // 2])]     # an edge band and an interior band
+        worst = max(ms)
+        out["bands"][str(n)] = {"edge_band_ms": round(ms[0], 4), "interior_band_ms": round(ms[1], 4),
+                                "compute_bound_speedup": round(full / worst, 2), "compute_bound_efficiency": round(full / worst / n, 3)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
