@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 #include "../../include/gfxexp.h"
+#include "emitter_spans.h"
 
 namespace gfx {
 
@@ -106,6 +107,12 @@ struct DevScene {
     uint32_t lightInstGuideCells;
     uint32_t lightInstDistOffset;   // level-0 distribution
     uint32_t numInsts;
+    // the three levels flattened into one interval table over ul (emitter_spans.h), one span per emitter record
+    const EmitterSpan* spans;
+    const SpanGuide* spanGuide;
+    const uint32_t* spanHeader;     // device uint32[4]: [0] table usable (verified by the build), [1] records checked
+    uint32_t numSpans;
+    uint32_t spanGuideCells;
 };
 
 // ---------------------------------------------------------------- BVH8 in HBM

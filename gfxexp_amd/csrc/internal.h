@@ -112,6 +112,10 @@ struct Context {
     DevBuf dLightInstGuide;          // uint16[lightInstGuideCells]
     uint32_t lightInstGuideCells = 0;
     bool lightsStaticBuilt = false;
+    // emitter interval table (emitter_spans.h): spans[numEmitterRecs], guide[spanGuideCells], header uint32[4],
+    // instance interval starts uint32[numInsts + 1] (build scratch)
+    DevBuf dSpans, dSpanGuide, dSpanHeader, dSpanInstBegin;
+    uint32_t spanGuideCells = 0;
     DevScene devScene() const;
     // accels
     std::vector<Accel*> accels;

@@ -9,6 +9,7 @@
 // own CDFs are only defined up to fp32 rounding; fixing the serial order makes the sampled
 // triangle indices reproducible.  One thread scans one distribution; the scene has many small
 // distributions (one per emitter geomInst / instance), so the work is still parallel.
+#include <cstdlib>
 #include "internal.h"
 #include "shading.hip.h"
 
@@ -202,6 +203,129 @@ __global__ __launch_bounds__(256) void k_inst_guide(uint32_t numInsts, uint32_t 
     guide[t] = static_cast<uint16_t>(idx);
 }
 
+// ---------------------------------------------------------------- emitter interval table (emitter_spans.h)
+// 1. k_span_inst_begin: per instance i, the smallest ul whose instance search returns an index >= i
+//    (pure arithmetic bisection over the bit patterns of ul).  Instance i is selected on [begin_i, begin_{i+1}).
+// 2. k_span_records: per emitter record (instance i, geometry instance k, primitive t), the smallest ul of
+//    that range whose levels 2 and 3 reach (k, t) or further; the last record of a geometry instance also
+//    finds where the level-2 search moves past k.  Records behind an early out (probability zero at level
+//    1 or 2) get an empty interval.
+// 3. k_span_finish: end_e = begin_{e+1} inside a geometry instance; checks that the intervals ascend and,
+//    with the reference's own three searches (light_locate_3level), that both ends of every interval select
+//    exactly that record and the values next to them do not.  Any failure withdraws the table (header[0] = 0)
+//    and sample_light runs the three searches instead.
+// 4. k_span_guide: guide table over ul.
+__global__ void k_span_init(const float* __restrict__ instHeader, uint32_t* __restrict__ spanHeader) {
+    const float integral = instHeader[0];
+    spanHeader[0] = (integral > 0.0f && integral < INFINITY) ? 1u : 0u;
+    spanHeader[1] = 0u;
+}
+
+__global__ void k_span_inst_begin(uint32_t numInsts, const float* __restrict__ cdf1, const float* __restrict__ header,
+                                  uint32_t* __restrict__ instBegin) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > numInsts) return;
+    if (i == numInsts) { instBegin[i] = kSpanBitsEnd; return; }
+    SpanInstPred pred; pred.integral = header[0]; pred.i = i; pred.cdfAtI = cdf1[i];
+    instBegin[i] = span_bisect(0u, kSpanBitsEnd, pred);
+}
+
+__global__ void k_span_records(DevScene sc, uint32_t numInsts, const uint32_t* __restrict__ instBegin,
+                               EmitterSpan* __restrict__ spans, uint32_t* __restrict__ spanHeader) {
+    const uint32_t ii = blockIdx.x;
+    if (ii >= numInsts) return;
+    const DevInstance* inst = sc.insts + ii;
+    if (inst->distOffset == 0xFFFFFFFFu) return;
+    const float* cdf1 = sc.lightCDF + sc.lightInstDistOffset;
+    SpanRecordKey key;
+    key.integral1 = *sc.lightInstIntegral;
+    key.lo1 = cdf1[ii];
+    key.hi1 = ii + 1 < numInsts ? cdf1[ii + 1] : key.integral1;
+    key.integral2 = inst->distIntegral;
+    key.n2 = inst->numGeomInsts;
+    const float instProb = sc.lightProbs[sc.lightInstDistOffset + ii];
+    const uint32_t rangeLo = instBegin[ii], rangeHi = instBegin[ii + 1];
+    bool monotone = key.lo1 <= key.hi1;
+    for (uint32_t k = 0; k < key.n2; ++k) {
+        const LightGeomRef ref = sc.lightGeomRefs[inst->distOffset + k];
+        if (ref.recBase == 0xFFFFFFFFu) continue;
+        key.k = k;
+        key.lo2 = sc.lightCDF[inst->distOffset + k];
+        key.hi2 = k + 1 < key.n2 ? sc.lightCDF[inst->distOffset + k + 1] : key.integral2;
+        key.integral3 = ref.distIntegral;
+        monotone = monotone && key.lo2 <= key.hi2;
+        const float geomProb = sc.lightProbs[inst->distOffset + k];
+        const bool earlyOut = instProb == 0.0f || geomProb == 0.0f;
+        for (uint32_t t = threadIdx.x; t < ref.distCount; t += blockDim.x) {
+            key.t = t;
+            key.cdf3AtT = sc.lightCDF[ref.distOffset + t];
+            if (t + 1 < ref.distCount) monotone = monotone && key.cdf3AtT <= sc.lightCDF[ref.distOffset + t + 1];
+            uint32_t b, e;
+            span_record_interval(key, rangeLo, rangeHi, earlyOut, t + 1 == ref.distCount, b, e);
+            const EmitterRec* rec = sc.emitterRecs + ref.recBase + t;
+            EmitterSpan s;
+            s.begin = span_float(b);
+            s.end = span_float(e);
+            // lightProb = 1; lightProb *= instProb; *= geomInstProb; *= primProb; density = lightProb * (2 / |ng|)
+            s.density = ((instProb * geomProb) * rec->primProb) * rec->twoOverLenNg;
+            s.instSlot = ii;
+            *reinterpret_cast<SpanWords*>(spans + ref.recBase + t) = __builtin_bit_cast(SpanWords, s);
+        }
+    }
+    if (!monotone) atomicAnd(spanHeader, 0u);
+}
+
+__global__ void k_span_finish(DevScene sc, EmitterSpan* __restrict__ spans, uint32_t* __restrict__ spanHeader) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= sc.numSpans) return;
+    EmitterSpan s = spans[e];
+    const uint32_t nextBegin = e + 1 < sc.numSpans ? span_bits(spans[e + 1].begin) : kSpanBitsEnd;
+    if (span_bits(s.end) == kSpanPending) s.end = span_float(nextBegin);
+    const uint32_t b = span_bits(s.begin), en = span_bits(s.end);
+    bool ok = b <= en && en <= nextBegin && en <= kSpanBitsEnd;
+    // the reference's own searches at and next to both ends
+    const InstDist dist = inst_dist_global_unguided(sc);
+    auto selects = [&](uint32_t ulBits) {
+        uint32_t rec, instSlot; float partial;
+        return light_locate_3level(sc, dist, span_float(ulBits), rec, instSlot, partial) && rec == e;
+    };
+    if (b < en) {
+        ok = ok && selects(b) && selects(en - 1u);
+        if (b > 0u) ok = ok && !selects(b - 1u);
+        if (en < kSpanBitsEnd) ok = ok && !selects(en);
+    }
+    else if (b < kSpanBitsEnd) ok = ok && !selects(b);
+    spans[e].end = s.end;   // only this thread writes spans[e].end; neighbours read spans[e].begin
+    if (!ok) atomicAnd(spanHeader, 0u);
+    else atomicAdd(spanHeader + 1, 1u);
+}
+
+__global__ void k_span_guide(const EmitterSpan* __restrict__ spans, uint32_t numSpans, SpanGuide* __restrict__ guide, uint32_t cells) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cells) return;
+    guide[c] = span_guide_entry(spans, numSpans, cells, c);
+}
+
+static void span_table_build(Context& ctx, hipStream_t stream) {
+    const uint32_t ni = static_cast<uint32_t>(ctx.insts.size());
+    const uint32_t ne = ctx.numEmitterRecs;
+    uint32_t* header = ctx.dSpanHeader.as<uint32_t>();
+    GFX_HIP(hipMemsetAsync(header, 0, 16, stream));
+    static int disabled = -1;
+    if (disabled < 0) { const char* e = getenv("GFX_LIGHT_TABLE"); disabled = (e && e[0] == '0') ? 1 : 0; }
+    if (!ni || !ne || disabled) return;
+    // usable until a check fails; the integral must be a positive finite number (k_scan_inst_dist's "usable" covers that)
+    hipLaunchKernelGGL(k_span_init, dim3(1), dim3(1), 0, stream, ctx.dLightInstIntegral.as<float>(), header);
+    hipLaunchKernelGGL(k_span_inst_begin, dim3((ni + 1 + 255) / 256), dim3(256), 0, stream, ni,
+                       ctx.dLightCDF.as<float>() + ctx.lightInstDistOffset, ctx.dLightInstIntegral.as<float>(), ctx.dSpanInstBegin.as<uint32_t>());
+    hipLaunchKernelGGL(k_span_records, dim3(ni), dim3(64), 0, stream, ctx.devScene(), ni, ctx.dSpanInstBegin.as<uint32_t>(),
+                       ctx.dSpans.as<EmitterSpan>(), header);
+    hipLaunchKernelGGL(k_span_finish, dim3((ne + 255) / 256), dim3(256), 0, stream, ctx.devScene(), ctx.dSpans.as<EmitterSpan>(), header);
+    hipLaunchKernelGGL(k_span_guide, dim3((ctx.spanGuideCells + 255) / 256), dim3(256), 0, stream, ctx.dSpans.as<EmitterSpan>(), ne,
+                       ctx.dSpanGuide.as<SpanGuide>(), ctx.spanGuideCells);
+    GFX_HIP(hipGetLastError());
+}
+
 void lights_build_static(Context& ctx, hipStream_t stream) {
     scene_upload(ctx, stream);
     const uint32_t ng = static_cast<uint32_t>(ctx.geoms.size());
@@ -261,6 +385,7 @@ void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t /*bufferI
         GFX_HIP(hipGetLastError());
     }
     else GFX_HIP(hipMemsetAsync(dIntegral, 0, 4 * sizeof(float), stream));
+    span_table_build(ctx, stream);
 }
 
 } // namespace gfx

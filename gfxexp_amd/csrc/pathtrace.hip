@@ -157,7 +157,6 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
     }
     else {
         if (!active) return;
-        const InstDist instDist = inst_dist_global(a.scene);
         float ul = rng.uniform();
         bool selectEnv = false;
         float probCurType = 1.0f;
@@ -171,7 +170,7 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
         float areaPDensity;
         const float u0 = rng.uniform();
         const float u1 = rng.uniform();
-        sample_light(a.scene, instDist, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, selectEnv, u0, u1, ls, areaPDensity);
+        sample_light(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, selectEnv, u0, u1, ls, areaPDensity);
         areaPDensity *= probCurType;
         const ShadowRay sr = shadow_ray(pos, ls);
         float misWeight;
@@ -467,11 +466,8 @@ GFX_DEV f3 regir_sample_intensity(const LightSample& ls, f3 cellCenter, f3 halfC
 }
 
 // buildCellReservoirsAndTemporalReuse<TEMPORAL>, build_cell_reservoirs.cu:70-219: one thread per light slot
-// LDS_DIST: the instance-level distribution (probabilities, CDF, guide table; searched once per candidate)
-// staged in LDS like in k_initial_candidates, when it fits.
-template <bool TEMPORAL, bool LDS_DIST>
+template <bool TEMPORAL>
 __global__ __launch_bounds__(kPtBlock) void k_regir_build(PtArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float ldsDist[];
     const gfx_regir_params& g = a.g;
     const uint32_t numCells = g.gridDimension[0] * g.gridDimension[1] * g.gridDimension[2];
     const size_t numLightSlots = static_cast<size_t>(numCells) * kNumLightSlotsPerCell;
@@ -483,19 +479,6 @@ __global__ __launch_bounds__(kPtBlock) void k_regir_build(PtArgs a) {
     if (i == 0) *static_cast<uint32_t*>(g.numActiveCells[bufferIndex]) = 0;
     if (i % kNumLightSlotsPerCell == 0) static_cast<uint32_t*>(g.perCellNumAccesses)[cell] = 0;
     if (a.f.frameIndex - lastAccess > 8) return;      // block-uniform: a cell owns 512 = 2 x kPtBlock consecutive slots
-    InstDist instDist = inst_dist_global(a.scene);
-    if (LDS_DIST) {
-        const uint32_t ni = a.scene.numInsts;
-        for (uint32_t k = threadIdx.x; k < ni; k += kPtBlock) { ldsDist[k] = instDist.probs[k]; ldsDist[ni + k] = instDist.cdf[k]; }
-        uint32_t* ldsGuide = reinterpret_cast<uint32_t*>(ldsDist + 2 * ni);
-        if (instDist.guide) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(instDist.guide);
-            for (uint32_t k = threadIdx.x; k < instDist.guideCells / 2; k += kPtBlock) ldsGuide[k] = src[k];
-            instDist.guide = reinterpret_cast<const uint16_t*>(ldsGuide);
-        }
-        __syncthreads();
-        instDist.probs = ldsDist; instDist.cdf = ldsDist + ni;
-    }
     const uint32_t gx = g.gridDimension[0], gy = g.gridDimension[1];
     const uint32_t iz = cell / (gx * gy), iy = (cell % (gx * gy)) / gx, ix = cell % gx;
     const f3 cs(g.gridCellSize[0], g.gridCellSize[1], g.gridCellSize[2]);
@@ -530,7 +513,7 @@ __global__ __launch_bounds__(kPtBlock) void k_regir_build(PtArgs a) {
         float pd;
         const float u0 = rng.uniform();
         const float u1 = rng.uniform();
-        sample_light(a.scene, instDist, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
+        sample_light(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
         const f3 cont = regir_sample_intensity(ls, cellCenter, halfCellSize, minSquaredDistance);
         pd *= probCurType;
         const float target = target_weight(cont);
@@ -1169,14 +1152,9 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         const size_t numLightSlots = static_cast<size_t>(a.g.gridDimension[0]) * a.g.gridDimension[1] * a.g.gridDimension[2] * kNumLightSlotsPerCell;
         ScopedKernelTimer timer(ctx, stream, "regir_build_cells");
         const dim3 grid(static_cast<uint32_t>((numLightSlots + kPtBlock - 1) / kPtBlock));
-        const size_t distBytes = 8ull * a.scene.numInsts + 2ull * a.scene.lightInstGuideCells;
         const bool temporal = pass != GFX_PT_REGIR_BUILD_CELL_RESERVOIRS;
-        if (distBytes <= 60 * 1024) {
-            if (temporal) hipLaunchKernelGGL((k_regir_build<true, true>), grid, dim3(kPtBlock), distBytes, stream, a);
-            else hipLaunchKernelGGL((k_regir_build<false, true>), grid, dim3(kPtBlock), distBytes, stream, a);
-        }
-        else if (temporal) hipLaunchKernelGGL((k_regir_build<true, false>), grid, dim3(kPtBlock), 0, stream, a);
-        else hipLaunchKernelGGL((k_regir_build<false, false>), grid, dim3(kPtBlock), 0, stream, a);
+        if (temporal) hipLaunchKernelGGL(k_regir_build<true>, grid, dim3(kPtBlock), 0, stream, a);
+        else hipLaunchKernelGGL(k_regir_build<false>, grid, dim3(kPtBlock), 0, stream, a);
         GFX_HIP(hipGetLastError());
         return;
     }

@@ -162,25 +162,9 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
 
 // ---------------------------------------------------------------- INITIAL (+ TEMPORAL)
 // candidate loop + visibility-ray emission: optix_restir_di_kernels.cu:57-133
-// The instance-level CDF (searched 32 times per pixel, log2(numInsts) dependent loads each) is
-// staged in LDS once per block when it fits (LDS_DIST); larger scenes search it in global memory.
-template <bool LDS_DIST>
+// The light of a candidate comes out of the emitter interval table (emitter_spans.h): one guided search
+// instead of the reference's three nested ones, identical result.
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_initial_candidates(RestirArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float ldsDist[];   // probs | CDF | guide table of the instance level
-    InstDist instDist = inst_dist_global(a.scene);
-    if (LDS_DIST) {
-        // probs[ni] | CDF[ni] | guide[cells] (uint16)
-        const uint32_t ni = a.scene.numInsts;
-        for (uint32_t i = threadIdx.x; i < ni; i += kBlock) { ldsDist[i] = instDist.probs[i]; ldsDist[ni + i] = instDist.cdf[i]; }
-        uint32_t* ldsGuide = reinterpret_cast<uint32_t*>(ldsDist + 2 * ni);
-        if (instDist.guide) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(instDist.guide);
-            for (uint32_t i = threadIdx.x; i < instDist.guideCells / 2; i += kBlock) ldsGuide[i] = src[i];
-            instDist.guide = reinterpret_cast<const uint16_t*>(ldsGuide);
-        }
-        __syncthreads();
-        instDist.probs = ldsDist; instDist.cdf = ldsDist + ni;
-    }
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     const uint32_t bufIdx = a.f.bufferIndex;
@@ -223,7 +207,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             float pd;
             const float u0 = rng.uniform();
             const float u1 = rng.uniform();
-            sample_light(a.scene, instDist, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
+            sample_light(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
             const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
             pd *= probCurType;
             const float target = target_weight(cont);
@@ -716,10 +700,8 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         {
             const size_t numPx = a.pixelEnd - a.pixelBegin;
             const uint32_t grid = static_cast<uint32_t>((numPx + kBlock - 1) / kBlock);
-            const size_t ldsBytes = 8ull * a.scene.numInsts + 2ull * a.scene.lightInstGuideCells;
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
-            if (ldsBytes <= 64 * 1024) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), ldsBytes, stream, a);
-            else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(k_initial_candidates, dim3(grid), dim3(kBlock), 0, stream, a);
             GFX_HIP(hipGetLastError());
         }
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void k_light_presample(RestirArgs a) {
     const float ul = rng.uniform();
     const float u0 = rng.uniform();
     const float u1 = rng.uniform();
-    sample_light(a.scene, inst_dist_global(a.scene), env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
+    sample_light(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
     pd *= probCurType;
     rngs[i] = rng.state;
     float4* q = static_cast<float4*>(a.s.preSampledLights) + 3ull * i;

@@ -12,7 +12,7 @@ Context::~Context() {
     DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dSubset[0], &dSubset[1], &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs,
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
-                      &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide,
+                      &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide, &dSpans, &dSpanGuide, &dSpanHeader, &dSpanInstBegin,
                       &dTraceDiag, &bCosts, &bDec, &bFlatIdx, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
                       &rearchSlots, &nrcState, &neeTrainIdx };
     for (NrcNet* net : nrcNets) if (net) nrc_destroy(net);
@@ -36,6 +36,11 @@ DevScene Context::devScene() const {
     s.lightInstIntegral = dLightInstIntegral.as<float>();
     s.lightInstGuide = dLightInstGuide.as<uint16_t>();
     s.lightInstGuideCells = lightInstGuideCells;
+    s.spans = dSpans.as<EmitterSpan>();
+    s.spanGuide = dSpanGuide.as<SpanGuide>();
+    s.spanHeader = dSpanHeader.as<uint32_t>();
+    s.numSpans = numEmitterRecs;
+    s.spanGuideCells = spanGuideCells;
     s.lightInstDistOffset = lightInstDistOffset;
     s.numInsts = static_cast<uint32_t>(insts.size());
     return s;
@@ -201,6 +206,16 @@ void scene_upload(Context& ctx, hipStream_t stream) {
         ctx.dLightInstGuide.reserve(sizeof(uint16_t) * cells);
     }
     GFX_HIP(hipMemsetAsync(ctx.dLightInstIntegral.p, 0, 16, stream));
+    {   // emitter interval table: about two guide cells per record (power of two: ul * cells is exact)
+        uint32_t cells = 256;
+        while (cells < 2u * ctx.numEmitterRecs && cells < (1u << 22)) cells *= 2;
+        ctx.spanGuideCells = cells;
+        ctx.dSpans.reserve(std::max<size_t>(sizeof(EmitterSpan) * ctx.numEmitterRecs, 16));
+        ctx.dSpanGuide.reserve(sizeof(SpanGuide) * cells);
+        ctx.dSpanHeader.reserve(16);
+        ctx.dSpanInstBegin.reserve(sizeof(uint32_t) * (ctx.insts.size() + 1));
+        GFX_HIP(hipMemsetAsync(ctx.dSpanHeader.p, 0, 16, stream));
+    }
 
     upload(ctx.dMaterials, ctx.materials, stream);
     upload(ctx.dGeomInsts, ctx.hGeomInsts, stream);

@@ -443,9 +443,7 @@ GFX_DEV m33 load_m33_rows(const float* __restrict__ p) {   // 3 rows padded to f
     return m;
 }
 
-// sampleLight<false>.  Returns the area density; sample left untouched past an early out exactly
-// like the reference (the caller starts from a default-constructed LightSample).
-// instDist: the instance-level distribution (level 0), usually an LDS copy.
+// the instance-level distribution (level 0) in global memory
 GFX_DEV InstDist inst_dist_global(const DevScene& sc) {
     InstDist d;
     d.probs = sc.lightProbs + sc.lightInstDistOffset;
@@ -457,7 +455,46 @@ GFX_DEV InstDist inst_dist_global(const DevScene& sc) {
     return d;
 }
 
-GFX_DEV void sample_light(const DevScene& sc, const InstDist& instDist,
+// the same without the guide table: the plain binary search of the reference at every level
+GFX_DEV InstDist inst_dist_global_unguided(const DevScene& sc) {
+    InstDist d = inst_dist_global(sc);
+    d.guide = nullptr;
+    return d;
+}
+
+// The reference's three nested searches (restir_di_shared.h:366-415): which emitter record does ul select?
+// Returns false on the two early outs (an instance or geometry instance of probability zero).
+// partialProb = (1 * instProb) * geomInstProb.  This is the definition the interval table is built from
+// and verified against (lights.hip); sample_light only runs it when the build withdrew the table.
+GFX_DEV bool light_locate_3level(const DevScene& sc, const InstDist& instDist, float ul,
+                                 uint32_t& recIndex, uint32_t& instSlot, float& partialProb) {
+    float lightProb = 1.0f;
+    float instProb, uGeomInst;
+    instSlot = discrete_sample_guided(instDist, *sc.lightInstIntegral, sc.numInsts, ul, instProb, &uGeomInst);
+    lightProb *= instProb;
+    if (instProb == 0.0f) return false;
+    const DevInstance* inst = sc.insts + instSlot;
+    // (distOffset, numGeomInsts, distIntegral, slotsOffset) in one 16-byte load
+    const uint4 ih = *reinterpret_cast<const uint4*>(&inst->distOffset);
+
+    float geomInstProb, uPrim;
+    const uint32_t gi = discrete_sample(sc.lightProbs + ih.x, sc.lightCDF + ih.x, bits2f(ih.z), ih.y, uGeomInst, &geomInstProb, &uPrim);
+    lightProb *= geomInstProb;
+    if (geomInstProb == 0.0f) return false;
+    const uint4 gr = *reinterpret_cast<const uint4*>(sc.lightGeomRefs + ih.x + gi);   // LightGeomRef
+
+    const uint32_t prim = discrete_sample(nullptr, sc.lightCDF + gr.y, bits2f(gr.w), gr.z, uPrim, nullptr, nullptr);
+    recIndex = gr.x + prim;
+    partialProb = lightProb;
+    return true;
+}
+__device__ __noinline__ bool light_locate_3level_slow(const DevScene& sc, float ul, uint32_t& recIndex, uint32_t& instSlot, float& partialProb) {
+    return light_locate_3level(sc, inst_dist_global(sc), ul, recIndex, instSlot, partialProb);
+}
+
+// sampleLight<false>.  Returns the area density; sample left untouched past an early out exactly
+// like the reference (the caller starts from a default-constructed LightSample).
+GFX_DEV void sample_light(const DevScene& sc,
                           const EnvMap& env, float envRotation, float envPowerCoeff,
                           float ul, bool sampleEnv, float u0, float u1, LightSample& ls, float& areaPDensity) {
     if (sampleEnv) {
@@ -477,29 +514,24 @@ GFX_DEV void sample_light(const DevScene& sc, const InstDist& instDist,
         ls.emittance = f3(kPi * envPowerCoeff) * env.fetch(u, v);
         return;
     }
-    float lightProb = 1.0f;
-    float instProb, uGeomInst;
-    const uint32_t instSlot = discrete_sample_guided(instDist, *sc.lightInstIntegral, sc.numInsts, ul, instProb, &uGeomInst);
-    lightProb *= instProb;
-    if (instProb == 0.0f) { areaPDensity = 0.0f; return; }
-    const DevInstance* inst = sc.insts + instSlot;
-    // (distOffset, numGeomInsts, distIntegral, slotsOffset) in one 16-byte load
-    const uint4 ih = *reinterpret_cast<const uint4*>(&inst->distOffset);
-
-    float geomInstProb, uPrim;
-    const uint32_t gi = discrete_sample(sc.lightProbs + ih.x, sc.lightCDF + ih.x, bits2f(ih.z), ih.y, uGeomInst, &geomInstProb, &uPrim);
-    lightProb *= geomInstProb;
-    if (geomInstProb == 0.0f) { areaPDensity = 0.0f; return; }
-    const uint4 gr = *reinterpret_cast<const uint4*>(sc.lightGeomRefs + ih.x + gi);   // LightGeomRef
-
-    const uint32_t prim = discrete_sample(nullptr, sc.lightCDF + gr.y, bits2f(gr.w), gr.z, uPrim, nullptr, nullptr);
+    // emitter record + instance + density: one guided search in the interval table (emitter_spans.h); the
+    // reference's three-level search only when the build found the table unusable (wave-uniform branch)
+    uint32_t recIndex, instSlot;
+    float density = 0.0f, partialProb = 0.0f;
+    const bool table = sc.spanHeader[0] != 0u;
+    if (table) {
+        EmitterSpan span;
+        const int32_t j = span_lookup(sc.spans, sc.numSpans, sc.spanGuide, sc.spanGuideCells, ul, span);
+        if (j < 0) { areaPDensity = 0.0f; return; }
+        recIndex = static_cast<uint32_t>(j); instSlot = span.instSlot; density = span.density;
+    }
+    else if (!light_locate_3level_slow(sc, ul, recIndex, instSlot, partialProb)) { areaPDensity = 0.0f; return; }
 
     // EmitterRec: world-space triangle, 2 / |ng| and the primitive's probability tabulated at build time
-    const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + gr.x + prim);
+    const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + recIndex);
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
     const f3 pA(r0.x, r0.y, r0.z), pB(r0.w, r1.x, r1.y), pC(r1.z, r1.w, r2.x);
     const f3 nA(r2.y, r2.z, r2.w), nB(r3.x, r3.y, r3.z), nC(r3.w, r4.x, r4.y);
-    lightProb *= r5.w;
 
     float bcA = 0.5f * u0;
     float bcB = 0.5f * u1;
@@ -507,12 +539,12 @@ GFX_DEV void sample_light(const DevScene& sc, const InstDist& instDist,
     if (off > 0) bcB += off;
     else bcA -= off;
     const float bcC = 1 - (bcA + bcB);
-    areaPDensity = lightProb * r5.z;
+    areaPDensity = table ? density : (partialProb * r5.w) * r5.z;
 
     ls.position = bcA * pA + bcB * pB + bcC * pC;
     ls.atInfinity = 0;
     const f3 n = bcA * nA + bcB * nB + bcC * nC;
-    ls.normal = unit(mul(load_m33_rows(inst->normalMatrix), n));
+    ls.normal = unit(mul(load_m33_rows(sc.insts[instSlot].normalMatrix), n));
     ls.emittance = f3(r4.z, r4.w, r5.x);
 }
 
