@@ -33,15 +33,24 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def _profiled_traffic():
-    """HBM bytes per traversal launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
-    inside this process); None when the file is missing."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+def _profile_value(name, key):
+    """A figure from a file committed under profiles/ (rocprofv3 / the CPU tree comparison cannot run inside this
+    process); None when the file or the key is missing."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     try:
         with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
+            return json.load(f)[key]
     except (OSError, KeyError, ValueError):
         return None
+
+
+def _profiled_traffic():
+    """HBM bytes per traversal launch from the PMC passes (newest round first)."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        v = _profile_value(name, "hbm_bytes_per_launch")
+        if v is not None:
+            return v
+    return None
 
 
 def parse():
@@ -51,8 +60,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--mse-ref-spp", type=int, default=8192, help="frames of plain-NEE reference accumulated in fp64 for the MSE figure (0 = skip)")
-    ap.add_argument("--cpu-sample", type=str, default="240x135", help="resolution of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--mse-ref-spp", type=int, default=65536, help="frames of plain-NEE reference accumulated in fp64 for the MSE figure; the metric names 64k (0 = skip)")
+    ap.add_argument("--cpu-sample", type=str, default="480x270", help="resolution of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
@@ -134,7 +143,7 @@ def main():
         "value": round(mpaths, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[2]: ReSTIR DI biased, procedural street stand-in for Bistro Exterior "
+        "config": {"workload": "configs[2] (0-based index into BASELINE.json): ReSTIR DI biased, procedural street stand-in for Bistro Exterior "
                                f"({counts['triangles']} instanced triangles, {counts['insts']} instances, "
                                "2100 emitter instances), 32 candidates, temporal + 2x5 spatial reuse, radius 20, visibility reuse",
                    "width": W, "height": H, "spp": 1, "parallelism": f"row-bands x{world}" if world > 1 else "single GPU",
@@ -144,7 +153,16 @@ def main():
 
     if rank == 0 and world == 1:
         if not args.no_roofline:
-            result["roofline"], result["kernels_ms_per_frame"] = roofline(ctx, renderer, stream, args.steps, W, H)
+            # per-kernel durations come from a second renderer that runs every pass on ONE stream: with the frame
+            # pipelining of the timed renderer the next frame's G-buffer pass overlaps the spatial / shading passes
+            # and both read longer than they are
+            os.environ["GFX_SERIAL_FRAMES"] = "1"
+            serial = api.RestirRenderer(ctx, cfg)
+            del os.environ["GFX_SERIAL_FRAMES"]
+            for _ in range(3):
+                serial.render_frame(stream)
+            result["roofline"], result["kernels_ms_per_frame"] = roofline(ctx, serial, stream, args.steps, W, H)
+            serial.close()
         if args.mse_ref_spp > 0:
             result["mse"] = mse_vs_reference(ctx, hs, renderer, cam, W, H, args.mse_ref_spp)
         if args.cpu_sample not in ("0", ""):
@@ -157,10 +175,12 @@ def main():
 
 
 def roofline(ctx, renderer, stream, steps, W, H):
-    """Dominant kernel by GPU time; achieved = algorithmic bytes per launch / mean launch duration.
-    Durations: HIP events on the launch stream around every kernel (gfx_timing_*), live in this run.
-    Algorithmic bytes of the traversal kernels: node fetches x 64 B + triangle fetches x 64 B +
-    rays x (32 B in + result out), counted by the counting instantiation of the same kernel."""
+    """Dominant kernel family by GPU time; achieved = algorithmic bytes per launch / mean launch duration.
+    Durations: HIP events on the launch stream around every kernel (gfx_timing_*), live in this run, passes
+    serialised on one stream.  Algorithmic bytes of the traversal kernels: node fetches x (64 + 16) B + triangle
+    fetches x 64 B + rays x (32 B in + result out), counted by the counting instantiation of the same kernel.
+    k_initial_candidates gets its own entry: 32 candidates x (16-B interval entry + 96-B emitter record + 48-B
+    normal matrix) + 64 B of pixel state in and 72 B out per pixel."""
     import torch
     ctx.timing_enable(True)
     n = max(4, min(steps, 16))
@@ -179,14 +199,29 @@ def roofline(ctx, renderer, stream, steps, W, H):
     per_frame = {k: round(ms / n, 4) for k, (ms, calls) in sorted(timings.items(), key=lambda kv: -kv[1][0])}
     trav_ms = sum(ms for k, (ms, calls) in timings.items() if k.startswith("trace_")) / n
     trav_launches = sum(calls for k, (ms, calls) in timings.items() if k.startswith("trace_")) / n
-    # one frame = 1 closest launch (16 B out) + 2 any-hit launches (4 B out); counters cover all of them
-    rays_closest = W * H
-    rays_any = c["rays"] - rays_closest
+    # one frame = 1 closest launch (16 B out) + 2 any-hit launches (4 B out)
+    rays_closest, rays_any = c["closest"]["rays"], c["any"]["rays"]
     bytes_frame = c["nodeFetches"] * (64 + 16) + c["triFetches"] * 64 + rays_closest * (32 + 16) + rays_any * (32 + 4)   # node = 64-B record + 16-B link
     achieved = bytes_frame / (trav_ms * 1e-3) / 1e9
+    nodes_per_primary = c["closest"]["nodeFetches"] / max(1, rays_closest)
+    # the same launch time priced with the node / triangle fetches a reference-style SAH + spatial-split tree needs
+    # for the same primary rays (tools/bvh_quality.py, committed): what the kernel achieves in units of useful work
+    sah = _profile_value("r02_bvh_quality.json", "sah_tree") or {}
+    frac_sah = None
+    if sah.get("nodes_per_ray") and sah.get("tris_per_ray") and c["closest"]["triFetches"]:
+        ours_bytes = nodes_per_primary * 80 + c["closest"]["triFetches"] / max(1, rays_closest) * 64
+        sah_bytes = sah["nodes_per_ray"] * 80 + sah["tris_per_ray"] * 64
+        frac_sah = round(achieved / HBM_PEAK_GBS * sah_bytes / ours_bytes, 4)
     roof = {"bound": "hbm", "kernel": "k_trace<closest|any> (software BVH8 traversal; 3 launches per frame)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _profiled_traffic(),
+            "node_visits_per_ray": {"primary": round(nodes_per_primary, 3),
+                                    "shadow": round(c["any"]["nodeFetches"] / max(1, rays_any), 3),
+                                    "sah_tree_primary": sah.get("nodes_per_ray")},
+            "tri_tests_per_ray": {"primary": round(c["closest"]["triFetches"] / max(1, rays_closest), 3),
+                                  "shadow": round(c["any"]["triFetches"] / max(1, rays_any), 3),
+                                  "sah_tree_primary": sah.get("tris_per_ray")},
+            "frac_sah_normalised": frac_sah,
             "scheduling": {"wave_iterations": diag["iterations"], "lane_occupancy": round(diag["itemLanes"] / max(1, 64 * diag["iterations"]), 4),
                            "drain_iteration_share": round(diag["drainIterations"] / max(1, diag["iterations"]), 4),
                            "drain_lane_occupancy": round(diag["drainItemLanes"] / max(1, 64 * diag["drainIterations"]), 4)},
@@ -194,6 +229,13 @@ def roofline(ctx, renderer, stream, steps, W, H):
             "avg_launch_ms": round(trav_ms / max(trav_launches, 1), 4),
             "per_frame": {"node_fetches": int(c["nodeFetches"]), "tri_fetches": int(c["triFetches"]), "rays": int(c["rays"]),
                           "stack_spills": int(c["spills"])}}
+    init_ms = timings.get("initial_candidates", (0.0, 0))[0] / n
+    if init_ms > 0:
+        cand_bytes = W * H * (32 * (16 + 96 + 48) + 64 + 72)
+        roof["initial_candidates"] = {"bound": "hbm", "kernel": "k_initial_candidates (32 streaming-RIS candidates per pixel)",
+                                      "ms": round(init_ms, 4), "algorithmic_bytes_per_launch": cand_bytes,
+                                      "achieved": round(cand_bytes / (init_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(cand_bytes / (init_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     return roof, per_frame
 
 
@@ -226,7 +268,7 @@ def mse_vs_reference(ctx, hs, renderer, cam, W, H, ref_spp):
     return {"mse": float(err.mean()), "rel_mse": float((err / (ref ** 2 + 1e-2)).mean()), "ref_spp": ref_spp,
             "mse_of_one_reference_frame": float(err_plain.mean()), "rel_mse_of_one_reference_frame": float((err_plain / (ref ** 2 + 1e-2)).mean()),
             "ref_estimator": "RIS/NEE 32 candidates + visibility, no reuse, fp64 accumulation", "ref_seconds": round(seconds, 1),
-            "note": "the metric names a 64k-spp reference: --mse-ref-spp 65536 (about 3 minutes on one MI355X)"}
+            "note": "the metric names a 64k-spp reference (the default); a smaller --mse-ref-spp reads higher by the reference's own noise"}
 
 
 def _device_view(ptr, num_floats):
@@ -241,39 +283,47 @@ def _device_view(ptr, num_floats):
 
 
 def cpu_baseline(hs, cam, sample, W, H):
-    """The CPU restatement (oracle/, test infrastructure) timed on this host: same scene, same
-    camera, same settings, steady-state frames on a reduced pixel count, one thread."""
-    import ctypes as C
+    """The CPU restatement (oracle/, test infrastructure) timed on this host: same scene, same camera, same
+    settings, steady-state frames on a reduced pixel count -- once on one thread (the scalar CPU path) and once
+    on every host thread (OpenMP over pixels inside each pass)."""
     from oracle import oracle as O
     from tests import util
     sw, sh = [int(x) for x in sample.lower().split("x")]
     osc = util.feed_oracle(hs, threads=1)
     ocam = util.copy_struct(O.GfxCamera, cam)
     ocam.aspect = float(sw) / float(sh)
-    pb = util.PixelBuffers(sw, sh)
-    s = pb.host_static_params()
-    last_res, last_base = 1, 0
-    times = []
-    frames = 3
-    for frame in range(frames):
-        kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=0)
-        f = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, sw, sh, ocam, **kw)
-        cur = (last_res + 1) % 2
-        t0 = time.perf_counter()
-        osc.restir_launch(s, f, cur, last_base, 0)
-        osc.restir_launch(s, f, cur, last_base, 1 if frame == 0 else 2)
-        for i in range(2):
-            osc.restir_launch(s, f, cur, last_base + 5 * i, 4)
-            cur = (cur + 1) % 2
-        last_base += 10
-        osc.restir_launch(s, f, cur, last_base, 6)
-        last_res = cur
-        times.append(time.perf_counter() - t0)
-    t = float(np.median(times[1:]))
-    return {"value": round(sw * sh / t / 1e6, 5), "unit": "Mpaths/s", "cores": 1, "kind": "port",
-            "sample": f"{sw}x{sh} pixels ({sw * sh / (W * H):.4f} of the frame), {frames - 1} steady-state frames, same scene/camera/settings, "
-                      f"scalar C++ restatement (oracle/), SAH BVH8 build {osc.build_seconds:.1f} s untimed",
-            "seconds_per_sample_frame": round(t, 3), "host_threads_available": O.lib().orc_max_threads()}
+
+    def run(threads, frames):
+        osc.set_threads(threads)
+        pb = util.PixelBuffers(sw, sh)
+        s = pb.host_static_params()
+        last_res, last_base = 1, 0
+        times = []
+        for frame in range(frames):
+            kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=0)
+            f = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, sw, sh, ocam, **kw)
+            cur = (last_res + 1) % 2
+            t0 = time.perf_counter()
+            osc.restir_launch(s, f, cur, last_base, 0)
+            osc.restir_launch(s, f, cur, last_base, 1 if frame == 0 else 2)
+            for i in range(2):
+                osc.restir_launch(s, f, cur, last_base + 5 * i, 4)
+                cur = (cur + 1) % 2
+            last_base += 10
+            osc.restir_launch(s, f, cur, last_base, 6)
+            last_res = cur
+            times.append(time.perf_counter() - t0)
+        return float(np.median(times[1:]))
+
+    t1 = run(1, 4)
+    cores = int(O.lib().orc_max_threads())
+    tn = run(cores, 8)
+    return {"value": round(sw * sh / t1 / 1e6, 5), "unit": "Mpaths/s", "cores": 1, "kind": "port",
+            "sample": f"{sw}x{sh} pixels ({sw * sh / (W * H):.4f} of the frame), steady-state frames (median of 3 on one thread, of 7 on all), "
+                      f"same scene/camera/settings, scalar C++ restatement (oracle/), SAH BVH8 build {osc.build_seconds:.1f} s untimed",
+            "seconds_per_sample_frame": round(t1, 3),
+            "all_cores": {"value": round(sw * sh / tn / 1e6, 5), "unit": "Mpaths/s", "cores": cores,
+                          "seconds_per_sample_frame": round(tn, 4), "how": "OpenMP over pixels inside every pass"}}
 
 
 if __name__ == "__main__":

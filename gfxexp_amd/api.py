@@ -147,7 +147,7 @@ C_ABI_SYMBOLS = [
     "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_instance_set_transform_and_normal_matrix", "gfx_instance_set_dynamic",
     "gfx_accel_build",
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
-    "gfx_lights_build_instances", "gfx_lights_read", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
+    "gfx_lights_build_instances", "gfx_lights_read", "gfx_lights_table_info", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
     "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
     "gfx_nrc_get_params", "gfx_nrc_set_render_params",
@@ -469,6 +469,12 @@ class Context:
                                            C.byref(n), C.byref(integ)))
         return w, c, integ.value
 
+    def lights_table_info(self):
+        """{usable, verified, records, cells} of the emitter interval table (emitter_spans.h)."""
+        info = (C.c_uint32 * 4)()
+        self._check(self.L.gfx_lights_table_info(self.h, info))
+        return {"usable": int(info[0]), "verified": int(info[1]), "records": int(info[2]), "cells": int(info[3])}
+
     def trace(self, accel, mode, d_ray_org, d_ray_dir, num_rays, d_out, d_counters=0, stream=0):
         self._check(self.L.gfx_trace(self.h, C.c_void_p(stream), C.c_uint64(accel), C.c_int(mode), C.c_void_p(d_ray_org),
                                      C.c_void_p(d_ray_dir), C.c_uint32(num_rays), C.c_void_p(d_out), C.c_void_p(d_counters)))
@@ -522,9 +528,13 @@ class Context:
         return dict(iterations=c[0], itemLanes=c[1], drainIterations=c[2], drainItemLanes=c[3])
 
     def counters_read(self, reset=True):
-        c = (C.c_uint64 * 4)()
+        c = (C.c_uint64 * 8)()
         self._check(self.L.gfx_counters_read(self.h, c, C.c_int(1 if reset else 0)))
-        return dict(nodeFetches=c[0], triFetches=c[1], rays=c[2], spills=c[3])
+        names = ("nodeFetches", "triFetches", "rays", "spills")
+        out = {n: c[i] + c[4 + i] for i, n in enumerate(names)}
+        out["any"] = {n: c[i] for i, n in enumerate(names)}
+        out["closest"] = {n: c[4 + i] for i, n in enumerate(names)}
+        return out
 
 
 NRC_TRIANGLE_WAVE, NRC_HASH_GRID = 0, 1

@@ -220,6 +220,16 @@ int gfx_lights_read(gfx_ctx* ctx, uint32_t level, uint32_t index, float* weights
     GFX_CATCH(ctx)
 }
 
+int gfx_lights_table_info(gfx_ctx* ctx, uint32_t info[4]) {
+    GFX_TRY(ctx)
+    Context& c = ctx->c;
+    GFX_HIP(hipDeviceSynchronize());
+    uint32_t header[4] = { 0, 0, 0, 0 };
+    if (c.dSpanHeader.p) GFX_HIP(hipMemcpy(header, c.dSpanHeader.p, sizeof(header), hipMemcpyDeviceToHost));
+    info[0] = header[0]; info[1] = header[1]; info[2] = c.numEmitterRecs; info[3] = c.spanGuideCells;
+    GFX_CATCH(ctx)
+}
+
 int gfx_trace(gfx_ctx* ctx, void* stream, uint64_t accel, int mode, const void* dRayOrgTmin, const void* dRayDirTmax,
               uint32_t numRays, void* dOut, void* dCounters) {
     GFX_TRY(ctx)
@@ -232,10 +242,10 @@ int gfx_trace(gfx_ctx* ctx, void* stream, uint64_t accel, int mode, const void* 
     // explicit counter buffer: count into the caller's u64[4]
     const bool savedEnabled = ctx->c.countersEnabled;
     DevBuf saved = ctx->c.dTraceCounters;
-    if (dCounters) { ctx->c.countersEnabled = true; ctx->c.dTraceCounters.p = dCounters; }
+    if (dCounters) { ctx->c.countersEnabled = true; ctx->c.dTraceCounters.p = dCounters; ctx->c.countersSplit = false; }
     try { trace_launch(ctx->c, static_cast<hipStream_t>(stream), t); }
-    catch (...) { ctx->c.dTraceCounters = saved; ctx->c.countersEnabled = savedEnabled; throw; }
-    ctx->c.dTraceCounters = saved; ctx->c.countersEnabled = savedEnabled;
+    catch (...) { ctx->c.dTraceCounters = saved; ctx->c.countersEnabled = savedEnabled; ctx->c.countersSplit = true; throw; }
+    ctx->c.dTraceCounters = saved; ctx->c.countersEnabled = savedEnabled; ctx->c.countersSplit = true;
     GFX_CATCH(ctx)
 }
 
@@ -389,11 +399,11 @@ int gfx_trace_diag_read(gfx_ctx* ctx, uint64_t diag[8], int reset) {
     GFX_CATCH(ctx)
 }
 
-int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[4], int reset) {
+int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[8], int reset) {
     GFX_TRY(ctx)
     GFX_HIP(hipDeviceSynchronize());
-    GFX_HIP(hipMemcpy(counters, ctx->c.dTraceCounters.p, 32, hipMemcpyDeviceToHost));
-    if (reset) GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 32));
+    GFX_HIP(hipMemcpy(counters, ctx->c.dTraceCounters.p, 64, hipMemcpyDeviceToHost));
+    if (reset) GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 64));
     GFX_CATCH(ctx)
 }
 

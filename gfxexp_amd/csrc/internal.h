@@ -143,7 +143,8 @@ struct Context {
     std::map<std::string, KernelTiming> timings;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pendingEvents;
     bool countersEnabled = false;
-    DevBuf dTraceCounters;     // u64[4]
+    DevBuf dTraceCounters;     // u64[8]: any-hit launches {nodes, triangles, rays, spills}, closest-hit launches {same}
+    bool countersSplit = true; // false while gfx_trace counts into a caller-supplied u64[4]
     DevBuf dTraceDiag;         // u64[8] scheduling diagnostics of counting launches
     ~Context();
 };

@@ -199,7 +199,8 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     a.rayOrgTmin = t.rayOrgTmin; a.rayDirTmax = t.rayDirTmax;
     a.numRaysPtr = t.numRaysPtr; a.numRays = t.numRays;
     a.out = t.out; a.ticket = ticket; a.spill = spill.as<uint2>();
-    a.counters = ctx.countersEnabled ? ctx.dTraceCounters.as<unsigned long long>() : nullptr;
+    // the context's own counters keep any-hit launches in [0..3] and closest-hit launches in [4..7]
+    a.counters = ctx.countersEnabled ? ctx.dTraceCounters.as<unsigned long long>() + ((ctx.countersSplit && t.mode != GFX_TRACE_ANY) ? 4 : 0) : nullptr;
     a.diag = nullptr;
     if (ctx.countersEnabled) {
         if (!ctx.dTraceDiag.p) { ctx.dTraceDiag.reserve(64); GFX_HIP(hipMemsetAsync(ctx.dTraceDiag.p, 0, 64, stream)); }

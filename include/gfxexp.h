@@ -143,6 +143,11 @@ int gfx_lights_build_instances(gfx_ctx* ctx, void* stream, uint32_t bufferIndex)
 int gfx_lights_read(gfx_ctx* ctx, uint32_t level, uint32_t index, float* weights, float* cdf,
                     uint32_t capacity, uint32_t* n, float* integral);
 
+/* State of the emitter interval table the last gfx_lights_build_instances produced (the three searches of
+ * sampleLight, restir_di_shared.h:366-415, flattened into one lookup): info = { usable (the build verified it
+ * against the three searches; 0 = kernels run the searches themselves), records verified, records, guide cells }. */
+int gfx_lights_table_info(gfx_ctx* ctx, uint32_t info[4]);
+
 /* ---------------------------------------------------------------- ray queries ---------------- */
 
 /* Replaces optixTrace (utils/optix_util.h:557-603) for wavefront ray queues and the scalar
@@ -387,9 +392,10 @@ int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes)
 int gfx_timing_enable(gfx_ctx* ctx, int enable);
 int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t* calls,
                        uint32_t capacity, uint32_t* n);
-/* Ray-traversal counters accumulated by the ReSTIR passes (device u64[4], see gfx_trace). */
+/* Ray-traversal counters accumulated by the renderer passes: {node fetches, triangle fetches, rays, stack spills}
+ * of the any-hit launches in [0..3] and of the closest-hit launches in [4..7]. */
 int gfx_counters_enable(gfx_ctx* ctx, int enable);
-int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[4], int reset);
+int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[8], int reset);
 /* Scheduling diagnostics of the counting trace launches: [0] wave iterations, [1] lanes that held an
  * item summed over iterations, [2] / [3] the same after the ray queue ran dry (drain phase). */
 int gfx_trace_diag_read(gfx_ctx* ctx, uint64_t diag[8], int reset);

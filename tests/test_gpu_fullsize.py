@@ -31,7 +31,7 @@ def _pick(arr, mask, n):
     return a[mask]
 
 
-@pytest.mark.parametrize("config", ["configs[2]: biased", "configs[5]: unbiased + 2048x1024 environment map"])
+@pytest.mark.parametrize("config", ["configs[2]: biased", "configs[4]: unbiased + 2048x1024 environment map"])
 def test_window_of_the_full_frame_matches_the_oracle(built_lib, config):
     import torch
     unbiased = "unbiased" in config

@@ -173,7 +173,7 @@ def test_row_band_renderers_match_full_frame(built_lib, renderer, with_env):
     hs.upload(ctx)
     cam = default_camera("bunny", width, height)
 
-    sky = api.env_make_sky(64, 32) if with_env else None     # BASELINE configs[5]: unbiased + environment map, row bands
+    sky = api.env_make_sky(64, 32) if with_env else None     # BASELINE configs[4]: unbiased + environment map, row bands
 
     def make(band):
         cfg = api.RestirRenderer.default_config(width, height, renderer)

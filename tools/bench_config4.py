@@ -1,4 +1,4 @@
-"""BASELINE configs[5] on one GPU: ReSTIR DI unbiased + 2048x1024 environment map (analytic sky + sun) on the
+"""BASELINE configs[4] on one GPU: ReSTIR DI unbiased + 2048x1024 environment map (analytic sky + sun) on the
 street stand-in, 1920x1080.  One JSON line with the frame time and the per-kernel split."""
 import json
 import os
@@ -32,7 +32,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     kern = {k: round(v[0] / steps, 4) for k, v in sorted(ctx.timing_collect().items(), key=lambda kv: -kv[1][0])}
-    print(json.dumps({"workload": "configs[5] on 1 GPU: unbiased ReSTIR DI + env map 2048x1024, street stand-in, 1920x1080",
+    print(json.dumps({"workload": "configs[4] on 1 GPU: unbiased ReSTIR DI + env map 2048x1024, street stand-in, 1920x1080",
                       "ms_per_frame": round(dt * 1e3, 4), "Mpaths_per_s": round(W * H / dt / 1e6, 2), "kernels_ms_per_frame": kern}))
 
 

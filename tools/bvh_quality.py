@@ -1,5 +1,12 @@
-"""Node visits per primary ray: the reference-style SAH + spatial-split BVH8 (oracle restatement, CPU)
-versus the GPU LBVH -> BVH8 of the product on the same rays.  Diagnostic, prints one JSON line."""
+"""Tree quality on the bench frame's primary rays: the reference-style SAH + spatial-split BVH8 (oracle
+restatement, CPU; common/bvh_builder.cpp:656-1125) versus the product's GPU tree, same rays.
+
+    python tools/bvh_quality.py [bench|small] [out.json]
+
+Rays: the pinhole rays of bench.py's camera (restir_di_shared.h:51-59 camera model) at 480x270.  The oracle counts
+node fetches / triangle tests with its own traversal (distance-sorted children, bvh_builder.cpp:1272-1649); the
+product counts with the counting instantiation of k_trace.  The JSON is what bench.py's
+`roofline.frac_sah_normalised` reads from profiles/r02_bvh_quality.json.  Diagnostic: imports tests/ and oracle/."""
 import json
 import os
 import sys
@@ -12,30 +19,60 @@ from gfxexp_amd import api  # noqa: E402
 from tests import util  # noqa: E402
 
 
+def camera_rays(cam, w, h, tmax=np.float32(3.0e38)):
+    ori = np.array(list(cam.orientation), np.float32).reshape(3, 3)
+    vh = np.float32(2 * np.tan(np.float32(cam.fovY) * np.float32(0.5)))
+    vw = np.float32(cam.aspect) * vh
+    xs = (np.arange(w, dtype=np.float32) + np.float32(0.5)) / np.float32(w)
+    ys = (np.arange(h, dtype=np.float32) + np.float32(0.5)) / np.float32(h)
+    X, Y = np.meshgrid(xs, ys)
+    local = np.stack([vw * (np.float32(0.5) - X), vh * (np.float32(0.5) - Y), np.ones_like(X)], -1).reshape(-1, 3)
+    d = local @ ori.T
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    n = w * h
+    org = np.zeros((n, 4), np.float32)
+    org[:, :3] = np.array(list(cam.position), np.float32)
+    dirs = np.zeros((n, 4), np.float32)
+    dirs[:, :3] = d
+    dirs[:, 3] = tmax
+    return org, dirs
+
+
 def main():
     import torch
     which = sys.argv[1] if len(sys.argv) > 1 else "small"
+    out_path = sys.argv[2] if len(sys.argv) > 2 else None
     hs = util.bench_street() if which == "bench" else util.small_street()
     w, h = 480, 270
-    org, dirs = util.pinhole_rays(w, h, (2.0, 5.0, 26.0), (0.0, 3.0, 0.0), 50.0)
+    cam = api.make_camera(w, h, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5) if which == "bench" else \
+        api.make_camera(w, h, pos=(2.0, 5.0, 26.0), pitch=4.0, yaw=180.0)
+    org, dirs = camera_rays(cam, w, h)
     ctx = api.Context(0)
     hs.upload(ctx)
     accel = ctx.accel_build()
     n = w * h
     d_org, d_dir = torch.from_numpy(org).cuda(), torch.from_numpy(dirs).cuda()
     out = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
-    ctx.counters_enable(True)
-    ctx.counters_read(True)
-    ctx.trace(accel, api.TRACE_CLOSEST, d_org.data_ptr(), d_dir.data_ptr(), n, out.data_ptr())
+    counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+    ctx.trace(accel, api.TRACE_CLOSEST, d_org.data_ptr(), d_dir.data_ptr(), n, out.data_ptr(), d_counters=counters.data_ptr())
     torch.cuda.synchronize()
-    c = ctx.counters_read(True)
+    c = counters.cpu().numpy()
+    hits = out.view(torch.float32).view(n, 4)[:, 0].cpu().numpy()
     t0 = time.time()
     osc = util.feed_oracle(hs)
     build_s = time.time() - t0
     _, stats = osc.trace(3, org, dirs, want_stats=True)
-    print(json.dumps({"scene": which, "rays": n, "gpu_lbvh_nodes_per_ray": c["nodeFetches"] / n, "gpu_tris_per_ray": c["triFetches"] / n,
-                      "cpu_sah_nodes_per_ray": int(stats[0]) / n, "cpu_sah_tris_per_ray": int(stats[1]) / n, "cpu_build_s": build_s,
-                      "accel_stats": ctx.accel_stats(accel) if hasattr(ctx, "accel_stats") else None}))
+    res = {"scene": which, "rays": n, "camera": "bench.py camera, 480x270 primary rays" if which == "bench" else "small street",
+           "hit_fraction": float(np.mean(hits < 1e30)),
+           "gpu_tree": {"nodes_per_ray": float(c[0]) / n, "tris_per_ray": float(c[1]) / n, "accel": ctx.accel_stats(accel),
+                        "builder": os.environ.get("GFX_BVH_VARIANT", "default")},
+           "sah_tree": {"nodes_per_ray": int(stats[0]) / n, "tris_per_ray": int(stats[1]) / n, "cpu_build_s": round(build_s, 2),
+                        "builder": "oracle restatement of common/bvh_builder.cpp (binned SAH + spatial splits), distance-sorted traversal"}}
+    line = json.dumps(res)
+    print(line)
+    if out_path:
+        with open(out_path, "w") as f:
+            f.write(json.dumps(res, indent=1) + "\n")
 
 
 if __name__ == "__main__":
