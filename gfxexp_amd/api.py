@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgfxexp.so")
+LIB_PATH = os.environ.get("GFX_LIB") or os.path.join(_HERE, "libgfxexp.so")   # GFX_LIB: an experiment build (build.build_variant)
 
 GFX_INVALID_SLOT = 0xFFFFFFFF
 TRACE_CLOSEST, TRACE_ANY = 0, 1

@@ -22,9 +22,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-I" + os.path.join(HERE, "..", "include")]
 
 
-def _deps_hash(src):
+def _deps_hash(src, flags):
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(flags).encode())
     for root in (CSRC, os.path.join(HERE, "..", "include")):
         for dp, _, fns in sorted(os.walk(root)):
             for fn in sorted(fns):
@@ -34,16 +34,16 @@ def _deps_hash(src):
     return h.hexdigest()
 
 
-def _compile(rel):
+def _compile(rel, obj_dir=OBJ, flags=FLAGS):
     src = os.path.join(CSRC, rel)
     if not os.path.exists(src):
         return None
-    obj = os.path.join(OBJ, rel.replace("/", "_") + ".o")
+    obj = os.path.join(obj_dir, rel.replace("/", "_") + ".o")
     stamp = obj + ".stamp"
-    want = _deps_hash(src)
+    want = _deps_hash(src, flags)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return obj
-    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if rel.endswith(".hip") else []) + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + flags + (["-x", "hip"] if rel.endswith(".hip") else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (rel, r.stdout[-4000:], r.stderr[-8000:]))
@@ -68,5 +68,22 @@ def build(force=False):
     return LIB
 
 
+def build_variant(name, defines):
+    """Experiment builds (tools/sessions): the same sources with extra -D switches -> gfxexp_amd/variants/libgfxexp_<name>.so;
+    api.py loads it when GFX_LIB names the file.  Not part of the product build."""
+    vdir = os.path.join(HERE, "variants")
+    odir = os.path.join(vdir, "obj_" + name)
+    os.makedirs(odir, exist_ok=True)
+    flags = FLAGS + ["-D" + d for d in defines]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = [o for o in ex.map(lambda r: _compile(r, odir, flags), SOURCES) if o]
+    lib = os.path.join(vdir, "libgfxexp_%s.so" % name)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        print(build(force="--force" in sys.argv))

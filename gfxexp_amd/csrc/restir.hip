@@ -164,7 +164,10 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
 // candidate loop + visibility-ray emission: optix_restir_di_kernels.cu:57-133
 // The light of a candidate comes out of the emitter interval table (emitter_spans.h): one guided search
 // instead of the reference's three nested ones, identical result.
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_initial_candidates(RestirArgs a) {
+#ifndef GFX_INIT_WAVES   // experiment switch (tools/sessions): waves per SIMD the register allocation of the kernel targets
+#define GFX_INIT_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     const uint32_t bufIdx = a.f.bufferIndex;

@@ -488,9 +488,6 @@ GFX_DEV bool light_locate_3level(const DevScene& sc, const InstDist& instDist, f
     partialProb = lightProb;
     return true;
 }
-__device__ __noinline__ bool light_locate_3level_slow(const DevScene& sc, float ul, uint32_t& recIndex, uint32_t& instSlot, float& partialProb) {
-    return light_locate_3level(sc, inst_dist_global(sc), ul, recIndex, instSlot, partialProb);
-}
 
 // sampleLight<false>.  Returns the area density; sample left untouched past an early out exactly
 // like the reference (the caller starts from a default-constructed LightSample).
@@ -518,14 +515,18 @@ GFX_DEV void sample_light(const DevScene& sc,
     // reference's three-level search only when the build found the table unusable (wave-uniform branch)
     uint32_t recIndex, instSlot;
     float density = 0.0f, partialProb = 0.0f;
+#ifdef GFX_LIGHT_TABLE_ONLY   // experiment: what the kernels cost without the search fallback compiled in
+    const bool table = true;
+#else
     const bool table = sc.spanHeader[0] != 0u;
+#endif
     if (table) {
         EmitterSpan span;
         const int32_t j = span_lookup(sc.spans, sc.numSpans, sc.spanGuide, sc.spanGuideCells, ul, span);
         if (j < 0) { areaPDensity = 0.0f; return; }
         recIndex = static_cast<uint32_t>(j); instSlot = span.instSlot; density = span.density;
     }
-    else if (!light_locate_3level_slow(sc, ul, recIndex, instSlot, partialProb)) { areaPDensity = 0.0f; return; }
+    else if (!light_locate_3level(sc, inst_dist_global(sc), ul, recIndex, instSlot, partialProb)) { areaPDensity = 0.0f; return; }
 
     // EmitterRec: world-space triangle, 2 / |ng| and the primitive's probability tabulated at build time
     const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + recIndex);
