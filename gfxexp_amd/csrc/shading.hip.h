@@ -489,48 +489,72 @@ GFX_DEV bool light_locate_3level(const DevScene& sc, const InstDist& instDist, f
     return true;
 }
 
-// sampleLight<false>.  Returns the area density; sample left untouched past an early out exactly
-// like the reference (the caller starts from a default-constructed LightSample).
-GFX_DEV void sample_light(const DevScene& sc,
-                          const EnvMap& env, float envRotation, float envPowerCoeff,
-                          float ul, bool sampleEnv, float u0, float u1, LightSample& ls, float& areaPDensity) {
-    if (sampleEnv) {
-        float u, v, uvPDF;
-        env.sample(u0, u1, u, v, uvPDF);
-        const float phi = 2 * kPi * u;
-        const float theta = kPi * v;
-        float posPhi = phi - envRotation;
-        posPhi = posPhi - floorf(posPhi / (2 * kPi)) * 2 * kPi;
-        const f3 dir = from_polar_yup(posPhi, theta);
-        ls.position = dir;
-        ls.atInfinity = 1;
-        ls.normal = -dir;
-        const float sinTheta = gm_sin(theta);
-        if (sinTheta == 0.0f) { areaPDensity = 0.0f; return; }
-        areaPDensity = uvPDF / (2 * kPi * kPi * sinTheta);
-        ls.emittance = f3(kPi * envPowerCoeff) * env.fetch(u, v);
-        return;
+// Which emitter record a light-selection number ul picks, and what comes with it.
+struct LightPick {
+    uint32_t rec, instSlot;
+    float density;        // table: the area density of a sample on the record
+    float partialProb;    // search fallback: (1 * instProb) * geomInstProb
+    bool ok;              // false: the reference returns early with a zero density (restir_di_shared.h:372, 391)
+    bool table;
+};
+
+// Interval-table lookup in three stages so that a caller can overlap the dependent loads of one candidate with the
+// arithmetic of another (k_initial_candidates): guide cell -> the two bracketing spans -> resolve.
+struct SpanProbe { EmitterSpan lo, hi; uint32_t loIdx, hiIdx; };
+GFX_DEV SpanGuide light_probe_guide(const DevScene& sc, float ul) { return sc.spanGuide[span_cell(ul, sc.spanGuideCells)]; }
+GFX_DEV SpanProbe light_probe_spans(const DevScene& sc, SpanGuide g) {
+    SpanProbe p;
+    p.loIdx = g.lo; p.hiIdx = g.hi;
+    p.lo = __builtin_bit_cast(EmitterSpan, *reinterpret_cast<const SpanWords*>(sc.spans + g.lo));
+    p.hi = __builtin_bit_cast(EmitterSpan, *reinterpret_cast<const SpanWords*>(sc.spans + g.hi));
+    return p;
+}
+GFX_DEV LightPick light_probe_resolve(const DevScene& sc, const SpanProbe& p, float ul) {
+    // the answer is the largest index in [lo, hi] whose begin is <= ul: hi or lo when the bracket holds at most
+    // two records (nearly always: the guide has about two cells per record), a search between them otherwise
+    EmitterSpan s = p.lo;
+    uint32_t idx = p.loIdx;
+    if (p.hi.begin <= ul) { s = p.hi; idx = p.hiIdx; }
+    else if (p.hiIdx - p.loIdx > 1u) {
+        int32_t lo = static_cast<int32_t>(p.loIdx), hi = static_cast<int32_t>(p.hiIdx) - 1;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (sc.spans[mid].begin <= ul) lo = mid;
+            else hi = mid - 1;
+        }
+        idx = static_cast<uint32_t>(lo);
+        s = __builtin_bit_cast(EmitterSpan, *reinterpret_cast<const SpanWords*>(sc.spans + lo));
     }
-    // emitter record + instance + density: one guided search in the interval table (emitter_spans.h); the
-    // reference's three-level search only when the build found the table unusable (wave-uniform branch)
-    uint32_t recIndex, instSlot;
-    float density = 0.0f, partialProb = 0.0f;
+    LightPick pk;
+    pk.rec = idx; pk.instSlot = s.instSlot; pk.density = s.density; pk.partialProb = 0.0f;
+    pk.ok = ul >= s.begin && ul < s.end;
+    pk.table = true;
+    return pk;
+}
+
+// Selection in one call: the table when the build verified it (wave-uniform), else the reference's searches.
+GFX_DEV LightPick light_select(const DevScene& sc, float ul) {
 #ifdef GFX_LIGHT_TABLE_ONLY   // experiment: what the kernels cost without the search fallback compiled in
     const bool table = true;
 #else
     const bool table = sc.spanHeader[0] != 0u;
 #endif
     if (table) {
-        EmitterSpan span;
-        const int32_t j = span_lookup(sc.spans, sc.numSpans, sc.spanGuide, sc.spanGuideCells, ul, span);
-        if (j < 0) { areaPDensity = 0.0f; return; }
-        recIndex = static_cast<uint32_t>(j); instSlot = span.instSlot; density = span.density;
+        if (sc.numSpans == 0) { LightPick pk; pk.rec = 0; pk.instSlot = 0; pk.density = 0; pk.partialProb = 0; pk.ok = false; pk.table = true; return pk; }
+        return light_probe_resolve(sc, light_probe_spans(sc, light_probe_guide(sc, ul)), ul);
     }
-    else if (!light_locate_3level(sc, inst_dist_global(sc), ul, recIndex, instSlot, partialProb)) { areaPDensity = 0.0f; return; }
+    LightPick pk;
+    pk.density = 0.0f; pk.table = false;
+    pk.ok = light_locate_3level(sc, inst_dist_global(sc), ul, pk.rec, pk.instSlot, pk.partialProb);
+    return pk;
+}
 
+// The rest of sampleLight<false> for a picked record: point on the triangle, normal, emittance, area density.
+GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, float u1, LightSample& ls, float& areaPDensity) {
     // EmitterRec: world-space triangle, 2 / |ng| and the primitive's probability tabulated at build time
-    const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + recIndex);
+    const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + pk.rec);
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
+    const m33 normalMatrix = load_m33_rows(sc.insts[pk.instSlot].normalMatrix);
     const f3 pA(r0.x, r0.y, r0.z), pB(r0.w, r1.x, r1.y), pC(r1.z, r1.w, r2.x);
     const f3 nA(r2.y, r2.z, r2.w), nB(r3.x, r3.y, r3.z), nC(r3.w, r4.x, r4.y);
 
@@ -540,13 +564,41 @@ GFX_DEV void sample_light(const DevScene& sc,
     if (off > 0) bcB += off;
     else bcA -= off;
     const float bcC = 1 - (bcA + bcB);
-    areaPDensity = table ? density : (partialProb * r5.w) * r5.z;
+    areaPDensity = pk.table ? pk.density : (pk.partialProb * r5.w) * r5.z;
 
     ls.position = bcA * pA + bcB * pB + bcC * pC;
     ls.atInfinity = 0;
     const f3 n = bcA * nA + bcB * nB + bcC * nC;
-    ls.normal = unit(mul(load_m33_rows(sc.insts[instSlot].normalMatrix), n));
+    ls.normal = unit(mul(normalMatrix, n));
     ls.emittance = f3(r4.z, r4.w, r5.x);
+}
+
+GFX_DEV void sample_env_light(const EnvMap& env, float envRotation, float envPowerCoeff, float u0, float u1, LightSample& ls, float& areaPDensity) {
+    float u, v, uvPDF;
+    env.sample(u0, u1, u, v, uvPDF);
+    const float phi = 2 * kPi * u;
+    const float theta = kPi * v;
+    float posPhi = phi - envRotation;
+    posPhi = posPhi - floorf(posPhi / (2 * kPi)) * 2 * kPi;
+    const f3 dir = from_polar_yup(posPhi, theta);
+    ls.position = dir;
+    ls.atInfinity = 1;
+    ls.normal = -dir;
+    const float sinTheta = gm_sin(theta);
+    if (sinTheta == 0.0f) { areaPDensity = 0.0f; return; }
+    areaPDensity = uvPDF / (2 * kPi * kPi * sinTheta);
+    ls.emittance = f3(kPi * envPowerCoeff) * env.fetch(u, v);
+}
+
+// sampleLight<false>.  Returns the area density; sample left untouched past an early out exactly
+// like the reference (the caller starts from a default-constructed LightSample).
+GFX_DEV void sample_light(const DevScene& sc,
+                          const EnvMap& env, float envRotation, float envPowerCoeff,
+                          float ul, bool sampleEnv, float u0, float u1, LightSample& ls, float& areaPDensity) {
+    if (sampleEnv) { sample_env_light(env, envRotation, envPowerCoeff, u0, u1, ls, areaPDensity); return; }
+    const LightPick pk = light_select(sc, ul);
+    if (!pk.ok) { areaPDensity = 0.0f; return; }
+    light_fetch(sc, pk, u0, u1, ls, areaPDensity);
 }
 
 // Geometry of a shadow ray toward a light sample (restir_di_shared.h:524-545, 564-581).
