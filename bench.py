@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--mse-ref-spp", type=int, default=65536, help="frames of plain-NEE reference accumulated in fp64 for the MSE figure; the metric names 64k (0 = skip)")
     ap.add_argument("--cpu-sample", type=str, default="480x270", help="resolution of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--plain", action="store_true", help="constant-colour materials (the round-1 workload) instead of the textured street")
+    ap.add_argument("--bump", type=int, default=1, help="enableBumpMapping (normal maps) for the textured workload")
     return ap.parse_args()
 
 
@@ -88,13 +90,15 @@ def main():
 
     W, H = args.width, args.height
     t0 = time.time()
-    hs = scenes.bench_street()
+    textured = not args.plain
+    hs = scenes.bench_street(textured=textured)
     counts = hs.counts()
     ctx = api.Context(local_rank)
     hs.upload(ctx)
     cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
     cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
     cfg.camera = cam
+    cfg.enableBumpMapping = int(textured and args.bump)
     band = tilesplit.band_for_rank(H, world, rank)
     cfg.rowBegin, cfg.rowEnd = band
     renderer = api.RestirRenderer(ctx, cfg)

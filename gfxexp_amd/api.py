@@ -39,7 +39,9 @@ class GfxError(RuntimeError):
 
 class GfxMaterial(C.Structure):
     _fields_ = [("bsdfType", C.c_uint32), ("a", C.c_float * 3), ("b", C.c_float * 3),
-                ("smoothness", C.c_float), ("emittance", C.c_float * 3), ("hasEmittance", C.c_uint32)]
+                ("smoothness", C.c_float), ("emittance", C.c_float * 3), ("hasEmittance", C.c_uint32),
+                ("texA", C.c_uint32), ("texB", C.c_uint32), ("texSmoothness", C.c_uint32), ("texNormal", C.c_uint32),
+                ("texEmittance", C.c_uint32), ("bumpMapType", C.c_uint32), ("pad", C.c_uint32 * 2)]
 
 
 class GfxCamera(C.Structure):
@@ -103,11 +105,15 @@ class GfxNrcParams(C.Structure):
                 ("preprocessOffsetToSelectTrainingPath", C.c_uint32), ("isNewSequence", C.c_uint32)]
 
 
+TEX_RGBA8_SRGB, TEX_RGBA8_UNORM, TEX_R8_UNORM, TEX_RG8_UNORM, TEX_RGBA32F = 0, 1, 2, 3, 4
+BUMP_NORMAL_MAP, BUMP_NORMAL_MAP_2CH, BUMP_HEIGHT_MAP, BUMP_LEFT_HANDED = 0, 1, 2, 0x100
+
+
 class GfxhStreetParams(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("groundTess", C.c_uint32), ("numBuildings", C.c_uint32),
                 ("facadeTess", C.c_uint32), ("numProps", C.c_uint32), ("propSubdiv", C.c_uint32),
                 ("numLamps", C.c_uint32), ("numSigns", C.c_uint32), ("extent", C.c_float),
-                ("lampEmittance", C.c_float), ("signEmittance", C.c_float)]
+                ("lampEmittance", C.c_float), ("signEmittance", C.c_float), ("textured", C.c_uint32)]
 
 
 class GfxhRestirConfig(C.Structure):
@@ -121,7 +127,8 @@ class GfxhRestirConfig(C.Structure):
                 ("maxPathLength", C.c_uint32), ("enableJittering", C.c_uint32),
                 ("regirAabbMin", C.c_float * 3), ("regirAabbMax", C.c_float * 3), ("regirGridDimension", C.c_uint32 * 3),
                 ("regirLog2CandidatesPerLightSlot", C.c_uint32), ("regirLog2CandidatesPerCell", C.c_uint32),
-                ("regirEnableTemporalReuse", C.c_uint32), ("regirEnableCellRandomization", C.c_uint32)]
+                ("regirEnableTemporalReuse", C.c_uint32), ("regirEnableCellRandomization", C.c_uint32),
+                ("enableBumpMapping", C.c_uint32)]
 
 
 class GfxhBandPlan(C.Structure):
@@ -143,7 +150,7 @@ GBUFFER3_DTYPE = np.dtype([("qShadingNormal", "<u4"), ("qShadingTangent", "<u4")
 
 # every symbol include/gfxexp.h and include/gfxexp_host.h declare
 C_ABI_SYMBOLS = [
-    "gfx_ctx_create", "gfx_ctx_destroy", "gfx_last_error", "gfx_version", "gfx_material_set", "gfx_geom_create",
+    "gfx_ctx_create", "gfx_ctx_destroy", "gfx_last_error", "gfx_version", "gfx_material_set", "gfx_texture_set", "gfx_texture_sample", "gfx_geom_create",
     "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_instance_set_transform_and_normal_matrix", "gfx_instance_set_dynamic",
     "gfx_accel_build",
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
@@ -155,7 +162,7 @@ C_ABI_SYMBOLS = [
 ]
 HOST_ABI_SYMBOLS = [
     "gfxh_scene_create", "gfxh_scene_destroy", "gfxh_last_error", "gfxh_scene_add_material_traditional",
-    "gfxh_scene_add_material", "gfxh_scene_add_geom", "gfxh_scene_add_group", "gfxh_scene_add_instance",
+    "gfxh_scene_add_material", "gfxh_scene_add_texture", "gfxh_scene_load_texture", "gfxh_scene_num_textures", "gfxh_scene_get_texture", "gfxh_scene_add_geom", "gfxh_scene_add_group", "gfxh_scene_add_instance",
     "gfxh_scene_load_obj", "gfxh_scene_add_rectangle", "gfxh_scene_make_street", "gfxh_scene_counts",
     "gfxh_scene_get_material", "gfxh_scene_get_geom", "gfxh_scene_get_group", "gfxh_scene_get_instance",
     "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
@@ -233,6 +240,33 @@ class HostScene:
 
     def add_material(self, mat):
         return self.L.gfxh_scene_add_material(self.h, C.byref(mat))
+
+    def add_texture(self, texels, fmt):
+        """texels: (H, W, 4) uint8 for the RGBA8 formats, (H, W) uint8 for R8, (H, W, 2) uint8 for RG8, (H, W, 4) float32 for
+        RGBA32F.  Returns the 1-based texture slot."""
+        t = np.ascontiguousarray(texels)
+        h, w = t.shape[0], t.shape[1]
+        slot = self.L.gfxh_scene_add_texture(self.h, C.c_uint32(w), C.c_uint32(h), C.c_uint32(fmt), _p(t))
+        if slot == 0:
+            raise GfxError(self.L.gfxh_last_error().decode())
+        return slot
+
+    def load_texture(self, path, fmt8=0):
+        slot = self.L.gfxh_scene_load_texture(self.h, path.encode(), C.c_uint32(fmt8))
+        if slot == 0:
+            raise GfxError(self.L.gfxh_last_error().decode())
+        return slot
+
+    def textures(self):
+        """[(slot, width, height, format, texel bytes)] of every texture."""
+        out = []
+        for slot in range(1, self.L.gfxh_scene_num_textures(self.h) + 1):
+            w, h, f, ptr = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_void_p()
+            self.L.gfxh_scene_get_texture(self.h, C.c_uint32(slot), C.byref(w), C.byref(h), C.byref(f), C.byref(ptr))
+            bpp = {TEX_RGBA8_SRGB: 4, TEX_RGBA8_UNORM: 4, TEX_R8_UNORM: 1, TEX_RG8_UNORM: 2, TEX_RGBA32F: 16}[f.value]
+            data = np.frombuffer((C.c_char * (bpp * w.value * h.value)).from_address(ptr.value), dtype=np.uint8).copy()
+            out.append((slot, w.value, h.value, f.value, data))
+        return out
 
     def add_geom(self, vertices, triangles, mat_slot):
         v = np.ascontiguousarray(vertices)
@@ -452,6 +486,14 @@ class Context:
         p, n = C.c_void_p(), C.c_uint32()
         self._check(self.L.gfx_accel_tri_ids(self.h, C.c_uint64(handle), C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def texture_set(self, slot, texels, fmt):
+        t = np.ascontiguousarray(texels)
+        self._check(self.L.gfx_texture_set(self.h, C.c_uint32(slot), C.c_uint32(t.shape[1]), C.c_uint32(t.shape[0]), C.c_uint32(fmt), _p(t)))
+
+    def texture_sample(self, slot, d_uv, n, d_out, gather=False, stream=0):
+        self._check(self.L.gfx_texture_sample(self.h, C.c_void_p(stream), C.c_uint32(slot), C.c_void_p(d_uv), C.c_uint32(n), C.c_void_p(d_out),
+                                              C.c_int(1 if gather else 0)))
 
     def lights_build_static(self, stream=0):
         self._check(self.L.gfx_lights_build_static(self.h, C.c_void_p(stream)))

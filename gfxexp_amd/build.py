@@ -15,7 +15,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgfxexp.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["capi.cpp", "scene.cpp", "lights.hip", "lbvh.hip", "trace.hip", "restir.hip", "pathtrace.hip", "nrc.hip",
+SOURCES = ["capi.cpp", "scene.cpp", "lights.hip", "lbvh.hip", "trace.hip", "restir.hip", "pathtrace.hip", "nrc.hip", "textures.hip",
            "host/scene_builder.cpp", "host/restir_driver.cpp", "host/nrc_driver.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
@@ -74,7 +74,7 @@ def build_variant(name, defines):
     vdir = os.path.join(HERE, "variants")
     odir = os.path.join(vdir, "obj_" + name)
     os.makedirs(odir, exist_ok=True)
-    flags = FLAGS + ["-D" + d for d in defines]
+    flags = FLAGS + [d if d.startswith("-") else "-D" + d for d in defines]
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = [o for o in ex.map(lambda r: _compile(r, odir, flags), SOURCES) if o]
     lib = os.path.join(vdir, "libgfxexp_%s.so" % name)

@@ -57,6 +57,33 @@ int gfx_material_set(gfx_ctx* ctx, uint32_t matSlot, const gfx_material* mat) {
     GFX_CATCH(ctx)
 }
 
+int gfx_texture_set(gfx_ctx* ctx, uint32_t texSlot, uint32_t width, uint32_t height, uint32_t format, const void* texels) {
+    GFX_TRY(ctx)
+    if (texSlot == 0 || texSlot > (1u << 20)) throw HipError("gfx_texture_set: texture slots are 1-based");
+    if (width == 0 || height == 0 || width > 16384 || height > 16384) throw HipError("gfx_texture_set: bad size");   // TexDimInfo: 14 bits
+    size_t bpp = 0;
+    switch (format) {
+    case GFX_TEX_RGBA8_SRGB: case GFX_TEX_RGBA8_UNORM: bpp = 4; break;
+    case GFX_TEX_R8_UNORM: bpp = 1; break;
+    case GFX_TEX_RG8_UNORM: bpp = 2; break;
+    case GFX_TEX_RGBA32F: bpp = 16; break;
+    default: throw HipError("gfx_texture_set: unknown format");
+    }
+    if (!texels) throw HipError("gfx_texture_set: null texels");
+    if (ctx->c.textures.size() <= texSlot) ctx->c.textures.resize(texSlot + 1);
+    HostTexture& t = ctx->c.textures[texSlot];
+    t.width = width; t.height = height; t.format = format;
+    t.texels.assign(static_cast<const uint8_t*>(texels), static_cast<const uint8_t*>(texels) + bpp * width * height);
+    ctx->c.sceneDirty = true;
+    GFX_CATCH(ctx)
+}
+
+int gfx_texture_sample(gfx_ctx* ctx, void* stream, uint32_t texSlot, const void* dUv, uint32_t n, void* dOut, int gather) {
+    GFX_TRY(ctx)
+    texture_sample(ctx->c, static_cast<hipStream_t>(stream), texSlot, dUv, n, dOut, gather);
+    GFX_CATCH(ctx)
+}
+
 int gfx_geom_create(gfx_ctx* ctx, const void* vertices, uint32_t vertexStride, uint32_t numVertices,
                     const uint32_t* triangles, uint32_t numTriangles, uint32_t matSlot, uint32_t* geomInstSlot) {
     GFX_TRY(ctx)

@@ -88,6 +88,24 @@ struct SubsetGeom {
     uint32_t globalBegin;
 };
 
+// One texture of the scene (gfx_texture_set): texels live in one pool of 32-bit words.
+struct DevTexture {
+    uint32_t offset;      // first word of the texels in the pool (16-byte aligned)
+    uint32_t width, height;
+    uint32_t format;      // enum gfx_tex_format
+};
+static_assert(sizeof(DevTexture) == 16, "DevTexture must be 16 bytes");
+
+// Texture coordinates of an emitter triangle + the emittance texture of its material (parallel to the emitter
+// records; read only when the scene has an emittance texture at all).
+struct EmitterTexRef {
+    float uvA[2], uvB[2], uvC[2];
+    uint32_t tex;         // texture slot or 0
+    uint32_t pad;
+    DevTexture desc;      // copy of textures[tex]: the texel loads do not wait for a descriptor fetch
+};
+static_assert(sizeof(EmitterTexRef) == 48, "EmitterTexRef must be 48 bytes");
+
 // Everything the shading kernels need to reach the scene.
 struct DevScene {
     const gfx_material* materials;
@@ -113,6 +131,11 @@ struct DevScene {
     const uint32_t* spanHeader;     // device uint32[4]: [0] table usable (verified by the build), [1] records checked
     uint32_t numSpans;
     uint32_t spanGuideCells;
+    // textures (texture.hip.h): descriptor table indexed by slot (slot 0 unused), texel pool, sRGB decode table
+    const DevTexture* textures;
+    const uint32_t* texelPool;
+    const float* srgbLut;                // float[256]
+    const EmitterTexRef* emitterTexRefs; // parallel to emitterRecs, or null when no material has an emittance texture
 };
 
 // ---------------------------------------------------------------- BVH8 in HBM

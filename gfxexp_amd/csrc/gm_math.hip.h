@@ -103,6 +103,7 @@ GFX_DEV float gm_atan_nonneg(float t) {
     p = fmaf(p, z, -3.33329491539e-1f);
     return y0 + fmaf(p * z, t, t);
 }
+GFX_DEV float gm_atan(float t) { return t < 0.0f ? -gm_atan_nonneg(-t) : gm_atan_nonneg(t); }
 GFX_DEV float gm_atan2(float y, float x) {
     if (x == 0.0f && y == 0.0f) return 0.0f;
     const float ax = fabsf(x), ay = fabsf(y);

@@ -68,6 +68,7 @@ void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_
     cfg->regirLog2CandidatesPerLightSlot = 3; cfg->regirLog2CandidatesPerCell = 2;                       // :1733-1734
     cfg->regirEnableTemporalReuse = 1; cfg->regirEnableCellRandomization = 1;                             // :1735-1736
     cfg->enableJittering = 0;
+    cfg->enableBumpMapping = 0;
     cfg->camera.aspect = static_cast<float>(width) / height;
     cfg->camera.fovY = 50 * 3.14159265358979323846f / 180;   // :1613
     const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
@@ -321,7 +322,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     fp.resetFlowBuffer = newSequence;
     fp.enableJittering = cfg.enableJittering;
     fp.enableEnvLight = r->sp.envLightTexture != nullptr;
-    fp.enableBumpMapping = 0;
+    fp.enableBumpMapping = cfg.enableBumpMapping;
 
     uint32_t currentReservoirIndex = (r->lastReservoirIndex + 1) % 2;  // :2352
     const uint32_t W = cfg.width, H = cfg.height;

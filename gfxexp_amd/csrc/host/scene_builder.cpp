@@ -9,8 +9,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cctype>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <random>
 #include <sstream>
@@ -25,6 +27,7 @@ thread_local std::string g_hostError;
 
 struct Geom { std::vector<gfx_vertex> v; std::vector<uint32_t> t; uint32_t mat; };
 struct Inst { uint32_t group; float xfm[12]; };
+struct Tex { uint32_t width = 0, height = 0, format = 0; std::vector<uint8_t> texels; };
 
 } // namespace
 
@@ -33,6 +36,8 @@ struct gfxh_scene {
     std::vector<Geom> geoms;
     std::vector<std::vector<uint32_t>> groups;
     std::vector<Inst> insts;
+    std::vector<Tex> textures;                       // textures[k] is texture slot k + 1
+    std::map<std::string, uint32_t> textureCache;    // file path + format -> slot (TextureCacheKey, common_host.cpp:1163-1182)
 };
 
 namespace {
@@ -201,6 +206,158 @@ uint32_t gfxh_scene_add_material_traditional(gfxh_scene* s, const float diffuse[
     return gfxh_scene_add_material(s, &m);
 }
 
+// ---------------------------------------------------------------- textures
+static size_t tex_bytes_per_texel(uint32_t format) {
+    switch (format) {
+    case GFX_TEX_RGBA8_SRGB: case GFX_TEX_RGBA8_UNORM: return 4;
+    case GFX_TEX_R8_UNORM: return 1;
+    case GFX_TEX_RG8_UNORM: return 2;
+    case GFX_TEX_RGBA32F: return 16;
+    default: return 0;
+    }
+}
+uint32_t gfxh_scene_add_texture(gfxh_scene* s, uint32_t width, uint32_t height, uint32_t format, const void* texels) {
+    const size_t bpp = tex_bytes_per_texel(format);
+    if (!bpp || !width || !height || !texels) { g_hostError = "gfxh_scene_add_texture: bad arguments"; return 0; }
+    Tex t;
+    t.width = width; t.height = height; t.format = format;
+    t.texels.assign(static_cast<const uint8_t*>(texels), static_cast<const uint8_t*>(texels) + bpp * width * height);
+    s->textures.push_back(std::move(t));
+    return static_cast<uint32_t>(s->textures.size());   // 1-based slot
+}
+uint32_t gfxh_scene_num_textures(gfxh_scene* s) { return static_cast<uint32_t>(s->textures.size()); }
+int gfxh_scene_get_texture(gfxh_scene* s, uint32_t slot, uint32_t* width, uint32_t* height, uint32_t* format, const void** texels) {
+    if (slot == 0 || slot > s->textures.size()) { g_hostError = "gfxh_scene_get_texture: bad slot"; return 1; }
+    const Tex& t = s->textures[slot - 1];
+    *width = t.width; *height = t.height; *format = t.format; *texels = t.texels.data();
+    return 0;
+}
+
+namespace {
+// Decoded image: 8-bit RGBA (stbi_load(..., 4) in the reference, common_host.cpp:1211-1226) or float RGBA (.pfm).
+struct Image { uint32_t w = 0, h = 0; bool isFloat = false; std::vector<uint8_t> rgba8; std::vector<float> rgba32f; };
+
+bool read_file(const std::string& path, std::vector<uint8_t>& out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return true;
+}
+// next whitespace-separated token of a Netpbm header ('#' comments skipped)
+bool pnm_token(const std::vector<uint8_t>& d, size_t& at, std::string& tok) {
+    tok.clear();
+    while (at < d.size()) {
+        if (d[at] == '#') { while (at < d.size() && d[at] != '\n') ++at; }
+        else if (std::isspace(d[at])) ++at;
+        else break;
+    }
+    while (at < d.size() && !std::isspace(d[at])) tok.push_back(static_cast<char>(d[at++]));
+    return !tok.empty();
+}
+// Uncompressed formats only (no third-party decoders in this build): binary PPM / PGM (8 bit), PFM, BMP 24 / 32 bit,
+// TGA types 2 / 3 (24 / 32 / 8 bit).  BC-compressed DDS files of the original assets are decoded offline.
+bool decode_image(const std::string& path, Image& img, std::string& err) {
+    std::vector<uint8_t> d;
+    if (!read_file(path, d)) { err = "cannot read " + path; return false; }
+    if (d.size() >= 2 && d[0] == 'P' && (d[1] == '6' || d[1] == '5')) {
+        size_t at = 2; std::string t;
+        uint32_t vals[3];
+        for (int k = 0; k < 3; ++k) { if (!pnm_token(d, at, t)) { err = "truncated PNM header"; return false; } vals[k] = static_cast<uint32_t>(std::strtoul(t.c_str(), nullptr, 10)); }
+        ++at;   // the single whitespace after maxval
+        const uint32_t ch = d[1] == '6' ? 3 : 1;
+        if (vals[2] != 255 || vals[0] == 0 || vals[1] == 0 || d.size() < at + static_cast<size_t>(vals[0]) * vals[1] * ch) { err = "unsupported PNM (8-bit binary only)"; return false; }
+        img.w = vals[0]; img.h = vals[1]; img.rgba8.resize(4ull * img.w * img.h);
+        for (size_t i = 0; i < static_cast<size_t>(img.w) * img.h; ++i) {
+            const uint8_t* px = d.data() + at + i * ch;
+            img.rgba8[4 * i] = px[0]; img.rgba8[4 * i + 1] = ch == 3 ? px[1] : px[0]; img.rgba8[4 * i + 2] = ch == 3 ? px[2] : px[0]; img.rgba8[4 * i + 3] = 255;
+        }
+        return true;
+    }
+    if (d.size() >= 2 && d[0] == 'P' && (d[1] == 'F' || d[1] == 'f')) {
+        size_t at = 2; std::string t;
+        if (!pnm_token(d, at, t)) { err = "truncated PFM header"; return false; }
+        const uint32_t w = static_cast<uint32_t>(std::strtoul(t.c_str(), nullptr, 10));
+        if (!pnm_token(d, at, t)) { err = "truncated PFM header"; return false; }
+        const uint32_t h = static_cast<uint32_t>(std::strtoul(t.c_str(), nullptr, 10));
+        if (!pnm_token(d, at, t)) { err = "truncated PFM header"; return false; }
+        const double scale = std::strtod(t.c_str(), nullptr);
+        ++at;
+        const uint32_t ch = d[1] == 'F' ? 3 : 1;
+        if (scale >= 0 || !w || !h || d.size() < at + 4ull * w * h * ch) { err = "unsupported PFM (little-endian only)"; return false; }
+        img.w = w; img.h = h; img.isFloat = true; img.rgba32f.resize(4ull * w * h);
+        for (uint32_t y = 0; y < h; ++y)   // PFM rows run bottom to top
+            for (uint32_t x = 0; x < w; ++x) {
+                float px[3] = { 0, 0, 0 };
+                std::memcpy(px, d.data() + at + 4ull * ch * (static_cast<size_t>(h - 1 - y) * w + x), 4ull * ch);
+                float* o = img.rgba32f.data() + 4ull * (static_cast<size_t>(y) * w + x);
+                o[0] = px[0]; o[1] = ch == 3 ? px[1] : px[0]; o[2] = ch == 3 ? px[2] : px[0]; o[3] = 1.0f;
+            }
+        return true;
+    }
+    if (d.size() >= 54 && d[0] == 'B' && d[1] == 'M') {
+        auto u32 = [&](size_t o) { uint32_t v; std::memcpy(&v, d.data() + o, 4); return v; };
+        auto i32 = [&](size_t o) { int32_t v; std::memcpy(&v, d.data() + o, 4); return v; };
+        const uint32_t off = u32(10); const int32_t w = i32(18), hh = i32(22);
+        uint16_t bpp; std::memcpy(&bpp, d.data() + 28, 2);
+        const uint32_t comp = u32(30);
+        if (w <= 0 || hh == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && comp != 3)) { err = "unsupported BMP (24 / 32 bit uncompressed only)"; return false; }
+        const uint32_t h = static_cast<uint32_t>(hh < 0 ? -hh : hh);
+        const size_t stride = (static_cast<size_t>(w) * (bpp / 8) + 3) & ~size_t(3);
+        if (d.size() < off + stride * h) { err = "truncated BMP"; return false; }
+        img.w = static_cast<uint32_t>(w); img.h = h; img.rgba8.resize(4ull * img.w * h);
+        for (uint32_t y = 0; y < h; ++y) {
+            const uint8_t* row = d.data() + off + stride * (hh < 0 ? y : h - 1 - y);
+            for (uint32_t x = 0; x < img.w; ++x) {
+                const uint8_t* px = row + static_cast<size_t>(x) * (bpp / 8);
+                uint8_t* o = img.rgba8.data() + 4ull * (static_cast<size_t>(y) * img.w + x);
+                o[0] = px[2]; o[1] = px[1]; o[2] = px[0]; o[3] = bpp == 32 ? px[3] : 255;
+            }
+        }
+        return true;
+    }
+    if (d.size() >= 18 && (d[2] == 2 || d[2] == 3) && d[1] == 0) {   // TGA, uncompressed true colour / grey
+        const uint32_t idLen = d[0];
+        uint16_t w, h; std::memcpy(&w, d.data() + 12, 2); std::memcpy(&h, d.data() + 14, 2);
+        const uint32_t bpp = d[16]; const bool topDown = (d[17] & 0x20) != 0;
+        const uint32_t ch = bpp / 8;
+        if (!w || !h || (d[2] == 2 && ch != 3 && ch != 4) || (d[2] == 3 && ch != 1) || d.size() < 18 + idLen + static_cast<size_t>(w) * h * ch) { err = "unsupported TGA (uncompressed 8 / 24 / 32 bit only)"; return false; }
+        img.w = w; img.h = h; img.rgba8.resize(4ull * w * h);
+        for (uint32_t y = 0; y < h; ++y)
+            for (uint32_t x = 0; x < w; ++x) {
+                const uint8_t* px = d.data() + 18 + idLen + (static_cast<size_t>(topDown ? y : h - 1 - y) * w + x) * ch;
+                uint8_t* o = img.rgba8.data() + 4ull * (static_cast<size_t>(y) * w + x);
+                if (ch == 1) { o[0] = o[1] = o[2] = px[0]; o[3] = 255; }
+                else { o[0] = px[2]; o[1] = px[1]; o[2] = px[0]; o[3] = ch == 4 ? px[3] : 255; }
+            }
+        return true;
+    }
+    err = "unsupported image format (PPM / PGM / PFM / BMP / TGA, uncompressed): " + path;
+    return false;
+}
+} // namespace
+
+// loadTexture (common_host.cpp:1163-1244): cached per path; 8-bit images become RGBA8 read through `format8`
+// (GFX_TEX_RGBA8_SRGB for colour maps = needsDegamma, GFX_TEX_RGBA8_UNORM for normal maps, GFX_TEX_R8_UNORM takes
+// the red channel); float images become GFX_TEX_RGBA32F (isHDR).  Returns the texture slot, 0 on failure.
+uint32_t gfxh_scene_load_texture(gfxh_scene* s, const char* path, uint32_t format8) {
+    const std::string key = std::string(path) + "#" + std::to_string(format8);
+    auto it = s->textureCache.find(key);
+    if (it != s->textureCache.end()) return it->second;
+    Image img; std::string err;
+    if (!decode_image(path, img, err)) { g_hostError = err; return 0; }
+    uint32_t slot = 0;
+    if (img.isFloat) slot = gfxh_scene_add_texture(s, img.w, img.h, GFX_TEX_RGBA32F, img.rgba32f.data());
+    else if (format8 == GFX_TEX_R8_UNORM || format8 == GFX_TEX_RG8_UNORM) {
+        const uint32_t ch = format8 == GFX_TEX_R8_UNORM ? 1 : 2;
+        std::vector<uint8_t> packed(static_cast<size_t>(img.w) * img.h * ch);
+        for (size_t i = 0; i < static_cast<size_t>(img.w) * img.h; ++i) for (uint32_t c = 0; c < ch; ++c) packed[i * ch + c] = img.rgba8[4 * i + c];
+        slot = gfxh_scene_add_texture(s, img.w, img.h, format8, packed.data());
+    }
+    else slot = gfxh_scene_add_texture(s, img.w, img.h, format8 == GFX_TEX_RGBA8_UNORM ? GFX_TEX_RGBA8_UNORM : GFX_TEX_RGBA8_SRGB, img.rgba8.data());
+    if (slot) s->textureCache[key] = slot;
+    return slot;
+}
+
 uint32_t gfxh_scene_add_geom(gfxh_scene* s, const gfx_vertex* v, uint32_t nv, const uint32_t* tris, uint32_t nt, uint32_t matSlot) {
     Geom g;
     g.v.assign(v, v + nv);
@@ -221,13 +378,21 @@ uint32_t gfxh_scene_add_instance(gfxh_scene* s, uint32_t group, const float xfm[
     return static_cast<uint32_t>(s->insts.size() - 1);
 }
 
+static uint32_t load_obj_impl(gfxh_scene* s, const char* path);
 uint32_t gfxh_scene_load_obj(gfxh_scene* s, const char* path) {
+    try { return load_obj_impl(s, path); }   // nothing may unwind through the C boundary
+    catch (const std::exception& e) { g_hostError = std::string("gfxh_scene_load_obj: ") + e.what(); return 0xFFFFFFFFu; }
+}
+static uint32_t load_obj_impl(gfxh_scene* s, const char* path) {
     std::ifstream in(path);
     if (!in) { g_hostError = std::string("cannot open ") + path; return 0xFFFFFFFFu; }
     const std::string dir = std::string(path).substr(0, std::string(path).find_last_of("/\\") + 1);
     std::vector<V3> pos, nrm;
     std::vector<std::pair<float, float>> uv;
-    struct MtlDesc { float kd[3] = { 0, 0, 0 }, ks[3] = { 0, 0, 0 }, ke[3] = { 0, 0, 0 }; float ns = 0; };
+    struct MtlDesc {
+        float kd[3] = { 0, 0, 0 }, ks[3] = { 0, 0, 0 }, ke[3] = { 0, 0, 0 }; float ns = 0;
+        std::string mapKd, mapKs, mapKe, mapBump, mapNormal;   // AI_MATKEY_TEXTURE_DIFFUSE / SPECULAR / EMISSIVE / HEIGHT / NORMALS
+    };
     std::map<std::string, MtlDesc> mtl;
     std::vector<std::string> matOrder;
     struct Corner { int v, t, n; };
@@ -245,6 +410,18 @@ uint32_t gfxh_scene_load_obj(gfxh_scene* s, const char* path) {
             else if (k == "Ks") ss >> mtl[cur].ks[0] >> mtl[cur].ks[1] >> mtl[cur].ks[2];
             else if (k == "Ke") ss >> mtl[cur].ke[0] >> mtl[cur].ke[1] >> mtl[cur].ke[2];
             else if (k == "Ns") ss >> mtl[cur].ns;
+            else if (k == "map_Kd" || k == "map_Ks" || k == "map_Ke" || k == "map_bump" || k == "map_Bump" || k == "bump" || k == "norm" || k == "map_Kn") {
+                // last token = file name (options such as "-bm 1.0" come before it)
+                std::string tok, file;
+                while (ss >> tok) file = tok;
+                for (char& ch : file) if (ch == '\\') ch = '/';
+                MtlDesc& d = mtl[cur];
+                if (k == "map_Kd") d.mapKd = file;
+                else if (k == "map_Ks") d.mapKs = file;
+                else if (k == "map_Ke") d.mapKe = file;
+                else if (k == "norm" || k == "map_Kn") d.mapNormal = file;
+                else d.mapBump = file;
+            }
         }
     };
     while (std::getline(in, line)) {
@@ -263,12 +440,24 @@ uint32_t gfxh_scene_load_obj(gfxh_scene* s, const char* path) {
                 int idx[3] = { 0, 0, 0 };
                 int which = 0; std::string num;
                 for (size_t i = 0; i <= tok.size(); ++i) {
-                    if (i == tok.size() || tok[i] == '/') { if (!num.empty()) idx[which] = std::stoi(num); num.clear(); ++which; if (which > 2) break; }
+                    if (i == tok.size() || tok[i] == '/') {
+                        if (!num.empty()) {
+                            char* end = nullptr;
+                            const long val = std::strtol(num.c_str(), &end, 10);
+                            if (*end != 0 || val < -2147483647L || val > 2147483647L) { g_hostError = std::string("bad face index '") + tok + "' in " + path; return 0xFFFFFFFFu; }
+                            idx[which] = static_cast<int>(val);
+                        }
+                        num.clear(); ++which; if (which > 2) break;
+                    }
                     else num.push_back(tok[i]);
                 }
                 c.v = idx[0] < 0 ? static_cast<int>(pos.size()) + idx[0] : idx[0] - 1;
                 c.t = idx[1] == 0 ? -1 : (idx[1] < 0 ? static_cast<int>(uv.size()) + idx[1] : idx[1] - 1);
                 c.n = idx[2] == 0 ? -1 : (idx[2] < 0 ? static_cast<int>(nrm.size()) + idx[2] : idx[2] - 1);
+                if (c.v < 0 || c.v >= static_cast<int>(pos.size()) || c.t >= static_cast<int>(uv.size()) || c.n >= static_cast<int>(nrm.size()) ||
+                    (idx[1] != 0 && c.t < 0) || (idx[2] != 0 && c.n < 0)) {
+                    g_hostError = std::string("face index out of range '") + tok + "' in " + path; return 0xFFFFFFFFu;
+                }
                 cs.push_back(c);
             }
             if (!facesByMat.count(curMat)) matOrder.push_back(curMat);
@@ -279,9 +468,23 @@ uint32_t gfxh_scene_load_obj(gfxh_scene* s, const char* path) {
     std::vector<uint32_t> geomSlots;
     for (const std::string& name : matOrder) {
         const MtlDesc d = mtl.count(name) ? mtl[name] : MtlDesc();
-        // smoothness = sqrt(Ns) / 11 (common_host.cpp:2271-2274)
-        const float smoothness = std::sqrt(d.ns) / 11.0f;
+        // smoothness = sqrt(Ns) / 11 (common_host.cpp:2271-2274); four Bistro pavement materials are pinned to 0.2 (:2286-2297)
+        float smoothness = std::sqrt(d.ns) / 11.0f;
+        if (name == "Pavement_Cobblestone_Big_BLENDSHADER" || name == "Pavement_Cobblestone_Small_BLENDSHADER" ||
+            name == "Pavement_Brick_BLENDSHADER" || name == "Pavement_Cobblestone_Wet_BLENDSHADER") smoothness = 0.2f;
         const uint32_t matSlot = gfxh_scene_add_material_traditional(s, d.kd, d.ks, smoothness, d.ke);
+        {   // texture maps (createDiffuseAndSpecularMaterial, common_host.cpp:1560-1700): a map that cannot be read
+            // leaves the immediate value in place
+            gfx_material& m = s->materials[matSlot];
+            if (!d.mapKd.empty()) m.texA = gfxh_scene_load_texture(s, (dir + d.mapKd).c_str(), GFX_TEX_RGBA8_SRGB);
+            if (!d.mapKs.empty()) m.texB = gfxh_scene_load_texture(s, (dir + d.mapKs).c_str(), GFX_TEX_RGBA8_SRGB);
+            const std::string& nmap = !d.mapBump.empty() ? d.mapBump : d.mapNormal;   // TEXTURE_HEIGHT first, then TEXTURE_NORMALS (:2278-2282)
+            if (!nmap.empty()) { m.texNormal = gfxh_scene_load_texture(s, (dir + nmap).c_str(), GFX_TEX_RGBA8_UNORM); m.bumpMapType = GFX_BUMP_NORMAL_MAP; }
+            if (!d.mapKe.empty()) {
+                m.texEmittance = gfxh_scene_load_texture(s, (dir + d.mapKe).c_str(), GFX_TEX_RGBA8_SRGB);
+                if (m.texEmittance) m.hasEmittance = 1u;
+            }
+        }
         const std::vector<Corner>& cs = facesByMat[name];
         Geom g; g.mat = matSlot;
         std::map<std::tuple<int, int, int>, uint32_t> dedup;   // aiProcess_JoinIdenticalVertices
@@ -357,9 +560,12 @@ int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p) {
         return gfxh_scene_add_material_traditional(s, d, sp, sm, em);
     };
     const float ident[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    uint32_t groundMat = 0, groundGeom = 0, crateMat = 0;
+    std::vector<uint32_t> wallMats, signMats;
     // ---- ground: cobbled street (height noise) as one big static instance
     {
         Geom g; g.mat = mat(0.35f, 0.33f, 0.30f, 0.2f, 0.2f);
+        groundMat = g.mat;
         std::mt19937 hgen(p->seed * 7919u + 1);
         std::vector<float> h((p->groundTess + 1) * (p->groundTess + 1));
         for (float& v : h) v = ((hgen() >> 8) * (1.0f / 16777216.0f)) * 0.02f;
@@ -367,6 +573,7 @@ int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p) {
         add_grid(g, { -E, 0, E }, { 2 * E, 0, 0 }, { 0, 0, -2 * E }, nt, nt, [&](uint32_t i, uint32_t j) { return h[j * (nt + 1) + i]; });
         s->geoms.push_back(std::move(g));
         const uint32_t gs = static_cast<uint32_t>(s->geoms.size() - 1);
+        groundGeom = gs;
         gfxh_scene_add_instance(s, gfxh_scene_add_group(s, &gs, 1), ident);
     }
     // ---- buildings: a few facade prototypes (wall grid with recessed windows + roof box), instanced
@@ -376,6 +583,7 @@ int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p) {
     for (uint32_t k = 0; k < numProto; ++k) {
         const float w = rng.range(6, 14), hgt = rng.range(8, 22), dpt = rng.range(6, 12);
         Geom wall; wall.mat = mat(rng.range(0.4f, 0.8f), rng.range(0.35f, 0.7f), rng.range(0.3f, 0.6f), 0.04f, 0.1f);
+        wallMats.push_back(wall.mat);
         Geom glass; glass.mat = mat(0.05f, 0.06f, 0.08f, 0.6f, 0.85f);
         const uint32_t ft = p->facadeTess;
         // four facades: displaced grids (window recesses) facing outward
@@ -421,6 +629,7 @@ int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p) {
         Geom sphere; sphere.mat = mat(0.55f, 0.25f, 0.2f, 0.1f, 0.5f);
         make_icosphere(sphere, p->propSubdiv, 0.5f);
         Geom crate; crate.mat = mat(0.45f, 0.32f, 0.18f, 0.03f, 0.2f);
+        crateMat = crate.mat;
         add_box(crate, { -0.5f, 0, -0.5f }, { 0.5f, 1, 0.5f });
         s->geoms.push_back(std::move(sphere));
         const uint32_t gsph = static_cast<uint32_t>(s->geoms.size() - 1);
@@ -464,6 +673,7 @@ int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p) {
         const float cols[5][3] = { { 1, 0.2f, 0.2f }, { 0.2f, 1, 0.3f }, { 0.2f, 0.4f, 1 }, { 1, 0.9f, 0.2f }, { 1, 0.3f, 0.9f } };
         for (int k = 0; k < 5; ++k) {
             Geom sign; sign.mat = mat(0.01f, 0.01f, 0.01f, 0, 0.3f, p->signEmittance * cols[k][0], p->signEmittance * cols[k][1], p->signEmittance * cols[k][2]);
+            signMats.push_back(sign.mat);
             add_grid(sign, { -0.6f, -0.2f, 0 }, { 1.2f, 0, 0 }, { 0, 0.4f, 0 }, 4, 2, [](uint32_t, uint32_t) { return 0.0f; });
             s->geoms.push_back(std::move(sign));
             const uint32_t gs = static_cast<uint32_t>(s->geoms.size() - 1);
@@ -482,6 +692,88 @@ int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p) {
             float xfm[12];
             gfxh_make_transform(rng.range(0.7f, 1.6f), 0, 0, b.yaw, wp, xfm);
             gfxh_scene_add_instance(s, signGroups[rng.gen() % 5], xfm);
+        }
+    }
+    // ---- textures (p->textured): the geometry above is unchanged, materials get maps instead of constants --
+    // cobbled ground and plastered / bricked facades with albedo, smoothness and normal maps, wooden crates, and
+    // signs whose emittance is a float texture (lettering-like stripes), so every texture fetch of the reference
+    // path is exercised: setupBSDFBody's three reads, the normal map under bump mapping, and the emittance reads of
+    // sampleLight, the shading pass and computeTriangleImportance.
+    if (p->textured) {
+        std::mt19937 tgen(p->seed * 2654435761u + 17u);
+        auto hash01 = [](uint32_t x, uint32_t y, uint32_t k) {   // integer hash -> [0, 1)
+            uint32_t h = x * 0x9E3779B1u ^ (y * 0x85EBCA77u + k * 0xC2B2AE3Du);
+            h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+            return (h >> 8) * (1.0f / 16777216.0f);
+        };
+        auto to8 = [](float v) { return static_cast<uint8_t>(std::min(255.0f, std::max(0.0f, v * 255.0f + 0.5f))); };
+        // height field of a tiling pattern: cells of (cw x ch) texels with a groove of `gap` texels, per-cell tint
+        auto tile_maps = [&](uint32_t N, uint32_t cw, uint32_t ch, uint32_t gap, bool stagger, const float base[3], float tintAmp, uint32_t salt,
+                             std::vector<uint8_t>& albedo, std::vector<uint8_t>& normal, std::vector<uint8_t>& smooth) {
+            std::vector<float> height(static_cast<size_t>(N) * N);
+            albedo.resize(4ull * N * N); normal.resize(4ull * N * N); smooth.resize(static_cast<size_t>(N) * N);
+            for (uint32_t y = 0; y < N; ++y)
+                for (uint32_t x = 0; x < N; ++x) {
+                    const uint32_t row = y / ch;
+                    const uint32_t xs = stagger && (row & 1u) ? x + cw / 2 : x;
+                    const uint32_t col = (xs / cw) % (N / cw);
+                    const uint32_t ix = xs % cw, iy = y % ch;
+                    const bool groove = ix < gap || iy < gap;
+                    const float grain = hash01(x, y, salt);
+                    const float tint = 1.0f + tintAmp * (hash01(col, row, salt + 1) - 0.5f);
+                    height[static_cast<size_t>(y) * N + x] = groove ? 0.0f : 0.7f + 0.3f * grain;
+                    uint8_t* a = albedo.data() + 4ull * (static_cast<size_t>(y) * N + x);
+                    for (int c = 0; c < 3; ++c) a[c] = to8((groove ? 0.45f : 1.0f) * base[c] * tint * (0.9f + 0.2f * grain));
+                    a[3] = 255;
+                    smooth[static_cast<size_t>(y) * N + x] = to8(groove ? 0.05f : 0.15f + 0.25f * hash01(col, row, salt + 2));
+                }
+            for (uint32_t y = 0; y < N; ++y)
+                for (uint32_t x = 0; x < N; ++x) {
+                    const float hx = height[static_cast<size_t>(y) * N + (x + 1) % N] - height[static_cast<size_t>(y) * N + (x + N - 1) % N];
+                    const float hy = height[static_cast<size_t>((y + 1) % N) * N + x] - height[static_cast<size_t>((y + N - 1) % N) * N + x];
+                    const V3 n = normalize({ -1.5f * hx, -1.5f * hy, 1.0f });
+                    uint8_t* o = normal.data() + 4ull * (static_cast<size_t>(y) * N + x);
+                    o[0] = to8(0.5f * n.x + 0.5f); o[1] = to8(0.5f * n.y + 0.5f); o[2] = to8(0.5f * n.z + 0.5f); o[3] = 255;
+                }
+        };
+        auto texture_material = [&](uint32_t matSlot, uint32_t N, uint32_t cw, uint32_t ch, uint32_t gap, bool stagger, const float base[3], float tintAmp) {
+            std::vector<uint8_t> albedo, normal, smooth;
+            tile_maps(N, cw, ch, gap, stagger, base, tintAmp, tgen(), albedo, normal, smooth);
+            gfx_material& m = s->materials[matSlot];
+            m.texA = gfxh_scene_add_texture(s, N, N, GFX_TEX_RGBA8_SRGB, albedo.data());
+            m.texSmoothness = gfxh_scene_add_texture(s, N, N, GFX_TEX_R8_UNORM, smooth.data());
+            m.texNormal = gfxh_scene_add_texture(s, N, N, GFX_TEX_RGBA8_UNORM, normal.data());
+            m.bumpMapType = GFX_BUMP_NORMAL_MAP;
+        };
+        const float cobble[3] = { 0.62f, 0.58f, 0.52f };
+        texture_material(groundMat, 256, 32, 32, 3, true, cobble, 0.5f);
+        for (gfx_vertex& v : s->geoms[groundGeom].v) { v.texCoord[0] *= 0.5f * E; v.texCoord[1] *= 0.5f * E; }   // one tile = 4 m
+        for (size_t k = 0; k < wallMats.size(); ++k) {
+            const gfx_material& wm = s->materials[wallMats[k]];
+            // bricks for every other prototype, large plaster panels for the rest; tinted by the prototype's own colour
+            const float base[3] = { std::min(1.0f, 0.35f + 1.2f * wm.a[0]), std::min(1.0f, 0.3f + 1.2f * wm.a[1]), std::min(1.0f, 0.28f + 1.2f * wm.a[2]) };
+            if (k & 1u) texture_material(wallMats[k], 256, 32, 16, 2, true, base, 0.35f);
+            else texture_material(wallMats[k], 128, 64, 64, 1, false, base, 0.12f);
+        }
+        {
+            const float wood[3] = { 0.72f, 0.52f, 0.30f };
+            texture_material(crateMat, 128, 128, 16, 1, false, wood, 0.4f);
+        }
+        for (size_t k = 0; k < signMats.size(); ++k) {   // float emittance map: bright strokes on a dim panel
+            const uint32_t W = 64, H = 32;
+            gfx_material& m = s->materials[signMats[k]];
+            std::vector<float> e(4ull * W * H);
+            const uint32_t salt = tgen();
+            for (uint32_t y = 0; y < H; ++y)
+                for (uint32_t x = 0; x < W; ++x) {
+                    const bool border = x < 2 || y < 2 || x >= W - 2 || y >= H - 2;
+                    const bool stroke = y > 8 && y < 24 && ((x / 4) % 2 == 0) && hash01(x / 4, y / 8, salt) > 0.25f;
+                    const float level = border ? 1.0f : stroke ? 1.6f : 0.25f;
+                    float* o = e.data() + 4ull * (static_cast<size_t>(y) * W + x);
+                    for (int c = 0; c < 3; ++c) o[c] = level * m.emittance[c];
+                    o[3] = 1.0f;
+                }
+            m.texEmittance = gfxh_scene_add_texture(s, W, H, GFX_TEX_RGBA32F, e.data());
         }
     }
     return 0;
@@ -528,6 +820,10 @@ int gfxh_scene_bounds(gfxh_scene* s, float bounds[6]) {
 }
 
 int gfxh_scene_upload(gfxh_scene* s, gfx_ctx* ctx) {
+    for (uint32_t t = 0; t < s->textures.size(); ++t) {
+        const Tex& tx = s->textures[t];
+        if (gfx_texture_set(ctx, t + 1, tx.width, tx.height, tx.format, tx.texels.data())) { g_hostError = gfx_last_error(ctx); return 1; }
+    }
     for (uint32_t i = 0; i < s->materials.size(); ++i)
         if (gfx_material_set(ctx, i, &s->materials[i])) { g_hostError = gfx_last_error(ctx); return 1; }
     for (const Geom& g : s->geoms) {

@@ -29,6 +29,10 @@ struct DevBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+struct HostTexture {
+    uint32_t width = 0, height = 0, format = 0;
+    std::vector<uint8_t> texels;   // tightly packed rows in `format`
+};
 struct HostGeom {
     std::vector<DevVertex> vertices;
     std::vector<uint32_t> triangles;   // 3 per triangle
@@ -85,12 +89,14 @@ struct Context {
     std::string lastError;
     // scene (host mirror)
     std::vector<gfx_material> materials;
+    std::vector<HostTexture> textures;       // indexed by slot; slot 0 stays empty ("no texture")
     std::vector<HostGeom> geoms;
     std::vector<std::vector<uint32_t>> groups;
     std::vector<HostInstance> insts;
     bool sceneDirty = true;
     // scene (device)
-    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightP, dLightCDF, dLightRefs, dEmitterRecs;
+    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightP, dLightCDF, dLightRefs, dEmitterRecs, dTextures, dTexelPool, dSrgbLut, dEmitterTexRefs;
+    bool anyEmittanceTexture = false;
     std::vector<LightGeomRef> hLightRefs;
     uint32_t numEmitterRecs = 0;
     std::vector<DevGeomInst> hGeomInsts;
@@ -181,6 +187,8 @@ struct TraceLaunch {
     DevBuf* counters = nullptr;
 };
 void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t);
+// ---- textures.hip
+void texture_sample(Context& ctx, hipStream_t stream, uint32_t texSlot, const void* dUv, uint32_t n, void* dOut, int gather);
 // ---- lights.hip
 void lights_build_static(Context& ctx, hipStream_t stream);
 void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t bufferIndex);

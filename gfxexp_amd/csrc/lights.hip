@@ -31,10 +31,15 @@ __global__ void k_triangle_importance(DevScene sc, uint32_t numGeomInsts, float*
         const f3 p0(v0.px, v0.py, v0.pz), p1(v1.px, v1.py, v1.pz), p2(v2.px, v2.py, v2.pz);
         const f3 n = cross(p1 - p0, p2 - p0);
         const float area = 0.5f * len(n);
-        // mean of the emittance at the three vertices (constant texture -> the same value thrice)
-        f3 est = f3(0.0f) + e;
-        est = est + e;
-        est = est + e;
+        // mean of the emittance texture at the three vertices (a constant reads the same value thrice)
+        f3 e0 = e, e1 = e, e2 = e;
+        if (mat.texEmittance) {
+            const float4 t0 = tex2d(sc, mat.texEmittance, v0.u, v0.v), t1 = tex2d(sc, mat.texEmittance, v1.u, v1.v), t2 = tex2d(sc, mat.texEmittance, v2.u, v2.v);
+            e0 = f3(t0.x, t0.y, t0.z); e1 = f3(t1.x, t1.y, t1.z); e2 = f3(t2.x, t2.y, t2.z);
+        }
+        f3 est = f3(0.0f) + e0;
+        est = est + e1;
+        est = est + e2;
         est = est / 3.0f;
         weights[g.distOffset + t] = luminance_srgb(est) * area;
     }
@@ -82,7 +87,8 @@ __global__ void k_inst_geom_dists(DevInstance* __restrict__ insts, uint32_t numI
 
 // Per (instance, geomInst): copy the emitter distribution's integral next to its offsets and
 // pre-transform the emitter triangles (EmitterRec, device_types.h).  One block per instance.
-__global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* __restrict__ refs, EmitterRec* __restrict__ recs) {
+__global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* __restrict__ refs, EmitterRec* __restrict__ recs,
+                                  EmitterTexRef* __restrict__ texRefs /* null: no emittance textures in the scene */) {
     const uint32_t ii = blockIdx.x;
     if (ii >= numInsts) return;
     const DevInstance* inst = sc.insts + ii;
@@ -119,6 +125,13 @@ __global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* 
             float4* dst = reinterpret_cast<float4*>(recs + recBase + t);
             const float4* src = reinterpret_cast<const float4*>(&r);
             for (int q = 0; q < 6; ++q) dst[q] = src[q];
+            if (texRefs) {
+                EmitterTexRef tr;
+                tr.uvA[0] = vA.u; tr.uvA[1] = vA.v; tr.uvB[0] = vB.u; tr.uvB[1] = vB.v; tr.uvC[0] = vC.u; tr.uvC[1] = vC.v;
+                tr.tex = mat.hasEmittance ? mat.texEmittance : 0u; tr.pad = 0u;
+                tr.desc = sc.textures[tr.tex];   // slot 0 is a zeroed entry
+                texRefs[recBase + t] = tr;
+            }
         }
     }
 }
@@ -344,7 +357,8 @@ void lights_build_static(Context& ctx, hipStream_t stream) {
                            ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>(), ctx.dLightP.as<float>());
     if (ni)
         hipLaunchKernelGGL(k_emitter_records, dim3(ni), dim3(64), 0, stream, ctx.devScene(), ni,
-                           ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>());
+                           ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(),
+                               ctx.anyEmittanceTexture ? ctx.dEmitterTexRefs.as<EmitterTexRef>() : nullptr);
     GFX_HIP(hipGetLastError());
     // keep the host mirrors of the integrals current (read by gfx_lights_read and the launch params)
     GFX_HIP(hipMemcpyAsync(ctx.hGeomInsts.data(), ctx.dGeomInsts.p, sizeof(DevGeomInst) * ng, hipMemcpyDeviceToHost, stream));
@@ -361,7 +375,8 @@ void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t /*bufferI
         const uint32_t numInsts = static_cast<uint32_t>(ctx.insts.size());
         if (numInsts)
             hipLaunchKernelGGL(k_emitter_records, dim3(numInsts), dim3(64), 0, stream, ctx.devScene(), numInsts,
-                               ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>());
+                               ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(),
+                               ctx.anyEmittanceTexture ? ctx.dEmitterTexRefs.as<EmitterTexRef>() : nullptr);
         GFX_HIP(hipGetLastError());
         ctx.emitterRecsDirty = false;
     }

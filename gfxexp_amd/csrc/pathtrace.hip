@@ -274,12 +274,14 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_first(PtArgs a) {
         const f3 vOut = unit(cam.pos - pos);
         const float frontHit = dot(vOut, ng) >= 0.0f ? 1.0f : -1.0f;
         pos = offset_ray_origin(pos, frontHit * ng);
+        const float tu = bcA * vA.u + bcB * vB.u + bcC * vC.u, tv = bcA * vA.v + bcB * vB.v + bcC * vC.v;
         frame = Frame(ns, tc0);
+        if (a.f.enableBumpMapping) apply_bump_mapping(read_modified_normal(a.scene, mat, tu, tv), frame);
         vOutLocal = frame.to_local(vOut);
         contribution = f3(0.0f);
         if (vOutLocal.z > 0 && mat.hasEmittance)
-            contribution = contribution + alpha * f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]) / kPi;
-        bsdf.setup(mat);
+            contribution = contribution + alpha * material_emittance(a.scene, mat, tu, tv) / kPi;
+        bsdf.setup(a.scene, mat, tu, tv);
     }
     else if (p < a.pixelEnd && envEnabled) {
         contribution = a.f.envLightPowerCoeff * env.fetch(decode_bc(g0.w & 0xFFFF), decode_bc(g0.w >> 16));
@@ -409,11 +411,13 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_bounce(PtArgs a) {
             const gfx_material& mat = a.scene.materials[g.materialSlot];
             const f3 vOut = unit(-rayDir);
             const float frontHit = dot(vOut, ng) >= 0.0f ? 1.0f : -1.0f;
+            const float tu = bcA * vA.u + bcB * vB.u + bcC * vC.u, tv = bcA * vA.v + bcB * vB.v + bcC * vC.v;
             frame = Frame(ns, tc0);
+            if (a.f.enableBumpMapping) apply_bump_mapping(read_modified_normal(a.scene, mat, tu, tv), frame);
             pos = offset_ray_origin(pos, frontHit * ng);
             vOutLocal = frame.to_local(vOut);
             if (vOutLocal.z > 0 && mat.hasEmittance) {
-                const f3 emittance(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+                const f3 emittance = material_emittance(a.scene, mat, tu, tv);
                 const float dist2 = len2(rayOrg - pos);
                 const float lightPDensity = hypAreaPDensity * dist2 / vOutLocal.z;
                 const float misWeight = (prevDirPDensity * prevDirPDensity) / (prevDirPDensity * prevDirPDensity + lightPDensity * lightPDensity);
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_bounce(PtArgs a) {
             const float continueProb = fminf(luminance_srgb(alpha) / luminance_srgb(f3(1.0f)), 1.0f);
             if (!(rng.uniform() >= continueProb || a.maxLengthTerminate)) {
                 alpha = alpha / continueProb;
-                bsdf.setup(mat);
+                bsdf.setup(a.scene, mat, tu, tv);
                 shade = true;
             }
         }
@@ -731,12 +735,14 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_first(PtArgs a) {
         const float frontHit = primaryDotVN >= 0.0f ? 1.0f : -1.0f;
         pos = offset_ray_origin(pos, frontHit * ng);
         primaryPathSpread = primaryDist2 / (4 * kPi * fabsf(primaryDotVN));
+        const float tu = bcA * vA.u + bcB * vB.u + bcC * vC.u, tv = bcA * vA.v + bcB * vB.v + bcC * vC.v;
         frame = Frame(ns, tc0);
+        if (a.f.enableBumpMapping) apply_bump_mapping(read_modified_normal(a.scene, mat, tu, tv), frame);
         vOutLocal = frame.to_local(vOut);
         contribution = f3(0.0f);
         if (vOutLocal.z > 0 && mat.hasEmittance)
-            contribution = contribution + alpha * f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]) / kPi;
-        bsdf.setup(mat);
+            contribution = contribution + alpha * material_emittance(a.scene, mat, tu, tv) / kPi;
+        bsdf.setup(a.scene, mat, tu, tv);
     }
     else if (inImage && envEnabled) {
         contribution = a.f.envLightPowerCoeff * env.fetch(decode_bc(g0.w & 0xFFFF), decode_bc(g0.w >> 16));
@@ -872,13 +878,15 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
             const gfx_material& mat = a.scene.materials[g.materialSlot];
             vOut = unit(-rayDir);
             const float frontHit = dot(vOut, ng) >= 0.0f ? 1.0f : -1.0f;
+            const float tu = bcA * vA.u + bcB * vB.u + bcC * vC.u, tv = bcA * vA.v + bcB * vB.v + bcC * vC.v;
             frame = Frame(ns, tc0);
+            if (a.f.enableBumpMapping) apply_bump_mapping(read_modified_normal(a.scene, mat, tu, tv), frame);
             pos = offset_ray_origin(pos, frontHit * ng);
             vOutLocal = frame.to_local(vOut);
             const float dist2 = len2(rayOrg - pos);
             curSqrtPathSpread += sqrtf(dist2 / (prevDirPDensity * fabsf(vOutLocal.z)));
             if (vOutLocal.z > 0 && mat.hasEmittance) {
-                const f3 emittance(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+                const f3 emittance = material_emittance(a.scene, mat, tu, tv);
                 const float lightPDensity = hypAreaPDensity * dist2 / vOutLocal.z;
                 const float misWeight = (prevDirPDensity * prevDirPDensity) / (prevDirPDensity * prevDirPDensity + lightPDensity * lightPDensity);
                 const f3 implicit = emittance * (misWeight / kPi);
@@ -902,7 +910,7 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
                 }
                 recContinueProb = 1.0f / continueProb;
             }
-            bsdf.setup(mat);
+            bsdf.setup(a.scene, mat, tu, tv);
             if (!stop) {   // cache termination heuristic (:479-538)
                 bool endsWithCache = curSqrtPathSpread * curSqrtPathSpread > 0.01f * primaryPathSpread;
                 if (unbiasedSuffix) endsWithCache = false;
@@ -1107,8 +1115,12 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_visualize(PtArgs a) {
         vOut = vOut / sqrtf(len2(vOut));
         const float frontHit = dot(vOut, ng) >= 0.0f ? 1.0f : -1.0f;
         pos = offset_ray_origin(pos, frontHit * ng);
-        Bsdf bsdf; bsdf.setup(a.scene.materials[g.materialSlot]);
-        nrc_store_query(a.nrc.inferenceRadianceQueryBuffer, p, nrc_make_query(a, pos, ns, vOut, bsdf));
+        const gfx_material& mat = a.scene.materials[g.materialSlot];
+        const float tu = bcA * vA.u + bcB * vB.u + bcC * vC.u, tv = bcA * vA.v + bcB * vB.v + bcC * vC.v;
+        Frame frame(ns, tc0);
+        if (a.f.enableBumpMapping) apply_bump_mapping(read_modified_normal(a.scene, mat, tu, tv), frame);
+        Bsdf bsdf; bsdf.setup(a.scene, mat, tu, tv);
+        nrc_store_query(a.nrc.inferenceRadianceQueryBuffer, p, nrc_make_query(a, pos, frame.n, vOut, bsdf));
     }
     static_cast<float4*>(a.nrc.inferenceTerminalInfoBuffer)[p] = make_float4(1.0f, 1.0f, 1.0f, bits2f(nrc_terminal_bits(surface, 1, false, false)));
 }

@@ -108,9 +108,12 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
         }
         qGeomNormal = encode_dir(geomNormalInWorld);
         qTexCoord = encode_uv(tu, tv);
-        Bsdf bsdf; bsdf.setup(a.scene.materials[matSlot]);
-        const Frame frame(shadingNormalInWorld, tc0DirInWorld);
+        const gfx_material& mat = a.scene.materials[matSlot];
+        Bsdf bsdf; bsdf.setup(a.scene, mat, tu, tv);
+        Frame frame(shadingNormalInWorld, tc0DirInWorld);
+        if (a.f.enableBumpMapping) apply_bump_mapping(read_modified_normal(a.scene, mat, tu, tv), frame);
         const f3 vOutLocal = frame.to_local(unit(-direction));
+        shadingNormalInWorld = frame.n;
         qTangent = encode_dir(frame.t);
         albedo = bsdf.dh_reflectance_estimate(vOutLocal);
     }
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
 #ifndef GFX_INIT_WAVES   // experiment switch (tools/sessions): waves per SIMD the register allocation of the kernel targets
 #define GFX_INIT_WAVES 4
 #endif
+template <bool EMITTER_TEX>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
             float pd;
             const float u0 = rng.uniform();
             const float u1 = rng.uniform();
-            sample_light(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
+            sample_light<EMITTER_TEX>(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
             const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
             pd *= probCurType;
             const float target = target_weight(cont);
@@ -558,8 +562,9 @@ __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
             recPDF = static_cast<const float2*>(a.s.reservoirInfoBuffer[a.curRes])[p].x;
             contribution = f3(0.0f);
             if (sp.vOutLocal.z > 0) {
-                f3 e(0.0f);
-                if (mat.hasEmittance) e = f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+                float tu, tv;
+                decode_uv(g3.z, tu, tv);
+                const f3 e = material_emittance(a.scene, mat, tu, tv);
                 contribution = contribution + e / kPi;
             }
             if (recPDF > 0 && is_finite(recPDF)) {
@@ -704,7 +709,8 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
             const size_t numPx = a.pixelEnd - a.pixelBegin;
             const uint32_t grid = static_cast<uint32_t>((numPx + kBlock - 1) / kBlock);
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
-            hipLaunchKernelGGL(k_initial_candidates, dim3(grid), dim3(kBlock), 0, stream, a);
+            if (a.scene.emitterTexRefs) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);
             GFX_HIP(hipGetLastError());
         }
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);

@@ -104,7 +104,9 @@ GFX_DEV void make_shading_point(const RestirArgs& a, uint32_t bufIdx, size_t p, 
     sp.pos = offset_ray_origin(pos, frontHit * ng);
     sp.frame = Frame(decode_dir(g3.x), decode_dir(g3.y));
     sp.vOutLocal = sp.frame.to_local(vOut);
-    sp.bsdf.setup(a.scene.materials[g3.w]);
+    float tu, tv;
+    decode_uv(g3.z, tu, tv);
+    sp.bsdf.setup(a.scene, a.scene.materials[g3.w], tu, tv);
 }
 
 // restir_di_shared.h:747-771

@@ -386,8 +386,9 @@ __global__ __launch_bounds__(kBlock) void k_rearch_shade(RestirArgs a) {
         const gfx_material& mat = a.scene.materials[g3.w];
         contribution = f3(0.0f);
         if (sp.vOutLocal.z > 0) {
-            f3 e(0.0f);
-            if (mat.hasEmittance) e = f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+            float tu, tv;
+            decode_uv(g3.z, tu, tv);
+            const f3 e = material_emittance(a.scene, mat, tu, tv);
             contribution = contribution + e / kPi;
         }
         uint32_t* visBuf = static_cast<uint32_t*>(a.s.sampleVisibilityBuffer[bufIdx]);

@@ -9,7 +9,7 @@ namespace gfx {
 
 Context::~Context() {
     for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->triIds.release(); a->rootBoxes.release(); delete a; } }
-    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dSubset[0], &dSubset[1], &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs,
+    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dSubset[0], &dSubset[1], &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs, &dTextures, &dTexelPool, &dSrgbLut, &dEmitterTexRefs,
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
                       &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide, &dSpans, &dSpanGuide, &dSpanHeader, &dSpanInstBegin,
@@ -41,6 +41,10 @@ DevScene Context::devScene() const {
     s.spanHeader = dSpanHeader.as<uint32_t>();
     s.numSpans = numEmitterRecs;
     s.spanGuideCells = spanGuideCells;
+    s.textures = dTextures.as<DevTexture>();
+    s.texelPool = dTexelPool.as<uint32_t>();
+    s.srgbLut = dSrgbLut.as<float>();
+    s.emitterTexRefs = anyEmittanceTexture ? dEmitterTexRefs.as<EmitterTexRef>() : nullptr;
     s.lightInstDistOffset = lightInstDistOffset;
     s.numInsts = static_cast<uint32_t>(insts.size());
     return s;
@@ -217,6 +221,39 @@ void scene_upload(Context& ctx, hipStream_t stream) {
         GFX_HIP(hipMemsetAsync(ctx.dSpanHeader.p, 0, 16, stream));
     }
 
+    {   // textures: descriptor table + one texel pool (every texture 16-byte aligned) + the sRGB decode table
+        std::vector<DevTexture> descs(std::max<size_t>(ctx.textures.size(), 1));
+        std::vector<uint32_t> pool;
+        for (size_t t = 0; t < ctx.textures.size(); ++t) {
+            const HostTexture& ht = ctx.textures[t];
+            DevTexture& d = descs[t];
+            d.offset = static_cast<uint32_t>(pool.size()); d.width = ht.width; d.height = ht.height; d.format = ht.format;
+            const size_t words = (ht.texels.size() + 3) / 4;
+            const size_t at = pool.size();
+            pool.resize(at + ((words + 3) & ~size_t(3)), 0u);
+            if (!ht.texels.empty()) std::memcpy(pool.data() + at, ht.texels.data(), ht.texels.size());
+        }
+        if (pool.empty()) pool.resize(4, 0u);
+        if (pool.size() >= (1ull << 32)) throw HipError("gfx: texel pool exceeds 16 GiB");
+        float lut[256];
+        for (int c = 0; c < 256; ++c) {   // sampler_sRGB: degamma of c / 255 (basic_types.h:5396-5402), fp32
+            const float v = static_cast<float>(c) / 255.0f;
+            lut[c] = v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f);
+        }
+        upload(ctx.dTextures, descs, stream);
+        upload(ctx.dTexelPool, pool, stream);
+        ctx.dSrgbLut.reserve(sizeof(lut));
+        GFX_HIP(hipMemcpyAsync(ctx.dSrgbLut.p, lut, sizeof(lut), hipMemcpyHostToDevice, stream));
+        GFX_HIP(hipStreamSynchronize(stream));
+        for (const gfx_material& m : ctx.materials) {
+            const uint32_t slots[5] = { m.texA, m.texB, m.texSmoothness, m.texNormal, m.texEmittance };
+            for (uint32_t sl : slots)
+                if (sl != 0 && (sl >= ctx.textures.size() || ctx.textures[sl].width == 0)) throw HipError("gfx: material references a texture slot that was never set");
+        }
+        ctx.anyEmittanceTexture = false;
+        for (const HostGeom& g : ctx.geoms)
+            if (g.materialSlot < ctx.materials.size() && ctx.materials[g.materialSlot].hasEmittance && ctx.materials[g.materialSlot].texEmittance != 0) ctx.anyEmittanceTexture = true;
+    }
     upload(ctx.dMaterials, ctx.materials, stream);
     upload(ctx.dGeomInsts, ctx.hGeomInsts, stream);
     upload(ctx.dInsts, ctx.hInsts, stream);
@@ -229,6 +266,7 @@ void scene_upload(Context& ctx, hipStream_t stream) {
     ctx.transformsDirty = false; ctx.movedInsts.clear(); ctx.emitterRecsDirty = false; ctx.instDistValid = false;
     upload(ctx.dLightRefs, ctx.hLightRefs, stream);
     ctx.dEmitterRecs.reserve(std::max<size_t>(sizeof(EmitterRec) * ctx.numEmitterRecs, 16));
+    ctx.dEmitterTexRefs.reserve(std::max<size_t>(ctx.anyEmittanceTexture ? sizeof(EmitterTexRef) * ctx.numEmitterRecs : 0, 16));
     ctx.dLightW.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
     ctx.dLightCDF.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
     ctx.dLightP.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));

@@ -15,6 +15,7 @@
 #pragma once
 #include "device_types.h"
 #include "gm_math.hip.h"
+#include "texture.hip.h"
 
 namespace gfx {
 
@@ -145,6 +146,65 @@ struct Frame {
     }
 };
 
+GFX_DEV void decode_uv(uint32_t q, float& u, float& v) {   // decodeTexCoords, common_device.cuh:72-78
+    u = (q & 0xFFFFu) / 65535.0f;
+    v = (q >> 16) / 65535.0f;
+}
+
+// mat.emittance read: RGB of tex2DLod(mat.emittance, texCoord, 0) (optix_restir_di_kernels.cu:595-599)
+GFX_DEV f3 material_emittance(const DevScene& sc, const gfx_material& m, float u, float v) {
+    if (!m.hasEmittance) return f3(0.0f);
+    if (m.texEmittance) { const float4 t = tex2d(sc, m.texEmittance, u, v); return f3(t.x, t.y, t.z); }
+    return f3(m.emittance[0], m.emittance[1], m.emittance[2]);
+}
+
+// readModifiedNormalFromNormalMap / ...2ch / ...FromHeightMap (common/common_device.cuh:205-240).
+// No normal texture = the reference's 1x1 (0.5, 0.5, 1) texture (common_host.cpp:1399-1403) read as a normal map.
+GFX_DEV f3 read_modified_normal(const DevScene& sc, const gfx_material& m, float u, float v) {
+    const uint32_t kind = m.bumpMapType & 0xFFu;
+    f3 n;
+    if (!m.texNormal) n = 2.0f * f3(0.5f, 0.5f, 1.0f) - f3(1.0f);
+    else if (kind == GFX_BUMP_NORMAL_MAP) {
+        const float4 t = tex2d(sc, m.texNormal, u, v);
+        n = 2.0f * f3(t.x, t.y, t.z) - f3(1.0f);
+    }
+    else if (kind == GFX_BUMP_NORMAL_MAP_2CH) {
+        const float4 t = tex2d(sc, m.texNormal, u, v);
+        const float x = 2.0f * t.x - 1.0f, y = 2.0f * t.y - 1.0f;
+        n = f3(x, y, sqrtf(1.0f - sq(x) - sq(y)));
+    }
+    else {
+        const float4 h = tex2d_gather_r(sc, m.texNormal, u, v);
+        const DevTexture t = sc.textures[m.texNormal];
+        constexpr float coeff = 5.0f / 1024;
+        const float dhdu = (coeff * t.width) * (h.y - h.x);
+        const float dhdv = (coeff * t.height) * (h.x - h.w);
+        return unit(f3(-dhdu, dhdv, 1));     // height maps ignore isLeftHanded in the reference
+    }
+    if (m.bumpMapType & GFX_BUMP_LEFT_HANDED) n.y *= -1;
+    return n;
+}
+
+// applyBumpMapping, common/common_device.cuh:176-203
+GFX_DEV void apply_bump_mapping(f3 modNormalInTF, Frame& frame) {
+    const float projLength = sqrtf(modNormalInTF.x * modNormalInTF.x + modNormalInTF.y * modNormalInTF.y);
+    if (projLength < 1e-3f) return;
+    const float tiltAngle = gm_atan(projLength / modNormalInTF.z);
+    float qSin, qCos;
+    gm_sincos(tiltAngle / 2, qSin, qCos);
+    const float qX = (-modNormalInTF.y / projLength) * qSin;
+    const float qY = (modNormalInTF.x / projLength) * qSin;
+    const float qW = qCos;
+    const f3 modTangentInTF(1 - 2 * qY * qY, 2 * qX * qY, -2 * qY * qW);
+    const f3 modBitangentInTF(2 * qX * qY, 1 - 2 * qX * qX, 2 * qX * qW);
+    // matTFtoW = columns (tangent, bitangent, normal); ReferenceFrame(t, b, n) keeps the three vectors as given
+    Frame out;
+    out.t = frame.from_local(modTangentInTF);
+    out.b = frame.from_local(modBitangentInTF);
+    out.n = frame.from_local(modNormalInTF);
+    frame = out;
+}
+
 GFX_DEV void concentric_disk(float u0, float u1, float& dx, float& dy) { // common_device.cuh:285-318
     const float sx = 2 * u0 - 1, sy = 2 * u1 - 1;
     if (sx == 0 && sy == 0) { dx = 0; dy = 0; return; }
@@ -176,19 +236,29 @@ struct Bsdf {
     f3 specularF0;
     float roughness;
 
-    GFX_DEV void setup(const gfx_material& m) {
+    // setupBSDFBody<> (common/common_device.cuh:376-385, 778-826): every value is tex2DLod(texture, texCoord, 0);
+    // texture slot 0 = the constant of the material (the reference's 1x1 immediate texture)
+    GFX_DEV void setup(const DevScene& sc, const gfx_material& m, float u, float v) {
         type = m.bsdfType;
-        diffuse = f3(m.a[0], m.a[1], m.a[2]);
+        f3 a(m.a[0], m.a[1], m.a[2]);
+        if (m.texA) { const float4 t = tex2d(sc, m.texA, u, v); a = f3(t.x, t.y, t.z); }
+        diffuse = a;
         specularF0 = f3(0.0f);
         roughness = 1.0f;
         if (type == GFX_BSDF_DIFFUSE_AND_SPECULAR) {
-            specularF0 = f3(m.b[0], m.b[1], m.b[2]);
-            roughness = 1 - fmin2(m.smoothness, 0.999f);
+            f3 b(m.b[0], m.b[1], m.b[2]);
+            if (m.texB) { const float4 t = tex2d(sc, m.texB, u, v); b = f3(t.x, t.y, t.z); }
+            float smooth = m.smoothness;
+            if (m.texSmoothness) smooth = tex2d(sc, m.texSmoothness, u, v).x;
+            specularF0 = b;
+            roughness = 1 - fmin2(smooth, 0.999f);
         }
         else if (type == GFX_BSDF_SIMPLE_PBR) {
-            const f3 base = diffuse;
-            const float smoothness = fmin2(1.0f - m.b[1], 0.999f);
-            const float metallic = m.b[2];
+            f3 orm(m.b[0], m.b[1], m.b[2]);
+            if (m.texB) { const float4 t = tex2d(sc, m.texB, u, v); orm = f3(t.x, t.y, t.z); }
+            const f3 base = a;
+            const float smoothness = fmin2(1.0f - orm.y, 0.999f);
+            const float metallic = orm.z;
             diffuse = base * (1 - metallic);
             specularF0 = f3(0.16f * sq(0.5f) * (1 - metallic)) + base * metallic;
             roughness = 1 - smoothness;
@@ -550,6 +620,9 @@ GFX_DEV LightPick light_select(const DevScene& sc, float ul) {
 }
 
 // The rest of sampleLight<false> for a picked record: point on the triangle, normal, emittance, area density.
+// EMITTER_TEX = false compiles the emittance-texture read out (kernels instantiate both and the host picks by
+// whether any emitter material has an emittance texture).
+template <bool EMITTER_TEX = true>
 GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, float u1, LightSample& ls, float& areaPDensity) {
     // EmitterRec: world-space triangle, 2 / |ng| and the primitive's probability tabulated at build time
     const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + pk.rec);
@@ -571,6 +644,19 @@ GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, floa
     const f3 n = bcA * nA + bcB * nB + bcC * nC;
     ls.normal = unit(mul(normalMatrix, n));
     ls.emittance = f3(r4.z, r4.w, r5.x);
+    if (EMITTER_TEX && sc.emitterTexRefs) {   // scene-uniform: some material has an emittance texture (restir_di_shared.h:504-514)
+        const float4* tp = reinterpret_cast<const float4*>(sc.emitterTexRefs + pk.rec);
+        const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+        const uint32_t tex = f2bits(t1.z);
+        if (tex) {
+            const float tu = bcA * t0.x + bcB * t0.z + bcC * t1.x;
+            const float tv = bcA * t0.y + bcB * t0.w + bcC * t1.y;
+            DevTexture desc;
+            desc.offset = f2bits(t2.x); desc.width = f2bits(t2.y); desc.height = f2bits(t2.z); desc.format = f2bits(t2.w);
+            const float4 tv4 = tex2d_desc(sc, desc, tu, tv);
+            ls.emittance = f3(1.0f) * f3(tv4.x, tv4.y, tv4.z);
+        }
+    }
 }
 
 GFX_DEV void sample_env_light(const EnvMap& env, float envRotation, float envPowerCoeff, float u0, float u1, LightSample& ls, float& areaPDensity) {
@@ -592,13 +678,14 @@ GFX_DEV void sample_env_light(const EnvMap& env, float envRotation, float envPow
 
 // sampleLight<false>.  Returns the area density; sample left untouched past an early out exactly
 // like the reference (the caller starts from a default-constructed LightSample).
+template <bool EMITTER_TEX = true>
 GFX_DEV void sample_light(const DevScene& sc,
                           const EnvMap& env, float envRotation, float envPowerCoeff,
                           float ul, bool sampleEnv, float u0, float u1, LightSample& ls, float& areaPDensity) {
     if (sampleEnv) { sample_env_light(env, envRotation, envPowerCoeff, u0, u1, ls, areaPDensity); return; }
     const LightPick pk = light_select(sc, ul);
     if (!pk.ok) { areaPDensity = 0.0f; return; }
-    light_fetch(sc, pk, u0, u1, ls, areaPDensity);
+    light_fetch<EMITTER_TEX>(sc, pk, u0, u1, ls, areaPDensity);
 }
 
 // Geometry of a shadow ray toward a light sample (restir_di_shared.h:524-545, 564-581).

@@ -12,8 +12,9 @@ from gfxexp_amd import api
 ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets")
 
 
-def small_street(seed=7, scale=1):
+def small_street(seed=7, scale=1, textured=False):
     p = api.GfxhStreetParams()
+    p.textured = int(textured)
     p.seed = seed
     p.groundTess = 24 * scale
     p.numBuildings = 8
@@ -30,9 +31,12 @@ def small_street(seed=7, scale=1):
     return s
 
 
-def bench_street(seed=2024):
-    """The Bistro-Exterior stand-in used by bench.py (2.55 M instanced triangles, 2 745 instances, 2 100 emitters)."""
+def bench_street(seed=2024, textured=False):
+    """The Bistro-Exterior stand-in used by bench.py (2.55 M instanced triangles, 2 745 instances, 2 100 emitters).
+    textured=True: the same geometry with albedo / smoothness / normal maps on ground, facades and crates and float
+    emittance maps on the signs (gfxh_scene_make_street, `textured`)."""
     p = api.GfxhStreetParams()
+    p.textured = int(textured)
     p.seed = seed
     p.groundTess = 512
     p.numBuildings = 44

@@ -35,12 +35,21 @@ typedef struct gfx_vertex {
     float texCoord[2];
 } gfx_vertex;
 
-/* Constant-colour material = what the reference's 1x1 "immediate" textures return from tex2DLod
- * (common/common_host.cpp:1045-1073,1602-1659).  Values are the *sampled* (linear) values. */
+/* Materials.  Every value of shared::MaterialData (common/common_shared.h:1144-1177) is a texture read through
+ * tex2DLod at mip level 0 (common/common_device.cuh:143-147, 778-826).  Here a value is either a texture slot
+ * (gfx_texture_set; slots are 1-based, 0 = none) or, with slot 0, the constant a / b / smoothness / emittance: what
+ * the reference's 1x1 "immediate" textures return (common/common_host.cpp:1045-1073, 1602-1659), i.e. the *sampled*
+ * (linear) value. */
 enum gfx_bsdf_type {
     GFX_BSDF_LAMBERT = 0,              /* common/common_device.cuh:335-374 */
     GFX_BSDF_DIFFUSE_AND_SPECULAR = 1, /* common/common_device.cuh:443-765 */
     GFX_BSDF_SIMPLE_PBR = 2            /* common/common_device.cuh:767-776 */
+};
+enum gfx_bump_type {                   /* BumpMapTextureType -> readModifiedNormal*, common/common_device.cuh:205-240 */
+    GFX_BUMP_NORMAL_MAP = 0,           /* RGB normal map: n = 2 t - 1 */
+    GFX_BUMP_NORMAL_MAP_2CH = 1,       /* two channels, z = sqrt(1 - x^2 - y^2) */
+    GFX_BUMP_HEIGHT_MAP = 2,           /* finite differences of the four texels under the bilinear footprint */
+    GFX_BUMP_LEFT_HANDED = 0x100       /* flag: flip y (TexDimInfo::isLeftHanded) */
 };
 typedef struct gfx_material {
     uint32_t bsdfType;
@@ -49,7 +58,24 @@ typedef struct gfx_material {
     float smoothness;    /* diffuse+specular only */
     float emittance[3];
     uint32_t hasEmittance; /* "mat.emittance != 0" in the reference */
+    uint32_t texA;          /* texture slot for a (reflectance | diffuse | baseColor_opacity), 0 = the constant */
+    uint32_t texB;          /* texture slot for b (specular | occlusion_roughness_metallic), 0 = the constant */
+    uint32_t texSmoothness; /* one-channel texture for smoothness, 0 = the constant */
+    uint32_t texNormal;     /* normal / height map read when gfx_restir_frame_params.enableBumpMapping, 0 = flat (0.5, 0.5, 1) */
+    uint32_t texEmittance;  /* 0 = the constant */
+    uint32_t bumpMapType;   /* enum gfx_bump_type, optionally | GFX_BUMP_LEFT_HANDED */
+    uint32_t pad[2];
 } gfx_material;
+
+/* Texel formats and the sampler each one is read through (createTextureObject, common/common_host.cpp:1462-1481):
+ * all samplers are bilinear, wrap = repeat in both directions, mip level 0. */
+enum gfx_tex_format {
+    GFX_TEX_RGBA8_SRGB = 0,   /* 8-bit RGBA, sampler_sRGB: R, G, B decoded sRGB -> linear per texel, A / 255 */
+    GFX_TEX_RGBA8_UNORM = 1,  /* 8-bit RGBA, sampler_normFloat: c / 255 */
+    GFX_TEX_R8_UNORM = 2,     /* one 8-bit channel (smoothness, height maps) */
+    GFX_TEX_RG8_UNORM = 3,    /* two 8-bit channels (two-channel normal maps, BC5 decoded offline) */
+    GFX_TEX_RGBA32F = 4       /* float RGBA, sampler_float (HDR emittance) */
+};
 
 /* restir_di/restir_di_shared.h:182-204 -- same element structs, row-major linear arrays. */
 typedef struct gfx_gbuffer0 { uint32_t instSlot, geomInstSlot, primIndex; uint16_t qbcB, qbcC; } gfx_gbuffer0;
@@ -92,8 +118,19 @@ const char* gfx_version(void);
 
 /* ---------------------------------------------------------------- scene --------------------- */
 
-/* common/common_host.cpp:1454-1815 (create*Material) reduced to constant colours. */
+/* common/common_host.cpp:1454-1815 (create*Material): constants and / or texture slots. */
 int gfx_material_set(gfx_ctx* ctx, uint32_t matSlot, const gfx_material* mat);
+/* Texture upload (loadTexture + cudau::Array::write + createTextureObject, common/common_host.cpp:1163-1244,
+ * 1462-1481).  texSlot >= 1; texels are tightly packed rows, row 0 first, in `format`.
+ * The CUDA texture unit is replaced by a software tex2DLod with a written contract ("Textures"):
+ *   x = (u - floor(u)) * W - 0.5, i = floor(x), alpha = round_to_8_fraction_bits(x - i)   (likewise y, beta)
+ *   T = ((1-alpha)(1-beta)) T[i,j] + (alpha (1-beta)) T[i+1,j] + ((1-alpha) beta) T[i,j+1] + (alpha beta) T[i+1,j+1]
+ * with indices wrapped modulo W / H, fp32 arithmetic in exactly this order, 8-bit texels decoded per texel
+ * before filtering (c / 255, or the exact sRGB formula rounded to fp32). */
+int gfx_texture_set(gfx_ctx* ctx, uint32_t texSlot, uint32_t width, uint32_t height, uint32_t format, const void* texels);
+/* Inspection: tex2DLod<float4> (gather = 0) or tex2Dgather<float4> of component 0 (gather = 1) of one texture at n
+ * coordinates; dUv = device float2[n], dOut = device float4[n].  Runs the functions the shading kernels call. */
+int gfx_texture_sample(gfx_ctx* ctx, void* stream, uint32_t texSlot, const void* dUv, uint32_t n, void* dOut, int gather);
 
 /* common/common_host.cpp:1817-1905 createGeometryInstance: host vertex/triangle arrays in,
  * geomInstSlot out.  `vertexStride` >= sizeof(gfx_vertex). */

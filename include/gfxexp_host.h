@@ -33,6 +33,16 @@ uint32_t gfxh_scene_add_material_traditional(gfxh_scene* s, const float diffuse[
 /* Raw material (values as sampled). */
 uint32_t gfxh_scene_add_material(gfxh_scene* s, const gfx_material* m);
 
+/* Textures.  Slots are 1-based (0 = "no texture" in gfx_material).  gfxh_scene_load_texture is loadTexture
+ * (common_host.cpp:1163-1244) for the formats this build decodes itself -- binary PPM / PGM, PFM, uncompressed BMP and
+ * TGA; DDS / PNG / JPEG assets are converted offline -- cached per path: 8-bit images are stored as `format8`
+ * (GFX_TEX_RGBA8_SRGB for colour maps, GFX_TEX_RGBA8_UNORM for normal maps, GFX_TEX_R8_UNORM / RG8 take the first
+ * channels), float images as GFX_TEX_RGBA32F.  Both return the slot, 0 on failure. */
+uint32_t gfxh_scene_add_texture(gfxh_scene* s, uint32_t width, uint32_t height, uint32_t format, const void* texels);
+uint32_t gfxh_scene_load_texture(gfxh_scene* s, const char* path, uint32_t format8);
+uint32_t gfxh_scene_num_textures(gfxh_scene* s);
+int gfxh_scene_get_texture(gfxh_scene* s, uint32_t slot, uint32_t* width, uint32_t* height, uint32_t* format, const void** texels);
+
 /* Geometry / groups / instances (return slot indices). */
 uint32_t gfxh_scene_add_geom(gfxh_scene* s, const gfx_vertex* v, uint32_t nv, const uint32_t* tris, uint32_t nt, uint32_t matSlot);
 uint32_t gfxh_scene_add_group(gfxh_scene* s, const uint32_t* geomSlots, uint32_t n);
@@ -59,6 +69,7 @@ typedef struct gfxh_street_params {
     float extent;               /* half size of the street block in metres */
     float lampEmittance;
     float signEmittance;
+    uint32_t textured;          /* 1: ground / facades / crates get albedo + smoothness + normal maps, signs a float emittance map */
 } gfxh_street_params;
 int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p);
 
@@ -135,6 +146,7 @@ typedef struct gfxh_restir_config {
     uint32_t regirLog2CandidatesPerCell;      /* 2 */
     uint32_t regirEnableTemporalReuse;        /* 1 */
     uint32_t regirEnableCellRandomization;    /* 1 */
+    uint32_t enableBumpMapping;               /* 0 (restir_di_main.cpp:1986); normal maps through applyBumpMapping */
 } gfxh_restir_config;
 
 void gfxh_restir_default_config(gfxh_restir_config* cfg, uint32_t width, uint32_t height, int renderer);

@@ -23,7 +23,9 @@ def build(force=False):
 
 class GfxMaterial(C.Structure):
     _fields_ = [("bsdfType", C.c_uint32), ("a", C.c_float * 3), ("b", C.c_float * 3),
-                ("smoothness", C.c_float), ("emittance", C.c_float * 3), ("hasEmittance", C.c_uint32)]
+                ("smoothness", C.c_float), ("emittance", C.c_float * 3), ("hasEmittance", C.c_uint32),
+                ("texA", C.c_uint32), ("texB", C.c_uint32), ("texSmoothness", C.c_uint32), ("texNormal", C.c_uint32),
+                ("texEmittance", C.c_uint32), ("bumpMapType", C.c_uint32), ("pad", C.c_uint32 * 2)]
 
 
 class GfxCamera(C.Structure):
@@ -130,6 +132,17 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+    def set_texture(self, slot, width, height, fmt, texel_bytes):
+        t = np.ascontiguousarray(texel_bytes)
+        self.L.orc_texture_set(self.h, C.c_uint32(slot), C.c_uint32(width), C.c_uint32(height), C.c_uint32(fmt), _p(t))
+
+    def texture_sample(self, slot, uv, gather=False):
+        """tex2DLod (or tex2Dgather of component 0) of texture `slot` at uv (n, 2) -> (n, 4) float32."""
+        c = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        out = np.zeros((len(c), 4), np.float32)
+        self.L.orc_texture_sample(self.h, C.c_uint32(slot), _p(c), C.c_uint32(len(c)), _p(out), C.c_int(1 if gather else 0))
+        return out
 
     def set_threads(self, n):
         self.threads = n

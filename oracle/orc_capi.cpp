@@ -41,7 +41,28 @@ int orc_material_set(orc_scene* s, uint32_t slot, const gfx_material* m) {
     for (int i = 0; i < 3; ++i) { d.a[i] = m->a[i]; d.b[i] = m->b[i]; d.emittance[i] = m->emittance[i]; }
     d.smoothness = m->smoothness;
     d.hasEmittance = m->hasEmittance;
+    d.texA = m->texA; d.texB = m->texB; d.texSmoothness = m->texSmoothness; d.texNormal = m->texNormal; d.texEmittance = m->texEmittance;
+    d.bumpMapType = m->bumpMapType;
     return 0;
+}
+
+int orc_texture_set(orc_scene* s, uint32_t slot, uint32_t width, uint32_t height, uint32_t format, const void* texels) {
+    if (slot == 0) return 1;
+    if (s->scene.textures.size() <= slot) s->scene.textures.resize(slot + 1);
+    Texture& t = s->scene.textures[slot];
+    const size_t bpp = format == TexRGBA32F ? 16 : format == TexR8_UNorm ? 1 : format == TexRG8_UNorm ? 2 : 4;
+    t.width = width; t.height = height; t.format = format; t.lutReady = false;
+    t.texels.assign(static_cast<const uint8_t*>(texels), static_cast<const uint8_t*>(texels) + bpp * width * height);
+    return 0;
+}
+
+// tex2DLod / tex2Dgather of one texture at n coordinates (tests of the sampler contract)
+void orc_texture_sample(orc_scene* s, uint32_t slot, const float* uv, uint32_t n, float* out4, int gather) {
+    const Texture& t = s->scene.textures[slot];
+    for (uint32_t i = 0; i < n; ++i) {
+        const Texel4 r = gather ? t.gatherR(uv[2 * i], uv[2 * i + 1]) : t.sample(uv[2 * i], uv[2 * i + 1]);
+        out4[4 * i] = r.x; out4[4 * i + 1] = r.y; out4[4 * i + 2] = r.z; out4[4 * i + 3] = r.w;
+    }
 }
 
 int orc_geom_create(orc_scene* s, const void* vertices, uint32_t stride, uint32_t numVertices,
@@ -473,7 +494,7 @@ void orc_bsdf_eval(const gfx_material* m, int mode, const float* vGiven3, const 
     MaterialData d; d.bsdfType = m->bsdfType;
     for (int i = 0; i < 3; ++i) { d.a[i] = m->a[i]; d.b[i] = m->b[i]; d.emittance[i] = m->emittance[i]; }
     d.smoothness = m->smoothness; d.hasEmittance = m->hasEmittance;
-    BSDF b; b.setup(d);
+    const TextureTable noTextures; BSDF b; b.setup(noTextures, d, V2{ 0.0f, 0.0f });   // constants only
     for (uint32_t i = 0; i < n; ++i) {
         const V3 vg(vGiven3[3 * i], vGiven3[3 * i + 1], vGiven3[3 * i + 2]);
         const V3 vs(vSampled3[3 * i], vSampled3[3 * i + 1], vSampled3[3 * i + 2]);

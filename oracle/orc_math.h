@@ -119,6 +119,7 @@ static inline float gm_atan_pos(float t) { // t >= 0
     p = std::fma(p, z, -3.33329491539e-1f);
     return y0 + std::fma(p * z, t, t);
 }
+static inline float gm_atan(float t) { return t < 0.0f ? -gm_atan_pos(-t) : gm_atan_pos(t); }
 static inline float gm_atan2(float y, float x) {
     if (x == 0.0f && y == 0.0f) return 0.0f;
     const float ax = std::fabs(x), ay = std::fabs(y);

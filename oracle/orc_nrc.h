@@ -183,14 +183,18 @@ static inline void nrcTraceVertex(const PathTraceParams& p, const NrcState& ns, 
     const MaterialData& mat = scene.materials[hg.materialSlot];
     const V3 vOut = normalize(-rayDir);
     const float frontHit = dot(vOut, geometricNormalInWorld) >= 0.0f ? 1.0f : -1.0f;
-    const ReferenceFrame shadingFrame(shadingNormalInWorld, texCoord0DirInWorld);
+    ReferenceFrame shadingFrame(shadingNormalInWorld, texCoord0DirInWorld);
+    if (p.f->enableBumpMapping) {
+        const V3 modLocalNormal = readModifiedNormal(scene.textures, mat, texCoord);
+        applyBumpMapping(modLocalNormal, &shadingFrame);
+    }
     positionInWorld = offsetRayOrigin(positionInWorld, frontHit * geometricNormalInWorld);
     const V3 vOutLocal = shadingFrame.toLocal(vOut);
     const float dist2 = sqLength(rayOrg - positionInWorld);
     pl.curSqrtPathSpread += std::sqrt(dist2 / (pl.prevDirPDensity * std::fabs(vOutLocal.z)));
 
     if (vOutLocal.z > 0 && mat.hasEmittance) {
-        const RGB emittance(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+        const RGB emittance = materialEmittance(scene.textures, mat, texCoord);
         const float lightPDensity = hypAreaPDensity * dist2 / vOutLocal.z;
         const float bsdfPDensity = pl.prevDirPDensity;
         const float misWeight = pow2(bsdfPDensity) / (pow2(bsdfPDensity) + pow2(lightPDensity));
@@ -215,7 +219,7 @@ static inline void nrcTraceVertex(const PathTraceParams& p, const NrcState& ns, 
         }
         recContinueProb = 1.0f / continueProb;
     }
-    BSDF bsdf; bsdf.setup(mat);
+    BSDF bsdf; bsdf.setup(scene.textures, mat, texCoord);
     {
         bool endsWithCache = false;
         const bool pathIsSpreadEnough = pow2(pl.curSqrtPathSpread) > kPathTerminationFactor * pl.primaryPathSpread;
@@ -323,14 +327,18 @@ static inline void nrcPathTracePixel(const PathTraceParams& p, const NrcState& n
             const float frontHit = primaryDotVN >= 0.0f ? 1.0f : -1.0f;
             positionInWorld = offsetRayOrigin(positionInWorld, frontHit * geometricNormalInWorld);
             primaryPathSpread = primaryDist2 / (4 * kPi * std::fabs(primaryDotVN));
-            const ReferenceFrame shadingFrame(shadingNormalInWorld, texCoord0DirInWorld);
+            ReferenceFrame shadingFrame(shadingNormalInWorld, texCoord0DirInWorld);
+            if (p.f->enableBumpMapping) {
+                const V3 modLocalNormal = readModifiedNormal(scene.textures, mat, texCoord);
+                applyBumpMapping(modLocalNormal, &shadingFrame);
+            }
             const V3 vOutLocal = shadingFrame.toLocal(vOut);
             contribution = RGB(0.0f);
             if (vOutLocal.z > 0 && mat.hasEmittance) {
-                const RGB emittance(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+                const RGB emittance = materialEmittance(scene.textures, mat, texCoord);
                 contribution += alpha * emittance / kPi;
             }
-            BSDF bsdf; bsdf.setup(mat);
+            BSDF bsdf; bsdf.setup(scene.textures, mat, texCoord);
             const RGB directContNEE = nrcNextEventEstimation(p, visFn, positionInWorld, vOutLocal, shadingFrame, bsdf, rng);
             contribution += alpha * directContNEE;
             V3 vInLocal;
@@ -496,8 +504,12 @@ static inline void visualizePredictionPixel(const PathTraceParams& p, const NrcS
         vOut /= std::sqrt(primaryDist2);
         const float frontHit = dot(vOut, geometricNormalInWorld) >= 0.0f ? 1.0f : -1.0f;
         positionInWorld = offsetRayOrigin(positionInWorld, frontHit * geometricNormalInWorld);
-        const ReferenceFrame shadingFrame(shadingNormalInWorld, texCoord0DirInWorld);
-        BSDF bsdf; bsdf.setup(mat);
+        ReferenceFrame shadingFrame(shadingNormalInWorld, texCoord0DirInWorld);
+        if (p.f->enableBumpMapping) {
+            const V3 modLocalNormal = readModifiedNormal(scene.textures, mat, texCoord);
+            applyBumpMapping(modLocalNormal, &shadingFrame);
+        }
+        BSDF bsdf; bsdf.setup(scene.textures, mat, texCoord);
         float roughness; RGB diffuseReflectance, specularReflectance;
         bsdf.getSurfaceParameters(&diffuseReflectance, &specularReflectance, &roughness);
         ns.inferenceQueries()[i] = createRadianceQuery(ns, positionInWorld, shadingFrame.normal, vOut, roughness, diffuseReflectance, specularReflectance);

@@ -183,14 +183,18 @@ static inline void pathTracePixel(const PathTraceParams& p, int x, int y) {
             const V3 vOut = normalize(p.camera.position - positionInWorld);
             const float frontHit = dot(vOut, geometricNormalInWorld) >= 0.0f ? 1.0f : -1.0f;
             positionInWorld = offsetRayOrigin(positionInWorld, frontHit * geometricNormalInWorld);
-            const ReferenceFrame shadingFrame(shadingNormalInWorld, texCoord0DirInWorld);
+            ReferenceFrame shadingFrame(shadingNormalInWorld, texCoord0DirInWorld);
+            if (p.f->enableBumpMapping) {   // optix_pathtracing_kernels.cu:117-121
+                const V3 modLocalNormal = readModifiedNormal(scene.textures, mat, texCoord);
+                applyBumpMapping(modLocalNormal, &shadingFrame);
+            }
             const V3 vOutLocal = shadingFrame.toLocal(vOut);
             contribution = RGB(0.0f);
             if (vOutLocal.z > 0 && mat.hasEmittance) {
-                const RGB emittance(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+                const RGB emittance = materialEmittance(scene.textures, mat, texCoord);
                 contribution += alpha * emittance / kPi;
             }
-            BSDF bsdf; bsdf.setup(mat);
+            BSDF bsdf; bsdf.setup(scene.textures, mat, texCoord);
             contribution += alpha * performNextEventEstimation(p, visFn, positionInWorld, vOutLocal, shadingFrame, bsdf, rng);
             V3 vInLocal;
             const float u0 = rng.getFloat0cTo1o();
@@ -244,11 +248,15 @@ static inline void pathTracePixel(const PathTraceParams& p, int x, int y) {
             const MaterialData& mat = scene.materials[hg.materialSlot];
             const V3 vOut = normalize(-rayDir);
             const float frontHit = dot(vOut, gn) >= 0.0f ? 1.0f : -1.0f;
-            const ReferenceFrame shadingFrame(sn, tc0);
+            ReferenceFrame shadingFrame(sn, tc0);
+            if (p.f->enableBumpMapping) {   // :251-255
+                const V3 modLocalNormal = readModifiedNormal(scene.textures, mat, tc);
+                applyBumpMapping(modLocalNormal, &shadingFrame);
+            }
             const V3 posOff = offsetRayOrigin(pos, frontHit * gn);
             const V3 vOutLocal = shadingFrame.toLocal(vOut);
             if (vOutLocal.z > 0 && mat.hasEmittance) {
-                const RGB emittance(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+                const RGB emittance = materialEmittance(scene.textures, mat, tc);
                 const V3 dd = rayOrg - posOff;   // sqDistance(rayOrigin, positionInWorld) AFTER the offset (:256-274)
                 const float dist2 = sqLength(dd);
                 const float lightPDensity = hypAreaPDensity * dist2 / vOutLocal.z;
@@ -259,7 +267,7 @@ static inline void pathTracePixel(const PathTraceParams& p, int x, int y) {
             const float continueProb = std::fmin(sRGB_calcLuminance(alpha) / initImportance, 1.0f);
             if (rng.getFloat0cTo1o() >= continueProb || maxLengthTerminate) break;
             alpha /= continueProb;
-            BSDF bsdf; bsdf.setup(mat);
+            BSDF bsdf; bsdf.setup(scene.textures, mat, tc);
             contribution += alpha * performNextEventEstimation(p, visFn, posOff, vOutLocal, shadingFrame, bsdf, rng);
             V3 vInLocal;
             float dpd;

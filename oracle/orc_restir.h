@@ -216,9 +216,12 @@ static inline void setupGBuffersPixel(const Params& p, int x, int y) {
         }
         qGeometricNormalInWorld = encodeNormal(geometricNormalInWorld);
         qTexCoord = encodeTexCoords(texCoord);
-        BSDF bsdf; bsdf.setup(mat);
-        const ReferenceFrame shadingFrame(shadingNormalInWorld, texCoord0DirInWorld);
-        // bump mapping is out of scope (constant 1x1 normal map == identity)
+        BSDF bsdf; bsdf.setup(scene.textures, mat, texCoord);
+        ReferenceFrame shadingFrame(shadingNormalInWorld, texCoord0DirInWorld);
+        if (p.f->enableBumpMapping) {   // :170-173
+            const V3 modLocalNormal = readModifiedNormal(scene.textures, mat, texCoord);
+            applyBumpMapping(modLocalNormal, &shadingFrame);
+        }
         const V3 vOut = -direction;
         const V3 vOutLocal = shadingFrame.toLocal(normalize(vOut));
         shadingNormalInWorld = shadingFrame.normal;
@@ -310,7 +313,7 @@ static inline void initialAndTemporalRISPixel(const Params& p, bool withTemporal
     const V3 shadingTangentInWorld = decodeVector(gb3.qShadingTangent);
     const ReferenceFrame shadingFrame(shadingNormalInWorld, shadingTangentInWorld);
     const V3 vOutLocal = shadingFrame.toLocal(vOut);
-    BSDF bsdf; bsdf.setup(mat);
+    BSDF bsdf; bsdf.setup(scene.textures, mat, decodeTexCoords(gb3.qTexCoord));
 
     const VisibilityFn visFn = [&p](V3 o, V3 d, float t0, float t1) { return !occluded(*p.accel, o, d, t0, t1); };
     const uint32_t curResIndex = p.currentReservoirIndex;
@@ -404,7 +407,7 @@ static inline void initialAndTemporalRISPixel(const Params& p, bool withTemporal
                 const float nbFrontHit = dot(nbVOut, nbGeometricNormalInWorld) >= 0.0f ? 1.0f : -1.0f;
                 nbPositionInWorld = offsetRayOrigin(nbPositionInWorld, nbFrontHit * nbGeometricNormalInWorld);
                 const MaterialData& nbMat = scene.materials[nb3.matSlot];
-                BSDF nbBsdf; nbBsdf.setup(nbMat);
+                BSDF nbBsdf; nbBsdf.setup(scene.textures, nbMat, decodeTexCoords(nb3.qTexCoord));
                 const V3 nbShadingNormalInWorld = decodeNormal(nb3.qShadingNormal);
                 const V3 nbShadingTangentInWorld = decodeVector(nb3.qShadingTangent);
                 const ReferenceFrame nbShadingFrame(nbShadingNormalInWorld, nbShadingTangentInWorld);
@@ -471,7 +474,7 @@ static inline void spatialRISPixel(const Params& p, bool useUnbiasedEstimator, i
     const ReferenceFrame shadingFrame(decodeNormal(gb3.qShadingNormal), decodeVector(gb3.qShadingTangent));
     const V3 vOutLocal = shadingFrame.toLocal(vOut);
     const MaterialData& mat = scene.materials[gb3.matSlot];
-    BSDF bsdf; bsdf.setup(mat);
+    BSDF bsdf; bsdf.setup(scene.textures, mat, decodeTexCoords(gb3.qTexCoord));
     const VisibilityFn visFn = [&p](V3 o, V3 d, float t0, float t1) { return !occluded(*p.accel, o, d, t0, t1); };
 
     const uint32_t srcResIndex = p.currentReservoirIndex;
@@ -539,7 +542,7 @@ static inline void spatialRISPixel(const Params& p, bool useUnbiasedEstimator, i
                     const float nbFrontHit = dot(nbVOut, nbGeometricNormalInWorld) >= 0.0f ? 1.0f : -1.0f;
                     nbPositionInWorld = offsetRayOrigin(nbPositionInWorld, nbFrontHit * nbGeometricNormalInWorld);
                     const MaterialData& nbMat = scene.materials[nb3.matSlot];
-                    BSDF nbBsdf; nbBsdf.setup(nbMat);
+                    BSDF nbBsdf; nbBsdf.setup(scene.textures, nbMat, decodeTexCoords(nb3.qTexCoord));
                     const ReferenceFrame nbShadingFrame(decodeNormal(nb3.qShadingNormal), decodeVector(nb3.qShadingTangent));
                     const V3 nbVOutLocal = nbShadingFrame.toLocal(nbVOut);
                     const Reservoir neighbor = readReservoir(p, srcResIndex, ni);
@@ -588,15 +591,14 @@ static inline void shadingPixel(const Params& p, int x, int y) {
         const ReferenceFrame shadingFrame(decodeNormal(gb3.qShadingNormal), decodeVector(gb3.qShadingTangent));
         const V3 vOutLocal = shadingFrame.toLocal(vOut);
         const MaterialData& mat = scene.materials[gb3.matSlot];
-        BSDF bsdf; bsdf.setup(mat);
+        BSDF bsdf; bsdf.setup(scene.textures, mat, decodeTexCoords(gb3.qTexCoord));
         const VisibilityFn visFn = [&p](V3 o, V3 d, float t0, float t1) { return !occluded(*p.accel, o, d, t0, t1); };
         const uint32_t curResIndex = p.currentReservoirIndex;
         const Reservoir reservoir = readReservoir(p, curResIndex, i);
         const gfx_reservoir_info reservoirInfo = static_cast<const gfx_reservoir_info*>(p.s->reservoirInfoBuffer[curResIndex])[i];
         contribution = RGB(0.0f);
         if (vOutLocal.z > 0) {
-            RGB emittance(0.0f, 0.0f, 0.0f);
-            if (mat.hasEmittance) emittance = RGB(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+            const RGB emittance = materialEmittance(scene.textures, mat, decodeTexCoords(gb3.qTexCoord));   // :594-599
             contribution += emittance / kPi;
         }
         const LightSample lightSample = reservoir.sample;

@@ -80,7 +80,7 @@ static inline void rearchShadingPoint(const Params& p, uint32_t bufIdx, size_t i
     sp->positionInWorld = offsetRayOrigin(positionInWorld, frontHit * geometricNormalInWorld);
     sp->shadingFrame = ReferenceFrame(decodeNormal(gb3.qShadingNormal), decodeVector(gb3.qShadingTangent));
     sp->vOutLocal = sp->shadingFrame.toLocal(sp->vOut);
-    sp->bsdf.setup(p.scene->materials[gb3.matSlot]);
+    sp->bsdf.setup(p.scene->textures, p.scene->materials[gb3.matSlot], decodeTexCoords(gb3.qTexCoord));
     sp->dist = 0;
 }
 
@@ -337,8 +337,7 @@ static inline void shadeAndResamplePixel(const Params& p, bool withTemporalRIS, 
         const MaterialData& mat = scene.materials[gb3.matSlot];
         contribution = RGB(0.0f);
         if (sp.vOutLocal.z > 0) {
-            RGB emittance(0.0f, 0.0f, 0.0f);
-            if (mat.hasEmittance) emittance = RGB(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+            const RGB emittance = materialEmittance(scene.textures, mat, decodeTexCoords(gb3.qTexCoord));
             contribution += emittance / kPi;
         }
         uint32_t* visBuf = static_cast<uint32_t*>(p.s->sampleVisibilityBuffer[curBufIdx]);

@@ -70,6 +70,7 @@ struct EnvLight {
 
 struct Scene {
     std::vector<MaterialData> materials;
+    TextureTable textures;   // indexed by slot, slot 0 unused
     std::vector<GeometryInstanceData> geomInsts;
     std::vector<InstanceData> insts;
     std::vector<float> lightInstWeights, lightInstCDF;
@@ -98,10 +99,13 @@ struct Scene {
         const V3 normal = cross(v1.position - v0.position, v2.position - v0.position);
         const float area = 0.5f * length(normal);
         RGB emittanceEstimate(0.0f, 0.0f, 0.0f);
-        const RGB e(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
-        emittanceEstimate += e;
-        emittanceEstimate += e;
-        emittanceEstimate += e;
+        auto fetch = [&](const Vertex& v) {   // tex2DLod<float4>(mat.emittance, v.texCoord, 0)
+            if (mat.texEmittance) { const Texel4 t = textures[mat.texEmittance].sample(v.texCoord.x, v.texCoord.y); return RGB(t.x, t.y, t.z); }
+            return RGB(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+        };
+        emittanceEstimate += fetch(v0);
+        emittanceEstimate += fetch(v1);
+        emittanceEstimate += fetch(v2);
         emittanceEstimate /= 3;
         return sRGB_calcLuminance(emittanceEstimate) * area;
     }
@@ -218,10 +222,13 @@ static inline void sampleLight(
         lightSample->atInfinity = false;
         lightSample->normal = bcA * vA.normal + bcB * vB.normal + bcC * vC.normal;
         lightSample->normal = normalize(mul(inst.normalMatrix, lightSample->normal));
-        if (mat.hasEmittance) {
+        if (mat.hasEmittance) {   // :504-508
             hasTexEmittance = true;
-            texValue = RGB(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
             emittance = RGB(1.0f, 1.0f, 1.0f);
+            const V2 texCoord{ bcA * vA.texCoord.x + bcB * vB.texCoord.x + bcC * vC.texCoord.x,
+                               bcA * vA.texCoord.y + bcB * vB.texCoord.y + bcC * vC.texCoord.y };
+            if (mat.texEmittance) { const Texel4 t = scene.textures[mat.texEmittance].sample(texCoord.x, texCoord.y); texValue = RGB(t.x, t.y, t.z); }
+            else texValue = RGB(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
         }
     }
     if (hasTexEmittance)

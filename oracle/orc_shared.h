@@ -9,6 +9,7 @@
 // (unspecified order in C++), this restatement draws LEFT TO RIGHT.
 #pragma once
 #include "orc_math.h"
+#include "orc_texture.h"
 
 namespace orc {
 
@@ -241,6 +242,26 @@ struct ReferenceFrame {
 };
 
 // common/common_device.cuh:285-324
+// applyBumpMapping, common/common_device.cuh:176-203
+static inline void applyBumpMapping(V3 modNormalInTF, ReferenceFrame* frameToModify) {
+    const float projLength = std::sqrt(modNormalInTF.x * modNormalInTF.x + modNormalInTF.y * modNormalInTF.y);
+    if (projLength < 1e-3f) return;
+    const float tiltAngle = gm_atan(projLength / modNormalInTF.z);
+    float qSin, qCos;
+    gm_sincos(tiltAngle / 2, &qSin, &qCos);
+    const float qX = (-modNormalInTF.y / projLength) * qSin;
+    const float qY = (modNormalInTF.x / projLength) * qSin;
+    const float qW = qCos;
+    const V3 modTangentInTF(1 - 2 * qY * qY, 2 * qX * qY, -2 * qY * qW);
+    const V3 modBitangentInTF(2 * qX * qY, 1 - 2 * qX * qX, 2 * qX * qW);
+    // matTFtoW = Matrix3x3(tangent, bitangent, normal) (columns); M * v = (dot(row_k, v))
+    ReferenceFrame bumpShadingFrame;
+    bumpShadingFrame.tangent = frameToModify->fromLocal(modTangentInTF);
+    bumpShadingFrame.bitangent = frameToModify->fromLocal(modBitangentInTF);
+    bumpShadingFrame.normal = frameToModify->fromLocal(modNormalInTF);
+    *frameToModify = bumpShadingFrame;
+}
+
 static inline void concentricSampleDisk(float u0, float u1, float* dx, float* dy) {
     float r, theta;
     const float sx = 2 * u0 - 1;
@@ -267,8 +288,9 @@ static inline V3 cosineSampleHemisphere(float u0, float u1) {
 }
 
 // ---------------------------------------------------------------- BSDFs
-// Flattened "constant colour" MaterialData (common/common_shared.h:1144-1177 with the 1x1
-// immediate textures of common/common_host.cpp:1045-1073 replaced by their sampled values).
+// MaterialData (common/common_shared.h:1144-1177): every value is a texture slot (1-based index into the
+// scene's textures) or, with slot 0, the sampled value of the reference's 1x1 immediate texture
+// (common/common_host.cpp:1045-1073).
 struct MaterialData {
     uint32_t bsdfType;   // 0 Lambert, 1 DiffuseAndSpecular, 2 SimplePBR
     float a[3];
@@ -276,7 +298,47 @@ struct MaterialData {
     float smoothness;
     float emittance[3];
     uint32_t hasEmittance;
+    uint32_t texA = 0, texB = 0, texSmoothness = 0, texNormal = 0, texEmittance = 0;
+    uint32_t bumpMapType = 0;   // 0 normal map, 1 two-channel normal map, 2 height map; | 0x100 left-handed
 };
+using TextureTable = std::vector<Texture>;
+
+// mat.emittance read at a surface point (optix_restir_di_kernels.cu:595-599; path tracers likewise)
+static inline RGB materialEmittance(const TextureTable& textures, const MaterialData& mat, V2 texCoord) {
+    if (!mat.hasEmittance) return RGB(0.0f, 0.0f, 0.0f);
+    if (mat.texEmittance) { const Texel4 t = textures[mat.texEmittance].sample(texCoord.x, texCoord.y); return RGB(t.x, t.y, t.z); }
+    return RGB(mat.emittance[0], mat.emittance[1], mat.emittance[2]);
+}
+
+// readModifiedNormalFromNormalMap / ...2ch / ...FromHeightMap, common/common_device.cuh:205-240
+static inline V3 readModifiedNormal(const TextureTable& textures, const MaterialData& mat, V2 texCoord) {
+    const uint32_t kind = mat.bumpMapType & 0xFFu;
+    const bool leftHanded = (mat.bumpMapType & 0x100u) != 0;
+    V3 modLocalNormal;
+    if (!mat.texNormal) {   // the 1x1 (0.5, 0.5, 1) normal texture of materials without a normal map (common_host.cpp:1399-1403)
+        modLocalNormal = 2.0f * V3(0.5f, 0.5f, 1.0f) - V3(1.0f);
+    }
+    else if (kind == 0) {
+        const Texel4 t = textures[mat.texNormal].sample(texCoord.x, texCoord.y);
+        modLocalNormal = 2.0f * V3(t.x, t.y, t.z) - V3(1.0f);
+    }
+    else if (kind == 1) {
+        const Texel4 t = textures[mat.texNormal].sample(texCoord.x, texCoord.y);
+        const float x = 2.0f * t.x - 1.0f, y = 2.0f * t.y - 1.0f;
+        const float z = std::sqrt(1.0f - pow2(x) - pow2(y));
+        modLocalNormal = V3(x, y, z);
+    }
+    else {
+        const Texture& tex = textures[mat.texNormal];
+        const Texel4 h = tex.gatherR(texCoord.x, texCoord.y);
+        constexpr float coeff = (5.0f / 1024);
+        const float dhdu = (coeff * tex.width) * (h.y - h.x);
+        const float dhdv = (coeff * tex.height) * (h.x - h.w);
+        return normalize(V3(-dhdu, dhdv, 1));
+    }
+    if (leftHanded) modLocalNormal.y *= -1;
+    return modLocalNormal;
+}
 
 // One struct covers LambertBRDF (common_device.cuh:335-374) and DiffuseAndSpecularBRDF /
 // SimplePBR_BRDF (:443-776); dispatch follows BSDF::setup/evaluate (:890-963).
@@ -286,21 +348,27 @@ struct BSDF {
     RGB specularF0Color;
     float roughness = 0;
 
-    // setupBSDFBody<> :376-385, 778-826
-    void setup(const MaterialData& mat) {
+    // setupBSDFBody<> :376-385, 778-826: every value is sample<>(texture, texCoord, mipLevel 0)
+    void setup(const TextureTable& textures, const MaterialData& mat, V2 texCoord) {
         type = mat.bsdfType;
+        RGB valA(mat.a[0], mat.a[1], mat.a[2]);
+        if (mat.texA) { const Texel4 t = textures[mat.texA].sample(texCoord.x, texCoord.y); valA = RGB(t.x, t.y, t.z); }
+        RGB valB(mat.b[0], mat.b[1], mat.b[2]);
+        if (mat.texB && type != 0) { const Texel4 t = textures[mat.texB].sample(texCoord.x, texCoord.y); valB = RGB(t.x, t.y, t.z); }
         if (type == 0) {
-            diffuseColor = RGB(mat.a[0], mat.a[1], mat.a[2]);
+            diffuseColor = valA;
         }
         else if (type == 1) {
-            diffuseColor = RGB(mat.a[0], mat.a[1], mat.a[2]);
-            specularF0Color = RGB(mat.b[0], mat.b[1], mat.b[2]);
-            roughness = 1 - fmin2(mat.smoothness, 0.999f);               // :518-523, 802
+            float smoothness = mat.smoothness;
+            if (mat.texSmoothness) smoothness = textures[mat.texSmoothness].sample(texCoord.x, texCoord.y).x;
+            diffuseColor = valA;
+            specularF0Color = valB;
+            roughness = 1 - fmin2(smoothness, 0.999f);               // :518-523, 802
         }
         else {
-            const RGB baseColor(mat.a[0], mat.a[1], mat.a[2]);
-            const float smoothness = fmin2(1.0f - mat.b[1], 0.999f);        // :819
-            const float metallic = mat.b[2];
+            const RGB baseColor = valA;
+            const float smoothness = fmin2(1.0f - valB.y, 0.999f);          // :819
+            const float metallic = valB.z;
             const float reflectance = 0.5f;                                 // :825
             diffuseColor = baseColor * (1 - metallic);                      // :772
             specularF0Color = RGB(0.16f * pow2(reflectance) * (1 - metallic)) + baseColor * metallic;

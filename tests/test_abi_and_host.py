@@ -34,7 +34,7 @@ def test_struct_layouts_match_between_product_and_oracle_bindings():
                  (api.GfxRestirStaticParams, O.GfxRestirStaticParams), (api.GfxRestirFrameParams, O.GfxRestirFrameParams)):
         assert C.sizeof(a) == C.sizeof(b)
         assert [f[0] for f in a._fields_] == [f[0] for f in b._fields_]
-    assert C.sizeof(api.GfxMaterial) == 48 and api.VERTEX_DTYPE.itemsize == 44
+    assert C.sizeof(api.GfxMaterial) == 80 and api.VERTEX_DTYPE.itemsize == 44
     assert api.GBUFFER0_DTYPE.itemsize == 16 and api.GBUFFER2_DTYPE.itemsize == 16 and api.GBUFFER3_DTYPE.itemsize == 16
 
 

@@ -21,6 +21,8 @@ def to_oracle_material(m):
 def feed_oracle(host_scene, threads=None, brute_force=False, config=None):
     """Push every array of a HostScene into an OracleScene (same slots, same order)."""
     osc = O.OracleScene(threads=threads)
+    for slot, w, h, fmt, data in host_scene.textures():
+        osc.set_texture(slot, w, h, fmt, data)
     for i, m in enumerate(host_scene.materials()):
         osc.set_material(i, to_oracle_material(m))
     for v, t, mat in host_scene.geoms():
@@ -251,6 +253,23 @@ class DeviceBuffers:
         return out
 
 
+# Frame-parameter overrides applied to BOTH sides by every harness (e.g. {"enableBumpMapping": 1}); use frame_overrides().
+FRAME_OVERRIDES = {}
+
+
+class frame_overrides:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = dict(FRAME_OVERRIDES)
+        FRAME_OVERRIDES.update(self.kw)
+
+    def __exit__(self, *exc):
+        FRAME_OVERRIDES.clear()
+        FRAME_OVERRIDES.update(self.saved)
+
+
 def frame_params(cls_frame, cls_cam, width, height, cam, prev_cam=None, **kw):
     f = cls_frame()
     C.memmove(C.byref(f.camera), C.byref(cam), C.sizeof(cam))
@@ -267,6 +286,8 @@ def frame_params(cls_frame, cls_cam, width, height, cam, prev_cam=None, **kw):
     f.enableTemporalReuse = 1
     f.enableSpatialReuse = 1
     for k, v in kw.items():
+        setattr(f, k, v)
+    for k, v in FRAME_OVERRIDES.items():
         setattr(f, k, v)
     return f
 
