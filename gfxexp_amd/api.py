@@ -80,7 +80,7 @@ class GfxRestirFrameParams(C.Structure):
         ("enableTemporalReuse", C.c_uint32), ("enableSpatialReuse", C.c_uint32),
         ("useUnbiasedEstimator", C.c_uint32), ("bufferIndex", C.c_uint32),
         ("resetFlowBuffer", C.c_uint32), ("enableJittering", C.c_uint32),
-        ("enableEnvLight", C.c_uint32), ("enableBumpMapping", C.c_uint32),
+        ("enableEnvLight", C.c_uint32), ("enableBumpMapping", C.c_uint32), ("useSolidAngleSampling", C.c_uint32),
     ]
 
 
@@ -154,7 +154,7 @@ C_ABI_SYMBOLS = [
     "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_instance_set_transform_and_normal_matrix", "gfx_instance_set_dynamic",
     "gfx_accel_build",
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
-    "gfx_lights_build_instances", "gfx_lights_read", "gfx_lights_table_info", "gfx_trace", "gfx_restir_set_params", "gfx_restir_launch",
+    "gfx_lights_build_instances", "gfx_lights_read", "gfx_lights_table_info", "gfx_trace", "gfx_restir_set_params", "gfx_restir_copy_to_linear", "gfx_visualize", "gfx_restir_launch",
     "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
     "gfx_nrc_get_params", "gfx_nrc_set_render_params",
@@ -526,6 +526,13 @@ class Context:
                                                  C.byref(static_params) if static_params is not None else None,
                                                  C.byref(frame_params) if frame_params is not None else None,
                                                  C.c_uint32(cur_res_index), C.c_uint32(base_index)))
+
+    def restir_copy_to_linear(self, d_color, d_albedo, d_normal, d_motion, stream=0):
+        self._check(self.L.gfx_restir_copy_to_linear(self.h, C.c_void_p(stream), C.c_void_p(d_color), C.c_void_p(d_albedo), C.c_void_p(d_normal), C.c_void_p(d_motion)))
+
+    def visualize(self, d_linear, buffer_type, width, height, d_out, mv_offset=0.5, mv_scale=0.02, stream=0):
+        self._check(self.L.gfx_visualize(self.h, C.c_void_p(stream), C.c_void_p(d_linear), C.c_int(buffer_type), C.c_float(mv_offset), C.c_float(mv_scale),
+                                         C.c_uint32(width), C.c_uint32(height), C.c_void_p(d_out)))
 
     def restir_launch_rows(self, pass_id, width, height, row_begin, row_end, stream=0):
         self._check(self.L.gfx_restir_launch_rows(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height),

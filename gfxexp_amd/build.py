@@ -2,6 +2,9 @@
 with the repository snapshot).  Flags that are part of the numerical contract:
   -ffp-contract=off                              no fused multiply-add unless written as fmaf
   -fhip-fp32-correctly-rounded-divide-sqrt       IEEE division / sqrt on the device
+and one that is not (measured, profiles/r02_initial_candidates.txt):
+  -fno-slp-vectorize                             the SLP vectoriser packs adjacent fp32 ops into v_pk_*_f32, which issue at
+                                                 half rate on gfx950 and cost extra v_mov to pair registers: -2..3 % frame time
 """
 import hashlib
 import os
@@ -18,7 +21,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["capi.cpp", "scene.cpp", "lights.hip", "lbvh.hip", "trace.hip", "restir.hip", "pathtrace.hip", "nrc.hip", "textures.hip",
            "host/scene_builder.cpp", "host/restir_driver.cpp", "host/nrc_driver.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(HERE, "..", "include")]
 
 

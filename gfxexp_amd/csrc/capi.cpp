@@ -276,6 +276,18 @@ int gfx_trace(gfx_ctx* ctx, void* stream, uint64_t accel, int mode, const void* 
     GFX_CATCH(ctx)
 }
 
+int gfx_restir_copy_to_linear(gfx_ctx* ctx, void* stream, void* dLinearColor, void* dLinearAlbedo, void* dLinearNormal, void* dLinearMotionVector) {
+    GFX_TRY(ctx)
+    restir_copy_to_linear(ctx->c, static_cast<hipStream_t>(stream), dLinearColor, dLinearAlbedo, dLinearNormal, dLinearMotionVector);
+    GFX_CATCH(ctx)
+}
+int gfx_visualize(gfx_ctx* ctx, void* stream, const void* dLinearBuffer, int bufferTypeToDisplay, float motionVectorOffset, float motionVectorScale,
+                  uint32_t width, uint32_t height, void* dOutputFloat4) {
+    GFX_TRY(ctx)
+    restir_visualize(ctx->c, static_cast<hipStream_t>(stream), dLinearBuffer, bufferTypeToDisplay, motionVectorOffset, motionVectorScale, width, height, dOutputFloat4);
+    GFX_CATCH(ctx)
+}
+
 int gfx_restir_set_params(gfx_ctx* ctx, void* /*stream*/, const gfx_restir_static_params* s, const gfx_restir_frame_params* f,
                           uint32_t currentReservoirIndex, uint32_t spatialNeighborBaseIndex) {
     GFX_TRY(ctx)

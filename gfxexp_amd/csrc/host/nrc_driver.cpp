@@ -167,7 +167,7 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     fp.prevCamera = frameIndex == 0 ? cfg.camera : r->prevCamera;
     fp.camera = cfg.camera;
     fp.envLightPowerCoeff = 1.0f; fp.envLightRotation = 0.0f;
-    fp.bufferIndex = bufferIndex; fp.resetFlowBuffer = newSequence; fp.enableJittering = 0; fp.enableEnvLight = 0; fp.enableBumpMapping = 0;
+    fp.bufferIndex = bufferIndex; fp.resetFlowBuffer = newSequence; fp.enableJittering = 0; fp.enableEnvLight = 0; fp.enableBumpMapping = 0; fp.useSolidAngleSampling = 0;
     r->np.radianceScale = cfg.radianceScale;
     r->np.preprocessOffsetToSelectUnbiasedTile = static_cast<uint32_t>(r->perFrameRng());   // main:2276-2277
     r->np.preprocessOffsetToSelectTrainingPath = static_cast<uint32_t>(r->perFrameRng());

@@ -323,6 +323,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     fp.enableJittering = cfg.enableJittering;
     fp.enableEnvLight = r->sp.envLightTexture != nullptr;
     fp.enableBumpMapping = cfg.enableBumpMapping;
+    fp.useSolidAngleSampling = 0;
 
     uint32_t currentReservoirIndex = (r->lastReservoirIndex + 1) % 2;  // :2352
     const uint32_t W = cfg.width, H = cfg.height;

@@ -1031,8 +1031,70 @@ extern "C" int gfxh_save_image_sdr(const char* path, uint32_t width, uint32_t he
     return 0;
 }
 
+// fp32 -> fp16, round to nearest even (what tinyexr's float_to_half_full does for the requested HALF pixel type)
+static uint16_t float_to_half(float v) {
+    uint32_t x; std::memcpy(&x, &v, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t mag = x & 0x7FFFFFFFu;
+    if (mag >= 0x7F800000u) return static_cast<uint16_t>(sign | 0x7C00u | (mag > 0x7F800000u ? 0x200u : 0u));   // inf / NaN
+    if (mag >= 0x477FF000u) return static_cast<uint16_t>(sign | 0x7C00u);                                        // rounds to >= 65520 -> inf
+    if (mag < 0x33000001u) return static_cast<uint16_t>(sign);                                                   // below half of the smallest subnormal
+    const int32_t e = static_cast<int32_t>(mag >> 23) - 127;
+    uint32_t m = (mag & 0x7FFFFFu) | 0x800000u;
+    uint32_t half;
+    uint32_t shift;
+    if (e < -14) { shift = static_cast<uint32_t>(13 + (-14 - e)); half = 0; }        // subnormal half
+    else { shift = 13; half = static_cast<uint32_t>(e + 15) << 10; m &= 0x7FFFFFu; }
+    const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    half += q;
+    if (rem > halfway || (rem == halfway && (half & 1u))) ++half;                      // carries into the exponent correctly
+    return static_cast<uint16_t>(sign | half);
+}
+
+// saveImageHDR (common_host.cpp:2762-2857): OpenEXR scanline file, channels A B G R stored as HALF.  The reference goes
+// through tinyexr (ZIP-compressed); this writer emits the same pixels uncompressed (compression = NO_COMPRESSION).
+static int save_exr(const char* path, uint32_t width, uint32_t height, float brightnessScale, const float* rgba, int flipY) {
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { g_hostError = std::string("cannot open ") + path; return 1; }
+    std::vector<uint8_t> hdr;
+    auto put = [&](const void* p, size_t n) { hdr.insert(hdr.end(), static_cast<const uint8_t*>(p), static_cast<const uint8_t*>(p) + n); };
+    auto put_str = [&](const char* t) { put(t, std::strlen(t) + 1); };
+    auto put_i32 = [&](int32_t v) { put(&v, 4); };
+    auto put_f32 = [&](float v) { put(&v, 4); };
+    const uint32_t magic = 20000630u, version = 2u;
+    put(&magic, 4); put(&version, 4);
+    put_str("channels"); put_str("chlist"); put_i32(4 * 18 + 1);
+    for (const char* name : { "A", "B", "G", "R" }) { put_str(name); put_i32(1 /* HALF */); const uint8_t lin[4] = { 0, 0, 0, 0 }; put(lin, 4); put_i32(1); put_i32(1); }
+    { const uint8_t z = 0; put(&z, 1); }
+    put_str("compression"); put_str("compression"); put_i32(1); { const uint8_t c = 0; put(&c, 1); }
+    put_str("dataWindow"); put_str("box2i"); put_i32(16); put_i32(0); put_i32(0); put_i32(static_cast<int32_t>(width) - 1); put_i32(static_cast<int32_t>(height) - 1);
+    put_str("displayWindow"); put_str("box2i"); put_i32(16); put_i32(0); put_i32(0); put_i32(static_cast<int32_t>(width) - 1); put_i32(static_cast<int32_t>(height) - 1);
+    put_str("lineOrder"); put_str("lineOrder"); put_i32(1); { const uint8_t c = 0; put(&c, 1); }
+    put_str("pixelAspectRatio"); put_str("float"); put_i32(4); put_f32(1.0f);
+    put_str("screenWindowCenter"); put_str("v2f"); put_i32(8); put_f32(0.0f); put_f32(0.0f);
+    put_str("screenWindowWidth"); put_str("float"); put_i32(4); put_f32(1.0f);
+    { const uint8_t z = 0; put(&z, 1); }
+    std::fwrite(hdr.data(), 1, hdr.size(), f);
+    const uint64_t rowBytes = 8ull + 4ull * 2ull * width;   // y, size, then A B G R planes of half
+    uint64_t offset = hdr.size() + 8ull * height;
+    for (uint32_t y = 0; y < height; ++y) { std::fwrite(&offset, 8, 1, f); offset += rowBytes; }
+    std::vector<uint16_t> row(4ull * width);
+    for (uint32_t y = 0; y < height; ++y) {
+        const uint32_t sy = flipY ? (height - 1 - y) : y;
+        const float* src = rgba + 4ull * static_cast<size_t>(sy) * width;
+        for (uint32_t x = 0; x < width; ++x)
+            for (int c = 0; c < 4; ++c) row[static_cast<size_t>(c) * width + x] = float_to_half(brightnessScale * src[4 * x + (3 - c)]);   // A, B, G, R planes
+        const int32_t yy = static_cast<int32_t>(y), size = static_cast<int32_t>(8ull * width);
+        std::fwrite(&yy, 4, 1, f); std::fwrite(&size, 4, 1, f);
+        std::fwrite(row.data(), 2, row.size(), f);
+    }
+    std::fclose(f);
+    return 0;
+}
+
 extern "C" int gfxh_save_image_hdr(const char* path, uint32_t width, uint32_t height, float brightnessScale, const float* rgba, int flipY) {
-    if (!has_ext(path, ".pfm")) { g_hostError = "gfxh_save_image_hdr: .pfm"; return 1; }
+    if (has_ext(path, ".exr")) return save_exr(path, width, height, brightnessScale, rgba, flipY);
+    if (!has_ext(path, ".pfm")) { g_hostError = "gfxh_save_image_hdr: .exr or .pfm"; return 1; }
     FILE* f = std::fopen(path, "wb");
     if (!f) { g_hostError = std::string("cannot open ") + path; return 1; }
     std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height);              // little endian, rows bottom to top

@@ -194,6 +194,8 @@ void lights_build_static(Context& ctx, hipStream_t stream);
 void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t bufferIndex);
 // ---- restir.hip
 void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd);
+void restir_copy_to_linear(Context& ctx, hipStream_t stream, void* color, void* albedo, void* normal, void* motion);
+void restir_visualize(Context& ctx, hipStream_t stream, const void* linearBuffer, int bufferType, float mvOffset, float mvScale, uint32_t width, uint32_t height, void* out);
 // ---- nrc.hip
 struct NrcNet;
 NrcNet* nrc_create(Context& ctx, int posEnc, uint32_t numHiddenLayers, float learningRate);

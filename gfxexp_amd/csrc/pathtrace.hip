@@ -170,7 +170,8 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
         float areaPDensity;
         const float u0 = rng.uniform();
         const float u1 = rng.uniform();
-        sample_light(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, selectEnv, u0, u1, ls, areaPDensity);
+        if (a.f.useSolidAngleSampling) sample_light_solid_angle(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, pos, ul, selectEnv, u0, u1, ls, areaPDensity);
+        else sample_light(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, selectEnv, u0, u1, ls, areaPDensity);
         areaPDensity *= probCurType;
         const ShadowRay sr = shadow_ray(pos, ls);
         float misWeight;
@@ -405,7 +406,16 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_bounce(PtArgs a) {
                     float pmf = 0.0f;
                     if (g.distOffset != 0xFFFFFFFFu && g.distIntegral != 0.0f) pmf = a.scene.lightWeights[g.distOffset + primIndex] / g.distIntegral;
                     lightProb *= pmf;
-                    hypAreaPDensity = lightProb / area;
+                    if (a.f.useSolidAngleSampling) {   // path_tracing_shared.h:550-568, reference point = the ray origin
+                        const SphericalTriangle st = spherical_triangle(pA, pB, pC, rayOrg);
+                        const float dirPDF = 1.0f / st.sphArea;
+                        f3 refDir = rayOrg - pos;
+                        const float dist2ToRef = len2(refDir);
+                        refDir = refDir / sqrtf(dist2ToRef);
+                        const float lpCosRef = dot(refDir, ng);
+                        hypAreaPDensity = (lpCosRef > 0 && is_finite(dirPDF)) ? lightProb * (dirPDF * lpCosRef / dist2ToRef) : 0.0f;
+                    }
+                    else hypAreaPDensity = lightProb / area;
                 }
             }
             const gfx_material& mat = a.scene.materials[g.materialSlot];
@@ -872,7 +882,16 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
                     float pmf = 0.0f;
                     if (g.distOffset != 0xFFFFFFFFu && g.distIntegral != 0.0f) pmf = a.scene.lightWeights[g.distOffset + primIndex] / g.distIntegral;
                     lightProb *= pmf;
-                    hypAreaPDensity = lightProb / area;
+                    if (a.f.useSolidAngleSampling) {   // path_tracing_shared.h:550-568, reference point = the ray origin
+                        const SphericalTriangle st = spherical_triangle(pA, pB, pC, rayOrg);
+                        const float dirPDF = 1.0f / st.sphArea;
+                        f3 refDir = rayOrg - pos;
+                        const float dist2ToRef = len2(refDir);
+                        refDir = refDir / sqrtf(dist2ToRef);
+                        const float lpCosRef = dot(refDir, ng);
+                        hypAreaPDensity = (lpCosRef > 0 && is_finite(dirPDF)) ? lightProb * (dirPDF * lpCosRef / dist2ToRef) : 0.0f;
+                    }
+                    else hypAreaPDensity = lightProb / area;
                 }
             }
             const gfx_material& mat = a.scene.materials[g.materialSlot];

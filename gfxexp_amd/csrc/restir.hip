@@ -214,8 +214,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
             float pd;
             const float u0 = rng.uniform();
             const float u1 = rng.uniform();
-            sample_light<EMITTER_TEX>(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
-            const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
+            f3 cont;
+            if (EMITTER_TEX) {
+                // the emittance texture of the candidate is read only when f * G is non-zero: a zero-weight candidate is
+                // never accepted by the reservoir, so its emittance is never observed (finite texels: 0 * Le = 0)
+                PendingEmittance pending; pending.tex = 0u; pending.tu = pending.tv = 0.0f;
+                pending.desc.offset = pending.desc.width = pending.desc.height = pending.desc.format = 0u;
+                if (sampleEnv) sample_env_light(env, a.f.envLightRotation, a.f.envLightPowerCoeff, u0, u1, ls, pd);
+                else {
+                    const LightPick pk = light_select(a.scene, ul);
+                    if (pk.ok) light_fetch<true, false>(a.scene, pk, u0, u1, ls, pd, f3(0.0f), &pending);
+                    else pd = 0.0f;
+                }
+                cont = direct_lighting_pending(a.scene, sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls, pending);
+            }
+            else {
+                sample_light<false>(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
+                cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
+            }
             pd *= probCurType;
             const float target = target_weight(cont);
             const float weight = target / pd;
@@ -674,6 +690,62 @@ static void trace_queue(Context& ctx, hipStream_t stream, const RestirArgs& a, i
     t.numRays = fixedCount; t.numRaysPtr = useCounter ? a.rayCount : nullptr;
     t.out = out; t.mode = mode;
     trace_launch(ctx, stream, t);
+}
+
+// ---------------------------------------------------------------- output chain (copy_buffers.cu:6-80)
+// copyToLinearBuffers: the accumulation buffers and the motion vectors as the linear arrays the denoiser / display
+// consume; the normal is normalised unless it is the zero vector.
+__global__ __launch_bounds__(kBlock) void k_copy_to_linear(gfx_restir_static_params s, uint32_t bufferIndex, size_t numPixels,
+                                                           float4* __restrict__ color, float4* __restrict__ albedo, float4* __restrict__ normal, float2* __restrict__ motion) {
+    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= numPixels) return;
+    color[p] = static_cast<const float4*>(s.beautyAccumBuffer)[p];
+    albedo[p] = static_cast<const float4*>(s.albedoAccumBuffer)[p];
+    const float4 nv = static_cast<const float4*>(s.normalAccumBuffer)[p];
+    f3 n(nv.x, nv.y, nv.z);
+    if (n.x != 0 || n.y != 0 || n.z != 0) n = unit(n);
+    normal[p] = make_float4(n.x, n.y, n.z, 1.0f);
+    motion[p] = static_cast<const float2*>(s.gbuffer1[bufferIndex])[p];
+}
+// visualizeToOutputBuffer: bufferType = BufferToDisplay (restir_di_shared.h:292-298)
+__global__ __launch_bounds__(kBlock) void k_visualize(const void* __restrict__ linearBuffer, int bufferType, float mvOffset, float mvScale,
+                                                      size_t numPixels, float4* __restrict__ out) {
+    const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= numPixels) return;
+    float4 value = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    switch (bufferType) {
+    case GFX_DISPLAY_NOISY_BEAUTY: case GFX_DISPLAY_DENOISED_BEAUTY: case GFX_DISPLAY_ALBEDO:
+        value = static_cast<const float4*>(linearBuffer)[p];
+        break;
+    case GFX_DISPLAY_NORMAL:
+        value = static_cast<const float4*>(linearBuffer)[p];
+        value.x = 0.5f + 0.5f * value.x; value.y = 0.5f + 0.5f * value.y; value.z = 0.5f + 0.5f * value.z;
+        break;
+    case GFX_DISPLAY_FLOW: {
+        const float2 f = static_cast<const float2*>(linearBuffer)[p];
+        value = make_float4(fminf(fmaxf(mvScale * f.x + mvOffset, 0.0f), 1.0f), fminf(fmaxf(mvScale * f.y + mvOffset, 0.0f), 1.0f), mvOffset, 1.0f);
+        break;
+    }
+    default: break;
+    }
+    out[p] = value;
+}
+void restir_copy_to_linear(Context& ctx, hipStream_t stream, void* color, void* albedo, void* normal, void* motion) {
+    if (!ctx.restir.valid) throw HipError("gfx_restir_copy_to_linear: gfx_restir_set_params first");
+    const gfx_restir_static_params& s = ctx.restir.s;
+    const size_t n = static_cast<size_t>(s.imageSizeX) * s.imageSizeY;
+    if (!n) return;
+    hipLaunchKernelGGL(k_copy_to_linear, dim3(static_cast<uint32_t>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, s, ctx.restir.f.bufferIndex, n,
+                       static_cast<float4*>(color), static_cast<float4*>(albedo), static_cast<float4*>(normal), static_cast<float2*>(motion));
+    GFX_HIP(hipGetLastError());
+}
+void restir_visualize(Context& ctx, hipStream_t stream, const void* linearBuffer, int bufferType, float mvOffset, float mvScale, uint32_t width, uint32_t height, void* out) {
+    (void)ctx;
+    const size_t n = static_cast<size_t>(width) * height;
+    if (!n) return;
+    hipLaunchKernelGGL(k_visualize, dim3(static_cast<uint32_t>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, linearBuffer, bufferType, mvOffset, mvScale, n,
+                       static_cast<float4*>(out));
+    GFX_HIP(hipGetLastError());
 }
 
 void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {

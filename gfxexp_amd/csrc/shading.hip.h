@@ -435,6 +435,9 @@ struct LightSample {
     f3 normal;
     uint32_t atInfinity;
 };
+// An emittance-texture read that has not happened yet (k_initial_candidates fetches it only for candidates whose
+// geometric / BSDF term is non-zero: the emittance of a zero-weight candidate is never observed).
+struct PendingEmittance { uint32_t tex; DevTexture desc; float tu, tv; };
 
 struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
     const float4* texels;
@@ -568,40 +571,6 @@ struct LightPick {
     bool table;
 };
 
-// Interval-table lookup in three stages so that a caller can overlap the dependent loads of one candidate with the
-// arithmetic of another (k_initial_candidates): guide cell -> the two bracketing spans -> resolve.
-struct SpanProbe { EmitterSpan lo, hi; uint32_t loIdx, hiIdx; };
-GFX_DEV SpanGuide light_probe_guide(const DevScene& sc, float ul) { return sc.spanGuide[span_cell(ul, sc.spanGuideCells)]; }
-GFX_DEV SpanProbe light_probe_spans(const DevScene& sc, SpanGuide g) {
-    SpanProbe p;
-    p.loIdx = g.lo; p.hiIdx = g.hi;
-    p.lo = __builtin_bit_cast(EmitterSpan, *reinterpret_cast<const SpanWords*>(sc.spans + g.lo));
-    p.hi = __builtin_bit_cast(EmitterSpan, *reinterpret_cast<const SpanWords*>(sc.spans + g.hi));
-    return p;
-}
-GFX_DEV LightPick light_probe_resolve(const DevScene& sc, const SpanProbe& p, float ul) {
-    // the answer is the largest index in [lo, hi] whose begin is <= ul: hi or lo when the bracket holds at most
-    // two records (nearly always: the guide has about two cells per record), a search between them otherwise
-    EmitterSpan s = p.lo;
-    uint32_t idx = p.loIdx;
-    if (p.hi.begin <= ul) { s = p.hi; idx = p.hiIdx; }
-    else if (p.hiIdx - p.loIdx > 1u) {
-        int32_t lo = static_cast<int32_t>(p.loIdx), hi = static_cast<int32_t>(p.hiIdx) - 1;
-        while (lo < hi) {
-            const int32_t mid = (lo + hi + 1) >> 1;
-            if (sc.spans[mid].begin <= ul) lo = mid;
-            else hi = mid - 1;
-        }
-        idx = static_cast<uint32_t>(lo);
-        s = __builtin_bit_cast(EmitterSpan, *reinterpret_cast<const SpanWords*>(sc.spans + lo));
-    }
-    LightPick pk;
-    pk.rec = idx; pk.instSlot = s.instSlot; pk.density = s.density; pk.partialProb = 0.0f;
-    pk.ok = ul >= s.begin && ul < s.end;
-    pk.table = true;
-    return pk;
-}
-
 // Selection in one call: the table when the build verified it (wave-uniform), else the reference's searches.
 GFX_DEV LightPick light_select(const DevScene& sc, float ul) {
 #ifdef GFX_LIGHT_TABLE_ONLY   // experiment: what the kernels cost without the search fallback compiled in
@@ -611,8 +580,37 @@ GFX_DEV LightPick light_select(const DevScene& sc, float ul) {
 #endif
     if (table) {
         if (sc.numSpans == 0) { LightPick pk; pk.rec = 0; pk.instSlot = 0; pk.density = 0; pk.partialProb = 0; pk.ok = false; pk.table = true; return pk; }
-        return light_probe_resolve(sc, light_probe_spans(sc, light_probe_guide(sc, ul)), ul);
+        // guide cell -> short search on the spans' begin values -> ONE 16-byte span load (loading both bracketing
+        // spans up front instead measured 15 % slower: profiles/r02_initial_candidates.txt)
+        EmitterSpan span;
+        const int32_t j = span_lookup(sc.spans, sc.numSpans, sc.spanGuide, sc.spanGuideCells, ul, span);
+        LightPick pk; pk.rec = j < 0 ? 0u : static_cast<uint32_t>(j); pk.instSlot = span.instSlot; pk.density = span.density; pk.partialProb = 0; pk.ok = j >= 0; pk.table = true;
+        return pk;
     }
+    LightPick pk;
+    pk.density = 0.0f; pk.table = false;
+    pk.ok = light_locate_3level(sc, inst_dist_global(sc), ul, pk.rec, pk.instSlot, pk.partialProb);
+    return pk;
+}
+
+// Spherical triangle of (pA, pB, pC) seen from a point (restir_di_shared.h:430-445, path_tracing_shared.h:551-561)
+struct SphericalTriangle { f3 A, B, C; float cos_c, cosAlpha, alpha, sinAlpha, sphArea; };
+GFX_DEV SphericalTriangle spherical_triangle(f3 pA, f3 pB, f3 pC, f3 ref) {
+    SphericalTriangle t;
+    t.A = unit(pA - ref); t.B = unit(pB - ref); t.C = unit(pC - ref);
+    const f3 cAB = unit(cross(t.A, t.B)), cBC = unit(cross(t.B, t.C)), cCA = unit(cross(t.C, t.A));
+    t.cos_c = dot(t.A, t.B);
+    t.cosAlpha = -dot(cAB, cCA);
+    const float cosBeta = -dot(cBC, cAB);
+    const float cosGamma = -dot(cCA, cBC);
+    t.alpha = gm_acos(t.cosAlpha);
+    t.sinAlpha = sqrtf(1 - sq(t.cosAlpha));
+    t.sphArea = t.alpha + gm_acos(cosBeta) + gm_acos(cosGamma) - kPi;
+    return t;
+}
+
+// Selection by the reference's searches regardless of the table (solid-angle sampling needs the plain probability).
+GFX_DEV LightPick light_select_search(const DevScene& sc, float ul) {
     LightPick pk;
     pk.density = 0.0f; pk.table = false;
     pk.ok = light_locate_3level(sc, inst_dist_global(sc), ul, pk.rec, pk.instSlot, pk.partialProb);
@@ -622,8 +620,11 @@ GFX_DEV LightPick light_select(const DevScene& sc, float ul) {
 // The rest of sampleLight<false> for a picked record: point on the triangle, normal, emittance, area density.
 // EMITTER_TEX = false compiles the emittance-texture read out (kernels instantiate both and the host picks by
 // whether any emitter material has an emittance texture).
-template <bool EMITTER_TEX = true>
-GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, float u1, LightSample& ls, float& areaPDensity) {
+// SOLID_ANGLE = sampleLight<true> (restir_di_shared.h:419-483): the point is drawn uniformly in the solid angle the
+// triangle subtends from shadingPoint.
+template <bool EMITTER_TEX = true, bool SOLID_ANGLE = false>
+GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, float u1, LightSample& ls, float& areaPDensity, f3 shadingPoint = f3(0.0f),
+                         PendingEmittance* pending = nullptr) {
     // EmitterRec: world-space triangle, 2 / |ng| and the primitive's probability tabulated at build time
     const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + pk.rec);
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
@@ -631,13 +632,44 @@ GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, floa
     const f3 pA(r0.x, r0.y, r0.z), pB(r0.w, r1.x, r1.y), pC(r1.z, r1.w, r2.x);
     const f3 nA(r2.y, r2.z, r2.w), nB(r3.x, r3.y, r3.z), nC(r3.w, r4.x, r4.y);
 
-    float bcA = 0.5f * u0;
-    float bcB = 0.5f * u1;
-    const float off = bcB - bcA;
-    if (off > 0) bcB += off;
-    else bcA -= off;
-    const float bcC = 1 - (bcA + bcB);
-    areaPDensity = pk.table ? pk.density : (pk.partialProb * r5.w) * r5.z;
+    float bcA, bcB, bcC;
+    if (SOLID_ANGLE) {
+        // the interval table tabulates lightProb * (2 / |ng|), not lightProb: solid-angle sampling always selects with the
+        // reference's three searches (light_select_search), whose partial product times the primitive's probability it is
+        const float lightProb = pk.partialProb * r5.w;
+        const SphericalTriangle st = spherical_triangle(pA, pB, pC, shadingPoint);
+        const float sphAreaHat = st.sphArea * u0;
+        float s, t;
+        gm_sincos(sphAreaHat - st.alpha, s, t);
+        const float uu = t - st.cosAlpha;
+        const float vv = s + st.sinAlpha * st.cos_c;
+        const float q = ((vv * t - uu * s) * st.cosAlpha - vv) / ((vv * s + uu * t) * st.sinAlpha);
+        const f3 cHat = q * st.A + sqrtf(1 - sq(q)) * unit(st.C - dot(st.C, st.A) * st.A);
+        const float z = 1 - u1 * (1 - dot(cHat, st.B));
+        const f3 dir = z * st.B + sqrtf(1 - sq(z)) * unit(cHat - dot(cHat, st.B) * st.B);
+        const f3 eAB = pB - pA, eAC = pC - pA;
+        const f3 pVec = cross(dir, eAC);
+        const float recDet = 1.0f / dot(eAB, pVec);
+        const f3 tVec = shadingPoint - pA;
+        bcB = dot(tVec, pVec) * recDet;
+        const f3 qVec = cross(tVec, eAB);
+        bcC = dot(dir, qVec) * recDet;
+        const float dist = dot(eAC, qVec) * recDet;
+        bcA = 1 - (bcB + bcC);
+        const float dirPDF = 1 / st.sphArea;
+        const f3 gn = unit(cross(pB - pA, pC - pA));
+        const float lpCos = -dot(dir, gn);
+        areaPDensity = (lpCos > 0 && is_finite(dirPDF)) ? lightProb * (dirPDF * lpCos / sq(dist)) : 0.0f;
+    }
+    else {
+        bcA = 0.5f * u0;
+        bcB = 0.5f * u1;
+        const float off = bcB - bcA;
+        if (off > 0) bcB += off;
+        else bcA -= off;
+        bcC = 1 - (bcA + bcB);
+        areaPDensity = pk.table ? pk.density : (pk.partialProb * r5.w) * r5.z;
+    }
 
     ls.position = bcA * pA + bcB * pB + bcC * pC;
     ls.atInfinity = 0;
@@ -653,8 +685,11 @@ GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, floa
             const float tv = bcA * t0.y + bcB * t0.w + bcC * t1.y;
             DevTexture desc;
             desc.offset = f2bits(t2.x); desc.width = f2bits(t2.y); desc.height = f2bits(t2.z); desc.format = f2bits(t2.w);
-            const float4 tv4 = tex2d_desc(sc, desc, tu, tv);
-            ls.emittance = f3(1.0f) * f3(tv4.x, tv4.y, tv4.z);
+            if (pending) { pending->tex = tex; pending->desc = desc; pending->tu = tu; pending->tv = tv; }
+            else {
+                const float4 tv4 = tex2d_desc(sc, desc, tu, tv);
+                ls.emittance = f3(1.0f) * f3(tv4.x, tv4.y, tv4.z);
+            }
         }
     }
 }
@@ -687,6 +722,14 @@ GFX_DEV void sample_light(const DevScene& sc,
     if (!pk.ok) { areaPDensity = 0.0f; return; }
     light_fetch<EMITTER_TEX>(sc, pk, u0, u1, ls, areaPDensity);
 }
+// sampleLight<true>: solid-angle sampling of the selected triangle from shadingPoint
+GFX_DEV void sample_light_solid_angle(const DevScene& sc, const EnvMap& env, float envRotation, float envPowerCoeff, f3 shadingPoint,
+                                      float ul, bool sampleEnv, float u0, float u1, LightSample& ls, float& areaPDensity) {
+    if (sampleEnv) { sample_env_light(env, envRotation, envPowerCoeff, u0, u1, ls, areaPDensity); return; }
+    const LightPick pk = light_select_search(sc, ul);
+    if (!pk.ok) { areaPDensity = 0.0f; return; }
+    light_fetch<true, true>(sc, pk, u0, u1, ls, areaPDensity, shadingPoint);
+}
 
 // Geometry of a shadow ray toward a light sample (restir_di_shared.h:524-545, 564-581).
 struct ShadowRay { f3 dir; float dist2; float tmax; };
@@ -703,6 +746,28 @@ GFX_DEV ShadowRay shadow_ray(f3 shadingPoint, const LightSample& ls) {
 
 // Unshadowed contribution f * Le * G (performDirectLighting<.., false>); the visibility factor of
 // the <.., true> form is applied by the caller from the traced occlusion bit.
+// The same with the emittance texture of the sample still pending: it is read (into ls.emittance) only when
+// f * G is non-zero, i.e. when the product can be non-zero at all.
+GFX_DEV f3 direct_lighting_pending(const DevScene& sc, f3 shadingPoint, f3 vOutLocal, const Frame& frame, const Bsdf& bsdf, LightSample& ls,
+                                   const PendingEmittance& pending) {
+    const ShadowRay sr = shadow_ray(shadingPoint, ls);
+    const f3 dirLocal = frame.to_local(sr.dir);
+    const float lpCos = dot(-sr.dir, ls.normal);
+    const float spCos = dirLocal.z;
+    if (lpCos > 0) {
+        const f3 fs = bsdf.evaluate(vOutLocal, dirLocal);
+        const float G = lpCos * fabsf(spCos) / sr.dist2;
+        const bool zero = (fs.x == 0.0f && fs.y == 0.0f && fs.z == 0.0f) || G == 0.0f;
+        if (pending.tex && !zero) {
+            const float4 t = tex2d_desc(sc, pending.desc, pending.tu, pending.tv);
+            ls.emittance = f3(1.0f) * f3(t.x, t.y, t.z);
+        }
+        const f3 Le = ls.emittance / kPi;
+        return fs * Le * G;
+    }
+    return f3(0.0f);
+}
+
 GFX_DEV f3 direct_lighting(f3 shadingPoint, f3 vOutLocal, const Frame& frame, const Bsdf& bsdf, const LightSample& ls) {
     const ShadowRay sr = shadow_ray(shadingPoint, ls);
     const f3 dirLocal = frame.to_local(sr.dir);

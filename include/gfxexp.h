@@ -259,6 +259,10 @@ typedef struct gfx_restir_frame_params {
     uint32_t enableJittering;
     uint32_t enableEnvLight;
     uint32_t enableBumpMapping;
+    /* path tracers: sampleLight<true> / computeSurfacePoint<.., true> -- emitter triangles sampled uniformly in the
+     * solid angle they subtend from the shading point (restir_di_shared.h:417-483, path_tracing_shared.h:319-385,
+     * 550-568; a compile-time `useSolidAngleSampling = false` in the reference, a run-time switch here) */
+    uint32_t useSolidAngleSampling;
 } gfx_restir_frame_params;
 
 /* restir_di/restir_di_main.cpp:2350-2359: the three cuMemcpyHtoDAsync of plp/perFramePlp.
@@ -305,6 +309,17 @@ int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint
  * full-frame size and indexing. */
 int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height,
                            uint32_t rowBegin, uint32_t rowEnd);
+
+/* Output chain (restir_di/gpu_kernels/copy_buffers.cu:6-80; host calls restir_di_main.cpp:2497-2571).
+ * gfx_restir_copy_to_linear = copyToLinearBuffers: beauty / albedo / normal accumulation buffers (normal normalised
+ * unless zero) and GBuffer1's motion vectors of the current gfx_restir_set_params into caller-owned linear device
+ * arrays (float4 x 3, float2).  gfx_visualize = visualizeToOutputBuffer: one linear buffer -> float4 display values. */
+enum gfx_buffer_to_display {                       /* BufferToDisplay, restir_di_shared.h:292-298 */
+    GFX_DISPLAY_NOISY_BEAUTY = 0, GFX_DISPLAY_ALBEDO = 1, GFX_DISPLAY_NORMAL = 2, GFX_DISPLAY_FLOW = 3, GFX_DISPLAY_DENOISED_BEAUTY = 4
+};
+int gfx_restir_copy_to_linear(gfx_ctx* ctx, void* stream, void* dLinearColor, void* dLinearAlbedo, void* dLinearNormal, void* dLinearMotionVector);
+int gfx_visualize(gfx_ctx* ctx, void* stream, const void* dLinearBuffer, int bufferTypeToDisplay, float motionVectorOffset, float motionVectorScale,
+                  uint32_t width, uint32_t height, void* dOutputFloat4);
 
 /* ---------------------------------------------------------------- path tracing ---------------- */
 

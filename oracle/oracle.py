@@ -64,7 +64,7 @@ class GfxRestirFrameParams(C.Structure):
         ("enableTemporalReuse", C.c_uint32), ("enableSpatialReuse", C.c_uint32),
         ("useUnbiasedEstimator", C.c_uint32), ("bufferIndex", C.c_uint32),
         ("resetFlowBuffer", C.c_uint32), ("enableJittering", C.c_uint32),
-        ("enableEnvLight", C.c_uint32), ("enableBumpMapping", C.c_uint32),
+        ("enableEnvLight", C.c_uint32), ("enableBumpMapping", C.c_uint32), ("useSolidAngleSampling", C.c_uint32),
     ]
 
 

@@ -179,7 +179,8 @@ static inline void nrcTraceVertex(const PathTraceParams& p, const NrcState& ns, 
     const GeometryInstanceData& hg = scene.geomInsts[hGeom];
     V3 positionInWorld, shadingNormalInWorld, texCoord0DirInWorld, geometricNormalInWorld; V2 texCoord; float hypAreaPDensity;
     computeSurfacePointCH(scene, useEnvLight, hInst, hi, hg, h.primIndex, h.bcB, h.bcC, &positionInWorld, &shadingNormalInWorld,
-                          &texCoord0DirInWorld, &geometricNormalInWorld, &texCoord, &hypAreaPDensity);
+                          &texCoord0DirInWorld, &geometricNormalInWorld, &texCoord, &hypAreaPDensity,
+                          p.f->useSolidAngleSampling != 0, rayOrg);
     const MaterialData& mat = scene.materials[hg.materialSlot];
     const V3 vOut = normalize(-rayDir);
     const float frontHit = dot(vOut, geometricNormalInWorld) >= 0.0f ? 1.0f : -1.0f;

@@ -51,7 +51,8 @@ static inline void computeSurfacePointCH(const Scene& scene, bool envEnabled, ui
                                          const InstanceData& inst, const GeometryInstanceData& geomInst,
                                          uint32_t primIndex, float bcB, float bcC,
                                          V3* positionInWorld, V3* shadingNormalInWorld, V3* texCoord0DirInWorld,
-                                         V3* geometricNormalInWorld, V2* texCoord, float* hypAreaPDensity) {
+                                         V3* geometricNormalInWorld, V2* texCoord, float* hypAreaPDensity,
+                                         bool useSolidAngleSampling = false, V3 referencePoint = V3(0.0f)) {
     (void)instSlot;
     const Triangle& tri = geomInst.triangleBuffer[primIndex];
     const Vertex& vA = geomInst.vertexBuffer[tri.index0];
@@ -86,7 +87,17 @@ static inline void computeSurfacePointCH(const Scene& scene, bool envEnabled, ui
     lightProb *= geomInst.emitterPrimDist.integral() / instImportance;
     if (!finitef(lightProb)) { *hypAreaPDensity = 0.0f; return; }
     lightProb *= geomInst.emitterPrimDist.evaluatePMF(primIndex);
-    *hypAreaPDensity = lightProb / area;
+    if (useSolidAngleSampling) {   // path_tracing_shared.h:550-568
+        const SphericalTriangle st = sphericalTriangle(pA, pB, pC, referencePoint);
+        const float dirPDF = 1.0f / st.sphArea;
+        V3 refDir = referencePoint - *positionInWorld;
+        const float dist2ToRefPoint = sqLength(refDir);
+        refDir /= std::sqrt(dist2ToRefPoint);
+        const float lpCos = dot(refDir, *geometricNormalInWorld);
+        if (lpCos > 0 && finitef(dirPDF)) *hypAreaPDensity = lightProb * (dirPDF * lpCos / dist2ToRefPoint);
+        else *hypAreaPDensity = 0.0f;
+    }
+    else *hypAreaPDensity = lightProb / area;
 }
 
 struct PathTraceParams {
@@ -135,7 +146,8 @@ static inline RGB performNextEventEstimation(const PathTraceParams& p, const Vis
     float areaPDensity;
     const float u0 = rng.getFloat0cTo1o();
     const float u1 = rng.getFloat0cTo1o();
-    sampleLight(scene, p.f->envLightRotation, p.f->envLightPowerCoeff, shadingPoint, uLight, selectEnvLight, u0, u1, &lightSample, &areaPDensity);
+    sampleLight(scene, p.f->envLightRotation, p.f->envLightPowerCoeff, shadingPoint, uLight, selectEnvLight, u0, u1, &lightSample, &areaPDensity,
+                p.f->useSolidAngleSampling != 0);
     areaPDensity *= probToSampleCurLightType;
     float misWeight = 1.0f;
     {
@@ -240,7 +252,8 @@ static inline void pathTracePixel(const PathTraceParams& p, int x, int y) {
             const InstanceData& hi = scene.insts[hInst];
             const GeometryInstanceData& hg = scene.geomInsts[hGeom];
             V3 pos, sn, tc0, gn; V2 tc; float hypAreaPDensity;
-            computeSurfacePointCH(scene, useEnvLight, hInst, hi, hg, h.primIndex, h.bcB, h.bcC, &pos, &sn, &tc0, &gn, &tc, &hypAreaPDensity);
+            computeSurfacePointCH(scene, useEnvLight, hInst, hi, hg, h.primIndex, h.bcB, h.bcC, &pos, &sn, &tc0, &gn, &tc, &hypAreaPDensity,
+                                  p.f->useSolidAngleSampling != 0, rayOrg);
             // pathTraceReGIR instantiates computeSurfacePoint<false, ..> and then READS hypAreaPDensity
             // uninitialised (regir/.../optix_pathtracing_kernels.cu:323-330, :356-361): undefined in the
             // reference; this build defines it as 0 (MIS weight 1 for implicit light hits).

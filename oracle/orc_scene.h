@@ -152,10 +152,34 @@ struct Scene {
 
 // ---------------------------------------------------------------- sampleLight<false>
 // restir_di/restir_di_shared.h:320-516 (useSolidAngleSampling = false)
+// Spherical-triangle quantities of (pA, pB, pC) seen from a point: restir_di_shared.h:430-445 and
+// path_tracing_shared.h:551-561 (acos / sin / cos through the math contract).
+struct SphericalTriangle {
+    V3 A, B, C;
+    float cos_c, cosAlpha, alpha, sinAlpha, sphArea;
+};
+static inline SphericalTriangle sphericalTriangle(V3 pA, V3 pB, V3 pC, V3 refPoint) {
+    SphericalTriangle t;
+    t.A = normalize(pA - refPoint);
+    t.B = normalize(pB - refPoint);
+    t.C = normalize(pC - refPoint);
+    const V3 cAB = normalize(cross(t.A, t.B));
+    const V3 cBC = normalize(cross(t.B, t.C));
+    const V3 cCA = normalize(cross(t.C, t.A));
+    t.cos_c = dot(t.A, t.B);
+    t.cosAlpha = -dot(cAB, cCA);
+    const float cosBeta = -dot(cBC, cAB);
+    const float cosGamma = -dot(cCA, cBC);
+    t.alpha = gm_acos(t.cosAlpha);
+    t.sinAlpha = std::sqrt(1 - pow2(t.cosAlpha));
+    t.sphArea = t.alpha + gm_acos(cosBeta) + gm_acos(cosGamma) - kPi;
+    return t;
+}
+
 static inline void sampleLight(
     const Scene& scene, float envLightRotation, float envLightPowerCoeff,
-    V3 /*shadingPoint*/, float ul, bool sampleEnvLight, float u0, float u1,
-    LightSample* lightSample, float* areaPDensity)
+    V3 shadingPoint, float ul, bool sampleEnvLight, float u0, float u1,
+    LightSample* lightSample, float* areaPDensity, bool useSolidAngleSampling = false)
 {
     bool hasTexEmittance = false;
     RGB texValue(0.0f);
@@ -208,15 +232,50 @@ static inline void sampleLight(
         const V3 pC = xfmPoint(inst.transform, vC.position);
         const V3 geomNormal = cross(pB - pA, pC - pA);
 
-        // A Low-Distortion Map Between Triangle and Square (:485-498)
-        float bcA = 0.5f * u0;
-        float bcB = 0.5f * u1;
-        const float offset = bcB - bcA;
-        if (offset > 0) bcB += offset;
-        else bcA -= offset;
-        const float bcC = 1 - (bcA + bcB);
-        const float recArea = 2.0f / length(geomNormal);
-        *areaPDensity = lightProb * recArea;
+        float bcA, bcB, bcC;
+        if (useSolidAngleSampling) {   // :419-483: uniform in the solid angle the triangle subtends from the shading point
+            const SphericalTriangle st = sphericalTriangle(pA, pB, pC, shadingPoint);
+            const auto project = [](V3 a, V3 b) { return normalize(a - dot(a, b) * b); };
+            const float sphAreaHat = st.sphArea * u0;
+            const float s = gm_sin(sphAreaHat - st.alpha);
+            const float t = gm_cos(sphAreaHat - st.alpha);
+            const float uu = t - st.cosAlpha;
+            const float vv = s + st.sinAlpha * st.cos_c;
+            const float q = ((vv * t - uu * s) * st.cosAlpha - vv) / ((vv * s + uu * t) * st.sinAlpha);
+            const V3 cHat = q * st.A + std::sqrt(1 - pow2(q)) * project(st.C, st.A);
+            const float z = 1 - u1 * (1 - dot(cHat, st.B));
+            const V3 P = z * st.B + std::sqrt(1 - pow2(z)) * project(cHat, st.B);
+            const V3 dir = P;
+            float dist;
+            {   // restoreBarycentrics
+                const V3 eAB = pB - pA;
+                const V3 eAC = pC - pA;
+                const V3 pVec = cross(dir, eAC);
+                const float recDet = 1.0f / dot(eAB, pVec);
+                const V3 tVec = shadingPoint - pA;
+                bcB = dot(tVec, pVec) * recDet;
+                const V3 qVec = cross(tVec, eAB);
+                bcC = dot(dir, qVec) * recDet;
+                dist = dot(eAC, qVec) * recDet;
+            }
+            bcA = 1 - (bcB + bcC);
+            const float dirPDF = 1 / st.sphArea;
+            const V3 gn = normalize(geomNormal);
+            const float lpCos = -dot(dir, gn);
+            if (lpCos > 0 && finitef(dirPDF)) *areaPDensity = lightProb * (dirPDF * lpCos / pow2(dist));
+            else *areaPDensity = 0.0f;
+        }
+        else {
+            // A Low-Distortion Map Between Triangle and Square (:485-498)
+            bcA = 0.5f * u0;
+            bcB = 0.5f * u1;
+            const float offset = bcB - bcA;
+            if (offset > 0) bcB += offset;
+            else bcA -= offset;
+            bcC = 1 - (bcA + bcB);
+            const float recArea = 2.0f / length(geomNormal);
+            *areaPDensity = lightProb * recArea;
+        }
 
         lightSample->position = bcA * pA + bcB * pB + bcC * pC;
         lightSample->atInfinity = false;

@@ -114,3 +114,20 @@ def test_headless_driver_path_trace_mode_with_accumulation(built_lib):
     torch.cuda.synchronize()
     out = ctx.read_device(r.beauty_ptr(), width * height * 16).view(np.float32).reshape(-1, 4)
     util.assert_same_bits("driver beauty", out, want)
+
+
+@pytest.mark.gpu
+def test_solid_angle_triangle_sampling_bit_exact(built_lib):
+    """sampleLight<true> + the solid-angle hypothetical density of computeSurfacePoint (restir_di_shared.h:417-483,
+    path_tracing_shared.h:319-385, 550-568): compiled out in the reference (useSolidAngleSampling = false), a run-time
+    switch here.  Bit-exact against the oracle, and a different image from area sampling."""
+    with util.frame_overrides(useSolidAngleSampling=1):
+        diffs = run_pt_both(util.bunny_scene(), 128, 80, frames=2, max_len=5)
+    assert not diffs, "\n".join(diffs[:10])
+    solid = run_pt_both.last_beauty.copy()
+    diffs = run_pt_both(util.bunny_scene(), 128, 80, frames=2, max_len=5)
+    assert not diffs, "\n".join(diffs[:10])
+    area = run_pt_both.last_beauty
+    assert np.isfinite(solid).all() and not np.array_equal(solid, area)
+    # same estimator in expectation: the image means agree within the noise of two 1-spp frames
+    assert abs(solid[:, :3].mean() - area[:, :3].mean()) < 0.25 * area[:, :3].mean()

@@ -94,3 +94,20 @@ def test_rng_draw_budget_per_path():
     assert np.all(s >= 5)
     allowed = {5} | {5 + 1 + 6 * j for j in range(0, 3)} | {5 + 6 * j for j in range(0, 3)} | {5 + 6 * 2 + 1}
     assert set(np.unique(s)).issubset(allowed), np.unique(s)
+
+
+def test_solid_angle_sampling_has_the_same_expectation_and_less_noise_near_lights():
+    """sampleLight<true> (restir_di_shared.h:417-483) draws the point uniformly in the solid angle of the selected
+    triangle; with the matching hypothetical density in computeSurfacePoint (path_tracing_shared.h:550-568) the MIS
+    estimator keeps its expectation.  Direct lighting only (maxPathLength 2), many frames, both modes."""
+    hs = util.bunny_scene()
+    osc = util.feed_oracle(hs)
+    w, h = 48, 32
+    area, inst, _ = _pt_mean_image(osc, w, h, 2, 128)
+    with util.frame_overrides(useSolidAngleSampling=1):
+        solid, _, _ = _pt_mean_image(osc, w, h, 2, 128)
+    surf = inst != 0xFFFFFFFF
+    assert np.all(np.isfinite(solid)) and np.all(solid >= 0)
+    assert not np.array_equal(solid, area)
+    a, b = area[surf].mean(axis=0), solid[surf].mean(axis=0)
+    assert np.allclose(a, b, rtol=0.04), (a, b)
