@@ -131,6 +131,48 @@ class GfxhRestirConfig(C.Structure):
                 ("enableBumpMapping", C.c_uint32)]
 
 
+class GfxhFrameStep(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("pass_", C.c_uint32), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32),
+                ("currentReservoirIndex", C.c_uint32), ("spatialNeighborBaseIndex", C.c_uint32),
+                ("exchangeRows", C.c_uint32), ("buffers", C.c_uint32), ("reservoirIndex", C.c_uint32)]
+
+
+class GfxhExchangeBuffer(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("bytesPerPixel", C.c_uint32), ("numPlanes", C.c_uint32), ("planeStride", C.c_uint64)]
+
+
+class GfxhExchangeDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("stage", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("bandBegin", C.c_uint32), ("bandEnd", C.c_uint32),
+                ("sendAbove", C.c_uint32 * 2), ("recvAbove", C.c_uint32 * 2), ("sendBelow", C.c_uint32 * 2), ("recvBelow", C.c_uint32 * 2),
+                ("numBuffers", C.c_uint32), ("buffers", GfxhExchangeBuffer * 8),
+                ("counters", C.c_void_p), ("numCounters", C.c_uint64)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(GfxhExchangeDesc))
+EXCHANGE_STRIPS, EXCHANGE_ALLREDUCE_SUM_U32, EXCHANGE_GATHER_BANDS = 0, 1, 2
+STEP_RESTIR_PASS, STEP_PT_PASS, STEP_EXCHANGE_STRIPS, STEP_ALLREDUCE_CELL_ACCESSES, STEP_GATHER_BANDS, STEP_PREV_GBUFFER_RELEASED = range(6)
+BUF_GBUFFERS, BUF_RESERVOIRS, BUF_SAMPLE_VISIBILITY = 1, 2, 4
+
+
+def frame_program(cfg, strip_mode, max_motion_rows, new_sequence, last_res, last_base, unbiased):
+    """gfxh_restir_frame_program -> (steps, new_last_res, new_last_base)."""
+    steps = (GfxhFrameStep * 64)()
+    n, nr, nb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = lib().gfxh_restir_frame_program(C.byref(cfg), C.c_int(int(strip_mode)), C.c_uint32(max_motion_rows), C.c_int(int(new_sequence)),
+                                         C.c_uint32(last_res), C.c_uint32(last_base), C.c_uint32(int(unbiased)), steps, C.c_uint32(64),
+                                         C.byref(n), C.byref(nr), C.byref(nb))
+    if rc:
+        raise GfxError("gfxh_restir_frame_program: the exchange strip is taller than the band")
+    return [steps[i] for i in range(n.value)], nr.value, nb.value
+
+
+def strip_rows(height, band_begin, band_end, rows):
+    d = GfxhExchangeDesc()
+    rc = lib().gfxh_strip_rows(C.c_uint32(height), C.c_uint32(band_begin), C.c_uint32(band_end), C.c_uint32(rows), C.byref(d))
+    return d, rc
+
+
 class GfxhBandPlan(C.Structure):
     _fields_ = [("bandBegin", C.c_uint32), ("bandEnd", C.c_uint32), ("haloRows", C.c_uint32),
                 ("gbufferRows", C.c_uint32 * 2), ("initialRows", C.c_uint32 * 2), ("spatialRows", (C.c_uint32 * 2) * 8),
@@ -167,7 +209,8 @@ HOST_ABI_SYMBOLS = [
     "gfxh_scene_get_material", "gfxh_scene_get_geom", "gfxh_scene_get_group", "gfxh_scene_get_instance",
     "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
     "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
-    "gfxh_restir_band_plan", "gfxh_restir_create",
+    "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_restir_frame_program",
+    "gfxh_rccl_unique_id", "gfxh_rccl_create", "gfxh_rccl_destroy", "gfxh_rccl_exchange", "gfxh_rccl_last_error", "gfxh_restir_create",
     "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
@@ -717,6 +760,19 @@ class RestirRenderer:
         plan = GfxhBandPlan()
         self.L.gfxh_restir_band_plan(self.h, C.byref(plan))
         return plan
+
+    def set_exchange(self, fn, max_motion_rows=0):
+        """Install the strip-exchange callback of a band renderer: fn(stream, desc: GfxhExchangeDesc) -> None / raises."""
+        def thunk(user, stream, desc):
+            try:
+                fn(stream, desc.contents)
+                return 0
+            except Exception:       # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._exchange_cb = EXCHANGE_FN(thunk)     # keep the trampoline alive
+        self.L.gfxh_restir_set_exchange(self.h, self._exchange_cb, None, C.c_uint32(max_motion_rows))
 
     def render_frame(self, stream=0):
         if self.L.gfxh_restir_render_frame(self.h, C.c_void_p(stream)):

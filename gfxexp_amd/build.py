@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libgfxexp.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = ["capi.cpp", "scene.cpp", "lights.hip", "lbvh.hip", "trace.hip", "restir.hip", "pathtrace.hip", "nrc.hip", "textures.hip",
-           "host/scene_builder.cpp", "host/restir_driver.cpp", "host/nrc_driver.cpp"]
+           "host/scene_builder.cpp", "host/restir_driver.cpp", "host/nrc_driver.cpp", "host/rccl_exchange.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(HERE, "..", "include")]

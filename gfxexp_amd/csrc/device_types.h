@@ -64,7 +64,7 @@ struct EmitterRec {
     float pA[3], pB[3], pC[3];
     float nA[3], nB[3], nC[3];
     float emittance[3];
-    uint32_t instSlot;
+    uint32_t texEmittance; // emittance-texture slot of the material, or 0: only then is the record's EmitterTexRef read
     float twoOverLenNg;   // 2 / |cross(pB - pA, pC - pA)|: the per-triangle factor of the area density
     float primProb;       // weight / integral inside the owning geometry instance's distribution
 };

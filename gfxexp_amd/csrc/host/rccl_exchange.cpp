@@ -1,0 +1,157 @@
+// rccl_exchange.cpp -- the exchange callback of a band renderer (gfxh_restir_set_exchange) over RCCL, for C++ host
+// programs that run one process per GPU of a node (xGMI).  librccl is loaded with dlopen on first use, so libgfxexp.so
+// has no link-time dependency on it and single-GPU users never touch it.
+//
+//   strips           ncclSend / ncclRecv of every (buffer, plane) row range, one group per exchange point: the two
+//                    neighbours of a rank sit on direct xGMI links, a strip is 2-4 MB at 1080p
+//   counters         ncclAllReduce(sum, u32) in place (ReGIR cell-access counters: 32 KB)
+//   HDR bands        ncclAllGather of slabs sized for the tallest band into a staging buffer, then one hipMemcpyAsync
+//                    per remote band into the frame (bands differ by at most 8 rows)
+// All operations are enqueued on the caller's stream.  bench.py and the tests use torch.distributed for the same
+// descriptors (gfxexp_amd/tilesplit.py StripExchange); both are driven by the same gfxh_exchange_desc.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../../include/gfxexp_host.h"
+
+namespace {
+
+typedef struct ncclComm* ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+enum { kNcclUint8 = 1, kNcclUint32 = 3, kNcclSum = 0 };
+
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    bool load(std::string& err) {
+        if (lib) return true;
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
+        return GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && AllGather;
+    }
+};
+RcclApi g_rccl;
+thread_local std::string g_rcclError;
+
+} // namespace
+
+struct gfxh_rccl {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    std::vector<uint32_t> bandBegin, bandEnd;   // of every rank: whole 8-row tiles, remainder spread from rank 0
+    void* staging = nullptr; size_t stagingBytes = 0;
+};
+
+extern "C" {
+
+const char* gfxh_rccl_last_error(void) { return g_rcclError.c_str(); }
+
+int gfxh_rccl_unique_id(void* id128) {
+    if (!g_rccl.load(g_rcclError)) return 1;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id)) { g_rcclError = "ncclGetUniqueId failed"; return 1; }
+    std::memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int gfxh_rccl_create(const void* id128, int rank, int world, uint32_t height, gfxh_rccl** out) {
+    *out = nullptr;
+    if (!g_rccl.load(g_rcclError)) return 1;
+    gfxh_rccl* c = new gfxh_rccl();
+    c->rank = rank; c->world = world;
+    const uint32_t tiles = (height + 7) / 8, base = tiles / world, extra = tiles % world;
+    uint32_t row = 0;
+    for (int r = 0; r < world; ++r) {
+        const uint32_t h = (base + (static_cast<uint32_t>(r) < extra ? 1u : 0u)) * 8;
+        c->bandBegin.push_back(row); row = std::min(height, row + h); c->bandEnd.push_back(row);
+    }
+    ncclUniqueId id; std::memcpy(&id, id128, sizeof(id));
+    if (g_rccl.CommInitRank(&c->comm, world, id, rank)) { g_rcclError = "ncclCommInitRank failed"; delete c; return 1; }
+    *out = c;
+    return 0;
+}
+
+void gfxh_rccl_destroy(gfxh_rccl* c) {
+    if (!c) return;
+    if (c->comm) g_rccl.CommDestroy(c->comm);
+    if (c->staging) (void)hipFree(c->staging);
+    delete c;
+}
+
+int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d) {
+    gfxh_rccl* c = static_cast<gfxh_rccl*>(user);
+    hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+    int err = 0;
+    if (d->kind == GFXH_EXCHANGE_ALLREDUCE_SUM_U32)
+        return g_rccl.AllReduce(d->counters, d->counters, d->numCounters, kNcclUint32, kNcclSum, c->comm, stream) ? 1 : 0;
+    if (d->kind == GFXH_EXCHANGE_STRIPS) {
+        err |= g_rccl.GroupStart();
+        for (uint32_t k = 0; k < d->numBuffers; ++k) {
+            const gfxh_exchange_buffer& b = d->buffers[k];
+            const size_t rowBytes = static_cast<size_t>(b.bytesPerPixel) * d->width;
+            for (uint32_t plane = 0; plane < b.numPlanes; ++plane) {
+                char* base = static_cast<char*>(b.base) + plane * b.planeStride;
+                auto rows = [&](const uint32_t r[2]) { return static_cast<size_t>(r[1] - r[0]) * rowBytes; };
+                if (c->rank > 0) {
+                    if (rows(d->sendAbove)) err |= g_rccl.Send(base + d->sendAbove[0] * rowBytes, rows(d->sendAbove), kNcclUint8, c->rank - 1, c->comm, stream);
+                    if (rows(d->recvAbove)) err |= g_rccl.Recv(base + d->recvAbove[0] * rowBytes, rows(d->recvAbove), kNcclUint8, c->rank - 1, c->comm, stream);
+                }
+                if (c->rank + 1 < c->world) {
+                    if (rows(d->sendBelow)) err |= g_rccl.Send(base + d->sendBelow[0] * rowBytes, rows(d->sendBelow), kNcclUint8, c->rank + 1, c->comm, stream);
+                    if (rows(d->recvBelow)) err |= g_rccl.Recv(base + d->recvBelow[0] * rowBytes, rows(d->recvBelow), kNcclUint8, c->rank + 1, c->comm, stream);
+                }
+            }
+        }
+        err |= g_rccl.GroupEnd();
+        return err ? 1 : 0;
+    }
+    if (d->kind == GFXH_EXCHANGE_GATHER_BANDS) {
+        const gfxh_exchange_buffer& b = d->buffers[0];
+        const size_t rowBytes = static_cast<size_t>(b.bytesPerPixel) * d->width;
+        uint32_t maxRows = 0;
+        for (int r = 0; r < c->world; ++r) maxRows = std::max(maxRows, c->bandEnd[r] - c->bandBegin[r]);
+        const size_t slab = static_cast<size_t>(maxRows) * rowBytes;
+        if (c->stagingBytes < slab * c->world) {
+            if (c->staging) (void)hipFree(c->staging);
+            if (hipMalloc(&c->staging, slab * c->world) != hipSuccess) { g_rcclError = "hipMalloc of the gather staging buffer failed"; return 1; }
+            c->stagingBytes = slab * c->world;
+        }
+        char* frame = static_cast<char*>(b.base);
+        // in-place form: every rank's own slab inside the staging buffer is its send buffer
+        char* own = static_cast<char*>(c->staging) + slab * c->rank;
+        if (hipMemcpyAsync(own, frame + c->bandBegin[c->rank] * rowBytes, (c->bandEnd[c->rank] - c->bandBegin[c->rank]) * rowBytes,
+                           hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
+        if (g_rccl.AllGather(own, c->staging, slab, kNcclUint8, c->comm, stream)) return 1;
+        for (int r = 0; r < c->world; ++r) {
+            if (r == c->rank) continue;
+            if (hipMemcpyAsync(frame + c->bandBegin[r] * rowBytes, static_cast<char*>(c->staging) + slab * r,
+                               (c->bandEnd[r] - c->bandBegin[r]) * rowBytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
+        }
+        return 0;
+    }
+    g_rcclError = "gfxh_rccl_exchange: unknown exchange kind";
+    return 1;
+}
+
+} // extern "C"

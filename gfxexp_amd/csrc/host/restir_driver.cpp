@@ -47,6 +47,11 @@ struct gfxh_restir {
     hipStream_t gbStream = nullptr;
     hipEvent_t evPrevRead = nullptr, evGbuffer = nullptr;
     bool prevReadPending = false, pipelineFrames = true;
+    // strip-exchange mode of a band renderer (gfxh_restir_set_exchange)
+    gfxh_exchange_fn exchange = nullptr;
+    void* exchangeUser = nullptr;
+    uint32_t maxMotionRows = 0;
+    bool viewMoved = false;     // the camera or an instance moved since the last frame (accumulation restarts; band seams need motion rows)
 };
 
 extern "C" {
@@ -215,6 +220,21 @@ void gfxh_restir_destroy(gfxh_restir* r) {
     delete r;
 }
 
+int gfxh_strip_rows(uint32_t height, uint32_t bandBegin, uint32_t bandEnd, uint32_t rows, gfxh_exchange_desc* out) {
+    const uint32_t b = bandBegin, e = bandEnd;
+    out->recvAbove[0] = b > rows ? b - rows : 0u; out->recvAbove[1] = b;
+    out->recvBelow[0] = e; out->recvBelow[1] = std::min(height, e + rows);
+    out->sendAbove[0] = b; out->sendAbove[1] = b == 0 ? b : std::min(e, b + rows);
+    out->sendBelow[0] = e >= height ? e : (e - b > rows ? e - rows : b); out->sendBelow[1] = e;
+    // a strip taller than the band would have to come from a rank further away than the adjacent one
+    return (rows > e - b && (b > 0 || e < height)) ? 1 : 0;
+}
+
+int gfxh_restir_set_exchange(gfxh_restir* r, gfxh_exchange_fn fn, void* user, uint32_t maxMotionRows) {
+    r->exchange = fn; r->exchangeUser = user; r->maxMotionRows = maxMotionRows;
+    return 0;
+}
+
 int gfxh_restir_band_plan(gfxh_restir* r, gfxh_band_plan* out) {
     const gfxh_restir_config& cfg = r->cfg;
     const bool whole = cfg.rowBegin == 0 && cfg.rowEnd == 0;
@@ -260,7 +280,11 @@ int gfxh_restir_set_env(gfxh_restir* r, float* texels, uint32_t w, uint32_t h, f
     r->resetRequested = true;
     return 0;
 }
-int gfxh_restir_set_camera(gfxh_restir* r, const gfx_camera* cam) { r->camera = *cam; return 0; }
+int gfxh_restir_set_camera(gfxh_restir* r, const gfx_camera* cam) {
+    if (std::memcmp(&r->camera, cam, sizeof(*cam)) != 0) r->viewMoved = true;
+    r->camera = *cam;
+    return 0;
+}
 int gfxh_restir_rebuild_accel(gfxh_restir* r, void* stream) {
     // in place: the handle stays valid.  Ordered after everything queued on `stream`; the pipelined G-buffer pass
     // of the last frame was joined into that stream before its later passes were queued.
@@ -268,6 +292,7 @@ int gfxh_restir_rebuild_accel(gfxh_restir* r, void* stream) {
     // the next frame's pipelined G-buffer pass must not start before the build
     if (r->evPrevRead && !hip_ok(hipEventRecord(r->evPrevRead, static_cast<hipStream_t>(stream)), "hipEventRecord")) return 1;
     r->prevReadPending = r->evPrevRead != nullptr;
+    r->viewMoved = true;   // "animate" of restir_di_main.cpp:2312-2313
     return 0;
 }
 void* gfxh_restir_beauty_buffer(gfxh_restir* r) { return r->sp.beautyAccumBuffer; }
@@ -281,6 +306,121 @@ int gfxh_restir_get_params(gfxh_restir* r, gfx_restir_static_params* s, gfx_rest
     if (lastSpatialNeighborBaseIndex) *lastSpatialNeighborBaseIndex = r->lastSpatialNeighborBaseIndex;
     if (frameIndex) *frameIndex = r->frameIndex;
     return 0;
+}
+
+// The frame of restir_di_main.cpp:2311-2493 (original and rearchitected ReSTIR), path_tracing_main.cpp:2068-2093 and
+// regir_main.cpp:2021-2066 as a list of steps: the passes with their row ranges and the reservoir / neighbour-table
+// indices in force, plus -- stripMode -- the exchange points of a band renderer (gfxexp_host.h, gfxh_restir_set_exchange).
+// Pure host logic: the GPU driver executes it, and the multi-process CPU tests execute the same program with the oracle.
+int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uint32_t maxMotionRows, int newSequence,
+                              uint32_t lastReservoirIndex, uint32_t lastSpatialNeighborBaseIndex, uint32_t useUnbiasedEstimator,
+                              gfxh_frame_step* steps, uint32_t capacity, uint32_t* numSteps, uint32_t* newLastReservoirIndex,
+                              uint32_t* newLastSpatialNeighborBaseIndex) {
+    const gfxh_restir_config& cfg = *cfgp;
+    const bool whole = cfg.rowBegin == 0 && cfg.rowEnd == 0;
+    const bool strips = stripMode && !whole;
+    const uint32_t passes = cfg.enableSpatialReuse ? cfg.numSpatialReusePasses : 0;
+    const uint32_t radiusRows = static_cast<uint32_t>(std::ceil(cfg.spatialNeighborRadius));
+    gfxh_band_plan plan;
+    gfxh_band_plan_compute(cfg.height, whole ? 0 : cfg.rowBegin, whole ? cfg.height : cfg.rowEnd, radiusRows, passes, 0, &plan);
+    if (strips) {   // every pass on the band only
+        plan.gbufferRows[0] = plan.initialRows[0] = plan.shadingRows[0] = plan.bandBegin;
+        plan.gbufferRows[1] = plan.initialRows[1] = plan.shadingRows[1] = plan.bandEnd;
+        for (int i = 0; i < 8; ++i) { plan.spatialRows[i][0] = plan.bandBegin; plan.spatialRows[i][1] = plan.bandEnd; }
+    }
+    uint32_t n = 0;
+    int tooTall = 0;
+    uint32_t currentReservoirIndex = (lastReservoirIndex + 1) % 2;  // :2352
+    uint32_t baseIndex = lastSpatialNeighborBaseIndex;
+    auto push = [&](uint32_t op, uint32_t pass, uint32_t rb, uint32_t re) -> gfxh_frame_step* {
+        if (n >= capacity) return nullptr;
+        gfxh_frame_step& st = steps[n++];
+        std::memset(&st, 0, sizeof(st));
+        st.op = op; st.pass = pass; st.rowBegin = rb; st.rowEnd = re;
+        st.currentReservoirIndex = currentReservoirIndex; st.spatialNeighborBaseIndex = baseIndex;
+        return &st;
+    };
+    auto exchange = [&](uint32_t rows, uint32_t buffers, uint32_t reservoirIndex) {
+        if (!strips || rows == 0) return;
+        gfxh_exchange_desc d;
+        if (gfxh_strip_rows(cfg.height, plan.bandBegin, plan.bandEnd, rows, &d)) tooTall = 1;
+        if (gfxh_frame_step* st = push(GFXH_STEP_EXCHANGE_STRIPS, 0, 0, 0)) { st->exchangeRows = rows; st->buffers = buffers; st->reservoirIndex = reservoirIndex; }
+    };
+    auto gather = [&]() { if (strips) push(GFXH_STEP_GATHER_BANDS, 0, plan.bandBegin, plan.bandEnd); };
+    const uint32_t motion = maxMotionRows;
+
+    if (cfg.renderer == GFXH_PATH_TRACE_REGIR) {
+        // regir_main.cpp:2021-2066: G-buffer, cell reservoirs (+ temporal reuse unless a new sequence), ReGIR path tracing,
+        // last-access update.  The grid lives in world space: every rank builds all of it (same slot RNGs, same access
+        // history) and traces its own rows; the per-cell access counters are summed over the ranks before they age the cells.
+        const uint32_t rb = strips ? plan.bandBegin : 0, re = strips ? plan.bandEnd : 0;
+        push(GFXH_STEP_PT_PASS, GFX_PT_SETUP_GBUFFERS, rb, re);
+        push(GFXH_STEP_PREV_GBUFFER_RELEASED, 0, 0, 0);
+        push(GFXH_STEP_PT_PASS, (cfg.regirEnableTemporalReuse && !newSequence) ? GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL : GFX_PT_REGIR_BUILD_CELL_RESERVOIRS, 0, 0);
+        push(GFXH_STEP_PT_PASS, GFX_PT_PATH_TRACE_REGIR, rb, re);
+        if (strips) push(GFXH_STEP_ALLREDUCE_CELL_ACCESSES, 0, 0, 0);
+        push(GFXH_STEP_PT_PASS, GFX_PT_REGIR_UPDATE_LAST_ACCESS, 0, 0);
+        gather();
+    }
+    else if (cfg.renderer == GFXH_PATH_TRACE_BASELINE) {
+        // path_tracing_main.cpp:2068-2093: G-buffer pipeline, then pathTraceBaseline.  Paths never read a neighbour's pixel state.
+        push(GFXH_STEP_PT_PASS, GFX_PT_SETUP_GBUFFERS, plan.bandBegin, whole ? 0 : plan.bandEnd);
+        push(GFXH_STEP_PREV_GBUFFER_RELEASED, 0, 0, 0);
+        push(GFXH_STEP_PT_PASS, GFX_PT_PATH_TRACE_BASELINE, plan.bandBegin, whole ? 0 : plan.bandEnd);
+        gather();
+    }
+    else if (cfg.renderer == GFXH_REARCHITECTED_RESTIR_BIASED || cfg.renderer == GFXH_REARCHITECTED_RESTIR_UNBIASED) {
+        // restir_di_main.cpp:2423-2487.  The pre-sampled lights are replicated (same RNG streams on every rank); the
+        // per-pixel passes run on the band.  A band without an exchange callback renders the whole frame (its halo
+        // would need the previous frame's state of other ranks).
+        const uint32_t rb = strips ? plan.bandBegin : 0, re = strips ? plan.bandEnd : 0;
+        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SETUP_GBUFFERS, rb, re);                       // :2366-2367
+        const bool T = cfg.enableTemporalReuse && !newSequence, S = cfg.enableSpatialReuse && !newSequence;
+        const int k = (T && S) ? 3 : T ? 1 : S ? 2 : 0;
+        const uint32_t trace = GFX_RESTIR_TRACE_SHADOW_RAYS + (k == 0 ? 0 : k + (useUnbiasedEstimator ? 3 : 0));
+        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_LIGHT_PRESAMPLING, 0, 0);
+        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_PER_PIXEL_RIS, rb, re);
+        push(GFXH_STEP_RESTIR_PASS, trace, rb, re);
+        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SHADE_AND_RESAMPLE + k, rb, re);
+        push(GFXH_STEP_PREV_GBUFFER_RELEASED, 0, 0, 0);   // shadeAndResample reads the previous G-buffer and sample visibility
+        // everything the next frame reads as "the previous frame" around a pixel: its temporal neighbour (motion) and
+        // its spatiotemporal neighbours (radius)
+        const uint32_t rows = (cfg.enableSpatialReuse ? radiusRows : 0u) + (cfg.enableTemporalReuse ? motion : 0u);
+        if (cfg.enableTemporalReuse || cfg.enableSpatialReuse)
+            exchange(rows, GFXH_BUF_GBUFFERS | GFXH_BUF_SAMPLE_VISIBILITY | GFXH_BUF_RESERVOIRS, currentReservoirIndex);
+        gather();
+        ++baseIndex;                                                                           // :2486
+    }
+    else {
+        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SETUP_GBUFFERS, plan.gbufferRows[0], whole ? 0 : plan.gbufferRows[1]);   // :2366-2367
+        // strip mode: the G-buffer rows the spatial passes (radius) and the next frame's temporal pass (motion) read
+        exchange(std::max(cfg.enableSpatialReuse ? radiusRows : 0u, cfg.enableTemporalReuse ? motion : 0u), GFXH_BUF_GBUFFERS, 0);
+        uint32_t entry = GFX_RESTIR_INITIAL_RIS;                                               // :2378-2384
+        if (cfg.enableTemporalReuse && !newSequence)
+            entry = useUnbiasedEstimator ? GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED : GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED;
+        push(GFXH_STEP_RESTIR_PASS, entry, plan.initialRows[0], whole ? 0 : plan.initialRows[1]);
+        push(GFXH_STEP_PREV_GBUFFER_RELEASED, 0, 0, 0);   // only the temporal pass reads the previous frame's G-buffer
+        if (cfg.enableSpatialReuse) {                                                          // :2393-2411
+            const uint32_t spatial = useUnbiasedEstimator ? GFX_RESTIR_SPATIAL_UNBIASED : GFX_RESTIR_SPATIAL_BIASED;
+            const uint32_t base0 = baseIndex;
+            for (uint32_t i = 0; i < cfg.numSpatialReusePasses; ++i) {
+                // strip mode: the reservoirs this pass resamples from, radius rows either side of the band
+                exchange(radiusRows, GFXH_BUF_RESERVOIRS, currentReservoirIndex);
+                baseIndex = base0 + cfg.numSpatialNeighbors * i;
+                push(GFXH_STEP_RESTIR_PASS, spatial, plan.spatialRows[i][0], whole ? 0 : plan.spatialRows[i][1]);
+                currentReservoirIndex = (currentReservoirIndex + 1) % 2;
+            }
+            baseIndex = base0 + cfg.numSpatialNeighbors * cfg.numSpatialReusePasses;
+        }
+        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SHADING, plan.shadingRows[0], whole ? 0 : plan.shadingRows[1]);   // :2418-2420
+        // strip mode: the final reservoirs the next frame's temporal pass reads across the seams
+        if (cfg.enableTemporalReuse) exchange(motion, GFXH_BUF_RESERVOIRS, currentReservoirIndex);
+        gather();
+    }
+    *numSteps = n;
+    *newLastReservoirIndex = (cfg.renderer == GFXH_PATH_TRACE_REGIR || cfg.renderer == GFXH_PATH_TRACE_BASELINE) ? lastReservoirIndex : currentReservoirIndex;   // :2493
+    *newLastSpatialNeighborBaseIndex = baseIndex;
+    return (n >= capacity || tooTall) ? 1 : 0;
 }
 
 int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
@@ -298,7 +438,9 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
 
     const bool newSequence = frameIndex == 0 || r->resetRequested;     // :2311 (no resize in a headless run)
     r->resetRequested = false;
-    const bool firstAccumFrame = !cfg.enableAccumulation || newSequence;   // :2312-2313 (no animation / camera motion)
+    const bool viewMoved = r->viewMoved;
+    r->viewMoved = false;
+    const bool firstAccumFrame = !cfg.enableAccumulation || newSequence || viewMoved;   // :2312-2313 (animate || cameraIsActuallyMoving)
     if (firstAccumFrame) r->numAccumFrames = 0;
     else r->numAccumFrames = std::min(r->numAccumFrames + 1, 1u << cfg.log2MaxNumAccums);
 
@@ -325,101 +467,87 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     fp.enableBumpMapping = cfg.enableBumpMapping;
     fp.useSolidAngleSampling = 0;
 
-    uint32_t currentReservoirIndex = (r->lastReservoirIndex + 1) % 2;  // :2352
+    // the frame as a program (gfxh_restir_frame_program): passes with their row ranges and index bookkeeping, and -- for a
+    // band renderer with an exchange callback -- the points where rows owned by other ranks have to arrive
+    const bool wholeFrame = cfg.rowBegin == 0 && cfg.rowEnd == 0;
+    const bool strips = r->exchange != nullptr && !wholeFrame;
+    if (!wholeFrame && viewMoved && (!strips || r->maxMotionRows == 0)) {
+        g_driverError = "gfxh_restir_render_frame: the camera or an instance moved, but this band renderer exchanges no motion rows "
+                        "(gfxh_restir_set_exchange with maxMotionRows > 0)";
+        return 1;
+    }
+    gfxh_frame_step steps[64];
+    uint32_t numSteps = 0, newLastRes = 0, newLastBase = 0;
+    if (gfxh_restir_frame_program(&cfg, strips ? 1 : 0, r->maxMotionRows, newSequence ? 1 : 0, r->lastReservoirIndex, r->lastSpatialNeighborBaseIndex,
+                                  fp.useUnbiasedEstimator, steps, 64, &numSteps, &newLastRes, &newLastBase)) {
+        g_driverError = "gfxh_restir_render_frame: the exchange strip is taller than the band (fewer ranks or a smaller radius)";
+        return 1;
+    }
     const uint32_t W = cfg.width, H = cfg.height;
-    gfxh_band_plan plan;
-    gfxh_restir_band_plan(r, &plan);
+    const size_t numPixelsAll = static_cast<size_t>(W) * H;
 #define DRV_GFX(call) do { if (call) { g_driverError = gfx_last_error(ctx); return 1; } } while (0)
     // G-buffer pass, pipelined under the previous frame when nothing forbids it: jittering advances the pixel
-    // RNGs the previous frame's passes are still drawing from, and a band renderer's halo exchange has its own
+    // RNGs the previous frame's passes are still drawing from, and a band renderer's exchanges have their own
     // ordering with the caller's stream.
     hipStream_t main = static_cast<hipStream_t>(stream);
-    const bool wholeFrame = cfg.rowBegin == 0 && cfg.rowEnd == 0;
     const bool pipelined = r->pipelineFrames && !cfg.enableJittering && wholeFrame;
-    auto gbuffer_pass = [&](bool pathTraceEntry, uint32_t rowBegin, uint32_t rowEnd) -> int {
-        hipStream_t s = main;
-        if (pipelined) {
-            s = r->gbStream;
-            if (r->prevReadPending) DRV_HIP(hipStreamWaitEvent(s, r->evPrevRead, 0));
-            else { DRV_HIP(hipEventRecord(r->evPrevRead, main)); DRV_HIP(hipStreamWaitEvent(s, r->evPrevRead, 0)); }   // first frame: after whatever the caller queued
+    if (cfg.renderer == GFXH_PATH_TRACE_REGIR) DRV_GFX(gfx_regir_set_params(ctx, &r->regir));
+    for (uint32_t k = 0; k < numSteps; ++k) {
+        const gfxh_frame_step& st = steps[k];
+        switch (st.op) {
+        case GFXH_STEP_RESTIR_PASS:
+        case GFXH_STEP_PT_PASS: {
+            hipStream_t s = main;
+            const bool gb = (st.op == GFXH_STEP_RESTIR_PASS && st.pass == GFX_RESTIR_SETUP_GBUFFERS) || (st.op == GFXH_STEP_PT_PASS && st.pass == GFX_PT_SETUP_GBUFFERS);
+            if (gb && pipelined) {
+                s = r->gbStream;
+                if (r->prevReadPending) DRV_HIP(hipStreamWaitEvent(s, r->evPrevRead, 0));
+                else { DRV_HIP(hipEventRecord(r->evPrevRead, main)); DRV_HIP(hipStreamWaitEvent(s, r->evPrevRead, 0)); }   // first frame: after whatever the caller queued
+            }
+            DRV_GFX(gfx_restir_set_params(ctx, s, &r->sp, &fp, st.currentReservoirIndex, st.spatialNeighborBaseIndex));
+            if (st.op == GFXH_STEP_PT_PASS) DRV_GFX(gfx_pt_launch(ctx, s, static_cast<int>(st.pass), W, H, cfg.maxPathLength, st.rowBegin, st.rowEnd));
+            else DRV_GFX(gfx_restir_launch_rows(ctx, s, static_cast<int>(st.pass), W, H, st.rowBegin, st.rowEnd));
+            if (gb && pipelined) {
+                DRV_HIP(hipEventRecord(r->evGbuffer, s));
+                DRV_HIP(hipStreamWaitEvent(main, r->evGbuffer, 0));
+            }
+            break;
         }
-        if (pathTraceEntry) DRV_GFX(gfx_pt_launch(ctx, s, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, rowBegin, rowEnd));
-        else DRV_GFX(gfx_restir_launch_rows(ctx, s, GFX_RESTIR_SETUP_GBUFFERS, W, H, rowBegin, rowEnd));
-        if (pipelined) {
-            DRV_HIP(hipEventRecord(r->evGbuffer, s));
-            DRV_HIP(hipStreamWaitEvent(main, r->evGbuffer, 0));
+        case GFXH_STEP_PREV_GBUFFER_RELEASED:   // the frame has queued its last pass that reads the previous frame's G-buffer
+            if (pipelined) { DRV_HIP(hipEventRecord(r->evPrevRead, main)); r->prevReadPending = true; }
+            break;
+        case GFXH_STEP_EXCHANGE_STRIPS:
+        case GFXH_STEP_ALLREDUCE_CELL_ACCESSES:
+        case GFXH_STEP_GATHER_BANDS: {
+            gfxh_exchange_desc d; std::memset(&d, 0, sizeof(d));
+            d.stage = k; d.width = W; d.height = H;
+            d.bandBegin = cfg.rowBegin; d.bandEnd = cfg.rowEnd;
+            auto add = [&](void* base, uint32_t bytesPerPixel, uint32_t planes) {
+                gfxh_exchange_buffer& b = d.buffers[d.numBuffers++];
+                b.base = base; b.bytesPerPixel = bytesPerPixel; b.numPlanes = planes; b.planeStride = static_cast<uint64_t>(bytesPerPixel) * numPixelsAll;
+            };
+            if (st.op == GFXH_STEP_EXCHANGE_STRIPS) {
+                d.kind = GFXH_EXCHANGE_STRIPS;
+                gfxh_strip_rows(H, cfg.rowBegin, cfg.rowEnd, st.exchangeRows, &d);
+                if (st.buffers & GFXH_BUF_GBUFFERS) { add(r->sp.gbuffer0[bufferIndex], 16, 1); add(r->sp.gbuffer2[bufferIndex], 16, 1); add(r->sp.gbuffer3[bufferIndex], 16, 1); }
+                if (st.buffers & GFXH_BUF_SAMPLE_VISIBILITY) add(r->sp.sampleVisibilityBuffer[bufferIndex], 4, 1);
+                if (st.buffers & GFXH_BUF_RESERVOIRS) { add(r->sp.reservoirBuffer[st.reservoirIndex], 16, 3); add(r->sp.reservoirInfoBuffer[st.reservoirIndex], 8, 1); }
+            }
+            else if (st.op == GFXH_STEP_ALLREDUCE_CELL_ACCESSES) {
+                d.kind = GFXH_EXCHANGE_ALLREDUCE_SUM_U32;
+                d.counters = r->regir.perCellNumAccesses;
+                d.numCounters = static_cast<uint64_t>(r->regir.gridDimension[0]) * r->regir.gridDimension[1] * r->regir.gridDimension[2];
+            }
+            else { d.kind = GFXH_EXCHANGE_GATHER_BANDS; add(r->sp.beautyAccumBuffer, 16, 1); }
+            if (r->exchange(r->exchangeUser, stream, &d)) { g_driverError = "gfxh_restir_render_frame: the exchange callback failed"; return 1; }
+            break;
         }
-        return 0;
-    };
-    // call once the frame has queued its last pass that reads the previous frame's G-buffer
-    auto prev_gbuffer_released = [&]() -> int {
-        if (pipelined) { DRV_HIP(hipEventRecord(r->evPrevRead, main)); r->prevReadPending = true; }
-        return 0;
-    };
-    DRV_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, currentReservoirIndex, r->lastSpatialNeighborBaseIndex));
-    if (cfg.renderer == GFXH_PATH_TRACE_REGIR) {
-        // regir_main.cpp:2021-2066: G-buffer, cell reservoirs (+ temporal reuse unless a new sequence), ReGIR path
-        // tracing, last-access update.  Whole frame (the grid is shared state).
-        DRV_GFX(gfx_regir_set_params(ctx, &r->regir));
-        if (gbuffer_pass(true, 0, 0) || prev_gbuffer_released()) return 1;
-        const int build = (cfg.regirEnableTemporalReuse && !newSequence) ? GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL : GFX_PT_REGIR_BUILD_CELL_RESERVOIRS;
-        DRV_GFX(gfx_pt_launch(ctx, stream, build, W, H, cfg.maxPathLength, 0, 0));
-        DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_REGIR, W, H, cfg.maxPathLength, 0, 0));
-        DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_REGIR_UPDATE_LAST_ACCESS, W, H, cfg.maxPathLength, 0, 0));
-        r->prevCamera = r->camera;
-        ++r->frameIndex;
-        return 0;
-    }
-    if (cfg.renderer == GFXH_PATH_TRACE_BASELINE) {
-        // path_tracing_main.cpp:2068-2093: G-buffer pipeline, then pathTraceBaseline.  A band needs no
-        // halo: paths never read a neighbour's pixel state.
-        if (gbuffer_pass(true, plan.bandBegin, plan.bandEnd) || prev_gbuffer_released()) return 1;
-        DRV_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_BASELINE, W, H, cfg.maxPathLength, plan.bandBegin, plan.bandEnd));
-        r->prevCamera = r->camera;
-        ++r->frameIndex;
-        return 0;
-    }
-    if (gbuffer_pass(false, plan.gbufferRows[0], plan.gbufferRows[1])) return 1;                  // :2366-2367
-
-    if (cfg.renderer == GFXH_REARCHITECTED_RESTIR_BIASED || cfg.renderer == GFXH_REARCHITECTED_RESTIR_UNBIASED) {
-        // restir_di_main.cpp:2423-2487; whole-frame only (the previous frame's reservoirs, sample
-        // visibility and G-buffers of halo rows are not exchanged for this renderer yet)
-        const bool T = cfg.enableTemporalReuse && !newSequence, S = cfg.enableSpatialReuse && !newSequence;
-        const int k = (T && S) ? 3 : T ? 1 : S ? 2 : 0;
-        const int trace = GFX_RESTIR_TRACE_SHADOW_RAYS + (k == 0 ? 0 : k + (fp.useUnbiasedEstimator ? 3 : 0));
-        const int shade = GFX_RESTIR_SHADE_AND_RESAMPLE + k;
-        DRV_GFX(gfx_restir_launch(ctx, stream, GFX_RESTIR_LIGHT_PRESAMPLING, W, H));
-        DRV_GFX(gfx_restir_launch(ctx, stream, GFX_RESTIR_PER_PIXEL_RIS, W, H));
-        DRV_GFX(gfx_restir_launch(ctx, stream, trace, W, H));
-        DRV_GFX(gfx_restir_launch(ctx, stream, shade, W, H));
-        if (prev_gbuffer_released()) return 1;   // shadeAndResample reads the previous G-buffer and sample visibility
-        ++r->lastSpatialNeighborBaseIndex;                                                     // :2486
-        r->lastReservoirIndex = currentReservoirIndex;
-        r->prevCamera = r->camera;
-        ++r->frameIndex;
-        return 0;
-    }
-
-    int entry = GFX_RESTIR_INITIAL_RIS;                                                        // :2378-2384
-    if (cfg.enableTemporalReuse && !newSequence)
-        entry = fp.useUnbiasedEstimator ? GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED : GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED;
-    DRV_GFX(gfx_restir_launch_rows(ctx, stream, entry, W, H, plan.initialRows[0], plan.initialRows[1]));
-    if (prev_gbuffer_released()) return 1;   // only the temporal pass reads the previous frame's G-buffer
-
-    if (cfg.enableSpatialReuse) {                                                              // :2393-2411
-        const int spatial = fp.useUnbiasedEstimator ? GFX_RESTIR_SPATIAL_UNBIASED : GFX_RESTIR_SPATIAL_BIASED;
-        for (uint32_t i = 0; i < cfg.numSpatialReusePasses; ++i) {
-            const uint32_t baseIndex = r->lastSpatialNeighborBaseIndex + cfg.numSpatialNeighbors * i;
-            DRV_GFX(gfx_restir_set_params(ctx, stream, nullptr, nullptr, currentReservoirIndex, baseIndex));
-            DRV_GFX(gfx_restir_launch_rows(ctx, stream, spatial, W, H, plan.spatialRows[i][0], plan.spatialRows[i][1]));
-            currentReservoirIndex = (currentReservoirIndex + 1) % 2;
+        default: break;
         }
-        r->lastSpatialNeighborBaseIndex += cfg.numSpatialNeighbors * cfg.numSpatialReusePasses;
     }
-    DRV_GFX(gfx_restir_set_params(ctx, stream, nullptr, nullptr, currentReservoirIndex, r->lastSpatialNeighborBaseIndex));
-    DRV_GFX(gfx_restir_launch_rows(ctx, stream, GFX_RESTIR_SHADING, W, H, plan.shadingRows[0], plan.shadingRows[1]));   // :2418-2420
 #undef DRV_GFX
-    r->lastReservoirIndex = currentReservoirIndex;                                             // :2493
+    r->lastReservoirIndex = newLastRes;                                                        // :2493
+    r->lastSpatialNeighborBaseIndex = newLastBase;
     r->prevCamera = r->camera;
     ++r->frameIndex;
     return 0;

@@ -119,7 +119,7 @@ __global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* 
             // emittance = RGB(1) * texel for an emitter material (restir_di_shared.h:504-514)
             const f3 e = mat.hasEmittance ? f3(1.0f) * f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]) : f3(0.0f);
             r.emittance[0] = e.x; r.emittance[1] = e.y; r.emittance[2] = e.z;
-            r.instSlot = ii;
+            r.texEmittance = (texRefs && mat.hasEmittance) ? mat.texEmittance : 0u;
             r.twoOverLenNg = 2.0f / len(cross(pB - pA, pC - pA));
             r.primProb = sc.lightWeights[g.distOffset + t] / g.distIntegral;
             float4* dst = reinterpret_cast<float4*>(recs + recBase + t);

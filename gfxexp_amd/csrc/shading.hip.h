@@ -676,11 +676,11 @@ GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, floa
     const f3 n = bcA * nA + bcB * nB + bcC * nC;
     ls.normal = unit(mul(normalMatrix, n));
     ls.emittance = f3(r4.z, r4.w, r5.x);
-    if (EMITTER_TEX && sc.emitterTexRefs) {   // scene-uniform: some material has an emittance texture (restir_di_shared.h:504-514)
+    const uint32_t tex = EMITTER_TEX ? f2bits(r5.y) : 0u;   // EmitterRec::texEmittance (restir_di_shared.h:504-514)
+    if (tex) {
         const float4* tp = reinterpret_cast<const float4*>(sc.emitterTexRefs + pk.rec);
         const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-        const uint32_t tex = f2bits(t1.z);
-        if (tex) {
+        {
             const float tu = bcA * t0.x + bcB * t0.z + bcC * t1.x;
             const float tv = bcA * t0.y + bcB * t0.w + bcC * t1.y;
             DevTexture desc;

@@ -46,6 +46,7 @@ GFX_DEV TexelQuad tex_footprint(uint32_t W, uint32_t H, float u, float v) {
 GFX_DEV float4 tex_texel(const DevScene& sc, const DevTexture& t, uint32_t i, uint32_t j) {
     const size_t idx = static_cast<size_t>(j) * t.width + i;
     const uint32_t* pool = sc.texelPool + t.offset;
+    if (t.format == GFX_TEX_RGBA32F) return reinterpret_cast<const float4*>(pool)[idx];   // the common case of emittance maps first
     switch (t.format) {
     case GFX_TEX_RGBA8_SRGB: {
         const uint32_t c = pool[idx];

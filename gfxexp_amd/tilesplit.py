@@ -127,6 +127,85 @@ class HaloExchange:
                 req.wait()
 
 
+class StripExchange:
+    """The exchange callback of a band renderer (gfxh_restir_set_exchange / gfxh_exchange_desc) over torch.distributed:
+    RCCL on the GPUs (backend "nccl"), gloo in the CPU tests.  `view(ptr, nbytes)` turns an address into a flat uint8
+    tensor (device_view for device memory, host_view for the oracle's numpy buffers).
+
+      strips        batch_isend_irecv of every (buffer, plane) row range with the rank above / below
+      counters      all_reduce(sum) on the u32 array (as int32: wrap-around addition is the same)
+      HDR bands     all_gather_into_tensor of slabs sized for the tallest band, scattered back into the frame
+    The C++ twin is gfxh_rccl_exchange (csrc/host/rccl_exchange.cpp); both consume the same descriptors."""
+
+    def __init__(self, dist, rank, world, height, view, device="cpu"):
+        self.dist, self.rank, self.world, self.view, self.device = dist, rank, world, view, device
+        self.bands = band_rows(height, world)
+        self.bytes_moved = 0
+        self._stage = None
+
+    def __call__(self, stream, d):
+        from gfxexp_amd import api
+        import torch
+        dist = self.dist
+        if d.kind == api.EXCHANGE_ALLREDUCE_SUM_U32:
+            t = self.view(d.counters, 4 * d.numCounters).view(torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return
+        if d.kind == api.EXCHANGE_STRIPS:
+            ops = []
+            for k in range(d.numBuffers):
+                b = d.buffers[k]
+                row_bytes = b.bytesPerPixel * d.width
+                for plane in range(b.numPlanes):
+                    base = b.base + plane * b.planeStride
+
+                    def rows(r):
+                        n = (int(r[1]) - int(r[0])) * row_bytes
+                        return self.view(base + int(r[0]) * row_bytes, n) if n > 0 else None
+                    if self.rank > 0:
+                        for t, op in ((rows(d.sendAbove), dist.isend), (rows(d.recvAbove), dist.irecv)):
+                            if t is not None:
+                                ops.append(dist.P2POp(op, t, self.rank - 1))
+                    if self.rank < self.world - 1:
+                        for t, op in ((rows(d.sendBelow), dist.isend), (rows(d.recvBelow), dist.irecv)):
+                            if t is not None:
+                                ops.append(dist.P2POp(op, t, self.rank + 1))
+            self.bytes_moved += sum(op.tensor.numel() for op in ops)
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            return
+        if d.kind == api.EXCHANGE_GATHER_BANDS:
+            b = d.buffers[0]
+            row_bytes = b.bytesPerPixel * d.width
+            max_rows = max(e - s for s, e in self.bands)
+            slab = max_rows * row_bytes
+            if self._stage is None or self._stage[0].numel() != slab:
+                self._stage = (torch.zeros(slab, dtype=torch.uint8, device=self.device),
+                               torch.zeros(slab * self.world, dtype=torch.uint8, device=self.device))
+            send, recv = self._stage
+            s0, e0 = self.bands[self.rank]
+            frame = self.view(b.base, row_bytes * d.height)
+            send[:(e0 - s0) * row_bytes].copy_(frame[s0 * row_bytes:e0 * row_bytes])
+            dist.all_gather_into_tensor(recv, send)
+            for r, (rs, re) in enumerate(self.bands):
+                if r != self.rank:
+                    frame[rs * row_bytes:re * row_bytes].copy_(recv[r * slab:r * slab + (re - rs) * row_bytes])
+            return
+        raise ValueError("unknown exchange kind %d" % d.kind)
+
+
+def host_view(ptr, nbytes):
+    """Flat uint8 torch tensor over host memory at `ptr` (the oracle's numpy buffers in the CPU tests)."""
+    import ctypes
+    import torch
+    return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * int(nbytes)).from_address(int(ptr))))
+
+
+def device_bytes(ptr, nbytes):
+    return device_view(ptr, nbytes, "|u1")
+
+
 def device_view(ptr, count, typestr="<f4"):
     """Wrap a raw device pointer as a flat torch tensor without copying (CUDA array interface)."""
     import torch

@@ -170,6 +170,79 @@ void gfxh_band_plan_compute(uint32_t height, uint32_t bandBegin, uint32_t bandEn
                             uint32_t numSpatialPasses, uint32_t maxMotionRows, gfxh_band_plan* out);
 /* The plan the renderer uses (band from cfg.rowBegin/rowEnd; whole frame when both are 0). */
 int gfxh_restir_band_plan(gfxh_restir* r, gfxh_band_plan* out);
+/* ---- band renderers without redundant work: strip exchange between the passes (second alternative).
+ * With an exchange callback installed a band renderer (cfg.rowBegin / rowEnd) runs EVERY pass on its own rows only
+ * and, at the points of a frame where a pass is about to read rows another rank owns, hands the callback a
+ * description of what has to move: device buffers (base pointer, bytes per pixel, planes), the row ranges to send to
+ * / receive from the rank above (rank - 1) and below (rank + 1), or a counter array to sum over all ranks, or the
+ * band of the HDR buffer to all-gather.  The callback performs the transfer ordered with `stream` (RCCL:
+ * ncclSend / ncclRecv / ncclAllReduce / ncclAllGather on that stream -- gfxh_rccl_exchange below; bench.py and the
+ * gloo tests: torch.distributed).  Per-pixel RNG streams are advanced by their owner only, so nothing else is shared and
+ * the result is bit-identical to the single-GPU frame.  Exchange points per frame:
+ *   original ReSTIR     G-buffers (16+16+16 B/pixel) after the G-buffer pass, rows max(radius, motion); reservoirs +
+ *                       infos (56 B/pixel) before every spatial pass, rows radius; final reservoirs + infos after the
+ *                       last reuse pass, rows motion (the next frame's temporal pass)
+ *   rearchitected       everything the next frame reads from "the previous frame" (G-buffers, sample visibility,
+ *                       reservoirs, infos: 108 B/pixel) once at the end of the frame, rows radius + motion
+ *   ReGIR path tracer   all-reduce(sum) of perCellNumAccesses (one u32 per cell) before the last-access update
+ *   every renderer      all-gather of the float4 HDR bands at the end of the frame
+ * maxMotionRows bounds |motion vector y| over the run (0 = static camera and scene: a camera or instance that moves
+ * then makes gfxh_restir_render_frame fail instead of silently dropping temporal reuse along the seams). */
+enum gfxh_exchange_kind { GFXH_EXCHANGE_STRIPS = 0, GFXH_EXCHANGE_ALLREDUCE_SUM_U32 = 1, GFXH_EXCHANGE_GATHER_BANDS = 2 };
+typedef struct gfxh_exchange_buffer {
+    void* base;               /* full-frame device buffer, row-major */
+    uint32_t bytesPerPixel;   /* per plane */
+    uint32_t numPlanes;       /* reservoirs: 3 planes of 16 B */
+    uint64_t planeStride;     /* bytes between planes */
+} gfxh_exchange_buffer;
+typedef struct gfxh_exchange_desc {
+    uint32_t kind;                       /* enum gfxh_exchange_kind */
+    uint32_t stage;                      /* ordinal of the exchange point inside the frame (diagnostics) */
+    uint32_t width, height;
+    uint32_t bandBegin, bandEnd;
+    uint32_t sendAbove[2], recvAbove[2], sendBelow[2], recvBelow[2];   /* STRIPS: row ranges [begin, end) */
+    uint32_t numBuffers;
+    gfxh_exchange_buffer buffers[8];     /* STRIPS: all of them; GATHER_BANDS: buffers[0] = the float4 HDR buffer */
+    void* counters; uint64_t numCounters; /* ALLREDUCE_SUM_U32 */
+} gfxh_exchange_desc;
+typedef int (*gfxh_exchange_fn)(void* user, void* stream, const gfxh_exchange_desc* desc);
+int gfxh_restir_set_exchange(gfxh_restir* r, gfxh_exchange_fn fn, void* user, uint32_t maxMotionRows);
+/* Row ranges of a strip exchange of `rows` rows for the band [bandBegin, bandEnd) of a frame of `height` rows, into
+ * the send* / recv* members of `out` (nothing is sent above row 0 / below the last row).  Returns 1 when `rows`
+ * exceeds the band height of this rank: the strip would have to come from a rank further away. */
+int gfxh_strip_rows(uint32_t height, uint32_t bandBegin, uint32_t bandEnd, uint32_t rows, gfxh_exchange_desc* out);
+/* An exchange callback over RCCL for C++ host programs (librccl is loaded with dlopen on first use; one process per
+ * GPU).  Create with the ncclUniqueId bytes rank 0 obtained from gfxh_rccl_unique_id and distributed its own way. */
+typedef struct gfxh_rccl gfxh_rccl;
+int gfxh_rccl_unique_id(void* id128);
+int gfxh_rccl_create(const void* id128, int rank, int world, uint32_t height, gfxh_rccl** out);
+void gfxh_rccl_destroy(gfxh_rccl* c);
+int gfxh_rccl_exchange(void* user /* gfxh_rccl* */, void* stream, const gfxh_exchange_desc* desc);
+const char* gfxh_rccl_last_error(void);
+
+/* One frame as a list of steps (host logic only: the driver executes it on the GPU, the multi-process CPU tests execute
+ * the same list with the oracle): passes with their row ranges and the index bookkeeping of restir_di_main.cpp:2311-2493,
+ * and the exchange points of strip mode. */
+enum gfxh_step_op {
+    GFXH_STEP_RESTIR_PASS = 0,            /* gfx_restir_launch_rows(pass, rowBegin, rowEnd) after gfx_restir_set_params(current indices) */
+    GFXH_STEP_PT_PASS = 1,                /* gfx_pt_launch(pass, rowBegin, rowEnd) */
+    GFXH_STEP_EXCHANGE_STRIPS = 2,        /* exchangeRows rows of `buffers` (reservoirs: those of reservoirIndex) */
+    GFXH_STEP_ALLREDUCE_CELL_ACCESSES = 3,
+    GFXH_STEP_GATHER_BANDS = 4,
+    GFXH_STEP_PREV_GBUFFER_RELEASED = 5   /* the frame no longer reads the previous frame's G-buffer (frame pipelining) */
+};
+enum gfxh_exchange_buffers { GFXH_BUF_GBUFFERS = 1 /* GBuffer 0, 2, 3 of the frame */, GFXH_BUF_RESERVOIRS = 2 /* + ReservoirInfo */, GFXH_BUF_SAMPLE_VISIBILITY = 4 };
+typedef struct gfxh_frame_step {
+    uint32_t op, pass;
+    uint32_t rowBegin, rowEnd;                                 /* 0, 0 = all rows */
+    uint32_t currentReservoirIndex, spatialNeighborBaseIndex;  /* launch parameters in force for a pass */
+    uint32_t exchangeRows, buffers, reservoirIndex;            /* GFXH_STEP_EXCHANGE_STRIPS */
+} gfxh_frame_step;
+int gfxh_restir_frame_program(const gfxh_restir_config* cfg, int stripMode, uint32_t maxMotionRows, int newSequence,
+                              uint32_t lastReservoirIndex, uint32_t lastSpatialNeighborBaseIndex, uint32_t useUnbiasedEstimator,
+                              gfxh_frame_step* steps, uint32_t capacity, uint32_t* numSteps, uint32_t* newLastReservoirIndex,
+                              uint32_t* newLastSpatialNeighborBaseIndex);
+
 /* Allocates every per-pixel buffer (hipMalloc), seeds the RNG buffer, uploads the Halton table,
  * builds BVH and light distributions for the uploaded scene. */
 int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir** out);

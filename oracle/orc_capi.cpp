@@ -414,8 +414,11 @@ int orc_pt_launch(orc_scene* s, const gfx_restir_static_params* sp, const gfx_re
         case GFX_PT_NRC_PREPROCESS: preprocessNRC(ns, *fp); break;
         case GFX_PT_PATH_TRACE_NRC: {
             // one thread, row-major: the training-record order (an atomicAdd race in the reference) is defined
+            // a window (x0, y0, x1, y1) restricts the pass to those pixels (full-size parity tests): per-pixel results
+            // do not depend on other pixels; the training-record indices do and are not comparable then
             uint32_t* counter = ns.numTrainingData(fp->bufferIndex);
-            for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) nrcPathTracePixel(p, ns, counter, x, y);
+            const int wx1 = x1 > 0 ? x1 : W, wy1 = y1 > 0 ? y1 : H;
+            for (int y = y0; y < wy1; ++y) for (int x = x0; x < wx1; ++x) nrcPathTracePixel(p, ns, counter, x, y);
             break;
         }
         case GFX_PT_NRC_ACCUMULATE:
@@ -425,9 +428,11 @@ int orc_pt_launch(orc_scene* s, const gfx_restir_static_params* sp, const gfx_re
             for (uint32_t i = 0; i < g_nrcParams.maxNumTrainingSuffixes; ++i) propagateRadianceSuffix(ns, *sp, i);
             break;
         case GFX_PT_NRC_SHUFFLE: shuffleTrainingData(ns, *fp); break;
-        case GFX_PT_NRC_VISUALIZE_PREDICTION:
-            for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) visualizePredictionPixel(p, ns, x, y);
+        case GFX_PT_NRC_VISUALIZE_PREDICTION: {
+            const int wx1 = x1 > 0 ? x1 : W, wy1 = y1 > 0 ? y1 : H;
+            for (int y = y0; y < wy1; ++y) for (int x = x0; x < wx1; ++x) visualizePredictionPixel(p, ns, x, y);
             break;
+        }
         }
         return 0;
     }

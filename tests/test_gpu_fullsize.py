@@ -220,3 +220,63 @@ def test_rearchitected_window_of_the_full_frame_matches_the_oracle(built_lib, un
             if not np.array_equal(a, b):
                 diffs.append(f"frame {frame}: {key}: {np.count_nonzero(a != b)} bytes differ inside the window")
     assert not diffs, "\n".join(diffs)
+
+
+def test_nrc_window_of_the_full_frame_matches_the_oracle(built_lib):
+    """BASELINE configs[3] at its full size: the NRC path tracer (tile / training-path selection, radiance queries,
+    terminal infos, per-frame contribution) at 1920x1080 on the bench scene; the oracle renders a 64 x 40 window (whole
+    8 x 8 tiles of frame 0) and every per-pixel buffer of that window is bit-equal over two frames.  The training-record
+    indices come from one frame-wide atomic counter and are not comparable for a window: frame 1's adaptive tile size is
+    derived from the GPU's own frame-0 record count on both sides."""
+    import torch
+    from tests.test_gpu_nrc_render import _compare_exact
+    hs = util.bench_street()
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    ctx.lights_build_static()
+    osc = util.feed_oracle(hs)
+    cam = api.make_camera(W, H, **CAM)
+    ocam = util.copy_struct(O.GfxCamera, cam)
+    pb_init, pb_cpu = util.PixelBuffers(W, H), util.PixelBuffers(W, H)
+    dev = util.DeviceBuffers(pb_init)
+    nb_gpu, nb_cpu = util.NrcBuffers(W, H, hs.bounds()), util.NrcBuffers(W, H, hs.bounds())
+    nb_gpu.to_device()
+    s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
+    stream = torch.cuda.current_stream().cuda_stream
+    window = (896, 560, 960, 600)
+    mask = _window_mask(*window)
+    n = W * H
+    offsets = np.random.default_rng(99)
+    diffs = []
+    for frame in range(2):
+        b = frame % 2
+        kw = dict(frameIndex=frame, bufferIndex=b, resetFlowBuffer=int(frame == 0), numAccumFrames=frame)
+        f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, W, H, cam, travHandle=accel, **kw)
+        f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, W, H, ocam, travHandle=0, **kw)
+        ou, ot = int(offsets.integers(0, 1 << 31)), int(offsets.integers(0, 1 << 31))
+        if frame > 0:   # the oracle only traced a window: give it the frame-wide state the preprocess pass reads
+            g = nb_gpu.download()
+            for k in ("nrc_num_0", "nrc_num_1", "nrc_tile_0", "nrc_tile_1"):
+                nb_cpu.a[k][:] = g[k]
+        ctx.lights_build_instances(stream)
+        ctx.restir_set_params(s_gpu, f_gpu, 0, 0, stream)
+        ctx.nrc_set_render_params(nb_gpu.device_params(ou, ot, frame == 0))
+        osc.nrc_set_render_params(nb_cpu.host_params(ou, ot, frame == 0))
+        for pass_id in (api.PT_SETUP_GBUFFERS, api.PT_NRC_PREPROCESS, api.PT_PATH_TRACE_NRC):
+            ctx.pt_launch(pass_id, W, H, 5, 0, 0, stream)
+            osc.pt_launch(s_cpu, f_cpu, pass_id, 5, rect=window)
+        got, want = dev.download(), pb_cpu.arrays()
+        got.update(nb_gpu.download()); want.update(nb_cpu.arrays())
+        _compare_exact(diffs, f"frame {frame}", got, want, [f"nrc_tile_{b}", "nrc_off_unbiased", "nrc_off_training"])
+        for key in ("rng", f"gb0_{b}", "nrc_contribution", "nrc_terminal"):
+            a = np.ascontiguousarray(_pick(got[key].reshape(want[key].shape), mask, n)).view(np.uint8)
+            c = np.ascontiguousarray(_pick(want[key], mask, n)).view(np.uint8)
+            if not np.array_equal(a, c):
+                diffs.append(f"frame {frame}: {key}: {np.count_nonzero(a != c)} bytes differ inside the window")
+        hq = ((want["nrc_terminal"][:, 3].view(np.uint32) & 1) == 1) & mask
+        assert hq.sum() > 0.2 * mask.sum()          # most paths of the window end in the cache
+        if not np.array_equal(got["nrc_queries"][:n][hq].view(np.uint32), want["nrc_queries"][:n][hq].view(np.uint32)):
+            diffs.append(f"frame {frame}: rendering-path queries differ inside the window")
+        assert int(got[f"nrc_num_{b}"][0]) > 10000   # the full frame produced training records
+    assert not diffs, "\n".join(diffs)
