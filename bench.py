@@ -12,7 +12,8 @@ neighbours, shading -- exactly the span of the reference's GPUTimer.frame minus 
 Inputs (scene, BVH, per-pixel state) are resident in HBM before the timed region starts.
 
 N > 1 splits the frame into N row bands (multiples of 8 rows), one process per GPU; every rank
-renders its band plus the halo the reuse passes read, and the HDR bands are all-gathered over
+runs every pass on its band only, the strips of G-buffer / reservoir rows the reuse passes read
+across the seams are exchanged between the passes, and the HDR bands are all-gathered over
 RCCL/xGMI once per frame ("strong" scaling: total work fixed).
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
@@ -106,17 +107,15 @@ def main():
     setup_s = time.time() - t0
     stream = torch.cuda.current_stream().cuda_stream
 
-    gather = exchange = None
+    exchange = None
     if world > 1:
-        state = tilesplit.renderer_state_views(renderer, W, H)
-        gather = tilesplit.BandGather(state["beauty"], W, H, world, rank, dist)
-        exchange = tilesplit.HaloExchange(state, renderer.band_plan(), W, H, rank, world, dist)
+        # strip exchange: every pass runs on the band only; the rows the next pass reads across the seams travel between
+        # the passes (G-buffers once, reservoirs before each spatial pass), the HDR bands are all-gathered asynchronously
+        exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda")
+        renderer.set_exchange(exchange, 0)             # static camera and scene: no motion rows
 
     def frame():
         renderer.render_frame(stream)
-        if exchange is not None:
-            exchange.exchange(renderer.params()[2])   # final reservoirs + RNG of the halo rows, from their owners
-            gather.all_gather()                       # float4 HDR bands -> full frame on every rank (asynchronous, see BandGather)
 
     def barrier():
         torch.cuda.synchronize()
@@ -131,8 +130,8 @@ def main():
     t_start = time.perf_counter()
     for _ in range(args.steps):
         frame()
-    if gather is not None:
-        gather.finish()                               # the last frame's bands are in place on every rank
+    if exchange is not None:
+        exchange.finish()                             # the last frame's bands are in place on every rank
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:

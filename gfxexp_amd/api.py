@@ -167,6 +167,17 @@ def frame_program(cfg, strip_mode, max_motion_rows, new_sequence, last_res, last
     return [steps[i] for i in range(n.value)], nr.value, nb.value
 
 
+def exchange_desc(cfg, step, step_index, static_params, regir_params, buffer_index):
+    """gfxh_frame_step_exchange_desc: the descriptor of an exchange step over the buffers of `static_params` (any structure
+    with the gfx_restir_static_params layout, device or host pointers)."""
+    d = GfxhExchangeDesc()
+    rc = lib().gfxh_frame_step_exchange_desc(C.byref(cfg), C.byref(step), C.c_uint32(step_index), C.byref(static_params),
+                                             C.byref(regir_params) if regir_params is not None else None, C.c_uint32(buffer_index), C.byref(d))
+    if rc:
+        raise GfxError("gfxh_frame_step_exchange_desc: not an exchange step, or the strip is taller than the band")
+    return d
+
+
 def strip_rows(height, band_begin, band_end, rows):
     d = GfxhExchangeDesc()
     rc = lib().gfxh_strip_rows(C.c_uint32(height), C.c_uint32(band_begin), C.c_uint32(band_end), C.c_uint32(rows), C.byref(d))
@@ -209,7 +220,7 @@ HOST_ABI_SYMBOLS = [
     "gfxh_scene_get_material", "gfxh_scene_get_geom", "gfxh_scene_get_group", "gfxh_scene_get_instance",
     "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
     "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
-    "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_restir_frame_program",
+    "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_restir_frame_program", "gfxh_frame_step_exchange_desc",
     "gfxh_rccl_unique_id", "gfxh_rccl_create", "gfxh_rccl_destroy", "gfxh_rccl_exchange", "gfxh_rccl_last_error", "gfxh_restir_create",
     "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",

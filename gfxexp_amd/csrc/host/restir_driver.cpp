@@ -423,6 +423,43 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
     return (n >= capacity || tooTall) ? 1 : 0;
 }
 
+// What an exchange step moves, as the descriptor the callback receives: built from the launch parameters alone, so the
+// CPU tests fill it from the oracle's host buffers with the same code the GPU driver uses.
+int gfxh_frame_step_exchange_desc(const gfxh_restir_config* cfg, const gfxh_frame_step* st, uint32_t stepIndex, const gfx_restir_static_params* sp,
+                                  const gfx_regir_params* regir, uint32_t bufferIndex, gfxh_exchange_desc* out) {
+    gfxh_exchange_desc& d = *out;
+    std::memset(&d, 0, sizeof(d));
+    const uint32_t W = cfg->width, H = cfg->height;
+    const size_t numPixelsAll = static_cast<size_t>(W) * H;
+    d.stage = stepIndex; d.width = W; d.height = H;
+    d.bandBegin = cfg->rowBegin; d.bandEnd = cfg->rowEnd;
+    auto add = [&](void* base, uint32_t bytesPerPixel, uint32_t planes) {
+        gfxh_exchange_buffer& b = d.buffers[d.numBuffers++];
+        b.base = base; b.bytesPerPixel = bytesPerPixel; b.numPlanes = planes; b.planeStride = static_cast<uint64_t>(bytesPerPixel) * numPixelsAll;
+    };
+    switch (st->op) {
+    case GFXH_STEP_EXCHANGE_STRIPS:
+        d.kind = GFXH_EXCHANGE_STRIPS;
+        if (gfxh_strip_rows(H, cfg->rowBegin, cfg->rowEnd, st->exchangeRows, &d)) return 1;
+        // GBuffer1 (motion vectors) is only ever read at a pass's own pixel
+        if (st->buffers & GFXH_BUF_GBUFFERS) { add(sp->gbuffer0[bufferIndex], 16, 1); add(sp->gbuffer2[bufferIndex], 16, 1); add(sp->gbuffer3[bufferIndex], 16, 1); }
+        if (st->buffers & GFXH_BUF_SAMPLE_VISIBILITY) add(sp->sampleVisibilityBuffer[bufferIndex], 4, 1);
+        if (st->buffers & GFXH_BUF_RESERVOIRS) { add(sp->reservoirBuffer[st->reservoirIndex], 16, 3); add(sp->reservoirInfoBuffer[st->reservoirIndex], 8, 1); }
+        return 0;
+    case GFXH_STEP_ALLREDUCE_CELL_ACCESSES:
+        if (!regir) return 1;
+        d.kind = GFXH_EXCHANGE_ALLREDUCE_SUM_U32;
+        d.counters = regir->perCellNumAccesses;
+        d.numCounters = static_cast<uint64_t>(regir->gridDimension[0]) * regir->gridDimension[1] * regir->gridDimension[2];
+        return 0;
+    case GFXH_STEP_GATHER_BANDS:
+        d.kind = GFXH_EXCHANGE_GATHER_BANDS;
+        add(sp->beautyAccumBuffer, 16, 1);
+        return 0;
+    default: return 1;
+    }
+}
+
 int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     gfx_ctx* ctx = r->ctx;
     const gfxh_restir_config& cfg = r->cfg;
@@ -484,7 +521,6 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
         return 1;
     }
     const uint32_t W = cfg.width, H = cfg.height;
-    const size_t numPixelsAll = static_cast<size_t>(W) * H;
 #define DRV_GFX(call) do { if (call) { g_driverError = gfx_last_error(ctx); return 1; } } while (0)
     // G-buffer pass, pipelined under the previous frame when nothing forbids it: jittering advances the pixel
     // RNGs the previous frame's passes are still drawing from, and a band renderer's exchanges have their own
@@ -519,26 +555,8 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
         case GFXH_STEP_EXCHANGE_STRIPS:
         case GFXH_STEP_ALLREDUCE_CELL_ACCESSES:
         case GFXH_STEP_GATHER_BANDS: {
-            gfxh_exchange_desc d; std::memset(&d, 0, sizeof(d));
-            d.stage = k; d.width = W; d.height = H;
-            d.bandBegin = cfg.rowBegin; d.bandEnd = cfg.rowEnd;
-            auto add = [&](void* base, uint32_t bytesPerPixel, uint32_t planes) {
-                gfxh_exchange_buffer& b = d.buffers[d.numBuffers++];
-                b.base = base; b.bytesPerPixel = bytesPerPixel; b.numPlanes = planes; b.planeStride = static_cast<uint64_t>(bytesPerPixel) * numPixelsAll;
-            };
-            if (st.op == GFXH_STEP_EXCHANGE_STRIPS) {
-                d.kind = GFXH_EXCHANGE_STRIPS;
-                gfxh_strip_rows(H, cfg.rowBegin, cfg.rowEnd, st.exchangeRows, &d);
-                if (st.buffers & GFXH_BUF_GBUFFERS) { add(r->sp.gbuffer0[bufferIndex], 16, 1); add(r->sp.gbuffer2[bufferIndex], 16, 1); add(r->sp.gbuffer3[bufferIndex], 16, 1); }
-                if (st.buffers & GFXH_BUF_SAMPLE_VISIBILITY) add(r->sp.sampleVisibilityBuffer[bufferIndex], 4, 1);
-                if (st.buffers & GFXH_BUF_RESERVOIRS) { add(r->sp.reservoirBuffer[st.reservoirIndex], 16, 3); add(r->sp.reservoirInfoBuffer[st.reservoirIndex], 8, 1); }
-            }
-            else if (st.op == GFXH_STEP_ALLREDUCE_CELL_ACCESSES) {
-                d.kind = GFXH_EXCHANGE_ALLREDUCE_SUM_U32;
-                d.counters = r->regir.perCellNumAccesses;
-                d.numCounters = static_cast<uint64_t>(r->regir.gridDimension[0]) * r->regir.gridDimension[1] * r->regir.gridDimension[2];
-            }
-            else { d.kind = GFXH_EXCHANGE_GATHER_BANDS; add(r->sp.beautyAccumBuffer, 16, 1); }
+            gfxh_exchange_desc d;
+            gfxh_frame_step_exchange_desc(&cfg, &st, k, &r->sp, cfg.renderer == GFXH_PATH_TRACE_REGIR ? &r->regir : nullptr, bufferIndex, &d);
             if (r->exchange(r->exchangeUser, stream, &d)) { g_driverError = "gfxh_restir_render_frame: the exchange callback failed"; return 1; }
             break;
         }

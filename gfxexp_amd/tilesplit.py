@@ -130,18 +130,31 @@ class HaloExchange:
 class StripExchange:
     """The exchange callback of a band renderer (gfxh_restir_set_exchange / gfxh_exchange_desc) over torch.distributed:
     RCCL on the GPUs (backend "nccl"), gloo in the CPU tests.  `view(ptr, nbytes)` turns an address into a flat uint8
-    tensor (device_view for device memory, host_view for the oracle's numpy buffers).
+    tensor (device_bytes for device memory, host_view for the oracle's numpy buffers); views are cached per address.
 
-      strips        batch_isend_irecv of every (buffer, plane) row range with the rank above / below
+      strips        batch_isend_irecv of every (buffer, plane) row range with the rank above / below: one RCCL group
+                    per exchange point, stream-ordered after the pass that produced the rows (the collective stream
+                    waits for torch's current stream, which is the stream the renderer launches on)
       counters      all_reduce(sum) on the u32 array (as int32: wrap-around addition is the same)
-      HDR bands     all_gather_into_tensor of slabs sized for the tallest band, scattered back into the frame
+      HDR bands     all_gather_into_tensor of slabs sized for the tallest band.  Asynchronous: nothing of the next frame
+                    reads the other ranks' pixels, so the collective runs underneath the next frame's kernels and the
+                    received bands are put into the frame at the next gather -- or by finish() after the last frame.
     The C++ twin is gfxh_rccl_exchange (csrc/host/rccl_exchange.cpp); both consume the same descriptors."""
 
     def __init__(self, dist, rank, world, height, view, device="cpu"):
-        self.dist, self.rank, self.world, self.view, self.device = dist, rank, world, view, device
+        self.dist, self.rank, self.world, self.device = dist, rank, world, device
+        self._view, self._views = view, {}
         self.bands = band_rows(height, world)
         self.bytes_moved = 0
         self._stage = None
+        self._pending = None
+
+    def view(self, ptr, nbytes):
+        key = (int(ptr), int(nbytes))
+        t = self._views.get(key)
+        if t is None:
+            t = self._views[key] = self._view(ptr, nbytes)
+        return t
 
     def __call__(self, stream, d):
         from gfxexp_amd import api
@@ -176,6 +189,7 @@ class StripExchange:
                     req.wait()
             return
         if d.kind == api.EXCHANGE_GATHER_BANDS:
+            self.finish()
             b = d.buffers[0]
             row_bytes = b.bytesPerPixel * d.width
             max_rows = max(e - s for s, e in self.bands)
@@ -187,12 +201,23 @@ class StripExchange:
             s0, e0 = self.bands[self.rank]
             frame = self.view(b.base, row_bytes * d.height)
             send[:(e0 - s0) * row_bytes].copy_(frame[s0 * row_bytes:e0 * row_bytes])
-            dist.all_gather_into_tensor(recv, send)
-            for r, (rs, re) in enumerate(self.bands):
-                if r != self.rank:
-                    frame[rs * row_bytes:re * row_bytes].copy_(recv[r * slab:r * slab + (re - rs) * row_bytes])
+            work = dist.all_gather_into_tensor(recv, send, async_op=True)
+            self._pending = (work, frame, row_bytes, slab)
             return
         raise ValueError("unknown exchange kind %d" % d.kind)
+
+    def finish(self):
+        """Wait (stream-ordered on RCCL, blocking on gloo) for the outstanding band gather and put the other ranks' bands
+        into the frame.  Called by the next gather; call it once after the last frame."""
+        if self._pending is None:
+            return
+        work, frame, row_bytes, slab = self._pending
+        self._pending = None
+        work.wait()
+        recv = self._stage[1]
+        for r, (rs, re) in enumerate(self.bands):
+            if r != self.rank:
+                frame[rs * row_bytes:re * row_bytes].copy_(recv[r * slab:r * slab + (re - rs) * row_bytes])
 
 
 def host_view(ptr, nbytes):

@@ -242,6 +242,12 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfg, int stripMode, uint
                               uint32_t lastReservoirIndex, uint32_t lastSpatialNeighborBaseIndex, uint32_t useUnbiasedEstimator,
                               gfxh_frame_step* steps, uint32_t capacity, uint32_t* numSteps, uint32_t* newLastReservoirIndex,
                               uint32_t* newLastSpatialNeighborBaseIndex);
+/* The descriptor an exchange step hands to the callback, from the launch parameters the buffers live in (device pointers in
+ * the driver, host pointers when the CPU tests run the program with the oracle).  `regir` may be null unless the step is
+ * GFXH_STEP_ALLREDUCE_CELL_ACCESSES.  Returns 1 for a step that is not an exchange or a strip taller than the band. */
+int gfxh_frame_step_exchange_desc(const gfxh_restir_config* cfg, const gfxh_frame_step* step, uint32_t stepIndex,
+                                  const gfx_restir_static_params* sp, const gfx_regir_params* regir, uint32_t bufferIndex,
+                                  gfxh_exchange_desc* out);
 
 /* Allocates every per-pixel buffer (hipMalloc), seeds the RNG buffer, uploads the Halton table,
  * builds BVH and light distributions for the uploaded scene. */

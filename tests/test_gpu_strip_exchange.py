@@ -1,0 +1,128 @@
+"""-m gpu: band renderers in strip-exchange mode (gfxh_restir_set_exchange) reproduce the whole-frame renderer bit for
+bit.  Three bands on one GPU, one host thread each, exchanging through tests/loopback.py: the C++ frame loop, its
+exchange descriptors and the band-limited kernels are the production code; only the transport differs from the RCCL
+callbacks (whose descriptor handling the world-2 gloo tests cover: tests/test_tilesplit_gloo.py)."""
+import numpy as np
+import pytest
+
+from gfxexp_amd import api, tilesplit
+from tests import util
+
+W, H, FRAMES, WORLD, MOTION_ROWS = 128, 96, 3, 3, 10
+
+CASES = [("biased", api.RENDERER_BIASED, False), ("unbiased_moving", api.RENDERER_UNBIASED, True),
+         ("rearch_biased_moving", api.RENDERER_REARCH_BIASED, True), ("rearch_unbiased", api.RENDERER_REARCH_UNBIASED, False),
+         ("regir", api.RENDERER_PATH_TRACE_REGIR, False), ("path_trace", api.RENDERER_PATH_TRACE, False)]
+
+
+def _camera(frame, moving):
+    dy = 0.6 * frame if moving else 0.0
+    return api.make_camera(W, H, pos=(1.5 + 0.5 * dy, 5.0 + dy, 14.0), pitch=12.0, yaw=186.0)
+
+
+def _make(hs, renderer, band):
+    ctx = api.Context(0)           # one context per band: launch parameters are per-context state
+    hs.upload(ctx)
+    cfg = api.RestirRenderer.default_config(W, H, renderer)
+    cfg.camera = _camera(0, False)
+    cfg.spatialNeighborRadius = 6.0
+    cfg.enableAccumulation = 0
+    cfg.maxPathLength = 4
+    cfg.rowBegin, cfg.rowEnd = band
+    if renderer == api.RENDERER_PATH_TRACE_REGIR:
+        b = hs.bounds()
+        for k in range(3):
+            cfg.regirAabbMin[k] = float(b[k]); cfg.regirAabbMax[k] = float(b[3 + k]); cfg.regirGridDimension[k] = (8, 4, 8)[k]
+    return ctx, api.RestirRenderer(ctx, cfg)
+
+
+def _read(ctx, r):
+    import torch
+    torch.cuda.synchronize()
+    s, _, last, _, _ = r.params()
+    n = W * H
+    return {"beauty": ctx.read_device(r.beauty_ptr(), n * 16).view(np.float32).reshape(H, W, 4),
+            "res": ctx.read_device(s.reservoirBuffer[last], n * 48).view(np.float32).reshape(3, H, W, 4),
+            "info": ctx.read_device(s.reservoirInfoBuffer[last], n * 8).view(np.float32).reshape(H, W, 2),
+            "rng": ctx.read_device(s.rngBuffer, n * 8).view(np.uint64).reshape(H, W), "last": last}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_three_band_strip_exchange_matches_whole_frame(built_lib, case):
+    from tests import loopback
+    name, renderer, moving = case
+    hs = util.bunny_scene()
+    full_ctx, full = _make(hs, renderer, (0, 0))
+    for frame in range(FRAMES):
+        if moving:
+            full.set_camera(_camera(frame, True))
+        full.render_frame()
+    want = _read(full_ctx, full)
+    assert np.abs(want["beauty"][..., :3]).sum() > 0
+
+    bands = tilesplit.band_rows(H, WORLD)
+    assert bands == [(0, 32), (32, 64), (64, 96)]
+    made = [_make(hs, renderer, b) for b in bands]
+    ex = loopback.LoopbackExchange(WORLD)
+    for rank, (_, r) in enumerate(made):
+        r.set_exchange(ex.callback(rank), MOTION_ROWS if moving else 0)
+
+    def before(frame, rank, r):
+        if moving:
+            r.set_camera(_camera(frame, True))
+    loopback.run_bands([r for _, r in made], FRAMES, before)
+    for rank, ((ctx, r), (b, e)) in enumerate(zip(made, bands)):
+        got = _read(ctx, r)
+        assert got["last"] == want["last"]
+        util.assert_same_bits(f"{name}: band {rank} gathered HDR frame", got["beauty"], want["beauty"])
+        util.assert_same_bits(f"{name}: band {rank} final reservoirs", got["res"][:, b:e], want["res"][:, b:e])
+        util.assert_same_bits(f"{name}: band {rank} final reservoir infos", got["info"][b:e], want["info"][b:e])
+        util.assert_same_bits(f"{name}: band {rank} pixel RNGs", got["rng"][b:e], want["rng"][b:e])
+        assert len(ex.calls[rank]) == len(ex.calls[0]) > 0
+
+
+@pytest.mark.gpu
+def test_band_renderer_refuses_motion_it_cannot_exchange(built_lib):
+    """A band renderer told the scene is static (maxMotionRows = 0) fails loudly when the camera moves instead of
+    dropping temporal reuse along the seams."""
+    hs = util.bunny_scene()
+    ctx, r = _make(hs, api.RENDERER_BIASED, (32, 64))
+    r.set_exchange(lambda stream, d: None, 0)
+    r.render_frame()
+    r.set_camera(_camera(1, True))
+    with pytest.raises(api.GfxError, match="moved"):
+        r.render_frame()
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_single_rank(built_lib):
+    """gfxh_rccl_exchange (the C++ callback over RCCL) with a communicator of one rank: create, all-reduce, band gather and
+    an (empty) strip exchange run on the stream and leave the single band's data untouched."""
+    import ctypes as C
+    import torch
+    L = api.lib()
+    L.gfxh_rccl_last_error.restype = C.c_char_p
+    ident = (C.c_uint8 * 128)()
+    assert L.gfxh_rccl_unique_id(ident) == 0, L.gfxh_rccl_last_error()
+    comm = C.c_void_p()
+    assert L.gfxh_rccl_create(ident, 0, 1, C.c_uint32(H), C.byref(comm)) == 0, L.gfxh_rccl_last_error()
+    try:
+        counters = torch.arange(64, dtype=torch.int32, device="cuda")
+        frame = torch.rand(H * W * 4, device="cuda")
+        keep = frame.clone()
+        d = api.GfxhExchangeDesc()
+        d.kind, d.width, d.height, d.bandBegin, d.bandEnd = api.EXCHANGE_ALLREDUCE_SUM_U32, W, H, 0, H
+        d.counters, d.numCounters = counters.data_ptr(), 64
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert L.gfxh_rccl_exchange(comm, stream, C.byref(d)) == 0, L.gfxh_rccl_last_error()
+        d.kind, d.numBuffers = api.EXCHANGE_GATHER_BANDS, 1
+        d.buffers[0].base, d.buffers[0].bytesPerPixel, d.buffers[0].numPlanes, d.buffers[0].planeStride = frame.data_ptr(), 16, 1, 16 * W * H
+        assert L.gfxh_rccl_exchange(comm, stream, C.byref(d)) == 0, L.gfxh_rccl_last_error()
+        d.kind = api.EXCHANGE_STRIPS
+        assert L.gfxh_rccl_exchange(comm, stream, C.byref(d)) == 0, L.gfxh_rccl_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(counters.cpu(), torch.arange(64, dtype=torch.int32))
+        assert torch.equal(frame, keep)
+    finally:
+        L.gfxh_rccl_destroy(comm)

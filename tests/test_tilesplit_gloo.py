@@ -1,7 +1,13 @@
-"""CPU, world_size 2, gloo: the row-band split (band plan + per-frame halo refresh + HDR all-gather)
-reproduces the single-process frame BIT FOR BIT.  The per-rank renderer here is the CPU oracle driven
-with the same gfxh_band_plan row ranges the GPU driver uses, and the communication code is the
-production code (gfxexp_amd/tilesplit.py) on the gloo backend."""
+"""CPU, world_size 2, gloo: the row-band split reproduces the single-process frame BIT FOR BIT.
+
+Two generations of the split are covered:
+  * strip exchange (gfxh_restir_set_exchange): every pass runs on the band only and the rows the next pass reads
+    across the seams are exchanged between passes.  The ranks execute gfxh_restir_frame_program -- the list of steps the
+    GPU driver executes -- with the CPU oracle as the kernels (tests/bandprog.py) and the production communication code
+    (gfxexp_amd/tilesplit.StripExchange) on the gloo backend: original ReSTIR biased / unbiased (static and moving
+    camera), rearchitected ReSTIR, the ReGIR path tracer (all-reduce of the cell access counters), baseline path tracer.
+  * halo recompute (gfxh_band_plan + HaloExchange + BandGather), the round-1 scheme that a band renderer WITHOUT an
+    exchange callback still uses."""
 import os
 import socket
 import sys
@@ -127,3 +133,132 @@ def test_two_rank_band_split_is_bit_exact(built_lib):
         b, e = bands[r]
         want = pb.res[last].reshape(3, H, W, 4)[:, b:e]
         util.assert_same_bits(f"rank {r} final reservoirs of its band", res[r].reshape(3, H, W, 4)[:, b:e], want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# strip exchange: the driver's frame program, run with the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+MOTION_ROWS = 8
+#            name              renderer attr                frames  moving  regir
+STRIP_CASES = [("biased", "RENDERER_BIASED", 3, False, False),
+               ("unbiased", "RENDERER_UNBIASED", 3, False, False),
+               ("biased_moving", "RENDERER_BIASED", 3, True, False),
+               ("unbiased_moving", "RENDERER_UNBIASED", 3, True, False),
+               ("rearch_biased", "RENDERER_REARCH_BIASED", 3, False, False),
+               ("rearch_unbiased_moving", "RENDERER_REARCH_UNBIASED", 3, True, False),
+               ("regir", "RENDERER_PATH_TRACE_REGIR", 3, False, True),
+               ("path_trace", "RENDERER_PATH_TRACE", 2, False, False)]
+
+
+def _case_camera(frame, moving):
+    from gfxexp_amd import api
+    dy = 1.0 * frame if moving else 0.0
+    return api.make_camera(W, H, pos=(1.5 + 0.5 * dy, 5.0 + dy, 14.0), pitch=12.0, yaw=186.0)
+
+
+def _run_case(case, band, exchange, threads):
+    """One sequence of a STRIP_CASES entry on `band` ((0, 0) = whole frame); returns the renderer (state in .pb / .regir)."""
+    from gfxexp_amd import api
+    from tests import bandprog, util
+    name, renderer, frames, moving, with_regir = case
+    hs = util.bunny_scene()
+    osc = util.feed_oracle(hs, threads=threads)
+    cfg = bandprog.small_config(W, H, getattr(api, renderer), band=band, radius=RADIUS, passes=PASSES, neighbors=NB)
+    cfg.maxPathLength = 3
+    regir = util.RegirBuffers(hs.bounds(), dims=(8, 4, 8)) if with_regir else None
+    r = bandprog.OracleBandRenderer(osc, cfg, regir=regir)
+    if exchange is not None:
+        r.set_exchange(exchange, MOTION_ROWS if moving else 0)
+    for frame in range(frames):
+        r.render_frame(_case_camera(frame, moving))
+    return r
+
+
+def _state(r):
+    out = {"beauty": r.pb.beauty, "res": r.pb.res[r.last_res], "info": r.pb.info[r.last_res], "rng": r.pb.rng,
+           "motion": r.pb.gb1[(r.frame_index - 1) % 2], "surface": r.pb.gb0[(r.frame_index - 1) % 2]["instSlot"] != 0xFFFFFFFF}
+    if r.regir is not None:
+        out.update(regir_accesses=r.regir.accesses, regir_last_access=r.regir.last_access, regir_rngs=r.regir.rngs,
+                   regir_res0=r.regir.res[0], regir_res1=r.regir.res[1])
+    return out
+
+
+def _strip_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from gfxexp_amd import tilesplit
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    band = tilesplit.band_for_rank(H, world, rank)
+    for case in STRIP_CASES:
+        ex = tilesplit.StripExchange(dist, rank, world, H, tilesplit.host_view)
+        r = _run_case(case, band, ex, threads=2)
+        ex.finish()
+        np.savez(os.path.join(out_dir, f"{case[0]}_{rank}.npz"), band=np.array(band), bytes_moved=ex.bytes_moved,
+                 log=np.array([(f, op, rows, bufs) for f, op, rows, bufs in r.log], np.int64).reshape(-1, 4), **_state(r))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def strip_runs(built_lib):
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    with tempfile.TemporaryDirectory() as out_dir:
+        mp.spawn(_strip_worker, args=(2, port, out_dir), nprocs=2, join=True)
+        yield {(c[0], r): dict(np.load(os.path.join(out_dir, f"{c[0]}_{r}.npz"))) for c in STRIP_CASES for r in range(2)}
+
+
+@pytest.mark.parametrize("case", STRIP_CASES, ids=[c[0] for c in STRIP_CASES])
+def test_two_rank_strip_exchange_is_bit_exact(strip_runs, case):
+    from gfxexp_amd import api
+    from tests import util
+    whole = _run_case(case, (0, 0), None, threads=4)
+    want = _state(whole)
+    assert np.abs(want["beauty"][:, :3]).sum() > 0
+    name, _, frames, moving, with_regir = case
+    if moving:   # the sequence really crosses the seam, and stays inside the strip the ranks exchange
+        my = np.abs(want["motion"][want["surface"], 1])
+        assert 3.0 < my.max() <= MOTION_ROWS - 1
+    for rank in range(2):
+        got = strip_runs[(name, rank)]
+        b, e = got["band"]
+        util.assert_same_bits(f"{name}: rank {rank} gathered HDR frame", got["beauty"], want["beauty"])
+        rows = lambda a, per: np.ascontiguousarray(a).reshape(-1, H, W, per)[:, b:e]
+        util.assert_same_bits(f"{name}: rank {rank} final reservoirs", rows(got["res"], 4), rows(want["res"], 4))
+        util.assert_same_bits(f"{name}: rank {rank} final reservoir infos", rows(got["info"], 2), rows(want["info"], 2))
+        util.assert_same_bits(f"{name}: rank {rank} pixel RNGs", got["rng"].reshape(H, W)[b:e], want["rng"].reshape(H, W)[b:e])
+        if with_regir:   # the world-space grid is replicated: identical on every rank, and to the single process
+            for k in ("regir_accesses", "regir_last_access", "regir_rngs", "regir_res0", "regir_res1"):
+                util.assert_same_bits(f"{name}: rank {rank} {k}", got[k], want[k])
+            assert want["regir_accesses"].sum() > 0
+        # what moved: per frame exactly the exchange points gfxexp_host.h documents
+        ops = [int(op) for f, op, _, _ in got["log"] if f == frames - 1]
+        if name in ("biased", "unbiased"):
+            assert ops == [api.STEP_EXCHANGE_STRIPS] * (1 + PASSES) + [api.STEP_GATHER_BANDS]
+        elif name.endswith("_moving") and not name.startswith("rearch"):
+            assert ops == [api.STEP_EXCHANGE_STRIPS] * (2 + PASSES) + [api.STEP_GATHER_BANDS]
+        elif name.startswith("rearch"):
+            assert ops == [api.STEP_EXCHANGE_STRIPS, api.STEP_GATHER_BANDS]
+        elif name == "regir":
+            assert ops == [api.STEP_ALLREDUCE_CELL_ACCESSES, api.STEP_GATHER_BANDS]
+        else:
+            assert ops == [api.STEP_GATHER_BANDS]
+
+
+def test_strip_rows_and_too_tall_strips(built_lib):
+    from gfxexp_amd import api
+    d, rc = api.strip_rows(1080, 136, 272, 20)
+    assert rc == 0
+    assert list(d.sendAbove) == [136, 156] and list(d.recvAbove) == [116, 136]
+    assert list(d.sendBelow) == [252, 272] and list(d.recvBelow) == [272, 292]
+    top, rc = api.strip_rows(1080, 0, 136, 20)
+    assert rc == 0 and top.sendAbove[0] == top.sendAbove[1] and top.recvAbove[0] == top.recvAbove[1]
+    bottom, rc = api.strip_rows(1080, 952, 1080, 20)
+    assert rc == 0 and bottom.sendBelow[0] == bottom.sendBelow[1] and bottom.recvBelow[0] == bottom.recvBelow[1]
+    _, rc = api.strip_rows(1080, 136, 272, 137)           # would need rows of a rank two bands away
+    assert rc == 1
+    cfg = api.RestirRenderer.default_config(1920, 1080, api.RENDERER_BIASED)
+    cfg.rowBegin, cfg.rowEnd = 136, 272
+    with pytest.raises(api.GfxError):
+        api.frame_program(cfg, True, 200, False, 1, 0, False)

@@ -1,6 +1,8 @@
-"""Frame time of ONE rank's row band on one GPU (no communication): what the halo recompute costs when the
-1920x1080 bench frame is split N ways (tilesplit.band_rows), as a bound on strong scaling.  The halo rows' temporal
-state is not refreshed here (no neighbour rank), which does not change the amount of work.  One JSON line."""
+"""Frame time of ONE rank's row band on one GPU (no communication) when the 1920x1080 bench frame is split N ways
+(tilesplit.band_rows), as a compute-only bound on strong scaling, in both band modes:
+  strips   gfxh_restir_set_exchange with a callback that moves nothing: every pass on the band only (what bench.py --gpus N runs)
+  halo     no callback: the band plus the halo rows the reuse passes read are recomputed (round-1 scheme)
+The seam rows' state is not refreshed here (no neighbour rank), which does not change the amount of work.  One JSON line."""
 import json
 import os
 import sys
@@ -10,12 +12,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gfxexp_amd import api, scenes, tilesplit  # noqa: E402
 
 
-def band_ms(ctx, cam, W, H, band, steps=30):
+def band_ms(ctx, cam, W, H, band, steps=30, strips=False):
     import torch
     cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
     cfg.camera = cam
     cfg.rowBegin, cfg.rowEnd = band
     r = api.RestirRenderer(ctx, cfg)
+    if strips:
+        r.set_exchange(lambda stream, d: None, 0)
     for _ in range(5):
         r.render_frame()
     torch.cuda.synchronize()
@@ -37,10 +41,13 @@ def main():
     out = {"workload": "bench frame, one rank's band rendered alone on one GPU (compute only)", "full_frame_ms": round(full, 4), "bands": {}}
     for n in (2, 4, 8):
         bands = tilesplit.band_rows(H, n)
-        ms = [band_ms(ctx, cam, W, H, b) for b in (bands[0], bands[n // 2])]     # an edge band and an interior band
-        worst = max(ms)
-        out["bands"][str(n)] = {"edge_band_ms": round(ms[0], 4), "interior_band_ms": round(ms[1], 4),
-                                "compute_bound_speedup": round(full / worst, 2), "compute_bound_efficiency": round(full / worst / n, 3)}
+        entry = {}
+        for mode in ("strips", "halo"):
+            ms = [band_ms(ctx, cam, W, H, b, strips=mode == "strips") for b in bands]
+            worst = max(ms)
+            entry[mode] = {"band_ms": [round(m, 4) for m in ms], "compute_bound_speedup": round(full / worst, 2),
+                           "compute_bound_efficiency": round(full / worst / n, 3)}
+        out["bands"][str(n)] = entry
     print(json.dumps(out))
 
 
