@@ -309,6 +309,7 @@ int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint
 
 int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {
     GFX_TRY(ctx)
+    if (rowBegin == 0 && rowEnd == 0) rowEnd = height;   // 0, 0 = every row, as in gfx_pt_launch
     restir_launch(ctx->c, static_cast<hipStream_t>(stream), pass, width, height, rowBegin, rowEnd);
     GFX_CATCH(ctx)
 }

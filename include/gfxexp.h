@@ -306,7 +306,7 @@ enum gfx_restir_pass {
 int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height);
 /* The same pass restricted to image rows [rowBegin, rowEnd): the unit of the multi-GPU row-band split
  * (no reference counterpart -- restir_di_main.cpp is single GPU, :130-133).  Buffers keep their
- * full-frame size and indexing. */
+ * full-frame size and indexing.  rowBegin == rowEnd == 0 -> every row. */
 int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height,
                            uint32_t rowBegin, uint32_t rowEnd);
 
