@@ -3,6 +3,7 @@
 // throws std::runtime_error from CUDADRV_CHECK, utils/cuda_util.cpp:58-69; a C++ shim above this
 // ABI can re-throw).
 #include <cstring>
+#include <memory>
 #include "internal.h"
 
 using namespace gfx;
@@ -11,7 +12,8 @@ struct gfx_ctx { Context c; };
 
 static thread_local std::string g_createError;
 
-#define GFX_TRY(ctx) try {
+// every entry point runs on the context's device, whatever the caller (torch, another context) made current
+#define GFX_TRY(ctx) try { GFX_HIP(hipSetDevice((ctx)->c.device));
 #define GFX_CATCH(ctx) \
     return 0; } \
     catch (const std::exception& e) { (ctx)->c.lastError = e.what(); return 1; } \
@@ -28,11 +30,14 @@ int gfx_ctx_create(int device, gfx_ctx** out) {
         GFX_HIP(hipGetDeviceCount(&count));
         if (device < 0 || device >= count) throw HipError("gfx_ctx_create: no such HIP device");
         GFX_HIP(hipSetDevice(device));
-        gfx_ctx* ctx = new gfx_ctx();
+        std::unique_ptr<gfx_ctx> ctx(new gfx_ctx());
         ctx->c.device = device;
+        hipDeviceProp_t prop;
+        GFX_HIP(hipGetDeviceProperties(&prop, device));
+        ctx->c.numCUs = prop.multiProcessorCount;
         ctx->c.dTraceCounters.reserve(64);
         GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 64));
-        *out = ctx;
+        *out = ctx.release();
         return 0;
     }
     catch (const std::exception& e) { g_createError = e.what(); return 1; }
@@ -48,6 +53,8 @@ const char* gfx_last_error(gfx_ctx* ctx) { return ctx ? ctx->c.lastError.c_str()
 
 int gfx_material_set(gfx_ctx* ctx, uint32_t matSlot, const gfx_material* mat) {
     GFX_TRY(ctx)
+    if (!mat) throw HipError("gfx_material_set: null material");
+    if (matSlot >= (1u << 24)) throw HipError("gfx_material_set: material slot out of range");   // also keeps matSlot + 1 from wrapping
     if (ctx->c.materials.size() <= matSlot) {
         gfx_material zero; std::memset(&zero, 0, sizeof(zero));
         ctx->c.materials.resize(matSlot + 1, zero);

@@ -35,6 +35,7 @@ struct gfxh_nrc {
     std::vector<void*> allocations;
     uint64_t accel = 0, network = 0;
     uint32_t frameIndex = 0, numAccumFrames = 0;
+    bool viewMoved = false;      // an instance moved since the last frame: accumulation restarts
     std::mt19937 perFrameRng{ 72139121 };                  // main:1602
     gfx_camera prevCamera;
     uint32_t lastNumTrainingData = 0, lastTileSize[2] = { 8, 8 }, lastNumInferenceQueries = 0;
@@ -161,7 +162,9 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     gfx_restir_frame_params& fp = r->fp;
     NRC_GFX(gfx_lights_build_instances(ctx, stream, bufferIndex));
     const bool newSequence = frameIndex == 0;                                       // main:2228
-    if (!cfg.enableAccumulation || newSequence) r->numAccumFrames = 0;
+    const bool viewMoved = r->viewMoved;                                // animate || cameraIsActuallyMoving (neural_radiance_caching_main.cpp firstAccumFrame)
+    r->viewMoved = false;
+    if (!cfg.enableAccumulation || newSequence || viewMoved) r->numAccumFrames = 0;
     else r->numAccumFrames = std::min(r->numAccumFrames + 1, 1u << 16);
     fp.travHandle = r->accel; fp.numAccumFrames = r->numAccumFrames; fp.frameIndex = frameIndex;
     fp.prevCamera = frameIndex == 0 ? cfg.camera : r->prevCamera;
@@ -217,6 +220,7 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
 }
 
 int gfxh_nrc_rebuild_accel(gfxh_nrc* r, void* stream) {
+    r->viewMoved = true;
     if (gfx_accel_build(r->ctx, stream, &r->accel)) { g_nrcError = gfx_last_error(r->ctx); return 1; }
     return 0;
 }

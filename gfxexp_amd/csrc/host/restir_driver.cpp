@@ -508,6 +508,16 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     // band renderer with an exchange callback -- the points where rows owned by other ranks have to arrive
     const bool wholeFrame = cfg.rowBegin == 0 && cfg.rowEnd == 0;
     const bool strips = r->exchange != nullptr && !wholeFrame;
+    if (!wholeFrame && !strips) {
+        // halo recompute: the halo comes from the neighbours' bands, which tilesplit / gfxh_rccl cut within 8 rows of this one
+        gfxh_band_plan plan;
+        gfxh_restir_band_plan(r, &plan);
+        if (plan.haloRows + 8 > cfg.rowEnd - cfg.rowBegin && plan.haloRows > 0 && !(cfg.rowBegin == 0 && cfg.rowEnd >= cfg.height)) {
+            g_driverError = "gfxh_restir_render_frame: the halo (radius x spatial passes) is taller than a neighbour's band; "
+                            "install a strip exchange (gfxh_restir_set_exchange) or use fewer ranks";
+            return 1;
+        }
+    }
     if (!wholeFrame && viewMoved && (!strips || r->maxMotionRows == 0)) {
         g_driverError = "gfxh_restir_render_frame: the camera or an instance moved, but this band renderer exchanges no motion rows "
                         "(gfxh_restir_set_exchange with maxMotionRows > 0)";

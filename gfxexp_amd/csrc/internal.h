@@ -86,6 +86,8 @@ struct NrcNet;
 
 struct Context {
     int device = 0;
+    int numCUs = 0;                  // of `device` (gfx_ctx_create)
+    size_t nrcTrainLdsConfigured = 0; // dynamic LDS bytes k_nrc_train has been enabled for on this device
     std::string lastError;
     // scene (host mirror)
     std::vector<gfx_material> materials;

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <stdexcept>
+#include "bvh8.hip.h"
 #include "internal.h"
 #include "shading.hip.h"
 
@@ -682,6 +683,10 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
         hipLaunchKernelGGL(k_super_root, dim3(1), dim3(64), 0, stream, out.rootBoxes.as<float>(), out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>());
         out.numNodes = rd.nodeEnd; out.maxDepth = std::max(rs.depth, rd.depth) + 1;
     }
+    // the traversal keeps one stack entry per level it has descended past (bvh8.hip.h LaneStack: LDS + spill area)
+    if (out.maxDepth + 1 > static_cast<uint32_t>(kLdsStackDepth + kSpillStackDepth))
+        throw std::runtime_error("gfx: acceleration structure is " + std::to_string(out.maxDepth) + " levels deep; the traversal stack holds " +
+                                 std::to_string(kLdsStackDepth + kSpillStackDepth) + " entries");
     out.numTris = n;
     hipLaunchKernelGGL(k_tri_ids, dim3((n + 255) / 256), dim3(256), 0, stream, out.trisPtr(), 0u, n, out.triIds.as<gfx_tri_ids>());
     GFX_HIP(hipGetLastError());

@@ -666,8 +666,7 @@ void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count) {
 void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions) {
     if (numData & 0x7F) throw HipError("gfx_nrc_infer: numData must be a multiple of 128");   // network_interface.cu:143
     if (numData == 0) return;
-    static int numCUs = 0;
-    if (!numCUs) { hipDeviceProp_t prop; GFX_HIP(hipGetDeviceProperties(&prop, ctx.device)); numCUs = prop.multiProcessorCount; }
+    const int numCUs = ctx.numCUs;
     const uint32_t numTiles = numData / 64;
     const uint32_t wavesPerBlock = kInferBlock / 64;
     uint32_t grid = std::min<uint32_t>((numTiles + wavesPerBlock - 1) / wavesPerBlock, static_cast<uint32_t>(numCUs) * 4);
@@ -691,10 +690,9 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     a.gradPartials = net->gradPartials.as<float>(); a.gridGrad = net->gridGrad.as<float>(); a.lossSum = net->lossSum.as<float>();
     const int numLayers = net->d.numHidden + 1;
     const size_t lds = static_cast<size_t>(numLayers) * 2 * 4 * 64 * 16 + (static_cast<size_t>(numLayers) + 1) * 64 * kTStride * 2;
-    static size_t ldsConfigured = 0;
-    if (lds > ldsConfigured) {
+    if (lds > ctx.nrcTrainLdsConfigured) {   // per device: the attribute belongs to the device's copy of the kernel
         GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_train), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        ldsConfigured = lds;
+        ctx.nrcTrainLdsConfigured = lds;
     }
     {
         ScopedKernelTimer timer(ctx, stream, "nrc_train_fwd_bwd");

@@ -145,6 +145,9 @@ void scene_upload(Context& ctx, hipStream_t stream) {
         d.triangleOffset = static_cast<uint32_t>(triangles.size() / 3);
         d.numVertices = static_cast<uint32_t>(g.vertices.size());
         d.numTriangles = static_cast<uint32_t>(g.triangles.size() / 3);
+        if (g.materialSlot >= ctx.materials.size())
+            throw std::runtime_error("gfx: a geometry refers to material slot " + std::to_string(g.materialSlot) + " but only " +
+                                     std::to_string(ctx.materials.size()) + " materials are set (gfx_material_set)");
         d.materialSlot = g.materialSlot;
         const bool emitter = g.materialSlot < ctx.materials.size() && ctx.materials[g.materialSlot].hasEmittance;
         d.distOffset = emitter ? lightPool : 0xFFFFFFFFu;   // only emitters own a distribution

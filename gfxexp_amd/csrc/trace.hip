@@ -171,12 +171,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
 }
 
 static uint32_t persistent_grid(Context& ctx) {
-    static int numCUs = 0;
-    if (!numCUs) {
-        hipDeviceProp_t prop;
-        GFX_HIP(hipGetDeviceProperties(&prop, ctx.device));
-        numCUs = prop.multiProcessorCount;
-    }
+    const int numCUs = ctx.numCUs;
     static int blocksPerCU = 0;
     if (!blocksPerCU) {
         const char* e = getenv("GFX_TRACE_BLOCKS_PER_CU");   // tuning knob; default 4 blocks of 256 per CU (LDS: 4 x 40 KiB)
