@@ -18,6 +18,7 @@
 // in registers from the encoding to the output with no LDS round trip and no cross-lane traffic;
 // LDS holds the packed bf16 weight fragments (one ds_read_b128 per fragment per lane).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "internal.h"
@@ -154,6 +155,36 @@ GFX_DEV void grid_corners(const NrcLevel& lv, float px, float py, float pz, uint
     }
 }
 
+// The 8 table entries of one level.  The two x-neighbours of a corner pair differ in the low bits of the index for three
+// quarters of the queries (dense levels: idx + 1; hashed levels: (x ^ H) and ((x + 1) ^ H) differ by 2^(k+1) - 1 with k
+// the trailing ones of x), so one 16-byte load of the aligned block of 4 entries around the first corner usually holds
+// both; the other quarter takes a second, predicated 4-byte load.  A gather instruction costs the texture addresser one
+// cycle per (lane, cache line) whatever its width, so this is 5 line requests per level instead of 8 (profiles/r02_nrc.txt).
+// Level offsets and sizes are multiples of 8 entries (nrc_levels), so the blocks never straddle levels.
+GFX_DEV uint32_t pick4(const uint4 a, uint32_t k) { return (k & 2u) ? ((k & 1u) ? a.w : a.z) : ((k & 1u) ? a.y : a.x); }
+#ifndef GFX_NRC_BLOCK_GATHER
+#define GFX_NRC_BLOCK_GATHER 0      // 1: one 16-byte block load per x-pair of corners (measured slower, profiles/r02_nrc.txt)
+#endif
+#ifndef GFX_NRC_INFER_WAVES
+#define GFX_NRC_INFER_WAVES 2       // waves per SIMD k_nrc_infer is compiled for: 3 and 4 measured slower (the gathers are bound by L2->L1 fills, profiles/r02_nrc.txt)
+#endif
+GFX_DEV void gather_corners(const uint32_t* __restrict__ grid, const uint32_t idx[8], uint32_t e[8]) {
+#if !GFX_NRC_BLOCK_GATHER
+#pragma unroll
+    for (int c = 0; c < 8; ++c) e[c] = grid[idx[c]];
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i0 = idx[2 * j], i1 = idx[2 * j + 1];
+        const uint4 blk = *reinterpret_cast<const uint4*>(grid + (i0 & ~3u));
+        e[2 * j] = pick4(blk, i0 & 3u);
+        uint32_t e1 = pick4(blk, i1 & 3u);
+        if ((i0 ^ i1) & ~3u) e1 = grid[i1];
+        e[2 * j + 1] = e1;
+    }
+}
+
 // The 32 canonical features a lane (half h) supplies for one batch column, in K-slot order
 // out[s * 8 + i] = feature f(s, h, i).  Canonical order: [position 32|36] [one-blob 20] [identity 6] [ones].
 GFX_DEV void encode_half(const NrcDev& d, const uint32_t* __restrict__ grid, const float x[kNrcIn], int h, float out[32]) {
@@ -169,8 +200,7 @@ GFX_DEV void encode_half(const NrcDev& d, const uint32_t* __restrict__ grid, con
                 const NrcLevel lv = d.levels[2 * g + k];
                 uint32_t idx[8]; float w[8]; uint32_t e[8];
                 grid_corners(lv, x[0], x[1], x[2], idx, w);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) e[c] = grid[idx[c]];
+                gather_corners(grid, idx, e);
                 float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -257,7 +287,7 @@ GFX_DEV void layer64(FragPtr frags, int lane, const uint4 b[4], f32x16 acc[2]) {
 // ---------------------------------------------------------------- inference
 // inputs [14, N] column-major fp32, predictions [3, N] column-major fp32 (network_interface.cu:141-147)
 constexpr int kInferBlock = 256;
-__global__ __launch_bounds__(kInferBlock) void k_nrc_infer(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_t* __restrict__ grid,
+__global__ __launch_bounds__(kInferBlock) __attribute__((amdgpu_waves_per_eu(GFX_NRC_INFER_WAVES, GFX_NRC_INFER_WAVES))) void k_nrc_infer(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_t* __restrict__ grid,
                                                            const float* __restrict__ inputs, uint32_t numData, float* __restrict__ predictions) {
     extern __shared__ __attribute__((aligned(16))) uint4 ldsW[];
     const uint32_t fwdElems = d.numHidden * kMatFwdElems + kOutFwdElems;
@@ -267,14 +297,29 @@ __global__ __launch_bounds__(kInferBlock) void k_nrc_infer(NrcDev d, const uint1
     const uint32_t wave = blockIdx.x * (kInferBlock / 64) + (threadIdx.x >> 6);
     const uint32_t numWaves = gridDim.x * (kInferBlock / 64);
     const uint32_t numTiles = (numData + 63) / 64;
+    // the tile's 64 x 14 inputs are one contiguous 3 584-byte run: 14 coalesced loads (4 cache lines each) into a
+    // wave-private LDS image, read back per column, instead of 14 strided scalars per lane and half (28 lines per load)
+    float* ldsX = reinterpret_cast<float*>(ldsW + fwdElems / 8) + (threadIdx.x >> 6) * (64 * kNrcIn);
     for (uint32_t tile = wave; tile < numTiles; tile += numWaves) {
+        {
+            const size_t base = static_cast<size_t>(tile) * 64 * kNrcIn;
+            const size_t limit = static_cast<size_t>(numData) * kNrcIn;
+            float v[kNrcIn];
+#pragma unroll
+            for (int j = 0; j < kNrcIn; ++j) { const size_t e = base + 64 * j + lane; v[j] = e < limit ? inputs[e] : 0.0f; }
+            __builtin_amdgcn_wave_barrier();          // the previous tile's reads are done (same wave, program order)
+#pragma unroll
+            for (int j = 0; j < kNrcIn; ++j) ldsX[64 * j + lane] = v[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         uint4 b[2][4];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const uint32_t col = tile * 64 + 32 * nt + n;
             float x[kNrcIn];
 #pragma unroll
-            for (int k = 0; k < kNrcIn; ++k) x[k] = col < numData ? inputs[static_cast<size_t>(col) * kNrcIn + k] : 0.0f;
+            for (int k = 0; k < kNrcIn; ++k) x[k] = ldsX[(32 * nt + n) * kNrcIn + k];
             float enc[32];
             encode_half(d, grid, x, h, enc);
             to_operand(enc, b[nt]);
@@ -316,7 +361,8 @@ struct NrcTrainArgs {
     const uint16_t* fwd; const uint16_t* bwd; const uint32_t* grid;
     const float* inputs; const float* targets; uint32_t numData;
     float* gradPartials;      // [numBlocks][mlpParams]
-    float* gridGrad;          // [gridParams] (atomics)
+    float* gridGrad;          // [gridParams] fp32 atomics, or (gridGradPacked) one fp16 pair per entry in the first half
+    int gridGradPacked;
     float* lossSum;
 };
 GFX_DEV void store_transposed(uint16_t* ldsT, int nt, int n, int h, const uint4 b[4]) {   // operand -> [feature][batch]
@@ -351,6 +397,19 @@ GFX_DEV void weight_gradient(const uint16_t* ldsDelta, const uint16_t* ldsAct, i
                 if (row < outRows) gradOut[row * 64 + 32 * nt + m] = c[r];
             }
         }
+}
+
+// Precision contract of the packed grid gradient (the default; GFX_NRC_GRID_GRAD=f32 selects the fp32 atomics): every
+// contribution w_c * dL/dfeature (loss-scaled by 128) is clamped to the fp16 range, rounded to fp16 (nearest even) and
+// added by the L2 atomic unit in fp16, so an entry that receives K contributions carries a relative error of the order
+// sqrt(K) * 2^-11 in its gradient sum (order-dependent, like the fp32 atomics) and contributions below 2^-24 * 128 vanish.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+GFX_DEV void grid_grad_add_f16x2(uint32_t* word, float g0, float g1) {
+    f16x2 v;
+    v.x = static_cast<_Float16>(fmin2(fmax2(g0, -65504.0f), 65504.0f));
+    v.y = static_cast<_Float16>(fmin2(fmax2(g1, -65504.0f), 65504.0f));
+    typedef __attribute__((address_space(1))) f16x2* GlobalF16x2;
+    (void)__builtin_amdgcn_global_atomic_fadd_v2f16((GlobalF16x2)word, v);
 }
 
 __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
@@ -503,10 +562,18 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
                             if (d0 == 0.0f && d1 == 0.0f) continue;
                             uint32_t idx[8]; float w[8];
                             grid_corners(lv, xpos[nt][0], xpos[nt][1], xpos[nt][2], idx, w);
+                            if (a.gridGradPacked) {
+                                // one packed-fp16 atomic per corner (global_atomic_pk_add_f16; tiny-cuda-nn scatters __half2
+                                // the same way): the two features of an entry share a 32-bit word
 #pragma unroll
-                            for (int c = 0; c < 8; ++c) {
-                                atomicAdd(a.gridGrad + 2ull * idx[c], w[c] * d0);
-                                atomicAdd(a.gridGrad + 2ull * idx[c] + 1, w[c] * d1);
+                                for (int c = 0; c < 8; ++c) grid_grad_add_f16x2(reinterpret_cast<uint32_t*>(a.gridGrad) + idx[c], w[c] * d0, w[c] * d1);
+                            }
+                            else {
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) {
+                                    atomicAdd(a.gridGrad + 2ull * idx[c], w[c] * d0);
+                                    atomicAdd(a.gridGrad + 2ull * idx[c] + 1, w[c] * d1);
+                                }
                             }
                         }
                     }
@@ -523,6 +590,7 @@ struct NrcOptArgs {
     float* params; float* adamM; float* adamV; float* ema;
     const float* gradPartials; uint32_t numPartials; uint32_t mlpParams;
     float* gridGrad;
+    int gridGradPacked;       // cleared by the caller afterwards (two parameters share a word)
     float lrT, beta1, beta2, eps, l2Reg, emaDecay, debiasOld, debiasNew;
 };
 __global__ void k_nrc_optimizer(NrcOptArgs a) {
@@ -530,7 +598,13 @@ __global__ void k_nrc_optimizer(NrcOptArgs a) {
     if (p >= a.d.total) return;
     const bool isGrid = p >= a.d.gridOff;
     float g;
-    if (isGrid) { g = a.gridGrad[p - a.d.gridOff]; a.gridGrad[p - a.d.gridOff] = 0.0f; }
+    if (isGrid && a.gridGradPacked) {
+        const uint32_t q = p - a.d.gridOff;
+        const uint32_t word = reinterpret_cast<const uint32_t*>(a.gridGrad)[q >> 1];
+        const uint16_t bits = static_cast<uint16_t>((q & 1u) ? word >> 16 : word & 0xFFFFu);
+        g = static_cast<float>(__builtin_bit_cast(_Float16, bits));
+    }
+    else if (isGrid) { g = a.gridGrad[p - a.d.gridOff]; a.gridGrad[p - a.d.gridOff] = 0.0f; }
     else {
         g = 0.0f;
         for (uint32_t k = 0; k < a.numPartials; ++k) g += a.gradPartials[static_cast<size_t>(k) * a.mlpParams + p];
@@ -557,6 +631,7 @@ struct NrcNet {
     DevBuf params, adamM, adamV, ema, gradPartials, gridGrad, lossSum;
     DevBuf packTrainFwd, packTrainBwd, packInferFwd, gridTrain, gridInfer;
     uint32_t partialCapacity = 0;
+    bool gridGradPacked = true;   // GFX_NRC_GRID_GRAD=f32 at creation: fp32 atomics, two per corner
 };
 
 static void nrc_levels(NrcDev& d) {
@@ -599,6 +674,7 @@ NrcNet* nrc_create(Context& ctx, int posEnc, uint32_t numHiddenLayers, float lea
     net->d.gridOff = net->mlpParams;
     nrc_levels(net->d);
     net->gridParams = net->d.total - net->d.gridOff;
+    if (const char* e = getenv("GFX_NRC_GRID_GRAD")) net->gridGradPacked = std::strcmp(e, "f32") != 0;
     const size_t bytes = sizeof(float) * net->d.total;
     net->params.reserve(bytes); net->adamM.reserve(bytes); net->adamV.reserve(bytes); net->ema.reserve(bytes);
     net->gridGrad.reserve(sizeof(float) * std::max<uint32_t>(net->gridParams, 4));
@@ -670,7 +746,7 @@ void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     const uint32_t numTiles = numData / 64;
     const uint32_t wavesPerBlock = kInferBlock / 64;
     uint32_t grid = std::min<uint32_t>((numTiles + wavesPerBlock - 1) / wavesPerBlock, static_cast<uint32_t>(numCUs) * 4);
-    const size_t lds = 2ull * (net->d.numHidden * kMatFwdElems + kOutFwdElems);
+    const size_t lds = 2ull * (net->d.numHidden * kMatFwdElems + kOutFwdElems) + wavesPerBlock * 64 * kNrcIn * sizeof(float);
     ScopedKernelTimer timer(ctx, stream, "nrc_infer");
     hipLaunchKernelGGL(k_nrc_infer, dim3(grid), dim3(kInferBlock), lds, stream, net->d, net->packInferFwd.as<uint16_t>(),
                        net->gridInfer.as<uint32_t>(), dInputs, numData, dPredictions);
@@ -688,6 +764,7 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     a.fwd = net->packTrainFwd.as<uint16_t>(); a.bwd = net->packTrainBwd.as<uint16_t>(); a.grid = net->gridTrain.as<uint32_t>();
     a.inputs = dInputs; a.targets = dTargets; a.numData = numData;
     a.gradPartials = net->gradPartials.as<float>(); a.gridGrad = net->gridGrad.as<float>(); a.lossSum = net->lossSum.as<float>();
+    a.gridGradPacked = net->gridGradPacked ? 1 : 0;
     const int numLayers = net->d.numHidden + 1;
     const size_t lds = static_cast<size_t>(numLayers) * 2 * 4 * 64 * 16 + (static_cast<size_t>(numLayers) + 1) * 64 * kTStride * 2;
     if (lds > ctx.nrcTrainLdsConfigured) {   // per device: the attribute belongs to the device's copy of the kernel
@@ -705,7 +782,7 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     o.d = net->d;
     o.params = net->params.as<float>(); o.adamM = net->adamM.as<float>(); o.adamV = net->adamV.as<float>(); o.ema = net->ema.as<float>();
     o.gradPartials = net->gradPartials.as<float>(); o.numPartials = numBlocks; o.mlpParams = net->mlpParams;
-    o.gridGrad = net->gridGrad.as<float>();
+    o.gridGrad = net->gridGrad.as<float>(); o.gridGradPacked = net->gridGradPacked ? 1 : 0;
     o.beta1 = 0.9f; o.beta2 = 0.99f; o.l2Reg = 1e-6f; o.emaDecay = 0.99f;
     o.eps = net->d.posEnc == 1 ? 1e-15f : 1e-8f;
     const double t = net->step;
@@ -717,6 +794,7 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
         ScopedKernelTimer timer(ctx, stream, "nrc_optimizer");
         hipLaunchKernelGGL(k_nrc_optimizer, dim3((net->d.total + 255) / 256), dim3(256), 0, stream, o);
         GFX_HIP(hipGetLastError());
+        if (net->gridGradPacked && net->gridParams) GFX_HIP(hipMemsetAsync(net->gridGrad.p, 0, sizeof(uint32_t) * (net->gridParams / 2), stream));
     }
     nrc_pack(ctx, stream, *net, true);
     nrc_pack(ctx, stream, *net, false);

@@ -190,7 +190,11 @@ def encode_hashgrid(x3, grid_bf16):
 class NrcNet:
     """fp32 master parameters + Adam/EMA state; forward/backward with the bf16 rounding contract."""
 
-    def __init__(self, pos_enc=POS_HASHGRID, num_hidden_layers=2, learning_rate=1e-2, params=None, bf16=True):
+    def __init__(self, pos_enc=POS_HASHGRID, num_hidden_layers=2, learning_rate=1e-2, params=None, bf16=True, grid_grad_f16=True):
+        # grid_grad_f16: the hash-grid gradient is scattered as fp16 pairs (tiny-cuda-nn's __half2 atomics; nrc.hip
+        # grid_grad_add_f16x2): contributions are rounded to fp16, and so is the per-entry sum.  The order of the
+        # additions on the device is not defined, so the restatement sums in fp32 and rounds once.
+        self.grid_grad_f16 = grid_grad_f16 and bf16
         self.pos_enc, self.n_hidden, self.lr = pos_enc, num_hidden_layers, np.float32(learning_rate)
         self.rnd = bf16_round if bf16 else (lambda a: np.ascontiguousarray(a, np.float32))   # bf16=False: plain fp32 (gradient checks)
         self.table, self.grid_off, self.total = layout(pos_enc, num_hidden_layers)
@@ -269,7 +273,12 @@ class NrcNet:
             for l, (idx, w) in enumerate(hash_corners(np.ascontiguousarray(x[:, 0:3], np.float32))):
                 d = delta[:, 2 * l:2 * l + 2]
                 for c in range(8):
-                    np.add.at(gg, idx[:, c], w[:, c:c + 1] * d)
+                    contrib = (w[:, c:c + 1] * d).astype(np.float32)
+                    if self.grid_grad_f16:
+                        contrib = np.clip(contrib, -65504.0, 65504.0).astype(np.float16).astype(np.float32)
+                    np.add.at(gg, idx[:, c], contrib)
+            if self.grid_grad_f16:
+                gg = gg.astype(np.float16).astype(np.float32)
             g[self.grid_off:] = gg.reshape(-1)
         return np.float32(loss.sum()), g
 
