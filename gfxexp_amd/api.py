@@ -216,7 +216,7 @@ C_ABI_SYMBOLS = [
 HOST_ABI_SYMBOLS = [
     "gfxh_scene_create", "gfxh_scene_destroy", "gfxh_last_error", "gfxh_scene_add_material_traditional",
     "gfxh_scene_add_material", "gfxh_scene_add_texture", "gfxh_scene_load_texture", "gfxh_scene_num_textures", "gfxh_scene_get_texture", "gfxh_scene_add_geom", "gfxh_scene_add_group", "gfxh_scene_add_instance",
-    "gfxh_scene_load_obj", "gfxh_scene_add_rectangle", "gfxh_scene_make_street", "gfxh_scene_counts",
+    "gfxh_scene_load_obj", "gfxh_scene_load_obj_conv", "gfxh_scene_add_rectangle_textured", "gfxh_scene_add_rectangle", "gfxh_scene_make_street", "gfxh_scene_counts",
     "gfxh_scene_get_material", "gfxh_scene_get_geom", "gfxh_scene_get_group", "gfxh_scene_get_instance",
     "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
     "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
@@ -255,7 +255,8 @@ def lib():
         L.gfxh_restir_beauty_buffer.restype = C.c_void_p
         L.gfxh_restir_accel.restype = C.c_uint64
         for name in ("gfxh_scene_add_material_traditional", "gfxh_scene_add_material", "gfxh_scene_add_geom",
-                     "gfxh_scene_add_group", "gfxh_scene_add_instance", "gfxh_scene_load_obj", "gfxh_scene_add_rectangle"):
+                     "gfxh_scene_add_group", "gfxh_scene_add_instance", "gfxh_scene_load_obj", "gfxh_scene_load_obj_conv",
+                     "gfxh_scene_add_rectangle", "gfxh_scene_add_rectangle_textured"):
             getattr(L, name).restype = C.c_uint32
         _lib = L
     return _lib

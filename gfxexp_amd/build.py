@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgfxexp.so")
+CLI = os.path.join(HERE, "restir_di_headless")       # host/restir_di_headless.cpp: the reference's command line, windowless
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = ["capi.cpp", "scene.cpp", "lights.hip", "lbvh.hip", "trace.hip", "restir.hip", "pathtrace.hip", "nrc.hip", "textures.hip",
@@ -68,6 +69,10 @@ def build(force=False):
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         subprocess.check_call(cmd)
+    cli_src = os.path.join(CSRC, "host", "restir_di_headless.cpp")
+    if force or not os.path.exists(CLI) or os.path.getmtime(CLI) < max(os.path.getmtime(cli_src), os.path.getmtime(LIB)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(HERE, "..", "include"), cli_src, "-o", CLI,
+                               "-L" + HERE, "-lgfxexp", "-Wl,-rpath,$ORIGIN"])
     return LIB
 
 

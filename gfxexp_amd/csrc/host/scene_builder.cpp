@@ -378,12 +378,13 @@ uint32_t gfxh_scene_add_instance(gfxh_scene* s, uint32_t group, const float xfm[
     return static_cast<uint32_t>(s->insts.size() - 1);
 }
 
-static uint32_t load_obj_impl(gfxh_scene* s, const char* path);
-uint32_t gfxh_scene_load_obj(gfxh_scene* s, const char* path) {
-    try { return load_obj_impl(s, path); }   // nothing may unwind through the C boundary
+static uint32_t load_obj_impl(gfxh_scene* s, const char* path, int simplePbr);
+uint32_t gfxh_scene_load_obj(gfxh_scene* s, const char* path) { return gfxh_scene_load_obj_conv(s, path, GFXH_MATCONV_TRADITIONAL); }
+uint32_t gfxh_scene_load_obj_conv(gfxh_scene* s, const char* path, int materialConvention) {
+    try { return load_obj_impl(s, path, materialConvention == GFXH_MATCONV_SIMPLE_PBR ? 1 : 0); }   // nothing may unwind through the C boundary
     catch (const std::exception& e) { g_hostError = std::string("gfxh_scene_load_obj: ") + e.what(); return 0xFFFFFFFFu; }
 }
-static uint32_t load_obj_impl(gfxh_scene* s, const char* path) {
+static uint32_t load_obj_impl(gfxh_scene* s, const char* path, int simplePbr) {
     std::ifstream in(path);
     if (!in) { g_hostError = std::string("cannot open ") + path; return 0xFFFFFFFFu; }
     const std::string dir = std::string(path).substr(0, std::string(path).find_last_of("/\\") + 1);
@@ -477,7 +478,15 @@ static uint32_t load_obj_impl(gfxh_scene* s, const char* path) {
             // leaves the immediate value in place
             gfx_material& m = s->materials[matSlot];
             if (!d.mapKd.empty()) m.texA = gfxh_scene_load_texture(s, (dir + d.mapKd).c_str(), GFX_TEX_RGBA8_SRGB);
-            if (!d.mapKs.empty()) m.texB = gfxh_scene_load_texture(s, (dir + d.mapKs).c_str(), GFX_TEX_RGBA8_SRGB);
+            if (!d.mapKs.empty()) m.texB = gfxh_scene_load_texture(s, (dir + d.mapKs).c_str(), simplePbr ? GFX_TEX_RGBA8_UNORM : GFX_TEX_RGBA8_SRGB);
+            if (simplePbr) {
+                // MaterialConvention::SimplePBR (common_host.cpp:2323-2334, createSimplePBRMaterial :1689-1760): the diffuse slot
+                // holds base colour (+ opacity) behind the sRGB sampler, the specular slot (occlusion, roughness, metallic) behind
+                // the normalised-float sampler -- no degamma; no smoothness
+                m.bsdfType = GFX_BSDF_SIMPLE_PBR;
+                for (int i = 0; i < 3; ++i) m.b[i] = quantize8(d.ks[i]);
+                m.smoothness = 0.0f;
+            }
             const std::string& nmap = !d.mapBump.empty() ? d.mapBump : d.mapNormal;   // TEXTURE_HEIGHT first, then TEXTURE_NORMALS (:2278-2282)
             if (!nmap.empty()) { m.texNormal = gfxh_scene_load_texture(s, (dir + nmap).c_str(), GFX_TEX_RGBA8_UNORM); m.bumpMapType = GFX_BUMP_NORMAL_MAP; }
             if (!d.mapKe.empty()) {
@@ -529,6 +538,16 @@ uint32_t gfxh_scene_add_rectangle(gfxh_scene* s, float width, float depth, const
     const uint32_t tris[6] = { 0, 1, 2, 0, 2, 3 };
     const uint32_t g = gfxh_scene_add_geom(s, v, 4, tris, 2, mat);
     return gfxh_scene_add_group(s, &g, 1);
+}
+
+uint32_t gfxh_scene_add_rectangle_textured(gfxh_scene* s, float width, float depth, const float emittance[3], const char* emitterTexturePath) {
+    const uint32_t group = gfxh_scene_add_rectangle(s, width, depth, emittance);
+    if (group == 0xFFFFFFFFu || !emitterTexturePath || !emitterTexturePath[0]) return group;
+    // createEmittanceTexture (common_host.cpp:1524-1531): an 8-bit image goes behind the sRGB sampler, a float image behind the
+    // float sampler; a file that cannot be read leaves the immediate emittance in place
+    const uint32_t tex = gfxh_scene_load_texture(s, emitterTexturePath, GFX_TEX_RGBA8_SRGB);
+    if (tex) { gfx_material& m = s->materials.back(); m.texEmittance = tex; m.hasEmittance = 1u; }
+    return group;
 }
 
 void gfxh_make_transform(float scale, float rollDeg, float pitchDeg, float yawDeg, const float pos[3], float out[12]) {

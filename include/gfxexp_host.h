@@ -52,8 +52,15 @@ uint32_t gfxh_scene_add_instance(gfxh_scene* s, uint32_t group, const float xfm[
  * Returns the group index or 0xFFFFFFFF on failure.  The scale belongs to the instance transform
  * (the reference passes it as the mesh pre-transform, restir_di_main.cpp:1119-1124). */
 uint32_t gfxh_scene_load_obj(gfxh_scene* s, const char* path);
+/* The same with the material convention of "-obj <path> <scale> trad|simple_pbr" (restir_di_main.cpp:701-726,
+ * MaterialConvention common_host.h:594-597): simple_pbr reads Kd / map_Kd as base colour and Ks / map_Ks as
+ * (occlusion, roughness, metallic) for the SimplePBR BRDF. */
+enum gfxh_material_convention { GFXH_MATCONV_TRADITIONAL = 0, GFXH_MATCONV_SIMPLE_PBR = 1 };
+uint32_t gfxh_scene_load_obj_conv(gfxh_scene* s, const char* path, int materialConvention);
 /* createRectangleLight (common_host.cpp:2431-2476): XZ rectangle facing -Y. Returns the group. */
 uint32_t gfxh_scene_add_rectangle(gfxh_scene* s, float width, float depth, const float emittance[3]);
+/* "-rect-emitter-tex <path>" (restir_di_main.cpp:693-699): the rectangle's emittance read from an image. */
+uint32_t gfxh_scene_add_rectangle_textured(gfxh_scene* s, float width, float depth, const float emittance[3], const char* emitterTexturePath);
 
 /* Procedural "street" stand-in for Bistro Exterior (the asset is not redistributable / absent):
  * tessellated ground, facade blocks with window grids, instanced props, and many small emitters. */
@@ -271,6 +278,8 @@ void* gfxh_restir_beauty_buffer(gfxh_restir* r);
 int gfxh_restir_get_params(gfxh_restir* r, gfx_restir_static_params* s, gfx_restir_frame_params* f,
                            uint32_t* lastReservoirIndex, uint32_t* lastSpatialNeighborBaseIndex, uint32_t* frameIndex);
 uint64_t gfxh_restir_accel(gfxh_restir* r);
+/* Message of the last gfxh_restir_* call that returned non-zero on this thread. */
+const char* gfxh_restir_last_error(void);
 
 /* ---------------------------------------------------------------- headless NRC renderer -------- */
 /* The frame loop of neural_radiance_caching_main.cpp:2225-2370 over the C ABI: G-buffer, preprocessNRC,
