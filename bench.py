@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=str, default="480x270", help="resolution of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--plain", action="store_true", help="constant-colour materials (the round-1 workload) instead of the textured street")
+    ap.add_argument("--cluttered", action="store_true", help="secondary workload: + 70 trees of 6 000 leaf cards, cables, railings (depth complexity)")
     ap.add_argument("--bump", type=int, default=1, help="enableBumpMapping (normal maps) for the textured workload")
     return ap.parse_args()
 
@@ -92,7 +93,7 @@ def main():
     W, H = args.width, args.height
     t0 = time.time()
     textured = not args.plain
-    hs = scenes.bench_street(textured=textured)
+    hs = scenes.bench_street(textured=textured, cluttered=args.cluttered)
     counts = hs.counts()
     ctx = api.Context(local_rank)
     hs.upload(ctx)
@@ -148,7 +149,11 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[2] (0-based index into BASELINE.json): ReSTIR DI biased, procedural street stand-in for Bistro Exterior "
                                f"({counts['triangles']} instanced triangles, {counts['insts']} instances, "
-                               "2100 emitter instances), 32 candidates, temporal + 2x5 spatial reuse, radius 20, visibility reuse",
+                               "2100 emitter instances), "
+                               + ("textured materials (albedo / smoothness / normal maps with bump mapping, float emittance maps on the signs), "
+                                  if textured else "constant-colour materials, ")
+                               + ("+ trees of leaf cards, cables and railings (depth-complexity variant), " if args.cluttered else "")
+                               + "32 candidates, temporal + 2x5 spatial reuse, radius 20, visibility reuse",
                    "width": W, "height": H, "spp": 1, "parallelism": f"row-bands x{world}" if world > 1 else "single GPU",
                    "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]}},
         "setup_s": round(setup_s, 2),

@@ -113,7 +113,8 @@ class GfxhStreetParams(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("groundTess", C.c_uint32), ("numBuildings", C.c_uint32),
                 ("facadeTess", C.c_uint32), ("numProps", C.c_uint32), ("propSubdiv", C.c_uint32),
                 ("numLamps", C.c_uint32), ("numSigns", C.c_uint32), ("extent", C.c_float),
-                ("lampEmittance", C.c_float), ("signEmittance", C.c_float), ("textured", C.c_uint32)]
+                ("lampEmittance", C.c_float), ("signEmittance", C.c_float), ("textured", C.c_uint32),
+                ("numTrees", C.c_uint32), ("leavesPerTree", C.c_uint32), ("numWires", C.c_uint32), ("numRailings", C.c_uint32)]
 
 
 class GfxhRestirConfig(C.Structure):
@@ -207,7 +208,7 @@ C_ABI_SYMBOLS = [
     "gfx_group_create", "gfx_instance_create", "gfx_instance_set_transform", "gfx_instance_set_transform_and_normal_matrix", "gfx_instance_set_dynamic",
     "gfx_accel_build",
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
-    "gfx_lights_build_instances", "gfx_lights_read", "gfx_lights_table_info", "gfx_trace", "gfx_restir_set_params", "gfx_restir_copy_to_linear", "gfx_visualize", "gfx_restir_launch",
+    "gfx_lights_build_instances", "gfx_lights_read", "gfx_lights_table_info", "gfx_trace", "gfx_trace_counted", "gfx_restir_set_params", "gfx_restir_copy_to_linear", "gfx_visualize", "gfx_restir_launch",
     "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
     "gfx_nrc_get_params", "gfx_nrc_set_render_params",
@@ -572,7 +573,12 @@ class Context:
         self._check(self.L.gfx_lights_table_info(self.h, info))
         return {"usable": int(info[0]), "verified": int(info[1]), "records": int(info[2]), "cells": int(info[3])}
 
-    def trace(self, accel, mode, d_ray_org, d_ray_dir, num_rays, d_out, d_counters=0, stream=0):
+    def trace(self, accel, mode, d_ray_org, d_ray_dir, num_rays, d_out, d_counters=0, stream=0, d_per_ray_items=0):
+        if d_per_ray_items:
+            self._check(self.L.gfx_trace_counted(self.h, C.c_void_p(stream), C.c_uint64(accel), C.c_int(mode), C.c_void_p(d_ray_org),
+                                                 C.c_void_p(d_ray_dir), C.c_uint32(num_rays), C.c_void_p(d_out), C.c_void_p(d_counters),
+                                                 C.c_void_p(d_per_ray_items)))
+            return
         self._check(self.L.gfx_trace(self.h, C.c_void_p(stream), C.c_uint64(accel), C.c_int(mode), C.c_void_p(d_ray_org),
                                      C.c_void_p(d_ray_dir), C.c_uint32(num_rays), C.c_void_p(d_out), C.c_void_p(d_counters)))
 

@@ -266,13 +266,20 @@ int gfx_lights_table_info(gfx_ctx* ctx, uint32_t info[4]) {
 
 int gfx_trace(gfx_ctx* ctx, void* stream, uint64_t accel, int mode, const void* dRayOrgTmin, const void* dRayDirTmax,
               uint32_t numRays, void* dOut, void* dCounters) {
+    return gfx_trace_counted(ctx, stream, accel, mode, dRayOrgTmin, dRayDirTmax, numRays, dOut, dCounters, nullptr);
+}
+
+int gfx_trace_counted(gfx_ctx* ctx, void* stream, uint64_t accel, int mode, const void* dRayOrgTmin, const void* dRayDirTmax,
+                      uint32_t numRays, void* dOut, void* dCounters, void* dPerRayItems) {
     GFX_TRY(ctx)
+    if (dPerRayItems && !dCounters) throw HipError("gfx_trace_counted: per-ray item counts need the counter buffer (the counting kernel)");
     const Accel* a = find_accel(ctx, accel);
     TraceLaunch t;
     t.accel = a->dev();
     t.rayOrgTmin = static_cast<const float4*>(dRayOrgTmin);
     t.rayDirTmax = static_cast<const float4*>(dRayDirTmax);
     t.numRays = numRays; t.numRaysPtr = nullptr; t.out = dOut; t.mode = mode;
+    t.perRayItems = static_cast<uint32_t*>(dPerRayItems);
     // explicit counter buffer: count into the caller's u64[4]
     const bool savedEnabled = ctx->c.countersEnabled;
     DevBuf saved = ctx->c.dTraceCounters;

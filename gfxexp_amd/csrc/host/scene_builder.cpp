@@ -713,6 +713,82 @@ int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p) {
             gfxh_scene_add_instance(s, signGroups[rng.gen() % 5], xfm);
         }
     }
+    // ---- depth complexity (p->numTrees, p->numWires, p->numRailings): what Bistro's vegetation, cables and balcony railings
+    // do to a ray tracer -- clumps of small randomly oriented leaf cards (thousands of overlapping boxes a ray grazes without
+    // hitting anything), and long thin boxes whose bounding volumes cover mostly air.  Own RNG stream: scenes without these
+    // parameters are unchanged.
+    if (p->numTrees || p->numWires || p->numRailings) {
+        Rng crng(p->seed * 747796405u + 2891336453u);
+        const uint32_t leafMat = mat(0.12f, 0.32f, 0.08f, 0.04f, 0.3f), barkMat = mat(0.25f, 0.18f, 0.12f, 0.02f, 0.1f), metalMat = mat(0.3f, 0.3f, 0.32f, 0.5f, 0.7f);
+        if (p->numTrees) {
+            std::vector<uint32_t> treeGroups;
+            for (int proto = 0; proto < 3; ++proto) {
+                Geom trunk; trunk.mat = barkMat;
+                const float th = crng.range(2.5f, 3.5f);
+                add_box(trunk, { -0.12f, 0, -0.12f }, { 0.12f, th, 0.12f });
+                Geom leaves; leaves.mat = leafMat;
+                const float rx = crng.range(1.4f, 2.2f), ry = crng.range(1.2f, 2.0f), rz = crng.range(1.4f, 2.2f);
+                for (uint32_t k = 0; k < p->leavesPerTree; ++k) {
+                    // a point inside the crown ellipsoid (rejection), a random card orientation, 12-30 cm
+                    V3 c;
+                    do { c = { crng.range(-1, 1), crng.range(-1, 1), crng.range(-1, 1) }; } while (c.x * c.x + c.y * c.y + c.z * c.z > 1.0f);
+                    c = { c.x * rx, th + ry * 0.8f + c.y * ry, c.z * rz };
+                    V3 u = normalize({ crng.range(-1, 1), crng.range(-1, 1), crng.range(-1, 1) });
+                    V3 w = normalize(cross(u, { crng.range(-1, 1), crng.range(-1, 1) + 1.5f, crng.range(-1, 1) }));
+                    const float hs = crng.range(0.06f, 0.15f);
+                    const V3 a = { u.x * hs, u.y * hs, u.z * hs }, b = { w.x * hs, w.y * hs, w.z * hs };
+                    add_quad(leaves, c - a - b, c + a - b, c + a + b, c - a + b);
+                }
+                s->geoms.push_back(std::move(trunk));
+                s->geoms.push_back(std::move(leaves));
+                const uint32_t gs[2] = { static_cast<uint32_t>(s->geoms.size() - 2), static_cast<uint32_t>(s->geoms.size() - 1) };
+                treeGroups.push_back(gfxh_scene_add_group(s, gs, 2));
+            }
+            for (uint32_t k = 0; k < p->numTrees; ++k) {   // two rows along the kerbs
+                const float side = (k & 1u) ? 1.0f : -1.0f;
+                const float pos[3] = { side * E * crng.range(0.22f, 0.3f), 0, -E * 0.92f + 2 * E * 0.92f * (static_cast<float>(k / 2) + crng.range(0.2f, 0.8f)) / std::max(1u, (p->numTrees + 1) / 2) };
+                float xfm[12];
+                gfxh_make_transform(crng.range(0.8f, 1.3f), 0, 0, crng.range(0, 360), pos, xfm);
+                gfxh_scene_add_instance(s, treeGroups[crng.gen() % 3], xfm);
+            }
+        }
+        if (p->numWires) {   // cables across the street between the facade rows, slightly sagging: 8 thin segments each
+            Geom wires; wires.mat = metalMat;
+            for (uint32_t k = 0; k < p->numWires; ++k) {
+                const float z0 = crng.range(-E * 0.9f, E * 0.9f), z1 = z0 + crng.range(-6.0f, 6.0f), y = crng.range(5.0f, 9.0f);
+                const float x0 = -E * 0.36f, x1 = E * 0.36f, r = 0.015f;
+                for (int sgm = 0; sgm < 8; ++sgm) {
+                    const float t0 = sgm / 8.0f, t1 = (sgm + 1) / 8.0f;
+                    const float xa = x0 + (x1 - x0) * t0, xb = x0 + (x1 - x0) * t1, za = z0 + (z1 - z0) * t0, zb = z0 + (z1 - z0) * t1;
+                    const float ya = y - 1.2f * 4 * t0 * (1 - t0), yb = y - 1.2f * 4 * t1 * (1 - t1);
+                    // a box around the segment, axis-aligned in x (the sag and the skew make its BVH box mostly empty)
+                    add_quad(wires, { xa, ya - r, za - r }, { xb, yb - r, zb - r }, { xb, yb + r, zb - r }, { xa, ya + r, za - r });
+                    add_quad(wires, { xa, ya + r, za + r }, { xb, yb + r, zb + r }, { xb, yb - r, zb + r }, { xa, ya - r, za + r });
+                    add_quad(wires, { xa, ya + r, za - r }, { xb, yb + r, zb - r }, { xb, yb + r, zb + r }, { xa, ya + r, za + r });
+                    add_quad(wires, { xa, ya - r, za + r }, { xb, yb - r, zb + r }, { xb, yb - r, zb - r }, { xa, ya - r, za - r });
+                }
+            }
+            s->geoms.push_back(std::move(wires));
+            const uint32_t gs = static_cast<uint32_t>(s->geoms.size() - 1);
+            gfxh_scene_add_instance(s, gfxh_scene_add_group(s, &gs, 1), ident);
+        }
+        if (p->numRailings) {   // a railing segment = two rails + 24 thin bars, instanced along the kerbs
+            Geom rail; rail.mat = metalMat;
+            add_box(rail, { -1.5f, 0.95f, -0.02f }, { 1.5f, 1.0f, 0.02f });
+            add_box(rail, { -1.5f, 0.1f, -0.02f }, { 1.5f, 0.14f, 0.02f });
+            for (int b = 0; b < 24; ++b) { const float x = -1.5f + 3.0f * (b + 0.5f) / 24; add_box(rail, { x - 0.008f, 0.14f, -0.008f }, { x + 0.008f, 0.95f, 0.008f }); }
+            s->geoms.push_back(std::move(rail));
+            const uint32_t gs = static_cast<uint32_t>(s->geoms.size() - 1);
+            const uint32_t grp = gfxh_scene_add_group(s, &gs, 1);
+            for (uint32_t k = 0; k < p->numRailings; ++k) {
+                const float side = (k & 1u) ? 1.0f : -1.0f;
+                const float pos[3] = { side * E * 0.2f, 0, -E * 0.95f + 2 * E * 0.95f * (static_cast<float>(k / 2) + 0.5f) / std::max(1u, (p->numRailings + 1) / 2) };
+                float xfm[12];
+                gfxh_make_transform(1.0f, 0, 0, 90.0f, pos, xfm);
+                gfxh_scene_add_instance(s, grp, xfm);
+            }
+        }
+    }
     // ---- textures (p->textured): the geometry above is unchanged, materials get maps instead of constants --
     // cobbled ground and plastered / bricked facades with albedo, smoothness and normal maps, wooden crates, and
     // signs whose emittance is a float texture (lettering-like stripes), so every texture fetch of the reference

@@ -187,6 +187,7 @@ struct TraceLaunch {
     int mode;
     DevBuf* spill = nullptr;        // stack-spill area / ticket word; null = the context's shared ones
     DevBuf* counters = nullptr;
+    uint32_t* perRayItems = nullptr; // counting launches: items fetched per ray
 };
 void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t);
 // ---- textures.hip

@@ -27,6 +27,7 @@ struct TraceArgs {
     uint32_t* ticket;           // queue head (zeroed before the launch)
     uint2* spill;               // kSpillStackDepth entries per thread of the grid
     unsigned long long* counters; // optional: node fetches, triangle fetches, rays, spills
+    uint32_t* perRayItems;        // optional (counting launches): items (nodes + triangle records) each ray fetched, indexed like the queue
     unsigned long long* diag;     // optional (counting launches): wave iterations, item-lanes, drain iterations, drain item-lanes
     int refillThreshold;        // refill when at least this many lanes are idle
     int ticketBatch;            // rays bought per device atomic
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
     bool exhausted = false;           // wave-uniform: the queue has no more rays
     uint32_t waveNext = 0, waveEnd = 0; // wave-uniform: rays [waveNext, waveEnd) already ticketed for this wave
     TraceCounters cnt = { 0, 0, 0 };
-    uint32_t raysDone = 0;
+    uint32_t raysDone = 0, rayItems = 0;
     uint32_t diagIter = 0, diagLanes = 0, diagDrainIter = 0, diagDrainLanes = 0;   // wave-uniform (COUNT only)
 
     auto write_result = [&]() {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
             gfx_hit h; h.dist = tr.hit.t; h.bcB = tr.hit.bcB; h.bcC = tr.hit.bcC; h.triIndex = tr.hit.tri;
             static_cast<gfx_hit*>(a.out)[rayIdx] = h;
         }
-        if (COUNT) ++raysDone;
+        if (COUNT) { ++raysDone; if (a.perRayItems) a.perRayItems[rayIdx] = rayItems; }
     };
 
     while (true) {
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
                     const float4 o = a.rayOrgTmin[i];
                     const float4 d = a.rayDirTmax[i];
                     rayIdx = i;
+                    if (COUNT) rayItems = 0;
                     tr.begin(f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, d.w, stack, hasNodes);
                     if (!hasNodes || !(d.w > o.w)) {   // empty interval or empty scene: immediate miss
                         tr.active = false;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
             if (code == kItemNone) write_result();          // traversal finished
         }
         if (COUNT) {
+            if (code != kItemNone) ++rayItems;
             const int held = __popcll(__ballot(code != kItemNone));
             ++diagIter; diagLanes += held;
             if (exhausted) { ++diagDrainIter; diagDrainLanes += held; }
@@ -197,6 +200,7 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     // the context's own counters keep any-hit launches in [0..3] and closest-hit launches in [4..7]
     a.counters = ctx.countersEnabled ? ctx.dTraceCounters.as<unsigned long long>() + ((ctx.countersSplit && t.mode != GFX_TRACE_ANY) ? 4 : 0) : nullptr;
     a.diag = nullptr;
+    a.perRayItems = ctx.countersEnabled ? t.perRayItems : nullptr;
     if (ctx.countersEnabled) {
         if (!ctx.dTraceDiag.p) { ctx.dTraceDiag.reserve(64); GFX_HIP(hipMemsetAsync(ctx.dTraceDiag.p, 0, 64, stream)); }
         a.diag = ctx.dTraceDiag.as<unsigned long long>();

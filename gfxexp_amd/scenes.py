@@ -12,9 +12,11 @@ from gfxexp_amd import api
 ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets")
 
 
-def small_street(seed=7, scale=1, textured=False):
+def small_street(seed=7, scale=1, textured=False, cluttered=False):
     p = api.GfxhStreetParams()
     p.textured = int(textured)
+    if cluttered:
+        p.numTrees, p.leavesPerTree, p.numWires, p.numRailings = 6, 300, 8, 10
     p.seed = seed
     p.groundTess = 24 * scale
     p.numBuildings = 8
@@ -31,12 +33,16 @@ def small_street(seed=7, scale=1, textured=False):
     return s
 
 
-def bench_street(seed=2024, textured=False):
+def bench_street(seed=2024, textured=False, cluttered=False):
     """The Bistro-Exterior stand-in used by bench.py (2.55 M instanced triangles, 2 745 instances, 2 100 emitters).
     textured=True: the same geometry with albedo / smoothness / normal maps on ground, facades and crates and float
-    emittance maps on the signs (gfxh_scene_make_street, `textured`)."""
+    emittance maps on the signs (gfxh_scene_make_street, `textured`).
+    cluttered=True: + 70 trees of 6 000 leaf cards, 120 cables and 160 railing segments (+ ~1 M thin / tiny triangles):
+    the depth complexity of Bistro's vegetation and ironwork (bench.py --cluttered, a secondary workload)."""
     p = api.GfxhStreetParams()
     p.textured = int(textured)
+    if cluttered:
+        p.numTrees, p.leavesPerTree, p.numWires, p.numRailings = 70, 6000, 120, 160
     p.seed = seed
     p.groundTess = 512
     p.numBuildings = 44

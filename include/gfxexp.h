@@ -196,6 +196,12 @@ enum gfx_trace_mode { GFX_TRACE_CLOSEST = 0, GFX_TRACE_ANY = 1 };
 int gfx_trace(gfx_ctx* ctx, void* stream, uint64_t accel, int mode,
               const void* dRayOrgTmin, const void* dRayDirTmax, uint32_t numRays,
               void* dOut, void* dCounters);
+/* The same through the counting instantiation, additionally writing how many 64-byte items (BVH8 nodes + triangle
+ * records) each ray fetched to dPerRayItems (device u32[numRays]): the work distribution a scene asks of the traversal
+ * (tools/bvh_quality.py reports its histogram).  dCounters must be given. */
+int gfx_trace_counted(gfx_ctx* ctx, void* stream, uint64_t accel, int mode,
+                      const void* dRayOrgTmin, const void* dRayDirTmax, uint32_t numRays,
+                      void* dOut, void* dCounters, void* dPerRayItems);
 
 /* ---------------------------------------------------------------- ReSTIR DI ------------------ */
 

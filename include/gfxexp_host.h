@@ -77,6 +77,11 @@ typedef struct gfxh_street_params {
     float lampEmittance;
     float signEmittance;
     uint32_t textured;          /* 1: ground / facades / crates get albedo + smoothness + normal maps, signs a float emittance map */
+    /* depth complexity (0 = none; the geometry above does not depend on these): */
+    uint32_t numTrees;          /* instanced trees: trunk + leavesPerTree randomly oriented 12-30 cm leaf cards in the crown */
+    uint32_t leavesPerTree;
+    uint32_t numWires;          /* sagging 3-cm cables across the street (8 segments each) */
+    uint32_t numRailings;       /* 3-m railing segments (2 rails + 24 bars of 1.6 cm) along the kerbs */
 } gfxh_street_params;
 int gfxh_scene_make_street(gfxh_scene* s, const gfxh_street_params* p);
 

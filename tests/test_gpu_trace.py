@@ -182,3 +182,34 @@ def test_split_tree_static_plus_animated_subtree(built_lib):
         assert np.array_equal(occ != 0, osc.trace(1, shadow_o, shadow_d) != 0), f"step {step}: any-hit"
     assert ctx.accel_stats(accel)["triRecords"] == hs.counts()["triangles"]
     assert nodes_before > 0
+
+
+def test_cluttered_street_and_per_ray_item_counts(built_lib):
+    """The depth-complexity variant of the stand-in (leaf cards, cables, railings: thin and tiny triangles whose boxes a ray
+    grazes) against the oracle, and gfx_trace_counted's per-ray item counts: they add up to the launch counters, every ray
+    that entered the tree fetched at least the root, and the hits are the same as the plain launch's."""
+    import torch
+    from gfxexp_amd import scenes
+    hs = scenes.small_street(cluttered=True)
+    plain = scenes.small_street()
+    assert hs.counts()["triangles"] > plain.counts()["triangles"] + 5000
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    osc = util.feed_oracle(hs)
+    org, dirs = util.pinhole_rays(320, 200, (2.0, 3.0, 28.0), (0.0, 3.0, 0.0), fov_y_deg=60.0)
+    n = len(org)
+    gpu_hits = _gpu_trace(ctx, accel, api.TRACE_CLOSEST, org, dirs)
+    _compare_closest(gpu_hits, _tri_ids(ctx, accel), osc.trace(0, org, dirs), osc.tri_ids(), "cluttered street")
+    d_org, d_dir = torch.from_numpy(org).cuda(), torch.from_numpy(dirs).cuda()
+    d_out = torch.zeros(n * 4, dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+    d_items = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    ctx.trace(accel, api.TRACE_CLOSEST, d_org.data_ptr(), d_dir.data_ptr(), n, d_out.data_ptr(), d_cnt.data_ptr(), d_per_ray_items=d_items.data_ptr())
+    torch.cuda.synchronize()
+    items, cnt = d_items.cpu().numpy(), d_cnt.cpu().numpy()
+    assert np.array_equal(d_out.cpu().numpy().view(api.HIT_DTYPE).reshape(n), gpu_hits)
+    assert items.min() >= 1 and items.sum() == cnt[0] + cnt[1] and cnt[2] == n
+    assert items.max() > 4 * np.median(items)          # the tail the band split runs into (profiles/r02_band_notes.txt)
+    with pytest.raises(api.GfxError):
+        ctx.trace(accel, api.TRACE_CLOSEST, d_org.data_ptr(), d_dir.data_ptr(), n, d_out.data_ptr(), 0, d_per_ray_items=d_items.data_ptr())
