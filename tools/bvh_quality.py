@@ -80,7 +80,7 @@ def main():
     osc = util.feed_oracle(hs)
     build_s = time.time() - t0
     _, stats = osc.trace(3, org, dirs, want_stats=True)
-    res = {"histogram": histogram,"scene": which, "rays": n, "camera": "bench.py camera, 480x270 primary rays" if which == "bench" else "small street",
+    res = {"histogram": histogram,"scene": which, "rays": n, "camera": "bench.py camera, 480x270 primary rays" if which.startswith("bench") else "small street",
            "hit_fraction": float(np.mean(hits < 1e30)),
            "gpu_tree": {"nodes_per_ray": float(c[0]) / n, "tris_per_ray": float(c[1]) / n, "accel": ctx.accel_stats(accel),
                         "builder": os.environ.get("GFX_BVH_VARIANT", "default")},
