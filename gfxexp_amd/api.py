@@ -338,7 +338,15 @@ class HostScene:
         x = np.ascontiguousarray(xfm12, np.float32).reshape(12)
         return self.L.gfxh_scene_add_instance(self.h, C.c_uint32(group), _p(x))
 
-    def load_obj(self, path):
+    def load_obj(self, path, simple_pbr=False):
+        if simple_pbr:
+            g = self.L.gfxh_scene_load_obj_conv(self.h, path.encode(), C.c_int(1))
+            if g == 0xFFFFFFFF:
+                raise GfxError("gfxh_scene_load_obj: " + self.L.gfxh_last_error().decode())
+            return g
+        return self._load_obj_trad(path)
+
+    def _load_obj_trad(self, path):
         g = self.L.gfxh_scene_load_obj(self.h, path.encode())
         if g == GFX_INVALID_SLOT:
             raise GfxError(self.L.gfxh_last_error().decode())

@@ -1,0 +1,180 @@
+"""An independent check of the host scene builder's OBJ / MTL conversion (gfxh_scene_load_obj, scene_builder.cpp): a reader
+written here from the Wavefront format alone (no shared code, no vertex welding) must describe the same triangle soup,
+material by material, and the same immediate material values (createTriangleMeshes, common/common_host.cpp:2181-2430:
+one geometry per material in order of first use, assimp's FlipUVs / JoinIdenticalVertices / face normals where the file
+has none; 8-bit immediate textures read through the sRGB sampler, :1045-1073)."""
+import os
+
+import numpy as np
+import pytest
+
+from gfxexp_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASSETS = os.path.join(ROOT, "tests", "golden", "assets")
+
+SYNTHETIC_OBJ = """\
+mtllib two.mtl
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0 0 1
+v 1 0 1
+v 1 1 1
+v 0 1 1
+vt 0 0
+vt 1 0
+vt 1 0.75
+vt 0.25 1
+vn 0 0 -1
+vn 0 0 2
+usemtl red
+f 1/1/1 4/4/1 3/3/1 2/2/1
+usemtl shiny
+f 5/1/2 6/2/2 7/3/2 8/4/2
+f -8 -7 -3
+usemtl red
+f 2//1 3//1 7//1
+f 1/2 5/3 8/4
+"""
+SYNTHETIC_MTL = """\
+newmtl red
+Kd 0.8 0.1 0.05
+Ks 0.02 0.02 0.02
+Ns 25
+newmtl shiny
+Kd 0.2 0.2 0.2
+Ks 0.9 0.6 0.3
+Ke 3 2 1
+Ns 400
+"""
+
+
+def read_obj(path):
+    """{material: [triangles of 3 corners (position, uv or None, normal or None)]} in order of first use; + mtl dict."""
+    pos, uv, nrm, mats, order = [], [], [], {}, []
+    mtl, cur, cur_mtl = {}, "", None
+    base = os.path.dirname(path)
+    for line in open(path):
+        tok = line.split()
+        if not tok or tok[0].startswith("#"):
+            continue
+        if tok[0] == "v":
+            pos.append([float(x) for x in tok[1:4]])
+        elif tok[0] == "vt":
+            uv.append([float(tok[1]), float(tok[2]) if len(tok) > 2 else 0.0])
+        elif tok[0] == "vn":
+            nrm.append([float(x) for x in tok[1:4]])
+        elif tok[0] == "mtllib":
+            for ml in open(os.path.join(base, tok[1])):
+                mt = ml.split()
+                if not mt:
+                    continue
+                if mt[0] == "newmtl":
+                    cur_mtl = mtl.setdefault(mt[1], {"Kd": [0, 0, 0], "Ks": [0, 0, 0], "Ke": [0, 0, 0], "Ns": 0.0})
+                elif mt[0] in ("Kd", "Ks", "Ke"):
+                    cur_mtl[mt[0]] = [float(x) for x in mt[1:4]]
+                elif mt[0] == "Ns":
+                    cur_mtl["Ns"] = float(mt[1])
+        elif tok[0] == "usemtl":
+            cur = tok[1]
+        elif tok[0] == "f":
+            corners = []
+            for c in tok[1:]:
+                idx = (c.split("/") + ["", ""])[:3]
+                ref = []
+                for k, pool in zip(idx, (pos, uv, nrm)):
+                    if k == "":
+                        ref.append(None)
+                    else:
+                        i = int(k)
+                        ref.append(pool[i - 1] if i > 0 else pool[len(pool) + i])
+                corners.append(ref)
+            if cur not in mats:
+                mats[cur] = []
+                order.append(cur)
+            for k in range(1, len(corners) - 1):           # fan triangulation
+                mats[cur].append((corners[0], corners[k], corners[k + 1]))
+    return order, mats, mtl
+
+
+def expected_soup(tris):
+    """float32 arrays [n, 3, 3] positions, [n, 3, 2] texcoords (v flipped), [n, 3, 3] unit normals (face normal where missing)."""
+    n = len(tris)
+    P, T, N = np.zeros((n, 3, 3), np.float32), np.zeros((n, 3, 2), np.float32), np.zeros((n, 3, 3), np.float64)
+    for i, tri in enumerate(tris):
+        for k, (p, t, nn) in enumerate(tri):
+            P[i, k] = p
+            if t is not None:
+                T[i, k] = (np.float32(t[0]), np.float32(1.0) - np.float32(t[1]))
+        if any(c[2] is None for c in tri):
+            p = P[i].astype(np.float64)
+            fn = np.cross(p[1] - p[0], p[2] - p[0])
+            N[i, :] = fn / np.linalg.norm(fn)
+        else:
+            for k in range(3):
+                v = np.array(tri[k][2], np.float64)
+                N[i, k] = v / np.linalg.norm(v)
+    return P, T, N
+
+
+def srgb_immediate(v):
+    q = min(int(np.float32(255) * np.float32(v)), 255) / 255.0
+    return q / 12.92 if q <= 0.04045 else ((q + 0.055) / 1.055) ** 2.4
+
+
+@pytest.fixture(scope="module")
+def synthetic(tmp_path_factory):
+    d = tmp_path_factory.mktemp("obj")
+    (d / "two.obj").write_text(SYNTHETIC_OBJ)
+    (d / "two.mtl").write_text(SYNTHETIC_MTL)
+    return str(d / "two.obj")
+
+
+@pytest.mark.parametrize("which", ["synthetic", "stanford_bunny_309_faces.obj", "teapot.obj"])
+def test_obj_conversion_against_an_independent_reader(built_lib, synthetic, which):
+    path = synthetic if which == "synthetic" else os.path.join(ASSETS, which)
+    order, mats, mtl = read_obj(path)
+    hs = api.HostScene()
+    group = hs.load_obj(path)
+    geoms, materials = hs.geoms(), hs.materials()
+    assert len(geoms) == len(order) and list(hs.groups()[group]) == list(range(len(order)))
+    for gi, name in enumerate(order):
+        v, t, mat_slot = geoms[gi]
+        P, T, N = expected_soup(mats[name])
+        assert len(t) == len(P), (name, len(t), len(P))
+        soup = v[np.asarray(t, np.int64)]                                   # [n, 3] records: the builder's indexing undone
+        assert np.array_equal(soup["position"], P), name
+        assert np.array_equal(soup["texCoord"], T), name
+        assert np.abs(soup["normal"].astype(np.float64) - N).max() < 3e-7, name
+        nn = v["normal"].astype(np.float64)
+        tt = v["texCoord0Dir"].astype(np.float64)
+        assert np.abs(np.linalg.norm(nn, axis=1) - 1).max() < 1e-6 and np.abs(np.linalg.norm(tt, axis=1) - 1).max() < 1e-6
+        assert np.abs((nn * tt).sum(1)).max() < 1e-5
+        # aiProcess_JoinIdenticalVertices: one vertex per distinct (position, texcoord, normal) reference of the file
+        keys = set()
+        for fi, tri in enumerate(mats[name]):
+            face_normal = any(c[2] is None for c in tri)
+            for p, tc, n_ in tri:
+                keys.add((tuple(p), None if tc is None else tuple(tc), ("face", fi) if face_normal else tuple(n_)))
+        assert len(v) <= len(keys) and len(np.unique(v.view(np.uint8).reshape(len(v), -1), axis=0)) == len(v)
+        m = materials[mat_slot]
+        d = mtl.get(name, {"Kd": [0, 0, 0], "Ks": [0, 0, 0], "Ke": [0, 0, 0], "Ns": 0.0})
+        assert m.bsdfType == 1                                              # DiffuseAndSpecular ("trad")
+        np.testing.assert_allclose(list(m.a), [srgb_immediate(x) for x in d["Kd"]], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(list(m.b), [srgb_immediate(x) for x in d["Ks"]], rtol=2e-6, atol=1e-9)
+        smooth = min(int(np.float32(255) * (np.sqrt(np.float32(d["Ns"])) / np.float32(11.0))), 255) / 255.0
+        assert abs(m.smoothness - smooth) < 1e-6
+        assert list(m.emittance) == [np.float32(x) for x in d["Ke"]] and m.hasEmittance == int(any(x != 0 for x in d["Ke"]))
+
+
+def test_simple_pbr_convention(built_lib, synthetic):
+    """"-obj <path> <scale> simple_pbr": Kd is base colour behind the sRGB sampler, Ks is (occlusion, roughness, metallic)
+    behind the normalised-float sampler -- 8-bit quantised, no degamma (createSimplePBRMaterial, common_host.cpp:1689-1760)."""
+    hs = api.HostScene()
+    hs.load_obj(synthetic, simple_pbr=True)
+    m = hs.materials()[1]                                                   # "shiny"
+    assert m.bsdfType == 2
+    np.testing.assert_allclose(list(m.a), [srgb_immediate(0.2)] * 3, rtol=2e-6)
+    np.testing.assert_allclose(list(m.b), [int(255 * np.float32(x)) / 255.0 for x in (0.9, 0.6, 0.3)], rtol=1e-6)
