@@ -15,7 +15,6 @@ namespace gfx {
 
 constexpr int kTraceBlock = 256;
 constexpr int kRefillThreshold = 8;
-constexpr int kTriShare = 0;       // GFX_TRACE_TRI_SHARE: see TraceArgs::triShare
 constexpr int kTicketBatch = 64;   // rays bought per device atomic (tuned: 32 and 128 are slower)
 
 struct TraceArgs {
@@ -32,7 +31,6 @@ struct TraceArgs {
     unsigned long long* diag;     // optional (counting launches): wave iterations, item-lanes, drain iterations, drain item-lanes
     int refillThreshold;        // refill when at least this many lanes are idle
     int ticketBatch;            // rays bought per device atomic
-    int triShare;               // 0: mixed iterations; 1..64: phased iterations, triangles when they are >= triShare/64 of the held items
 };
 
 // Cooperative fetch of one 64-byte item (node or triangle record) per lane.
@@ -91,7 +89,6 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
     uint32_t waveNext = 0, waveEnd = 0; // wave-uniform: rays [waveNext, waveEnd) already ticketed for this wave
     TraceCounters cnt = { 0, 0, 0 };
     uint32_t raysDone = 0, rayItems = 0;
-    uint32_t held = kItemNone;        // the item this lane has popped and not processed yet
     uint32_t diagIter = 0, diagLanes = 0, diagDrainIter = 0, diagDrainLanes = 0;   // wave-uniform (COUNT only)
 
     auto write_result = [&]() {
@@ -138,42 +135,27 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
             if (exhausted) break;
             continue;
         }
-        // Every lane holds at most one popped, unprocessed item.  Mixed mode (triShare == 0): every holder processes its
-        // item this iteration, node and triangle code both run (each with part of the lanes).  Phased mode: the wave picks
-        // ONE kind per iteration -- triangles once they are at least triShare/64 of the held items (or nothing else is
-        // held), nodes otherwise -- so only one of the two instruction streams is issued; holders of the other kind wait.
-        if (tr.active && held == kItemNone) {
-            held = tr.next_item(stack, a.accel.triItemOffset);
-            if (held == kItemNone) write_result();          // traversal finished
+        uint32_t code = kItemNone;
+        if (tr.active) {
+            code = tr.next_item(stack, a.accel.triItemOffset);
+            if (code == kItemNone) write_result();          // traversal finished
         }
-        uint32_t code = held;
-        bool triPhase = false, nodePhase = false;
-        if (a.triShare > 0) {
-            const bool holdsTri = held != kItemNone && (held & kItemTri) != 0u;
-            const int numTri = __popcll(__ballot(holdsTri)), numHeld = __popcll(__ballot(held != kItemNone));
-            triPhase = numTri > 0 && numTri * 64 >= a.triShare * numHeld;
-            nodePhase = !triPhase;
-            if (held != kItemNone && holdsTri != triPhase) code = kItemNone;
-        }
-        if (code != kItemNone) held = kItemNone;
         if (COUNT) {
             if (code != kItemNone) ++rayItems;
-            const int heldLanes = __popcll(__ballot(code != kItemNone));
-            ++diagIter; diagLanes += heldLanes;
-            if (exhausted) { ++diagDrainIter; diagDrainLanes += heldLanes; }
+            const int held = __popcll(__ballot(code != kItemNone));
+            ++diagIter; diagLanes += held;
+            if (exhausted) { ++diagDrainIter; diagDrainLanes += held; }
         }
         uint4 link = make_uint4(0u, 0u, 0u, 0u);
-        if (!triPhase && code != kItemNone && !(code & kItemTri)) link = reinterpret_cast<const uint4*>(a.accel.links)[code];   // in flight with the item fetch
+        if (code != kItemNone && !(code & kItemTri)) link = reinterpret_cast<const uint4*>(a.accel.links)[code];   // in flight with the item fetch
         uint4 q0, q1, q2, q3;
         fetch_items(code, a.accel, waveBuf, lane, q0, q1, q2, q3);
-        if (!nodePhase) {        // wave-uniform in phased mode: a scalar branch around the whole triangle code
-            if (code != kItemNone && (code & kItemTri)) {
+        if (code != kItemNone) {
+            if (code & kItemTri) {
                 if (!tr.template process_triangle<ANY_HIT, COUNT>((code & 0x7FFFFFFFu) - a.accel.triItemOffset, q0, q1, q2, q3, a.accel.tris, cnt))
                     write_result();                         // any-hit ray found its occluder
             }
-        }
-        if (!triPhase) {
-            if (code != kItemNone && !(code & kItemTri)) tr.template process_node<COUNT>(q0, q1, q2, q3, link, stack, cnt);
+            else tr.template process_node<COUNT>(q0, q1, q2, q3, link, stack, cnt);
         }
     }
     if (COUNT && a.diag && lane == 0) {
@@ -229,9 +211,6 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     static int batch = 0;
     if (!batch) { const char* e = getenv("GFX_TRACE_BATCH"); batch = e ? atoi(e) : kTicketBatch; if (batch < 1 || batch > 65536) batch = kTicketBatch; }
     a.ticketBatch = batch;
-    static int triShare = -1;
-    if (triShare < 0) { const char* e = getenv("GFX_TRACE_TRI_SHARE"); triShare = e ? atoi(e) : kTriShare; if (triShare < 0 || triShare > 64) triShare = kTriShare; }
-    a.triShare = triShare;
     const bool any = t.mode == GFX_TRACE_ANY;
     ScopedKernelTimer timer(ctx, stream, any ? "trace_any" : "trace_closest");
     if (ctx.countersEnabled) {
