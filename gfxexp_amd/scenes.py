@@ -8,8 +8,6 @@ import numpy as np
 
 from gfxexp_amd import api
 
-# data fixtures (flattened meshes the reference's own harness names); they live with the tests' golden data
-ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets")
 
 
 def small_street(seed=7, scale=1, textured=False, cluttered=False):
@@ -59,10 +57,11 @@ def bench_street(seed=2024, textured=False, cluttered=False):
     return s
 
 
-def bunny_scene(with_light=True, with_ground=True):
-    """BASELINE config 2: bunny (scale 0.1) + rectangle light + ground quad."""
+def bunny_scene(obj_path, with_light=True, with_ground=True):
+    """BASELINE config 2: bunny (scale 0.1) + rectangle light + ground quad.  `obj_path`: the bunny mesh the reference's test
+    harness names (stanford_bunny_309_faces.obj); the package ships no mesh data -- tests and tools pass the fixture's path."""
     s = api.HostScene()
-    g = s.load_obj(os.path.join(ASSETS, "stanford_bunny_309_faces.obj"))
+    g = s.load_obj(obj_path)
     s.add_instance(g, api.make_transform(scale=0.1))
     if with_ground:
         mat = s.add_material_traditional((0.7, 0.7, 0.7), (0.04, 0.04, 0.04), 0.1)

@@ -36,7 +36,11 @@ def feed_oracle(host_scene, threads=None, brute_force=False, config=None):
     return osc
 
 
-from gfxexp_amd.scenes import bunny_scene  # noqa: E402,F401
+from gfxexp_amd import scenes as _scenes  # noqa: E402
+
+
+def bunny_scene(with_light=True, with_ground=True):
+    return _scenes.bunny_scene(os.path.join(ASSETS, "stanford_bunny_309_faces.obj"), with_light, with_ground)
 
 
 def teapot_scene(emissive=False):

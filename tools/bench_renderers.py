@@ -20,6 +20,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gfxexp_amd import api  # noqa: E402
 from gfxexp_amd import scenes  # noqa: E402
 
+BUNNY_OBJ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets", "stanford_bunny_309_faces.obj")
+
 
 def timed(ctx, renderer, steps, warmup):
     import torch
@@ -45,7 +47,7 @@ def main():
     args = ap.parse_args()
 
     # configs[1]
-    hs = scenes.bunny_scene()
+    hs = scenes.bunny_scene(BUNNY_OBJ)
     ctx = api.Context(0)
     hs.upload(ctx)
     w = h = 512

@@ -14,6 +14,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gfxexp_amd import api, scenes  # noqa: E402
 
+BUNNY_OBJ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets", "stanford_bunny_309_faces.obj")
+
 
 def write_png(path, px, width, height):
     """px: uint32 R | G << 8 | B << 16 per pixel, top row first."""
@@ -44,10 +46,10 @@ def main():
         scenes.bench_street().upload(ctx)
         cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
     else:
-        scenes.bunny_scene().upload(ctx)
+        scenes.bunny_scene(BUNNY_OBJ).upload(ctx)
         cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
     if args.renderer == 6:     # neural radiance cache: --warm frames of training without accumulation, then accumulate
-        hs_bounds = (scenes.bench_street() if args.scene == "street" else scenes.bunny_scene()).bounds()
+        hs_bounds = (scenes.bench_street() if args.scene == "street" else scenes.bunny_scene(BUNNY_OBJ)).bounds()
         cfg = api.NrcRenderer.default_config(W, H, hs_bounds)
         cfg.camera = cam
         cfg.enableAccumulation = 1
