@@ -151,7 +151,7 @@ class GfxhExchangeDesc(C.Structure):
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(GfxhExchangeDesc))
-EXCHANGE_STRIPS, EXCHANGE_ALLREDUCE_SUM_U32, EXCHANGE_GATHER_BANDS = 0, 1, 2
+EXCHANGE_STRIPS, EXCHANGE_ALLREDUCE_SUM_U32, EXCHANGE_GATHER_BANDS, EXCHANGE_GATHER_RECORDS, EXCHANGE_BROADCAST = 0, 1, 2, 3, 4
 STEP_RESTIR_PASS, STEP_PT_PASS, STEP_EXCHANGE_STRIPS, STEP_ALLREDUCE_CELL_ACCESSES, STEP_GATHER_BANDS, STEP_PREV_GBUFFER_RELEASED = range(6)
 BUF_GBUFFERS, BUF_RESERVOIRS, BUF_SAMPLE_VISIBILITY = 1, 2, 4
 
@@ -211,7 +211,7 @@ C_ABI_SYMBOLS = [
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_lights_table_info", "gfx_trace", "gfx_trace_counted", "gfx_restir_set_params", "gfx_restir_copy_to_linear", "gfx_visualize", "gfx_restir_launch",
     "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
-    "gfx_nrc_get_params", "gfx_nrc_set_render_params",
+    "gfx_nrc_get_params", "gfx_nrc_inference_image", "gfx_nrc_set_render_params",
     "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read", "gfx_trace_diag_read",
 ]
 HOST_ABI_SYMBOLS = [
@@ -226,7 +226,7 @@ HOST_ABI_SYMBOLS = [
     "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
-    "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_rebuild_accel", "gfxh_nrc_beauty_buffer",
+    "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_set_exchange", "gfxh_nrc_rebuild_accel", "gfxh_nrc_beauty_buffer",
     "gfxh_nrc_network", "gfxh_nrc_stats", "gfxh_save_image_sdr", "gfxh_save_image_hdr", "gfxh_tonemap_sdr",
 ]
 
@@ -610,6 +610,12 @@ class Context:
     def restir_launch(self, pass_id, width, height, stream=0):
         self._check(self.L.gfx_restir_launch(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height)))
 
+    def nrc_inference_image(self, net, which):
+        """(device pointer, bytes) of the packed inference image gfx_nrc_infer reads: 0 = MLP fragments, 1 = hash grid."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self._check(self.L.gfx_nrc_inference_image(self.h, C.c_uint64(net), C.c_int(which), C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
     def nrc_set_render_params(self, params):
         self._check(self.L.gfx_nrc_set_render_params(self.h, C.byref(params)))
 
@@ -704,7 +710,7 @@ class GfxhNrcConfig(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("positionEncoding", C.c_int), ("numHiddenLayers", C.c_uint32),
                 ("learningRate", C.c_float), ("maxPathLength", C.c_uint32), ("radianceScale", C.c_float), ("train", C.c_uint32),
                 ("enableAccumulation", C.c_uint32), ("camera", GfxCamera), ("sceneAabbMin", C.c_float * 3),
-                ("sceneAabbMax", C.c_float * 3)]
+                ("sceneAabbMax", C.c_float * 3), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32)]
 
 
 class NrcRenderer:
@@ -732,6 +738,22 @@ class NrcRenderer:
         if self.h:
             self.L.gfxh_nrc_destroy(self.h)
             self.h = None
+
+    def set_exchange(self, fn, rank):
+        """Band renderer (cfg.rowBegin / rowEnd): fn(stream, desc: GfxhExchangeDesc) as for RestirRenderer.set_exchange."""
+        def thunk(user, stream, desc):
+            try:
+                fn(stream, desc.contents)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._exchange_cb = EXCHANGE_FN(thunk)
+        self.L.gfxh_nrc_set_exchange(self.h, self._exchange_cb, None, C.c_int(rank))
+
+    def network(self):
+        return self.L.gfxh_nrc_network(self.h)
 
     def rebuild_accel(self, stream=0):
         if self.L.gfxh_nrc_rebuild_accel(self.h, C.c_void_p(stream)):

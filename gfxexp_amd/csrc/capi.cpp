@@ -397,6 +397,13 @@ int gfx_nrc_get_params(gfx_ctx* ctx, uint64_t handle, int which, float* hostOut,
     GFX_CATCH(ctx)
 }
 
+int gfx_nrc_inference_image(gfx_ctx* ctx, uint64_t handle, int which, void** dPtr, uint64_t* bytes) {
+    GFX_TRY(ctx)
+    if (!dPtr || !bytes) throw HipError("gfx_nrc_inference_image: null output");
+    nrc_inference_image(nrc_of(ctx, handle), which, dPtr, bytes);
+    GFX_CATCH(ctx)
+}
+
 int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes) {
     GFX_TRY(ctx)
     GFX_HIP(hipDeviceSynchronize());

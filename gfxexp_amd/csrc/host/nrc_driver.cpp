@@ -46,6 +46,9 @@ struct gfxh_nrc {
     hipStream_t trainStream = nullptr;
     hipEvent_t evData = nullptr, evTrained = nullptr;
     bool trainPending = false, overlapTraining = true;
+    // band renderer (gfxh_nrc_set_exchange)
+    gfxh_exchange_fn exchange = nullptr; void* exchangeUser = nullptr; int rank = 0;
+    uint32_t gatherCounts[2] = { 0, 0 };
 };
 
 static int nrc_alloc(gfxh_nrc* r, void** p, size_t bytes) {
@@ -177,9 +180,13 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     r->np.isNewSequence = newSequence;
     NRC_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, 0, 0));
     NRC_GFX(gfx_nrc_set_render_params(ctx, &r->np));
-    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, 0, 0));
+    const bool band = !(cfg.rowBegin == 0 && cfg.rowEnd == 0);
+    if (band && !r->exchange) { g_nrcError = "gfxh_nrc_render_frame: a band renderer needs gfxh_nrc_set_exchange"; return 1; }
+    if (band && (cfg.rowEnd > H || cfg.rowBegin >= cfg.rowEnd)) { g_nrcError = "gfxh_nrc_render_frame: row band outside the image"; return 1; }
+    const uint32_t rb = band ? cfg.rowBegin : 0, re = band ? cfg.rowEnd : 0;
+    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, rb, re));
     NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_PREPROCESS, W, H, cfg.maxPathLength, 0, 0));
-    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_NRC, W, H, cfg.maxPathLength, 0, 0));
+    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_NRC, W, H, cfg.maxPathLength, rb, re));
     // main:2293-2303: the inference batch size needs the tile size of this frame
     NRC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     NRC_HIP(hipMemcpy(&r->lastNumTrainingData, r->np.numTrainingData[bufferIndex], 4, hipMemcpyDeviceToHost));
@@ -192,30 +199,92 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
         NRC_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), r->evTrained, 0));
         r->trainPending = false;
     }
-    NRC_GFX(gfx_nrc_infer(ctx, stream, r->network, r->np.inferenceRadianceQueryBuffer, numInferenceQueries, r->np.inferredRadianceBuffer));
-    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_ACCUMULATE, W, H, cfg.maxPathLength, 0, 0));
+    auto exchange = [&](gfxh_exchange_desc& d) -> int {
+        d.width = W; d.height = H; d.bandBegin = cfg.rowBegin; d.bandEnd = cfg.rowEnd;
+        if (r->exchange(r->exchangeUser, stream, &d)) { g_nrcError = "gfxh_nrc_render_frame: the exchange callback failed"; return 1; }
+        return 0;
+    };
+    if (!band) {
+        NRC_GFX(gfx_nrc_infer(ctx, stream, r->network, r->np.inferenceRadianceQueryBuffer, numInferenceQueries, r->np.inferredRadianceBuffer));
+    }
+    else {
+        // the band's pixels, then the suffix queries of the training tiles (all of them: the ones whose training pixel lies
+        // in another band are never read).  Rounding a batch up to 128 touches queries this rank does not use.
+        char* q = static_cast<char*>(r->np.inferenceRadianceQueryBuffer); char* y = static_cast<char*>(r->np.inferredRadianceBuffer);
+        const size_t first = static_cast<size_t>(cfg.rowBegin) * W;
+        const uint32_t bandQueries = ((cfg.rowEnd - cfg.rowBegin) * W + 127) / 128 * 128;
+        NRC_GFX(gfx_nrc_infer(ctx, stream, r->network, q + 56 * first, bandQueries, y + 12 * first));
+        const uint32_t tileQueries = (tilesX * tilesY + 127) / 128 * 128;
+        NRC_GFX(gfx_nrc_infer(ctx, stream, r->network, q + 56ull * W * H, tileQueries, y + 12ull * W * H));
+    }
+    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_ACCUMULATE, W, H, cfg.maxPathLength, rb, re));
     if (cfg.train) {
         NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_PROPAGATE, W, H, cfg.maxPathLength, 0, 0));
+        if (band) {   // every rank ends up with every band's records (rank order) and the global count
+            gfxh_exchange_desc d; std::memset(&d, 0, sizeof(d));
+            d.kind = GFXH_EXCHANGE_GATHER_RECORDS;
+            d.numBuffers = 2;
+            d.buffers[0].base = r->np.trainRadianceQueryBuffer[0]; d.buffers[0].bytesPerPixel = 56; d.buffers[0].numPlanes = 1;
+            d.buffers[1].base = r->np.trainTargetBuffer[0]; d.buffers[1].bytesPerPixel = 12; d.buffers[1].numPlanes = 1;
+            r->gatherCounts[0] = std::min(r->lastNumTrainingData, kTrainBufferSize); r->gatherCounts[1] = 0;
+            d.counters = r->gatherCounts; d.numCounters = kTrainBufferSize;
+            if (exchange(d)) return 1;
+            r->lastNumTrainingData = r->gatherCounts[0];
+            NRC_HIP(hipMemcpyAsync(r->np.numTrainingData[bufferIndex], &r->gatherCounts[0], 4, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+        }
         NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_SHUFFLE, W, H, cfg.maxPathLength, 0, 0));
         constexpr uint32_t batchSize = kNumTrainingDataPerFrame / 4;                 // main:2350
         void* ts = stream;
-        if (r->overlapTraining) {
+        const bool overlap = r->overlapTraining && !band;
+        if (overlap) {
             NRC_HIP(hipEventRecord(r->evData, static_cast<hipStream_t>(stream)));
             NRC_HIP(hipStreamWaitEvent(r->trainStream, r->evData, 0));
             ts = r->trainStream;
         }
-        for (uint32_t step = 0; step < 4; ++step) {
-            const char* q = static_cast<const char*>(r->np.trainRadianceQueryBuffer[1]) + 56ull * step * batchSize;
-            const char* t = static_cast<const char*>(r->np.trainTargetBuffer[1]) + 12ull * step * batchSize;
-            NRC_GFX(gfx_nrc_train(ctx, ts, r->network, q, t, batchSize, (lossOut && step == 3) ? lossOut : nullptr));
+        if (!band || r->rank == 0) {
+            for (uint32_t step = 0; step < 4; ++step) {
+                const char* q = static_cast<const char*>(r->np.trainRadianceQueryBuffer[1]) + 56ull * step * batchSize;
+                const char* t = static_cast<const char*>(r->np.trainTargetBuffer[1]) + 12ull * step * batchSize;
+                NRC_GFX(gfx_nrc_train(ctx, ts, r->network, q, t, batchSize, (lossOut && step == 3) ? lossOut : nullptr));
+            }
         }
-        if (r->overlapTraining) {
+        else if (lossOut) *lossOut = 0.0f;
+        if (overlap) {
             NRC_HIP(hipEventRecord(r->evTrained, r->trainStream));
             r->trainPending = true;
         }
+        if (band) {   // rank 0's freshly packed inference images -> everyone
+            gfxh_exchange_desc d; std::memset(&d, 0, sizeof(d));
+            d.kind = GFXH_EXCHANGE_BROADCAST;
+            for (int which = 0; which < 2; ++which) {
+                void* p = nullptr; uint64_t bytes = 0;
+                NRC_GFX(gfx_nrc_inference_image(ctx, r->network, which, &p, &bytes));
+                if (!p || !bytes) continue;
+                gfxh_exchange_buffer& b = d.buffers[d.numBuffers++];
+                b.base = p; b.bytesPerPixel = 1; b.numPlanes = 1; b.planeStride = bytes;
+            }
+            if (exchange(d)) return 1;
+        }
+    }
+    else if (band) {   // the tile size of the next frame adapts to the global record count
+        gfxh_exchange_desc d; std::memset(&d, 0, sizeof(d));
+        d.kind = GFXH_EXCHANGE_ALLREDUCE_SUM_U32; d.counters = r->np.numTrainingData[bufferIndex]; d.numCounters = 1;
+        if (exchange(d)) return 1;
+    }
+    if (band) {
+        gfxh_exchange_desc d; std::memset(&d, 0, sizeof(d));
+        d.kind = GFXH_EXCHANGE_GATHER_BANDS; d.numBuffers = 1;
+        d.buffers[0].base = r->sp.beautyAccumBuffer; d.buffers[0].bytesPerPixel = 16; d.buffers[0].numPlanes = 1;
+        d.buffers[0].planeStride = 16ull * W * H;
+        if (exchange(d)) return 1;
     }
     r->prevCamera = cfg.camera;
     ++r->frameIndex;
+    return 0;
+}
+
+int gfxh_nrc_set_exchange(gfxh_nrc* r, gfxh_exchange_fn fn, void* user, int rank) {
+    r->exchange = fn; r->exchangeUser = user; r->rank = rank;
     return 0;
 }
 

@@ -11,6 +11,7 @@
 // descriptors (gfxexp_amd/tilesplit.py StripExchange); both are driven by the same gfxh_exchange_desc.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,6 +34,7 @@ struct RcclApi {
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     bool load(std::string& err) {
         if (lib) return true;
         lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -48,7 +50,8 @@ struct RcclApi {
         Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
         AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
-        return GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && AllGather;
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
+        return Broadcast && GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && AllGather;
     }
 };
 RcclApi g_rccl;
@@ -148,6 +151,48 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
             if (hipMemcpyAsync(frame + c->bandBegin[r] * rowBytes, static_cast<char*>(c->staging) + slab * r,
                                (c->bandEnd[r] - c->bandBegin[r]) * rowBytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
         }
+        return 0;
+    }
+    if (d->kind == GFXH_EXCHANGE_BROADCAST) {
+        for (uint32_t k = 0; k < d->numBuffers; ++k)
+            if (g_rccl.Broadcast(d->buffers[k].base, d->buffers[k].base, d->buffers[k].planeStride, kNcclUint8, 0, c->comm, stream)) return 1;
+        return 0;
+    }
+    if (d->kind == GFXH_EXCHANGE_GATHER_RECORDS) {
+        // counts of every rank (one all-gather of a u32 + a host round trip: the caller needs the total on the host anyway),
+        // then per array an all-gather of slabs sized for the largest count and a compaction into rank order
+        uint32_t* hostCounts = static_cast<uint32_t*>(d->counters);
+        const size_t need = 256 + 0;
+        if (c->stagingBytes < need) { if (c->staging) (void)hipFree(c->staging); if (hipMalloc(&c->staging, 1 << 20) != hipSuccess) return 1; c->stagingBytes = 1 << 20; }
+        uint32_t* dCounts = static_cast<uint32_t*>(c->staging);
+        if (hipMemcpyAsync(dCounts + c->world + c->rank, &hostCounts[0], 4, hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
+        if (g_rccl.AllGather(dCounts + c->world + c->rank, dCounts, 1, kNcclUint32, c->comm, stream)) return 1;
+        std::vector<uint32_t> counts(c->world);
+        if (hipMemcpyAsync(counts.data(), dCounts, 4 * c->world, hipMemcpyDeviceToHost, stream) != hipSuccess) return 1;
+        if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+        uint32_t most = 0, total = 0, first = 0;
+        for (int r = 0; r < c->world; ++r) { most = std::max(most, counts[r]); if (r < c->rank) first += counts[r]; total += counts[r]; }
+        if (total > d->numCounters) { g_rcclError = "gfxh_rccl_exchange: more records than the arrays hold"; return 1; }
+        for (uint32_t k = 0; k < d->numBuffers && most; ++k) {
+            const size_t rec = d->buffers[k].bytesPerPixel, slab = rec * most;
+            const size_t bytes = 4096 + slab * c->world;
+            if (c->stagingBytes < bytes) {
+                if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+                (void)hipFree(c->staging);
+                if (hipMalloc(&c->staging, bytes) != hipSuccess) { c->staging = nullptr; c->stagingBytes = 0; return 1; }
+                c->stagingBytes = bytes;
+            }
+            char* slabs = static_cast<char*>(c->staging) + 4096;
+            char* base = static_cast<char*>(d->buffers[k].base);
+            if (hipMemcpyAsync(slabs + slab * c->rank, base, rec * counts[c->rank], hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
+            if (g_rccl.AllGather(slabs + slab * c->rank, slabs, slab, kNcclUint8, c->comm, stream)) return 1;
+            size_t at = 0;
+            for (int r = 0; r < c->world; ++r) {
+                if (counts[r] && hipMemcpyAsync(base + at * rec, slabs + slab * r, rec * counts[r], hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
+                at += counts[r];
+            }
+        }
+        hostCounts[0] = total; hostCounts[1] = first;
         return 0;
     }
     g_rcclError = "gfxh_rccl_exchange: unknown exchange kind";

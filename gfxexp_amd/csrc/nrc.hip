@@ -732,6 +732,13 @@ void nrc_set_params(Context& ctx, hipStream_t stream, NrcNet* net, const float* 
     nrc_pack(ctx, stream, *net, false);
     GFX_HIP(hipStreamSynchronize(stream));
 }
+void nrc_inference_image(NrcNet* net, int which, void** dPtr, uint64_t* bytes) {
+    const uint32_t fwdElems = net->d.numHidden * kMatFwdElems + kOutFwdElems;
+    if (which == 0) { *dPtr = net->packInferFwd.p; *bytes = 2ull * fwdElems; }
+    else if (which == 1) { *dPtr = net->d.posEnc == 1 ? net->gridInfer.p : nullptr; *bytes = net->d.posEnc == 1 ? 2ull * net->gridParams : 0; }
+    else throw HipError("gfx_nrc_inference_image: which must be 0 (MLP fragments) or 1 (hash grid)");
+}
+
 void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count) {
     if (count != net->d.total) throw HipError("gfx_nrc_get_params: parameter count mismatch");
     GFX_HIP(hipDeviceSynchronize());

@@ -1016,8 +1016,8 @@ GFX_DEV f3 nrc_scaled_prediction(const PtArgs& a, size_t entry) {
 
 // accumulateInferredRadianceValues, nrc_setup_kernels.cu:51-93
 __global__ __launch_bounds__(kPtBlock) void k_nrc_accumulate(PtArgs a) {
-    const size_t p = static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
-    if (p >= static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY) return;
+    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
+    if (p >= a.pixelEnd) return;
     const float4 t = static_cast<const float4*>(a.nrc.inferenceTerminalInfoBuffer)[p];
     const float* d = static_cast<const float*>(a.nrc.perFrameContributionBuffer) + 3 * p;
     const f3 directCont(d[0], d[1], d[2]);
@@ -1173,7 +1173,13 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
             GFX_HIP(hipGetLastError());
         };
         if (pass == GFX_PT_NRC_PREPROCESS) { simple("nrc_preprocess", k_nrc_preprocess, a.nrc.maxNumTrainingSuffixes); return; }
-        if (pass == GFX_PT_NRC_ACCUMULATE) { simple("nrc_accumulate", k_nrc_accumulate, np); return; }
+        if (pass == GFX_PT_NRC_ACCUMULATE) {   // the one per-pixel NRC pass besides the path tracing: honours the row band
+            if (rowEnd > height || rowBegin > rowEnd) throw HipError("gfx_pt_launch: row range outside the image");
+            a.pixelBegin = static_cast<size_t>(rowBegin) * width;
+            a.pixelEnd = (rowBegin == 0 && rowEnd == 0) ? np : static_cast<size_t>(rowEnd) * width;
+            simple("nrc_accumulate", k_nrc_accumulate, a.pixelEnd - a.pixelBegin);
+            return;
+        }
         if (pass == GFX_PT_NRC_PROPAGATE) { simple("nrc_propagate", k_nrc_propagate, a.nrc.maxNumTrainingSuffixes); return; }
         if (pass == GFX_PT_NRC_SHUFFLE) { simple("nrc_shuffle", k_nrc_shuffle, kNumTrainingDataPerFrame); return; }
         if (pass == GFX_PT_NRC_VISUALIZE_PREDICTION) { simple("nrc_visualize", k_nrc_visualize, np); return; }

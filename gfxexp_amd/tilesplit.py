@@ -204,6 +204,38 @@ class StripExchange:
             work = dist.all_gather_into_tensor(recv, send, async_op=True)
             self._pending = (work, frame, row_bytes, slab)
             return
+        if d.kind == api.EXCHANGE_GATHER_RECORDS:
+            # NRC band renderers: variable-length record arrays of every rank, concatenated in rank order on every rank
+            import ctypes
+            counts_host = (ctypes.c_uint32 * 2).from_address(d.counters)
+            mine = int(counts_host[0])
+            counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(counts, torch.tensor([mine], dtype=torch.int64, device=self.device))
+            counts = [int(c) for c in counts.cpu()]
+            total = sum(counts)
+            if total > d.numCounters:
+                raise ValueError("gathered %d records, capacity %d" % (total, d.numCounters))
+            most, first = max(counts), sum(counts[:self.rank])
+            for k in range(d.numBuffers):
+                rec = d.buffers[k].bytesPerPixel
+                if most == 0:
+                    continue
+                send = torch.zeros(most * rec, dtype=torch.uint8, device=self.device)
+                recv = torch.zeros(most * rec * self.world, dtype=torch.uint8, device=self.device)
+                whole = self.view(d.buffers[k].base, d.numCounters * rec)
+                send[:mine * rec].copy_(whole[:mine * rec])
+                dist.all_gather_into_tensor(recv, send)
+                at = 0
+                for r, c in enumerate(counts):
+                    whole[at * rec:(at + c) * rec].copy_(recv[r * most * rec:r * most * rec + c * rec])
+                    at += c
+                self.bytes_moved += most * rec * self.world
+            counts_host[0], counts_host[1] = total, first
+            return
+        if d.kind == api.EXCHANGE_BROADCAST:
+            for k in range(d.numBuffers):
+                dist.broadcast(self.view(d.buffers[k].base, d.buffers[k].planeStride), src=0)
+            return
         raise ValueError("unknown exchange kind %d" % d.kind)
 
     def finish(self):

@@ -337,7 +337,8 @@ int gfx_visualize(gfx_ctx* ctx, void* stream, const void* dLinearBuffer, int buf
  * and {travHandle, numAccumFrames, camera, prevCamera, envLightPowerCoeff/Rotation, bufferIndex,
  * resetFlowBuffer, enableJittering, enableEnvLight} of the per-frame block; maxPathLength
  * (path_tracing_shared.h:165, 4-bit field, UI range 2..15, default 5 at path_tracing_main.cpp:1519)
- * is passed here.  Rows [rowBegin, rowEnd) as in gfx_restir_launch_rows; rowEnd == 0 -> whole frame. */
+ * is passed here.  Rows [rowBegin, rowEnd) as in gfx_restir_launch_rows; rowEnd == 0 -> whole frame.  Of the NRC passes
+ * GFX_PT_PATH_TRACE_NRC and GFX_PT_NRC_ACCUMULATE are per pixel and honour the rows; the others run over tiles / records. */
 enum gfx_pt_pass {
     GFX_PT_SETUP_GBUFFERS = 0,        /* path_tracing/gpu_kernels/optix_gbuffer_kernels.cu */
     GFX_PT_PATH_TRACE_BASELINE = 1,   /* optix_pathtracing_kernels.cu:298-341 (pathTraceBaseline RG/CH/MS) */
@@ -440,6 +441,10 @@ int gfx_nrc_train(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInpu
 int gfx_nrc_num_params(gfx_ctx* ctx, uint64_t handle, uint32_t* outCount);
 int gfx_nrc_set_params(gfx_ctx* ctx, uint64_t handle, const float* hostParams, uint32_t count);
 int gfx_nrc_get_params(gfx_ctx* ctx, uint64_t handle, int which, float* hostOut, uint32_t count);
+/* The device images gfx_nrc_infer reads: which = 0 the packed bf16 MLP fragments, 1 the packed bf16 hash grid (null / 0 for
+ * the triangle-wave encoding); rewritten by every gfx_nrc_train / gfx_nrc_set_params.  A process that does not train (a band
+ * renderer other than rank 0, gfxh_nrc_set_exchange) receives these bytes from the one that does. */
+int gfx_nrc_inference_image(gfx_ctx* ctx, uint64_t handle, int which, void** dPtr, uint64_t* bytes);
 
 /* Blocking device-to-host copy of library- or caller-owned device memory (TypedBuffer::read,
  * utils/cuda_util.h; used for pick info at restir_di_main.cpp:2010). */

@@ -200,7 +200,14 @@ int gfxh_restir_band_plan(gfxh_restir* r, gfxh_band_plan* out);
  *   every renderer      all-gather of the float4 HDR bands at the end of the frame
  * maxMotionRows bounds |motion vector y| over the run (0 = static camera and scene: a camera or instance that moves
  * then makes gfxh_restir_render_frame fail instead of silently dropping temporal reuse along the seams). */
-enum gfxh_exchange_kind { GFXH_EXCHANGE_STRIPS = 0, GFXH_EXCHANGE_ALLREDUCE_SUM_U32 = 1, GFXH_EXCHANGE_GATHER_BANDS = 2 };
+enum gfxh_exchange_kind {
+    GFXH_EXCHANGE_STRIPS = 0, GFXH_EXCHANGE_ALLREDUCE_SUM_U32 = 1, GFXH_EXCHANGE_GATHER_BANDS = 2,
+    /* NRC band renderers (gfxh_nrc_set_exchange): */
+    GFXH_EXCHANGE_GATHER_RECORDS = 3,   /* buffers[k] = record arrays (bytesPerPixel = bytes per record); `counters` is a HOST uint32_t[2]:
+                                         * in [0] = this rank's record count, out [0] = the total; afterwards every rank holds all
+                                         * records, rank 0's first, then rank 1's, ... (numCounters = capacity in records) */
+    GFXH_EXCHANGE_BROADCAST = 4         /* buffers[k]: planeStride bytes at base, from rank 0 to everyone */
+};
 typedef struct gfxh_exchange_buffer {
     void* base;               /* full-frame device buffer, row-major */
     uint32_t bytesPerPixel;   /* per plane */
@@ -303,12 +310,20 @@ typedef struct gfxh_nrc_config {
     uint32_t enableAccumulation; /* 0 */
     gfx_camera camera;
     float sceneAabbMin[3], sceneAabbMax[3];   /* scene.initialSceneAabb (main:1139) */
+    uint32_t rowBegin, rowEnd;   /* rows [rowBegin, rowEnd) of a band renderer (needs gfxh_nrc_set_exchange); 0, 0 = the whole frame */
 } gfxh_nrc_config;
 void gfxh_nrc_default_config(gfxh_nrc_config* cfg, uint32_t width, uint32_t height);
 int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out);
 void gfxh_nrc_destroy(gfxh_nrc* r);
 /* lossOut (optional): the loss of the fourth training step (main:2363). */
 int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut);
+/* Row-band split of the NRC frame over the GPUs of a node (no reference counterpart; one process per GPU, `rank` of them).
+ * Every rank path-traces, infers and accumulates its own rows; the training records of all bands are gathered in rank order
+ * (GFXH_EXCHANGE_GATHER_RECORDS: 68 B per record, <= 2^17 records), every rank shuffles the same batch, RANK 0 runs the four
+ * training steps and its inference images (gfx_nrc_inference_image: 20 KB + 2 MB) are broadcast (GFXH_EXCHANGE_BROADCAST), so
+ * all ranks infer the next frame with identical weights; the tile size adapts to the global record count; the HDR bands are
+ * gathered like gfxh_restir's.  Training is not overlapped with the next frame in this mode. */
+int gfxh_nrc_set_exchange(gfxh_nrc* r, gfxh_exchange_fn fn, void* user, int rank);
 /* Scene::updateASs of an animated frame: rebuild the renderer's BVH in place after gfx_instance_set_transform. */
 int gfxh_nrc_rebuild_accel(gfxh_nrc* r, void* stream);
 void* gfxh_nrc_beauty_buffer(gfxh_nrc* r);

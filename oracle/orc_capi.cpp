@@ -421,9 +421,11 @@ int orc_pt_launch(orc_scene* s, const gfx_restir_static_params* sp, const gfx_re
             for (int y = y0; y < wy1; ++y) for (int x = x0; x < wx1; ++x) nrcPathTracePixel(p, ns, counter, x, y);
             break;
         }
-        case GFX_PT_NRC_ACCUMULATE:
-            for (size_t i = 0; i < static_cast<size_t>(W) * H; ++i) accumulateInferredRadiancePixel(ns, *sp, *fp, i);
+        case GFX_PT_NRC_ACCUMULATE: {   // per pixel: honours the window like the path tracing (band renderers)
+            const int wx1 = x1 > 0 ? x1 : W, wy1 = y1 > 0 ? y1 : H;
+            for (int y = y0; y < wy1; ++y) for (int x = x0; x < wx1; ++x) accumulateInferredRadiancePixel(ns, *sp, *fp, static_cast<size_t>(y) * W + x);
             break;
+        }
         case GFX_PT_NRC_PROPAGATE:
             for (uint32_t i = 0; i < g_nrcParams.maxNumTrainingSuffixes; ++i) propagateRadianceSuffix(ns, *sp, i);
             break;

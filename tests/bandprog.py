@@ -69,3 +69,75 @@ def small_config(W, H, renderer, band=(0, 0), radius=5.0, passes=2, neighbors=3)
     cfg.enableAccumulation = 0
     cfg.rowBegin, cfg.rowEnd = band
     return cfg
+
+
+class OracleNrcBandRenderer:
+    """gfxh_nrc_render_frame's band sequence (csrc/host/nrc_driver.cpp) with the oracle as the kernels and oracle/nrc_net.py as
+    the network: path tracing / inference / accumulation on the band, records gathered in rank order, rank 0 trains, the
+    inference parameters are broadcast.  band = (0, 0) and exchange = None: the whole-frame loop."""
+
+    def __init__(self, osc, hs, W, H, band=(0, 0), rank=0, exchange=None, max_len=3):
+        from oracle import nrc_net as N
+        self.N = N
+        self.osc, self.W, self.H, self.band, self.rank, self.exchange, self.max_len = osc, W, H, band, rank, exchange, max_len
+        self.pb = util.PixelBuffers(W, H)
+        self.nb = util.NrcBuffers(W, H, hs.bounds())
+        self.net = N.NrcNet(N.POS_TRIANGLEWAVE, 2, 1e-2)
+        self.frame = 0
+        self.counts = np.zeros(2, np.uint32)
+        self.last_loss = None
+
+    def _desc(self, kind):
+        d = api.GfxhExchangeDesc()
+        d.kind, d.width, d.height, d.bandBegin, d.bandEnd = kind, self.W, self.H, self.band[0], self.band[1]
+        return d
+
+    def render_frame(self, cam):
+        W, H, frame, nb, pb = self.W, self.H, self.frame, self.nb, self.pb
+        b = frame % 2
+        banded = self.band != (0, 0)
+        rect = (0, self.band[0], W, self.band[1]) if banded else None
+        s = pb.host_static_params()
+        ocam = util.copy_struct(O.GfxCamera, cam)
+        f = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, W, H, ocam, frameIndex=frame, bufferIndex=b,
+                              resetFlowBuffer=int(frame == 0), numAccumFrames=0)
+        self.osc.nrc_set_render_params(nb.host_params(3 + 7 * frame, 5 + 11 * frame, frame == 0))
+        self.osc.pt_launch(s, f, api.PT_SETUP_GBUFFERS, self.max_len, rect=rect)
+        self.osc.pt_launch(s, f, api.PT_NRC_PREPROCESS, self.max_len)
+        self.osc.pt_launch(s, f, api.PT_PATH_TRACE_NRC, self.max_len, rect=rect)
+        a = nb.a
+        tile = a[f"nrc_tile_{b}"]
+        tiles = ((W + int(tile[0]) - 1) // int(tile[0])) * ((H + int(tile[1]) - 1) // int(tile[1]))
+        n = W * H
+        if banded:
+            rows = slice(self.band[0] * W, self.band[1] * W)
+            a["nrc_inferred"][rows] = self.net.infer(a["nrc_queries"][rows])
+            a["nrc_inferred"][n:n + tiles] = self.net.infer(a["nrc_queries"][n:n + tiles])
+        else:
+            a["nrc_inferred"][:n + tiles] = self.net.infer(a["nrc_queries"][:n + tiles])
+        self.osc.pt_launch(s, f, api.PT_NRC_ACCUMULATE, self.max_len, rect=rect)
+        self.osc.pt_launch(s, f, api.PT_NRC_PROPAGATE, self.max_len)
+        if banded:
+            d = self._desc(api.EXCHANGE_GATHER_RECORDS)
+            d.numBuffers = 2
+            d.buffers[0].base, d.buffers[0].bytesPerPixel, d.buffers[0].numPlanes = a["nrc_trainq_0"].ctypes.data, 56, 1
+            d.buffers[1].base, d.buffers[1].bytesPerPixel, d.buffers[1].numPlanes = a["nrc_traint_0"].ctypes.data, 12, 1
+            self.counts[0], self.counts[1] = a[f"nrc_num_{b}"][0], 0
+            d.counters, d.numCounters = self.counts.ctypes.data, nb.TRAIN
+            self.exchange(0, d)
+            a[f"nrc_num_{b}"][0] = self.counts[0]
+        self.osc.pt_launch(s, f, api.PT_NRC_SHUFFLE, self.max_len)
+        if not banded or self.rank == 0:
+            for step in range(4):
+                sl = slice(step * 16384, (step + 1) * 16384)
+                self.last_loss = self.net.train(a["nrc_trainq_1"][sl], a["nrc_traint_1"][sl])
+        if banded:
+            d = self._desc(api.EXCHANGE_BROADCAST)
+            d.numBuffers = 1
+            d.buffers[0].base, d.buffers[0].bytesPerPixel, d.buffers[0].numPlanes, d.buffers[0].planeStride = self.net.ema.ctypes.data, 1, 1, self.net.ema.nbytes
+            self.exchange(0, d)
+            d = self._desc(api.EXCHANGE_GATHER_BANDS)
+            d.numBuffers = 1
+            d.buffers[0].base, d.buffers[0].bytesPerPixel, d.buffers[0].numPlanes, d.buffers[0].planeStride = pb.beauty.ctypes.data, 16, 1, 16 * n
+            self.exchange(0, d)
+        self.frame += 1

@@ -17,6 +17,7 @@ class LoopbackExchange:
         self.world = world
         self.barrier = threading.Barrier(world, timeout=timeout)
         self.descs = [None] * world
+        self.staged = [None] * world
         self.calls = [[] for _ in range(world)]
 
     def callback(self, rank):
@@ -54,6 +55,28 @@ class LoopbackExchange:
             torch.cuda.synchronize()
             self.barrier.wait()          # everyone has read everyone's counters
             tilesplit.device_bytes(mine.counters, 4 * mine.numCounters).view(torch.int32).copy_(total)
+        elif mine.kind == api.EXCHANGE_GATHER_RECORDS:
+            counts_host = (ctypes.c_uint32 * 2).from_address(mine.counters)
+            n = int(counts_host[0])
+            self.staged[rank] = (n, [tilesplit.device_bytes(mine.buffers[k].base, max(1, n * mine.buffers[k].bytesPerPixel)).clone()
+                                     for k in range(mine.numBuffers)])
+            torch.cuda.synchronize()
+            self.barrier.wait()          # everyone's records are staged and counted
+            counts = [self.staged[r][0] for r in range(self.world)]
+            for k in range(mine.numBuffers):
+                rec = mine.buffers[k].bytesPerPixel
+                whole = tilesplit.device_bytes(mine.buffers[k].base, mine.numCounters * rec)
+                at = 0
+                for r, c in enumerate(counts):
+                    if c:
+                        whole[at * rec:(at + c) * rec].copy_(self.staged[r][1][k][:c * rec])
+                    at += c
+            counts_host[0], counts_host[1] = sum(counts), sum(counts[:rank])
+        elif mine.kind == api.EXCHANGE_BROADCAST:
+            if rank != 0:
+                for k in range(mine.numBuffers):
+                    n = mine.buffers[k].planeStride
+                    tilesplit.device_bytes(mine.buffers[k].base, n).copy_(tilesplit.device_bytes(self.descs[0].buffers[k].base, n))
         elif mine.kind == api.EXCHANGE_GATHER_BANDS:
             for peer, other in enumerate(self.descs):
                 if peer != rank:

@@ -126,3 +126,66 @@ def test_rccl_exchange_single_rank(built_lib):
         assert torch.equal(frame, keep)
     finally:
         L.gfxh_rccl_destroy(comm)
+
+
+@pytest.mark.gpu
+def test_three_band_nrc_renderers(built_lib):
+    """NRC band renderers (gfxh_nrc_set_exchange) on one GPU: frame 0 -- initial weights everywhere -- is bit-identical to the
+    whole-frame renderer and the gathered record count is the whole frame's; after rank 0 trained and broadcast, every rank
+    holds the same inference images bit for bit; frame 1 (weights trained on the same records in another order) agrees with
+    the whole-frame renderer to the training's own noise."""
+    import torch
+    from tests import loopback
+    hs = util.bunny_scene()
+    cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+
+    def make(band):
+        ctx = api.Context(0)
+        hs.upload(ctx)
+        cfg = api.NrcRenderer.default_config(W, H, hs.bounds())
+        cfg.camera = cam
+        cfg.maxPathLength = 4
+        cfg.rowBegin, cfg.rowEnd = band
+        return ctx, api.NrcRenderer(ctx, cfg)
+
+    def beauty(ctx, r):
+        torch.cuda.synchronize()
+        return ctx.read_device(r.beauty_ptr(), W * H * 16).view(np.float32).reshape(H, W, 4).copy()
+
+    full_ctx, full = make((0, 0))
+    full.render_frame()
+    want0, stats0 = beauty(full_ctx, full), full.stats()
+    full.render_frame()
+    want1 = beauty(full_ctx, full)
+    assert np.abs(want0[..., :3]).sum() > 0 and stats0["numTrainingData"] > 100
+
+    bands = tilesplit.band_rows(H, WORLD)
+    made = [make(b) for b in bands]
+    ex = loopback.LoopbackExchange(WORLD)
+    for rank, (_, r) in enumerate(made):
+        r.set_exchange(ex.callback(rank), rank)
+    loopback.run_bands([r for _, r in made], 1)
+    images = []
+    for rank, (ctx, r) in enumerate(made):
+        util.assert_same_bits(f"nrc band {rank} frame 0", beauty(ctx, r), want0)
+        assert r.stats()["numTrainingData"] == stats0["numTrainingData"] and r.stats()["tileSize"] == stats0["tileSize"]
+        imgs = []
+        for which in (0, 1):
+            ptr, n = ctx.nrc_inference_image(r.network(), which)
+            assert ptr and n
+            imgs.append(ctx.read_device(ptr, n).copy())
+        images.append(imgs)
+    initial = api.Context(0)
+    for rank in range(1, WORLD):
+        for which in (0, 1):
+            assert np.array_equal(images[rank][which], images[0][which]), (rank, which)
+    ctx0, fresh = make((0, 0))           # an untrained network: the broadcast images are NOT the initial ones
+    p0, n0 = ctx0.nrc_inference_image(fresh.network(), 1)
+    assert not np.array_equal(ctx0.read_device(p0, n0), images[1][1])
+    loopback.run_bands([r for _, r in made], 1)
+    for rank, (ctx, r) in enumerate(made):
+        got1 = beauty(ctx, r)
+        err = np.abs(got1[..., :3] - want1[..., :3]).mean() / max(1e-6, np.abs(want1[..., :3]).mean())
+        assert err < 0.05, (rank, err)
+        assert np.array_equal(got1, beauty(made[0][0], made[0][1]))      # every rank gathered the same frame
+    del initial

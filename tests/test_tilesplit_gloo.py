@@ -262,3 +262,61 @@ def test_strip_rows_and_too_tall_strips(built_lib):
     cfg.rowBegin, cfg.rowEnd = 136, 272
     with pytest.raises(api.GfxError):
         api.frame_program(cfg, True, 200, False, 1, 0, False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NRC band renderers: records gathered in rank order, rank 0 trains, inference parameters broadcast
+# ---------------------------------------------------------------------------------------------------------------------
+NRC_FRAMES = 2
+
+
+def _nrc_run(band, rank, exchange, threads):
+    from gfxexp_amd import api
+    from tests import bandprog, util
+    hs = util.bunny_scene()
+    osc = util.feed_oracle(hs, threads=threads)
+    r = bandprog.OracleNrcBandRenderer(osc, hs, W, H, band=band, rank=rank, exchange=exchange)
+    cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+    for _ in range(NRC_FRAMES):
+        r.render_frame(cam)
+    b = (NRC_FRAMES - 1) % 2
+    n = int(r.nb.a[f"nrc_num_{b}"][0])
+    return {"beauty": r.pb.beauty, "ema": r.net.ema, "num": np.array([n]), "tile": r.nb.a[f"nrc_tile_{b}"],
+            "trainq": r.nb.a["nrc_trainq_0"][:n], "traint": r.nb.a["nrc_traint_0"][:n],
+            "batchq": r.nb.a["nrc_trainq_1"][:1 << 16], "batcht": r.nb.a["nrc_traint_1"][:1 << 16], "rng": r.pb.rng}
+
+
+def _nrc_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from gfxexp_amd import tilesplit
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    band = tilesplit.band_for_rank(H, world, rank)
+    ex = tilesplit.StripExchange(dist, rank, world, H, tilesplit.host_view)
+    out = _nrc_run(band, rank, ex, threads=2)
+    ex.finish()
+    np.savez(os.path.join(out_dir, f"nrc_{rank}.npz"), band=np.array(band), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_nrc_band_split_is_bit_exact(built_lib):
+    """The CPU oracle allocates training records in pixel order, so the bands' records concatenated in rank order ARE the
+    single-process records: the gathered batch, the trained parameters and both frames are bit-identical."""
+    import torch.multiprocessing as mp
+    from tests import util
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    with tempfile.TemporaryDirectory() as out_dir:
+        mp.spawn(_nrc_worker, args=(2, port, out_dir), nprocs=2, join=True)
+        got = [dict(np.load(os.path.join(out_dir, f"nrc_{r}.npz"))) for r in range(2)]
+    want = _nrc_run((0, 0), 0, None, threads=4)
+    assert want["num"][0] > 100 and np.abs(want["beauty"][:, :3]).sum() > 0
+    assert not np.array_equal(want["ema"], __import__("oracle.nrc_net", fromlist=["x"]).NrcNet(0, 2, 1e-2).ema)   # it trained
+    for rank in range(2):
+        g = got[rank]
+        b, e = g["band"]
+        for k in ("num", "tile", "trainq", "traint", "batchq", "batcht", "ema"):
+            util.assert_same_bits(f"nrc rank {rank} {k}", g[k], want[k])
+        util.assert_same_bits(f"nrc rank {rank} gathered HDR frame", g["beauty"], want["beauty"])
+        util.assert_same_bits(f"nrc rank {rank} pixel RNGs", g["rng"].reshape(H, W)[b:e], want["rng"].reshape(H, W)[b:e])
