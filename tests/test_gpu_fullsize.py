@@ -280,3 +280,43 @@ def test_nrc_window_of_the_full_frame_matches_the_oracle(built_lib):
             diffs.append(f"frame {frame}: rendering-path queries differ inside the window")
         assert int(got[f"nrc_num_{b}"][0]) > 10000   # the full frame produced training records
     assert not diffs, "\n".join(diffs)
+
+
+def test_eight_band_strip_exchange_at_the_bench_configuration(built_lib):
+    """bench.py --gpus 8 on one GPU: eight band renderers (7 x 136 + 128 rows of the 1920x1080 frame, radius-20 strips, the
+    textured bench scene) driven by eight host threads through the loop-back transport reproduce the whole-frame renderer
+    bit for bit over three frames -- the same descriptors tilesplit.StripExchange sends over RCCL."""
+    import torch
+    from gfxexp_amd import scenes, tilesplit
+    from tests import loopback
+    hs = scenes.bench_street(textured=True)
+    world, frames = 8, 3
+
+    def make(band):
+        ctx = api.Context(0)
+        hs.upload(ctx)
+        cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
+        cfg.camera = api.make_camera(W, H, **CAM)
+        cfg.enableBumpMapping = 1
+        cfg.rowBegin, cfg.rowEnd = band
+        return ctx, api.RestirRenderer(ctx, cfg)
+
+    ctx_full, full = make((0, 0))
+    for _ in range(frames):
+        full.render_frame()
+    torch.cuda.synchronize()
+    want = ctx_full.read_device(full.beauty_ptr(), W * H * 16).view(np.float32).reshape(H, W, 4).copy()
+    del full, ctx_full
+    bands = tilesplit.band_rows(H, world)
+    assert bands[0] == (0, 136) and bands[-1] == (952, 1080)
+    made = [make(b) for b in bands]
+    ex = loopback.LoopbackExchange(world, timeout=300.0)
+    for rank, (_, r) in enumerate(made):
+        r.set_exchange(ex.callback(rank), 0)
+    loopback.run_bands([r for _, r in made], frames)
+    for rank, (ctx, r) in enumerate(made):
+        got = ctx.read_device(r.beauty_ptr(), W * H * 16).view(np.float32).reshape(H, W, 4)
+        util.assert_same_bits(f"band {rank} gathered HDR frame", got, want)
+    assert np.isfinite(want).all() and want[..., :3].mean() > 1e-3
+    kinds = [k for k, _ in ex.calls[0]]
+    assert kinds.count(api.EXCHANGE_STRIPS) == frames * 3 and kinds.count(api.EXCHANGE_GATHER_BANDS) == frames
