@@ -155,34 +155,15 @@ GFX_DEV void grid_corners(const NrcLevel& lv, float px, float py, float pz, uint
     }
 }
 
-// The 8 table entries of one level.  The two x-neighbours of a corner pair differ in the low bits of the index for three
-// quarters of the queries (dense levels: idx + 1; hashed levels: (x ^ H) and ((x + 1) ^ H) differ by 2^(k+1) - 1 with k
-// the trailing ones of x), so one 16-byte load of the aligned block of 4 entries around the first corner usually holds
-// both; the other quarter takes a second, predicated 4-byte load.  A gather instruction costs the texture addresser one
-// cycle per (lane, cache line) whatever its width, so this is 5 line requests per level instead of 8 (profiles/r02_nrc.txt).
-// Level offsets and sizes are multiples of 8 entries (nrc_levels), so the blocks never straddle levels.
-GFX_DEV uint32_t pick4(const uint4 a, uint32_t k) { return (k & 2u) ? ((k & 1u) ? a.w : a.z) : ((k & 1u) ? a.y : a.x); }
-#ifndef GFX_NRC_BLOCK_GATHER
-#define GFX_NRC_BLOCK_GATHER 0      // 1: one 16-byte block load per x-pair of corners (measured slower, profiles/r02_nrc.txt)
-#endif
+// The 8 table entries of one level: eight 4-byte gathers.  (Fetching the x-neighbour pair of a corner with one 16-byte block
+// load was measured slower -- the pair already shares its 64-byte sector in ~90 % of the cases and the gathers are bound by
+// L2 -> L1 sector fills, profiles/r02_nrc.txt.)
 #ifndef GFX_NRC_INFER_WAVES
-#define GFX_NRC_INFER_WAVES 2       // waves per SIMD k_nrc_infer is compiled for: 3 and 4 measured slower (the gathers are bound by L2->L1 fills, profiles/r02_nrc.txt)
+#define GFX_NRC_INFER_WAVES 2       // waves per SIMD k_nrc_infer is compiled for: 3 and 4 measured slower (same file)
 #endif
 GFX_DEV void gather_corners(const uint32_t* __restrict__ grid, const uint32_t idx[8], uint32_t e[8]) {
-#if !GFX_NRC_BLOCK_GATHER
 #pragma unroll
     for (int c = 0; c < 8; ++c) e[c] = grid[idx[c]];
-    return;
-#endif
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t i0 = idx[2 * j], i1 = idx[2 * j + 1];
-        const uint4 blk = *reinterpret_cast<const uint4*>(grid + (i0 & ~3u));
-        e[2 * j] = pick4(blk, i0 & 3u);
-        uint32_t e1 = pick4(blk, i1 & 3u);
-        if ((i0 ^ i1) & ~3u) e1 = grid[i1];
-        e[2 * j + 1] = e1;
-    }
 }
 
 // The 32 canonical features a lane (half h) supplies for one batch column, in K-slot order

@@ -121,9 +121,25 @@ def test_rccl_exchange_single_rank(built_lib):
         assert L.gfxh_rccl_exchange(comm, stream, C.byref(d)) == 0, L.gfxh_rccl_last_error()
         d.kind = api.EXCHANGE_STRIPS
         assert L.gfxh_rccl_exchange(comm, stream, C.byref(d)) == 0, L.gfxh_rccl_last_error()
+        # the NRC kinds: record gather (one rank: the records stay, the host count is the total) and broadcast from rank 0
+        records = torch.rand(1000 * 14, device="cuda")
+        keep_records = records.clone()
+        host_counts = (C.c_uint32 * 2)(600, 0)
+        d = api.GfxhExchangeDesc()
+        d.kind, d.width, d.height, d.numBuffers = api.EXCHANGE_GATHER_RECORDS, W, H, 1
+        d.buffers[0].base, d.buffers[0].bytesPerPixel, d.buffers[0].numPlanes = records.data_ptr(), 56, 1
+        d.counters, d.numCounters = C.addressof(host_counts), 1000
+        assert L.gfxh_rccl_exchange(comm, stream, C.byref(d)) == 0, L.gfxh_rccl_last_error()
+        assert list(host_counts) == [600, 0]
+        host_counts[0] = 2000                                   # more records than the arrays hold: refused
+        assert L.gfxh_rccl_exchange(comm, stream, C.byref(d)) == 1
+        d = api.GfxhExchangeDesc()
+        d.kind, d.numBuffers = api.EXCHANGE_BROADCAST, 1
+        d.buffers[0].base, d.buffers[0].bytesPerPixel, d.buffers[0].numPlanes, d.buffers[0].planeStride = records.data_ptr(), 1, 1, records.numel() * 4
+        assert L.gfxh_rccl_exchange(comm, stream, C.byref(d)) == 0, L.gfxh_rccl_last_error()
         torch.cuda.synchronize()
         assert torch.equal(counters.cpu(), torch.arange(64, dtype=torch.int32))
-        assert torch.equal(frame, keep)
+        assert torch.equal(frame, keep) and torch.equal(records, keep_records)
     finally:
         L.gfxh_rccl_destroy(comm)
 
