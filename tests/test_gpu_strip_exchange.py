@@ -205,3 +205,36 @@ def test_three_band_nrc_renderers(built_lib):
         assert err < 0.05, (rank, err)
         assert np.array_equal(got1, beauty(made[0][0], made[0][1]))      # every rank gathered the same frame
     del initial
+
+
+@pytest.mark.gpu
+def test_strip_exchange_over_torch_nccl_single_rank(built_lib):
+    """The code path bench.py --gpus N installs -- tilesplit.StripExchange over torch.distributed's nccl (= RCCL) backend with
+    device-memory views -- on a process group of one rank whose band is the whole frame: the strip exchanges have nothing to
+    send, the asynchronous band gather and the ReGIR counter all-reduce run through RCCL, and the frames equal the
+    whole-frame renderer's."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        hs = util.bunny_scene()
+        for renderer in (api.RENDERER_BIASED, api.RENDERER_PATH_TRACE_REGIR):
+            ctx_full, full = _make(hs, renderer, (0, 0))
+            ctx_band, band = _make(hs, renderer, (0, H))
+            ex = tilesplit.StripExchange(dist, 0, 1, H, tilesplit.device_bytes, device="cuda")
+            band.set_exchange(ex, 0)
+            stream = torch.cuda.current_stream().cuda_stream
+            for _ in range(FRAMES):
+                full.render_frame(stream)
+                band.render_frame(stream)
+            ex.finish()
+            want, got = _read(ctx_full, full), _read(ctx_band, band)
+            util.assert_same_bits("band = whole frame over RCCL", got["beauty"], want["beauty"])
+            util.assert_same_bits("band = whole frame over RCCL, reservoirs", got["res"], want["res"])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
