@@ -187,7 +187,7 @@ def roofline(ctx, renderer, stream, steps, W, H):
     Durations: HIP events on the launch stream around every kernel (gfx_timing_*), live in this run, passes
     serialised on one stream.  Algorithmic bytes of the traversal kernels: node fetches x (64 + 16) B + triangle
     fetches x 64 B + rays x (32 B in + result out), counted by the counting instantiation of the same kernel.
-    k_initial_candidates gets its own entry: 32 candidates x (16-B interval entry + 96-B emitter record + 48-B
+    k_initial_candidates gets its own entry: 32 candidates x (16-B interval entry + 64-B emitter record + 48-B
     normal matrix) + 64 B of pixel state in and 72 B out per pixel."""
     import torch
     ctx.timing_enable(True)
@@ -239,7 +239,7 @@ def roofline(ctx, renderer, stream, steps, W, H):
                           "stack_spills": int(c["spills"])}}
     init_ms = timings.get("initial_candidates", (0.0, 0))[0] / n
     if init_ms > 0:
-        cand_bytes = W * H * (32 * (16 + 96 + 48) + 64 + 72)
+        cand_bytes = W * H * (32 * (16 + 64 + 48) + 64 + 72)
         roof["initial_candidates"] = {"bound": "hbm", "kernel": "k_initial_candidates (32 streaming-RIS candidates per pixel)",
                                       "ms": round(init_ms, 4), "algorithmic_bytes_per_launch": cand_bytes,
                                       "achieved": round(cand_bytes / (init_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

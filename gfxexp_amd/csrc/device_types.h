@@ -60,15 +60,22 @@ static_assert(sizeof(LightGeomRef) == 16, "LightGeomRef must be 16 bytes");
 // world positions are inst.transform * v.position computed ONCE with the same fp32 operations
 // sampleLight performs per candidate (restir_di_shared.h:412-414); normals stay in object space
 // (the normal matrix is applied to the interpolated normal, :501-502).
-struct EmitterRec {
+struct EmitterRec {          // 64 B: four aligned 16-byte gathers per light candidate
     float pA[3], pB[3], pC[3];
-    float nA[3], nB[3], nC[3];
+    float nA[3];             // object-space vertex normal; flat emitters (the three normals bit-equal) need no other
     float emittance[3];
-    uint32_t texEmittance; // emittance-texture slot of the material, or 0: only then is the record's EmitterTexRef read
+    uint32_t flags;          // bits 0-23: emittance-texture slot of the material, or 0 (only then is the record's EmitterTexRef
+                             // read); bit 31: nB / nC differ from nA -> EmitterRecExtra holds them
+};
+static_assert(sizeof(EmitterRec) == 64, "EmitterRec must be 64 bytes");
+constexpr uint32_t kEmitterSmooth = 0x80000000u, kEmitterTexMask = 0x00FFFFFFu;
+// Parallel to the records: what only smooth emitters, the three-search fallback and the solid-angle sampler read.
+struct EmitterRecExtra {
+    float nB[3], nC[3];
     float twoOverLenNg;   // 2 / |cross(pB - pA, pC - pA)|: the per-triangle factor of the area density
     float primProb;       // weight / integral inside the owning geometry instance's distribution
 };
-static_assert(sizeof(EmitterRec) == 96, "EmitterRec must be 96 bytes");
+static_assert(sizeof(EmitterRecExtra) == 32, "EmitterRecExtra must be 32 bytes");
 
 // One entry per (instance, geomInst) pair in (instSlot asc, list order) enumeration: the
 // "geometry" list the BVH is built over (bvh::Geometry + preTransform, common/bvh_builder.h:26-36).
@@ -119,6 +126,7 @@ struct DevScene {
     const float* lightCDF;
     const LightGeomRef* lightGeomRefs;   // indexed like the light pools (inst.distOffset + i)
     const EmitterRec* emitterRecs;
+    const EmitterRecExtra* emitterRecExtras;   // parallel to emitterRecs
     const float* lightInstIntegral; // device float[4]: [0] integral of the level-0 distribution,
                                     // [1] guide-table scale (cells / integral), [2] guide valid (uint32)
     const uint16_t* lightInstGuide; // guide table of the level-0 distribution (see lights.hip)

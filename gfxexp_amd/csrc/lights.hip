@@ -88,7 +88,7 @@ __global__ void k_inst_geom_dists(DevInstance* __restrict__ insts, uint32_t numI
 // Per (instance, geomInst): copy the emitter distribution's integral next to its offsets and
 // pre-transform the emitter triangles (EmitterRec, device_types.h).  One block per instance.
 __global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* __restrict__ refs, EmitterRec* __restrict__ recs,
-                                  EmitterTexRef* __restrict__ texRefs /* null: no emittance textures in the scene */) {
+                                  EmitterRecExtra* __restrict__ extras, EmitterTexRef* __restrict__ texRefs /* null: no emittance textures in the scene */) {
     const uint32_t ii = blockIdx.x;
     if (ii >= numInsts) return;
     const DevInstance* inst = sc.insts + ii;
@@ -114,17 +114,24 @@ __global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* 
             r.pB[0] = pB.x; r.pB[1] = pB.y; r.pB[2] = pB.z;
             r.pC[0] = pC.x; r.pC[1] = pC.y; r.pC[2] = pC.z;
             r.nA[0] = vA.nx; r.nA[1] = vA.ny; r.nA[2] = vA.nz;
-            r.nB[0] = vB.nx; r.nB[1] = vB.ny; r.nB[2] = vB.nz;
-            r.nC[0] = vC.nx; r.nC[1] = vC.ny; r.nC[2] = vC.nz;
+            EmitterRecExtra x;
+            x.nB[0] = vB.nx; x.nB[1] = vB.ny; x.nB[2] = vB.nz;
+            x.nC[0] = vC.nx; x.nC[1] = vC.ny; x.nC[2] = vC.nz;
+            // flat = the three normals have the same bits: interpolating three copies of nA then gives the same result
+            const bool smooth = f2bits(vB.nx) != f2bits(vA.nx) || f2bits(vB.ny) != f2bits(vA.ny) || f2bits(vB.nz) != f2bits(vA.nz) ||
+                                f2bits(vC.nx) != f2bits(vA.nx) || f2bits(vC.ny) != f2bits(vA.ny) || f2bits(vC.nz) != f2bits(vA.nz);
             // emittance = RGB(1) * texel for an emitter material (restir_di_shared.h:504-514)
             const f3 e = mat.hasEmittance ? f3(1.0f) * f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]) : f3(0.0f);
             r.emittance[0] = e.x; r.emittance[1] = e.y; r.emittance[2] = e.z;
-            r.texEmittance = (texRefs && mat.hasEmittance) ? mat.texEmittance : 0u;
-            r.twoOverLenNg = 2.0f / len(cross(pB - pA, pC - pA));
-            r.primProb = sc.lightWeights[g.distOffset + t] / g.distIntegral;
+            r.flags = ((texRefs && mat.hasEmittance) ? (mat.texEmittance & kEmitterTexMask) : 0u) | (smooth ? kEmitterSmooth : 0u);
+            x.twoOverLenNg = 2.0f / len(cross(pB - pA, pC - pA));
+            x.primProb = sc.lightWeights[g.distOffset + t] / g.distIntegral;
             float4* dst = reinterpret_cast<float4*>(recs + recBase + t);
             const float4* src = reinterpret_cast<const float4*>(&r);
-            for (int q = 0; q < 6; ++q) dst[q] = src[q];
+            for (int q = 0; q < 4; ++q) dst[q] = src[q];
+            float4* dstX = reinterpret_cast<float4*>(extras + recBase + t);
+            const float4* srcX = reinterpret_cast<const float4*>(&x);
+            dstX[0] = srcX[0]; dstX[1] = srcX[1];
             if (texRefs) {
                 EmitterTexRef tr;
                 tr.uvA[0] = vA.u; tr.uvA[1] = vA.v; tr.uvB[0] = vB.u; tr.uvB[1] = vB.v; tr.uvC[0] = vC.u; tr.uvC[1] = vC.v;
@@ -275,7 +282,7 @@ __global__ void k_span_records(DevScene sc, uint32_t numInsts, const uint32_t* _
             if (t + 1 < ref.distCount) monotone = monotone && key.cdf3AtT <= sc.lightCDF[ref.distOffset + t + 1];
             uint32_t b, e;
             span_record_interval(key, rangeLo, rangeHi, earlyOut, t + 1 == ref.distCount, b, e);
-            const EmitterRec* rec = sc.emitterRecs + ref.recBase + t;
+            const EmitterRecExtra* rec = sc.emitterRecExtras + ref.recBase + t;
             EmitterSpan s;
             s.begin = span_float(b);
             s.end = span_float(e);
@@ -357,7 +364,7 @@ void lights_build_static(Context& ctx, hipStream_t stream) {
                            ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>(), ctx.dLightP.as<float>());
     if (ni)
         hipLaunchKernelGGL(k_emitter_records, dim3(ni), dim3(64), 0, stream, ctx.devScene(), ni,
-                           ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(),
+                           ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(), ctx.dEmitterRecExtras.as<EmitterRecExtra>(),
                                ctx.anyEmittanceTexture ? ctx.dEmitterTexRefs.as<EmitterTexRef>() : nullptr);
     GFX_HIP(hipGetLastError());
     // keep the host mirrors of the integrals current (read by gfx_lights_read and the launch params)
@@ -375,7 +382,7 @@ void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t /*bufferI
         const uint32_t numInsts = static_cast<uint32_t>(ctx.insts.size());
         if (numInsts)
             hipLaunchKernelGGL(k_emitter_records, dim3(numInsts), dim3(64), 0, stream, ctx.devScene(), numInsts,
-                               ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(),
+                               ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(), ctx.dEmitterRecExtras.as<EmitterRecExtra>(),
                                ctx.anyEmittanceTexture ? ctx.dEmitterTexRefs.as<EmitterTexRef>() : nullptr);
         GFX_HIP(hipGetLastError());
         ctx.emitterRecsDirty = false;

@@ -625,18 +625,28 @@ GFX_DEV LightPick light_select_search(const DevScene& sc, float ul) {
 template <bool EMITTER_TEX = true, bool SOLID_ANGLE = false>
 GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, float u1, LightSample& ls, float& areaPDensity, f3 shadingPoint = f3(0.0f),
                          PendingEmittance* pending = nullptr) {
-    // EmitterRec: world-space triangle, 2 / |ng| and the primitive's probability tabulated at build time
+    // EmitterRec: world-space triangle + first vertex normal + emittance in 64 bytes; the other two normals (smooth emitters
+    // only), 2 / |ng| and the primitive's probability (three-search fallback, solid-angle sampling) in EmitterRecExtra
     const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + pk.rec);
-    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
+    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
     const m33 normalMatrix = load_m33_rows(sc.insts[pk.instSlot].normalMatrix);
     const f3 pA(r0.x, r0.y, r0.z), pB(r0.w, r1.x, r1.y), pC(r1.z, r1.w, r2.x);
-    const f3 nA(r2.y, r2.z, r2.w), nB(r3.x, r3.y, r3.z), nC(r3.w, r4.x, r4.y);
+    const f3 nA(r2.y, r2.z, r2.w);
+    const uint32_t flags = f2bits(r3.w);
+    f3 nB = nA, nC = nA;
+    float twoOverLenNg = 0.0f, primProb = 0.0f;
+    if ((flags & kEmitterSmooth) || SOLID_ANGLE || !pk.table) {
+        const float4* xp = reinterpret_cast<const float4*>(sc.emitterRecExtras + pk.rec);
+        const float4 x0 = xp[0], x1 = xp[1];
+        if (flags & kEmitterSmooth) { nB = f3(x0.x, x0.y, x0.z); nC = f3(x0.w, x1.x, x1.y); }
+        twoOverLenNg = x1.z; primProb = x1.w;
+    }
 
     float bcA, bcB, bcC;
     if (SOLID_ANGLE) {
         // the interval table tabulates lightProb * (2 / |ng|), not lightProb: solid-angle sampling always selects with the
         // reference's three searches (light_select_search), whose partial product times the primitive's probability it is
-        const float lightProb = pk.partialProb * r5.w;
+        const float lightProb = pk.partialProb * primProb;
         const SphericalTriangle st = spherical_triangle(pA, pB, pC, shadingPoint);
         const float sphAreaHat = st.sphArea * u0;
         float s, t;
@@ -668,15 +678,15 @@ GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, floa
         if (off > 0) bcB += off;
         else bcA -= off;
         bcC = 1 - (bcA + bcB);
-        areaPDensity = pk.table ? pk.density : (pk.partialProb * r5.w) * r5.z;
+        areaPDensity = pk.table ? pk.density : (pk.partialProb * primProb) * twoOverLenNg;
     }
 
     ls.position = bcA * pA + bcB * pB + bcC * pC;
     ls.atInfinity = 0;
     const f3 n = bcA * nA + bcB * nB + bcC * nC;
     ls.normal = unit(mul(normalMatrix, n));
-    ls.emittance = f3(r4.z, r4.w, r5.x);
-    const uint32_t tex = EMITTER_TEX ? f2bits(r5.y) : 0u;   // EmitterRec::texEmittance (restir_di_shared.h:504-514)
+    ls.emittance = f3(r3.x, r3.y, r3.z);
+    const uint32_t tex = EMITTER_TEX ? (flags & kEmitterTexMask) : 0u;   // emittance-texture slot (restir_di_shared.h:504-514)
     if (tex) {
         const float4* tp = reinterpret_cast<const float4*>(sc.emitterTexRefs + pk.rec);
         const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
