@@ -97,7 +97,7 @@ struct Context {
     std::vector<HostInstance> insts;
     bool sceneDirty = true;
     // scene (device)
-    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightP, dLightCDF, dLightRefs, dEmitterRecs, dEmitterRecExtras, dTextures, dTexelPool, dSrgbLut, dEmitterTexRefs;
+    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightP, dLightCDF, dLightRefs, dEmitterRecs, dEmitterRecExtras, dLightNormalMatrices, dTextures, dTexelPool, dSrgbLut, dEmitterTexRefs;
     bool anyEmittanceTexture = false;
     std::vector<LightGeomRef> hLightRefs;
     uint32_t numEmitterRecs = 0;

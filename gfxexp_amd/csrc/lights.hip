@@ -88,11 +88,13 @@ __global__ void k_inst_geom_dists(DevInstance* __restrict__ insts, uint32_t numI
 // Per (instance, geomInst): copy the emitter distribution's integral next to its offsets and
 // pre-transform the emitter triangles (EmitterRec, device_types.h).  One block per instance.
 __global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* __restrict__ refs, EmitterRec* __restrict__ recs,
-                                  EmitterRecExtra* __restrict__ extras, EmitterTexRef* __restrict__ texRefs /* null: no emittance textures in the scene */) {
+                                  EmitterRecExtra* __restrict__ extras, float4* __restrict__ normalMatrices,
+                                  EmitterTexRef* __restrict__ texRefs /* null: no emittance textures in the scene */) {
     const uint32_t ii = blockIdx.x;
     if (ii >= numInsts) return;
     const DevInstance* inst = sc.insts + ii;
     if (inst->distOffset == 0xFFFFFFFFu) return;
+    if (threadIdx.x < 3) normalMatrices[3 * ii + threadIdx.x] = reinterpret_cast<const float4*>(inst->normalMatrix)[threadIdx.x];
     const m34 xfm = load_m34(inst->transform);
     for (uint32_t k = 0; k < inst->numGeomInsts; ++k) {
         const DevGeomInst g = sc.geomInsts[sc.geomInstSlotPool[inst->slotsOffset + k]];
@@ -364,7 +366,7 @@ void lights_build_static(Context& ctx, hipStream_t stream) {
                            ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>(), ctx.dLightP.as<float>());
     if (ni)
         hipLaunchKernelGGL(k_emitter_records, dim3(ni), dim3(64), 0, stream, ctx.devScene(), ni,
-                           ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(), ctx.dEmitterRecExtras.as<EmitterRecExtra>(),
+                           ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(), ctx.dEmitterRecExtras.as<EmitterRecExtra>(), ctx.dLightNormalMatrices.as<float4>(),
                                ctx.anyEmittanceTexture ? ctx.dEmitterTexRefs.as<EmitterTexRef>() : nullptr);
     GFX_HIP(hipGetLastError());
     // keep the host mirrors of the integrals current (read by gfx_lights_read and the launch params)
@@ -382,7 +384,7 @@ void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t /*bufferI
         const uint32_t numInsts = static_cast<uint32_t>(ctx.insts.size());
         if (numInsts)
             hipLaunchKernelGGL(k_emitter_records, dim3(numInsts), dim3(64), 0, stream, ctx.devScene(), numInsts,
-                               ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(), ctx.dEmitterRecExtras.as<EmitterRecExtra>(),
+                               ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(), ctx.dEmitterRecExtras.as<EmitterRecExtra>(), ctx.dLightNormalMatrices.as<float4>(),
                                ctx.anyEmittanceTexture ? ctx.dEmitterTexRefs.as<EmitterTexRef>() : nullptr);
         GFX_HIP(hipGetLastError());
         ctx.emitterRecsDirty = false;

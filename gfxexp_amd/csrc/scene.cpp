@@ -9,7 +9,7 @@ namespace gfx {
 
 Context::~Context() {
     for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->triIds.release(); a->rootBoxes.release(); delete a; } }
-    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dSubset[0], &dSubset[1], &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs, &dEmitterRecExtras, &dTextures, &dTexelPool, &dSrgbLut, &dEmitterTexRefs,
+    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dSubset[0], &dSubset[1], &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs, &dEmitterRecExtras, &dLightNormalMatrices, &dTextures, &dTexelPool, &dSrgbLut, &dEmitterTexRefs,
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
                       &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide, &dSpans, &dSpanGuide, &dSpanHeader, &dSpanInstBegin,
@@ -34,6 +34,7 @@ DevScene Context::devScene() const {
     s.lightGeomRefs = dLightRefs.as<LightGeomRef>();
     s.emitterRecs = dEmitterRecs.as<EmitterRec>();
     s.emitterRecExtras = dEmitterRecExtras.as<EmitterRecExtra>();
+    s.lightNormalMatrices = dLightNormalMatrices.as<float>();
     s.lightInstIntegral = dLightInstIntegral.as<float>();
     s.lightInstGuide = dLightInstGuide.as<uint16_t>();
     s.lightInstGuideCells = lightInstGuideCells;
@@ -271,6 +272,7 @@ void scene_upload(Context& ctx, hipStream_t stream) {
     upload(ctx.dLightRefs, ctx.hLightRefs, stream);
     ctx.dEmitterRecs.reserve(std::max<size_t>(sizeof(EmitterRec) * ctx.numEmitterRecs, 16));
     ctx.dEmitterRecExtras.reserve(std::max<size_t>(sizeof(EmitterRecExtra) * ctx.numEmitterRecs, 16));
+    ctx.dLightNormalMatrices.reserve(std::max<size_t>(48 * ctx.insts.size(), 16));
     ctx.dEmitterTexRefs.reserve(std::max<size_t>(ctx.anyEmittanceTexture ? sizeof(EmitterTexRef) * ctx.numEmitterRecs : 0, 16));
     ctx.dLightW.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
     ctx.dLightCDF.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));

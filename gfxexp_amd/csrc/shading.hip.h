@@ -629,7 +629,7 @@ GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, floa
     // only), 2 / |ng| and the primitive's probability (three-search fallback, solid-angle sampling) in EmitterRecExtra
     const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + pk.rec);
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-    const m33 normalMatrix = load_m33_rows(sc.insts[pk.instSlot].normalMatrix);
+    const m33 normalMatrix = load_m33_rows(sc.lightNormalMatrices + 12u * pk.instSlot);
     const f3 pA(r0.x, r0.y, r0.z), pB(r0.w, r1.x, r1.y), pC(r1.z, r1.w, r2.x);
     const f3 nA(r2.y, r2.z, r2.w);
     const uint32_t flags = f2bits(r3.w);
