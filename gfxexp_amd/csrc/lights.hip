@@ -137,8 +137,9 @@ __global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* 
             if (texRefs) {
                 EmitterTexRef tr;
                 tr.uvA[0] = vA.u; tr.uvA[1] = vA.v; tr.uvB[0] = vB.u; tr.uvB[1] = vB.v; tr.uvC[0] = vC.u; tr.uvC[1] = vC.v;
-                tr.tex = mat.hasEmittance ? mat.texEmittance : 0u; tr.pad = 0u;
-                tr.desc = sc.textures[tr.tex];   // slot 0 is a zeroed entry
+                const DevTexture desc = sc.textures[mat.hasEmittance ? mat.texEmittance : 0u];   // slot 0 is a zeroed entry
+                tr.texelOffset = desc.offset;
+                tr.dims = desc.width ? (((desc.width - 1u) & 0x3FFFu) | (((desc.height - 1u) & 0x3FFFu) << 14) | (desc.format << 28)) : 0u;
                 texRefs[recBase + t] = tr;
             }
         }

@@ -689,12 +689,13 @@ GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, floa
     const uint32_t tex = EMITTER_TEX ? (flags & kEmitterTexMask) : 0u;   // emittance-texture slot (restir_di_shared.h:504-514)
     if (tex) {
         const float4* tp = reinterpret_cast<const float4*>(sc.emitterTexRefs + pk.rec);
-        const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+        const float4 t0 = tp[0], t1 = tp[1];
         {
             const float tu = bcA * t0.x + bcB * t0.z + bcC * t1.x;
             const float tv = bcA * t0.y + bcB * t0.w + bcC * t1.y;
+            const uint32_t dims = f2bits(t1.w);
             DevTexture desc;
-            desc.offset = f2bits(t2.x); desc.width = f2bits(t2.y); desc.height = f2bits(t2.z); desc.format = f2bits(t2.w);
+            desc.offset = f2bits(t1.z); desc.width = (dims & 0x3FFFu) + 1u; desc.height = ((dims >> 14) & 0x3FFFu) + 1u; desc.format = dims >> 28;
             if (pending) { pending->tex = tex; pending->desc = desc; pending->tu = tu; pending->tv = tv; }
             else {
                 const float4 tv4 = tex2d_desc(sc, desc, tu, tv);
