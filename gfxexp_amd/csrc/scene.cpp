@@ -4,6 +4,9 @@
 #include <cmath>
 #include <cstring>
 #include "internal.h"
+#ifndef GFX_SPAN_CELLS_PER_REC   // guide cells per emitter record (power of two after rounding): finer cells = shorter searches, bigger table
+#define GFX_SPAN_CELLS_PER_REC 2u
+#endif
 
 namespace gfx {
 
@@ -217,7 +220,7 @@ void scene_upload(Context& ctx, hipStream_t stream) {
     GFX_HIP(hipMemsetAsync(ctx.dLightInstIntegral.p, 0, 16, stream));
     {   // emitter interval table: about two guide cells per record (power of two: ul * cells is exact)
         uint32_t cells = 256;
-        while (cells < 2u * ctx.numEmitterRecs && cells < (1u << 22)) cells *= 2;
+        while (cells < GFX_SPAN_CELLS_PER_REC * ctx.numEmitterRecs && cells < (1u << 22)) cells *= 2;
         ctx.spanGuideCells = cells;
         ctx.dSpans.reserve(std::max<size_t>(sizeof(EmitterSpan) * ctx.numEmitterRecs, 16));
         ctx.dSpanGuide.reserve(sizeof(SpanGuide) * cells);
