@@ -134,3 +134,31 @@ def test_every_bsdf_type(built_lib):
     diffs += run_regir_both(_all_bsdf_scene(), W, H, frames=2, max_len=4, camera=cam)
     diffs += run_nrc_both(_all_bsdf_scene(), W, H, frames=1, max_len=5, camera=cam)
     assert not diffs, "\n".join(diffs[:12])
+
+
+def _smooth_emitter_scene():
+    """A smooth-shaded emissive mesh (the teapot with every triangle an emitter: three different vertex normals per record,
+    the EmitterRecExtra path of light_fetch) next to a flat one, lighting a ground plane and a bunny."""
+    s = util.bunny_scene(with_light=False)
+    pot = util.teapot_scene(emissive=True)
+    mat = s.add_material_traditional((0.01, 0.01, 0.01), (0, 0, 0), 0.3, (4.0, 3.0, 2.0))
+    geoms = [s.add_geom(v, t, mat) for v, t, _ in pot.geoms()]
+    x = np.zeros((3, 4), np.float32)
+    x[:, :3] = np.array([[0.05, 0.01, 0.0], [0.0, 0.04, -0.01], [0.005, 0.0, 0.06]])     # sheared: the normal matrix matters
+    x[:, 3] = (-3.0, 5.0, 3.0)
+    s.add_instance(s.add_group(geoms), x.reshape(12))
+    s.add_instance(s.add_rectangle(1.0, 1.0, (30, 30, 30)), api.make_transform(pos=(4.0, 8.0, 1.0)))
+    return s
+
+
+def test_smooth_shaded_emitters(built_lib):
+    hs = _smooth_emitter_scene()
+    vn = hs.geoms()[-2][0]["normal"]           # a teapot geometry: its vertex normals really differ
+    assert len(np.unique(vn.round(4), axis=0)) > 100
+    cam = api.make_camera(W, H, pos=(1.5, 6.0, 18.0), pitch=12.0, yaw=186.0)
+    diffs = run_sequence_both(_smooth_emitter_scene(), W, H, frames=2, renderer=api.RENDERER_BIASED, camera=cam)
+    diffs += run_pt_both(_smooth_emitter_scene(), W, H, frames=1, max_len=4, camera=cam)
+    with util.frame_overrides(useSolidAngleSampling=1):
+        diffs += run_pt_both(_smooth_emitter_scene(), W, H, frames=1, max_len=3, camera=cam)
+    diffs += run_regir_both(_smooth_emitter_scene(), W, H, frames=2, max_len=3, camera=cam)
+    assert not diffs, "\n".join(diffs[:12])
