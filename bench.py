@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=str, default="480x270", help="resolution of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--plain", action="store_true", help="constant-colour materials (the round-1 workload) instead of the textured street")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "rccl"],
+                    help="N > 1: strip-exchange callback -- tilesplit.StripExchange over torch.distributed (default) or the C++ gfxh_rccl_exchange")
     ap.add_argument("--cluttered", action="store_true", help="secondary workload: + 70 trees of 6 000 leaf cards, cables, railings (depth complexity)")
     ap.add_argument("--bump", type=int, default=1, help="enableBumpMapping (normal maps) for the textured workload")
     return ap.parse_args()
@@ -112,8 +114,31 @@ def main():
     if world > 1:
         # strip exchange: every pass runs on the band only; the rows the next pass reads across the seams travel between
         # the passes (G-buffers once, reservoirs before each spatial pass), the HDR bands are all-gathered asynchronously
-        exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda")
-        renderer.set_exchange(exchange, 0)             # static camera and scene: no motion rows
+        if args.exchange == "rccl":
+            # no Python between the passes: the C++ callback issues ncclSend / ncclRecv / ncclAllGather on the renderer's stream.
+            # Its communicator id comes from rank 0 over the torch process group.
+            L = api.lib()
+            ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                raw = (C.c_uint8 * 128)()
+                if L.gfxh_rccl_unique_id(raw):
+                    raise SystemExit("gfxh_rccl_unique_id failed")
+                ident.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            dist.broadcast(ident, src=0)
+            raw = (C.c_uint8 * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
+            comm = C.c_void_p()
+            L.gfxh_rccl_last_error.restype = C.c_char_p
+            if L.gfxh_rccl_create(raw, C.c_int(rank), C.c_int(world), C.c_uint32(H), C.byref(comm)):
+                raise SystemExit("gfxh_rccl_create: " + L.gfxh_rccl_last_error().decode())
+            L.gfxh_restir_set_exchange(renderer.h, C.cast(L.gfxh_rccl_exchange, C.c_void_p), comm, C.c_uint32(0))
+
+            class _Done:
+                def finish(self):
+                    pass
+            exchange = _Done()
+        else:
+            exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda")
+            renderer.set_exchange(exchange, 0)             # static camera and scene: no motion rows
 
     def frame():
         renderer.render_frame(stream)

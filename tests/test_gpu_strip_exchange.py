@@ -238,3 +238,31 @@ def test_strip_exchange_over_torch_nccl_single_rank(built_lib):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_callback_drives_a_band_renderer(built_lib):
+    """bench.py --exchange rccl: gfxh_rccl_exchange installed as the C callback (no Python between the passes) on a
+    communicator of one rank whose band is the whole frame; frames equal the whole-frame renderer's."""
+    import ctypes as C
+    import torch
+    L = api.lib()
+    L.gfxh_rccl_last_error.restype = C.c_char_p
+    ident = (C.c_uint8 * 128)()
+    assert L.gfxh_rccl_unique_id(ident) == 0, L.gfxh_rccl_last_error()
+    comm = C.c_void_p()
+    assert L.gfxh_rccl_create(ident, 0, 1, C.c_uint32(H), C.byref(comm)) == 0, L.gfxh_rccl_last_error()
+    try:
+        hs = util.bunny_scene()
+        for renderer in (api.RENDERER_BIASED, api.RENDERER_REARCH_BIASED, api.RENDERER_PATH_TRACE_REGIR):
+            ctx_full, full = _make(hs, renderer, (0, 0))
+            ctx_band, band = _make(hs, renderer, (0, H))
+            L.gfxh_restir_set_exchange(band.h, C.cast(L.gfxh_rccl_exchange, C.c_void_p), comm, C.c_uint32(0))
+            for _ in range(FRAMES):
+                full.render_frame()
+                band.render_frame()
+            want, got = _read(ctx_full, full), _read(ctx_band, band)
+            util.assert_same_bits("band = whole frame through gfxh_rccl_exchange", got["beauty"], want["beauty"])
+    finally:
+        torch.cuda.synchronize()
+        L.gfxh_rccl_destroy(comm)
