@@ -131,3 +131,67 @@ def test_cli_animation_moves_the_light(built_lib):
     base = _scene_args() + ["-size", 96, 64, "-frames", 20]
     still, moved = _run(base), _run(base + ["-animate"])
     assert still["mean_rgb"] != moved["mean_rgb"] and all(np.isfinite(moved["mean_rgb"])) and min(moved["mean_rgb"]) > 0
+
+
+def _write_textured_asset(tmp):
+    """A small "real asset": OBJ + MTL with diffuse / normal maps (PPM, TGA) and an emitter image for -rect-emitter-tex."""
+    import struct
+    rng = np.random.default_rng(9)
+    w = h = 16
+    rgb = rng.integers(30, 226, (h, w, 3), dtype=np.uint8)
+    with open(os.path.join(tmp, "albedo.ppm"), "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h) + rgb.tobytes())
+    nrm = np.zeros((h, w, 4), np.uint8)
+    nrm[..., 0] = 128 + rng.integers(-30, 31, (h, w)); nrm[..., 1] = 128 + rng.integers(-30, 31, (h, w)); nrm[..., 2] = 235; nrm[..., 3] = 255
+    with open(os.path.join(tmp, "normal.tga"), "wb") as f:
+        f.write(struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, w, h, 32, 0x28) + nrm[..., [2, 1, 0, 3]].tobytes())
+    glow = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    with open(os.path.join(tmp, "glow.ppm"), "wb") as f:
+        f.write(b"P6\n8 8\n255\n" + glow.tobytes())
+    with open(os.path.join(tmp, "room.mtl"), "w") as f:
+        f.write("newmtl floor\nKd 0.6 0.6 0.6\nKs 0.05 0.05 0.05\nNs 30\nmap_Kd albedo.ppm\nmap_bump normal.tga\n"
+                "newmtl wall\nKd 0.7 0.3 0.2\nKs 0.2 0.2 0.2\nNs 80\n")
+    with open(os.path.join(tmp, "room.obj"), "w") as f:
+        f.write("mtllib room.mtl\n"
+                "v -6 0 -6\nv 6 0 -6\nv 6 0 6\nv -6 0 6\nv -6 5 -6\nv 6 5 -6\n"
+                "vt 0 0\nvt 4 0\nvt 4 4\nvt 0 4\nvn 0 1 0\nvn 0 0 1\n"
+                "usemtl floor\nf 1/1/1 4/4/1 3/3/1 2/2/1\n"
+                "usemtl wall\nf 1/1/2 2/2/2 6/3/2 5/4/2\n")
+    return os.path.join(tmp, "room.obj"), os.path.join(tmp, "glow.ppm")
+
+
+@pytest.mark.gpu
+def test_cli_with_a_textured_asset(built_lib, tmp_path):
+    """-obj with MTL texture maps, -rect-emitter-tex and -bump through the command line equal the same scene built through the
+    bindings (whose textured kernels are checked against the oracle in tests/test_gpu_textures.py)."""
+    import torch
+    obj, glow = _write_textured_asset(str(tmp_path))
+    W, H, frames = 128, 96, 3
+    out = str(tmp_path / "room.pfm")
+    d = _run(["-cam-pos", 0, 2.5, 9, "-cam-yaw", 180, "-name", "room", "-obj", obj, 1.0, "trad",
+              "-name", "panel", "-emittance", 40, 40, 40, "-rect-emitter-tex", glow, "-rectangle", 2.0, 2.0,
+              "-inst", "room", "-begin-pos", 0, 4.5, 0, "-inst", "panel",
+              "-size", W, H, "-frames", frames, "-bump", "-out", out])
+    assert d["textures"] == 3 and d["materials"] == 3
+    lib = api.lib()
+    h2 = api.HostScene()                                             # "panel" sorts before "room"
+    g_panel = lib.gfxh_scene_add_rectangle_textured(h2.h, api.C.c_float(2.0), api.C.c_float(2.0), (api.C.c_float * 3)(40, 40, 40), glow.encode())
+    g_room = h2.load_obj(obj)
+    h2.add_instance(g_room, api.make_transform())
+    h2.add_instance(g_panel, api.make_transform(pos=(0.0, 4.5, 0.0)))
+    assert h2.materials()[0].texEmittance == 1 and h2.materials()[1].texA != 0 and h2.materials()[1].texNormal != 0
+    ctx = api.Context(0)
+    h2.upload(ctx)
+    cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
+    cam = api.make_camera(W, H, (0.0, 2.5, 9.0))
+    for k in range(9):
+        cam.orientation[k] = d["camera_orientation"][k]
+    cfg.camera = cam
+    cfg.enableBumpMapping = 1
+    r = api.RestirRenderer(ctx, cfg)
+    for _ in range(frames):
+        r.render_frame()
+    torch.cuda.synchronize()
+    want = ctx.read_device(r.beauty_ptr(), W * H * 16).view(np.float32).reshape(H, W, 4)
+    assert np.abs(want[..., :3]).sum() > 0
+    assert np.array_equal(_read_pfm(out).view(np.uint32), np.ascontiguousarray(want[..., :3]).view(np.uint32))

@@ -3,5 +3,5 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/r02u
 mkdir -p $OUT
-( timeout 900 python -m pytest tests/test_gpu_strip_exchange.py -m gpu -q -k "nccl or rccl or cpp" 2>&1 | tail -12 ) > $OUT/pytest.log
+( timeout 900 python -m pytest tests/test_headless_cli.py -m gpu -q 2>&1 | tail -12 ) > $OUT/pytest.log
 cat $OUT/pytest.log
