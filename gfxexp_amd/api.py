@@ -213,6 +213,7 @@ C_ABI_SYMBOLS = [
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
     "gfx_nrc_get_params", "gfx_nrc_inference_image", "gfx_nrc_set_render_params",
     "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read", "gfx_trace_diag_read",
+    "gfx_tunable_set",
 ]
 HOST_ABI_SYMBOLS = [
     "gfxh_scene_create", "gfxh_scene_destroy", "gfxh_last_error", "gfxh_scene_add_material_traditional",
@@ -642,6 +643,11 @@ class Context:
         n = C.c_uint32()
         self._check(self.L.gfx_timing_collect(self.h, names, ms, calls, C.c_uint32(cap), C.byref(n)))
         return {names[i].value.decode(): (ms[i], calls[i]) for i in range(min(n.value, cap))}
+
+    def tunable_set(self, name, value):
+        """Scheduling knob of this context ("pixel_map", "super_x", "super_y", "trace_blocks_per_cu", "trace_refill",
+        "trace_batch"); changes no result."""
+        self._check(self.L.gfx_tunable_set(self.h, name.encode(), C.c_int(int(value))))
 
     def counters_enable(self, on=True):
         self._check(self.L.gfx_counters_enable(self.h, C.c_int(1 if on else 0)))

@@ -2,6 +2,7 @@
 // Error model: every HIP failure becomes a non-zero return + gfx_last_error() text (the reference
 // throws std::runtime_error from CUDADRV_CHECK, utils/cuda_util.cpp:58-69; a C++ shim above this
 // ABI can re-throw).
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include "internal.h"
@@ -12,8 +13,25 @@ struct gfx_ctx { Context c; };
 
 static thread_local std::string g_createError;
 
-// every entry point runs on the context's device, whatever the caller (torch, another context) made current
-#define GFX_TRY(ctx) try { GFX_HIP(hipSetDevice((ctx)->c.device));
+// Every entry point runs on the context's device and leaves the calling thread's current device as it found it
+// (a process may drive several GPUs: torch, several contexts).
+namespace {
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int device) {
+        GFX_HIP(hipGetDevice(&prev));
+        if (prev != device) { GFX_HIP(hipSetDevice(device)); switched = true; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+int env_int(const char* name, int fallback, int lo, int hi) {
+    const char* e = getenv(name);
+    if (!e || !*e) return fallback;
+    const int v = atoi(e);
+    return (v < lo || v > hi) ? fallback : v;
+}
+}
+#define GFX_TRY(ctx) if (!(ctx)) return 1; try { DeviceGuard deviceGuard__((ctx)->c.device);
 #define GFX_CATCH(ctx) \
     return 0; } \
     catch (const std::exception& e) { (ctx)->c.lastError = e.what(); return 1; } \
@@ -35,6 +53,13 @@ int gfx_ctx_create(int device, gfx_ctx** out) {
         hipDeviceProp_t prop;
         GFX_HIP(hipGetDeviceProperties(&prop, device));
         ctx->c.numCUs = prop.multiProcessorCount;
+        Tunables& t = ctx->c.tune;
+        t.pixelMap = env_int("GFX_PIXEL_MAP", t.pixelMap, 0, 2);
+        t.superShiftX = env_int("GFX_SUPER_X", t.superShiftX, 0, 6);
+        t.superShiftY = env_int("GFX_SUPER_Y", t.superShiftY, 0, 6);
+        t.traceBlocksPerCU = env_int("GFX_TRACE_BLOCKS_PER_CU", t.traceBlocksPerCU, 1, 8);
+        t.traceRefill = env_int("GFX_TRACE_REFILL", t.traceRefill, 1, 64);
+        t.traceBatch = env_int("GFX_TRACE_BATCH", t.traceBatch, 1, 65536);
         ctx->c.dTraceCounters.reserve(64);
         GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 64));
         *out = ctx.release();
@@ -440,6 +465,22 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
     }
     *n = i;
     c.timings.clear();
+    GFX_CATCH(ctx)
+}
+
+int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value) {
+    GFX_TRY(ctx)
+    if (!name) throw HipError("gfx_tunable_set: null name");
+    Tunables& t = ctx->c.tune;
+    const std::string n(name);
+    auto in = [&](int lo, int hi) { if (value < lo || value > hi) throw HipError("gfx_tunable_set: value out of range for " + n); return value; };
+    if (n == "pixel_map") t.pixelMap = in(0, 2);
+    else if (n == "super_x") t.superShiftX = in(0, 6);
+    else if (n == "super_y") t.superShiftY = in(0, 6);
+    else if (n == "trace_blocks_per_cu") t.traceBlocksPerCU = in(1, 8);
+    else if (n == "trace_refill") t.traceRefill = in(1, 64);
+    else if (n == "trace_batch") t.traceBatch = in(1, 65536);
+    else throw HipError("gfx_tunable_set: unknown tunable " + n);
     GFX_CATCH(ctx)
 }
 

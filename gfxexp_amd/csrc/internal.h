@@ -84,9 +84,21 @@ struct RestirParams {
 
 struct NrcNet;
 
+// Scheduling knobs of a context (none changes a result).  Defaults are the measured best on MI355X; gfx_ctx_create
+// overrides them from the environment (GFX_PIXEL_MAP, GFX_SUPER_X, GFX_SUPER_Y, GFX_TRACE_BLOCKS_PER_CU, GFX_TRACE_REFILL,
+// GFX_TRACE_BATCH) and gfx_tunable_set changes them per context at run time (profiles/, tools/).
+struct Tunables {
+    int pixelMap = 2;                // restir_common.hip.h PixelGrid::mode: 0 scan lines, 1 8x8 tiles, 2 tiles + XCD supertiles
+    int superShiftX = 3, superShiftY = 2;   // supertile = 2^3 x 2^2 blocks of 16 x 16 pixels = 128 x 64 pixels
+    int traceBlocksPerCU = 4;        // persistent traversal grid: blocks of 256 per CU (LDS: 4 x 40 KiB)
+    int traceRefill = 8;             // refill a wave when at least this many lanes are idle
+    int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
+};
+
 struct Context {
     int device = 0;
     int numCUs = 0;                  // of `device` (gfx_ctx_create)
+    Tunables tune;
     size_t nrcTrainLdsConfigured = 0; // dynamic LDS bytes k_nrc_train has been enabled for on this device
     std::string lastError;
     // scene (host mirror)

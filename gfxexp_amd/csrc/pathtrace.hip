@@ -35,7 +35,7 @@ struct PtArgs {
     DevScene scene;
     gfx_restir_static_params s;
     gfx_restir_frame_params f;
-    size_t pixelBegin, pixelEnd;
+    PixelGrid px;                 // per-pixel launches: rows [rowBegin, rowEnd) (restir_common.hip.h)
     uint32_t pathLength;          // pathLength of the vertices k_pt_bounce processes
     uint32_t maxLengthTerminate;  // pathLength >= maxPathLength
     // NEE (any-hit) queue, rebuilt every bounce
@@ -228,7 +228,8 @@ GFX_DEV void push_vertex(const PtArgs& a, uint32_t pixel, f3 pos, const PtVertex
 // pathTrace_rayGen_generic up to the path extension loop (optix_pathtracing_kernels.cu:74-160)
 template <bool REGIR>
 __global__ __launch_bounds__(kPtBlock) void k_pt_first(PtArgs a) {
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
+    const PixelId px = pixel_of_thread(a.px);
+    const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     PtVertexOut o;
     o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_first(PtArgs a) {
     float dirPDensity = 0.0f;
     bool surface = false;
     uint4 g0 = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-    if (p < a.pixelEnd) g0 = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p];
+    if (px.valid) g0 = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p];
     surface = g0.x != 0xFFFFFFFFu;
     if (surface) {
         const float bcB = decode_bc(g0.w & 0xFFFF), bcC = decode_bc(g0.w >> 16);
@@ -284,12 +285,12 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_first(PtArgs a) {
             contribution = contribution + alpha * material_emittance(a.scene, mat, tu, tv) / kPi;
         bsdf.setup(a.scene, mat, tu, tv);
     }
-    else if (p < a.pixelEnd && envEnabled) {
+    else if (px.valid && envEnabled) {
         contribution = a.f.envLightPowerCoeff * env.fetch(decode_bc(g0.w & 0xFFFF), decode_bc(g0.w >> 16));
     }
     shade_vertex<REGIR>(a, surface, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
     if (surface) static_cast<uint64_t*>(a.s.rngBuffer)[p] = rng.state;
-    if (p < a.pixelEnd) {
+    if (px.valid) {
         a.state[2 * p] = make_float4(alpha.x, alpha.y, alpha.z, dirPDensity);
         a.state[2 * p + 1] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
     }
@@ -575,8 +576,9 @@ __global__ __launch_bounds__(kPtBlock) void k_regir_update_last_access(PtArgs a)
 
 // running mean (optix_pathtracing_kernels.cu:203-208)
 __global__ __launch_bounds__(kPtBlock) void k_pt_finish(PtArgs a) {
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
-    if (p >= a.pixelEnd) return;
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const size_t p = px.p;
     const float4 c = a.state[2 * p + 1];
     const f3 contribution(c.x, c.y, c.z);
     float4* beauty = static_cast<float4*>(a.s.beautyAccumBuffer) + p;
@@ -694,7 +696,8 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_preprocess(PtArgs a) {
 
 // pathTrace_raygen_generic<true> up to the path extension loop (:133-318)
 __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_first(PtArgs a) {
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
+    const PixelId px = pixel_of_thread(a.px);
+    const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     PtVertexOut o;
     o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_first(PtArgs a) {
     f3 contribution(0.001f, 0.001f, 0.001f);
     f3 alpha(1.0f);
     float dirPDensity = 0.0f, primaryPathSpread = 0.0f;
-    const bool inImage = p < a.pixelEnd;
+    const bool inImage = px.valid;
     uint4 g0 = make_uint4(0xFFFFFFFFu, 0, 0, 0);
     if (inImage) g0 = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p];
     const bool surface = g0.x != 0xFFFFFFFFu;
@@ -999,8 +1002,9 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
 
 // perFrameContributionBuffer = contribution (:375)
 __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_finish(PtArgs a) {
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
-    if (p >= a.pixelEnd) return;
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const size_t p = px.p;
     const float4 c = a.state[2 * p + 1];
     float* dst = static_cast<float*>(a.nrc.perFrameContributionBuffer) + 3 * p;
     dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
@@ -1016,8 +1020,9 @@ GFX_DEV f3 nrc_scaled_prediction(const PtArgs& a, size_t entry) {
 
 // accumulateInferredRadianceValues, nrc_setup_kernels.cu:51-93
 __global__ __launch_bounds__(kPtBlock) void k_nrc_accumulate(PtArgs a) {
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kPtBlock + threadIdx.x;
-    if (p >= a.pixelEnd) return;
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const size_t p = px.p;
     const float4 t = static_cast<const float4*>(a.nrc.inferenceTerminalInfoBuffer)[p];
     const float* d = static_cast<const float*>(a.nrc.perFrameContributionBuffer) + 3 * p;
     const f3 directCont(d[0], d[1], d[2]);
@@ -1175,9 +1180,9 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         if (pass == GFX_PT_NRC_PREPROCESS) { simple("nrc_preprocess", k_nrc_preprocess, a.nrc.maxNumTrainingSuffixes); return; }
         if (pass == GFX_PT_NRC_ACCUMULATE) {   // the one per-pixel NRC pass besides the path tracing: honours the row band
             if (rowEnd > height || rowBegin > rowEnd) throw HipError("gfx_pt_launch: row range outside the image");
-            a.pixelBegin = static_cast<size_t>(rowBegin) * width;
-            a.pixelEnd = (rowBegin == 0 && rowEnd == 0) ? np : static_cast<size_t>(rowEnd) * width;
-            simple("nrc_accumulate", k_nrc_accumulate, a.pixelEnd - a.pixelBegin);
+            a.px = make_pixel_grid(ctx, width, rowBegin, (rowBegin == 0 && rowEnd == 0) ? height : rowEnd);
+            if (a.px.rowEnd == a.px.rowBegin) return;
+            simple("nrc_accumulate", k_nrc_accumulate, static_cast<size_t>(a.px.launchBlocks) * kPtBlock);
             return;
         }
         if (pass == GFX_PT_NRC_PROPAGATE) { simple("nrc_propagate", k_nrc_propagate, a.nrc.maxNumTrainingSuffixes); return; }
@@ -1224,8 +1229,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     uint32_t* counters = ctx.smallCounters.as<uint32_t>() + 8;   // [0] nee, [1] ext ping, [2] ext pong
     GFX_HIP(hipMemsetAsync(counters, 0, 3 * sizeof(uint32_t), stream));
 
-    a.pixelBegin = static_cast<size_t>(rowBegin) * width;
-    a.pixelEnd = static_cast<size_t>(rowEnd) * width;
+    a.px = make_pixel_grid(ctx, width, rowBegin, rowEnd);
     a.neeOrg = ctx.rayOrg.as<float4>(); a.neeDir = ctx.rayDir.as<float4>(); a.neePending = ctx.ptPending.as<float4>();
     a.neeCount = counters;
     a.occluded = ctx.rayOut.as<uint32_t>();
@@ -1242,9 +1246,14 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         a.extOrgIn = extOrg[in]; a.extDirIn = extDir[in]; a.extOwnerIn = extOwner[in]; a.extCountIn = counters + 1 + in;
         a.extOrgOut = extOrg[out]; a.extDirOut = extDir[out]; a.extOwnerOut = extOwner[out]; a.extCountOut = counters + 1 + out;
     };
-    auto launch = [&](const char* name, void (*kernel)(PtArgs)) {
+    auto launch = [&](const char* name, void (*kernel)(PtArgs)) {          // one thread per queue entry (capacity = the band's pixels)
         ScopedKernelTimer timer(ctx, stream, name);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kPtBlock), 0, stream, a);
+        GFX_HIP(hipGetLastError());
+    };
+    auto launch_pixels = [&](const char* name, void (*kernel)(PtArgs)) {   // one thread per pixel of the band (a.px)
+        ScopedKernelTimer timer(ctx, stream, name);
+        hipLaunchKernelGGL(kernel, dim3(a.px.launchBlocks), dim3(kPtBlock), 0, stream, a);
         GFX_HIP(hipGetLastError());
     };
     auto trace = [&](int mode, const float4* org, const float4* dir, const uint32_t* count, void* out) {
@@ -1257,8 +1266,8 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     set_queues(1, cur);
     a.pathLength = 1; a.maxLengthTerminate = 0;
     a.nextMaxLengthTerminate = 2 >= maxPathLength ? 1u : 0u;
-    if (nrc) launch("nrc_pt_first", k_nrc_pt_first);
-    else launch("pt_first", regir ? k_pt_first<true> : k_pt_first<false>);
+    if (nrc) launch_pixels("nrc_pt_first", k_nrc_pt_first);
+    else launch_pixels("pt_first", regir ? k_pt_first<true> : k_pt_first<false>);
     // while (true) { ++pathLength; trace; }.  Baseline: at least one extension even when maxPathLength < 2,
     // the terminal vertex (implicit light only) emits no NEE ray.  ReGIR: the loop head breaks before the
     // trace at the length limit, so the last vertex's NEE ray is resolved after the loop.  NRC:
@@ -1290,8 +1299,8 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         cur ^= 1;
         if (!regir && !nrc && a.maxLengthTerminate) break;
     }
-    if (nrc) { launch("nrc_pt_finish", k_nrc_pt_finish); return; }
-    launch("pt_finish", k_pt_finish);
+    if (nrc) { launch_pixels("nrc_pt_finish", k_nrc_pt_finish); return; }
+    launch_pixels("pt_finish", k_pt_finish);
 }
 
 } // namespace gfx

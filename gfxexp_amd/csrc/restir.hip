@@ -23,9 +23,15 @@ namespace gfx {
 // ---------------------------------------------------------------- SETUP_GBUFFERS
 // ray generation of optix_gbuffer_kernels.cu:5-27
 __global__ __launch_bounds__(kBlock) void k_primary_rays(RestirArgs a) {
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= a.pixelEnd) return;
-    const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) {
+        // the queue of this pass is indexed by launch slot: slots without a pixel hold an empty-interval ray (an immediate miss)
+        a.rayOrg[px.slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        a.rayDir[px.slot] = make_float4(0.0f, 0.0f, 1.0f, -1.0f);
+        return;
+    }
+    const size_t p = px.p;
+    const int x = px.x, y = px.y;
     const Camera cam = load_camera(a.f.camera);
     float jx = 0.5f, jy = 0.5f;
     if (a.f.enableJittering) {
@@ -40,8 +46,8 @@ __global__ __launch_bounds__(kBlock) void k_primary_rays(RestirArgs a) {
     const float vh = 2 * gm_tan(cam.fovY * 0.5f);
     const float vw = cam.aspect * vh;
     const f3 dir = unit(mul(cam.ori, f3(vw * (0.5f - fx), vh * (0.5f - fy), 1)));
-    a.rayOrg[p - a.pixelBegin] = make_float4(cam.pos.x, cam.pos.y, cam.pos.z, 0.0f);
-    a.rayDir[p - a.pixelBegin] = make_float4(dir.x, dir.y, dir.z, 3.402823466e+38f);
+    a.rayOrg[px.slot] = make_float4(cam.pos.x, cam.pos.y, cam.pos.z, 0.0f);
+    a.rayDir[px.slot] = make_float4(dir.x, dir.y, dir.z, 3.402823466e+38f);
 }
 
 // PerspectiveCamera::calcScreenPosition, restir_di_shared.h:51-59
@@ -57,12 +63,13 @@ GFX_DEV void calc_screen_position(const Camera& cam, f3 pw, float& sx, float& sy
 
 // closest-hit / miss programs + the tail of the ray-generation program (optix_gbuffer_kernels.cu:56-243)
 __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= a.pixelEnd) return;
-    const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const size_t p = px.p;
+    const int x = px.x, y = px.y;
     const uint32_t bufIdx = a.f.bufferIndex;
-    const gfx_hit h = a.hits[p - a.pixelBegin];
-    const float4 rd = a.rayDir[p - a.pixelBegin];
+    const gfx_hit h = a.hits[px.slot];
+    const float4 rd = a.rayDir[px.slot];
     const f3 direction(rd.x, rd.y, rd.z);
 
     f3 albedo(0.0f);
@@ -173,10 +180,11 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
 template <bool EMITTER_TEX>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const PixelId px = pixel_of_thread(a.px);
+    const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     bool surface = false;
-    if (p < a.pixelEnd) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
+    if (px.valid) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
 
     bool wantRay = false;
     f3 rayO(0.0f), rayD(0.0f);
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
         static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes])[p] = make_float2(recPDF, selectedTarget);
     }
     const uint32_t slot = queue_append_wave(wantRay, rayO, rayD, 0.0f, rayTmax, a.rayOrg, a.rayDir, a.rayCount);
-    if (p < a.pixelEnd) a.pixelRaySlot[p] = slot;
+    if (px.valid) a.pixelRaySlot[p] = slot;
 }
 
 // visibility application + temporal reuse: optix_restir_di_kernels.cu:128-286
@@ -257,11 +265,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_temporal(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= a.pixelEnd) return;
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x == 0xFFFFFFFFu) return;
-    const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
+    const int x = px.x, y = px.y;
 
     float2* infoBuf = static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes]);
     float2 info = infoBuf[p];
@@ -366,12 +375,13 @@ GFX_DEV void spatial_neighbor(const RestirArgs& a, Pcg32& rng, uint32_t nIdx, in
 template <bool UNBIASED>
 __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const PixelId px = pixel_of_thread(a.px);
+    const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     const uint32_t numNb = a.f.numSpatialNeighbors;
     bool surface = false;
-    if (p < a.pixelEnd) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
-    const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
+    if (px.valid) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
+    const int x = px.x, y = px.y;
     const uint32_t srcRes = a.curRes, dstRes = (a.curRes + 1) % 2;
     const Camera cam = load_camera(a.f.camera);
 
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
     // ---- unbiased: targets of the selected sample at self and at every neighbour, rays where needed
     const bool needMis = surface && selectedTarget > 0.0f;
     const LightSample selected = combined.sample;
-    SpatialSlot* slots = a.spatialScratch + (p < a.pixelEnd ? p * (numNb + 1) : 0);
+    SpatialSlot* slots = a.spatialScratch + (px.valid ? p * (numNb + 1) : 0);
     const Camera prevCam = load_camera(a.f.prevCamera);
     // MIS term k (0 = self, 1 + nIdx = neighbour): target density, stream length, and the visibility ray it needs
     struct MisTerm { float target; uint32_t streamLength; bool want, evaluated; f3 ro, rd; float tmax; };
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
     };
     auto store_term = [&](uint32_t k, const MisTerm& t, uint32_t slot) {
         if (!t.evaluated) slot = kSlotSkipped;   // out of bounds / self / background: the reference `continue`s
-        if (p < a.pixelEnd) { SpatialSlot s; s.targetDensity = t.target; s.streamLength = t.streamLength; s.raySlot = slot; slots[k] = s; }
+        if (px.valid) { SpatialSlot s; s.targetDensity = t.target; s.streamLength = t.streamLength; s.raySlot = slot; slots[k] = s; }
     };
     constexpr int kBatch = 4;                    // self + the reference's three neighbours: one queue reservation
     if (numNb + 1 <= static_cast<uint32_t>(kBatch)) {
@@ -513,8 +523,9 @@ __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
 // MIS weights of the unbiased spatial pass once the rays are back: optix_restir_di_kernels.cu:413-546
 __global__ __launch_bounds__(kBlock) void k_spatial_mis_finish(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= a.pixelEnd) return;
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x == 0xFFFFFFFFu) return;
     const uint32_t numNb = a.f.numSpatialNeighbors;
@@ -559,14 +570,15 @@ __global__ __launch_bounds__(kBlock) void k_spatial_mis_finish(RestirArgs a) {
 // optix_restir_di_kernels.cu:559-629 up to the final shadow ray
 __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const PixelId px = pixel_of_thread(a.px);
+    const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     bool want = false;
     f3 ro(0.0f), rd(0.0f); float tmax = 0;
     f3 contribution(0.01f, 0.01f, 0.01f);
     f3 direct(0.0f);
     float recPDF = 0.0f;
-    if (p < a.pixelEnd) {
+    if (px.valid) {
         const uint32_t instSlot = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x;
         const uint4 g3 = static_cast<const uint4*>(a.s.gbuffer3[bufIdx])[p];
         if (instSlot != 0xFFFFFFFFu) {
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
         }
     }
     const uint32_t slot = emit_ray(want, ro, rd, 0.0f, tmax, a);
-    if (p < a.pixelEnd) {
+    if (px.valid) {
         a.shadeScratch[2 * p] = make_float4(contribution.x, contribution.y, contribution.z, bits2f(slot));
         a.shadeScratch[2 * p + 1] = make_float4(direct.x, direct.y, direct.z, recPDF);
     }
@@ -613,8 +625,9 @@ __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
 
 // contribution += recPDFEstimate * directCont; running mean (optix_restir_di_kernels.cu:619-636)
 __global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= a.pixelEnd) return;
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const size_t p = px.p;
     const float4 c0 = a.shadeScratch[2 * p], c1 = a.shadeScratch[2 * p + 1];
     f3 contribution(c0.x, c0.y, c0.z);
     const uint32_t bufIdx = a.f.bufferIndex;
@@ -668,18 +681,15 @@ static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint3
         a.rearchSlots = ctx.rearchSlots.as<uint32_t>();
     }
     if (rowEnd > height || rowBegin > rowEnd) throw HipError("gfx_restir_launch_rows: row range outside the image");
-    a.pixelBegin = static_cast<size_t>(rowBegin) * width;
-    a.pixelEnd = static_cast<size_t>(rowEnd) * width;
+    a.px = make_pixel_grid(ctx, width, rowBegin, rowEnd);
     return a;
 }
 
 template <typename K>
 static void launch_pixels(Context& ctx, hipStream_t stream, const char* name, K kernel, const RestirArgs& a) {
-    const size_t numPixels = a.pixelEnd - a.pixelBegin;
-    if (numPixels == 0) return;
-    const uint32_t grid = static_cast<uint32_t>((numPixels + kBlock - 1) / kBlock);
+    if (a.px.rowEnd == a.px.rowBegin) return;
     ScopedKernelTimer timer(ctx, stream, name);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a);
     GFX_HIP(hipGetLastError());
 }
 
@@ -751,22 +761,23 @@ void restir_visualize(Context& ctx, hipStream_t stream, const void* linearBuffer
 void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {
     const bool rearch = pass >= GFX_RESTIR_LIGHT_PRESAMPLING;
     RestirArgs a = make_args(ctx, width, height, rowBegin, rowEnd, rearch);
-    const uint32_t numPixels = static_cast<uint32_t>(a.pixelEnd - a.pixelBegin);
-    if (numPixels == 0) return;
+    if (rowEnd == rowBegin) return;
     auto reset_queue = [&]() { GFX_HIP(hipMemsetAsync(a.rayCount, 0, sizeof(uint32_t), stream)); };
     switch (pass) {
     case GFX_RESTIR_SETUP_GBUFFERS: {
-        // own scratch set (internal.h): this pass may overlap other passes of the previous frame
-        const size_t framePixels = static_cast<size_t>(width) * height;
-        ctx.gbRayOrg.reserve(16 * framePixels); ctx.gbRayDir.reserve(16 * framePixels);
-        ctx.gbRayHits.reserve(sizeof(gfx_hit) * framePixels);
+        // own scratch set (internal.h): this pass may overlap other passes of the previous frame.  One queue entry per
+        // launch slot (restir_common.hip.h): the tiled pixel maps pad the frame to whole 16 x 16 blocks / supertiles
+        const size_t frameSlots = static_cast<size_t>(make_pixel_grid(ctx, width, 0, height).launchBlocks) * kBlock;
+        const uint32_t numSlots = a.px.launchBlocks * kBlock;
+        ctx.gbRayOrg.reserve(16 * frameSlots); ctx.gbRayDir.reserve(16 * frameSlots);
+        ctx.gbRayHits.reserve(sizeof(gfx_hit) * frameSlots);
         a.rayOrg = ctx.gbRayOrg.as<float4>(); a.rayDir = ctx.gbRayDir.as<float4>();
         a.hits = ctx.gbRayHits.as<gfx_hit>();
         launch_pixels(ctx, stream, "primary_rays", k_primary_rays, a);
         TraceLaunch t;
         t.accel = ctx.accels[ctx.restir.f.travHandle - 1]->dev();
         t.rayOrgTmin = a.rayOrg; t.rayDirTmax = a.rayDir;
-        t.numRays = numPixels; t.numRaysPtr = nullptr;
+        t.numRays = numSlots; t.numRaysPtr = nullptr;
         t.out = ctx.gbRayHits.p; t.mode = GFX_TRACE_CLOSEST;
         t.spill = &ctx.gbSpill; t.counters = &ctx.gbCounters;
         trace_launch(ctx, stream, t);
@@ -778,8 +789,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     case GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED:
         reset_queue();
         {
-            const size_t numPx = a.pixelEnd - a.pixelBegin;
-            const uint32_t grid = static_cast<uint32_t>((numPx + kBlock - 1) / kBlock);
+            const uint32_t grid = a.px.launchBlocks;
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
             if (a.scene.emitterTexRefs) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);

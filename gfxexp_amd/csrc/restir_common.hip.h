@@ -16,12 +16,79 @@ struct SpatialSlot {            // per (pixel, k): k = 0 self, 1..N neighbours (
     uint32_t raySlot;           // GFX_INVALID_SLOT: no ray needed
 };
 
+// ---------------------------------------------------------------- pixel <-> thread mapping
+// Every per-pixel kernel asks pixel_of_thread() which pixel its thread owns.  All per-pixel state lives in
+// row-major arrays indexed by p = y * width + x and no kernel communicates between pixels except through those
+// arrays, so the mapping changes no result -- only which pixels share a wave, a CU and an XCD:
+//   mode 0  row-major: a wave is a 64 x 1 strip of one scan line (rounds 1-2).
+//   mode 1  a wave is an 8 x 8 tile, a 256-thread block a 16 x 16 square (the reference's own tiling for the
+//           per-tile light subsets, per_pixel_ris.cu:44-61); blocks in scan order.  Rays of a tile enter the queue
+//           together, G-buffer / reservoir reads are 8 rows x 128 B, and the radius-r neighbourhoods of the spatial
+//           pass overlap inside a wave.
+//   mode 2  mode 1 + XCD-aware block order: hardware block b runs on XCD b % 8, so blocks are dealt out such
+//           that every XCD works through whole "supertiles" (2^sx x 2^sy blocks) -- the neighbours a spatial pass
+//           gathers were mostly written into / are mostly found in that XCD's own 4-MiB L2.  Supertiles (not one
+//           contiguous eighth of the image per XCD) keep the XCDs balanced when cost varies over the image.
+// `slot` is the thread's index in the launch: dense per-launch arrays (primary rays, their hits) use it.
+struct PixelGrid {
+    uint32_t width, rowBegin, rowEnd;
+    uint32_t mode;
+    uint32_t blocksX, blocksY;          // 16 x 16-pixel blocks covering the rows
+    uint32_t superShiftX, superShiftY;  // log2 of the supertile size in blocks
+    uint32_t supersX;
+    uint32_t launchBlocks;              // grid size (host side)
+};
+struct PixelId { size_t p; int x, y; uint32_t slot; bool valid; };
+GFX_DEV PixelId pixel_of_thread(const PixelGrid& g) {
+    PixelId r;
+    r.slot = blockIdx.x * 256u + threadIdx.x;
+    if (g.mode == 0) {
+        r.p = static_cast<size_t>(g.rowBegin) * g.width + r.slot;
+        r.valid = r.p < static_cast<size_t>(g.rowEnd) * g.width;
+        r.x = static_cast<int>(r.p % g.width); r.y = static_cast<int>(r.p / g.width);
+        return r;
+    }
+    uint32_t bx, by;
+    if (g.mode == 1) { bx = blockIdx.x % g.blocksX; by = blockIdx.x / g.blocksX; }
+    else {
+        const uint32_t xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        const uint32_t sh = g.superShiftX + g.superShiftY;
+        const uint32_t super = ((i >> sh) << 3) | xcd, within = i & ((1u << sh) - 1u);
+        const uint32_t sx = super % g.supersX, sy = super / g.supersX;   // sy beyond the last row of supertiles: by >= blocksY below
+        bx = (sx << g.superShiftX) + (within & ((1u << g.superShiftX) - 1u));
+        by = (sy << g.superShiftY) + (within >> g.superShiftX);
+    }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t y = g.rowBegin + by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    r.valid = bx < g.blocksX && by < g.blocksY && x < g.width && y < g.rowEnd;
+    r.x = static_cast<int>(x); r.y = static_cast<int>(y);
+    r.p = r.valid ? static_cast<size_t>(y) * g.width + x : 0;
+    return r;
+}
+
+// host side: the grid of a per-pixel launch over rows [rowBegin, rowEnd) (Context::pixelMap* = the mode, internal.h)
+inline PixelGrid make_pixel_grid(const Context& ctx, uint32_t width, uint32_t rowBegin, uint32_t rowEnd) {
+    PixelGrid g;
+    g.width = width; g.rowBegin = rowBegin; g.rowEnd = rowEnd;
+    g.mode = static_cast<uint32_t>(ctx.tune.pixelMap);
+    const uint32_t rows = rowEnd - rowBegin;
+    g.blocksX = (width + 15u) / 16u; g.blocksY = (rows + 15u) / 16u;
+    g.superShiftX = static_cast<uint32_t>(ctx.tune.superShiftX); g.superShiftY = static_cast<uint32_t>(ctx.tune.superShiftY);
+    g.supersX = (g.blocksX + (1u << g.superShiftX) - 1u) >> g.superShiftX;
+    const uint32_t supersY = (g.blocksY + (1u << g.superShiftY) - 1u) >> g.superShiftY;
+    if (g.mode == 0) g.launchBlocks = static_cast<uint32_t>((static_cast<size_t>(rows) * width + 255u) / 256u);
+    else if (g.mode == 1) g.launchBlocks = g.blocksX * g.blocksY;
+    else g.launchBlocks = (((g.supersX * supersY + 7u) / 8u) * 8u) << (g.superShiftX + g.superShiftY);
+    return g;
+}
+
 struct RestirArgs {
     DevScene scene;
     gfx_restir_static_params s;
     gfx_restir_frame_params f;
     uint32_t curRes, baseIdx;
-    size_t pixelBegin, pixelEnd;   // the launch covers pixels [pixelBegin, pixelEnd) (whole rows)
+    PixelGrid px;                  // which pixel each thread of a per-pixel launch owns (whole rows [rowBegin, rowEnd))
     float4* rayOrg; float4* rayDir;
     uint32_t* rayCount;
     uint32_t* pixelRaySlot;

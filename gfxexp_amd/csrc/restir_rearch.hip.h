@@ -78,12 +78,12 @@ __global__ __launch_bounds__(kBlock) void k_light_presample(RestirArgs a) {
     q[2] = make_float4(ls.normal.z, bits2f(ls.atInfinity & 1u), pd, 0.0f);
 }
 
-// One wave per 8x8 tile; tiles enumerated row-major over the band [pixelBegin, pixelEnd).
+// One wave per 8x8 tile; tiles enumerated row-major over the band of rows [rowBegin, rowEnd).
 __global__ __launch_bounds__(kBlock) void k_per_pixel_ris(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const int W = a.s.imageSizeX, H = a.s.imageSizeY;
     const int tilesX = (W + 7) / 8;
-    const int rowBegin = static_cast<int>(a.pixelBegin / W), rowEnd = static_cast<int>(a.pixelEnd / W);
+    const int rowBegin = static_cast<int>(a.px.rowBegin), rowEnd = static_cast<int>(a.px.rowEnd);
     const int tileRowBegin = rowBegin / 8, tileRowEnd = (rowEnd + 7) / 8;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -163,11 +163,12 @@ GFX_DEV f3 rearch_neighbor_origin(const RestirArgs& a, uint32_t prevBuf, size_t 
 template <bool TEMPORAL, bool SPATIAL, bool UNBIASED>
 __global__ __launch_bounds__(kBlock) void k_rearch_emit(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const PixelId px = pixel_of_thread(a.px);
+    const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     const uint32_t prevBuf = (bufIdx + 1) % 2, prevRes = (a.curRes + 1) % 2;
     bool surface = false;
-    if (p < a.pixelEnd) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
+    if (px.valid) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
     uint32_t sv = 0;
     bool want[kRearchRayKinds] = { false, false, false, false, false, false, false };
     f3 pos(0.0f), tPos(0.0f), stPos(0.0f);
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_rearch_emit(RestirArgs a) {
     newS.emittance = newS.position = newS.normal = f3(0.0f); newS.atInfinity = 0;
     tS = newS; stS = newS;
     if (surface) {
-        const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
+        const int x = px.x, y = px.y;
         const Camera cam = load_camera(a.f.camera);
         const f3 prevCamPos(a.f.prevCamera.position[0], a.f.prevCamera.position[1], a.f.prevCamera.position[2]);
         const float4 g2 = static_cast<const float4*>(a.s.gbuffer2[bufIdx])[p];
@@ -276,16 +277,17 @@ __global__ __launch_bounds__(kBlock) void k_rearch_emit(RestirArgs a) {
             const ShadowRay sr = shadow_ray(*orgs[k], *smps[k]);
             queue_write(slots[k], *orgs[k], sr.dir, 0.0f, sr.tmax, a.rayOrg, a.rayDir);
         }
-        if (p < a.pixelEnd) a.rearchSlots[static_cast<size_t>(k) * numPixels + p] = slots[k];
+        if (px.valid) a.rearchSlots[static_cast<size_t>(k) * numPixels + p] = slots[k];
     }
-    if (p < a.pixelEnd) a.pixelRaySlot[p] = sv;
+    if (px.valid) a.pixelRaySlot[p] = sv;
 }
 
 template <bool TEMPORAL, bool SPATIAL, bool UNBIASED>
 __global__ __launch_bounds__(kBlock) void k_rearch_vis_finish(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= a.pixelEnd) return;
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x == 0xFFFFFFFFu) return;   // the reference returns before the write
     uint32_t sv = a.pixelRaySlot[p];
@@ -358,9 +360,10 @@ GFX_DEV float rearch_mis_weight(const RestirArgs& a, size_t numPixels, uint32_t 
 template <bool TEMPORAL, bool SPATIAL>
 __global__ __launch_bounds__(kBlock) void k_rearch_shade(RestirArgs a) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = a.pixelBegin + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (p >= a.pixelEnd) return;
-    const int x = static_cast<int>(p % a.s.imageSizeX), y = static_cast<int>(p / a.s.imageSizeX);
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const size_t p = px.p;
+    const int x = px.x, y = px.y;
     const uint32_t bufIdx = a.f.bufferIndex;
     const uint32_t prevBuf = (bufIdx + 1) % 2, prevRes = (a.curRes + 1) % 2;
     const uint32_t instSlot = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x;

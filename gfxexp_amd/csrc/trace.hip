@@ -7,15 +7,12 @@
 // kRefillThreshold lanes are idle and the queue is not exhausted, the wave takes one atomic ticket
 // for exactly popcount(idle) rays (ballot + mbcnt compaction) and the idle lanes start new rays
 // while the others keep traversing -- the SIMT analogue of OptiX's hardware ray scheduling.
-#include <cstdlib>
 #include "bvh8.hip.h"
 #include "internal.h"
 
 namespace gfx {
 
 constexpr int kTraceBlock = 256;
-constexpr int kRefillThreshold = 8;
-constexpr int kTicketBatch = 64;   // rays bought per device atomic (tuned: 32 and 128 are slower)
 
 struct TraceArgs {
     DevAccel accel;
@@ -174,14 +171,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
 }
 
 static uint32_t persistent_grid(Context& ctx) {
-    const int numCUs = ctx.numCUs;
-    static int blocksPerCU = 0;
-    if (!blocksPerCU) {
-        const char* e = getenv("GFX_TRACE_BLOCKS_PER_CU");   // tuning knob; default 4 blocks of 256 per CU (LDS: 4 x 40 KiB)
-        blocksPerCU = e ? atoi(e) : 4;
-        if (blocksPerCU < 1 || blocksPerCU > 8) blocksPerCU = 4;
-    }
-    return static_cast<uint32_t>(numCUs) * static_cast<uint32_t>(blocksPerCU);
+    return static_cast<uint32_t>(ctx.numCUs) * static_cast<uint32_t>(ctx.tune.traceBlocksPerCU);
 }
 
 void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
@@ -205,12 +195,8 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
         if (!ctx.dTraceDiag.p) { ctx.dTraceDiag.reserve(64); GFX_HIP(hipMemsetAsync(ctx.dTraceDiag.p, 0, 64, stream)); }
         a.diag = ctx.dTraceDiag.as<unsigned long long>();
     }
-    static int refill = 0;
-    if (!refill) { const char* e = getenv("GFX_TRACE_REFILL"); refill = e ? atoi(e) : kRefillThreshold; if (refill < 1 || refill > 64) refill = kRefillThreshold; }
-    a.refillThreshold = refill;
-    static int batch = 0;
-    if (!batch) { const char* e = getenv("GFX_TRACE_BATCH"); batch = e ? atoi(e) : kTicketBatch; if (batch < 1 || batch > 65536) batch = kTicketBatch; }
-    a.ticketBatch = batch;
+    a.refillThreshold = ctx.tune.traceRefill;
+    a.ticketBatch = ctx.tune.traceBatch;
     const bool any = t.mode == GFX_TRACE_ANY;
     ScopedKernelTimer timer(ctx, stream, any ? "trace_any" : "trace_closest");
     if (ctx.countersEnabled) {

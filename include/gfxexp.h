@@ -455,6 +455,14 @@ int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes)
 int gfx_timing_enable(gfx_ctx* ctx, int enable);
 int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t* calls,
                        uint32_t capacity, uint32_t* n);
+/* Scheduling knobs of a context; none changes a result (no reference counterpart: OptiX schedules in the driver).
+ *   "pixel_map" 0|1|2           which pixels share a wave / block / XCD in the per-pixel kernels: scan lines, 8 x 8 tiles
+ *                               (the tiling of restir_di/gpu_kernels/per_pixel_ris.cu:44-61), tiles + XCD-aware supertiles (default)
+ *   "super_x", "super_y"        log2 of the supertile size in 16 x 16-pixel blocks (mode 2; default 3, 2)
+ *   "trace_blocks_per_cu", "trace_refill", "trace_batch"   persistent traversal grid, lane-refill threshold, rays per ticket
+ * The same knobs are read once from the environment by gfx_ctx_create (GFX_PIXEL_MAP, GFX_SUPER_X, GFX_SUPER_Y,
+ * GFX_TRACE_BLOCKS_PER_CU, GFX_TRACE_REFILL, GFX_TRACE_BATCH). */
+int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value);
 /* Ray-traversal counters accumulated by the renderer passes: {node fetches, triangle fetches, rays, stack spills}
  * of the any-hit launches in [0..3] and of the closest-hit launches in [4..7]. */
 int gfx_counters_enable(gfx_ctx* ctx, int enable);

@@ -1,0 +1,68 @@
+#!/bin/bash
+# tools/profile_round.sh -- every measurement behind profiles/r03_* as named steps, runnable from a clean checkout on a
+# GPU box (through gpurun: `gpurun --timeout 1500 -- 'bash tools/profile_round.sh tests ab pmc'`).  Raw output goes to
+# gpurun_out/r03/<step>/ (scratch); the summaries quoted in DESIGN.md are copied from there into profiles/ by hand-picked
+# names (listed next to each step).  Replaces the one-off tools/sessions/r0*.sh scripts of rounds 1-2.
+#
+#   tests        python -m pytest tests -m gpu -x -q                                   -> gpurun_out/r03/tests.log
+#   bench        default bench.py line (64k-spp MSE + CPU rows, ~3 min)                -> profiles/r03_bench_default.json
+#   benchq       bench.py without the MSE / CPU legs, default + --plain + --cluttered  -> profiles/r03_bench_quick.jsonl
+#   ab           tools/pixel_map_ab.py: scan-line / tiled / XCD-supertile pixel maps   -> profiles/r03_pixel_map_ab.jsonl
+#   absweep      the same over supertile shapes                                        -> profiles/r03_pixel_map_supers.jsonl
+#   stats        rocprofv3 --kernel-trace --stats of the short bench command           -> profiles/r03_kernel_stats.txt
+#   pmc          PMC passes (SQ x2, TCP/TCC, FETCH, WRITE) of the same command, default pixel map
+#   pmc0         the same with GFX_PIXEL_MAP=0 (rounds 1-2 mapping) for the before/after table -> profiles/r03_pixel_map_pmc.txt
+#   nrcpmc       MFMA / VALU counters of k_nrc_infer, k_nrc_train                       -> profiles/r03_nrc_pmc.txt
+#   nrc          tools/bench_nrc.py, NRC frame with training overlapped and serial      -> profiles/r03_nrc_frame.json
+#   renderers    tools/bench_renderers.py + tools/bench_config4.py                      -> profiles/r03_renderers.jsonl
+#   bands        tools/bench_band.py (compute-only bound of N row bands)                -> profiles/r03_band_compute_bound.json
+#   hbm          tools/hbm_stream.py (streaming-copy ceiling of this box)               -> profiles/r03_hbm_stream.json
+set -u
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+export TMPDIR=/tmp
+OUT=gpurun_out/r03
+mkdir -p $OUT
+B="python bench.py --steps 6 --warmup 2 --mse-ref-spp 0 --cpu-sample 0"
+
+pmc_passes() {   # $1 = output tag, rest = environment assignments
+  local tag=$1; shift
+  local d=$OUT/$tag
+  mkdir -p $d
+  env "$@" timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $d/sq -- $B --no-roofline > /dev/null 2>&1
+  env "$@" timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_THREAD_CYCLES_VALU SQ_WAVES --output-format csv -d $d/sq2 -- $B --no-roofline > /dev/null 2>&1
+  env "$@" timeout 300 rocprofv3 --pmc TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $d/tc -- $B --no-roofline > /dev/null 2>&1
+  env "$@" timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $d/ea -- $B --no-roofline > /dev/null 2>&1
+  env "$@" timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $d/wr -- $B --no-roofline > /dev/null 2>&1
+  for p in sq sq2 tc ea wr; do
+    python profiles/summarize_pmc.py $d/$p/*/*counter_collection.csv > $d/$p.txt 2>&1
+  done
+  rm -rf $d/sq $d/sq2 $d/tc $d/ea $d/wr
+}
+
+for step in "$@"; do
+  echo "==== $step"
+  case $step in
+    tests)     timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/tests.log ;;
+    bench)     timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | cut -c1-600 ;;
+    benchq)    : > $OUT/bench_quick.jsonl
+               for f in "" "--plain" "--cluttered"; do timeout 300 python bench.py --steps 30 --warmup 5 --mse-ref-spp 0 --cpu-sample 0 $f >> $OUT/bench_quick.jsonl 2>> $OUT/bench_quick.err; done
+               cut -c1-400 $OUT/bench_quick.jsonl ;;
+    ab)        timeout 600 python tools/pixel_map_ab.py > $OUT/pixel_map_ab.jsonl 2> $OUT/pixel_map_ab.err
+               timeout 600 python tools/pixel_map_ab.py --plain >> $OUT/pixel_map_ab.jsonl 2>> $OUT/pixel_map_ab.err
+               cat $OUT/pixel_map_ab.jsonl; tail -3 $OUT/pixel_map_ab.err ;;
+    absweep)   timeout 900 python tools/pixel_map_ab.py --modes 2 --supers 0x0,1x1,2x1,2x2,3x2,3x3,4x3,4x4 > $OUT/pixel_map_supers.jsonl 2> $OUT/pixel_map_supers.err
+               cat $OUT/pixel_map_supers.jsonl; tail -3 $OUT/pixel_map_supers.err ;;
+    stats)     rm -rf $OUT/stats; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > /dev/null 2>&1
+               cat $OUT/stats/*/*kernel_stats.csv | cut -c1-200 | head -40 | tee $OUT/kernel_stats.csv ;;
+    pmc)       pmc_passes pmc_default GFX_NOOP=1; head -60 $OUT/pmc_default/sq.txt ;;
+    pmc0)      pmc_passes pmc_map0 GFX_PIXEL_MAP=0 ;;
+    pmc1)      pmc_passes pmc_map1 GFX_PIXEL_MAP=1 ;;
+    nrcpmc)    bash tools/nrc_prof.sh ;;
+    nrc)       timeout 600 python tools/bench_nrc.py > $OUT/nrc_frame.json 2> $OUT/nrc_frame.err; cat $OUT/nrc_frame.json; tail -3 $OUT/nrc_frame.err ;;
+    renderers) timeout 900 python tools/bench_renderers.py > $OUT/renderers.jsonl 2> $OUT/renderers.err
+               timeout 300 python tools/bench_config4.py >> $OUT/renderers.jsonl 2>> $OUT/renderers.err; cat $OUT/renderers.jsonl ;;
+    bands)     timeout 900 python tools/bench_band.py > $OUT/band_compute_bound.json 2> $OUT/band.err; cat $OUT/band_compute_bound.json; tail -3 $OUT/band.err ;;
+    hbm)       timeout 300 python tools/hbm_stream.py > $OUT/hbm_stream.json 2> $OUT/hbm.err; cat $OUT/hbm_stream.json ;;
+    *)         echo "unknown step $step" ;;
+  esac
+done
