@@ -130,6 +130,7 @@ def main():
             L.gfxh_rccl_last_error.restype = C.c_char_p
             if L.gfxh_rccl_create(raw, C.c_int(rank), C.c_int(world), C.c_uint32(H), C.byref(comm)):
                 raise SystemExit("gfxh_rccl_create: " + L.gfxh_rccl_last_error().decode())
+            api.check_partition(cfg, world, 0)          # the same verdict on every rank, before the first collective
             L.gfxh_restir_set_exchange(renderer.h, C.cast(L.gfxh_rccl_exchange, C.c_void_p), comm, C.c_uint32(0))
 
             class _Done:
@@ -137,7 +138,7 @@ def main():
                     pass
             exchange = _Done()
         else:
-            exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda")
+            exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda", async_gather=True)
             renderer.set_exchange(exchange, 0)             # static camera and scene: no motion rows
 
     def frame():
@@ -317,16 +318,18 @@ def _device_view(ptr, num_floats):
 
 def cpu_baseline(hs, cam, sample, W, H):
     """The CPU restatement (oracle/, test infrastructure) timed on this host: same scene, same camera, same
-    settings, steady-state frames on a reduced pixel count -- once on one thread (the scalar CPU path) and once
-    on every host thread (OpenMP over pixels inside each pass)."""
+    settings, steady-state frames on a reduced pixel count.  BASELINE.md section 2 names two builds of it -- the parity
+    build (the checker: contraction off, x86-64-v3) and a speed build (-O3 -march=native, contraction allowed, compiled on
+    this host) -- each once on one thread (the scalar CPU path) and once on every host thread (OpenMP over pixels inside
+    each pass).  `value` is the faster of the two builds on one thread: the best the scalar CPU path does here."""
     from oracle import oracle as O
     from tests import util
     sw, sh = [int(x) for x in sample.lower().split("x")]
-    osc = util.feed_oracle(hs, threads=1)
     ocam = util.copy_struct(O.GfxCamera, cam)
     ocam.aspect = float(sw) / float(sh)
+    cores = int(O.lib().orc_max_threads())
 
-    def run(threads, frames):
+    def run(osc, threads, frames):
         osc.set_threads(threads)
         pb = util.PixelBuffers(sw, sh)
         s = pb.host_static_params()
@@ -348,15 +351,30 @@ def cpu_baseline(hs, cam, sample, W, H):
             times.append(time.perf_counter() - t0)
         return float(np.median(times[1:]))
 
-    t1 = run(1, 4)
-    cores = int(O.lib().orc_max_threads())
-    tn = run(cores, 8)
-    return {"value": round(sw * sh / t1 / 1e6, 5), "unit": "Mpaths/s", "cores": 1, "kind": "port",
+    def rows(library, flags):
+        osc = util.feed_oracle(hs, threads=1, library=library)
+        t1 = run(osc, 1, 4)
+        tn = run(osc, cores, 8)
+        out = {"flags": "g++ " + flags, "one_thread": {"value": round(sw * sh / t1 / 1e6, 5), "cores": 1, "seconds_per_sample_frame": round(t1, 3)},
+               "all_threads": {"value": round(sw * sh / tn / 1e6, 5), "cores": cores, "seconds_per_sample_frame": round(tn, 4)},
+               "bvh_build_s": round(osc.build_seconds, 2)}
+        osc.close()
+        return out
+
+    parity = rows(None, O.PARITY_FLAGS)
+    try:
+        speed = rows(O.lib_fast(), O.FAST_FLAGS)
+    except Exception as e:                       # no compiler on the host: the parity rows stand alone
+        speed = {"error": repr(e)[:200]}
+    best = speed if "one_thread" in speed and speed["one_thread"]["value"] >= parity["one_thread"]["value"] else parity
+    return {"value": best["one_thread"]["value"], "unit": "Mpaths/s", "cores": 1, "kind": "port",
+            "build": "speed" if best is speed else "parity",
             "sample": f"{sw}x{sh} pixels ({sw * sh / (W * H):.4f} of the frame), steady-state frames (median of 3 on one thread, of 7 on all), "
-                      f"same scene/camera/settings, scalar C++ restatement (oracle/), SAH BVH8 build {osc.build_seconds:.1f} s untimed",
-            "seconds_per_sample_frame": round(t1, 3),
-            "all_cores": {"value": round(sw * sh / tn / 1e6, 5), "unit": "Mpaths/s", "cores": cores,
-                          "seconds_per_sample_frame": round(tn, 4), "how": "OpenMP over pixels inside every pass"}}
+                      "same scene/camera/settings, scalar C++ restatement (oracle/), SAH BVH8 build untimed",
+            "seconds_per_sample_frame": best["one_thread"]["seconds_per_sample_frame"],
+            "all_cores": {"value": best["all_threads"]["value"], "unit": "Mpaths/s", "cores": cores,
+                          "seconds_per_sample_frame": best["all_threads"]["seconds_per_sample_frame"], "how": "OpenMP over pixels inside every pass"},
+            "builds": {"parity": parity, "speed": speed}}
 
 
 if __name__ == "__main__":

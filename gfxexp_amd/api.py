@@ -179,6 +179,21 @@ def exchange_desc(cfg, step, step_index, static_params, regir_params, buffer_ind
     return d
 
 
+def band_rows(height, world, rank):
+    """gfxh_band_rows: the row band of `rank` (whole 8-row tiles, remainder spread from rank 0)."""
+    b, e = C.c_uint32(), C.c_uint32()
+    if lib().gfxh_band_rows(C.c_uint32(height), C.c_uint32(world), C.c_uint32(rank), C.byref(b), C.byref(e)):
+        raise GfxError("gfxh_band_rows: rank outside the world")
+    return b.value, e.value
+
+
+def check_partition(cfg, world, max_motion_rows=0):
+    """gfxh_restir_check_partition: raises when a strip of this configuration is taller than the smallest band of `world`
+    ranks -- the same verdict on every rank, before anyone enters a collective."""
+    if lib().gfxh_restir_check_partition(C.byref(cfg), C.c_uint32(world), C.c_uint32(max_motion_rows)):
+        raise GfxError(lib().gfxh_restir_last_error().decode())
+
+
 def strip_rows(height, band_begin, band_end, rows):
     d = GfxhExchangeDesc()
     rc = lib().gfxh_strip_rows(C.c_uint32(height), C.c_uint32(band_begin), C.c_uint32(band_end), C.c_uint32(rows), C.byref(d))
@@ -222,7 +237,7 @@ HOST_ABI_SYMBOLS = [
     "gfxh_scene_get_material", "gfxh_scene_get_geom", "gfxh_scene_get_group", "gfxh_scene_get_instance",
     "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
     "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
-    "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_restir_frame_program", "gfxh_frame_step_exchange_desc",
+    "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_band_rows", "gfxh_restir_check_partition", "gfxh_restir_frame_program", "gfxh_frame_step_exchange_desc",
     "gfxh_rccl_unique_id", "gfxh_rccl_create", "gfxh_rccl_destroy", "gfxh_rccl_exchange", "gfxh_rccl_last_error", "gfxh_restir_create",
     "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
@@ -816,7 +831,13 @@ class RestirRenderer:
         return plan
 
     def set_exchange(self, fn, max_motion_rows=0):
-        """Install the strip-exchange callback of a band renderer: fn(stream, desc: GfxhExchangeDesc) -> None / raises."""
+        """Install the strip-exchange callback of a band renderer: fn(stream, desc: GfxhExchangeDesc) -> None / raises.
+        A callback that knows its world size (tilesplit.StripExchange) gets the partition checked here, on every rank
+        alike (gfxh_restir_check_partition)."""
+        world = getattr(fn, "world", None)
+        if world:
+            check_partition(self.cfg, int(world), max_motion_rows)
+
         def thunk(user, stream, desc):
             try:
                 fn(stream, desc.contents)

@@ -7,11 +7,14 @@
 //   counters         ncclAllReduce(sum, u32) in place (ReGIR cell-access counters: 32 KB)
 //   HDR bands        ncclAllGather of slabs sized for the tallest band into a staging buffer, then one hipMemcpyAsync
 //                    per remote band into the frame (bands differ by at most 8 rows)
+// GFX_RCCL_LIBRARY names the library to load instead of librccl.so.1 (another RCCL build; tests/native/rccl_stub.cpp, a
+// recording stand-in that lets the send / receive plan of ANY rank of ANY world size be checked in one process).
 // All operations are enqueued on the caller's stream.  bench.py and the tests use torch.distributed for the same
 // descriptors (gfxexp_amd/tilesplit.py StripExchange); both are driven by the same gfxh_exchange_desc.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -37,10 +40,16 @@ struct RcclApi {
     int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     bool load(std::string& err) {
         if (lib) return true;
-        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
-        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        void* h = nullptr;
+        const char* named = std::getenv("GFX_RCCL_LIBRARY");
+        if (named && *named) h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+        else {
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!h) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        bool complete = true;
+        auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) { err = std::string("librccl lacks ") + n; complete = false; } return p; };
         GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
         CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
@@ -51,7 +60,9 @@ struct RcclApi {
         AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
         AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
         Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
-        return Broadcast && GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && AllGather;
+        if (!complete) { dlclose(h); return false; }   // `lib` stays null: the next call tries again instead of running on null pointers
+        lib = h;
+        return true;
     }
 };
 RcclApi g_rccl;
@@ -82,12 +93,12 @@ int gfxh_rccl_create(const void* id128, int rank, int world, uint32_t height, gf
     *out = nullptr;
     if (!g_rccl.load(g_rcclError)) return 1;
     gfxh_rccl* c = new gfxh_rccl();
+    if (world < 1 || rank < 0 || rank >= world) { g_rcclError = "gfxh_rccl_create: rank outside the world"; delete c; return 1; }
     c->rank = rank; c->world = world;
-    const uint32_t tiles = (height + 7) / 8, base = tiles / world, extra = tiles % world;
-    uint32_t row = 0;
     for (int r = 0; r < world; ++r) {
-        const uint32_t h = (base + (static_cast<uint32_t>(r) < extra ? 1u : 0u)) * 8;
-        c->bandBegin.push_back(row); row = std::min(height, row + h); c->bandEnd.push_back(row);
+        uint32_t b = 0, e = 0;
+        gfxh_band_rows(height, static_cast<uint32_t>(world), static_cast<uint32_t>(r), &b, &e);
+        c->bandBegin.push_back(b); c->bandEnd.push_back(e);
     }
     ncclUniqueId id; std::memcpy(&id, id128, sizeof(id));
     if (g_rccl.CommInitRank(&c->comm, world, id, rank)) { g_rcclError = "ncclCommInitRank failed"; delete c; return 1; }
@@ -130,6 +141,13 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
         return err ? 1 : 0;
     }
     if (d->kind == GFXH_EXCHANGE_GATHER_BANDS) {
+        // the communicator was created for one partition of the frame; a renderer configured with other bands would
+        // have its rows gathered into the wrong place
+        if (d->bandBegin != c->bandBegin[c->rank] || d->bandEnd != c->bandEnd[c->rank]) {
+            g_rcclError = "gfxh_rccl_exchange: the renderer's band [" + std::to_string(d->bandBegin) + ", " + std::to_string(d->bandEnd) + ") is not rank " +
+                          std::to_string(c->rank) + "'s band [" + std::to_string(c->bandBegin[c->rank]) + ", " + std::to_string(c->bandEnd[c->rank]) + ") of gfxh_band_rows";
+            return 1;
+        }
         const gfxh_exchange_buffer& b = d->buffers[0];
         const size_t rowBytes = static_cast<size_t>(b.bytesPerPixel) * d->width;
         uint32_t maxRows = 0;
@@ -162,8 +180,16 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
         // counts of every rank (one all-gather of a u32 + a host round trip: the caller needs the total on the host anyway),
         // then per array an all-gather of slabs sized for the largest count and a compaction into rank order
         uint32_t* hostCounts = static_cast<uint32_t*>(d->counters);
-        const size_t need = 256 + 0;
-        if (c->stagingBytes < need) { if (c->staging) (void)hipFree(c->staging); if (hipMalloc(&c->staging, 1 << 20) != hipSuccess) return 1; c->stagingBytes = 1 << 20; }
+        // staging layout: [0, headBytes) the counts (world gathered + world own, u32), then the record slabs
+        const size_t headBytes = ((2 * sizeof(uint32_t) * static_cast<size_t>(c->world) + 255) / 256) * 256;
+        const size_t need = headBytes;
+        if (c->stagingBytes < need) {
+            if (c->staging) (void)hipFree(c->staging);
+            c->staging = nullptr; c->stagingBytes = 0;
+            const size_t first = std::max<size_t>(need, 1 << 20);
+            if (hipMalloc(&c->staging, first) != hipSuccess) { c->staging = nullptr; return 1; }
+            c->stagingBytes = first;
+        }
         uint32_t* dCounts = static_cast<uint32_t*>(c->staging);
         if (hipMemcpyAsync(dCounts + c->world + c->rank, &hostCounts[0], 4, hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
         if (g_rccl.AllGather(dCounts + c->world + c->rank, dCounts, 1, kNcclUint32, c->comm, stream)) return 1;
@@ -175,14 +201,14 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
         if (total > d->numCounters) { g_rcclError = "gfxh_rccl_exchange: more records than the arrays hold"; return 1; }
         for (uint32_t k = 0; k < d->numBuffers && most; ++k) {
             const size_t rec = d->buffers[k].bytesPerPixel, slab = rec * most;
-            const size_t bytes = 4096 + slab * c->world;
+            const size_t bytes = headBytes + slab * c->world;
             if (c->stagingBytes < bytes) {
                 if (hipStreamSynchronize(stream) != hipSuccess) return 1;
                 (void)hipFree(c->staging);
                 if (hipMalloc(&c->staging, bytes) != hipSuccess) { c->staging = nullptr; c->stagingBytes = 0; return 1; }
                 c->stagingBytes = bytes;
             }
-            char* slabs = static_cast<char*>(c->staging) + 4096;
+            char* slabs = static_cast<char*>(c->staging) + headBytes;
             char* base = static_cast<char*>(d->buffers[k].base);
             if (hipMemcpyAsync(slabs + slab * c->rank, base, rec * counts[c->rank], hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
             if (g_rccl.AllGather(slabs + slab * c->rank, slabs, slab, kNcclUint8, c->comm, stream)) return 1;

@@ -16,9 +16,12 @@
 //   -begin-pos|-end-pos x y z   -begin-roll|pitch|yaw  -end-roll|pitch|yaw deg   -begin-scale|-end-scale s   -freq f   -time t
 //   -inst n
 // Headless options (no counterpart; the reference takes these from its GUI):
-//   -size W H (1920 1080)   -frames N (1)   -renderer restir-biased|restir-unbiased|rearch-biased|rearch-unbiased|pt|regir
+//   -size W H (1920 1080)   -frames N (1)   -renderer restir-biased|restir-unbiased|rearch-biased|rearch-unbiased|pt|regir|nrc
 //   -animate (advance the instance controllers by 1/60 s per frame, :2249-2257)   -accumulate   -bump   -device k
 //   -out path (.exr / .pfm: HDR; .bmp / .ppm: tone-mapped SDR)   -dry-run (parse, build the scene on the host, print it, no GPU)
+// Neural radiance caching (-renderer nrc; neural_radiance_caching/neural_radiance_caching_main.cpp:755-790, defaults :458-460):
+//   -position-encoding tri-wave|hash-grid (hash-grid)   -num-hidden-layers n (2)   -learning-rate lr (1e-2)
+//   and, headless: -max-path-length n (5; 0 = unlimited, :1860-1861)   -no-train   -log10-radiance-scale s (0, :2240)
 // Textures are read by the host decoders of scene_builder.cpp (PPM / PGM / PFM / BMP / TGA); DDS / PNG / JPEG assets have to be
 // decoded offline (the image has no image libraries).
 #include <cmath>
@@ -81,6 +84,11 @@ struct Options {
     int renderer = GFXH_ORIGINAL_RESTIR_BIASED, device = 0;
     bool animate = false, accumulate = false, bump = false, dryRun = false;
     std::string out;
+    // neural radiance caching (neural_radiance_caching_main.cpp:458-460)
+    bool nrc = false, nrcTrain = true;
+    int positionEncoding = GFX_NRC_HASH_GRID;
+    uint32_t numHiddenLayers = 2, maxPathLength = 5;
+    float learningRate = 1e-2f, log10RadianceScale = 0.0f;
 };
 
 [[noreturn]] void fail(const char* what, const char* arg) {
@@ -183,9 +191,29 @@ Options parse(int argc, const char* argv[]) {
             else if (r == "rearch-unbiased") o.renderer = GFXH_REARCHITECTED_RESTIR_UNBIASED;
             else if (r == "pt") o.renderer = GFXH_PATH_TRACE_BASELINE;
             else if (r == "regir") o.renderer = GFXH_PATH_TRACE_REGIR;
+            else if (r == "nrc") o.nrc = true;
             else fail("unknown renderer:", argv[i + 1]);
             i += 1;
         }
+        // ---- neural_radiance_caching_main.cpp:755-790
+        else if (a == "-position-encoding") {
+            need(i, 1);
+            const std::string enc = argv[i + 1];
+            if (enc == "tri-wave") o.positionEncoding = GFX_NRC_TRIANGLE_WAVE;
+            else if (enc == "hash-grid") o.positionEncoding = GFX_NRC_HASH_GRID;
+            else fail("invalid position encoding:", argv[i + 1]);
+            i += 1;
+        }
+        else if (a == "-num-hidden-layers") { need(i, 1); o.numHiddenLayers = static_cast<uint32_t>(std::atoi(argv[i + 1])); i += 1; }
+        else if (a == "-learning-rate") {
+            need(i, 1);
+            o.learningRate = static_cast<float>(std::atof(argv[i + 1]));
+            if (!std::isfinite(o.learningRate)) fail("invalid value:", argv[i]);
+            i += 1;
+        }
+        else if (a == "-max-path-length") { need(i, 1); o.maxPathLength = static_cast<uint32_t>(std::atoi(argv[i + 1])); i += 1; }
+        else if (a == "-log10-radiance-scale") { need(i, 1); o.log10RadianceScale = static_cast<float>(std::atof(argv[i + 1])); i += 1; }
+        else if (a == "-no-train") o.nrcTrain = false;
         else if (a == "-animate") o.animate = true;
         else if (a == "-accumulate") o.accumulate = true;
         else if (a == "-bump") o.bump = true;
@@ -263,7 +291,9 @@ int main(int argc, const char* argv[]) {
                 " \"camera_orientation\": [%.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g], \"renderer\": %d, \"size\": [%u, %u], \"frames\": %u",
                 counts[0], counts[1], counts[2], counts[3], counts[4], gfxh_scene_num_textures(scene), controllers.size(),
                 bounds[0], bounds[1], bounds[2], bounds[3], bounds[4], bounds[5], o.camPos[0], o.camPos[1], o.camPos[2],
-                camM[0], camM[1], camM[2], camM[3], camM[4], camM[5], camM[6], camM[7], camM[8], o.renderer, o.width, o.height, o.frames);
+                camM[0], camM[1], camM[2], camM[3], camM[4], camM[5], camM[6], camM[7], camM[8], o.nrc ? -1 : o.renderer, o.width, o.height, o.frames);
+    if (o.nrc) std::printf(",\n \"nrc\": {\"position_encoding\": \"%s\", \"num_hidden_layers\": %u, \"learning_rate\": %.9g, \"max_path_length\": %u, \"train\": %s}",
+                           o.positionEncoding == GFX_NRC_HASH_GRID ? "hash-grid" : "tri-wave", o.numHiddenLayers, o.learningRate, o.maxPathLength, o.nrcTrain ? "true" : "false");
     std::printf(",\n \"instance_transforms\": [");
     for (uint32_t i = 0; i < counts[3]; ++i) {
         uint32_t group; float xfm[12];
@@ -280,6 +310,50 @@ int main(int argc, const char* argv[]) {
     if (gfx_ctx_create(o.device, &ctx)) fail("gfx_ctx_create:", gfx_last_error(nullptr));
     if (gfxh_scene_upload(scene, ctx)) fail("gfxh_scene_upload:", gfxh_last_error());
     for (const Controller& c : controllers) gfx_instance_set_dynamic(ctx, c.instSlot, 1);
+    auto animate_instances = [&]() {                                                  // :2249-2264
+        for (Controller& c : controllers) {
+            float xfm[12], nm[9];
+            c.transform(1.0 / 60.0, xfm, nm);
+            const float pre = preScaleOf[c.d.name];
+            for (int r = 0; r < 3; ++r) for (int col = 0; col < 3; ++col) xfm[4 * r + col] *= pre;
+            if (gfx_instance_set_transform_and_normal_matrix(ctx, c.instSlot, xfm, nm)) fail("gfx_instance_set_transform:", gfx_last_error(ctx));
+        }
+    };
+    std::vector<float> rgba(4ull * o.width * o.height);
+    gfxh_restir* renderer = nullptr;
+    gfxh_nrc* nrc = nullptr;
+    if (o.nrc) {
+        // neural_radiance_caching_main.cpp: NeuralRadianceCache::initialize(g_positionEncoding, g_numHiddenLayers, g_learningRate)
+        // (:1198), the frame loop :2225-2370 behind gfxh_nrc_render_frame
+        if (!o.envTexture.empty()) fail("-env-texture is not wired to the headless NRC renderer", nullptr);
+        gfxh_nrc_config cfg;
+        gfxh_nrc_default_config(&cfg, o.width, o.height);
+        cfg.positionEncoding = o.positionEncoding; cfg.numHiddenLayers = o.numHiddenLayers; cfg.learningRate = o.learningRate;
+        cfg.maxPathLength = o.maxPathLength; cfg.train = o.nrcTrain ? 1u : 0u;
+        cfg.radianceScale = std::pow(10.0f, o.log10RadianceScale);                    // :2240
+        cfg.enableAccumulation = o.accumulate ? 1u : 0u;
+        for (int k = 0; k < 3; ++k) cfg.camera.position[k] = static_cast<float>(o.camPos[k]);
+        for (int k = 0; k < 9; ++k) cfg.camera.orientation[k] = static_cast<float>(camM[k]);
+        for (int k = 0; k < 3; ++k) { cfg.sceneAabbMin[k] = bounds[k]; cfg.sceneAabbMax[k] = bounds[3 + k]; }   // scene.initialSceneAabb (:1139)
+        if (gfxh_nrc_create(ctx, &cfg, &nrc)) fail("gfxh_nrc_create:", gfxh_nrc_last_error());
+        float loss = 0.0f;
+        for (uint32_t frame = 0; frame < o.frames; ++frame) {
+            if (o.animate && frame > 0 && !controllers.empty()) {
+                animate_instances();
+                if (gfxh_nrc_rebuild_accel(nrc, nullptr)) fail("gfxh_nrc_rebuild_accel:", gfxh_nrc_last_error());
+            }
+            // the loss is read back (a host wait for the training stream) on the last frame only: on the others the four
+            // training steps stay overlapped with the next frame
+            if (gfxh_nrc_render_frame(nrc, nullptr, frame + 1 == o.frames ? &loss : nullptr)) fail("gfxh_nrc_render_frame:", gfxh_nrc_last_error());
+        }
+        uint32_t numTrainingData = 0, tileSize[2] = { 0, 0 }, numQueries = 0;
+        gfxh_nrc_stats(nrc, &numTrainingData, tileSize, &numQueries);
+        (void)gfxh_nrc_network(nrc);                                                  // joins the training stream: `loss` is final
+        std::printf(",\n \"nrc_last_frame\": {\"training_records\": %u, \"tile_size\": [%u, %u], \"inference_queries\": %u, \"loss\": %.9g}",
+                    numTrainingData, tileSize[0], tileSize[1], numQueries, loss);
+        if (gfx_read_device(ctx, gfxh_nrc_beauty_buffer(nrc), rgba.data(), rgba.size() * sizeof(float))) fail("gfx_read_device:", gfx_last_error(ctx));
+    }
+    else {
     gfxh_restir_config cfg;
     gfxh_restir_default_config(&cfg, o.width, o.height, o.renderer);
     for (int k = 0; k < 3; ++k) cfg.camera.position[k] = static_cast<float>(o.camPos[k]);
@@ -287,7 +361,6 @@ int main(int argc, const char* argv[]) {
     cfg.enableAccumulation = o.accumulate ? 1u : 0u;
     cfg.enableBumpMapping = o.bump ? 1u : 0u;
     for (int k = 0; k < 3; ++k) { cfg.regirAabbMin[k] = bounds[k]; cfg.regirAabbMax[k] = bounds[3 + k]; }
-    gfxh_restir* renderer = nullptr;
     if (gfxh_restir_create(ctx, &cfg, &renderer)) fail("gfxh_restir_create:", gfxh_restir_last_error());
     if (!o.envTexture.empty()) {
         gfxh_scene* tmp = gfxh_scene_create();
@@ -299,20 +372,14 @@ int main(int argc, const char* argv[]) {
         gfxh_scene_destroy(tmp);
     }
     for (uint32_t frame = 0; frame < o.frames; ++frame) {
-        if (o.animate && frame > 0 && !controllers.empty()) {                         // :2249-2264
-            for (Controller& c : controllers) {
-                float xfm[12], nm[9];
-                c.transform(1.0 / 60.0, xfm, nm);
-                const float pre = preScaleOf[c.d.name];
-                for (int r = 0; r < 3; ++r) for (int col = 0; col < 3; ++col) xfm[4 * r + col] *= pre;
-                if (gfx_instance_set_transform_and_normal_matrix(ctx, c.instSlot, xfm, nm)) fail("gfx_instance_set_transform:", gfx_last_error(ctx));
-            }
+        if (o.animate && frame > 0 && !controllers.empty()) {
+            animate_instances();
             if (gfxh_restir_rebuild_accel(renderer, nullptr)) fail("gfxh_restir_rebuild_accel:", gfxh_restir_last_error());
         }
         if (gfxh_restir_render_frame(renderer, nullptr)) fail("gfxh_restir_render_frame:", gfxh_restir_last_error());
     }
-    std::vector<float> rgba(4ull * o.width * o.height);
     if (gfx_read_device(ctx, gfxh_restir_beauty_buffer(renderer), rgba.data(), rgba.size() * sizeof(float))) fail("gfx_read_device:", gfx_last_error(ctx));
+    }
     double sum[3] = { 0, 0, 0 };
     for (size_t p = 0; p < static_cast<size_t>(o.width) * o.height; ++p) for (int k = 0; k < 3; ++k) sum[k] += rgba[4 * p + k];
     const double n = static_cast<double>(o.width) * o.height;
@@ -326,7 +393,8 @@ int main(int argc, const char* argv[]) {
         std::printf(", \"out\": \"%s\"", o.out.c_str());
     }
     std::printf("}\n");
-    gfxh_restir_destroy(renderer);
+    if (renderer) gfxh_restir_destroy(renderer);
+    if (nrc) gfxh_nrc_destroy(nrc);
     gfxh_scene_destroy(scene);
     gfx_ctx_destroy(ctx);
     return 0;

@@ -235,6 +235,49 @@ int gfxh_restir_set_exchange(gfxh_restir* r, gfxh_exchange_fn fn, void* user, ui
     return 0;
 }
 
+int gfxh_band_rows(uint32_t height, uint32_t world, uint32_t rank, uint32_t* begin, uint32_t* end) {
+    if (world == 0 || rank >= world) return 1;
+    const uint32_t tiles = (height + 7) / 8, base = tiles / world, extra = tiles % world;
+    uint32_t row = 0;
+    for (uint32_t r = 0; r <= rank; ++r) {
+        const uint32_t h = (base + (r < extra ? 1u : 0u)) * 8;
+        *begin = row; row = std::min(height, row + h); *end = row;
+    }
+    return 0;
+}
+
+// Strip feasibility as a decision every rank takes identically: the tallest strip any frame of this configuration
+// exchanges (new sequence or not) against the SMALLEST band of the partition.  gfxh_strip_rows alone looks at the
+// calling rank's band: with 1080 rows over 8 ranks (7 x 136 + 128) a 130-row strip passes on ranks 0-6 and fails
+// on rank 7, whose neighbours would already be inside the collective.
+int gfxh_restir_check_partition(const gfxh_restir_config* cfgp, uint32_t world, uint32_t maxMotionRows) {
+    if (world <= 1) return 0;
+    uint32_t minBand = 0xFFFFFFFFu;
+    for (uint32_t rank = 0; rank < world; ++rank) {
+        uint32_t b = 0, e = 0;
+        if (gfxh_band_rows(cfgp->height, world, rank, &b, &e)) return 1;
+        minBand = std::min(minBand, e - b);
+    }
+    if (minBand == 0) { g_driverError = "gfxh_restir_check_partition: more ranks than 8-row tiles"; return 1; }
+    gfxh_restir_config cfg = *cfgp;
+    // any interior band will do: the program's exchange rows do not depend on where the band lies
+    gfxh_band_rows(cfg.height, world, 0, &cfg.rowBegin, &cfg.rowEnd);
+    const uint32_t unbiased = cfg.renderer == GFXH_ORIGINAL_RESTIR_UNBIASED || cfg.renderer == GFXH_REARCHITECTED_RESTIR_UNBIASED;
+    uint32_t tallest = 0;
+    for (int newSequence = 0; newSequence < 2; ++newSequence) {
+        gfxh_frame_step steps[64];
+        uint32_t n = 0, a = 0, c = 0;
+        (void)gfxh_restir_frame_program(&cfg, 1, maxMotionRows, newSequence, 1, 0, unbiased, steps, 64, &n, &a, &c);
+        for (uint32_t k = 0; k < n; ++k) if (steps[k].op == GFXH_STEP_EXCHANGE_STRIPS) tallest = std::max(tallest, steps[k].exchangeRows);
+    }
+    if (tallest > minBand) {
+        g_driverError = "gfxh_restir_check_partition: an exchange strip of " + std::to_string(tallest) + " rows (spatial radius, motion rows) is taller than the smallest band ("
+                        + std::to_string(minBand) + " rows of " + std::to_string(cfg.height) + " over " + std::to_string(world) + " ranks): fewer ranks, a smaller radius or fewer motion rows";
+        return 1;
+    }
+    return 0;
+}
+
 int gfxh_restir_band_plan(gfxh_restir* r, gfxh_band_plan* out) {
     const gfxh_restir_config& cfg = r->cfg;
     const bool whole = cfg.rowBegin == 0 && cfg.rowEnd == 0;
@@ -474,12 +517,47 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     if (gfx_lights_build_instances(ctx, stream, bufferIndex)) { g_driverError = gfx_last_error(ctx); return 1; }
 
     const bool newSequence = frameIndex == 0 || r->resetRequested;     // :2311 (no resize in a headless run)
-    r->resetRequested = false;
     const bool viewMoved = r->viewMoved;
-    r->viewMoved = false;
     const bool firstAccumFrame = !cfg.enableAccumulation || newSequence || viewMoved;   // :2312-2313 (animate || cameraIsActuallyMoving)
-    if (firstAccumFrame) r->numAccumFrames = 0;
-    else r->numAccumFrames = std::min(r->numAccumFrames + 1, 1u << cfg.log2MaxNumAccums);
+    const uint32_t numAccumFrames = firstAccumFrame ? 0u : std::min(r->numAccumFrames + 1, 1u << cfg.log2MaxNumAccums);
+
+    // ---- everything that can refuse the frame is decided before any renderer state changes, so a caller that fixes the
+    // configuration and retries gets the frame it would have got the first time.  The decisions below depend on the
+    // configuration and on calls every rank of a band split makes alike (camera, rebuilds), never on this rank's own band
+    // -- except the strip-height test of the program, which gfxh_restir_check_partition takes for all ranks at install time.
+    const bool wholeFrame = cfg.rowBegin == 0 && cfg.rowEnd == 0;
+    const bool strips = r->exchange != nullptr && !wholeFrame;
+    const bool useUnbiased = cfg.renderer == GFXH_ORIGINAL_RESTIR_UNBIASED || cfg.renderer == GFXH_REARCHITECTED_RESTIR_UNBIASED;
+    if (!wholeFrame && !strips) {
+        // halo recompute: the halo comes from the neighbours' bands, which tilesplit / gfxh_rccl cut within 8 rows of this one
+        gfxh_band_plan plan;
+        gfxh_restir_band_plan(r, &plan);
+        if (plan.haloRows + 8 > cfg.rowEnd - cfg.rowBegin && plan.haloRows > 0 && !(cfg.rowBegin == 0 && cfg.rowEnd >= cfg.height)) {
+            g_driverError = "gfxh_restir_render_frame: the halo (radius x spatial passes) is taller than a neighbour's band; "
+                            "install a strip exchange (gfxh_restir_set_exchange) or use fewer ranks";
+            return 1;
+        }
+    }
+    // A strip-exchange band renderer moves `maxMotionRows` rows of the previous frame's state across its seams for the
+    // temporal pass.  With none, a frame that follows a camera or instance move would silently read stale rows there --
+    // refuse it.  Not a concern of a frame that reads no previous frame (new sequence, temporal reuse off) or of the
+    // halo-recompute scheme, whose refreshed halo (radius x passes rows) is what its temporal pass may reach into.
+    if (strips && viewMoved && r->maxMotionRows == 0 && cfg.enableTemporalReuse && !newSequence) {
+        g_driverError = "gfxh_restir_render_frame: the camera or an instance moved, but this band renderer exchanges no motion rows "
+                        "(gfxh_restir_set_exchange with maxMotionRows > 0)";
+        return 1;
+    }
+    gfxh_frame_step steps[64];
+    uint32_t numSteps = 0, newLastRes = 0, newLastBase = 0;
+    if (gfxh_restir_frame_program(&cfg, strips ? 1 : 0, r->maxMotionRows, newSequence ? 1 : 0, r->lastReservoirIndex, r->lastSpatialNeighborBaseIndex,
+                                  useUnbiased, steps, 64, &numSteps, &newLastRes, &newLastBase)) {
+        g_driverError = "gfxh_restir_render_frame: the exchange strip is taller than the band (fewer ranks or a smaller radius; "
+                        "gfxh_restir_check_partition decides this for all ranks at once)";
+        return 1;
+    }
+    r->resetRequested = false;
+    r->viewMoved = false;
+    r->numAccumFrames = numAccumFrames;
 
     fp.travHandle = r->accel;
     fp.numAccumFrames = r->numAccumFrames;
@@ -504,39 +582,19 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     fp.enableBumpMapping = cfg.enableBumpMapping;
     fp.useSolidAngleSampling = 0;
 
-    // the frame as a program (gfxh_restir_frame_program): passes with their row ranges and index bookkeeping, and -- for a
-    // band renderer with an exchange callback -- the points where rows owned by other ranks have to arrive
-    const bool wholeFrame = cfg.rowBegin == 0 && cfg.rowEnd == 0;
-    const bool strips = r->exchange != nullptr && !wholeFrame;
-    if (!wholeFrame && !strips) {
-        // halo recompute: the halo comes from the neighbours' bands, which tilesplit / gfxh_rccl cut within 8 rows of this one
-        gfxh_band_plan plan;
-        gfxh_restir_band_plan(r, &plan);
-        if (plan.haloRows + 8 > cfg.rowEnd - cfg.rowBegin && plan.haloRows > 0 && !(cfg.rowBegin == 0 && cfg.rowEnd >= cfg.height)) {
-            g_driverError = "gfxh_restir_render_frame: the halo (radius x spatial passes) is taller than a neighbour's band; "
-                            "install a strip exchange (gfxh_restir_set_exchange) or use fewer ranks";
-            return 1;
-        }
-    }
-    if (!wholeFrame && viewMoved && (!strips || r->maxMotionRows == 0)) {
-        g_driverError = "gfxh_restir_render_frame: the camera or an instance moved, but this band renderer exchanges no motion rows "
-                        "(gfxh_restir_set_exchange with maxMotionRows > 0)";
-        return 1;
-    }
-    gfxh_frame_step steps[64];
-    uint32_t numSteps = 0, newLastRes = 0, newLastBase = 0;
-    if (gfxh_restir_frame_program(&cfg, strips ? 1 : 0, r->maxMotionRows, newSequence ? 1 : 0, r->lastReservoirIndex, r->lastSpatialNeighborBaseIndex,
-                                  fp.useUnbiasedEstimator, steps, 64, &numSteps, &newLastRes, &newLastBase)) {
-        g_driverError = "gfxh_restir_render_frame: the exchange strip is taller than the band (fewer ranks or a smaller radius)";
-        return 1;
-    }
+    // the frame as a program (gfxh_restir_frame_program, built above): passes with their row ranges and index bookkeeping,
+    // and -- for a band renderer with an exchange callback -- the points where rows owned by other ranks have to arrive
     const uint32_t W = cfg.width, H = cfg.height;
 #define DRV_GFX(call) do { if (call) { g_driverError = gfx_last_error(ctx); return 1; } } while (0)
     // G-buffer pass, pipelined under the previous frame when nothing forbids it: jittering advances the pixel
-    // RNGs the previous frame's passes are still drawing from, and a band renderer's exchanges have their own
-    // ordering with the caller's stream.
+    // RNGs the previous frame's passes are still drawing from.  A strip-exchange band renderer pipelines too: the pass
+    // writes only this band's rows of the OTHER G-buffer half, the exchange that follows it is issued on the caller's
+    // stream after that stream has waited for the pass, and the strips a neighbour sends into this frame's half never
+    // touch the half being written.  (A band's launches are too small to fill the GPU -- 261 k rays on 262 k traversal
+    // lanes at 8 bands -- so running the next G-buffer pass underneath the reuse passes is worth more there than on the
+    // whole frame: profiles/r03_band_compute_bound.json.)  The halo-recompute scheme stays serial.
     hipStream_t main = static_cast<hipStream_t>(stream);
-    const bool pipelined = r->pipelineFrames && !cfg.enableJittering && wholeFrame;
+    const bool pipelined = r->pipelineFrames && !cfg.enableJittering && (wholeFrame || strips);
     if (cfg.renderer == GFXH_PATH_TRACE_REGIR) DRV_GFX(gfx_regir_set_params(ctx, &r->regir));
     for (uint32_t k = 0; k < numSteps; ++k) {
         const gfxh_frame_step& st = steps[k];

@@ -136,13 +136,18 @@ class StripExchange:
                     per exchange point, stream-ordered after the pass that produced the rows (the collective stream
                     waits for torch's current stream, which is the stream the renderer launches on)
       counters      all_reduce(sum) on the u32 array (as int32: wrap-around addition is the same)
-      HDR bands     all_gather_into_tensor of slabs sized for the tallest band.  Asynchronous: nothing of the next frame
-                    reads the other ranks' pixels, so the collective runs underneath the next frame's kernels and the
-                    received bands are put into the frame at the next gather -- or by finish() after the last frame.
+      HDR bands     all_gather_into_tensor of slabs sized for the tallest band.  Synchronous by default, like the C++
+                    twin: when render_frame returns, the frame buffer holds every rank's rows of THIS frame (stream-ordered
+                    on RCCL), so any reader -- tone map, save, MSE, copy_to_linear -- sees a complete frame.
+                    async_gather=True (bench.py): nothing of the next frame reads the other ranks' pixels, so the
+                    collective is left running underneath the next frame's kernels and the received bands are put into the
+                    frame at the NEXT gather -- until then the other ranks' rows are one frame old -- or by finish(), which
+                    a caller in this mode must invoke (with the renderer's stream current) before it reads the frame.
     The C++ twin is gfxh_rccl_exchange (csrc/host/rccl_exchange.cpp); both consume the same descriptors."""
 
-    def __init__(self, dist, rank, world, height, view, device="cpu"):
+    def __init__(self, dist, rank, world, height, view, device="cpu", async_gather=False):
         self.dist, self.rank, self.world, self.device = dist, rank, world, device
+        self.async_gather = bool(async_gather)
         self._view, self._views = view, {}
         self.bands = band_rows(height, world)
         self.bytes_moved = 0
@@ -203,6 +208,8 @@ class StripExchange:
             send[:(e0 - s0) * row_bytes].copy_(frame[s0 * row_bytes:e0 * row_bytes])
             work = dist.all_gather_into_tensor(recv, send, async_op=True)
             self._pending = (work, frame, row_bytes, slab)
+            if not self.async_gather:
+                self.finish()
             return
         if d.kind == api.EXCHANGE_GATHER_RECORDS:
             # NRC band renderers: variable-length record arrays of every rank, concatenated in rank order on every rank

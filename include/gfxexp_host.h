@@ -230,6 +230,16 @@ int gfxh_restir_set_exchange(gfxh_restir* r, gfxh_exchange_fn fn, void* user, ui
  * the send* / recv* members of `out` (nothing is sent above row 0 / below the last row).  Returns 1 when `rows`
  * exceeds the band height of this rank: the strip would have to come from a rank further away. */
 int gfxh_strip_rows(uint32_t height, uint32_t bandBegin, uint32_t bandEnd, uint32_t rows, gfxh_exchange_desc* out);
+/* The row band of `rank` when a frame of `height` rows is split over `world` ranks: whole 8-row tiles, the remainder
+ * spread from rank 0 (1080 rows / 8 ranks = 7 x 136 + 128).  The one partition every part of this library uses
+ * (gfxh_rccl_create, tilesplit.band_rows, bench.py). */
+int gfxh_band_rows(uint32_t height, uint32_t world, uint32_t rank, uint32_t* bandBegin, uint32_t* bandEnd);
+/* Whether `cfg` can be split over `world` ranks with strip exchanges of up to `maxMotionRows` motion rows: the tallest strip
+ * of any frame against the SMALLEST band of the partition.  A pure function of its arguments, so every rank reaches the
+ * same verdict -- call it where the exchange is installed (tilesplit.StripExchange, bench.py and restir_di_headless do);
+ * the per-frame test inside gfxh_restir_render_frame only sees the calling rank's band.  1 + gfxh_restir_last_error()
+ * when it does not fit. */
+int gfxh_restir_check_partition(const gfxh_restir_config* cfg, uint32_t world, uint32_t maxMotionRows);
 /* An exchange callback over RCCL for C++ host programs (librccl is loaded with dlopen on first use; one process per
  * GPU).  Create with the ncclUniqueId bytes rank 0 obtained from gfxh_rccl_unique_id and distributed its own way. */
 typedef struct gfxh_rccl gfxh_rccl;

@@ -96,17 +96,58 @@ GFX_VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("tex
 assert GFX_VERTEX_DTYPE.itemsize == 44
 
 _lib = None
+_fast_lib = None
+PARITY_FLAGS = "-std=c++17 -O2 -march=x86-64-v3 -ffp-contract=off -fno-fast-math -fopenmp"      # oracle/Makefile
+FAST_FLAGS = "-std=c++17 -O3 -march=native -fopenmp"      # BASELINE.md section 2 "speed mode": contraction allowed (GNU default)
+
+
+def _declare(L):
+    L.orc_scene_create.restype = C.c_void_p
+    L.orc_version.restype = C.c_char_p
+    L.orc_max_threads.restype = C.c_int
+    return L
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.orc_scene_create.restype = C.c_void_p
-        _lib.orc_version.restype = C.c_char_p
-        _lib.orc_max_threads.restype = C.c_int
+        _lib = _declare(C.CDLL(_LIB_PATH))
     return _lib
+
+
+def _host_id():
+    try:
+        with open("/proc/cpuinfo") as f:
+            lines = [ln for ln in f if ln.startswith(("model name", "flags"))][:2]
+        return "".join(lines)
+    except OSError:
+        return "unknown"
+
+
+def build_fast(force=False):
+    """The SPEED build of the same sources for bench.py's cpu_baseline: g++ -O3 -march=native, contraction allowed.  Its
+    results are NOT the parity contract (fused multiply-adds round differently) -- nothing compares against it.
+    -march=native binds the binary to the machine that compiled it, so it is built where it runs (5 s) and rebuilt when
+    the host CPU differs from the one in its stamp."""
+    path = os.path.join(_HERE, "liboracle_fast.so")
+    stamp = path + ".host"
+    want = FAST_FLAGS + "\n" + _host_id()
+    if not force and os.path.exists(path) and os.path.exists(stamp) and open(stamp).read() == want \
+            and os.path.getmtime(path) >= max(os.path.getmtime(os.path.join(_HERE, f)) for f in os.listdir(_HERE) if f.endswith((".h", ".cpp"))):
+        return path
+    subprocess.check_call(["g++"] + FAST_FLAGS.split() + ["-fPIC", "-Wall", "-Wno-unused-function", "-shared", "-o", path,
+                                                         os.path.join(_HERE, "orc_capi.cpp")])
+    with open(stamp, "w") as f:
+        f.write(want)
+    return path
+
+
+def lib_fast():
+    global _fast_lib
+    if _fast_lib is None:
+        _fast_lib = _declare(C.CDLL(build_fast()))
+    return _fast_lib
 
 
 def _p(a):
@@ -116,8 +157,8 @@ def _p(a):
 class OracleScene:
     """Scene + world BVH + passes of the CPU restatement."""
 
-    def __init__(self, threads=None):
-        self.L = lib()
+    def __init__(self, threads=None, library=None):
+        self.L = library if library is not None else lib()
         self.h = C.c_void_p(self.L.orc_scene_create())
         self.keep = []
         self.set_threads(threads if threads else min(8, self.L.orc_max_threads()))

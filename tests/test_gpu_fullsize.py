@@ -24,6 +24,92 @@ def _window_mask(x0, y0, x1, y1):
     return m.reshape(-1)
 
 
+# The workloads bench.py times.  "textured" is its default (albedo / smoothness / normal maps with bump mapping on, float
+# emittance maps on the signs), "plain" is --plain (the round-1 constant-colour scene), "cluttered" is --cluttered
+# (textured + trees of leaf cards, cables, railings).
+WORKLOADS = {"plain": dict(textured=False, cluttered=False, bump=0),
+             "textured": dict(textured=True, cluttered=False, bump=1),
+             "cluttered": dict(textured=True, cluttered=True, bump=1)}
+BASE_INSTANCES = 2745          # instances of the street without the clutter; trees / cables / railings come after them
+
+
+def _scene(workload):
+    w = WORKLOADS[workload]
+    return util.bench_street(textured=w["textured"], cluttered=w["cluttered"])
+
+
+_windows = {}
+
+
+def _choose_window(workload, hs, size=(80, 40)):
+    """An 8-aligned window of the bench frame that shows what the workload adds: for the textured street at least one
+    sign (a material with an emittance MAP) and a bump-mapped facade / ground / crate (a material with a normal map); for
+    the cluttered street also leaf cards / cables / railings.  Found on the GPU's own primary-hit G-buffer (which the
+    test then compares with the oracle inside the window like every other buffer); the plain street keeps the fixed
+    window of round 2."""
+    if workload == "plain":
+        return (900, 560, 900 + size[0], 560 + size[1])
+    if (workload, size) in _windows:
+        return _windows[(workload, size)]
+    import torch
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    ctx.lights_build_static()
+    dev = util.DeviceBuffers(util.PixelBuffers(W, H))
+    cam = api.make_camera(W, H, **CAM)
+    stream = torch.cuda.current_stream().cuda_stream
+    f = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, W, H, cam, travHandle=accel, frameIndex=0, bufferIndex=0, resetFlowBuffer=1)
+    ctx.lights_build_instances(stream)
+    ctx.restir_set_params(dev.static_params(), f, 0, 0, stream)
+    ctx.restir_launch(api.PASS_SETUP_GBUFFERS, W, H, stream)
+    got = dev.download()
+    mats = hs.materials()
+    sign_mat = np.array([m.texEmittance != 0 for m in mats] + [False])
+    bump_mat = np.array([m.texNormal != 0 for m in mats] + [False])
+    inst = got["gb0_0"]["instSlot"].reshape(H, W)
+    surface = inst != 0xFFFFFFFF
+    mat = np.where(surface, got["gb3_0"]["matSlot"].reshape(H, W), len(mats)).astype(np.int64)
+    layers = [sign_mat[mat], bump_mat[mat]]
+    need = [24, 600]
+    if WORKLOADS[workload]["cluttered"]:
+        layers.append(surface & (inst >= BASE_INSTANCES))
+        need.append(200)
+    ww, wh = size
+    sums = []
+    for layer in layers:                                   # window sums on the 8-pixel grid through an integral image
+        ii = np.zeros((H + 1, W + 1), np.int64)
+        ii[1:, 1:] = np.cumsum(np.cumsum(layer.astype(np.int64), 0), 1)
+        ys, xs = np.arange(0, H - wh + 1, 8), np.arange(0, W - ww + 1, 8)
+        sums.append(ii[ys[:, None] + wh, xs[None, :] + ww] - ii[ys[:, None], xs[None, :] + ww] - ii[ys[:, None] + wh, xs[None, :]] + ii[ys[:, None], xs[None, :]])
+    ok = np.ones_like(sums[0], bool)
+    for ssum, n in zip(sums, need):
+        ok &= ssum >= n
+    assert ok.any(), "no window of the %s frame shows %s" % (workload, "signs, bump-mapped surfaces" + (", clutter" if len(need) > 2 else ""))
+    ys, xs = np.nonzero(ok)
+    # the candidate closest to the frame centre, away from the frame border (the reuse margins stay inside the image)
+    cy, cx = ys * 8 + wh / 2 - H / 2, xs * 8 + ww / 2 - W / 2
+    k = int(np.argmin(cx * cx + cy * cy))
+    win = (int(xs[k]) * 8, int(ys[k]) * 8, int(xs[k]) * 8 + ww, int(ys[k]) * 8 + wh)
+    _windows[(workload, size)] = win
+    return win
+
+
+def _assert_window_shows_the_workload(workload, hs, gb0, gb3, window):
+    """The oracle's own G-buffer inside the window holds a sign, a bump-mapped surface and (cluttered) clutter."""
+    if workload == "plain":
+        return
+    mats = hs.materials()
+    x0, y0, x1, y1 = window
+    inst = gb0["instSlot"].reshape(H, W)[y0:y1, x0:x1]
+    mat = gb3["matSlot"].reshape(H, W)[y0:y1, x0:x1][inst != 0xFFFFFFFF]
+    used = set(int(m) for m in np.unique(mat))
+    assert any(mats[m].texEmittance for m in used), "no emittance-mapped sign inside the window"
+    assert any(mats[m].texNormal for m in used), "no bump-mapped surface inside the window"
+    if WORKLOADS[workload]["cluttered"]:
+        assert ((inst != 0xFFFFFFFF) & (inst >= BASE_INSTANCES)).sum() > 100, "no leaf cards / cables / railings inside the window"
+
+
 def _pick(arr, mask, n):
     a = np.asarray(arr)
     if a.ndim >= 2 and a.shape[0] == 3 and a.shape[1] == n:      # reservoir planes [3][n][4]
@@ -31,11 +117,18 @@ def _pick(arr, mask, n):
     return a[mask]
 
 
+@pytest.mark.parametrize("workload", ["plain", "textured", "cluttered"])
 @pytest.mark.parametrize("config", ["configs[2]: biased", "configs[4]: unbiased + 2048x1024 environment map"])
-def test_window_of_the_full_frame_matches_the_oracle(built_lib, config):
+def test_window_of_the_full_frame_matches_the_oracle(built_lib, config, workload):
+    with util.frame_overrides(enableBumpMapping=WORKLOADS[workload]["bump"]):
+        _window_of_the_full_frame(config, workload)
+
+
+def _window_of_the_full_frame(config, workload):
     import torch
     unbiased = "unbiased" in config
-    hs = util.bench_street()
+    hs = _scene(workload)
+    inner = _choose_window(workload, hs)
     ctx = api.Context(0)
     hs.upload(ctx)
     accel = ctx.accel_build()
@@ -55,7 +148,6 @@ def test_window_of_the_full_frame_matches_the_oracle(built_lib, config):
     s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
     stream = torch.cuda.current_stream().cuda_stream
     n = W * H
-    inner = (900, 560, 980, 600)                       # street level, left of the frame centre: lamps, facades, props
     radius = 20
     passes, nb = (1, 3) if unbiased else (2, 5)        # restir_di_main.cpp:1965-1967
     spatial = api.PASS_SPATIAL_UNBIASED if unbiased else api.PASS_SPATIAL_BIASED
@@ -102,6 +194,7 @@ def test_window_of_the_full_frame_matches_the_oracle(built_lib, config):
     assert not diffs, "\n".join(diffs)
     beauty = pb_cpu.beauty.reshape(H, W, 4)[inner[1]:inner[3], inner[0]:inner[2], :3]
     assert np.isfinite(beauty).all() and beauty.mean() > 1e-4     # the window is lit, not background
+    _assert_window_shows_the_workload(workload, hs, pb_cpu.gb0[1], pb_cpu.gb3[1], inner)
 
 
 def _render(frames, serial=False, band=None, monkeypatch=None):
@@ -132,11 +225,18 @@ def test_full_size_frames_are_deterministic_and_pipelining_changes_nothing(built
     assert np.isfinite(a).all() and a[:, :3].mean() > 1e-3
 
 
-def test_path_tracer_window_of_the_full_frame_matches_the_oracle(built_lib):
+@pytest.mark.parametrize("workload", ["plain", "textured"])
+def test_path_tracer_window_of_the_full_frame_matches_the_oracle(built_lib, workload):
     """Baseline path tracer (max path length 5) on the bench scene at 1920x1080: paths never read a neighbour's
     state, so the oracle's window needs no margin; two frames with accumulation."""
+    with util.frame_overrides(enableBumpMapping=WORKLOADS[workload]["bump"]):
+        _path_tracer_window(workload)
+
+
+def _path_tracer_window(workload):
     import torch
-    hs = util.bench_street()
+    hs = _scene(workload)
+    window = _choose_window(workload, hs, (128, 64)) if workload != "plain" else (880, 540, 1008, 604)
     ctx = api.Context(0)
     hs.upload(ctx)
     accel = ctx.accel_build()
@@ -148,7 +248,6 @@ def test_path_tracer_window_of_the_full_frame_matches_the_oracle(built_lib):
     dev = util.DeviceBuffers(pb_init)
     s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
     stream = torch.cuda.current_stream().cuda_stream
-    window = (880, 540, 1008, 604)
     mask = _window_mask(*window)
     diffs = []
     for frame in range(2):
@@ -169,15 +268,23 @@ def test_path_tracer_window_of_the_full_frame_matches_the_oracle(built_lib):
     assert not diffs, "\n".join(diffs)
     beauty = pb_cpu.beauty.reshape(H, W, 4)[window[1]:window[3], window[0]:window[2], :3]
     assert np.isfinite(beauty).all() and beauty.mean() > 1e-4
+    _assert_window_shows_the_workload(workload, hs, pb_cpu.gb0[1], pb_cpu.gb3[1], window)
 
 
+@pytest.mark.parametrize("workload", ["plain", "textured"])
 @pytest.mark.parametrize("unbiased", [False, True])
-def test_rearchitected_window_of_the_full_frame_matches_the_oracle(built_lib, unbiased):
+def test_rearchitected_window_of_the_full_frame_matches_the_oracle(built_lib, unbiased, workload):
+    with util.frame_overrides(enableBumpMapping=WORKLOADS[workload]["bump"]):
+        _rearchitected_window(unbiased, workload)
+
+
+def _rearchitected_window(unbiased, workload):
     """Rearchitected ReSTIR at 1920x1080 on the bench scene: the 131072 pre-sampled lights are compared in full, the
     per-pixel passes on an 8-aligned window plus a 48-pixel margin (frame 1's temporal and spatiotemporal
     neighbours lie within 20 pixels of a pixel; frame 0 reads no neighbour)."""
     import torch
-    hs = util.bench_street()
+    hs = _scene(workload)
+    inner = _choose_window(workload, hs) if workload != "plain" else (896, 560, 976, 600)
     ctx = api.Context(0)
     hs.upload(ctx)
     accel = ctx.accel_build()
@@ -189,7 +296,6 @@ def test_rearchitected_window_of_the_full_frame_matches_the_oracle(built_lib, un
     dev = util.DeviceBuffers(pb_init)
     s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
     stream = torch.cuda.current_stream().cuda_stream
-    inner = (896, 560, 976, 600)
     region = (inner[0] - 48, inner[1] - 48, inner[2] + 48, inner[3] + 48)
     mask = _window_mask(*inner)
     n = W * H
@@ -222,7 +328,13 @@ def test_rearchitected_window_of_the_full_frame_matches_the_oracle(built_lib, un
     assert not diffs, "\n".join(diffs)
 
 
-def test_nrc_window_of_the_full_frame_matches_the_oracle(built_lib):
+@pytest.mark.parametrize("workload", ["plain", "textured"])
+def test_nrc_window_of_the_full_frame_matches_the_oracle(built_lib, workload):
+    with util.frame_overrides(enableBumpMapping=WORKLOADS[workload]["bump"]):
+        _nrc_window(workload)
+
+
+def _nrc_window(workload):
     """BASELINE configs[3] at its full size: the NRC path tracer (tile / training-path selection, radiance queries,
     terminal infos, per-frame contribution) at 1920x1080 on the bench scene; the oracle renders a 64 x 40 window (whole
     8 x 8 tiles of frame 0) and every per-pixel buffer of that window is bit-equal over two frames.  The training-record
@@ -230,7 +342,8 @@ def test_nrc_window_of_the_full_frame_matches_the_oracle(built_lib):
     derived from the GPU's own frame-0 record count on both sides."""
     import torch
     from tests.test_gpu_nrc_render import _compare_exact
-    hs = util.bench_street()
+    hs = _scene(workload)
+    window = _choose_window(workload, hs, (64, 40)) if workload != "plain" else (896, 560, 960, 600)
     ctx = api.Context(0)
     hs.upload(ctx)
     accel = ctx.accel_build()
@@ -244,7 +357,6 @@ def test_nrc_window_of_the_full_frame_matches_the_oracle(built_lib):
     nb_gpu.to_device()
     s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
     stream = torch.cuda.current_stream().cuda_stream
-    window = (896, 560, 960, 600)
     mask = _window_mask(*window)
     n = W * H
     offsets = np.random.default_rng(99)
@@ -282,24 +394,32 @@ def test_nrc_window_of_the_full_frame_matches_the_oracle(built_lib):
     assert not diffs, "\n".join(diffs)
 
 
-def test_eight_band_strip_exchange_at_the_bench_configuration(built_lib):
+@pytest.mark.parametrize("config", ["configs[2]: biased", "configs[4]: unbiased + 2048x1024 environment map"])
+def test_eight_band_strip_exchange_at_the_bench_configuration(built_lib, config):
     """bench.py --gpus 8 on one GPU: eight band renderers (7 x 136 + 128 rows of the 1920x1080 frame, radius-20 strips, the
     textured bench scene) driven by eight host threads through the loop-back transport reproduce the whole-frame renderer
-    bit for bit over three frames -- the same descriptors tilesplit.StripExchange sends over RCCL."""
+    bit for bit over three frames -- the same descriptors tilesplit.StripExchange sends over RCCL.  configs[4] is the
+    workload BASELINE.json names for the 8-GPU split: the unbiased estimator (1 x 3 neighbours with MIS rays) under a
+    2048 x 1024 environment map."""
     import torch
     from gfxexp_amd import scenes, tilesplit
     from tests import loopback
     hs = scenes.bench_street(textured=True)
     world, frames = 8, 3
+    unbiased = "unbiased" in config
+    sky = api.env_make_sky(2048, 1024) if unbiased else None
 
     def make(band):
         ctx = api.Context(0)
         hs.upload(ctx)
-        cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
+        cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_UNBIASED if unbiased else api.RENDERER_BIASED)
         cfg.camera = api.make_camera(W, H, **CAM)
         cfg.enableBumpMapping = 1
         cfg.rowBegin, cfg.rowEnd = band
-        return ctx, api.RestirRenderer(ctx, cfg)
+        r = api.RestirRenderer(ctx, cfg)
+        if unbiased:
+            r.set_env(sky, 2048, 1024, power_coeff=0.6, rotation=0.4)
+        return ctx, r
 
     ctx_full, full = make((0, 0))
     for _ in range(frames):
@@ -319,4 +439,5 @@ def test_eight_band_strip_exchange_at_the_bench_configuration(built_lib):
         util.assert_same_bits(f"band {rank} gathered HDR frame", got, want)
     assert np.isfinite(want).all() and want[..., :3].mean() > 1e-3
     kinds = [k for k, _ in ex.calls[0]]
-    assert kinds.count(api.EXCHANGE_STRIPS) == frames * 3 and kinds.count(api.EXCHANGE_GATHER_BANDS) == frames
+    # G-buffer strips + one reservoir strip per spatial pass (2 biased, 1 unbiased) per frame; one HDR gather per frame
+    assert kinds.count(api.EXCHANGE_STRIPS) == frames * (2 if unbiased else 3) and kinds.count(api.EXCHANGE_GATHER_BANDS) == frames

@@ -93,6 +93,15 @@ def test_band_renderer_refuses_motion_it_cannot_exchange(built_lib):
     r.set_camera(_camera(1, True))
     with pytest.raises(api.GfxError, match="moved"):
         r.render_frame()
+    # the refusal changed nothing: with motion rows installed the same frame renders (frame index 1, not 2)
+    r.set_exchange(lambda stream, d: None, 8)
+    r.render_frame()
+    assert r.params()[4] == 2
+    # a camera set before the first frame is not "motion" (frame 0 reads no previous frame), nor is it with temporal reuse off
+    ctx2, r2 = _make(hs, api.RENDERER_BIASED, (32, 64))
+    r2.set_exchange(lambda stream, d: None, 0)
+    r2.set_camera(_camera(1, True))
+    r2.render_frame()
 
 
 @pytest.mark.gpu

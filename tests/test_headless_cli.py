@@ -79,6 +79,24 @@ def test_option_errors(built_lib):
     assert r.returncode != 0 and "more arguments" in r.stderr
 
 
+def test_nrc_options_of_the_reference_command_line(built_lib):
+    """-position-encoding / -num-hidden-layers / -learning-rate as neural_radiance_caching_main.cpp:755-790 parses them, with its
+    defaults (:458-460: hash grid, 2 hidden layers, 1e-2)."""
+    base = _scene_args() + ["-size", 64, 48, "-renderer", "nrc", "-dry-run"]
+    d = _run(base)
+    assert d["renderer"] == -1 and d["nrc"] == {"position_encoding": "hash-grid", "num_hidden_layers": 2, "learning_rate": 0.00999999978,
+                                                "max_path_length": 5, "train": True}
+    d = _run(base + ["-position-encoding", "tri-wave", "-num-hidden-layers", 5, "-learning-rate", "1e-3", "-max-path-length", 0, "-no-train"])
+    assert d["nrc"]["position_encoding"] == "tri-wave" and d["nrc"]["num_hidden_layers"] == 5 and abs(d["nrc"]["learning_rate"] - 1e-3) < 1e-9
+    assert d["nrc"]["max_path_length"] == 0 and d["nrc"]["train"] is False
+    r = _run(base + ["-position-encoding", "fourier"], check=False)
+    assert r.returncode != 0 and "position encoding" in r.stderr
+    r = _run(base + ["-learning-rate", "nan"], check=False)
+    assert r.returncode != 0 and "invalid value" in r.stderr
+    r = _run(base + ["-num-hidden-layers"], check=False)
+    assert r.returncode != 0 and "more arguments" in r.stderr
+
+
 def _python_scene():
     s = api.HostScene()
     bunny = s.load_obj(BUNNY)
@@ -195,3 +213,50 @@ def test_cli_with_a_textured_asset(built_lib, tmp_path):
     want = ctx.read_device(r.beauty_ptr(), W * H * 16).view(np.float32).reshape(H, W, 4)
     assert np.abs(want[..., :3]).sum() > 0
     assert np.array_equal(_read_pfm(out).view(np.uint32), np.ascontiguousarray(want[..., :3]).view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("encoding,layers,lr", [("hash-grid", 2, 1e-2), ("tri-wave", 5, 5e-3)])
+def test_cli_nrc_renderer_matches_the_python_driver(built_lib, tmp_path, encoding, layers, lr):
+    """-renderer nrc with the reference's network options (neural_radiance_caching_main.cpp:755-790) over gfxh_nrc_*: frame 0
+    (inference with the initial parameters, no training step has run) is bit-identical to the NRC renderer driven through
+    the bindings; after three frames the pictures agree to the training's own noise (the order of the gradient atomics)."""
+    import torch
+    W, H = 160, 96
+    enc = api.NRC_HASH_GRID if encoding == "hash-grid" else api.NRC_TRIANGLE_WAVE
+    opts = ["-size", W, H, "-renderer", "nrc", "-position-encoding", encoding, "-num-hidden-layers", layers, "-learning-rate", lr]
+
+    def python_frames(frames):
+        ctx = api.Context(0)
+        hs = _python_scene()
+        hs.upload(ctx)
+        cfg = api.NrcRenderer.default_config(W, H, hs.bounds())
+        cfg.positionEncoding, cfg.numHiddenLayers, cfg.learningRate = enc, layers, lr
+        cam = api.make_camera(W, H, (1.5, 5.0, 14.0))
+        for k in range(9):
+            cam.orientation[k] = d["camera_orientation"][k]
+        cfg.camera = cam
+        r = api.NrcRenderer(ctx, cfg)
+        for _ in range(frames):
+            r.render_frame()
+        r.network()                                    # joins the training stream
+        torch.cuda.synchronize()
+        out = ctx.read_device(r.beauty_ptr(), W * H * 16).view(np.float32).reshape(H, W, 4)[..., :3].copy()
+        stats = r.stats()
+        r.close()
+        return out, stats
+
+    out = str(tmp_path / "nrc0.pfm")
+    d = _run(_scene_args() + opts + ["-frames", 1, "-out", out])
+    want, stats = python_frames(1)
+    assert np.abs(want).sum() > 0
+    assert np.array_equal(_read_pfm(out).view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+    assert d["nrc_last_frame"]["training_records"] == stats["numTrainingData"] > 100
+    assert d["nrc_last_frame"]["tile_size"] == list(stats["tileSize"]) and np.isfinite(d["nrc_last_frame"]["loss"])
+    out3 = str(tmp_path / "nrc3.pfm")
+    d3 = _run(_scene_args() + opts + ["-frames", 4, "-out", out3])
+    want3, _ = python_frames(4)
+    got3 = _read_pfm(out3)
+    assert np.isfinite(got3).all()
+    assert abs(got3.mean() - want3.mean()) < 0.02 * want3.mean()
+    assert not np.array_equal(got3, _read_pfm(out))                    # the cache is being trained: the picture moves

@@ -1,4 +1,8 @@
-"""CPU, world_size 2, gloo: the row-band split reproduces the single-process frame BIT FOR BIT.
+"""CPU, world_size 2 / 3 / 4, gloo: the row-band split reproduces the single-process frame BIT FOR BIT.
+
+World 3 and 4 run on frames whose bands are UNEQUAL (56 rows / 3 ranks = 24 + 16 + 16, 72 rows / 4 = 24 + 16 + 16 + 16; 1080
+rows / 8 ranks are 7 x 136 + 128): interior ranks exchange strips with two neighbours, and the all-gathers pad every slab
+to the tallest band.  The smallest band (16 rows) still holds the tallest strip of the cases (radius 5 + 8 motion rows).
 
 Two generations of the split are covered:
   * strip exchange (gfxh_restir_set_exchange): every pass runs on the band only and the rows the next pass reads
@@ -150,27 +154,31 @@ STRIP_CASES = [("biased", "RENDERER_BIASED", 3, False, False),
                ("path_trace", "RENDERER_PATH_TRACE", 2, False, False)]
 
 
-def _case_camera(frame, moving):
+# frame heights by world size: equal bands for 2 ranks, unequal ones (24 rows, then 16s) for 3 and 4
+HEIGHTS = {2: 48, 3: 56, 4: 72}
+
+
+def _case_camera(frame, moving, height=H):
     from gfxexp_amd import api
     dy = 1.0 * frame if moving else 0.0
-    return api.make_camera(W, H, pos=(1.5 + 0.5 * dy, 5.0 + dy, 14.0), pitch=12.0, yaw=186.0)
+    return api.make_camera(W, height, pos=(1.5 + 0.5 * dy, 5.0 + dy, 14.0), pitch=12.0, yaw=186.0)
 
 
-def _run_case(case, band, exchange, threads):
+def _run_case(case, band, exchange, threads, height=H):
     """One sequence of a STRIP_CASES entry on `band` ((0, 0) = whole frame); returns the renderer (state in .pb / .regir)."""
     from gfxexp_amd import api
     from tests import bandprog, util
     name, renderer, frames, moving, with_regir = case
     hs = util.bunny_scene()
     osc = util.feed_oracle(hs, threads=threads)
-    cfg = bandprog.small_config(W, H, getattr(api, renderer), band=band, radius=RADIUS, passes=PASSES, neighbors=NB)
+    cfg = bandprog.small_config(W, height, getattr(api, renderer), band=band, radius=RADIUS, passes=PASSES, neighbors=NB)
     cfg.maxPathLength = 3
     regir = util.RegirBuffers(hs.bounds(), dims=(8, 4, 8)) if with_regir else None
     r = bandprog.OracleBandRenderer(osc, cfg, regir=regir)
     if exchange is not None:
         r.set_exchange(exchange, MOTION_ROWS if moving else 0)
     for frame in range(frames):
-        r.render_frame(_case_camera(frame, moving))
+        r.render_frame(_case_camera(frame, moving, height))
     return r
 
 
@@ -183,14 +191,18 @@ def _state(r):
     return out
 
 
-def _strip_worker(rank, world, port, out_dir):
+def _strip_worker(rank, world, port, out_dir, case_names):
     import torch.distributed as dist
     from gfxexp_amd import tilesplit
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    band = tilesplit.band_for_rank(H, world, rank)
+    height = HEIGHTS[world]
+    band = tilesplit.band_for_rank(height, world, rank)
     for case in STRIP_CASES:
-        ex = tilesplit.StripExchange(dist, rank, world, H, tilesplit.host_view)
-        r = _run_case(case, band, ex, threads=2)
+        if case[0] not in case_names:
+            continue
+        # the asynchronous gather (bench.py's mode) on the odd cases, the synchronous default on the others
+        ex = tilesplit.StripExchange(dist, rank, world, height, tilesplit.host_view, async_gather=(STRIP_CASES.index(case) % 2 == 1))
+        r = _run_case(case, band, ex, threads=2, height=height)
         ex.finish()
         np.savez(os.path.join(out_dir, f"{case[0]}_{rank}.npz"), band=np.array(band), bytes_moved=ex.bytes_moved,
                  log=np.array([(f, op, rows, bufs) for f, op, rows, bufs in r.log], np.int64).reshape(-1, 4), **_state(r))
@@ -198,31 +210,72 @@ def _strip_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def strip_runs(built_lib):
+def _spawn_strip_runs(world, case_names):
     import torch.multiprocessing as mp
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_strip_worker, args=(2, port, out_dir), nprocs=2, join=True)
-        yield {(c[0], r): dict(np.load(os.path.join(out_dir, f"{c[0]}_{r}.npz"))) for c in STRIP_CASES for r in range(2)}
+        mp.spawn(_strip_worker, args=(world, port, out_dir, case_names), nprocs=world, join=True)
+        return {(c, r): dict(np.load(os.path.join(out_dir, f"{c}_{r}.npz"))) for c in case_names for r in range(world)}
+
+
+@pytest.fixture(scope="module")
+def strip_runs(built_lib):
+    return _spawn_strip_runs(2, [c[0] for c in STRIP_CASES])
+
+
+# three ranks: every case; four ranks: the cases whose exchanges differ in kind (strips with motion, the rearchitected
+# once-per-frame strip, the counter all-reduce)
+WORLD3_CASES = [c[0] for c in STRIP_CASES]
+WORLD4_CASES = ["biased_moving", "rearch_unbiased_moving", "regir"]
+
+
+@pytest.fixture(scope="module")
+def strip_runs_world3(built_lib):
+    return _spawn_strip_runs(3, WORLD3_CASES)
+
+
+@pytest.fixture(scope="module")
+def strip_runs_world4(built_lib):
+    return _spawn_strip_runs(4, WORLD4_CASES)
 
 
 @pytest.mark.parametrize("case", STRIP_CASES, ids=[c[0] for c in STRIP_CASES])
 def test_two_rank_strip_exchange_is_bit_exact(strip_runs, case):
-    from gfxexp_amd import api
+    _check_strip_runs(strip_runs, case, 2)
+
+
+@pytest.mark.parametrize("case", STRIP_CASES, ids=[c[0] for c in STRIP_CASES])
+def test_three_rank_strip_exchange_with_unequal_bands_is_bit_exact(strip_runs_world3, case):
+    """Rank 1 has two neighbours; the bands are 24 + 16 + 16 rows."""
+    _check_strip_runs(strip_runs_world3, case, 3)
+
+
+@pytest.mark.parametrize("case", [c for c in STRIP_CASES if c[0] in WORLD4_CASES], ids=WORLD4_CASES)
+def test_four_rank_strip_exchange_with_unequal_bands_is_bit_exact(strip_runs_world4, case):
+    """Two interior ranks; the bands are 24 + 16 + 16 + 16 rows."""
+    _check_strip_runs(strip_runs_world4, case, 4)
+
+
+def _check_strip_runs(strip_runs, case, world):
+    from gfxexp_amd import api, tilesplit
     from tests import util
-    whole = _run_case(case, (0, 0), None, threads=4)
+    H = HEIGHTS[world]
+    bands = tilesplit.band_rows(H, world)
+    if world > 2:
+        assert len(set(e - b for b, e in bands)) > 1, "the bands of this test are meant to be unequal"
+    whole = _run_case(case, (0, 0), None, threads=4, height=H)
     want = _state(whole)
     assert np.abs(want["beauty"][:, :3]).sum() > 0
     name, _, frames, moving, with_regir = case
     if moving:   # the sequence really crosses the seam, and stays inside the strip the ranks exchange
         my = np.abs(want["motion"][want["surface"], 1])
         assert 3.0 < my.max() <= MOTION_ROWS - 1
-    for rank in range(2):
+    for rank in range(world):
         got = strip_runs[(name, rank)]
         b, e = got["band"]
+        assert (int(b), int(e)) == bands[rank]
         util.assert_same_bits(f"{name}: rank {rank} gathered HDR frame", got["beauty"], want["beauty"])
         rows = lambda a, per: np.ascontiguousarray(a).reshape(-1, H, W, per)[:, b:e]
         util.assert_same_bits(f"{name}: rank {rank} final reservoirs", rows(got["res"], 4), rows(want["res"], 4))
@@ -264,13 +317,44 @@ def test_strip_rows_and_too_tall_strips(built_lib):
         api.frame_program(cfg, True, 200, False, 1, 0, False)
 
 
+def test_partition_check_is_the_same_verdict_on_every_rank(built_lib):
+    """gfxh_restir_check_partition compares the tallest strip with the SMALLEST band, so all ranks agree.  The per-frame test
+    of the frame program only sees the calling rank's band: 1080 rows over 8 ranks are 7 x 136 + 128, and a 130-row strip
+    passes there on ranks 0-6 and fails on rank 7 -- whose neighbours would already be waiting in the exchange."""
+    from gfxexp_amd import api, tilesplit
+    for h, world in ((1080, 8), (48, 2), (56, 3), (1081, 5)):
+        assert [api.band_rows(h, world, r) for r in range(world)] == tilesplit.band_rows(h, world)
+    cfg = api.RestirRenderer.default_config(1920, 1080, api.RENDERER_BIASED)
+    api.check_partition(cfg, 8, 0)                      # radius 20 against 128 rows
+    api.check_partition(cfg, 8, 128)
+    with pytest.raises(api.GfxError, match="130 rows.*smallest band .128"):
+        api.check_partition(cfg, 8, 130)
+    verdicts = []
+    for rank in range(8):                               # what each rank would have decided on its own
+        cfg.rowBegin, cfg.rowEnd = api.band_rows(1080, 8, rank)
+        try:
+            api.frame_program(cfg, True, 130, False, 1, 0, False)
+            verdicts.append(True)
+        except api.GfxError:
+            verdicts.append(False)
+    assert verdicts == [True] * 7 + [False]
+    # the rearchitected renderer moves radius + motion rows at once; 40 rows over 3 ranks leave an 8-row band
+    small = api.RestirRenderer.default_config(64, 40, api.RENDERER_REARCH_UNBIASED)
+    small.spatialNeighborRadius = 5.0
+    api.check_partition(small, 3, 3)
+    with pytest.raises(api.GfxError):
+        api.check_partition(small, 3, 8)
+    with pytest.raises(api.GfxError):
+        api.check_partition(small, 6, 0)                # more ranks than 8-row tiles
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # NRC band renderers: records gathered in rank order, rank 0 trains, inference parameters broadcast
 # ---------------------------------------------------------------------------------------------------------------------
 NRC_FRAMES = 2
 
 
-def _nrc_run(band, rank, exchange, threads):
+def _nrc_run(band, rank, exchange, threads, H=H):
     from gfxexp_amd import api
     from tests import bandprog, util
     hs = util.bunny_scene()
@@ -290,30 +374,34 @@ def _nrc_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     from gfxexp_amd import tilesplit
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    H = HEIGHTS[world]
     band = tilesplit.band_for_rank(H, world, rank)
     ex = tilesplit.StripExchange(dist, rank, world, H, tilesplit.host_view)
-    out = _nrc_run(band, rank, ex, threads=2)
+    out = _nrc_run(band, rank, ex, threads=2, H=H)
     ex.finish()
     np.savez(os.path.join(out_dir, f"nrc_{rank}.npz"), band=np.array(band), **out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_nrc_band_split_is_bit_exact(built_lib):
+@pytest.mark.parametrize("world", [2, 3])
+def test_nrc_band_split_is_bit_exact(built_lib, world):
     """The CPU oracle allocates training records in pixel order, so the bands' records concatenated in rank order ARE the
-    single-process records: the gathered batch, the trained parameters and both frames are bit-identical."""
+    single-process records: the gathered batch, the trained parameters and both frames are bit-identical.  Three ranks:
+    unequal bands (24 + 16 + 16 rows), so the record gather pads to the largest count of three different ones."""
     import torch.multiprocessing as mp
     from tests import util
+    H = HEIGHTS[world]
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_nrc_worker, args=(2, port, out_dir), nprocs=2, join=True)
-        got = [dict(np.load(os.path.join(out_dir, f"nrc_{r}.npz"))) for r in range(2)]
-    want = _nrc_run((0, 0), 0, None, threads=4)
+        mp.spawn(_nrc_worker, args=(world, port, out_dir), nprocs=world, join=True)
+        got = [dict(np.load(os.path.join(out_dir, f"nrc_{r}.npz"))) for r in range(world)]
+    want = _nrc_run((0, 0), 0, None, threads=4, H=H)
     assert want["num"][0] > 100 and np.abs(want["beauty"][:, :3]).sum() > 0
     assert not np.array_equal(want["ema"], __import__("oracle.nrc_net", fromlist=["x"]).NrcNet(0, 2, 1e-2).ema)   # it trained
-    for rank in range(2):
+    for rank in range(world):
         g = got[rank]
         b, e = g["band"]
         for k in ("num", "tile", "trainq", "traint", "batchq", "batcht", "ema"):

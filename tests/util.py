@@ -18,9 +18,10 @@ def to_oracle_material(m):
     return om
 
 
-def feed_oracle(host_scene, threads=None, brute_force=False, config=None):
-    """Push every array of a HostScene into an OracleScene (same slots, same order)."""
-    osc = O.OracleScene(threads=threads)
+def feed_oracle(host_scene, threads=None, brute_force=False, config=None, library=None):
+    """Push every array of a HostScene into an OracleScene (same slots, same order).  `library`: another build of the
+    oracle sources (O.lib_fast(), bench.py's speed-mode CPU baseline); default = the parity build."""
+    osc = O.OracleScene(threads=threads, library=library)
     for slot, w, h, fmt, data in host_scene.textures():
         osc.set_texture(slot, w, h, fmt, data)
     for i, m in enumerate(host_scene.materials()):

@@ -1,7 +1,9 @@
 """Frame time of ONE rank's row band on one GPU (no communication) when the 1920x1080 bench frame is split N ways
 (tilesplit.band_rows), as a compute-only bound on strong scaling, in both band modes:
-  strips   gfxh_restir_set_exchange with a callback that moves nothing: every pass on the band only (what bench.py --gpus N runs)
-  halo     no callback: the band plus the halo rows the reuse passes read are recomputed (round-1 scheme)
+  strips          gfxh_restir_set_exchange with a callback that moves nothing: every pass on the band only (what bench.py --gpus N
+                  runs), the next frame's G-buffer pass pipelined underneath the reuse passes (round 3)
+  strips_serial   the same with GFX_SERIAL_FRAMES=1: every pass on one stream (round 2)
+  halo            no callback: the band plus the halo rows the reuse passes read are recomputed (round-1 scheme)
 The seam rows' state is not refreshed here (no neighbour rank), which does not change the amount of work.  One JSON line."""
 import json
 import os
@@ -12,12 +14,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gfxexp_amd import api, scenes, tilesplit  # noqa: E402
 
 
-def band_ms(ctx, cam, W, H, band, steps=30, strips=False):
+def band_ms(ctx, cam, W, H, band, steps=30, strips=False, serial=False):
     import torch
     cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
     cfg.camera = cam
     cfg.rowBegin, cfg.rowEnd = band
+    cfg.enableBumpMapping = int("--plain" not in sys.argv)
+    if serial:
+        os.environ["GFX_SERIAL_FRAMES"] = "1"
     r = api.RestirRenderer(ctx, cfg)
+    os.environ.pop("GFX_SERIAL_FRAMES", None)
     if strips:
         r.set_exchange(lambda stream, d: None, 0)
     for _ in range(5):
@@ -35,15 +41,16 @@ def band_ms(ctx, cam, W, H, band, steps=30, strips=False):
 def main():
     W, H = 1920, 1080
     ctx = api.Context(0)
-    scenes.bench_street().upload(ctx)
+    textured = "--plain" not in sys.argv
+    scenes.bench_street(textured=textured).upload(ctx)
     cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
     full = band_ms(ctx, cam, W, H, (0, 0))
-    out = {"workload": "bench frame, one rank's band rendered alone on one GPU (compute only)", "full_frame_ms": round(full, 4), "bands": {}}
+    out = {"workload": "bench frame (%s street), one rank's band rendered alone on one GPU (compute only)" % ("textured" if textured else "plain"), "full_frame_ms": round(full, 4), "bands": {}}
     for n in (2, 4, 8):
         bands = tilesplit.band_rows(H, n)
         entry = {}
-        for mode in ("strips", "halo"):
-            ms = [band_ms(ctx, cam, W, H, b, strips=mode == "strips") for b in bands]
+        for mode in ("strips", "strips_serial", "halo"):
+            ms = [band_ms(ctx, cam, W, H, b, strips=mode != "halo", serial=mode == "strips_serial") for b in bands]
             worst = max(ms)
             entry[mode] = {"band_ms": [round(m, 4) for m in ms], "compute_bound_speedup": round(full / worst, 2),
                            "compute_bound_efficiency": round(full / worst / n, 3)}
