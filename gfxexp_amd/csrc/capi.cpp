@@ -401,6 +401,19 @@ int gfx_nrc_infer(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInpu
     nrc_infer(ctx->c, static_cast<hipStream_t>(stream), nrc_of(ctx, handle), static_cast<const float*>(dInputData), numData, static_cast<float*>(dPredictionData));
     GFX_CATCH(ctx)
 }
+int gfx_nrc_infer_indirect(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInputData, const void* dNumData, uint32_t maxNumData, void* dPredictionData) {
+    GFX_TRY(ctx)
+    if (!dNumData) throw HipError("gfx_nrc_infer_indirect: null batch-size pointer");
+    nrc_infer(ctx->c, static_cast<hipStream_t>(stream), nrc_of(ctx, handle), static_cast<const float*>(dInputData), maxNumData, static_cast<float*>(dPredictionData),
+              static_cast<const uint32_t*>(dNumData));
+    GFX_CATCH(ctx)
+}
+int gfx_nrc_query_count_ptr(gfx_ctx* ctx, void** dNumData) {
+    GFX_TRY(ctx)
+    if (!ctx->c.nrcQueryCount.p) { ctx->c.nrcQueryCount.reserve(256); GFX_HIP(hipMemset(ctx->c.nrcQueryCount.p, 0, 256)); }
+    *dNumData = ctx->c.nrcQueryCount.p;
+    GFX_CATCH(ctx)
+}
 int gfx_nrc_train(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInputData, const void* dTargetData, uint32_t numData, float* lossOnCPU) {
     GFX_TRY(ctx)
     nrc_train(ctx->c, static_cast<hipStream_t>(stream), nrc_of(ctx, handle), static_cast<const float*>(dInputData), static_cast<const float*>(dTargetData), numData, lossOnCPU);

@@ -39,6 +39,13 @@ struct gfxh_nrc {
     std::mt19937 perFrameRng{ 72139121 };                  // main:1602
     gfx_camera prevCamera;
     uint32_t lastNumTrainingData = 0, lastTileSize[2] = { 8, 8 }, lastNumInferenceQueries = 0;
+    // whole-frame renderers never wait for the GPU inside a frame: the inference batch size is formed on the device
+    // (GFX_PT_NRC_COUNT_QUERIES + gfx_nrc_infer_indirect) and the figures gfxh_nrc_stats reports are copied into pinned
+    // host words asynchronously (evStats marks their arrival)
+    uint32_t* hostStats = nullptr;            // pinned: [0] numTrainingData, [1..2] tileSize, [3] numInferenceQueries
+    void* dQueryCount = nullptr;
+    hipEvent_t evStats = nullptr;
+    bool statsPending = false;
     // The four training steps of frame N only feed the inference of frame N + 1, so they run on their own
     // stream underneath the G-buffer / path-tracing kernels of frame N + 1 (a training step is ~300 single-wave
     // blocks: it leaves most of the chip idle on its own).  evData: shuffled training data ready;
@@ -74,6 +81,8 @@ void gfxh_nrc_default_config(gfxh_nrc_config* cfg, uint32_t width, uint32_t heig
 void gfxh_nrc_destroy(gfxh_nrc* r) {
     if (!r) return;
     (void)hipDeviceSynchronize();
+    if (r->evStats) (void)hipEventDestroy(r->evStats);
+    if (r->hostStats) (void)hipHostFree(r->hostStats);
     if (r->evData) (void)hipEventDestroy(r->evData);
     if (r->evTrained) (void)hipEventDestroy(r->evTrained);
     if (r->trainStream) (void)hipStreamDestroy(r->trainStream);
@@ -148,10 +157,14 @@ int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out) {
         // non-blocking: the caller's stream may be the legacy default stream, which would serialise a blocking one
         if (!nrc_hip_ok(hipStreamCreateWithFlags(&r->trainStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
             !nrc_hip_ok(hipEventCreateWithFlags(&r->evData, hipEventDisableTiming), "hipEventCreate") ||
-            !nrc_hip_ok(hipEventCreateWithFlags(&r->evTrained, hipEventDisableTiming), "hipEventCreate")) {
+            !nrc_hip_ok(hipEventCreateWithFlags(&r->evTrained, hipEventDisableTiming), "hipEventCreate") ||
+            !nrc_hip_ok(hipEventCreateWithFlags(&r->evStats, hipEventDisableTiming), "hipEventCreate") ||
+            !nrc_hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r->hostStats), 64, hipHostMallocDefault), "hipHostMalloc")) {
             gfxh_nrc_destroy(r);
             return 1;
         }
+        std::memset(r->hostStats, 0, 64);
+        if (gfx_nrc_query_count_ptr(ctx, &r->dQueryCount)) { g_nrcError = gfx_last_error(ctx); gfxh_nrc_destroy(r); return 1; }
     }
     *out = r;
     return 0;
@@ -187,14 +200,28 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, rb, re));
     NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_PREPROCESS, W, H, cfg.maxPathLength, 0, 0));
     NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_NRC, W, H, cfg.maxPathLength, rb, re));
-    // main:2293-2303: the inference batch size needs the tile size of this frame
-    NRC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    NRC_HIP(hipMemcpy(&r->lastNumTrainingData, r->np.numTrainingData[bufferIndex], 4, hipMemcpyDeviceToHost));
-    NRC_HIP(hipMemcpy(r->lastTileSize, r->np.tileSize[bufferIndex], 8, hipMemcpyDeviceToHost));
-    const uint32_t tilesX = (W + r->lastTileSize[0] - 1) / r->lastTileSize[0], tilesY = (H + r->lastTileSize[1] - 1) / r->lastTileSize[1];
-    uint32_t numInferenceQueries = W * H + tilesX * tilesY;
-    numInferenceQueries = (numInferenceQueries + 127) / 128 * 128;
-    r->lastNumInferenceQueries = numInferenceQueries;
+    // main:2293-2303: the inference batch size needs the tile size of this frame.  The reference synchronises the stream and
+    // reads it back; a band renderer does the same here (the record gather needs the counts on the host anyway).  The whole-
+    // frame renderer forms the batch size on the device instead and never waits for the GPU inside a frame.
+    uint32_t tilesX = 0, tilesY = 0, numInferenceQueries = 0;
+    if (band) {
+        NRC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        NRC_HIP(hipMemcpy(&r->lastNumTrainingData, r->np.numTrainingData[bufferIndex], 4, hipMemcpyDeviceToHost));
+        NRC_HIP(hipMemcpy(r->lastTileSize, r->np.tileSize[bufferIndex], 8, hipMemcpyDeviceToHost));
+        tilesX = (W + r->lastTileSize[0] - 1) / r->lastTileSize[0]; tilesY = (H + r->lastTileSize[1] - 1) / r->lastTileSize[1];
+        numInferenceQueries = (W * H + tilesX * tilesY + 127) / 128 * 128;
+        r->lastNumInferenceQueries = numInferenceQueries;
+    }
+    else {
+        NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_COUNT_QUERIES, W, H, cfg.maxPathLength, 0, 0));
+        if (r->statsPending) { NRC_HIP(hipEventSynchronize(r->evStats)); r->statsPending = false; }   // the previous frame's copies (long done)
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        NRC_HIP(hipMemcpyAsync(r->hostStats + 0, r->np.numTrainingData[bufferIndex], 4, hipMemcpyDeviceToHost, s));
+        NRC_HIP(hipMemcpyAsync(r->hostStats + 1, r->np.tileSize[bufferIndex], 8, hipMemcpyDeviceToHost, s));
+        NRC_HIP(hipMemcpyAsync(r->hostStats + 3, r->dQueryCount, 4, hipMemcpyDeviceToHost, s));
+        NRC_HIP(hipEventRecord(r->evStats, s));
+        r->statsPending = true;
+    }
     if (r->trainPending) {   // the weights this frame infers with come from the previous frame's training
         NRC_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), r->evTrained, 0));
         r->trainPending = false;
@@ -205,7 +232,9 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
         return 0;
     };
     if (!band) {
-        NRC_GFX(gfx_nrc_infer(ctx, stream, r->network, r->np.inferenceRadianceQueryBuffer, numInferenceQueries, r->np.inferredRadianceBuffer));
+        // sized for the smallest tile (4 x 4: W * H / 16 = maxNumTrainingSuffixes tiles); the kernel reads the real count
+        const uint32_t maxQueries = static_cast<uint32_t>((static_cast<size_t>(W) * H + r->np.maxNumTrainingSuffixes + 255) / 256 * 256);
+        NRC_GFX(gfx_nrc_infer_indirect(ctx, stream, r->network, r->np.inferenceRadianceQueryBuffer, r->dQueryCount, maxQueries, r->np.inferredRadianceBuffer));
     }
     else {
         // the band's pixels, then the suffix queries of the training tiles (all of them: the ones whose training pixel lies
@@ -299,6 +328,14 @@ uint64_t gfxh_nrc_network(gfxh_nrc* r) {
     return r->network;
 }
 int gfxh_nrc_stats(gfxh_nrc* r, uint32_t* numTrainingData, uint32_t tileSize[2], uint32_t* numInferenceQueries) {
+    if (r->statsPending) {      // whole-frame renderer: the last frame's figures arrive through pinned memory
+        if (hipEventSynchronize(r->evStats) != hipSuccess) return 1;
+        r->statsPending = false;
+    }
+    if (r->hostStats && !(r->exchange && !(r->cfg.rowBegin == 0 && r->cfg.rowEnd == 0)) && r->frameIndex > 0) {
+        r->lastNumTrainingData = r->hostStats[0]; r->lastTileSize[0] = r->hostStats[1]; r->lastTileSize[1] = r->hostStats[2];
+        r->lastNumInferenceQueries = r->hostStats[3];
+    }
     if (numTrainingData) *numTrainingData = r->lastNumTrainingData;
     if (tileSize) { tileSize[0] = r->lastTileSize[0]; tileSize[1] = r->lastTileSize[1]; }
     if (numInferenceQueries) *numInferenceQueries = r->lastNumInferenceQueries;

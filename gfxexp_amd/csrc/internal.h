@@ -149,6 +149,7 @@ struct Context {
     DevBuf ptPending, ptExtOrg, ptExtDir, ptExtOwner, ptState;
     DevBuf rearchSlots;
     DevBuf nrcState, neeTrainIdx;
+    DevBuf nrcQueryCount;            // u32: inference batch size of the NRC frame (GFX_PT_NRC_COUNT_QUERIES)
     // build scratch
     DevBuf bTris, bBoxes, bKeys, bKeysAlt, bVals, bValsAlt, bSortTemp, bNodesLR, bParents, bFlags, bNodeBoxes, bRanges, bQueueA, bQueueB, bCounters, bCosts, bDec, bFlatIdx;
     // restir
@@ -219,7 +220,7 @@ uint32_t nrc_num_params(const NrcNet* net);
 void nrc_set_params(Context& ctx, hipStream_t stream, NrcNet* net, const float* hostParams, uint32_t count);
 void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count);
 void nrc_inference_image(NrcNet* net, int which, void** dPtr, uint64_t* bytes);
-void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions);
+void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions, const uint32_t* dNumData = nullptr);
 void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, const float* dTargets, uint32_t numData, float* lossOnCPU);
 // ---- pathtrace.hip
 void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height,

@@ -269,8 +269,10 @@ GFX_DEV void layer64(FragPtr frags, int lane, const uint4 b[4], f32x16 acc[2]) {
 // inputs [14, N] column-major fp32, predictions [3, N] column-major fp32 (network_interface.cu:141-147)
 constexpr int kInferBlock = 256;
 __global__ __launch_bounds__(kInferBlock) __attribute__((amdgpu_waves_per_eu(GFX_NRC_INFER_WAVES, GFX_NRC_INFER_WAVES))) void k_nrc_infer(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_t* __restrict__ grid,
-                                                           const float* __restrict__ inputs, uint32_t numData, float* __restrict__ predictions) {
+                                                           const float* __restrict__ inputs, uint32_t numDataArg, const uint32_t* __restrict__ numDataPtr,
+                                                           float* __restrict__ predictions) {
     extern __shared__ __attribute__((aligned(16))) uint4 ldsW[];
+    const uint32_t numData = numDataPtr ? min(*numDataPtr, numDataArg) : numDataArg;   // device-side batch size (gfx_nrc_infer_indirect)
     const uint32_t fwdElems = d.numHidden * kMatFwdElems + kOutFwdElems;
     for (uint32_t i = threadIdx.x; i < fwdElems / 8; i += kInferBlock) ldsW[i] = reinterpret_cast<const uint4*>(fwd)[i];
     __syncthreads();
@@ -727,7 +729,7 @@ void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count) {
     GFX_HIP(hipMemcpy(hostOut, src.p, sizeof(float) * count, hipMemcpyDeviceToHost));
 }
 
-void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions) {
+void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions, const uint32_t* dNumData) {
     if (numData & 0x7F) throw HipError("gfx_nrc_infer: numData must be a multiple of 128");   // network_interface.cu:143
     if (numData == 0) return;
     const int numCUs = ctx.numCUs;
@@ -737,7 +739,7 @@ void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     const size_t lds = 2ull * (net->d.numHidden * kMatFwdElems + kOutFwdElems) + wavesPerBlock * 64 * kNrcIn * sizeof(float);
     ScopedKernelTimer timer(ctx, stream, "nrc_infer");
     hipLaunchKernelGGL(k_nrc_infer, dim3(grid), dim3(kInferBlock), lds, stream, net->d, net->packInferFwd.as<uint16_t>(),
-                       net->gridInfer.as<uint32_t>(), dInputs, numData, dPredictions);
+                       net->gridInfer.as<uint32_t>(), dInputs, numData, dNumData, dPredictions);
     GFX_HIP(hipGetLastError());
 }
 

@@ -1000,6 +1000,14 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
     push_vertex(a, pixel, pos, o);
 }
 
+// numInferenceQueries of the frame on the device (neural_radiance_caching_main.cpp:2293-2303 does this on the host)
+__global__ void k_nrc_count_queries(PtArgs a, uint32_t* out) {
+    const uint2 ts = *static_cast<const uint2*>(a.nrc.tileSize[a.f.bufferIndex]);
+    const uint32_t W = static_cast<uint32_t>(a.s.imageSizeX), H = static_cast<uint32_t>(a.s.imageSizeY);
+    const uint32_t n = W * H + ((W + ts.x - 1) / ts.x) * ((H + ts.y - 1) / ts.y);
+    *out = (n + 127u) / 128u * 128u;
+}
+
 // perFrameContributionBuffer = contribution (:375)
 __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_finish(PtArgs a) {
     const PixelId px = pixel_of_thread(a.px);
@@ -1161,7 +1169,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     const RestirParams& rp = ctx.restir;
     if (!rp.valid) throw HipError("gfx_pt_launch: gfx_restir_set_params has not been called");
     const bool regirPass = pass >= GFX_PT_REGIR_BUILD_CELL_RESERVOIRS && pass <= GFX_PT_REGIR_UPDATE_LAST_ACCESS;
-    const bool nrcPass = pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_VISUALIZE_PREDICTION;
+    const bool nrcPass = pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_COUNT_QUERIES;
     if (!regirPass && !nrcPass && pass != GFX_PT_PATH_TRACE_BASELINE) throw HipError("gfx_pt_launch: unknown pass");
     if (regirPass && !ctx.regirValid) throw HipError("gfx_pt_launch: gfx_regir_set_params has not been called");
     if (nrcPass && !ctx.nrcRenderValid) throw HipError("gfx_pt_launch: gfx_nrc_set_render_params has not been called");
@@ -1188,6 +1196,12 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         if (pass == GFX_PT_NRC_PROPAGATE) { simple("nrc_propagate", k_nrc_propagate, a.nrc.maxNumTrainingSuffixes); return; }
         if (pass == GFX_PT_NRC_SHUFFLE) { simple("nrc_shuffle", k_nrc_shuffle, kNumTrainingDataPerFrame); return; }
         if (pass == GFX_PT_NRC_VISUALIZE_PREDICTION) { simple("nrc_visualize", k_nrc_visualize, np); return; }
+        if (pass == GFX_PT_NRC_COUNT_QUERIES) {
+            if (!ctx.nrcQueryCount.p) { ctx.nrcQueryCount.reserve(256); GFX_HIP(hipMemsetAsync(ctx.nrcQueryCount.p, 0, 256, stream)); }
+            hipLaunchKernelGGL(k_nrc_count_queries, dim3(1), dim3(1), 0, stream, a, ctx.nrcQueryCount.as<uint32_t>());
+            GFX_HIP(hipGetLastError());
+            return;
+        }
     }
     if (regirPass) a.g = ctx.regir;
     if (pass == GFX_PT_REGIR_BUILD_CELL_RESERVOIRS || pass == GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL) {

@@ -354,7 +354,11 @@ enum gfx_pt_pass {
     GFX_PT_NRC_ACCUMULATE = 8,                        /* nrc_setup_kernels.cu:51-93 */
     GFX_PT_NRC_PROPAGATE = 9,                         /* :95-137 */
     GFX_PT_NRC_SHUFFLE = 10,                          /* :139-216 */
-    GFX_PT_NRC_VISUALIZE_PREDICTION = 11              /* optix_pathtracing_kernels.cu:705-778 */
+    GFX_PT_NRC_VISUALIZE_PREDICTION = 11,             /* optix_pathtracing_kernels.cu:705-778 */
+    /* numInferenceQueries = (W * H + #tiles of tileSize[bufferIndex]) rounded up to 128 -- what the reference computes on the
+     * host after a stream synchronisation and a device read (neural_radiance_caching_main.cpp:2293-2303) -- written to the
+     * context's device word (gfx_nrc_query_count_ptr) for gfx_nrc_infer_indirect: the frame needs no host round trip. */
+    GFX_PT_NRC_COUNT_QUERIES = 12
 };
 
 /* The ReGIR members of regir/regir_shared.h:200-263 (grid of cells x 512 light slots).  Light-slot
@@ -438,6 +442,11 @@ int gfx_nrc_destroy(gfx_ctx* ctx, uint64_t handle);
 int gfx_nrc_infer(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInputData, uint32_t numData, void* dPredictionData);
 int gfx_nrc_train(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInputData, const void* dTargetData,
                   uint32_t numData, float* lossOnCPU);
+/* gfx_nrc_infer with the batch size read on the device: *dNumData queries (a multiple of 128, <= maxNumData) are inferred;
+ * the launch is sized for maxNumData.  dNumData = gfx_nrc_query_count_ptr after GFX_PT_NRC_COUNT_QUERIES in the NRC frame. */
+int gfx_nrc_infer_indirect(gfx_ctx* ctx, void* stream, uint64_t handle, const void* dInputData, const void* dNumData, uint32_t maxNumData,
+                           void* dPredictionData);
+int gfx_nrc_query_count_ptr(gfx_ctx* ctx, void** dNumData);
 int gfx_nrc_num_params(gfx_ctx* ctx, uint64_t handle, uint32_t* outCount);
 int gfx_nrc_set_params(gfx_ctx* ctx, uint64_t handle, const float* hostParams, uint32_t count);
 int gfx_nrc_get_params(gfx_ctx* ctx, uint64_t handle, int which, float* hostOut, uint32_t count);

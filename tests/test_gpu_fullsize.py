@@ -142,7 +142,7 @@ def _window_of_the_full_frame(config, workload):
         ew, eh = 2048, 1024                            # analytic sky + sun, lat-long
         sky = api.env_make_sky(ew, eh)
         pb_init.set_env(sky, ew, eh)
-        pb_cpu.set_env(sky, ew, eh)
+        pb_cpu.set_env(sky, ew, eh, oracle_side=True)
         env_kw = dict(enableEnvLight=1, envLightPowerCoeff=0.6, envLightRotation=0.4)
     dev = util.DeviceBuffers(pb_init)
     s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()

@@ -18,7 +18,7 @@ def _setup(hs, width, height, env=None, radiance_scale=1.0):
     osc = util.feed_oracle(hs, threads=1)
     pb_gpu_init, pb_cpu = util.PixelBuffers(width, height), util.PixelBuffers(width, height)
     if env is not None:
-        pb_gpu_init.set_env(*env); pb_cpu.set_env(*env)
+        pb_gpu_init.set_env(*env); pb_cpu.set_env(*env, oracle_side=True)
     dev = util.DeviceBuffers(pb_gpu_init)
     nb_gpu, nb_cpu = util.NrcBuffers(width, height, hs.bounds(), radiance_scale), util.NrcBuffers(width, height, hs.bounds(), radiance_scale)
     nb_gpu.to_device()

@@ -22,7 +22,7 @@ def run_pt_both(hs, width, height, frames=2, max_len=5, camera=None, env=None, j
     pb_cpu = util.PixelBuffers(width, height)
     if env is not None:
         pb_gpu_init.set_env(*env)
-        pb_cpu.set_env(*env)
+        pb_cpu.set_env(*env, oracle_side=True)
     dev = util.DeviceBuffers(pb_gpu_init)
     s_gpu = dev.static_params()
     s_cpu = pb_cpu.host_static_params()

@@ -22,7 +22,7 @@ def run_regir_both(hs, width, height, frames, max_len, temporal=True, dims=(8, 4
     pb_gpu_init, pb_cpu = util.PixelBuffers(width, height), util.PixelBuffers(width, height)
     if env is not None:
         pb_gpu_init.set_env(*env)
-        pb_cpu.set_env(*env)
+        pb_cpu.set_env(*env, oracle_side=True)
     dev = util.DeviceBuffers(pb_gpu_init)
     s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
     rb_gpu = util.RegirBuffers(hs.bounds(), dims, log2_slot, log2_cell, randomize)

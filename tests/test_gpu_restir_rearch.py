@@ -23,7 +23,7 @@ def run_rearch_both(hs, width, height, frames, temporal, spatial, unbiased, low_
     pb_cpu = util.PixelBuffers(width, height)
     if env is not None:
         pb_gpu_init.set_env(*env)
-        pb_cpu.set_env(*env)
+        pb_cpu.set_env(*env, oracle_side=True)
     dev = util.DeviceBuffers(pb_gpu_init)
     s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
     stream = torch.cuda.current_stream().cuda_stream

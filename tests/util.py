@@ -159,11 +159,13 @@ class PixelBuffers:
         self.presample_rngs = O.seed_rngs(PRESAMPLED_LIGHTS, 894213312210)
         self.presampled = np.zeros((PRESAMPLED_LIGHTS, 12), np.float32)
 
-    def set_env(self, texels, w, h):
-        """Attach a lat-long environment map; the importance map comes from the product's host builder
-        (the oracle's own restatement of it is compared separately in test_env_light.py)."""
+    def set_env(self, texels, w, h, oracle_side=False):
+        """Attach a lat-long environment map with its importance map.  The GPU side gets the PRODUCT's host builder
+        (gfxh_env_build_importance + guide tables); oracle_side=True -- what every harness passes for the buffers it hands to
+        the oracle -- builds it with the ORACLE's own restatement (orc_env_build), so a host-builder error shows up as a
+        GPU-vs-oracle mismatch instead of cancelling out (the two builders are also compared directly in test_env_light.py)."""
         t = np.ascontiguousarray(texels, np.float32).copy()
-        e = api.env_build_importance(t, w, h)
+        e = O.env_build(t, w, h) if oracle_side else api.env_build_importance(t, w, h)
         e.update(texels=t, w=w, h=h)
         self.env = e
 

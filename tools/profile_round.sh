@@ -12,8 +12,10 @@
 #   stats        rocprofv3 --kernel-trace --stats of the short bench command           -> profiles/r03_kernel_stats.txt
 #   pmc          PMC passes (SQ x2, TCP/TCC, FETCH, WRITE) of the same command, default pixel map
 #   pmc0         the same with GFX_PIXEL_MAP=0 (rounds 1-2 mapping) for the before/after table -> profiles/r03_pixel_map_pmc.txt
-#   nrcpmc       MFMA / VALU counters of k_nrc_infer, k_nrc_train                       -> profiles/r03_nrc_pmc.txt
-#   nrc          tools/bench_nrc.py, NRC frame with training overlapped and serial      -> profiles/r03_nrc_frame.json
+#   nrcpmc       MFMA / VALU counters of k_nrc_infer, k_nrc_train (tools/bench_nrc.py)  -> profiles/r03_nrc_pmc.txt
+#   nrc          tools/bench_nrc.py (network alone) + tools/bench_nrc_frame.py (NRC frame, training overlapped / serial)
+#                                                                                       -> profiles/r03_nrc_frame.jsonl
+#   pmcjson      profiles/make_pmc_json.py over the pmc (+ pmc0) outputs                -> profiles/r03_pmc.json
 #   renderers    tools/bench_renderers.py + tools/bench_config4.py                      -> profiles/r03_renderers.jsonl
 #   bands        tools/bench_band.py (compute-only bound of N row bands)                -> profiles/r03_band_compute_bound.json
 #   hbm          tools/hbm_stream.py (streaming-copy ceiling of this box)               -> profiles/r03_hbm_stream.json
@@ -57,8 +59,19 @@ for step in "$@"; do
     pmc)       pmc_passes pmc_default GFX_NOOP=1; head -60 $OUT/pmc_default/sq.txt ;;
     pmc0)      pmc_passes pmc_map0 GFX_PIXEL_MAP=0 ;;
     pmc1)      pmc_passes pmc_map1 GFX_PIXEL_MAP=1 ;;
-    nrcpmc)    bash tools/nrc_prof.sh ;;
-    nrc)       timeout 600 python tools/bench_nrc.py > $OUT/nrc_frame.json 2> $OUT/nrc_frame.err; cat $OUT/nrc_frame.json; tail -3 $OUT/nrc_frame.err ;;
+    nrcpmc)    N="python tools/bench_nrc.py --steps 5"; mkdir -p $OUT/nrc_pmc
+               timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/nrc_pmc/a -- $N > /dev/null 2>&1
+               timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_WAVES --output-format csv -d $OUT/nrc_pmc/b -- $N > /dev/null 2>&1
+               timeout 300 rocprofv3 --pmc TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/nrc_pmc/c -- $N > /dev/null 2>&1
+               timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/nrc_pmc/stats -- $N > /dev/null 2>&1
+               for p in a b c; do python profiles/summarize_pmc.py $OUT/nrc_pmc/$p/*/*counter_collection.csv > $OUT/nrc_pmc/$p.txt 2>&1; done
+               cat $OUT/nrc_pmc/stats/*/*kernel_stats.csv | cut -c1-160 | head -12 > $OUT/nrc_pmc/kernel_stats.csv
+               rm -rf $OUT/nrc_pmc/a $OUT/nrc_pmc/b $OUT/nrc_pmc/c $OUT/nrc_pmc/stats
+               grep -A9 "k_nrc_infer\|k_nrc_train" $OUT/nrc_pmc/a.txt | head -40 ;;
+    nrc)       timeout 300 python tools/bench_nrc.py --steps 20 2> $OUT/nrc_net.err | tail -1 > $OUT/nrc_net.json; cut -c1-700 $OUT/nrc_net.json
+               timeout 600 python tools/bench_nrc_frame.py > $OUT/nrc_frame.jsonl 2> $OUT/nrc_frame.err; cat $OUT/nrc_frame.jsonl; tail -3 $OUT/nrc_frame.err ;;
+    pmcjson)   if [ -d $OUT/pmc_map0 ]; then python profiles/make_pmc_json.py $OUT/pmc_default $OUT/pmc_map0 pixel_map_0_scan_lines > $OUT/r03_pmc.json
+               else python profiles/make_pmc_json.py $OUT/pmc_default > $OUT/r03_pmc.json; fi; head -c 600 $OUT/r03_pmc.json ;;
     renderers) timeout 900 python tools/bench_renderers.py > $OUT/renderers.jsonl 2> $OUT/renderers.err
                timeout 300 python tools/bench_config4.py >> $OUT/renderers.jsonl 2>> $OUT/renderers.err; cat $OUT/renderers.jsonl ;;
     bands)     timeout 900 python tools/bench_band.py > $OUT/band_compute_bound.json 2> $OUT/band.err; cat $OUT/band_compute_bound.json; tail -3 $OUT/band.err ;;
