@@ -34,14 +34,30 @@ struct AABB { // common/basic_types.h AABB_T
         return V3(d.x != 0 ? n.x / d.x : 0.0f, d.y != 0 ? n.y / d.y : 0.0f, d.z != 0 ? n.z / d.z : 0.0f);
     }
     bool isValid() const { const V3 d = maxP - minP; return d.x >= 0 && d.y >= 0 && d.z >= 0; }
-    // basic_types.h:3450-3465
-    bool intersect(V3 org, V3 dir, float distMin, float distMax, float* hitDistMin, float* hitDistMax) const {
+    // basic_types.h:3450-3465.  widen = false is the reference's test as written.  Its slab distances carry the rounding of
+    // (plane - org) * (1 / dir) while the triangle test computes its distance another way, so a triangle lying IN a box face
+    // (flat, axis-aligned geometry: every sign and wall of the street scenes) can be accepted at a distance one ulp below the
+    // entry distance computed for its own box -- and is then culled once a coincident triangle of another instance was hit
+    // first (found at 1920x1080 on the textured street: two overlapping sign instances).  The reference only runs this
+    // traversal in a builder test harness; the oracle renders with it, so its ray queries widen every slab by
+    // 2^-20 |1/dir_k| (|org_k| + |plane_k|), twice the bound of that rounding.  A widened test only ever visits MORE boxes.
+    bool intersect(V3 org, V3 dir, float distMin, float distMax, float* hitDistMin, float* hitDistMax, bool widen = false) const {
         if (!isValid()) return false;
         const V3 invRayDir(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
         const V3 tNear = (minP - org) * invRayDir;
         const V3 tFar = (maxP - org) * invRayDir;
-        const V3 near_ = vminNaN(tNear, tFar);
-        const V3 far_ = vmaxNaN(tNear, tFar);
+        V3 near_ = vminNaN(tNear, tFar);
+        V3 far_ = vmaxNaN(tNear, tFar);
+        if (widen) {
+            constexpr float k = 9.5367431640625e-07f;   // 2^-20
+            const V3 e(k * std::fabs(invRayDir.x) * (std::fabs(org.x) + std::fmax(std::fabs(minP.x), std::fabs(maxP.x))),
+                       k * std::fabs(invRayDir.y) * (std::fabs(org.y) + std::fmax(std::fabs(minP.y), std::fabs(maxP.y))),
+                       k * std::fabs(invRayDir.z) * (std::fabs(org.z) + std::fmax(std::fabs(minP.z), std::fabs(maxP.z))));
+            // an axis the ray runs parallel to has e = inf and near / far = -+inf already (or NaN, which fmin / fmax drop)
+            if (std::isfinite(e.x)) { near_.x -= e.x; far_.x += e.x; }
+            if (std::isfinite(e.y)) { near_.y -= e.y; far_.y += e.y; }
+            if (std::isfinite(e.z)) { near_.z -= e.z; far_.z += e.z; }
+        }
         *hitDistMin = std::fmax(std::fmax(near_.x, near_.y), near_.z);
         *hitDistMax = std::fmin(std::fmin(far_.x, far_.y), far_.z);
         *hitDistMin = std::fmax(*hitDistMin, distMin);
@@ -646,8 +662,9 @@ static inline void sortOrder8(uint32_t (&keys)[8], uint32_t* values) { // :1239-
 
 // common/bvh_builder.cpp:1272-1514 (USE_COMPRESSED_STACK path).  `anyHit` = stop at the first
 // accepted triangle (the reference has closest-hit only; occlusion is order independent).
+// `widenBoxes`: the renderer's ray queries (AABB::intersect).
 static inline HitObject traverse(const GeometryBVH& bvh, V3 rayOrg, V3 rayDir, float distMin, float distMax,
-                                 TraversalStatistics* stats = nullptr, bool anyHit = false) {
+                                 TraversalStatistics* stats = nullptr, bool anyHit = false, bool widenBoxes = false) {
     HitObject ret;
     ret.dist = distMax; ret.geomIndex = 0xFFFFFFFFu; ret.primIndex = 0xFFFFFFFFu;
     ret.bcA = ret.bcB = ret.bcC = NAN;
@@ -684,7 +701,7 @@ static inline HitObject traverse(const GeometryBVH& bvh, V3 rayOrg, V3 rayDir, f
                 if (stats) ++stats->numAabbTests;
                 const AABB aabb = intNode.getChildAabb(slot);
                 float hitDistMin, hitDistMax;
-                if (aabb.intersect(rayOrg, rayDir, distMin, ret.dist, &hitDistMin, &hitDistMax)) {
+                if (aabb.intersect(rayOrg, rayDir, distMin, ret.dist, &hitDistMin, &hitDistMax, widenBoxes)) {
                     const bool isLeaf = intNode.getChildIsLeaf(slot);
                     const float dist = 0.5f * (hitDistMin + hitDistMax);
                     keys[slot] = (floatToOrderedUInt(dist) >> 1) | (static_cast<uint32_t>(!isLeaf) << 31);

@@ -33,7 +33,7 @@ struct PixelHit {
 // dependent, common/bvh_builder.cpp:1486-1497).
 static inline bvh::HitObject closestHitCanonical(const WorldAccel& a, V3 org, V3 dir, float tmin, float tmax) {
     if (a.useBruteForce) return bvh::bruteForce(a.bvh.triStorages, org, dir, tmin, tmax, false);
-    bvh::HitObject h = bvh::traverse(a.bvh, org, dir, tmin, tmax);
+    bvh::HitObject h = bvh::traverse(a.bvh, org, dir, tmin, tmax, nullptr, false, true);
     if (!h.isHit()) return h;
     // re-run over the closed interval end to collect exact ties: any triangle with the same dist
     // and a lower flattened index replaces the winner.
@@ -51,7 +51,7 @@ static inline bvh::HitObject closestHitCanonical(const WorldAccel& a, V3 org, V3
             for (uint32_t slot = 0; slot < bvh::arity; ++slot) {
                 if (!n.getChildIsValid(slot)) break;
                 float t0, t1;
-                if (!n.getChildAabb(slot).intersect(org, dir, lo, hi, &t0, &t1)) continue;
+                if (!n.getChildAabb(slot).intersect(org, dir, lo, hi, &t0, &t1, true)) continue;
                 if (!n.getChildIsLeaf(slot)) { st.push_back(n.intNodeChildBaseIndex + n.getInternalChildNumber(slot)); continue; }
                 uint32_t idx = n.leafBaseIndex + n.childMetas[slot];
                 while (true) {
@@ -78,7 +78,7 @@ static inline bvh::HitObject closestHitCanonical(const WorldAccel& a, V3 org, V3
 
 static inline bool occluded(const WorldAccel& a, V3 org, V3 dir, float tmin, float tmax) {
     if (a.useBruteForce) return bvh::bruteForce(a.bvh.triStorages, org, dir, tmin, tmax, true).isHit();
-    return bvh::traverse(a.bvh, org, dir, tmin, tmax, nullptr, true).isHit();
+    return bvh::traverse(a.bvh, org, dir, tmin, tmax, nullptr, true, true).isHit();
 }
 
 // ---------------------------------------------------------------- pixel-buffer accessors

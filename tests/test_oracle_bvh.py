@@ -78,3 +78,25 @@ def test_light_distributions_follow_compute_light_probs(built_lib):
     on_first = np.isclose(ls[:, 4], 12.0, atol=1e-4)
     frac = on_first.mean()
     assert abs(frac - w[2] / (w[2] + w[3])) < 0.01
+
+
+
+def test_renderer_queries_are_conservative_where_the_verbatim_traversal_is_not(built_lib):
+    """A ray of the textured bench street on which the reference's traversal as written returns the SECOND-closest triangle:
+    two overlapping sign instances are hit one ulp apart, the farther one first, and the nearer one's box is then culled
+    because its slab distance (plane - org) * (1 / dir) rounds above the triangle test's own distance.  Found by the
+    full-size path-tracer window of round 3 (the product agreed with brute force, the oracle did not).  The oracle's
+    renderer queries widen the slabs (orc_bvh.h AABB::intersect) and must equal brute force."""
+    hs = util.bench_street(textured=True)
+    osc = util.feed_oracle(hs)
+    org = np.zeros((1, 4), np.float32)
+    dirs = np.zeros((1, 4), np.float32)
+    org[0, :3] = [float.fromhex(x) for x in ("-0x1.045adcp+0", "0x1.b256e8p+1", "0x1.f19c58p+4")]
+    dirs[0, :3] = [float.fromhex(x) for x in ("0x1.c2e188p-1", "0x1.6b402ap-3", "0x1.c1e7ap-2")]
+    dirs[0, 3] = 3.402823466e+38
+    brute = osc.trace(2, org, dirs)
+    canon = osc.trace(0, org, dirs)
+    verbatim, _ = osc.trace(3, org, dirs, want_stats=True)
+    assert brute["dist"][0] == np.float32(float.fromhex("0x1.8f1da6p+4"))
+    util.assert_same_bits("renderer query vs brute force", canon, brute)
+    assert verbatim["dist"][0] == np.float32(float.fromhex("0x1.8f1da8p+4"))      # the reference traversal's answer: one ulp too far
