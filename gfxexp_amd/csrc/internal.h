@@ -89,7 +89,7 @@ struct NrcNet;
 // GFX_TRACE_BATCH) and gfx_tunable_set changes them per context at run time (profiles/, tools/).
 struct Tunables {
     int pixelMap = 2;                // restir_common.hip.h PixelGrid::mode: 0 scan lines, 1 8x8 tiles, 2 tiles + XCD supertiles
-    int superShiftX = 3, superShiftY = 2;   // supertile = 2^3 x 2^2 blocks of 16 x 16 pixels = 128 x 64 pixels
+    int superShiftX = 2, superShiftY = 2;   // supertile = 2^2 x 2^2 blocks of 16 x 16 pixels = 64 x 64 pixels (profiles/r03_pixel_map_supers.jsonl)
     int traceBlocksPerCU = 4;        // persistent traversal grid: blocks of 256 per CU (LDS: 4 x 40 KiB)
     int traceRefill = 8;             // refill a wave when at least this many lanes are idle
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)

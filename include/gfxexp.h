@@ -467,7 +467,7 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
 /* Scheduling knobs of a context; none changes a result (no reference counterpart: OptiX schedules in the driver).
  *   "pixel_map" 0|1|2           which pixels share a wave / block / XCD in the per-pixel kernels: scan lines, 8 x 8 tiles
  *                               (the tiling of restir_di/gpu_kernels/per_pixel_ris.cu:44-61), tiles + XCD-aware supertiles (default)
- *   "super_x", "super_y"        log2 of the supertile size in 16 x 16-pixel blocks (mode 2; default 3, 2)
+ *   "super_x", "super_y"        log2 of the supertile size in 16 x 16-pixel blocks (mode 2; default 2, 2)
  *   "trace_blocks_per_cu", "trace_refill", "trace_batch"   persistent traversal grid, lane-refill threshold, rays per ticket
  * The same knobs are read once from the environment by gfx_ctx_create (GFX_PIXEL_MAP, GFX_SUPER_X, GFX_SUPER_Y,
  * GFX_TRACE_BLOCKS_PER_CU, GFX_TRACE_REFILL, GFX_TRACE_BATCH). */

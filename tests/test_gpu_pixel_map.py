@@ -33,9 +33,9 @@ def _ids(p):
     return "map%d-super%dx%d" % p
 
 
-# mode 2 twice: the default supertile (8 x 4 blocks: one supertile covers these small images, 7 of 8 XCDs get
-# nothing) and 1 x 1 blocks (every XCD gets blocks, the last supertile row / column is ragged)
-CASES = [(0, 3, 2), (1, 3, 2), (2, 3, 2), (2, 0, 0), (2, 1, 0)]
+# mode 2 four times: a supertile larger than these small images (8 x 4 blocks: 7 of 8 XCDs get nothing), the default
+# 4 x 4, 1 x 1 blocks (every XCD gets blocks) and 2 x 1 (the last supertile row / column is ragged)
+CASES = [(0, 2, 2), (1, 2, 2), (2, 3, 2), (2, 2, 2), (2, 0, 0), (2, 1, 0)]
 
 
 @pytest.mark.gpu

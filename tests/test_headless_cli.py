@@ -251,7 +251,7 @@ def test_cli_nrc_renderer_matches_the_python_driver(built_lib, tmp_path, encodin
     want, stats = python_frames(1)
     assert np.abs(want).sum() > 0
     assert np.array_equal(_read_pfm(out).view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
-    assert d["nrc_last_frame"]["training_records"] == stats["numTrainingData"] > 100
+    assert d["nrc_last_frame"]["training_records"] == stats["numTrainingData"] > 20
     assert d["nrc_last_frame"]["tile_size"] == list(stats["tileSize"]) and np.isfinite(d["nrc_last_frame"]["loss"])
     out3 = str(tmp_path / "nrc3.pfm")
     d3 = _run(_scene_args() + opts + ["-frames", 4, "-out", out3])
