@@ -30,7 +30,7 @@ def rearch_passes(temporal, spatial, unbiased, new_sequence):
 RENDERER_BIASED, RENDERER_UNBIASED, RENDERER_REARCH_BIASED, RENDERER_REARCH_UNBIASED, RENDERER_PATH_TRACE, RENDERER_PATH_TRACE_REGIR = 0, 1, 2, 3, 4, 5
 (PT_SETUP_GBUFFERS, PT_PATH_TRACE_BASELINE, PT_REGIR_BUILD_CELLS, PT_REGIR_BUILD_CELLS_TEMPORAL,
  PT_PATH_TRACE_REGIR, PT_REGIR_UPDATE_LAST_ACCESS, PT_NRC_PREPROCESS, PT_PATH_TRACE_NRC, PT_NRC_ACCUMULATE,
- PT_NRC_PROPAGATE, PT_NRC_SHUFFLE, PT_NRC_VISUALIZE_PREDICTION) = range(12)
+ PT_NRC_PROPAGATE, PT_NRC_SHUFFLE, PT_NRC_VISUALIZE_PREDICTION, PT_NRC_COUNT_QUERIES, PT_PATH_TRACE_NRC_REGIR) = range(14)
 
 
 class GfxError(RuntimeError):
@@ -731,7 +731,13 @@ class GfxhNrcConfig(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("positionEncoding", C.c_int), ("numHiddenLayers", C.c_uint32),
                 ("learningRate", C.c_float), ("maxPathLength", C.c_uint32), ("radianceScale", C.c_float), ("train", C.c_uint32),
                 ("enableAccumulation", C.c_uint32), ("camera", GfxCamera), ("sceneAabbMin", C.c_float * 3),
-                ("sceneAabbMax", C.c_float * 3), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32)]
+                ("sceneAabbMax", C.c_float * 3), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32),
+                ("neeSampler", C.c_uint32), ("regirGridDimension", C.c_uint32 * 3),
+                ("regirLog2CandidatesPerLightSlot", C.c_uint32), ("regirLog2CandidatesPerCell", C.c_uint32),
+                ("regirEnableTemporalReuse", C.c_uint32), ("regirEnableCellRandomization", C.c_uint32), ("enableBumpMapping", C.c_uint32)]
+
+
+NRC_NEE_LIGHTS, NRC_NEE_REGIR = 0, 1
 
 
 class NrcRenderer:

@@ -32,6 +32,7 @@ struct gfxh_nrc {
     gfx_restir_static_params sp;
     gfx_restir_frame_params fp;
     gfx_nrc_params np;
+    gfx_regir_params regir;      // neeSampler == 1
     std::vector<void*> allocations;
     uint64_t accel = 0, network = 0;
     uint32_t frameIndex = 0, numAccumFrames = 0;
@@ -72,6 +73,10 @@ void gfxh_nrc_default_config(gfxh_nrc_config* cfg, uint32_t width, uint32_t heig
     cfg->width = width; cfg->height = height;
     cfg->positionEncoding = GFX_NRC_HASH_GRID; cfg->numHiddenLayers = 2; cfg->learningRate = 1e-2f;
     cfg->maxPathLength = 5; cfg->radianceScale = 1.0f; cfg->train = 1; cfg->enableAccumulation = 0;
+    cfg->neeSampler = 0;
+    cfg->regirGridDimension[0] = 32; cfg->regirGridDimension[1] = 8; cfg->regirGridDimension[2] = 32;   // regir_main.cpp:1112
+    cfg->regirLog2CandidatesPerLightSlot = 3; cfg->regirLog2CandidatesPerCell = 2;                       // :1733-1734
+    cfg->regirEnableTemporalReuse = 1; cfg->regirEnableCellRandomization = 1;                             // :1735-1736
     cfg->camera.aspect = static_cast<float>(width) / height;
     cfg->camera.fovY = 50 * 3.14159265358979323846f / 180;
     const float ident[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
@@ -130,6 +135,37 @@ int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out) {
     err |= nrc_alloc(r, &np.trainVertexInfoBuffer, 16ull * kTrainBufferSize);
     err |= nrc_alloc(r, &np.trainSuffixTerminalInfoBuffer, 4ull * np.maxNumTrainingSuffixes);
     err |= nrc_alloc(r, &np.dataShufflerBuffer, 4ull * kNumTrainingDataPerFrame);
+    std::memset(&r->regir, 0, sizeof(r->regir));
+    if (cfg->neeSampler == 1) {   // the light-slot grid of regir_main.cpp:1071-1097 over the scene box
+        gfx_regir_params& g = r->regir;
+        const uint32_t* d = cfg->regirGridDimension;
+        const size_t numCells = static_cast<size_t>(d[0]) * d[1] * d[2], numSlots = numCells * 512;
+        if (numCells == 0) { g_nrcError = "gfxh_nrc_create: empty ReGIR grid"; gfxh_nrc_destroy(r); return 1; }
+        if (!(cfg->rowBegin == 0 && cfg->rowEnd == 0)) { g_nrcError = "gfxh_nrc_create: the ReGIR NEE sampler is not wired to band renderers"; gfxh_nrc_destroy(r); return 1; }
+        for (int i = 0; i < 2; ++i) {
+            err |= nrc_alloc(r, &g.reservoirs[i], 48 * numSlots);
+            err |= nrc_alloc(r, &g.reservoirInfos[i], 8 * numSlots);
+            err |= nrc_alloc(r, &g.numActiveCells[i], 4);
+        }
+        err |= nrc_alloc(r, &g.lightSlotRngs, 8 * numSlots);
+        err |= nrc_alloc(r, &g.perCellNumAccesses, 4 * numCells);
+        err |= nrc_alloc(r, &g.lastAccessFrameIndices, 4 * numCells);
+        if (!err) {
+            std::vector<uint64_t> states(numSlots);
+            gfxh_seed_rng_states(states.data(), numSlots, 591842031321323413ull);
+            if (!nrc_hip_ok(hipMemcpy(g.lightSlotRngs, states.data(), 8 * numSlots, hipMemcpyHostToDevice), "upload light-slot rng states") ||
+                !nrc_hip_ok(hipMemset(g.lastAccessFrameIndices, 0xFF, 4 * numCells), "fill lastAccessFrameIndices")) err = 1;
+        }
+        for (int k = 0; k < 3; ++k) {
+            g.gridOrigin[k] = cfg->sceneAabbMin[k];
+            g.gridCellSize[k] = (cfg->sceneAabbMax[k] - cfg->sceneAabbMin[k]) / static_cast<float>(d[k]);
+            g.gridDimension[k] = d[k];
+        }
+        g.log2NumCandidatesPerLightSlot = cfg->regirLog2CandidatesPerLightSlot;
+        g.log2NumCandidatesPerCell = cfg->regirLog2CandidatesPerCell;
+        g.enableCellRandomization = cfg->regirEnableCellRandomization;
+    }
+    else if (cfg->neeSampler != 0) { g_nrcError = "gfxh_nrc_create: unknown neeSampler"; gfxh_nrc_destroy(r); return 1; }
     if (err) { gfxh_nrc_destroy(r); return 1; }
     {
         std::vector<uint64_t> states(n);
@@ -186,7 +222,7 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     fp.prevCamera = frameIndex == 0 ? cfg.camera : r->prevCamera;
     fp.camera = cfg.camera;
     fp.envLightPowerCoeff = 1.0f; fp.envLightRotation = 0.0f;
-    fp.bufferIndex = bufferIndex; fp.resetFlowBuffer = newSequence; fp.enableJittering = 0; fp.enableEnvLight = 0; fp.enableBumpMapping = 0; fp.useSolidAngleSampling = 0;
+    fp.bufferIndex = bufferIndex; fp.resetFlowBuffer = newSequence; fp.enableJittering = 0; fp.enableEnvLight = 0; fp.enableBumpMapping = cfg.enableBumpMapping; fp.useSolidAngleSampling = 0;
     r->np.radianceScale = cfg.radianceScale;
     r->np.preprocessOffsetToSelectUnbiasedTile = static_cast<uint32_t>(r->perFrameRng());   // main:2276-2277
     r->np.preprocessOffsetToSelectTrainingPath = static_cast<uint32_t>(r->perFrameRng());
@@ -197,9 +233,16 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     if (band && !r->exchange) { g_nrcError = "gfxh_nrc_render_frame: a band renderer needs gfxh_nrc_set_exchange"; return 1; }
     if (band && (cfg.rowEnd > H || cfg.rowBegin >= cfg.rowEnd)) { g_nrcError = "gfxh_nrc_render_frame: row band outside the image"; return 1; }
     const uint32_t rb = band ? cfg.rowBegin : 0, re = band ? cfg.rowEnd : 0;
+    const bool regirNee = cfg.neeSampler == 1;
     NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, rb, re));
+    if (regirNee) {   // regir_main.cpp:2031-2066 around the tracer: build (with temporal reuse past the first frame), trace, age
+        NRC_GFX(gfx_regir_set_params(ctx, &r->regir));
+        NRC_GFX(gfx_pt_launch(ctx, stream, (cfg.regirEnableTemporalReuse && !newSequence) ? GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL : GFX_PT_REGIR_BUILD_CELL_RESERVOIRS,
+                              W, H, cfg.maxPathLength, 0, 0));
+    }
     NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_PREPROCESS, W, H, cfg.maxPathLength, 0, 0));
-    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_PATH_TRACE_NRC, W, H, cfg.maxPathLength, rb, re));
+    NRC_GFX(gfx_pt_launch(ctx, stream, regirNee ? GFX_PT_PATH_TRACE_NRC_REGIR : GFX_PT_PATH_TRACE_NRC, W, H, cfg.maxPathLength, rb, re));
+    if (regirNee) NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_REGIR_UPDATE_LAST_ACCESS, W, H, cfg.maxPathLength, 0, 0));
     // main:2293-2303: the inference batch size needs the tile size of this frame.  The reference synchronises the stream and
     // reads it back; a band renderer does the same here (the record gather needs the counts on the host anyway).  The whole-
     // frame renderer forms the batch size on the device instead and never waits for the GPU inside a frame.

@@ -22,6 +22,7 @@
 // Neural radiance caching (-renderer nrc; neural_radiance_caching/neural_radiance_caching_main.cpp:755-790, defaults :458-460):
 //   -position-encoding tri-wave|hash-grid (hash-grid)   -num-hidden-layers n (2)   -learning-rate lr (1e-2)
 //   and, headless: -max-path-length n (5; 0 = unlimited, :1860-1861)   -no-train   -log10-radiance-scale s (0, :2240)
+//   -nee lights|regir (lights): next-event estimation from the emitter distributions (the reference) or from the ReGIR grid
 // Textures are read by the host decoders of scene_builder.cpp (PPM / PGM / PFM / BMP / TGA); DDS / PNG / JPEG assets have to be
 // decoded offline (the image has no image libraries).
 #include <cmath>
@@ -89,6 +90,7 @@ struct Options {
     int positionEncoding = GFX_NRC_HASH_GRID;
     uint32_t numHiddenLayers = 2, maxPathLength = 5;
     float learningRate = 1e-2f, log10RadianceScale = 0.0f;
+    uint32_t neeSampler = 0;
 };
 
 [[noreturn]] void fail(const char* what, const char* arg) {
@@ -214,6 +216,14 @@ Options parse(int argc, const char* argv[]) {
         else if (a == "-max-path-length") { need(i, 1); o.maxPathLength = static_cast<uint32_t>(std::atoi(argv[i + 1])); i += 1; }
         else if (a == "-log10-radiance-scale") { need(i, 1); o.log10RadianceScale = static_cast<float>(std::atof(argv[i + 1])); i += 1; }
         else if (a == "-no-train") o.nrcTrain = false;
+        else if (a == "-nee") {
+            need(i, 1);
+            const std::string v = argv[i + 1];
+            if (v == "lights") o.neeSampler = 0;
+            else if (v == "regir") o.neeSampler = 1;
+            else fail("unknown NEE sampler:", argv[i + 1]);
+            i += 1;
+        }
         else if (a == "-animate") o.animate = true;
         else if (a == "-accumulate") o.accumulate = true;
         else if (a == "-bump") o.bump = true;
@@ -292,8 +302,9 @@ int main(int argc, const char* argv[]) {
                 counts[0], counts[1], counts[2], counts[3], counts[4], gfxh_scene_num_textures(scene), controllers.size(),
                 bounds[0], bounds[1], bounds[2], bounds[3], bounds[4], bounds[5], o.camPos[0], o.camPos[1], o.camPos[2],
                 camM[0], camM[1], camM[2], camM[3], camM[4], camM[5], camM[6], camM[7], camM[8], o.nrc ? -1 : o.renderer, o.width, o.height, o.frames);
-    if (o.nrc) std::printf(",\n \"nrc\": {\"position_encoding\": \"%s\", \"num_hidden_layers\": %u, \"learning_rate\": %.9g, \"max_path_length\": %u, \"train\": %s}",
-                           o.positionEncoding == GFX_NRC_HASH_GRID ? "hash-grid" : "tri-wave", o.numHiddenLayers, o.learningRate, o.maxPathLength, o.nrcTrain ? "true" : "false");
+    if (o.nrc) std::printf(",\n \"nrc\": {\"position_encoding\": \"%s\", \"num_hidden_layers\": %u, \"learning_rate\": %.9g, \"max_path_length\": %u, \"train\": %s, \"nee\": \"%s\"}",
+                           o.positionEncoding == GFX_NRC_HASH_GRID ? "hash-grid" : "tri-wave", o.numHiddenLayers, o.learningRate, o.maxPathLength, o.nrcTrain ? "true" : "false",
+                           o.neeSampler == 1 ? "regir" : "lights");
     std::printf(",\n \"instance_transforms\": [");
     for (uint32_t i = 0; i < counts[3]; ++i) {
         uint32_t group; float xfm[12];
@@ -332,6 +343,8 @@ int main(int argc, const char* argv[]) {
         cfg.maxPathLength = o.maxPathLength; cfg.train = o.nrcTrain ? 1u : 0u;
         cfg.radianceScale = std::pow(10.0f, o.log10RadianceScale);                    // :2240
         cfg.enableAccumulation = o.accumulate ? 1u : 0u;
+        cfg.enableBumpMapping = o.bump ? 1u : 0u;
+        cfg.neeSampler = o.neeSampler;
         for (int k = 0; k < 3; ++k) cfg.camera.position[k] = static_cast<float>(o.camPos[k]);
         for (int k = 0; k < 9; ++k) cfg.camera.orientation[k] = static_cast<float>(camM[k]);
         for (int k = 0; k < 3; ++k) { cfg.sceneAabbMin[k] = bounds[k]; cfg.sceneAabbMax[k] = bounds[3 + k]; }   // scene.initialSceneAabb (:1139)

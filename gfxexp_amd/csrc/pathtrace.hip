@@ -143,7 +143,9 @@ struct PtVertexOut {              // what one shaded vertex hands to the queues
 // unshadowed estimate and the shadow ray; + BSDF sampling of the next direction (:140-147, :283-295)
 // and the head of the path extension loop.  Every lane of the wave must call it (`active` = lanes
 // that shade a vertex) because the ReGIR variant merges its cell-access atomics across the wave.
-template <bool REGIR>
+// REGIR: NEE from the grid cell (sampleFromCell); REGIR_LOOP: Russian roulette at the loop head as pathTraceReGIR does
+// (the NRC tracer with ReGIR NEE keeps its own Russian roulette: REGIR = true, REGIR_LOOP = false).
+template <bool REGIR, bool REGIR_LOOP = REGIR>
 GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool envEnabled, f3 pos, f3 vOutLocal, const Frame& frame,
                           const Bsdf& bsdf, Pcg32& rng, f3& alpha, f3& contribution, float& dirPDensity, PtVertexOut& o) {
     f3 ret(0.0f);
@@ -199,7 +201,7 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
     o.extDir = frame.from_local(vInLocal);
     // loop head of the ray-generation program (:163-166): only valid samples are extended
     o.wantExt = dirPDensity > 0.0f && is_finite(dirPDensity);
-    if (REGIR && o.wantExt) {   // regir/gpu_kernels/optix_pathtracing_kernels.cu:247-256
+    if (REGIR_LOOP && o.wantExt) {   // regir/gpu_kernels/optix_pathtracing_kernels.cu:247-256
         if (a.nextMaxLengthTerminate) o.wantExt = false;
         else {
             const float continueProb = fminf(luminance_srgb(alpha) / luminance_srgb(f3(1.0f)), 1.0f);
@@ -694,7 +696,9 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_preprocess(PtArgs a) {
     static_cast<uint32_t*>(a.nrc.trainSuffixTerminalInfoBuffer)[i] = nrc_suffix_bits(kInvalidVertexDataIndex, false, 0);
 }
 
-// pathTrace_raygen_generic<true> up to the path extension loop (:133-318)
+// pathTrace_raygen_generic<true> up to the path extension loop (:133-318).  REGIR: next-event estimation from the ReGIR
+// grid (GFX_PT_PATH_TRACE_NRC_REGIR, include/gfxexp.h).
+template <bool REGIR>
 __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_first(PtArgs a) {
     const PixelId px = pixel_of_thread(a.px);
     const size_t p = px.p;
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_first(PtArgs a) {
     else if (inImage && envEnabled) {
         contribution = a.f.envLightPowerCoeff * env.fetch(decode_bc(g0.w & 0xFFFF), decode_bc(g0.w >> 16));
     }
-    shade_vertex<false>(a, surface, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
+    shade_vertex<REGIR, false>(a, surface, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
     // training record of the first vertex (:238-277)
     uint32_t trainIdx = nrc_alloc_train_index(static_cast<uint32_t*>(a.nrc.numTrainingData[bufIdx]), surface && tile.training);
     if (surface && tile.training) {
@@ -789,7 +793,9 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_first(PtArgs a) {
 }
 
 // pathTrace_closestHit_generic<true> / pathTrace_miss_generic<true> for one extension ray, then the
-// loop head and, when the path stops, the tail of the ray-generation program (:380-677, :320-373)
+// loop head and, when the path stops, the tail of the ray-generation program (:380-677, :320-373).  REGIR: emitters
+// found by BSDF sampling contribute nothing (the ReGIR NEE has no density to weight them against).
+template <bool REGIR>
 __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
     const uint32_t i = blockIdx.x * kPtBlock + threadIdx.x;
     const uint32_t count = *a.extCountIn;
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
         float* prevTarget = static_cast<float*>(a.nrc.trainTargetBuffer[0]) + 3ull * prevTrainIdx;
         const bool linkPrev = tile.training && prevTrainIdx != kInvalidVertexDataIndex;
         if (h.triIndex == GFX_INVALID_SLOT) {
-            if (envEnabled) {
+            if (envEnabled && !REGIR) {
                 const f3 rd = unit(rayDir);
                 float posPhi, theta;
                 to_polar_yup(rd, posPhi, theta);
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
             if (!all_finite(ns)) { ns = f3(0, 0, 1); tc0 = f3(1, 0, 0); }
             if (!all_finite(tc0)) { f3 bt; make_coordinate_system(ns, tc0, bt); }
             float hypAreaPDensity = 0.0f;
-            {
+            if (!REGIR) {
                 float lightProb = 1.0f;
                 if (envEnabled) lightProb *= (1 - 0.25f);
                 const float instImportance = inst->distIntegral;
@@ -907,7 +913,7 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
             vOutLocal = frame.to_local(vOut);
             const float dist2 = len2(rayOrg - pos);
             curSqrtPathSpread += sqrtf(dist2 / (prevDirPDensity * fabsf(vOutLocal.z)));
-            if (vOutLocal.z > 0 && mat.hasEmittance) {
+            if (!REGIR && vOutLocal.z > 0 && mat.hasEmittance) {
                 const f3 emittance = material_emittance(a.scene, mat, tu, tv);
                 const float lightPDensity = hypAreaPDensity * dist2 / vOutLocal.z;
                 const float misWeight = (prevDirPDensity * prevDirPDensity) / (prevDirPDensity * prevDirPDensity + lightPDensity * lightPDensity);
@@ -969,7 +975,7 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
             }
         }
     }
-    shade_vertex<false>(a, shade, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
+    shade_vertex<REGIR, false>(a, shade, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
     // training record of this vertex (:574-631)
     const bool wantRecord = shade && tile.training && !(flags & kNrcFlagSuffixEnds);
     uint32_t trainIdx = nrc_alloc_train_index(static_cast<uint32_t*>(a.nrc.numTrainingData[bufIdx]), wantRecord);
@@ -1168,8 +1174,9 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     }
     const RestirParams& rp = ctx.restir;
     if (!rp.valid) throw HipError("gfx_pt_launch: gfx_restir_set_params has not been called");
-    const bool regirPass = pass >= GFX_PT_REGIR_BUILD_CELL_RESERVOIRS && pass <= GFX_PT_REGIR_UPDATE_LAST_ACCESS;
-    const bool nrcPass = pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_COUNT_QUERIES;
+    const bool nrcRegir = pass == GFX_PT_PATH_TRACE_NRC_REGIR;
+    const bool regirPass = (pass >= GFX_PT_REGIR_BUILD_CELL_RESERVOIRS && pass <= GFX_PT_REGIR_UPDATE_LAST_ACCESS) || nrcRegir;
+    const bool nrcPass = (pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_COUNT_QUERIES) || nrcRegir;
     if (!regirPass && !nrcPass && pass != GFX_PT_PATH_TRACE_BASELINE) throw HipError("gfx_pt_launch: unknown pass");
     if (regirPass && !ctx.regirValid) throw HipError("gfx_pt_launch: gfx_regir_set_params has not been called");
     if (nrcPass && !ctx.nrcRenderValid) throw HipError("gfx_pt_launch: gfx_nrc_set_render_params has not been called");
@@ -1222,7 +1229,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         return;
     }
     const bool regir = pass == GFX_PT_PATH_TRACE_REGIR;
-    const bool nrc = pass == GFX_PT_PATH_TRACE_NRC;
+    const bool nrc = pass == GFX_PT_PATH_TRACE_NRC || nrcRegir;
     if (static_cast<uint32_t>(rp.s.imageSizeX) != width || static_cast<uint32_t>(rp.s.imageSizeY) != height)
         throw HipError("gfx_pt_launch: launch size differs from imageSize in the static parameters");
     const uint64_t h = rp.f.travHandle;
@@ -1280,7 +1287,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     set_queues(1, cur);
     a.pathLength = 1; a.maxLengthTerminate = 0;
     a.nextMaxLengthTerminate = 2 >= maxPathLength ? 1u : 0u;
-    if (nrc) launch_pixels("nrc_pt_first", k_nrc_pt_first);
+    if (nrc) launch_pixels("nrc_pt_first", nrcRegir ? k_nrc_pt_first<true> : k_nrc_pt_first<false>);
     else launch_pixels("pt_first", regir ? k_pt_first<true> : k_pt_first<false>);
     // while (true) { ++pathLength; trace; }.  Baseline: at least one extension even when maxPathLength < 2,
     // the terminal vertex (implicit light only) emits no NEE ray.  ReGIR: the loop head breaks before the
@@ -1308,7 +1315,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         a.pathLength = pathLength;
         a.maxLengthTerminate = (pathLength >= maxPathLength && (!nrc || maxPathLength > 0)) ? 1u : 0u;
         a.nextMaxLengthTerminate = pathLength + 1 >= maxPathLength ? 1u : 0u;
-        if (nrc) launch("nrc_pt_bounce", k_nrc_pt_bounce);
+        if (nrc) launch("nrc_pt_bounce", nrcRegir ? k_nrc_pt_bounce<true> : k_nrc_pt_bounce<false>);
         else launch("pt_bounce", regir ? k_pt_bounce<true> : k_pt_bounce<false>);
         cur ^= 1;
         if (!regir && !nrc && a.maxLengthTerminate) break;

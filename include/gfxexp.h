@@ -358,7 +358,17 @@ enum gfx_pt_pass {
     /* numInferenceQueries = (W * H + #tiles of tileSize[bufferIndex]) rounded up to 128 -- what the reference computes on the
      * host after a stream synchronisation and a device read (neural_radiance_caching_main.cpp:2293-2303) -- written to the
      * context's device word (gfx_nrc_query_count_ptr) for gfx_nrc_infer_indirect: the frame needs no host round trip. */
-    GFX_PT_NRC_COUNT_QUERIES = 12
+    GFX_PT_NRC_COUNT_QUERIES = 12,
+    /* GFX_PT_PATH_TRACE_NRC with many-light next-event estimation: every path vertex draws its light sample from the ReGIR
+     * grid cell under it (sampleFromCell, regir/gpu_kernels/optix_pathtracing_kernels.cu:18-82) instead of the emitter
+     * distributions (neural_radiance_caching/gpu_kernels/optix_pathtracing_kernels.cu:38-63).  The combination is an open
+     * item of the reference (README.md:80-81 "Combine with many-light sampling techniques like ReSTIR/ReGIR"), so its
+     * definition is this build's: the ReGIR estimate has no evaluable density, hence no MIS -- NEE carries all direct light
+     * at a path vertex and emitters found by BSDF sampling (path length >= 2, incl. the environment) contribute nothing;
+     * Russian roulette, cache termination and the training records are those of the NRC tracer.  Needs gfx_regir_set_params
+     * (grid built by GFX_PT_REGIR_BUILD_CELL_RESERVOIRS* before, GFX_PT_REGIR_UPDATE_LAST_ACCESS after) AND
+     * gfx_nrc_set_render_params. */
+    GFX_PT_PATH_TRACE_NRC_REGIR = 13
 };
 
 /* The ReGIR members of regir/regir_shared.h:200-263 (grid of cells x 512 light slots).  Light-slot

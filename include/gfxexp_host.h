@@ -321,6 +321,14 @@ typedef struct gfxh_nrc_config {
     gfx_camera camera;
     float sceneAabbMin[3], sceneAabbMax[3];   /* scene.initialSceneAabb (main:1139) */
     uint32_t rowBegin, rowEnd;   /* rows [rowBegin, rowEnd) of a band renderer (needs gfxh_nrc_set_exchange); 0, 0 = the whole frame */
+    /* next-event estimation of the NRC tracer: 0 = the emitter distributions (the reference), 1 = the ReGIR grid
+     * (GFX_PT_PATH_TRACE_NRC_REGIR: an extension, the reference lists the combination as open, README.md:80-81).  The grid
+     * spans sceneAabb; its parameters default to regir_main.cpp:1112, 1733-1736.  Whole-frame renderers only. */
+    uint32_t neeSampler;
+    uint32_t regirGridDimension[3];
+    uint32_t regirLog2CandidatesPerLightSlot, regirLog2CandidatesPerCell;
+    uint32_t regirEnableTemporalReuse, regirEnableCellRandomization;
+    uint32_t enableBumpMapping;  /* 0 */
 } gfxh_nrc_config;
 void gfxh_nrc_default_config(gfxh_nrc_config* cfg, uint32_t width, uint32_t height);
 int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out);

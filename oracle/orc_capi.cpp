@@ -406,12 +406,17 @@ int orc_pt_launch(orc_scene* s, const gfx_restir_static_params* sp, const gfx_re
     p.scene = &s->scene; p.accel = &s->accel; p.s = sp; p.f = fp;
     p.camera = toCamera(fp->camera);
     p.maxPathLength = maxPathLength & 15u; // 4-bit bitfield, path_tracing_shared.h:165
-    if (pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_VISUALIZE_PREDICTION) {
+    if ((pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_VISUALIZE_PREDICTION) || pass == GFX_PT_PATH_TRACE_NRC_REGIR) {
         if (!g_nrcValid) return 1;
+        if (pass == GFX_PT_PATH_TRACE_NRC_REGIR) {
+            if (!g_regirValid) return 1;
+            p.regir = &rs;
+        }
         NrcState ns; ns.n = &g_nrcParams;
         const int W = sp->imageSizeX, H = sp->imageSizeY;
         switch (pass) {
         case GFX_PT_NRC_PREPROCESS: preprocessNRC(ns, *fp); break;
+        case GFX_PT_PATH_TRACE_NRC_REGIR:
         case GFX_PT_PATH_TRACE_NRC: {
             // one thread, row-major: the training-record order (an atomicAdd race in the reference) is defined
             // a window (x0, y0, x1, y1) restricts the pass to those pixels (full-size parity tests): per-pixel results

@@ -151,8 +151,13 @@ static inline void nrcTraceVertex(const PathTraceParams& p, const NrcState& ns, 
     const bool useEnvLight = p.envEnabled();
     const size_t numPixels = static_cast<size_t>(p.s->imageSizeX) * p.s->imageSizeY;
     const bvh::HitObject h = closestHitCanonical(*p.accel, rayOrg, rayDir, 0.0f, 3.402823466e+38f);
+    // p.regir (GFX_PT_PATH_TRACE_NRC_REGIR, include/gfxexp.h): next-event estimation samples the ReGIR grid cell
+    // (performNextEventEstimation's regir branch); that estimate has no evaluable density, so there is no MIS and emitters
+    // found by BSDF sampling -- the environment in the miss program, emissive surfaces in the closest-hit program --
+    // contribute nothing at path length >= 2.  An extension of this build: the reference lists the combination as open
+    // (README.md:80-81).
     if (!h.isHit()) { // miss
-        if (!useEnvLight) return;
+        if (!useEnvLight || p.regir) return;
         const V3 rd = normalize(rayDir);
         float posPhi, theta;
         toPolarYUp(rd, &posPhi, &theta);
@@ -194,7 +199,7 @@ static inline void nrcTraceVertex(const PathTraceParams& p, const NrcState& ns, 
     const float dist2 = sqLength(rayOrg - positionInWorld);
     pl.curSqrtPathSpread += std::sqrt(dist2 / (pl.prevDirPDensity * std::fabs(vOutLocal.z)));
 
-    if (vOutLocal.z > 0 && mat.hasEmittance) {
+    if (!p.regir && vOutLocal.z > 0 && mat.hasEmittance) {
         const RGB emittance = materialEmittance(scene.textures, mat, texCoord);
         const float lightPDensity = hypAreaPDensity * dist2 / vOutLocal.z;
         const float bsdfPDensity = pl.prevDirPDensity;

@@ -34,9 +34,16 @@ def _compare_exact(diffs, tag, got, want, keys):
             diffs.append(f"{tag}: {k}: {len(np.unique(np.nonzero(a != b)[0] // item))} of {want[k].size} elements differ")
 
 
-def run_nrc_both(hs, width, height, frames, max_len, env=None, camera=None, radiance_scale=1.0):
+def run_nrc_both(hs, width, height, frames, max_len, env=None, camera=None, radiance_scale=1.0, regir=False):
+    """regir=True: GFX_PT_PATH_TRACE_NRC_REGIR -- the ReGIR grid (built and aged every frame, compared like the per-pixel
+    buffers) supplies the next-event estimation of the NRC tracer."""
     import torch
     ctx, accel, osc, dev, pb_cpu, nb_gpu, nb_cpu = _setup(hs, width, height, env, radiance_scale)
+    rb_gpu = rb_cpu = None
+    if regir:
+        rb_gpu, rb_cpu = util.RegirBuffers(hs.bounds(), (8, 4, 8)), util.RegirBuffers(hs.bounds(), (8, 4, 8))
+        ctx.regir_set_params(rb_gpu.device_params())
+        osc.regir_set_params(rb_cpu.host_params())
     cam = camera if camera is not None else api.make_camera(width, height, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
     ocam = util.copy_struct(O.GfxCamera, cam)
     s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
@@ -56,12 +63,20 @@ def run_nrc_both(hs, width, height, frames, max_len, env=None, camera=None, radi
         ctx.nrc_set_render_params(nb_gpu.device_params(ou, ot, frame == 0))
         osc.nrc_set_render_params(nb_cpu.host_params(ou, ot, frame == 0))
         b = frame % 2
-        for pass_id in (api.PT_SETUP_GBUFFERS, api.PT_NRC_PREPROCESS, api.PT_PATH_TRACE_NRC):
+        passes = (api.PT_SETUP_GBUFFERS, api.PT_NRC_PREPROCESS, api.PT_PATH_TRACE_NRC)
+        if regir:   # regir_main.cpp:2031-2066 around the NRC tracer
+            build = api.PT_REGIR_BUILD_CELLS if frame == 0 else api.PT_REGIR_BUILD_CELLS_TEMPORAL
+            passes = (api.PT_SETUP_GBUFFERS, build, api.PT_NRC_PREPROCESS, api.PT_PATH_TRACE_NRC_REGIR, api.PT_REGIR_UPDATE_LAST_ACCESS)
+        for pass_id in passes:
             ctx.pt_launch(pass_id, width, height, max_len, 0, 0, stream)
             osc.pt_launch(s_cpu, f_cpu, pass_id, max_len)
         got, want = dev.download(), pb_cpu.arrays()
         got.update(nb_gpu.download()); want.update(nb_cpu.arrays())
         tag = f"frame {frame} path trace"
+        if regir:
+            gr, wr = rb_gpu.download(), rb_cpu.arrays()
+            _compare_exact(diffs, tag, gr, wr, list(wr.keys()))
+            assert wr["regir_accesses"].sum() > 0
         _compare_exact(diffs, tag, got, want, ["rng", f"gb0_{b}", "nrc_contribution", "nrc_terminal", f"nrc_num_{b}", f"nrc_tile_{b}",
                                                "nrc_off_unbiased", "nrc_off_training"])
         # inference queries: pixel entries of paths that ended in the cache, suffix entries with a query
@@ -118,6 +133,27 @@ def test_nrc_render_street_with_env_light(built_lib):
     cam = api.make_camera(96, 64, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
     diffs = run_nrc_both(util.small_street(), 96, 64, 2, 5, env=(sky, w, h), camera=cam)
     assert not diffs, "\n".join(diffs[:12])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_len", [5, 3])
+def test_nrc_render_with_regir_next_event_estimation(built_lib, max_len):
+    """SURVEY 8(f) row 4, last clause (README.md:80-81 of the reference lists it as open): the NRC path tracer whose NEE samples
+    the ReGIR grid cell -- sampleFromCell (regir/gpu_kernels/optix_pathtracing_kernels.cu:18-82) at the NEE site of
+    neural_radiance_caching/gpu_kernels/optix_pathtracing_kernels.cu:38-63 -- bit for bit against the oracle: pixel RNGs,
+    contributions, terminal infos, queries, training chains, the light-slot reservoirs and the cell bookkeeping over
+    three frames (grid temporal reuse active from the second)."""
+    diffs = run_nrc_both(util.bunny_scene(), 96, 64, 3, max_len, regir=True)
+    assert not diffs, "\n".join(diffs)
+
+
+@pytest.mark.gpu
+def test_nrc_render_with_regir_nee_street_and_env_light(built_lib):
+    hs = util.small_street()
+    sky = api.env_make_sky(64, 32)
+    cam = api.make_camera(96, 64, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
+    diffs = run_nrc_both(hs, 96, 64, 2, 4, env=(sky, 64, 32), camera=cam, regir=True)
+    assert not diffs, "\n".join(diffs)
 
 
 @pytest.mark.gpu
@@ -193,3 +229,37 @@ def test_headless_nrc_renderer_learns_the_indirect_light(built_lib):
     err_trained = np.abs(img_trained.mean(axis=0) - ref_img.mean(axis=0)).sum()
     print("nrc end-to-end: |mean error| untrained %.5f trained %.5f" % (err_untrained, err_trained))
     assert err_trained < 0.85 * err_untrained, (err_trained, err_untrained, ref_img.mean(axis=0), img_trained.mean(axis=0))
+
+
+@pytest.mark.gpu
+def test_headless_nrc_renderer_with_regir_nee_sees_the_same_light(built_lib):
+    """gfxh_nrc with neeSampler = ReGIR (the grid is built, traced and aged inside gfxh_nrc_render_frame): without training and
+    with maxPathLength 2 the accumulated picture is the direct light of the first vertex in both samplers, so the two means
+    agree (6 %, as on the CPU); with training on the renderer runs and stays finite."""
+    import torch
+    hs = util.bunny_scene()
+    W, H = 160, 96
+
+    def mean_image(nee, frames, train, max_len):
+        ctx = api.Context(0)
+        hs.upload(ctx)
+        cfg = api.NrcRenderer.default_config(W, H, hs.bounds())
+        cfg.camera = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+        cfg.neeSampler, cfg.train, cfg.maxPathLength, cfg.enableAccumulation = nee, int(train), max_len, 1
+        for k in range(3):
+            cfg.regirGridDimension[k] = (8, 4, 8)[k]
+        r = api.NrcRenderer(ctx, cfg)
+        for _ in range(frames):
+            r.render_frame()
+        r.network()
+        torch.cuda.synchronize()
+        out = ctx.read_device(r.beauty_ptr(), W * H * 16).view(np.float32).reshape(H, W, 4)[..., :3].copy()
+        r.close()
+        return out
+
+    base = mean_image(api.NRC_NEE_LIGHTS, 64, False, 2)
+    grid = mean_image(api.NRC_NEE_REGIR, 64, False, 2)
+    assert np.isfinite(grid).all() and base.mean() > 1e-3
+    assert abs(grid.mean() - base.mean()) < 0.06 * base.mean(), (grid.mean(), base.mean())
+    trained = mean_image(api.NRC_NEE_REGIR, 12, True, 5)
+    assert np.isfinite(trained).all() and trained.mean() > 0.5 * base.mean()

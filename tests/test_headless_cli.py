@@ -85,10 +85,13 @@ def test_nrc_options_of_the_reference_command_line(built_lib):
     base = _scene_args() + ["-size", 64, 48, "-renderer", "nrc", "-dry-run"]
     d = _run(base)
     assert d["renderer"] == -1 and d["nrc"] == {"position_encoding": "hash-grid", "num_hidden_layers": 2, "learning_rate": 0.00999999978,
-                                                "max_path_length": 5, "train": True}
+                                                "max_path_length": 5, "train": True, "nee": "lights"}
     d = _run(base + ["-position-encoding", "tri-wave", "-num-hidden-layers", 5, "-learning-rate", "1e-3", "-max-path-length", 0, "-no-train"])
     assert d["nrc"]["position_encoding"] == "tri-wave" and d["nrc"]["num_hidden_layers"] == 5 and abs(d["nrc"]["learning_rate"] - 1e-3) < 1e-9
     assert d["nrc"]["max_path_length"] == 0 and d["nrc"]["train"] is False
+    assert _run(base + ["-nee", "regir"])["nrc"]["nee"] == "regir"
+    r = _run(base + ["-nee", "restir"], check=False)
+    assert r.returncode != 0 and "NEE sampler" in r.stderr
     r = _run(base + ["-position-encoding", "fourier"], check=False)
     assert r.returncode != 0 and "position encoding" in r.stderr
     r = _run(base + ["-learning-rate", "nan"], check=False)
