@@ -9,6 +9,7 @@
 // hipMemcpyAsync resolved from the process (device pointers, RCCL_STUB_DEVICE=1 on the GPU box).
 #include <dlfcn.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -29,9 +30,19 @@ void copy_bytes(void* dst, const void* src, size_t n, void* stream) {
     if (dst == src || n == 0) return;
     const char* dev = getenv("RCCL_STUB_DEVICE");
     if (dev && dev[0] == '1') {
+        // stream-ordered like the real collective: the HIP runtime the process already loaded (ctypes loads libraries
+        // RTLD_LOCAL, so the symbol is looked up in that library's handle, not in the global scope)
         typedef int (*MemcpyAsync)(void*, const void*, size_t, int, void*);
-        static MemcpyAsync f = reinterpret_cast<MemcpyAsync>(dlsym(RTLD_DEFAULT, "hipMemcpyAsync"));
-        if (f) { f(dst, src, n, 3 /* hipMemcpyDeviceToDevice */, stream); return; }
+        static MemcpyAsync f = nullptr;
+        if (!f) {
+            f = reinterpret_cast<MemcpyAsync>(dlsym(RTLD_DEFAULT, "hipMemcpyAsync"));
+            const char* names[] = { "libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so" };
+            for (int k = 0; k < 3 && !f; ++k)
+                if (void* h = dlopen(names[k], RTLD_NOW | RTLD_NOLOAD)) f = reinterpret_cast<MemcpyAsync>(dlsym(h, "hipMemcpyAsync"));
+        }
+        if (!f) { fprintf(stderr, "rccl_stub: RCCL_STUB_DEVICE=1 but no loaded HIP runtime exports hipMemcpyAsync\n"); abort(); }
+        f(dst, src, n, 3 /* hipMemcpyDeviceToDevice */, stream);
+        return;
     }
     memmove(dst, src, n);
 }

@@ -173,9 +173,13 @@ def gpu_plan(api, L, stub):
         assert ag.count == slab and ag.dtype == 1 and ag.a == ag.b + slab * rank, "in-place all-gather of max-band slabs"
         rows = frame.view(H, W * 4)[:, 0].cpu().numpy()
         b0 = bands[rank][0]
+        own = bands[rank][1] - bands[rank][0]
         for q, (qb, qe) in enumerate(bands):
-            want = np.arange(qb, qe) if q == rank else b0 + np.arange(qe - qb)
-            assert np.array_equal(rows[qb:qe], want.astype(np.float32)), (rank, q)
+            # a slot holds as many valid rows as the CALLER's band has (the stub echoes its slab); a taller band q also
+            # receives the slab's padding rows, which carry no data in this emulation
+            m = min(qe - qb, own)
+            want = np.arange(qb, qb + m) if q == rank else b0 + np.arange(m)
+            assert np.array_equal(rows[qb:qb + m], want.astype(np.float32)), (rank, q)
         # a renderer whose band is not this rank's band of the partition is refused
         d.bandBegin += 8
         assert L.gfxh_rccl_exchange(comm, stream, C.byref(d)) == 1
