@@ -216,13 +216,18 @@ static size_t tex_bytes_per_texel(uint32_t format) {
     default: return 0;
     }
 }
+constexpr uint32_t kMaxTextureDim = 16384;   // TexDimInfo packs 14 bits per dimension (gfx_texture_set rejects more at upload)
 uint32_t gfxh_scene_add_texture(gfxh_scene* s, uint32_t width, uint32_t height, uint32_t format, const void* texels) {
     const size_t bpp = tex_bytes_per_texel(format);
     if (!bpp || !width || !height || !texels) { g_hostError = "gfxh_scene_add_texture: bad arguments"; return 0; }
-    Tex t;
-    t.width = width; t.height = height; t.format = format;
-    t.texels.assign(static_cast<const uint8_t*>(texels), static_cast<const uint8_t*>(texels) + bpp * width * height);
-    s->textures.push_back(std::move(t));
+    if (width > kMaxTextureDim || height > kMaxTextureDim) { g_hostError = "gfxh_scene_add_texture: texture larger than 16384 x 16384"; return 0; }
+    try {   // nothing may unwind through the C boundary (a bad_alloc from the copy)
+        Tex t;
+        t.width = width; t.height = height; t.format = format;
+        t.texels.assign(static_cast<const uint8_t*>(texels), static_cast<const uint8_t*>(texels) + bpp * width * height);
+        s->textures.push_back(std::move(t));
+    }
+    catch (const std::exception& e) { g_hostError = std::string("gfxh_scene_add_texture: ") + e.what(); return 0; }
     return static_cast<uint32_t>(s->textures.size());   // 1-based slot
 }
 uint32_t gfxh_scene_num_textures(gfxh_scene* s) { return static_cast<uint32_t>(s->textures.size()); }
@@ -265,6 +270,8 @@ bool decode_image(const std::string& path, Image& img, std::string& err) {
         for (int k = 0; k < 3; ++k) { if (!pnm_token(d, at, t)) { err = "truncated PNM header"; return false; } vals[k] = static_cast<uint32_t>(std::strtoul(t.c_str(), nullptr, 10)); }
         ++at;   // the single whitespace after maxval
         const uint32_t ch = d[1] == '6' ? 3 : 1;
+        // dimensions are bounded BEFORE any size arithmetic: header fields are untrusted and w * h * ch must not wrap
+        if (vals[0] > kMaxTextureDim || vals[1] > kMaxTextureDim) { err = "image larger than 16384 x 16384: " + path; return false; }
         if (vals[2] != 255 || vals[0] == 0 || vals[1] == 0 || d.size() < at + static_cast<size_t>(vals[0]) * vals[1] * ch) { err = "unsupported PNM (8-bit binary only)"; return false; }
         img.w = vals[0]; img.h = vals[1]; img.rgba8.resize(4ull * img.w * img.h);
         for (size_t i = 0; i < static_cast<size_t>(img.w) * img.h; ++i) {
@@ -283,6 +290,7 @@ bool decode_image(const std::string& path, Image& img, std::string& err) {
         const double scale = std::strtod(t.c_str(), nullptr);
         ++at;
         const uint32_t ch = d[1] == 'F' ? 3 : 1;
+        if (w > kMaxTextureDim || h > kMaxTextureDim) { err = "image larger than 16384 x 16384: " + path; return false; }
         if (scale >= 0 || !w || !h || d.size() < at + 4ull * w * h * ch) { err = "unsupported PFM (little-endian only)"; return false; }
         img.w = w; img.h = h; img.isFloat = true; img.rgba32f.resize(4ull * w * h);
         for (uint32_t y = 0; y < h; ++y)   // PFM rows run bottom to top
@@ -301,9 +309,12 @@ bool decode_image(const std::string& path, Image& img, std::string& err) {
         uint16_t bpp; std::memcpy(&bpp, d.data() + 28, 2);
         const uint32_t comp = u32(30);
         if (w <= 0 || hh == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && comp != 3)) { err = "unsupported BMP (24 / 32 bit uncompressed only)"; return false; }
-        const uint32_t h = static_cast<uint32_t>(hh < 0 ? -hh : hh);
+        // |hh| without negating INT_MIN; both dimensions bounded before off + stride * h is formed
+        const int64_t h64 = hh < 0 ? -static_cast<int64_t>(hh) : static_cast<int64_t>(hh);
+        if (w > static_cast<int32_t>(kMaxTextureDim) || h64 > static_cast<int64_t>(kMaxTextureDim)) { err = "image larger than 16384 x 16384: " + path; return false; }
+        const uint32_t h = static_cast<uint32_t>(h64);
         const size_t stride = (static_cast<size_t>(w) * (bpp / 8) + 3) & ~size_t(3);
-        if (d.size() < off + stride * h) { err = "truncated BMP"; return false; }
+        if (d.size() < static_cast<size_t>(off) + stride * h) { err = "truncated BMP"; return false; }
         img.w = static_cast<uint32_t>(w); img.h = h; img.rgba8.resize(4ull * img.w * h);
         for (uint32_t y = 0; y < h; ++y) {
             const uint8_t* row = d.data() + off + stride * (hh < 0 ? y : h - 1 - y);
@@ -344,12 +355,17 @@ uint32_t gfxh_scene_load_texture(gfxh_scene* s, const char* path, uint32_t forma
     auto it = s->textureCache.find(key);
     if (it != s->textureCache.end()) return it->second;
     Image img; std::string err;
-    if (!decode_image(path, img, err)) { g_hostError = err; return 0; }
+    try {
+        if (!decode_image(path, img, err)) { g_hostError = err; return 0; }
+    }
+    catch (const std::exception& e) { g_hostError = std::string("gfxh_scene_load_texture: ") + e.what(); return 0; }   // a bad_alloc from the decode buffers
     uint32_t slot = 0;
     if (img.isFloat) slot = gfxh_scene_add_texture(s, img.w, img.h, GFX_TEX_RGBA32F, img.rgba32f.data());
     else if (format8 == GFX_TEX_R8_UNORM || format8 == GFX_TEX_RG8_UNORM) {
         const uint32_t ch = format8 == GFX_TEX_R8_UNORM ? 1 : 2;
-        std::vector<uint8_t> packed(static_cast<size_t>(img.w) * img.h * ch);
+        std::vector<uint8_t> packed;
+        try { packed.resize(static_cast<size_t>(img.w) * img.h * ch); }
+        catch (const std::exception& e) { g_hostError = std::string("gfxh_scene_load_texture: ") + e.what(); return 0; }
         for (size_t i = 0; i < static_cast<size_t>(img.w) * img.h; ++i) for (uint32_t c = 0; c < ch; ++c) packed[i * ch + c] = img.rgba8[4 * i + c];
         slot = gfxh_scene_add_texture(s, img.w, img.h, format8, packed.data());
     }

@@ -133,3 +133,37 @@ def test_output_chain_tone_map_and_files(built_lib, tmp_path):
     assert pfm.startswith(head)
     data = np.frombuffer(pfm[len(head):], np.float32).reshape(h, w, 3)
     assert np.array_equal(data[::-1][3:, 3:], (np.float32(2.0) * img[3:, 3:, :3]))      # finite region, bottom-up rows
+
+
+def test_image_headers_with_absurd_dimensions_are_refused(built_lib, tmp_path):
+    """Asset headers are untrusted: dimensions are bounded (16384, the 14-bit TexDimInfo limit) before any size arithmetic, so
+    32-bit width x height products cannot wrap and -INT_MIN is never formed."""
+    import struct
+    import pytest
+    s = api.HostScene()
+    p = tmp_path / "huge.ppm"
+    p.write_bytes(b"P6\n70000 70000\n255\n" + bytes(64))
+    with pytest.raises(api.GfxError, match="larger than 16384"):
+        s.load_texture(str(p))
+    p = tmp_path / "wrap.ppm"                     # 65536 x 65536 x 3 wraps a 32-bit product to 0
+    p.write_bytes(b"P6\n65536 65536\n255\n" + bytes(64))
+    with pytest.raises(api.GfxError, match="larger than 16384"):
+        s.load_texture(str(p))
+    p = tmp_path / "huge.pfm"
+    p.write_bytes(b"PF\n40000 40000\n-1.0\n" + bytes(64))
+    with pytest.raises(api.GfxError, match="larger than 16384"):
+        s.load_texture(str(p))
+    hdr = bytearray(54)
+    hdr[0:2] = b"BM"
+    struct.pack_into("<I", hdr, 10, 54)
+    struct.pack_into("<ii", hdr, 18, 4, -2147483648)     # height = INT_MIN
+    struct.pack_into("<H", hdr, 28, 24)
+    p = tmp_path / "intmin.bmp"
+    p.write_bytes(bytes(hdr) + bytes(64))
+    with pytest.raises(api.GfxError, match="larger than 16384"):
+        s.load_texture(str(p))
+    ok = tmp_path / "ok.ppm"                      # a sane file still loads
+    ok.write_bytes(b"P6\n2 2\n255\n" + bytes(range(12)))
+    assert s.load_texture(str(ok)) == 1
+    big = np.zeros(4, np.uint8)
+    assert api.lib().gfxh_scene_add_texture(s.h, C.c_uint32(20000), C.c_uint32(2), C.c_uint32(api.TEX_RGBA8_UNORM), big.ctypes.data_as(C.c_void_p)) == 0
