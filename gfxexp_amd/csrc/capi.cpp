@@ -60,6 +60,7 @@ int gfx_ctx_create(int device, gfx_ctx** out) {
         t.traceBlocksPerCU = env_int("GFX_TRACE_BLOCKS_PER_CU", t.traceBlocksPerCU, 1, 8);
         t.traceRefill = env_int("GFX_TRACE_REFILL", t.traceRefill, 1, 64);
         t.traceBatch = env_int("GFX_TRACE_BATCH", t.traceBatch, 1, 65536);
+        t.pooledCandidates = env_int("GFX_POOLED_CANDIDATES", t.pooledCandidates, 0, 1);
         ctx->c.dTraceCounters.reserve(64);
         GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 64));
         *out = ctx.release();
@@ -493,6 +494,7 @@ int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value) {
     else if (n == "trace_blocks_per_cu") t.traceBlocksPerCU = in(1, 8);
     else if (n == "trace_refill") t.traceRefill = in(1, 64);
     else if (n == "trace_batch") t.traceBatch = in(1, 65536);
+    else if (n == "pooled_candidates") t.pooledCandidates = in(0, 1);
     else throw HipError("gfx_tunable_set: unknown tunable " + n);
     GFX_CATCH(ctx)
 }

@@ -93,6 +93,8 @@ struct Tunables {
     int traceBlocksPerCU = 4;        // persistent traversal grid: blocks of 256 per CU (LDS: 4 x 40 KiB)
     int traceRefill = 8;             // refill a wave when at least this many lanes are idle
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
+    int pooledCandidates = 0;        // 1: k_initial_candidates_pooled (wave-pooled BSDF evaluations) instead of the per-lane loop --
+                                     // 19 % fewer VALU instructions, same time: the gathers bound it (profiles/r03_initial_candidates.txt)
 };
 
 struct Context {

@@ -8,6 +8,8 @@ wr.txt: output of profiles/summarize_pmc.py) into the figures bench.py quotes in
   lane_fraction    SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): active lanes per issued VALU instruction
   valu_insts       SQ_INSTS_VALU per launch (wave-level instructions)
   l2_hit           TCC_HIT / (TCC_HIT + TCC_MISS)
+  tcp_accesses_per_cu_clk   TCP_TOTAL_ACCESSES / 256 CUs / (SQ_BUSY_CYCLES / 32): cache-line requests of the vector-memory instructions
+                   per CU and clock; a gather of 64 different lines is 64 requests, and the path takes about one per clock
   hbm_bytes        2 x FETCH_SIZE KiB (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md) + WRITE_SIZE KiB
 """
 import json
@@ -15,7 +17,7 @@ import re
 import sys
 
 KERNELS = {"k_trace_any": "k_trace<true, false>", "k_trace_closest": "k_trace<false, false>",
-           "k_initial_candidates": "k_initial_candidates<", "k_spatial": "k_spatial<false>", "k_temporal": "k_temporal<1>",
+           "k_initial_candidates": "k_initial_candidates<", "k_initial_candidates_pooled": "k_initial_candidates_pooled<", "k_spatial": "k_spatial<false>", "k_temporal": "k_temporal<1>",
            "k_shade_prepare": "k_shade_prepare", "k_gbuffer_resolve": "k_gbuffer_resolve"}
 
 
@@ -56,6 +58,10 @@ def condense(d):
         if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
             e["l2_hit"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
             e["l2_requests"] = int(c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        if c.get("TCP_TOTAL_ACCESSES_sum") and c.get("SQ_BUSY_CYCLES"):
+            # vector-memory cache-line requests per CU and clock (SQ_BUSY_CYCLES sums 32 shader engines; 256 CUs): the
+            # texture-addresser / L1 path takes about one per clock
+            e["tcp_accesses_per_cu_clk"] = round(c["TCP_TOTAL_ACCESSES_sum"] / 256.0 / (c["SQ_BUSY_CYCLES"] / 32.0), 3)
         if c.get("FETCH_SIZE") is not None:
             e["hbm_bytes"] = int((2 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0)) * 1024)
         res[short] = e

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Lane-utilisation profile of k_initial_candidates on the bench frame: an experiment build (GFX_LANE_PROFILE, gm_math.hip.h
+GFX_PROF) counts, per code section, how often a wave enters it and with how many active lanes.
+
+    python gfxexp_amd/build.py --variant laneprof GFX_LANE_PROFILE
+    GFX_LIB=$PWD/gfxexp_amd/variants/libgfxexp_laneprof.so python tools/lane_profile.py [--plain]
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+SECTIONS = {0: "candidate loop body (RNG, light selection, fetch, shadow-ray geometry, reservoir update)",
+            1: "light_fetch (record + normal matrix gathers, point on the triangle)",
+            2: "emitter faces the shading point (lpCos > 0): BSDF evaluate is called",
+            3: "BSDF evaluate past the horizon test (GGX D / G / Fresnel, diffuse lobe)",
+            4: "deferred emittance-texture read",
+            5: "reservoir accepts the candidate (sample copy)",
+            7: "smooth-emitter / fallback extra record",
+            8: "after the loop (finalise, shadow ray)"}
+
+
+def main():
+    import torch
+    from gfxexp_amd import api, scenes
+    from tests import util
+    W, H = 1920, 1080
+    textured = "--plain" not in sys.argv
+    hs = scenes.bench_street(textured=textured)
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    ctx.lights_build_static()
+    dev = util.DeviceBuffers(util.PixelBuffers(W, H))
+    cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
+    stream = torch.cuda.current_stream().cuda_stream
+    f = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, W, H, cam, travHandle=accel, frameIndex=0, bufferIndex=0, resetFlowBuffer=1,
+                          enableBumpMapping=int(textured))
+    ctx.lights_build_instances(stream)
+    ctx.restir_set_params(dev.static_params(), f, 0, 0, stream)
+    ctx.restir_launch(api.PASS_SETUP_GBUFFERS, W, H, stream)
+    torch.cuda.synchronize()
+    L = api.lib()
+    out = (C.c_uint64 * 64)()
+    assert L.gfx_debug_lane_profile(out, 1) == 0
+    ctx.restir_launch(api.PASS_INITIAL_RIS, W, H, stream)
+    torch.cuda.synchronize()
+    assert L.gfx_debug_lane_profile(out, 1) == 0
+    res = {}
+    for k, name in SECTIONS.items():
+        lanes, visits = int(out[2 * k]), int(out[2 * k + 1])
+        res[k] = {"section": name, "wave_visits": visits, "lanes": lanes, "lanes_per_visit": round(lanes / max(1, visits), 2)}
+    print(json.dumps({"workload": "textured" if textured else "plain", "sections": res}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
