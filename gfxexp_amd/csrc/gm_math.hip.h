@@ -17,6 +17,17 @@ namespace gfx {
 
 #define GFX_DEV __device__ __forceinline__
 
+// GFX_LANE_PROFILE (an experiment build: `python gfxexp_amd/build.py --variant laneprof GFX_LANE_PROFILE`, tools/lane_profile.py):
+// per code section, how often a wave enters it and with how many lanes.  g_laneProfile[2 k] += active lanes, [2 k + 1] += 1.
+// Expands to nothing in the product build.
+#ifdef GFX_LANE_PROFILE
+static __device__ unsigned long long g_laneProfile[64];
+#define GFX_PROF(k) do { const unsigned long long m__ = __ballot(1); if ((threadIdx.x & 63) == __builtin_ctzll(m__)) { \
+    atomicAdd(&g_laneProfile[2 * (k)], static_cast<unsigned long long>(__popcll(m__))); atomicAdd(&g_laneProfile[2 * (k) + 1], 1ull); } } while (0)
+#else
+#define GFX_PROF(k) do { } while (0)
+#endif
+
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kTwoPi = 2 * 3.14159265358979323846f;
 constexpr float kHalfPi = 1.5707963705062866f;

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
         float selectedTarget = 0.0f;
         const uint32_t numCandidates = 1u << a.f.log2NumCandidateSamples;
         for (uint32_t i = 0; i < numCandidates; ++i) {
+            GFX_PROF(0);
             float ul = rng.uniform();
             float probCurType = 1.0f;
             bool sampleEnv = false;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
                 if (sampleEnv) sample_env_light(env, a.f.envLightRotation, a.f.envLightPowerCoeff, u0, u1, ls, pd);
                 else {
                     const LightPick pk = light_select(a.scene, ul);
-                    if (pk.ok) light_fetch<true, false>(a.scene, pk, u0, u1, ls, pd, f3(0.0f), &pending);
+                    if (pk.ok) { GFX_PROF(1); light_fetch<true, false>(a.scene, pk, u0, u1, ls, pd, f3(0.0f), &pending); }
                     else pd = 0.0f;
                 }
                 cont = direct_lighting_pending(a.scene, sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls, pending);
@@ -243,8 +244,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
             pd *= probCurType;
             const float target = target_weight(cont);
             const float weight = target / pd;
-            if (reservoir.update(ls, weight, rng.uniform())) selectedTarget = target;
+            if (reservoir.update(ls, weight, rng.uniform())) { GFX_PROF(5); selectedTarget = target; }
         }
+        GFX_PROF(8);
         float recPDF = reservoir.sumWeights / (selectedTarget * reservoir.streamLength);
         if (!is_finite(recPDF)) { recPDF = 0.0f; selectedTarget = 0.0f; }
 
@@ -884,6 +886,14 @@ __global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
     const f3 result = (1 - curWeight) * prev + curWeight * contribution;
     *beauty = make_float4(result.x, result.y, result.z, 1.0f);
 }
+
+#ifdef GFX_LANE_PROFILE   // experiment builds only (gm_math.hip.h GFX_PROF, tools/lane_profile.py)
+extern "C" int gfx_debug_lane_profile(unsigned long long* out64, int reset) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_laneProfile), sizeof(g_laneProfile)) != hipSuccess) return 1;
+    if (reset) { unsigned long long zero[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_laneProfile), zero, sizeof(zero)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 // ---------------------------------------------------------------- host sequencing
 static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd, bool rearch) {

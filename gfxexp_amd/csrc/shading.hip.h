@@ -331,6 +331,7 @@ struct Bsdf {
         if (type == GFX_BSDF_LAMBERT)
             return vGiven.z * vSampled.z > 0 ? diffuse / kPi : f3(0.0f);
         if (vSampled.z * vGiven.z <= 0) return f3(0.0f);
+        GFX_PROF(3);
         const bool entering = vGiven.z >= 0.0f;
         const f3 dirV = entering ? vGiven : -vGiven;
         const f3 dirL = entering ? vSampled : -vSampled;
@@ -636,6 +637,7 @@ GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, floa
     f3 nB = nA, nC = nA;
     float twoOverLenNg = 0.0f, primProb = 0.0f;
     if ((flags & kEmitterSmooth) || SOLID_ANGLE || !pk.table) {
+        GFX_PROF(7);
         const float4* xp = reinterpret_cast<const float4*>(sc.emitterRecExtras + pk.rec);
         const float4 x0 = xp[0], x1 = xp[1];
         if (flags & kEmitterSmooth) { nB = f3(x0.x, x0.y, x0.z); nC = f3(x0.w, x1.x, x1.y); }
@@ -766,10 +768,12 @@ GFX_DEV f3 direct_lighting_pending(const DevScene& sc, f3 shadingPoint, f3 vOutL
     const float lpCos = dot(-sr.dir, ls.normal);
     const float spCos = dirLocal.z;
     if (lpCos > 0) {
+        GFX_PROF(2);
         const f3 fs = bsdf.evaluate(vOutLocal, dirLocal);
         const float G = lpCos * fabsf(spCos) / sr.dist2;
         const bool zero = (fs.x == 0.0f && fs.y == 0.0f && fs.z == 0.0f) || G == 0.0f;
         if (pending.tex && !zero) {
+            GFX_PROF(4);
             const float4 t = tex2d_desc(sc, pending.desc, pending.tu, pending.tv);
             ls.emittance = f3(1.0f) * f3(t.x, t.y, t.z);
         }

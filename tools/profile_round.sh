@@ -16,6 +16,8 @@
 #   nrc          tools/bench_nrc.py (network alone) + tools/bench_nrc_frame.py (NRC frame, training overlapped / serial)
 #                                                                                       -> profiles/r03_nrc_frame.jsonl
 #   pmcjson      profiles/make_pmc_json.py over the pmc (+ pmc0) outputs                -> profiles/r03_pmc.json
+#   laneprof     lane-utilisation profile of k_initial_candidates (builds the GFX_LANE_PROFILE variant first, on this
+#                host: python gfxexp_amd/build.py --variant laneprof GFX_LANE_PROFILE)    -> profiles/r03_initial_candidates.txt
 #   renderers    tools/bench_renderers.py + tools/bench_config4.py                      -> profiles/r03_renderers.jsonl
 #   bands        tools/bench_band.py (compute-only bound of N row bands)                -> profiles/r03_band_compute_bound.json
 #   hbm          tools/hbm_stream.py (streaming-copy ceiling of this box)               -> profiles/r03_hbm_stream.json
@@ -72,6 +74,7 @@ for step in "$@"; do
                timeout 600 python tools/bench_nrc_frame.py > $OUT/nrc_frame.jsonl 2> $OUT/nrc_frame.err; cat $OUT/nrc_frame.jsonl; tail -3 $OUT/nrc_frame.err ;;
     pmcjson)   if [ -d $OUT/pmc_map0 ]; then python profiles/make_pmc_json.py $OUT/pmc_default $OUT/pmc_map0 pixel_map_0_scan_lines > $OUT/r03_pmc.json
                else python profiles/make_pmc_json.py $OUT/pmc_default > $OUT/r03_pmc.json; fi; head -c 600 $OUT/r03_pmc.json ;;
+    laneprof)  GFX_LIB=$PWD/gfxexp_amd/variants/libgfxexp_laneprof.so GFX_POOLED_CANDIDATES=0 timeout 300 python tools/lane_profile.py > $OUT/lane_profile.json 2> $OUT/lane_profile.err; cat $OUT/lane_profile.json ;;
     renderers) timeout 900 python tools/bench_renderers.py > $OUT/renderers.jsonl 2> $OUT/renderers.err
                timeout 300 python tools/bench_config4.py >> $OUT/renderers.jsonl 2>> $OUT/renderers.err; cat $OUT/renderers.jsonl ;;
     bands)     timeout 900 python tools/bench_band.py > $OUT/band_compute_bound.json 2> $OUT/band.err; cat $OUT/band_compute_bound.json; tail -3 $OUT/band.err ;;
