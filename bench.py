@@ -205,7 +205,8 @@ def main():
                                + ("+ trees of leaf cards, cables and railings (depth-complexity variant), " if args.cluttered else "")
                                + "32 candidates, temporal + 2x5 spatial reuse, radius 20, visibility reuse",
                    "width": W, "height": H, "spp": 1, "parallelism": f"row-bands x{world}" if world > 1 else "single GPU",
-                   "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]}},
+                   "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]},
+                   "light_table": ctx.lights_table_info()},
         "setup_s": round(setup_s, 2),
     }
 

@@ -592,10 +592,11 @@ class Context:
         return w, c, integ.value
 
     def lights_table_info(self):
-        """{usable, verified, records, cells} of the emitter interval table (emitter_spans.h)."""
-        info = (C.c_uint32 * 4)()
+        """{usable, verified, records, cells, matrices, interior_cells} of the emitter interval table (emitter_spans.h)."""
+        info = (C.c_uint32 * 8)()
         self._check(self.L.gfx_lights_table_info(self.h, info))
-        return {"usable": int(info[0]), "verified": int(info[1]), "records": int(info[2]), "cells": int(info[3])}
+        return {"usable": int(info[0]), "verified": int(info[1]), "records": int(info[2]), "cells": int(info[3]),
+                "matrices": int(info[4]), "interior_cells": int(info[5])}
 
     def trace(self, accel, mode, d_ray_org, d_ray_dir, num_rays, d_out, d_counters=0, stream=0, d_per_ray_items=0):
         if d_per_ray_items:

@@ -19,7 +19,10 @@
 
 namespace gfx {
 
-constexpr int kLdsStackDepth = 12;     // entries per lane held in LDS
+#ifndef GFX_TRACE_LDS_STACK
+#define GFX_TRACE_LDS_STACK 12         // experiment builds trade stack depth for resident waves (tools/microbench/README)
+#endif
+constexpr int kLdsStackDepth = GFX_TRACE_LDS_STACK;     // entries per lane held in LDS
 constexpr int kSpillStackDepth = 64;   // entries per lane in the HBM spill area
 
 struct TraceCounters { uint32_t nodes, tris, spills; };

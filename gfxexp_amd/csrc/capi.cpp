@@ -60,7 +60,7 @@ int gfx_ctx_create(int device, gfx_ctx** out) {
         t.traceBlocksPerCU = env_int("GFX_TRACE_BLOCKS_PER_CU", t.traceBlocksPerCU, 1, 8);
         t.traceRefill = env_int("GFX_TRACE_REFILL", t.traceRefill, 1, 64);
         t.traceBatch = env_int("GFX_TRACE_BATCH", t.traceBatch, 1, 65536);
-        t.pooledCandidates = env_int("GFX_POOLED_CANDIDATES", t.pooledCandidates, 0, 1);
+        t.noLdsMatrices = env_int("GFX_NO_LDS_MATRICES", t.noLdsMatrices, 0, 1);
         ctx->c.dTraceCounters.reserve(64);
         GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 64));
         *out = ctx.release();
@@ -280,13 +280,19 @@ int gfx_lights_read(gfx_ctx* ctx, uint32_t level, uint32_t index, float* weights
     GFX_CATCH(ctx)
 }
 
-int gfx_lights_table_info(gfx_ctx* ctx, uint32_t info[4]) {
+int gfx_lights_table_info(gfx_ctx* ctx, uint32_t info[8]) {
     GFX_TRY(ctx)
     Context& c = ctx->c;
     GFX_HIP(hipDeviceSynchronize());
     uint32_t header[4] = { 0, 0, 0, 0 };
     if (c.dSpanHeader.p) GFX_HIP(hipMemcpy(header, c.dSpanHeader.p, sizeof(header), hipMemcpyDeviceToHost));
     info[0] = header[0]; info[1] = header[1]; info[2] = c.numEmitterRecs; info[3] = c.spanGuideCells;
+    info[4] = c.numLightMatrices; info[5] = 0; info[6] = 0; info[7] = 0;
+    if (header[0] && c.spanGuideCells && c.dSpanGuide.p) {
+        std::vector<SpanGuide> guide(c.spanGuideCells);
+        GFX_HIP(hipMemcpy(guide.data(), c.dSpanGuide.p, sizeof(SpanGuide) * guide.size(), hipMemcpyDeviceToHost));
+        for (const SpanGuide& g : guide) if (g.a & kGuideInterior) ++info[5];
+    }
     GFX_CATCH(ctx)
 }
 
@@ -493,8 +499,8 @@ int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value) {
     else if (n == "super_y") t.superShiftY = in(0, 6);
     else if (n == "trace_blocks_per_cu") t.traceBlocksPerCU = in(1, 8);
     else if (n == "trace_refill") t.traceRefill = in(1, 64);
+    else if (n == "no_lds_matrices") t.noLdsMatrices = in(0, 1);
     else if (n == "trace_batch") t.traceBatch = in(1, 65536);
-    else if (n == "pooled_candidates") t.pooledCandidates = in(0, 1);
     else throw HipError("gfx_tunable_set: unknown tunable " + n);
     GFX_CATCH(ctx)
 }

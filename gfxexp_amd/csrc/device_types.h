@@ -64,11 +64,12 @@ struct EmitterRec {          // 64 B: four aligned 16-byte gathers per light can
     float pA[3], pB[3], pC[3];
     float nA[3];             // object-space vertex normal; flat emitters (the three normals bit-equal) need no other
     float emittance[3];
-    uint32_t flags;          // bits 0-23: emittance-texture slot of the material, or 0 (only then is the record's EmitterTexRef
-                             // read); bit 31: nB / nC differ from nA -> EmitterRecExtra holds them
+    uint32_t flags;          // bits 0-14: emittance-texture slot of the material, or 0 (only then is the record's EmitterTexRef
+                             // read); bits 15-30: index of the instance's normal matrix in DevScene::lightNormalMatrices;
+                             // bit 31: nB / nC differ from nA -> EmitterRecExtra holds them
 };
 static_assert(sizeof(EmitterRec) == 64, "EmitterRec must be 64 bytes");
-constexpr uint32_t kEmitterSmooth = 0x80000000u, kEmitterTexMask = 0x00FFFFFFu;
+constexpr uint32_t kEmitterSmooth = 0x80000000u, kEmitterTexMask = 0x00007FFFu, kEmitterMatrixShift = 15u, kEmitterMatrixMask = 0xFFFFu;
 // Parallel to the records: what only smooth emitters, the three-search fallback and the solid-angle sampler read.
 struct EmitterRecExtra {
     float nB[3], nC[3];
@@ -126,8 +127,9 @@ struct DevScene {
     const LightGeomRef* lightGeomRefs;   // indexed like the light pools (inst.distOffset + i)
     const EmitterRec* emitterRecs;
     const EmitterRecExtra* emitterRecExtras;   // parallel to emitterRecs
-    const float* lightNormalMatrices;          // [12 * instSlot]: the normal-matrix rows of the emitter instances, 48 B apart (132 KB for
-                                               // 2 745 instances instead of the same rows spread over 176-byte DevInstance entries)
+    const float* lightNormalMatrices;          // [16 * matrix index]: the distinct normal matrices of the emitter instances, one 64-byte
+                                               // item each (three float4 rows + padding); EmitterRec::flags holds the index
+    uint32_t numLightMatrices;
     const float* lightInstIntegral; // device float[4]: [0] integral of the level-0 distribution,
                                     // [1] guide-table scale (cells / integral), [2] guide valid (uint32)
     const uint16_t* lightInstGuide; // guide table of the level-0 distribution (see lights.hip)

@@ -113,8 +113,16 @@ GFX_SPAN_HD void span_record_interval(const SpanRecordKey& key, uint32_t rangeLo
     else if (lastOfGroup) endBits = span_bisect(beginBits, rangeHi, [kk](float ul) { return kk.past_group(ul); });
 }
 
-// Guide table entry of one cell: the answer for any ul of the cell lies in [lo, hi].
-struct alignas(8) SpanGuide { uint32_t lo, hi; };
+// Guide table entry of one cell.
+//   boundary cell (a record's interval begins inside it): a = hi, b = lo -- the answer for any ul of the cell lies in [lo, hi];
+//   interior cell (every ul of the cell selects the same record): a = kGuideInterior | record, b = bit pattern of the record's
+//   density -- the lookup is done after this one load (no probe, no span load).  With GFX_SPAN_CELLS_PER_REC cells per record at
+//   most 1 / GFX_SPAN_CELLS_PER_REC of the ul range lies in boundary cells.
+struct alignas(8) SpanGuide { uint32_t a, b; };
+constexpr uint32_t kGuideInterior = 0x80000000u;
+#ifndef GFX_SPAN_CELLS_PER_REC
+#define GFX_SPAN_CELLS_PER_REC 4u
+#endif
 
 // Guide cell of a ul (cells is a power of two, so ul * cells is exact).
 GFX_SPAN_HD uint32_t span_cell(float ul, uint32_t cells) {
@@ -122,8 +130,16 @@ GFX_SPAN_HD uint32_t span_cell(float ul, uint32_t cells) {
     return c < cells - 1u ? c : cells - 1u;
 }
 
+// Smallest ul (bit pattern) that span_cell maps to a cell >= c; kSpanBitsEnd when there is none (c >= cells).
+GFX_SPAN_HD uint32_t span_cell_first_ul(uint32_t cells, uint32_t c) {
+    if (c >= cells) return kSpanBitsEnd;
+    return span_bisect(0u, kSpanBitsEnd, [cells, c](float ul) { return span_cell(ul, cells) >= c; });
+}
+
 // Guide entry of cell c: hi = the largest j with cell(begin_j) <= c (begin ascends, span_cell is monotone),
-// lo = the same for c - 1; 0 when there is none.
+// lo = the same for c - 1; 0 when there is none.  lo == hi means that no interval begins inside the cell; if that record's
+// interval also covers every ul of the cell -- begin <= the cell's smallest ul, end >= the next cell's smallest ul (the first
+// float above 1 for the last cell) -- the cell is interior.
 GFX_SPAN_HD SpanGuide span_guide_entry(const EmitterSpan* __restrict__ spans, uint32_t numSpans, uint32_t cells, uint32_t c) {
     auto last_at_or_before = [&](uint32_t cell) {
         uint32_t lo = 0, hi = numSpans;   // first j in [0, numSpans] with cell(begin_j) > cell
@@ -135,19 +151,31 @@ GFX_SPAN_HD SpanGuide span_guide_entry(const EmitterSpan* __restrict__ spans, ui
         return lo ? lo - 1u : 0u;
     };
     SpanGuide g;
-    g.hi = last_at_or_before(c);
-    g.lo = c ? last_at_or_before(c - 1u) : 0u;
+    g.a = last_at_or_before(c);
+    g.b = c ? last_at_or_before(c - 1u) : 0u;
+    if (g.a == g.b && numSpans != 0 && g.a < kGuideInterior) {
+        const EmitterSpan s = spans[g.a];
+        const uint32_t first = span_cell_first_ul(cells, c), next = span_cell_first_ul(cells, c + 1u);
+        if (span_bits(s.begin) <= first && span_bits(s.end) >= next && first < next) {
+            g.b = span_bits(s.density);
+            g.a |= kGuideInterior;
+        }
+    }
     return g;
 }
 
-// Index of the record whose interval holds ul, or -1.  guide[c]: hi = the largest record whose begin falls into
-// a cell <= c, lo = the same for c - 1 (0 when there is none).
+// Index of the record whose interval holds ul, or -1; out.density = its density.  The other members of `out` are set only when
+// the answer came out of a boundary cell.
 struct alignas(16) SpanWords { uint32_t w[4]; };   // one aligned 16-byte load per span
 GFX_SPAN_HD int32_t span_lookup(const EmitterSpan* __restrict__ spans, uint32_t numSpans,
                                 const SpanGuide* __restrict__ guide, uint32_t cells, float ul, EmitterSpan& out) {
     if (numSpans == 0) return -1;
     const SpanGuide g = guide[span_cell(ul, cells)];
-    int32_t lo = static_cast<int32_t>(g.lo), hi = static_cast<int32_t>(g.hi);
+    if (g.a & kGuideInterior) {
+        out.begin = 0.0f; out.end = 0.0f; out.density = span_float(g.b); out.instSlot = 0xFFFFFFFFu;
+        return static_cast<int32_t>(g.a & ~kGuideInterior);
+    }
+    int32_t lo = static_cast<int32_t>(g.b), hi = static_cast<int32_t>(g.a);
     while (lo < hi) {
         const int32_t mid = (lo + hi + 1) >> 1;
         if (spans[mid].begin <= ul) lo = mid;

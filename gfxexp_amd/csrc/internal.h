@@ -93,8 +93,7 @@ struct Tunables {
     int traceBlocksPerCU = 4;        // persistent traversal grid: blocks of 256 per CU (LDS: 4 x 40 KiB)
     int traceRefill = 8;             // refill a wave when at least this many lanes are idle
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
-    int pooledCandidates = 0;        // 1: k_initial_candidates_pooled (wave-pooled BSDF evaluations) instead of the per-lane loop --
-                                     // 19 % fewer VALU instructions, same time: the gathers bound it (profiles/r03_initial_candidates.txt)
+    int noLdsMatrices = 0;           // 1: k_initial_candidates reads the emitter normal matrices from global memory even when they would fit LDS (tests)
 };
 
 struct Context {
@@ -111,7 +110,7 @@ struct Context {
     std::vector<HostInstance> insts;
     bool sceneDirty = true;
     // scene (device)
-    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightP, dLightCDF, dLightRefs, dEmitterRecs, dEmitterRecExtras, dLightNormalMatrices, dTextures, dTexelPool, dSrgbLut, dEmitterTexRefs;
+    DevBuf dMaterials, dGeomInsts, dInsts, dVertices, dTriangles, dSlotPool, dFlatGeoms, dLightW, dLightP, dLightCDF, dLightRefs, dEmitterRecs, dEmitterRecExtras, dLightNormalMatrices, dInstMatrixIndex, dTextures, dTexelPool, dSrgbLut, dEmitterTexRefs;
     bool anyEmittanceTexture = false;
     std::vector<LightGeomRef> hLightRefs;
     uint32_t numEmitterRecs = 0;
@@ -138,6 +137,7 @@ struct Context {
     // instance interval starts uint32[numInsts + 1] (build scratch)
     DevBuf dSpans, dSpanGuide, dSpanHeader, dSpanInstBegin;
     uint32_t spanGuideCells = 0;
+    uint32_t numLightMatrices = 0;   // distinct normal matrices of the emitter instances (scene.cpp light_matrices_upload)
     DevScene devScene() const;
     // accels
     std::vector<Accel*> accels;
@@ -208,6 +208,7 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t);
 // ---- textures.hip
 void texture_sample(Context& ctx, hipStream_t stream, uint32_t texSlot, const void* dUv, uint32_t n, void* dOut, int gather);
 // ---- lights.hip
+void light_matrices_upload(Context& ctx, hipStream_t stream);
 void lights_build_static(Context& ctx, hipStream_t stream);
 void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t bufferIndex);
 // ---- restir.hip

@@ -88,13 +88,13 @@ __global__ void k_inst_geom_dists(DevInstance* __restrict__ insts, uint32_t numI
 // Per (instance, geomInst): copy the emitter distribution's integral next to its offsets and
 // pre-transform the emitter triangles (EmitterRec, device_types.h).  One block per instance.
 __global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* __restrict__ refs, EmitterRec* __restrict__ recs,
-                                  EmitterRecExtra* __restrict__ extras, float4* __restrict__ normalMatrices,
+                                  EmitterRecExtra* __restrict__ extras, const uint32_t* __restrict__ instMatrixIndex,
                                   EmitterTexRef* __restrict__ texRefs /* null: no emittance textures in the scene */) {
     const uint32_t ii = blockIdx.x;
     if (ii >= numInsts) return;
     const DevInstance* inst = sc.insts + ii;
     if (inst->distOffset == 0xFFFFFFFFu) return;
-    if (threadIdx.x < 3) normalMatrices[3 * ii + threadIdx.x] = reinterpret_cast<const float4*>(inst->normalMatrix)[threadIdx.x];
+    const uint32_t matrixBits = (instMatrixIndex[ii] & kEmitterMatrixMask) << kEmitterMatrixShift;
     const m34 xfm = load_m34(inst->transform);
     for (uint32_t k = 0; k < inst->numGeomInsts; ++k) {
         const DevGeomInst g = sc.geomInsts[sc.geomInstSlotPool[inst->slotsOffset + k]];
@@ -125,7 +125,7 @@ __global__ void k_emitter_records(DevScene sc, uint32_t numInsts, LightGeomRef* 
             // emittance = RGB(1) * texel for an emitter material (restir_di_shared.h:504-514)
             const f3 e = mat.hasEmittance ? f3(1.0f) * f3(mat.emittance[0], mat.emittance[1], mat.emittance[2]) : f3(0.0f);
             r.emittance[0] = e.x; r.emittance[1] = e.y; r.emittance[2] = e.z;
-            r.flags = ((texRefs && mat.hasEmittance) ? (mat.texEmittance & kEmitterTexMask) : 0u) | (smooth ? kEmitterSmooth : 0u);
+            r.flags = ((texRefs && mat.hasEmittance) ? (mat.texEmittance & kEmitterTexMask) : 0u) | matrixBits | (smooth ? kEmitterSmooth : 0u);
             x.twoOverLenNg = 2.0f / len(cross(pB - pA, pC - pA));
             x.primProb = sc.lightWeights[g.distOffset + t] / g.distIntegral;
             float4* dst = reinterpret_cast<float4*>(recs + recBase + t);
@@ -367,7 +367,7 @@ void lights_build_static(Context& ctx, hipStream_t stream) {
                            ctx.dLightW.as<float>(), ctx.dLightCDF.as<float>(), ctx.dLightP.as<float>());
     if (ni)
         hipLaunchKernelGGL(k_emitter_records, dim3(ni), dim3(64), 0, stream, ctx.devScene(), ni,
-                           ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(), ctx.dEmitterRecExtras.as<EmitterRecExtra>(), ctx.dLightNormalMatrices.as<float4>(),
+                           ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(), ctx.dEmitterRecExtras.as<EmitterRecExtra>(), ctx.dInstMatrixIndex.as<uint32_t>(),
                                ctx.anyEmittanceTexture ? ctx.dEmitterTexRefs.as<EmitterTexRef>() : nullptr);
     GFX_HIP(hipGetLastError());
     // keep the host mirrors of the integrals current (read by gfx_lights_read and the launch params)
@@ -381,11 +381,12 @@ void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t /*bufferI
     if (!ctx.lightsStaticBuilt) lights_build_static(ctx, stream);
     transforms_upload(ctx, stream);
     if (ctx.emitterRecsDirty) {
-        // animated instances moved: their emitter triangles are stored in world space
+        // animated instances moved: their emitter triangles are stored in world space, their normal matrices changed
+        light_matrices_upload(ctx, stream);
         const uint32_t numInsts = static_cast<uint32_t>(ctx.insts.size());
         if (numInsts)
             hipLaunchKernelGGL(k_emitter_records, dim3(numInsts), dim3(64), 0, stream, ctx.devScene(), numInsts,
-                               ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(), ctx.dEmitterRecExtras.as<EmitterRecExtra>(), ctx.dLightNormalMatrices.as<float4>(),
+                               ctx.dLightRefs.as<LightGeomRef>(), ctx.dEmitterRecs.as<EmitterRec>(), ctx.dEmitterRecExtras.as<EmitterRecExtra>(), ctx.dInstMatrixIndex.as<uint32_t>(),
                                ctx.anyEmittanceTexture ? ctx.dEmitterTexRefs.as<EmitterTexRef>() : nullptr);
         GFX_HIP(hipGetLastError());
         ctx.emitterRecsDirty = false;

@@ -16,6 +16,7 @@
 #include "shading.hip.h"
 #include "pass_common.hip.h"
 #include "restir_common.hip.h"
+#include "coop_fetch.hip.h"
 #include "restir_rearch.hip.h"
 
 namespace gfx {
@@ -174,11 +175,27 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
 // candidate loop + visibility-ray emission: optix_restir_di_kernels.cu:57-133
 // The light of a candidate comes out of the emitter interval table (emitter_spans.h): one guided search
 // instead of the reference's three nested ones, identical result.
+constexpr uint32_t kInitialMatrixLdsBytes = 22 * 1024;   // 4 blocks x (16 KB fetch buffers + this) = 152 KB of a CU's 160 KB: 625 matrices
 #ifndef GFX_INIT_WAVES   // experiment switch (tools/sessions): waves per SIMD the register allocation of the kernel targets
 #define GFX_INIT_WAVES 4
 #endif
+// The emitter record (64 B) of a candidate is gathered by the wave cooperatively (coop_fetch.hip.h): 16 line requests per 16 lanes
+// instead of 4 per lane; the normal matrix comes out of the deduplicated table the record's flags index.  At 11 gathers per lane and candidate
+// the kernel ran exactly at the CU's one-line-request-per-clock time (profiles/r03_experiments.txt).  The candidate loop is therefore
+// wave-uniform: lanes without a surface take part in the fetch and in nothing else.
 template <bool EMITTER_TEX>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a, uint32_t matricesInLds) {
+    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];   // per wave: 256 x 16 B = 64 records
+    // the distinct normal matrices of the emitter instances, 9 floats each, when the host found that they fit (dynamic LDS)
+    extern __shared__ float ldsMatrices[];
+    const uint32_t numLdsMatrices = matricesInLds;
+    for (uint32_t k = threadIdx.x; k < numLdsMatrices * 9u; k += kBlock) {
+        const uint32_t m = k / 9u, e = k - 9u * m;
+        ldsMatrices[k] = a.scene.lightNormalMatrices[16u * m + 4u * (e / 3u) + (e % 3u)];
+    }
+    if (numLdsMatrices) __syncthreads();
+    const int lane = threadIdx.x & 63;
+    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, kept scalar
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const PixelId px = pixel_of_thread(a.px);
     const size_t p = px.p;
@@ -189,24 +206,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
     bool wantRay = false;
     f3 rayO(0.0f), rayD(0.0f);
     float rayTmax = 0;
+    const EnvMap env = load_env(a.s);
+    const bool envEnabled = env.present() && a.f.enableEnvLight;
+    ShadingPoint sp;
+    uint64_t* rngBuf = static_cast<uint64_t*>(a.s.rngBuffer);
+    Pcg32 rng; rng.state = 0;
     if (surface) {
         const Camera cam = load_camera(a.f.camera);
-        const EnvMap env = load_env(a.s);
-        const bool envEnabled = env.present() && a.f.enableEnvLight;
-        ShadingPoint sp;
         make_shading_point(a, bufIdx, p, cam.pos, false, sp);
-        uint64_t* rngBuf = static_cast<uint64_t*>(a.s.rngBuffer);
-        Pcg32 rng; rng.state = rngBuf[p];
-
-        Reservoir reservoir;
-        reservoir.reset();
-        float selectedTarget = 0.0f;
-        const uint32_t numCandidates = 1u << a.f.log2NumCandidateSamples;
-        for (uint32_t i = 0; i < numCandidates; ++i) {
-            GFX_PROF(0);
+        rng.state = rngBuf[p];
+    }
+    Reservoir reservoir;
+    reservoir.reset();
+    float selectedTarget = 0.0f;
+    const uint32_t numCandidates = 1u << a.f.log2NumCandidateSamples;
+    for (uint32_t i = 0; i < numCandidates; ++i) {
+        GFX_PROF(0);
+        // ---- what this lane's candidate needs from the tables
+        float probCurType = 1.0f, u0 = 0.0f, u1 = 0.0f;
+        bool sampleEnv = false;
+        LightPick pk; pk.rec = 0; pk.instSlot = 0; pk.density = 0.0f; pk.partialProb = 0.0f; pk.ok = false; pk.table = true;
+        if (surface) {
             float ul = rng.uniform();
-            float probCurType = 1.0f;
-            bool sampleEnv = false;
             if (envEnabled) {
                 if (*a.scene.lightInstIntegral > 0.0f) {
                     const float prob = fmin2(fmax2(0.25f * numCandidates - i, 0.0f), 1.0f);
@@ -218,34 +239,63 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
                 }
                 else sampleEnv = true;
             }
+            u0 = rng.uniform();
+            u1 = rng.uniform();
+            if (!sampleEnv) pk = light_select(a.scene, ul);
+#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 1)   // timing experiment: no table search, coalesced records (results differ)
+            if (!sampleEnv) { pk.ok = true; pk.table = true; pk.rec = (static_cast<uint32_t>(lane) + 64u * i) % a.scene.numSpans; pk.instSlot = 1u + (i & 7u); pk.density = 1.0f + ul; }
+#endif
+#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 4)   // timing experiment: the real table search, then coalesced records
+            if (!sampleEnv && pk.ok) { pk.rec = (static_cast<uint32_t>(lane) + 64u * i) % a.scene.numSpans; pk.instSlot = 1u + (i & 7u); }
+#endif
+#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 8)   // timing experiment: no table search, scattered records
+            if (!sampleEnv) { pk.ok = true; pk.table = true; pk.rec = (f2bits(ul) * 2654435761u >> 8) % a.scene.numSpans; pk.instSlot = (f2bits(ul) * 40503u >> 4) % a.scene.numInsts; pk.density = 1.0f + ul; }
+#endif
+#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 16)   // timing experiment: one guide load picks the record, nothing else is searched
+            if (!sampleEnv) { const SpanGuide g = a.scene.spanGuide[span_cell(ul, a.scene.spanGuideCells)]; pk.ok = true; pk.table = true; pk.rec = g.a & 0x7FFFFFFFu; pk.instSlot = 0; pk.density = 1.0f + ul; }
+#endif
+        }
+        // ---- the wave gathers the records and the matrix rows
+        const bool fetch = surface && !sampleEnv && pk.ok;
+        if (__ballot(fetch) != 0ull) {
+            coop_fetch64_issue(fetch ? pk.rec : kCoopNone, reinterpret_cast<const char*>(a.scene.emitterRecs), waveBuf, lane);
+            coop_fetch64_wait();
+        }
+        // ---- the candidate itself
+        if (surface) {
             LightSample ls;
             ls.emittance = f3(0.0f); ls.position = f3(0.0f); ls.normal = f3(0.0f); ls.atInfinity = 0;
-            float pd;
-            const float u0 = rng.uniform();
-            const float u1 = rng.uniform();
-            f3 cont;
-            if (EMITTER_TEX) {
-                // the emittance texture of the candidate is read only when f * G is non-zero: a zero-weight candidate is
-                // never accepted by the reservoir, so its emittance is never observed (finite texels: 0 * Le = 0)
-                PendingEmittance pending; pending.tex = 0u; pending.tu = pending.tv = 0.0f;
-                pending.desc.offset = pending.desc.width = pending.desc.height = pending.desc.format = 0u;
-                if (sampleEnv) sample_env_light(env, a.f.envLightRotation, a.f.envLightPowerCoeff, u0, u1, ls, pd);
-                else {
-                    const LightPick pk = light_select(a.scene, ul);
-                    if (pk.ok) { GFX_PROF(1); light_fetch<true, false>(a.scene, pk, u0, u1, ls, pd, f3(0.0f), &pending); }
-                    else pd = 0.0f;
+            float pd = 0.0f;
+            // the emittance texture of the candidate is read only when f * G is non-zero: a zero-weight candidate is
+            // never accepted by the reservoir, so its emittance is never observed (finite texels: 0 * Le = 0)
+            PendingEmittance pending; pending.tex = 0u; pending.rec = 0u; pending.bcA = pending.bcB = pending.bcC = 0.0f;
+            if (sampleEnv) sample_env_light(env, a.f.envLightRotation, a.f.envLightPowerCoeff, u0, u1, ls, pd);
+            else if (pk.ok) {
+                GFX_PROF(1);
+                uint4 q0, q1, q2, q3;
+                coop_fetch64_read(waveBuf, lane, q0, q1, q2, q3);
+                m33 normalMatrix;
+                if (numLdsMatrices) {
+                    const float* mp = ldsMatrices + 9u * emitter_matrix_index(q3.w);
+                    normalMatrix.r0 = f3(mp[0], mp[1], mp[2]); normalMatrix.r1 = f3(mp[3], mp[4], mp[5]); normalMatrix.r2 = f3(mp[6], mp[7], mp[8]);
                 }
-                cont = direct_lighting_pending(a.scene, sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls, pending);
+                else normalMatrix = load_m33_rows(a.scene.lightNormalMatrices + 16u * emitter_matrix_index(q3.w));
+                light_from_record<EMITTER_TEX, false>(a.scene, pk, as_float4(q0), as_float4(q1), as_float4(q2), as_float4(q3), normalMatrix, u0, u1, ls, pd,
+                                                      f3(0.0f), EMITTER_TEX ? &pending : nullptr);
             }
-            else {
-                sample_light<false>(a.scene, env, a.f.envLightRotation, a.f.envLightPowerCoeff, ul, sampleEnv, u0, u1, ls, pd);
-                cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
-            }
+#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 2)   // timing experiment: no BSDF evaluation (results differ)
+            const f3 cont = ls.emittance * (1.0f / (1.0f + dot(ls.position - sp.pos, ls.position - sp.pos))) * fabsf(dot(ls.normal, sp.frame.n));
+#else
+            const f3 cont = EMITTER_TEX ? direct_lighting_pending(a.scene, sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls, pending)
+                                        : direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
+#endif
             pd *= probCurType;
             const float target = target_weight(cont);
             const float weight = target / pd;
             if (reservoir.update(ls, weight, rng.uniform())) { GFX_PROF(5); selectedTarget = target; }
         }
+    }
+    if (surface) {
         GFX_PROF(8);
         float recPDF = reservoir.sumWeights / (selectedTarget * reservoir.streamLength);
         if (!is_finite(recPDF)) { recPDF = 0.0f; selectedTarget = 0.0f; }
@@ -257,246 +307,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
         rngBuf[p] = rng.state;
         store_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p, reservoir);
         static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes])[p] = make_float2(recPDF, selectedTarget);
-    }
-    const uint32_t slot = queue_append_wave(wantRay, rayO, rayD, 0.0f, rayTmax, a.rayOrg, a.rayDir, a.rayCount);
-    if (px.valid) a.pixelRaySlot[p] = slot;
-}
-
-// ---------------------------------------------------------------- the same pass with pooled BSDF evaluations
-// Lane-utilisation profile of the kernel above on the bench frame (tools/lane_profile.py, profiles/r03_initial_candidates.txt):
-// of the 64 lanes that draw a candidate, 33.6 have an emitter that faces them and 11.3 (17.6 %) reach the full BSDF evaluation --
-// ~290 VALU instructions (GGX D / G, Fresnel, the diffuse lobe: a dozen IEEE divisions and square roots) issued for a sixth of the
-// wave in 97 % of the loop iterations; the deferred emittance-texture read (~150 instructions) runs for 2.1 lanes in 68 % of them.
-// Together that is more than half of the kernel's instruction issue.
-//
-// Here a lane does not evaluate its own candidate.  Per candidate it does the part every lane needs (random numbers, light
-// selection and fetch, shadow-ray geometry) and, if the evaluation is needed at all, appends a JOB -- direction in the shading
-// frame, geometry term, emittance or emittance-texture footprint -- to a wave-private queue in LDS.  Whenever 64 jobs are
-// queued the whole wave evaluates them, one per lane (the shading point of the lane a job belongs to is read across lanes),
-// and leaves each result where its owner finds it.  The reservoir updates of a batch of 4 candidates run after the batch's
-// jobs are done, in candidate order with the random numbers drawn in candidate order, so every reservoir is bit-identical to
-// the one the loop above builds.  The selected light sample is not carried through the updates: only the index of the
-// accepted candidate is, and the sample is re-derived once after the loop from that candidate's three random numbers
-// (PCG32 jump-ahead from the pixel's state at loop entry).
-constexpr int kPoolBatch = 4;          // candidates between two runs of reservoir updates
-constexpr int kPoolQueue = 128;        // job slots per wave: a flush leaves < 64, one candidate adds <= 64
-struct PoolWaveLds {
-    uint32_t meta[kPoolQueue];         // owner lane | candidate-in-batch << 6 | has emittance texture << 10
-    float dir[3][kPoolQueue];          // light direction in the owner's shading frame
-    float geom[kPoolQueue];            // G = lpCos |spCos| / dist2
-    // emittance of the sample, or -- a texture read is pending -- its footprint: u, v, DevTexture offset,
-    // (width - 1) | (height - 1) << 14 | format << 28 (bit patterns)
-    float le[4][kPoolQueue];
-    float target[kPoolBatch][64];      // per (candidate of the batch, lane): target function value ...
-    float density[kPoolBatch][64];     // ... probability density of the candidate ...
-    float uRes[kPoolBatch][64];        // ... and the reservoir's random number for it
-};
-
-// PCG32 state after `delta` more draws (the LCG is state' = state * A + 1): O(log delta) jump-ahead of the PCG reference
-// implementation (pcg_advance_lcg_64), exact in 64-bit integer arithmetic.
-GFX_DEV uint64_t pcg32_advance(uint64_t state, uint32_t delta) {
-    uint64_t accMult = 1ull, accPlus = 0ull, curMult = 6364136223846793005ull, curPlus = 1ull;
-    while (delta > 0) {
-        if (delta & 1u) { accMult *= curMult; accPlus = accPlus * curMult + curPlus; }
-        curPlus = (curMult + 1ull) * curPlus;
-        curMult *= curMult;
-        delta >>= 1;
-    }
-    return accMult * state + accPlus;
-}
-
-// What candidate i of a pixel draws and samples (optix_restir_di_kernels.cu:71-107): shared by the candidate pass of the
-// pooled kernel and by the re-derivation of the selected sample.  `pending` non-null defers the emittance-texture read.
-template <bool EMITTER_TEX>
-GFX_DEV void draw_candidate(const RestirArgs& a, const EnvMap& env, bool envEnabled, uint32_t numCandidates, uint32_t i, Pcg32& rng,
-                            LightSample& ls, float& pd, PendingEmittance* pending) {
-    float ul = rng.uniform();
-    float probCurType = 1.0f;
-    bool sampleEnv = false;
-    if (envEnabled) {
-        if (*a.scene.lightInstIntegral > 0.0f) {
-            const float prob = fmin2(fmax2(0.25f * numCandidates - i, 0.0f), 1.0f);
-            if (prob == 1.0f) { probCurType = 0.25f; sampleEnv = true; }
-            else if (prob == 0.0f) probCurType = 1.0f - 0.25f;
-            else if (ul < prob) { probCurType = 0.25f; ul = ul / prob; sampleEnv = true; }
-            else { probCurType = 1.0f - 0.25f; ul = (ul - prob) / (1 - prob); }
-        }
-        else sampleEnv = true;
-    }
-    ls.emittance = f3(0.0f); ls.position = f3(0.0f); ls.normal = f3(0.0f); ls.atInfinity = 0;
-    const float u0 = rng.uniform();
-    const float u1 = rng.uniform();
-    if (sampleEnv) sample_env_light(env, a.f.envLightRotation, a.f.envLightPowerCoeff, u0, u1, ls, pd);
-    else {
-        const LightPick pk = light_select(a.scene, ul);
-        if (pk.ok) light_fetch<EMITTER_TEX, false>(a.scene, pk, u0, u1, ls, pd, f3(0.0f), pending);
-        else pd = 0.0f;
-    }
-    pd *= probCurType;
-}
-
-template <bool EMITTER_TEX>
-__global__ __launch_bounds__(kBlock) void k_initial_candidates_pooled(RestirArgs a) {
-    __shared__ PoolWaveLds poolLds[kBlock / 64];
-    PoolWaveLds& L = poolLds[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-    const int lane = threadIdx.x & 63;
-    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const PixelId px = pixel_of_thread(a.px);
-    const size_t p = px.p;
-    const uint32_t bufIdx = a.f.bufferIndex;
-    bool surface = false;
-    if (px.valid) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
-
-    bool wantRay = false;
-    f3 rayO(0.0f), rayD(0.0f);
-    float rayTmax = 0;
-    if (__ballot(surface) != 0ull) {          // a wave of sky / padding has nothing to do
-        const EnvMap env = load_env(a.s);
-        const bool envEnabled = env.present() && a.f.enableEnvLight;
-        ShadingPoint sp;
-        sp.pos = f3(0.0f); sp.vOutLocal = f3(0.0f, 0.0f, 1.0f); sp.dist = 0; sp.frame = Frame(f3(0, 0, 1), f3(1, 0, 0));
-        sp.bsdf.type = GFX_BSDF_LAMBERT; sp.bsdf.diffuse = f3(0.0f); sp.bsdf.specularF0 = f3(0.0f); sp.bsdf.roughness = 1.0f;
-        uint64_t* rngBuf = static_cast<uint64_t*>(a.s.rngBuffer);
-        Pcg32 rng; rng.state = 0;
-        if (surface) {
-            const Camera cam = load_camera(a.f.camera);
-            make_shading_point(a, bufIdx, p, cam.pos, false, sp);
-            rng.state = rngBuf[p];
-        }
-        const uint64_t rngAtEntry = rng.state;
-
-        float sumWeights = 0.0f, selectedTarget = 0.0f;
-        uint32_t streamLength = 0, selectedIndex = 0xFFFFFFFFu;
-        const uint32_t numCandidates = 1u << a.f.log2NumCandidateSamples;
-        uint32_t queued = 0;                  // wave-uniform: jobs in the queue
-
-        // one job per lane: evaluate, leave the target where its owner reads it
-        auto run_jobs = [&](uint32_t first, uint32_t count) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const bool mine = static_cast<uint32_t>(lane) < count;
-            const uint32_t slot = first + (mine ? lane : 0);
-            const uint32_t meta = L.meta[slot];
-            const int owner = static_cast<int>(meta & 63u);
-            // the owner's shading point, read across lanes (every lane takes part in the exchange)
-            Bsdf bsdf;
-            bsdf.type = static_cast<uint32_t>(__shfl(static_cast<int>(sp.bsdf.type), owner));
-            bsdf.diffuse = f3(__shfl(sp.bsdf.diffuse.x, owner), __shfl(sp.bsdf.diffuse.y, owner), __shfl(sp.bsdf.diffuse.z, owner));
-            bsdf.specularF0 = f3(__shfl(sp.bsdf.specularF0.x, owner), __shfl(sp.bsdf.specularF0.y, owner), __shfl(sp.bsdf.specularF0.z, owner));
-            bsdf.roughness = __shfl(sp.bsdf.roughness, owner);
-            const f3 vOutLocal(__shfl(sp.vOutLocal.x, owner), __shfl(sp.vOutLocal.y, owner), __shfl(sp.vOutLocal.z, owner));
-            if (mine) {
-                const f3 dirLocal(L.dir[0][slot], L.dir[1][slot], L.dir[2][slot]);
-                const float G = L.geom[slot];
-                const float w0 = L.le[0][slot], w1 = L.le[1][slot], w2 = L.le[2][slot];
-                f3 emittance(w0, w1, w2);
-                // direct_lighting_pending from the BSDF evaluation on (shading.hip.h)
-                const f3 fs = bsdf.evaluate(vOutLocal, dirLocal);
-                const bool zero = (fs.x == 0.0f && fs.y == 0.0f && fs.z == 0.0f) || G == 0.0f;
-                if (EMITTER_TEX && (meta & 0x400u)) {
-                    // f * G == 0: the texture is not read and the product below is 0 (or NaN through a non-finite f or G)
-                    // whatever finite emittance it is formed with -- the reference forms it with the texel, the loop above
-                    // with the record's constant, this one with 0
-                    emittance = f3(0.0f);
-                    if (!zero) {
-                        DevTexture desc;
-                        const uint32_t dims = f2bits(L.le[3][slot]);
-                        desc.offset = f2bits(w2); desc.width = (dims & 0x3FFFu) + 1u; desc.height = ((dims >> 14) & 0x3FFFu) + 1u; desc.format = dims >> 28;
-                        const float4 t = tex2d_desc(a.scene, desc, w0, w1);
-                        emittance = f3(1.0f) * f3(t.x, t.y, t.z);
-                    }
-                }
-                const f3 Le = emittance / kPi;
-                L.target[(meta >> 6) & 3u][owner] = target_weight(fs * Le * G);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-
-        for (uint32_t base = 0; base < numCandidates; base += kPoolBatch) {
-            const uint32_t batch = min(static_cast<uint32_t>(kPoolBatch), numCandidates - base);
-            for (uint32_t c = 0; c < batch; ++c) {
-                bool job = false;
-                f3 dirLocal(0.0f), emittance(0.0f);
-                float G = 0.0f;
-                PendingEmittance pending; pending.tex = 0u; pending.tu = pending.tv = 0.0f;
-                pending.desc.offset = pending.desc.width = pending.desc.height = pending.desc.format = 0u;
-                if (surface) {
-                    LightSample ls;
-                    float pd;
-                    draw_candidate<EMITTER_TEX>(a, env, envEnabled, numCandidates, base + c, rng, ls, pd, EMITTER_TEX ? &pending : nullptr);
-                    L.density[c][lane] = pd;
-                    L.uRes[c][lane] = rng.uniform();
-                    // direct_lighting_pending up to the BSDF evaluation
-                    const ShadowRay sr = shadow_ray(sp.pos, ls);
-                    dirLocal = sp.frame.to_local(sr.dir);
-                    const float lpCos = dot(-sr.dir, ls.normal);
-                    float target = 0.0f;      // target_weight(f3(0)) for an emitter that faces away
-                    if (lpCos > 0) {
-                        G = lpCos * fabsf(dirLocal.z) / sr.dist2;
-                        emittance = ls.emittance;
-                        // Bsdf::evaluate returns f3(0) without arithmetic on the wrong side of the surface
-                        const float side = sp.bsdf.type == GFX_BSDF_LAMBERT ? sp.vOutLocal.z * dirLocal.z : dirLocal.z * sp.vOutLocal.z;
-                        job = sp.bsdf.type == GFX_BSDF_LAMBERT ? side > 0 : !(side <= 0);
-                        if (!job) target = target_weight(f3(0.0f) * (emittance / kPi) * G);   // the products the reference forms with fs = 0
-                    }
-                    L.target[c][lane] = target;
-                }
-                const unsigned long long jobMask = __ballot(job);
-                if (job) {
-                    const uint32_t slot = queued + __popcll(jobMask & ((1ull << lane) - 1ull));
-                    L.meta[slot] = static_cast<uint32_t>(lane) | (c << 6) | (pending.tex ? 0x400u : 0u);
-                    L.dir[0][slot] = dirLocal.x; L.dir[1][slot] = dirLocal.y; L.dir[2][slot] = dirLocal.z;
-                    L.geom[slot] = G;
-                    if (EMITTER_TEX && pending.tex) {
-                        L.le[0][slot] = pending.tu; L.le[1][slot] = pending.tv;
-                        L.le[2][slot] = bits2f(pending.desc.offset);
-                        L.le[3][slot] = bits2f((pending.desc.width - 1u) | ((pending.desc.height - 1u) << 14) | (pending.desc.format << 28));
-                    }
-                    else { L.le[0][slot] = emittance.x; L.le[1][slot] = emittance.y; L.le[2][slot] = emittance.z; }
-                }
-                queued += static_cast<uint32_t>(__popcll(jobMask));
-                if (queued >= 64u) { queued -= 64u; run_jobs(queued, 64u); }     // the 64 youngest: the rest stays where it is
-            }
-            if (queued) { run_jobs(0u, queued); queued = 0; }                      // the updates below need every job of the batch
-            else {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            if (surface) {
-                for (uint32_t c = 0; c < batch; ++c) {       // Reservoir::update in candidate order (restir_di_shared.h:118-125)
-                    const float target = L.target[c][lane];
-                    const float weight = target / L.density[c][lane];
-                    sumWeights += weight;
-                    if (L.uRes[c][lane] < weight / sumWeights) { selectedTarget = target; selectedIndex = base + c; }
-                    ++streamLength;
-                }
-            }
-        }
-
-        if (surface) {
-            Reservoir reservoir;
-            reservoir.reset();
-            if (selectedIndex != 0xFFFFFFFFu) {   // the accepted candidate's sample, from its own three random numbers
-                Pcg32 replay; replay.state = pcg32_advance(rngAtEntry, 4u * selectedIndex);
-                float pdUnused;
-                draw_candidate<EMITTER_TEX>(a, env, envEnabled, numCandidates, selectedIndex, replay, reservoir.sample, pdUnused, nullptr);
-            }
-            reservoir.sumWeights = sumWeights;
-            reservoir.streamLength = streamLength;
-            float recPDF = reservoir.sumWeights / (selectedTarget * reservoir.streamLength);
-            if (!is_finite(recPDF)) { recPDF = 0.0f; selectedTarget = 0.0f; }
-            if (a.f.reuseVisibility && selectedTarget > 0.0f) {
-                const ShadowRay sr = shadow_ray(sp.pos, reservoir.sample);
-                wantRay = true; rayO = sp.pos; rayD = sr.dir; rayTmax = sr.tmax;
-            }
-            rngBuf[p] = rng.state;
-            store_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p, reservoir);
-            static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes])[p] = make_float2(recPDF, selectedTarget);
-        }
     }
     const uint32_t slot = queue_append_wave(wantRay, rayO, rayD, 0.0f, rayTmax, a.rayOrg, a.rayDir, a.rayCount);
     if (px.valid) a.pixelRaySlot[p] = slot;
@@ -1041,12 +851,11 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         {
             const uint32_t grid = a.px.launchBlocks;
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
-            if (ctx.tune.pooledCandidates) {
-                if (a.scene.emitterTexRefs) hipLaunchKernelGGL(k_initial_candidates_pooled<true>, dim3(grid), dim3(kBlock), 0, stream, a);
-                else hipLaunchKernelGGL(k_initial_candidates_pooled<false>, dim3(grid), dim3(kBlock), 0, stream, a);
-            }
-            else if (a.scene.emitterTexRefs) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), 0, stream, a);
-            else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);
+            // the emitter instances' distinct normal matrices ride in LDS when four blocks of them fit a CU next to the fetch buffers
+            const uint32_t inLds = (a.scene.numLightMatrices * 36u <= kInitialMatrixLdsBytes && !ctx.tune.noLdsMatrices) ? a.scene.numLightMatrices : 0u;
+            const size_t dyn = inLds * 36u;
+            if (a.scene.emitterTexRefs) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), dyn, stream, a, inLds);
+            else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), dyn, stream, a, inLds);
             GFX_HIP(hipGetLastError());
         }
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);

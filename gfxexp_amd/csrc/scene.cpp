@@ -4,15 +4,15 @@
 #include <cmath>
 #include <cstring>
 #include "internal.h"
-#ifndef GFX_SPAN_CELLS_PER_REC   // guide cells per emitter record (power of two after rounding): finer cells = shorter searches, bigger table
-#define GFX_SPAN_CELLS_PER_REC 2u
-#endif
+#include <cstdlib>
+#include <map>
+#include <array>
 
 namespace gfx {
 
 Context::~Context() {
     for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->triIds.release(); a->rootBoxes.release(); delete a; } }
-    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dSubset[0], &dSubset[1], &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs, &dEmitterRecExtras, &dLightNormalMatrices, &dTextures, &dTexelPool, &dSrgbLut, &dEmitterTexRefs,
+    DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dSubset[0], &dSubset[1], &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs, &dEmitterRecExtras, &dLightNormalMatrices, &dInstMatrixIndex, &dTextures, &dTexelPool, &dSrgbLut, &dEmitterTexRefs,
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
                       &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide, &dSpans, &dSpanGuide, &dSpanHeader, &dSpanInstBegin,
@@ -38,6 +38,7 @@ DevScene Context::devScene() const {
     s.emitterRecs = dEmitterRecs.as<EmitterRec>();
     s.emitterRecExtras = dEmitterRecExtras.as<EmitterRecExtra>();
     s.lightNormalMatrices = dLightNormalMatrices.as<float>();
+    s.numLightMatrices = numLightMatrices;
     s.lightInstIntegral = dLightInstIntegral.as<float>();
     s.lightInstGuide = dLightInstGuide.as<uint16_t>();
     s.lightInstGuideCells = lightInstGuideCells;
@@ -116,6 +117,36 @@ static void fill_instance_transform(const HostInstance& hi, DevInstance& d) {
 // Transform-only update (gfx_instance_set_transform on instances that already live in the animated subtree): the
 // pools, the distributions' layout and the static subtree stay; only the moved DevInstance entries go to the device.
 // The emitter records (world-space triangles) are refreshed by the next lights_build_instances.
+// The normal matrices of the emitter instances, deduplicated by bit pattern (instances of one prototype placed by translation
+// share theirs): EmitterRec::flags carries the index, light_from_record reads the rows.  A table of few entries stays in L1 /
+// LDS; the rows themselves are the ones fill_instance_transform computed, so nothing changes numerically.
+void light_matrices_upload(Context& ctx, hipStream_t stream) {
+    std::map<std::array<uint32_t, 9>, uint32_t> seen;
+    std::vector<float> rows;              // 16 floats per matrix: three rows padded to float4 + one zero quarter (64-byte items)
+    std::vector<uint32_t> index(ctx.hInsts.size(), 0u);
+    for (size_t ii = 0; ii < ctx.hInsts.size(); ++ii) {
+        const DevInstance& d = ctx.hInsts[ii];
+        if (d.distOffset == 0xFFFFFFFFu) continue;
+        std::array<uint32_t, 9> key;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) std::memcpy(&key[3 * r + c], &d.normalMatrix[4 * r + c], 4);
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            it = seen.emplace(key, static_cast<uint32_t>(seen.size())).first;
+            for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) rows.push_back(d.normalMatrix[4 * r + c]); rows.push_back(0.0f); }
+            rows.insert(rows.end(), 4, 0.0f);
+        }
+        index[ii] = it->second;
+    }
+    if (seen.size() > kEmitterMatrixMask + 1u)
+        throw HipError("gfx: more than 65536 distinct normal matrices among the emitter instances");
+    ctx.numLightMatrices = static_cast<uint32_t>(seen.size());
+    ctx.dLightNormalMatrices.reserve(std::max<size_t>(rows.size() * sizeof(float), 64));
+    ctx.dInstMatrixIndex.reserve(std::max<size_t>(index.size() * sizeof(uint32_t), 16));
+    if (!rows.empty()) GFX_HIP(hipMemcpyAsync(ctx.dLightNormalMatrices.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (!index.empty()) GFX_HIP(hipMemcpyAsync(ctx.dInstMatrixIndex.p, index.data(), index.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    GFX_HIP(hipStreamSynchronize(stream));   // the host vectors go out of scope
+}
+
 void transforms_upload(Context& ctx, hipStream_t stream) {
     if (!ctx.transformsDirty) return;
     for (uint32_t slot : ctx.movedInsts) {
@@ -218,9 +249,12 @@ void scene_upload(Context& ctx, hipStream_t stream) {
         ctx.dLightInstGuide.reserve(sizeof(uint16_t) * cells);
     }
     GFX_HIP(hipMemsetAsync(ctx.dLightInstIntegral.p, 0, 16, stream));
-    {   // emitter interval table: about two guide cells per record (power of two: ul * cells is exact)
+    {   // emitter interval table: GFX_SPAN_CELLS_PER_REC guide cells per record, rounded up to a power of two (ul * cells is exact);
+        // finer cells = more of the ul range in interior cells (one load per lookup), bigger table
+        uint32_t perRec = GFX_SPAN_CELLS_PER_REC;
+        if (const char* e = std::getenv("GFX_SPAN_CELLS_PER_REC")) { const long v = std::atol(e); if (v >= 1 && v <= 64) perRec = static_cast<uint32_t>(v); }
         uint32_t cells = 256;
-        while (cells < GFX_SPAN_CELLS_PER_REC * ctx.numEmitterRecs && cells < (1u << 22)) cells *= 2;
+        while (cells < static_cast<uint64_t>(perRec) * ctx.numEmitterRecs && cells < (1u << 22)) cells *= 2;
         ctx.spanGuideCells = cells;
         ctx.dSpans.reserve(std::max<size_t>(sizeof(EmitterSpan) * ctx.numEmitterRecs, 16));
         ctx.dSpanGuide.reserve(sizeof(SpanGuide) * cells);
@@ -257,6 +291,7 @@ void scene_upload(Context& ctx, hipStream_t stream) {
             const uint32_t slots[5] = { m.texA, m.texB, m.texSmoothness, m.texNormal, m.texEmittance };
             for (uint32_t sl : slots)
                 if (sl != 0 && (sl >= ctx.textures.size() || ctx.textures[sl].width == 0)) throw HipError("gfx: material references a texture slot that was never set");
+            if (m.hasEmittance && m.texEmittance > kEmitterTexMask) throw HipError("gfx: an emittance texture must sit in a texture slot below 32768");
         }
         ctx.anyEmittanceTexture = false;
         for (const HostGeom& g : ctx.geoms)
@@ -275,7 +310,7 @@ void scene_upload(Context& ctx, hipStream_t stream) {
     upload(ctx.dLightRefs, ctx.hLightRefs, stream);
     ctx.dEmitterRecs.reserve(std::max<size_t>(sizeof(EmitterRec) * ctx.numEmitterRecs, 16));
     ctx.dEmitterRecExtras.reserve(std::max<size_t>(sizeof(EmitterRecExtra) * ctx.numEmitterRecs, 16));
-    ctx.dLightNormalMatrices.reserve(std::max<size_t>(48 * ctx.insts.size(), 16));
+    light_matrices_upload(ctx, stream);
     ctx.dEmitterTexRefs.reserve(std::max<size_t>(ctx.anyEmittanceTexture ? sizeof(EmitterTexRef) * ctx.numEmitterRecs : 0, 16));
     ctx.dLightW.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));
     ctx.dLightCDF.reserve(std::max<size_t>(sizeof(float) * lightPool, 16));

@@ -438,7 +438,9 @@ struct LightSample {
 };
 // An emittance-texture read that has not happened yet (k_initial_candidates fetches it only for candidates whose
 // geometric / BSDF term is non-zero: the emittance of a zero-weight candidate is never observed).
-struct PendingEmittance { uint32_t tex; DevTexture desc; float tu, tv; };
+// Holds the record and the barycentric coordinates; the record's EmitterTexRef (texture coordinates + descriptor, its own 32-byte
+// gather) is read with the texels, not before.
+struct PendingEmittance { uint32_t tex; uint32_t rec; float bcA, bcB, bcC; };
 
 struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
     const float4* texels;
@@ -563,6 +565,21 @@ GFX_DEV bool light_locate_3level(const DevScene& sc, const InstDist& instDist, f
     return true;
 }
 
+// The emittance texel of a point (barycentric coordinates) on emitter record `rec`: texture coordinates and descriptor out of the
+// record's EmitterTexRef, then the build's tex2DLod (restir_di_shared.h:504-514).
+GFX_DEV float4 emitter_texel(const DevScene& sc, uint32_t rec, float bcA, float bcB, float bcC) {
+    const float4* tp = reinterpret_cast<const float4*>(sc.emitterTexRefs + rec);
+    const float4 t0 = tp[0], t1 = tp[1];
+    const float tu = bcA * t0.x + bcB * t0.z + bcC * t1.x;
+    const float tv = bcA * t0.y + bcB * t0.w + bcC * t1.y;
+    const uint32_t dims = f2bits(t1.w);
+    DevTexture desc;
+    desc.offset = f2bits(t1.z); desc.width = (dims & 0x3FFFu) + 1u; desc.height = ((dims >> 14) & 0x3FFFu) + 1u; desc.format = dims >> 28;
+    return tex2d_desc(sc, desc, tu, tv);
+}
+
+GFX_DEV uint32_t emitter_matrix_index(uint32_t recFlags) { return (recFlags >> kEmitterMatrixShift) & kEmitterMatrixMask; }
+
 // Which emitter record a light-selection number ul picks, and what comes with it.
 struct LightPick {
     uint32_t rec, instSlot;
@@ -624,13 +641,11 @@ GFX_DEV LightPick light_select_search(const DevScene& sc, float ul) {
 // SOLID_ANGLE = sampleLight<true> (restir_di_shared.h:419-483): the point is drawn uniformly in the solid angle the
 // triangle subtends from shadingPoint.
 template <bool EMITTER_TEX = true, bool SOLID_ANGLE = false>
-GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, float u1, LightSample& ls, float& areaPDensity, f3 shadingPoint = f3(0.0f),
-                         PendingEmittance* pending = nullptr) {
-    // EmitterRec: world-space triangle + first vertex normal + emittance in 64 bytes; the other two normals (smooth emitters
+GFX_DEV void light_from_record(const DevScene& sc, const LightPick& pk, float4 r0, float4 r1, float4 r2, float4 r3, const m33& normalMatrix,
+                               float u0, float u1, LightSample& ls, float& areaPDensity, f3 shadingPoint = f3(0.0f),
+                               PendingEmittance* pending = nullptr) {
+    // EmitterRec (r0..r3): world-space triangle + first vertex normal + emittance in 64 bytes; the other two normals (smooth emitters
     // only), 2 / |ng| and the primitive's probability (three-search fallback, solid-angle sampling) in EmitterRecExtra
-    const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + pk.rec);
-    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-    const m33 normalMatrix = load_m33_rows(sc.lightNormalMatrices + 12u * pk.instSlot);
     const f3 pA(r0.x, r0.y, r0.z), pB(r0.w, r1.x, r1.y), pC(r1.z, r1.w, r2.x);
     const f3 nA(r2.y, r2.z, r2.w);
     const uint32_t flags = f2bits(r3.w);
@@ -690,21 +705,23 @@ GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, floa
     ls.emittance = f3(r3.x, r3.y, r3.z);
     const uint32_t tex = EMITTER_TEX ? (flags & kEmitterTexMask) : 0u;   // emittance-texture slot (restir_di_shared.h:504-514)
     if (tex) {
-        const float4* tp = reinterpret_cast<const float4*>(sc.emitterTexRefs + pk.rec);
-        const float4 t0 = tp[0], t1 = tp[1];
-        {
-            const float tu = bcA * t0.x + bcB * t0.z + bcC * t1.x;
-            const float tv = bcA * t0.y + bcB * t0.w + bcC * t1.y;
-            const uint32_t dims = f2bits(t1.w);
-            DevTexture desc;
-            desc.offset = f2bits(t1.z); desc.width = (dims & 0x3FFFu) + 1u; desc.height = ((dims >> 14) & 0x3FFFu) + 1u; desc.format = dims >> 28;
-            if (pending) { pending->tex = tex; pending->desc = desc; pending->tu = tu; pending->tv = tv; }
-            else {
-                const float4 tv4 = tex2d_desc(sc, desc, tu, tv);
-                ls.emittance = f3(1.0f) * f3(tv4.x, tv4.y, tv4.z);
-            }
+        if (pending) { pending->tex = tex; pending->rec = pk.rec; pending->bcA = bcA; pending->bcB = bcB; pending->bcC = bcC; }
+        else {
+            const float4 tv4 = emitter_texel(sc, pk.rec, bcA, bcB, bcC);
+            ls.emittance = f3(1.0f) * f3(tv4.x, tv4.y, tv4.z);
         }
     }
+}
+
+// The same with the record and the instance's normal-matrix rows gathered by the calling lane itself (seven 16-byte loads);
+// k_initial_candidates gathers them cooperatively instead (coop_fetch.hip.h) and calls light_from_record directly.
+template <bool EMITTER_TEX = true, bool SOLID_ANGLE = false>
+GFX_DEV void light_fetch(const DevScene& sc, const LightPick& pk, float u0, float u1, LightSample& ls, float& areaPDensity, f3 shadingPoint = f3(0.0f),
+                         PendingEmittance* pending = nullptr) {
+    const float4* rp = reinterpret_cast<const float4*>(sc.emitterRecs + pk.rec);
+    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+    const m33 normalMatrix = load_m33_rows(sc.lightNormalMatrices + 16u * emitter_matrix_index(f2bits(r3.w)));
+    light_from_record<EMITTER_TEX, SOLID_ANGLE>(sc, pk, r0, r1, r2, r3, normalMatrix, u0, u1, ls, areaPDensity, shadingPoint, pending);
 }
 
 GFX_DEV void sample_env_light(const EnvMap& env, float envRotation, float envPowerCoeff, float u0, float u1, LightSample& ls, float& areaPDensity) {
@@ -774,7 +791,7 @@ GFX_DEV f3 direct_lighting_pending(const DevScene& sc, f3 shadingPoint, f3 vOutL
         const bool zero = (fs.x == 0.0f && fs.y == 0.0f && fs.z == 0.0f) || G == 0.0f;
         if (pending.tex && !zero) {
             GFX_PROF(4);
-            const float4 t = tex2d_desc(sc, pending.desc, pending.tu, pending.tv);
+            const float4 t = emitter_texel(sc, pending.rec, pending.bcA, pending.bcB, pending.bcC);
             ls.emittance = f3(1.0f) * f3(t.x, t.y, t.z);
         }
         const f3 Le = ls.emittance / kPi;

@@ -8,6 +8,7 @@
 // for exactly popcount(idle) rays (ballot + mbcnt compaction) and the idle lanes start new rays
 // while the others keep traversing -- the SIMT analogue of OptiX's hardware ray scheduling.
 #include "bvh8.hip.h"
+#include "coop_fetch.hip.h"
 #include "internal.h"
 
 namespace gfx {
@@ -30,42 +31,12 @@ struct TraceArgs {
     int ticketBatch;            // rays bought per device atomic
 };
 
-// Cooperative fetch of one 64-byte item (node or triangle record) per lane.
-// A per-lane gather of 64 B costs four dwordx4 instructions whose 64 lanes all touch different
-// cache lines: 256 line requests per wave-iteration, and the CU's texture-addresser (one line
-// request per clock) is what the kernel was bound by (profiles/r01b: same time at 2 and 6 blocks
-// per CU).  Here four neighbouring lanes fetch the four 16-byte quarters of ONE item with a
-// global->LDS DMA (global_load_lds_dwordx4, no VGPR round trip), so each instruction issues 16
-// line requests instead of 64, and every lane then reads its own item back from LDS with four
-// ds_read_b128.  LDS-DMA writes lane-linearly (base + lane * 16), so the quarter a lane fetches is
-// XOR-swizzled with (item >> 2) & 3 to make those reads bank-conflict free.
-GFX_DEV void fetch_items(uint32_t code, const DevAccel& acc, uint4* waveBuf /* 256 x 16 B, wave-private */, int lane,
-                         uint4& q0, uint4& q1, uint4& q2, uint4& q3) {
-    // nodes and triangle records share one allocation (internal.h Accel): item = code & 0x7FFFFFFF.  The builder
-    // keeps the item count below 2^26, so the byte offset fits 32 bits and the loads use the scalar-base form.
-    const char* itemBase = reinterpret_cast<const char*>(acc.nodes);
-    // item 16 k + (lane >> 2) of round k: its swizzle ((item >> 2) & 3) = (lane >> 4) & 3 does not depend on k
-    const uint32_t quarterOff = static_cast<uint32_t>((lane & 3) ^ ((lane >> 4) & 3)) << 4;
-    uint32_t c[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) c[k] = __shfl(code, 16 * k + (lane >> 2));   // whose item this lane helps to fetch
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (c[k] != kItemNone) {
-            const uint32_t off = (c[k] << 6) | quarterOff;   // the tag bit (bit 31) falls off the top
-            typedef const __attribute__((address_space(1))) void* GlobalPtr;
-            typedef __attribute__((address_space(3))) void* LdsPtr;
-            __builtin_amdgcn_global_load_lds((GlobalPtr)(itemBase + off), (LdsPtr)(waveBuf + 64 * k), 16, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int sw = (lane >> 2) & 3;
-    const uint4* mine = waveBuf + 4 * lane;
-    q0 = mine[0 ^ sw]; q1 = mine[1 ^ sw]; q2 = mine[2 ^ sw]; q3 = mine[3 ^ sw];
-}
-
+// fetch_items: coop_fetch.hip.h (the cooperative 64-byte gather; the candidate kernel of restir.hip uses it for emitter records).
+#ifndef GFX_TRACE_MIN_WAVES
+#define GFX_TRACE_MIN_WAVES 1
+#endif
 template <bool ANY_HIT, bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
+__global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(TraceArgs a) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kTraceBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[kTraceBlock * 4];   // 4 KiB per wave
     const int tid = threadIdx.x;
@@ -147,6 +118,15 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs a) {
         if (code != kItemNone && !(code & kItemTri)) link = reinterpret_cast<const uint4*>(a.accel.links)[code];   // in flight with the item fetch
         uint4 q0, q1, q2, q3;
         fetch_items(code, a.accel, waveBuf, lane, q0, q1, q2, q3);
+#ifdef GFX_WHATIF_VALU   // sensitivity experiment: GFX_WHATIF_VALU extra dependent-free VALU instructions per wave iteration
+        {
+            float w0 = bits2f(q0.x), w1 = bits2f(q0.y), w2 = bits2f(q0.z), w3 = bits2f(q0.w);
+#pragma unroll
+            for (int k = 0; k < GFX_WHATIF_VALU / 4; ++k)
+                asm volatile("v_fma_f32 %0, %0, %0, %1\n v_fma_f32 %1, %1, %1, %2\n v_fma_f32 %2, %2, %2, %3\n v_fma_f32 %3, %3, %3, %0\n" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+            if (w0 + w1 + w2 + w3 == 123.456f) q3.x ^= 1u;   // never true in practice; keeps the chain alive
+        }
+#endif
         if (code != kItemNone) {
             if (code & kItemTri) {
                 if (!tr.template process_triangle<ANY_HIT, COUNT>((code & 0x7FFFFFFFu) - a.accel.triItemOffset, q0, q1, q2, q3, a.accel.tris, cnt))

@@ -182,8 +182,10 @@ int gfx_lights_read(gfx_ctx* ctx, uint32_t level, uint32_t index, float* weights
 
 /* State of the emitter interval table the last gfx_lights_build_instances produced (the three searches of
  * sampleLight, restir_di_shared.h:366-415, flattened into one lookup): info = { usable (the build verified it
- * against the three searches; 0 = kernels run the searches themselves), records verified, records, guide cells }. */
-int gfx_lights_table_info(gfx_ctx* ctx, uint32_t info[4]);
+ * against the three searches; 0 = kernels run the searches themselves), records verified, records, guide cells,
+ * distinct normal matrices among the emitter instances, interior guide cells (a lookup that lands in one is done after
+ * one load), 0, 0 }. */
+int gfx_lights_table_info(gfx_ctx* ctx, uint32_t info[8]);
 
 /* ---------------------------------------------------------------- ray queries ---------------- */
 
@@ -479,9 +481,10 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
  *                               (the tiling of restir_di/gpu_kernels/per_pixel_ris.cu:44-61), tiles + XCD-aware supertiles (default)
  *   "super_x", "super_y"        log2 of the supertile size in 16 x 16-pixel blocks (mode 2; default 2, 2)
  *   "trace_blocks_per_cu", "trace_refill", "trace_batch"   persistent traversal grid, lane-refill threshold, rays per ticket
- *   "pooled_candidates" 0|1     the initial-candidate pass with the BSDF evaluations of a wave pooled (restir.hip; default 0)
+ *   "no_lds_matrices" 0|1       the initial-candidate pass reads the emitter instances' normal matrices from global memory even
+ *                               when the distinct ones fit LDS (default 0; GFX_NO_LDS_MATRICES)
  * The same knobs are read once from the environment by gfx_ctx_create (GFX_PIXEL_MAP, GFX_SUPER_X, GFX_SUPER_Y,
- * GFX_TRACE_BLOCKS_PER_CU, GFX_TRACE_REFILL, GFX_TRACE_BATCH, GFX_POOLED_CANDIDATES). */
+ * GFX_TRACE_BLOCKS_PER_CU, GFX_TRACE_REFILL, GFX_TRACE_BATCH). */
 int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value);
 /* Ray-traversal counters accumulated by the renderer passes: {node fetches, triangle fetches, rays, stack spills}
  * of the any-hit launches in [0..3] and of the closest-hit launches in [4..7]. */

@@ -163,7 +163,7 @@ static Table build_table(const Scene& sc) {
         if (!(b <= en && en <= nextBegin && en <= kSpanBitsEnd)) tb.usable = false;
     }
     uint32_t cells = 256;
-    while (cells < 2u * sc.numRecs && cells < (1u << 22)) cells *= 2;
+    while (cells < GFX_SPAN_CELLS_PER_REC * sc.numRecs && cells < (1u << 22)) cells *= 2;
     tb.cells = cells;
     tb.guide.resize(cells);
     for (uint32_t c = 0; c < cells; ++c) tb.guide[c] = span_guide_entry(tb.spans.data(), sc.numRecs, cells, c);

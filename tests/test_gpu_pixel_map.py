@@ -85,21 +85,3 @@ def test_tunable_set_rejects_unknown_names_and_values(built_lib):
         ctx.tunable_set("pixel_map", 3)
     with pytest.raises(api.GfxError):
         ctx.tunable_set("no_such_knob", 1)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("renderer", [api.RENDERER_BIASED, api.RENDERER_UNBIASED])
-def test_pooled_candidate_kernel_is_bit_exact(built_lib, monkeypatch, renderer):
-    """gfx_tunable_set "pooled_candidates" (k_initial_candidates_pooled, restir.hip): the BSDF evaluations of a wave are
-    queued in LDS and run 64 at a time, the reservoir updates follow in candidate order and the selected sample is re-derived
-    from its own random numbers (PCG32 jump-ahead) -- every buffer equals the oracle's after every pass, on the bunny, on a
-    textured street with emittance maps (deferred texture reads inside the jobs) and under an environment light."""
-    monkeypatch.setenv("GFX_POOLED_CANDIDATES", "1")
-    diffs = run_sequence_both(util.bunny_scene(), 150, 91, frames=2, renderer=renderer)
-    assert not diffs, "\n".join(diffs)
-    with util.frame_overrides(enableBumpMapping=1):
-        diffs = run_sequence_both(util.small_street(textured=True), 160, 90, frames=2, renderer=renderer, scene_kind="street")
-    assert not diffs, "\n".join(diffs)
-    sky = api.env_make_sky(64, 32)
-    diffs = run_sequence_both(util.bunny_scene(), 96, 64, frames=2, renderer=renderer, env=(sky, 64, 32), env_power=0.7, env_rotation=0.3)
-    assert not diffs, "\n".join(diffs)

@@ -20,6 +20,8 @@
 #                host: python gfxexp_amd/build.py --variant laneprof GFX_LANE_PROFILE)    -> profiles/r03_initial_candidates.txt
 #   renderers    tools/bench_renderers.py + tools/bench_config4.py                      -> profiles/r03_renderers.jsonl
 #   bands        tools/bench_band.py (compute-only bound of N row bands)                -> profiles/r03_band_compute_bound.json
+#   valurate     tools/microbench/valu_rate.hip: wave64 VALU issue rate per SIMD by instruction kind and resident waves
+#   whatif       k_trace with extra VALU work / more resident waves (experiment variants)  -> profiles/r03_experiments.txt
 #   hbm          tools/hbm_stream.py (streaming-copy ceiling of this box)               -> profiles/r03_hbm_stream.json
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
@@ -74,10 +76,36 @@ for step in "$@"; do
                timeout 600 python tools/bench_nrc_frame.py > $OUT/nrc_frame.jsonl 2> $OUT/nrc_frame.err; cat $OUT/nrc_frame.jsonl; tail -3 $OUT/nrc_frame.err ;;
     pmcjson)   if [ -d $OUT/pmc_map0 ]; then python profiles/make_pmc_json.py $OUT/pmc_default $OUT/pmc_map0 pixel_map_0_scan_lines > $OUT/r03_pmc.json
                else python profiles/make_pmc_json.py $OUT/pmc_default > $OUT/r03_pmc.json; fi; head -c 600 $OUT/r03_pmc.json ;;
-    laneprof)  GFX_LIB=$PWD/gfxexp_amd/variants/libgfxexp_laneprof.so GFX_POOLED_CANDIDATES=0 timeout 300 python tools/lane_profile.py > $OUT/lane_profile.json 2> $OUT/lane_profile.err; cat $OUT/lane_profile.json ;;
+    laneprof)  GFX_LIB=$PWD/gfxexp_amd/variants/libgfxexp_laneprof.so timeout 300 python tools/lane_profile.py > $OUT/lane_profile.json 2> $OUT/lane_profile.err; cat $OUT/lane_profile.json ;;
     renderers) timeout 900 python tools/bench_renderers.py > $OUT/renderers.jsonl 2> $OUT/renderers.err
                timeout 300 python tools/bench_config4.py >> $OUT/renderers.jsonl 2>> $OUT/renderers.err; cat $OUT/renderers.jsonl ;;
     bands)     timeout 900 python tools/bench_band.py > $OUT/band_compute_bound.json 2> $OUT/band.err; cat $OUT/band_compute_bound.json; tail -3 $OUT/band.err ;;
+    valurate)  hipcc --offload-arch=gfx950 -O3 -w -o /tmp/valu_rate tools/microbench/valu_rate.hip && timeout 120 /tmp/valu_rate | tee $OUT/valu_rate.jsonl ;;
+    whatif)    # sensitivity of k_trace to extra VALU work and to more resident waves (variants built beforehand on this host:
+               #   python gfxexp_amd/build.py --variant valu64 GFX_WHATIF_VALU=64 ; ... valu128 GFX_WHATIF_VALU=128 ;
+               #   ... occ5 GFX_TRACE_LDS_STACK=6 GFX_TRACE_MIN_WAVES=5 ; ... occ6 GFX_TRACE_LDS_STACK=4 GFX_TRACE_MIN_WAVES=6 ;
+               #   ... fastdiv -fno-hip-fp32-correctly-rounded-divide-sqrt   (approximate / and sqrtf: timing only, results differ))
+               : > $OUT/whatif.jsonl
+               Q="python bench.py --steps 20 --warmup 5 --mse-ref-spp 0 --cpu-sample 0"
+               run_v() { tag=$1; shift; echo "{\"variant\": \"$tag\"}" >> $OUT/whatif.jsonl; env "$@" timeout 300 $Q >> $OUT/whatif.jsonl 2>> $OUT/whatif.err; }
+               V=$PWD/gfxexp_amd/variants
+               run_v shipped GFX_NOOP=1
+               [ -f $V/libgfxexp_valu64.so ] && run_v valu64 GFX_LIB=$V/libgfxexp_valu64.so
+               [ -f $V/libgfxexp_valu128.so ] && run_v valu128 GFX_LIB=$V/libgfxexp_valu128.so
+               [ -f $V/libgfxexp_occ5.so ] && run_v occ5_stack6_4blocks GFX_LIB=$V/libgfxexp_occ5.so GFX_TRACE_BLOCKS_PER_CU=4
+               [ -f $V/libgfxexp_occ5.so ] && run_v occ5_stack6_5blocks GFX_LIB=$V/libgfxexp_occ5.so GFX_TRACE_BLOCKS_PER_CU=5
+               [ -f $V/libgfxexp_occ6.so ] && run_v occ6_stack4_4blocks GFX_LIB=$V/libgfxexp_occ6.so GFX_TRACE_BLOCKS_PER_CU=4
+               [ -f $V/libgfxexp_occ6.so ] && run_v occ6_stack4_6blocks GFX_LIB=$V/libgfxexp_occ6.so GFX_TRACE_BLOCKS_PER_CU=6
+               [ -f $V/libgfxexp_fastdiv.so ] && run_v fastdiv GFX_LIB=$V/libgfxexp_fastdiv.so
+               for n in 1 2 3 4 8 16 32; do [ -f $V/libgfxexp_init$n.so ] && run_v init_whatif_$n GFX_LIB=$V/libgfxexp_init$n.so; done   # GFX_WHATIF_INIT bit 0: no table search, coalesced records; bit 1: no BSDF evaluation; bit 2: real search, coalesced records; bit 3: no search, scattered records; bit 4: one guide load picks the record; bit 5: no material-texture reads in make_shading_point
+               python - <<'PY'
+import json
+for l in open("gpurun_out/r03/whatif.jsonl"):
+    d = json.loads(l)
+    if "variant" in d: print(d["variant"], end=": ")
+    else: print(d["ms_per_step"], d["kernels_ms_per_frame"])
+PY
+               ;;
     hbm)       timeout 300 python tools/hbm_stream.py > $OUT/hbm_stream.json 2> $OUT/hbm.err; cat $OUT/hbm_stream.json ;;
     *)         echo "unknown step $step" ;;
   esac
