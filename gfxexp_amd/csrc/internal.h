@@ -93,7 +93,6 @@ struct Tunables {
     int traceBlocksPerCU = 4;        // persistent traversal grid: blocks of 256 per CU (LDS: 4 x 40 KiB)
     int traceRefill = 8;             // refill a wave when at least this many lanes are idle
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
-    int noLdsMatrices = 0;           // 1: k_initial_candidates reads the emitter normal matrices from global memory even when they would fit LDS (tests)
 };
 
 struct Context {

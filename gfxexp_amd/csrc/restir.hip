@@ -175,7 +175,6 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
 // candidate loop + visibility-ray emission: optix_restir_di_kernels.cu:57-133
 // The light of a candidate comes out of the emitter interval table (emitter_spans.h): one guided search
 // instead of the reference's three nested ones, identical result.
-constexpr uint32_t kInitialMatrixLdsBytes = 22 * 1024;   // 4 blocks x (16 KB fetch buffers + this) = 152 KB of a CU's 160 KB: 625 matrices
 #ifndef GFX_INIT_WAVES   // experiment switch (tools/sessions): waves per SIMD the register allocation of the kernel targets
 #define GFX_INIT_WAVES 4
 #endif
@@ -184,16 +183,8 @@ constexpr uint32_t kInitialMatrixLdsBytes = 22 * 1024;   // 4 blocks x (16 KB fe
 // the kernel ran exactly at the CU's one-line-request-per-clock time (profiles/r03_experiments.txt).  The candidate loop is therefore
 // wave-uniform: lanes without a surface take part in the fetch and in nothing else.
 template <bool EMITTER_TEX>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a, uint32_t matricesInLds) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a) {
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];   // per wave: 256 x 16 B = 64 records
-    // the distinct normal matrices of the emitter instances, 9 floats each, when the host found that they fit (dynamic LDS)
-    extern __shared__ float ldsMatrices[];
-    const uint32_t numLdsMatrices = matricesInLds;
-    for (uint32_t k = threadIdx.x; k < numLdsMatrices * 9u; k += kBlock) {
-        const uint32_t m = k / 9u, e = k - 9u * m;
-        ldsMatrices[k] = a.scene.lightNormalMatrices[16u * m + 4u * (e / 3u) + (e % 3u)];
-    }
-    if (numLdsMatrices) __syncthreads();
     const int lane = threadIdx.x & 63;
     uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, kept scalar
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
@@ -255,11 +246,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
             if (!sampleEnv) { const SpanGuide g = a.scene.spanGuide[span_cell(ul, a.scene.spanGuideCells)]; pk.ok = true; pk.table = true; pk.rec = g.a & 0x7FFFFFFFu; pk.instSlot = 0; pk.density = 1.0f + ul; }
 #endif
         }
-        // ---- the wave gathers the records and the matrix rows
+        // ---- the wave gathers the records, then -- their flags name them -- the normal matrices
         const bool fetch = surface && !sampleEnv && pk.ok;
+        uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0, q2 = q0, q3 = q0;
+        m33 normalMatrix;
+        normalMatrix.r0 = normalMatrix.r1 = normalMatrix.r2 = f3(0.0f);
         if (__ballot(fetch) != 0ull) {
             coop_fetch64_issue(fetch ? pk.rec : kCoopNone, reinterpret_cast<const char*>(a.scene.emitterRecs), waveBuf, lane);
             coop_fetch64_wait();
+            if (fetch) coop_fetch64_read(waveBuf, lane, q0, q1, q2, q3);
+            // the matrix: three 16-byte loads per lane out of the deduplicated table.  Measured alternatives, all slower: a second
+            // cooperative round (+6 %: its wait cannot hide behind arithmetic the way these loads do); the table in LDS with one
+            // 16-wave block per CU (+5 %, 2 100 matrices: bank conflicts of the scattered reads and the coarser block granularity
+            // cost more than the saved L2 sector) -- profiles/r03_experiments.txt
+            if (fetch) normalMatrix = load_m33_rows(a.scene.lightNormalMatrices + 16u * emitter_matrix_index(q3.w));
         }
         // ---- the candidate itself
         if (surface) {
@@ -272,14 +272,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
             if (sampleEnv) sample_env_light(env, a.f.envLightRotation, a.f.envLightPowerCoeff, u0, u1, ls, pd);
             else if (pk.ok) {
                 GFX_PROF(1);
-                uint4 q0, q1, q2, q3;
-                coop_fetch64_read(waveBuf, lane, q0, q1, q2, q3);
-                m33 normalMatrix;
-                if (numLdsMatrices) {
-                    const float* mp = ldsMatrices + 9u * emitter_matrix_index(q3.w);
-                    normalMatrix.r0 = f3(mp[0], mp[1], mp[2]); normalMatrix.r1 = f3(mp[3], mp[4], mp[5]); normalMatrix.r2 = f3(mp[6], mp[7], mp[8]);
-                }
-                else normalMatrix = load_m33_rows(a.scene.lightNormalMatrices + 16u * emitter_matrix_index(q3.w));
                 light_from_record<EMITTER_TEX, false>(a.scene, pk, as_float4(q0), as_float4(q1), as_float4(q2), as_float4(q3), normalMatrix, u0, u1, ls, pd,
                                                       f3(0.0f), EMITTER_TEX ? &pending : nullptr);
             }
@@ -851,11 +843,8 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         {
             const uint32_t grid = a.px.launchBlocks;
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
-            // the emitter instances' distinct normal matrices ride in LDS when four blocks of them fit a CU next to the fetch buffers
-            const uint32_t inLds = (a.scene.numLightMatrices * 36u <= kInitialMatrixLdsBytes && !ctx.tune.noLdsMatrices) ? a.scene.numLightMatrices : 0u;
-            const size_t dyn = inLds * 36u;
-            if (a.scene.emitterTexRefs) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), dyn, stream, a, inLds);
-            else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), dyn, stream, a, inLds);
+            if (a.scene.emitterTexRefs) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);
             GFX_HIP(hipGetLastError());
         }
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);

@@ -39,9 +39,10 @@ struct PixelGrid {
     uint32_t launchBlocks;              // grid size (host side)
 };
 struct PixelId { size_t p; int x, y; uint32_t slot; bool valid; };
-GFX_DEV PixelId pixel_of_thread(const PixelGrid& g) {
+// Pixel of thread `tid` (0..255) of 256-thread block `block` of the launch; a block index past the launch owns no pixel.
+GFX_DEV PixelId pixel_of_block_thread(const PixelGrid& g, uint32_t block, uint32_t tid) {
     PixelId r;
-    r.slot = blockIdx.x * 256u + threadIdx.x;
+    r.slot = block * 256u + tid;
     if (g.mode == 0) {
         r.p = static_cast<size_t>(g.rowBegin) * g.width + r.slot;
         r.valid = r.p < static_cast<size_t>(g.rowEnd) * g.width;
@@ -49,16 +50,16 @@ GFX_DEV PixelId pixel_of_thread(const PixelGrid& g) {
         return r;
     }
     uint32_t bx, by;
-    if (g.mode == 1) { bx = blockIdx.x % g.blocksX; by = blockIdx.x / g.blocksX; }
+    if (g.mode == 1) { bx = block % g.blocksX; by = block / g.blocksX; }
     else {
-        const uint32_t xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        const uint32_t xcd = block & 7u, i = block >> 3;
         const uint32_t sh = g.superShiftX + g.superShiftY;
         const uint32_t super = ((i >> sh) << 3) | xcd, within = i & ((1u << sh) - 1u);
         const uint32_t sx = super % g.supersX, sy = super / g.supersX;   // sy beyond the last row of supertiles: by >= blocksY below
         bx = (sx << g.superShiftX) + (within & ((1u << g.superShiftX) - 1u));
         by = (sy << g.superShiftY) + (within >> g.superShiftX);
     }
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
     const uint32_t x = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t y = g.rowBegin + by * 16u + (wave >> 1) * 8u + (lane >> 3);
     r.valid = bx < g.blocksX && by < g.blocksY && x < g.width && y < g.rowEnd;
@@ -66,6 +67,8 @@ GFX_DEV PixelId pixel_of_thread(const PixelGrid& g) {
     r.p = r.valid ? static_cast<size_t>(y) * g.width + x : 0;
     return r;
 }
+
+GFX_DEV PixelId pixel_of_thread(const PixelGrid& g) { return pixel_of_block_thread(g, blockIdx.x, threadIdx.x); }
 
 // host side: the grid of a per-pixel launch over rows [rowBegin, rowEnd) (Context::pixelMap* = the mode, internal.h)
 inline PixelGrid make_pixel_grid(const Context& ctx, uint32_t width, uint32_t rowBegin, uint32_t rowEnd) {

@@ -116,8 +116,15 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
         }
         uint4 link = make_uint4(0u, 0u, 0u, 0u);
         if (code != kItemNone && !(code & kItemTri)) link = reinterpret_cast<const uint4*>(a.accel.links)[code];   // in flight with the item fetch
+#ifdef GFX_WHATIF_SECTOR   // sensitivity experiment: one more scattered 16-byte gather (a different 64-byte sector) per node visit
+        uint4 extra = make_uint4(0u, 0u, 0u, 0u);
+        if (code != kItemNone && !(code & kItemTri)) extra = reinterpret_cast<const uint4*>(a.accel.links)[(code * 2654435761u) % a.accel.numNodes];
+#endif
         uint4 q0, q1, q2, q3;
         fetch_items(code, a.accel, waveBuf, lane, q0, q1, q2, q3);
+#ifdef GFX_WHATIF_SECTOR
+        if ((extra.x ^ extra.y ^ extra.z ^ extra.w) == 0x12345677u) q3.x ^= 1u;   // never true in practice; keeps the load alive
+#endif
 #ifdef GFX_WHATIF_VALU   // sensitivity experiment: GFX_WHATIF_VALU extra dependent-free VALU instructions per wave iteration
         {
             float w0 = bits2f(q0.x), w1 = bits2f(q0.y), w2 = bits2f(q0.z), w3 = bits2f(q0.w);

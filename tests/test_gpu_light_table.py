@@ -42,15 +42,3 @@ def test_scene_without_emitters_keeps_the_search_path(built_lib):
     ctx.lights_build_instances()
     info = ctx.lights_table_info()
     assert info["records"] == 0 and info["usable"] == 0
-
-
-@pytest.mark.parametrize("no_lds", [0, 1])
-def test_candidate_pass_with_matrices_in_lds_and_in_global_memory(built_lib, monkeypatch, no_lds):
-    """k_initial_candidates keeps the distinct normal matrices of the emitter instances in LDS when they fit and reads them from
-    the deduplicated global table otherwise (gfx_tunable_set "no_lds_matrices" forces the latter): same frames either way,
-    on a street whose emitter instances are scaled and rotated (many distinct matrices) and with emittance maps."""
-    from tests.test_gpu_restir import run_sequence_both
-    monkeypatch.setenv("GFX_NO_LDS_MATRICES", str(no_lds))
-    with util.frame_overrides(enableBumpMapping=1):
-        diffs = run_sequence_both(util.small_street(textured=True), 160, 90, frames=2, renderer=api.RENDERER_BIASED, scene_kind="street")
-    assert not diffs, "\n".join(diffs)

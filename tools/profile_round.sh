@@ -20,6 +20,8 @@
 #                host: python gfxexp_amd/build.py --variant laneprof GFX_LANE_PROFILE)    -> profiles/r03_initial_candidates.txt
 #   renderers    tools/bench_renderers.py + tools/bench_config4.py                      -> profiles/r03_renderers.jsonl
 #   bands        tools/bench_band.py (compute-only bound of N row bands)                -> profiles/r03_band_compute_bound.json
+#   l2gather     tools/microbench/l2_gather.hip: scattered 64-byte sectors per second out of L2 / Infinity Cache / HBM by table size
+#                                                                                       -> profiles/r03_l2_gather.jsonl
 #   valurate     tools/microbench/valu_rate.hip: wave64 VALU issue rate per SIMD by instruction kind and resident waves
 #   whatif       k_trace with extra VALU work / more resident waves (experiment variants)  -> profiles/r03_experiments.txt
 #   hbm          tools/hbm_stream.py (streaming-copy ceiling of this box)               -> profiles/r03_hbm_stream.json
@@ -80,6 +82,7 @@ for step in "$@"; do
     renderers) timeout 900 python tools/bench_renderers.py > $OUT/renderers.jsonl 2> $OUT/renderers.err
                timeout 300 python tools/bench_config4.py >> $OUT/renderers.jsonl 2>> $OUT/renderers.err; cat $OUT/renderers.jsonl ;;
     bands)     timeout 900 python tools/bench_band.py > $OUT/band_compute_bound.json 2> $OUT/band.err; cat $OUT/band_compute_bound.json; tail -3 $OUT/band.err ;;
+    l2gather)  hipcc --offload-arch=gfx950 -O3 -w -o /tmp/l2_gather tools/microbench/l2_gather.hip && timeout 120 /tmp/l2_gather | tee $OUT/l2_gather.jsonl ;;
     valurate)  hipcc --offload-arch=gfx950 -O3 -w -o /tmp/valu_rate tools/microbench/valu_rate.hip && timeout 120 /tmp/valu_rate | tee $OUT/valu_rate.jsonl ;;
     whatif)    # sensitivity of k_trace to extra VALU work and to more resident waves (variants built beforehand on this host:
                #   python gfxexp_amd/build.py --variant valu64 GFX_WHATIF_VALU=64 ; ... valu128 GFX_WHATIF_VALU=128 ;
@@ -97,7 +100,8 @@ for step in "$@"; do
                [ -f $V/libgfxexp_occ6.so ] && run_v occ6_stack4_4blocks GFX_LIB=$V/libgfxexp_occ6.so GFX_TRACE_BLOCKS_PER_CU=4
                [ -f $V/libgfxexp_occ6.so ] && run_v occ6_stack4_6blocks GFX_LIB=$V/libgfxexp_occ6.so GFX_TRACE_BLOCKS_PER_CU=6
                [ -f $V/libgfxexp_fastdiv.so ] && run_v fastdiv GFX_LIB=$V/libgfxexp_fastdiv.so
-               for n in 1 2 3 4 8 16 32; do [ -f $V/libgfxexp_init$n.so ] && run_v init_whatif_$n GFX_LIB=$V/libgfxexp_init$n.so; done   # GFX_WHATIF_INIT bit 0: no table search, coalesced records; bit 1: no BSDF evaluation; bit 2: real search, coalesced records; bit 3: no search, scattered records; bit 4: one guide load picks the record; bit 5: no material-texture reads in make_shading_point
+               [ -f $V/libgfxexp_sector.so ] && run_v trace_one_more_sector_per_node GFX_LIB=$V/libgfxexp_sector.so
+               for n in 1 2 3 4 8 16 32 64 128 192; do [ -f $V/libgfxexp_init$n.so ] && run_v init_whatif_$n GFX_LIB=$V/libgfxexp_init$n.so; done   # GFX_WHATIF_INIT bit 0: no table search, coalesced records; bit 1: no BSDF evaluation; bit 2: real search, coalesced records; bit 3: no search, scattered records; bit 4: one guide load picks the record; bit 5: no material-texture reads in make_shading_point
                python - <<'PY'
 import json
 for l in open("gpurun_out/r03/whatif.jsonl"):
