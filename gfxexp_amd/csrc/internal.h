@@ -93,6 +93,7 @@ struct Tunables {
     int traceBlocksPerCU = 4;        // persistent traversal grid: blocks of 256 per CU (LDS: 4 x 40 KiB)
     int traceRefill = 8;             // refill a wave when at least this many lanes are idle
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
+    int temporalHints = 1;           // primary rays test the triangle their pixel hit one frame ago first (trace.hip)
 };
 
 struct Context {
@@ -193,6 +194,11 @@ void transforms_upload(Context& ctx, hipStream_t stream);   // moved instances o
 void lbvh_build(Context& ctx, hipStream_t stream, Accel& out);
 bool lbvh_update_dynamic(Context& ctx, hipStream_t stream, Accel& out);   // false: a full lbvh_build is needed
 // ---- trace.hip
+// The small per-context counter buffers (Context::smallCounters / gbCounters): bytes [0, 1024) hold the ray-queue counts of the passes
+// (restir.hip, pathtrace.hip), bytes [1024, 1024 + 4096) the ticket counters of k_trace (trace.hip).  Always reserved at full size,
+// so that no later reserve() moves it under a pointer a pass already holds.
+constexpr size_t kSmallCountersBytes = 1024 + 4096;
+constexpr size_t kSmallCountersTicketOffset = 1024;
 struct TraceLaunch {
     DevAccel accel;
     const float4* rayOrgTmin; const float4* rayDirTmax;
@@ -202,6 +208,8 @@ struct TraceLaunch {
     DevBuf* spill = nullptr;        // stack-spill area / ticket word; null = the context's shared ones
     DevBuf* counters = nullptr;
     uint32_t* perRayItems = nullptr; // counting launches: items fetched per ray
+    bool hintFromOut = false;       // closest-hit: out[] still holds the previous launch's results for the same rays (primary rays of
+                                    // the previous frame): each ray tests that triangle first (trace.hip)
 };
 void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t);
 // ---- textures.hip

@@ -1246,7 +1246,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     ctx.ptExtOrg.reserve(2 * 16 * bandPixels); ctx.ptExtDir.reserve(2 * 16 * bandPixels); ctx.ptExtOwner.reserve(2 * 4 * bandPixels);
     ctx.ptState.reserve(32 * numPixels);
     if (nrc) { ctx.nrcState.reserve(32 * numPixels); ctx.neeTrainIdx.reserve(4 * numPixels); }
-    ctx.smallCounters.reserve(256);
+    ctx.smallCounters.reserve(kSmallCountersBytes);
     uint32_t* counters = ctx.smallCounters.as<uint32_t>() + 8;   // [0] nee, [1] ext ping, [2] ext pong
     GFX_HIP(hipMemsetAsync(counters, 0, 3 * sizeof(uint32_t), stream));
 

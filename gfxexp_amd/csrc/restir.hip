@@ -713,7 +713,7 @@ static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint3
     ctx.pixelRaySlot.reserve(4 * numPixels);
     ctx.shadeScratch.reserve(32 * numPixels);
     ctx.spatialScratch.reserve(sizeof(SpatialSlot) * maxRays);
-    ctx.smallCounters.reserve(256);
+    ctx.smallCounters.reserve(kSmallCountersBytes);
     RestirArgs a;
     a.scene = ctx.devScene();
     a.s = rp.s; a.f = rp.f;
@@ -832,6 +832,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         t.numRays = numSlots; t.numRaysPtr = nullptr;
         t.out = ctx.gbRayHits.p; t.mode = GFX_TRACE_CLOSEST;
         t.spill = &ctx.gbSpill; t.counters = &ctx.gbCounters;
+        t.hintFromOut = true;   // gbRayHits keeps the previous frame's hit of every ray slot
         trace_launch(ctx, stream, t);
         launch_pixels(ctx, stream, "gbuffer_resolve", k_gbuffer_resolve, a);
         break;

@@ -14,6 +14,14 @@
 namespace gfx {
 
 constexpr int kTraceBlock = 256;
+// The ray queue is handed out in chunks of `ticketBatch` rays.  ONE device-scope counter for all chunks is a serial resource: atomics
+// on one address retire at ~13 ns each on MI355X whatever the grid does, so 2.07 M primary rays in chunks of 64 cost 0.42 ms of
+// atomics alone -- the floor every launch of rounds 1-3a sat on (tools/trace_tail.py: rays with an EMPTY interval took 0.418 ms,
+// the full closest-hit traversal 0.489).  Chunk j now belongs to counter j % kTicketCounters (each on its own 128-byte line): a
+// wave draws from "its" counter and moves on to the next one when that runs dry (a plain load first: only a wave that can
+// still get a chunk issues the atomic).
+constexpr uint32_t kTicketCounters = 32;
+constexpr uint32_t kTicketStride = 32;      // words between counters
 
 struct TraceArgs {
     DevAccel accel;
@@ -22,13 +30,14 @@ struct TraceArgs {
     const uint32_t* numRaysPtr;
     uint32_t numRays;
     void* out;
-    uint32_t* ticket;           // queue head (zeroed before the launch)
+    uint32_t* ticket;           // kTicketCounters queue heads, kTicketStride words apart (zeroed before the launch)
     uint2* spill;               // kSpillStackDepth entries per thread of the grid
     unsigned long long* counters; // optional: node fetches, triangle fetches, rays, spills
     uint32_t* perRayItems;        // optional (counting launches): items (nodes + triangle records) each ray fetched, indexed like the queue
     unsigned long long* diag;     // optional (counting launches): wave iterations, item-lanes, drain iterations, drain item-lanes
     int refillThreshold;        // refill when at least this many lanes are idle
     int ticketBatch;            // rays bought per device atomic
+    int hintFromOut;            // closest-hit launches: out[i].triIndex of the previous launch is ray i's first triangle to test
 };
 
 // fetch_items: coop_fetch.hip.h (the cooperative 64-byte gather; the candidate kernel of restir.hip uses it for emitter records).
@@ -55,6 +64,9 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     uint32_t rayIdx = 0;
     bool exhausted = false;           // wave-uniform: the queue has no more rays
     uint32_t waveNext = 0, waveEnd = 0; // wave-uniform: rays [waveNext, waveEnd) already ticketed for this wave
+    uint32_t myCounter = (blockIdx.x * (kTraceBlock / 64) + (tid >> 6)) % kTicketCounters;   // wave-uniform: the counter this wave draws from
+    uint32_t dryCounters = 0;         // wave-uniform: counters this wave has seen run dry
+    const uint32_t numChunks = (n + static_cast<uint32_t>(a.ticketBatch) - 1u) / static_cast<uint32_t>(a.ticketBatch);
     TraceCounters cnt = { 0, 0, 0 };
     uint32_t raysDone = 0, rayItems = 0;
     uint32_t diagIter = 0, diagLanes = 0, diagDrainIter = 0, diagDrainLanes = 0;   // wave-uniform (COUNT only)
@@ -75,11 +87,25 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             // wave-local ticket range: one device atomic buys a batch of rays, bought on demand
             // (buying ahead of need strands rays in waves that finish late; measured slower)
             if (waveNext == waveEnd) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.ticket, static_cast<uint32_t>(a.ticketBatch));
-                base = __shfl(base, 0);
-                if (base >= n) exhausted = true;
-                else { waveNext = base; waveEnd = min(base + static_cast<uint32_t>(a.ticketBatch), n); }
+                // counter c hands out chunks c, c + K, c + 2 K, ...
+                uint32_t chunk = 0xFFFFFFFFu, c = myCounter, dry = dryCounters;
+                if (lane == 0) {
+                    for (uint32_t attempt = 0; attempt < kTicketCounters && chunk == 0xFFFFFFFFu; ++attempt) {
+                        const uint32_t cc = (myCounter + attempt) % kTicketCounters;
+                        if (dry & (1u << cc)) continue;
+                        uint32_t* counter = a.ticket + cc * kTicketStride;
+                        const uint32_t seen = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (static_cast<uint64_t>(seen) * kTicketCounters + cc < numChunks) {
+                            const uint32_t t = atomicAdd(counter, 1u);
+                            const uint64_t j = static_cast<uint64_t>(t) * kTicketCounters + cc;
+                            if (j < numChunks) { chunk = static_cast<uint32_t>(j); c = cc; continue; }
+                        }
+                        dry |= 1u << cc;
+                    }
+                }
+                chunk = __shfl(chunk, 0); myCounter = __shfl(c, 0); dryCounters = __shfl(dry, 0);
+                if (chunk == 0xFFFFFFFFu) exhausted = true;
+                else { waveNext = chunk * static_cast<uint32_t>(a.ticketBatch); waveEnd = min(waveNext + static_cast<uint32_t>(a.ticketBatch), n); }
             }
             const uint32_t take = min(static_cast<uint32_t>(numIdle), waveEnd - waveNext);
             if (!tr.active) {
@@ -91,6 +117,14 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
                     rayIdx = i;
                     if (COUNT) rayItems = 0;
                     tr.begin(f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, d.w, stack, hasNodes);
+                    if (!ANY_HIT && a.hintFromOut) {
+                        // Temporal hint: the triangle this ray slot hit in the previous launch (the same pixel's primary ray one frame
+                        // ago) is tested first -- as the one pending "leaf" of a node that does not exist.  When it is hit again the
+                        // traversal starts with the right upper bound and skips everything behind it; the answer cannot change
+                        // (closest hit with the order-independent tie rule), a stale or garbage index costs one triangle test.
+                        const uint32_t h = static_cast<const gfx_hit*>(a.out)[i].triIndex;
+                        if (h < a.accel.numTris) { tr.triBase = h; tr.triMask = 0x0101u; }
+                    }
                     if (!hasNodes || !(d.w > o.w)) {   // empty interval or empty scene: immediate miss
                         tr.active = false;
                         write_result();
@@ -166,9 +200,10 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     DevBuf& spill = t.spill ? *t.spill : ctx.spill;
     DevBuf& small = t.counters ? *t.counters : ctx.smallCounters;
     spill.reserve(sizeof(uint2) * static_cast<size_t>(grid) * kTraceBlock * kSpillStackDepth);
-    small.reserve(256);
-    uint32_t* ticket = small.as<uint32_t>();
-    GFX_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream));
+    static_assert(sizeof(uint32_t) * kTicketCounters * kTicketStride <= kSmallCountersBytes - kSmallCountersTicketOffset, "ticket counters must fit");
+    small.reserve(kSmallCountersBytes);
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(static_cast<char*>(small.p) + kSmallCountersTicketOffset);
+    GFX_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t) * kTicketCounters * kTicketStride, stream));
     TraceArgs a;
     a.accel = t.accel;
     a.rayOrgTmin = t.rayOrgTmin; a.rayDirTmax = t.rayDirTmax;
@@ -182,6 +217,7 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
         if (!ctx.dTraceDiag.p) { ctx.dTraceDiag.reserve(64); GFX_HIP(hipMemsetAsync(ctx.dTraceDiag.p, 0, 64, stream)); }
         a.diag = ctx.dTraceDiag.as<unsigned long long>();
     }
+    a.hintFromOut = (t.hintFromOut && t.mode != GFX_TRACE_ANY && ctx.tune.temporalHints) ? 1 : 0;
     a.refillThreshold = ctx.tune.traceRefill;
     a.ticketBatch = ctx.tune.traceBatch;
     const bool any = t.mode == GFX_TRACE_ANY;
