@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
         store_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p, reservoir);
         static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes])[p] = make_float2(recPDF, selectedTarget);
     }
-    const uint32_t slot = queue_append_wave(wantRay, rayO, rayD, 0.0f, rayTmax, a.rayOrg, a.rayDir, a.rayCount);
+    const uint32_t slot = emit_ray_at_slot(px, wantRay, rayO, rayD, 0.0f, rayTmax, a);
     if (px.valid) a.pixelRaySlot[p] = slot;
 }
 
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
             }
         }
     }
-    const uint32_t slot = emit_ray(want, ro, rd, 0.0f, tmax, a);
+    const uint32_t slot = emit_ray_at_slot(px, want, ro, rd, 0.0f, tmax, a);
     if (px.valid) {
         a.shadeScratch[2 * p] = make_float4(contribution.x, contribution.y, contribution.z, bits2f(slot));
         a.shadeScratch[2 * p + 1] = make_float4(direct.x, direct.y, direct.z, recPDF);
@@ -706,7 +706,9 @@ static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint3
     const uint64_t h = rp.f.travHandle;
     if (h == 0 || h > ctx.accels.size() || !ctx.accels[h - 1]) throw HipError("gfx_restir_launch: invalid travHandle");
     const size_t numPixels = static_cast<size_t>(width) * height;
-    const size_t maxRays = numPixels * std::max<size_t>(1 + rp.f.numSpatialNeighbors, rearch ? kRearchRayKinds : 1);
+    // one entry per launch slot for the passes that do not compact their rays (emit_ray_at_slot): the tiled pixel maps pad the frame
+    const size_t frameSlots = static_cast<size_t>(make_pixel_grid(ctx, width, 0, height).launchBlocks) * kBlock;
+    const size_t maxRays = std::max(frameSlots, numPixels * std::max<size_t>(1 + rp.f.numSpatialNeighbors, rearch ? kRearchRayKinds : 1));
     ctx.rayOrg.reserve(16 * maxRays); ctx.rayDir.reserve(16 * maxRays);
     ctx.rayOut.reserve(4 * maxRays);
     ctx.rayHits.reserve(sizeof(gfx_hit) * numPixels);
@@ -840,7 +842,6 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     case GFX_RESTIR_INITIAL_RIS:
     case GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED:
     case GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED:
-        reset_queue();
         {
             const uint32_t grid = a.px.launchBlocks;
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
@@ -848,7 +849,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
             else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);
             GFX_HIP(hipGetLastError());
         }
-        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p);   // one entry per launch slot (emit_ray_at_slot)
         if (pass == GFX_RESTIR_INITIAL_RIS) launch_pixels(ctx, stream, "temporal_none", k_temporal<0>, a);
         else if (pass == GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED) launch_pixels(ctx, stream, "temporal_biased", k_temporal<1>, a);
         else launch_pixels(ctx, stream, "temporal_unbiased", k_temporal<2>, a);
@@ -863,9 +864,8 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         launch_pixels(ctx, stream, "spatial_unbiased_finish", k_spatial_mis_finish, a);
         break;
     case GFX_RESTIR_SHADING:
-        reset_queue();
         launch_pixels(ctx, stream, "shade_prepare", k_shade_prepare, a);
-        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p);   // one entry per launch slot (emit_ray_at_slot)
         launch_pixels(ctx, stream, "shade_finish", k_shade_finish, a);
         break;
     case GFX_RESTIR_LIGHT_PRESAMPLING: {

@@ -142,6 +142,16 @@ GFX_DEV void store_reservoir(void* buf, size_t numPixels, size_t p, const Reserv
 GFX_DEV uint32_t emit_ray(bool want, f3 org, f3 dir, float tmin, float tmax, const RestirArgs& a) {
     return queue_append(want, org, dir, tmin, tmax, a.rayOrg, a.rayDir, a.rayCount);
 }
+// For passes in which nearly every pixel has its one ray (the visibility ray of the selected candidate, the final shadow ray):
+// no compaction -- the ray of launch slot s sits at queue entry s, a thread without a ray writes an empty interval (k_trace
+// retires it at the fetch) and the trace runs over all launch slots.  A dense queue needs an atomic on its head per block or
+// wave, and atomics on one address retire at ~13 ns each: 0.1 ms per full-HD pass for 8 100 blocks, more than the kernel around
+// them (profiles/r03_experiments.txt).  EVERY thread of the launch must call it.
+GFX_DEV uint32_t emit_ray_at_slot(const PixelId& px, bool want, f3 org, f3 dir, float tmin, float tmax, const RestirArgs& a) {
+    a.rayOrg[px.slot] = make_float4(org.x, org.y, org.z, want ? tmin : 0.0f);
+    a.rayDir[px.slot] = make_float4(dir.x, dir.y, dir.z, want ? tmax : -1.0f);
+    return want ? px.slot : GFX_INVALID_SLOT;
+}
 
 // Shading point re-derived from the quantised G-buffer (every pass does this).
 struct ShadingPoint {
