@@ -300,7 +300,12 @@ def roofline(ctx, renderer, stream, steps, W, H):
             "frac_sah_normalised": frac_sah,
             "scheduling": {"wave_iterations": diag["iterations"], "lane_occupancy": round(diag["itemLanes"] / max(1, 64 * diag["iterations"]), 4),
                            "drain_iteration_share": round(diag["drainIterations"] / max(1, diag["iterations"]), 4),
-                           "drain_lane_occupancy": round(diag["drainItemLanes"] / max(1, 64 * diag["drainIterations"]), 4)},
+                           "drain_lane_occupancy": round(diag["drainItemLanes"] / max(1, 64 * diag["drainIterations"]), 4),
+                           # where the waves' clock cycles go in the counting launches (s_memtime around the sections of the loop)
+                           "wave_cycle_shares": {"ray_refill": round(diag["refillCycles"] / max(1, diag["waveCycles"]), 4),
+                                                 "item_fetch_wait": round(diag["fetchCycles"] / max(1, diag["waveCycles"]), 4),
+                                                 "item_processing": round(diag["processCycles"] / max(1, diag["waveCycles"]), 4)},
+                           "wave_cycles_per_iteration": round(diag["waveCycles"] / max(1, diag["iterations"]), 1)},
             "algorithmic_bytes_per_launch": int(bytes_frame / max(trav_launches, 1)),
             "avg_launch_ms": round(trav_ms / max(trav_launches, 1), 4),
             "per_frame": {"node_fetches": int(c["nodeFetches"]), "tri_fetches": int(c["triFetches"]), "rays": int(c["rays"]),

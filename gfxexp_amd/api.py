@@ -671,7 +671,8 @@ class Context:
     def trace_diag_read(self, reset=True):
         c = (C.c_uint64 * 8)()
         self._check(self.L.gfx_trace_diag_read(self.h, c, C.c_int(1 if reset else 0)))
-        return dict(iterations=c[0], itemLanes=c[1], drainIterations=c[2], drainItemLanes=c[3])
+        return dict(iterations=c[0], itemLanes=c[1], drainIterations=c[2], drainItemLanes=c[3],
+                    waveCycles=c[4], refillCycles=c[5], fetchCycles=c[6], processCycles=c[7])
 
     def counters_read(self, reset=True):
         c = (C.c_uint64 * 8)()

@@ -70,6 +70,10 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     TraceCounters cnt = { 0, 0, 0 };
     uint32_t raysDone = 0, rayItems = 0;
     uint32_t diagIter = 0, diagLanes = 0, diagDrainIter = 0, diagDrainLanes = 0;   // wave-uniform (COUNT only)
+    // COUNT only: where a wave's clock cycles go (s_memtime): ray refill (ticket + ray loads + setup), item fetch (issue to data in
+    // registers), item processing (slab / triangle tests); the rest is item selection and loop overhead
+    unsigned long long cycRefill = 0, cycFetch = 0, cycProcess = 0;
+    const unsigned long long cycStart = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
 
     auto write_result = [&]() {
         if (ANY_HIT) static_cast<uint32_t*>(a.out)[rayIdx] = tr.hit.tri != GFX_INVALID_SLOT ? 1u : 0u;
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     };
 
     while (true) {
+        const unsigned long long cyc0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         const unsigned long long idleMask = __ballot(!tr.active);
         const int numIdle = __popcll(idleMask);
         if (!exhausted && numIdle >= a.refillThreshold) {
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             }
             waveNext += take;
         }
+        if (COUNT) cycRefill += __builtin_amdgcn_s_memtime() - cyc0;
         if (__ballot(tr.active) == 0ull) {
             if (exhausted) break;
             continue;
@@ -155,7 +161,10 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
         if (code != kItemNone && !(code & kItemTri)) extra = reinterpret_cast<const uint4*>(a.accel.links)[(code * 2654435761u) % a.accel.numNodes];
 #endif
         uint4 q0, q1, q2, q3;
+        const unsigned long long cyc1 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         fetch_items(code, a.accel, waveBuf, lane, q0, q1, q2, q3);
+        if (COUNT) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); cycFetch += __builtin_amdgcn_s_memtime() - cyc1; }
+        const unsigned long long cyc2 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
 #ifdef GFX_WHATIF_SECTOR
         if ((extra.x ^ extra.y ^ extra.z ^ extra.w) == 0x12345677u) q3.x ^= 1u;   // never true in practice; keeps the load alive
 #endif
@@ -175,10 +184,13 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             }
             else tr.template process_node<COUNT>(q0, q1, q2, q3, link, stack, cnt);
         }
+        if (COUNT) cycProcess += __builtin_amdgcn_s_memtime() - cyc2;
     }
     if (COUNT && a.diag && lane == 0) {
         atomicAdd(a.diag + 0, static_cast<unsigned long long>(diagIter)); atomicAdd(a.diag + 1, static_cast<unsigned long long>(diagLanes));
         atomicAdd(a.diag + 2, static_cast<unsigned long long>(diagDrainIter)); atomicAdd(a.diag + 3, static_cast<unsigned long long>(diagDrainLanes));
+        atomicAdd(a.diag + 4, __builtin_amdgcn_s_memtime() - cycStart); atomicAdd(a.diag + 5, cycRefill);
+        atomicAdd(a.diag + 6, cycFetch); atomicAdd(a.diag + 7, cycProcess);
     }
     if (COUNT && a.counters) {
         // wave-level reduction, one atomic per wave and counter

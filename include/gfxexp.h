@@ -489,7 +489,9 @@ int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value);
 int gfx_counters_enable(gfx_ctx* ctx, int enable);
 int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[8], int reset);
 /* Scheduling diagnostics of the counting trace launches: [0] wave iterations, [1] lanes that held an
- * item summed over iterations, [2] / [3] the same after the ray queue ran dry (drain phase). */
+ * item summed over iterations, [2] / [3] the same after the ray queue ran dry (drain phase), [4] clock cycles summed over
+ * the waves, of which [5] in the ray refill (ticket, ray loads, setup), [6] waiting for the item fetch, [7] processing
+ * items (the rest: item selection, loop overhead). */
 int gfx_trace_diag_read(gfx_ctx* ctx, uint64_t diag[8], int reset);
 
 #ifdef __cplusplus
