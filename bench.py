@@ -45,6 +45,16 @@ def _profile_value(name, key):
         return None
 
 
+def _profile_lines(name):
+    """Non-empty lines of a JSON-lines file committed under profiles/ ([] when missing)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    try:
+        with open(path) as f:
+            return [l for l in f if l.strip().startswith("{")]
+    except OSError:
+        return []
+
+
 def _profiled_traffic():
     """HBM bytes per traversal launch from the PMC passes (newest round first)."""
     for name in ("r03_pmc.json", "r02_traffic.json", "r01_traffic.json"):
@@ -312,12 +322,26 @@ def roofline(ctx, renderer, stream, steps, W, H):
                           "stack_spills": int(c["spills"])}}
     init_ms = timings.get("initial_candidates", (0.0, 0))[0] / n
     if init_ms > 0:
-        cand_bytes = W * H * (32 * (16 + 64 + 48) + 64 + 72)
-        ic = pmc.get("k_initial_candidates")
-        roof["initial_candidates"] = {"bound": "valu (nominal hbm: gather volume, L2 hit 99 %)", "valu": ({"busy": ic["valu_busy"], "lane_fraction": ic["lane_fraction"]} if ic else None), "kernel": "k_initial_candidates (32 streaming-RIS candidates per pixel)",
-                                      "ms": round(init_ms, 4), "algorithmic_bytes_per_launch": cand_bytes,
-                                      "achieved": round(cand_bytes / (init_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(cand_bytes / (init_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # The candidate pass gathers from ~3.4 MB of L2-resident tables: what bounds it is the rate at which the L2s hand scattered
+        # 64-byte sectors to the CUs (tools/microbench/l2_gather.hip -> profiles/r03_l2_gather.jsonl: 218-243 G sectors/s out of a
+        # 4-MB table, whatever the access shape), not HBM and not arithmetic (profiles/r03_experiments.txt: approximate division, -30 %
+        # instructions, bought 1.5 %).  Per candidate: one guide cell (8 B), one emitter record (64 B), one normal matrix (48 B);
+        # a lookup that lands in a boundary cell of the guide also reads one or two 16-byte spans.
+        lt = ctx.lights_table_info()
+        boundary = 1.0 - lt["interior_cells"] / max(1, lt["cells"])
+        cand_bytes = W * H * (32 * (8 + 64 + 48 + boundary * 16) + 64 + 72)
+        cand_sectors = W * H * (32 * (3 + boundary * 1.25) + 3)
+        l2 = [json.loads(l) for l in _profile_lines("r03_l2_gather.jsonl")]
+        l2_peak = [r["Gsectors_per_s"] for r in l2 if abs(r.get("table_MB", 0) - 4.0) < 1e-6]
+        l2_peak = sum(l2_peak) / len(l2_peak) if l2_peak else None
+        ach = cand_sectors / (init_ms * 1e-3) / 1e9
+        roof["initial_candidates"] = {"bound": "l2-gather (64-byte sectors out of L2-resident tables)", "kernel": "k_initial_candidates (32 streaming-RIS candidates per pixel)",
+                                      "ms": round(init_ms, 4), "algorithmic_bytes_per_launch": int(cand_bytes), "sectors_per_launch": int(cand_sectors),
+                                      "guide_boundary_fraction": round(boundary, 4),
+                                      "achieved": round(ach * 64, 1), "peak": round(l2_peak * 64, 1) if l2_peak else None, "unit": "GB/s",
+                                      "frac": round(ach / l2_peak, 4) if l2_peak else None,
+                                      "peak_source": "profiles/r03_l2_gather.jsonl: mean of the three access shapes at a 4-MB table, G sectors/s x 64 B",
+                                      "frac_of_hbm_peak_nominal": round(cand_bytes / (init_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     return roof, per_frame
 
 
