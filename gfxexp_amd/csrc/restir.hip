@@ -845,7 +845,8 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         {
             const uint32_t grid = a.px.launchBlocks;
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
-            if (a.scene.emitterTexRefs) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), 0, stream, a);
+            static const bool whatifNoTex = getenv("GFX_WHATIF_NO_EMITTER_TEX") != nullptr;   // timing experiment only (results differ)
+            if (a.scene.emitterTexRefs && !whatifNoTex) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);
             GFX_HIP(hipGetLastError());
         }
