@@ -85,3 +85,38 @@ def test_tunable_set_rejects_unknown_names_and_values(built_lib):
         ctx.tunable_set("pixel_map", 3)
     with pytest.raises(api.GfxError):
         ctx.tunable_set("no_such_knob", 1)
+
+
+@pytest.mark.gpu
+def test_temporal_hints_change_the_work_not_the_frames(built_lib, monkeypatch):
+    """gfx_tunable_set "temporal_hints" (trace.hip): a pixel's primary ray first tests the triangle it hit one frame ago.  With the
+    hints off every buffer still equals the oracle's (the default -- on -- is what every other multi-frame test runs); with them on
+    the second frame of a static camera fetches fewer nodes for its primary rays, the first frame the same number."""
+    import torch
+    monkeypatch.setenv("GFX_TEMPORAL_HINTS", "0")
+    diffs = run_sequence_both(util.bunny_scene(), 150, 91, frames=2, renderer=api.RENDERER_BIASED)
+    assert not diffs, "\n".join(diffs)
+    monkeypatch.delenv("GFX_TEMPORAL_HINTS")
+    monkeypatch.setenv("GFX_SERIAL_FRAMES", "1")   # one frame's passes per render_frame call: the counters below are per frame
+    fetched = {}
+    for hints in (0, 1):
+        ctx = api.Context(0)
+        ctx.tunable_set("temporal_hints", hints)
+        hs = util.small_street()
+        hs.upload(ctx)
+        cfg = api.RestirRenderer.default_config(320, 180, api.RENDERER_BIASED)
+        cfg.camera = api.make_camera(320, 180, pos=(2.0, 5.0, 26.0), pitch=4.0, yaw=180.0)
+        r = api.RestirRenderer(ctx, cfg)
+        ctx.counters_enable(True)
+        per_frame = []
+        for _ in range(3):
+            ctx.counters_read(reset=True)
+            r.render_frame()
+            torch.cuda.synchronize()
+            per_frame.append(ctx.counters_read(reset=True)["closest"]["nodeFetches"])
+        fetched[hints] = per_frame
+        beauty = ctx.read_device(r.beauty_ptr(), 320 * 180 * 16).copy()
+        fetched[("beauty", hints)] = beauty
+    assert fetched[0][0] == fetched[1][0], fetched                     # nothing to hint at in the first frame
+    assert fetched[1][1] < 0.95 * fetched[0][1], fetched               # the second frame starts every ray at last frame's triangle
+    assert (fetched[("beauty", 0)] == fetched[("beauty", 1)]).all()    # same frames, bit for bit
