@@ -137,6 +137,9 @@ struct Context {
     // instance interval starts uint32[numInsts + 1] (build scratch)
     DevBuf dSpans, dSpanGuide, dSpanHeader, dSpanInstBegin;
     uint32_t spanGuideCells = 0;
+    // ticket areas of k_trace per counter buffer ([0] smallCounters, [1] any other): which of the two areas the next launch draws from
+    // (the launch before it zeroed that one), and whether both have been zeroed once
+    struct TicketState { bool zeroed = false; uint32_t next = 0; void* buffer = nullptr; } ticketState[2];
     uint32_t numLightMatrices = 0;   // distinct normal matrices of the emitter instances (scene.cpp light_matrices_upload)
     DevScene devScene() const;
     // accels
@@ -195,9 +198,9 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out);
 bool lbvh_update_dynamic(Context& ctx, hipStream_t stream, Accel& out);   // false: a full lbvh_build is needed
 // ---- trace.hip
 // The small per-context counter buffers (Context::smallCounters / gbCounters): bytes [0, 1024) hold the ray-queue counts of the passes
-// (restir.hip, pathtrace.hip), bytes [1024, 1024 + 4096) the ticket counters of k_trace (trace.hip).  Always reserved at full size,
+// (restir.hip, pathtrace.hip), bytes [1024, 1024 + 2 x 4096) the two ticket-counter areas of k_trace (trace.hip: a launch draws from one and zeroes the other for the next launch).  Always reserved at full size,
 // so that no later reserve() moves it under a pointer a pass already holds.
-constexpr size_t kSmallCountersBytes = 1024 + 4096;
+constexpr size_t kSmallCountersBytes = 1024 + 2 * 4096;
 constexpr size_t kSmallCountersTicketOffset = 1024;
 struct TraceLaunch {
     DevAccel accel;

@@ -30,7 +30,8 @@ struct TraceArgs {
     const uint32_t* numRaysPtr;
     uint32_t numRays;
     void* out;
-    uint32_t* ticket;           // kTicketCounters queue heads, kTicketStride words apart (zeroed before the launch)
+    uint32_t* ticket;           // kTicketCounters queue heads, kTicketStride words apart (zero at the start of the launch)
+    uint32_t* ticketNext;       // the area the NEXT launch on this buffer draws from: block 0 zeroes it
     uint2* spill;               // kSpillStackDepth entries per thread of the grid
     unsigned long long* counters; // optional: node fetches, triangle fetches, rays, spills
     uint32_t* perRayItems;        // optional (counting launches): items (nodes + triangle records) each ray fetched, indexed like the queue
@@ -56,6 +57,8 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     stack.ldsStride = kTraceBlock;
     stack.spill = a.spill + (static_cast<size_t>(blockIdx.x) * kTraceBlock + tid) * kSpillStackDepth;
     stack.sp = 0;
+    // the other ticket area belongs to the next launch (stream order: nobody reads it while this kernel runs)
+    if (blockIdx.x == 0 && tid < static_cast<int>(kTicketCounters)) a.ticketNext[tid * kTicketStride] = 0u;
     const uint32_t n = a.numRaysPtr ? *a.numRaysPtr : a.numRays;
     const bool hasNodes = a.accel.numNodes != 0;
 
@@ -212,15 +215,25 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     DevBuf& spill = t.spill ? *t.spill : ctx.spill;
     DevBuf& small = t.counters ? *t.counters : ctx.smallCounters;
     spill.reserve(sizeof(uint2) * static_cast<size_t>(grid) * kTraceBlock * kSpillStackDepth);
-    static_assert(sizeof(uint32_t) * kTicketCounters * kTicketStride <= kSmallCountersBytes - kSmallCountersTicketOffset, "ticket counters must fit");
+    constexpr size_t kTicketAreaBytes = sizeof(uint32_t) * kTicketCounters * kTicketStride;
+    static_assert(2 * kTicketAreaBytes <= kSmallCountersBytes - kSmallCountersTicketOffset, "two ticket areas must fit");
     small.reserve(kSmallCountersBytes);
-    uint32_t* ticket = reinterpret_cast<uint32_t*>(static_cast<char*>(small.p) + kSmallCountersTicketOffset);
-    GFX_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t) * kTicketCounters * kTicketStride, stream));
+    // Two ticket areas per counter buffer: a launch draws from one and its block 0 zeroes the other, which the next launch on this
+    // buffer (same stream by construction: the pipelined G-buffer pass has its own buffer) then finds zero -- no memset per launch.
+    Context::TicketState& ts = ctx.ticketState[&small == &ctx.smallCounters ? 0 : 1];
+    char* areas = static_cast<char*>(small.p) + kSmallCountersTicketOffset;
+    if (!ts.zeroed || ts.buffer != small.p) {
+        GFX_HIP(hipMemsetAsync(areas, 0, 2 * kTicketAreaBytes, stream));
+        ts.zeroed = true; ts.next = 0; ts.buffer = small.p;
+    }
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(areas + ts.next * kTicketAreaBytes);
+    uint32_t* ticketNext = reinterpret_cast<uint32_t*>(areas + (ts.next ^ 1u) * kTicketAreaBytes);
+    ts.next ^= 1u;
     TraceArgs a;
     a.accel = t.accel;
     a.rayOrgTmin = t.rayOrgTmin; a.rayDirTmax = t.rayDirTmax;
     a.numRaysPtr = t.numRaysPtr; a.numRays = t.numRays;
-    a.out = t.out; a.ticket = ticket; a.spill = spill.as<uint2>();
+    a.out = t.out; a.ticket = ticket; a.ticketNext = ticketNext; a.spill = spill.as<uint2>();
     // the context's own counters keep any-hit launches in [0..3] and closest-hit launches in [4..7]
     a.counters = ctx.countersEnabled ? ctx.dTraceCounters.as<unsigned long long>() + ((ctx.countersSplit && t.mode != GFX_TRACE_ANY) ? 4 : 0) : nullptr;
     a.diag = nullptr;
