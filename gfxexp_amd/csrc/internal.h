@@ -211,6 +211,8 @@ struct TraceLaunch {
     DevBuf* spill = nullptr;        // stack-spill area / ticket word; null = the context's shared ones
     DevBuf* counters = nullptr;
     uint32_t* perRayItems = nullptr; // counting launches: items fetched per ray
+    uint32_t* zeroWords[2] = { nullptr, nullptr };   // device words the launch sets to zero (queue heads the NEXT pass appends to:
+                                    // saves the path tracers two memsets per bounce); must not be this launch's own count
     bool hintFromOut = false;       // closest-hit: out[] still holds the previous launch's results for the same rays (primary rays of
                                     // the previous frame): each ray tests that triangle first (trace.hip)
 };

@@ -1277,9 +1277,10 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         hipLaunchKernelGGL(kernel, dim3(a.px.launchBlocks), dim3(kPtBlock), 0, stream, a);
         GFX_HIP(hipGetLastError());
     };
-    auto trace = [&](int mode, const float4* org, const float4* dir, const uint32_t* count, void* out) {
+    auto trace = [&](int mode, const float4* org, const float4* dir, const uint32_t* count, void* out, uint32_t* zero0 = nullptr, uint32_t* zero1 = nullptr) {
         TraceLaunch t;
         t.accel = accel; t.rayOrgTmin = org; t.rayDirTmax = dir; t.numRays = 0; t.numRaysPtr = count; t.out = out; t.mode = mode;
+        t.zeroWords[0] = zero0; t.zeroWords[1] = zero1;
         trace_launch(ctx, stream, t);
     };
 
@@ -1308,9 +1309,9 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
             GFX_HIP(hipStreamSynchronize(stream));
             if (live == 0) break;
         }
-        trace(GFX_TRACE_CLOSEST, extOrg[cur], extDir[cur], counters + 1 + cur, ctx.rayHits.p);
-        GFX_HIP(hipMemsetAsync(counters, 0, sizeof(uint32_t), stream));
-        GFX_HIP(hipMemsetAsync(counters + 1 + (cur ^ 1), 0, sizeof(uint32_t), stream));
+        // the extension trace also resets the two queue heads the bounce kernel appends to (the NEE queue, already consumed by
+        // k_pt_apply_nee, and the other extension queue): no memset between the kernels of a bounce
+        trace(GFX_TRACE_CLOSEST, extOrg[cur], extDir[cur], counters + 1 + cur, ctx.rayHits.p, counters, counters + 1 + (cur ^ 1));
         set_queues(cur, cur ^ 1);
         a.pathLength = pathLength;
         a.maxLengthTerminate = (pathLength >= maxPathLength && (!nrc || maxPathLength > 0)) ? 1u : 0u;

@@ -32,6 +32,7 @@ struct TraceArgs {
     void* out;
     uint32_t* ticket;           // kTicketCounters queue heads, kTicketStride words apart (zero at the start of the launch)
     uint32_t* ticketNext;       // the area the NEXT launch on this buffer draws from: block 0 zeroes it
+    uint32_t* zeroWords[2];     // optional: words block 0 sets to zero (TraceLaunch::zeroWords)
     uint2* spill;               // kSpillStackDepth entries per thread of the grid
     unsigned long long* counters; // optional: node fetches, triangle fetches, rays, spills
     uint32_t* perRayItems;        // optional (counting launches): items (nodes + triangle records) each ray fetched, indexed like the queue
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     stack.sp = 0;
     // the other ticket area belongs to the next launch (stream order: nobody reads it while this kernel runs)
     if (blockIdx.x == 0 && tid < static_cast<int>(kTicketCounters)) a.ticketNext[tid * kTicketStride] = 0u;
+    if (blockIdx.x == 0 && tid < 2 && a.zeroWords[tid]) *a.zeroWords[tid] = 0u;
     const uint32_t n = a.numRaysPtr ? *a.numRaysPtr : a.numRays;
     const bool hasNodes = a.accel.numNodes != 0;
 
@@ -234,6 +236,7 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     a.rayOrgTmin = t.rayOrgTmin; a.rayDirTmax = t.rayDirTmax;
     a.numRaysPtr = t.numRaysPtr; a.numRays = t.numRays;
     a.out = t.out; a.ticket = ticket; a.ticketNext = ticketNext; a.spill = spill.as<uint2>();
+    a.zeroWords[0] = t.zeroWords[0]; a.zeroWords[1] = t.zeroWords[1];
     // the context's own counters keep any-hit launches in [0..3] and closest-hit launches in [4..7]
     a.counters = ctx.countersEnabled ? ctx.dTraceCounters.as<unsigned long long>() + ((ctx.countersSplit && t.mode != GFX_TRACE_ANY) ? 4 : 0) : nullptr;
     a.diag = nullptr;
