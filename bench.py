@@ -98,6 +98,9 @@ def parse():
     ap.add_argument("--mse-ref-spp", type=int, default=65536, help="frames of plain-NEE reference accumulated in fp64 for the MSE figure; the metric names 64k (0 = skip)")
     ap.add_argument("--cpu-sample", type=str, default="480x270", help="resolution of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--balance-bands", type=int, default=0,
+                    help="N > 1 with the torch.distributed exchange: rounds of cost-balancing the row bands during the warm-up (each round: "
+                         "4 frames, all-gather of the ranks' frame times, gfxh_balance_bands, band renderers re-created); 0 = equal bands")
     ap.add_argument("--plain", action="store_true", help="constant-colour materials (the round-1 workload) instead of the textured street")
     ap.add_argument("--exchange", default="torch", choices=["torch", "rccl"],
                     help="N > 1: strip-exchange callback -- tilesplit.StripExchange over torch.distributed (default) or the C++ gfxh_rccl_exchange")
@@ -137,6 +140,7 @@ def main():
     cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
     cfg.camera = cam
     cfg.enableBumpMapping = int(textured and args.bump)
+    bands = tilesplit.band_rows(H, world) if world > 1 else None
     band = tilesplit.band_for_rank(H, world, rank)
     cfg.rowBegin, cfg.rowEnd = band
     renderer = api.RestirRenderer(ctx, cfg)
@@ -174,6 +178,32 @@ def main():
         else:
             exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda", async_gather=True)
             renderer.set_exchange(exchange, 0)             # static camera and scene: no motion rows
+            # Equal rows are not equal work (sky rows are cheap).  Each round: time this rank's band over a few frames, all-gather
+            # the times, cut the frame where gfxh_balance_bands says (the same call with the same numbers on every rank) and start
+            # over with band renderers for the new rows -- all inside the untimed warm-up; the timed frames use the final partition.
+            for _ in range(max(0, args.balance_bands)):
+                for _ in range(2):
+                    renderer.render_frame(stream)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(4):
+                    renderer.render_frame(stream)
+                e1.record()
+                torch.cuda.synchronize()
+                mine = torch.tensor([e0.elapsed_time(e1) / 4], dtype=torch.float32, device="cuda")
+                times = torch.zeros(world, dtype=torch.float32, device="cuda")
+                dist.all_gather_into_tensor(times, mine)
+                new_bands = api.balance_bands(H, bands, [float(t) for t in times.cpu()], min_rows=24)
+                exchange.finish()
+                if new_bands == bands:
+                    break
+                bands = new_bands
+                renderer.close()
+                cfg.rowBegin, cfg.rowEnd = bands[rank]
+                renderer = api.RestirRenderer(ctx, cfg)
+                exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda", async_gather=True, bands=bands)
+                renderer.set_exchange(exchange, 0)
 
     def frame():
         renderer.render_frame(stream)
@@ -215,6 +245,7 @@ def main():
                                + ("+ trees of leaf cards, cables and railings (depth-complexity variant), " if args.cluttered else "")
                                + "32 candidates, temporal + 2x5 spatial reuse, radius 20, visibility reuse",
                    "width": W, "height": H, "spp": 1, "parallelism": f"row-bands x{world}" if world > 1 else "single GPU",
+                   "bands": bands,
                    "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]},
                    "light_table": ctx.lights_table_info()},
         "setup_s": round(setup_s, 2),

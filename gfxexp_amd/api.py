@@ -194,6 +194,25 @@ def check_partition(cfg, world, max_motion_rows=0):
         raise GfxError(lib().gfxh_restir_last_error().decode())
 
 
+def check_bands(cfg, bands, max_motion_rows=0):
+    """gfxh_restir_check_bands: the strip-feasibility verdict for an explicit partition [(begin, end)] (cost-balanced bands)."""
+    begins = (C.c_uint32 * (len(bands) + 1))(*([b for b, _ in bands] + [bands[-1][1]]))
+    if lib().gfxh_restir_check_bands(C.byref(cfg), C.c_uint32(len(bands)), begins, C.c_uint32(max_motion_rows)):
+        raise GfxError(lib().gfxh_restir_last_error().decode())
+
+
+def balance_bands(height, bands, band_ms, min_rows=8):
+    """gfxh_balance_bands: the partition that would have equalised the band times `band_ms` measured with `bands`
+    ([(begin, end)] per rank; every rank must pass the same numbers).  Returns the new [(begin, end)]."""
+    world = len(bands)
+    begins = (C.c_uint32 * (world + 1))(*([b for b, _ in bands] + [bands[-1][1]]))
+    ms = (C.c_float * world)(*[float(t) for t in band_ms])
+    out = (C.c_uint32 * (world + 1))()
+    if lib().gfxh_balance_bands(C.c_uint32(height), C.c_uint32(world), begins, ms, C.c_uint32(min_rows), out):
+        raise GfxError("gfxh_balance_bands: invalid partition or times")
+    return [(int(out[r]), int(out[r + 1])) for r in range(world)]
+
+
 def strip_rows(height, band_begin, band_end, rows):
     d = GfxhExchangeDesc()
     rc = lib().gfxh_strip_rows(C.c_uint32(height), C.c_uint32(band_begin), C.c_uint32(band_end), C.c_uint32(rows), C.byref(d))
@@ -237,7 +256,7 @@ HOST_ABI_SYMBOLS = [
     "gfxh_scene_get_material", "gfxh_scene_get_geom", "gfxh_scene_get_group", "gfxh_scene_get_instance",
     "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
     "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
-    "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_band_rows", "gfxh_restir_check_partition", "gfxh_restir_frame_program", "gfxh_frame_step_exchange_desc",
+    "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_band_rows", "gfxh_restir_check_partition", "gfxh_restir_check_bands", "gfxh_balance_bands", "gfxh_restir_frame_program", "gfxh_frame_step_exchange_desc",
     "gfxh_rccl_unique_id", "gfxh_rccl_create", "gfxh_rccl_destroy", "gfxh_rccl_exchange", "gfxh_rccl_last_error", "gfxh_restir_create",
     "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
@@ -843,7 +862,10 @@ class RestirRenderer:
         A callback that knows its world size (tilesplit.StripExchange) gets the partition checked here, on every rank
         alike (gfxh_restir_check_partition)."""
         world = getattr(fn, "world", None)
-        if world:
+        bands = getattr(fn, "custom_bands", None)
+        if bands:
+            check_bands(self.cfg, bands, max_motion_rows)
+        elif world:
             check_partition(self.cfg, int(world), max_motion_rows)
 
         def thunk(user, stream, desc):

@@ -278,6 +278,71 @@ int gfxh_restir_check_partition(const gfxh_restir_config* cfgp, uint32_t world, 
     return 0;
 }
 
+static uint32_t tallest_strip(const gfxh_restir_config* cfgp, uint32_t firstBandEnd, uint32_t maxMotionRows) {
+    gfxh_restir_config cfg = *cfgp;
+    cfg.rowBegin = 0; cfg.rowEnd = firstBandEnd;   // any band will do: the program's exchange rows do not depend on where the band lies
+    const uint32_t unbiased = cfg.renderer == GFXH_ORIGINAL_RESTIR_UNBIASED || cfg.renderer == GFXH_REARCHITECTED_RESTIR_UNBIASED;
+    uint32_t tallest = 0;
+    for (int newSequence = 0; newSequence < 2; ++newSequence) {
+        gfxh_frame_step steps[64];
+        uint32_t n = 0, a = 0, c = 0;
+        (void)gfxh_restir_frame_program(&cfg, 1, maxMotionRows, newSequence, 1, 0, unbiased, steps, 64, &n, &a, &c);
+        for (uint32_t k = 0; k < n; ++k) if (steps[k].op == GFXH_STEP_EXCHANGE_STRIPS) tallest = std::max(tallest, steps[k].exchangeRows);
+    }
+    return tallest;
+}
+
+int gfxh_restir_check_bands(const gfxh_restir_config* cfgp, uint32_t world, const uint32_t* bandBegin, uint32_t maxMotionRows) {
+    if (world <= 1) return 0;
+    if (!bandBegin || bandBegin[0] != 0 || bandBegin[world] != cfgp->height) { g_driverError = "gfxh_restir_check_bands: the partition must run from row 0 to the image height"; return 1; }
+    uint32_t minBand = 0xFFFFFFFFu;
+    for (uint32_t r = 0; r < world; ++r) {
+        if (bandBegin[r + 1] <= bandBegin[r] || (r + 1 < world && bandBegin[r + 1] % 8u != 0)) {
+            g_driverError = "gfxh_restir_check_bands: band boundaries must ascend on whole 8-row tiles";
+            return 1;
+        }
+        minBand = std::min(minBand, bandBegin[r + 1] - bandBegin[r]);
+    }
+    const uint32_t tallest = tallest_strip(cfgp, bandBegin[1], maxMotionRows);
+    if (tallest > minBand) {
+        g_driverError = "gfxh_restir_check_bands: an exchange strip of " + std::to_string(tallest) + " rows is taller than the smallest band (" + std::to_string(minBand) + " rows)";
+        return 1;
+    }
+    return 0;
+}
+
+int gfxh_balance_bands(uint32_t height, uint32_t world, const uint32_t* in, const float* ms, uint32_t minRows, uint32_t* out) {
+    if (world == 0 || !in || !ms || !out || in[0] != 0 || in[world] != height) return 1;
+    const uint32_t tiles = (height + 7u) / 8u;
+    const uint32_t minTiles = std::max(1u, (minRows + 7u) / 8u);
+    if (static_cast<uint64_t>(minTiles) * world > tiles) return 1;
+    // cost per 8-row tile: a band's time spread evenly over its tiles (double: the prefix sums decide the cuts)
+    std::vector<double> cost(tiles, 0.0);
+    double total = 0.0;
+    for (uint32_t r = 0; r < world; ++r) {
+        if (in[r + 1] <= in[r] || !(ms[r] > 0.0f) || !(ms[r] < 1e30f)) return 1;
+        const uint32_t t0 = in[r] / 8u, t1 = (in[r + 1] + 7u) / 8u;
+        for (uint32_t t = t0; t < t1 && t < tiles; ++t) cost[t] = static_cast<double>(ms[r]) / (t1 - t0);
+        total += ms[r];
+    }
+    // cut k after the tile at which the running cost passes k / world of the total (nearest tile edge), each band at least
+    // minTiles tall and leaving room for the bands behind it
+    out[0] = 0;
+    uint32_t tile = 0;
+    double run = 0.0;
+    for (uint32_t k = 1; k < world; ++k) {
+        const double want = total * k / world;
+        const uint32_t lo = out[k - 1] / 8u + minTiles, hi = tiles - (world - k) * minTiles;
+        while (tile < tiles && run + cost[tile] <= want) run += cost[tile++];
+        uint32_t cut = tile;
+        if (tile < tiles && (want - run) > (run + cost[tile] - want)) cut = tile + 1;   // the nearer edge
+        cut = std::min(std::max(cut, lo), hi);
+        out[k] = cut * 8u;
+    }
+    out[world] = height;
+    return 0;
+}
+
 int gfxh_restir_band_plan(gfxh_restir* r, gfxh_band_plan* out) {
     const gfxh_restir_config& cfg = r->cfg;
     const bool whole = cfg.rowBegin == 0 && cfg.rowEnd == 0;

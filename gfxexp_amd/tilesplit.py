@@ -43,12 +43,12 @@ class BandGather:
     4.15 MB per rank at 8 ranks.  The collective is asynchronous: nothing of the next frame depends on the other
     ranks' pixels, so it overlaps that frame's rendering."""
 
-    def __init__(self, beauty_view, width, height, world, rank, dist):
+    def __init__(self, beauty_view, width, height, world, rank, dist, bands=None):
         import torch
         self.torch = torch
         self.dist = dist
         self.w, self.h, self.world, self.rank = width, height, world, rank
-        self.bands = band_rows(height, world)
+        self.bands = [(int(b), int(e)) for b, e in bands] if bands is not None else band_rows(height, world)
         self.max_rows = max(e - b for b, e in self.bands)
         self.beauty = beauty_view                      # tensor view of the full-frame beauty buffer [H*W*4]
         device = beauty_view.device
@@ -145,11 +145,15 @@ class StripExchange:
                     a caller in this mode must invoke (with the renderer's stream current) before it reads the frame.
     The C++ twin is gfxh_rccl_exchange (csrc/host/rccl_exchange.cpp); both consume the same descriptors."""
 
-    def __init__(self, dist, rank, world, height, view, device="cpu", async_gather=False):
+    def __init__(self, dist, rank, world, height, view, device="cpu", async_gather=False, bands=None):
         self.dist, self.rank, self.world, self.device = dist, rank, world, device
         self.async_gather = bool(async_gather)
         self._view, self._views = view, {}
-        self.bands = band_rows(height, world)
+        # `bands`: an explicit partition [(begin, end)] per rank (cost-balanced bands, api.balance_bands) instead of the equal one;
+        # every rank must pass the same list.  RestirRenderer.set_exchange then checks THAT partition (api.check_bands).
+        self.custom_bands = [(int(b), int(e)) for b, e in bands] if bands is not None else None
+        self.bands = self.custom_bands if bands is not None else band_rows(height, world)
+        assert len(self.bands) == world and self.bands[0][0] == 0 and self.bands[-1][1] == height
         self.bytes_moved = 0
         self._stage = None
         self._pending = None

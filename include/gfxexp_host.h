@@ -240,6 +240,16 @@ int gfxh_band_rows(uint32_t height, uint32_t world, uint32_t rank, uint32_t* ban
  * the per-frame test inside gfxh_restir_render_frame only sees the calling rank's band.  1 + gfxh_restir_last_error()
  * when it does not fit. */
 int gfxh_restir_check_partition(const gfxh_restir_config* cfg, uint32_t world, uint32_t maxMotionRows);
+/* The same test for a partition given explicitly: band r = rows [bandBegin[r], bandBegin[r + 1]), world + 1 entries from 0 to
+ * cfg->height, every boundary a multiple of 8 (except the last).  For cost-balanced bands (gfxh_balance_bands). */
+int gfxh_restir_check_bands(const gfxh_restir_config* cfg, uint32_t world, const uint32_t* bandBegin, uint32_t maxMotionRows);
+/* Cost-balanced bands.  Equal rows are not equal work (sky rows are cheap, street-level rows are not): given the partition a
+ * frame was rendered with and the time every rank took for its band (all-gathered by the caller, so that every rank passes the
+ * same numbers), writes the partition that would have equalised the times, assuming the cost is uniform inside each old band:
+ * boundaries on whole 8-row tiles, no band shorter than minRows rows (the tallest exchange strip; at least one tile).  A pure
+ * function of its arguments.  bandBeginIn / bandBeginOut: world + 1 entries.  Returns 1 on invalid arguments. */
+int gfxh_balance_bands(uint32_t height, uint32_t world, const uint32_t* bandBeginIn, const float* bandMilliseconds, uint32_t minRows,
+                       uint32_t* bandBeginOut);
 /* An exchange callback over RCCL for C++ host programs (librccl is loaded with dlopen on first use; one process per
  * GPU).  Create with the ncclUniqueId bytes rank 0 obtained from gfxh_rccl_unique_id and distributed its own way. */
 typedef struct gfxh_rccl gfxh_rccl;

@@ -191,17 +191,18 @@ def _state(r):
     return out
 
 
-def _strip_worker(rank, world, port, out_dir, case_names):
+def _strip_worker(rank, world, port, out_dir, case_names, custom_bands=None):
     import torch.distributed as dist
     from gfxexp_amd import tilesplit
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     height = HEIGHTS[world]
-    band = tilesplit.band_for_rank(height, world, rank)
+    band = custom_bands[rank] if custom_bands else tilesplit.band_for_rank(height, world, rank)
     for case in STRIP_CASES:
         if case[0] not in case_names:
             continue
         # the asynchronous gather (bench.py's mode) on the odd cases, the synchronous default on the others
-        ex = tilesplit.StripExchange(dist, rank, world, height, tilesplit.host_view, async_gather=(STRIP_CASES.index(case) % 2 == 1))
+        ex = tilesplit.StripExchange(dist, rank, world, height, tilesplit.host_view, async_gather=(STRIP_CASES.index(case) % 2 == 1),
+                                     bands=custom_bands)
         r = _run_case(case, band, ex, threads=2, height=height)
         ex.finish()
         np.savez(os.path.join(out_dir, f"{case[0]}_{rank}.npz"), band=np.array(band), bytes_moved=ex.bytes_moved,
@@ -210,13 +211,13 @@ def _strip_worker(rank, world, port, out_dir, case_names):
     dist.destroy_process_group()
 
 
-def _spawn_strip_runs(world, case_names):
+def _spawn_strip_runs(world, case_names, custom_bands=None):
     import torch.multiprocessing as mp
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_strip_worker, args=(world, port, out_dir, case_names), nprocs=world, join=True)
+        mp.spawn(_strip_worker, args=(world, port, out_dir, case_names, custom_bands), nprocs=world, join=True)
         return {(c, r): dict(np.load(os.path.join(out_dir, f"{c}_{r}.npz"))) for c in case_names for r in range(world)}
 
 
@@ -252,17 +253,65 @@ def test_three_rank_strip_exchange_with_unequal_bands_is_bit_exact(strip_runs_wo
     _check_strip_runs(strip_runs_world3, case, 3)
 
 
+# a partition that is not the default one (what gfxh_balance_bands hands bench.py): the short band first
+CUSTOM_BANDS_WORLD3 = [(0, 16), (16, 40), (40, 56)]
+CUSTOM_CASES = ["biased_moving", "rearch_unbiased_moving"]
+
+
+@pytest.fixture(scope="module")
+def strip_runs_custom(built_lib):
+    return _spawn_strip_runs(3, CUSTOM_CASES, CUSTOM_BANDS_WORLD3)
+
+
+@pytest.mark.parametrize("case", [c for c in STRIP_CASES if c[0] in CUSTOM_CASES], ids=CUSTOM_CASES)
+def test_three_rank_strip_exchange_with_an_explicit_partition_is_bit_exact(strip_runs_custom, case):
+    """Cost-balanced bands: StripExchange(bands=...) and band renderers cut at 16 | 24 | 16 rows instead of 24 | 16 | 16."""
+    from gfxexp_amd import tilesplit
+    assert CUSTOM_BANDS_WORLD3 != tilesplit.band_rows(HEIGHTS[3], 3)
+    _check_strip_runs(strip_runs_custom, case, 3, CUSTOM_BANDS_WORLD3)
+
+
+def test_balance_bands_and_check_bands(built_lib):
+    """gfxh_balance_bands / gfxh_restir_check_bands (include/gfxexp_host.h): tile-aligned cuts that cover the frame, honour the
+    minimum band height, equalise the predicted band times -- and do nothing to a partition whose bands already take equally long."""
+    from gfxexp_amd import api, tilesplit
+    H, world = 1080, 8
+    equal = tilesplit.band_rows(H, world)
+    ms = [0.6072, 0.7118, 0.7705, 0.7858, 0.7631, 0.7489, 0.7401, 0.5912]      # tools/bench_band.py, eight bands of the bench frame
+    cut = api.balance_bands(H, equal, ms, min_rows=24)
+    assert cut[0][0] == 0 and cut[-1][1] == H and all(a[1] == b[0] for a, b in zip(cut, cut[1:]))
+    assert all(b % 8 == 0 for b, _ in cut) and all(e - b >= 24 for b, e in cut)
+    cost = np.zeros(H)
+    for (b, e), t in zip(equal, ms):
+        cost[b:e] = t / (e - b)
+    predicted = [cost[b:e].sum() for b, e in cut]
+    assert max(predicted) < 0.95 * max(ms) and cut[0][1] > equal[0][1] and cut[-1][0] < equal[-1][0]   # the sky and ground bands grow
+    same = api.balance_bands(H, equal, [1.0 * (e - b) for b, e in equal], min_rows=24)    # uniform cost: 135 rows each, to the nearest tile
+    assert all(abs((e - b) - H / world) <= 8 for b, e in same) and all(abs(b - k * H / world) <= 4 for k, (b, _) in enumerate(same))
+    with pytest.raises(api.GfxError):
+        api.balance_bands(H, equal, ms, min_rows=200)                       # eight bands of 200 rows do not fit 1080
+    # a lopsided profile cannot squeeze a band below the minimum
+    tight = api.balance_bands(H, equal, [10.0] + [0.1] * 7, min_rows=64)
+    assert all(e - b >= 64 for b, e in tight) and tight[0][1] - tight[0][0] == 64
+    cfg = api.RestirRenderer.default_config(1920, H, api.RENDERER_BIASED)
+    api.check_bands(cfg, cut)                                              # radius-20 strips fit every band of `cut`
+    with pytest.raises(api.GfxError):
+        api.check_bands(cfg, [(0, 8), (8, H)])                             # a 20-row strip out of an 8-row band
+    with pytest.raises(api.GfxError):
+        api.check_bands(cfg, [(0, 100), (100, H)])                         # not on a tile boundary
+
+
 @pytest.mark.parametrize("case", [c for c in STRIP_CASES if c[0] in WORLD4_CASES], ids=WORLD4_CASES)
 def test_four_rank_strip_exchange_with_unequal_bands_is_bit_exact(strip_runs_world4, case):
     """Two interior ranks; the bands are 24 + 16 + 16 + 16 rows."""
     _check_strip_runs(strip_runs_world4, case, 4)
 
 
-def _check_strip_runs(strip_runs, case, world):
+def _check_strip_runs(strip_runs, case, world, custom_bands=None):
     from gfxexp_amd import api, tilesplit
     from tests import util
     H = HEIGHTS[world]
-    bands = tilesplit.band_rows(H, world)
+    bands = custom_bands if custom_bands else tilesplit.band_rows(H, world)
     if world > 2:
         assert len(set(e - b for b, e in bands)) > 1, "the bands of this test are meant to be unequal"
     whole = _run_case(case, (0, 0), None, threads=4, height=H)

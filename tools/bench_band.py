@@ -3,6 +3,8 @@
   strips          gfxh_restir_set_exchange with a callback that moves nothing: every pass on the band only (what bench.py --gpus N
                   runs), the next frame's G-buffer pass pipelined underneath the reuse passes (round 3)
   strips_serial   the same with GFX_SERIAL_FRAMES=1: every pass on one stream (round 2)
+  strips_balanced the pipelined strip mode with cost-balanced bands: the equal partition's band times go through
+                  gfxh_balance_bands (what bench.py --gpus N does during its warm-up), twice
   halo            no callback: the band plus the halo rows the reuse passes read are recomputed (round-1 scheme)
 The seam rows' state is not refreshed here (no neighbour rank), which does not change the amount of work.  One JSON line."""
 import json
@@ -54,6 +56,14 @@ def main():
             worst = max(ms)
             entry[mode] = {"band_ms": [round(m, 4) for m in ms], "compute_bound_speedup": round(full / worst, 2),
                            "compute_bound_efficiency": round(full / worst / n, 3)}
+        # cost-balanced bands: two rounds of measuring and re-cutting, strips no shorter than the exchange strip (radius 20 -> 24 rows)
+        cur, ms = bands, [band_ms(ctx, cam, W, H, b, strips=True) for b in bands]
+        for _ in range(2):
+            cur = api.balance_bands(H, cur, ms, min_rows=24)
+            ms = [band_ms(ctx, cam, W, H, b, strips=True) for b in cur]
+        worst = max(ms)
+        entry["strips_balanced"] = {"bands": cur, "band_ms": [round(m, 4) for m in ms], "compute_bound_speedup": round(full / worst, 2),
+                                    "compute_bound_efficiency": round(full / worst / n, 3)}
         out["bands"][str(n)] = entry
     print(json.dumps(out))
 
