@@ -93,6 +93,9 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
         const unsigned long long cyc0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         const unsigned long long idleMask = __ballot(!tr.active);
         const int numIdle = __popcll(idleMask);
+        bool newRay = false;
+        float4 rayO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rayD = rayO;
+        uint32_t hint = 0xFFFFFFFFu;
         if (!exhausted && numIdle >= a.refillThreshold) {
             // wave-local ticket range: one device atomic buys a batch of rays, bought on demand
             // (buying ahead of need strands rays in waves that finish late; measured slower)
@@ -121,30 +124,24 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             if (!tr.active) {
                 const uint32_t rank = __popcll(idleMask & ((1ull << lane) - 1ull));
                 if (rank < take) {
+                    // only the loads are issued here: a new ray's first item is the root node whatever the ray is, so it asks for it
+                    // in this very iteration and its origin / direction arrive together with the items (one wait for both)
                     const uint32_t i = waveNext + rank;
-                    const float4 o = a.rayOrgTmin[i];
-                    const float4 d = a.rayDirTmax[i];
+                    rayO = a.rayOrgTmin[i];
+                    rayD = a.rayDirTmax[i];
+                    // Temporal hint: the triangle this ray slot hit in the previous launch (the same pixel's primary ray one frame
+                    // ago) is tested right after the root -- as the one pending "leaf" of a node that does not exist.  When it is hit
+                    // again the traversal descends with the right upper bound and skips what lies behind it; the answer cannot change
+                    // (closest hit with the order-independent tie rule), a stale or garbage index costs one triangle test.
+                    if (!ANY_HIT && a.hintFromOut) hint = static_cast<const gfx_hit*>(a.out)[i].triIndex;
                     rayIdx = i;
-                    if (COUNT) rayItems = 0;
-                    tr.begin(f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, d.w, stack, hasNodes);
-                    if (!ANY_HIT && a.hintFromOut) {
-                        // Temporal hint: the triangle this ray slot hit in the previous launch (the same pixel's primary ray one frame
-                        // ago) is tested first -- as the one pending "leaf" of a node that does not exist.  When it is hit again the
-                        // traversal starts with the right upper bound and skips everything behind it; the answer cannot change
-                        // (closest hit with the order-independent tie rule), a stale or garbage index costs one triangle test.
-                        const uint32_t h = static_cast<const gfx_hit*>(a.out)[i].triIndex;
-                        if (h < a.accel.numTris) { tr.triBase = h; tr.triMask = 0x0101u; }
-                    }
-                    if (!hasNodes || !(d.w > o.w)) {   // empty interval or empty scene: immediate miss
-                        tr.active = false;
-                        write_result();
-                    }
+                    newRay = true;
                 }
             }
             waveNext += take;
         }
         if (COUNT) cycRefill += __builtin_amdgcn_s_memtime() - cyc0;
-        if (__ballot(tr.active) == 0ull) {
+        if (__ballot(tr.active || newRay) == 0ull) {
             if (exhausted) break;
             continue;
         }
@@ -153,7 +150,9 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             code = tr.next_item(stack, a.accel.triItemOffset);
             if (code == kItemNone) write_result();          // traversal finished
         }
+        if (newRay && hasNodes) code = 0u;                      // the root node
         if (COUNT) {
+            if (newRay) rayItems = 0;
             if (code != kItemNone) ++rayItems;
             const int held = __popcll(__ballot(code != kItemNone));
             ++diagIter; diagLanes += held;
@@ -182,6 +181,15 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             if (w0 + w1 + w2 + w3 == 123.456f) q3.x ^= 1u;   // never true in practice; keeps the chain alive
         }
 #endif
+        if (newRay) {                                           // its origin and direction have arrived with the items
+            tr.begin(f3(rayO.x, rayO.y, rayO.z), f3(rayD.x, rayD.y, rayD.z), rayO.w, rayD.w, stack, hasNodes);
+            tr.grp.y = 0u;                                      // the root (begin's one-child group) is this iteration's item
+            if (!hasNodes || !(rayD.w > rayO.w)) {              // empty interval or empty scene: immediate miss
+                tr.active = false;
+                code = kItemNone;
+                write_result();
+            }
+        }
         if (code != kItemNone) {
             if (code & kItemTri) {
                 if (!tr.template process_triangle<ANY_HIT, COUNT>((code & 0x7FFFFFFFu) - a.accel.triItemOffset, q0, q1, q2, q3, a.accel.tris, cnt))
@@ -189,6 +197,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             }
             else tr.template process_node<COUNT>(q0, q1, q2, q3, link, stack, cnt);
         }
+        if (!ANY_HIT && newRay && tr.active && hint < a.accel.numTris && tr.triMask == 0u) { tr.triBase = hint; tr.triMask = 0x0101u; }
         if (COUNT) cycProcess += __builtin_amdgcn_s_memtime() - cyc2;
     }
     if (COUNT && a.diag && lane == 0) {
