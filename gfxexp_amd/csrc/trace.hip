@@ -188,7 +188,8 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
                 tr.active = false;
                 code = kItemNone;
                 write_result();
-            }
+                if (COUNT) --raysDone;                           // the counters report rays that were traversed: a queue entry without a
+            }                                                   // ray (emit_ray_at_slot, padding slots) is not one
         }
         if (code != kItemNone) {
             if (code & kItemTri) {

@@ -485,7 +485,8 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
  * The same knobs are read once from the environment by gfx_ctx_create (GFX_PIXEL_MAP, GFX_SUPER_X, GFX_SUPER_Y,
  * GFX_TRACE_BLOCKS_PER_CU, GFX_TRACE_REFILL, GFX_TRACE_BATCH). */
 int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value);
-/* Ray-traversal counters accumulated by the renderer passes: {node fetches, triangle fetches, rays, stack spills}
+/* Ray-traversal counters accumulated by the renderer passes: {node fetches, triangle fetches, rays (queue entries with an empty
+ * interval are not counted), stack spills}
  * of the any-hit launches in [0..3] and of the closest-hit launches in [4..7]. */
 int gfx_counters_enable(gfx_ctx* ctx, int enable);
 int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[8], int reset);
