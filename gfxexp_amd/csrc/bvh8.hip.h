@@ -177,10 +177,13 @@ struct Traversal {
                        fmaf(fmaf(255.0f, scale.z, fabsf(origin.z)), slackScale.z, slackOrg.z));
         const f3 An = A - slack, Af = A + slack;
 
-        // branch-free: one bit per hit SLOT, classified after the loop
-        uint32_t hitSlots = 0;
+        // branch-free: one bit per SLOT, classified after the loop.  Child s is missed iff tf < tn, i.e. iff the sign bit of
+        // tf - tn is set (no NaNs here: every input is finite; tf is never -0: the far planes carry a positive slack and hit.t
+        // is a positive bound, so tf - tn = -0 would need tf = tn = -0); the sign bits are shifted into one word with a funnel
+        // shift per child -- subtract + v_alignbit instead of compare + select + or.
+        uint32_t missSlots = 0;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 7; s >= 0; --s) {
             const int w = s >> 2, sh = (s & 3) * 8;
             const float tnx = fmaf(static_cast<float>((nx[w] >> sh) & 0xFFu), B.x, An.x);
             const float tny = fmaf(static_cast<float>((ny[w] >> sh) & 0xFFu), B.y, An.y);
@@ -190,8 +193,9 @@ struct Traversal {
             const float tfz = fmaf(static_cast<float>((fz[w] >> sh) & 0xFFu), B.z, Af.z);
             const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
             const float tf = fminf(fminf(tfx, tfy), fminf(tfz, hit.t));
-            hitSlots |= (tn <= tf) ? (1u << s) : 0u;
+            missSlots = __builtin_amdgcn_alignbit(missSlots, f2bits(tf - tn), 31);   // (missSlots << 1) | sign(tf - tn)
         }
+        uint32_t hitSlots = ~missSlots & 0xFFu;                 // children were taken 7 .. 0: bit s belongs to child s
         hitSlots &= valid;
         // internal children in (slot ^ oct) order: XOR-permute the 8 bit positions with three conditional swaps
         uint32_t nodeHits = hitSlots & imask;
