@@ -199,9 +199,10 @@ struct Traversal {
         hitSlots &= valid;
         // internal children in (slot ^ oct) order: XOR-permute the 8 bit positions with three conditional swaps
         uint32_t nodeHits = hitSlots & imask;
-        nodeHits = (oct & 1u) ? (((nodeHits & 0x55u) << 1) | ((nodeHits & 0xAAu) >> 1)) : nodeHits;
-        nodeHits = (oct & 2u) ? (((nodeHits & 0x33u) << 2) | ((nodeHits & 0xCCu) >> 2)) : nodeHits;
-        nodeHits = (oct & 4u) ? (((nodeHits & 0x0Fu) << 4) | ((nodeHits & 0xF0u) >> 4)) : nodeHits;
+        // (xNeg / yNeg / zNeg are the bits of oct as lane masks the near / far selection above already holds in scalar registers)
+        nodeHits = xNeg ? (((nodeHits & 0x55u) << 1) | ((nodeHits & 0xAAu) >> 1)) : nodeHits;
+        nodeHits = yNeg ? (((nodeHits & 0x33u) << 2) | ((nodeHits & 0xCCu) >> 2)) : nodeHits;
+        nodeHits = zNeg ? (((nodeHits & 0x0Fu) << 4) | ((nodeHits & 0xF0u) >> 4)) : nodeHits;
         // leaf children: keep the hit slots and the node's leaf-slot set; the rank (= triangle offset) is
         // taken when the triangle is fetched (next_item)
         const uint32_t leafBits = valid & ~imask;
