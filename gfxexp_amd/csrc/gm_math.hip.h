@@ -24,8 +24,17 @@ namespace gfx {
 static __device__ unsigned long long g_laneProfile[64];
 #define GFX_PROF(k) do { const unsigned long long m__ = __ballot(1); if ((threadIdx.x & 63) == __builtin_ctzll(m__)) { \
     atomicAdd(&g_laneProfile[2 * (k)], static_cast<unsigned long long>(__popcll(m__))); atomicAdd(&g_laneProfile[2 * (k) + 1], 1ull); } } while (0)
+// ... and where a wave's clock cycles go: GFX_CYC(k) closes the running section and opens section k (s_memtime; wave-level, so a
+// section entered by any lane is charged to the whole wave); GFX_CYC_BEGIN / GFX_CYC_END bracket a kernel.  Totals in
+// g_laneProfile[32 + k].
+#define GFX_CYC_BEGIN unsigned long long cyc__[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; unsigned long long cycT__ = __builtin_amdgcn_s_memtime(); int cycK__ = 7;
+#define GFX_CYC(k) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); cyc__[cycK__] += t__ - cycT__; cycT__ = t__; cycK__ = (k); } while (0)
+#define GFX_CYC_END do { GFX_CYC(7); if ((threadIdx.x & 63) == 0) for (int k__ = 0; k__ < 8; ++k__) atomicAdd(&g_laneProfile[32 + k__], cyc__[k__]); } while (0)
 #else
 #define GFX_PROF(k) do { } while (0)
+#define GFX_CYC_BEGIN
+#define GFX_CYC(k) do { } while (0)
+#define GFX_CYC_END do { } while (0)
 #endif
 
 constexpr float kPi = 3.14159265358979323846f;

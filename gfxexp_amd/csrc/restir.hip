@@ -211,8 +211,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
     reservoir.reset();
     float selectedTarget = 0.0f;
     const uint32_t numCandidates = 1u << a.f.log2NumCandidateSamples;
+    GFX_CYC_BEGIN
     for (uint32_t i = 0; i < numCandidates; ++i) {
         GFX_PROF(0);
+        GFX_CYC(0);   // random numbers, light type, table lookup
         // ---- what this lane's candidate needs from the tables
         float probCurType = 1.0f, u0 = 0.0f, u1 = 0.0f;
         bool sampleEnv = false;
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
 #endif
         }
         // ---- the wave gathers the records, then -- their flags name them -- the normal matrices
+        GFX_CYC(1);   // cooperative record fetch (issue, wait, read back), matrix loads issued
         const bool fetch = surface && !sampleEnv && pk.ok;
         uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0, q2 = q0, q3 = q0;
         m33 normalMatrix;
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
             if (fetch) normalMatrix = load_m33_rows(a.scene.lightNormalMatrices + 16u * emitter_matrix_index(q3.w));
         }
         // ---- the candidate itself
+        GFX_CYC(2);   // point on the emitter (waits for the matrix)
         if (surface) {
             LightSample ls;
             ls.emittance = f3(0.0f); ls.position = f3(0.0f); ls.normal = f3(0.0f); ls.atInfinity = 0;
@@ -275,18 +279,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
                 light_from_record<EMITTER_TEX, false>(a.scene, pk, as_float4(q0), as_float4(q1), as_float4(q2), as_float4(q3), normalMatrix, u0, u1, ls, pd,
                                                       f3(0.0f), EMITTER_TEX ? &pending : nullptr);
             }
+            GFX_CYC(3);   // shadow-ray geometry, BSDF evaluation, emittance texture
 #if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 2)   // timing experiment: no BSDF evaluation (results differ)
             const f3 cont = ls.emittance * (1.0f / (1.0f + dot(ls.position - sp.pos, ls.position - sp.pos))) * fabsf(dot(ls.normal, sp.frame.n));
 #else
             const f3 cont = EMITTER_TEX ? direct_lighting_pending(a.scene, sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls, pending)
                                         : direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
 #endif
+            GFX_CYC(4);   // reservoir update
             pd *= probCurType;
             const float target = target_weight(cont);
             const float weight = target / pd;
             if (reservoir.update(ls, weight, rng.uniform())) { GFX_PROF(5); selectedTarget = target; }
         }
     }
+    GFX_CYC(5);       // after the loop
     if (surface) {
         GFX_PROF(8);
         float recPDF = reservoir.sumWeights / (selectedTarget * reservoir.streamLength);
@@ -302,6 +309,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
     }
     const uint32_t slot = emit_ray_at_slot(px, wantRay, rayO, rayD, 0.0f, rayTmax, a);
     if (px.valid) a.pixelRaySlot[p] = slot;
+    GFX_CYC_END;
 }
 
 // visibility application + temporal reuse: optix_restir_di_kernels.cu:128-286

@@ -53,7 +53,14 @@ def main():
     for k, name in SECTIONS.items():
         lanes, visits = int(out[2 * k]), int(out[2 * k + 1])
         res[k] = {"section": name, "wave_visits": visits, "lanes": lanes, "lanes_per_visit": round(lanes / max(1, visits), 2)}
-    print(json.dumps({"workload": "textured" if textured else "plain", "sections": res}, indent=1))
+    # where the waves' clock cycles went (GFX_CYC marks in k_initial_candidates; wave-level s_memtime)
+    names = {0: "random numbers, light type, table lookup", 1: "cooperative record fetch (issue, wait, read back), matrix loads issued",
+             2: "point on the emitter (waits for the matrix)", 3: "shadow-ray geometry, BSDF evaluation, emittance texture", 4: "reservoir update",
+             5: "after the loop", 7: "before the loop"}
+    cyc = {k: int(out[32 + k]) for k in names}
+    total = max(1, sum(cyc.values()))
+    print(json.dumps({"workload": "textured" if textured else "plain", "sections": res,
+                      "wave_cycle_shares": {names[k]: round(cyc[k] / total, 4) for k in names}, "wave_cycles_total": total}, indent=1))
 
 
 if __name__ == "__main__":
