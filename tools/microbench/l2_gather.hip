@@ -4,6 +4,9 @@
 //   lane16   every lane loads 16 B from its own random sector               (64 line requests per wave instruction)
 //   lane64   every lane loads its whole sector with four 16-byte loads      (4 x 64 requests, one sector per lane)
 //   coop64   four lanes share a sector, 16 B each, global -> LDS DMA        (16 requests per instruction; coop_fetch.hip.h)
+//   lane128  every lane loads a whole 128-byte line (two adjacent sectors) with eight 16-byte loads: is the unit of cost the
+//            sector or the line?  (Reported in sectors: two per lane and iteration.)
+//   pair64   every lane loads two sectors from two unrelated places (what record + normal matrix cost today)
 // hipcc --offload-arch=gfx950 -O3 -o /tmp/l2_gather l2_gather.hip ; prints one JSON line per (shape, table size).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -27,6 +30,16 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ table, uint32
         } else if (SHAPE == 1) {
             const uint4 a = table[sector * 4u], b = table[sector * 4u + 1], c = table[sector * 4u + 2], d = table[sector * 4u + 3];
             acc ^= a.x + b.y + c.z + d.w;
+        } else if (SHAPE == 3) {
+            const uint4* q = table + (sector & ~1u) * 4u;
+            const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6], h = q[7];
+            acc ^= a.x + b.y + c.z + d.w + e.x + f.y + g.z + h.w;
+        } else if (SHAPE == 4) {
+            const uint32_t sector2 = hash32(seed ^ 0x9e3779b9u) & sectorMask;
+            const uint4* q = table + sector * 4u;
+            const uint4* r = table + sector2 * 4u;
+            const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = r[0], f = r[1], g = r[2], h = r[3];
+            acc ^= a.x + b.y + c.z + d.w + e.x + f.y + g.z + h.w;
         } else {
             typedef const __attribute__((address_space(1))) void* GlobalPtr;
             typedef __attribute__((address_space(3))) void* LdsPtr;
@@ -54,7 +67,7 @@ static void run(const char* name, const uint4* table, size_t bytes, uint32_t* ou
     hipLaunchKernelGGL(k<SHAPE>, dim3(grid), dim3(256), 0, 0, table, sectors - 1, iters, out);
     (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-    const double n = double(grid) * 256.0 * iters;
+    const double n = double(grid) * 256.0 * iters * (SHAPE >= 3 ? 2.0 : 1.0);
     printf("{\"shape\": \"%s\", \"table_MB\": %.2f, \"ms\": %.3f, \"Gsectors_per_s\": %.1f, \"TB_per_s_of_64B_sectors\": %.2f}\n",
            name, bytes / 1048576.0, ms, n / ms * 1e-6, n * 64.0 / ms * 1e-9);
 }
@@ -70,6 +83,8 @@ int main() {
         run<0>("lane16", table, s, out, p.multiProcessorCount);
         run<1>("lane64", table, s, out, p.multiProcessorCount);
         run<2>("coop64", table, s, out, p.multiProcessorCount);
+        run<3>("lane128", table, s, out, p.multiProcessorCount);
+        run<4>("pair64", table, s, out, p.multiProcessorCount);
     }
     return 0;
 }
