@@ -48,9 +48,10 @@ def _choose_window(workload, hs, size=(80, 40)):
     test then compares with the oracle inside the window like every other buffer); the plain street keeps the fixed
     window of round 2."""
     if workload == "plain":
-        return (900, 560, 900 + size[0], 560 + size[1])
-    if (workload, size) in _windows:
-        return _windows[(workload, size)]
+        x0, y0 = 900 * W // 1920 // 8 * 8, 560 * H // 1080 // 8 * 8
+        return (x0, y0, x0 + size[0], y0 + size[1])
+    if (workload, size, W, H) in _windows:
+        return _windows[(workload, size, W, H)]
     import torch
     ctx = api.Context(0)
     hs.upload(ctx)
@@ -91,7 +92,7 @@ def _choose_window(workload, hs, size=(80, 40)):
     cy, cx = ys * 8 + wh / 2 - H / 2, xs * 8 + ww / 2 - W / 2
     k = int(np.argmin(cx * cx + cy * cy))
     win = (int(xs[k]) * 8, int(ys[k]) * 8, int(xs[k]) * 8 + ww, int(ys[k]) * 8 + wh)
-    _windows[(workload, size)] = win
+    _windows[(workload, size, W, H)] = win
     return win
 
 
@@ -122,6 +123,18 @@ def _pick(arr, mask, n):
 def test_window_of_the_full_frame_matches_the_oracle(built_lib, config, workload):
     with util.frame_overrides(enableBumpMapping=WORKLOADS[workload]["bump"]):
         _window_of_the_full_frame(config, workload)
+
+
+@pytest.mark.parametrize("workload", ["plain", "textured"])
+def test_window_of_a_3840x2160_frame_matches_the_oracle(built_lib, monkeypatch, workload):
+    """The same check at four times the pixels of BASELINE's configuration (8.3 M pixels: padded launch slots, ray-queue
+    sizes, the 8x8 tile / XCD supertile map with a different supertile grid): a window of the 4K frame, bit for bit, after every pass of two frames."""
+    import sys
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, "W", 3840)
+    monkeypatch.setattr(mod, "H", 2160)
+    with util.frame_overrides(enableBumpMapping=WORKLOADS[workload]["bump"]):
+        _window_of_the_full_frame("configs[2]: biased", workload)
 
 
 def _window_of_the_full_frame(config, workload):
