@@ -247,7 +247,7 @@ C_ABI_SYMBOLS = [
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_infer_indirect", "gfx_nrc_query_count_ptr", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
     "gfx_nrc_get_params", "gfx_nrc_inference_image", "gfx_nrc_set_render_params",
     "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read", "gfx_trace_diag_read",
-    "gfx_tunable_set",
+    "gfx_tunable_set", "gfx_stream_copy",
 ]
 HOST_ABI_SYMBOLS = [
     "gfxh_scene_create", "gfxh_scene_destroy", "gfxh_last_error", "gfxh_scene_add_material_traditional",
@@ -681,8 +681,12 @@ class Context:
 
     def tunable_set(self, name, value):
         """Scheduling knob of this context ("pixel_map", "super_x", "super_y", "trace_blocks_per_cu", "trace_refill",
-        "trace_batch"); changes no result."""
+        "trace_batch", "temporal_hints", "any_hints", "trace_segments", "trace_seg_fill"); changes no result."""
         self._check(self.L.gfx_tunable_set(self.h, name.encode(), C.c_int(int(value))))
+
+    def stream_copy(self, d_dst, d_src, nbytes, stream=0):
+        """Measurement utility: device-to-device copy with 16-byte accesses per lane (bench.py times it for roofline.peak_measured)."""
+        self._check(self.L.gfx_stream_copy(self.h, C.c_void_p(d_dst), C.c_void_p(d_src), C.c_size_t(nbytes), C.c_void_p(stream)))
 
     def counters_enable(self, on=True):
         self._check(self.L.gfx_counters_enable(self.h, C.c_int(1 if on else 0)))

@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libgfxexp.so")
 CLI = os.path.join(HERE, "restir_di_headless")       # host/restir_di_headless.cpp: the reference's command line, windowless
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["capi.cpp", "scene.cpp", "lights.hip", "lbvh.hip", "trace.hip", "restir.hip", "pathtrace.hip", "nrc.hip", "textures.hip",
+SOURCES = ["capi.cpp", "scene.cpp", "lights.hip", "lbvh.hip", "trace.hip", "restir.hip", "pathtrace.hip", "nrc.hip", "textures.hip", "diag.hip",
            "host/scene_builder.cpp", "host/restir_driver.cpp", "host/nrc_driver.cpp", "host/rccl_exchange.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
@@ -80,7 +80,8 @@ def build_variant(name, defines):
     """Experiment builds (tools/sessions): the same sources with extra -D switches -> gfxexp_amd/variants/libgfxexp_<name>.so;
     api.py loads it when GFX_LIB names the file.  Not part of the product build."""
     vdir = os.path.join(HERE, "variants")
-    odir = os.path.join(vdir, "obj_" + name)
+    odir = os.path.join(HERE, "build_variants", "obj_" + name)      # objects stay here (.gpurunignore); only the .so travels
+    os.makedirs(vdir, exist_ok=True)
     os.makedirs(odir, exist_ok=True)
     flags = FLAGS + [d if d.startswith("-") else "-D" + d for d in defines]
     with ThreadPoolExecutor(max_workers=8) as ex:

@@ -171,11 +171,7 @@ GFX_SPAN_HD int32_t span_lookup(const EmitterSpan* __restrict__ spans, uint32_t 
                                 const SpanGuide* __restrict__ guide, uint32_t cells, float ul, EmitterSpan& out) {
     if (numSpans == 0) return -1;
     const SpanGuide g = guide[span_cell(ul, cells)];
-#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 128)   // timing experiment: every cell answers like an interior one
-    if (true) {
-#else
     if (g.a & kGuideInterior) {
-#endif
         out.begin = 0.0f; out.end = 0.0f; out.density = span_float(g.b); out.instSlot = 0xFFFFFFFFu;
         return static_cast<int32_t>(g.a & ~kGuideInterior);
     }

@@ -235,18 +235,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
             u0 = rng.uniform();
             u1 = rng.uniform();
             if (!sampleEnv) pk = light_select(a.scene, ul);
-#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 1)   // timing experiment: no table search, coalesced records (results differ)
-            if (!sampleEnv) { pk.ok = true; pk.table = true; pk.rec = (static_cast<uint32_t>(lane) + 64u * i) % a.scene.numSpans; pk.instSlot = 1u + (i & 7u); pk.density = 1.0f + ul; }
-#endif
-#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 4)   // timing experiment: the real table search, then coalesced records
-            if (!sampleEnv && pk.ok) { pk.rec = (static_cast<uint32_t>(lane) + 64u * i) % a.scene.numSpans; pk.instSlot = 1u + (i & 7u); }
-#endif
-#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 8)   // timing experiment: no table search, scattered records
-            if (!sampleEnv) { pk.ok = true; pk.table = true; pk.rec = (f2bits(ul) * 2654435761u >> 8) % a.scene.numSpans; pk.instSlot = (f2bits(ul) * 40503u >> 4) % a.scene.numInsts; pk.density = 1.0f + ul; }
-#endif
-#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 16)   // timing experiment: one guide load picks the record, nothing else is searched
-            if (!sampleEnv) { const SpanGuide g = a.scene.spanGuide[span_cell(ul, a.scene.spanGuideCells)]; pk.ok = true; pk.table = true; pk.rec = g.a & 0x7FFFFFFFu; pk.instSlot = 0; pk.density = 1.0f + ul; }
-#endif
         }
         // ---- the wave gathers the records, then -- their flags name them -- the normal matrices
         GFX_CYC(1);   // cooperative record fetch (issue, wait, read back), matrix loads issued
@@ -280,12 +268,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
                                                       f3(0.0f), EMITTER_TEX ? &pending : nullptr);
             }
             GFX_CYC(3);   // shadow-ray geometry, BSDF evaluation, emittance texture
-#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 2)   // timing experiment: no BSDF evaluation (results differ)
-            const f3 cont = ls.emittance * (1.0f / (1.0f + dot(ls.position - sp.pos, ls.position - sp.pos))) * fabsf(dot(ls.normal, sp.frame.n));
-#else
             const f3 cont = EMITTER_TEX ? direct_lighting_pending(a.scene, sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls, pending)
                                         : direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, ls);
-#endif
             GFX_CYC(4);   // reservoir update
             pd *= probCurType;
             const float target = target_weight(cont);
@@ -755,8 +739,17 @@ static void launch_pixels(Context& ctx, hipStream_t stream, const char* name, K 
     GFX_HIP(hipGetLastError());
 }
 
-static void trace_queue(Context& ctx, hipStream_t stream, const RestirArgs& a, int mode, uint32_t fixedCount, bool useCounter, void* out) {
+// The occluder hints of a slot-addressed shadow-ray pass: one word per launch slot of the frame, zero when (re)allocated.
+static uint32_t* any_hint_buffer(Context& ctx, hipStream_t stream, DevBuf& buf, uint32_t width, uint32_t height) {
+    const size_t bytes = 4 * static_cast<size_t>(make_pixel_grid(ctx, width, 0, height).launchBlocks) * kBlock;
+    if (buf.bytes < bytes) { buf.reserve(bytes); GFX_HIP(hipMemsetAsync(buf.p, 0, buf.bytes, stream)); }
+    return buf.as<uint32_t>();
+}
+
+static void trace_queue(Context& ctx, hipStream_t stream, const RestirArgs& a, int mode, uint32_t fixedCount, bool useCounter, void* out,
+                        uint32_t* anyHint = nullptr, uint32_t maxRays = 0) {
     TraceLaunch t;
+    t.anyHint = anyHint; t.maxRays = maxRays;
     t.accel = ctx.accels[ctx.restir.f.travHandle - 1]->dev();
     t.rayOrgTmin = a.rayOrg; t.rayDirTmax = a.rayDir;
     t.numRays = fixedCount; t.numRaysPtr = useCounter ? a.rayCount : nullptr;
@@ -853,12 +846,12 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         {
             const uint32_t grid = a.px.launchBlocks;
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
-            static const bool whatifNoTex = getenv("GFX_WHATIF_NO_EMITTER_TEX") != nullptr;   // timing experiment only (results differ)
-            if (a.scene.emitterTexRefs && !whatifNoTex) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), 0, stream, a);
+            if (a.scene.emitterTexRefs) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);
             GFX_HIP(hipGetLastError());
         }
-        trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p);   // one entry per launch slot (emit_ray_at_slot)
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p,   // one entry per launch slot (emit_ray_at_slot)
+                    any_hint_buffer(ctx, stream, ctx.anyHintInitial, width, height));
         if (pass == GFX_RESTIR_INITIAL_RIS) launch_pixels(ctx, stream, "temporal_none", k_temporal<0>, a);
         else if (pass == GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED) launch_pixels(ctx, stream, "temporal_biased", k_temporal<1>, a);
         else launch_pixels(ctx, stream, "temporal_unbiased", k_temporal<2>, a);
@@ -869,12 +862,14 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     case GFX_RESTIR_SPATIAL_UNBIASED:
         reset_queue();
         launch_pixels(ctx, stream, "spatial_unbiased_select", k_spatial<true>, a);
-        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p, nullptr,
+                    (a.px.rowEnd - a.px.rowBegin) * width * (1u + static_cast<uint32_t>(a.f.numSpatialNeighbors)));
         launch_pixels(ctx, stream, "spatial_unbiased_finish", k_spatial_mis_finish, a);
         break;
     case GFX_RESTIR_SHADING:
         launch_pixels(ctx, stream, "shade_prepare", k_shade_prepare, a);
-        trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p);   // one entry per launch slot (emit_ray_at_slot)
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p,   // one entry per launch slot (emit_ray_at_slot)
+                    any_hint_buffer(ctx, stream, ctx.anyHintShade, width, height));
         launch_pixels(ctx, stream, "shade_finish", k_shade_finish, a);
         break;
     case GFX_RESTIR_LIGHT_PRESAMPLING: {
@@ -914,7 +909,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
 #undef GFX_REARCH_CASE
         }
         launch_pixels(ctx, stream, "rearch_emit", emit, a);
-        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p, nullptr, (a.px.rowEnd - a.px.rowBegin) * width * kRearchRayKinds);
         launch_pixels(ctx, stream, "rearch_vis_finish", finish, a);
         break;
     }

@@ -186,9 +186,6 @@ GFX_DEV void make_shading_point(const RestirArgs& a, uint32_t bufIdx, size_t p, 
     sp.vOutLocal = sp.frame.to_local(vOut);
     float tu, tv;
     decode_uv(g3.z, tu, tv);
-#if defined(GFX_WHATIF_INIT) && (GFX_WHATIF_INIT & 32)   // timing experiment: no material-texture reads in the reuse passes
-    { gfx_material m = a.scene.materials[g3.w]; m.texA = m.texB = m.texSmoothness = 0u; sp.bsdf.setup(a.scene, m, tu, tv); return; }
-#endif
     sp.bsdf.setup(a.scene, a.scene.materials[g3.w], tu, tv);
 }
 
