@@ -16,6 +16,13 @@ runs every pass on its band only, the strips of G-buffer / reservoir rows the re
 across the seams are exchanged between the passes, and the HDR bands are all-gathered over
 RCCL/xGMI once per frame ("strong" scaling: total work fixed).
 
+--config selects another BASELINE.json configuration (0-based index; the default, 2, is the one the metric is quoted on):
+    1  path tracing on the bunny scene, 512x512, max path length 5 (1 GPU)
+    3  NRC frame (path trace + inference + 4 training steps), hash grid, 1920x1080, street stand-in for Zero-Day (1 GPU)
+    4  ReSTIR DI unbiased + 2048x1024 environment map, 1920x1080 (1..N GPUs, same band split as config 2)
+--animate adds the reference command line's moving rectangle light (restir_di_main.cpp:7-12) and a slowly orbiting camera to
+config 2 / 4: every frame updates the light's transform (in-place rebuild of the animated BVH subtree) and the camera.
+
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
 import argparse
@@ -64,28 +71,31 @@ def _profiled_traffic():
     return None
 
 
-def hbm_stream_peak():
+def hbm_stream_peak(ctx):
     """Streaming-copy rate of THIS box ("measure peak with a streaming-copy microbenchmark on the box, don't quote
-    the datasheet"): device-to-device copy of 1 GiB (4x the 256-MiB Infinity Cache), read + write bytes over the HIP-event
-    time of 10 copies.  tools/hbm_stream.py is the stand-alone form."""
+    the datasheet"): gfx_stream_copy (16-byte loads and stores per lane, non-temporal, grid-stride) over 1 GiB -- 4x the 256-MiB
+    Infinity Cache -- read + write bytes over the HIP-event time of 10 copies.  The torch byte copy of rounds 1-3 read 4.7-5.2 TB/s;
+    the microarchitecture guide quotes 6.29 TB/s for a float4 copy.  tools/hbm_stream.py is the stand-alone form."""
     import torch
     n = 1 << 30
     a = torch.empty(n, dtype=torch.uint8, device="cuda")
     b = torch.empty(n, dtype=torch.uint8, device="cuda")
     a.fill_(1)
+    stream = torch.cuda.current_stream().cuda_stream
     for _ in range(2):
-        b.copy_(a)
+        ctx.stream_copy(b.data_ptr(), a.data_ptr(), n, stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 10
     e0.record()
     for _ in range(reps):
-        b.copy_(a)
+        ctx.stream_copy(b.data_ptr(), a.data_ptr(), n, stream)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
+    ok = bool((b[::4097] == 1).all().item())
     del a, b
     torch.cuda.empty_cache()
-    return round(2 * n / (ms * 1e-3) / 1e9, 1)
+    return round(2 * n / (ms * 1e-3) / 1e9, 1) if ok else None
 
 
 def parse():
@@ -106,7 +116,30 @@ def parse():
                     help="N > 1: strip-exchange callback -- tilesplit.StripExchange over torch.distributed (default) or the C++ gfxh_rccl_exchange")
     ap.add_argument("--cluttered", action="store_true", help="secondary workload: + 70 trees of 6 000 leaf cards, cables, railings (depth complexity)")
     ap.add_argument("--bump", type=int, default=1, help="enableBumpMapping (normal maps) for the textured workload")
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4], help="BASELINE.json configs[] index (0-based); 2 = the metric's configuration")
+    ap.add_argument("--animate", action="store_true", help="configs 2 / 4: moving rectangle light (restir_di_main.cpp:7-12) + slowly orbiting camera")
     return ap.parse_args()
+
+
+BUNNY_OBJ = os.path.join(ROOT, "tests", "golden", "assets", "stanford_bunny_309_faces.obj")   # data fixture (a mesh the reference's harness names)
+
+
+def light_transform(api, t_seconds):
+    """The reference command line's moving rectangle light (restir_di_main.cpp:7-12: -begin-pos / -end-pos, InstanceController::
+    updateBody's cosine ease, 5 s period), placed over the street of the stand-in."""
+    import math
+    t = 0.5 - 0.5 * math.cos(2 * math.pi * (t_seconds % 5.0) / 5.0)
+    pos = ((1 - t) * -6.0 + t * 7.0, 4.5, (1 - t) * 30.0 + t * 12.0)
+    return api.make_transform(pitch=-90.0, yaw=(1 - t) * 150.0 + t * 30.0, pos=pos)
+
+
+def orbit_camera(api, W, H, frame):
+    """A slow orbit around the bench camera's pose: +-0.75 m sideways, +-0.3 m up, +-2 degrees of yaw over 600 frames -- a few
+    pixels of screen-space motion per frame, enough for the temporal hint and the temporal reuse to miss where geometry is close."""
+    import math
+    ph = 2 * math.pi * frame / 600.0
+    return api.make_camera(W, H, pos=(1.5 + 0.75 * math.sin(ph), 2.2 + 0.3 * math.sin(2 * ph), 52.0 - 0.5 * (1 - math.cos(ph))),
+                           pitch=4.0 + 0.5 * math.sin(ph), yaw=181.5 + 2.0 * math.sin(ph))
 
 
 def main():
@@ -117,6 +150,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 and args.config in (1, 3):
+        raise SystemExit(f"--config {args.config} is a single-GPU configuration in BASELINE.json")
+    if world > 1 and args.animate:
+        raise SystemExit("--animate is measured on one GPU (a band renderer needs maxMotionRows for it; not wired into bench.py)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -130,21 +167,62 @@ def main():
     from gfxexp_amd import scenes            # the measured path imports nothing from tests/ or oracle/
 
     W, H = args.width, args.height
+    if args.config == 1:
+        W = H = 512
     t0 = time.time()
     textured = not args.plain
-    hs = scenes.bench_street(textured=textured, cluttered=args.cluttered)
-    counts = hs.counts()
     ctx = api.Context(local_rank)
+    light_slot = None
+    if args.config == 1:
+        hs = scenes.bunny_scene(BUNNY_OBJ)
+    else:
+        hs = scenes.bench_street(textured=textured, cluttered=args.cluttered)
+        if args.animate:
+            light_slot = hs.add_instance(hs.add_rectangle(1.5, 1.5, (60, 60, 60)), light_transform(api, 0.0))
+    counts = hs.counts()
     hs.upload(ctx)
-    cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
-    cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
-    cfg.camera = cam
-    cfg.enableBumpMapping = int(textured and args.bump)
+    if light_slot is not None:
+        ctx.instance_set_dynamic(light_slot)
     bands = tilesplit.band_rows(H, world) if world > 1 else None
     band = tilesplit.band_for_rank(H, world, rank)
-    cfg.rowBegin, cfg.rowEnd = band
-    renderer = api.RestirRenderer(ctx, cfg)
-    accel_stats = ctx.accel_stats(renderer.accel())
+    street = (f"procedural street stand-in ({counts['triangles']} instanced triangles, {counts['insts']} instances, 2100 emitter instances), "
+              + ("textured materials (albedo / smoothness / normal maps with bump mapping, float emittance maps on the signs), " if textured else "constant-colour materials, ")
+              + ("+ trees of leaf cards, cables and railings (depth-complexity variant), " if args.cluttered else ""))
+    if args.config == 1:
+        cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+        cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_PATH_TRACE)
+        cfg.camera = cam
+        renderer = api.RestirRenderer(ctx, cfg)
+        metric = "Mpaths/s, path tracing (BVH8 traversal + BSDF) 512x512 1 spp, stanford_bunny_309_faces"
+        workload = ("configs[1] (0-based index into BASELINE.json): baseline path tracer, bunny (309 faces) + ground + 2 rectangle lights, "
+                    f"{counts['triangles']} triangles, max path length 5, NEE + MIS")
+    elif args.config == 3:
+        cam = api.make_camera(W, H, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
+        cfg = api.NrcRenderer.default_config(W, H, hs.bounds())
+        cfg.camera = cam
+        renderer = api.NrcRenderer(ctx, cfg)
+        metric = "Mpaths/s, NRC frame (path trace + cache inference + 4 training steps) 1920x1080 1 spp, Zero-Day stand-in"
+        workload = ("configs[3] (0-based index into BASELINE.json): neural radiance caching, hash-grid encoding, fully fused 64-wide MLP (2 hidden layers) "
+                    "on bf16 MFMA, training on; " + street + "Zero-Day is not in the reference checkout")
+    else:
+        unbiased = args.config == 4
+        cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
+        cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_UNBIASED if unbiased else api.RENDERER_BIASED)
+        cfg.camera = cam
+        cfg.enableBumpMapping = int(textured and args.bump)
+        cfg.rowBegin, cfg.rowEnd = band
+        renderer = api.RestirRenderer(ctx, cfg)
+        sky = api.env_make_sky(2048, 1024) if unbiased else None
+        if unbiased:
+            renderer.set_env(sky, 2048, 1024, 0.6, 0.4)
+        metric = ("Mpaths/s, ReSTIR DI (original, unbiased) + environment light 1920x1080 1 spp, Bistro-Exterior stand-in" if unbiased
+                  else "Mpaths/s, ReSTIR DI (original, biased) 1920x1080 1 spp, Bistro-Exterior stand-in")
+        workload = (f"configs[{args.config}] (0-based index into BASELINE.json): ReSTIR DI " + ("unbiased, 2048x1024 sky + sun environment map, " if unbiased else "biased, ")
+                    + street.replace("procedural street stand-in", "procedural street stand-in for Bistro Exterior")
+                    + ("32 candidates, temporal + 1x3 spatial reuse with MIS rays, radius 20, visibility reuse" if unbiased
+                       else "32 candidates, temporal + 2x5 spatial reuse, radius 20, visibility reuse")
+                    + (", moving rectangle light (animated BVH subtree rebuilt per frame) + orbiting camera" if args.animate else ""))
+    accel_stats = ctx.accel_stats(renderer.accel()) if hasattr(renderer, "accel") else None
     setup_s = time.time() - t0
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -202,13 +280,25 @@ def main():
                 renderer.close()
                 cfg.rowBegin, cfg.rowEnd = bands[rank]
                 renderer = api.RestirRenderer(ctx, cfg)
+                if args.config == 4:
+                    renderer.set_env(sky, 2048, 1024, 0.6, 0.4)
                 exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda", async_gather=True, bands=bands)
                 renderer.set_exchange(exchange, 0)
 
+    frame_no = [0]
+
     def frame():
+        if args.animate:
+            # InstanceController::update + updateASs of the reference's frame loop (restir_di_main.cpp:2258-2264), at 60 frames per second
+            ctx.instance_set_transform(light_slot, light_transform(api, frame_no[0] / 60.0))
+            renderer.rebuild_accel(stream)
+            renderer.set_camera(orbit_camera(api, W, H, frame_no[0]))
         renderer.render_frame(stream)
+        frame_no[0] += 1
 
     def barrier():
+        if args.config == 3:
+            renderer.network()                            # joins the training stream of the last frame
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -233,40 +323,46 @@ def main():
     mpaths = W * H * args.steps / elapsed / 1e6
 
     result = {
-        "metric": "Mpaths/s, ReSTIR DI (original, biased) 1920x1080 1 spp, Bistro-Exterior stand-in",
+        "metric": metric,
         "value": round(mpaths, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[2] (0-based index into BASELINE.json): ReSTIR DI biased, procedural street stand-in for Bistro Exterior "
-                               f"({counts['triangles']} instanced triangles, {counts['insts']} instances, "
-                               "2100 emitter instances), "
-                               + ("textured materials (albedo / smoothness / normal maps with bump mapping, float emittance maps on the signs), "
-                                  if textured else "constant-colour materials, ")
-                               + ("+ trees of leaf cards, cables and railings (depth-complexity variant), " if args.cluttered else "")
-                               + "32 candidates, temporal + 2x5 spatial reuse, radius 20, visibility reuse",
+        # the frame is fixed and split across the GPUs: total work does not grow with N (also the label of the N = 1 point of that curve)
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32" if args.config != 3 else "f32 path tracing + bf16 MFMA network (fp32 accumulate, fp32 master weights)", "data": "synthetic",
+        "config": {"workload": workload,
                    "width": W, "height": H, "spp": 1, "parallelism": f"row-bands x{world}" if world > 1 else "single GPU",
                    "bands": bands,
-                   "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]},
+                   "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]} if accel_stats else None,
                    "light_table": ctx.lights_table_info()},
         "setup_s": round(setup_s, 2),
     }
 
     if rank == 0 and world == 1:
         if not args.no_roofline:
-            # per-kernel durations come from a second renderer that runs every pass on ONE stream: with the frame
-            # pipelining of the timed renderer the next frame's G-buffer pass overlaps the spatial / shading passes
-            # and both read longer than they are
-            os.environ["GFX_SERIAL_FRAMES"] = "1"
-            serial = api.RestirRenderer(ctx, cfg)
-            del os.environ["GFX_SERIAL_FRAMES"]
-            for _ in range(3):
-                serial.render_frame(stream)
-            result["roofline"], result["kernels_ms_per_frame"] = roofline(ctx, serial, stream, args.steps, W, H)
-            serial.close()
-        if args.mse_ref_spp > 0:
+            if args.config == 3:
+                result["roofline"], result["kernels_ms_per_frame"], result["nrc"] = roofline_nrc(ctx, renderer, stream, W, H)
+            else:
+                # per-kernel durations come from a second renderer that runs every pass on ONE stream: with the frame
+                # pipelining of the timed renderer the next frame's G-buffer pass overlaps the spatial / shading passes
+                # and both read longer than they are
+                os.environ["GFX_SERIAL_FRAMES"] = "1"
+                serial = api.RestirRenderer(ctx, cfg)
+                del os.environ["GFX_SERIAL_FRAMES"]
+                if args.config == 4:
+                    serial.set_env(sky, 2048, 1024, 0.6, 0.4)
+                for _ in range(3):
+                    serial.render_frame(stream)
+                result["roofline"], result["kernels_ms_per_frame"] = roofline(ctx, serial, stream, args.steps, W, H, args.config)
+                serial.close()
+        if args.mse_ref_spp > 0 and args.config == 2 and not args.animate:
             result["mse"] = mse_vs_reference(ctx, hs, renderer, cam, W, H, args.mse_ref_spp)
         if args.cpu_sample not in ("0", ""):
-            result["cpu_baseline"] = cpu_baseline(hs, cam, args.cpu_sample, W, H)
+            if args.config in (2, 4) and not args.animate:
+                result["cpu_baseline"] = cpu_baseline(hs, cam, args.cpu_sample, W, H, unbiased=args.config == 4, env=(sky, 2048, 1024, 0.6, 0.4) if args.config == 4 else None)
+            elif args.config == 1:
+                result["cpu_baseline"] = cpu_baseline_path_tracer(hs, cam, W, H)
+            else:
+                result["cpu_baseline"] = {"value": None, "unit": "Mpaths/s", "cores": 0, "kind": "port",
+                                          "sample": "not timed for this line: see the default line (configs[2], static) for the CPU restatement on this host"}
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -61,9 +61,7 @@ int gfx_ctx_create(int device, gfx_ctx** out) {
         t.traceRefill = env_int("GFX_TRACE_REFILL", t.traceRefill, 1, 64);
         t.traceBatch = env_int("GFX_TRACE_BATCH", t.traceBatch, 1, 65536);
         t.temporalHints = env_int("GFX_TEMPORAL_HINTS", t.temporalHints, 0, 1);
-        t.anyHints = env_int("GFX_ANY_HINTS", t.anyHints, 0, 2);
-        { const int sgm = env_int("GFX_TRACE_SEGMENTS", t.traceSegments, 0, 8); if (sgm == 0 || sgm == 1 || sgm == 2 || sgm == 4 || sgm == 8) t.traceSegments = sgm; }
-        t.traceSegFill = env_int("GFX_TRACE_SEG_FILL", t.traceSegFill, 1, 64);
+        t.traceCompact = env_int("GFX_TRACE_COMPACT", t.traceCompact, 0, 63);
         ctx->c.dTraceCounters.reserve(64);
         GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 64));
         *out = ctx.release();
@@ -504,9 +502,8 @@ int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value) {
     else if (n == "trace_refill") t.traceRefill = in(1, 64);
     else if (n == "temporal_hints") t.temporalHints = in(0, 1);
     else if (n == "trace_batch") t.traceBatch = in(1, 65536);
-    else if (n == "any_hints") t.anyHints = in(0, 2);
-    else if (n == "trace_segments") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) throw HipError("gfx_tunable_set: trace_segments is 0 (auto), 1, 2, 4 or 8"); t.traceSegments = value; }
-    else if (n == "trace_seg_fill") t.traceSegFill = in(1, 64);
+    else if (n == "trace_compact") t.traceCompact = in(0, 63);
+
     else throw HipError("gfx_tunable_set: unknown tunable " + n);
     GFX_CATCH(ctx)
 }

@@ -94,10 +94,8 @@ struct Tunables {
     int traceRefill = 8;             // refill a wave when at least this many lanes are idle
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
     int temporalHints = 1;           // primary rays test the triangle their pixel hit one frame ago first (trace.hip)
-    int anyHints = 1;                // slot-addressed shadow rays test the occluder their pixel found one frame ago first: 0 off, 1 on (an
-                                     // unoccluded ray clears its slot's hint), 2 on (an unoccluded ray keeps it)
-    int traceSegments = 0;           // lanes per ray in k_trace (ray segments): 1 / 2 / 4 / 8, or 0 = by the launch's size (trace.hip)
-    int traceSegFill = 4;            // auto mode: 4 segments up to traceSegFill / 4 rays per lane of the persistent grid, 2 up to twice that
+    int traceCompact = 32;           // wave compaction in k_trace: once the queue is dry, a wave with at most this many live rays hands them to
+                                     // the other waves of its block and exits (0: off)
 };
 
 struct Context {
@@ -154,9 +152,6 @@ struct Context {
     // The G-buffer pass has its own ray queue / hit / stack-spill / ticket scratch, so a driver may run the next
     // frame's G-buffer pass on a second stream underneath the tail of the current frame (restir_driver.cpp).
     DevBuf gbRayOrg, gbRayDir, gbRayHits, gbSpill, gbCounters;
-    // occluder hints of the two slot-addressed shadow-ray launches of original ReSTIR (visibility of the selected candidate, final
-    // shadow ray): one word per launch slot, kept from frame to frame (TraceLaunch::anyHint)
-    DevBuf anyHintInitial, anyHintShade;
     // path tracer scratch (pathtrace.hip)
     DevBuf ptPending, ptExtOrg, ptExtDir, ptExtOwner, ptState;
     DevBuf rearchSlots;
@@ -220,9 +215,6 @@ struct TraceLaunch {
     uint32_t* perRayItems = nullptr; // counting launches: items fetched per ray
     uint32_t* zeroWords[2] = { nullptr, nullptr };   // device words the launch sets to zero (queue heads the NEXT pass appends to:
                                     // saves the path tracers two memsets per bounce); must not be this launch's own count
-    uint32_t maxRays = 0;           // with numRaysPtr: an upper bound of the device-side count (0: unknown); sizes the ray segments
-    uint32_t* anyHint = nullptr;    // any-hit launches over a fixed slot -> pixel assignment: per slot, the occluder found by the previous
-                                    // launch of the same pass (triangle + 1, 0 = none); read and rewritten by the launch (trace.hip)
     bool hintFromOut = false;       // closest-hit: out[] still holds the previous launch's results for the same rays (primary rays of
                                     // the previous frame): each ray tests that triangle first (trace.hip)
 };

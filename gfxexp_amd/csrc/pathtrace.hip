@@ -1281,7 +1281,6 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         TraceLaunch t;
         t.accel = accel; t.rayOrgTmin = org; t.rayDirTmax = dir; t.numRays = 0; t.numRaysPtr = count; t.out = out; t.mode = mode;
         t.zeroWords[0] = zero0; t.zeroWords[1] = zero1;
-        t.maxRays = static_cast<uint32_t>(grid) * kPtBlock;   // the queues' capacity (the band's pixels): sizes the ray segments
         trace_launch(ctx, stream, t);
     };
 

@@ -739,17 +739,8 @@ static void launch_pixels(Context& ctx, hipStream_t stream, const char* name, K 
     GFX_HIP(hipGetLastError());
 }
 
-// The occluder hints of a slot-addressed shadow-ray pass: one word per launch slot of the frame, zero when (re)allocated.
-static uint32_t* any_hint_buffer(Context& ctx, hipStream_t stream, DevBuf& buf, uint32_t width, uint32_t height) {
-    const size_t bytes = 4 * static_cast<size_t>(make_pixel_grid(ctx, width, 0, height).launchBlocks) * kBlock;
-    if (buf.bytes < bytes) { buf.reserve(bytes); GFX_HIP(hipMemsetAsync(buf.p, 0, buf.bytes, stream)); }
-    return buf.as<uint32_t>();
-}
-
-static void trace_queue(Context& ctx, hipStream_t stream, const RestirArgs& a, int mode, uint32_t fixedCount, bool useCounter, void* out,
-                        uint32_t* anyHint = nullptr, uint32_t maxRays = 0) {
+static void trace_queue(Context& ctx, hipStream_t stream, const RestirArgs& a, int mode, uint32_t fixedCount, bool useCounter, void* out) {
     TraceLaunch t;
-    t.anyHint = anyHint; t.maxRays = maxRays;
     t.accel = ctx.accels[ctx.restir.f.travHandle - 1]->dev();
     t.rayOrgTmin = a.rayOrg; t.rayDirTmax = a.rayDir;
     t.numRays = fixedCount; t.numRaysPtr = useCounter ? a.rayCount : nullptr;
@@ -850,8 +841,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
             else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);
             GFX_HIP(hipGetLastError());
         }
-        trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p,   // one entry per launch slot (emit_ray_at_slot)
-                    any_hint_buffer(ctx, stream, ctx.anyHintInitial, width, height));
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p);   // one entry per launch slot (emit_ray_at_slot)
         if (pass == GFX_RESTIR_INITIAL_RIS) launch_pixels(ctx, stream, "temporal_none", k_temporal<0>, a);
         else if (pass == GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED) launch_pixels(ctx, stream, "temporal_biased", k_temporal<1>, a);
         else launch_pixels(ctx, stream, "temporal_unbiased", k_temporal<2>, a);
@@ -862,14 +852,12 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     case GFX_RESTIR_SPATIAL_UNBIASED:
         reset_queue();
         launch_pixels(ctx, stream, "spatial_unbiased_select", k_spatial<true>, a);
-        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p, nullptr,
-                    (a.px.rowEnd - a.px.rowBegin) * width * (1u + static_cast<uint32_t>(a.f.numSpatialNeighbors)));
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
         launch_pixels(ctx, stream, "spatial_unbiased_finish", k_spatial_mis_finish, a);
         break;
     case GFX_RESTIR_SHADING:
         launch_pixels(ctx, stream, "shade_prepare", k_shade_prepare, a);
-        trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p,   // one entry per launch slot (emit_ray_at_slot)
-                    any_hint_buffer(ctx, stream, ctx.anyHintShade, width, height));
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p);   // one entry per launch slot (emit_ray_at_slot)
         launch_pixels(ctx, stream, "shade_finish", k_shade_finish, a);
         break;
     case GFX_RESTIR_LIGHT_PRESAMPLING: {
@@ -909,7 +897,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
 #undef GFX_REARCH_CASE
         }
         launch_pixels(ctx, stream, "rearch_emit", emit, a);
-        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p, nullptr, (a.px.rowEnd - a.px.rowBegin) * width * kRearchRayKinds);
+        trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
         launch_pixels(ctx, stream, "rearch_vis_finish", finish, a);
         break;
     }

@@ -30,8 +30,6 @@ struct TraceArgs {
     const uint32_t* numRaysPtr;
     uint32_t numRays;
     void* out;
-    uint32_t* anyHint;          // optional (any-hit): per ray slot, the occluder the slot's ray found in the previous launch as triangle + 1
-                                // (0: none); read when the ray starts, rewritten with the result (TraceLaunch::anyHint)
     uint32_t* ticket;           // kTicketCounters queue heads, kTicketStride words apart (zero at the start of the launch)
     uint32_t* ticketNext;       // the area the NEXT launch on this buffer draws from: block 0 zeroes it
     uint32_t* zeroWords[2];     // optional: words block 0 sets to zero (TraceLaunch::zeroWords)
@@ -42,92 +40,47 @@ struct TraceArgs {
     int refillThreshold;        // refill when at least this many lanes are idle
     int ticketBatch;            // rays bought per device atomic
     int hintFromOut;            // closest-hit launches: out[i].triIndex of the previous launch is ray i's first triangle to test
-    int keepAnyHint;            // any-hit launches with anyHint: an unoccluded ray leaves its slot's hint as it is
+    int compactBelow;           // wave compaction: a wave left with at most this many live rays hands them to the block's other waves (0: off)
 };
 
-// ---------------------------------------------------------------- ray segments (SEG > 1)
-// A launch that does not fill the machine lasts as long as its longest ray: one ray per lane, nothing to refill, up to 86 dependent
-// 64-byte fetches at 1.5-3 us each for a primary ray of the bench street while the mean ray needs 14 (profiles/r02_band_notes.txt) --
-// the wall a rank's band of an 8-way split frame runs into.  Such a launch cuts every ray into SEG pieces along t and gives each
-// piece its own lane: SEG adjacent lanes hold the SEG segments (lo_k, hi_k) of one ray, each a traversal of its own with the
-// segment as its interval, so the dependent chain of a long ray shrinks to about 1/SEG of its leaf-level items plus the common
-// ancestors.  The segments PARTITION the ray's interval exactly -- whatever the split points are, every t with tmin < t < tmax
-// falls into exactly one of them (segment k accepts m_k < t <= m_k+1, the first one tmin < t, the last one t < tmax) -- and the
-// triangle test does not read the interval (ray_triangle computes t, b, c from origin and direction alone), so:
-//   any-hit      the ray is occluded iff one of its segments is;
-//   closest-hit  the hit is the hit of the first segment that has one (equal t -> same segment -> the tie rule applies inside it).
-// Same answers, bit for bit; the split points only decide how evenly the work is shared.  They are taken uniformly over the
-// part of the ray inside the root's box (read from node 0 once per wave).  A segment that finds a hit retires the segments it
-// makes pointless (any-hit: all others; closest-hit: the ones behind it) through one ballot per iteration; the group's leader
-// lane writes the merged result once all SEG lanes are idle, and only then is the group refilled.
-template <int SEG> struct SegConst {
-    static constexpr unsigned long long leaderBits = SEG == 2 ? 0x5555555555555555ull : SEG == 4 ? 0x1111111111111111ull : SEG == 8 ? 0x0101010101010101ull : ~0ull;
-    static constexpr uint32_t groupMask = (1u << SEG) - 1u;
+// ---------------------------------------------------------------- wave compaction
+// An iteration of the wave loop costs the same ~340 instructions whether 5 or 60 lanes hold a ray, and once the queue is dry
+// nothing refills the lanes that finish: the full frame spends 14 % of its wave iterations in that drain at a quarter of the lanes,
+// a rank's band of an 8-way split frame more than half of them (profiles/r04_band_diag.jsonl) -- issue slots that carry no ray.  So a
+// wave that is down to a few live rays after the queue has run dry ORPHANS them: every live lane leaves a 64-byte record
+// (Traversal::suspend) in the wave's fetch buffer -- which the wave no longer needs -- publishes the lanes in a mask in LDS, and
+// the wave exits.  A wave of the same block that has idle lanes ADOPTS orphans instead of new rays: the record restores the
+// traversal state (Traversal::resume recomputes the per-ray constants from origin and direction with begin()'s own code) and the
+// lane's stack pointer is re-pointed at the orphan's LDS column, so the stack is adopted without a copy.  A ray continues with exactly the state it was
+// suspended with: same items, same tests, same result -- only in another lane.
+//   * `alive` (low half) counts the block's waves that have neither orphaned their rays nor left; a wave may orphan only while
+//     another wave is alive: it claims its leave first (alive - 1 and, in the high half, publishing + 1, one compare-and-swap that
+//     requires alive > 1), then writes the records, publishes the mask and takes publishing back down.  A refused wave finishes its rays.
+//   * a wave with nothing left to do leaves (alive - 1); the one that finds itself last waits until no dumper is between claim and
+//     publication, re-checks the masks and keeps adopting until they are empty -- nothing is lost, and records are only ever read
+//     from waves that have exited (their fetch buffers are never written again).
+//   * rays whose stack has spilled past the LDS column stay where they are (the spill area is addressed per lane).
+struct CompactShared {
+    unsigned long long orphans[kTraceBlock / 64];   // per wave: lanes whose record + stack column wait for adoption
+    uint32_t alive;
 };
-
-struct SceneBox { f3 lo, hi; };
-// World box of the root's children in the traversal's own decode (origin + q * scale): conservative enough for choosing split points,
-// which is all it is used for.  Every lane computes the same values (the loads are broadcasts).
-GFX_DEV SceneBox root_box(const DevAccel& acc) {
-    const uint4* n = reinterpret_cast<const uint4*>(acc.nodes);
-    const uint4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-    const uint32_t valid = reinterpret_cast<const uint4*>(acc.links)[0].z;
-    const f3 origin(bits2f(n0.x), bits2f(n0.y), bits2f(n0.z));
-    const f3 scale(bits2f(bfe(n0.w, 0, 8) << 23), bits2f(bfe(n0.w, 8, 8) << 23), bits2f(bfe(n0.w, 16, 8) << 23));
-    const uint32_t lx[2] = { n1.x, n1.y }, ly[2] = { n1.z, n1.w }, lz[2] = { n2.x, n2.y };
-    const uint32_t hx[2] = { n2.z, n2.w }, hy[2] = { n3.x, n3.y }, hz[2] = { n3.z, n3.w };
-    SceneBox b; b.lo = f3(3.0e38f); b.hi = f3(-3.0e38f);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        if (!((valid >> s) & 1u)) continue;
-        const int w = s >> 2, sh = (s & 3) * 8;
-        b.lo.x = fminf(b.lo.x, fmaf(static_cast<float>((lx[w] >> sh) & 0xFFu), scale.x, origin.x));
-        b.lo.y = fminf(b.lo.y, fmaf(static_cast<float>((ly[w] >> sh) & 0xFFu), scale.y, origin.y));
-        b.lo.z = fminf(b.lo.z, fmaf(static_cast<float>((lz[w] >> sh) & 0xFFu), scale.z, origin.z));
-        b.hi.x = fmaxf(b.hi.x, fmaf(static_cast<float>((hx[w] >> sh) & 0xFFu), scale.x, origin.x));
-        b.hi.y = fmaxf(b.hi.y, fmaf(static_cast<float>((hy[w] >> sh) & 0xFFu), scale.y, origin.y));
-        b.hi.z = fmaxf(b.hi.z, fmaf(static_cast<float>((hz[w] >> sh) & 0xFFu), scale.z, origin.z));
-    }
-    return b;
-}
-// the next float above m (m finite, not NaN): t < next_up(m)  <=>  t <= m
-GFX_DEV float next_up(float m) {
-    const float x = m + 0.0f;                       // -0 -> +0
-    const uint32_t b = f2bits(x);
-    return bits2f(x >= 0.0f ? b + 1u : b - 1u);
-}
-// Interval of segment `seg` of SEG of the ray (o, d, tmin, tmax), tmax > tmin: see the partition argument above.
-template <int SEG>
-GFX_DEV void segment_interval(f3 o, f3 d, float tmin, float tmax, const SceneBox& box, int seg, float& lo, float& hi) {
-    const float dx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
-    const float dy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
-    const float dz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    const float ax = (box.lo.x - o.x) * ix, bx = (box.hi.x - o.x) * ix;
-    const float ay = (box.lo.y - o.y) * iy, by = (box.hi.y - o.y) * iy;
-    const float az = (box.lo.z - o.z) * iz, bz = (box.hi.z - o.z) * iz;
-    float a = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    float b = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-    if (!(b > a)) { a = tmin; b = tmin; }           // the ray misses the box (or NaNs): the last segment gets everything
-    // split point k (1 .. SEG - 1), the same expression in both lanes that use it; NaN / out of range -> clamped into [tmin, tmax]
-    auto split = [&](int k) { return fminf(fmaxf(fmaf(b - a, static_cast<float>(k) * (1.0f / SEG), a), tmin), tmax); };
-    lo = seg == 0 ? tmin : split(seg);
-    hi = seg == SEG - 1 ? tmax : fminf(next_up(split(seg + 1)), tmax);
-}
 
 // fetch_items: coop_fetch.hip.h (the cooperative 64-byte gather; the candidate kernel of restir.hip uses it for emitter records).
 #ifndef GFX_TRACE_MIN_WAVES
 #define GFX_TRACE_MIN_WAVES 1
 #endif
-template <bool ANY_HIT, bool COUNT, int SEG>
+template <bool ANY_HIT, bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(TraceArgs a) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kTraceBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[kTraceBlock * 4];   // 4 KiB per wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int seg = lane & (SEG - 1);                  // which segment of its ray this lane traverses (SEG == 1: the ray)
-    const int leader = lane & ~(SEG - 1);              // first lane of the group of SEG lanes that share a ray
-    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, kept scalar
+    __shared__ CompactShared compact;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint4* waveBuf = fetchBuf + 256 * wave;   // wave-uniform, kept scalar
+    if (tid < kTraceBlock / 64) compact.orphans[tid] = 0ull;
+    if (tid == 0) compact.alive = kTraceBlock / 64;
+    __syncthreads();
     LaneStack stack;
     stack.lds = ldsStack + tid;
     stack.ldsStride = kTraceBlock;
@@ -138,37 +91,29 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     if (blockIdx.x == 0 && tid < 2 && a.zeroWords[tid]) *a.zeroWords[tid] = 0u;
     const uint32_t n = a.numRaysPtr ? *a.numRaysPtr : a.numRays;
     const bool hasNodes = a.accel.numNodes != 0;
-    SceneBox box; box.lo = f3(0.0f); box.hi = f3(0.0f);
-    if (SEG > 1 && hasNodes) box = root_box(a.accel);
 
     Traversal tr;
     tr.active = false;
-    tr.hit.tri = GFX_INVALID_SLOT;
     uint32_t rayIdx = 0;
-    bool hasRay = false;              // SEG > 1: the group holds a ray whose merged result is not written yet (same in all its lanes)
     bool exhausted = false;           // wave-uniform: the queue has no more rays
+    // wave compaction (wave-uniform): this wave has decremented `alive` (it is the block's last one, finishing the orphans); it may not
+    // orphan its rays any more (it was refused once: it is the last wave alive)
+    bool left = false, mayOrphan = a.compactBelow > 0 && !(COUNT && a.perRayItems);
+    const bool compaction = mayOrphan;
     uint32_t waveNext = 0, waveEnd = 0; // wave-uniform: rays [waveNext, waveEnd) already ticketed for this wave
     uint32_t myCounter = (blockIdx.x * (kTraceBlock / 64) + (tid >> 6)) % kTicketCounters;   // wave-uniform: the counter this wave draws from
     uint32_t dryCounters = 0;         // wave-uniform: counters this wave has seen run dry
     const uint32_t numChunks = (n + static_cast<uint32_t>(a.ticketBatch) - 1u) / static_cast<uint32_t>(a.ticketBatch);
     TraceCounters cnt = { 0, 0, 0 };
     uint32_t raysDone = 0, rayItems = 0;
-    bool traversed = false;           // COUNT: this lane's ray (segment) entered the tree
     uint32_t diagIter = 0, diagLanes = 0, diagDrainIter = 0, diagDrainLanes = 0;   // wave-uniform (COUNT only)
     // COUNT only: where a wave's clock cycles go (s_memtime): ray refill (ticket + ray loads + setup), item fetch (issue to data in
     // registers), item processing (slab / triangle tests); the rest is item selection and loop overhead
     unsigned long long cycRefill = 0, cycFetch = 0, cycProcess = 0;
     const unsigned long long cycStart = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
 
-    // SEG == 1: the lane's own result, written the moment its ray finishes.  SEG > 1: nothing here -- the group's leader writes the
-    // merged result at the top of the loop once all its lanes are idle.
     auto write_result = [&]() {
-        if (SEG > 1) return;
-        if (ANY_HIT) {
-            const bool occluded = tr.hit.tri != GFX_INVALID_SLOT;
-            static_cast<uint32_t*>(a.out)[rayIdx] = occluded ? 1u : 0u;
-            if (a.anyHint && (occluded || !a.keepAnyHint)) a.anyHint[rayIdx] = occluded ? tr.hit.tri + 1u : 0u;
-        }
+        if (ANY_HIT) static_cast<uint32_t*>(a.out)[rayIdx] = tr.hit.tri != GFX_INVALID_SLOT ? 1u : 0u;
         else {
             gfx_hit h; h.dist = tr.hit.t; h.bcB = tr.hit.bcB; h.bcC = tr.hit.bcC; h.triIndex = tr.hit.tri;
             static_cast<gfx_hit*>(a.out)[rayIdx] = h;
@@ -178,46 +123,12 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
 
     while (true) {
         const unsigned long long cyc0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
-        unsigned long long idleMask = __ballot(!tr.active);     // SEG == 1: idle lanes; SEG > 1: leader bits of refillable groups (below)
-        if (SEG > 1) {
-            const bool groupIdle = ((idleMask >> leader) & SegConst<SEG>::groupMask) == SegConst<SEG>::groupMask;
-            const bool finish = hasRay && groupIdle;
-            if (__ballot(finish) != 0ull) {
-                // the first segment with a hit holds the ray's result (any-hit: any of them will do)
-                const unsigned long long found = __ballot(tr.hit.tri != GFX_INVALID_SLOT);
-                const uint32_t gbits = static_cast<uint32_t>(found >> leader) & SegConst<SEG>::groupMask;
-                const int src = leader + (gbits ? __builtin_ctz(gbits) : 0);
-                const uint32_t tri = __shfl(tr.hit.tri, src);
-                if (ANY_HIT) {
-                    if (finish && seg == 0) {
-                        static_cast<uint32_t*>(a.out)[rayIdx] = gbits ? 1u : 0u;
-                        if (a.anyHint && (gbits || !a.keepAnyHint)) a.anyHint[rayIdx] = gbits ? tri + 1u : 0u;
-                    }
-                }
-                else {
-                    gfx_hit h;
-                    h.dist = __shfl(tr.hit.t, src); h.bcB = __shfl(tr.hit.bcB, src); h.bcC = __shfl(tr.hit.bcC, src); h.triIndex = tri;
-                    // no segment has a hit: every lane still holds bcB = bcC = 0 and its own upper bound; the ray's is the last segment's
-                    const float tmaxRay = __shfl(tr.hit.t, leader + SEG - 1);
-                    if (!gbits) h.dist = tmaxRay;
-                    if (finish && seg == 0) static_cast<gfx_hit*>(a.out)[rayIdx] = h;
-                }
-                if (COUNT) {
-                    uint32_t items = rayItems;
-                    bool any = traversed;
-#pragma unroll
-                    for (int off = 1; off < SEG; off <<= 1) { items += __shfl_xor(items, off); const int other = __shfl_xor(any ? 1 : 0, off); any = any || other != 0; }
-                    if (finish && seg == 0) { if (any) ++raysDone; if (a.perRayItems) a.perRayItems[rayIdx] = items; }
-                }
-                if (finish) hasRay = false;
-            }
-            idleMask = __ballot(!hasRay) & SegConst<SEG>::leaderBits;
-        }
-        const int numIdle = __popcll(idleMask);                 // idle lanes (SEG == 1) / idle groups
+        const unsigned long long idleMask = __ballot(!tr.active);
+        const int numIdle = __popcll(idleMask);
         bool newRay = false;
         float4 rayO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rayD = rayO;
         uint32_t hint = 0xFFFFFFFFu;
-        if (!exhausted && numIdle * SEG >= a.refillThreshold) {
+        if (!exhausted && numIdle >= a.refillThreshold) {
             // wave-local ticket range: one device atomic buys a batch of rays, bought on demand
             // (buying ahead of need strands rays in waves that finish late; measured slower)
             if (waveNext == waveEnd) {
@@ -242,8 +153,8 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
                 else { waveNext = chunk * static_cast<uint32_t>(a.ticketBatch); waveEnd = min(waveNext + static_cast<uint32_t>(a.ticketBatch), n); }
             }
             const uint32_t take = min(static_cast<uint32_t>(numIdle), waveEnd - waveNext);
-            if (SEG > 1 ? !hasRay : !tr.active) {
-                const uint32_t rank = __popcll(idleMask & ((1ull << leader) - 1ull));   // SEG == 1: leader == lane
+            if (!tr.active) {
+                const uint32_t rank = __popcll(idleMask & ((1ull << lane) - 1ull));
                 if (rank < take) {
                     // only the loads are issued here: a new ray's first item is the root node whatever the ray is, so it asks for it
                     // in this very iteration and its origin / direction arrive together with the items (one wait for both)
@@ -255,20 +166,101 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
                     // again the traversal descends with the right upper bound and skips what lies behind it; the answer cannot change
                     // (closest hit with the order-independent tie rule), a stale or garbage index costs one triangle test.
                     if (!ANY_HIT && a.hintFromOut) hint = static_cast<const gfx_hit*>(a.out)[i].triIndex;
-                    // Any-hit: the occluder this slot's ray found in the previous launch (the same pixel's shadow ray one frame ago) is
-                    // the FIRST item, before the root: whichever triangle stops an any-hit ray, the answer is "occluded"
-                    // (optix_restir_di_kernels.cu:5-8 sets visibility 0 on any hit), so the order of the tests cannot change it.
-                    if (ANY_HIT && a.anyHint) hint = a.anyHint[i] - 1u;
                     rayIdx = i;
                     newRay = true;
-                    hasRay = true;
                 }
             }
             waveNext += take;
         }
+        if (compaction && exhausted) {
+            const int numActive = 64 - numIdle;
+            unsigned long long m[kTraceBlock / 64];
+#pragma unroll
+            for (int w = 0; w < kTraceBlock / 64; ++w) m[w] = __hip_atomic_load(&compact.orphans[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int src = -1;
+#pragma unroll
+            for (int w = kTraceBlock / 64 - 1; w >= 0; --w) if (m[w] != 0ull && w != wave) src = w;
+            if (src >= 0 && numIdle >= a.refillThreshold) {
+                // ---- adopt: lane 0 claims up to numIdle of the lowest orphans of wave `src`
+                unsigned long long claimed = 0ull;
+                if (lane == 0) {
+                    unsigned long long seen = __hip_atomic_load(&compact.orphans[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    while (seen != 0ull) {
+                        unsigned long long take = seen;
+                        if (__popcll(seen) > numIdle) {                       // keep the numIdle lowest bits
+                            take = 0ull;
+                            unsigned long long rest = seen;
+                            for (int k = 0; k < numIdle; ++k) { take |= rest & (0ull - rest); rest &= rest - 1ull; }
+                        }
+                        if (__hip_atomic_compare_exchange_strong(&compact.orphans[src], &seen, seen & ~take, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { claimed = take; break; }
+                    }
+                }
+                claimed = __shfl(claimed, 0);
+                if (claimed != 0ull) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const uint32_t rank = __popcll(idleMask & ((1ull << lane) - 1ull));
+                    if (!tr.active && rank < static_cast<uint32_t>(__popcll(claimed))) {
+                        unsigned long long rest = claimed;
+                        for (uint32_t k = 0; k < rank; ++k) rest &= rest - 1ull;
+                        const int orphanLane = __builtin_ctzll(rest);
+                        const uint4* rec = fetchBuf + 256 * src + 4 * orphanLane;
+                        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                        tr.resume(r0, r1, r2, r3);
+                        rayIdx = r2.w;
+                        stack.sp = static_cast<int>((r3.w >> 16) & 0x7Fu);
+                        const uint32_t column = r3.w >> 24;
+                        stack.lds = ldsStack + column;                  // the orphan's stack column, adopted in place
+                    }
+                }
+            }
+            else if (src < 0 && mayOrphan && numActive > 0 && numActive <= a.compactBelow && __ballot(tr.active && stack.sp > kLdsStackDepth) == 0ull) {
+                // ---- orphan: claim the right to leave first (alive - 1, "publishing" + 1, only while another wave is alive), then the
+                // records into this wave's fetch buffer (never used again), then the mask, then publishing - 1
+                uint32_t ok = 0;
+                if (lane == 0) {
+                    uint32_t v = __hip_atomic_load(&compact.alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    while ((v & 0xFFFFu) > 1u && !ok)
+                        if (__hip_atomic_compare_exchange_strong(&compact.alive, &v, v - 1u + 0x10000u, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) ok = 1u;
+                }
+                ok = __shfl(ok, 0);
+                if (!ok) mayOrphan = false;                               // the last wave alive finishes what it has
+                else {
+                    if (tr.active) {
+                        uint4 r0, r1, r2, r3;
+                        tr.suspend(rayIdx, static_cast<uint32_t>(stack.sp), static_cast<uint32_t>(stack.lds - ldsStack), r0, r1, r2, r3);
+                        uint4* rec = waveBuf + 4 * lane;
+                        rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) {
+                        __hip_atomic_store(&compact.orphans[wave], ~idleMask, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&compact.alive, 0u - 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    break;
+                }
+            }
+        }
         if (COUNT) cycRefill += __builtin_amdgcn_s_memtime() - cyc0;
         if (__ballot(tr.active || newRay) == 0ull) {
-            if (exhausted && (SEG == 1 || __ballot(hasRay) == 0ull)) break;
+            if (!exhausted) continue;
+            if (!compaction) break;
+            // nothing to do here: orphans of another wave first; else leave -- and the wave that finds itself the last one alive
+            // looks again (a dumper publishes before it decrements `alive`) and stays until the masks are empty
+            unsigned long long pending = 0ull;
+#pragma unroll
+            for (int w = 0; w < kTraceBlock / 64; ++w) if (w != wave) pending |= __hip_atomic_load(&compact.orphans[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (pending != 0ull) continue;
+            if (left) break;
+            uint32_t before = 0;
+            if (lane == 0) {
+                before = __hip_atomic_fetch_add(&compact.alive, 0xFFFFFFFFu, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // the last one waits for dumpers that have claimed their leave but not published yet
+                if ((before & 0xFFFFu) == 1u)
+                    while ((__hip_atomic_load(&compact.alive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) != 0u) __builtin_amdgcn_s_sleep(1);
+            }
+            before = __shfl(before, 0);
+            left = true; mayOrphan = false;
+            if ((before & 0xFFFFu) > 1u) break;
             continue;
         }
         uint32_t code = kItemNone;
@@ -276,8 +268,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             code = tr.next_item(stack, a.accel.triItemOffset);
             if (code == kItemNone) write_result();          // traversal finished
         }
-        const bool hintFirst = ANY_HIT && newRay && hasNodes && hint < a.accel.numTris;
-        if (newRay && hasNodes) code = hintFirst ? (kItemTri | (a.accel.triItemOffset + hint)) : 0u;   // the hinted occluder, else the root node
+        if (newRay && hasNodes) code = 0u;                      // the root node
         if (COUNT) {
             if (newRay) rayItems = 0;
             if (code != kItemNone) ++rayItems;
@@ -293,17 +284,13 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
         if (COUNT) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); cycFetch += __builtin_amdgcn_s_memtime() - cyc1; }
         const unsigned long long cyc2 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         if (newRay) {                                           // its origin and direction have arrived with the items
-            float lo = rayO.w, hi = rayD.w;
-            const bool empty = !hasNodes || !(rayD.w > rayO.w);  // empty interval or empty scene: immediate miss
-            if (SEG > 1 && !empty) segment_interval<SEG>(f3(rayO.x, rayO.y, rayO.z), f3(rayD.x, rayD.y, rayD.z), rayO.w, rayD.w, box, seg, lo, hi);
-            tr.begin(f3(rayO.x, rayO.y, rayO.z), f3(rayD.x, rayD.y, rayD.z), lo, hi, stack, hasNodes);
-            if (!hintFirst) tr.grp.y = 0u;                      // the root (begin's one-child group) is this iteration's item
-            if (COUNT) traversed = !empty;
-            if (empty || !(hi > lo)) {                          // (an empty segment of a non-empty ray: nothing to find in it)
+            tr.begin(f3(rayO.x, rayO.y, rayO.z), f3(rayD.x, rayD.y, rayD.z), rayO.w, rayD.w, stack, hasNodes);
+            tr.grp.y = 0u;                                      // the root (begin's one-child group) is this iteration's item
+            if (!hasNodes || !(rayD.w > rayO.w)) {              // empty interval or empty scene: immediate miss
                 tr.active = false;
                 code = kItemNone;
                 write_result();
-                if (COUNT && SEG == 1) --raysDone;               // the counters report rays that were traversed: a queue entry without a
+                if (COUNT) --raysDone;                           // the counters report rays that were traversed: a queue entry without a
             }                                                   // ray (emit_ray_at_slot, padding slots) is not one
         }
         if (code != kItemNone) {
@@ -314,13 +301,6 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             else tr.template process_node<COUNT>(q0, q1, q2, q3, link, stack, cnt);
         }
         if (!ANY_HIT && newRay && tr.active && hint < a.accel.numTris && tr.triMask == 0u) { tr.triBase = hint; tr.triMask = 0x0101u; }
-        if (SEG > 1) {
-            // a segment with a hit retires the segments it makes pointless: all others (any-hit), the ones behind it (closest-hit).
-            // Lanes of a group start their ray in the same iteration (begin() resets hit.tri in all of them), so the bits are the ray's.
-            const unsigned long long found = __ballot(hasRay && tr.hit.tri != GFX_INVALID_SLOT);
-            const uint32_t gbits = static_cast<uint32_t>(found >> leader) & SegConst<SEG>::groupMask;
-            if (ANY_HIT ? gbits != 0u : (gbits & ((1u << seg) - 1u)) != 0u) tr.active = false;
-        }
         if (COUNT) cycProcess += __builtin_amdgcn_s_memtime() - cyc2;
     }
     if (COUNT && a.diag && lane == 0) {
@@ -378,32 +358,19 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
         a.diag = ctx.dTraceDiag.as<unsigned long long>();
     }
     a.hintFromOut = (t.hintFromOut && t.mode != GFX_TRACE_ANY && ctx.tune.temporalHints) ? 1 : 0;
-    const bool any = t.mode == GFX_TRACE_ANY;
-    a.anyHint = (any && ctx.tune.anyHints) ? t.anyHint : nullptr;
-    a.keepAnyHint = ctx.tune.anyHints == 2 ? 1 : 0;
+    a.compactBelow = ctx.tune.traceCompact;
     a.refillThreshold = ctx.tune.traceRefill;
     a.ticketBatch = ctx.tune.traceBatch;
-    // Ray segments (see k_trace): a launch with about one ray per lane of the persistent grid or fewer is latency bound -- it lasts as
-    // long as its longest ray -- and is cut into segments; a launch that fills the machine several times over is throughput bound
-    // and is not (segments repeat the walk through the common ancestors).  Device-counted queues pass their capacity as maxRays.
-    int seg = ctx.tune.traceSegments;
-    if (seg == 0) {
-        const uint64_t lanes = static_cast<uint64_t>(grid) * kTraceBlock;
-        const uint64_t rays = t.numRaysPtr ? t.maxRays : t.numRays;
-        seg = 1;
-        if (rays != 0 && !ctx.countersEnabled) {
-            if (rays * 4 <= lanes * static_cast<uint64_t>(ctx.tune.traceSegFill)) seg = 4;
-            else if (rays * 2 <= lanes * static_cast<uint64_t>(ctx.tune.traceSegFill)) seg = 2;
-        }
-    }
+    const bool any = t.mode == GFX_TRACE_ANY;
     ScopedKernelTimer timer(ctx, stream, any ? "trace_any" : "trace_closest");
-#define GFX_TRACE_LAUNCH(ANY, COUNT, SEG) hipLaunchKernelGGL((k_trace<ANY, COUNT, SEG>), dim3(grid), dim3(kTraceBlock), 0, stream, a)
-#define GFX_TRACE_SEGS(ANY, COUNT) do { switch (seg) { case 8: GFX_TRACE_LAUNCH(ANY, COUNT, 8); break; case 4: GFX_TRACE_LAUNCH(ANY, COUNT, 4); break; \
-                                         case 2: GFX_TRACE_LAUNCH(ANY, COUNT, 2); break; default: GFX_TRACE_LAUNCH(ANY, COUNT, 1); break; } } while (0)
-    if (ctx.countersEnabled) { if (any) GFX_TRACE_SEGS(true, true); else GFX_TRACE_SEGS(false, true); }
-    else { if (any) GFX_TRACE_SEGS(true, false); else GFX_TRACE_SEGS(false, false); }
-#undef GFX_TRACE_SEGS
-#undef GFX_TRACE_LAUNCH
+    if (ctx.countersEnabled) {
+        if (any) hipLaunchKernelGGL((k_trace<true, true>), dim3(grid), dim3(kTraceBlock), 0, stream, a);
+        else hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(kTraceBlock), 0, stream, a);
+    }
+    else {
+        if (any) hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(kTraceBlock), 0, stream, a);
+        else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(kTraceBlock), 0, stream, a);
+    }
     GFX_HIP(hipGetLastError());
 }
 

@@ -482,14 +482,9 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
  *   "super_x", "super_y"        log2 of the supertile size in 16 x 16-pixel blocks (mode 2; default 2, 2)
  *   "trace_blocks_per_cu", "trace_refill", "trace_batch"   persistent traversal grid, lane-refill threshold, rays per ticket
  *   "temporal_hints" 0|1        the primary ray of a pixel first tests the triangle it hit one frame ago (default 1; GFX_TEMPORAL_HINTS)
- *   "any_hints" 0|1|2           the slot-addressed shadow rays of original ReSTIR (visibility of the selected candidate, final shadow
- *                               ray) first test the occluder their pixel found one frame ago: off / on, an unoccluded ray clears the
- *                               hint (default) / on, it keeps it (GFX_ANY_HINTS).  optixTrace's any-hit program sets visibility 0 on any
- *                               hit (optix_restir_di_kernels.cu:5-8), so the order of the tests cannot change the answer
- *   "trace_segments" 0|1|2|4|8  lanes per ray in the traversal kernel: a launch too small to fill the GPU cuts every ray into that many
- *                               segments along t, traversed by adjacent lanes and merged (exact partition of the ray's interval: same
- *                               hits bit for bit); 0 = chosen per launch from its size (default; GFX_TRACE_SEGMENTS)
- *   "trace_seg_fill"            auto mode: 4 segments up to value / 4 rays per lane of the persistent grid, 2 up to twice that
+ *   "trace_compact" 0..63       wave compaction of the traversal kernel: once the ray queue is dry, a wave left with at most this many live
+ *                               rays hands them (state + stack, in LDS) to the other waves of its block and exits (default 32, 0 = off;
+ *                               GFX_TRACE_COMPACT).  A ray continues in another lane with the state it was suspended with: same result
  * The same knobs are read once from the environment by gfx_ctx_create (GFX_PIXEL_MAP, GFX_SUPER_X, GFX_SUPER_Y,
  * GFX_TRACE_BLOCKS_PER_CU, GFX_TRACE_REFILL, GFX_TRACE_BATCH). */
 int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value);

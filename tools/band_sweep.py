@@ -1,7 +1,7 @@
-"""Ray segments / occluder hints against the band size: wall time per frame and per-kernel GPU time of ONE rank's band of the
-1920x1080 bench frame (strip mode, no-op exchange, pipelined frames as bench.py --gpus N runs them) for every setting of the
-k_trace scheduling knobs.  JSON lines: {"bands": N, "band": [r0, r1], "segments": S, "any_hints": A, "wall_ms", "kernels_ms"}.
-usage: band_sweep.py [--plain] [--bands 8,4,2,1] [--segments 0,1,2,4,8] [--hints 0,1,2] [--ranks all|mid]"""
+"""One scheduling knob of the context against the band size: wall time per frame and per-kernel GPU time of ONE rank's band of the
+1920x1080 bench frame (strip mode, no-op exchange, pipelined frames as bench.py --gpus N runs them) for every value of a
+gfx_tunable_set knob.  JSON lines.
+usage: band_sweep.py --knob trace_compact --values 0,16,32,48 [--plain] [--bands 8,4,2,1] [--ranks all|mid] [--serial]"""
 import json
 import os
 import sys
@@ -21,7 +21,10 @@ def measure(ctx, cam, W, H, band, steps=30, kernels=True):
     cfg.camera = cam
     cfg.rowBegin, cfg.rowEnd = band
     cfg.enableBumpMapping = int("--plain" not in sys.argv)
+    if "--serial" in sys.argv:
+        os.environ["GFX_SERIAL_FRAMES"] = "1"
     r = api.RestirRenderer(ctx, cfg)
+    os.environ.pop("GFX_SERIAL_FRAMES", None)
     if band != (0, 0):
         r.set_exchange(lambda stream, d: None, 0)
     for _ in range(6):
@@ -51,23 +54,20 @@ def main():
     scenes.bench_street(textured="--plain" not in sys.argv).upload(ctx)
     cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
     band_counts = [int(x) for x in arg("--bands", "8,4,2,1").split(",")]
-    segs = [int(x) for x in arg("--segments", "0,1,2,4,8").split(",")]
-    hints = [int(x) for x in arg("--hints", "1").split(",")]
+    knob = arg("--knob", "trace_compact")
+    values = [int(x) for x in arg("--values", "0,32").split(",")]
     ranks = arg("--ranks", "mid")
     for n in band_counts:
         bands = [(0, 0)] if n == 1 else tilesplit.band_rows(H, n)
         chosen = bands if ranks == "all" else [bands[(len(bands) - 1) // 2 + (1 if n == 8 else 0)] if n > 1 else bands[0]]
-        for s in segs:
-            for h in hints:
-                ctx.tunable_set("trace_segments", s)
-                ctx.tunable_set("any_hints", h)
-                walls, kern = [], None
-                for b in chosen:
-                    w, per = measure(ctx, cam, W, H, b, kernels=(b == chosen[-1]))
-                    walls.append(w)
-                    kern = per
-                print(json.dumps({"bands": n, "rows": [list(b) for b in chosen], "segments": s, "any_hints": h, "wall_ms": walls,
-                                  "worst_ms": max(walls), "kernels_ms_last": kern}), flush=True)
+        for v in values:
+            ctx.tunable_set(knob, v)
+            walls, kern = [], None
+            for b in chosen:
+                w, per = measure(ctx, cam, W, H, b, kernels=(b == chosen[-1]))
+                walls.append(w)
+                kern = per
+            print(json.dumps({"bands": n, "rows": [list(b) for b in chosen], knob: v, "wall_ms": walls, "worst_ms": max(walls), "kernels_ms_last": kern}), flush=True)
 
 
 if __name__ == "__main__":
