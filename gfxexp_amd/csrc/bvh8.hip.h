@@ -20,7 +20,7 @@
 namespace gfx {
 
 #ifndef GFX_TRACE_LDS_STACK
-#define GFX_TRACE_LDS_STACK 11         // 11 x 256 x 8 B + the 16-KiB fetch buffer + the compaction words: four blocks per CU (12 would be 40 bytes over)
+#define GFX_TRACE_LDS_STACK 12         // experiment builds trade stack depth for resident waves (tools/microbench/README)
 #endif
 constexpr int kLdsStackDepth = GFX_TRACE_LDS_STACK;     // entries per lane held in LDS
 constexpr int kSpillStackDepth = 64;   // entries per lane in the HBM spill area
@@ -86,8 +86,7 @@ struct Traversal {
     bool xNeg, yNeg, zNeg;                 // the ray travels toward -k: near plane = hi, far plane = lo
     bool active;
 
-    // the per-ray constants every slab test uses, from origin and direction alone (begin() and resume() must agree to the bit)
-    GFX_DEV void setup(f3 o, f3 d, float t0) {
+    GFX_DEV void begin(f3 o, f3 d, float t0, float t1, LaneStack& stack, bool hasNodes) {
         org = o; dir = d; tmin = t0;
         // |dir_k| below 1e-20 behaves like an axis-parallel ray without producing inf / NaN
         const float dx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
@@ -96,13 +95,10 @@ struct Traversal {
         inv = f3(1.0f / dx, 1.0f / dy, 1.0f / dz);
         slackScale = f3(fabsf(inv.x) * 4.76837158203125e-07f, fabsf(inv.y) * 4.76837158203125e-07f, fabsf(inv.z) * 4.76837158203125e-07f);
         slackOrg = f3(fabsf(o.x) * slackScale.x, fabsf(o.y) * slackScale.y, fabsf(o.z) * slackScale.z);
+        hit.t = t1; hit.bcB = 0; hit.bcC = 0; hit.tri = GFX_INVALID_SLOT;
         // octant mask: bit k set when the ray travels toward -k, so (slot ^ oct) ascending = near to far
         oct = (dx < 0 ? 1u : 0u) | (dy < 0 ? 2u : 0u) | (dz < 0 ? 4u : 0u);
         xNeg = dx < 0; yNeg = dy < 0; zNeg = dz < 0;
-    }
-    GFX_DEV void begin(f3 o, f3 d, float t0, float t1, LaneStack& stack, bool hasNodes) {
-        setup(o, d, t0);
-        hit.t = t1; hit.bcB = 0; hit.bcC = 0; hit.tri = GFX_INVALID_SLOT;
         // current group: x = index of the first internal child; y = hit bits | imask << 8.
         // Hit bit p stands for child slot (p ^ oct).  The root is a one-child group: slot 0
         // (bit 0 ^ oct), empty imask -> node index 0.
@@ -110,20 +106,6 @@ struct Traversal {
         triBase = 0; triMask = 0;
         stack.sp = 0;
         active = hasNodes;
-    }
-    // A ray another lane has traversed part of (trace.hip, wave compaction): the 16-dword record that lane left + its stack column.
-    GFX_DEV void resume(uint4 r0, uint4 r1, uint4 r2, uint4 r3) {
-        setup(f3(bits2f(r0.x), bits2f(r0.y), bits2f(r0.z)), f3(bits2f(r1.x), bits2f(r1.y), bits2f(r1.z)), bits2f(r0.w));
-        hit.t = bits2f(r1.w); hit.bcB = bits2f(r2.x); hit.bcC = bits2f(r2.y); hit.tri = r2.z;
-        grp = make_uint2(r3.x, r3.y);
-        triBase = r3.z; triMask = r3.w & 0xFFFFu;
-        active = true;
-    }
-    GFX_DEV void suspend(uint32_t rayIdx, uint32_t sp, uint32_t column, uint4& r0, uint4& r1, uint4& r2, uint4& r3) const {
-        r0 = make_uint4(f2bits(org.x), f2bits(org.y), f2bits(org.z), f2bits(tmin));
-        r1 = make_uint4(f2bits(dir.x), f2bits(dir.y), f2bits(dir.z), f2bits(hit.t));
-        r2 = make_uint4(f2bits(hit.bcB), f2bits(hit.bcC), hit.tri, rayIdx);
-        r3 = make_uint4(grp.x, grp.y, triBase, (triMask & 0xFFFFu) | (sp << 16) | (column << 24));
     }
 
     // Which 64-byte item does this lane need next?  kItemNone = the ray has finished.

@@ -94,8 +94,6 @@ struct Tunables {
     int traceRefill = 8;             // refill a wave when at least this many lanes are idle
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
     int temporalHints = 1;           // primary rays test the triangle their pixel hit one frame ago first (trace.hip)
-    int traceCompact = 32;           // wave compaction in k_trace: once the queue is dry, a wave with at most this many live rays hands them to
-                                     // the other waves of its block and exits (0: off)
 };
 
 struct Context {

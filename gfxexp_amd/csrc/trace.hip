@@ -40,29 +40,6 @@ struct TraceArgs {
     int refillThreshold;        // refill when at least this many lanes are idle
     int ticketBatch;            // rays bought per device atomic
     int hintFromOut;            // closest-hit launches: out[i].triIndex of the previous launch is ray i's first triangle to test
-    int compactBelow;           // wave compaction: a wave left with at most this many live rays hands them to the block's other waves (0: off)
-};
-
-// ---------------------------------------------------------------- wave compaction
-// An iteration of the wave loop costs the same ~340 instructions whether 5 or 60 lanes hold a ray, and once the queue is dry
-// nothing refills the lanes that finish: the full frame spends 14 % of its wave iterations in that drain at a quarter of the lanes,
-// a rank's band of an 8-way split frame more than half of them (profiles/r04_band_diag.jsonl) -- issue slots that carry no ray.  So a
-// wave that is down to a few live rays after the queue has run dry ORPHANS them: every live lane leaves a 64-byte record
-// (Traversal::suspend) in the wave's fetch buffer -- which the wave no longer needs -- publishes the lanes in a mask in LDS, and
-// the wave exits.  A wave of the same block that has idle lanes ADOPTS orphans instead of new rays: the record restores the
-// traversal state (Traversal::resume recomputes the per-ray constants from origin and direction with begin()'s own code) and the
-// lane's stack pointer is re-pointed at the orphan's LDS column, so the stack is adopted without a copy.  A ray continues with exactly the state it was
-// suspended with: same items, same tests, same result -- only in another lane.
-//   * `alive` (low half) counts the block's waves that have neither orphaned their rays nor left; a wave may orphan only while
-//     another wave is alive: it claims its leave first (alive - 1 and, in the high half, publishing + 1, one compare-and-swap that
-//     requires alive > 1), then writes the records, publishes the mask and takes publishing back down.  A refused wave finishes its rays.
-//   * a wave with nothing left to do leaves (alive - 1); the one that finds itself last waits until no dumper is between claim and
-//     publication, re-checks the masks and keeps adopting until they are empty -- nothing is lost, and records are only ever read
-//     from waves that have exited (their fetch buffers are never written again).
-//   * rays whose stack has spilled past the LDS column stay where they are (the spill area is addressed per lane).
-struct CompactShared {
-    unsigned long long orphans[kTraceBlock / 64];   // per wave: lanes whose record + stack column wait for adoption
-    uint32_t alive;
 };
 
 // fetch_items: coop_fetch.hip.h (the cooperative 64-byte gather; the candidate kernel of restir.hip uses it for emitter records).
@@ -75,12 +52,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[kTraceBlock * 4];   // 4 KiB per wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    __shared__ CompactShared compact;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint4* waveBuf = fetchBuf + 256 * wave;   // wave-uniform, kept scalar
-    if (tid < kTraceBlock / 64) compact.orphans[tid] = 0ull;
-    if (tid == 0) compact.alive = kTraceBlock / 64;
-    __syncthreads();
+    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, kept scalar
     LaneStack stack;
     stack.lds = ldsStack + tid;
     stack.ldsStride = kTraceBlock;
@@ -96,10 +68,6 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     tr.active = false;
     uint32_t rayIdx = 0;
     bool exhausted = false;           // wave-uniform: the queue has no more rays
-    // wave compaction (wave-uniform): this wave has decremented `alive` (it is the block's last one, finishing the orphans); it may not
-    // orphan its rays any more (it was refused once: it is the last wave alive)
-    bool left = false, mayOrphan = a.compactBelow > 0 && !(COUNT && a.perRayItems);
-    const bool compaction = mayOrphan;
     uint32_t waveNext = 0, waveEnd = 0; // wave-uniform: rays [waveNext, waveEnd) already ticketed for this wave
     uint32_t myCounter = (blockIdx.x * (kTraceBlock / 64) + (tid >> 6)) % kTicketCounters;   // wave-uniform: the counter this wave draws from
     uint32_t dryCounters = 0;         // wave-uniform: counters this wave has seen run dry
@@ -172,95 +140,9 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             }
             waveNext += take;
         }
-        if (compaction && exhausted) {
-            const int numActive = 64 - numIdle;
-            unsigned long long m[kTraceBlock / 64];
-#pragma unroll
-            for (int w = 0; w < kTraceBlock / 64; ++w) m[w] = __hip_atomic_load(&compact.orphans[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            int src = -1;
-#pragma unroll
-            for (int w = kTraceBlock / 64 - 1; w >= 0; --w) if (m[w] != 0ull && w != wave) src = w;
-            if (src >= 0 && numIdle >= a.refillThreshold) {
-                // ---- adopt: lane 0 claims up to numIdle of the lowest orphans of wave `src`
-                unsigned long long claimed = 0ull;
-                if (lane == 0) {
-                    unsigned long long seen = __hip_atomic_load(&compact.orphans[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    while (seen != 0ull) {
-                        unsigned long long take = seen;
-                        if (__popcll(seen) > numIdle) {                       // keep the numIdle lowest bits
-                            take = 0ull;
-                            unsigned long long rest = seen;
-                            for (int k = 0; k < numIdle; ++k) { take |= rest & (0ull - rest); rest &= rest - 1ull; }
-                        }
-                        if (__hip_atomic_compare_exchange_strong(&compact.orphans[src], &seen, seen & ~take, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { claimed = take; break; }
-                    }
-                }
-                claimed = __shfl(claimed, 0);
-                if (claimed != 0ull) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const uint32_t rank = __popcll(idleMask & ((1ull << lane) - 1ull));
-                    if (!tr.active && rank < static_cast<uint32_t>(__popcll(claimed))) {
-                        unsigned long long rest = claimed;
-                        for (uint32_t k = 0; k < rank; ++k) rest &= rest - 1ull;
-                        const int orphanLane = __builtin_ctzll(rest);
-                        const uint4* rec = fetchBuf + 256 * src + 4 * orphanLane;
-                        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                        tr.resume(r0, r1, r2, r3);
-                        rayIdx = r2.w;
-                        stack.sp = static_cast<int>((r3.w >> 16) & 0x7Fu);
-                        const uint32_t column = r3.w >> 24;
-                        stack.lds = ldsStack + column;                  // the orphan's stack column, adopted in place
-                    }
-                }
-            }
-            else if (src < 0 && mayOrphan && numActive > 0 && numActive <= a.compactBelow && __ballot(tr.active && stack.sp > kLdsStackDepth) == 0ull) {
-                // ---- orphan: claim the right to leave first (alive - 1, "publishing" + 1, only while another wave is alive), then the
-                // records into this wave's fetch buffer (never used again), then the mask, then publishing - 1
-                uint32_t ok = 0;
-                if (lane == 0) {
-                    uint32_t v = __hip_atomic_load(&compact.alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    while ((v & 0xFFFFu) > 1u && !ok)
-                        if (__hip_atomic_compare_exchange_strong(&compact.alive, &v, v - 1u + 0x10000u, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) ok = 1u;
-                }
-                ok = __shfl(ok, 0);
-                if (!ok) mayOrphan = false;                               // the last wave alive finishes what it has
-                else {
-                    if (tr.active) {
-                        uint4 r0, r1, r2, r3;
-                        tr.suspend(rayIdx, static_cast<uint32_t>(stack.sp), static_cast<uint32_t>(stack.lds - ldsStack), r0, r1, r2, r3);
-                        uint4* rec = waveBuf + 4 * lane;
-                        rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) {
-                        __hip_atomic_store(&compact.orphans[wave], ~idleMask, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&compact.alive, 0u - 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    break;
-                }
-            }
-        }
         if (COUNT) cycRefill += __builtin_amdgcn_s_memtime() - cyc0;
         if (__ballot(tr.active || newRay) == 0ull) {
-            if (!exhausted) continue;
-            if (!compaction) break;
-            // nothing to do here: orphans of another wave first; else leave -- and the wave that finds itself the last one alive
-            // looks again (a dumper publishes before it decrements `alive`) and stays until the masks are empty
-            unsigned long long pending = 0ull;
-#pragma unroll
-            for (int w = 0; w < kTraceBlock / 64; ++w) if (w != wave) pending |= __hip_atomic_load(&compact.orphans[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (pending != 0ull) continue;
-            if (left) break;
-            uint32_t before = 0;
-            if (lane == 0) {
-                before = __hip_atomic_fetch_add(&compact.alive, 0xFFFFFFFFu, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-                // the last one waits for dumpers that have claimed their leave but not published yet
-                if ((before & 0xFFFFu) == 1u)
-                    while ((__hip_atomic_load(&compact.alive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) != 0u) __builtin_amdgcn_s_sleep(1);
-            }
-            before = __shfl(before, 0);
-            left = true; mayOrphan = false;
-            if ((before & 0xFFFFu) > 1u) break;
+            if (exhausted) break;
             continue;
         }
         uint32_t code = kItemNone;
@@ -358,7 +240,6 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
         a.diag = ctx.dTraceDiag.as<unsigned long long>();
     }
     a.hintFromOut = (t.hintFromOut && t.mode != GFX_TRACE_ANY && ctx.tune.temporalHints) ? 1 : 0;
-    a.compactBelow = ctx.tune.traceCompact;
     a.refillThreshold = ctx.tune.traceRefill;
     a.ticketBatch = ctx.tune.traceBatch;
     const bool any = t.mode == GFX_TRACE_ANY;

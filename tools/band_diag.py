@@ -59,8 +59,6 @@ def measure(ctx, cam, W, H, band, bpc=4):
 def main():
     W, H = 1920, 1080
     ctx = api.Context(0)
-    if "--compact" in sys.argv:
-        ctx.tunable_set("trace_compact", int(sys.argv[sys.argv.index("--compact") + 1]))
     scenes.bench_street(textured=True).upload(ctx)
     cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
     print(json.dumps(measure(ctx, cam, W, H, (0, 0))), flush=True)

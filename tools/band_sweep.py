@@ -1,7 +1,7 @@
 """One scheduling knob of the context against the band size: wall time per frame and per-kernel GPU time of ONE rank's band of the
 1920x1080 bench frame (strip mode, no-op exchange, pipelined frames as bench.py --gpus N runs them) for every value of a
 gfx_tunable_set knob.  JSON lines.
-usage: band_sweep.py --knob trace_compact --values 0,16,32,48 [--plain] [--bands 8,4,2,1] [--ranks all|mid] [--serial]"""
+usage: band_sweep.py --knob trace_refill --values 4,8,16 [--plain] [--bands 8,4,2,1] [--ranks all|mid] [--serial]"""
 import json
 import os
 import sys
@@ -54,8 +54,8 @@ def main():
     scenes.bench_street(textured="--plain" not in sys.argv).upload(ctx)
     cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
     band_counts = [int(x) for x in arg("--bands", "8,4,2,1").split(",")]
-    knob = arg("--knob", "trace_compact")
-    values = [int(x) for x in arg("--values", "0,32").split(",")]
+    knob = arg("--knob", "trace_refill")
+    values = [int(x) for x in arg("--values", "8").split(",")]
     ranks = arg("--ranks", "mid")
     for n in band_counts:
         bands = [(0, 0)] if n == 1 else tilesplit.band_rows(H, n)
