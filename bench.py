@@ -62,13 +62,24 @@ def _profile_lines(name):
         return []
 
 
+PMC_FILES = ("r04_pmc.json", "r03_pmc.json")     # newest round first (tools/profile_round.sh pmc -> profiles/make_pmc_json.py)
+
+
 def _profiled_traffic():
-    """HBM bytes per traversal launch from the PMC passes (newest round first)."""
-    for name in ("r03_pmc.json", "r02_traffic.json", "r01_traffic.json"):
+    """HBM bytes per traversal launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process): value + file."""
+    for name in PMC_FILES + ("r02_traffic.json", "r01_traffic.json"):
         v = _profile_value(name, "hbm_bytes_per_launch")
         if v is not None:
-            return v
-    return None
+            return v, "profiles/" + name
+    return None, None
+
+
+def _profiled_kernels():
+    for name in PMC_FILES:
+        k = _profile_value(name, "kernels")
+        if k:
+            return k, "profiles/" + name
+    return {}, None
 
 
 def hbm_stream_peak(ctx):
@@ -370,7 +381,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(ctx, renderer, stream, steps, W, H):
+def roofline(ctx, renderer, stream, steps, W, H, config=2):
     """Dominant kernel family by GPU time; achieved = algorithmic bytes per launch / mean launch duration.
     Durations: HIP events on the launch stream around every kernel (gfx_timing_*), live in this run, passes
     serialised on one stream.  Algorithmic bytes of the traversal kernels: node fetches x (64 + 16) B + triangle
@@ -395,7 +406,7 @@ def roofline(ctx, renderer, stream, steps, W, H):
     per_frame = {k: round(ms / n, 4) for k, (ms, calls) in sorted(timings.items(), key=lambda kv: -kv[1][0])}
     trav_ms = sum(ms for k, (ms, calls) in timings.items() if k.startswith("trace_")) / n
     trav_launches = sum(calls for k, (ms, calls) in timings.items() if k.startswith("trace_")) / n
-    # one frame = 1 closest launch (16 B out) + 2 any-hit launches (4 B out)
+    # (configs[2]: one frame = 1 closest-hit launch (16 B out) + 2 any-hit launches (4 B out); the other configurations launch more)
     rays_closest, rays_any = c["closest"]["rays"], c["any"]["rays"]
     bytes_frame = c["nodeFetches"] * (64 + 16) + c["triFetches"] * 64 + rays_closest * (32 + 16) + rays_any * (32 + 4)   # node = 64-B record + 16-B link
     achieved = bytes_frame / (trav_ms * 1e-3) / 1e9
@@ -408,26 +419,37 @@ def roofline(ctx, renderer, stream, steps, W, H):
         ours_bytes = nodes_per_primary * 80 + c["closest"]["triFetches"] / max(1, rays_closest) * 64
         sah_bytes = sah["nodes_per_ray"] * 80 + sah["tris_per_ray"] * 64
         frac_sah = round(achieved / HBM_PEAK_GBS * sah_bytes / ours_bytes, 4)
-    peak_measured = hbm_stream_peak()
-    # what actually bounds the kernel (committed rocprofv3 PMC passes: profiles/r03_pmc.json, profiles/make_pmc_json.py): VALU issue.
+    peak_measured = hbm_stream_peak(ctx)
+    # what actually bounds the kernel (committed rocprofv3 PMC passes, profiles/make_pmc_json.py): VALU issue.
     # The BVH is served from L2 / Infinity Cache (`traffic` is 20-30x below the algorithmic bytes), so the SURVEY 8(d) byte
     # roof is nominal; the hardware-side figure is the share of VALU issue slots used and how many lanes each instruction carries.
-    pmc = _profile_value("r03_pmc.json", "kernels") or {}
+    pmc, pmc_file = _profiled_kernels()
+    traffic, traffic_file = _profiled_traffic()
     valu = None
-    if "k_trace_any" in pmc and "k_trace_closest" in pmc:
+    if "k_trace_any" in pmc and "k_trace_closest" in pmc and config == 2:
         ka, kc = pmc["k_trace_any"], pmc["k_trace_closest"]
         insts_frame = 2 * ka["valu_insts"] + kc["valu_insts"]
-        valu = {"source": "profiles/r03_pmc.json (rocprofv3 --pmc, same command; per-launch means of k_trace<any> x 2 and k_trace<closest>)",
+        valu = {"source": pmc_file + " (rocprofv3 --pmc of the default command; per-launch means of k_trace<any> x 2 and k_trace<closest>)",
                 "busy": round((2 * ka["valu_busy"] + kc["valu_busy"]) / 3, 4),
                 "lane_fraction": round((2 * ka["valu_insts"] * ka["lane_fraction"] + kc["valu_insts"] * kc["lane_fraction"]) / insts_frame, 4),
                 "insts_per_wave_iteration": round(insts_frame / max(1, diag["iterations"]), 1),
                 "useful_fraction_of_valu_peak": None}
         valu["useful_fraction_of_valu_peak"] = round(valu["busy"] * valu["lane_fraction"], 4)
-    roof = {"bound": "valu (nominal hbm per SURVEY 8d)", "kernel": "k_trace<closest|any> (software BVH8 traversal; 3 launches per frame)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "peak_measured": peak_measured, "frac_of_peak_measured": round(achieved / peak_measured, 4) if peak_measured else None,
+    # The headline fraction is the one that binds: the share of the SIMDs' VALU issue slots x lanes that carry a ray (`valu`), when the
+    # committed counter pass covers this configuration; the SURVEY 8(d) byte figure stays beside it as frac_nominal_hbm.
+    useful = valu["useful_fraction_of_valu_peak"] if valu else None
+    roof = {"bound": "valu" if useful is not None else "hbm (nominal, SURVEY 8d; no VALU counter pass committed for this configuration)",
+            "kernel": "k_trace<closest|any> (software BVH8 traversal; %g launches per frame)" % round(trav_launches, 1),
+            "achieved": useful if useful is not None else round(achieved, 1),
+            "peak": 1.0 if useful is not None else HBM_PEAK_GBS,
+            "unit": "share of VALU issue slots x lanes carrying a ray (VALU busy x active lanes per instruction)" if useful is not None else "GB/s",
+            "frac": useful if useful is not None else round(achieved / HBM_PEAK_GBS, 4),
+            "achieved_nominal_hbm": round(achieved, 1), "peak_nominal_hbm": HBM_PEAK_GBS, "frac_nominal_hbm": round(achieved / HBM_PEAK_GBS, 4),
+            "peak_measured": peak_measured, "peak_measured_how": "gfx_stream_copy: 16-byte non-temporal loads / stores per lane, 1 GiB, read + write bytes, HIP events, live in this run",
+            "frac_of_peak_measured": round(achieved / peak_measured, 4) if peak_measured else None,
             "valu": valu,
-            "traffic": _profiled_traffic(),
+            "traffic": traffic if config == 2 else None,
+            "traffic_source": (traffic_file + ": HBM bytes per launch by PMC (TCC_EA0_RDREQ / WRREQ passes of the default command), mean of the three launches") if config == 2 and traffic_file else None,
             "node_visits_per_ray": {"primary": round(nodes_per_primary, 3),
                                     "shadow": round(c["any"]["nodeFetches"] / max(1, rays_any), 3),
                                     "sah_tree_primary": sah.get("nodes_per_ray")},
@@ -470,6 +492,56 @@ def roofline(ctx, renderer, stream, steps, W, H):
                                       "peak_source": "profiles/r03_l2_gather.jsonl: mean of the three access shapes at a 4-MB table, G sectors/s x 64 B",
                                       "frac_of_hbm_peak_nominal": round(cand_bytes / (init_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     return roof, per_frame
+
+
+def roofline_nrc(ctx, renderer, stream, W, H):
+    """configs[3]: the fully fused MLP is the one dense contraction of the path (north_star: "evidenced by rocprof MFMA utilisation").
+    achieved = 18 432 FLOP per query (2 x (64x64 + 64x64 + 64x16): first layer, one hidden-to-hidden layer, padded output layer)
+    x the frame's inference queries / the HIP-event duration of k_nrc_infer, live in this run, against the dense bf16 MFMA peak.
+    The MFMA-busy counter and the TCP request rate of the same kernel come from the committed rocprofv3 --pmc pass."""
+    import torch
+    from gfxexp_amd import api
+    os.environ["GFX_NRC_SERIAL_TRAINING"] = "1"          # one stream: kernels that overlap read longer than they are
+    serial = api.NrcRenderer(ctx, renderer.cfg)
+    os.environ.pop("GFX_NRC_SERIAL_TRAINING", None)
+    for _ in range(6):
+        serial.render_frame(stream)
+    serial.network()
+    torch.cuda.synchronize()
+    ctx.timing_enable(True)
+    ctx.timing_collect()
+    n = 10
+    for _ in range(n):
+        serial.render_frame(stream)
+    serial.network()
+    torch.cuda.synchronize()
+    timings = ctx.timing_collect()
+    ctx.timing_enable(False)
+    stats = serial.stats()
+    serial.close()
+    per_frame = {k: round(ms / n, 4) for k, (ms, calls) in sorted(timings.items(), key=lambda kv: -kv[1][0])}
+    infer_ms, infer_calls = timings.get("nrc_infer", (0.0, 0))
+    queries = stats["numInferenceQueries"]
+    flop_per_query = 2 * (64 * 64 + 64 * 64 + 64 * 16)
+    launch_ms = infer_ms / max(1, infer_calls)
+    # a frame infers the pixels' queries in one launch and the training tiles' suffix queries in a second, small one
+    tflops = flop_per_query * queries / max(1e-9, infer_ms / n * 1e-3) / 1e12
+    peak = 2500.0
+    pmc_txt = None
+    for name in ("r04_nrc_pmc.txt", "r03_nrc_pmc.txt"):
+        if os.path.exists(os.path.join(ROOT, "profiles", name)):
+            pmc_txt = "profiles/" + name
+            break
+    roof = {"bound": "mfma (nominal: the kernel is bound by the hash-grid gathers, 128 corner loads per query)", "kernel": "k_nrc_infer (hash-grid encoding + fused 64-wide MLP, v_mfma_f32_32x32x16_bf16)",
+            "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 5),
+            "flop_per_query": flop_per_query, "queries_per_frame": queries, "launches_per_frame": round(infer_calls / n, 2), "avg_launch_ms": round(launch_ms, 4),
+            "infer_ms_per_frame": round(infer_ms / n, 4),
+            "traffic": None,
+            "counters": pmc_txt and (pmc_txt + ": SQ_VALU_MFMA_BUSY_CYCLES, TCP request rate and L2 hit rate of k_nrc_infer / k_nrc_train (rocprofv3 --pmc of tools/bench_nrc_frame.py)"),
+            "training": {"records_per_frame": stats["numTrainingData"], "tile": list(stats["tileSize"]),
+                         "fwd_bwd_ms_per_frame": per_frame.get("nrc_train_fwd_bwd"), "optimizer_ms_per_frame": per_frame.get("nrc_optimizer"), "pack_ms_per_frame": per_frame.get("nrc_pack")},
+            "traversal_ms_per_frame": round(sum(v for k, v in per_frame.items() if k.startswith("trace_")), 4)}
+    return roof, per_frame, stats
 
 
 def mse_vs_reference(ctx, hs, renderer, cam, W, H, ref_spp):
@@ -515,7 +587,7 @@ def _device_view(ptr, num_floats):
     return torch.as_tensor(h, device="cuda")
 
 
-def cpu_baseline(hs, cam, sample, W, H):
+def cpu_baseline(hs, cam, sample, W, H, unbiased=False, env=None):
     """The CPU restatement (oracle/, test infrastructure) timed on this host: same scene, same camera, same
     settings, steady-state frames on a reduced pixel count.  BASELINE.md section 2 names two builds of it -- the parity
     build (the checker: contraction off, x86-64-v3) and a speed build (-O3 -march=native, contraction allowed, compiled on
@@ -528,23 +600,30 @@ def cpu_baseline(hs, cam, sample, W, H):
     ocam.aspect = float(sw) / float(sh)
     cores = int(O.lib().orc_max_threads())
 
+    num_passes, num_nb = (1, 3) if unbiased else (2, 5)
+
     def run(osc, threads, frames):
         osc.set_threads(threads)
         pb = util.PixelBuffers(sw, sh)
+        if env is not None:
+            pb.set_env(env[0], env[1], env[2], oracle_side=True)
         s = pb.host_static_params()
         last_res, last_base = 1, 0
         times = []
         for frame in range(frames):
-            kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=0)
+            kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=0,
+                      numSpatialNeighbors=num_nb, useUnbiasedEstimator=int(unbiased))
+            if env is not None:
+                kw.update(enableEnvLight=1, envLightPowerCoeff=env[3], envLightRotation=env[4])
             f = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, sw, sh, ocam, **kw)
             cur = (last_res + 1) % 2
             t0 = time.perf_counter()
             osc.restir_launch(s, f, cur, last_base, 0)
-            osc.restir_launch(s, f, cur, last_base, 1 if frame == 0 else 2)
-            for i in range(2):
-                osc.restir_launch(s, f, cur, last_base + 5 * i, 4)
+            osc.restir_launch(s, f, cur, last_base, 1 if frame == 0 else (3 if unbiased else 2))
+            for i in range(num_passes):
+                osc.restir_launch(s, f, cur, last_base + num_nb * i, 5 if unbiased else 4)
                 cur = (cur + 1) % 2
-            last_base += 10
+            last_base += num_nb * num_passes
             osc.restir_launch(s, f, cur, last_base, 6)
             last_res = cur
             times.append(time.perf_counter() - t0)
@@ -574,6 +653,46 @@ def cpu_baseline(hs, cam, sample, W, H):
             "all_cores": {"value": best["all_threads"]["value"], "unit": "Mpaths/s", "cores": cores,
                           "seconds_per_sample_frame": best["all_threads"]["seconds_per_sample_frame"], "how": "OpenMP over pixels inside every pass"},
             "builds": {"parity": parity, "speed": speed}}
+
+
+def cpu_baseline_path_tracer(hs, cam, W, H):
+    """configs[1] on the host cores: the oracle's restatement of the baseline path tracer (path_tracing/gpu_kernels/
+    optix_pathtracing_kernels.cu:74-341 over the restated SAH BVH8), the whole 512x512 frame, one thread and all threads."""
+    from oracle import oracle as O
+    from tests import util
+    ocam = util.copy_struct(O.GfxCamera, cam)
+    cores = int(O.lib().orc_max_threads())
+
+    def run(osc, threads, frames):
+        osc.set_threads(threads)
+        pb = util.PixelBuffers(W, H)
+        s = pb.host_static_params()
+        times = []
+        for frame in range(frames):
+            kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=frame, enableJittering=1)
+            f = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, W, H, ocam, **kw)
+            t0 = time.perf_counter()
+            osc.pt_launch(s, f, 0, 5)          # GFX_PT_SETUP_GBUFFERS
+            osc.pt_launch(s, f, 1, 5)          # GFX_PT_PATH_TRACE_BASELINE
+            times.append(time.perf_counter() - t0)
+        return float(np.median(times[1:])) if len(times) > 1 else times[0]
+
+    out = {}
+    for label, library, flags in (("parity", None, O.PARITY_FLAGS), ("speed", "fast", O.FAST_FLAGS)):
+        try:
+            osc = util.feed_oracle(hs, threads=1, library=O.lib_fast() if library else None)
+        except Exception as e:
+            out[label] = {"error": repr(e)[:200]}
+            continue
+        t1, tn = run(osc, 1, 3), run(osc, cores, 6)
+        out[label] = {"flags": "g++ " + flags, "one_thread": {"value": round(W * H / t1 / 1e6, 5), "cores": 1, "seconds_per_frame": round(t1, 3)},
+                      "all_threads": {"value": round(W * H / tn / 1e6, 5), "cores": cores, "seconds_per_frame": round(tn, 4)}}
+        osc.close()
+    best = max((v for v in out.values() if "one_thread" in v), key=lambda v: v["one_thread"]["value"])
+    return {"value": best["one_thread"]["value"], "unit": "Mpaths/s", "cores": 1, "kind": "port",
+            "sample": f"the whole {W}x{H} frame, max path length 5, scalar C++ restatement (oracle/), median of 2 frames on one thread, of 5 on all; SAH BVH8 build untimed",
+            "all_cores": {"value": best["all_threads"]["value"], "unit": "Mpaths/s", "cores": cores, "how": "OpenMP over pixels"},
+            "builds": out}
 
 
 if __name__ == "__main__":

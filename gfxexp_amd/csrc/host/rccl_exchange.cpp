@@ -98,6 +98,10 @@ int gfxh_rccl_create(const void* id128, int rank, int world, uint32_t height, gf
     for (int r = 0; r < world; ++r) {
         uint32_t b = 0, e = 0;
         gfxh_band_rows(height, static_cast<uint32_t>(world), static_cast<uint32_t>(r), &b, &e);
+        if (e <= b) {   // more ranks than 8-row tiles: an empty band would enter the strip / gather collectives with nothing to send
+            g_rcclError = "gfxh_rccl_create: " + std::to_string(world) + " ranks for " + std::to_string(height) + " rows leave rank " + std::to_string(r) + " without a band";
+            delete c; return 1;
+        }
         c->bandBegin.push_back(b); c->bandEnd.push_back(e);
     }
     ncclUniqueId id; std::memcpy(&id, id128, sizeof(id));

@@ -315,12 +315,14 @@ int gfxh_balance_bands(uint32_t height, uint32_t world, const uint32_t* in, cons
     if (world == 0 || !in || !ms || !out || in[0] != 0 || in[world] != height) return 1;
     const uint32_t tiles = (height + 7u) / 8u;
     const uint32_t minTiles = std::max(1u, (minRows + 7u) / 8u);
-    if (static_cast<uint64_t>(minTiles) * world > tiles) return 1;
+    // every band but the last is whole tiles; the last one ends at `height`, which need not be a multiple of 8: it is measured in rows
+    if (static_cast<uint64_t>(minTiles) * 8u * (world - 1u) + std::max(minRows, 1u) > height) return 1;
     // cost per 8-row tile: a band's time spread evenly over its tiles (double: the prefix sums decide the cuts)
     std::vector<double> cost(tiles, 0.0);
     double total = 0.0;
     for (uint32_t r = 0; r < world; ++r) {
         if (in[r + 1] <= in[r] || !(ms[r] > 0.0f) || !(ms[r] < 1e30f)) return 1;
+        if (r > 0 && in[r] % 8u != 0) return 1;                     // interior boundaries sit on tile edges (gfxh_restir_check_bands)
         const uint32_t t0 = in[r] / 8u, t1 = (in[r + 1] + 7u) / 8u;
         for (uint32_t t = t0; t < t1 && t < tiles; ++t) cost[t] = static_cast<double>(ms[r]) / (t1 - t0);
         total += ms[r];
@@ -332,7 +334,9 @@ int gfxh_balance_bands(uint32_t height, uint32_t world, const uint32_t* in, cons
     double run = 0.0;
     for (uint32_t k = 1; k < world; ++k) {
         const double want = total * k / world;
-        const uint32_t lo = out[k - 1] / 8u + minTiles, hi = tiles - (world - k) * minTiles;
+        // bands k .. world - 2 behind the cut are at least minTiles tiles, the last one at least minRows ROWS of a possibly partial tile
+        const uint32_t lo = out[k - 1] / 8u + minTiles, hi = (height - ((world - k - 1u) * minTiles * 8u + std::max(minRows, 1u))) / 8u;
+        if (hi < lo) return 1;
         while (tile < tiles && run + cost[tile] <= want) run += cost[tile++];
         uint32_t cut = tile;
         if (tile < tiles && (want - run) > (run + cost[tile] - want)) cut = tile + 1;   // the nearer edge
@@ -603,13 +607,16 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
             return 1;
         }
     }
-    // A strip-exchange band renderer moves `maxMotionRows` rows of the previous frame's state across its seams for the
-    // temporal pass.  With none, a frame that follows a camera or instance move would silently read stale rows there --
-    // refuse it.  Not a concern of a frame that reads no previous frame (new sequence, temporal reuse off) or of the
-    // halo-recompute scheme, whose refreshed halo (radius x passes rows) is what its temporal pass may reach into.
-    if (strips && viewMoved && r->maxMotionRows == 0 && cfg.enableTemporalReuse && !newSequence) {
-        g_driverError = "gfxh_restir_render_frame: the camera or an instance moved, but this band renderer exchanges no motion rows "
-                        "(gfxh_restir_set_exchange with maxMotionRows > 0)";
+    // A band renderer reads the previous frame across its seams in the temporal pass.  A strip exchange moves `maxMotionRows` rows of
+    // that state for it; with none -- or in the halo-recompute scheme, whose one refresh per frame covers radius x passes rows of the
+    // *final* state and nothing of what a moved camera or instance makes the temporal pass reproject into beyond them -- a frame that
+    // follows a move would silently read stale rows there: refuse it.  Not a concern of a frame that reads no previous frame (new
+    // sequence, temporal reuse off).
+    if (!wholeFrame && viewMoved && (!strips || r->maxMotionRows == 0) && cfg.enableTemporalReuse && !newSequence) {
+        g_driverError = strips ? "gfxh_restir_render_frame: the camera or an instance moved, but this band renderer exchanges no motion rows "
+                                 "(gfxh_restir_set_exchange with maxMotionRows > 0)"
+                               : "gfxh_restir_render_frame: the camera or an instance moved, but a halo-recompute band renderer refreshes no motion rows "
+                                 "(install a strip exchange with maxMotionRows > 0, or call gfxh_restir_reset to start a new sequence)";
         return 1;
     }
     gfxh_frame_step steps[64];

@@ -138,8 +138,9 @@ struct Context {
     DevBuf dSpans, dSpanGuide, dSpanHeader, dSpanInstBegin;
     uint32_t spanGuideCells = 0;
     // ticket areas of k_trace per counter buffer ([0] smallCounters, [1] any other): which of the two areas the next launch draws from
-    // (the launch before it zeroed that one), and whether both have been zeroed once
-    struct TicketState { bool zeroed = false; uint32_t next = 0; void* buffer = nullptr; } ticketState[2];
+    // (the launch before it zeroed that one), whether both have been zeroed once, and the stream of the last launch (a launch on another
+    // stream waits for it and re-zeroes: the hand-over between launches is stream order)
+    struct TicketState { bool zeroed = false; uint32_t next = 0; void* buffer = nullptr; hipStream_t stream = nullptr; } ticketState[2];
     uint32_t numLightMatrices = 0;   // distinct normal matrices of the emitter instances (scene.cpp light_matrices_upload)
     DevScene devScene() const;
     // accels

@@ -218,10 +218,21 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     // buffer (same stream by construction: the pipelined G-buffer pass has its own buffer) then finds zero -- no memset per launch.
     Context::TicketState& ts = ctx.ticketState[&small == &ctx.smallCounters ? 0 : 1];
     char* areas = static_cast<char*>(small.p) + kSmallCountersTicketOffset;
+    if (ts.zeroed && ts.buffer == small.p && ts.stream != stream) {
+        // the "previous launch zeroed my area" hand-over is stream order; a launch on another stream first waits for the last launch on
+        // the old one, then starts over with two zeroed areas (a caller that alternates streams pays an event and a memset per switch)
+        hipEvent_t done;
+        GFX_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        GFX_HIP(hipEventRecord(done, ts.stream));
+        GFX_HIP(hipStreamWaitEvent(stream, done, 0));
+        GFX_HIP(hipEventDestroy(done));
+        ts.zeroed = false;
+    }
     if (!ts.zeroed || ts.buffer != small.p) {
         GFX_HIP(hipMemsetAsync(areas, 0, 2 * kTicketAreaBytes, stream));
         ts.zeroed = true; ts.next = 0; ts.buffer = small.p;
     }
+    ts.stream = stream;
     uint32_t* ticket = reinterpret_cast<uint32_t*>(areas + ts.next * kTicketAreaBytes);
     uint32_t* ticketNext = reinterpret_cast<uint32_t*>(areas + (ts.next ^ 1u) * kTicketAreaBytes);
     ts.next ^= 1u;

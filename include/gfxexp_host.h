@@ -251,7 +251,10 @@ int gfxh_restir_check_bands(const gfxh_restir_config* cfg, uint32_t world, const
 int gfxh_balance_bands(uint32_t height, uint32_t world, const uint32_t* bandBeginIn, const float* bandMilliseconds, uint32_t minRows,
                        uint32_t* bandBeginOut);
 /* An exchange callback over RCCL for C++ host programs (librccl is loaded with dlopen on first use; one process per
- * GPU).  Create with the ncclUniqueId bytes rank 0 obtained from gfxh_rccl_unique_id and distributed its own way. */
+ * GPU).  Create with the ncclUniqueId bytes rank 0 obtained from gfxh_rccl_unique_id and distributed its own way.  It exchanges
+ * the DEFAULT partition (gfxh_band_rows): gfxh_rccl_create fails when that leaves a rank without a band (more ranks than 8-row
+ * tiles), and a renderer whose band is not its rank's default one -- the cost-balanced bands of gfxh_balance_bands -- is refused
+ * at the first gather; those partitions go through a caller-supplied exchange (tilesplit.StripExchange(bands=...)). */
 typedef struct gfxh_rccl gfxh_rccl;
 int gfxh_rccl_unique_id(void* id128);
 int gfxh_rccl_create(const void* id128, int rank, int world, uint32_t height, gfxh_rccl** out);

@@ -88,6 +88,8 @@ def cpu_plan(api, L, stub):
         comms.append(comm)
     bad = C.c_void_p()
     assert L.gfxh_rccl_create(ident, 8, WORLD, C.c_uint32(H), C.byref(bad)) == 1      # rank outside the world
+    assert L.gfxh_rccl_create(ident, 0, WORLD, C.c_uint32(40), C.byref(bad)) == 1     # 40 rows = 5 tiles for 8 ranks: three ranks without a band
+    assert b"without a band" in L.gfxh_rccl_last_error()
     sp = fake_static_params(api)
     regir = api.GfxRegirParams()
     regir.perCellNumAccesses = 0x7000000000

@@ -220,6 +220,37 @@ def test_row_band_renderers_match_full_frame(built_lib, renderer, with_env):
 
 
 @pytest.mark.gpu
+def test_halo_band_renderer_refuses_a_frame_after_the_camera_moved(built_lib):
+    """A halo-recompute band renderer (no strip exchange) refreshes radius x passes rows of final state per frame and no motion rows:
+    after a camera move its temporal pass would reproject into rows nobody refreshed.  The driver refuses that frame (before touching
+    any renderer state) instead of rendering it silently different from the whole-frame renderer; a new sequence is fine."""
+    from gfxexp_amd import tilesplit
+    width, height = 128, 96
+    ctx = api.Context(0)
+    util.bunny_scene().upload(ctx)
+    cfg = api.RestirRenderer.default_config(width, height, api.RENDERER_BIASED)
+    cfg.camera = default_camera("bunny", width, height)
+    cfg.spatialNeighborRadius = 6.0
+    cfg.rowBegin, cfg.rowEnd = tilesplit.band_rows(height, 2)[0]
+    r = api.RestirRenderer(ctx, cfg)
+    r.render_frame()
+    r.render_frame()
+    before = r.params()[2:]
+    r.set_camera(api.make_camera(width, height, pos=(1.7, 5.1, 14.0), pitch=12.0, yaw=186.0))
+    with pytest.raises(api.GfxError, match="halo-recompute"):
+        r.render_frame()
+    assert r.params()[2:] == before               # nothing advanced: the caller can fix the configuration and render the same frame
+    r.reset()                                     # ... for instance by starting a new sequence, which reads no previous frame
+    r.render_frame()
+    full_cfg = api.RestirRenderer.default_config(width, height, api.RENDERER_BIASED)
+    full_cfg.camera = cfg.camera
+    full = api.RestirRenderer(ctx, full_cfg)      # the whole-frame renderer takes the same move without complaint
+    full.render_frame()
+    full.set_camera(api.make_camera(width, height, pos=(1.7, 5.1, 14.0), pitch=12.0, yaw=186.0))
+    full.render_frame()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("renderer", [api.RENDERER_BIASED, api.RENDERER_UNBIASED])
 def test_environment_light_sequence_bit_exact(built_lib, renderer):
     """BASELINE config 5 ingredients: environment light (importance-sampled lat-long map, 25 % of the

@@ -121,6 +121,30 @@ def test_street_scene_and_counters(built_lib):
     _compare_closest(h2, _tri_ids(ctx, accel2), gpu_hits, gpu_ids, "street maxLeaf=2 vs 4")
 
 
+def test_launches_on_alternating_streams_hand_the_ticket_areas_over(built_lib):
+    """k_trace zeroes the ticket counters of the NEXT launch (no memset per launch): that hand-over is stream order, so a launch on
+    another stream waits for the last one and starts over with zeroed areas.  Six launches alternating between two streams with no
+    host synchronisation in between return what one launch returns."""
+    import torch
+    hs = util.small_street()
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    org, dirs = util.pinhole_rays(320, 200, (2.0, 5.0, 26.0), (0.0, 3.0, 0.0), fov_y_deg=60.0)
+    want = _gpu_trace(ctx, accel, api.TRACE_CLOSEST, org, dirs)
+    n = len(org)
+    d_org, d_dir = torch.from_numpy(org).cuda(), torch.from_numpy(dirs).cuda()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.zeros(n * 4, dtype=torch.int32, device="cuda") for _ in range(6)]
+    torch.cuda.synchronize()
+    for k, out in enumerate(outs):
+        ctx.trace(accel, api.TRACE_CLOSEST, d_org.data_ptr(), d_dir.data_ptr(), n, out.data_ptr(), 0, stream=streams[k % 2].cuda_stream)
+    torch.cuda.synchronize()
+    for k, out in enumerate(outs):
+        got = out.cpu().numpy().view(api.HIT_DTYPE).reshape(n)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"launch {k}"
+
+
 def test_degenerate_inputs(built_lib):
     ctx = api.Context(0)
     # empty scene: every ray misses

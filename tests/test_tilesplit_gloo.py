@@ -293,6 +293,13 @@ def test_balance_bands_and_check_bands(built_lib):
     # a lopsided profile cannot squeeze a band below the minimum
     tight = api.balance_bands(H, equal, [10.0] + [0.1] * 7, min_rows=64)
     assert all(e - b >= 64 for b, e in tight) and tight[0][1] - tight[0][0] == 64
+    # a height off the tile grid (1084 = 135 tiles + 4 rows): the last band ends in the partial tile and still gets its minimum in ROWS
+    ragged = api.balance_bands(1084, tilesplit.band_rows(1084, world), [0.1] * 7 + [10.0], min_rows=24)
+    assert ragged[-1][1] == 1084 and all(e - b >= 24 for b, e in ragged) and all(b % 8 == 0 for b, _ in ragged), ragged
+    ragged = api.balance_bands(1084, tilesplit.band_rows(1084, world), [10.0] + [0.1] * 7, min_rows=24)
+    assert all(e - b >= 24 for b, e in ragged), ragged
+    with pytest.raises(api.GfxError):
+        api.balance_bands(H, [(0, 100)] + [(100 + 140 * k, 240 + 140 * k) for k in range(6)] + [(940, H)], ms, min_rows=24)   # a boundary off the tile grid
     cfg = api.RestirRenderer.default_config(1920, H, api.RENDERER_BIASED)
     api.check_bands(cfg, cut)                                              # radius-20 strips fit every band of `cut`
     with pytest.raises(api.GfxError):
