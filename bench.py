@@ -83,30 +83,36 @@ def _profiled_kernels():
 
 
 def hbm_stream_peak(ctx):
-    """Streaming-copy rate of THIS box ("measure peak with a streaming-copy microbenchmark on the box, don't quote
-    the datasheet"): gfx_stream_copy (16-byte loads and stores per lane, non-temporal, grid-stride) over 1 GiB -- 4x the 256-MiB
-    Infinity Cache -- read + write bytes over the HIP-event time of 10 copies.  The torch byte copy of rounds 1-3 read 4.7-5.2 TB/s;
-    the microarchitecture guide quotes 6.29 TB/s for a float4 copy.  tools/hbm_stream.py is the stand-alone form."""
+    """Streaming rates of THIS box ("measure peak with a streaming-copy microbenchmark on the box, don't quote the
+    datasheet"): gfx_stream_copy -- per-block contiguous chunks, 16-byte non-temporal loads and stores per lane, the best of the shapes
+    of tools/microbench/stream_copy.hip -- over 1 GiB (4x the 256-MiB Infinity Cache), read + write bytes over the HIP-event time of
+    10 copies; and the same bytes read only.  Returns (copy GB/s, read-only GB/s).  The torch byte copy of rounds 1-3 read 4.7-5.2
+    TB/s; the microarchitecture guide quotes 6.29 TB/s for a float4 copy."""
     import torch
     n = 1 << 30
     a = torch.empty(n, dtype=torch.uint8, device="cuda")
     b = torch.empty(n, dtype=torch.uint8, device="cuda")
     a.fill_(1)
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(2):
-        ctx.stream_copy(b.data_ptr(), a.data_ptr(), n, stream)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
-    e0.record()
-    for _ in range(reps):
-        ctx.stream_copy(b.data_ptr(), a.data_ptr(), n, stream)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    ok = bool((b[::4097] == 1).all().item())
+
+    def timed(dst):
+        for _ in range(2):
+            ctx.stream_copy(dst, a.data_ptr(), n, stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            ctx.stream_copy(dst, a.data_ptr(), n, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    copy_s = timed(b.data_ptr())
+    ok = bool((b[::4097] == 1).all().item()) and bool((b[-64:] == 1).all().item())
+    read_s = timed(0)
     del a, b
     torch.cuda.empty_cache()
-    return round(2 * n / (ms * 1e-3) / 1e9, 1) if ok else None
+    return (round(2 * n / copy_s / 1e9, 1) if ok else None), round(n / read_s / 1e9, 1)
 
 
 def parse():
@@ -419,7 +425,7 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2):
         ours_bytes = nodes_per_primary * 80 + c["closest"]["triFetches"] / max(1, rays_closest) * 64
         sah_bytes = sah["nodes_per_ray"] * 80 + sah["tris_per_ray"] * 64
         frac_sah = round(achieved / HBM_PEAK_GBS * sah_bytes / ours_bytes, 4)
-    peak_measured = hbm_stream_peak(ctx)
+    peak_measured, peak_read_only = hbm_stream_peak(ctx)
     # what actually bounds the kernel (committed rocprofv3 PMC passes, profiles/make_pmc_json.py): VALU issue.
     # The BVH is served from L2 / Infinity Cache (`traffic` is 20-30x below the algorithmic bytes), so the SURVEY 8(d) byte
     # roof is nominal; the hardware-side figure is the share of VALU issue slots used and how many lanes each instruction carries.
@@ -445,8 +451,10 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2):
             "unit": "share of VALU issue slots x lanes carrying a ray (VALU busy x active lanes per instruction)" if useful is not None else "GB/s",
             "frac": useful if useful is not None else round(achieved / HBM_PEAK_GBS, 4),
             "achieved_nominal_hbm": round(achieved, 1), "peak_nominal_hbm": HBM_PEAK_GBS, "frac_nominal_hbm": round(achieved / HBM_PEAK_GBS, 4),
-            "peak_measured": peak_measured, "peak_measured_how": "gfx_stream_copy: 16-byte non-temporal loads / stores per lane, 1 GiB, read + write bytes, HIP events, live in this run",
+            "peak_measured": peak_measured, "peak_measured_read_only": peak_read_only,
+            "peak_measured_how": "gfx_stream_copy (per-block contiguous chunks, 16-byte non-temporal loads / stores per lane) over 1 GiB: read + write bytes, and the same bytes read only; HIP events, live in this run",
             "frac_of_peak_measured": round(achieved / peak_measured, 4) if peak_measured else None,
+            "frac_of_peak_measured_read_only": round(achieved / peak_read_only, 4) if peak_read_only else None,
             "valu": valu,
             "traffic": traffic if config == 2 else None,
             "traffic_source": (traffic_file + ": HBM bytes per launch by PMC (TCC_EA0_RDREQ / WRREQ passes of the default command), mean of the three launches") if config == 2 and traffic_file else None,

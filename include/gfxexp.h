@@ -496,8 +496,9 @@ int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[8], int reset);
  * items (the rest: item selection, loop overhead). */
 int gfx_trace_diag_read(gfx_ctx* ctx, uint64_t diag[8], int reset);
 /* Measurement utility ("measure peak with a streaming-copy microbenchmark on the box, don't quote the datasheet"): copies
- * `bytes` (a multiple of 16; both pointers 16-byte aligned, device memory) with 16-byte loads and stores per lane, on `stream`.  bench.py
- * times it with HIP events for roofline.peak_measured; no renderer calls it. */
+ * `bytes` (a multiple of 16; both pointers 16-byte aligned, device memory) with 16-byte non-temporal loads and stores per lane, on
+ * `stream`; dDst == NULL makes it a read-only pass over dSrc.  bench.py times both with HIP events for roofline.peak_measured /
+ * peak_measured_read_only; no renderer calls it. */
 int gfx_stream_copy(gfx_ctx* ctx, void* dDst, const void* dSrc, size_t bytes, void* stream);
 
 #ifdef __cplusplus

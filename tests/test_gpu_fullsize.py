@@ -454,3 +454,19 @@ def test_eight_band_strip_exchange_at_the_bench_configuration(built_lib, config)
     kinds = [k for k, _ in ex.calls[0]]
     # G-buffer strips + one reservoir strip per spatial pass (2 biased, 1 unbiased) per frame; one HDR gather per frame
     assert kinds.count(api.EXCHANGE_STRIPS) == frames * (2 if unbiased else 3) and kinds.count(api.EXCHANGE_GATHER_BANDS) == frames
+
+
+def test_regir_at_the_reference_grid_size_matches_the_oracle(built_lib):
+    """ReGIR at the reference's own scale (regir/regir_main.cpp:1112, regir_shared.h:7: 32 x 8 x 32 cells x 512 light slots =
+    4 194 304 slot reservoirs, 2^3 candidates per slot, 2^2 per cell, cell randomisation on) on the textured bench street at
+    1920x1080, two frames with temporal slot reuse, max path length 5.  Nothing is windowed: the oracle builds every slot and
+    path-traces every pixel (128 host threads), and after every pass of both frames ALL 4.19 M slot reservoirs and infos, the slot
+    RNGs, the per-cell access counters, the last-access frames, the active-cell counts, the pixel RNGs and the whole beauty /
+    albedo / normal buffers are compared bit for bit -- the big-launch paths of k_regir_build (one thread per slot, per-wave merge
+    of the cell counters) that the small-grid cases of test_gpu_regir.py never reach."""
+    from tests.test_gpu_regir import run_regir_both
+    hs = _scene("textured")
+    with util.frame_overrides(enableBumpMapping=1):
+        diffs = run_regir_both(hs, W, H, frames=2, max_len=5, temporal=True, dims=(32, 8, 32), randomize=1,
+                               camera=api.make_camera(W, H, **CAM), log2_slot=3, log2_cell=2)
+    assert not diffs, "\n".join(diffs[:16])

@@ -33,6 +33,7 @@ def main():
         b = torch.empty(n, dtype=torch.uint8, device="cuda")
         a.fill_(1)
         out[f"gfx_stream_copy_{gib}GiB_GBps"] = round(2 * n / timed(lambda: ctx.stream_copy(b.data_ptr(), a.data_ptr(), n, stream), 10) / 1e9, 1)
+        out[f"gfx_stream_read_only_{gib}GiB_GBps"] = round(n / timed(lambda: ctx.stream_copy(0, a.data_ptr(), n, stream), 10) / 1e9, 1)
         out[f"torch_copy_{gib}GiB_GBps"] = round(2 * n / timed(lambda: b.copy_(a), 10) / 1e9, 1)
         del a, b
         torch.cuda.empty_cache()
