@@ -344,8 +344,9 @@ struct NrcTrainArgs {
     const uint16_t* fwd; const uint16_t* bwd; const uint32_t* grid;
     const float* inputs; const float* targets; uint32_t numData;
     float* gradPartials;      // [numBlocks][mlpParams]
-    float* gridGrad;          // [gridParams] fp32 atomics, or (gridGradPacked) one fp16 pair per entry in the first half
-    int gridGradPacked;
+    float* gridGrad;          // [gridParams] fp32 atomics, or (mode 1) one fp16 pair per entry in the first half
+    int gridGradMode;         // kGridGradF32Atomics / kGridGradF16Atomics / kGridGradLdsTables
+    float2* gridDelta;        // mode 2: [16 levels][numData] dL/d(the level's two features), loss-scaled, for k_nrc_grid_scatter
     float* lossSum;
 };
 GFX_DEV void store_transposed(uint16_t* ldsT, int nt, int n, int h, const uint4 b[4]) {   // operand -> [feature][batch]
@@ -386,6 +387,16 @@ GFX_DEV void weight_gradient(const uint16_t* ldsDelta, const uint16_t* ldsAct, i
 // contribution w_c * dL/dfeature (loss-scaled by 128) is clamped to the fp16 range, rounded to fp16 (nearest even) and
 // added by the L2 atomic unit in fp16, so an entry that receives K contributions carries a relative error of the order
 // sqrt(K) * 2^-11 in its gradient sum (order-dependent, like the fp32 atomics) and contributions below 2^-24 * 128 vanish.
+// How the hash-grid gradient is summed (NrcNet::gridGradMode; GFX_NRC_GRID_GRAD = f32 | f16atomic | lds):
+//   0  two fp32 atomics per corner (global_atomic_add_f32)
+//   1  one packed-fp16 atomic per corner (global_atomic_pk_add_f16; what tiny-cuda-nn does with __half2) -- rounds 1-3
+//   2  the default: no global atomics.  The L2s retire these atomics at ~20 G/s in this access pattern whatever the launch shape
+//      (tools/microbench/pk_atomics.hip: 2.1 M atomics of a training step = 104 us, 138-307 us when the records cluster), which was
+//      72-76 % of k_nrc_train (profiles/r04_nrc_train_profile_before.jsonl).  Instead k_nrc_train writes dL/dfeature per record and
+//      level (coalesced), and k_nrc_grid_scatter -- one block per (level, chunk of records) -- sums a whole level table (<= 32 768
+//      packed-fp16 words = 128 KiB) in LDS with ds_pk_add_f16 and writes it out as one coalesced run; the optimizer adds the chunks'
+//      tables in fp32.  Same rounding points as mode 1 per contribution (clamp, fp16), fp16 sums inside a chunk, fp32 across chunks.
+constexpr int kGridGradF32Atomics = 0, kGridGradF16Atomics = 1, kGridGradLdsTables = 2;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 GFX_DEV void grid_grad_add_f16x2(uint32_t* word, float g0, float g1) {
     f16x2 v;
@@ -410,6 +421,8 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
     float* gradOut = a.gradPartials + static_cast<size_t>(tile) * mlpParams;
 
     // ---- forward
+    GFX_CYC_BEGIN
+    GFX_CYC(0);   // inputs + encoding (hash-grid gathers, one-blob)
     uint4 b[2][4];
     float xpos[2][3];
 #pragma unroll
@@ -426,6 +439,7 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
         for (int s = 0; s < 4; ++s) ldsOp[((0 * 2 + nt) * 4 + s) * 64 + lane] = b[nt][s];
         store_transposed(ldsActT, nt, n, h, b[nt]);
     }
+    GFX_CYC(1);   // hidden layers forward (weight fragments from L2, MFMA, activations to LDS twice)
     for (int layer = 0; layer < d.numHidden; ++layer) {
         const uint4* frags = fwd4 + layer * (kMatFwdElems / 8);
 #pragma unroll
@@ -439,6 +453,7 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
         }
     }
     // ---- output layer + loss gradient (RelativeL2Luminance)
+    GFX_CYC(2);   // output layer, loss, loss gradient
     uint4 delta[2][4];
     float lossLocal = 0.0f;
     {
@@ -477,6 +492,7 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
 
     // ---- backward
     // output matrix: dWout = delta_out . h_last^T; delta_last = (Wout^T . delta_out) * relu'(h_last)
+    GFX_CYC(3);   // backward through the layers: dW (MFMA over the batch, partials to HBM), delta (MFMA, ReLU masks from LDS)
     weight_gradient(ldsDeltaT, ldsActT + d.numHidden * 64 * kTStride, lane, 1, kNrcOutPad, gradOut + d.numHidden * 4096);
     __syncthreads();
     {
@@ -529,6 +545,7 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
                 store_transposed(ldsDeltaT, nt, n, h, delta[nt]);
             }
             else {
+                GFX_CYC(4);   // hash-grid gradient scatter (grid_corners again + one packed atomic per corner)
                 // dL/d(encoded input), fp32: scatter the hash-grid part.  Owned group q < 4 (canonical
                 // features 8 q + 4 h .. + 3 = levels 2 g, 2 g + 1 with g = 2 q + h) sits in M tile 0,
                 // registers 8 (q >> 1) + 4 (q & 1) + r.
@@ -542,10 +559,14 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
                         for (int k = 0; k < 2; ++k) {
                             const NrcLevel lv = d.levels[2 * g + k];
                             const float d0 = acc[0][base + 2 * k], d1 = acc[0][base + 2 * k + 1];
+                            if (a.gridGradMode == kGridGradLdsTables) {      // consecutive lanes = consecutive records: coalesced 8-byte stores
+                                a.gridDelta[static_cast<size_t>(2 * g + k) * a.numData + col] = make_float2(d0, d1);
+                                continue;
+                            }
                             if (d0 == 0.0f && d1 == 0.0f) continue;
                             uint32_t idx[8]; float w[8];
                             grid_corners(lv, xpos[nt][0], xpos[nt][1], xpos[nt][2], idx, w);
-                            if (a.gridGradPacked) {
+                            if (a.gridGradMode == kGridGradF16Atomics) {
                                 // one packed-fp16 atomic per corner (global_atomic_pk_add_f16; tiny-cuda-nn scatters __half2
                                 // the same way): the two features of an entry share a 32-bit word
 #pragma unroll
@@ -565,6 +586,44 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
         }
         __syncthreads();
     }
+    GFX_CYC_END;
+}
+#ifdef GFX_LANE_PROFILE   // experiment builds only (gm_math.hip.h GFX_CYC, tools/nrc_train_profile.py)
+extern "C" int gfx_debug_nrc_profile(unsigned long long* out64, int reset) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_laneProfile), sizeof(g_laneProfile)) != hipSuccess) return 1;
+    if (reset) { unsigned long long zero[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_laneProfile), zero, sizeof(zero)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
+// ---------------------------------------------------------------- hash-grid gradient: one level table per block, in LDS
+// grid (numChunks, 16 levels) x 256 threads; dynamic LDS = the level's entries x 4 B.  partials: [numChunks][all entries] packed fp16 pairs.
+constexpr int kScatterBlock = 256;
+__global__ __launch_bounds__(kScatterBlock) void k_nrc_grid_scatter(NrcDev d, const float* __restrict__ inputs, const float2* __restrict__ gridDelta,
+                                                                    uint32_t numData, uint32_t chunkRecords, uint32_t totalEntries, uint32_t* __restrict__ partials) {
+    extern __shared__ uint32_t ldsTable[];
+    const NrcLevel lv = d.levels[blockIdx.y];
+    for (uint32_t e = threadIdx.x; e < lv.entries; e += kScatterBlock) ldsTable[e] = 0u;
+    __syncthreads();
+    const uint32_t begin = blockIdx.x * chunkRecords, end = min(begin + chunkRecords, numData);
+    for (uint32_t r = begin + threadIdx.x; r < end; r += kScatterBlock) {
+        const float2 dl = gridDelta[static_cast<size_t>(blockIdx.y) * numData + r];
+        if (dl.x == 0.0f && dl.y == 0.0f) continue;
+        const float* x = inputs + static_cast<size_t>(r) * kNrcIn;
+        uint32_t idx[8]; float w[8];
+        grid_corners(lv, x[0], x[1], x[2], idx, w);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f16x2 v;
+            v.x = static_cast<_Float16>(fmin2(fmax2(w[c] * dl.x, -65504.0f), 65504.0f));
+            v.y = static_cast<_Float16>(fmin2(fmax2(w[c] * dl.y, -65504.0f), 65504.0f));
+            typedef __attribute__((address_space(3))) f16x2* LdsF16x2;
+            (void)__builtin_amdgcn_ds_atomic_fadd_v2f16((LdsF16x2)(ldsTable + (idx[c] - lv.offset)), v);
+        }
+    }
+    __syncthreads();
+    uint32_t* out = partials + static_cast<size_t>(blockIdx.x) * totalEntries + lv.offset;
+    for (uint32_t e = threadIdx.x; e < lv.entries; e += kScatterBlock) out[e] = ldsTable[e];
 }
 
 // ---------------------------------------------------------------- optimizer: Adam + EMA
@@ -573,7 +632,8 @@ struct NrcOptArgs {
     float* params; float* adamM; float* adamV; float* ema;
     const float* gradPartials; uint32_t numPartials; uint32_t mlpParams;
     float* gridGrad;
-    int gridGradPacked;       // cleared by the caller afterwards (two parameters share a word)
+    int gridGradMode;         // mode 1: cleared by the caller afterwards (two parameters share a word)
+    const uint32_t* gridPartials; uint32_t numGridChunks, totalEntries;   // mode 2: k_nrc_grid_scatter's tables
     float lrT, beta1, beta2, eps, l2Reg, emaDecay, debiasOld, debiasNew;
 };
 __global__ void k_nrc_optimizer(NrcOptArgs a) {
@@ -581,7 +641,16 @@ __global__ void k_nrc_optimizer(NrcOptArgs a) {
     if (p >= a.d.total) return;
     const bool isGrid = p >= a.d.gridOff;
     float g;
-    if (isGrid && a.gridGradPacked) {
+    if (isGrid && a.gridGradMode == kGridGradLdsTables) {
+        const uint32_t q = p - a.d.gridOff;
+        g = 0.0f;
+        for (uint32_t c = 0; c < a.numGridChunks; ++c) {        // chunk order: a defined fp32 sum
+            const uint32_t word = a.gridPartials[static_cast<size_t>(c) * a.totalEntries + (q >> 1)];
+            const uint16_t bits = static_cast<uint16_t>((q & 1u) ? word >> 16 : word & 0xFFFFu);
+            g += static_cast<float>(__builtin_bit_cast(_Float16, bits));
+        }
+    }
+    else if (isGrid && a.gridGradMode == kGridGradF16Atomics) {
         const uint32_t q = p - a.d.gridOff;
         const uint32_t word = reinterpret_cast<const uint32_t*>(a.gridGrad)[q >> 1];
         const uint16_t bits = static_cast<uint16_t>((q & 1u) ? word >> 16 : word & 0xFFFFu);
@@ -611,10 +680,11 @@ struct NrcNet {
     float learningRate;
     uint32_t step = 0;
     uint32_t mlpParams = 0, gridParams = 0;
-    DevBuf params, adamM, adamV, ema, gradPartials, gridGrad, lossSum;
+    DevBuf params, adamM, adamV, ema, gradPartials, gridGrad, lossSum, gridDelta, gridPartials;
     DevBuf packTrainFwd, packTrainBwd, packInferFwd, gridTrain, gridInfer;
     uint32_t partialCapacity = 0;
-    bool gridGradPacked = true;   // GFX_NRC_GRID_GRAD=f32 at creation: fp32 atomics, two per corner
+    int gridGradMode = kGridGradLdsTables;   // GFX_NRC_GRID_GRAD = f32 | f16atomic | lds at creation
+    size_t scatterLdsConfigured = 0;
 };
 
 static void nrc_levels(NrcDev& d) {
@@ -657,7 +727,8 @@ NrcNet* nrc_create(Context& ctx, int posEnc, uint32_t numHiddenLayers, float lea
     net->d.gridOff = net->mlpParams;
     nrc_levels(net->d);
     net->gridParams = net->d.total - net->d.gridOff;
-    if (const char* e = getenv("GFX_NRC_GRID_GRAD")) net->gridGradPacked = std::strcmp(e, "f32") != 0;
+    if (const char* e = getenv("GFX_NRC_GRID_GRAD"))
+        net->gridGradMode = std::strcmp(e, "f32") == 0 ? kGridGradF32Atomics : std::strcmp(e, "f16atomic") == 0 ? kGridGradF16Atomics : kGridGradLdsTables;
     const size_t bytes = sizeof(float) * net->d.total;
     net->params.reserve(bytes); net->adamM.reserve(bytes); net->adamV.reserve(bytes); net->ema.reserve(bytes);
     net->gridGrad.reserve(sizeof(float) * std::max<uint32_t>(net->gridParams, 4));
@@ -695,7 +766,7 @@ NrcNet* nrc_create(Context& ctx, int posEnc, uint32_t numHiddenLayers, float lea
 
 void nrc_destroy(NrcNet* net) {
     if (!net) return;
-    DevBuf* all[] = { &net->params, &net->adamM, &net->adamV, &net->ema, &net->gradPartials, &net->gridGrad, &net->lossSum,
+    DevBuf* all[] = { &net->params, &net->adamM, &net->adamV, &net->ema, &net->gradPartials, &net->gridGrad, &net->lossSum, &net->gridDelta, &net->gridPartials,
                       &net->packTrainFwd, &net->packTrainBwd, &net->packInferFwd, &net->gridTrain, &net->gridInfer };
     for (DevBuf* b : all) b->release();
     delete net;
@@ -754,7 +825,18 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     a.fwd = net->packTrainFwd.as<uint16_t>(); a.bwd = net->packTrainBwd.as<uint16_t>(); a.grid = net->gridTrain.as<uint32_t>();
     a.inputs = dInputs; a.targets = dTargets; a.numData = numData;
     a.gradPartials = net->gradPartials.as<float>(); a.gridGrad = net->gridGrad.as<float>(); a.lossSum = net->lossSum.as<float>();
-    a.gridGradPacked = net->gridGradPacked ? 1 : 0;
+    a.gridGradMode = net->gridGradMode;
+    a.gridDelta = nullptr;
+    const bool ldsTables = net->d.posEnc == 1 && net->gridGradMode == kGridGradLdsTables;
+    // chunks of records per level table: sixteen for the reference's 16 384-record step (256 blocks), never fewer than 256 records
+    const uint32_t chunkRecords = std::max<uint32_t>(256u, ((numData + 15u) / 16u + 63u) / 64u * 64u);
+    const uint32_t numChunks = (numData + chunkRecords - 1u) / chunkRecords;
+    const uint32_t totalEntries = net->gridParams / 2;
+    if (ldsTables) {
+        net->gridDelta.reserve(sizeof(float2) * static_cast<size_t>(kHashLevels) * numData);
+        net->gridPartials.reserve(sizeof(uint32_t) * static_cast<size_t>(numChunks) * totalEntries);
+        a.gridDelta = net->gridDelta.as<float2>();
+    }
     const int numLayers = net->d.numHidden + 1;
     const size_t lds = static_cast<size_t>(numLayers) * 2 * 4 * 64 * 16 + (static_cast<size_t>(numLayers) + 1) * 64 * kTStride * 2;
     if (lds > ctx.nrcTrainLdsConfigured) {   // per device: the attribute belongs to the device's copy of the kernel
@@ -766,13 +848,27 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
         hipLaunchKernelGGL(k_nrc_train, dim3(numBlocks), dim3(64), lds, stream, a);
         GFX_HIP(hipGetLastError());
     }
+    if (ldsTables) {
+        uint32_t maxEntries = 0;
+        for (int l = 0; l < kHashLevels; ++l) maxEntries = std::max(maxEntries, net->d.levels[l].entries);
+        const size_t scatterLds = sizeof(uint32_t) * maxEntries;
+        if (scatterLds > net->scatterLdsConfigured) {
+            GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(scatterLds)));
+            net->scatterLdsConfigured = scatterLds;
+        }
+        ScopedKernelTimer timer(ctx, stream, "nrc_grid_scatter");
+        hipLaunchKernelGGL(k_nrc_grid_scatter, dim3(numChunks, kHashLevels), dim3(kScatterBlock), scatterLds, stream, net->d, dInputs, net->gridDelta.as<float2>(),
+                           numData, chunkRecords, totalEntries, net->gridPartials.as<uint32_t>());
+        GFX_HIP(hipGetLastError());
+    }
     // Adam (beta1 0.9, beta2 0.99, l2_reg 1e-6) inside EMA(0.99): network_interface.cu:53-64, 91, 118
     ++net->step;
     NrcOptArgs o;
     o.d = net->d;
     o.params = net->params.as<float>(); o.adamM = net->adamM.as<float>(); o.adamV = net->adamV.as<float>(); o.ema = net->ema.as<float>();
     o.gradPartials = net->gradPartials.as<float>(); o.numPartials = numBlocks; o.mlpParams = net->mlpParams;
-    o.gridGrad = net->gridGrad.as<float>(); o.gridGradPacked = net->gridGradPacked ? 1 : 0;
+    o.gridGrad = net->gridGrad.as<float>(); o.gridGradMode = net->gridGradMode;
+    o.gridPartials = net->gridPartials.as<uint32_t>(); o.numGridChunks = ldsTables ? numChunks : 0; o.totalEntries = totalEntries;
     o.beta1 = 0.9f; o.beta2 = 0.99f; o.l2Reg = 1e-6f; o.emaDecay = 0.99f;
     o.eps = net->d.posEnc == 1 ? 1e-15f : 1e-8f;
     const double t = net->step;
@@ -784,7 +880,7 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
         ScopedKernelTimer timer(ctx, stream, "nrc_optimizer");
         hipLaunchKernelGGL(k_nrc_optimizer, dim3((net->d.total + 255) / 256), dim3(256), 0, stream, o);
         GFX_HIP(hipGetLastError());
-        if (net->gridGradPacked && net->gridParams) GFX_HIP(hipMemsetAsync(net->gridGrad.p, 0, sizeof(uint32_t) * (net->gridParams / 2), stream));
+        if (net->gridGradMode == kGridGradF16Atomics && net->gridParams) GFX_HIP(hipMemsetAsync(net->gridGrad.p, 0, sizeof(uint32_t) * (net->gridParams / 2), stream));
     }
     nrc_pack(ctx, stream, *net, true);
     nrc_pack(ctx, stream, *net, false);

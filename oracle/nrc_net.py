@@ -191,9 +191,10 @@ class NrcNet:
     """fp32 master parameters + Adam/EMA state; forward/backward with the bf16 rounding contract."""
 
     def __init__(self, pos_enc=POS_HASHGRID, num_hidden_layers=2, learning_rate=1e-2, params=None, bf16=True, grid_grad_f16=True):
-        # grid_grad_f16: the hash-grid gradient is scattered as fp16 pairs (tiny-cuda-nn's __half2 atomics; nrc.hip
-        # grid_grad_add_f16x2): contributions are rounded to fp16, and so is the per-entry sum.  The order of the
-        # additions on the device is not defined, so the restatement sums in fp32 and rounds once.
+        # grid_grad_f16: the hash-grid gradient is summed as fp16 pairs (tiny-cuda-nn scatters __half2; nrc.hip k_nrc_grid_scatter
+        # sums a level table per chunk of records in LDS with ds_pk_add_f16): contributions are rounded to fp16, and so is the
+        # per-entry sum of a chunk.  The order of the additions inside a chunk is not defined on the device, so the restatement
+        # sums a chunk in fp32 and rounds once; the chunks are added in fp32 (gradients()).
         self.grid_grad_f16 = grid_grad_f16 and bf16
         self.pos_enc, self.n_hidden, self.lr = pos_enc, num_hidden_layers, np.float32(learning_rate)
         self.rnd = bf16_round if bf16 else (lambda a: np.ascontiguousarray(a, np.float32))   # bf16=False: plain fp32 (gradient checks)
@@ -269,17 +270,28 @@ class NrcNet:
                     back = back * (a > 0)
                 delta = self.rnd(back) if li > 0 else back    # the grid scatter consumes fp32
         if self.pos_enc == POS_HASHGRID:
-            gg = np.zeros((self.total - self.grid_off) // HASH_FEATURES * HASH_FEATURES, np.float32).reshape(-1, HASH_FEATURES)
-            for l, (idx, w) in enumerate(hash_corners(np.ascontiguousarray(x[:, 0:3], np.float32))):
-                d = delta[:, 2 * l:2 * l + 2]
-                for c in range(8):
-                    contrib = (w[:, c:c + 1] * d).astype(np.float32)
-                    if self.grid_grad_f16:
-                        contrib = np.clip(contrib, -65504.0, 65504.0).astype(np.float16).astype(np.float32)
-                    np.add.at(gg, idx[:, c], contrib)
-            if self.grid_grad_f16:
-                gg = gg.astype(np.float16).astype(np.float32)
-            g[self.grid_off:] = gg.reshape(-1)
+            n_rec = x.shape[0]
+            entries = (self.total - self.grid_off) // HASH_FEATURES
+            # nrc.hip k_nrc_grid_scatter: the records are cut into chunks (sixteen for a 16 384-record step, at least 256 records each);
+            # a chunk's contributions are summed in fp16 (LDS atomics, order undefined -- restated as an fp32 sum rounded once), the
+            # chunks' sums are added in fp32 in chunk order
+            chunk = max(256, ((n_rec + 15) // 16 + 63) // 64 * 64) if self.grid_grad_f16 else n_rec
+            corners = hash_corners(np.ascontiguousarray(x[:, 0:3], np.float32))
+            total = np.zeros((entries, HASH_FEATURES), np.float32)
+            for begin in range(0, n_rec, chunk):
+                sl = slice(begin, min(begin + chunk, n_rec))
+                gg = np.zeros((entries, HASH_FEATURES), np.float32)
+                for l, (idx, w) in enumerate(corners):
+                    d = delta[sl, 2 * l:2 * l + 2]
+                    for c in range(8):
+                        contrib = (w[sl, c:c + 1] * d).astype(np.float32)
+                        if self.grid_grad_f16:
+                            contrib = np.clip(contrib, -65504.0, 65504.0).astype(np.float16).astype(np.float32)
+                        np.add.at(gg, idx[sl, c], contrib)
+                if self.grid_grad_f16:
+                    gg = gg.astype(np.float16).astype(np.float32)
+                total = (total + gg).astype(np.float32)
+            g[self.grid_off:] = total.reshape(-1)
         return np.float32(loss.sum()), g
 
     def optimizer_step(self, g, loss_scale=128.0):
