@@ -445,7 +445,7 @@ int gfx_nrc_get_params(gfx_ctx* ctx, uint64_t handle, int which, float* hostOut,
 int gfx_nrc_inference_image(gfx_ctx* ctx, uint64_t handle, int which, void** dPtr, uint64_t* bytes) {
     GFX_TRY(ctx)
     if (!dPtr || !bytes) throw HipError("gfx_nrc_inference_image: null output");
-    nrc_inference_image(nrc_of(ctx, handle), which, dPtr, bytes);
+    nrc_inference_image(ctx->c, nrc_of(ctx, handle), which, dPtr, bytes);
     GFX_CATCH(ctx)
 }
 

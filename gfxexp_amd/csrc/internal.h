@@ -237,7 +237,7 @@ void nrc_destroy(NrcNet* net);
 uint32_t nrc_num_params(const NrcNet* net);
 void nrc_set_params(Context& ctx, hipStream_t stream, NrcNet* net, const float* hostParams, uint32_t count);
 void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count);
-void nrc_inference_image(NrcNet* net, int which, void** dPtr, uint64_t* bytes);
+void nrc_inference_image(Context& ctx, NrcNet* net, int which, void** dPtr, uint64_t* bytes);
 void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions, const uint32_t* dNumData = nullptr);
 void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, const float* dTargets, uint32_t numData, float* lossOnCPU);
 // ---- pathtrace.hip

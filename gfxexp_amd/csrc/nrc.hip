@@ -361,6 +361,7 @@ GFX_DEV void store_transposed(uint16_t* ldsT, int nt, int n, int h, const uint4 
     }
 }
 // dW [outRows x 64] of one layer: A = delta^T (M = out feature, K = batch), B = act^T (K = batch, N = in feature)
+template <int KSTEPS>   // K = batch: 16 records per MFMA step
 GFX_DEV void weight_gradient(const uint16_t* ldsDelta, const uint16_t* ldsAct, int lane, int outTiles, int outRows, float* gradOut) {
     const int m = lane & 31, h = lane >> 5;
     for (int mt = 0; mt < outTiles; ++mt)
@@ -370,7 +371,7 @@ GFX_DEV void weight_gradient(const uint16_t* ldsDelta, const uint16_t* ldsAct, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[r] = 0.0f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < KSTEPS; ++ks) {
                 const uint4 a = *reinterpret_cast<const uint4*>(ldsDelta + (32 * mt + m) * kTStride + 16 * ks + 8 * h);
                 const uint4 b = *reinterpret_cast<const uint4*>(ldsAct + (32 * nt + m) * kTStride + 16 * ks + 8 * h);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -406,12 +407,16 @@ GFX_DEV void grid_grad_add_f16x2(uint32_t* word, float g0, float g1) {
     (void)__builtin_amdgcn_global_atomic_fadd_v2f16((GlobalF16x2)word, v);
 }
 
+// NT = N tiles (of 32 records) per wave: 2 = 64 records per block (rounds 1-3), 1 = 32 records per block -- twice the blocks, two waves
+// per CU for the reference's 16 384-record step, half the dependent gathers per wave (the step is a latency chain of one wave per CU).
+template <int NT>
 __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
+    constexpr int kTile = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) uint4 ldsT4[];
     const NrcDev& d = a.d;
     const int numLayers = d.numHidden + 1;                       // activation sets: encoded input + hidden outputs
     uint4* ldsOp = ldsT4;                                        // [numLayers][nt][s][lane] operand order
-    uint16_t* ldsActT = reinterpret_cast<uint16_t*>(ldsOp + numLayers * 2 * 4 * 64);   // [numLayers][64][kTStride]
+    uint16_t* ldsActT = reinterpret_cast<uint16_t*>(ldsOp + numLayers * NT * 4 * 64);   // [numLayers][64][kTStride]
     uint16_t* ldsDeltaT = ldsActT + numLayers * 64 * kTStride;   // [64][kTStride]
     const int lane = threadIdx.x, h = lane >> 5, n = lane & 31;
     const uint32_t tile = blockIdx.x;
@@ -423,11 +428,11 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
     // ---- forward
     GFX_CYC_BEGIN
     GFX_CYC(0);   // inputs + encoding (hash-grid gathers, one-blob)
-    uint4 b[2][4];
-    float xpos[2][3];
+    uint4 b[NT][4];
+    float xpos[NT][3];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const uint32_t col = tile * 64 + 32 * nt + n;
+    for (int nt = 0; nt < NT; ++nt) {
+        const uint32_t col = tile * kTile + 32 * nt + n;
         float x[kNrcIn];
 #pragma unroll
         for (int k = 0; k < kNrcIn; ++k) x[k] = col < a.numData ? a.inputs[static_cast<size_t>(col) * kNrcIn + k] : 0.0f;
@@ -436,31 +441,31 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
         encode_half(d, a.grid, x, h, enc);
         to_operand(enc, b[nt]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ldsOp[((0 * 2 + nt) * 4 + s) * 64 + lane] = b[nt][s];
+        for (int s = 0; s < 4; ++s) ldsOp[((0 * NT + nt) * 4 + s) * 64 + lane] = b[nt][s];
         store_transposed(ldsActT, nt, n, h, b[nt]);
     }
     GFX_CYC(1);   // hidden layers forward (weight fragments from L2, MFMA, activations to LDS twice)
     for (int layer = 0; layer < d.numHidden; ++layer) {
         const uint4* frags = fwd4 + layer * (kMatFwdElems / 8);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             f32x16 acc[2];
             layer64(frags, lane, b[nt], acc);
             relu_to_operand(acc, b[nt]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) ldsOp[(((layer + 1) * 2 + nt) * 4 + s) * 64 + lane] = b[nt][s];
+            for (int s = 0; s < 4; ++s) ldsOp[(((layer + 1) * NT + nt) * 4 + s) * 64 + lane] = b[nt][s];
             store_transposed(ldsActT + (layer + 1) * 64 * kTStride, nt, n, h, b[nt]);
         }
     }
     // ---- output layer + loss gradient (RelativeL2Luminance)
     GFX_CYC(2);   // output layer, loss, loss gradient
-    uint4 delta[2][4];
+    uint4 delta[NT][4];
     float lossLocal = 0.0f;
     {
         const uint4* fragsOut = fwd4 + d.numHidden * (kMatFwdElems / 8);
         const float nTotal = static_cast<float>(a.numData) * kNrcOut;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             f32x16 c;
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[r] = 0.0f;
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fragsOut[s * 64 + lane]),
                                                             __builtin_bit_cast(bf16x8, b[nt][s]), c, 0, 0, 0);
             float dv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-            const uint32_t col = tile * 64 + 32 * nt + n;
+            const uint32_t col = tile * kTile + 32 * nt + n;
             if (h == 0 && col < a.numData) {
                 const float* t = a.targets + static_cast<size_t>(col) * kNrcOut;
                 const float lum = 0.299f * c[0] + 0.587f * c[1] + 0.114f * c[2];
@@ -493,12 +498,12 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
     // ---- backward
     // output matrix: dWout = delta_out . h_last^T; delta_last = (Wout^T . delta_out) * relu'(h_last)
     GFX_CYC(3);   // backward through the layers: dW (MFMA over the batch, partials to HBM), delta (MFMA, ReLU masks from LDS)
-    weight_gradient(ldsDeltaT, ldsActT + d.numHidden * 64 * kTStride, lane, 1, kNrcOutPad, gradOut + d.numHidden * 4096);
+    weight_gradient<2 * NT>(ldsDeltaT, ldsActT + d.numHidden * 64 * kTStride, lane, 1, kNrcOutPad, gradOut + d.numHidden * 4096);
     __syncthreads();
     {
         const uint4* fragsT = bwd4 + d.numHidden * (kMatFwdElems / 8);     // WoutT: fragments (mt, s), s in {0, 1}
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             f32x16 acc[2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float act[8], v[8];
-                unpack8(ldsOp[((d.numHidden * 2 + nt) * 4 + s) * 64 + lane], act);
+                unpack8(ldsOp[((d.numHidden * NT + nt) * 4 + s) * 64 + lane], act);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = act[i] > 0.0f ? acc[s >> 1][8 * (s & 1) + i] : 0.0f;
                 delta[nt][s] = pack8(v);
@@ -525,19 +530,19 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
     __syncthreads();
     for (int layer = d.numHidden - 1; layer >= 0; --layer) {
         // dW_layer = delta_{layer+1} . act_layer^T
-        weight_gradient(ldsDeltaT, ldsActT + layer * 64 * kTStride, lane, 2, 64, gradOut + layer * 4096);
+        weight_gradient<2 * NT>(ldsDeltaT, ldsActT + layer * 64 * kTStride, lane, 2, 64, gradOut + layer * 4096);
         __syncthreads();
         if (layer == 0 && d.posEnc != 1) break;
         const uint4* fragsT = bwd4 + layer * (kMatFwdElems / 8);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             f32x16 acc[2];
             layer64(fragsT, lane, delta[nt], acc);
             if (layer > 0) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     float act[8], v[8];
-                    unpack8(ldsOp[((layer * 2 + nt) * 4 + s) * 64 + lane], act);
+                    unpack8(ldsOp[((layer * NT + nt) * 4 + s) * 64 + lane], act);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = act[i] > 0.0f ? acc[s >> 1][8 * (s & 1) + i] : 0.0f;
                     delta[nt][s] = pack8(v);
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(64) void k_nrc_train(NrcTrainArgs a) {
                 // dL/d(encoded input), fp32: scatter the hash-grid part.  Owned group q < 4 (canonical
                 // features 8 q + 4 h .. + 3 = levels 2 g, 2 g + 1 with g = 2 q + h) sits in M tile 0,
                 // registers 8 (q >> 1) + 4 (q & 1) + r.
-                const uint32_t col = tile * 64 + 32 * nt + n;
+                const uint32_t col = tile * kTile + 32 * nt + n;
                 if (col < a.numData) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -626,11 +631,33 @@ __global__ __launch_bounds__(kScatterBlock) void k_nrc_grid_scatter(NrcDev d, co
     for (uint32_t e = threadIdx.x; e < lv.entries; e += kScatterBlock) out[e] = ldsTable[e];
 }
 
+// ---------------------------------------------------------------- dW partials -> one gradient
+// The training blocks leave one dW partial each (256-512 per step); summing them per parameter inside the optimizer was a chain of
+// that many dependent-latency loads in the 9 216 threads that own an MLP weight while the million grid threads had long finished.
+// Here 16 threads share a parameter (each sums every 16th partial), the 16 sums are added in slice order through LDS: a defined fp32 order.
+constexpr int kReduceBlock = 256, kReduceSlices = 16;
+__global__ __launch_bounds__(kReduceBlock) void k_nrc_reduce_partials(const float* __restrict__ partials, uint32_t numPartials, uint32_t mlpParams, float* __restrict__ gradSum) {
+    __shared__ float lds[kReduceBlock];
+    const uint32_t pi = threadIdx.x & (kReduceBlock / kReduceSlices - 1), slice = threadIdx.x / (kReduceBlock / kReduceSlices);
+    const uint32_t p = blockIdx.x * (kReduceBlock / kReduceSlices) + pi;
+    float g = 0.0f;
+    if (p < mlpParams)
+        for (uint32_t k = slice; k < numPartials; k += kReduceSlices) g += partials[static_cast<size_t>(k) * mlpParams + p];
+    lds[threadIdx.x] = g;
+    __syncthreads();
+    if (slice == 0 && p < mlpParams) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int sl = 0; sl < kReduceSlices; ++sl) sum += lds[sl * (kReduceBlock / kReduceSlices) + pi];
+        gradSum[p] = sum;
+    }
+}
+
 // ---------------------------------------------------------------- optimizer: Adam + EMA
 struct NrcOptArgs {
     NrcDev d;
     float* params; float* adamM; float* adamV; float* ema;
-    const float* gradPartials; uint32_t numPartials; uint32_t mlpParams;
+    const float* gradPartials; uint32_t mlpParams;      // the summed dW (k_nrc_reduce_partials)
     float* gridGrad;
     int gridGradMode;         // mode 1: cleared by the caller afterwards (two parameters share a word)
     const uint32_t* gridPartials; uint32_t numGridChunks, totalEntries;   // mode 2: k_nrc_grid_scatter's tables
@@ -657,10 +684,7 @@ __global__ void k_nrc_optimizer(NrcOptArgs a) {
         g = static_cast<float>(__builtin_bit_cast(_Float16, bits));
     }
     else if (isGrid) { g = a.gridGrad[p - a.d.gridOff]; a.gridGrad[p - a.d.gridOff] = 0.0f; }
-    else {
-        g = 0.0f;
-        for (uint32_t k = 0; k < a.numPartials; ++k) g += a.gradPartials[static_cast<size_t>(k) * a.mlpParams + p];
-    }
+    else g = a.gradPartials[p];                                  // k_nrc_reduce_partials' sum
     float grad = g / kLossScale;
     float w = a.params[p];
     if (!(isGrid && grad == 0.0f)) {       // untouched hash-grid entries keep their moments
@@ -680,9 +704,13 @@ struct NrcNet {
     float learningRate;
     uint32_t step = 0;
     uint32_t mlpParams = 0, gridParams = 0;
-    DevBuf params, adamM, adamV, ema, gradPartials, gridGrad, lossSum, gridDelta, gridPartials;
+    DevBuf params, adamM, adamV, ema, gradPartials, gradSum, gridGrad, lossSum, gridDelta, gridPartials;
     DevBuf packTrainFwd, packTrainBwd, packInferFwd, gridTrain, gridInfer;
     uint32_t partialCapacity = 0;
+    // the inference images (bf16 fragments + grid of the EMA weights) are packed when somebody asks for them, not after every step:
+    // a frame trains four steps and infers once
+    bool inferDirty = false;
+    hipStream_t lastTrainStream = nullptr;
     int gridGradMode = kGridGradLdsTables;   // GFX_NRC_GRID_GRAD = f32 | f16atomic | lds at creation
     size_t scatterLdsConfigured = 0;
 };
@@ -766,7 +794,7 @@ NrcNet* nrc_create(Context& ctx, int posEnc, uint32_t numHiddenLayers, float lea
 
 void nrc_destroy(NrcNet* net) {
     if (!net) return;
-    DevBuf* all[] = { &net->params, &net->adamM, &net->adamV, &net->ema, &net->gradPartials, &net->gridGrad, &net->lossSum, &net->gridDelta, &net->gridPartials,
+    DevBuf* all[] = { &net->params, &net->adamM, &net->adamV, &net->ema, &net->gradPartials, &net->gradSum, &net->gridGrad, &net->lossSum, &net->gridDelta, &net->gridPartials,
                       &net->packTrainFwd, &net->packTrainBwd, &net->packInferFwd, &net->gridTrain, &net->gridInfer };
     for (DevBuf* b : all) b->release();
     delete net;
@@ -784,9 +812,12 @@ void nrc_set_params(Context& ctx, hipStream_t stream, NrcNet* net, const float* 
     net->step = 0;
     nrc_pack(ctx, stream, *net, true);
     nrc_pack(ctx, stream, *net, false);
+    net->inferDirty = false;
     GFX_HIP(hipStreamSynchronize(stream));
 }
-void nrc_inference_image(NrcNet* net, int which, void** dPtr, uint64_t* bytes) {
+void nrc_inference_image(Context& ctx, NrcNet* net, int which, void** dPtr, uint64_t* bytes) {
+    // stream order with the training that made the images stale (the caller orders itself after that stream, as it always had to)
+    if (net->inferDirty) { nrc_pack(ctx, net->lastTrainStream, *net, false); net->inferDirty = false; }
     const uint32_t fwdElems = net->d.numHidden * kMatFwdElems + kOutFwdElems;
     if (which == 0) { *dPtr = net->packInferFwd.p; *bytes = 2ull * fwdElems; }
     else if (which == 1) { *dPtr = net->d.posEnc == 1 ? net->gridInfer.p : nullptr; *bytes = net->d.posEnc == 1 ? 2ull * net->gridParams : 0; }
@@ -803,6 +834,8 @@ void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count) {
 void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions, const uint32_t* dNumData) {
     if (numData & 0x7F) throw HipError("gfx_nrc_infer: numData must be a multiple of 128");   // network_interface.cu:143
     if (numData == 0) return;
+    // `stream` is ordered after the training whose weights it wants to see (it read the packed images before, too)
+    if (net->inferDirty) { nrc_pack(ctx, stream, *net, false); net->inferDirty = false; }
     const int numCUs = ctx.numCUs;
     const uint32_t numTiles = numData / 64;
     const uint32_t wavesPerBlock = kInferBlock / 64;
@@ -817,7 +850,11 @@ void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
 void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, const float* dTargets, uint32_t numData, float* lossOnCPU) {
     if (numData & 0x7F) throw HipError("gfx_nrc_train: numData must be a multiple of 128");   // network_interface.cu:151
     if (numData == 0) return;
-    const uint32_t numBlocks = numData / 64;
+    // records per one-wave block: 32 while that still leaves the GPU short of blocks (the reference's 16 384-record step: 512 blocks on 256 CUs),
+    // 64 for large batches (half the dW partials)
+    static const int forcedTile = [] { const char* e = getenv("GFX_NRC_TRAIN_TILE"); return e ? atoi(e) : 0; }();
+    const uint32_t tileRecords = forcedTile == 32 || forcedTile == 64 ? static_cast<uint32_t>(forcedTile) : (numData / 64 >= 4u * static_cast<uint32_t>(ctx.numCUs) ? 64u : 32u);
+    const uint32_t numBlocks = numData / tileRecords;
     net->gradPartials.reserve(sizeof(float) * static_cast<size_t>(numBlocks) * net->mlpParams);
     GFX_HIP(hipMemsetAsync(net->lossSum.p, 0, sizeof(float), stream));
     NrcTrainArgs a;
@@ -838,14 +875,18 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
         a.gridDelta = net->gridDelta.as<float2>();
     }
     const int numLayers = net->d.numHidden + 1;
-    const size_t lds = static_cast<size_t>(numLayers) * 2 * 4 * 64 * 16 + (static_cast<size_t>(numLayers) + 1) * 64 * kTStride * 2;
-    if (lds > ctx.nrcTrainLdsConfigured) {   // per device: the attribute belongs to the device's copy of the kernel
-        GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_train), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        ctx.nrcTrainLdsConfigured = lds;
+    const uint32_t nTiles = tileRecords / 32;
+    const size_t lds = static_cast<size_t>(numLayers) * nTiles * 4 * 64 * 16 + (static_cast<size_t>(numLayers) + 1) * 64 * kTStride * 2;
+    const size_t ldsMax = static_cast<size_t>(kMaxHidden + 1) * 2 * 4 * 64 * 16 + (static_cast<size_t>(kMaxHidden) + 2) * 64 * kTStride * 2;
+    if (ldsMax > ctx.nrcTrainLdsConfigured) {   // per device: the attribute belongs to the device's copy of the kernels
+        GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_train<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsMax)));
+        GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_train<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsMax)));
+        ctx.nrcTrainLdsConfigured = ldsMax;
     }
     {
         ScopedKernelTimer timer(ctx, stream, "nrc_train_fwd_bwd");
-        hipLaunchKernelGGL(k_nrc_train, dim3(numBlocks), dim3(64), lds, stream, a);
+        if (nTiles == 1) hipLaunchKernelGGL(k_nrc_train<1>, dim3(numBlocks), dim3(64), lds, stream, a);
+        else hipLaunchKernelGGL(k_nrc_train<2>, dim3(numBlocks), dim3(64), lds, stream, a);
         GFX_HIP(hipGetLastError());
     }
     if (ldsTables) {
@@ -866,7 +907,15 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     NrcOptArgs o;
     o.d = net->d;
     o.params = net->params.as<float>(); o.adamM = net->adamM.as<float>(); o.adamV = net->adamV.as<float>(); o.ema = net->ema.as<float>();
-    o.gradPartials = net->gradPartials.as<float>(); o.numPartials = numBlocks; o.mlpParams = net->mlpParams;
+    net->gradSum.reserve(sizeof(float) * net->mlpParams);
+    {
+        ScopedKernelTimer timer(ctx, stream, "nrc_reduce_partials");
+        const uint32_t perBlock = kReduceBlock / kReduceSlices;
+        hipLaunchKernelGGL(k_nrc_reduce_partials, dim3((net->mlpParams + perBlock - 1) / perBlock), dim3(kReduceBlock), 0, stream,
+                           net->gradPartials.as<float>(), numBlocks, net->mlpParams, net->gradSum.as<float>());
+        GFX_HIP(hipGetLastError());
+    }
+    o.gradPartials = net->gradSum.as<float>(); o.mlpParams = net->mlpParams;
     o.gridGrad = net->gridGrad.as<float>(); o.gridGradMode = net->gridGradMode;
     o.gridPartials = net->gridPartials.as<uint32_t>(); o.numGridChunks = ldsTables ? numChunks : 0; o.totalEntries = totalEntries;
     o.beta1 = 0.9f; o.beta2 = 0.99f; o.l2Reg = 1e-6f; o.emaDecay = 0.99f;
@@ -883,7 +932,7 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
         if (net->gridGradMode == kGridGradF16Atomics && net->gridParams) GFX_HIP(hipMemsetAsync(net->gridGrad.p, 0, sizeof(uint32_t) * (net->gridParams / 2), stream));
     }
     nrc_pack(ctx, stream, *net, true);
-    nrc_pack(ctx, stream, *net, false);
+    net->inferDirty = true; net->lastTrainStream = stream;
     if (lossOnCPU) {
         GFX_HIP(hipStreamSynchronize(stream));
         GFX_HIP(hipMemcpy(lossOnCPU, net->lossSum.p, sizeof(float), hipMemcpyDeviceToHost));

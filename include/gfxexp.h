@@ -463,8 +463,9 @@ int gfx_nrc_num_params(gfx_ctx* ctx, uint64_t handle, uint32_t* outCount);
 int gfx_nrc_set_params(gfx_ctx* ctx, uint64_t handle, const float* hostParams, uint32_t count);
 int gfx_nrc_get_params(gfx_ctx* ctx, uint64_t handle, int which, float* hostOut, uint32_t count);
 /* The device images gfx_nrc_infer reads: which = 0 the packed bf16 MLP fragments, 1 the packed bf16 hash grid (null / 0 for
- * the triangle-wave encoding); rewritten by every gfx_nrc_train / gfx_nrc_set_params.  A process that does not train (a band
- * renderer other than rank 0, gfxh_nrc_set_exchange) receives these bytes from the one that does. */
+ * the triangle-wave encoding); brought up to date with the trained (EMA) weights by this call and by gfx_nrc_infer -- in stream order
+ * after the last gfx_nrc_train, on that call's stream -- not after every training step (a frame trains four steps and infers once).
+ * A process that does not train (a band renderer other than rank 0, gfxh_nrc_set_exchange) receives these bytes from the one that does. */
 int gfx_nrc_inference_image(gfx_ctx* ctx, uint64_t handle, int which, void** dPtr, uint64_t* bytes);
 
 /* Blocking device-to-host copy of library- or caller-owned device memory (TypedBuffer::read,
