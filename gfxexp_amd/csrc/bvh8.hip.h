@@ -133,32 +133,6 @@ struct Traversal {
         return grp.x + __builtin_popcount(imaskG & ((1u << slot) - 1u));
     }
 
-    // The dual form of next_item (trace.hip, DUAL): the next pending triangle AND -- when it is the last one pending of its node -- the
-    // next node of the walk, for the same iteration.  A lane that tests the last leaf triangle of a node no longer spends an iteration
-    // of its own on it: the node walk goes on underneath.  (While more triangles of the node wait, the walk stays where it is: the
-    // next node's leaf hits would need the one triMask register.)  nodeCode = kItemNone / node index, triIndex = kItemNone / triangle.
-    GFX_DEV void next_items(LaneStack& stack, uint32_t& nodeCode, uint32_t& triIndex) {
-        nodeCode = kItemNone; triIndex = kItemNone;
-        if (triMask & 0xFFu) {
-            const uint32_t slot = __builtin_ctz(triMask);
-            triMask &= triMask - 1u;
-            triIndex = triBase + __builtin_popcount((triMask >> 8) & ((1u << slot) - 1u));
-            if (triMask & 0xFFu) return;
-        }
-        triMask = 0;
-        uint32_t hits = grp.y & 0xFFu;
-        if (hits == 0) {
-            if (stack.sp == 0) { if (triIndex == kItemNone) active = false; return; }
-            grp = stack.pop();
-            hits = grp.y & 0xFFu;
-        }
-        const uint32_t pos = __builtin_ctz(hits);
-        grp.y &= ~(1u << pos);
-        const uint32_t slot = pos ^ oct;
-        const uint32_t imaskG = (grp.y >> 8) & 0xFFu;
-        nodeCode = grp.x + __builtin_popcount(imaskG & ((1u << slot) - 1u));
-    }
-
     // One triangle record (device_types.h Bvh8Tri).  Returns false when an any-hit ray is done.
     template <bool ANY_HIT, bool COUNT>
     GFX_DEV bool process_triangle(uint32_t ti, uint4 q0, uint4 q1, uint4 q2, uint4 q3, const Bvh8Tri* __restrict__ tris, TraceCounters& cnt) {

@@ -94,7 +94,6 @@ struct Tunables {
     int traceRefill = 8;             // refill a wave when at least this many lanes are idle
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
     int temporalHints = 1;           // primary rays test the triangle their pixel hit one frame ago first (trace.hip)
-    int traceDual = 1;               // a lane tests the last pending leaf triangle of a node and walks on to the next node in one iteration (trace.hip DUAL)
 };
 
 struct Context {

@@ -46,14 +46,7 @@ struct TraceArgs {
 #ifndef GFX_TRACE_MIN_WAVES
 #define GFX_TRACE_MIN_WAVES 1
 #endif
-// DUAL: a lane may hold TWO items in one iteration -- the last pending leaf triangle of the node it visited and the next node of its walk
-// (Traversal::next_items).  An iteration costs the wave the same ~340 instructions whether a lane uses the node path, the triangle
-// path or both (with 64 lanes both paths run in nearly every iteration anyway), so a ray's 3-4 triangle tests stop costing it
-// iterations of their own: 14.5 -> ~12 iterations per primary ray.  The triangle is processed before the node of the same iteration,
-// so the node's slab tests see the bound it sets; the node itself was chosen before -- at worst one visit whose children all miss.
-// Same hits: closest-hit with the order-independent tie rule, any-hit a boolean.  The triangle record comes by four per-lane 16-byte
-// loads (a fifth of the lanes hold one: fewer line requests than a cooperative round), nodes by the cooperative fetch as before.
-template <bool ANY_HIT, bool COUNT, bool DUAL>
+template <bool ANY_HIT, bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(TraceArgs a) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kTraceBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[kTraceBlock * 4];   // 4 KiB per wave
@@ -152,29 +145,21 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             if (exhausted) break;
             continue;
         }
-        uint32_t code = kItemNone;        // the item of the cooperative fetch: a node (DUAL), a node or a triangle (kItemTri) otherwise
-        uint32_t triIdx = kItemNone;      // DUAL: the triangle this lane tests in this iteration
+        uint32_t code = kItemNone;
         if (tr.active) {
-            if (DUAL) tr.next_items(stack, code, triIdx);
-            else code = tr.next_item(stack, a.accel.triItemOffset);
-            if (code == kItemNone && triIdx == kItemNone) write_result();          // traversal finished
+            code = tr.next_item(stack, a.accel.triItemOffset);
+            if (code == kItemNone) write_result();          // traversal finished
         }
         if (newRay && hasNodes) code = 0u;                      // the root node
         if (COUNT) {
             if (newRay) rayItems = 0;
             if (code != kItemNone) ++rayItems;
-            if (triIdx != kItemNone) ++rayItems;
-            const int held = __popcll(__ballot(code != kItemNone || triIdx != kItemNone));
+            const int held = __popcll(__ballot(code != kItemNone));
             ++diagIter; diagLanes += held;
             if (exhausted) { ++diagDrainIter; diagDrainLanes += held; }
         }
         uint4 link = make_uint4(0u, 0u, 0u, 0u);
         if (code != kItemNone && !(code & kItemTri)) link = reinterpret_cast<const uint4*>(a.accel.links)[code];   // in flight with the item fetch
-        uint4 t0 = make_uint4(0u, 0u, 0u, 0u), t1 = t0, t2 = t0, t3 = t0;
-        if (DUAL && triIdx != kItemNone) {
-            const uint4* rec = reinterpret_cast<const uint4*>(a.accel.tris + triIdx);
-            t0 = rec[0]; t1 = rec[1]; t2 = rec[2]; t3 = rec[3];
-        }
         uint4 q0, q1, q2, q3;
         const unsigned long long cyc1 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         fetch_items(code, a.accel, waveBuf, lane, q0, q1, q2, q3);
@@ -190,13 +175,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
                 if (COUNT) --raysDone;                           // the counters report rays that were traversed: a queue entry without a
             }                                                   // ray (emit_ray_at_slot, padding slots) is not one
         }
-        if (DUAL) {
-            if (triIdx != kItemNone) {
-                if (!tr.template process_triangle<ANY_HIT, COUNT>(triIdx, t0, t1, t2, t3, a.accel.tris, cnt)) write_result();   // any-hit ray found its occluder
-            }
-            if (code != kItemNone && tr.active) tr.template process_node<COUNT>(q0, q1, q2, q3, link, stack, cnt);
-        }
-        else if (code != kItemNone) {
+        if (code != kItemNone) {
             if (code & kItemTri) {
                 if (!tr.template process_triangle<ANY_HIT, COUNT>((code & 0x7FFFFFFFu) - a.accel.triItemOffset, q0, q1, q2, q3, a.accel.tris, cnt))
                     write_result();                         // any-hit ray found its occluder
@@ -276,19 +255,14 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     a.ticketBatch = ctx.tune.traceBatch;
     const bool any = t.mode == GFX_TRACE_ANY;
     ScopedKernelTimer timer(ctx, stream, any ? "trace_any" : "trace_closest");
-#define GFX_TRACE_LAUNCH(ANY, COUNT, DUAL) hipLaunchKernelGGL((k_trace<ANY, COUNT, DUAL>), dim3(grid), dim3(kTraceBlock), 0, stream, a)
-    const int variant = (any ? 4 : 0) | (ctx.countersEnabled ? 2 : 0) | (ctx.tune.traceDual ? 1 : 0);
-    switch (variant) {
-    case 0: GFX_TRACE_LAUNCH(false, false, false); break;
-    case 1: GFX_TRACE_LAUNCH(false, false, true); break;
-    case 2: GFX_TRACE_LAUNCH(false, true, false); break;
-    case 3: GFX_TRACE_LAUNCH(false, true, true); break;
-    case 4: GFX_TRACE_LAUNCH(true, false, false); break;
-    case 5: GFX_TRACE_LAUNCH(true, false, true); break;
-    case 6: GFX_TRACE_LAUNCH(true, true, false); break;
-    default: GFX_TRACE_LAUNCH(true, true, true); break;
+    if (ctx.countersEnabled) {
+        if (any) hipLaunchKernelGGL((k_trace<true, true>), dim3(grid), dim3(kTraceBlock), 0, stream, a);
+        else hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(kTraceBlock), 0, stream, a);
     }
-#undef GFX_TRACE_LAUNCH
+    else {
+        if (any) hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(kTraceBlock), 0, stream, a);
+        else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(kTraceBlock), 0, stream, a);
+    }
     GFX_HIP(hipGetLastError());
 }
 
