@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_round.sh -- every measurement behind profiles/r03_* as named steps, runnable from a clean checkout on a
+# tools/profile_round.sh -- every measurement behind profiles/<round>_* (ROUND=r04 by default; r03 in the step list below reads "the round") as named steps, runnable from a clean checkout on a
 # GPU box (through gpurun: `gpurun --timeout 1500 -- 'bash tools/profile_round.sh tests ab pmc'`).  Raw output goes to
 # gpurun_out/r03/<step>/ (scratch); the summaries quoted in DESIGN.md are copied from there into profiles/ by hand-picked
 # names (listed next to each step).  Replaces the one-off tools/sessions/r0*.sh scripts of rounds 1-2.
@@ -28,7 +28,8 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
-OUT=gpurun_out/r03
+ROUND=${ROUND:-r04}
+OUT=gpurun_out/$ROUND
 mkdir -p $OUT
 B="python bench.py --steps 6 --warmup 2 --mse-ref-spp 0 --cpu-sample 0"
 
@@ -76,15 +77,16 @@ for step in "$@"; do
                grep -A9 "k_nrc_infer\|k_nrc_train" $OUT/nrc_pmc/a.txt | head -40 ;;
     nrc)       timeout 300 python tools/bench_nrc.py --steps 20 2> $OUT/nrc_net.err | tail -1 > $OUT/nrc_net.json; cut -c1-700 $OUT/nrc_net.json
                timeout 600 python tools/bench_nrc_frame.py > $OUT/nrc_frame.jsonl 2> $OUT/nrc_frame.err; cat $OUT/nrc_frame.jsonl; tail -3 $OUT/nrc_frame.err ;;
-    pmcjson)   if [ -d $OUT/pmc_map0 ]; then python profiles/make_pmc_json.py $OUT/pmc_default $OUT/pmc_map0 pixel_map_0_scan_lines > $OUT/r03_pmc.json
-               else python profiles/make_pmc_json.py $OUT/pmc_default > $OUT/r03_pmc.json; fi; head -c 600 $OUT/r03_pmc.json ;;
+    pmcjson)   if [ -d $OUT/pmc_map0 ]; then python profiles/make_pmc_json.py $OUT/pmc_default $OUT/pmc_map0 pixel_map_0_scan_lines > $OUT/${ROUND}_pmc.json
+               else python profiles/make_pmc_json.py $OUT/pmc_default > $OUT/${ROUND}_pmc.json; fi; head -c 600 $OUT/${ROUND}_pmc.json ;;
     laneprof)  GFX_LIB=$PWD/gfxexp_amd/variants/libgfxexp_laneprof.so timeout 300 python tools/lane_profile.py > $OUT/lane_profile.json 2> $OUT/lane_profile.err; cat $OUT/lane_profile.json ;;
     renderers) timeout 900 python tools/bench_renderers.py > $OUT/renderers.jsonl 2> $OUT/renderers.err
                timeout 300 python tools/bench_config4.py >> $OUT/renderers.jsonl 2>> $OUT/renderers.err; cat $OUT/renderers.jsonl ;;
     bands)     timeout 900 python tools/bench_band.py > $OUT/band_compute_bound.json 2> $OUT/band.err; cat $OUT/band_compute_bound.json; tail -3 $OUT/band.err ;;
     l2gather)  hipcc --offload-arch=gfx950 -O3 -w -o /tmp/l2_gather tools/microbench/l2_gather.hip && timeout 120 /tmp/l2_gather | tee $OUT/l2_gather.jsonl ;;
     valurate)  hipcc --offload-arch=gfx950 -O3 -w -o /tmp/valu_rate tools/microbench/valu_rate.hip && timeout 120 /tmp/valu_rate | tee $OUT/valu_rate.jsonl ;;
-    whatif)    # sensitivity of k_trace to extra VALU work and to more resident waves (variants built beforehand on this host:
+    whatif)    # (round 3 only: the GFX_WHATIF_* hooks these variants switched were removed from the kernels in round 4)
+               # sensitivity of k_trace to extra VALU work and to more resident waves (variants built beforehand on this host:
                #   python gfxexp_amd/build.py --variant valu64 GFX_WHATIF_VALU=64 ; ... valu128 GFX_WHATIF_VALU=128 ;
                #   ... occ5 GFX_TRACE_LDS_STACK=6 GFX_TRACE_MIN_WAVES=5 ; ... occ6 GFX_TRACE_LDS_STACK=4 GFX_TRACE_MIN_WAVES=6 ;
                #   ... fastdiv -fno-hip-fp32-correctly-rounded-divide-sqrt   (approximate / and sqrtf: timing only, results differ))
