@@ -30,7 +30,7 @@ def rearch_passes(temporal, spatial, unbiased, new_sequence):
 RENDERER_BIASED, RENDERER_UNBIASED, RENDERER_REARCH_BIASED, RENDERER_REARCH_UNBIASED, RENDERER_PATH_TRACE, RENDERER_PATH_TRACE_REGIR = 0, 1, 2, 3, 4, 5
 (PT_SETUP_GBUFFERS, PT_PATH_TRACE_BASELINE, PT_REGIR_BUILD_CELLS, PT_REGIR_BUILD_CELLS_TEMPORAL,
  PT_PATH_TRACE_REGIR, PT_REGIR_UPDATE_LAST_ACCESS, PT_NRC_PREPROCESS, PT_PATH_TRACE_NRC, PT_NRC_ACCUMULATE,
- PT_NRC_PROPAGATE, PT_NRC_SHUFFLE, PT_NRC_VISUALIZE_PREDICTION, PT_NRC_COUNT_QUERIES, PT_PATH_TRACE_NRC_REGIR) = range(14)
+ PT_NRC_PROPAGATE, PT_NRC_SHUFFLE, PT_NRC_VISUALIZE_PREDICTION, PT_NRC_COUNT_QUERIES, PT_PATH_TRACE_NRC_REGIR, PT_PATH_TRACE_NRC_RESTIR) = range(15)
 
 
 class GfxError(RuntimeError):
@@ -762,7 +762,7 @@ class GfxhNrcConfig(C.Structure):
                 ("regirEnableTemporalReuse", C.c_uint32), ("regirEnableCellRandomization", C.c_uint32), ("enableBumpMapping", C.c_uint32)]
 
 
-NRC_NEE_LIGHTS, NRC_NEE_REGIR = 0, 1
+NRC_NEE_LIGHTS, NRC_NEE_REGIR, NRC_NEE_RESTIR = 0, 1, 2
 
 
 class NrcRenderer:

@@ -33,6 +33,8 @@ struct gfxh_nrc {
     gfx_restir_frame_params fp;
     gfx_nrc_params np;
     gfx_regir_params regir;      // neeSampler == 1
+    // neeSampler == 2: the ReSTIR DI passes ahead of the tracer -- reservoir ping-pong and neighbour-table index as restir_di_main.cpp:1686, 2402-2411
+    uint32_t lastReservoirIndex = 1, lastSpatialNeighborBaseIndex = 0;
     std::vector<void*> allocations;
     uint64_t accel = 0, network = 0;
     uint32_t frameIndex = 0, numAccumFrames = 0;
@@ -165,6 +167,21 @@ int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out) {
         g.log2NumCandidatesPerCell = cfg->regirLog2CandidatesPerCell;
         g.enableCellRandomization = cfg->regirEnableCellRandomization;
     }
+    else if (cfg->neeSampler == 2) {   // the per-pixel reservoirs and the neighbour table of restir_di_main.cpp:1233-1325
+        if (!(cfg->rowBegin == 0 && cfg->rowEnd == 0)) { g_nrcError = "gfxh_nrc_create: the ReSTIR NEE sampler is not wired to band renderers"; gfxh_nrc_destroy(r); return 1; }
+        for (int i = 0; i < 2; ++i) {
+            err |= nrc_alloc(r, &sp.reservoirBuffer[i], 48 * n);
+            err |= nrc_alloc(r, &sp.reservoirInfoBuffer[i], 8 * n);
+        }
+        void* deltas = nullptr;
+        err |= nrc_alloc(r, &deltas, 8 * 1024);
+        if (!err) {
+            std::vector<float> host(2 * 1024);
+            gfxh_spatial_neighbor_deltas(host.data());
+            if (!nrc_hip_ok(hipMemcpy(deltas, host.data(), 8 * 1024, hipMemcpyHostToDevice), "upload the neighbour table")) err = 1;
+            sp.spatialNeighborDeltas = deltas;
+        }
+    }
     else if (cfg->neeSampler != 0) { g_nrcError = "gfxh_nrc_create: unknown neeSampler"; gfxh_nrc_destroy(r); return 1; }
     if (err) { gfxh_nrc_destroy(r); return 1; }
     {
@@ -233,15 +250,35 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     if (band && !r->exchange) { g_nrcError = "gfxh_nrc_render_frame: a band renderer needs gfxh_nrc_set_exchange"; return 1; }
     if (band && (cfg.rowEnd > H || cfg.rowBegin >= cfg.rowEnd)) { g_nrcError = "gfxh_nrc_render_frame: row band outside the image"; return 1; }
     const uint32_t rb = band ? cfg.rowBegin : 0, re = band ? cfg.rowEnd : 0;
-    const bool regirNee = cfg.neeSampler == 1;
+    const bool regirNee = cfg.neeSampler == 1, restirNee = cfg.neeSampler == 2;
+    if (restirNee) {   // the reference's ReSTIR DI defaults (restir_di_main.cpp:1944-1967): 32 candidates, temporal + 2 x 5 biased spatial reuse, radius 20
+        fp.spatialNeighborRadius = 20.0f; fp.radiusThresholdForSpatialVisReuse = 10.0f;
+        fp.log2NumCandidateSamples = 5; fp.numSpatialNeighbors = 5; fp.useLowDiscrepancyNeighbors = 1;
+        fp.reuseVisibility = 1; fp.reuseVisibilityForTemporal = 1; fp.reuseVisibilityForSpatiotemporal = 0;
+        fp.enableTemporalReuse = 1; fp.enableSpatialReuse = 1; fp.useUnbiasedEstimator = 0;
+        NRC_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, 0, 0));
+    }
     NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, rb, re));
+    if (restirNee) {   // restir_di_main.cpp:2365-2421 without the shading pass: its direct term is formed at the tracer's first vertex
+        uint32_t cur = (r->lastReservoirIndex + 1) % 2, base = r->lastSpatialNeighborBaseIndex;
+        NRC_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, cur, base));
+        NRC_GFX(gfx_restir_launch(ctx, stream, newSequence ? GFX_RESTIR_INITIAL_RIS : GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED, W, H));
+        for (uint32_t i = 0; i < 2; ++i) {
+            NRC_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, cur, base + fp.numSpatialNeighbors * i));
+            NRC_GFX(gfx_restir_launch(ctx, stream, GFX_RESTIR_SPATIAL_BIASED, W, H));
+            cur = (cur + 1) % 2;
+        }
+        base += fp.numSpatialNeighbors * 2;
+        r->lastReservoirIndex = cur; r->lastSpatialNeighborBaseIndex = base;
+        NRC_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, cur, base));      // the tracer reads reservoirs[cur]
+    }
     if (regirNee) {   // regir_main.cpp:2031-2066 around the tracer: build (with temporal reuse past the first frame), trace, age
         NRC_GFX(gfx_regir_set_params(ctx, &r->regir));
         NRC_GFX(gfx_pt_launch(ctx, stream, (cfg.regirEnableTemporalReuse && !newSequence) ? GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL : GFX_PT_REGIR_BUILD_CELL_RESERVOIRS,
                               W, H, cfg.maxPathLength, 0, 0));
     }
     NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_PREPROCESS, W, H, cfg.maxPathLength, 0, 0));
-    NRC_GFX(gfx_pt_launch(ctx, stream, regirNee ? GFX_PT_PATH_TRACE_NRC_REGIR : GFX_PT_PATH_TRACE_NRC, W, H, cfg.maxPathLength, rb, re));
+    NRC_GFX(gfx_pt_launch(ctx, stream, regirNee ? GFX_PT_PATH_TRACE_NRC_REGIR : restirNee ? GFX_PT_PATH_TRACE_NRC_RESTIR : GFX_PT_PATH_TRACE_NRC, W, H, cfg.maxPathLength, rb, re));
     if (regirNee) NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_REGIR_UPDATE_LAST_ACCESS, W, H, cfg.maxPathLength, 0, 0));
     // main:2293-2303: the inference batch size needs the tile size of this frame.  The reference synchronises the stream and
     // reads it back; a band renderer does the same here (the record gather needs the counts on the host anyway).  The whole-

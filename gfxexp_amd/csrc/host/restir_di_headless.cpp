@@ -22,7 +22,8 @@
 // Neural radiance caching (-renderer nrc; neural_radiance_caching/neural_radiance_caching_main.cpp:755-790, defaults :458-460):
 //   -position-encoding tri-wave|hash-grid (hash-grid)   -num-hidden-layers n (2)   -learning-rate lr (1e-2)
 //   and, headless: -max-path-length n (5; 0 = unlimited, :1860-1861)   -no-train   -log10-radiance-scale s (0, :2240)
-//   -nee lights|regir (lights): next-event estimation from the emitter distributions (the reference) or from the ReGIR grid
+//   -nee lights|regir|restir (lights): next-event estimation from the emitter distributions (the reference), from the ReGIR grid, or --
+//        at the first path vertex -- from the pixel's ReSTIR DI reservoir (the two halves of README.md:80-81)
 // Textures are read by the host decoders of scene_builder.cpp (PPM / PGM / PFM / BMP / TGA); DDS / PNG / JPEG assets have to be
 // decoded offline (the image has no image libraries).
 #include <cmath>
@@ -221,6 +222,7 @@ Options parse(int argc, const char* argv[]) {
             const std::string v = argv[i + 1];
             if (v == "lights") o.neeSampler = 0;
             else if (v == "regir") o.neeSampler = 1;
+            else if (v == "restir") o.neeSampler = 2;
             else fail("unknown NEE sampler:", argv[i + 1]);
             i += 1;
         }
@@ -304,7 +306,7 @@ int main(int argc, const char* argv[]) {
                 camM[0], camM[1], camM[2], camM[3], camM[4], camM[5], camM[6], camM[7], camM[8], o.nrc ? -1 : o.renderer, o.width, o.height, o.frames);
     if (o.nrc) std::printf(",\n \"nrc\": {\"position_encoding\": \"%s\", \"num_hidden_layers\": %u, \"learning_rate\": %.9g, \"max_path_length\": %u, \"train\": %s, \"nee\": \"%s\"}",
                            o.positionEncoding == GFX_NRC_HASH_GRID ? "hash-grid" : "tri-wave", o.numHiddenLayers, o.learningRate, o.maxPathLength, o.nrcTrain ? "true" : "false",
-                           o.neeSampler == 1 ? "regir" : "lights");
+                           o.neeSampler == 1 ? "regir" : o.neeSampler == 2 ? "restir" : "lights");
     std::printf(",\n \"instance_transforms\": [");
     for (uint32_t i = 0; i < counts[3]; ++i) {
         uint32_t group; float xfm[12];

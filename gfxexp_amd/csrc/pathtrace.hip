@@ -54,6 +54,7 @@ struct PtArgs {
     float4* nrcState;             // per pixel: [2p] = prevLocalThroughput.rgb, primaryPathSpread;
                                   //            [2p+1] = curSqrtPathSpread, prevTrainDataIndex, flags, -
     uint32_t* neeTrainIdx;        // per NEE slot: training record initialised with that NEE estimate (or invalid)
+    uint32_t curRes;              // GFX_PT_PATH_TRACE_NRC_RESTIR: the reservoir buffer the frame's ReSTIR passes finished in
 };
 
 // ---------------------------------------------------------------- ReGIR
@@ -137,6 +138,7 @@ struct PtVertexOut {              // what one shaded vertex hands to the queues
     f3 neeRet;                    // unshadowed NEE estimate (NRC: initial training target)
     f3 localThroughput;           // BSDF sampling throughput of this vertex
     uint32_t trainIdx;            // NRC: training record tied to the NEE ray
+    bool neeFromOrg; f3 neeOrg;   // the NEE ray starts at neeOrg instead of the vertex (ReSTIR-driven first vertex: the G-buffer's shading point)
 };
 
 // performNextEventEstimation (optix_pathtracing_kernels.cu:18-72) without the trace: returns the
@@ -145,13 +147,39 @@ struct PtVertexOut {              // what one shaded vertex hands to the queues
 // that shade a vertex) because the ReGIR variant merges its cell-access atomics across the wave.
 // REGIR: NEE from the grid cell (sampleFromCell); REGIR_LOOP: Russian roulette at the loop head as pathTraceReGIR does
 // (the NRC tracer with ReGIR NEE keeps its own Russian roulette: REGIR = true, REGIR_LOOP = false).
+// What the ReSTIR DI passes of the frame left for pixel p (GFX_PT_PATH_TRACE_NRC_RESTIR): the direct term of the shading pass,
+// recPDFEstimate x unshadowed performDirectLighting of the final reservoir sample at the G-buffer's shading point (restir.hip
+// k_shade_prepare; optix_restir_di_kernels.cu:574-606), and the shadow ray that decides it.
+struct ReservoirNee { f3 ret; f3 org; LightSample ls; };
+GFX_DEV ReservoirNee restir_reservoir_nee(const PtArgs& a, uint32_t bufIdx, size_t p) {
+    ReservoirNee r;
+    r.ret = f3(0.0f); r.org = f3(0.0f);
+    r.ls.emittance = f3(0.0f); r.ls.position = f3(0.0f); r.ls.normal = f3(0.0f); r.ls.atInfinity = 0;
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const Camera cam = load_camera(a.f.camera);
+    ShadingPoint sp;
+    make_shading_point(a, bufIdx, p, cam.pos, true, sp);
+    const Reservoir reservoir = load_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p);
+    const float recPDF = static_cast<const float2*>(a.s.reservoirInfoBuffer[a.curRes])[p].x;
+    r.org = sp.pos; r.ls = reservoir.sample;
+    if (recPDF > 0 && is_finite(recPDF)) r.ret = recPDF * direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, reservoir.sample);
+    return r;
+}
+
+// `given`: the vertex's next-event estimation is already made (the ReSTIR-driven first vertex of the NRC tracer): no light is
+// sampled and no random number drawn for it here.
 template <bool REGIR, bool REGIR_LOOP = REGIR>
 GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool envEnabled, f3 pos, f3 vOutLocal, const Frame& frame,
-                          const Bsdf& bsdf, Pcg32& rng, f3& alpha, f3& contribution, float& dirPDensity, PtVertexOut& o) {
+                          const Bsdf& bsdf, Pcg32& rng, f3& alpha, f3& contribution, float& dirPDensity, PtVertexOut& o,
+                          const ReservoirNee* given = nullptr) {
     f3 ret(0.0f);
     LightSample ls;
     ls.emittance = f3(0.0f); ls.position = f3(0.0f); ls.normal = f3(0.0f); ls.atInfinity = 0;
-    if (REGIR) {
+    if (given) {
+        if (!active) return;
+        ret = given->ret; ls = given->ls;
+    }
+    else if (REGIR) {
         float recPDF;
         const f3 unshadowed = regir_sample_from_cell(a, active, pos, vOutLocal, frame, bsdf, rng, ls, recPDF);
         if (!active) return;
@@ -186,7 +214,8 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
         }
         if (areaPDensity > 0.0f) ret = direct_lighting(pos, vOutLocal, frame, bsdf, ls) * (misWeight / areaPDensity);
     }
-    const ShadowRay sr = shadow_ray(pos, ls);
+    const ShadowRay sr = shadow_ray(given ? given->org : pos, ls);
+    if (given) { o.neeFromOrg = true; o.neeOrg = given->org; }
     o.wantNee = ret.x != 0.0f || ret.y != 0.0f || ret.z != 0.0f;
     o.neeDir = sr.dir; o.neeTmax = sr.tmax;
     o.pending = alpha * ret;
@@ -218,7 +247,7 @@ GFX_DEV void push_vertex(const PtArgs& a, uint32_t pixel, f3 pos, const PtVertex
     uint32_t slots[2];
     queue_reserve_each<2>(want, counters, slots);
     const uint32_t ns = slots[0], es = slots[1];
-    queue_write(ns, pos, o.neeDir, 0.0f, o.neeTmax, a.neeOrg, a.neeDir);
+    queue_write(ns, o.neeFromOrg ? o.neeOrg : pos, o.neeDir, 0.0f, o.neeTmax, a.neeOrg, a.neeDir);
     if (o.wantNee) {
         a.neePending[ns] = make_float4(o.pending.x, o.pending.y, o.pending.z, bits2f(pixel));
         if (a.neeTrainIdx) a.neeTrainIdx[ns] = o.trainIdx;
@@ -235,7 +264,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_first(PtArgs a) {
     const uint32_t bufIdx = a.f.bufferIndex;
     PtVertexOut o;
     o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
-    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = 0x007FFFFFu;
+    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = 0x007FFFFFu; o.neeFromOrg = false; o.neeOrg = f3(0.0f);
     f3 pos(0.0f), vOutLocal(0.0f);
     Frame frame(f3(0, 0, 1), f3(1, 0, 0));
     Bsdf bsdf;
@@ -330,7 +359,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_bounce(PtArgs a) {
     const uint32_t count = *a.extCountIn;
     PtVertexOut o;
     o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
-    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = 0x007FFFFFu;
+    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = 0x007FFFFFu; o.neeFromOrg = false; o.neeOrg = f3(0.0f);
     f3 pos(0.0f), vOutLocal(0.0f);
     Frame frame(f3(0, 0, 1), f3(1, 0, 0));
     Bsdf bsdf;
@@ -698,14 +727,16 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_preprocess(PtArgs a) {
 
 // pathTrace_raygen_generic<true> up to the path extension loop (:133-318).  REGIR: next-event estimation from the ReGIR
 // grid (GFX_PT_PATH_TRACE_NRC_REGIR, include/gfxexp.h).
-template <bool REGIR>
+// NEE: 0 the tracer's own light sample, 1 ReGIR cell sampling, 2 the pixel's ReSTIR DI reservoir (first vertex only).
+template <int NEE>
 __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_first(PtArgs a) {
+    constexpr bool REGIR = NEE == 1;
     const PixelId px = pixel_of_thread(a.px);
     const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     PtVertexOut o;
     o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
-    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = kInvalidVertexDataIndex;
+    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = kInvalidVertexDataIndex; o.neeFromOrg = false; o.neeOrg = f3(0.0f);
     f3 pos(0.0f), vOutLocal(0.0f), vOut(0.0f);
     Frame frame(f3(0, 0, 1), f3(1, 0, 0));
     Bsdf bsdf; bsdf.type = 0; bsdf.diffuse = f3(0.0f); bsdf.specularF0 = f3(0.0f); bsdf.roughness = 1.0f;
@@ -764,7 +795,14 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_first(PtArgs a) {
     else if (inImage && envEnabled) {
         contribution = a.f.envLightPowerCoeff * env.fetch(decode_bc(g0.w & 0xFFFF), decode_bc(g0.w >> 16));
     }
-    shade_vertex<REGIR, false>(a, surface, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
+    if (NEE == 2) {
+        ReservoirNee given;
+        given.ret = f3(0.0f); given.org = f3(0.0f);
+        given.ls.emittance = f3(0.0f); given.ls.position = f3(0.0f); given.ls.normal = f3(0.0f); given.ls.atInfinity = 0;
+        if (surface) given = restir_reservoir_nee(a, bufIdx, p);
+        shade_vertex<false, false>(a, surface, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o, &given);
+    }
+    else shade_vertex<REGIR, false>(a, surface, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
     // training record of the first vertex (:238-277)
     uint32_t trainIdx = nrc_alloc_train_index(static_cast<uint32_t*>(a.nrc.numTrainingData[bufIdx]), surface && tile.training);
     if (surface && tile.training) {
@@ -795,15 +833,19 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_first(PtArgs a) {
 // pathTrace_closestHit_generic<true> / pathTrace_miss_generic<true> for one extension ray, then the
 // loop head and, when the path stops, the tail of the ray-generation program (:380-677, :320-373).  REGIR: emitters
 // found by BSDF sampling contribute nothing (the ReGIR NEE has no density to weight them against).
-template <bool REGIR>
+template <int NEE>
 __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
+    constexpr bool REGIR = NEE == 1;
+    // NEE == 2: the first vertex's direct light came from the ReSTIR reservoir, which has no density to weight a BSDF-sampled emitter
+    // against: what the first extension ray finds emitting counts nothing (GFX_PT_PATH_TRACE_NRC_RESTIR, include/gfxexp.h)
+    const bool noImplicit = REGIR || (NEE == 2 && a.pathLength == 2);
     const uint32_t i = blockIdx.x * kPtBlock + threadIdx.x;
     const uint32_t count = *a.extCountIn;
     const uint32_t bufIdx = a.f.bufferIndex;
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     PtVertexOut o;
     o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
-    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = kInvalidVertexDataIndex;
+    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = kInvalidVertexDataIndex; o.neeFromOrg = false; o.neeOrg = f3(0.0f);
     f3 pos(0.0f), vOutLocal(0.0f), vOut(0.0f);
     Frame frame(f3(0, 0, 1), f3(1, 0, 0));
     Bsdf bsdf; bsdf.type = 0; bsdf.diffuse = f3(0.0f); bsdf.specularF0 = f3(0.0f); bsdf.roughness = 1.0f;
@@ -833,7 +875,7 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
         float* prevTarget = static_cast<float*>(a.nrc.trainTargetBuffer[0]) + 3ull * prevTrainIdx;
         const bool linkPrev = tile.training && prevTrainIdx != kInvalidVertexDataIndex;
         if (h.triIndex == GFX_INVALID_SLOT) {
-            if (envEnabled && !REGIR) {
+            if (envEnabled && !noImplicit) {
                 const f3 rd = unit(rayDir);
                 float posPhi, theta;
                 to_polar_yup(rd, posPhi, theta);
@@ -913,7 +955,7 @@ __global__ __launch_bounds__(kPtBlock) void k_nrc_pt_bounce(PtArgs a) {
             vOutLocal = frame.to_local(vOut);
             const float dist2 = len2(rayOrg - pos);
             curSqrtPathSpread += sqrtf(dist2 / (prevDirPDensity * fabsf(vOutLocal.z)));
-            if (!REGIR && vOutLocal.z > 0 && mat.hasEmittance) {
+            if (!noImplicit && vOutLocal.z > 0 && mat.hasEmittance) {
                 const f3 emittance = material_emittance(a.scene, mat, tu, tv);
                 const float lightPDensity = hypAreaPDensity * dist2 / vOutLocal.z;
                 const float misWeight = (prevDirPDensity * prevDirPDensity) / (prevDirPDensity * prevDirPDensity + lightPDensity * lightPDensity);
@@ -1174,9 +1216,9 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     }
     const RestirParams& rp = ctx.restir;
     if (!rp.valid) throw HipError("gfx_pt_launch: gfx_restir_set_params has not been called");
-    const bool nrcRegir = pass == GFX_PT_PATH_TRACE_NRC_REGIR;
+    const bool nrcRegir = pass == GFX_PT_PATH_TRACE_NRC_REGIR, nrcRestir = pass == GFX_PT_PATH_TRACE_NRC_RESTIR;
     const bool regirPass = (pass >= GFX_PT_REGIR_BUILD_CELL_RESERVOIRS && pass <= GFX_PT_REGIR_UPDATE_LAST_ACCESS) || nrcRegir;
-    const bool nrcPass = (pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_COUNT_QUERIES) || nrcRegir;
+    const bool nrcPass = (pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_COUNT_QUERIES) || nrcRegir || nrcRestir;
     if (!regirPass && !nrcPass && pass != GFX_PT_PATH_TRACE_BASELINE) throw HipError("gfx_pt_launch: unknown pass");
     if (regirPass && !ctx.regirValid) throw HipError("gfx_pt_launch: gfx_regir_set_params has not been called");
     if (nrcPass && !ctx.nrcRenderValid) throw HipError("gfx_pt_launch: gfx_nrc_set_render_params has not been called");
@@ -1229,7 +1271,15 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         return;
     }
     const bool regir = pass == GFX_PT_PATH_TRACE_REGIR;
-    const bool nrc = pass == GFX_PT_PATH_TRACE_NRC || nrcRegir;
+    const bool nrc = pass == GFX_PT_PATH_TRACE_NRC || nrcRegir || nrcRestir;
+    if (nrcRestir) {
+        if (!rp.s.reservoirBuffer[0] || !rp.s.reservoirBuffer[1] || !rp.s.reservoirInfoBuffer[0] || !rp.s.reservoirInfoBuffer[1] ||
+            !rp.s.gbuffer2[0] || !rp.s.gbuffer3[0])
+            throw HipError("gfx_pt_launch: GFX_PT_PATH_TRACE_NRC_RESTIR reads the reservoirs and G-buffers 2 / 3 of the ReSTIR passes (static parameters)");
+        if (!(rowBegin == 0 && (rowEnd == 0 || rowEnd == height)))
+            throw HipError("gfx_pt_launch: GFX_PT_PATH_TRACE_NRC_RESTIR is a whole-frame pass");
+        a.curRes = rp.currentReservoirIndex & 1u;
+    }
     if (static_cast<uint32_t>(rp.s.imageSizeX) != width || static_cast<uint32_t>(rp.s.imageSizeY) != height)
         throw HipError("gfx_pt_launch: launch size differs from imageSize in the static parameters");
     const uint64_t h = rp.f.travHandle;
@@ -1288,7 +1338,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     set_queues(1, cur);
     a.pathLength = 1; a.maxLengthTerminate = 0;
     a.nextMaxLengthTerminate = 2 >= maxPathLength ? 1u : 0u;
-    if (nrc) launch_pixels("nrc_pt_first", nrcRegir ? k_nrc_pt_first<true> : k_nrc_pt_first<false>);
+    if (nrc) launch_pixels("nrc_pt_first", nrcRegir ? k_nrc_pt_first<1> : nrcRestir ? k_nrc_pt_first<2> : k_nrc_pt_first<0>);
     else launch_pixels("pt_first", regir ? k_pt_first<true> : k_pt_first<false>);
     // while (true) { ++pathLength; trace; }.  Baseline: at least one extension even when maxPathLength < 2,
     // the terminal vertex (implicit light only) emits no NEE ray.  ReGIR: the loop head breaks before the
@@ -1316,7 +1366,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         a.pathLength = pathLength;
         a.maxLengthTerminate = (pathLength >= maxPathLength && (!nrc || maxPathLength > 0)) ? 1u : 0u;
         a.nextMaxLengthTerminate = pathLength + 1 >= maxPathLength ? 1u : 0u;
-        if (nrc) launch("nrc_pt_bounce", nrcRegir ? k_nrc_pt_bounce<true> : k_nrc_pt_bounce<false>);
+        if (nrc) launch("nrc_pt_bounce", nrcRegir ? k_nrc_pt_bounce<1> : nrcRestir ? k_nrc_pt_bounce<2> : k_nrc_pt_bounce<0>);
         else launch("pt_bounce", regir ? k_pt_bounce<true> : k_pt_bounce<false>);
         cur ^= 1;
         if (!regir && !nrc && a.maxLengthTerminate) break;

@@ -164,7 +164,10 @@ struct ShadingPoint {
 // normalizeFirst = false: vOut = cam - p; frontHit from the unnormalised vector; vOut /= |vOut|
 //                         (optix_restir_di_kernels.cu:41-46, 320-325)
 // normalizeFirst = true : vOut = normalize(cam - p); frontHit from the unit vector (:230-232, 574-577)
-GFX_DEV void make_shading_point(const RestirArgs& a, uint32_t bufIdx, size_t p, f3 camPos, bool normalizeFirst, ShadingPoint& sp) {
+// (Args: RestirArgs, or pathtrace.hip's PtArgs for the NRC tracer whose first-vertex NEE is the ReSTIR reservoir -- both carry
+// the static parameters `s` and the scene)
+template <typename Args>
+GFX_DEV void make_shading_point(const Args& a, uint32_t bufIdx, size_t p, f3 camPos, bool normalizeFirst, ShadingPoint& sp) {
     const float4 g2 = static_cast<const float4*>(a.s.gbuffer2[bufIdx])[p];
     const uint4 g3 = static_cast<const uint4*>(a.s.gbuffer3[bufIdx])[p];
     f3 pos(g2.x, g2.y, g2.z);

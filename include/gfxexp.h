@@ -370,7 +370,18 @@ enum gfx_pt_pass {
      * Russian roulette, cache termination and the training records are those of the NRC tracer.  Needs gfx_regir_set_params
      * (grid built by GFX_PT_REGIR_BUILD_CELL_RESERVOIRS* before, GFX_PT_REGIR_UPDATE_LAST_ACCESS after) AND
      * gfx_nrc_set_render_params. */
-    GFX_PT_PATH_TRACE_NRC_REGIR = 13
+    GFX_PT_PATH_TRACE_NRC_REGIR = 13,
+    /* GFX_PT_PATH_TRACE_NRC whose FIRST path vertex takes its next-event estimation from the pixel's ReSTIR DI reservoir -- the other
+     * half of the reference's open item (README.md:80-81 "... like ReSTIR/ReGIR"; NEE site neural_radiance_caching/gpu_kernels/
+     * optix_pathtracing_kernels.cu:38-63), again a composition of two things the reference has: the frame first runs the original
+     * ReSTIR DI passes (GFX_RESTIR_INITIAL_* and the spatial passes, restir_di_main.cpp:2365-2421, up to but excluding SHADING) on the
+     * same G-buffers and per-pixel RNGs; this pass then adds, at the first vertex, recPDFEstimate x performDirectLighting of the
+     * final reservoir sample at the G-buffer's shading point with its shadow ray (the direct term of the shading pass,
+     * optix_restir_di_kernels.cu:574-606) in place of the tracer's own light sample, and draws no random numbers there.  The
+     * reservoir estimates all direct light of that vertex and has no density, so what the first extension ray finds emitting (path
+     * length 2: surface or environment) contributes nothing; deeper vertices keep the tracer's NEE + MIS.  The reservoirs are the
+     * ones of `currentReservoirIndex` (gfx_restir_set_params).  Whole-frame renderers only. */
+    GFX_PT_PATH_TRACE_NRC_RESTIR = 14
 };
 
 /* The ReGIR members of regir/regir_shared.h:200-263 (grid of cells x 512 light slots).  Light-slot

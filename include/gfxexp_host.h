@@ -336,7 +336,10 @@ typedef struct gfxh_nrc_config {
     uint32_t rowBegin, rowEnd;   /* rows [rowBegin, rowEnd) of a band renderer (needs gfxh_nrc_set_exchange); 0, 0 = the whole frame */
     /* next-event estimation of the NRC tracer: 0 = the emitter distributions (the reference), 1 = the ReGIR grid
      * (GFX_PT_PATH_TRACE_NRC_REGIR: an extension, the reference lists the combination as open, README.md:80-81).  The grid
-     * spans sceneAabb; its parameters default to regir_main.cpp:1112, 1733-1736.  Whole-frame renderers only. */
+     * spans sceneAabb; its parameters default to regir_main.cpp:1112, 1733-1736), 2 = the pixel's ReSTIR DI reservoir at the first
+     * path vertex (GFX_PT_PATH_TRACE_NRC_RESTIR: the other half of the same open item; the frame runs the original ReSTIR DI passes
+     * -- 32 candidates, temporal + 2 x 5 biased spatial reuse, radius 20, restir_di_main.cpp:1944-1967, 2365-2421 -- ahead of the
+     * tracer).  1 and 2: whole-frame renderers only. */
     uint32_t neeSampler;
     uint32_t regirGridDimension[3];
     uint32_t regirLog2CandidatesPerLightSlot, regirLog2CandidatesPerCell;

@@ -16,8 +16,13 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 def build(force=False):
     """Compile liboracle.so with the committed Makefile (gcc only, no GPU needed)."""
-    if force or not os.path.exists(_LIB_PATH):
+    # make decides (the Makefile lists every header): a library older than a source is rebuilt, an up-to-date one costs nothing.
+    # Where there is no compiler (a GPU box that received the prebuilt library) the library is used as it is.
+    try:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(_LIB_PATH):
+            raise
     return _LIB_PATH
 
 
@@ -281,6 +286,10 @@ class OracleScene:
 
     def regir_set_params(self, params):
         self.L.orc_regir_set_params(self.h, C.byref(params))
+
+    def pt_set_reservoir_index(self, index):
+        """The reservoir buffer the ReSTIR passes of this frame finished in: read by GFX_PT_PATH_TRACE_NRC_RESTIR (pass 14)."""
+        self.L.orc_pt_set_reservoir_index(self.h, C.c_uint32(index))
 
     def pt_launch(self, static_params, frame_params, pass_id, max_path_length, rect=None):
         x0, y0, x1, y1 = rect if rect else (0, 0, 0, 0)

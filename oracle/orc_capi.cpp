@@ -366,6 +366,10 @@ static gfx_regir_params g_regirParams;
 static bool g_regirValid = false;
 int orc_regir_set_params(orc_scene*, const gfx_regir_params* p) { g_regirParams = *p; g_regirValid = true; return 0; }
 
+// reservoir index of the ReSTIR passes that ran before GFX_PT_PATH_TRACE_NRC_RESTIR (the C ABI takes it through gfx_restir_set_params)
+static uint32_t g_ptReservoirIndex = 0;
+int orc_pt_set_reservoir_index(orc_scene*, uint32_t index) { g_ptReservoirIndex = index & 1u; return 0; }
+
 static gfx_nrc_params g_nrcParams;
 static bool g_nrcValid = false;
 int orc_nrc_set_render_params(orc_scene*, const gfx_nrc_params* p) { g_nrcParams = *p; g_nrcValid = true; return 0; }
@@ -406,17 +410,22 @@ int orc_pt_launch(orc_scene* s, const gfx_restir_static_params* sp, const gfx_re
     p.scene = &s->scene; p.accel = &s->accel; p.s = sp; p.f = fp;
     p.camera = toCamera(fp->camera);
     p.maxPathLength = maxPathLength & 15u; // 4-bit bitfield, path_tracing_shared.h:165
-    if ((pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_VISUALIZE_PREDICTION) || pass == GFX_PT_PATH_TRACE_NRC_REGIR) {
+    if ((pass >= GFX_PT_NRC_PREPROCESS && pass <= GFX_PT_NRC_VISUALIZE_PREDICTION) || pass == GFX_PT_PATH_TRACE_NRC_REGIR || pass == GFX_PT_PATH_TRACE_NRC_RESTIR) {
         if (!g_nrcValid) return 1;
         if (pass == GFX_PT_PATH_TRACE_NRC_REGIR) {
             if (!g_regirValid) return 1;
             p.regir = &rs;
+        }
+        if (pass == GFX_PT_PATH_TRACE_NRC_RESTIR) {
+            rp.currentReservoirIndex = g_ptReservoirIndex;
+            p.restir = &rp;
         }
         NrcState ns; ns.n = &g_nrcParams;
         const int W = sp->imageSizeX, H = sp->imageSizeY;
         switch (pass) {
         case GFX_PT_NRC_PREPROCESS: preprocessNRC(ns, *fp); break;
         case GFX_PT_PATH_TRACE_NRC_REGIR:
+        case GFX_PT_PATH_TRACE_NRC_RESTIR:
         case GFX_PT_PATH_TRACE_NRC: {
             // one thread, row-major: the training-record order (an atomicAdd race in the reference) is defined
             // a window (x0, y0, x1, y1) restricts the pass to those pixels (full-size parity tests): per-pixel results

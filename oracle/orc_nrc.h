@@ -156,8 +156,12 @@ static inline void nrcTraceVertex(const PathTraceParams& p, const NrcState& ns, 
     // found by BSDF sampling -- the environment in the miss program, emissive surfaces in the closest-hit program --
     // contribute nothing at path length >= 2.  An extension of this build: the reference lists the combination as open
     // (README.md:80-81).
+    // p.restir (GFX_PT_PATH_TRACE_NRC_RESTIR): the first vertex's direct lighting is the pixel's ReSTIR DI reservoir, an estimate of ALL
+    // the direct light at that vertex with no density to weight a BSDF-sampled emitter against -- so what the first extension ray (path
+    // length 2) finds emitting, surface or environment, contributes nothing; deeper vertices keep the tracer's own NEE + MIS.
+    const bool firstVertexIsRestir = p.restir != nullptr && pl.pathLength == 2;
     if (!h.isHit()) { // miss
-        if (!useEnvLight || p.regir) return;
+        if (!useEnvLight || p.regir || firstVertexIsRestir) return;
         const V3 rd = normalize(rayDir);
         float posPhi, theta;
         toPolarYUp(rd, &posPhi, &theta);
@@ -199,7 +203,7 @@ static inline void nrcTraceVertex(const PathTraceParams& p, const NrcState& ns, 
     const float dist2 = sqLength(rayOrg - positionInWorld);
     pl.curSqrtPathSpread += std::sqrt(dist2 / (pl.prevDirPDensity * std::fabs(vOutLocal.z)));
 
-    if (!p.regir && vOutLocal.z > 0 && mat.hasEmittance) {
+    if (!p.regir && !firstVertexIsRestir && vOutLocal.z > 0 && mat.hasEmittance) {
         const RGB emittance = materialEmittance(scene.textures, mat, texCoord);
         const float lightPDensity = hypAreaPDensity * dist2 / vOutLocal.z;
         const float bsdfPDensity = pl.prevDirPDensity;
@@ -345,7 +349,10 @@ static inline void nrcPathTracePixel(const PathTraceParams& p, const NrcState& n
                 contribution += alpha * emittance / kPi;
             }
             BSDF bsdf; bsdf.setup(scene.textures, mat, texCoord);
-            const RGB directContNEE = nrcNextEventEstimation(p, visFn, positionInWorld, vOutLocal, shadingFrame, bsdf, rng);
+            // first-vertex next-event estimation: the tracer's own light sample, or (p.restir) what the ReSTIR DI passes of this frame
+            // left in the pixel's reservoir -- no random numbers are drawn here then
+            const RGB directContNEE = p.restir ? restirDirectEstimate(*p.restir, x, y)
+                                               : nrcNextEventEstimation(p, visFn, positionInWorld, vOutLocal, shadingFrame, bsdf, rng);
             contribution += alpha * directContNEE;
             V3 vInLocal;
             const float u0 = rng.getFloat0cTo1o();

@@ -106,6 +106,7 @@ struct PathTraceParams {
     PerspectiveCamera camera;
     uint32_t maxPathLength;
     const RegirState* regir = nullptr;   // non-null: pathTraceReGIR (regir/gpu_kernels/optix_pathtracing_kernels.cu:425-433)
+    const Params* restir = nullptr;      // non-null (NRC tracer only): the first vertex's NEE is the pixel's ReSTIR DI reservoir (orc_nrc.h)
     bool envEnabled() const { return s->envLightTexture != nullptr && f->enableEnvLight; }
 };
 

@@ -573,6 +573,37 @@ static inline void spatialRISPixel(const Params& p, bool useUnbiasedEstimator, i
 }
 
 // ---------------------------------------------------------------- shading
+// The direct-lighting term of the shading pass for pixel (x, y): recPDFEstimate x performDirectLighting of the pixel's final reservoir
+// sample at the shading point the G-buffer holds (the statements of shadingPixel, :574-606, with the visibility always tested).  Used by
+// the NRC path tracer whose first-vertex next-event estimation is the ReSTIR DI reservoir (orc_nrc.h, GFX_PT_PATH_TRACE_NRC_RESTIR):
+// a composition of this build -- the reference names it as open work (README.md:80-81) and has no code for it.
+// `shadowRayOrigin` / `sample`: what the caller needs to restate the visibility test itself.
+static inline RGB restirDirectEstimate(const Params& p, int x, int y) {
+    const Scene& scene = *p.scene;
+    const uint32_t bufIdx = p.f->bufferIndex;
+    const size_t i = pix(p, x, y);
+    const gfx_gbuffer0& gb0 = static_cast<const gfx_gbuffer0*>(p.s->gbuffer0[bufIdx])[i];
+    if (gb0.instSlot == 0xFFFFFFFFu) return RGB(0.0f);
+    const gfx_gbuffer3& gb3 = static_cast<const gfx_gbuffer3*>(p.s->gbuffer3[bufIdx])[i];
+    const gfx_gbuffer2& gb2 = static_cast<const gfx_gbuffer2*>(p.s->gbuffer2[bufIdx])[i];
+    V3 positionInWorld(gb2.positionInWorld[0], gb2.positionInWorld[1], gb2.positionInWorld[2]);
+    const V3 geometricNormalInWorld = decodeNormal(gb2.qGeometricNormal);
+    const V3 vOut = normalize(p.camera.position - positionInWorld);
+    const float frontHit = dot(vOut, geometricNormalInWorld) >= 0.0f ? 1.0f : -1.0f;
+    positionInWorld = offsetRayOrigin(positionInWorld, frontHit * geometricNormalInWorld);
+    const ReferenceFrame shadingFrame(decodeNormal(gb3.qShadingNormal), decodeVector(gb3.qShadingTangent));
+    const V3 vOutLocal = shadingFrame.toLocal(vOut);
+    const MaterialData& mat = scene.materials[gb3.matSlot];
+    BSDF bsdf; bsdf.setup(scene.textures, mat, decodeTexCoords(gb3.qTexCoord));
+    const VisibilityFn visFn = [&p](V3 o, V3 d, float t0, float t1) { return !occluded(*p.accel, o, d, t0, t1); };
+    const Reservoir reservoir = readReservoir(p, p.currentReservoirIndex, i);
+    const float recPDFEstimate = static_cast<const gfx_reservoir_info*>(p.s->reservoirInfoBuffer[p.currentReservoirIndex])[i].recPDFEstimate;
+    RGB directCont(0.0f);
+    if (recPDFEstimate > 0 && finitef(recPDFEstimate))
+        directCont = performDirectLighting(true, visFn, positionInWorld, vOutLocal, shadingFrame, bsdf, reservoir.sample);
+    return recPDFEstimate * directCont;
+}
+
 static inline void shadingPixel(const Params& p, int x, int y) {
     const Scene& scene = *p.scene;
     const uint32_t bufIdx = p.f->bufferIndex;

@@ -34,9 +34,12 @@ def _compare_exact(diffs, tag, got, want, keys):
             diffs.append(f"{tag}: {k}: {len(np.unique(np.nonzero(a != b)[0] // item))} of {want[k].size} elements differ")
 
 
-def run_nrc_both(hs, width, height, frames, max_len, env=None, camera=None, radiance_scale=1.0, regir=False):
+def run_nrc_both(hs, width, height, frames, max_len, env=None, camera=None, radiance_scale=1.0, regir=False, restir=False):
     """regir=True: GFX_PT_PATH_TRACE_NRC_REGIR -- the ReGIR grid (built and aged every frame, compared like the per-pixel
-    buffers) supplies the next-event estimation of the NRC tracer."""
+    buffers) supplies the next-event estimation of the NRC tracer.
+    restir=True: GFX_PT_PATH_TRACE_NRC_RESTIR -- the original ReSTIR DI passes (initial + temporal, two biased spatial passes,
+    sequenced as restir_di_main.cpp:2365-2421 without the shading pass) run on the frame's G-buffers first, every buffer compared
+    after every pass; the NRC tracer's first vertex then takes its next-event estimation from the final reservoirs."""
     import torch
     ctx, accel, osc, dev, pb_cpu, nb_gpu, nb_cpu = _setup(hs, width, height, env, radiance_scale)
     rb_gpu = rb_cpu = None
@@ -52,6 +55,7 @@ def run_nrc_both(hs, width, height, frames, max_len, env=None, camera=None, radi
     offsets = np.random.default_rng(72139121)
     diffs = []
     n = width * height
+    last_res, last_base = 1, 0          # reservoir ping-pong and neighbour-table index of the ReSTIR passes (restir_di_main.cpp:1686, :2402-2411)
     for frame in range(frames):
         kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=frame,
                   enableEnvLight=int(env is not None))
@@ -67,6 +71,25 @@ def run_nrc_both(hs, width, height, frames, max_len, env=None, camera=None, radi
         if regir:   # regir_main.cpp:2031-2066 around the NRC tracer
             build = api.PT_REGIR_BUILD_CELLS if frame == 0 else api.PT_REGIR_BUILD_CELLS_TEMPORAL
             passes = (api.PT_SETUP_GBUFFERS, build, api.PT_NRC_PREPROCESS, api.PT_PATH_TRACE_NRC_REGIR, api.PT_REGIR_UPDATE_LAST_ACCESS)
+        if restir:
+            ctx.pt_launch(api.PT_SETUP_GBUFFERS, width, height, max_len, 0, 0, stream)
+            osc.pt_launch(s_cpu, f_cpu, api.PT_SETUP_GBUFFERS, max_len)
+            cur = (last_res + 1) % 2
+            seq = [(api.PASS_INITIAL_RIS if frame == 0 else api.PASS_INITIAL_TEMPORAL_BIASED, cur, last_base)]
+            for i in range(2):
+                seq.append((api.PASS_SPATIAL_BIASED, cur, last_base + 5 * i))
+                cur = (cur + 1) % 2
+            last_base += 10
+            for pass_id, cur_res, base in seq:
+                ctx.restir_set_params(s_gpu, f_gpu, cur_res, base, stream)
+                ctx.restir_launch(pass_id, width, height, stream)
+                osc.restir_launch(s_cpu, f_cpu, cur_res, base, pass_id)
+                got, want = dev.download(), pb_cpu.arrays()
+                _compare_exact(diffs, f"frame {frame} restir pass {pass_id}", got, want, [k for k in want if k.startswith(("rng", "res_", "info_"))])
+            last_res = cur
+            ctx.restir_set_params(s_gpu, f_gpu, cur, last_base, stream)      # the tracer reads reservoirs[cur]
+            osc.pt_set_reservoir_index(cur)
+            passes = (api.PT_NRC_PREPROCESS, api.PT_PATH_TRACE_NRC_RESTIR)
         for pass_id in passes:
             ctx.pt_launch(pass_id, width, height, max_len, 0, 0, stream)
             osc.pt_launch(s_cpu, f_cpu, pass_id, max_len)
@@ -263,3 +286,28 @@ def test_headless_nrc_renderer_with_regir_nee_sees_the_same_light(built_lib):
     assert abs(grid.mean() - base.mean()) < 0.06 * base.mean(), (grid.mean(), base.mean())
     trained = mean_image(api.NRC_NEE_REGIR, 12, True, 5)
     assert np.isfinite(trained).all() and trained.mean() > 0.5 * base.mean()
+    # neeSampler = ReSTIR DI (the original ReSTIR passes run inside gfxh_nrc_render_frame ahead of the tracer): the first vertex's direct
+    # light again, now through the pixel's reservoir -- within the bias of the biased spatial reuse (8 %, as on the CPU)
+    restir = mean_image(api.NRC_NEE_RESTIR, 64, False, 2)
+    assert np.isfinite(restir).all()
+    assert abs(restir.mean() - base.mean()) < 0.08 * base.mean(), (restir.mean(), base.mean())
+    trained = mean_image(api.NRC_NEE_RESTIR, 12, True, 5)
+    assert np.isfinite(trained).all() and trained.mean() > 0.5 * base.mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_len", [5, 2])
+def test_nrc_render_with_restir_next_event_estimation(built_lib, max_len):
+    """GFX_PT_PATH_TRACE_NRC_RESTIR on the bunny scene, three frames (temporal reuse from frame 1 on): the ReSTIR passes and the
+    NRC tracer they feed, every per-pixel buffer, the inference queries and the training chains against the oracle."""
+    diffs = run_nrc_both(util.bunny_scene(), 128, 96, 3, max_len, radiance_scale=2.5, restir=True)
+    assert not diffs, "\n".join(diffs[:12])
+
+
+@pytest.mark.gpu
+def test_nrc_render_with_restir_nee_on_the_street_with_env_light(built_lib):
+    w, h = 64, 32
+    sky = api.env_make_sky(w, h)
+    cam = api.make_camera(96, 64, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
+    diffs = run_nrc_both(util.small_street(), 96, 64, 2, 5, env=(sky, w, h), camera=cam, restir=True)
+    assert not diffs, "\n".join(diffs[:12])

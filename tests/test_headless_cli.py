@@ -90,7 +90,8 @@ def test_nrc_options_of_the_reference_command_line(built_lib):
     assert d["nrc"]["position_encoding"] == "tri-wave" and d["nrc"]["num_hidden_layers"] == 5 and abs(d["nrc"]["learning_rate"] - 1e-3) < 1e-9
     assert d["nrc"]["max_path_length"] == 0 and d["nrc"]["train"] is False
     assert _run(base + ["-nee", "regir"])["nrc"]["nee"] == "regir"
-    r = _run(base + ["-nee", "restir"], check=False)
+    assert _run(base + ["-nee", "restir"])["nrc"]["nee"] == "restir"
+    r = _run(base + ["-nee", "lightcuts"], check=False)
     assert r.returncode != 0 and "NEE sampler" in r.stderr
     r = _run(base + ["-position-encoding", "fourier"], check=False)
     assert r.returncode != 0 and "position encoding" in r.stderr

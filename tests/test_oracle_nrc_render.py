@@ -177,3 +177,66 @@ def test_regir_next_event_estimation_in_the_nrc_tracer_keeps_the_direct_light():
     assert rb.accesses.sum() > 0 and (rb.last_access != 0xFFFFFFFF).any()
     # training records exist and their first-vertex targets are finite (NEE estimates of the grid)
     assert int(nb.a["nrc_num_1"][0]) > 0 and np.isfinite(nb.a["nrc_traint_0"][:int(nb.a["nrc_num_1"][0])]).all()
+
+
+def test_restir_next_event_estimation_in_the_nrc_tracer_keeps_the_direct_light():
+    """GFX_PT_PATH_TRACE_NRC_RESTIR (the ReSTIR half of README.md:80-81): the NRC tracer whose first vertex takes its
+    next-event estimation from the pixel's ReSTIR DI reservoir, with no weight for what the first extension ray finds emitting.
+    With maxPathLength = 2 the per-frame contribution of a rendering path is the direct light of its first vertex (+ its own emission):
+      * it equals, pixel by pixel and bit for bit, what the ReSTIR shading pass computes from the same reservoirs minus nothing --
+        the shading pass's `emittance / pi + recPDFEstimate x directCont` against the tracer's `alpha (= 1) x emittance / pi +
+        alpha x directContNEE`: the same two terms from the same G-buffer and reservoir (checked exactly where the first vertex is
+        not emissive and the G-buffer's quantised frame gives the same emission test);
+      * its image mean agrees with the baseline NRC tracer's (NEE + MIS) to the noise of the frames plus the bias of the BIASED spatial
+        reuse (within 8 %)."""
+    hs = util.bunny_scene()
+    w, h, frames = 48, 32, 40
+    cam = util.copy_struct(O.GfxCamera, _camera(w, h))
+
+    def run(restir):
+        osc = util.feed_oracle(hs, threads=4)
+        pb, nb = util.PixelBuffers(w, h), util.NrcBuffers(w, h, hs.bounds())
+        s = pb.host_static_params()
+        acc = np.zeros((w * h, 3), np.float64)
+        last_res, last_base = 1, 0
+        exact = 0
+        for frame in range(frames):
+            f = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, w, h, cam, frameIndex=frame, bufferIndex=frame % 2,
+                                  resetFlowBuffer=int(frame == 0), numAccumFrames=0)
+            osc.nrc_set_render_params(nb.host_params(3 + frame, 5 + 2 * frame, frame == 0))
+            osc.pt_launch(s, f, api.PT_SETUP_GBUFFERS, 2)
+            if restir:
+                cur = (last_res + 1) % 2
+                osc.restir_launch(s, f, cur, last_base, api.PASS_INITIAL_RIS if frame == 0 else api.PASS_INITIAL_TEMPORAL_BIASED)
+                for i in range(2):
+                    osc.restir_launch(s, f, cur, last_base + 5 * i, api.PASS_SPATIAL_BIASED)
+                    cur = (cur + 1) % 2
+                last_base += 10
+                last_res = cur
+                osc.pt_set_reservoir_index(cur)
+                rng_before = pb.rng.copy()
+                osc.pt_launch(s, f, api.PT_NRC_PREPROCESS, 2)
+                osc.pt_launch(s, f, api.PT_PATH_TRACE_NRC_RESTIR, 2)
+                contribution = nb.a["nrc_contribution"].copy()
+                # the shading pass on the same reservoirs (it draws no random numbers and writes only the beauty buffer)
+                pb.rng[:] = pb.rng
+                osc.restir_launch(s, f, cur, last_base, api.PASS_SHADING)
+                shaded = pb.beauty[:, :3]
+                surface = pb.gb0[frame % 2]["instSlot"] != 0xFFFFFFFF
+                same = np.all(shaded == contribution, axis=1)
+                exact += int(np.count_nonzero(same & surface))
+                assert np.count_nonzero(same & surface) > 0.9 * np.count_nonzero(surface), (frame, np.count_nonzero(same & surface), np.count_nonzero(surface))
+                del rng_before
+            else:
+                osc.pt_launch(s, f, api.PT_NRC_PREPROCESS, 2)
+                osc.pt_launch(s, f, api.PT_PATH_TRACE_NRC, 2)
+            acc += nb.a["nrc_contribution"]
+            assert np.isfinite(nb.a["nrc_contribution"]).all()
+        return acc / frames, nb, exact
+
+    base, _, _ = run(False)
+    got, nb, exact = run(True)
+    assert base.mean() > 1e-3 and exact > 0
+    assert abs(got.mean() - base.mean()) < 0.08 * base.mean(), (got.mean(), base.mean())
+    n_train = int(nb.a["nrc_num_1"][0])
+    assert n_train > 0 and np.isfinite(nb.a["nrc_traint_0"][:n_train]).all()
