@@ -440,7 +440,9 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2):
                 "lane_fraction": round((2 * ka["valu_insts"] * ka["lane_fraction"] + kc["valu_insts"] * kc["lane_fraction"]) / insts_frame, 4),
                 "insts_per_wave_iteration": round(insts_frame / max(1, diag["iterations"]), 1),
                 "useful_fraction_of_valu_peak": None}
-        valu["useful_fraction_of_valu_peak"] = round(valu["busy"] * valu["lane_fraction"], 4)
+        # busy is SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES); the r04 passes read 1.00-1.08 for the traversal kernels (the busy-cycle
+        # normalisation is good to a few per cent): a SIMD cannot issue more than all the time, so the product is taken with min(busy, 1)
+        valu["useful_fraction_of_valu_peak"] = round(min(valu["busy"], 1.0) * valu["lane_fraction"], 4)
     # The headline fraction is the one that binds: the share of the SIMDs' VALU issue slots x lanes that carry a ray (`valu`), when the
     # committed counter pass covers this configuration; the SURVEY 8(d) byte figure stays beside it as frac_nominal_hbm.
     useful = valu["useful_fraction_of_valu_peak"] if valu else None

@@ -53,6 +53,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--textured", action="store_true")
+    ap.add_argument("--nee", default="lights", choices=["lights", "regir", "restir"], help="next-event estimation of the tracer (gfxh_nrc_config::neeSampler)")
     args = ap.parse_args()
     hs = scenes.bench_street(textured=args.textured)
     ctx = api.Context(0)
@@ -60,8 +61,11 @@ def main():
     w, h = 1920, 1080
     cfg = api.NrcRenderer.default_config(w, h, hs.bounds())
     cfg.camera = api.make_camera(w, h, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
+    cfg.neeSampler = {"lights": api.NRC_NEE_LIGHTS, "regir": api.NRC_NEE_REGIR, "restir": api.NRC_NEE_RESTIR}[args.nee]
     for serial in (False, True):
-        print(json.dumps(run(ctx, cfg, args.steps, serial)), flush=True)
+        out = run(ctx, cfg, args.steps, serial)
+        out["nee"] = args.nee
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
