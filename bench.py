@@ -355,6 +355,7 @@ def main():
 
     if rank == 0 and world == 1:
         if not args.no_roofline:
+            ctx.tunable_set("pt_overlap", 0)          # per-kernel durations: kernels that share the GPU with another stream read longer than they are
             if args.config == 3:
                 result["roofline"], result["kernels_ms_per_frame"], result["nrc"] = roofline_nrc(ctx, renderer, stream, W, H)
             else:
@@ -370,6 +371,7 @@ def main():
                     serial.render_frame(stream)
                 result["roofline"], result["kernels_ms_per_frame"] = roofline(ctx, serial, stream, args.steps, W, H, args.config)
                 serial.close()
+            ctx.tunable_set("pt_overlap", 1)
         if args.mse_ref_spp > 0 and args.config == 2 and not args.animate:
             result["mse"] = mse_vs_reference(ctx, hs, renderer, cam, W, H, args.mse_ref_spp)
         if args.cpu_sample not in ("0", ""):

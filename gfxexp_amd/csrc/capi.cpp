@@ -61,6 +61,7 @@ int gfx_ctx_create(int device, gfx_ctx** out) {
         t.traceRefill = env_int("GFX_TRACE_REFILL", t.traceRefill, 1, 64);
         t.traceBatch = env_int("GFX_TRACE_BATCH", t.traceBatch, 1, 65536);
         t.temporalHints = env_int("GFX_TEMPORAL_HINTS", t.temporalHints, 0, 1);
+        t.ptOverlap = env_int("GFX_PT_OVERLAP", t.ptOverlap, 0, 1);
         ctx->c.dTraceCounters.reserve(64);
         GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 64));
         *out = ctx.release();
@@ -501,6 +502,7 @@ int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value) {
     else if (n == "trace_refill") t.traceRefill = in(1, 64);
     else if (n == "temporal_hints") t.temporalHints = in(0, 1);
     else if (n == "trace_batch") t.traceBatch = in(1, 65536);
+    else if (n == "pt_overlap") t.ptOverlap = in(0, 1);
 
     else throw HipError("gfx_tunable_set: unknown tunable " + n);
     GFX_CATCH(ctx)

@@ -55,6 +55,13 @@ struct gfxh_nrc {
     // evTrained: weights of the last step packed.
     hipStream_t trainStream = nullptr;
     hipEvent_t evData = nullptr, evTrained = nullptr;
+    // Frame pipelining (as gfxh_restir): the G-buffer pass of a frame depends on nothing the previous frame computes -- it writes the
+    // other half of the double-buffered G-buffers from its own ray queue / hit / ticket scratch inside the context -- so it runs on
+    // gbStream, where it overlaps the previous frame's inference, accumulation and propagation that are still queued on the caller's
+    // stream.  evGb: G-buffer written; evGbFree: the caller's stream has passed the point up to which it read these buffers.
+    hipStream_t gbStream = nullptr;
+    hipEvent_t evGb = nullptr, evGbFree = nullptr;
+    bool pipelineFrames = true, gbFreePending = false;
     bool trainPending = false, overlapTraining = true;
     // band renderer (gfxh_nrc_set_exchange)
     gfxh_exchange_fn exchange = nullptr; void* exchangeUser = nullptr; int rank = 0;
@@ -93,6 +100,9 @@ void gfxh_nrc_destroy(gfxh_nrc* r) {
     if (r->evData) (void)hipEventDestroy(r->evData);
     if (r->evTrained) (void)hipEventDestroy(r->evTrained);
     if (r->trainStream) (void)hipStreamDestroy(r->trainStream);
+    if (r->evGb) (void)hipEventDestroy(r->evGb);
+    if (r->evGbFree) (void)hipEventDestroy(r->evGbFree);
+    if (r->gbStream) (void)hipStreamDestroy(r->gbStream);
     if (r->network) (void)gfx_nrc_destroy(r->ctx, r->network);
     for (void* p : r->allocations) (void)hipFree(p);
     delete r;
@@ -208,7 +218,12 @@ int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out) {
         const char* e = std::getenv("GFX_NRC_SERIAL_TRAINING");   // debugging aid: train on the caller's stream
         r->overlapTraining = !(e && e[0] == '1');
         // non-blocking: the caller's stream may be the legacy default stream, which would serialise a blocking one
-        if (!nrc_hip_ok(hipStreamCreateWithFlags(&r->trainStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
+        const char* sf = std::getenv("GFX_SERIAL_FRAMES");   // debugging aid: everything on the caller's stream
+        r->pipelineFrames = !(sf && sf[0] == '1');
+        if (!nrc_hip_ok(hipStreamCreateWithFlags(&r->gbStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
+            !nrc_hip_ok(hipEventCreateWithFlags(&r->evGb, hipEventDisableTiming), "hipEventCreate") ||
+            !nrc_hip_ok(hipEventCreateWithFlags(&r->evGbFree, hipEventDisableTiming), "hipEventCreate") ||
+            !nrc_hip_ok(hipStreamCreateWithFlags(&r->trainStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
             !nrc_hip_ok(hipEventCreateWithFlags(&r->evData, hipEventDisableTiming), "hipEventCreate") ||
             !nrc_hip_ok(hipEventCreateWithFlags(&r->evTrained, hipEventDisableTiming), "hipEventCreate") ||
             !nrc_hip_ok(hipEventCreateWithFlags(&r->evStats, hipEventDisableTiming), "hipEventCreate") ||
@@ -258,7 +273,20 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
         fp.enableTemporalReuse = 1; fp.enableSpatialReuse = 1; fp.useUnbiasedEstimator = 0;
         NRC_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, 0, 0));
     }
-    NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, rb, re));
+    // The G-buffer pass: pipelined under the previous frame's tail unless something it depends on was queued on the caller's stream
+    // since (an instance moved: the BVH update) or it is not a whole-frame renderer.  It overwrites the G-buffers of two frames ago,
+    // which the caller's stream read last in that frame's path-tracing pass (evGbFree).
+    const bool pipelined = r->pipelineFrames && !band && !viewMoved && !newSequence;
+    if (pipelined) {
+        if (r->gbFreePending) NRC_HIP(hipStreamWaitEvent(r->gbStream, r->evGbFree, 0));
+        NRC_GFX(gfx_pt_launch(ctx, r->gbStream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, rb, re));
+        NRC_HIP(hipEventRecord(r->evGb, r->gbStream));
+        NRC_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), r->evGb, 0));
+    }
+    else {
+        // (a pass still running on gbStream belongs to an earlier frame and was joined by that frame)
+        NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, rb, re));
+    }
     if (restirNee) {   // restir_di_main.cpp:2365-2421 without the shading pass: its direct term is formed at the tracer's first vertex
         uint32_t cur = (r->lastReservoirIndex + 1) % 2, base = r->lastSpatialNeighborBaseIndex;
         NRC_GFX(gfx_restir_set_params(ctx, stream, &r->sp, &fp, cur, base));
@@ -280,6 +308,10 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_PREPROCESS, W, H, cfg.maxPathLength, 0, 0));
     NRC_GFX(gfx_pt_launch(ctx, stream, regirNee ? GFX_PT_PATH_TRACE_NRC_REGIR : restirNee ? GFX_PT_PATH_TRACE_NRC_RESTIR : GFX_PT_PATH_TRACE_NRC, W, H, cfg.maxPathLength, rb, re));
     if (regirNee) NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_REGIR_UPDATE_LAST_ACCESS, W, H, cfg.maxPathLength, 0, 0));
+    if (r->pipelineFrames && !band) {   // nothing later in the frame reads the G-buffers
+        NRC_HIP(hipEventRecord(r->evGbFree, static_cast<hipStream_t>(stream)));
+        r->gbFreePending = true;
+    }
     // main:2293-2303: the inference batch size needs the tile size of this frame.  The reference synchronises the stream and
     // reads it back; a band renderer does the same here (the record gather needs the counts on the host anyway).  The whole-
     // frame renderer forms the batch size on the device instead and never waits for the GPU inside a frame.

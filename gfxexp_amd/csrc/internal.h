@@ -94,6 +94,8 @@ struct Tunables {
     int traceRefill = 8;             // refill a wave when at least this many lanes are idle
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
     int temporalHints = 1;           // primary rays test the triangle their pixel hit one frame ago first (trace.hip)
+    int ptOverlap = 1;               // path tracers: the NEE (any-hit) trace + its apply kernel of a bounce run on a second stream underneath
+                                     // the extension (closest-hit) trace of the same bounce (pathtrace.hip)
 };
 
 struct Context {
@@ -140,7 +142,7 @@ struct Context {
     // ticket areas of k_trace per counter buffer ([0] smallCounters, [1] any other): which of the two areas the next launch draws from
     // (the launch before it zeroed that one), whether both have been zeroed once, and the stream of the last launch (a launch on another
     // stream waits for it and re-zeroes: the hand-over between launches is stream order)
-    struct TicketState { bool zeroed = false; uint32_t next = 0; void* buffer = nullptr; hipStream_t stream = nullptr; } ticketState[2];
+    struct TicketState { bool zeroed = false; uint32_t next = 0; void* buffer = nullptr; hipStream_t stream = nullptr; } ticketState[3];
     uint32_t numLightMatrices = 0;   // distinct normal matrices of the emitter instances (scene.cpp light_matrices_upload)
     DevScene devScene() const;
     // accels
@@ -151,6 +153,11 @@ struct Context {
     // The G-buffer pass has its own ray queue / hit / stack-spill / ticket scratch, so a driver may run the next
     // frame's G-buffer pass on a second stream underneath the tail of the current frame (restir_driver.cpp).
     DevBuf gbRayOrg, gbRayDir, gbRayHits, gbSpill, gbCounters;
+    // ... and the path tracers a third (stack spill + ticket areas) for the NEE trace that runs on `auxStream` underneath the extension
+    // trace of the same bounce (pathtrace.hip); auxFork / auxJoin order the two streams
+    DevBuf auxSpill, auxCounters;
+    hipStream_t auxStream = nullptr;
+    hipEvent_t auxFork = nullptr, auxJoin = nullptr;
     // path tracer scratch (pathtrace.hip)
     DevBuf ptPending, ptExtOrg, ptExtDir, ptExtOwner, ptState;
     DevBuf rearchSlots;

@@ -1297,12 +1297,27 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     ctx.ptState.reserve(32 * numPixels);
     if (nrc) { ctx.nrcState.reserve(32 * numPixels); ctx.neeTrainIdx.reserve(4 * numPixels); }
     ctx.smallCounters.reserve(kSmallCountersBytes);
-    uint32_t* counters = ctx.smallCounters.as<uint32_t>() + 8;   // [0] nee, [1] ext ping, [2] ext pong
-    GFX_HIP(hipMemsetAsync(counters, 0, 3 * sizeof(uint32_t), stream));
+    uint32_t* counters = ctx.smallCounters.as<uint32_t>() + 8;   // [0] nee (even bounces), [1] ext ping, [2] ext pong, [3] nee (odd bounces)
+    GFX_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream));
+    uint32_t* const neeCounts[2] = { counters, counters + 3 };
+
+    // The NEE trace of a bounce (any-hit) and the kernel that applies its result touch the NEE queue, the occlusion words and the
+    // per-pixel contribution; the extension trace of the same bounce (closest-hit) touches the extension queue and the hit records:
+    // disjoint, and both only needed by the bounce kernel.  So the first two run on a second stream (own stack-spill / ticket scratch)
+    // underneath the third -- small launches are mostly ramp-up and the tail of their longest rays (profiles/r04_experiments.txt 8),
+    // which now overlap.  The NEE queue head alternates between two words so that the extension trace can zero the one the bounce kernel
+    // appends to while the NEE trace still reads the other.
+    const bool overlap = ctx.tune.ptOverlap != 0;
+    if (overlap && !ctx.auxStream) {
+        GFX_HIP(hipStreamCreateWithFlags(&ctx.auxStream, hipStreamNonBlocking));
+        GFX_HIP(hipEventCreateWithFlags(&ctx.auxFork, hipEventDisableTiming));
+        GFX_HIP(hipEventCreateWithFlags(&ctx.auxJoin, hipEventDisableTiming));
+    }
+    hipStream_t neeStream = overlap ? ctx.auxStream : stream;
 
     a.px = make_pixel_grid(ctx, width, rowBegin, rowEnd);
     a.neeOrg = ctx.rayOrg.as<float4>(); a.neeDir = ctx.rayDir.as<float4>(); a.neePending = ctx.ptPending.as<float4>();
-    a.neeCount = counters;
+    a.neeCount = neeCounts[0];
     a.occluded = ctx.rayOut.as<uint32_t>();
     a.hits = ctx.rayHits.as<gfx_hit>();
     a.tris = ctx.accels[h - 1]->trisPtr();
@@ -1317,9 +1332,9 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         a.extOrgIn = extOrg[in]; a.extDirIn = extDir[in]; a.extOwnerIn = extOwner[in]; a.extCountIn = counters + 1 + in;
         a.extOrgOut = extOrg[out]; a.extDirOut = extDir[out]; a.extOwnerOut = extOwner[out]; a.extCountOut = counters + 1 + out;
     };
-    auto launch = [&](const char* name, void (*kernel)(PtArgs)) {          // one thread per queue entry (capacity = the band's pixels)
-        ScopedKernelTimer timer(ctx, stream, name);
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kPtBlock), 0, stream, a);
+    auto launch = [&](hipStream_t s, const char* name, void (*kernel)(PtArgs)) {   // one thread per queue entry (capacity = the band's pixels)
+        ScopedKernelTimer timer(ctx, s, name);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kPtBlock), 0, s, a);
         GFX_HIP(hipGetLastError());
     };
     auto launch_pixels = [&](const char* name, void (*kernel)(PtArgs)) {   // one thread per pixel of the band (a.px)
@@ -1327,12 +1342,15 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         hipLaunchKernelGGL(kernel, dim3(a.px.launchBlocks), dim3(kPtBlock), 0, stream, a);
         GFX_HIP(hipGetLastError());
     };
-    auto trace = [&](int mode, const float4* org, const float4* dir, const uint32_t* count, void* out, uint32_t* zero0 = nullptr, uint32_t* zero1 = nullptr) {
+    auto trace = [&](hipStream_t s, bool auxScratch, int mode, const float4* org, const float4* dir, const uint32_t* count, void* out,
+                     uint32_t* zero0 = nullptr, uint32_t* zero1 = nullptr) {
         TraceLaunch t;
         t.accel = accel; t.rayOrgTmin = org; t.rayDirTmax = dir; t.numRays = 0; t.numRaysPtr = count; t.out = out; t.mode = mode;
         t.zeroWords[0] = zero0; t.zeroWords[1] = zero1;
-        trace_launch(ctx, stream, t);
+        if (auxScratch) { t.spill = &ctx.auxSpill; t.counters = &ctx.auxCounters; }
+        trace_launch(ctx, s, t);
     };
+    auto join = [&]() { if (overlap) GFX_HIP(hipStreamWaitEvent(stream, ctx.auxJoin, 0)); };
 
     int cur = 0;                 // the queue k_pt_first fills
     set_queues(1, cur);
@@ -1345,29 +1363,36 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     // trace at the length limit, so the last vertex's NEE ray is resolved after the loop.  NRC:
     // maxPathLength == 0 means unlimited bounces (neural_radiance_caching_main.cpp:2246) -- the live
     // path count is read back every fourth bounce to stop (the 6-bit pathLength field caps it at 63).
+    int nee = 0;                 // the NEE queue head the last vertex kernel appended to
     for (uint32_t pathLength = 2;; ++pathLength) {
-        trace(GFX_TRACE_ANY, a.neeOrg, a.neeDir, a.neeCount, ctx.rayOut.p);
-        launch("pt_apply_nee", k_pt_apply_nee);
-        if (regir && pathLength >= maxPathLength) break;
+        if (overlap) { GFX_HIP(hipEventRecord(ctx.auxFork, stream)); GFX_HIP(hipStreamWaitEvent(neeStream, ctx.auxFork, 0)); }
+        a.neeCount = neeCounts[nee];
+        trace(neeStream, overlap, GFX_TRACE_ANY, a.neeOrg, a.neeDir, a.neeCount, ctx.rayOut.p);
+        launch(neeStream, "pt_apply_nee", k_pt_apply_nee);
+        if (overlap) GFX_HIP(hipEventRecord(ctx.auxJoin, neeStream));
+        if (regir && pathLength >= maxPathLength) { join(); break; }
         // NRC: training paths skip Russian roulette (and with it the length test) at pathLength 2 (:459-462),
         // so the last vertex that can exist is max(maxPathLength, 3)
-        if (nrc && maxPathLength > 0 && pathLength > (maxPathLength > 3 ? maxPathLength : 3)) break;
-        if (nrc && pathLength >= 63) break;
+        if (nrc && maxPathLength > 0 && pathLength > (maxPathLength > 3 ? maxPathLength : 3)) { join(); break; }
+        if (nrc && pathLength >= 63) { join(); break; }
         if (nrc && maxPathLength == 0 && pathLength > 2 && (pathLength & 3u) == 2u) {
             uint32_t live = 0;
             GFX_HIP(hipMemcpyAsync(&live, counters + 1 + cur, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             GFX_HIP(hipStreamSynchronize(stream));
-            if (live == 0) break;
+            if (live == 0) { join(); break; }
         }
-        // the extension trace also resets the two queue heads the bounce kernel appends to (the NEE queue, already consumed by
-        // k_pt_apply_nee, and the other extension queue): no memset between the kernels of a bounce
-        trace(GFX_TRACE_CLOSEST, extOrg[cur], extDir[cur], counters + 1 + cur, ctx.rayHits.p, counters, counters + 1 + (cur ^ 1));
+        // the extension trace also resets the two queue heads the bounce kernel appends to (the NEE head of the NEXT bounce -- not the
+        // one the NEE trace above is reading -- and the other extension queue): no memset between the kernels of a bounce
+        trace(stream, false, GFX_TRACE_CLOSEST, extOrg[cur], extDir[cur], counters + 1 + cur, ctx.rayHits.p, neeCounts[nee ^ 1], counters + 1 + (cur ^ 1));
+        join();                  // the bounce kernel adds to the contribution after k_pt_apply_nee has, and rewrites the NEE queue
         set_queues(cur, cur ^ 1);
+        nee ^= 1;
+        a.neeCount = neeCounts[nee];
         a.pathLength = pathLength;
         a.maxLengthTerminate = (pathLength >= maxPathLength && (!nrc || maxPathLength > 0)) ? 1u : 0u;
         a.nextMaxLengthTerminate = pathLength + 1 >= maxPathLength ? 1u : 0u;
-        if (nrc) launch("nrc_pt_bounce", nrcRegir ? k_nrc_pt_bounce<1> : nrcRestir ? k_nrc_pt_bounce<2> : k_nrc_pt_bounce<0>);
-        else launch("pt_bounce", regir ? k_pt_bounce<true> : k_pt_bounce<false>);
+        if (nrc) launch(stream, "nrc_pt_bounce", nrcRegir ? k_nrc_pt_bounce<1> : nrcRestir ? k_nrc_pt_bounce<2> : k_nrc_pt_bounce<0>);
+        else launch(stream, "pt_bounce", regir ? k_pt_bounce<true> : k_pt_bounce<false>);
         cur ^= 1;
         if (!regir && !nrc && a.maxLengthTerminate) break;
     }

@@ -216,7 +216,7 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     small.reserve(kSmallCountersBytes);
     // Two ticket areas per counter buffer: a launch draws from one and its block 0 zeroes the other, which the next launch on this
     // buffer (same stream by construction: the pipelined G-buffer pass has its own buffer) then finds zero -- no memset per launch.
-    Context::TicketState& ts = ctx.ticketState[&small == &ctx.smallCounters ? 0 : 1];
+    Context::TicketState& ts = ctx.ticketState[&small == &ctx.smallCounters ? 0 : &small == &ctx.auxCounters ? 2 : 1];
     char* areas = static_cast<char*>(small.p) + kSmallCountersTicketOffset;
     if (ts.zeroed && ts.buffer == small.p && ts.stream != stream) {
         // the "previous launch zeroed my area" hand-over is stream order; a launch on another stream first waits for the last launch on

@@ -494,6 +494,9 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
  *   "super_x", "super_y"        log2 of the supertile size in 16 x 16-pixel blocks (mode 2; default 2, 2)
  *   "trace_blocks_per_cu", "trace_refill", "trace_batch"   persistent traversal grid, lane-refill threshold, rays per ticket
  *   "temporal_hints" 0|1        the primary ray of a pixel first tests the triangle it hit one frame ago (default 1; GFX_TEMPORAL_HINTS)
+ *   "pt_overlap" 0|1            path tracers (gfx_pt_launch): the NEE any-hit trace of a bounce and the kernel that applies it run on a
+ *                               library-owned second stream underneath the extension closest-hit trace of the same bounce -- the two
+ *                               read and write disjoint buffers; the bounce kernel waits for both (default 1; GFX_PT_OVERLAP)
  * The same knobs are read once from the environment by gfx_ctx_create (GFX_PIXEL_MAP, GFX_SUPER_X, GFX_SUPER_Y,
  * GFX_TRACE_BLOCKS_PER_CU, GFX_TRACE_REFILL, GFX_TRACE_BATCH). */
 int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value);
