@@ -144,6 +144,10 @@ struct Context {
     // stream waits for it and re-zeroes: the hand-over between launches is stream order)
     struct TicketState { bool zeroed = false; uint32_t next = 0; void* buffer = nullptr; hipStream_t stream = nullptr; } ticketState[3];
     uint32_t numLightMatrices = 0;   // distinct normal matrices of the emitter instances (scene.cpp light_matrices_upload)
+    // pinned staging of light_matrices_upload (two buffers, an event each): the per-frame re-upload after an animated emitter moved is
+    // truly asynchronous -- a host wait there would stall the frame loop and with it the overlap of consecutive frames
+    struct PinnedStage { void* p = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; } lightStage[2];
+    uint32_t lightStageNext = 0;
     DevScene devScene() const;
     // accels
     std::vector<Accel*> accels;

@@ -21,6 +21,7 @@ Context::~Context() {
     for (NrcNet* net : nrcNets) if (net) nrc_destroy(net);
     for (DevBuf* b : all) b->release();
     for (auto& e : pendingEvents) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    for (PinnedStage& st : lightStage) { if (st.done) (void)hipEventDestroy(st.done); if (st.p) (void)hipHostFree(st.p); }
     if (auxFork) (void)hipEventDestroy(auxFork);
     if (auxJoin) (void)hipEventDestroy(auxJoin);
     if (auxStream) (void)hipStreamDestroy(auxStream);
@@ -143,11 +144,25 @@ void light_matrices_upload(Context& ctx, hipStream_t stream) {
     if (seen.size() > kEmitterMatrixMask + 1u)
         throw HipError("gfx: more than 65536 distinct normal matrices among the emitter instances");
     ctx.numLightMatrices = static_cast<uint32_t>(seen.size());
-    ctx.dLightNormalMatrices.reserve(std::max<size_t>(rows.size() * sizeof(float), 64));
+    // (a little slack: an animated emitter that gains a distinct matrix must not make reserve() free a buffer kernels in flight read)
+    ctx.dLightNormalMatrices.reserve(std::max<size_t>(rows.size() * sizeof(float) + 64 * 64, 64));
     ctx.dInstMatrixIndex.reserve(std::max<size_t>(index.size() * sizeof(uint32_t), 16));
-    if (!rows.empty()) GFX_HIP(hipMemcpyAsync(ctx.dLightNormalMatrices.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    if (!index.empty()) GFX_HIP(hipMemcpyAsync(ctx.dInstMatrixIndex.p, index.data(), index.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    GFX_HIP(hipStreamSynchronize(stream));   // the host vectors go out of scope
+    const size_t rowBytes = rows.size() * sizeof(float), indexBytes = index.size() * sizeof(uint32_t);
+    if (rowBytes + indexBytes == 0) return;
+    Context::PinnedStage& st = ctx.lightStage[ctx.lightStageNext];
+    ctx.lightStageNext ^= 1u;
+    if (st.done) GFX_HIP(hipEventSynchronize(st.done));     // the copy issued out of this buffer two uploads ago: long finished
+    else GFX_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    if (st.bytes < rowBytes + indexBytes) {
+        if (st.p) GFX_HIP(hipHostFree(st.p));
+        st.p = nullptr; st.bytes = 0;
+        GFX_HIP(hipHostMalloc(&st.p, (rowBytes + indexBytes) * 2, hipHostMallocDefault));
+        st.bytes = (rowBytes + indexBytes) * 2;
+    }
+    char* base = static_cast<char*>(st.p);
+    if (rowBytes) { std::memcpy(base, rows.data(), rowBytes); GFX_HIP(hipMemcpyAsync(ctx.dLightNormalMatrices.p, base, rowBytes, hipMemcpyHostToDevice, stream)); }
+    if (indexBytes) { std::memcpy(base + rowBytes, index.data(), indexBytes); GFX_HIP(hipMemcpyAsync(ctx.dInstMatrixIndex.p, base + rowBytes, indexBytes, hipMemcpyHostToDevice, stream)); }
+    GFX_HIP(hipEventRecord(st.done, stream));
 }
 
 void transforms_upload(Context& ctx, hipStream_t stream) {
