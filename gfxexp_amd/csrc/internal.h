@@ -141,8 +141,8 @@ struct Context {
     uint32_t spanGuideCells = 0;
     // ticket areas of k_trace per counter buffer ([0] smallCounters, [1] any other): which of the two areas the next launch draws from
     // (the launch before it zeroed that one), whether both have been zeroed once, and the stream of the last launch (a launch on another
-    // stream waits for it and re-zeroes: the hand-over between launches is stream order)
-    struct TicketState { bool zeroed = false; uint32_t next = 0; void* buffer = nullptr; hipStream_t stream = nullptr; } ticketState[3];
+    // stream waits for the event recorded behind that launch and re-zeroes: the hand-over between launches is stream order)
+    struct TicketState { bool zeroed = false; uint32_t next = 0; void* buffer = nullptr; hipStream_t stream = nullptr; hipEvent_t lastLaunch = nullptr; } ticketState[3];
     uint32_t numLightMatrices = 0;   // distinct normal matrices of the emitter instances (scene.cpp light_matrices_upload)
     // pinned staging of light_matrices_upload (two buffers, an event each): the per-frame re-upload after an animated emitter moved is
     // truly asynchronous -- a host wait there would stall the frame loop and with it the overlap of consecutive frames

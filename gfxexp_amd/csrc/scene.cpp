@@ -21,6 +21,7 @@ Context::~Context() {
     for (NrcNet* net : nrcNets) if (net) nrc_destroy(net);
     for (DevBuf* b : all) b->release();
     for (auto& e : pendingEvents) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    for (TicketState& ts : ticketState) if (ts.lastLaunch) (void)hipEventDestroy(ts.lastLaunch);
     for (PinnedStage& st : lightStage) { if (st.done) (void)hipEventDestroy(st.done); if (st.p) (void)hipHostFree(st.p); }
     if (auxFork) (void)hipEventDestroy(auxFork);
     if (auxJoin) (void)hipEventDestroy(auxJoin);

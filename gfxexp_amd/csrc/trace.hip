@@ -220,12 +220,9 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
     char* areas = static_cast<char*>(small.p) + kSmallCountersTicketOffset;
     if (ts.zeroed && ts.buffer == small.p && ts.stream != stream) {
         // the "previous launch zeroed my area" hand-over is stream order; a launch on another stream first waits for the last launch on
-        // the old one, then starts over with two zeroed areas (a caller that alternates streams pays an event and a memset per switch)
-        hipEvent_t done;
-        GFX_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        GFX_HIP(hipEventRecord(done, ts.stream));
-        GFX_HIP(hipStreamWaitEvent(stream, done, 0));
-        GFX_HIP(hipEventDestroy(done));
+        // this buffer (an event recorded behind it: the stream it ran on may be gone by now -- a renderer's private stream), then starts
+        // over with two zeroed areas (a caller that alternates streams pays a wait and a memset per switch)
+        if (ts.lastLaunch) GFX_HIP(hipStreamWaitEvent(stream, ts.lastLaunch, 0));
         ts.zeroed = false;
     }
     if (!ts.zeroed || ts.buffer != small.p) {
@@ -264,6 +261,8 @@ void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t) {
         else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(kTraceBlock), 0, stream, a);
     }
     GFX_HIP(hipGetLastError());
+    if (!ts.lastLaunch) GFX_HIP(hipEventCreateWithFlags(&ts.lastLaunch, hipEventDisableTiming));
+    GFX_HIP(hipEventRecord(ts.lastLaunch, stream));
 }
 
 } // namespace gfx
