@@ -514,8 +514,10 @@ def roofline_nrc(ctx, renderer, stream, W, H):
     import torch
     from gfxexp_amd import api
     os.environ["GFX_NRC_SERIAL_TRAINING"] = "1"          # one stream: kernels that overlap read longer than they are
+    os.environ["GFX_SERIAL_FRAMES"] = "1"                # ... nor the next frame's G-buffer pass under this frame's inference
     serial = api.NrcRenderer(ctx, renderer.cfg)
     os.environ.pop("GFX_NRC_SERIAL_TRAINING", None)
+    os.environ.pop("GFX_SERIAL_FRAMES", None)
     for _ in range(6):
         serial.render_frame(stream)
     serial.network()
