@@ -182,13 +182,37 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
 // instead of 4 per lane; the normal matrix comes out of the deduplicated table the record's flags index.  At 11 gathers per lane and candidate
 // the kernel ran exactly at the CU's one-line-request-per-clock time (profiles/r03_experiments.txt).  The candidate loop is therefore
 // wave-uniform: lanes without a surface take part in the fetch and in nothing else.
-template <bool EMITTER_TEX>
+//
+// SPLIT > 1 (small launches -- a row band of a multi-GPU frame is ONE round of waves, each a chain of 32 dependent candidate
+// iterations): SPLIT neighbouring lanes share a pixel and take its candidates round robin (lane j: candidates j, j + SPLIT, ...), so the
+// launch has SPLIT times the waves, each 1 / SPLIT as long.  Same result, bit for bit:
+//   * every candidate draws exactly four numbers, so lane j starts 4 j draws into the pixel's PCG32 stream and skips 4 (SPLIT - 1)
+//     draws after each candidate (an LCG jumps n steps with one multiply-add by constants);
+//   * the weights of the SPLIT candidates of a step are added to the running sum left to right through the lanes (quad-permute DPP), so
+//     every candidate sees the fp32 sum the sequential loop has at its turn (Reservoir::update, restir_di_shared.h:118-125);
+//   * each lane keeps the last candidate IT accepted; the pixel's sample is the one with the highest candidate index, and the lane that
+//     holds it writes the pixel's outputs.
+struct LcgJump { uint64_t mul, add; };
+constexpr LcgJump lcg_jump(uint32_t n) {      // n steps of state -> state * 6364136223846793005 + 1 (shading.hip.h Pcg32)
+    LcgJump j = { 1ull, 0ull };
+    for (uint32_t k = 0; k < n; ++k) { j.add = j.add * 6364136223846793005ULL + 1ull; j.mul = j.mul * 6364136223846793005ULL; }
+    return j;
+}
+template <int CTRL> GFX_DEV float quad_perm(float v) {      // v of the lane quad_perm names, within every aligned group of four lanes
+    return bits2f(static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(f2bits(v)), CTRL, 0xF, 0xF, false)));
+}
+template <int CTRL> GFX_DEV int quad_perm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <bool EMITTER_TEX, int SPLIT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a) {
+    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "a pixel's lanes are an aligned pair or quad");
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];   // per wave: 256 x 16 B = 64 records
     const int lane = threadIdx.x & 63;
     uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, kept scalar
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const PixelId px = pixel_of_thread(a.px);
+    // SPLIT lanes per pixel: launch thread t works for thread t / SPLIT of the one-lane-per-pixel launch (same pixel, same ray slot)
+    const uint32_t launchThread = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t sub = SPLIT == 1 ? 0u : launchThread & (SPLIT - 1);
+    const PixelId px = SPLIT == 1 ? pixel_of_thread(a.px) : pixel_of_block_thread(a.px, (launchThread / SPLIT) / kBlock, (launchThread / SPLIT) % kBlock);
     const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     bool surface = false;
@@ -206,13 +230,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
         const Camera cam = load_camera(a.f.camera);
         make_shading_point(a, bufIdx, p, cam.pos, false, sp);
         rng.state = rngBuf[p];
+        if (SPLIT > 1 && sub > 0) {                       // 4 draws per candidate: this lane's first candidate is `sub`
+            constexpr LcgJump j1 = lcg_jump(4), j2 = lcg_jump(8), j3 = lcg_jump(12);
+            rng.state = rng.state * (sub == 1 ? j1.mul : sub == 2 ? j2.mul : j3.mul) + (sub == 1 ? j1.add : sub == 2 ? j2.add : j3.add);
+        }
     }
     Reservoir reservoir;
     reservoir.reset();
     float selectedTarget = 0.0f;
+    float sumWeights = 0.0f;             // SPLIT > 1: the pixel's running sum (the same in its lanes between two steps)
+    int lastAccepted = -1;               // SPLIT > 1: the last candidate this lane accepted
     const uint32_t numCandidates = 1u << a.f.log2NumCandidateSamples;
     GFX_CYC_BEGIN
-    for (uint32_t i = 0; i < numCandidates; ++i) {
+    for (uint32_t i = sub; i < numCandidates; i += SPLIT) {
         GFX_PROF(0);
         GFX_CYC(0);   // random numbers, light type, table lookup
         // ---- what this lane's candidate needs from the tables
@@ -220,6 +250,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
         bool sampleEnv = false;
         LightPick pk; pk.rec = 0; pk.instSlot = 0; pk.density = 0.0f; pk.partialProb = 0.0f; pk.ok = false; pk.table = true;
         if (surface) {
+            if (SPLIT > 1 && i >= SPLIT) {                // past the draws of the other lanes' candidates since this lane's last one
+                constexpr LcgJump skip = lcg_jump(4 * (SPLIT - 1));
+                rng.state = rng.state * skip.mul + skip.add;
+            }
             float ul = rng.uniform();
             if (envEnabled) {
                 if (*a.scene.lightInstIntegral > 0.0f) {
@@ -274,11 +308,35 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
             pd *= probCurType;
             const float target = target_weight(cont);
             const float weight = target / pd;
-            if (reservoir.update(ls, weight, rng.uniform())) { GFX_PROF(5); selectedTarget = target; }
+            if (SPLIT == 1) {
+                if (reservoir.update(ls, weight, rng.uniform())) { GFX_PROF(5); selectedTarget = target; }
+            }
+            else {
+                const float u = rng.uniform();
+                // the lanes of a pixel share `surface`, so they are all here: candidate i - sub + j of lane j joins the sum after j - 1's
+                float s = sumWeights + weight;
+#pragma unroll
+                for (int j = 1; j < SPLIT; ++j) {
+                    const float before = SPLIT == 2 ? quad_perm<0xA0>(s) : quad_perm<0x90>(s);   // lane sub - 1 of the pair / quad
+                    if (sub >= static_cast<uint32_t>(j)) s = before + weight;
+                }
+                if (u < weight / s) { GFX_PROF(5); reservoir.sample = ls; selectedTarget = target; lastAccepted = static_cast<int>(i); }
+                sumWeights = SPLIT == 2 ? quad_perm<0xF5>(s) : quad_perm<0xFF>(s);                 // the last lane's sum: after all SPLIT candidates
+            }
         }
     }
+    bool writer = true;                  // SPLIT > 1: the lane that holds the pixel's sample (lane 0 when no candidate was accepted)
+    if (SPLIT > 1) {
+        int last = lastAccepted;
+        last = max(last, quad_perm<0xB1>(last));                                                   // lane ^ 1
+        if (SPLIT == 4) last = max(last, quad_perm<0x4E>(last));                                   // lane ^ 2
+        writer = last < 0 ? sub == 0 : lastAccepted == last;
+        reservoir.sumWeights = sumWeights;
+        reservoir.streamLength = numCandidates;
+        if (surface && sub == SPLIT - 1) rngBuf[p] = rng.state;                                    // the state after the last candidate's fourth draw
+    }
     GFX_CYC(5);       // after the loop
-    if (surface) {
+    if (surface && writer) {
         GFX_PROF(8);
         float recPDF = reservoir.sumWeights / (selectedTarget * reservoir.streamLength);
         if (!is_finite(recPDF)) { recPDF = 0.0f; selectedTarget = 0.0f; }
@@ -287,12 +345,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
             const ShadowRay sr = shadow_ray(sp.pos, reservoir.sample);
             wantRay = true; rayO = sp.pos; rayD = sr.dir; rayTmax = sr.tmax;
         }
-        rngBuf[p] = rng.state;
+        if (SPLIT == 1) rngBuf[p] = rng.state;
         store_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p, reservoir);
         static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes])[p] = make_float2(recPDF, selectedTarget);
     }
-    const uint32_t slot = emit_ray_at_slot(px, wantRay, rayO, rayD, 0.0f, rayTmax, a);
-    if (px.valid) a.pixelRaySlot[p] = slot;
+    if (writer) {
+        const uint32_t slot = emit_ray_at_slot(px, wantRay, rayO, rayD, 0.0f, rayTmax, a);
+        if (px.valid) a.pixelRaySlot[p] = slot;
+    }
     GFX_CYC_END;
 }
 
@@ -835,10 +895,20 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     case GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED:
     case GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED:
         {
-            const uint32_t grid = a.px.launchBlocks;
+            // lanes per pixel (k_initial_candidates SPLIT): one while the launch is several rounds of waves -- the kernel is then bound by
+            // instruction issue and the split only adds to it (full frame + 2 % with two lanes, + 6 % with four; a band of a 4-way split:
+            // no difference) -- four when the whole launch fits the GPU's wave slots about once (a band of an 8-way split: 4 080 waves
+            // on 4 096 slots, - 6 % of the band's frame); "candidate_split" overrides (profiles/r04_experiments.txt 12)
+            const uint32_t numCandidates = 1u << a.f.log2NumCandidateSamples;
+            const uint32_t waves = a.px.launchBlocks * (kBlock / 64), slots = static_cast<uint32_t>(ctx.numCUs) * 4u * GFX_INIT_WAVES;
+            uint32_t split = ctx.tune.candidateSplit > 0 ? static_cast<uint32_t>(ctx.tune.candidateSplit) : waves <= slots + slots / 2 ? 4u : 1u;
+            split = std::min(split, numCandidates);
+            const uint32_t grid = a.px.launchBlocks * split;
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
-            if (a.scene.emitterTexRefs) hipLaunchKernelGGL(k_initial_candidates<true>, dim3(grid), dim3(kBlock), 0, stream, a);
-            else hipLaunchKernelGGL(k_initial_candidates<false>, dim3(grid), dim3(kBlock), 0, stream, a);
+            void (*kernel)(RestirArgs) = a.scene.emitterTexRefs
+                ? (split == 4 ? k_initial_candidates<true, 4> : split == 2 ? k_initial_candidates<true, 2> : k_initial_candidates<true, 1>)
+                : (split == 4 ? k_initial_candidates<false, 4> : split == 2 ? k_initial_candidates<false, 2> : k_initial_candidates<false, 1>);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a);
             GFX_HIP(hipGetLastError());
         }
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p);   // one entry per launch slot (emit_ray_at_slot)

@@ -497,6 +497,10 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
  *   "pt_overlap" 0|1            path tracers (gfx_pt_launch): the NEE any-hit trace of a bounce and the kernel that applies it run on a
  *                               library-owned second stream underneath the extension closest-hit trace of the same bounce -- the two
  *                               read and write disjoint buffers; the bounce kernel waits for both (default 1; GFX_PT_OVERLAP)
+ *   "candidate_split" 0|1|2|4   lanes per pixel in the candidate loop of the initial-RIS passes (GFX_RESTIR_INITIAL_*): the lanes take the
+ *                               pixel's candidates round robin and the reservoir is formed as the sequential loop forms it; 0 (default)
+ *                               = by launch size: 4 when the launch fills the GPU's wave slots at most ~1.5 times (a row band of an
+ *                               8-way split frame), else 1 (GFX_CANDIDATE_SPLIT)
  * The same knobs are read once from the environment by gfx_ctx_create (GFX_PIXEL_MAP, GFX_SUPER_X, GFX_SUPER_Y,
  * GFX_TRACE_BLOCKS_PER_CU, GFX_TRACE_REFILL, GFX_TRACE_BATCH). */
 int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value);

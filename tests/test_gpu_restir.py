@@ -28,12 +28,14 @@ def default_camera(scene_kind, width, height):
 
 def run_sequence_both(hs, width, height, frames=2, renderer=api.RENDERER_BIASED, scene_kind="bunny",
                       low_discrepancy=True, reuse_visibility=True, camera=None, stop_after=None, threads=None,
-                      env=None, env_power=1.0, env_rotation=0.0, animate=None):
+                      env=None, env_power=1.0, env_rotation=0.0, animate=None, tunables=None):
     """Run `frames` frames with the sequencing of restir_di_main.cpp:2311-2493 on the GPU (through
     the C ABI) and in the oracle, comparing all buffers after every pass.  Returns a list of
     mismatch descriptions (empty = bit-identical)."""
     import torch
     ctx = api.Context(0)
+    for name, value in (tunables or {}).items():
+        ctx.tunable_set(name, value)
     hs.upload(ctx)
     accel = ctx.accel_build()
     ctx.lights_build_static()
@@ -123,6 +125,20 @@ def test_bunny_sequence_bit_exact(built_lib, renderer):
     surf = run_sequence_both.last_gb0["instSlot"] != 0xFFFFFFFF
     assert surf.mean() > 0.3
     assert np.isfinite(beauty).all() and beauty[surf, :3].mean() > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [1, 2, 4])
+def test_lanes_per_pixel_of_the_candidate_pass_change_nothing(built_lib, split):
+    """k_initial_candidates with 1, 2 or 4 lanes per pixel (the library picks by launch size; "candidate_split" forces it): same
+    reservoirs, same RNG streams, same rays -- street scene (many emitters, textured ones among them), two frames."""
+    diffs = run_sequence_both(util.small_street(), 192, 108, frames=2, renderer=api.RENDERER_BIASED, scene_kind="street",
+                              tunables={"candidate_split": split})
+    assert not diffs, "\n".join(diffs)
+    ctx = api.Context(0)
+    with pytest.raises(api.GfxError, match="candidate_split"):
+        ctx.tunable_set("candidate_split", 3)
+    ctx.close()
 
 
 @pytest.mark.gpu

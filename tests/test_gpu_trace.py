@@ -237,3 +237,26 @@ def test_cluttered_street_and_per_ray_item_counts(built_lib):
     assert items.max() > 4 * np.median(items)          # the tail the band split runs into (profiles/r02_band_notes.txt)
     with pytest.raises(api.GfxError):
         ctx.trace(accel, api.TRACE_CLOSEST, d_org.data_ptr(), d_dir.data_ptr(), n, d_out.data_ptr(), 0, d_per_ray_items=d_items.data_ptr())
+
+
+@pytest.mark.parametrize("num_bytes", [16, 16 * 255, 16 * 1024 * 4 + 16 * 3, (1 << 24) + 16 * 77])
+def test_stream_copy_moves_every_byte(built_lib, num_bytes):
+    """gfx_stream_copy (the measurement utility behind roofline.peak_measured) is a copy: every 16-byte word arrives, nothing
+    outside the range is written; the read-only form writes nothing; sizes that are not multiples of 16 are refused."""
+    import torch
+    ctx = api.Context(0)
+    rng = np.random.default_rng(num_bytes)
+    src = torch.from_numpy(rng.integers(0, 256, num_bytes + 64, dtype=np.uint8)).cuda()
+    dst = torch.full((num_bytes + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.stream_copy(dst.data_ptr() + 32, src.data_ptr() + 16, num_bytes, stream=s)
+    ctx.stream_copy(0, src.data_ptr(), num_bytes, stream=s)          # read-only pass
+    torch.cuda.synchronize()
+    got, want = dst.cpu().numpy(), src.cpu().numpy()
+    assert np.array_equal(got[32:32 + num_bytes], want[16:16 + num_bytes])
+    assert np.all(got[:32] == 0xA5) and np.all(got[32 + num_bytes:] == 0xA5)
+    with pytest.raises(api.GfxError, match="multiples of 16"):
+        ctx.stream_copy(dst.data_ptr(), src.data_ptr(), num_bytes - 8, stream=s)
+    with pytest.raises(api.GfxError, match="multiples of 16"):
+        ctx.stream_copy(dst.data_ptr() + 4, src.data_ptr(), 16, stream=s)
+    ctx.close()
