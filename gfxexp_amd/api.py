@@ -15,6 +15,7 @@ GFX_INVALID_SLOT = 0xFFFFFFFF
 TRACE_CLOSEST, TRACE_ANY = 0, 1
 (PASS_SETUP_GBUFFERS, PASS_INITIAL_RIS, PASS_INITIAL_TEMPORAL_BIASED, PASS_INITIAL_TEMPORAL_UNBIASED,
  PASS_SPATIAL_BIASED, PASS_SPATIAL_UNBIASED, PASS_SHADING) = range(7)
+PASS_SPATIAL_BIASED_AND_SHADING = 20
 # rearchitected ReSTIR: trace-shadow-rays / shade-and-resample entry points in the order of
 # RearchitectedReSTIREntryPoint (restir_di_main.cpp:83-95)
 PASS_LIGHT_PRESAMPLING, PASS_PER_PIXEL_RIS, PASS_TRACE_SHADOW_RAYS = 7, 8, 9
@@ -681,7 +682,7 @@ class Context:
 
     def tunable_set(self, name, value):
         """Scheduling knob of this context ("pixel_map", "super_x", "super_y", "trace_blocks_per_cu", "trace_refill",
-        "trace_batch", "temporal_hints", "pt_overlap", "candidate_split"); changes no result."""
+        "trace_batch", "temporal_hints", "pt_overlap", "candidate_split", "fuse_passes"); changes no result."""
         self._check(self.L.gfx_tunable_set(self.h, name.encode(), C.c_int(int(value))))
 
     def stream_copy(self, d_dst, d_src, nbytes, stream=0):

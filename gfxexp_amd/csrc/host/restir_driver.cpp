@@ -512,6 +512,7 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
             entry = useUnbiasedEstimator ? GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED : GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED;
         push(GFXH_STEP_RESTIR_PASS, entry, plan.initialRows[0], whole ? 0 : plan.initialRows[1]);
         push(GFXH_STEP_PREV_GBUFFER_RELEASED, 0, 0, 0);   // only the temporal pass reads the previous frame's G-buffer
+        bool shadingIssued = false;
         if (cfg.enableSpatialReuse) {                                                          // :2393-2411
             const uint32_t spatial = useUnbiasedEstimator ? GFX_RESTIR_SPATIAL_UNBIASED : GFX_RESTIR_SPATIAL_BIASED;
             const uint32_t base0 = baseIndex;
@@ -519,12 +520,17 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
                 // strip mode: the reservoirs this pass resamples from, radius rows either side of the band
                 exchange(radiusRows, GFXH_BUF_RESERVOIRS, currentReservoirIndex);
                 baseIndex = base0 + cfg.numSpatialNeighbors * i;
-                push(GFXH_STEP_RESTIR_PASS, spatial, plan.spatialRows[i][0], whole ? 0 : plan.spatialRows[i][1]);
+                // the last biased pass and the shading pass (:2418-2420) as one step where they cover the same rows (not the halo
+                // scheme, whose spatial passes run over the halo too): one kernel for a band-sized launch (include/gfxexp.h)
+                const bool last = i + 1 == cfg.numSpatialReusePasses;
+                shadingIssued = last && !useUnbiasedEstimator && plan.spatialRows[i][0] == plan.shadingRows[0] && plan.spatialRows[i][1] == plan.shadingRows[1];
+                push(GFXH_STEP_RESTIR_PASS, shadingIssued ? static_cast<uint32_t>(GFX_RESTIR_SPATIAL_BIASED_AND_SHADING) : spatial,
+                     plan.spatialRows[i][0], whole ? 0 : plan.spatialRows[i][1]);
                 currentReservoirIndex = (currentReservoirIndex + 1) % 2;
             }
             baseIndex = base0 + cfg.numSpatialNeighbors * cfg.numSpatialReusePasses;
         }
-        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SHADING, plan.shadingRows[0], whole ? 0 : plan.shadingRows[1]);   // :2418-2420
+        if (!shadingIssued) push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SHADING, plan.shadingRows[0], whole ? 0 : plan.shadingRows[1]);   // :2418-2420
         // strip mode: the final reservoirs the next frame's temporal pass reads across the seams
         if (cfg.enableTemporalReuse) exchange(motion, GFXH_BUF_RESERVOIRS, currentReservoirIndex);
         gather();

@@ -95,6 +95,7 @@ struct Tunables {
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
     int temporalHints = 1;           // primary rays test the triangle their pixel hit one frame ago first (trace.hip)
     int candidateSplit = 0;          // k_initial_candidates: lanes per pixel (1, 2, 4); 0 = by launch size (restir.hip)
+    int fusePasses = 0;              // ReSTIR ray passes as one kernel each (restir.hip k_*_fused): 0 = small launches only, 1 never, 2 always
     int ptOverlap = 1;               // path tracers: the NEE (any-hit) trace + its apply kernel of a bounce run on a second stream underneath
                                      // the extension (closest-hit) trace of the same bounce (pathtrace.hip)
 };

@@ -12,25 +12,27 @@
 //   SPATIAL_BIASED                  k_spatial<false>
 //   SPATIAL_UNBIASED                k_spatial<true> (select + emit MIS rays) -> trace any -> k_spatial_mis_finish
 //   SHADING                         k_shade_prepare -> trace any -> k_shade_finish
+//   SPATIAL_BIASED_AND_SHADING      the two above, back to back
+// (a small launch runs each of the ray passes as one kernel: k_gbuffer_fused / k_initial_fused / k_shading_fused below)
 #include "internal.h"
 #include "shading.hip.h"
 #include "pass_common.hip.h"
 #include "restir_common.hip.h"
 #include "coop_fetch.hip.h"
+#include "trace_local.hip.h"
 #include "restir_rearch.hip.h"
 
 namespace gfx {
 
 // ---------------------------------------------------------------- SETUP_GBUFFERS
 // ray generation of optix_gbuffer_kernels.cu:5-27
-__global__ __launch_bounds__(kBlock) void k_primary_rays(RestirArgs a) {
-    const PixelId px = pixel_of_thread(a.px);
-    if (!px.valid) {
-        // the queue of this pass is indexed by launch slot: slots without a pixel hold an empty-interval ray (an immediate miss)
-        a.rayOrg[px.slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        a.rayDir[px.slot] = make_float4(0.0f, 0.0f, 1.0f, -1.0f);
-        return;
-    }
+// (org.xyz | tmin, dir.xyz | tmax) of the pixel's primary ray; a launch slot without a pixel holds an empty-interval ray (an immediate miss)
+struct RayPair { float4 org, dir; };
+GFX_DEV RayPair primary_ray(const RestirArgs& a, const PixelId& px) {
+    RayPair r;
+    r.org = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    r.dir = make_float4(0.0f, 0.0f, 1.0f, -1.0f);
+    if (!px.valid) return r;
     const size_t p = px.p;
     const int x = px.x, y = px.y;
     const Camera cam = load_camera(a.f.camera);
@@ -47,8 +49,15 @@ __global__ __launch_bounds__(kBlock) void k_primary_rays(RestirArgs a) {
     const float vh = 2 * gm_tan(cam.fovY * 0.5f);
     const float vw = cam.aspect * vh;
     const f3 dir = unit(mul(cam.ori, f3(vw * (0.5f - fx), vh * (0.5f - fy), 1)));
-    a.rayOrg[px.slot] = make_float4(cam.pos.x, cam.pos.y, cam.pos.z, 0.0f);
-    a.rayDir[px.slot] = make_float4(dir.x, dir.y, dir.z, 3.402823466e+38f);
+    r.org = make_float4(cam.pos.x, cam.pos.y, cam.pos.z, 0.0f);
+    r.dir = make_float4(dir.x, dir.y, dir.z, 3.402823466e+38f);
+    return r;
+}
+__global__ __launch_bounds__(kBlock) void k_primary_rays(RestirArgs a) {
+    const PixelId px = pixel_of_thread(a.px);
+    const RayPair r = primary_ray(a, px);          // the queue of this pass is indexed by launch slot
+    a.rayOrg[px.slot] = r.org;
+    a.rayDir[px.slot] = r.dir;
 }
 
 // PerspectiveCamera::calcScreenPosition, restir_di_shared.h:51-59
@@ -63,15 +72,10 @@ GFX_DEV void calc_screen_position(const Camera& cam, f3 pw, float& sx, float& sy
 }
 
 // closest-hit / miss programs + the tail of the ray-generation program (optix_gbuffer_kernels.cu:56-243)
-__global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
-    const PixelId px = pixel_of_thread(a.px);
-    if (!px.valid) return;
+GFX_DEV void gbuffer_resolve(const RestirArgs& a, const PixelId& px, const gfx_hit& h, f3 direction) {
     const size_t p = px.p;
     const int x = px.x, y = px.y;
     const uint32_t bufIdx = a.f.bufferIndex;
-    const gfx_hit h = a.hits[px.slot];
-    const float4 rd = a.rayDir[px.slot];
-    const f3 direction(rd.x, rd.y, rd.z);
 
     f3 albedo(0.0f);
     const float qnan = bits2f(0x7FC00000u);
@@ -170,6 +174,12 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
     *albedoAcc = make_float4(albedoResult.x, albedoResult.y, albedoResult.z, 1.0f);
     *normalAcc = make_float4(normalResult.x, normalResult.y, normalResult.z, 1.0f);
 }
+__global__ __launch_bounds__(kBlock) void k_gbuffer_resolve(RestirArgs a) {
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const float4 rd = a.rayDir[px.slot];
+    gbuffer_resolve(a, px, a.hits[px.slot], f3(rd.x, rd.y, rd.z));
+}
 
 // ---------------------------------------------------------------- INITIAL (+ TEMPORAL)
 // candidate loop + visibility-ray emission: optix_restir_di_kernels.cu:57-133
@@ -202,17 +212,22 @@ template <int CTRL> GFX_DEV float quad_perm(float v) {      // v of the lane qua
     return bits2f(static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(f2bits(v)), CTRL, 0xF, 0xF, false)));
 }
 template <int CTRL> GFX_DEV int quad_perm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
-template <bool EMITTER_TEX, int SPLIT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a) {
-    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "a pixel's lanes are an aligned pair or quad");
-    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];   // per wave: 256 x 16 B = 64 records
-    const int lane = threadIdx.x & 63;
-    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, kept scalar
-    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    // SPLIT lanes per pixel: launch thread t works for thread t / SPLIT of the one-lane-per-pixel launch (same pixel, same ray slot)
+// The pixel of launch thread t when SPLIT lanes share a pixel: thread t / SPLIT of the one-lane-per-pixel launch (same pixel, same ray slot).
+template <int SPLIT>
+GFX_DEV PixelId pixel_of_split_thread(const PixelGrid& g, uint32_t& sub) {
+    if (SPLIT == 1) { sub = 0u; return pixel_of_thread(g); }
     const uint32_t launchThread = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t sub = SPLIT == 1 ? 0u : launchThread & (SPLIT - 1);
-    const PixelId px = SPLIT == 1 ? pixel_of_thread(a.px) : pixel_of_block_thread(a.px, (launchThread / SPLIT) / kBlock, (launchThread / SPLIT) % kBlock);
+    sub = launchThread & (SPLIT - 1);
+    return pixel_of_block_thread(g, (launchThread / SPLIT) / kBlock, (launchThread / SPLIT) % kBlock);
+}
+// What the candidate loop leaves in registers: the visibility ray of the selected candidate (want: there is one), held by the lane
+// that wrote the pixel's reservoir (writer; with one lane per pixel every lane is one).
+struct CandidateRay { bool writer, want; f3 org, dir; float tmax; };
+// waveBuf: 256 x 16 B of LDS private to the wave (64 emitter records).  EVERY lane of the wave must call.
+template <bool EMITTER_TEX, int SPLIT>
+GFX_DEV CandidateRay initial_candidates(const RestirArgs& a, uint4* waveBuf, int lane, const PixelId& px, uint32_t sub) {
+    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "a pixel's lanes are an aligned pair or quad");
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     bool surface = false;
@@ -349,19 +364,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
         store_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p, reservoir);
         static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes])[p] = make_float2(recPDF, selectedTarget);
     }
-    if (writer) {
-        const uint32_t slot = emit_ray_at_slot(px, wantRay, rayO, rayD, 0.0f, rayTmax, a);
-        if (px.valid) a.pixelRaySlot[p] = slot;
-    }
     GFX_CYC_END;
+    CandidateRay r;
+    r.writer = writer; r.want = wantRay; r.org = rayO; r.dir = rayD; r.tmax = rayTmax;
+    return r;
+}
+template <bool EMITTER_TEX, int SPLIT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a) {
+    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];   // per wave: 256 x 16 B = 64 records
+    const int lane = threadIdx.x & 63;
+    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, kept scalar
+    uint32_t sub;
+    const PixelId px = pixel_of_split_thread<SPLIT>(a.px, sub);
+    const CandidateRay r = initial_candidates<EMITTER_TEX, SPLIT>(a, waveBuf, lane, px, sub);
+    if (r.writer) {
+        const uint32_t slot = emit_ray_at_slot(px, r.want, r.org, r.dir, 0.0f, r.tmax, a);
+        if (px.valid) a.pixelRaySlot[px.p] = slot;
+    }
 }
 
 // visibility application + temporal reuse: optix_restir_di_kernels.cu:128-286
 // MODE 0: performInitialRIS, 1: ...TemporalRISBiased, 2: ...TemporalRISUnbiased
+// `occluded`: the visibility ray of the pixel's selected candidate found an occluder (false when the pixel had no ray)
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_temporal(RestirArgs a) {
+GFX_DEV void temporal_reuse(const RestirArgs& a, const PixelId& px, bool occluded) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const PixelId px = pixel_of_thread(a.px);
     if (!px.valid) return;
     const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
@@ -371,8 +398,7 @@ __global__ __launch_bounds__(kBlock) void k_temporal(RestirArgs a) {
     float2* infoBuf = static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes]);
     float2 info = infoBuf[p];
     float recPDF = info.x, selectedTarget = info.y;
-    const uint32_t slot = a.pixelRaySlot[p];
-    if (slot != GFX_INVALID_SLOT && a.occluded[slot]) { recPDF = 0.0f; selectedTarget = 0.0f; }
+    if (occluded) { recPDF = 0.0f; selectedTarget = 0.0f; }
     if (MODE == 0) {
         infoBuf[p] = make_float2(recPDF, selectedTarget);
         return;
@@ -445,6 +471,13 @@ __global__ __launch_bounds__(kBlock) void k_temporal(RestirArgs a) {
     store_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p, reservoir);
     infoBuf[p] = make_float2(recPDF, selectedTarget);
 }
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_temporal(RestirArgs a) {
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const uint32_t slot = a.pixelRaySlot[px.p];
+    temporal_reuse<MODE>(a, px, slot != GFX_INVALID_SLOT && a.occluded[slot] != 0u);
+}
 
 // ---------------------------------------------------------------- SPATIAL
 GFX_DEV void spatial_neighbor(const RestirArgs& a, Pcg32& rng, uint32_t nIdx, int x, int y, int& nbx, int& nby) {
@@ -468,10 +501,10 @@ GFX_DEV void spatial_neighbor(const RestirArgs& a, Pcg32& rng, uint32_t nIdx, in
 }
 
 // optix_restir_di_kernels.cu:303-547.  UNBIASED: combines, then emits the MIS-denominator rays.
+// EVERY thread of the block must call the UNBIASED form (its ray queue reservation is a block-wide operation).
 template <bool UNBIASED>
-__global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
+GFX_DEV void spatial_reuse(const RestirArgs& a, const PixelId& px) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const PixelId px = pixel_of_thread(a.px);
     const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     const uint32_t numNb = a.f.numSpatialNeighbors;
@@ -615,6 +648,8 @@ __global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) {
     // stash (selectedNeighborIndex, selectedTarget) for the finishing kernel
     static_cast<float2*>(a.s.reservoirInfoBuffer[dstRes])[p] = make_float2(bits2f(static_cast<uint32_t>(selectedNeighborIndex)), selectedTarget);
 }
+template <bool UNBIASED>
+__global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) { spatial_reuse<UNBIASED>(a, pixel_of_thread(a.px)); }
 
 // MIS weights of the unbiased spatial pass once the rays are back: optix_restir_di_kernels.cu:413-546
 __global__ __launch_bounds__(kBlock) void k_spatial_mis_finish(RestirArgs a) {
@@ -664,9 +699,11 @@ __global__ __launch_bounds__(kBlock) void k_spatial_mis_finish(RestirArgs a) {
 
 // ---------------------------------------------------------------- SHADING
 // optix_restir_di_kernels.cu:559-629 up to the final shadow ray
-__global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
+// What the first half of the shading pass leaves for the second: the emitted / environment term, the unshadowed direct term with its
+// reciprocal PDF estimate, and the final shadow ray (want: there is one).
+struct ShadeState { bool want; f3 ro, rd; float tmax; f3 contribution, direct; float recPDF; };
+GFX_DEV ShadeState shade_prepare(const RestirArgs& a, const PixelId& px, uint32_t curRes) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const PixelId px = pixel_of_thread(a.px);
     const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     bool want = false;
@@ -682,8 +719,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
             ShadingPoint sp;
             make_shading_point(a, bufIdx, p, cam.pos, true, sp);
             const gfx_material& mat = a.scene.materials[g3.w];
-            const Reservoir reservoir = load_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p);
-            recPDF = static_cast<const float2*>(a.s.reservoirInfoBuffer[a.curRes])[p].x;
+            const Reservoir reservoir = load_reservoir(a.s.reservoirBuffer[curRes], numPixels, p);
+            recPDF = static_cast<const float2*>(a.s.reservoirInfoBuffer[curRes])[p].x;
             contribution = f3(0.0f);
             if (sp.vOutLocal.z > 0) {
                 float tu, tv;
@@ -712,26 +749,28 @@ __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
             }
         }
     }
-    const uint32_t slot = emit_ray_at_slot(px, want, ro, rd, 0.0f, tmax, a);
+    ShadeState st;
+    st.want = want; st.ro = ro; st.rd = rd; st.tmax = tmax; st.contribution = contribution; st.direct = direct; st.recPDF = recPDF;
+    return st;
+}
+__global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
+    const PixelId px = pixel_of_thread(a.px);
+    const ShadeState st = shade_prepare(a, px, a.curRes);
+    const uint32_t slot = emit_ray_at_slot(px, st.want, st.ro, st.rd, 0.0f, st.tmax, a);
     if (px.valid) {
-        a.shadeScratch[2 * p] = make_float4(contribution.x, contribution.y, contribution.z, bits2f(slot));
-        a.shadeScratch[2 * p + 1] = make_float4(direct.x, direct.y, direct.z, recPDF);
+        a.shadeScratch[2 * px.p] = make_float4(st.contribution.x, st.contribution.y, st.contribution.z, bits2f(slot));
+        a.shadeScratch[2 * px.p + 1] = make_float4(st.direct.x, st.direct.y, st.direct.z, st.recPDF);
     }
 }
 
-// contribution += recPDFEstimate * directCont; running mean (optix_restir_di_kernels.cu:619-636)
-__global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
-    const PixelId px = pixel_of_thread(a.px);
-    if (!px.valid) return;
+// contribution += recPDFEstimate * directCont; running mean (optix_restir_di_kernels.cu:619-636).  `occluded`: the final shadow ray
+// found an occluder (false when the pixel had no ray).
+GFX_DEV void shade_finish(const RestirArgs& a, const PixelId& px, f3 contribution, f3 direct, float recPDF, bool occluded) {
     const size_t p = px.p;
-    const float4 c0 = a.shadeScratch[2 * p], c1 = a.shadeScratch[2 * p + 1];
-    f3 contribution(c0.x, c0.y, c0.z);
     const uint32_t bufIdx = a.f.bufferIndex;
     if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu) {
-        f3 direct(c1.x, c1.y, c1.z);
-        const uint32_t slot = f2bits(c0.w);
-        if (slot != GFX_INVALID_SLOT && a.occluded[slot]) direct = f3(0.0f);
-        contribution = contribution + c1.w * direct;
+        if (occluded) direct = f3(0.0f);
+        contribution = contribution + recPDF * direct;
     }
     float4* beauty = static_cast<float4*>(a.s.beautyAccumBuffer) + p;
     f3 prev(0.0f);
@@ -739,6 +778,88 @@ __global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
     const float curWeight = 1.0f / (1 + a.f.numAccumFrames);
     const f3 result = (1 - curWeight) * prev + curWeight * contribution;
     *beauty = make_float4(result.x, result.y, result.z, 1.0f);
+}
+__global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
+    const PixelId px = pixel_of_thread(a.px);
+    if (!px.valid) return;
+    const float4 c0 = a.shadeScratch[2 * px.p], c1 = a.shadeScratch[2 * px.p + 1];
+    const uint32_t slot = f2bits(c0.w);
+    shade_finish(a, px, f3(c0.x, c0.y, c0.z), f3(c1.x, c1.y, c1.z), c1.w, slot != GFX_INVALID_SLOT && a.occluded[slot] != 0u);
+}
+
+// ---------------------------------------------------------------- the three ray passes as ONE kernel each, for small launches
+// trace_local.hip.h: the kernel that makes a ray traces it and consumes the result -- a frame of a row band is 5 launches instead
+// of 11 and none of them waits for the slowest wave of a traversal before the next short kernel may start.  Same buffers out as the
+// three-kernel form (the ray queue, the per-pixel ray slots, the occlusion words and the shading scratch are skipped: they were
+// only the kernels' way of talking to each other).  `spill`: kSpillStackDepth entries per tracing thread of the launch.
+__global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel accel, gfx_hit* hits, uint2* spill, int useHint) {
+    __shared__ uint2 ldsStack[kLdsStackDepth * kBlock];
+    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);
+    const PixelId px = pixel_of_thread(a.px);
+    const RayPair r = primary_ray(a, px);
+    // the triangle this pixel's primary ray hit one frame ago is tested right after the root (trace.hip: temporal hint)
+    const uint32_t hint = useHint ? hits[px.slot].triIndex : 0xFFFFFFFFu;
+    const RayHit h = trace_wave_local<false>(accel, true, f3(r.org.x, r.org.y, r.org.z), f3(r.dir.x, r.dir.y, r.dir.z), r.org.w, r.dir.w, ldsStack + tid, kBlock,
+                                             spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * kSpillStackDepth, waveBuf, lane, hint);
+    gfx_hit gh; gh.dist = h.t; gh.bcB = h.bcB; gh.bcC = h.bcC; gh.triIndex = h.tri;
+    hits[px.slot] = gh;                          // the next frame's hint
+    if (px.valid) gbuffer_resolve(a, px, gh, f3(r.dir.x, r.dir.y, r.dir.z));
+}
+
+// SPLIT = 4 lanes per pixel in the candidate loop: the 64 rays of a block are handed to its first wave through LDS, the other three
+// waves leave (their slots go to the next block), the first one traces and runs the temporal pass of those 64 pixels.  The hand-over
+// and the traversal stack live in the record buffers of the waves that have left, so a block holds 16 KB of LDS, not 24: ten blocks
+// fit a CU, and the one-wave tails of the blocks that trace do not keep new blocks out.
+template <bool EMITTER_TEX, int SPLIT, int MODE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_fused(RestirArgs a, DevAccel accel, uint2* spill) {
+    static_assert(SPLIT == 1 || SPLIT == 4, "one lane per pixel, or four with the block's rays gathered in its first wave");
+    constexpr int kRays = kBlock / SPLIT;
+    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];           // per wave: 256 x 16 B = 64 records
+    __shared__ uint2 ownStack[SPLIT == 1 ? kLdsStackDepth * kBlock : 1];
+    static_assert(SPLIT == 1 || kLdsStackDepth * kRays * sizeof(uint2) <= 2 * 256 * sizeof(uint4), "the stack of 64 rays fits the buffers of waves 1 and 2");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint4* waveBuf = fetchBuf + 256 * wave;
+    uint32_t sub;
+    PixelId px = pixel_of_split_thread<SPLIT>(a.px, sub);
+    const CandidateRay r = initial_candidates<EMITTER_TEX, SPLIT>(a, waveBuf, lane, px, sub);
+    float4 org = make_float4(r.org.x, r.org.y, r.org.z, 0.0f), dir = make_float4(r.dir.x, r.dir.y, r.dir.z, r.want ? r.tmax : -1.0f);
+    uint2* stack = ownStack + tid;
+    if (SPLIT > 1) {
+        // ray k of the block (pixel k of its 64) comes from lanes 4 k .. 4 k + 3 = wave k / 16: it waits in the last 512 bytes of that
+        // wave's own buffer, which the wave is done with
+        float4* handOver = reinterpret_cast<float4*>(fetchBuf + 256 * (tid >> 6) + 224);
+        if (r.writer) { handOver[2 * ((tid & 63) / SPLIT)] = org; handOver[2 * ((tid & 63) / SPLIT) + 1] = dir; }
+        __syncthreads();                           // also: the reservoirs the writer lanes stored are visible to the block
+        if (tid >= kRays) return;
+        const float4* from = reinterpret_cast<const float4*>(fetchBuf + 256 * (tid >> 4) + 224);
+        org = from[2 * (tid & 15)]; dir = from[2 * (tid & 15) + 1];
+        const uint32_t t = blockIdx.x * kRays + tid;   // thread of the one-lane-per-pixel launch
+        px = pixel_of_block_thread(a.px, t / kBlock, t % kBlock);
+        stack = reinterpret_cast<uint2*>(fetchBuf + 256) + tid;   // buffers of waves 1 and 2 (their hand-over slots have just been read)
+    }
+    const bool want = dir.w > org.w;
+    const RayHit h = trace_wave_local<true>(accel, want, f3(org.x, org.y, org.z), f3(dir.x, dir.y, dir.z), org.w, dir.w, stack, kRays,
+                                            spill + (static_cast<size_t>(blockIdx.x) * kRays + tid) * kSpillStackDepth, waveBuf, lane);
+    temporal_reuse<MODE>(a, px, want && h.tri != GFX_INVALID_SLOT);
+}
+
+// SPATIAL_FIRST: GFX_RESTIR_SPATIAL_BIASED_AND_SHADING -- the pixel's last spatial pass (it reads neighbours in reservoir a.curRes and
+// writes the pixel's own entry of the other one), then the shading of that entry by the same thread.
+template <bool SPATIAL_FIRST>
+__global__ __launch_bounds__(kBlock) void k_shading_fused(RestirArgs a, DevAccel accel, uint2* spill) {
+    __shared__ uint2 ldsStack[kLdsStackDepth * kBlock];
+    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);
+    const PixelId px = pixel_of_thread(a.px);
+    if (SPATIAL_FIRST) spatial_reuse<false>(a, px);
+    const ShadeState st = shade_prepare(a, px, SPATIAL_FIRST ? (a.curRes + 1) % 2 : a.curRes);
+    const RayHit h = trace_wave_local<true>(accel, st.want, st.ro, st.rd, 0.0f, st.tmax, ldsStack + tid, kBlock,
+                                            spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * kSpillStackDepth, waveBuf, lane);
+    if (px.valid) shade_finish(a, px, st.contribution, st.direct, st.recPDF, st.want && h.tri != GFX_INVALID_SLOT);
 }
 
 #ifdef GFX_LANE_PROFILE   // experiment builds only (gm_math.hip.h GFX_PROF, tools/lane_profile.py)
@@ -865,10 +986,20 @@ void restir_visualize(Context& ctx, hipStream_t stream, const void* linearBuffer
 }
 
 void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {
-    const bool rearch = pass >= GFX_RESTIR_LIGHT_PRESAMPLING;
+    const bool rearch = pass >= GFX_RESTIR_LIGHT_PRESAMPLING && pass <= GFX_RESTIR_SHADE_AND_RESAMPLE_SPATIOTEMPORAL;
     RestirArgs a = make_args(ctx, width, height, rowBegin, rowEnd, rearch);
     if (rowEnd == rowBegin) return;
     auto reset_queue = [&]() { GFX_HIP(hipMemsetAsync(a.rayCount, 0, sizeof(uint32_t), stream)); };
+    // A launch of up to about half a full-HD frame (a row band of a multi-GPU frame) runs each of the three ray passes as ONE kernel
+    // (k_*_fused above); a larger one keeps the persistent k_trace with its refill between two per-pixel kernels (band of 8 / 4 / 2 /
+    // whole frame, same box: 0.709 -> 0.653, 1.070 -> 0.974, 1.709 -> 1.647, 3.156 -> 3.199 ms per frame; profiles/r04_experiments.txt 14).
+    // "fuse_passes": 0 by launch size, 1 never, 2 always.  Counting launches (gfx_counters_enable) always take the three-kernel form:
+    // the counters live in k_trace.
+    const uint32_t launchWaves = a.px.launchBlocks * (kBlock / 64), waveSlots = static_cast<uint32_t>(ctx.numCUs) * 4u * GFX_INIT_WAVES;
+    const bool smallLaunch = launchWaves <= waveSlots + waveSlots / 2;           // about one round of waves: the candidate loop is split over four lanes
+    const bool fusableLaunch = 2u * launchWaves <= 9u * waveSlots;
+    const size_t fusedSpillBytes = sizeof(uint2) * static_cast<size_t>(a.px.launchBlocks) * kBlock * kSpillStackDepth;
+    const bool fused = !ctx.countersEnabled && fusedSpillBytes <= (size_t(1) << 30) && (ctx.tune.fusePasses == 2 || (ctx.tune.fusePasses == 0 && fusableLaunch));
     switch (pass) {
     case GFX_RESTIR_SETUP_GBUFFERS: {
         // own scratch set (internal.h): this pass may overlap other passes of the previous frame.  One queue entry per
@@ -879,6 +1010,14 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         ctx.gbRayHits.reserve(sizeof(gfx_hit) * frameSlots);
         a.rayOrg = ctx.gbRayOrg.as<float4>(); a.rayDir = ctx.gbRayDir.as<float4>();
         a.hits = ctx.gbRayHits.as<gfx_hit>();
+        if (fused) {
+            ctx.gbSpill.reserve(fusedSpillBytes);
+            ScopedKernelTimer timer(ctx, stream, "gbuffer_fused");
+            hipLaunchKernelGGL(k_gbuffer_fused, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a, ctx.accels[ctx.restir.f.travHandle - 1]->dev(),
+                               ctx.gbRayHits.as<gfx_hit>(), ctx.gbSpill.as<uint2>(), ctx.tune.temporalHints ? 1 : 0);
+            GFX_HIP(hipGetLastError());
+            break;
+        }
         launch_pixels(ctx, stream, "primary_rays", k_primary_rays, a);
         TraceLaunch t;
         t.accel = ctx.accels[ctx.restir.f.travHandle - 1]->dev();
@@ -900,10 +1039,25 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
             // no difference) -- four when the whole launch fits the GPU's wave slots about once (a band of an 8-way split: 4 080 waves
             // on 4 096 slots, - 6 % of the band's frame); "candidate_split" overrides (profiles/r04_experiments.txt 12)
             const uint32_t numCandidates = 1u << a.f.log2NumCandidateSamples;
-            const uint32_t waves = a.px.launchBlocks * (kBlock / 64), slots = static_cast<uint32_t>(ctx.numCUs) * 4u * GFX_INIT_WAVES;
-            uint32_t split = ctx.tune.candidateSplit > 0 ? static_cast<uint32_t>(ctx.tune.candidateSplit) : waves <= slots + slots / 2 ? 4u : 1u;
+            uint32_t split = ctx.tune.candidateSplit > 0 ? static_cast<uint32_t>(ctx.tune.candidateSplit) : smallLaunch ? 4u : 1u;
             split = std::min(split, numCandidates);
+            if (fused && split == 2) split = 1;      // the fused form exists for one and four lanes per pixel
             const uint32_t grid = a.px.launchBlocks * split;
+            if (fused) {
+                ctx.spill.reserve(fusedSpillBytes);
+                const DevAccel accel = ctx.accels[ctx.restir.f.travHandle - 1]->dev();
+                const int mode = pass == GFX_RESTIR_INITIAL_RIS ? 0 : pass == GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED ? 1 : 2;
+                const bool tex = a.scene.emitterTexRefs != nullptr;
+                void (*kernel)(RestirArgs, DevAccel, uint2*) = nullptr;
+#define GFX_PICK(TEX, SPLIT) (mode == 0 ? k_initial_fused<TEX, SPLIT, 0> : mode == 1 ? k_initial_fused<TEX, SPLIT, 1> : k_initial_fused<TEX, SPLIT, 2>)
+                if (tex) kernel = split == 4 ? GFX_PICK(true, 4) : GFX_PICK(true, 1);
+                else kernel = split == 4 ? GFX_PICK(false, 4) : GFX_PICK(false, 1);
+#undef GFX_PICK
+                ScopedKernelTimer timer(ctx, stream, "initial_fused");
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a, accel, ctx.spill.as<uint2>());
+                GFX_HIP(hipGetLastError());
+                break;
+            }
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
             void (*kernel)(RestirArgs) = a.scene.emitterTexRefs
                 ? (split == 4 ? k_initial_candidates<true, 4> : split == 2 ? k_initial_candidates<true, 2> : k_initial_candidates<true, 1>)
@@ -925,7 +1079,21 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);
         launch_pixels(ctx, stream, "spatial_unbiased_finish", k_spatial_mis_finish, a);
         break;
+    case GFX_RESTIR_SPATIAL_BIASED_AND_SHADING:
     case GFX_RESTIR_SHADING:
+        if (fused) {
+            ctx.spill.reserve(fusedSpillBytes);
+            const bool both = pass == GFX_RESTIR_SPATIAL_BIASED_AND_SHADING;
+            ScopedKernelTimer timer(ctx, stream, both ? "spatial_shading_fused" : "shading_fused");
+            hipLaunchKernelGGL(both ? k_shading_fused<true> : k_shading_fused<false>, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a,
+                               ctx.accels[ctx.restir.f.travHandle - 1]->dev(), ctx.spill.as<uint2>());
+            GFX_HIP(hipGetLastError());
+            break;
+        }
+        if (pass == GFX_RESTIR_SPATIAL_BIASED_AND_SHADING) {
+            launch_pixels(ctx, stream, "spatial_biased", k_spatial<false>, a);
+            a.curRes = (a.curRes + 1) % 2;           // the shading pass reads what the spatial pass wrote
+        }
         launch_pixels(ctx, stream, "shade_prepare", k_shade_prepare, a);
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p);   // one entry per launch slot (emit_ray_at_slot)
         launch_pixels(ctx, stream, "shade_finish", k_shade_finish, a);

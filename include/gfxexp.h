@@ -309,6 +309,11 @@ enum gfx_restir_pass {
     GFX_RESTIR_SHADE_AND_RESAMPLE_TEMPORAL = 17,
     GFX_RESTIR_SHADE_AND_RESAMPLE_SPATIAL = 18,
     GFX_RESTIR_SHADE_AND_RESAMPLE_SPATIOTEMPORAL = 19,
+    /* No reference entry point of its own: GFX_RESTIR_SPATIAL_BIASED followed by GFX_RESTIR_SHADING of the reservoirs that pass wrote
+     * (currentReservoirIndex is the spatial pass's; the shading reads the other buffer), as restir_di_main.cpp:2393-2420 issues them for
+     * the last spatial pass of a frame.  Both on the same rows.  One kernel where the launch is small (a row band), two launches otherwise;
+     * same results as the two calls. */
+    GFX_RESTIR_SPATIAL_BIASED_AND_SHADING = 20,
     GFX_RESTIR_NUM_PASSES
 };
 int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height);
@@ -497,6 +502,10 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
  *   "pt_overlap" 0|1            path tracers (gfx_pt_launch): the NEE any-hit trace of a bounce and the kernel that applies it run on a
  *                               library-owned second stream underneath the extension closest-hit trace of the same bounce -- the two
  *                               read and write disjoint buffers; the bounce kernel waits for both (default 1; GFX_PT_OVERLAP)
+ *   "fuse_passes" 0|1|2         the ray passes of original ReSTIR (GFX_RESTIR_SETUP_GBUFFERS, _INITIAL_*, _SHADING) as ONE kernel each -- the thread
+ *                               that makes a ray traces it and consumes the result (csrc/trace_local.hip.h) -- instead of producer kernel,
+ *                               k_trace launch, consumer kernel: 0 (default) where the launch is about one round of waves (a row band of
+ *                               a multi-GPU frame), 1 never, 2 always (GFX_FUSE_PASSES)
  *   "candidate_split" 0|1|2|4   lanes per pixel in the candidate loop of the initial-RIS passes (GFX_RESTIR_INITIAL_*): the lanes take the
  *                               pixel's candidates round robin and the reservoir is formed as the sequential loop forms it; 0 (default)
  *                               = by launch size: 4 when the launch fills the GPU's wave slots at most ~1.5 times (a row band of an

@@ -307,6 +307,10 @@ int orc_env_set(orc_scene* s, const gfx_restir_static_params* sp) {
 int orc_restir_launch(orc_scene* s, const gfx_restir_static_params* sp, const gfx_restir_frame_params* fp,
                       uint32_t currentReservoirIndex, uint32_t spatialNeighborBaseIndex, int pass,
                       int x0, int y0, int x1, int y1) {
+    if (pass == GFX_RESTIR_SPATIAL_BIASED_AND_SHADING) {   // include/gfxexp.h: the two passes back to back (restir_di_main.cpp:2393-2420)
+        if (int rc = orc_restir_launch(s, sp, fp, currentReservoirIndex, spatialNeighborBaseIndex, GFX_RESTIR_SPATIAL_BIASED, x0, y0, x1, y1)) return rc;
+        return orc_restir_launch(s, sp, fp, currentReservoirIndex + 1, spatialNeighborBaseIndex, GFX_RESTIR_SHADING, x0, y0, x1, y1);
+    }
     orc_env_set(s, sp);
     Params p;
     p.scene = &s->scene; p.accel = &s->accel; p.s = sp; p.f = fp;

@@ -340,3 +340,48 @@ def test_headless_driver_with_animated_instances(built_lib):
     torch.cuda.synchronize()
     out = ctx.read_device(r.beauty_ptr(), width * height * 16).view(np.float32).reshape(-1, 4)
     util.assert_same_bits("driver beauty (animated)", out, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [1, 2])
+def test_spatial_and_shading_as_one_pass(built_lib, fuse):
+    """GFX_RESTIR_SPATIAL_BIASED_AND_SHADING = the last biased spatial pass followed by the shading of what it wrote, as two
+    launches (fuse_passes 1) or one kernel (2): beauty, reservoirs, RNG states equal to the oracle's two passes, bit for bit."""
+    import torch
+    hs = util.small_street()
+    width, height = 192, 108
+    ctx = api.Context(0)
+    ctx.tunable_set("fuse_passes", fuse)
+    hs.upload(ctx)
+    accel = ctx.accel_build()
+    ctx.lights_build_static()
+    osc = util.feed_oracle(hs)
+    cam = default_camera("street", width, height)
+    ocam = util.copy_struct(O.GfxCamera, cam)
+    pb_cpu = util.PixelBuffers(width, height)
+    dev = util.DeviceBuffers(util.PixelBuffers(width, height))
+    s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
+    stream = torch.cuda.current_stream().cuda_stream
+    last_res, last_base, nb = 1, 0, 5
+    for frame in range(2):
+        kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=0, numSpatialNeighbors=nb)
+        f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, width, height, cam, travHandle=accel, **kw)
+        f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, width, height, ocam, travHandle=0, **kw)
+        ctx.lights_build_instances(stream)
+        cur = (last_res + 1) % 2
+        entry = api.PASS_INITIAL_RIS if frame == 0 else api.PASS_INITIAL_TEMPORAL_BIASED
+        for pass_id, cur_res, base in ((api.PASS_SETUP_GBUFFERS, cur, last_base), (entry, cur, last_base), (api.PASS_SPATIAL_BIASED, cur, last_base),
+                                       (api.PASS_SPATIAL_BIASED_AND_SHADING, (cur + 1) % 2, last_base + nb)):
+            ctx.restir_set_params(s_gpu, f_gpu, cur_res, base, stream)
+            ctx.restir_launch(pass_id, width, height, stream)
+            if pass_id == api.PASS_SPATIAL_BIASED_AND_SHADING:      # the oracle: the two passes it stands for
+                osc.restir_launch(s_cpu, f_cpu, cur_res, base, api.PASS_SPATIAL_BIASED)
+                osc.restir_launch(s_cpu, f_cpu, (cur_res + 1) % 2, base + nb, api.PASS_SHADING)
+            else:
+                osc.restir_launch(s_cpu, f_cpu, cur_res, base, pass_id)
+        last_base += 2 * nb
+        last_res = cur                                                # two flips
+        got, want = dev.download(), pb_cpu.arrays()
+        for k in want:
+            assert np.array_equal(np.ascontiguousarray(got[k]).view(np.uint8), np.ascontiguousarray(want[k]).view(np.uint8)), f"frame {frame}: {k}"
+    ctx.close()
