@@ -128,12 +128,13 @@ def test_bunny_sequence_bit_exact(built_lib, renderer):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("split", [1, 2, 4])
-def test_lanes_per_pixel_of_the_candidate_pass_change_nothing(built_lib, split):
-    """k_initial_candidates with 1, 2 or 4 lanes per pixel (the library picks by launch size; "candidate_split" forces it): same
-    reservoirs, same RNG streams, same rays -- street scene (many emitters, textured ones among them), two frames."""
+@pytest.mark.parametrize("split,fuse", [(1, 1), (2, 1), (4, 1), (1, 2), (4, 2)])
+def test_lanes_per_pixel_of_the_candidate_pass_change_nothing(built_lib, split, fuse):
+    """k_initial_candidates with 1, 2 or 4 lanes per pixel (the library picks by launch size; "candidate_split" forces it), as a kernel
+    of its own between k_trace launches (fuse_passes 1) or inside k_initial_fused (2): same reservoirs, same RNG streams, same
+    G-buffers and beauty -- street scene (many emitters, textured ones among them), two frames."""
     diffs = run_sequence_both(util.small_street(), 192, 108, frames=2, renderer=api.RENDERER_BIASED, scene_kind="street",
-                              tunables={"candidate_split": split})
+                              tunables={"candidate_split": split, "fuse_passes": fuse})
     assert not diffs, "\n".join(diffs)
     ctx = api.Context(0)
     with pytest.raises(api.GfxError, match="candidate_split"):
