@@ -412,11 +412,23 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2):
     diag = ctx.trace_diag_read(reset=True)
     ctx.counters_enable(False)
     per_frame = {k: round(ms / n, 4) for k, (ms, calls) in sorted(timings.items(), key=lambda kv: -kv[1][0])}
-    trav_ms = sum(ms for k, (ms, calls) in timings.items() if k.startswith("trace_")) / n
-    trav_launches = sum(calls for k, (ms, calls) in timings.items() if k.startswith("trace_")) / n
-    # (configs[2]: one frame = 1 closest-hit launch (16 B out) + 2 any-hit launches (4 B out); the other configurations launch more)
+    # a small launch (configs[1]: 512 x 512 is one round of waves) runs with the traversal INSIDE the per-pixel kernels (k_*_fused,
+    # csrc/trace_local.hip.h): those kernels are then the ones priced; the counting launches below always take the k_trace form
+    # The G-buffer pass of every renderer, and every ray pass of a small launch (configs[1]: 512 x 512 is one round of waves), run with
+    # the traversal INSIDE the per-pixel kernel (k_*_fused, csrc/trace_local.hip.h).  configs[2] at full size keeps two k_trace<any>
+    # launches per frame -- the visibility ray of the selected candidate and the final shadow ray, 0.9 of the frame's 1.25 ms of
+    # traversal: that kernel is the one priced here, with its own bytes; the fused G-buffer kernel gets a line of its own below.
+    # The other configurations price all their traversal kernels together.  (The counting frame always takes the k_trace form.)
+    fused_form = sorted(k for k in timings if k.endswith("_fused"))
+    any_only = config == 2 and "trace_any" in timings and "trace_closest" not in timings
+    is_trav = (lambda k: k == "trace_any") if any_only else (lambda k: k.startswith("trace_") or k.endswith("_fused"))
+    trav_ms = sum(ms for k, (ms, calls) in timings.items() if is_trav(k)) / n
+    trav_launches = sum(calls for k, (ms, calls) in timings.items() if is_trav(k)) / n
+    # (configs[2]: one frame = 1 closest-hit traversal (16 B out) + 2 any-hit launches (4 B out); the other configurations launch more)
     rays_closest, rays_any = c["closest"]["rays"], c["any"]["rays"]
-    bytes_frame = c["nodeFetches"] * (64 + 16) + c["triFetches"] * 64 + rays_closest * (32 + 16) + rays_any * (32 + 4)   # node = 64-B record + 16-B link
+    bytes_closest = c["closest"]["nodeFetches"] * (64 + 16) + c["closest"]["triFetches"] * 64 + rays_closest * (32 + 16)   # node = 64-B record + 16-B link
+    bytes_any = c["any"]["nodeFetches"] * (64 + 16) + c["any"]["triFetches"] * 64 + rays_any * (32 + 4)
+    bytes_frame = bytes_any if any_only else bytes_closest + bytes_any
     achieved = bytes_frame / (trav_ms * 1e-3) / 1e9
     nodes_per_primary = c["closest"]["nodeFetches"] / max(1, rays_closest)
     # the same launch time priced with the node / triangle fetches a reference-style SAH + spatial-split tree needs
@@ -434,14 +446,15 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2):
     pmc, pmc_file = _profiled_kernels()
     traffic, traffic_file = _profiled_traffic()
     valu = None
-    if "k_trace_any" in pmc and "k_trace_closest" in pmc and config == 2:
-        ka, kc = pmc["k_trace_any"], pmc["k_trace_closest"]
-        insts_frame = 2 * ka["valu_insts"] + kc["valu_insts"]
-        valu = {"source": pmc_file + " (rocprofv3 --pmc of the default command; per-launch means of k_trace<any> x 2 and k_trace<closest>)",
-                "busy": round((2 * ka["valu_busy"] + kc["valu_busy"]) / 3, 4),
-                "lane_fraction": round((2 * ka["valu_insts"] * ka["lane_fraction"] + kc["valu_insts"] * kc["lane_fraction"]) / insts_frame, 4),
-                "insts_per_wave_iteration": round(insts_frame / max(1, diag["iterations"]), 1),
+    if "k_trace_any" in pmc and config == 2:
+        ka = pmc["k_trace_any"]
+        valu = {"source": pmc_file + " (rocprofv3 --pmc of the default command; per-launch means of k_trace<any>)",
+                "busy": ka["valu_busy"], "lane_fraction": ka["lane_fraction"],
+                # (the counting frame runs all three traversals as k_trace launches; the per-iteration figure needs the counters of all three)
+                "insts_per_wave_iteration": round((2 * ka["valu_insts"] + pmc["k_trace_closest"]["valu_insts"]) / max(1, diag["iterations"]), 1) if "k_trace_closest" in pmc else None,
                 "useful_fraction_of_valu_peak": None}
+        if "k_gbuffer_fused" in pmc:
+            valu["gbuffer_fused"] = {k: pmc["k_gbuffer_fused"].get(k) for k in ("valu_busy", "lane_fraction", "valu_insts", "l2_hit", "hbm_bytes")}
         # busy is SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES); the r04 passes read 1.00-1.08 for the traversal kernels (the busy-cycle
         # normalisation is good to a few per cent): a SIMD cannot issue more than all the time, so the product is taken with min(busy, 1)
         valu["useful_fraction_of_valu_peak"] = round(min(valu["busy"], 1.0) * valu["lane_fraction"], 4)
@@ -449,7 +462,11 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2):
     # committed counter pass covers this configuration; the SURVEY 8(d) byte figure stays beside it as frac_nominal_hbm.
     useful = valu["useful_fraction_of_valu_peak"] if valu else None
     roof = {"bound": "valu" if useful is not None else "hbm (nominal, SURVEY 8d; no VALU counter pass committed for this configuration)",
-            "kernel": "k_trace<closest|any> (software BVH8 traversal; %g launches per frame)" % round(trav_launches, 1),
+            "kernel": "k_trace<any> (software BVH8 traversal; %g launches per frame: visibility of the selected candidate, final shadow ray)" % round(trav_launches, 1) if any_only
+                      else ("%s (%g launches per frame; the k_*_fused kernels are per-pixel kernels with the software BVH8 traversal inside, csrc/trace_local.hip.h; "
+                            "bytes = the traversal's, counted by a k_trace-form frame of the same rays)"
+                            % (" + ".join(sorted("k_" + k for k in timings if is_trav(k))), round(trav_launches, 1))) if fused_form
+                      else "k_trace<closest|any> (software BVH8 traversal; %g launches per frame)" % round(trav_launches, 1),
             "achieved": useful if useful is not None else round(achieved, 1),
             "peak": 1.0 if useful is not None else HBM_PEAK_GBS,
             "unit": "share of VALU issue slots x lanes carrying a ray (VALU busy x active lanes per instruction)" if useful is not None else "GB/s",
@@ -481,6 +498,13 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2):
             "avg_launch_ms": round(trav_ms / max(trav_launches, 1), 4),
             "per_frame": {"node_fetches": int(c["nodeFetches"]), "tri_fetches": int(c["triFetches"]), "rays": int(c["rays"]),
                           "stack_spills": int(c["spills"])}}
+    gb_ms = timings.get("gbuffer_fused", (0.0, 0))[0] / n
+    if gb_ms > 0 and any_only:
+        roof["gbuffer_fused"] = {"kernel": "k_gbuffer_fused (primary ray -> closest hit with the temporal hint -> G-buffer resolve, one kernel)", "ms": round(gb_ms, 4),
+                                 "algorithmic_bytes_per_launch": int(bytes_closest + W * H * 88),
+                                 "achieved_nominal_hbm": round((bytes_closest + W * H * 88) / (gb_ms * 1e-3) / 1e9, 1),
+                                 "frac_nominal_hbm": round((bytes_closest + W * H * 88) / (gb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "bytes": "the traversal's (node / triangle fetches of the primary rays) + 88 B of G-buffer written per pixel (SURVEY 8d)"}
     init_ms = timings.get("initial_candidates", (0.0, 0))[0] / n
     if init_ms > 0:
         # The candidate pass gathers from ~3.4 MB of L2-resident tables: what bounds it is the rate at which the L2s hand scattered

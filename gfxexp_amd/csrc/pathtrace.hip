@@ -25,6 +25,7 @@
 #include "shading.hip.h"
 #include "pass_common.hip.h"
 #include "restir_common.hip.h"
+#include "trace_local.hip.h"
 
 namespace gfx {
 
@@ -171,7 +172,7 @@ GFX_DEV ReservoirNee restir_reservoir_nee(const PtArgs& a, uint32_t bufIdx, size
 template <bool REGIR, bool REGIR_LOOP = REGIR>
 GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool envEnabled, f3 pos, f3 vOutLocal, const Frame& frame,
                           const Bsdf& bsdf, Pcg32& rng, f3& alpha, f3& contribution, float& dirPDensity, PtVertexOut& o,
-                          const ReservoirNee* given = nullptr) {
+                          const ReservoirNee* given = nullptr, int nextMaxLengthTerminate = -1 /* -1: a.nextMaxLengthTerminate */) {
     f3 ret(0.0f);
     LightSample ls;
     ls.emittance = f3(0.0f); ls.position = f3(0.0f); ls.normal = f3(0.0f); ls.atInfinity = 0;
@@ -231,7 +232,7 @@ GFX_DEV void shade_vertex(const PtArgs& a, bool active, const EnvMap& env, bool 
     // loop head of the ray-generation program (:163-166): only valid samples are extended
     o.wantExt = dirPDensity > 0.0f && is_finite(dirPDensity);
     if (REGIR_LOOP && o.wantExt) {   // regir/gpu_kernels/optix_pathtracing_kernels.cu:247-256
-        if (a.nextMaxLengthTerminate) o.wantExt = false;
+        if (nextMaxLengthTerminate < 0 ? a.nextMaxLengthTerminate != 0u : nextMaxLengthTerminate != 0) o.wantExt = false;
         else {
             const float continueProb = fminf(luminance_srgb(alpha) / luminance_srgb(f3(1.0f)), 1.0f);
             if (rng.uniform() >= continueProb) o.wantExt = false;
@@ -257,23 +258,40 @@ GFX_DEV void push_vertex(const PtArgs& a, uint32_t pixel, f3 pos, const PtVertex
 }
 
 // pathTrace_rayGen_generic up to the path extension loop (optix_pathtracing_kernels.cu:74-160)
-template <bool REGIR>
-__global__ __launch_bounds__(kPtBlock) void k_pt_first(PtArgs a) {
-    const PixelId px = pixel_of_thread(a.px);
-    const size_t p = px.p;
-    const uint32_t bufIdx = a.f.bufferIndex;
+// One path in registers between two vertices: throughput, radiance so far, the density its last direction was sampled with, the
+// pixel's RNG, the vertex position and what the vertex asked for (its NEE ray and its extension ray).
+struct PtPath {
+    f3 alpha, contribution; float dirPDensity;
+    Pcg32 rng;
+    f3 pos;
     PtVertexOut o;
+};
+GFX_DEV void reset_vertex_out(PtVertexOut& o) {
     o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
     o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = 0x007FFFFFu; o.neeFromOrg = false; o.neeOrg = f3(0.0f);
-    f3 pos(0.0f), vOutLocal(0.0f);
+}
+// The first vertex from the G-buffer.  Returns whether the pixel shows a surface (its RNG state moved).  EVERY lane must call
+// (ReGIR merges its cell-access atomics across the wave).
+template <bool REGIR>
+GFX_DEV bool pt_first_vertex(const PtArgs& a, const PixelId& px, PtPath& path) {
+    const size_t p = px.p;
+    const uint32_t bufIdx = a.f.bufferIndex;
+    PtVertexOut& o = path.o;
+    reset_vertex_out(o);
+    f3& pos = path.pos;
+    pos = f3(0.0f);
+    f3 vOutLocal(0.0f);
     Frame frame(f3(0, 0, 1), f3(1, 0, 0));
     Bsdf bsdf;
-    Pcg32 rng; rng.state = 0;
+    Pcg32& rng = path.rng; rng.state = 0;
     const EnvMap env = load_env(a.s);
     const bool envEnabled = env.present() && a.f.enableEnvLight;
-    f3 contribution(0.001f, 0.001f, 0.001f);
-    f3 alpha(1.0f);
-    float dirPDensity = 0.0f;
+    f3& contribution = path.contribution;
+    f3& alpha = path.alpha;
+    float& dirPDensity = path.dirPDensity;
+    contribution = f3(0.001f, 0.001f, 0.001f);
+    alpha = f3(1.0f);
+    dirPDensity = 0.0f;
     bool surface = false;
     uint4 g0 = make_uint4(0xFFFFFFFFu, 0, 0, 0);
     if (px.valid) g0 = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p];
@@ -320,12 +338,20 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_first(PtArgs a) {
         contribution = a.f.envLightPowerCoeff * env.fetch(decode_bc(g0.w & 0xFFFF), decode_bc(g0.w >> 16));
     }
     shade_vertex<REGIR>(a, surface, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
-    if (surface) static_cast<uint64_t*>(a.s.rngBuffer)[p] = rng.state;
+    return surface;
+}
+template <bool REGIR>
+__global__ __launch_bounds__(kPtBlock) void k_pt_first(PtArgs a) {
+    const PixelId px = pixel_of_thread(a.px);
+    const size_t p = px.p;
+    PtPath path;
+    const bool surface = pt_first_vertex<REGIR>(a, px, path);
+    if (surface) static_cast<uint64_t*>(a.s.rngBuffer)[p] = path.rng.state;
     if (px.valid) {
-        a.state[2 * p] = make_float4(alpha.x, alpha.y, alpha.z, dirPDensity);
-        a.state[2 * p + 1] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+        a.state[2 * p] = make_float4(path.alpha.x, path.alpha.y, path.alpha.z, path.dirPDensity);
+        a.state[2 * p + 1] = make_float4(path.contribution.x, path.contribution.y, path.contribution.z, 0.0f);
     }
-    push_vertex(a, static_cast<uint32_t>(p), pos, o);
+    push_vertex(a, static_cast<uint32_t>(p), path.pos, path.o);
 }
 
 // The visibility factor of performDirectLighting<.., true> applied after the any-hit trace:
@@ -353,33 +379,31 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_apply_nee(PtArgs a) {
 
 // closest-hit + miss programs of one path vertex, then the loop head of the ray-generation program
 // (optix_pathtracing_kernels.cu:210-296, :306-341, :161-201; ReGIR: regir/.../optix_pathtracing_kernels.cu:302-392)
+// What the extension ray of the previous vertex found (h; `active`: the lane holds such a ray, with path.alpha / contribution /
+// dirPDensity as that vertex left them): implicit light or environment with its MIS weight, Russian roulette, the next vertex.
+// rngBuf: where the pixel's RNG state is read when the ray hit a surface (the wavefront kernels), or null: path.rng holds it.
+// Returns kPtHitSurface (the RNG state moved and the whole state changed) | kPtMissAdded (only the contribution changed).
+// EVERY lane must call (ReGIR merges its cell-access atomics across the wave).
+constexpr uint32_t kPtHitSurface = 1u, kPtMissAdded = 2u;
 template <bool REGIR>
-__global__ __launch_bounds__(kPtBlock) void k_pt_bounce(PtArgs a) {
-    const uint32_t i = blockIdx.x * kPtBlock + threadIdx.x;
-    const uint32_t count = *a.extCountIn;
-    PtVertexOut o;
-    o.wantNee = false; o.wantExt = false; o.neeDir = f3(0.0f); o.extDir = f3(0.0f); o.neeTmax = 0; o.pending = f3(0.0f);
-    o.neeRet = f3(0.0f); o.localThroughput = f3(0.0f); o.trainIdx = 0x007FFFFFu; o.neeFromOrg = false; o.neeOrg = f3(0.0f);
-    f3 pos(0.0f), vOutLocal(0.0f);
+GFX_DEV uint32_t pt_next_vertex(const PtArgs& a, bool active, const gfx_hit& h, f3 rayOrg, f3 rayDir, const uint64_t* rngBuf, PtPath& path,
+                                int maxLengthTerminate = -1, int nextMaxLengthTerminate = -1 /* -1: the launch's (a.*) */) {
+    PtVertexOut& o = path.o;
+    reset_vertex_out(o);
+    f3& pos = path.pos;
+    pos = f3(0.0f);
+    f3 vOutLocal(0.0f);
     Frame frame(f3(0, 0, 1), f3(1, 0, 0));
     Bsdf bsdf;
-    Pcg32 rng; rng.state = 0;
+    Pcg32& rng = path.rng;
     const EnvMap env = load_env(a.s);
     const bool envEnabled = env.present() && a.f.enableEnvLight;
-    f3 alpha(0.0f), contribution(0.0f);
-    float dirPDensity = 0.0f;
-    uint32_t pixel = 0;
-    bool hitSurface = false, shade = false;
-    if (i < count) {
-        pixel = a.extOwnerIn[i];
-        const gfx_hit h = a.hits[i];
-        const float4 ro4 = a.extOrgIn[i], rd4 = a.extDirIn[i];
-        const f3 rayOrg(ro4.x, ro4.y, ro4.z), rayDir(rd4.x, rd4.y, rd4.z);
-        const float4 s0 = a.state[2ull * pixel], s1 = a.state[2ull * pixel + 1];
-        alpha = f3(s0.x, s0.y, s0.z);
-        const float prevDirPDensity = s0.w;
-        dirPDensity = prevDirPDensity;
-        contribution = f3(s1.x, s1.y, s1.z);
+    f3& alpha = path.alpha;
+    f3& contribution = path.contribution;
+    float& dirPDensity = path.dirPDensity;
+    bool hitSurface = false, shade = false, missAdded = false;
+    if (active) {
+        const float prevDirPDensity = dirPDensity;
         if (h.triIndex == GFX_INVALID_SLOT) {
             if (envEnabled && !REGIR) {   // the ReGIR ray type has an empty miss program (regir_main.cpp:250)
                 const f3 rd = unit(rayDir);
@@ -394,7 +418,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_bounce(PtArgs a) {
                 const float lightPDensity = (*a.scene.lightInstIntegral > 0.0f ? 0.25f : 1.0f) * hypAreaPDensity;
                 const float misWeight = (prevDirPDensity * prevDirPDensity) / (prevDirPDensity * prevDirPDensity + lightPDensity * lightPDensity);
                 contribution = contribution + alpha * luminance * misWeight;
-                a.state[2ull * pixel + 1] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+                missAdded = true;
             }
         }
         else {
@@ -465,23 +489,46 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_bounce(PtArgs a) {
                 const float misWeight = (prevDirPDensity * prevDirPDensity) / (prevDirPDensity * prevDirPDensity + lightPDensity * lightPDensity);
                 contribution = contribution + alpha * emittance * (misWeight / kPi);
             }
-            rng.state = static_cast<const uint64_t*>(a.s.rngBuffer)[pixel];
+            if (rngBuf) rng.state = *rngBuf;
             // Russian roulette; initImportance = sRGB_calcLuminance(RGB(1))
             const float continueProb = fminf(luminance_srgb(alpha) / luminance_srgb(f3(1.0f)), 1.0f);
-            if (!(rng.uniform() >= continueProb || a.maxLengthTerminate)) {
+            if (!(rng.uniform() >= continueProb || (maxLengthTerminate < 0 ? a.maxLengthTerminate != 0u : maxLengthTerminate != 0))) {
                 alpha = alpha / continueProb;
                 bsdf.setup(a.scene, mat, tu, tv);
                 shade = true;
             }
         }
     }
-    shade_vertex<REGIR>(a, shade, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
-    if (hitSurface) {
-        static_cast<uint64_t*>(a.s.rngBuffer)[pixel] = rng.state;
-        a.state[2ull * pixel] = make_float4(alpha.x, alpha.y, alpha.z, dirPDensity);
-        a.state[2ull * pixel + 1] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+    shade_vertex<REGIR>(a, shade, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o, nullptr, nextMaxLengthTerminate);
+    return (hitSurface ? kPtHitSurface : 0u) | (missAdded ? kPtMissAdded : 0u);
+}
+template <bool REGIR>
+__global__ __launch_bounds__(kPtBlock) void k_pt_bounce(PtArgs a) {
+    const uint32_t i = blockIdx.x * kPtBlock + threadIdx.x;
+    const uint32_t count = *a.extCountIn;
+    PtPath path;
+    path.alpha = f3(0.0f); path.contribution = f3(0.0f); path.dirPDensity = 0.0f; path.rng.state = 0;
+    uint32_t pixel = 0;
+    gfx_hit h; h.dist = 0.0f; h.bcB = 0.0f; h.bcC = 0.0f; h.triIndex = GFX_INVALID_SLOT;
+    f3 rayOrg(0.0f), rayDir(0.0f);
+    const bool active = i < count;
+    if (active) {
+        pixel = a.extOwnerIn[i];
+        h = a.hits[i];
+        const float4 ro4 = a.extOrgIn[i], rd4 = a.extDirIn[i];
+        rayOrg = f3(ro4.x, ro4.y, ro4.z); rayDir = f3(rd4.x, rd4.y, rd4.z);
+        const float4 s0 = a.state[2ull * pixel], s1 = a.state[2ull * pixel + 1];
+        path.alpha = f3(s0.x, s0.y, s0.z);
+        path.dirPDensity = s0.w;
+        path.contribution = f3(s1.x, s1.y, s1.z);
     }
-    push_vertex(a, pixel, pos, o);
+    const uint32_t what = pt_next_vertex<REGIR>(a, active, h, rayOrg, rayDir, static_cast<const uint64_t*>(a.s.rngBuffer) + pixel, path);
+    if (what & kPtHitSurface) {
+        static_cast<uint64_t*>(a.s.rngBuffer)[pixel] = path.rng.state;
+        a.state[2ull * pixel] = make_float4(path.alpha.x, path.alpha.y, path.alpha.z, path.dirPDensity);
+    }
+    if (what & (kPtHitSurface | kPtMissAdded)) a.state[2ull * pixel + 1] = make_float4(path.contribution.x, path.contribution.y, path.contribution.z, 0.0f);
+    push_vertex(a, pixel, path.pos, path.o);
 }
 
 // ---------------------------------------------------------------- ReGIR grid maintenance
@@ -617,6 +664,52 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_finish(PtArgs a) {
     if (a.f.numAccumFrames > 0) { const float4 b = *beauty; prev = f3(b.x, b.y, b.z); }
     const float curWeight = 1.0f / (1 + a.f.numAccumFrames);
     const f3 result = (1 - curWeight) * prev + curWeight * contribution;
+    *beauty = make_float4(result.x, result.y, result.z, 1.0f);
+}
+
+// The whole path of a pixel in ONE kernel, for small launches (trace_local.hip.h): first vertex, then per further vertex the NEE ray
+// (any hit), its visibility applied, the extension ray (closest hit), the next vertex -- what k_pt_first, the two k_trace launches,
+// k_pt_apply_nee, k_pt_bounce and k_pt_finish do through queues, here in the registers of the pixel's lane, in the same order per pixel
+// (so the same sums).  A 512 x 512 frame is one round of waves; its wavefront form is ~20 launches of which most last as long as their
+// slowest wave.  A lane whose path has ended idles until its wave's longest path has (no compaction: that is the price, and why large
+// launches keep the wavefront form).
+template <bool REGIR>
+__global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel, uint2* spill, uint32_t maxPathLength) {
+    __shared__ uint2 ldsStack[kLdsStackDepth * kPtBlock];
+    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kPtBlock / 64) * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint2* stackLds = ldsStack + tid;
+    uint2* stackSpill = spill + (static_cast<size_t>(blockIdx.x) * kPtBlock + tid) * kSpillStackDepth;
+    const PixelId px = pixel_of_thread(a.px);
+    PtPath path;
+    bool rngMoved = pt_first_vertex<REGIR>(a, px, path);       // a.pathLength = 1 (set by the host)
+    for (uint32_t pathLength = 2;; ++pathLength) {
+        const RayHit shadow = trace_wave_local<true>(accel, path.o.wantNee, path.o.neeFromOrg ? path.o.neeOrg : path.pos, path.o.neeDir, 0.0f, path.o.neeTmax,
+                                                     stackLds, kPtBlock, stackSpill, waveBuf, lane);
+        if (path.o.wantNee) {                                   // k_pt_apply_nee
+            f3 add = path.o.pending;
+            if (shadow.tri != GFX_INVALID_SLOT) add = add * 0.0f;
+            path.contribution = path.contribution + add;
+        }
+        if (REGIR && pathLength >= maxPathLength) break;
+        if (__ballot(path.o.wantExt) == 0ull) break;            // no path of the wave goes on: nothing further can be added
+        const bool extend = path.o.wantExt;
+        const f3 rayOrg = path.pos, rayDir = path.o.extDir;
+        const RayHit hit = trace_wave_local<false>(accel, extend, rayOrg, rayDir, 0.0f, 3.402823466e+38f, stackLds, kPtBlock, stackSpill, waveBuf, lane);
+        gfx_hit h; h.dist = hit.t; h.bcB = hit.bcB; h.bcC = hit.bcC; h.triIndex = hit.tri;
+        const bool lastVertex = pathLength >= maxPathLength;     // what the host sets per bounce launch in the wavefront form
+        if (pt_next_vertex<REGIR>(a, extend, h, rayOrg, rayDir, nullptr, path, lastVertex ? 1 : 0, pathLength + 1 >= maxPathLength ? 1 : 0) & kPtHitSurface) rngMoved = true;
+        if (!REGIR && lastVertex) break;
+    }
+    if (!px.valid) return;
+    const size_t p = px.p;
+    if (rngMoved) static_cast<uint64_t*>(a.s.rngBuffer)[p] = path.rng.state;
+    float4* beauty = static_cast<float4*>(a.s.beautyAccumBuffer) + p;          // k_pt_finish
+    f3 prev(0.0f);
+    if (a.f.numAccumFrames > 0) { const float4 bb = *beauty; prev = f3(bb.x, bb.y, bb.z); }
+    const float curWeight = 1.0f / (1 + a.f.numAccumFrames);
+    const f3 result = (1 - curWeight) * prev + curWeight * path.contribution;
     *beauty = make_float4(result.x, result.y, result.z, 1.0f);
 }
 
@@ -1356,6 +1449,20 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     set_queues(1, cur);
     a.pathLength = 1; a.maxLengthTerminate = 0;
     a.nextMaxLengthTerminate = 2 >= maxPathLength ? 1u : 0u;
+    // a launch of about one round of waves (512 x 512; a band of an 8-way split full-HD frame): the path of a pixel in one kernel.
+    // "fuse_passes" 1 never, 2 always; counting launches keep the wavefront form (the counters live in k_trace).
+    {
+        const uint32_t launchWaves = a.px.launchBlocks * (kPtBlock / 64), waveSlots = static_cast<uint32_t>(ctx.numCUs) * 16u;
+        const size_t spillBytes = sizeof(uint2) * static_cast<size_t>(a.px.launchBlocks) * kPtBlock * kSpillStackDepth;
+        const bool small = launchWaves <= waveSlots + waveSlots / 2;
+        if (!nrc && !ctx.countersEnabled && spillBytes <= (size_t(1) << 30) && (ctx.tune.fusePasses == 2 || (ctx.tune.fusePasses == 0 && small))) {
+            ctx.spill.reserve(spillBytes);
+            ScopedKernelTimer timer(ctx, stream, regir ? "pt_regir_fused" : "pt_fused");
+            hipLaunchKernelGGL(regir ? k_pt_fused<true> : k_pt_fused<false>, dim3(a.px.launchBlocks), dim3(kPtBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), maxPathLength);
+            GFX_HIP(hipGetLastError());
+            return;
+        }
+    }
     if (nrc) launch_pixels("nrc_pt_first", nrcRegir ? k_nrc_pt_first<1> : nrcRestir ? k_nrc_pt_first<2> : k_nrc_pt_first<0>);
     else launch_pixels("pt_first", regir ? k_pt_first<true> : k_pt_first<false>);
     // while (true) { ++pathLength; trace; }.  Baseline: at least one extension even when maxPathLength < 2,

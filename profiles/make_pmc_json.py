@@ -18,7 +18,7 @@ import sys
 
 KERNELS = {"k_trace_any": "k_trace<true, false>", "k_trace_closest": "k_trace<false, false>",
            "k_initial_candidates": "k_initial_candidates<", "k_initial_candidates_pooled": "k_initial_candidates_pooled<", "k_spatial": "k_spatial<false>", "k_temporal": "k_temporal<1>",
-           "k_shade_prepare": "k_shade_prepare", "k_gbuffer_resolve": "k_gbuffer_resolve"}
+           "k_shade_prepare": "k_shade_prepare", "k_gbuffer_resolve": "k_gbuffer_resolve", "k_gbuffer_fused": "k_gbuffer_fused"}
 
 
 def parse(path):
@@ -74,6 +74,8 @@ def main(argv):
     t = out["kernels"]
     if "k_trace_any" in t and "k_trace_closest" in t and "hbm_bytes" in t["k_trace_any"]:
         out["hbm_bytes_per_launch"] = int((2 * t["k_trace_any"]["hbm_bytes"] + t["k_trace_closest"]["hbm_bytes"]) / 3)
+    elif "k_trace_any" in t and "hbm_bytes" in t["k_trace_any"]:     # round 4 on: the closest-hit traversal of the frame runs inside k_gbuffer_fused
+        out["hbm_bytes_per_launch"] = int(t["k_trace_any"]["hbm_bytes"])
     for d, label in zip(argv[1::2], argv[2::2]):
         out[label] = condense(d)
     print(json.dumps(out, indent=1))
