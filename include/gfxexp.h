@@ -502,10 +502,13 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
  *   "pt_overlap" 0|1            path tracers (gfx_pt_launch): the NEE any-hit trace of a bounce and the kernel that applies it run on a
  *                               library-owned second stream underneath the extension closest-hit trace of the same bounce -- the two
  *                               read and write disjoint buffers; the bounce kernel waits for both (default 1; GFX_PT_OVERLAP)
- *   "fuse_passes" 0|1|2         the ray passes of original ReSTIR (GFX_RESTIR_SETUP_GBUFFERS, _INITIAL_*, _SHADING) as ONE kernel each -- the thread
- *                               that makes a ray traces it and consumes the result (csrc/trace_local.hip.h) -- instead of producer kernel,
- *                               k_trace launch, consumer kernel: 0 (default) where the launch is about one round of waves (a row band of
- *                               a multi-GPU frame), 1 never, 2 always (GFX_FUSE_PASSES)
+ *   "fuse_passes" 0|1|2         ray passes as ONE kernel each -- the thread that makes a ray traces it and consumes the result
+ *                               (csrc/trace_local.hip.h) -- instead of producer kernel, k_trace launch, consumer kernel.  0 (default): the
+ *                               G-buffer pass (GFX_RESTIR_SETUP_GBUFFERS, GFX_PT_SETUP_GBUFFERS) at every size; GFX_RESTIR_INITIAL_*, _SHADING
+ *                               and _SPATIAL_BIASED_AND_SHADING for launches of up to about half a full-HD frame (a row band of a multi-GPU
+ *                               frame); GFX_PT_PATH_TRACE_BASELINE / _REGIR (the whole path of a pixel in one kernel) for launches of about
+ *                               one round of waves (512 x 512).  1 never, 2 always (GFX_FUSE_PASSES).  Counting launches
+ *                               (gfx_counters_enable) always take the k_trace form.
  *   "candidate_split" 0|1|2|4   lanes per pixel in the candidate loop of the initial-RIS passes (GFX_RESTIR_INITIAL_*): the lanes take the
  *                               pixel's candidates round robin and the reservoir is formed as the sequential loop forms it; 0 (default)
  *                               = by launch size: 4 when the launch fills the GPU's wave slots at most ~1.5 times (a row band of an
