@@ -17,7 +17,8 @@ def arg(name, default):
 
 def measure(ctx, cam, W, H, band, steps=30, kernels=True):
     import torch
-    cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
+    config4 = "--config4" in sys.argv       # BASELINE configs[4]: unbiased estimator + 2048 x 1024 environment map
+    cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_UNBIASED if config4 else api.RENDERER_BIASED)
     cfg.camera = cam
     cfg.rowBegin, cfg.rowEnd = band
     cfg.enableBumpMapping = int("--plain" not in sys.argv)
@@ -25,6 +26,8 @@ def measure(ctx, cam, W, H, band, steps=30, kernels=True):
         os.environ["GFX_SERIAL_FRAMES"] = "1"
     r = api.RestirRenderer(ctx, cfg)
     os.environ.pop("GFX_SERIAL_FRAMES", None)
+    if config4:
+        r.set_env(api.env_make_sky(2048, 1024), 2048, 1024, 0.6, 0.4)
     if band != (0, 0):
         r.set_exchange(lambda stream, d: None, 0)
     for _ in range(6):
