@@ -51,9 +51,10 @@ GFX_DEV bool ray_triangle(f3 org, f3 dir, float tmin, f3 pA, f3 eAB, f3 eCA, f3 
 // Stack of 8-byte group entries: LDS column first, HBM spill behind it.
 struct LaneStack {
     uint2* lds; int ldsStride; uint2* spill; int sp;
+    int spillCap;                      // entries of this lane's spill area (kSpillStackDepth in k_trace; sized by the tree's depth in trace_local.hip.h)
     GFX_DEV void push(uint2 e, TraceCounters& cnt, bool count) {
         if (sp < kLdsStackDepth) lds[sp * ldsStride] = e;
-        else { if (sp - kLdsStackDepth < kSpillStackDepth) spill[sp - kLdsStackDepth] = e; if (count) ++cnt.spills; }
+        else { if (sp - kLdsStackDepth < spillCap) spill[sp - kLdsStackDepth] = e; if (count) ++cnt.spills; }
         ++sp;
     }
     GFX_DEV uint2 pop() {

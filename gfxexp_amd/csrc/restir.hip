@@ -792,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
 // of 11 and none of them waits for the slowest wave of a traversal before the next short kernel may start.  Same buffers out as the
 // three-kernel form (the ray queue, the per-pixel ray slots, the occlusion words and the shading scratch are skipped: they were
 // only the kernels' way of talking to each other).  `spill`: kSpillStackDepth entries per tracing thread of the launch.
-__global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel accel, gfx_hit* hits, uint2* spill, int useHint) {
+__global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel accel, gfx_hit* hits, uint2* spill, int spillCap, int useHint) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel
     // the triangle this pixel's primary ray hit one frame ago is tested right after the root (trace.hip: temporal hint)
     const uint32_t hint = useHint ? hits[px.slot].triIndex : 0xFFFFFFFFu;
     const RayHit h = trace_wave_local<false>(accel, true, f3(r.org.x, r.org.y, r.org.z), f3(r.dir.x, r.dir.y, r.dir.z), r.org.w, r.dir.w, ldsStack + tid, kBlock,
-                                             spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * kSpillStackDepth, waveBuf, lane, hint);
+                                             spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * spillCap, spillCap, waveBuf, lane, hint);
     gfx_hit gh; gh.dist = h.t; gh.bcB = h.bcB; gh.bcC = h.bcC; gh.triIndex = h.tri;
     hits[px.slot] = gh;                          // the next frame's hint
     if (px.valid) gbuffer_resolve(a, px, gh, f3(r.dir.x, r.dir.y, r.dir.z));
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel
 // and the traversal stack live in the record buffers of the waves that have left, so a block holds 16 KB of LDS, not 24: ten blocks
 // fit a CU, and the one-wave tails of the blocks that trace do not keep new blocks out.
 template <bool EMITTER_TEX, int SPLIT, int MODE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_fused(RestirArgs a, DevAccel accel, uint2* spill) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap) {
     static_assert(SPLIT == 1 || SPLIT == 4, "one lane per pixel, or four with the block's rays gathered in its first wave");
     constexpr int kRays = kBlock / SPLIT;
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];           // per wave: 256 x 16 B = 64 records
@@ -842,14 +842,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
     }
     const bool want = dir.w > org.w;
     const RayHit h = trace_wave_local<true>(accel, want, f3(org.x, org.y, org.z), f3(dir.x, dir.y, dir.z), org.w, dir.w, stack, kRays,
-                                            spill + (static_cast<size_t>(blockIdx.x) * kRays + tid) * kSpillStackDepth, waveBuf, lane);
+                                            spill + (static_cast<size_t>(blockIdx.x) * kRays + tid) * spillCap, spillCap, waveBuf, lane);
     temporal_reuse<MODE>(a, px, want && h.tri != GFX_INVALID_SLOT);
 }
 
 // SPATIAL_FIRST: GFX_RESTIR_SPATIAL_BIASED_AND_SHADING -- the pixel's last spatial pass (it reads neighbours in reservoir a.curRes and
 // writes the pixel's own entry of the other one), then the shading of that entry by the same thread.
 template <bool SPATIAL_FIRST>
-__global__ __launch_bounds__(kBlock) void k_shading_fused(RestirArgs a, DevAccel accel, uint2* spill) {
+__global__ __launch_bounds__(kBlock) void k_shading_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(kBlock) void k_shading_fused(RestirArgs a, DevAccel
     if (SPATIAL_FIRST) spatial_reuse<false>(a, px);
     const ShadeState st = shade_prepare(a, px, SPATIAL_FIRST ? (a.curRes + 1) % 2 : a.curRes);
     const RayHit h = trace_wave_local<true>(accel, st.want, st.ro, st.rd, 0.0f, st.tmax, ldsStack + tid, kBlock,
-                                            spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * kSpillStackDepth, waveBuf, lane);
+                                            spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * spillCap, spillCap, waveBuf, lane);
     if (px.valid) shade_finish(a, px, st.contribution, st.direct, st.recPDF, st.want && h.tri != GFX_INVALID_SLOT);
 }
 
@@ -998,7 +998,8 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     const uint32_t launchWaves = a.px.launchBlocks * (kBlock / 64), waveSlots = static_cast<uint32_t>(ctx.numCUs) * 4u * GFX_INIT_WAVES;
     const bool smallLaunch = launchWaves <= waveSlots + waveSlots / 2;           // about one round of waves: the candidate loop is split over four lanes
     const bool fusableLaunch = 2u * launchWaves <= 9u * waveSlots;
-    const size_t fusedSpillBytes = sizeof(uint2) * static_cast<size_t>(a.px.launchBlocks) * kBlock * kSpillStackDepth;
+    const int spillCap = static_cast<int>(local_spill_depth(ctx.accels[ctx.restir.f.travHandle - 1]->maxDepth));   // stack entries per thread behind the LDS part
+    const size_t fusedSpillBytes = sizeof(uint2) * static_cast<size_t>(a.px.launchBlocks) * kBlock * spillCap;
     const bool fused = !ctx.countersEnabled && fusedSpillBytes <= (size_t(1) << 30) && (ctx.tune.fusePasses == 2 || (ctx.tune.fusePasses == 0 && fusableLaunch));
     switch (pass) {
     case GFX_RESTIR_SETUP_GBUFFERS: {
@@ -1013,11 +1014,11 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         // primary rays are coherent (neighbouring lanes walk nearly the same nodes, the temporal hint ends most of them early): the
         // wave-local traversal loses little to the missing refill and saves the ray queue and two launches at every size (rearchitected
         // ReSTIR at 1920x1080: 2.250 -> 2.115 ms per frame, NRC 3.65 -> 3.53) -- fused unless "fuse_passes" says never
-        if (!ctx.countersEnabled && fusedSpillBytes <= (size_t(5) << 28) && ctx.tune.fusePasses != 1) {
+        if (!ctx.countersEnabled && fusedSpillBytes <= (size_t(1) << 30) && ctx.tune.fusePasses != 1) {
             ctx.gbSpill.reserve(fusedSpillBytes);
             ScopedKernelTimer timer(ctx, stream, "gbuffer_fused");
             hipLaunchKernelGGL(k_gbuffer_fused, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a, ctx.accels[ctx.restir.f.travHandle - 1]->dev(),
-                               ctx.gbRayHits.as<gfx_hit>(), ctx.gbSpill.as<uint2>(), ctx.tune.temporalHints ? 1 : 0);
+                               ctx.gbRayHits.as<gfx_hit>(), ctx.gbSpill.as<uint2>(), spillCap, ctx.tune.temporalHints ? 1 : 0);
             GFX_HIP(hipGetLastError());
             break;
         }
@@ -1051,13 +1052,13 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
                 const DevAccel accel = ctx.accels[ctx.restir.f.travHandle - 1]->dev();
                 const int mode = pass == GFX_RESTIR_INITIAL_RIS ? 0 : pass == GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED ? 1 : 2;
                 const bool tex = a.scene.emitterTexRefs != nullptr;
-                void (*kernel)(RestirArgs, DevAccel, uint2*) = nullptr;
+                void (*kernel)(RestirArgs, DevAccel, uint2*, int) = nullptr;
 #define GFX_PICK(TEX, SPLIT) (mode == 0 ? k_initial_fused<TEX, SPLIT, 0> : mode == 1 ? k_initial_fused<TEX, SPLIT, 1> : k_initial_fused<TEX, SPLIT, 2>)
                 if (tex) kernel = split == 4 ? GFX_PICK(true, 4) : GFX_PICK(true, 1);
                 else kernel = split == 4 ? GFX_PICK(false, 4) : GFX_PICK(false, 1);
 #undef GFX_PICK
                 ScopedKernelTimer timer(ctx, stream, "initial_fused");
-                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a, accel, ctx.spill.as<uint2>());
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap);
                 GFX_HIP(hipGetLastError());
                 break;
             }
@@ -1089,7 +1090,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
             const bool both = pass == GFX_RESTIR_SPATIAL_BIASED_AND_SHADING;
             ScopedKernelTimer timer(ctx, stream, both ? "spatial_shading_fused" : "shading_fused");
             hipLaunchKernelGGL(both ? k_shading_fused<true> : k_shading_fused<false>, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a,
-                               ctx.accels[ctx.restir.f.travHandle - 1]->dev(), ctx.spill.as<uint2>());
+                               ctx.accels[ctx.restir.f.travHandle - 1]->dev(), ctx.spill.as<uint2>(), spillCap);
             GFX_HIP(hipGetLastError());
             break;
         }

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     stack.ldsStride = kTraceBlock;
     stack.spill = a.spill + (static_cast<size_t>(blockIdx.x) * kTraceBlock + tid) * kSpillStackDepth;
     stack.sp = 0;
+    stack.spillCap = kSpillStackDepth;
     // the other ticket area belongs to the next launch (stream order: nobody reads it while this kernel runs)
     if (blockIdx.x == 0 && tid < static_cast<int>(kTicketCounters)) a.ticketNext[tid * kTicketStride] = 0u;
     if (blockIdx.x == 0 && tid < 2 && a.zeroWords[tid]) *a.zeroWords[tid] = 0u;

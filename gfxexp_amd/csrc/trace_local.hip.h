@@ -15,16 +15,25 @@
 
 namespace gfx {
 
+// Entries of HBM stack spill a lane needs behind its kLdsStackDepth LDS entries for a tree `maxDepth` levels deep (host side; lbvh.hip
+// refuses trees deeper than kLdsStackDepth + kSpillStackDepth - 1): one entry per level below the LDS part, + 1, at least 4.
+inline uint32_t local_spill_depth(uint32_t maxDepth) {
+    const uint32_t need = maxDepth + 1 > static_cast<uint32_t>(kLdsStackDepth) ? maxDepth + 1 - static_cast<uint32_t>(kLdsStackDepth) : 0u;
+    return need + 1 < 4u ? 4u : need + 1;
+}
+
 // EVERY lane of the wave must call (the item fetch is cooperative); a lane without a ray passes want = false.
-//   stackLds / stackStride  this lane's LDS column (kLdsStackDepth entries, `stackStride` uint2 apart), stackSpill its HBM spill area
+//   stackLds / stackStride  this lane's LDS column (kLdsStackDepth entries, `stackStride` uint2 apart)
+//   stackSpill / spillCap   its HBM spill area of spillCap entries: local_spill_depth() of the tree -- a stack is never deeper than the
+//                           tree, so the area is sized by the tree (a few entries), not by the worst case k_trace's fixed grid can afford
 //   waveBuf                 256 x 16 B of LDS private to the wave (the cooperative fetch)
 //   hint                    closest hit only: a triangle record to test right after the root (k_trace's temporal hint), or an
 //                           index >= numTris for none
 template <bool ANY_HIT>
 GFX_DEV RayHit trace_wave_local(const DevAccel& accel, bool want, f3 org, f3 dir, float tmin, float tmax, uint2* stackLds, int stackStride,
-                                uint2* stackSpill, uint4* waveBuf, int lane, uint32_t hint = 0xFFFFFFFFu) {
+                                uint2* stackSpill, int spillCap, uint4* waveBuf, int lane, uint32_t hint = 0xFFFFFFFFu) {
     LaneStack stack;
-    stack.lds = stackLds; stack.ldsStride = stackStride; stack.spill = stackSpill; stack.sp = 0;
+    stack.lds = stackLds; stack.ldsStride = stackStride; stack.spill = stackSpill; stack.sp = 0; stack.spillCap = spillCap;
     const bool hasNodes = accel.numNodes != 0;
     Traversal tr;
     tr.begin(org, dir, tmin, tmax, stack, hasNodes);
