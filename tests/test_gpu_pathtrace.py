@@ -9,9 +9,11 @@ from oracle import oracle as O
 from tests import util
 
 
-def run_pt_both(hs, width, height, frames=2, max_len=5, camera=None, env=None, jitter=0, env_rotation=0.0, rows=None):
+def run_pt_both(hs, width, height, frames=2, max_len=5, camera=None, env=None, jitter=0, env_rotation=0.0, rows=None, fuse=None):
     import torch
     ctx = api.Context(0)
+    if fuse is not None:
+        ctx.tunable_set("fuse_passes", fuse)
     hs.upload(ctx)
     accel = ctx.accel_build()
     ctx.lights_build_static()
@@ -50,6 +52,18 @@ def run_pt_both(hs, width, height, frames=2, max_len=5, camera=None, env=None, j
                 diffs.append(f"frame {frame}: {k}: {nbad} of {want[k].size} elements differ")
     run_pt_both.last_beauty = pb_cpu.beauty.copy()
     return diffs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [1, 2])
+def test_wavefront_and_one_kernel_forms_of_the_path_tracer(built_lib, fuse):
+    """fuse_passes 1: k_pt_first, two k_trace launches, k_pt_apply_nee and k_pt_bounce per bounce through the ray queues (what a full-HD
+    frame runs); 2: the whole path of a pixel in k_pt_fused (what a small launch runs).  Both against the oracle, street scene with an
+    environment map (implicit environment hits with MIS), path length 6, three frames with accumulation."""
+    sky = api.env_make_sky(64, 32)
+    diffs = run_pt_both(util.small_street(), 160, 96, frames=3, max_len=6, camera=api.make_camera(160, 96, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0),
+                        env=(sky, 64, 32), env_rotation=0.4, fuse=fuse)
+    assert not diffs, "\n".join(diffs)
 
 
 @pytest.mark.gpu

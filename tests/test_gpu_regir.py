@@ -10,9 +10,11 @@ from tests import util
 
 
 def run_regir_both(hs, width, height, frames, max_len, temporal=True, dims=(8, 4, 8), randomize=1, env=None, camera=None,
-                   log2_slot=3, log2_cell=2):
+                   log2_slot=3, log2_cell=2, fuse=None):
     import torch
     ctx = api.Context(0)
+    if fuse is not None:
+        ctx.tunable_set("fuse_passes", fuse)
     hs.upload(ctx)
     accel = ctx.accel_build()
     ctx.lights_build_static()
@@ -65,6 +67,16 @@ def run_regir_both(hs, width, height, frames, max_len, temporal=True, dims=(8, 4
 @pytest.mark.parametrize("max_len", [2, 5])
 def test_regir_bunny_bit_exact(built_lib, max_len):
     diffs = run_regir_both(util.bunny_scene(), 128, 96, 3, max_len)
+    assert not diffs, "\n".join(diffs[:12])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [1, 2])
+def test_regir_wavefront_and_one_kernel_forms(built_lib, fuse):
+    """The ReGIR path tracer as a wavefront of launches (fuse_passes 1: what a full-HD frame runs) and as k_pt_fused<REGIR> (2): cell
+    reservoirs, access counters, RNG states and beauty against the oracle, street scene, path length 5, three frames."""
+    cam = api.make_camera(128, 80, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
+    diffs = run_regir_both(util.small_street(), 128, 80, 3, 5, camera=cam, dims=(8, 2, 8), fuse=fuse)
     assert not diffs, "\n".join(diffs[:12])
 
 
