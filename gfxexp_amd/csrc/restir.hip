@@ -787,11 +787,13 @@ __global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
     shade_finish(a, px, f3(c0.x, c0.y, c0.z), f3(c1.x, c1.y, c1.z), c1.w, slot != GFX_INVALID_SLOT && a.occluded[slot] != 0u);
 }
 
-// ---------------------------------------------------------------- the three ray passes as ONE kernel each, for small launches
-// trace_local.hip.h: the kernel that makes a ray traces it and consumes the result -- a frame of a row band is 5 launches instead
-// of 11 and none of them waits for the slowest wave of a traversal before the next short kernel may start.  Same buffers out as the
-// three-kernel form (the ray queue, the per-pixel ray slots, the occlusion words and the shading scratch are skipped: they were
-// only the kernels' way of talking to each other).  `spill`: kSpillStackDepth entries per tracing thread of the launch.
+// ---------------------------------------------------------------- the ray passes as ONE kernel each
+// trace_local.hip.h: the kernel that makes a ray traces it and consumes the result.  The G-buffer pass runs this way at every size
+// (primary rays are coherent: the wave-local traversal loses little to the missing refill); the candidate and shading passes where the
+// launch is a row band of a multi-GPU frame -- its frame is 4 launches instead of 11 and none of them waits for the slowest wave of a
+// traversal before the next short kernel may start (restir_launch decides).  Same buffers out as the three-kernel form; the ray queue,
+// the per-pixel ray slots, the occlusion words and the shading scratch are skipped: they were only the kernels' way of talking to each
+// other.  `spill`: spillCap (trace_local.hip.h local_spill_depth) stack entries per tracing thread of the launch.
 __global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel accel, gfx_hit* hits, uint2* spill, int spillCap, int useHint) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];
