@@ -682,7 +682,7 @@ class Context:
 
     def tunable_set(self, name, value):
         """Scheduling knob of this context ("pixel_map", "super_x", "super_y", "trace_blocks_per_cu", "trace_refill",
-        "trace_batch", "temporal_hints", "pt_overlap", "candidate_split", "fuse_passes"); changes no result."""
+        "trace_batch", "temporal_hints", "pt_overlap", "candidate_split", "fuse_passes", "block_order"); changes no result."""
         self._check(self.L.gfx_tunable_set(self.h, name.encode(), C.c_int(int(value))))
 
     def stream_copy(self, d_dst, d_src, nbytes, stream=0):

@@ -95,6 +95,7 @@ struct Tunables {
     int traceBatch = 64;             // rays bought per device atomic (32 and 128 are slower)
     int temporalHints = 1;           // primary rays test the triangle their pixel hit one frame ago first (trace.hip)
     int candidateSplit = 0;          // k_initial_candidates: lanes per pixel (1, 2, 4); 0 = by launch size (restir.hip)
+    int blockOrder = 1;              // k_initial_fused: blocks start by decreasing cost of one frame ago (restir.hip k_order_blocks); 0 = index order
     int fusePasses = 0;              // ReSTIR ray passes as one kernel each (restir.hip k_*_fused): 0 = small launches only, 1 never, 2 always
     int ptOverlap = 1;               // path tracers: the NEE (any-hit) trace + its apply kernel of a bounce run on a second stream underneath
                                      // the extension (closest-hit) trace of the same bounce (pathtrace.hip)
@@ -162,6 +163,10 @@ struct Context {
     // ... and the path tracers a third (stack spill + ticket areas) for the NEE trace that runs on `auxStream` underneath the extension
     // trace of the same bounce (pathtrace.hip); auxFork / auxJoin order the two streams
     DevBuf auxSpill, auxCounters;
+    // fused ReSTIR kernels (restir.hip): step counts per block of the last launch and the block order made from them, for one launch shape
+    // ([0] k_initial_fused, [1] k_shading_fused).  k_order_blocks runs on auxStream behind the launch that wrote the costs (`counted`);
+    // the next launch of that kind waits for `ordered`.
+    struct BlockOrder { DevBuf cost, order; uint64_t key = 0; uint32_t blocks = 0; bool valid = false; hipEvent_t counted = nullptr, ordered = nullptr; } blockOrders[2];
     hipStream_t auxStream = nullptr;
     hipEvent_t auxFork = nullptr, auxJoin = nullptr;
     // path tracer scratch (pathtrace.hip)

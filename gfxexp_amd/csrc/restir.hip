@@ -214,9 +214,9 @@ template <int CTRL> GFX_DEV float quad_perm(float v) {      // v of the lane qua
 template <int CTRL> GFX_DEV int quad_perm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
 // The pixel of launch thread t when SPLIT lanes share a pixel: thread t / SPLIT of the one-lane-per-pixel launch (same pixel, same ray slot).
 template <int SPLIT>
-GFX_DEV PixelId pixel_of_split_thread(const PixelGrid& g, uint32_t& sub) {
-    if (SPLIT == 1) { sub = 0u; return pixel_of_thread(g); }
-    const uint32_t launchThread = blockIdx.x * kBlock + threadIdx.x;
+GFX_DEV PixelId pixel_of_split_thread(const PixelGrid& g, uint32_t& sub, uint32_t block = blockIdx.x) {
+    if (SPLIT == 1) { sub = 0u; return pixel_of_block_thread(g, block, threadIdx.x); }
+    const uint32_t launchThread = block * kBlock + threadIdx.x;
     sub = launchThread & (SPLIT - 1);
     return pixel_of_block_thread(g, (launchThread / SPLIT) / kBlock, (launchThread / SPLIT) % kBlock);
 }
@@ -815,7 +815,8 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel
 // and the traversal stack live in the record buffers of the waves that have left, so a block holds 16 KB of LDS, not 24: ten blocks
 // fit a CU, and the one-wave tails of the blocks that trace do not keep new blocks out.
 template <bool EMITTER_TEX, int SPLIT, int MODE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap,
+                                                                                                                                    const uint32_t* __restrict__ blockOrder, uint32_t* __restrict__ blockCost) {
     static_assert(SPLIT == 1 || SPLIT == 4, "one lane per pixel, or four with the block's rays gathered in its first wave");
     constexpr int kRays = kBlock / SPLIT;
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];           // per wave: 256 x 16 B = 64 records
@@ -824,8 +825,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint4* waveBuf = fetchBuf + 256 * wave;
+    // Which pixels this block works for: the blocks of a launch start in index order, a few rounds of them per CU, and the launch ends
+    // when the last tracing wave has walked its longest ray -- so the blocks whose rays took longest one frame ago go first
+    // (blockOrder: a permutation made by k_order_blocks from the step counts this kernel leaves in blockCost; null: index order)
+    const uint32_t block = blockOrder ? blockOrder[blockIdx.x] : blockIdx.x;
     uint32_t sub;
-    PixelId px = pixel_of_split_thread<SPLIT>(a.px, sub);
+    PixelId px = pixel_of_split_thread<SPLIT>(a.px, sub, block);
     const CandidateRay r = initial_candidates<EMITTER_TEX, SPLIT>(a, waveBuf, lane, px, sub);
     float4 org = make_float4(r.org.x, r.org.y, r.org.z, 0.0f), dir = make_float4(r.dir.x, r.dir.y, r.dir.z, r.want ? r.tmax : -1.0f);
     uint2* stack = ownStack + tid;
@@ -838,29 +843,54 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
         if (tid >= kRays) return;
         const float4* from = reinterpret_cast<const float4*>(fetchBuf + 256 * (tid >> 4) + 224);
         org = from[2 * (tid & 15)]; dir = from[2 * (tid & 15) + 1];
-        const uint32_t t = blockIdx.x * kRays + tid;   // thread of the one-lane-per-pixel launch
+        const uint32_t t = block * kRays + tid;        // thread of the one-lane-per-pixel launch
         px = pixel_of_block_thread(a.px, t / kBlock, t % kBlock);
         stack = reinterpret_cast<uint2*>(fetchBuf + 256) + tid;   // buffers of waves 1 and 2 (their hand-over slots have just been read)
     }
     const bool want = dir.w > org.w;
+    uint32_t steps = 0;
     const RayHit h = trace_wave_local<true>(accel, want, f3(org.x, org.y, org.z), f3(dir.x, dir.y, dir.z), org.w, dir.w, stack, kRays,
-                                            spill + (static_cast<size_t>(blockIdx.x) * kRays + tid) * spillCap, spillCap, waveBuf, lane);
+                                            spill + (static_cast<size_t>(blockIdx.x) * kRays + tid) * spillCap, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
+    if (blockCost && lane == 0) atomicMax(blockCost + block, steps);      // (one tracing wave per block with four lanes per pixel, four with one)
     temporal_reuse<MODE>(a, px, want && h.tri != GFX_INVALID_SLOT);
+}
+
+// blockOrder = the blocks of the launch by decreasing cost (counting sort over min(cost, 255): the order inside a class is whatever the
+// LDS atomics make it -- any permutation gives the same image); the costs are cleared for the next frame.  One block of 1024 threads.
+__global__ __launch_bounds__(1024) void k_order_blocks(uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order) {
+    __shared__ uint32_t start[256];
+    if (threadIdx.x < 256) start[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&start[255u - min(cost[i], 255u)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (int c = 0; c < 256; ++c) { const uint32_t k = start[c]; start[c] = sum; sum += k; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        order[atomicAdd(&start[255u - min(cost[i], 255u)], 1u)] = i;
+        cost[i] = 0u;
+    }
 }
 
 // SPATIAL_FIRST: GFX_RESTIR_SPATIAL_BIASED_AND_SHADING -- the pixel's last spatial pass (it reads neighbours in reservoir a.curRes and
 // writes the pixel's own entry of the other one), then the shading of that entry by the same thread.
 template <bool SPATIAL_FIRST>
-__global__ __launch_bounds__(kBlock) void k_shading_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap) {
+__global__ __launch_bounds__(kBlock) void k_shading_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap,
+                                                          const uint32_t* __restrict__ blockOrder, uint32_t* __restrict__ blockCost) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];
     const int tid = threadIdx.x, lane = tid & 63;
     uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);
-    const PixelId px = pixel_of_thread(a.px);
+    const uint32_t block = blockOrder ? blockOrder[blockIdx.x] : blockIdx.x;      // costliest blocks of one frame ago first (k_initial_fused)
+    const PixelId px = pixel_of_block_thread(a.px, block, threadIdx.x);
     if (SPATIAL_FIRST) spatial_reuse<false>(a, px);
     const ShadeState st = shade_prepare(a, px, SPATIAL_FIRST ? (a.curRes + 1) % 2 : a.curRes);
+    uint32_t steps = 0;
     const RayHit h = trace_wave_local<true>(accel, st.want, st.ro, st.rd, 0.0f, st.tmax, ldsStack + tid, kBlock,
-                                            spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * spillCap, spillCap, waveBuf, lane);
+                                            spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * spillCap, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
+    if (blockCost && lane == 0) atomicMax(blockCost + block, steps);
     if (px.valid) shade_finish(a, px, st.contribution, st.direct, st.recPDF, st.want && h.tri != GFX_INVALID_SLOT);
 }
 
@@ -1003,6 +1033,35 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     const int spillCap = static_cast<int>(local_spill_depth(ctx.accels[ctx.restir.f.travHandle - 1]->maxDepth));   // stack entries per thread behind the LDS part
     const size_t fusedSpillBytes = sizeof(uint2) * static_cast<size_t>(a.px.launchBlocks) * kBlock * spillCap;
     const bool fused = !ctx.countersEnabled && fusedSpillBytes <= (size_t(1) << 30) && (ctx.tune.fusePasses == 2 || (ctx.tune.fusePasses == 0 && fusableLaunch));
+    // Cost-ordered block start for the fused kernels whose launch is several rounds of blocks: the launch ends when its last tracing wave
+    // has walked its longest ray, so the blocks whose rays took longest one frame ago start first ("block_order" 0: index order).  The
+    // kernel leaves its step counts per block; k_order_blocks turns them into the next launch's order on the context's side stream.
+    auto block_order_begin = [&](int which, uint32_t blocks, uint32_t variant, const uint32_t*& order, uint32_t*& cost) {
+        order = nullptr; cost = nullptr;
+        if (!ctx.tune.blockOrder || blocks <= 8u * static_cast<uint32_t>(ctx.numCUs)) return;     // about one round: they all start together
+        Context::BlockOrder& bo = ctx.blockOrders[which];
+        const uint64_t key = (static_cast<uint64_t>(rowBegin) << 44) ^ (static_cast<uint64_t>(rowEnd) << 24) ^ (static_cast<uint64_t>(width) << 4) ^ variant;
+        if (bo.key != key || bo.blocks != blocks) {
+            if (bo.ordered) GFX_HIP(hipStreamWaitEvent(stream, bo.ordered, 0));    // a sort of the old shape may still be running
+            bo.cost.reserve(sizeof(uint32_t) * blocks); bo.order.reserve(sizeof(uint32_t) * blocks);
+            GFX_HIP(hipMemsetAsync(bo.cost.p, 0, sizeof(uint32_t) * blocks, stream));
+            bo.key = key; bo.blocks = blocks; bo.valid = false;
+        }
+        cost = bo.cost.as<uint32_t>();
+        if (bo.valid) { GFX_HIP(hipStreamWaitEvent(stream, bo.ordered, 0)); order = bo.order.as<uint32_t>(); }
+    };
+    auto block_order_end = [&](int which, uint32_t blocks, uint32_t* cost) {
+        if (!cost) return;
+        Context::BlockOrder& bo = ctx.blockOrders[which];
+        if (!ctx.auxStream) GFX_HIP(hipStreamCreateWithFlags(&ctx.auxStream, hipStreamNonBlocking));
+        if (!bo.counted) { GFX_HIP(hipEventCreateWithFlags(&bo.counted, hipEventDisableTiming)); GFX_HIP(hipEventCreateWithFlags(&bo.ordered, hipEventDisableTiming)); }
+        GFX_HIP(hipEventRecord(bo.counted, stream));
+        GFX_HIP(hipStreamWaitEvent(ctx.auxStream, bo.counted, 0));
+        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx.auxStream, cost, blocks, bo.order.as<uint32_t>());
+        GFX_HIP(hipGetLastError());
+        GFX_HIP(hipEventRecord(bo.ordered, ctx.auxStream));
+        bo.valid = true;
+    };
     switch (pass) {
     case GFX_RESTIR_SETUP_GBUFFERS: {
         // own scratch set (internal.h): this pass may overlap other passes of the previous frame.  One queue entry per
@@ -1054,14 +1113,20 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
                 const DevAccel accel = ctx.accels[ctx.restir.f.travHandle - 1]->dev();
                 const int mode = pass == GFX_RESTIR_INITIAL_RIS ? 0 : pass == GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED ? 1 : 2;
                 const bool tex = a.scene.emitterTexRefs != nullptr;
-                void (*kernel)(RestirArgs, DevAccel, uint2*, int) = nullptr;
+                void (*kernel)(RestirArgs, DevAccel, uint2*, int, const uint32_t*, uint32_t*) = nullptr;
 #define GFX_PICK(TEX, SPLIT) (mode == 0 ? k_initial_fused<TEX, SPLIT, 0> : mode == 1 ? k_initial_fused<TEX, SPLIT, 1> : k_initial_fused<TEX, SPLIT, 2>)
                 if (tex) kernel = split == 4 ? GFX_PICK(true, 4) : GFX_PICK(true, 1);
                 else kernel = split == 4 ? GFX_PICK(false, 4) : GFX_PICK(false, 1);
 #undef GFX_PICK
-                ScopedKernelTimer timer(ctx, stream, "initial_fused");
-                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap);
-                GFX_HIP(hipGetLastError());
+                const uint32_t* order = nullptr;
+                uint32_t* cost = nullptr;
+                block_order_begin(0, grid, split, order, cost);
+                {
+                    ScopedKernelTimer timer(ctx, stream, "initial_fused");
+                    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap, order, cost);
+                    GFX_HIP(hipGetLastError());
+                }
+                block_order_end(0, grid, cost);
                 break;
             }
             ScopedKernelTimer timer(ctx, stream, "initial_candidates");
@@ -1090,10 +1155,16 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         if (fused) {
             ctx.spill.reserve(fusedSpillBytes);
             const bool both = pass == GFX_RESTIR_SPATIAL_BIASED_AND_SHADING;
-            ScopedKernelTimer timer(ctx, stream, both ? "spatial_shading_fused" : "shading_fused");
-            hipLaunchKernelGGL(both ? k_shading_fused<true> : k_shading_fused<false>, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a,
-                               ctx.accels[ctx.restir.f.travHandle - 1]->dev(), ctx.spill.as<uint2>(), spillCap);
-            GFX_HIP(hipGetLastError());
+            const uint32_t* order = nullptr;
+            uint32_t* cost = nullptr;
+            block_order_begin(1, a.px.launchBlocks, both ? 1u : 0u, order, cost);
+            {
+                ScopedKernelTimer timer(ctx, stream, both ? "spatial_shading_fused" : "shading_fused");
+                hipLaunchKernelGGL(both ? k_shading_fused<true> : k_shading_fused<false>, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a,
+                                   ctx.accels[ctx.restir.f.travHandle - 1]->dev(), ctx.spill.as<uint2>(), spillCap, order, cost);
+                GFX_HIP(hipGetLastError());
+            }
+            block_order_end(1, a.px.launchBlocks, cost);
             break;
         }
         if (pass == GFX_RESTIR_SPATIAL_BIASED_AND_SHADING) {

@@ -13,7 +13,7 @@ namespace gfx {
 Context::~Context() {
     for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->triIds.release(); a->rootBoxes.release(); delete a; } }
     DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dSubset[0], &dSubset[1], &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs, &dEmitterRecExtras, &dLightNormalMatrices, &dInstMatrixIndex, &dTextures, &dTexelPool, &dSrgbLut, &dEmitterTexRefs,
-                      &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &auxSpill, &auxCounters, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
+                      &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &auxSpill, &auxCounters, &blockOrders[0].cost, &blockOrders[0].order, &blockOrders[1].cost, &blockOrders[1].order, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
                       &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide, &dSpans, &dSpanGuide, &dSpanHeader, &dSpanInstBegin,
                       &dTraceDiag, &bCosts, &bDec, &bFlatIdx, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
@@ -23,6 +23,7 @@ Context::~Context() {
     for (auto& e : pendingEvents) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
     for (TicketState& ts : ticketState) if (ts.lastLaunch) (void)hipEventDestroy(ts.lastLaunch);
     for (PinnedStage& st : lightStage) { if (st.done) (void)hipEventDestroy(st.done); if (st.p) (void)hipHostFree(st.p); }
+    for (BlockOrder& b : blockOrders) { if (b.counted) (void)hipEventDestroy(b.counted); if (b.ordered) (void)hipEventDestroy(b.ordered); }
     if (auxFork) (void)hipEventDestroy(auxFork);
     if (auxJoin) (void)hipEventDestroy(auxJoin);
     if (auxStream) (void)hipStreamDestroy(auxStream);

@@ -29,9 +29,10 @@ inline uint32_t local_spill_depth(uint32_t maxDepth) {
 //   waveBuf                 256 x 16 B of LDS private to the wave (the cooperative fetch)
 //   hint                    closest hit only: a triangle record to test right after the root (k_trace's temporal hint), or an
 //                           index >= numTris for none
+//   waveSteps               optional out: how many steps the wave took (its longest ray)
 template <bool ANY_HIT>
 GFX_DEV RayHit trace_wave_local(const DevAccel& accel, bool want, f3 org, f3 dir, float tmin, float tmax, uint2* stackLds, int stackStride,
-                                uint2* stackSpill, int spillCap, uint4* waveBuf, int lane, uint32_t hint = 0xFFFFFFFFu) {
+                                uint2* stackSpill, int spillCap, uint4* waveBuf, int lane, uint32_t hint = 0xFFFFFFFFu, uint32_t* waveSteps = nullptr) {
     LaneStack stack;
     stack.lds = stackLds; stack.ldsStride = stackStride; stack.spill = stackSpill; stack.sp = 0; stack.spillCap = spillCap;
     const bool hasNodes = accel.numNodes != 0;
@@ -40,7 +41,9 @@ GFX_DEV RayHit trace_wave_local(const DevAccel& accel, bool want, f3 org, f3 dir
     tr.active = want && hasNodes && tmax > tmin;        // an empty interval or an empty scene: a miss (hit.t = tmax, no triangle)
     TraceCounters cnt = { 0, 0, 0 };
     bool first = true;
+    uint32_t steps = 0;                                  // wave-uniform: iterations until the wave's last ray has ended
     while (__ballot(tr.active) != 0ull) {
+        ++steps;
         uint32_t code = kItemNone;
         if (tr.active) code = tr.next_item(stack, accel.triItemOffset);      // the first item of a ray is the root (begin's one-child group)
         uint4 link = make_uint4(0u, 0u, 0u, 0u);
@@ -54,6 +57,7 @@ GFX_DEV RayHit trace_wave_local(const DevAccel& accel, bool want, f3 org, f3 dir
         if (!ANY_HIT && first && tr.active && hint < accel.numTris && tr.triMask == 0u) { tr.triBase = hint; tr.triMask = 0x0101u; }
         first = false;
     }
+    if (waveSteps) *waveSteps = steps;
     return tr.hit;
 }
 

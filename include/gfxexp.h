@@ -509,6 +509,9 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
  *                               frame); GFX_PT_PATH_TRACE_BASELINE / _REGIR (the whole path of a pixel in one kernel) for launches of about
  *                               one round of waves (512 x 512).  1 never, 2 always (GFX_FUSE_PASSES).  Counting launches
  *                               (gfx_counters_enable) always take the k_trace form.
+ *   "block_order" 0|1           fused GFX_RESTIR_INITIAL_* / _SHADING kernels whose launch is several rounds of blocks start their blocks by
+ *                               decreasing cost (traversal steps of the block's longest ray) of the same launch one frame ago instead of in
+ *                               index order: the launch ends when its last tracing wave does (default 1; GFX_BLOCK_ORDER)
  *   "candidate_split" 0|1|2|4   lanes per pixel in the candidate loop of the initial-RIS passes (GFX_RESTIR_INITIAL_*): the lanes take the
  *                               pixel's candidates round robin and the reservoir is formed as the sequential loop forms it; 0 (default)
  *                               = by launch size: 4 when the launch fills the GPU's wave slots at most ~1.5 times (a row band of an

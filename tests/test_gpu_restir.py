@@ -386,3 +386,49 @@ def test_spatial_and_shading_as_one_pass(built_lib, fuse):
         for k in want:
             assert np.array_equal(np.ascontiguousarray(got[k]).view(np.uint8), np.ascontiguousarray(want[k]).view(np.uint8)), f"frame {frame}: {k}"
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("band", [(136, 272), (128, 416)])
+def test_block_start_order_of_the_fused_kernels_changes_nothing(built_lib, band):
+    """A band of a 1920-wide frame through the headless driver, four frames: 136 rows (four lanes per pixel: 4 080 blocks of
+    k_initial_fused start in cost order) and 288 rows (one lane per pixel: 2 160 blocks of k_initial_fused and of k_shading_fused do).
+    Index order ("block_order" 0) and cost order (1, in effect from the second frame on) leave the same beauty, reservoirs, reservoir
+    infos and RNG states, bit for bit -- and so does the three-kernel form."""
+    import torch
+    from gfxexp_amd import scenes
+    W, H = 1920, 544
+    hs = scenes.bench_street(textured=True)
+    cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
+
+    def render(tunables):
+        ctx = api.Context(0)
+        for k, v in tunables.items():
+            ctx.tunable_set(k, v)
+        hs.upload(ctx)
+        cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
+        cfg.camera = cam
+        cfg.enableBumpMapping = 1
+        cfg.rowBegin, cfg.rowEnd = band
+        r = api.RestirRenderer(ctx, cfg)
+        r.set_exchange(lambda stream, d: None, 0)
+        for _ in range(4):
+            r.render_frame()
+        torch.cuda.synchronize()
+        s, f, cur, base, _ = r.params()
+        n = W * H
+        out = {"beauty": ctx.read_device(r.beauty_ptr(), 16 * n), "rng": ctx.read_device(s.rngBuffer, 8 * n)}
+        for i in range(2):
+            out[f"res{i}"] = ctx.read_device(s.reservoirBuffer[i], 48 * n)
+            out[f"info{i}"] = ctx.read_device(s.reservoirInfoBuffer[i], 8 * n)
+        rows = slice(band[0] * W, band[1] * W)
+        out = {k: (np.frombuffer(v, np.uint8).reshape(3, n, 16)[:, rows] if k.startswith("res") else np.frombuffer(v, np.uint8).reshape(n, -1)[rows]).copy()
+               for k, v in out.items()}
+        r.close()
+        ctx.close()
+        return out
+
+    ordered = render({"block_order": 1})
+    for name, other in (("index order", render({"block_order": 0})), ("three kernels per ray pass", render({"fuse_passes": 1}))):
+        for k in ordered:
+            assert np.array_equal(ordered[k], other[k]), f"{name}: {k} differs"
