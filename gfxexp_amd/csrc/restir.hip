@@ -214,7 +214,7 @@ template <int CTRL> GFX_DEV float quad_perm(float v) {      // v of the lane qua
 template <int CTRL> GFX_DEV int quad_perm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
 // The pixel of launch thread t when SPLIT lanes share a pixel: thread t / SPLIT of the one-lane-per-pixel launch (same pixel, same ray slot).
 template <int SPLIT>
-GFX_DEV PixelId pixel_of_split_thread(const PixelGrid& g, uint32_t& sub, uint32_t block = blockIdx.x) {
+GFX_DEV PixelId pixel_of_split_thread(const PixelGrid& g, uint32_t& sub, uint32_t block) {
     if (SPLIT == 1) { sub = 0u; return pixel_of_block_thread(g, block, threadIdx.x); }
     const uint32_t launchThread = block * kBlock + threadIdx.x;
     sub = launchThread & (SPLIT - 1);
@@ -370,17 +370,22 @@ GFX_DEV CandidateRay initial_candidates(const RestirArgs& a, uint4* waveBuf, int
     return r;
 }
 template <bool EMITTER_TEX, int SPLIT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a, uint32_t* __restrict__ blockCost) {
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];   // per wave: 256 x 16 B = 64 records
     const int lane = threadIdx.x & 63;
     uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, kept scalar
+    // costliest blocks of one frame ago first (a.px.order, k_order_blocks): sky tiles cost nothing, tiles in reach of many textured emitters
+    // the most, and the launch is eight rounds of blocks; the cost of a block = the clock its slowest wave spent here, in units of 2048 cycles
+    const uint32_t block = launch_block(a.px);
+    const unsigned long long t0 = blockCost ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t sub;
-    const PixelId px = pixel_of_split_thread<SPLIT>(a.px, sub);
+    const PixelId px = pixel_of_split_thread<SPLIT>(a.px, sub, block);
     const CandidateRay r = initial_candidates<EMITTER_TEX, SPLIT>(a, waveBuf, lane, px, sub);
     if (r.writer) {
         const uint32_t slot = emit_ray_at_slot(px, r.want, r.org, r.dir, 0.0f, r.tmax, a);
         if (px.valid) a.pixelRaySlot[px.p] = slot;
     }
+    if (blockCost && lane == 0) atomicMax(blockCost + block, static_cast<uint32_t>((__builtin_amdgcn_s_memtime() - t0) >> 11));
 }
 
 // visibility application + temporal reuse: optix_restir_di_kernels.cu:128-286
@@ -794,17 +799,20 @@ __global__ __launch_bounds__(kBlock) void k_shade_finish(RestirArgs a) {
 // traversal before the next short kernel may start (restir_launch decides).  Same buffers out as the three-kernel form; the ray queue,
 // the per-pixel ray slots, the occlusion words and the shading scratch are skipped: they were only the kernels' way of talking to each
 // other.  `spill`: spillCap (trace_local.hip.h local_spill_depth) stack entries per tracing thread of the launch.
-__global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel accel, gfx_hit* hits, uint2* spill, int spillCap, int useHint) {
+__global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel accel, gfx_hit* hits, uint2* spill, int spillCap, int useHint, uint32_t* __restrict__ blockCost) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];
     const int tid = threadIdx.x, lane = tid & 63;
     uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);
-    const PixelId px = pixel_of_thread(a.px);
+    const uint32_t block = launch_block(a.px);                                     // costliest blocks of one frame ago first (k_order_blocks)
+    const PixelId px = pixel_of_block_thread(a.px, block, threadIdx.x);
     const RayPair r = primary_ray(a, px);
     // the triangle this pixel's primary ray hit one frame ago is tested right after the root (trace.hip: temporal hint)
     const uint32_t hint = useHint ? hits[px.slot].triIndex : 0xFFFFFFFFu;
+    uint32_t steps = 0;
     const RayHit h = trace_wave_local<false>(accel, true, f3(r.org.x, r.org.y, r.org.z), f3(r.dir.x, r.dir.y, r.dir.z), r.org.w, r.dir.w, ldsStack + tid, kBlock,
-                                             spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * spillCap, spillCap, waveBuf, lane, hint);
+                                             spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * spillCap, spillCap, waveBuf, lane, hint, &steps);
+    if (blockCost && lane == 0) atomicMax(blockCost + block, steps);
     gfx_hit gh; gh.dist = h.t; gh.bcB = h.bcB; gh.bcC = h.bcC; gh.triIndex = h.tri;
     hits[px.slot] = gh;                          // the next frame's hint
     if (px.valid) gbuffer_resolve(a, px, gh, f3(r.dir.x, r.dir.y, r.dir.z));
@@ -815,8 +823,7 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel
 // and the traversal stack live in the record buffers of the waves that have left, so a block holds 16 KB of LDS, not 24: ten blocks
 // fit a CU, and the one-wave tails of the blocks that trace do not keep new blocks out.
 template <bool EMITTER_TEX, int SPLIT, int MODE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap,
-                                                                                                                                    const uint32_t* __restrict__ blockOrder, uint32_t* __restrict__ blockCost) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap, uint32_t* __restrict__ blockCost) {
     static_assert(SPLIT == 1 || SPLIT == 4, "one lane per pixel, or four with the block's rays gathered in its first wave");
     constexpr int kRays = kBlock / SPLIT;
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];           // per wave: 256 x 16 B = 64 records
@@ -827,8 +834,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
     uint4* waveBuf = fetchBuf + 256 * wave;
     // Which pixels this block works for: the blocks of a launch start in index order, a few rounds of them per CU, and the launch ends
     // when the last tracing wave has walked its longest ray -- so the blocks whose rays took longest one frame ago go first
-    // (blockOrder: a permutation made by k_order_blocks from the step counts this kernel leaves in blockCost; null: index order)
-    const uint32_t block = blockOrder ? blockOrder[blockIdx.x] : blockIdx.x;
+    // (a.px.order: a permutation made by k_order_blocks from the step counts this kernel leaves in blockCost; null: index order)
+    const uint32_t block = launch_block(a.px);
     uint32_t sub;
     PixelId px = pixel_of_split_thread<SPLIT>(a.px, sub, block);
     const CandidateRay r = initial_candidates<EMITTER_TEX, SPLIT>(a, waveBuf, lane, px, sub);
@@ -877,13 +884,12 @@ __global__ __launch_bounds__(1024) void k_order_blocks(uint32_t* __restrict__ co
 // SPATIAL_FIRST: GFX_RESTIR_SPATIAL_BIASED_AND_SHADING -- the pixel's last spatial pass (it reads neighbours in reservoir a.curRes and
 // writes the pixel's own entry of the other one), then the shading of that entry by the same thread.
 template <bool SPATIAL_FIRST>
-__global__ __launch_bounds__(kBlock) void k_shading_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap,
-                                                          const uint32_t* __restrict__ blockOrder, uint32_t* __restrict__ blockCost) {
+__global__ __launch_bounds__(kBlock) void k_shading_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap, uint32_t* __restrict__ blockCost) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];
     const int tid = threadIdx.x, lane = tid & 63;
     uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t block = blockOrder ? blockOrder[blockIdx.x] : blockIdx.x;      // costliest blocks of one frame ago first (k_initial_fused)
+    const uint32_t block = launch_block(a.px);                                     // costliest blocks of one frame ago first (k_initial_fused)
     const PixelId px = pixel_of_block_thread(a.px, block, threadIdx.x);
     if (SPATIAL_FIRST) spatial_reuse<false>(a, px);
     const ShadeState st = shade_prepare(a, px, SPATIAL_FIRST ? (a.curRes + 1) % 2 : a.curRes);
@@ -1037,7 +1043,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     // has walked its longest ray, so the blocks whose rays took longest one frame ago start first ("block_order" 0: index order).  The
     // kernel leaves its step counts per block; k_order_blocks turns them into the next launch's order on the context's side stream.
     auto block_order_begin = [&](int which, uint32_t blocks, uint32_t variant, const uint32_t*& order, uint32_t*& cost) {
-        order = nullptr; cost = nullptr;
+        order = nullptr; cost = nullptr; a.px.order = nullptr;
         if (!ctx.tune.blockOrder || blocks <= 8u * static_cast<uint32_t>(ctx.numCUs)) return;     // about one round: they all start together
         Context::BlockOrder& bo = ctx.blockOrders[which];
         const uint64_t key = (static_cast<uint64_t>(rowBegin) << 44) ^ (static_cast<uint64_t>(rowEnd) << 24) ^ (static_cast<uint64_t>(width) << 4) ^ variant;
@@ -1049,6 +1055,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         }
         cost = bo.cost.as<uint32_t>();
         if (bo.valid) { GFX_HIP(hipStreamWaitEvent(stream, bo.ordered, 0)); order = bo.order.as<uint32_t>(); }
+        a.px.order = order;
     };
     auto block_order_end = [&](int which, uint32_t blocks, uint32_t* cost) {
         if (!cost) return;
@@ -1062,6 +1069,9 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         GFX_HIP(hipEventRecord(bo.ordered, ctx.auxStream));
         bo.valid = true;
     };
+    // (Not for the kernels that gather from neighbouring pixels: started in the candidate kernel's cost order k_spatial took 0.47 ms per
+    // frame instead of 0.37 -- blocks of equal cost are scattered over the image, and the XCD-supertile block order is what keeps a tile's
+    // neighbours in its XCD's L2.  profiles/r04_experiments.txt 19.)
     switch (pass) {
     case GFX_RESTIR_SETUP_GBUFFERS: {
         // own scratch set (internal.h): this pass may overlap other passes of the previous frame.  One queue entry per
@@ -1077,10 +1087,16 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         // ReSTIR at 1920x1080: 2.250 -> 2.115 ms per frame, NRC 3.65 -> 3.53) -- fused unless "fuse_passes" says never
         if (!ctx.countersEnabled && fusedSpillBytes <= (size_t(1) << 30) && ctx.tune.fusePasses != 1) {
             ctx.gbSpill.reserve(fusedSpillBytes);
-            ScopedKernelTimer timer(ctx, stream, "gbuffer_fused");
-            hipLaunchKernelGGL(k_gbuffer_fused, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a, ctx.accels[ctx.restir.f.travHandle - 1]->dev(),
-                               ctx.gbRayHits.as<gfx_hit>(), ctx.gbSpill.as<uint2>(), spillCap, ctx.tune.temporalHints ? 1 : 0);
-            GFX_HIP(hipGetLastError());
+            const uint32_t* order = nullptr;
+            uint32_t* cost = nullptr;
+            block_order_begin(2, a.px.launchBlocks, 0u, order, cost);
+            {
+                ScopedKernelTimer timer(ctx, stream, "gbuffer_fused");
+                hipLaunchKernelGGL(k_gbuffer_fused, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a, ctx.accels[ctx.restir.f.travHandle - 1]->dev(),
+                                   ctx.gbRayHits.as<gfx_hit>(), ctx.gbSpill.as<uint2>(), spillCap, ctx.tune.temporalHints ? 1 : 0, cost);
+                GFX_HIP(hipGetLastError());
+            }
+            block_order_end(2, a.px.launchBlocks, cost);
             break;
         }
         launch_pixels(ctx, stream, "primary_rays", k_primary_rays, a);
@@ -1113,7 +1129,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
                 const DevAccel accel = ctx.accels[ctx.restir.f.travHandle - 1]->dev();
                 const int mode = pass == GFX_RESTIR_INITIAL_RIS ? 0 : pass == GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED ? 1 : 2;
                 const bool tex = a.scene.emitterTexRefs != nullptr;
-                void (*kernel)(RestirArgs, DevAccel, uint2*, int, const uint32_t*, uint32_t*) = nullptr;
+                void (*kernel)(RestirArgs, DevAccel, uint2*, int, uint32_t*) = nullptr;
 #define GFX_PICK(TEX, SPLIT) (mode == 0 ? k_initial_fused<TEX, SPLIT, 0> : mode == 1 ? k_initial_fused<TEX, SPLIT, 1> : k_initial_fused<TEX, SPLIT, 2>)
                 if (tex) kernel = split == 4 ? GFX_PICK(true, 4) : GFX_PICK(true, 1);
                 else kernel = split == 4 ? GFX_PICK(false, 4) : GFX_PICK(false, 1);
@@ -1123,18 +1139,25 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
                 block_order_begin(0, grid, split, order, cost);
                 {
                     ScopedKernelTimer timer(ctx, stream, "initial_fused");
-                    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap, order, cost);
+                    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap, cost);
                     GFX_HIP(hipGetLastError());
                 }
                 block_order_end(0, grid, cost);
                 break;
             }
-            ScopedKernelTimer timer(ctx, stream, "initial_candidates");
-            void (*kernel)(RestirArgs) = a.scene.emitterTexRefs
+            void (*kernel)(RestirArgs, uint32_t*) = a.scene.emitterTexRefs
                 ? (split == 4 ? k_initial_candidates<true, 4> : split == 2 ? k_initial_candidates<true, 2> : k_initial_candidates<true, 1>)
                 : (split == 4 ? k_initial_candidates<false, 4> : split == 2 ? k_initial_candidates<false, 2> : k_initial_candidates<false, 1>);
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a);
-            GFX_HIP(hipGetLastError());
+            const uint32_t* order = nullptr;
+            uint32_t* cost = nullptr;
+            block_order_begin(3, grid, split, order, cost);
+            {
+                ScopedKernelTimer timer(ctx, stream, "initial_candidates");
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a, cost);
+                GFX_HIP(hipGetLastError());
+            }
+            block_order_end(3, grid, cost);
+            a.px.order = nullptr;                      // the trace and the temporal kernel below run in index order
         }
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p);   // one entry per launch slot (emit_ray_at_slot)
         if (pass == GFX_RESTIR_INITIAL_RIS) launch_pixels(ctx, stream, "temporal_none", k_temporal<0>, a);
@@ -1161,7 +1184,7 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
             {
                 ScopedKernelTimer timer(ctx, stream, both ? "spatial_shading_fused" : "shading_fused");
                 hipLaunchKernelGGL(both ? k_shading_fused<true> : k_shading_fused<false>, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a,
-                                   ctx.accels[ctx.restir.f.travHandle - 1]->dev(), ctx.spill.as<uint2>(), spillCap, order, cost);
+                                   ctx.accels[ctx.restir.f.travHandle - 1]->dev(), ctx.spill.as<uint2>(), spillCap, cost);
                 GFX_HIP(hipGetLastError());
             }
             block_order_end(1, a.px.launchBlocks, cost);

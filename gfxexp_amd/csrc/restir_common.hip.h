@@ -37,6 +37,7 @@ struct PixelGrid {
     uint32_t superShiftX, superShiftY;  // log2 of the supertile size in blocks
     uint32_t supersX;
     uint32_t launchBlocks;              // grid size (host side)
+    const uint32_t* order;              // optional: hardware block b works as block order[b] of the launch (a permutation: cost-ordered start, restir.hip)
 };
 struct PixelId { size_t p; int x, y; uint32_t slot; bool valid; };
 // Pixel of thread `tid` (0..255) of 256-thread block `block` of the launch; a block index past the launch owns no pixel.
@@ -68,12 +69,15 @@ GFX_DEV PixelId pixel_of_block_thread(const PixelGrid& g, uint32_t block, uint32
     return r;
 }
 
-GFX_DEV PixelId pixel_of_thread(const PixelGrid& g) { return pixel_of_block_thread(g, blockIdx.x, threadIdx.x); }
+// The block of the launch this hardware block works as.
+GFX_DEV uint32_t launch_block(const PixelGrid& g) { return g.order ? g.order[blockIdx.x] : blockIdx.x; }
+GFX_DEV PixelId pixel_of_thread(const PixelGrid& g) { return pixel_of_block_thread(g, launch_block(g), threadIdx.x); }
 
 // host side: the grid of a per-pixel launch over rows [rowBegin, rowEnd) (Context::pixelMap* = the mode, internal.h)
 inline PixelGrid make_pixel_grid(const Context& ctx, uint32_t width, uint32_t rowBegin, uint32_t rowEnd) {
     PixelGrid g;
     g.width = width; g.rowBegin = rowBegin; g.rowEnd = rowEnd;
+    g.order = nullptr;
     g.mode = static_cast<uint32_t>(ctx.tune.pixelMap);
     const uint32_t rows = rowEnd - rowBegin;
     g.blocksX = (width + 15u) / 16u; g.blocksY = (rows + 15u) / 16u;
