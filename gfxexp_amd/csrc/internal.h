@@ -164,9 +164,9 @@ struct Context {
     // trace of the same bounce (pathtrace.hip); auxFork / auxJoin order the two streams
     DevBuf auxSpill, auxCounters;
     // fused ReSTIR kernels (restir.hip): step counts per block of the last launch and the block order made from them, for one launch shape
-    // ([0] k_initial_fused, [1] k_shading_fused, [2] k_gbuffer_fused, [3] k_initial_candidates).  k_order_blocks runs on auxStream behind the launch that wrote the costs (`counted`);
+    // ([0] k_initial_fused, [1] k_shading_fused, [2] k_gbuffer_fused, [3] k_initial_candidates, [4] k_pt_fused).  k_order_blocks runs on auxStream behind the launch that wrote the costs (`counted`);
     // the next launch of that kind waits for `ordered`.
-    struct BlockOrder { DevBuf cost, order; uint64_t key = 0; uint32_t blocks = 0; bool valid = false; hipEvent_t counted = nullptr, ordered = nullptr; } blockOrders[4];
+    struct BlockOrder { DevBuf cost, order; uint64_t key = 0; uint32_t blocks = 0; bool valid = false; hipEvent_t counted = nullptr, ordered = nullptr; } blockOrders[5];
     hipStream_t auxStream = nullptr;
     hipEvent_t auxFork = nullptr, auxJoin = nullptr;
     // path tracer scratch (pathtrace.hip)
@@ -236,6 +236,9 @@ struct TraceLaunch {
                                     // the previous frame): each ray tests that triangle first (trace.hip)
 };
 void trace_launch(Context& ctx, hipStream_t stream, const TraceLaunch& t);
+// ---- restir.hip: cost-ordered block start (Context::blockOrders)
+void block_order_begin(Context& ctx, hipStream_t stream, int which, uint32_t blocks, uint64_t key, uint32_t minBlocks, const uint32_t*& order, uint32_t*& cost);
+void block_order_end(Context& ctx, hipStream_t stream, int which, uint32_t blocks, uint32_t* cost);
 // ---- diag.hip
 void stream_copy(Context& ctx, hipStream_t stream, void* dDst, const void* dSrc, size_t bytes);
 // ---- textures.hip

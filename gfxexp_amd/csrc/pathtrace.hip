@@ -674,19 +674,21 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_finish(PtArgs a) {
 // slowest wave.  A lane whose path has ended idles until its wave's longest path has (no compaction: that is the price, and why large
 // launches keep the wavefront form).
 template <bool REGIR>
-__global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel, uint2* spill, int spillCap, uint32_t maxPathLength) {
+__global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel, uint2* spill, int spillCap, uint32_t maxPathLength, uint32_t* __restrict__ blockCost) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kPtBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kPtBlock / 64) * 256];
     const int tid = threadIdx.x, lane = tid & 63;
     uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);
     uint2* stackLds = ldsStack + tid;
     uint2* stackSpill = spill + (static_cast<size_t>(blockIdx.x) * kPtBlock + tid) * spillCap;
-    const PixelId px = pixel_of_thread(a.px);
+    const PixelId px = pixel_of_thread(a.px);                   // (a.px.order: the blocks whose paths took most steps one frame ago start first)
+    uint32_t steps = 0, totalSteps = 0;
     PtPath path;
     bool rngMoved = pt_first_vertex<REGIR>(a, px, path);       // a.pathLength = 1 (set by the host)
     for (uint32_t pathLength = 2;; ++pathLength) {
         const RayHit shadow = trace_wave_local<true>(accel, path.o.wantNee, path.o.neeFromOrg ? path.o.neeOrg : path.pos, path.o.neeDir, 0.0f, path.o.neeTmax,
-                                                     stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane);
+                                                     stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
+        totalSteps += steps;
         if (path.o.wantNee) {                                   // k_pt_apply_nee
             f3 add = path.o.pending;
             if (shadow.tri != GFX_INVALID_SLOT) add = add * 0.0f;
@@ -696,12 +698,14 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel,
         if (__ballot(path.o.wantExt) == 0ull) break;            // no path of the wave goes on: nothing further can be added
         const bool extend = path.o.wantExt;
         const f3 rayOrg = path.pos, rayDir = path.o.extDir;
-        const RayHit hit = trace_wave_local<false>(accel, extend, rayOrg, rayDir, 0.0f, 3.402823466e+38f, stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane);
+        const RayHit hit = trace_wave_local<false>(accel, extend, rayOrg, rayDir, 0.0f, 3.402823466e+38f, stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
+        totalSteps += steps;
         gfx_hit h; h.dist = hit.t; h.bcB = hit.bcB; h.bcC = hit.bcC; h.triIndex = hit.tri;
         const bool lastVertex = pathLength >= maxPathLength;     // what the host sets per bounce launch in the wavefront form
         if (pt_next_vertex<REGIR>(a, extend, h, rayOrg, rayDir, nullptr, path, lastVertex ? 1 : 0, pathLength + 1 >= maxPathLength ? 1 : 0) & kPtHitSurface) rngMoved = true;
         if (!REGIR && lastVertex) break;
     }
+    if (blockCost && lane == 0) atomicMax(blockCost + launch_block(a.px), totalSteps >> 1);    // (<= 255 after the sort's clamp: 510 steps)
     if (!px.valid) return;
     const size_t p = px.p;
     if (rngMoved) static_cast<uint64_t*>(a.s.rngBuffer)[p] = path.rng.state;
@@ -1458,9 +1462,18 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         const bool small = launchWaves <= waveSlots + waveSlots / 2;
         if (!nrc && !ctx.countersEnabled && spillBytes <= (size_t(1) << 30) && (ctx.tune.fusePasses == 2 || (ctx.tune.fusePasses == 0 && small))) {
             ctx.spill.reserve(spillBytes);
-            ScopedKernelTimer timer(ctx, stream, regir ? "pt_regir_fused" : "pt_fused");
-            hipLaunchKernelGGL(regir ? k_pt_fused<true> : k_pt_fused<false>, dim3(a.px.launchBlocks), dim3(kPtBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap, maxPathLength);
-            GFX_HIP(hipGetLastError());
+            // 159 VGPRs: three blocks per CU are resident, so a 512 x 512 frame (1 024 blocks) is already more than one round
+            const uint32_t* order = nullptr;
+            uint32_t* cost = nullptr;
+            const uint64_t key = (static_cast<uint64_t>(rowBegin) << 44) ^ (static_cast<uint64_t>(rowEnd) << 24) ^ (static_cast<uint64_t>(width) << 4) ^ (regir ? 1u : 0u);
+            block_order_begin(ctx, stream, 4, a.px.launchBlocks, key, 3u * static_cast<uint32_t>(ctx.numCUs), order, cost);
+            a.px.order = order;
+            {
+                ScopedKernelTimer timer(ctx, stream, regir ? "pt_regir_fused" : "pt_fused");
+                hipLaunchKernelGGL(regir ? k_pt_fused<true> : k_pt_fused<false>, dim3(a.px.launchBlocks), dim3(kPtBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap, maxPathLength, cost);
+                GFX_HIP(hipGetLastError());
+            }
+            block_order_end(ctx, stream, 4, a.px.launchBlocks, cost);
             return;
         }
     }

@@ -881,6 +881,38 @@ __global__ __launch_bounds__(1024) void k_order_blocks(uint32_t* __restrict__ co
     }
 }
 
+// Cost-ordered block start.  A launch of several rounds of blocks ends when its last block does, and which block that is was left to the
+// index order (in which the sky comes first and the street last).  A kernel that takes part leaves a cost per block in `cost` (atomicMax:
+// steps of its longest ray, or the clock its slowest wave spent); k_order_blocks turns the costs into the NEXT launch's order on the
+// context's side stream, and hardware block b of that launch works as block order[b] (PixelGrid::order) -- a permutation of who works for
+// which pixels, on which no result can depend.  `which`: Context::blockOrders slot (one launch shape each, `key`).  order / cost come back
+// null when the launch is too small (minBlocks) or "block_order" is 0; order alone is null for the first launch of a shape.
+void block_order_begin(Context& ctx, hipStream_t stream, int which, uint32_t blocks, uint64_t key, uint32_t minBlocks, const uint32_t*& order, uint32_t*& cost) {
+    order = nullptr; cost = nullptr;
+    if (!ctx.tune.blockOrder || blocks <= minBlocks) return;
+    Context::BlockOrder& bo = ctx.blockOrders[which];
+    if (bo.key != key || bo.blocks != blocks) {
+        if (bo.ordered) GFX_HIP(hipStreamWaitEvent(stream, bo.ordered, 0));    // a sort of the old shape may still be running
+        bo.cost.reserve(sizeof(uint32_t) * blocks); bo.order.reserve(sizeof(uint32_t) * blocks);
+        GFX_HIP(hipMemsetAsync(bo.cost.p, 0, sizeof(uint32_t) * blocks, stream));
+        bo.key = key; bo.blocks = blocks; bo.valid = false;
+    }
+    cost = bo.cost.as<uint32_t>();
+    if (bo.valid) { GFX_HIP(hipStreamWaitEvent(stream, bo.ordered, 0)); order = bo.order.as<uint32_t>(); }
+}
+void block_order_end(Context& ctx, hipStream_t stream, int which, uint32_t blocks, uint32_t* cost) {
+    if (!cost) return;
+    Context::BlockOrder& bo = ctx.blockOrders[which];
+    if (!ctx.auxStream) GFX_HIP(hipStreamCreateWithFlags(&ctx.auxStream, hipStreamNonBlocking));
+    if (!bo.counted) { GFX_HIP(hipEventCreateWithFlags(&bo.counted, hipEventDisableTiming)); GFX_HIP(hipEventCreateWithFlags(&bo.ordered, hipEventDisableTiming)); }
+    GFX_HIP(hipEventRecord(bo.counted, stream));
+    GFX_HIP(hipStreamWaitEvent(ctx.auxStream, bo.counted, 0));
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx.auxStream, cost, blocks, bo.order.as<uint32_t>());
+    GFX_HIP(hipGetLastError());
+    GFX_HIP(hipEventRecord(bo.ordered, ctx.auxStream));
+    bo.valid = true;
+}
+
 // SPATIAL_FIRST: GFX_RESTIR_SPATIAL_BIASED_AND_SHADING -- the pixel's last spatial pass (it reads neighbours in reservoir a.curRes and
 // writes the pixel's own entry of the other one), then the shading of that entry by the same thread.
 template <bool SPATIAL_FIRST>
@@ -1039,36 +1071,14 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
     const int spillCap = static_cast<int>(local_spill_depth(ctx.accels[ctx.restir.f.travHandle - 1]->maxDepth));   // stack entries per thread behind the LDS part
     const size_t fusedSpillBytes = sizeof(uint2) * static_cast<size_t>(a.px.launchBlocks) * kBlock * spillCap;
     const bool fused = !ctx.countersEnabled && fusedSpillBytes <= (size_t(1) << 30) && (ctx.tune.fusePasses == 2 || (ctx.tune.fusePasses == 0 && fusableLaunch));
-    // Cost-ordered block start for the fused kernels whose launch is several rounds of blocks: the launch ends when its last tracing wave
-    // has walked its longest ray, so the blocks whose rays took longest one frame ago start first ("block_order" 0: index order).  The
-    // kernel leaves its step counts per block; k_order_blocks turns them into the next launch's order on the context's side stream.
+    // Cost-ordered block start (block_order_begin / _end below) for the kernels whose launch is several rounds of blocks.
+    const uint64_t orderKey = (static_cast<uint64_t>(rowBegin) << 44) ^ (static_cast<uint64_t>(rowEnd) << 24) ^ (static_cast<uint64_t>(width) << 4);
+    const uint32_t orderMinBlocks = 8u * static_cast<uint32_t>(ctx.numCUs);     // up to about one round: they all start together
     auto block_order_begin = [&](int which, uint32_t blocks, uint32_t variant, const uint32_t*& order, uint32_t*& cost) {
-        order = nullptr; cost = nullptr; a.px.order = nullptr;
-        if (!ctx.tune.blockOrder || blocks <= 8u * static_cast<uint32_t>(ctx.numCUs)) return;     // about one round: they all start together
-        Context::BlockOrder& bo = ctx.blockOrders[which];
-        const uint64_t key = (static_cast<uint64_t>(rowBegin) << 44) ^ (static_cast<uint64_t>(rowEnd) << 24) ^ (static_cast<uint64_t>(width) << 4) ^ variant;
-        if (bo.key != key || bo.blocks != blocks) {
-            if (bo.ordered) GFX_HIP(hipStreamWaitEvent(stream, bo.ordered, 0));    // a sort of the old shape may still be running
-            bo.cost.reserve(sizeof(uint32_t) * blocks); bo.order.reserve(sizeof(uint32_t) * blocks);
-            GFX_HIP(hipMemsetAsync(bo.cost.p, 0, sizeof(uint32_t) * blocks, stream));
-            bo.key = key; bo.blocks = blocks; bo.valid = false;
-        }
-        cost = bo.cost.as<uint32_t>();
-        if (bo.valid) { GFX_HIP(hipStreamWaitEvent(stream, bo.ordered, 0)); order = bo.order.as<uint32_t>(); }
+        gfx::block_order_begin(ctx, stream, which, blocks, orderKey ^ variant, orderMinBlocks, order, cost);
         a.px.order = order;
     };
-    auto block_order_end = [&](int which, uint32_t blocks, uint32_t* cost) {
-        if (!cost) return;
-        Context::BlockOrder& bo = ctx.blockOrders[which];
-        if (!ctx.auxStream) GFX_HIP(hipStreamCreateWithFlags(&ctx.auxStream, hipStreamNonBlocking));
-        if (!bo.counted) { GFX_HIP(hipEventCreateWithFlags(&bo.counted, hipEventDisableTiming)); GFX_HIP(hipEventCreateWithFlags(&bo.ordered, hipEventDisableTiming)); }
-        GFX_HIP(hipEventRecord(bo.counted, stream));
-        GFX_HIP(hipStreamWaitEvent(ctx.auxStream, bo.counted, 0));
-        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx.auxStream, cost, blocks, bo.order.as<uint32_t>());
-        GFX_HIP(hipGetLastError());
-        GFX_HIP(hipEventRecord(bo.ordered, ctx.auxStream));
-        bo.valid = true;
-    };
+    auto block_order_end = [&](int which, uint32_t blocks, uint32_t* cost) { gfx::block_order_end(ctx, stream, which, blocks, cost); };
     // (Not for the kernels that gather from neighbouring pixels: started in the candidate kernel's cost order k_spatial took 0.47 ms per
     // frame instead of 0.37 -- blocks of equal cost are scattered over the image, and the XCD-supertile block order is what keeps a tile's
     // neighbours in its XCD's L2.  profiles/r04_experiments.txt 19.)

@@ -13,7 +13,7 @@ namespace gfx {
 Context::~Context() {
     for (Accel* a : accels) { if (a) { a->nodes.release(); a->links.release(); a->triIds.release(); a->rootBoxes.release(); delete a; } }
     DevBuf* all[] = { &dMaterials, &dGeomInsts, &dInsts, &dVertices, &dTriangles, &dSlotPool, &dFlatGeoms, &dSubset[0], &dSubset[1], &dLightW, &dLightP, &dLightCDF, &dLightRefs, &dEmitterRecs, &dEmitterRecExtras, &dLightNormalMatrices, &dInstMatrixIndex, &dTextures, &dTexelPool, &dSrgbLut, &dEmitterTexRefs,
-                      &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &auxSpill, &auxCounters, &blockOrders[0].cost, &blockOrders[0].order, &blockOrders[1].cost, &blockOrders[1].order, &blockOrders[2].cost, &blockOrders[2].order, &blockOrders[3].cost, &blockOrders[3].order, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
+                      &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &auxSpill, &auxCounters, &blockOrders[0].cost, &blockOrders[0].order, &blockOrders[1].cost, &blockOrders[1].order, &blockOrders[2].cost, &blockOrders[2].order, &blockOrders[3].cost, &blockOrders[3].order, &blockOrders[4].cost, &blockOrders[4].order, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
                       &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide, &dSpans, &dSpanGuide, &dSpanHeader, &dSpanInstBegin,
                       &dTraceDiag, &bCosts, &bDec, &bFlatIdx, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
