@@ -45,6 +45,22 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b)
         } else if (KIND == 9) {   // v_max3 / v_min3
             asm volatile(REP16("v_max3_f32 %0, %0, %1, %2\n v_min3_f32 %1, %1, %2, %3\n v_max3_f32 %2, %2, %3, %0\n v_min3_f32 %3, %3, %0, %1\n")
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+        } else if (KIND == 10) {  // v_fma_mix_f32: fp16 half of a register as the first source, fp32 fma -- the conversion folded into the fma
+            asm volatile(REP16("v_fma_mix_f32 %0, %4, %5, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %5, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                               "v_fma_mix_f32 %2, %4, %6, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %4, %6, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n")
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(u), "v"(a), "v"(b));
+        } else if (KIND == 11) {  // the slab-test mix with it: fma_mix, max, min (what cvt + fma + max + min would become)
+            asm volatile(REP16("v_fma_mix_f32 %1, %4, %5, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_max_f32 %2, %2, %1\n v_fma_mix_f32 %0, %4, %5, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_min_f32 %3, %3, %0\n")
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(u), "v"(a), "v"(b));
+        } else if (KIND == 12) {  // v_cvt_f32_f16 (plain and SDWA high half) for comparison
+            asm volatile(REP16("v_cvt_f32_f16 %0, %4\n v_cvt_f32_f16 %1, %4\n v_cvt_f32_f16 %2, %4\n v_cvt_f32_f16 %3, %4\n")
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(u));
+        } else if (KIND == 13) {  // fma + max + min without any conversion (the floor of a slab test)
+            asm volatile(REP16("v_fma_f32 %1, %4, %5, %6\n v_max_f32 %2, %2, %1\n v_fma_f32 %0, %4, %6, %5\n v_min_f32 %3, %3, %0\n")
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(u), "v"(a), "v"(b));
+        } else if (KIND == 14) {  // v_pk_max_f16 / v_pk_min_f16 / v_pk_fma_f16: a slab test on packed halves
+            asm volatile(REP16("v_pk_fma_f16 %1, %4, %5, %6\n v_pk_max_f16 %2, %2, %1\n v_pk_fma_f16 %0, %4, %6, %5\n v_pk_min_f16 %3, %3, %0\n")
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(u), "v"(a), "v"(b));
         }
     }
     out[blockIdx.x * 64 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (float)u;
@@ -83,5 +99,10 @@ int main() {
     run<7>("cmp_cndmask", d, p.multiProcessorCount, ghz);
     run<8>("rcp_sqrt_rsq", d, p.multiProcessorCount, ghz);
     run<9>("max3_min3", d, p.multiProcessorCount, ghz);
+    run<10>("fma_mix_f32_from_f16", d, p.multiProcessorCount, ghz);
+    run<11>("fmamix_max_fmamix_min", d, p.multiProcessorCount, ghz);
+    run<12>("cvt_f32_f16", d, p.multiProcessorCount, ghz);
+    run<13>("fma_max_fma_min", d, p.multiProcessorCount, ghz);
+    run<14>("pk_fma_max_min_f16", d, p.multiProcessorCount, ghz);
     return 0;
 }

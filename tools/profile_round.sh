@@ -28,7 +28,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 OUT=gpurun_out/$ROUND
 mkdir -p $OUT
 B="python bench.py --steps 6 --warmup 2 --mse-ref-spp 0 --cpu-sample 0"
@@ -110,6 +110,26 @@ for l in open("gpurun_out/r03/whatif.jsonl"):
     d = json.loads(l)
     if "variant" in d: print(d["variant"], end=": ")
     else: print(d["ms_per_step"], d["kernels_ms_per_frame"])
+PY
+               ;;
+    deferab)   # round 5: the candidate loop with the BSDF evaluation deferred (restir.hip initial_candidates_deferred): off / on, thresholds
+               : > $OUT/defer_ab.jsonl
+               Q="python bench.py --steps 30 --warmup 5 --mse-ref-spp 0 --cpu-sample 0"
+               for cfg in "0 24 4" "1 24 4" "1 16 4" "1 32 4" "1 24 8" "1 32 8" "1 40 4" "1 24 2" "1 12 2" "0 24 4" "1 24 4"; do
+                 set -- $cfg
+                 echo "{\"defer\": $1, \"park\": $2, \"blocked\": $3}" >> $OUT/defer_ab.jsonl
+                 GFX_DEFER_CANDIDATES=$1 GFX_DEFER_PARK=$2 GFX_DEFER_BLOCKED=$3 timeout 300 $Q >> $OUT/defer_ab.jsonl 2>> $OUT/defer_ab.err
+               done
+               for f in "--plain" "--cluttered"; do for d in 0 1; do
+                 echo "{\"defer\": $d, \"workload\": \"$f\"}" >> $OUT/defer_ab.jsonl
+                 GFX_DEFER_CANDIDATES=$d timeout 300 $Q $f >> $OUT/defer_ab.jsonl 2>> $OUT/defer_ab.err
+               done; done
+               python - $OUT/defer_ab.jsonl <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    d = json.loads(l)
+    if "defer" in d: print(d, end=": ")
+    else: print(d["ms_per_step"], {k: round(v, 4) for k, v in d["kernels_ms_per_frame"].items() if "initial" in k or "trace" in k})
 PY
                ;;
     hbm)       timeout 300 python tools/hbm_stream.py > $OUT/hbm_stream.json 2> $OUT/hbm.err; cat $OUT/hbm_stream.json ;;
