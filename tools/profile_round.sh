@@ -116,9 +116,9 @@ PY
                : > $OUT/defer_ab.jsonl
                Q="python bench.py --steps 30 --warmup 5 --mse-ref-spp 0 --cpu-sample 0"
                for cfg in "0 24 4" "1 24 4" "1 16 4" "1 32 4" "1 24 8" "1 32 8" "1 40 4" "1 24 2" "1 12 2" "0 24 4" "1 24 4"; do
-                 set -- $cfg
-                 echo "{\"defer\": $1, \"park\": $2, \"blocked\": $3}" >> $OUT/defer_ab.jsonl
-                 GFX_DEFER_CANDIDATES=$1 GFX_DEFER_PARK=$2 GFX_DEFER_BLOCKED=$3 timeout 300 $Q >> $OUT/defer_ab.jsonl 2>> $OUT/defer_ab.err
+                 read dfr park blk <<< "$cfg"
+                 echo "{\"defer\": $dfr, \"park\": $park, \"blocked\": $blk}" >> $OUT/defer_ab.jsonl
+                 GFX_DEFER_CANDIDATES=$dfr GFX_DEFER_PARK=$park GFX_DEFER_BLOCKED=$blk timeout 300 $Q >> $OUT/defer_ab.jsonl 2>> $OUT/defer_ab.err
                done
                for f in "--plain" "--cluttered"; do for d in 0 1; do
                  echo "{\"defer\": $d, \"workload\": \"$f\"}" >> $OUT/defer_ab.jsonl
