@@ -62,24 +62,52 @@ def _profile_lines(name):
         return []
 
 
-PMC_FILES = ("r04_pmc.json", "r03_pmc.json")     # newest round first (tools/profile_round.sh pmc -> profiles/make_pmc_json.py)
+# committed counter passes, newest round first (tools/profile_round.sh pmc / pmc1 / pmc4 / pmca -> profiles/make_pmc_json.py), per BASELINE configuration
+PMC_FILES = {2: ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json"), 1: ("r05_pmc_config1.json",), 4: ("r05_pmc_config4.json",), "animate": ("r05_pmc_animate.json",)}
 
 
-def _profiled_traffic():
+def sources_sha16():
+    """A hash of the kernel sources this run's library was built from (gfxexp_amd/csrc: *.hip, *.h, *.cpp, sorted by path): the committed
+    counter files carry the same hash of the tree they were measured on (profiles/make_pmc_json.py), so a counter file that no longer
+    belongs to the kernels shows in the line (`pmc_matches_sources`)."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(ROOT, "gfxexp_amd", "csrc")
+    for dp, dn, fns in sorted(os.walk(root)):
+        dn.sort()
+        for fn in sorted(fns):
+            if fn.endswith((".hip", ".h", ".cpp")):
+                h.update(os.path.relpath(os.path.join(dp, fn), root).encode())
+                with open(os.path.join(dp, fn), "rb") as f:
+                    h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _profiled_traffic(config=2):
     """HBM bytes per traversal launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process): value + file."""
-    for name in PMC_FILES + ("r02_traffic.json", "r01_traffic.json"):
+    for name in PMC_FILES.get(config, ()) + (("r02_traffic.json", "r01_traffic.json") if config == 2 else ()):
         v = _profile_value(name, "hbm_bytes_per_launch")
         if v is not None:
             return v, "profiles/" + name
     return None, None
 
 
-def _profiled_kernels():
-    for name in PMC_FILES:
+def _profiled_kernels(config=2):
+    for name in PMC_FILES.get(config, ()):
         k = _profile_value(name, "kernels")
         if k:
             return k, "profiles/" + name
     return {}, None
+
+
+def _pmc_provenance(pmc_file):
+    """Which commit / which sources the counter file was measured on, and whether those are this run's sources."""
+    if not pmc_file:
+        return {"pmc_head": None, "pmc_sources_sha16": None, "pmc_matches_sources": None}
+    name = os.path.basename(pmc_file)
+    sha = _profile_value(name, "sources_sha16")
+    return {"pmc_head": _profile_value(name, "git_head"), "pmc_sources_sha16": sha, "run_sources_sha16": sources_sha16(),
+            "pmc_matches_sources": (sha == sources_sha16()) if sha else None}
 
 
 def hbm_stream_peak(ctx):
@@ -135,6 +163,10 @@ def parse():
     ap.add_argument("--bump", type=int, default=1, help="enableBumpMapping (normal maps) for the textured workload")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4], help="BASELINE.json configs[] index (0-based); 2 = the metric's configuration")
     ap.add_argument("--animate", action="store_true", help="configs 2 / 4: moving rectangle light (restir_di_main.cpp:7-12) + slowly orbiting camera")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="default run only (configs[2], static, textured, one GPU): afterwards measure configs[1], [3], [4] and --animate for --other-steps "
+                         "steps each and report them inside the one JSON line as `other_configs` (0 = skip)")
+    ap.add_argument("--other-steps", type=int, default=10)
     return ap.parse_args()
 
 
@@ -159,8 +191,14 @@ def orbit_camera(api, W, H, frame):
                            pitch=4.0 + 0.5 * math.sin(ph), yaw=181.5 + 2.0 * math.sin(ph))
 
 
+# rows a pixel's motion vector may span per frame under --animate (orbit_camera: a few pixels; the moving light: ~6 at the bench camera's
+# distance): what a band renderer exchanges across its seams besides the reuse radius (gfxh_restir_set_exchange maxMotionRows)
+ANIMATE_MAX_MOTION_ROWS = 24
+
+
 def main():
     args = parse()
+    import copy
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -169,8 +207,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1 and args.config in (1, 3):
         raise SystemExit(f"--config {args.config} is a single-GPU configuration in BASELINE.json")
-    if world > 1 and args.animate:
-        raise SystemExit("--animate is measured on one GPU (a band renderer needs maxMotionRows for it; not wired into bench.py)")
+    if world > 1 and args.animate and args.exchange == "rccl":
+        raise SystemExit("--animate --gpus N runs over the torch.distributed exchange (--exchange torch)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -178,7 +216,38 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    result = run_config(args, rank, local_rank, world, dist)
+    # Every other BASELINE configuration under the same clock as the headline (the driver runs this file once): a short run of each after
+    # the headline measurement, reported inside the one line.  The headline's own fields are untouched.
+    if rank == 0 and world == 1 and args.other_configs and args.config == 2 and not (args.animate or args.plain or args.cluttered):
+        others = {}
+        for name, over in (("configs[1]", {"config": 1}), ("configs[3]", {"config": 3}), ("configs[4]", {"config": 4}), ("configs[2] --animate", {"animate": True})):
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup, a2.mse_ref_spp, a2.cpu_sample = args.other_steps, 3, 0, "0"
+            for k, v in over.items():
+                setattr(a2, k, v)
+            t0 = time.time()
+            try:
+                r = run_config(a2, rank, local_rank, world, dist)
+                roof = r.get("roofline") or {}
+                others[name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
+                                "workload": r["config"]["workload"], "width": r["config"]["width"], "height": r["config"]["height"],
+                                "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_nominal_hbm", "avg_launch_ms", "valu",
+                                                                    "pmc_head", "pmc_matches_sources", "infer_ms_per_frame") if k in roof},
+                                "kernels_ms_per_frame": r.get("kernels_ms_per_frame"), "seconds": round(time.time() - t0, 1)}
+            except Exception as e:               # the headline stands on its own
+                others[name] = {"error": repr(e)[:300]}
+        result["other_configs"] = others
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def run_config(args, rank, local_rank, world, dist):
+    """One measurement: scene, renderer, warm-up, the timed steps, and (rank 0, one GPU) the roofline / MSE / CPU legs.  Returns the JSON object."""
+    import torch
     from gfxexp_amd import api
     from gfxexp_amd import tilesplit
     from gfxexp_amd import scenes            # the measured path imports nothing from tests/ or oracle/
@@ -272,7 +341,8 @@ def main():
             exchange = _Done()
         else:
             exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda", async_gather=True)
-            renderer.set_exchange(exchange, 0)             # static camera and scene: no motion rows
+            motion_rows = ANIMATE_MAX_MOTION_ROWS if args.animate else 0       # static camera and scene: no motion rows
+            renderer.set_exchange(exchange, motion_rows)
             # Equal rows are not equal work (sky rows are cheap).  Each round: time this rank's band over a few frames, all-gather
             # the times, cut the frame where gfxh_balance_bands says (the same call with the same numbers on every rank) and start
             # over with band renderers for the new rows -- all inside the untimed warm-up; the timed frames use the final partition.
@@ -300,7 +370,7 @@ def main():
                 if args.config == 4:
                     renderer.set_env(sky, 2048, 1024, 0.6, 0.4)
                 exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda", async_gather=True, bands=bands)
-                renderer.set_exchange(exchange, 0)
+                renderer.set_exchange(exchange, motion_rows)
 
     frame_no = [0]
 
@@ -369,7 +439,7 @@ def main():
                     serial.set_env(sky, 2048, 1024, 0.6, 0.4)
                 for _ in range(3):
                     serial.render_frame(stream)
-                result["roofline"], result["kernels_ms_per_frame"] = roofline(ctx, serial, stream, args.steps, W, H, args.config)
+                result["roofline"], result["kernels_ms_per_frame"] = roofline(ctx, serial, stream, args.steps, W, H, args.config, animate=args.animate)
                 serial.close()
             ctx.tunable_set("pt_overlap", 1)
         if args.mse_ref_spp > 0 and args.config == 2 and not args.animate:
@@ -382,14 +452,12 @@ def main():
             else:
                 result["cpu_baseline"] = {"value": None, "unit": "Mpaths/s", "cores": 0, "kind": "port",
                                           "sample": "not timed for this line: see the default line (configs[2], static) for the CPU restatement on this host"}
-    if rank == 0:
-        print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    renderer.close()
+    ctx.close()
+    return result
 
 
-def roofline(ctx, renderer, stream, steps, W, H, config=2):
+def roofline(ctx, renderer, stream, steps, W, H, config=2, animate=False):
     """Dominant kernel family by GPU time; achieved = algorithmic bytes per launch / mean launch duration.
     Durations: HIP events on the launch stream around every kernel (gfx_timing_*), live in this run, passes
     serialised on one stream.  Algorithmic bytes of the traversal kernels: node fetches x (64 + 16) B + triangle
@@ -443,18 +511,23 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2):
     # what actually bounds the kernel (committed rocprofv3 PMC passes, profiles/make_pmc_json.py): VALU issue.
     # The BVH is served from L2 / Infinity Cache (`traffic` is 20-30x below the algorithmic bytes), so the SURVEY 8(d) byte
     # roof is nominal; the hardware-side figure is the share of VALU issue slots used and how many lanes each instruction carries.
-    pmc, pmc_file = _profiled_kernels()
-    traffic, traffic_file = _profiled_traffic()
+    pmc_key = "animate" if (animate and config == 2) else config
+    pmc, pmc_file = _profiled_kernels(pmc_key)
+    traffic, traffic_file = _profiled_traffic(pmc_key)
     valu = None
-    if "k_trace_any" in pmc and config == 2:
-        ka = pmc["k_trace_any"]
-        valu = {"source": pmc_file + " (rocprofv3 --pmc of the default command; per-launch means of k_trace<any>)",
+    # which kernel's counters stand for the configuration's traversal: k_trace<any> where the frame's traversal is mostly any-hit launches
+    # (configs[2]: 2 per frame, configs[4]: 3 incl. the MIS rays of the unbiased spatial pass), the one-kernel path tracer for configs[1]
+    valu_kernel = "k_trace_any" if config in (2, 4) else "k_pt_fused" if config == 1 else None
+    if valu_kernel in pmc:
+        ka = pmc[valu_kernel]
+        valu = {"source": pmc_file + " (rocprofv3 --pmc of this configuration's bench command; per-launch means of %s)" % valu_kernel.replace("k_trace_any", "k_trace<any>"),
                 "busy": ka["valu_busy"], "lane_fraction": ka["lane_fraction"],
                 # (the counting frame runs all three traversals as k_trace launches; the per-iteration figure needs the counters of all three)
                 "insts_per_wave_iteration": round((2 * ka["valu_insts"] + pmc["k_trace_closest"]["valu_insts"]) / max(1, diag["iterations"]), 1) if "k_trace_closest" in pmc else None,
                 "useful_fraction_of_valu_peak": None}
-        if "k_gbuffer_fused" in pmc:
-            valu["gbuffer_fused"] = {k: pmc["k_gbuffer_fused"].get(k) for k in ("valu_busy", "lane_fraction", "valu_insts", "l2_hit", "hbm_bytes")}
+        for extra in ("k_gbuffer_fused", "k_initial_candidates", "k_spatial_unbiased"):
+            if extra in pmc and extra != valu_kernel:
+                valu[extra[2:]] = {k: pmc[extra].get(k) for k in ("valu_busy", "lane_fraction", "valu_insts", "l2_hit", "hbm_bytes")}
         # busy is SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES); the r04 passes read 1.00-1.08 for the traversal kernels (the busy-cycle
         # normalisation is good to a few per cent): a SIMD cannot issue more than all the time, so the product is taken with min(busy, 1)
         valu["useful_fraction_of_valu_peak"] = round(min(valu["busy"], 1.0) * valu["lane_fraction"], 4)
@@ -477,8 +550,8 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2):
             "frac_of_peak_measured": round(achieved / peak_measured, 4) if peak_measured else None,
             "frac_of_peak_measured_read_only": round(achieved / peak_read_only, 4) if peak_read_only else None,
             "valu": valu,
-            "traffic": traffic if config == 2 else None,
-            "traffic_source": (traffic_file + ": HBM bytes per launch by PMC (TCC_EA0_RDREQ / WRREQ passes of the default command), mean of the three launches") if config == 2 and traffic_file else None,
+            "traffic": traffic,
+            "traffic_source": (traffic_file + ": HBM bytes per launch by PMC (FETCH_SIZE / WRITE_SIZE passes of this configuration's bench command), mean over the k_trace<any> launches") if traffic_file else None,
             "node_visits_per_ray": {"primary": round(nodes_per_primary, 3),
                                     "shadow": round(c["any"]["nodeFetches"] / max(1, rays_any), 3),
                                     "sah_tree_primary": sah.get("nodes_per_ray")},
@@ -498,6 +571,7 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2):
             "avg_launch_ms": round(trav_ms / max(trav_launches, 1), 4),
             "per_frame": {"node_fetches": int(c["nodeFetches"]), "tri_fetches": int(c["triFetches"]), "rays": int(c["rays"]),
                           "stack_spills": int(c["spills"])}}
+    roof.update(_pmc_provenance(pmc_file))
     gb_ms = timings.get("gbuffer_fused", (0.0, 0))[0] / n
     if gb_ms > 0 and any_only:
         roof["gbuffer_fused"] = {"kernel": "k_gbuffer_fused (primary ray -> closest hit with the temporal hint -> G-buffer resolve, one kernel)", "ms": round(gb_ms, 4),
@@ -566,7 +640,7 @@ def roofline_nrc(ctx, renderer, stream, W, H):
     tflops = flop_per_query * queries / max(1e-9, infer_ms / n * 1e-3) / 1e12
     peak = 2500.0
     pmc_txt = None
-    for name in ("r04_nrc_pmc.txt", "r03_nrc_pmc.txt"):
+    for name in ("r05_nrc_pmc.txt", "r04_nrc_pmc.txt", "r03_nrc_pmc.txt"):
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
             pmc_txt = "profiles/" + name
             break

@@ -97,9 +97,6 @@ struct Tunables {
     int candidateSplit = 0;          // k_initial_candidates: lanes per pixel (1, 2, 4); 0 = by launch size (restir.hip)
     int blockOrder = 1;              // k_initial_fused: blocks start by decreasing cost of one frame ago (restir.hip k_order_blocks); 0 = index order
     int fusePasses = 0;              // ReSTIR ray passes as one kernel each (restir.hip k_*_fused): 0 = small launches only, 1 never, 2 always
-    int deferCandidates = 1;         // one-lane-per-pixel candidate loop with the BSDF evaluation deferred until enough lanes hold a live candidate
-                                     // (restir.hip initial_candidates_deferred); 0 = the lockstep loop
-    int deferPark = 24, deferBlocked = 4;   // ... evaluate when this many lanes of the wave hold a parked candidate / have stopped behind one
     int ptOverlap = 1;               // path tracers: the NEE (any-hit) trace + its apply kernel of a bounce run on a second stream underneath
                                      // the extension (closest-hit) trace of the same bounce (pathtrace.hip)
 };

@@ -369,242 +369,7 @@ GFX_DEV CandidateRay initial_candidates(const RestirArgs& a, uint4* waveBuf, int
     r.writer = writer; r.want = wantRay; r.org = rayO; r.dir = rayD; r.tmax = rayTmax;
     return r;
 }
-// ---- the same loop with the BSDF evaluation deferred (one lane per pixel; "defer_candidates")
-// The loop above runs its ~290-instruction BSDF section in 97 % of its wave iterations for 11 of 64 lanes and its ~150-instruction
-// emittance-map section in 68 % for 2 (profiles/r03_initial_candidates.txt): the kernel is issue bound at 0.58 lanes per instruction.
-// Here every lane walks the pixel's candidates at its own pace.  Per wave iteration a lane that may run generates its next candidate --
-// random numbers, table lookup, cooperative record fetch, point on the emitter, the geometry of the shadow ray -- and then
-//   * a candidate whose weight is EXACTLY +-0 (the emitter faces away, or the direction is below the horizon of the shading frame, and
-//     the density is a non-zero number) is finished: Reservoir::update (restir_di_shared.h:118-125) adds +-0 to the sum (x + +-0 = x,
-//     +0 + -0 = +0, NaN stays NaN), never accepts (u >= 0 is not below +-0 / sum or NaN) and counts the candidate -- nothing a later
-//     or an earlier candidate of the pixel could observe except the count, which is the same for every pixel (streamLength = candidates);
-//   * any other candidate (live, or with a weight that is NaN: a zero density poisons the sum exactly as in the reference) is PARKED in
-//     eleven registers (position, normal, emittance or texture reference, density, the update's random number); a lane that already
-//     holds a parked candidate keeps the new one where it is and stops generating.
-// The wave evaluates the parked candidates -- shadow-ray geometry again, BSDF, emittance map, reservoir update: the code of the loop
-// above on the parked values -- when enough lanes hold one (a.deferPark), when a.deferBlocked lanes have stopped, or when no lane can
-// run; a stopped lane then parks the candidate it was holding and goes on.  A lane evaluates its candidates in candidate order, so
-// every update sees the sum the sequential loop has at its turn and the pixel's random-number stream is drawn in the same order
-// (four numbers per candidate, the fourth at generation time): same reservoir, bit for bit.
-struct ParkedCandidate {
-    f3 position, normal;
-    f3 e;          // emittance; with a pending emittance-map read: (emitter record, bcA, bcB) as bits
-    float pd;      // area density x probability of the light type
-    float u;       // the candidate's fourth draw (the reservoir update's)
-};
-// Unshadowed contribution of a parked candidate: direct_lighting_pending on the parked values.  texPending: the emittance is the
-// emittance map's texel at (bcA, bcB, 1 - (bcA + bcB)) of record e.x, read when f * G is non-zero; otherwise the record's constant.
-GFX_DEV f3 direct_lighting_parked(const DevScene& sc, f3 shadingPoint, f3 vOutLocal, const Frame& frame, const Bsdf& bsdf, LightSample& ls,
-                                  bool texPending, const ParkedCandidate& pc) {
-    const ShadowRay sr = shadow_ray(shadingPoint, ls);
-    const f3 dirLocal = frame.to_local(sr.dir);
-    const float lpCos = dot(-sr.dir, ls.normal);
-    const float spCos = dirLocal.z;
-    if (lpCos > 0) {
-        const f3 fs = bsdf.evaluate(vOutLocal, dirLocal);
-        const float G = lpCos * fabsf(spCos) / sr.dist2;
-        if (texPending) {
-            const bool zero = (fs.x == 0.0f && fs.y == 0.0f && fs.z == 0.0f) || G == 0.0f;
-            const uint32_t rec = f2bits(pc.e.x);
-            if (!zero) {
-                GFX_PROF(4);
-                const float4 t = emitter_texel(sc, rec, pc.e.y, pc.e.z, 1 - (pc.e.y + pc.e.z));
-                ls.emittance = f3(1.0f) * f3(t.x, t.y, t.z);
-            }
-            else {
-                const float4 r3 = reinterpret_cast<const float4*>(sc.emitterRecs + rec)[3];
-                ls.emittance = f3(r3.x, r3.y, r3.z);
-            }
-        }
-        const f3 Le = ls.emittance / kPi;
-        return fs * Le * G;
-    }
-    return f3(0.0f);
-}
-// `cold`: this lane's column of kDeferColdWords words of LDS, 64 words apart (wave-private).  What the evaluation needs of the shading
-// point but the generation of a candidate does not -- tangent, bitangent, the outgoing direction's x and y, the BSDF's parameters: 15
-// words -- waits there, and the reservoir's sample (9 words) is written there when a candidate is accepted: 24 registers the loop does
-// not carry, which is what the two parked candidates cost (without it the kernel spills 15-24 registers at four waves per SIMD).
-constexpr int kDeferColdWords = 24;
-GFX_DEV void cold_store3(uint32_t* cold, int j, f3 v) { cold[64 * j] = f2bits(v.x); cold[64 * (j + 1)] = f2bits(v.y); cold[64 * (j + 2)] = f2bits(v.z); }
-GFX_DEV f3 cold_load3(const uint32_t* cold, int j) { return f3(bits2f(cold[64 * j]), bits2f(cold[64 * (j + 1)]), bits2f(cold[64 * (j + 2)])); }
-template <bool EMITTER_TEX>
-GFX_DEV CandidateRay initial_candidates_deferred(const RestirArgs& a, uint4* waveBuf, uint32_t* cold, int lane, const PixelId& px) {
-    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const size_t p = px.p;
-    const uint32_t bufIdx = a.f.bufferIndex;
-    bool surface = false;
-    if (px.valid) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
-
-    bool wantRay = false;
-    f3 rayO(0.0f), rayD(0.0f);
-    float rayTmax = 0;
-    const EnvMap env = load_env(a.s);
-    const bool envEnabled = env.present() && a.f.enableEnvLight;
-    // hot part of the shading point: offset origin, shading normal, on which side of the surface the eye is
-    f3 spPos(0.0f), spNormal(0.0f);
-    float vOutZ = 0.0f;
-    uint32_t bsdfType = 0u;
-    uint64_t* rngBuf = static_cast<uint64_t*>(a.s.rngBuffer);
-    Pcg32 rng; rng.state = 0;
-    if (surface) {
-        const Camera cam = load_camera(a.f.camera);
-        ShadingPoint sp;
-        make_shading_point(a, bufIdx, p, cam.pos, false, sp);
-        rng.state = rngBuf[p];
-        spPos = sp.pos; spNormal = sp.frame.n; vOutZ = sp.vOutLocal.z; bsdfType = sp.bsdf.type;
-        cold_store3(cold, 0, sp.frame.t); cold_store3(cold, 3, sp.frame.b);
-        cold[64 * 6] = f2bits(sp.vOutLocal.x); cold[64 * 7] = f2bits(sp.vOutLocal.y);
-        cold_store3(cold, 8, sp.bsdf.diffuse); cold_store3(cold, 11, sp.bsdf.specularF0);
-        cold[64 * 14] = f2bits(sp.bsdf.roughness);
-    }
-    float sumWeights = 0.0f, selectedTarget = 0.0f;
-    bool selected = false, selectedInf = false;        // a candidate has been accepted: its sample is in cold[15 .. 23]
-    const uint32_t numCandidates = 1u << a.f.log2NumCandidateSamples;
-    const int parkLimit = static_cast<int>(a.deferPark), blockedLimit = static_cast<int>(a.deferBlocked);
-
-    uint32_t ci = 0;                          // the next candidate this lane generates
-    bool hasParked = false, blocked = false;  // blocked: `cur` holds a live candidate behind the parked one
-    bool parkedInf = false, parkedTex = false, curInf = false, curTex = false;
-    ParkedCandidate parked, cur;
-    parked.position = parked.normal = parked.e = f3(0.0f); parked.pd = parked.u = 0.0f;
-    cur = parked;
-    GFX_CYC_BEGIN
-    for (;;) {
-        const bool run = surface && !blocked && ci < numCandidates;
-        const unsigned long long runMask = __ballot(run);
-        if (runMask == 0ull && __ballot(hasParked) == 0ull) break;
-        if (runMask != 0ull) {
-            GFX_PROF(0);
-            GFX_CYC(0);
-            // ---- what this lane's candidate needs from the tables
-            float probCurType = 1.0f, u0 = 0.0f, u1 = 0.0f;
-            bool sampleEnv = false;
-            LightPick pk; pk.rec = 0; pk.instSlot = 0; pk.density = 0.0f; pk.partialProb = 0.0f; pk.ok = false; pk.table = true;
-            if (run) {
-                float ul = rng.uniform();
-                if (envEnabled) {
-                    if (*a.scene.lightInstIntegral > 0.0f) {
-                        const float prob = fmin2(fmax2(0.25f * numCandidates - ci, 0.0f), 1.0f);
-                        if (prob == 1.0f) { probCurType = 0.25f; sampleEnv = true; }
-                        else if (prob == 0.0f) probCurType = 1.0f - 0.25f;
-                        else if (ul < prob) { probCurType = 0.25f; ul = ul / prob; sampleEnv = true; }
-                        else { probCurType = 1.0f - 0.25f; ul = (ul - prob) / (1 - prob); }
-                    }
-                    else sampleEnv = true;
-                }
-                u0 = rng.uniform();
-                u1 = rng.uniform();
-                if (!sampleEnv) pk = light_select(a.scene, ul);
-            }
-            // ---- the wave gathers the records, then the normal matrices (initial_candidates above)
-            GFX_CYC(1);
-            const bool fetch = run && !sampleEnv && pk.ok;
-            uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0, q2 = q0, q3 = q0;
-            m33 normalMatrix;
-            normalMatrix.r0 = normalMatrix.r1 = normalMatrix.r2 = f3(0.0f);
-            if (__ballot(fetch) != 0ull) {
-                coop_fetch64_issue(fetch ? pk.rec : kCoopNone, reinterpret_cast<const char*>(a.scene.emitterRecs), waveBuf, lane);
-                coop_fetch64_wait();
-                if (fetch) coop_fetch64_read(waveBuf, lane, q0, q1, q2, q3);
-                if (fetch) normalMatrix = load_m33_rows(a.scene.lightNormalMatrices + 16u * emitter_matrix_index(q3.w));
-            }
-            GFX_CYC(2);
-            if (run) {
-                LightSample ls;
-                ls.emittance = f3(0.0f); ls.position = f3(0.0f); ls.normal = f3(0.0f); ls.atInfinity = 0;
-                float pd = 0.0f;
-                PendingEmittance pending; pending.tex = 0u; pending.rec = 0u; pending.bcA = pending.bcB = pending.bcC = 0.0f;
-                if (sampleEnv) sample_env_light(env, a.f.envLightRotation, a.f.envLightPowerCoeff, u0, u1, ls, pd);
-                else if (pk.ok) {
-                    GFX_PROF(1);
-                    light_from_record<EMITTER_TEX, false>(a.scene, pk, as_float4(q0), as_float4(q1), as_float4(q2), as_float4(q3), normalMatrix, u0, u1, ls, pd,
-                                                          f3(0.0f), EMITTER_TEX ? &pending : nullptr);
-                }
-                cur.u = rng.uniform();
-                cur.pd = pd * probCurType;
-                cur.position = ls.position; cur.normal = ls.normal;
-                curInf = ls.atInfinity != 0u;
-                curTex = EMITTER_TEX && pending.tex != 0u;
-                cur.e = curTex ? f3(bits2f(pending.rec), pending.bcA, pending.bcB) : ls.emittance;
-                GFX_CYC(3);
-                // ---- is the weight exactly +-0?  (the tests of direct_lighting and Bsdf::evaluate on the same values)
-                const ShadowRay sr = shadow_ray(spPos, ls);
-                const float lpCos = dot(-sr.dir, ls.normal);
-                const float spCos = dot(spNormal, sr.dir);                    // Frame::to_local(dir).z
-                // below the horizon: f = 0, and 0 * Le * G is +-0 when Le and G are finite (G = lpCos |spCos| / dist2 < 16e30 here)
-                const bool belowHorizon = spCos * vOutZ <= 0 && lpCos < 4.0f && fabsf(spCos) < 4.0f && sr.dist2 > 1e-30f && all_finite(ls.emittance);
-                const bool densityIsNumber = cur.pd != 0.0f && cur.pd == cur.pd;  // 0 / pd = +-0
-                const bool zeroWeight = densityIsNumber && (!(lpCos > 0) || belowHorizon);
-                if (zeroWeight) ++ci;
-                else if (!hasParked) { parked = cur; parkedInf = curInf; parkedTex = curTex; hasParked = true; ++ci; }
-                else blocked = true;
-            }
-        }
-        // ---- evaluate the parked candidates?
-        const unsigned long long parkedMask = __ballot(hasParked);
-        if (parkedMask != 0ull) {
-            const bool evaluate = __popcll(parkedMask) >= parkLimit || __popcll(__ballot(blocked)) >= blockedLimit ||
-                                  __ballot(surface && !blocked && ci < numCandidates) == 0ull;
-            if (evaluate) {
-                GFX_CYC(4);
-                if (hasParked) {
-                    GFX_PROF(2);
-                    Frame frame;
-                    frame.t = cold_load3(cold, 0); frame.b = cold_load3(cold, 3); frame.n = spNormal;
-                    const f3 vOutLocal(bits2f(cold[64 * 6]), bits2f(cold[64 * 7]), vOutZ);
-                    Bsdf bsdf;
-                    bsdf.type = bsdfType; bsdf.diffuse = cold_load3(cold, 8); bsdf.specularF0 = cold_load3(cold, 11); bsdf.roughness = bits2f(cold[64 * 14]);
-                    LightSample ls;
-                    ls.position = parked.position; ls.normal = parked.normal; ls.emittance = parked.e; ls.atInfinity = parkedInf ? 1u : 0u;
-                    const f3 cont = direct_lighting_parked(a.scene, spPos, vOutLocal, frame, bsdf, ls, EMITTER_TEX && parkedTex, parked);
-                    const float target = target_weight(cont);
-                    const float weight = target / parked.pd;
-                    sumWeights += weight;                                   // Reservoir::update, restir_di_shared.h:118-125
-                    if (parked.u < weight / sumWeights) {
-                        GFX_PROF(5);
-                        selectedTarget = target; selected = true; selectedInf = parkedInf;
-                        cold_store3(cold, 15, ls.emittance); cold_store3(cold, 18, ls.position); cold_store3(cold, 21, ls.normal);
-                    }
-                }
-                hasParked = blocked;
-                if (blocked) { parked = cur; parkedInf = curInf; parkedTex = curTex; ++ci; blocked = false; }
-            }
-        }
-    }
-    GFX_CYC(5);
-    if (surface) {
-        GFX_PROF(8);
-        Reservoir reservoir;
-        reservoir.reset();
-        if (selected) {
-            reservoir.sample.emittance = cold_load3(cold, 15); reservoir.sample.position = cold_load3(cold, 18); reservoir.sample.normal = cold_load3(cold, 21);
-            reservoir.sample.atInfinity = selectedInf ? 1u : 0u;
-        }
-        reservoir.sumWeights = sumWeights;
-        reservoir.streamLength = numCandidates;         // every candidate counts, evaluated or not
-        float recPDF = reservoir.sumWeights / (selectedTarget * reservoir.streamLength);
-        if (!is_finite(recPDF)) { recPDF = 0.0f; selectedTarget = 0.0f; }
-        if (a.f.reuseVisibility && selectedTarget > 0.0f) {
-            const ShadowRay sr = shadow_ray(spPos, reservoir.sample);
-            wantRay = true; rayO = spPos; rayD = sr.dir; rayTmax = sr.tmax;
-        }
-        rngBuf[p] = rng.state;
-        store_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, p, reservoir);
-        static_cast<float2*>(a.s.reservoirInfoBuffer[a.curRes])[p] = make_float2(recPDF, selectedTarget);
-    }
-    GFX_CYC_END;
-    CandidateRay r;
-    r.writer = true; r.want = wantRay; r.org = rayO; r.dir = rayD; r.tmax = rayTmax;
-    return r;
-}
-// SPLIT lanes per pixel -> the lockstep loop; one lane per pixel -> DEFER picks the loop
-template <bool EMITTER_TEX, int SPLIT, bool DEFER>
-GFX_DEV CandidateRay initial_candidates_any(const RestirArgs& a, uint4* waveBuf, uint32_t* cold, int lane, const PixelId& px, uint32_t sub) {
-    if constexpr (DEFER && SPLIT == 1) return initial_candidates_deferred<EMITTER_TEX>(a, waveBuf, cold, lane, px);
-    else return initial_candidates<EMITTER_TEX, SPLIT>(a, waveBuf, lane, px, sub);
-}
-template <bool EMITTER_TEX, int SPLIT, bool DEFER>
+template <bool EMITTER_TEX, int SPLIT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_candidates(RestirArgs a, uint32_t* __restrict__ blockCost) {
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];   // per wave: 256 x 16 B = 64 records
     const int lane = threadIdx.x & 63;
@@ -615,9 +380,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
     const unsigned long long t0 = blockCost ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t sub;
     const PixelId px = pixel_of_split_thread<SPLIT>(a.px, sub, block);
-    __shared__ uint32_t coldBuf[DEFER && SPLIT == 1 ? kDeferColdWords * kBlock : 1];                   // initial_candidates_deferred: 24 words per lane, wave-private
-    uint32_t* cold = coldBuf + (DEFER && SPLIT == 1 ? kDeferColdWords * 64 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + lane : 0);
-    const CandidateRay r = initial_candidates_any<EMITTER_TEX, SPLIT, DEFER>(a, waveBuf, cold, lane, px, sub);
+    const CandidateRay r = initial_candidates<EMITTER_TEX, SPLIT>(a, waveBuf, lane, px, sub);
     if (r.writer) {
         const uint32_t slot = emit_ray_at_slot(px, r.want, r.org, r.dir, 0.0f, r.tmax, a);
         if (px.valid) a.pixelRaySlot[px.p] = slot;
@@ -1059,7 +822,7 @@ __global__ __launch_bounds__(kBlock) void k_gbuffer_fused(RestirArgs a, DevAccel
 // waves leave (their slots go to the next block), the first one traces and runs the temporal pass of those 64 pixels.  The hand-over
 // and the traversal stack live in the record buffers of the waves that have left, so a block holds 16 KB of LDS, not 24: ten blocks
 // fit a CU, and the one-wave tails of the blocks that trace do not keep new blocks out.
-template <bool EMITTER_TEX, int SPLIT, int MODE, bool DEFER>
+template <bool EMITTER_TEX, int SPLIT, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT_WAVES, GFX_INIT_WAVES))) void k_initial_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap, uint32_t* __restrict__ blockCost) {
     static_assert(SPLIT == 1 || SPLIT == 4, "one lane per pixel, or four with the block's rays gathered in its first wave");
     constexpr int kRays = kBlock / SPLIT;
@@ -1075,14 +838,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
     const uint32_t block = launch_block(a.px);
     uint32_t sub;
     PixelId px = pixel_of_split_thread<SPLIT>(a.px, sub, block);
-    // the deferred candidate loop keeps 24 words per lane in LDS (initial_candidates_deferred): in the wave's own part of the traversal
-    // stack, which the wave uses only after the loop -- the stack is laid out wave by wave for that (a column is 64 entries apart)
-    constexpr bool kWaveStack = DEFER && SPLIT == 1;
-    static_assert(!kWaveStack || kLdsStackDepth * sizeof(uint2) >= kDeferColdWords * sizeof(uint32_t), "the cold words of a lane fit its stack column");
-    uint2* waveStack = ownStack + (kWaveStack ? kLdsStackDepth * 64 * wave : 0);
-    const CandidateRay r = initial_candidates_any<EMITTER_TEX, SPLIT, DEFER>(a, waveBuf, reinterpret_cast<uint32_t*>(waveStack) + lane, lane, px, sub);
+    const CandidateRay r = initial_candidates<EMITTER_TEX, SPLIT>(a, waveBuf, lane, px, sub);
     float4 org = make_float4(r.org.x, r.org.y, r.org.z, 0.0f), dir = make_float4(r.dir.x, r.dir.y, r.dir.z, r.want ? r.tmax : -1.0f);
-    uint2* stack = kWaveStack ? waveStack + lane : ownStack + tid;
+    uint2* stack = ownStack + tid;
     if (SPLIT > 1) {
         // ray k of the block (pixel k of its 64) comes from lanes 4 k .. 4 k + 3 = wave k / 16: it waits in the last 512 bytes of that
         // wave's own buffer, which the wave is done with
@@ -1098,7 +856,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GFX_INIT
     }
     const bool want = dir.w > org.w;
     uint32_t steps = 0;
-    const RayHit h = trace_wave_local<true>(accel, want, f3(org.x, org.y, org.z), f3(dir.x, dir.y, dir.z), org.w, dir.w, stack, kWaveStack ? 64 : kRays,
+    const RayHit h = trace_wave_local<true>(accel, want, f3(org.x, org.y, org.z), f3(dir.x, dir.y, dir.z), org.w, dir.w, stack, kRays,
                                             spill + (static_cast<size_t>(blockIdx.x) * kRays + tid) * spillCap, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
     if (blockCost && lane == 0) atomicMax(blockCost + block, steps);      // (one tracing wave per block with four lanes per pixel, four with one)
     temporal_reuse<MODE>(a, px, want && h.tri != GFX_INVALID_SLOT);
@@ -1215,7 +973,6 @@ static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint3
     a.shadeScratch = ctx.shadeScratch.as<float4>();
     a.spatialScratch = ctx.spatialScratch.as<SpatialSlot>();
     a.rearchSlots = nullptr;
-    a.deferPark = 24u; a.deferBlocked = 4u;
     if (rearch) {
         ctx.rearchSlots.reserve(sizeof(uint32_t) * kRearchRayKinds * numPixels);
         a.rearchSlots = ctx.rearchSlots.as<uint32_t>();
@@ -1376,9 +1133,6 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
             uint32_t split = ctx.tune.candidateSplit > 0 ? static_cast<uint32_t>(ctx.tune.candidateSplit) : smallLaunch ? 4u : 1u;
             split = std::min(split, numCandidates);
             if (fused && split == 2) split = 1;      // the fused form exists for one and four lanes per pixel
-            // one lane per pixel: the loop with the deferred BSDF evaluation (initial_candidates_deferred) unless "defer_candidates" is 0
-            const bool defer = split == 1 && ctx.tune.deferCandidates != 0;
-            a.deferPark = static_cast<uint32_t>(ctx.tune.deferPark); a.deferBlocked = static_cast<uint32_t>(ctx.tune.deferBlocked);
             const uint32_t grid = a.px.launchBlocks * split;
             if (fused) {
                 ctx.spill.reserve(fusedSpillBytes);
@@ -1386,9 +1140,9 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
                 const int mode = pass == GFX_RESTIR_INITIAL_RIS ? 0 : pass == GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED ? 1 : 2;
                 const bool tex = a.scene.emitterTexRefs != nullptr;
                 void (*kernel)(RestirArgs, DevAccel, uint2*, int, uint32_t*) = nullptr;
-#define GFX_PICK(TEX, SPLIT, DEFER) (mode == 0 ? k_initial_fused<TEX, SPLIT, 0, DEFER> : mode == 1 ? k_initial_fused<TEX, SPLIT, 1, DEFER> : k_initial_fused<TEX, SPLIT, 2, DEFER>)
-                if (tex) kernel = split == 4 ? GFX_PICK(true, 4, false) : defer ? GFX_PICK(true, 1, true) : GFX_PICK(true, 1, false);
-                else kernel = split == 4 ? GFX_PICK(false, 4, false) : defer ? GFX_PICK(false, 1, true) : GFX_PICK(false, 1, false);
+#define GFX_PICK(TEX, SPLIT) (mode == 0 ? k_initial_fused<TEX, SPLIT, 0> : mode == 1 ? k_initial_fused<TEX, SPLIT, 1> : k_initial_fused<TEX, SPLIT, 2>)
+                if (tex) kernel = split == 4 ? GFX_PICK(true, 4) : GFX_PICK(true, 1);
+                else kernel = split == 4 ? GFX_PICK(false, 4) : GFX_PICK(false, 1);
 #undef GFX_PICK
                 const uint32_t* order = nullptr;
                 uint32_t* cost = nullptr;
@@ -1402,8 +1156,8 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
                 break;
             }
             void (*kernel)(RestirArgs, uint32_t*) = a.scene.emitterTexRefs
-                ? (split == 4 ? k_initial_candidates<true, 4, false> : split == 2 ? k_initial_candidates<true, 2, false> : defer ? k_initial_candidates<true, 1, true> : k_initial_candidates<true, 1, false>)
-                : (split == 4 ? k_initial_candidates<false, 4, false> : split == 2 ? k_initial_candidates<false, 2, false> : defer ? k_initial_candidates<false, 1, true> : k_initial_candidates<false, 1, false>);
+                ? (split == 4 ? k_initial_candidates<true, 4> : split == 2 ? k_initial_candidates<true, 2> : k_initial_candidates<true, 1>)
+                : (split == 4 ? k_initial_candidates<false, 4> : split == 2 ? k_initial_candidates<false, 2> : k_initial_candidates<false, 1>);
             const uint32_t* order = nullptr;
             uint32_t* cost = nullptr;
             block_order_begin(3, grid, split, order, cost);

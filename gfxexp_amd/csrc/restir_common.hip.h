@@ -105,7 +105,6 @@ struct RestirArgs {
     float4* shadeScratch;
     SpatialSlot* spatialScratch;
     uint32_t* rearchSlots;         // rearchitected traceShadowRays: 7 planes of ray slots per pixel
-    uint32_t deferPark, deferBlocked;   // initial_candidates_deferred (restir.hip): evaluate when this many lanes hold a parked candidate / have stopped
 };
 
 // ---------------------------------------------------------------- reservoir planes

@@ -516,11 +516,6 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
  *                               pixel's candidates round robin and the reservoir is formed as the sequential loop forms it; 0 (default)
  *                               = by launch size: 4 when the launch fills the GPU's wave slots at most ~1.5 times (a row band of an
  *                               8-way split frame), else 1 (GFX_CANDIDATE_SPLIT)
- *   "defer_candidates" 0|1      one lane per pixel in the candidate loop: every lane walks its pixel's candidates at its own pace, finishes a
- *                               candidate whose weight is exactly zero (emitter facing away, direction below the horizon) at once and parks a
- *                               live one; the wave runs the BSDF / emittance-map section when "defer_park" (default 24) lanes hold a parked
- *                               candidate or "defer_blocked" (default 4) lanes wait behind theirs -- the same reservoir bit for bit, a third
- *                               fewer instructions issued (default 1; 0 = the lockstep loop; GFX_DEFER_CANDIDATES, GFX_DEFER_PARK, GFX_DEFER_BLOCKED)
  * The same knobs are read once from the environment by gfx_ctx_create (GFX_PIXEL_MAP, GFX_SUPER_X, GFX_SUPER_Y,
  * GFX_TRACE_BLOCKS_PER_CU, GFX_TRACE_REFILL, GFX_TRACE_BATCH). */
 int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value);

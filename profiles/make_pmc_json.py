@@ -1,4 +1,6 @@
 """profiles/make_pmc_json.py DIR [DIR2 label2 ...] > profiles/r03_pmc.json
+   profiles/make_pmc_json.py --stamp FILE > profiles/FILE      (in the repository: adds `git_head` after checking that the file's
+                                                                 `sources_sha16` is the hash of the checked-out kernel sources)
 
 Condenses the per-kernel means of the rocprofv3 --pmc passes of tools/profile_round.sh (DIR/sq.txt, sq2.txt, tc.txt, ea.txt,
 wr.txt: output of profiles/summarize_pmc.py) into the figures bench.py quotes in its `roofline` object:
@@ -18,7 +20,25 @@ import sys
 
 KERNELS = {"k_trace_any": "k_trace<true, false>", "k_trace_closest": "k_trace<false, false>",
            "k_initial_candidates": "k_initial_candidates<", "k_initial_candidates_pooled": "k_initial_candidates_pooled<", "k_spatial": "k_spatial<false>", "k_temporal": "k_temporal<1>",
-           "k_shade_prepare": "k_shade_prepare", "k_gbuffer_resolve": "k_gbuffer_resolve", "k_gbuffer_fused": "k_gbuffer_fused"}
+           "k_shade_prepare": "k_shade_prepare", "k_gbuffer_resolve": "k_gbuffer_resolve", "k_gbuffer_fused": "k_gbuffer_fused",
+           "k_pt_fused": "k_pt_fused<", "k_spatial_unbiased": "k_spatial<true>", "k_spatial_mis_finish": "k_spatial_mis_finish", "k_temporal_unbiased": "k_temporal<2>",
+           "k_initial_fused": "k_initial_fused<", "k_shading_fused": "k_shading_fused<"}
+
+
+def sources_sha16():
+    """bench.py sources_sha16: the hash of gfxexp_amd/csrc the counters belong to (the GPU box runs a snapshot of the tree without .git)."""
+    import hashlib
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gfxexp_amd", "csrc")
+    h = hashlib.sha256()
+    for dp, dn, fns in sorted(os.walk(root)):
+        dn.sort()
+        for fn in sorted(fns):
+            if fn.endswith((".hip", ".h", ".cpp")):
+                h.update(os.path.relpath(os.path.join(dp, fn), root).encode())
+                with open(os.path.join(dp, fn), "rb") as f:
+                    h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def parse(path):
@@ -68,8 +88,25 @@ def condense(d):
     return res
 
 
+def stamp(path):
+    import subprocess
+    d = json.load(open(path))
+    if d.get("sources_sha16") != sources_sha16():
+        sys.exit("make_pmc_json --stamp: %s was measured on other kernel sources (%s) than the checked-out ones (%s)" % (path, d.get("sources_sha16"), sources_sha16()))
+    d["git_head"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+    dirty = subprocess.run(["git", "status", "--porcelain", "--", "gfxexp_amd/csrc"], capture_output=True, text=True).stdout.strip()
+    if dirty:
+        sys.exit("make_pmc_json --stamp: uncommitted changes under gfxexp_amd/csrc -- commit first, HEAD would not name these sources")
+    print(json.dumps(d, indent=1))
+
+
 def main(argv):
-    out = {"source": "rocprofv3 --pmc passes of tools/profile_round.sh (step pmc / pmc0) over `python bench.py --steps 6 --warmup 2 --mse-ref-spp 0 "
+    if argv and argv[0] == "--stamp":
+        return stamp(argv[1])
+    command = "python bench.py --steps 6 --warmup 2 --mse-ref-spp 0 --cpu-sample 0 --no-roofline"
+    if argv and argv[0] == "--command":
+        command, argv = argv[1], argv[2:]
+    out = {"sources_sha16": sources_sha16(), "git_head": None, "command": command, "source": "rocprofv3 --pmc passes of tools/profile_round.sh (step pmc / pmc0) over `python bench.py --steps 6 --warmup 2 --mse-ref-spp 0 "
                      "--cpu-sample 0 --no-roofline`, MI355X; formulas in profiles/make_pmc_json.py", "kernels": condense(argv[0])}
     t = out["kernels"]
     if "k_trace_any" in t and "k_trace_closest" in t and "hbm_bytes" in t["k_trace_any"]:

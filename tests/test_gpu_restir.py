@@ -143,30 +143,6 @@ def test_lanes_per_pixel_of_the_candidate_pass_change_nothing(built_lib, split, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("defer,park,blocked,fuse", [(0, 24, 4, 1), (1, 1, 1, 1), (1, 24, 4, 1), (1, 64, 64, 1), (1, 24, 4, 2), (1, 6, 2, 2), (1, 40, 1, 1)])
-@pytest.mark.parametrize("scene", ["street", "street+sky", "adversarial"])
-def test_deferred_evaluation_in_the_candidate_loop_changes_nothing(built_lib, defer, park, blocked, fuse, scene):
-    """One lane per pixel in the candidate loop, "defer_candidates" 0 (the lockstep loop) or 1 (restir.hip initial_candidates_deferred:
-    every lane walks its pixel's candidates at its own pace, a zero-weight candidate is finished at once, a live one parked until
-    `park` lanes hold one or `blocked` lanes wait behind theirs -- from "evaluate at once" (1, 1) to "only when nobody can go on"
-    (64, 64)), as a kernel of its own (fuse_passes 1) or inside k_initial_fused (2).  Same reservoirs, RNG streams and beauty as the
-    oracle's sequential loop after every pass: textured emitters (street), the environment map's share of the candidates (street+sky,
-    unbiased estimator), and importances over 12 decades with zero-probability runs -- NaN weights that must poison the sum in
-    candidate order (adversarial)."""
-    tunables = {"candidate_split": 1, "defer_candidates": defer, "defer_park": park, "defer_blocked": blocked, "fuse_passes": fuse}
-    if scene == "street":
-        diffs = run_sequence_both(util.small_street(), 192, 108, frames=2, renderer=api.RENDERER_BIASED, scene_kind="street", tunables=tunables)
-    elif scene == "street+sky":
-        sky = api.env_make_sky(64, 32)
-        diffs = run_sequence_both(util.small_street(), 160, 96, frames=2, renderer=api.RENDERER_UNBIASED, scene_kind="street",
-                                  env=(sky, 64, 32), env_rotation=0.4, tunables=tunables)
-    else:
-        diffs = run_sequence_both(util.pathological_light_scene(), 48, 32, frames=3, renderer=api.RENDERER_BIASED,
-                                  camera=api.make_camera(48, 32, pos=(0.0, 9.0, 38.0), pitch=10.0, yaw=180.0), tunables=tunables)
-    assert not diffs, "\n".join(diffs[:12])
-
-
-@pytest.mark.gpu
 def test_street_sequence_bit_exact(built_lib):
     diffs = run_sequence_both(util.small_street(), 192, 108, frames=2, renderer=api.RENDERER_BIASED, scene_kind="street")
     assert not diffs, "\n".join(diffs)

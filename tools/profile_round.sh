@@ -31,10 +31,11 @@ export TMPDIR=/tmp
 ROUND=${ROUND:-r05}
 OUT=gpurun_out/$ROUND
 mkdir -p $OUT
-B="python bench.py --steps 6 --warmup 2 --mse-ref-spp 0 --cpu-sample 0"
+B="python bench.py --steps 6 --warmup 2 --mse-ref-spp 0 --cpu-sample 0 --other-configs 0"
 
-pmc_passes() {   # $1 = output tag, rest = environment assignments
+pmc_passes() {   # $1 = output tag, rest = environment assignments; $BFLAGS = extra bench.py flags (--config N, --animate)
   local tag=$1; shift
+  local B="$B ${BFLAGS:-}"
   local d=$OUT/$tag
   mkdir -p $d
   env "$@" timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $d/sq -- $B --no-roofline > /dev/null 2>&1
@@ -54,7 +55,7 @@ for step in "$@"; do
     tests)     timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/tests.log ;;
     bench)     timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | cut -c1-600 ;;
     benchq)    : > $OUT/bench_quick.jsonl
-               for f in "" "--plain" "--cluttered"; do timeout 300 python bench.py --steps 30 --warmup 5 --mse-ref-spp 0 --cpu-sample 0 $f >> $OUT/bench_quick.jsonl 2>> $OUT/bench_quick.err; done
+               for f in "" "--plain" "--cluttered"; do timeout 300 python bench.py --steps 30 --warmup 5 --mse-ref-spp 0 --cpu-sample 0 --other-configs 0 $f >> $OUT/bench_quick.jsonl 2>> $OUT/bench_quick.err; done
                cut -c1-400 $OUT/bench_quick.jsonl ;;
     ab)        timeout 600 python tools/pixel_map_ab.py > $OUT/pixel_map_ab.jsonl 2> $OUT/pixel_map_ab.err
                timeout 600 python tools/pixel_map_ab.py --plain >> $OUT/pixel_map_ab.jsonl 2>> $OUT/pixel_map_ab.err
@@ -65,6 +66,12 @@ for step in "$@"; do
                cat $OUT/stats/*/*kernel_stats.csv | cut -c1-200 | head -40 | tee $OUT/kernel_stats.csv ;;
     pmc)       pmc_passes pmc_default GFX_NOOP=1; head -60 $OUT/pmc_default/sq.txt ;;
     pmc0)      pmc_passes pmc_map0 GFX_PIXEL_MAP=0 ;;
+    pmcc1)     BFLAGS="--config 1" pmc_passes pmc_config1 GFX_NOOP=1      # round 5: counter passes of the other BASELINE configurations -> profiles/r05_pmc_config1.json ...
+               python profiles/make_pmc_json.py --command "$B --config 1 --no-roofline" $OUT/pmc_config1 > $OUT/${ROUND}_pmc_config1.json; head -c 400 $OUT/${ROUND}_pmc_config1.json ;;
+    pmcc4)     BFLAGS="--config 4" pmc_passes pmc_config4 GFX_NOOP=1
+               python profiles/make_pmc_json.py --command "$B --config 4 --no-roofline" $OUT/pmc_config4 > $OUT/${ROUND}_pmc_config4.json; head -c 400 $OUT/${ROUND}_pmc_config4.json ;;
+    pmca)      BFLAGS="--animate" pmc_passes pmc_animate GFX_NOOP=1
+               python profiles/make_pmc_json.py --command "$B --animate --no-roofline" $OUT/pmc_animate > $OUT/${ROUND}_pmc_animate.json; head -c 400 $OUT/${ROUND}_pmc_animate.json ;;
     pmc1)      pmc_passes pmc_map1 GFX_PIXEL_MAP=1 ;;
     nrcpmc)    N="python tools/bench_nrc.py --steps 5"; mkdir -p $OUT/nrc_pmc
                timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/nrc_pmc/a -- $N > /dev/null 2>&1
@@ -91,7 +98,7 @@ for step in "$@"; do
                #   ... occ5 GFX_TRACE_LDS_STACK=6 GFX_TRACE_MIN_WAVES=5 ; ... occ6 GFX_TRACE_LDS_STACK=4 GFX_TRACE_MIN_WAVES=6 ;
                #   ... fastdiv -fno-hip-fp32-correctly-rounded-divide-sqrt   (approximate / and sqrtf: timing only, results differ))
                : > $OUT/whatif.jsonl
-               Q="python bench.py --steps 20 --warmup 5 --mse-ref-spp 0 --cpu-sample 0"
+               Q="python bench.py --steps 20 --warmup 5 --mse-ref-spp 0 --cpu-sample 0 --other-configs 0"
                run_v() { tag=$1; shift; echo "{\"variant\": \"$tag\"}" >> $OUT/whatif.jsonl; env "$@" timeout 300 $Q >> $OUT/whatif.jsonl 2>> $OUT/whatif.err; }
                V=$PWD/gfxexp_amd/variants
                run_v shipped GFX_NOOP=1
@@ -112,26 +119,8 @@ for l in open("gpurun_out/r03/whatif.jsonl"):
     else: print(d["ms_per_step"], d["kernels_ms_per_frame"])
 PY
                ;;
-    deferab)   # round 5: the candidate loop with the BSDF evaluation deferred (restir.hip initial_candidates_deferred): off / on, thresholds
-               : > $OUT/defer_ab.jsonl
-               Q="python bench.py --steps 30 --warmup 5 --mse-ref-spp 0 --cpu-sample 0"
-               for cfg in "0 24 4" "1 24 4" "1 16 4" "1 32 4" "1 24 8" "1 32 8" "1 40 4" "1 24 2" "1 12 2" "0 24 4" "1 24 4"; do
-                 read dfr park blk <<< "$cfg"
-                 echo "{\"defer\": $dfr, \"park\": $park, \"blocked\": $blk}" >> $OUT/defer_ab.jsonl
-                 GFX_DEFER_CANDIDATES=$dfr GFX_DEFER_PARK=$park GFX_DEFER_BLOCKED=$blk timeout 300 $Q >> $OUT/defer_ab.jsonl 2>> $OUT/defer_ab.err
-               done
-               for f in "--plain" "--cluttered"; do for d in 0 1; do
-                 echo "{\"defer\": $d, \"workload\": \"$f\"}" >> $OUT/defer_ab.jsonl
-                 GFX_DEFER_CANDIDATES=$d timeout 300 $Q $f >> $OUT/defer_ab.jsonl 2>> $OUT/defer_ab.err
-               done; done
-               python - $OUT/defer_ab.jsonl <<'PY'
-import json, sys
-for l in open(sys.argv[1]):
-    d = json.loads(l)
-    if "defer" in d: print(d, end=": ")
-    else: print(d["ms_per_step"], {k: round(v, 4) for k, v in d["kernels_ms_per_frame"].items() if "initial" in k or "trace" in k})
-PY
-               ;;
+    # (round 5's deferab step -- the candidate loop with the BSDF evaluation deferred, GFX_DEFER_CANDIDATES / _PARK / _BLOCKED sweeps -- went with the
+    #  experiment: commit 5fd9a5c has it; profiles/r05_experiments.txt 1)
     hbm)       timeout 300 python tools/hbm_stream.py > $OUT/hbm_stream.json 2> $OUT/hbm.err; cat $OUT/hbm_stream.json ;;
     *)         echo "unknown step $step" ;;
   esac
