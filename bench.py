@@ -165,8 +165,8 @@ def parse():
     ap.add_argument("--animate", action="store_true", help="configs 2 / 4: moving rectangle light (restir_di_main.cpp:7-12) + slowly orbiting camera")
     ap.add_argument("--other-configs", type=int, default=1,
                     help="default run only (configs[2], static, textured, one GPU): afterwards measure configs[1], [3], [4] and --animate for --other-steps "
-                         "steps each and report them inside the one JSON line as `other_configs` (0 = skip)")
-    ap.add_argument("--other-steps", type=int, default=10)
+                         "steps each (5 warm-up frames) and report them inside the one JSON line as `other_configs` (0 = skip)")
+    ap.add_argument("--other-steps", type=int, default=20)
     return ap.parse_args()
 
 
@@ -223,10 +223,10 @@ def main():
         others = {}
         for name, over in (("configs[1]", {"config": 1}), ("configs[3]", {"config": 3}), ("configs[4]", {"config": 4}), ("configs[2] --animate", {"animate": True})):
             a2 = copy.copy(args)
-            a2.steps, a2.warmup, a2.mse_ref_spp, a2.cpu_sample = args.other_steps, 3, 0, "0"
+            a2.steps, a2.warmup, a2.mse_ref_spp, a2.cpu_sample = args.other_steps, 5, 0, "0"
             for k, v in over.items():
                 setattr(a2, k, v)
-            t0 = time.time()
+            t0 = time.perf_counter()
             try:
                 r = run_config(a2, rank, local_rank, world, dist)
                 roof = r.get("roofline") or {}
@@ -234,7 +234,7 @@ def main():
                                 "workload": r["config"]["workload"], "width": r["config"]["width"], "height": r["config"]["height"],
                                 "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_nominal_hbm", "avg_launch_ms", "valu",
                                                                     "pmc_head", "pmc_matches_sources", "infer_ms_per_frame") if k in roof},
-                                "kernels_ms_per_frame": r.get("kernels_ms_per_frame"), "seconds": round(time.time() - t0, 1)}
+                                "kernels_ms_per_frame": r.get("kernels_ms_per_frame"), "seconds": round(time.perf_counter() - t0, 1)}
             except Exception as e:               # the headline stands on its own
                 others[name] = {"error": repr(e)[:300]}
         result["other_configs"] = others

@@ -137,13 +137,80 @@ def test_window_of_a_3840x2160_frame_matches_the_oracle(built_lib, monkeypatch, 
         _window_of_the_full_frame("configs[2]: biased", workload)
 
 
-def _window_of_the_full_frame(config, workload):
+# Windows that are NOT where the workload's defining geometry is: the frame's corner and edges (the reuse margins are clipped by the
+# image there, launch slots of padded 16 x 16 blocks / XCD supertiles lie next to them) in other supertiles than the chosen window.
+BORDER_WINDOWS = {"bottom-left corner": lambda: (0, H - 40, 80, H),
+                  "right edge": lambda: (W - 80, 600 * H // 1080 // 8 * 8, W, 600 * H // 1080 // 8 * 8 + 40),
+                  "top edge, left of centre": lambda: (640 * W // 1920 // 8 * 8, 0, 640 * W // 1920 // 8 * 8 + 80, 40)}
+
+
+@pytest.mark.parametrize("where", sorted(BORDER_WINDOWS))
+def test_border_window_of_the_full_frame_matches_the_oracle(built_lib, where):
+    """A second net at full size (textured workload, configs[2]): windows on the frame's border -- clipped reuse margins, padded launch
+    slots -- in other XCD supertiles than the window test_window_of_the_full_frame_matches_the_oracle picks."""
+    with util.frame_overrides(enableBumpMapping=1):
+        _window_of_the_full_frame("configs[2]: biased", "textured", inner=BORDER_WINDOWS[where](), workload_window=False)
+
+
+def _animation(frame):
+    """bench.py --animate: the reference command line's moving rectangle light (restir_di_main.cpp:7-12) at 60 frames per second and
+    the slowly orbiting camera, as bench.py applies them before frame `frame`."""
+    import bench
+    return bench.light_transform(api, frame / 60.0), bench.orbit_camera(api, W, H, frame)
+
+
+def test_animated_window_of_the_full_frame_matches_the_oracle(built_lib):
+    """bench.py --animate under the oracle at BASELINE's size: the textured street + the moving rectangle light in the animated BVH
+    subtree (rebuilt in place every frame) + the orbiting camera, three frames -- motion vectors, the temporal hint and the temporal
+    reuse across the motion, every buffer of a window lit by the moving light after every frame (restir_di_main.cpp:2249-2264)."""
+    with util.frame_overrides(enableBumpMapping=1):
+        _window_of_the_full_frame("configs[2]: biased", "textured", frames=3, animated=True, workload_window=False)
+
+
+def _window_lit_by_the_moving_light(hs, light_slot, size=(80, 40)):
+    """An 8-aligned window around the pixel that sees the ground under the light's position of frame 1 (found on the GPU's own
+    G-buffer of that frame; the test then compares that G-buffer with the oracle like every other buffer)."""
+    import torch
+    ctx = api.Context(0)
+    hs.upload(ctx)
+    ctx.instance_set_dynamic(light_slot)
+    xfm, cam = _animation(1)
+    ctx.instance_set_transform(light_slot, xfm)
+    accel = ctx.accel_build()
+    ctx.lights_build_static()
+    dev = util.DeviceBuffers(util.PixelBuffers(W, H))
+    stream = torch.cuda.current_stream().cuda_stream
+    f = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, W, H, cam, travHandle=accel, frameIndex=0, bufferIndex=0, resetFlowBuffer=1)
+    ctx.lights_build_instances(stream)
+    ctx.restir_set_params(dev.static_params(), f, 0, 0, stream)
+    ctx.restir_launch(api.PASS_SETUP_GBUFFERS, W, H, stream)
+    got = dev.download()
+    pos = np.asarray(got["gb2_0"]).view(np.float32).reshape(H, W, 4)[:, :, :3]
+    inst = got["gb0_0"]["instSlot"].reshape(H, W)
+    under = np.array([xfm[3], 0.0, xfm[11]], np.float32)           # the light's position projected on the ground plane
+    d = np.where(inst != 0xFFFFFFFF, np.linalg.norm(np.nan_to_num(pos) - under, axis=2), 1e30)
+    y, x = np.unravel_index(int(np.argmin(d)), d.shape)
+    assert d[y, x] < 1.5, "the ground under the moving light is not in view"
+    x0 = min(max(0, (x - size[0] // 2) // 8 * 8), W - size[0])
+    y0 = min(max(0, (y - size[1] // 2) // 8 * 8), H - size[1])
+    ctx.close()
+    return (int(x0), int(y0), int(x0) + size[0], int(y0) + size[1])
+
+
+def _window_of_the_full_frame(config, workload, inner=None, frames=2, animated=False, workload_window=True):
     import torch
     unbiased = "unbiased" in config
     hs = _scene(workload)
-    inner = _choose_window(workload, hs)
+    light_slot = None
+    if animated:
+        light_slot = hs.add_instance(hs.add_rectangle(1.5, 1.5, (60, 60, 60)), _animation(0)[0])
+        inner = _window_lit_by_the_moving_light(hs, light_slot)
+    if inner is None:
+        inner = _choose_window(workload, hs)
     ctx = api.Context(0)
     hs.upload(ctx)
+    if light_slot is not None:
+        ctx.instance_set_dynamic(light_slot)
     accel = ctx.accel_build()
     ctx.lights_build_static()
     osc = util.feed_oracle(hs)
@@ -162,22 +229,36 @@ def _window_of_the_full_frame(config, workload):
     stream = torch.cuda.current_stream().cuda_stream
     n = W * H
     radius = 20
+    motion = 24 if animated else 0                     # pixels a motion vector may span per frame (bench.py ANIMATE_MAX_MOTION_ROWS; asserted below)
     passes, nb = (1, 3) if unbiased else (2, 5)        # restir_di_main.cpp:1965-1967
     spatial = api.PASS_SPATIAL_UNBIASED if unbiased else api.PASS_SPATIAL_BIASED
     # margins: a frame's final reservoirs are exact `radius * passes` pixels inside the region its first passes
-    # covered, and the next frame's temporal pass reads them -- so frame 0 starts that much wider than frame 1
-    pads = [2 * radius * passes + 8, radius * passes + 8]
+    # covered, and the next frame's temporal pass reads them (`motion` pixels away at most) -- so every frame starts that much wider than the next
+    pads = [radius * passes + 8]
+    for _ in range(frames - 1):
+        pads.insert(0, pads[0] + radius * passes + motion)
 
     def grow(r, d):
         return (max(0, r[0] - d), max(0, r[1] - d), min(W, r[2] + d), min(H, r[3] + d))
 
     diffs = []
     last_res, last_base = 1, 0
-    for frame in range(2):
+    prev_cam = prev_ocam = None
+    for frame in range(frames):
+        if animated:
+            # InstanceController::update + updateASs (restir_di_main.cpp:2258-2264), then the camera
+            xfm, cam = _animation(frame)
+            ocam = util.copy_struct(O.GfxCamera, cam)
+            ctx.instance_set_transform(light_slot, xfm)
+            osc.set_instance_transform(light_slot, xfm)
+            assert ctx.accel_build(handle=accel) == accel
+            osc.commit()
         kw = dict(frameIndex=frame, bufferIndex=frame % 2, resetFlowBuffer=int(frame == 0), numAccumFrames=0,
                   numSpatialNeighbors=nb, useUnbiasedEstimator=int(unbiased), useLowDiscrepancyNeighbors=1, reuseVisibility=1, **env_kw)
-        f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, W, H, cam, travHandle=accel, **kw)
-        f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, W, H, ocam, travHandle=0, **kw)
+        f_gpu = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, W, H, cam, prev_cam=prev_cam, travHandle=accel, **kw)
+        f_cpu = util.frame_params(O.GfxRestirFrameParams, O.GfxCamera, W, H, ocam, prev_cam=prev_ocam, travHandle=0, **kw)
+        if animated:
+            prev_cam, prev_ocam = cam, ocam
         ctx.lights_build_instances(stream)
         cur = (last_res + 1) % 2
         pad = pads[frame]
@@ -204,10 +285,24 @@ def _window_of_the_full_frame(config, workload):
             b = np.ascontiguousarray(_pick(want[key], mask, n)).view(np.uint8)
             if not np.array_equal(a, b):
                 diffs.append(f"frame {frame}: {key}: {np.count_nonzero(a != b)} bytes differ inside the window")
+        if animated and frame > 0:
+            # the margins assume |motion vector| <= `motion` inside the region the oracle rendered; and the window does see motion
+            big = grow(inner, pads[frame])
+            mv = np.nan_to_num(np.asarray(pb_cpu.gb1[frame % 2]).view(np.float32).reshape(H, W, 2)[big[1]:big[3], big[0]:big[2]])
+            assert np.abs(mv).max() <= motion, f"frame {frame}: a motion vector of {np.abs(mv).max():.1f} pixels exceeds the margin"
+            assert np.abs(mv).max() > 0.25, "nothing moves inside the window"
     assert not diffs, "\n".join(diffs)
     beauty = pb_cpu.beauty.reshape(H, W, 4)[inner[1]:inner[3], inner[0]:inner[2], :3]
-    assert np.isfinite(beauty).all() and beauty.mean() > 1e-4     # the window is lit, not background
-    _assert_window_shows_the_workload(workload, hs, pb_cpu.gb0[1], pb_cpu.gb3[1], inner)
+    assert np.isfinite(beauty).all()
+    if workload_window:
+        assert beauty.mean() > 1e-4                                  # the window is lit, not background
+        _assert_window_shows_the_workload(workload, hs, pb_cpu.gb0[(frames - 1) % 2], pb_cpu.gb3[(frames - 1) % 2], inner)
+    if animated:
+        # the moving light lights the window (60 W/m2 sr over 1.5 x 1.5 m, a few metres above the ground)
+        assert beauty.mean() > 1e-2, "the window is not lit by the moving light"
+        gb0 = pb_cpu.gb0[(frames - 1) % 2]["instSlot"].reshape(H, W)
+        assert (gb0[inner[1]:inner[3], inner[0]:inner[2]] != 0xFFFFFFFF).mean() > 0.5
+    ctx.close()
 
 
 def _render(frames, serial=False, band=None, monkeypatch=None):
