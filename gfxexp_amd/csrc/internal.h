@@ -97,6 +97,7 @@ struct Tunables {
     int candidateSplit = 0;          // k_initial_candidates: lanes per pixel (1, 2, 4); 0 = by launch size (restir.hip)
     int blockOrder = 1;              // k_initial_fused: blocks start by decreasing cost of one frame ago (restir.hip k_order_blocks); 0 = index order
     int fusePasses = 0;              // ReSTIR ray passes as one kernel each (restir.hip k_*_fused): 0 = small launches only, 1 never, 2 always
+    int nrcStagedInfer = 0;          // k_nrc_infer_staged (hash-grid levels through LDS): 0 = large batches only, 1 never, 2 always (nrc.hip)
     int ptOverlap = 1;               // path tracers: the NEE (any-hit) trace + its apply kernel of a bounce run on a second stream underneath
                                      // the extension (closest-hit) trace of the same bounce (pathtrace.hip)
 };
@@ -105,6 +106,7 @@ struct Context {
     int device = 0;
     int numCUs = 0;                  // of `device` (gfx_ctx_create)
     Tunables tune;
+    bool nrcInferStagedConfigured = false;   // k_nrc_infer_staged has been given its 128 KiB of dynamic LDS on this device
     size_t nrcTrainLdsConfigured = 0; // dynamic LDS bytes k_nrc_train has been enabled for on this device
     std::string lastError;
     // scene (host mirror)

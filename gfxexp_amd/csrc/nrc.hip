@@ -166,6 +166,29 @@ GFX_DEV void gather_corners(const uint32_t* __restrict__ grid, const uint32_t id
     for (int c = 0; c < 8; ++c) e[c] = grid[idx[c]];
 }
 
+// Canonical features f0 .. f0 + 3 of one batch column that do not come out of the hash grid: triangle wave (posEnc 0), one-blob,
+// identity, padding ones.
+GFX_DEV void encode_plain_group(int posFeatures /* 32: hash grid, 36: triangle wave */, const float x[kNrcIn], int f0, float v[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = f0 + r;
+        float val = 1.0f;                                       // padding
+        if (f < posFeatures) {                                  // triangle wave: feature 12 dim + freq
+            const int dim = f / kTriFreqs, freq = f % kTriFreqs;
+            const float xs = ldexpf(x[dim], freq - 1);
+            val = fabsf(xs - floorf(xs) - 0.5f) * 4 - 1;
+        }
+        else if (f < posFeatures + 20) {
+            const int o = f - posFeatures;
+            float ob[4];
+            oneblob4(x[3 + (o >> 2)], ob);
+            val = ob[o & 3];
+        }
+        else if (f < posFeatures + 26) val = x[8 + (f - posFeatures - 20)];
+        v[r] = val;
+    }
+}
+
 // The 32 canonical features a lane (half h) supplies for one batch column, in K-slot order
 // out[s * 8 + i] = feature f(s, h, i).  Canonical order: [position 32|36] [one-blob 20] [identity 6] [ones].
 GFX_DEV void encode_half(const NrcDev& d, const uint32_t* __restrict__ grid, const float x[kNrcIn], int h, float out[32]) {
@@ -191,27 +214,7 @@ GFX_DEV void encode_half(const NrcDev& d, const uint32_t* __restrict__ grid, con
                 v[2 * k] = a0; v[2 * k + 1] = a1;
             }
         }
-        else {
-            const int posFeatures = d.posEnc == 1 ? 32 : 3 * kTriFreqs;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = f0 + r;
-                float val = 1.0f;                                       // padding
-                if (f < posFeatures) {                                  // triangle wave: feature 12 dim + freq
-                    const int dim = f / kTriFreqs, freq = f % kTriFreqs;
-                    const float xs = ldexpf(x[dim], freq - 1);
-                    val = fabsf(xs - floorf(xs) - 0.5f) * 4 - 1;
-                }
-                else if (f < posFeatures + 20) {
-                    const int o = f - posFeatures;
-                    float ob[4];
-                    oneblob4(x[3 + (o >> 2)], ob);
-                    val = ob[o & 3];
-                }
-                else if (f < posFeatures + 26) val = x[8 + (f - posFeatures - 20)];
-                v[r] = val;
-            }
-        }
+        else encode_plain_group(d.posEnc == 1 ? 32 : 3 * kTriFreqs, x, f0, v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[4 * q + r] = v[r];
     }
@@ -331,6 +334,182 @@ __global__ __launch_bounds__(kInferBlock) __attribute__((amdgpu_waves_per_eu(GFX
                 float* o = predictions + static_cast<size_t>(col) * kNrcOut;
                 o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- inference, hash-grid levels staged through LDS
+// k_nrc_infer above gathers 128 four-byte table entries per query through the vector-memory path: 270 M L1 fills of a 64-byte sector
+// each per full-HD batch, 0.89 TCP requests per CU and clock -- that, not the matrix pipe (MFMA busy 3 %), is what it runs at
+// (profiles/r04_nrc_pmc.txt).  A level's table is at most 2^15 entries x (2 x bf16) = 128 KiB and a CU has 160 KiB of LDS, so a large
+// batch is encoded level-synchronously instead: one persistent 8-wave block per CU; per pass it owns 8 x kStagedTiles tiles of 64
+// queries; for each of the 16 levels the block copies the level's table into LDS with global->LDS DMA (coalesced, 2 MB of L2 reads per
+// pass and CU) and every lane computes the level's two features of ONE query of each of its wave's tiles -- eight ds_read_b32 per
+// corner set, no L1 fill, no 64-byte sector per 4-byte corner -- packs them to the bf16 pair the MFMA operand wants and hands the
+// pair to the lane that owns that (query, feature group) in the operand layout (lane n of half h: queries n and 32 + n of the tile, the
+// levels with bit 1 == h), which is its partner lane ^ 32 or itself.  The hash half of the operands (16 registers per tile) waits in
+// registers; when the 16 levels are done the LDS holds the weight fragments and a staging area instead, and the wave runs the rest of
+// k_nrc_infer's body per tile: one-blob / identity features, the layers, the output.  Per query the same operations in the same order as
+// k_nrc_infer: the outputs are bit-equal (tests/test_gpu_nrc_net.py).  Small batches (the training tiles' suffix queries) keep k_nrc_infer:
+// a pass costs 2 MB of table copies whatever it encodes.
+constexpr int kStagedBlock = 512;                        // 8 waves, 2 per SIMD
+constexpr int kStagedTiles = 8;                          // tiles per wave and pass: 8 x 8 x 64 = 4 096 queries per pass and CU
+constexpr uint32_t kStagedTableBytes = 4u << kLog2Hashmap;
+GFX_DEV uint32_t staged_word(const uint4& v, int w) { return w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w; }
+GFX_DEV void staged_set_word(uint4& v, int w, uint32_t x) { if (w == 0) v.x = x; else if (w == 1) v.y = x; else if (w == 2) v.z = x; else v.w = x; }
+__global__ __launch_bounds__(kStagedBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_t* __restrict__ grid, const float* __restrict__ inputs,
+                        uint32_t numDataArg, const uint32_t* __restrict__ numDataPtr, float* __restrict__ predictions) {
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsAll[];         // kStagedTableBytes: a level's table, then weights + staging
+    const uint32_t numData = numDataPtr ? min(*numDataPtr, numDataArg) : numDataArg;
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t numTiles = (numData + 63) / 64;
+    constexpr uint32_t kTilesPerPass = (kStagedBlock / 64) * kStagedTiles;
+    const uint32_t numPasses = (numTiles + kTilesPerPass - 1) / kTilesPerPass;
+    const uint32_t fwdElems = d.numHidden * kMatFwdElems + kOutFwdElems;
+    const uint32_t* ldsTable = reinterpret_cast<const uint32_t*>(ldsAll);
+    for (uint32_t pass = blockIdx.x; pass < numPasses; pass += gridDim.x) {
+        const uint32_t tile0 = pass * kTilesPerPass + wave * kStagedTiles;
+        // the position of query `lane` of each tile (inputs are [14] per query: three strided loads)
+        float px[kStagedTiles], py[kStagedTiles], pz[kStagedTiles];
+#pragma unroll
+        for (int t = 0; t < kStagedTiles; ++t) {
+            const size_t col = static_cast<size_t>(tile0 + t) * 64 + lane;
+            const bool ok = col < numData;
+            px[t] = ok ? inputs[col * kNrcIn] : 0.0f; py[t] = ok ? inputs[col * kNrcIn + 1] : 0.0f; pz[t] = ok ? inputs[col * kNrcIn + 2] : 0.0f;
+        }
+        uint4 hb[kStagedTiles][2][2];                       // [tile][nt][s]: K steps 0 and 1 of the B operand = the 16 hash-grid features of this half
+#pragma unroll
+        for (int t = 0; t < kStagedTiles; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hb[t][k >> 1][k & 1] = make_uint4(0u, 0u, 0u, 0u);
+        // Level L = 2 g + k: group g belongs to half g & 1 as its (g >> 1)-th group, slots 4 (g >> 1) + 2 k, + 1 (encode_half), i.e. word
+        // pos = 2 (g >> 1) + k of the half's eight hash words (K step pos >> 2, word pos & 3).  Levels L and L + 2 (bit 1 of L clear) fill
+        // the same word position, one for each half: the loop runs over the positions, two levels each.
+        for (int pos = 0; pos < 8; ++pos) {
+            uint32_t w0[kStagedTiles], w1[kStagedTiles];    // the new word of tile half 0 / 1 of every tile
+#pragma unroll
+            for (int t = 0; t < kStagedTiles; ++t) { w0[t] = 0u; w1[t] = 0u; }
+#pragma unroll
+            for (int hL = 0; hL < 2; ++hL) {
+                const int L = 4 * (pos >> 1) + (pos & 1) + 2 * hL;
+                NrcLevel lv = d.levels[L];
+                __syncthreads();                            // the table (or the weights / staging area) of before is no longer read
+                {
+                    const char* src = reinterpret_cast<const char*>(grid + lv.offset);
+                    const uint32_t bytes = lv.entries * 4u; // a multiple of 32
+                    for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < bytes; off += (kStagedBlock / 64) * 1024u) {
+                        if (off + static_cast<uint32_t>(lane) * 16u < bytes) {
+                            typedef const __attribute__((address_space(1))) void* GlobalPtr;
+                            typedef __attribute__((address_space(3))) void* LdsPtr;
+                            __builtin_amdgcn_global_load_lds((GlobalPtr)(src + off + lane * 16), (LdsPtr)(reinterpret_cast<char*>(ldsAll) + off), 16, 0, 0);
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                lv.offset = 0u;                             // indices into the LDS copy
+#pragma unroll
+                for (int t = 0; t < kStagedTiles; ++t) {
+                    uint32_t idx[8]; float w[8]; uint32_t e[8];
+                    grid_corners(lv, px[t], py[t], pz[t], idx, w);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) e[c] = ldsTable[idx[c]];
+                    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        a0 = a0 + w[c] * from_bf16_bits(e[c] & 0xFFFFu);
+                        a1 = a1 + w[c] * from_bf16_bits(e[c] >> 16);
+                    }
+                    const uint32_t mine = to_bf16_bits(a0) | (to_bf16_bits(a1) << 16);       // query `lane` of the tile
+                    const uint32_t partner = static_cast<uint32_t>(__shfl_xor(static_cast<int>(mine), 32));   // query `lane ^ 32`
+                    if (h == hL) {
+                        // this lane owns queries n (tile half 0: computed by lane n) and 32 + n (half 1: computed by lane 32 + n)
+                        w0[t] = h ? partner : mine;
+                        w1[t] = h ? mine : partner;
+                    }
+                }
+            }
+            switch (pos) {                                  // block-uniform
+#define GFX_STAGED_CASE(P) case P: _Pragma("unroll") for (int t = 0; t < kStagedTiles; ++t) { \
+                staged_set_word(hb[t][0][(P) >> 2], (P) & 3, w0[t]); staged_set_word(hb[t][1][(P) >> 2], (P) & 3, w1[t]); } break;
+            GFX_STAGED_CASE(0) GFX_STAGED_CASE(1) GFX_STAGED_CASE(2) GFX_STAGED_CASE(3)
+            GFX_STAGED_CASE(4) GFX_STAGED_CASE(5) GFX_STAGED_CASE(6) GFX_STAGED_CASE(7)
+#undef GFX_STAGED_CASE
+            default: break;
+            }
+        }
+        __syncthreads();                                    // the last table is no longer read
+        for (uint32_t i = threadIdx.x; i < fwdElems / 8; i += kStagedBlock) ldsAll[i] = reinterpret_cast<const uint4*>(fwd)[i];
+        __syncthreads();
+        const uint4* ldsW = ldsAll;
+        float* ldsX = reinterpret_cast<float*>(ldsAll + fwdElems / 8) + wave * (64 * kNrcIn);
+        for (int t = 0; t < kStagedTiles; ++t) {           // not unrolled: the tile in turn is hb[0], the others move up behind it
+            const uint32_t tile = tile0 + t;
+            if (tile < numTiles) {                          // wave-uniform
+            {
+                const size_t base = static_cast<size_t>(tile) * 64 * kNrcIn;
+                const size_t limit = static_cast<size_t>(numData) * kNrcIn;
+                float v[kNrcIn];
+#pragma unroll
+                for (int j = 0; j < kNrcIn; ++j) { const size_t e = base + 64 * j + lane; v[j] = e < limit ? inputs[e] : 0.0f; }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < kNrcIn; ++j) ldsX[64 * j + lane] = v[j];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            uint4 b[2][4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float x[kNrcIn];
+#pragma unroll
+                for (int k = 0; k < kNrcIn; ++k) x[k] = ldsX[(32 * nt + n) * kNrcIn + k];
+                // groups 8 .. 15 of this half (slots 16 .. 31): one-blob, identity, padding -- encode_half's plain branch
+                float enc[16];
+                if (h == 0) {
+#pragma unroll
+                    for (int q = 4; q < 8; ++q) encode_plain_group(32, x, 4 * (2 * q), enc + 4 * (q - 4));
+                }
+                else {
+#pragma unroll
+                    for (int q = 4; q < 8; ++q) encode_plain_group(32, x, 4 * (2 * q + 1), enc + 4 * (q - 4));
+                }
+                b[nt][0] = hb[0][nt][0]; b[nt][1] = hb[0][nt][1];
+                b[nt][2] = pack8(enc); b[nt][3] = pack8(enc + 8);
+            }
+            for (int layer = 0; layer < d.numHidden; ++layer) {
+                const uint4* frags = ldsW + layer * (kMatFwdElems / 8);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x16 acc[2];
+                    layer64(frags, lane, b[nt], acc);
+                    relu_to_operand(acc, b[nt]);
+                }
+            }
+            const uint4* fragsOut = ldsW + d.numHidden * (kMatFwdElems / 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fragsOut[s * 64 + lane]),
+                                                                __builtin_bit_cast(bf16x8, b[nt][s]), c, 0, 0, 0);
+                const uint32_t col = tile * 64 + 32 * nt + n;
+                if (h == 0 && col < numData) {
+                    float* o = predictions + static_cast<size_t>(col) * kNrcOut;
+                    o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+                }
+            }
+            }
+#pragma unroll
+            for (int k = 0; k + 1 < kStagedTiles; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hb[k][j >> 1][j & 1] = hb[k + 1][j >> 1][j & 1];
         }
     }
 }
@@ -838,6 +1017,21 @@ void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     if (net->inferDirty) { nrc_pack(ctx, stream, *net, false); net->inferDirty = false; }
     const int numCUs = ctx.numCUs;
     const uint32_t numTiles = numData / 64;
+    // A large hash-grid batch is encoded level by level out of LDS copies of the level tables (k_nrc_infer_staged): worth it when every CU
+    // gets at least one pass of 4 096 queries ("nrc_staged_infer": 0 by batch size, 1 never, 2 always)
+    const uint32_t stagedPasses = (numTiles + (kStagedBlock / 64) * kStagedTiles - 1) / ((kStagedBlock / 64) * kStagedTiles);
+    const bool staged = net->d.posEnc == 1 && ctx.tune.nrcStagedInfer != 1 && (ctx.tune.nrcStagedInfer == 2 || stagedPasses >= static_cast<uint32_t>(numCUs));
+    if (staged) {
+        if (!ctx.nrcInferStagedConfigured) {
+            GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_infer_staged), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kStagedTableBytes)));
+            ctx.nrcInferStagedConfigured = true;
+        }
+        ScopedKernelTimer timer(ctx, stream, "nrc_infer");
+        hipLaunchKernelGGL(k_nrc_infer_staged, dim3(std::min<uint32_t>(stagedPasses, static_cast<uint32_t>(numCUs))), dim3(kStagedBlock), kStagedTableBytes, stream, net->d,
+                           net->packInferFwd.as<uint16_t>(), net->gridInfer.as<uint32_t>(), dInputs, numData, dNumData, dPredictions);
+        GFX_HIP(hipGetLastError());
+        return;
+    }
     const uint32_t wavesPerBlock = kInferBlock / 64;
     uint32_t grid = std::min<uint32_t>((numTiles + wavesPerBlock - 1) / wavesPerBlock, static_cast<uint32_t>(numCUs) * 4);
     const size_t lds = 2ull * (net->d.numHidden * kMatFwdElems + kOutFwdElems) + wavesPerBlock * 64 * kNrcIn * sizeof(float);

@@ -65,6 +65,52 @@ def test_inference_matches_oracle(built_lib, pos_enc, hidden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hidden,n", [(2, 128 * 37), (5, 128 * 261 + 128), (2, 4096 * 260 + 128 * 9)])
+def test_level_staged_inference_equals_the_in_place_kernel(built_lib, hidden, n):
+    """gfx_nrc_infer with the hash-grid encoding, "nrc_staged_infer" 2 (k_nrc_infer_staged: one persistent block per CU, every level's
+    table copied into LDS, corners read with ds_read, features handed to the lane that owns them in the MFMA operand layout) against 1
+    (k_nrc_infer: 128 gathers per query from the tables in place): the same predictions BIT FOR BIT -- the same operations per query in
+    the same order -- for a batch of less than one pass, a ragged batch of a few passes per block with the deep network, and a
+    full-HD-sized batch (more passes than CUs, last pass ragged); the device-side batch size (gfx_nrc_infer_indirect) is honoured; the
+    small batch is also held against the oracle."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(5 + hidden)
+    p = _random_params(rng, N.POS_HASHGRID, hidden)
+    x = _inputs(rng, n)
+    x[:4, :3] = [[0, 0, 0], [1, 1, 1], [0.999999, 0.5, 0.25], [0.5, 0.0, 1.0]]      # grid borders
+    outs = {}
+    for mode in (1, 2):
+        ctx = api.Context(0)
+        ctx.tunable_set("nrc_staged_infer", mode)
+        net = api.NeuralRadianceCache(ctx, N.POS_HASHGRID, hidden)
+        net.set_params(p)
+        dx = torch.from_numpy(x).cuda()
+        dy = torch.full((n, 3), -7.0, dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        net.infer(dx.data_ptr(), n, dy.data_ptr(), stream)
+        torch.cuda.synchronize()
+        outs[mode] = dy.cpu().numpy().copy()
+        # device-side count: only the first `live` queries are inferred, the rest of the output is untouched
+        live = n - 128 * 3
+        cnt = torch.tensor([live], dtype=torch.int32, device="cuda")
+        dz = torch.full((n, 3), -7.0, dtype=torch.float32, device="cuda")
+        ctx._check(api.lib().gfx_nrc_infer_indirect(ctx.h, C.c_void_p(stream), C.c_uint64(net.h), C.c_void_p(dx.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                                      C.c_uint32(n), C.c_void_p(dz.data_ptr())))
+        torch.cuda.synchronize()
+        z = dz.cpu().numpy()
+        assert np.array_equal(z[:live].view(np.uint32), outs[mode][:live].view(np.uint32)), f"mode {mode}: indirect batch differs"
+        assert (z[live:] == -7.0).all(), f"mode {mode}: queries past the device-side count were written"
+        net.close()
+        ctx.close()
+    assert np.isfinite(outs[1]).all() and (outs[1] != -7.0).any()
+    diff = outs[1].view(np.uint32) != outs[2].view(np.uint32)
+    assert not diff.any(), f"{np.count_nonzero(diff)} of {diff.size} outputs differ between the staged and the in-place kernel (first query {np.argwhere(diff)[0][0]})"
+    if n < 10000:
+        _check_inference(outs[2], N.NrcNet(N.POS_HASHGRID, hidden, params=p).infer(x))
+
+
+@pytest.mark.gpu
 def test_batch_size_must_be_a_multiple_of_128(built_lib):
     import torch
     ctx = api.Context(0)
