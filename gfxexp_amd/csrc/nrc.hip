@@ -125,15 +125,17 @@ GFX_DEV void oneblob4(float x, float out[4]) {
 // Hashed levels: x ^ y * 2654435761 ^ z * 805459861 (uint32) modulo the table size; dense levels:
 // x + y res + z res^2 modulo the table size.  Table sizes are powers of two for the configuration
 // the reference uses (4096, 32768), where the modulo is a mask.
-GFX_DEV void grid_corners(const NrcLevel& lv, float px, float py, float pz, uint32_t idx[8], float w[8]) {
+// DENSE / POW2: 0 or 1 when the caller has decided (both are properties of the level, the same for every query), -1 = decided here.
+template <int DENSE, int POW2>
+GFX_DEV void grid_corners_t(const NrcLevel& lv, float px, float py, float pz, uint32_t idx[8], float w[8]) {
     const float x = px * lv.scale + 0.5f, y = py * lv.scale + 0.5f, z = pz * lv.scale + 0.5f;
     const float bx = floorf(x), by = floorf(y), bz = floorf(z);
     const float fx = x - bx, fy = y - by, fz = z - bz;
     const uint32_t ix = static_cast<uint32_t>(static_cast<int32_t>(bx));
     const uint32_t iy = static_cast<uint32_t>(static_cast<int32_t>(by));
     const uint32_t iz = static_cast<uint32_t>(static_cast<int32_t>(bz));
-    const bool dense = static_cast<unsigned long long>(lv.res) * lv.res * lv.res <= lv.entries;
-    const bool pow2 = (lv.entries & (lv.entries - 1)) == 0;
+    const bool dense = DENSE >= 0 ? DENSE != 0 : static_cast<unsigned long long>(lv.res) * lv.res * lv.res <= lv.entries;
+    const bool pow2 = POW2 >= 0 ? POW2 != 0 : (lv.entries & (lv.entries - 1)) == 0;
     uint32_t tx[2], ty[2], tz[2];
     if (dense) {
         tx[0] = ix; tx[1] = ix + 1;
@@ -154,6 +156,7 @@ GFX_DEV void grid_corners(const NrcLevel& lv, float px, float py, float pz, uint
         w[c] = wx[ox] * wy[oy] * wz[oz];
     }
 }
+GFX_DEV void grid_corners(const NrcLevel& lv, float px, float py, float pz, uint32_t idx[8], float w[8]) { grid_corners_t<-1, -1>(lv, px, py, pz, idx, w); }
 
 // The 8 table entries of one level: eight 4-byte gathers.  (Fetching the x-neighbour pair of a corner with one 16-byte block
 // load was measured slower -- the pair already shares its 64-byte sector in ~90 % of the cases and the gathers are bound by
@@ -357,6 +360,32 @@ constexpr int kStagedTiles = 8;                          // tiles per wave and p
 constexpr uint32_t kStagedTableBytes = 4u << kLog2Hashmap;
 GFX_DEV uint32_t staged_word(const uint4& v, int w) { return w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w; }
 GFX_DEV void staged_set_word(uint4& v, int w, uint32_t x) { if (w == 0) v.x = x; else if (w == 1) v.y = x; else if (w == 2) v.z = x; else v.w = x; }
+// One level for the wave's kStagedTiles tiles: the level's two features of query `lane` of every tile out of the LDS copy of the table,
+// as the bf16 pair of the operand layout, for the lane that owns it (half hL: queries n and 32 + n of the tile).
+template <int DENSE, int POW2>
+GFX_DEV void staged_level(const NrcLevel& lv, const uint32_t* ldsTable, const float (&px)[kStagedTiles], const float (&py)[kStagedTiles], const float (&pz)[kStagedTiles],
+                          int h, int hL, uint32_t (&w0)[kStagedTiles], uint32_t (&w1)[kStagedTiles]) {
+#pragma unroll
+    for (int t = 0; t < kStagedTiles; ++t) {
+        uint32_t idx[8]; float w[8]; uint32_t e[8];
+        grid_corners_t<DENSE, POW2>(lv, px[t], py[t], pz[t], idx, w);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) e[c] = ldsTable[idx[c]];
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            a0 = a0 + w[c] * from_bf16_bits(e[c] & 0xFFFFu);
+            a1 = a1 + w[c] * from_bf16_bits(e[c] >> 16);
+        }
+        const uint32_t mine = to_bf16_bits(a0) | (to_bf16_bits(a1) << 16);       // query `lane` of the tile
+        const uint32_t partner = static_cast<uint32_t>(__shfl_xor(static_cast<int>(mine), 32));   // query `lane ^ 32`
+        if (h == hL) {
+            // this lane owns queries n (tile half 0: computed by lane n) and 32 + n (half 1: computed by lane 32 + n)
+            w0[t] = h ? partner : mine;
+            w1[t] = h ? mine : partner;
+        }
+    }
+}
 __global__ __launch_bounds__(kStagedBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_t* __restrict__ grid, const float* __restrict__ inputs,
                         uint32_t numDataArg, const uint32_t* __restrict__ numDataPtr, float* __restrict__ predictions) {
@@ -410,26 +439,12 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
                 }
                 __syncthreads();
                 lv.offset = 0u;                             // indices into the LDS copy
-#pragma unroll
-                for (int t = 0; t < kStagedTiles; ++t) {
-                    uint32_t idx[8]; float w[8]; uint32_t e[8];
-                    grid_corners(lv, px[t], py[t], pz[t], idx, w);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) e[c] = ldsTable[idx[c]];
-                    float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        a0 = a0 + w[c] * from_bf16_bits(e[c] & 0xFFFFu);
-                        a1 = a1 + w[c] * from_bf16_bits(e[c] >> 16);
-                    }
-                    const uint32_t mine = to_bf16_bits(a0) | (to_bf16_bits(a1) << 16);       // query `lane` of the tile
-                    const uint32_t partner = static_cast<uint32_t>(__shfl_xor(static_cast<int>(mine), 32));   // query `lane ^ 32`
-                    if (h == hL) {
-                        // this lane owns queries n (tile half 0: computed by lane n) and 32 + n (half 1: computed by lane 32 + n)
-                        w0[t] = h ? partner : mine;
-                        w1[t] = h ? mine : partner;
-                    }
-                }
+                // (the kind of the level decides the index arithmetic once for all queries: a mask for the power-of-two tables of the
+                // reference's configuration, hashed or dense; anything else takes the general form)
+                const bool dense = static_cast<unsigned long long>(lv.res) * lv.res * lv.res <= lv.entries, pow2 = (lv.entries & (lv.entries - 1)) == 0;
+                if (pow2 && !dense) staged_level<0, 1>(lv, ldsTable, px, py, pz, h, hL, w0, w1);
+                else if (pow2) staged_level<1, 1>(lv, ldsTable, px, py, pz, h, hL, w0, w1);
+                else staged_level<-1, -1>(lv, ldsTable, px, py, pz, h, hL, w0, w1);
             }
             switch (pos) {                                  // block-uniform
 #define GFX_STAGED_CASE(P) case P: _Pragma("unroll") for (int t = 0; t < kStagedTiles; ++t) { \
@@ -467,16 +482,24 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
                 float x[kNrcIn];
 #pragma unroll
                 for (int k = 0; k < kNrcIn; ++k) x[k] = ldsX[(32 * nt + n) * kNrcIn + k];
-                // groups 8 .. 15 of this half (slots 16 .. 31): one-blob, identity, padding -- encode_half's plain branch
+                // groups 8 .. 15 of this half (slots 16 .. 31): one-blob, identity, padding -- encode_half's plain branch, with the two halves
+                // side by side instead of one after the other: half h owns groups 8 + h, 10 + h, 12 + h, 14 + h; groups 8 .. 12 are the one-blob
+                // encodings of inputs 3 .. 7 (four features each), 13 and 14 the six identity inputs + two ones, 15 ones
                 float enc[16];
-                if (h == 0) {
 #pragma unroll
-                    for (int q = 4; q < 8; ++q) encode_plain_group(32, x, 4 * (2 * q), enc + 4 * (q - 4));
-                }
-                else {
+                for (int i = 0; i < 2; ++i) {               // groups 8 + h and 10 + h: one-blob of input 3 + h / 5 + h
+                    float ob[4];
+                    oneblob4(h ? x[4 + 2 * i] : x[3 + 2 * i], ob);
 #pragma unroll
-                    for (int q = 4; q < 8; ++q) encode_plain_group(32, x, 4 * (2 * q + 1), enc + 4 * (q - 4));
+                    for (int r = 0; r < 4; ++r) enc[4 * i + r] = ob[r];
                 }
+                {                                           // group 12 (h = 0): one-blob of input 7; group 13 (h = 1): inputs 8 .. 11
+                    float ob[4];
+                    oneblob4(x[7], ob);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) enc[8 + r] = h ? x[8 + r] : ob[r];
+                }
+                enc[12] = h ? 1.0f : x[12]; enc[13] = h ? 1.0f : x[13]; enc[14] = 1.0f; enc[15] = 1.0f;   // group 14 (h = 0): inputs 12, 13, ones; 15: ones
                 b[nt][0] = hb[0][nt][0]; b[nt][1] = hb[0][nt][1];
                 b[nt][2] = pack8(enc); b[nt][3] = pack8(enc + 8);
             }
