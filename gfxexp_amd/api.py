@@ -246,7 +246,7 @@ C_ABI_SYMBOLS = [
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_lights_table_info", "gfx_trace", "gfx_trace_counted", "gfx_restir_set_params", "gfx_restir_copy_to_linear", "gfx_visualize", "gfx_restir_launch",
     "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_infer_indirect", "gfx_nrc_query_count_ptr", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
-    "gfx_nrc_get_params", "gfx_nrc_inference_image", "gfx_nrc_set_render_params",
+    "gfx_nrc_get_params", "gfx_nrc_inference_image", "gfx_nrc_inference_image_async", "gfx_nrc_set_render_params",
     "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read", "gfx_trace_diag_read",
     "gfx_tunable_set", "gfx_stream_copy",
 ]
@@ -260,9 +260,9 @@ HOST_ABI_SYMBOLS = [
     "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_band_rows", "gfxh_restir_check_partition", "gfxh_restir_check_bands", "gfxh_balance_bands", "gfxh_restir_frame_program", "gfxh_frame_step_exchange_desc",
     "gfxh_rccl_unique_id", "gfxh_rccl_create", "gfxh_rccl_destroy", "gfxh_rccl_exchange", "gfxh_rccl_last_error", "gfxh_restir_create",
     "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_make_sky", "gfxh_restir_set_env",
-    "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
+    "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_outputs_consumed", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
-    "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_set_exchange", "gfxh_nrc_rebuild_accel", "gfxh_nrc_beauty_buffer",
+    "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_outputs_consumed", "gfxh_nrc_set_exchange", "gfxh_nrc_rebuild_accel", "gfxh_nrc_beauty_buffer",
     "gfxh_nrc_network", "gfxh_nrc_stats", "gfxh_save_image_sdr", "gfxh_save_image_hdr", "gfxh_tonemap_sdr",
 ]
 

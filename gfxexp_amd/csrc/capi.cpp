@@ -455,6 +455,13 @@ int gfx_nrc_inference_image(gfx_ctx* ctx, uint64_t handle, int which, void** dPt
     GFX_CATCH(ctx)
 }
 
+int gfx_nrc_inference_image_async(gfx_ctx* ctx, void* stream, uint64_t handle, int which, void** dPtr, uint64_t* bytes) {
+    GFX_TRY(ctx)
+    if (!dPtr || !bytes) throw HipError("gfx_nrc_inference_image_async: null output");
+    nrc_inference_image(ctx->c, nrc_of(ctx, handle), which, dPtr, bytes, static_cast<hipStream_t>(stream), true);
+    GFX_CATCH(ctx)
+}
+
 int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes) {
     GFX_TRY(ctx)
     GFX_HIP(hipDeviceSynchronize());

@@ -62,6 +62,8 @@ struct gfxh_nrc {
     hipStream_t gbStream = nullptr;
     hipEvent_t evGb = nullptr, evGbFree = nullptr;
     bool pipelineFrames = true, gbFreePending = false;
+    hipEvent_t evConsumed = nullptr;          // gfxh_nrc_outputs_consumed: the caller's reads of the albedo / normal accumulators are behind this event
+    bool consumedPending = false;
     bool trainPending = false, overlapTraining = true;
     // band renderer (gfxh_nrc_set_exchange)
     gfxh_exchange_fn exchange = nullptr; void* exchangeUser = nullptr; int rank = 0;
@@ -102,6 +104,7 @@ void gfxh_nrc_destroy(gfxh_nrc* r) {
     if (r->trainStream) (void)hipStreamDestroy(r->trainStream);
     if (r->evGb) (void)hipEventDestroy(r->evGb);
     if (r->evGbFree) (void)hipEventDestroy(r->evGbFree);
+    if (r->evConsumed) (void)hipEventDestroy(r->evConsumed);
     if (r->gbStream) (void)hipStreamDestroy(r->gbStream);
     if (r->network) (void)gfx_nrc_destroy(r->ctx, r->network);
     for (void* p : r->allocations) (void)hipFree(p);
@@ -279,6 +282,7 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     const bool pipelined = r->pipelineFrames && !band && !viewMoved && !newSequence;
     if (pipelined) {
         if (r->gbFreePending) NRC_HIP(hipStreamWaitEvent(r->gbStream, r->evGbFree, 0));
+        if (r->consumedPending) { NRC_HIP(hipStreamWaitEvent(r->gbStream, r->evConsumed, 0)); r->consumedPending = false; }
         NRC_GFX(gfx_pt_launch(ctx, r->gbStream, GFX_PT_SETUP_GBUFFERS, W, H, cfg.maxPathLength, rb, re));
         NRC_HIP(hipEventRecord(r->evGb, r->gbStream));
         NRC_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), r->evGb, 0));
@@ -399,7 +403,7 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
             d.kind = GFXH_EXCHANGE_BROADCAST;
             for (int which = 0; which < 2; ++which) {
                 void* p = nullptr; uint64_t bytes = 0;
-                NRC_GFX(gfx_nrc_inference_image(ctx, r->network, which, &p, &bytes));
+                NRC_GFX(gfx_nrc_inference_image_async(ctx, ts, r->network, which, &p, &bytes));   // packed on the training stream, behind the four steps
                 if (!p || !bytes) continue;
                 gfxh_exchange_buffer& b = d.buffers[d.numBuffers++];
                 b.base = p; b.bytesPerPixel = 1; b.numPlanes = 1; b.planeStride = bytes;
@@ -451,6 +455,13 @@ int gfxh_nrc_stats(gfxh_nrc* r, uint32_t* numTrainingData, uint32_t tileSize[2],
     if (numTrainingData) *numTrainingData = r->lastNumTrainingData;
     if (tileSize) { tileSize[0] = r->lastTileSize[0]; tileSize[1] = r->lastTileSize[1]; }
     if (numInferenceQueries) *numInferenceQueries = r->lastNumInferenceQueries;
+    return 0;
+}
+int gfxh_nrc_outputs_consumed(gfxh_nrc* r, void* stream) {
+    if (!r) { g_nrcError = "gfxh_nrc_outputs_consumed: null renderer"; return 1; }
+    if (!r->evConsumed) NRC_HIP(hipEventCreateWithFlags(&r->evConsumed, hipEventDisableTiming));
+    NRC_HIP(hipEventRecord(r->evConsumed, static_cast<hipStream_t>(stream)));
+    r->consumedPending = true;
     return 0;
 }
 const char* gfxh_nrc_last_error(void) { return g_nrcError.c_str(); }

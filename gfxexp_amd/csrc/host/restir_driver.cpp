@@ -47,6 +47,9 @@ struct gfxh_restir {
     hipStream_t gbStream = nullptr;
     hipEvent_t evPrevRead = nullptr, evGbuffer = nullptr;
     bool prevReadPending = false, pipelineFrames = true;
+    // gfxh_restir_outputs_consumed: the caller's stream has passed its reads of the albedo / normal accumulators the next G-buffer pass rewrites
+    hipEvent_t evConsumed = nullptr;
+    bool consumedPending = false;
     // strip-exchange mode of a band renderer (gfxh_restir_set_exchange)
     gfxh_exchange_fn exchange = nullptr;
     void* exchangeUser = nullptr;
@@ -214,6 +217,7 @@ void gfxh_restir_destroy(gfxh_restir* r) {
     if (!r) return;
     (void)hipDeviceSynchronize();
     if (r->evPrevRead) (void)hipEventDestroy(r->evPrevRead);
+    if (r->evConsumed) (void)hipEventDestroy(r->evConsumed);
     if (r->evGbuffer) (void)hipEventDestroy(r->evGbuffer);
     if (r->gbStream) (void)hipStreamDestroy(r->gbStream);
     for (void* p : r->allocations) (void)hipFree(p);
@@ -685,6 +689,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
                 s = r->gbStream;
                 if (r->prevReadPending) DRV_HIP(hipStreamWaitEvent(s, r->evPrevRead, 0));
                 else { DRV_HIP(hipEventRecord(r->evPrevRead, main)); DRV_HIP(hipStreamWaitEvent(s, r->evPrevRead, 0)); }   // first frame: after whatever the caller queued
+                if (r->consumedPending) { DRV_HIP(hipStreamWaitEvent(s, r->evConsumed, 0)); r->consumedPending = false; }   // gfxh_restir_outputs_consumed
             }
             DRV_GFX(gfx_restir_set_params(ctx, s, &r->sp, &fp, st.currentReservoirIndex, st.spatialNeighborBaseIndex));
             if (st.op == GFXH_STEP_PT_PASS) DRV_GFX(gfx_pt_launch(ctx, s, static_cast<int>(st.pass), W, H, cfg.maxPathLength, st.rowBegin, st.rowEnd));
@@ -714,6 +719,15 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     r->lastSpatialNeighborBaseIndex = newLastBase;
     r->prevCamera = r->camera;
     ++r->frameIndex;
+    return 0;
+}
+
+int gfxh_restir_outputs_consumed(gfxh_restir* r, void* stream) {
+    if (!r) { g_driverError = "gfxh_restir_outputs_consumed: null renderer"; return 1; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!r->evConsumed && !hip_ok(hipEventCreateWithFlags(&r->evConsumed, hipEventDisableTiming), "hipEventCreate")) return 1;
+    if (!hip_ok(hipEventRecord(r->evConsumed, s), "hipEventRecord")) return 1;
+    r->consumedPending = true;
     return 0;
 }
 

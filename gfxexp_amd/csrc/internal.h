@@ -63,7 +63,7 @@ struct Accel {
     // roots (2 x 8 floats, device), triangle count and node range of the static part
     bool split = false;
     DevBuf rootBoxes;
-    uint32_t numStaticTris = 0, staticNodeEnd = 0;
+    uint32_t numStaticTris = 0, staticNodeEnd = 0, staticDepth = 0;   // staticDepth: levels of the static subtree (lbvh_update_dynamic re-derives maxDepth)
     Bvh8Tri* trisPtr() const { return reinterpret_cast<Bvh8Tri*>(nodes.as<Bvh8Node>() + triItemOffset); }
     DevAccel dev() const {
         DevAccel a; a.nodes = nodes.as<Bvh8Node>(); a.links = links.as<Bvh8Link>(); a.tris = trisPtr(); a.numNodes = numNodes; a.numTris = numTris;
@@ -166,10 +166,11 @@ struct Context {
     // trace of the same bounce (pathtrace.hip); auxFork / auxJoin order the two streams
     DevBuf auxSpill, auxCounters;
     // fused ReSTIR kernels (restir.hip): step counts per block of the last launch and the block order made from them, for one launch shape
-    // ([0] k_initial_fused, [1] k_shading_fused, [2] k_gbuffer_fused, [3] k_initial_candidates, [4] k_pt_fused).  k_order_blocks runs on auxStream behind the launch that wrote the costs (`counted`);
+    // ([0] k_initial_fused, [1] k_shading_fused, [2] k_gbuffer_fused, [3] k_initial_candidates, [4] k_pt_fused).  k_order_blocks runs on orderStream behind the launch that wrote the costs (`counted`);
     // the next launch of that kind waits for `ordered`.
     struct BlockOrder { DevBuf cost, order; uint64_t key = 0; uint32_t blocks = 0; bool valid = false; hipEvent_t counted = nullptr, ordered = nullptr; } blockOrders[5];
     hipStream_t auxStream = nullptr;
+    hipStream_t orderStream = nullptr;       // k_order_blocks (restir.hip block_order_end)
     hipEvent_t auxFork = nullptr, auxJoin = nullptr;
     // path tracer scratch (pathtrace.hip)
     DevBuf ptPending, ptExtOrg, ptExtDir, ptExtOwner, ptState;
@@ -260,7 +261,7 @@ void nrc_destroy(NrcNet* net);
 uint32_t nrc_num_params(const NrcNet* net);
 void nrc_set_params(Context& ctx, hipStream_t stream, NrcNet* net, const float* hostParams, uint32_t count);
 void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count);
-void nrc_inference_image(Context& ctx, NrcNet* net, int which, void** dPtr, uint64_t* bytes);
+void nrc_inference_image(Context& ctx, NrcNet* net, int which, void** dPtr, uint64_t* bytes, hipStream_t stream = nullptr, bool onStream = false);
 void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions, const uint32_t* dNumData = nullptr);
 void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, const float* dTargets, uint32_t numData, float* lossOnCPU);
 // ---- pathtrace.hip

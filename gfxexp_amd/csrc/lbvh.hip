@@ -681,7 +681,7 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
         out.staticNodeEnd = std::max(rs.nodeEnd, 3u);
         const SubtreeResult rd = build_subtree(ctx, stream, out, 1, 2u, out.staticNodeEnd, nStatic, out.rootBoxes.as<float>() + 8);
         hipLaunchKernelGGL(k_super_root, dim3(1), dim3(64), 0, stream, out.rootBoxes.as<float>(), out.nodes.as<Bvh8Node>(), out.links.as<Bvh8Link>());
-        out.numNodes = rd.nodeEnd; out.maxDepth = std::max(rs.depth, rd.depth) + 1;
+        out.numNodes = rd.nodeEnd; out.staticDepth = rs.depth; out.maxDepth = std::max(rs.depth, rd.depth) + 1;
     }
     // the traversal keeps one stack entry per level it has descended past (bvh8.hip.h LaneStack: LDS + spill area)
     if (out.maxDepth + 1 > static_cast<uint32_t>(kLdsStackDepth + kSpillStackDepth))
@@ -704,6 +704,13 @@ bool lbvh_update_dynamic(Context& ctx, hipStream_t stream, Accel& out) {
     hipLaunchKernelGGL(k_tri_ids, dim3((nDynamic + 255) / 256), dim3(256), 0, stream, out.trisPtr(), nStatic, nDynamic, out.triIds.as<gfx_tri_ids>());
     GFX_HIP(hipGetLastError());
     out.numNodes = rd.nodeEnd;
+    // The animated subtree may have grown deeper than it was at build time: the kernels that trace inside the producing kernel size their
+    // per-lane spill area by the tree's depth (trace_local.hip.h local_spill_depth; a push past it would be dropped).  The depth never
+    // shrinks here, so spill areas sized for an earlier frame stay large enough.
+    out.maxDepth = std::max(out.maxDepth, std::max(out.staticDepth, rd.depth) + 1);
+    if (out.maxDepth + 1 > static_cast<uint32_t>(kLdsStackDepth + kSpillStackDepth))
+        throw std::runtime_error("gfx: acceleration structure is " + std::to_string(out.maxDepth) + " levels deep after the update; the traversal stack holds " +
+                                 std::to_string(kLdsStackDepth + kSpillStackDepth) + " entries");
     return true;
 }
 

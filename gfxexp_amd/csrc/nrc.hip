@@ -912,7 +912,8 @@ struct NrcNet {
     // the inference images (bf16 fragments + grid of the EMA weights) are packed when somebody asks for them, not after every step:
     // a frame trains four steps and infers once
     bool inferDirty = false;
-    hipStream_t lastTrainStream = nullptr;
+    hipEvent_t trained = nullptr;            // recorded behind the last training step (its optimizer): whoever packs the inference images waits for it
+    hipStream_t packStream = nullptr;        // gfx_nrc_inference_image without a stream packs here and waits for it on the host
     int gridGradMode = kGridGradLdsTables;   // GFX_NRC_GRID_GRAD = f32 | f16atomic | lds at creation
     size_t scatterLdsConfigured = 0;
 };
@@ -999,6 +1000,8 @@ void nrc_destroy(NrcNet* net) {
     DevBuf* all[] = { &net->params, &net->adamM, &net->adamV, &net->ema, &net->gradPartials, &net->gradSum, &net->gridGrad, &net->lossSum, &net->gridDelta, &net->gridPartials,
                       &net->packTrainFwd, &net->packTrainBwd, &net->packInferFwd, &net->gridTrain, &net->gridInfer };
     for (DevBuf* b : all) b->release();
+    if (net->trained) (void)hipEventDestroy(net->trained);
+    if (net->packStream) (void)hipStreamDestroy(net->packStream);
     delete net;
 }
 uint32_t nrc_num_params(const NrcNet* net) { return net->d.total; }
@@ -1017,9 +1020,21 @@ void nrc_set_params(Context& ctx, hipStream_t stream, NrcNet* net, const float* 
     net->inferDirty = false;
     GFX_HIP(hipStreamSynchronize(stream));
 }
-void nrc_inference_image(Context& ctx, NrcNet* net, int which, void** dPtr, uint64_t* bytes) {
-    // stream order with the training that made the images stale (the caller orders itself after that stream, as it always had to)
-    if (net->inferDirty) { nrc_pack(ctx, net->lastTrainStream, *net, false); net->inferDirty = false; }
+// The inference images brought up to date on `stream`, behind the training that made them stale (the event recorded after its optimizer): no
+// stream handle of an earlier call is kept.
+static void nrc_refresh_inference_images(Context& ctx, hipStream_t stream, NrcNet* net) {
+    if (!net->inferDirty) return;
+    if (net->trained) GFX_HIP(hipStreamWaitEvent(stream, net->trained, 0));
+    nrc_pack(ctx, stream, *net, false);
+    net->inferDirty = false;
+}
+void nrc_inference_image(Context& ctx, NrcNet* net, int which, void** dPtr, uint64_t* bytes, hipStream_t stream, bool onStream) {
+    if (onStream) nrc_refresh_inference_images(ctx, stream, net);      // the caller uses the images in `stream` order
+    else if (net->inferDirty) {                                        // no stream to order with: the images are complete when this returns
+        if (!net->packStream) GFX_HIP(hipStreamCreateWithFlags(&net->packStream, hipStreamNonBlocking));
+        nrc_refresh_inference_images(ctx, net->packStream, net);
+        GFX_HIP(hipStreamSynchronize(net->packStream));
+    }
     const uint32_t fwdElems = net->d.numHidden * kMatFwdElems + kOutFwdElems;
     if (which == 0) { *dPtr = net->packInferFwd.p; *bytes = 2ull * fwdElems; }
     else if (which == 1) { *dPtr = net->d.posEnc == 1 ? net->gridInfer.p : nullptr; *bytes = net->d.posEnc == 1 ? 2ull * net->gridParams : 0; }
@@ -1036,8 +1051,7 @@ void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count) {
 void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions, const uint32_t* dNumData) {
     if (numData & 0x7F) throw HipError("gfx_nrc_infer: numData must be a multiple of 128");   // network_interface.cu:143
     if (numData == 0) return;
-    // `stream` is ordered after the training whose weights it wants to see (it read the packed images before, too)
-    if (net->inferDirty) { nrc_pack(ctx, stream, *net, false); net->inferDirty = false; }
+    nrc_refresh_inference_images(ctx, stream, net);
     const int numCUs = ctx.numCUs;
     const uint32_t numTiles = numData / 64;
     // A large hash-grid batch is encoded level by level out of LDS copies of the level tables (k_nrc_infer_staged): worth it when every CU
@@ -1149,7 +1163,9 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
         if (net->gridGradMode == kGridGradF16Atomics && net->gridParams) GFX_HIP(hipMemsetAsync(net->gridGrad.p, 0, sizeof(uint32_t) * (net->gridParams / 2), stream));
     }
     nrc_pack(ctx, stream, *net, true);
-    net->inferDirty = true; net->lastTrainStream = stream;
+    if (!net->trained) GFX_HIP(hipEventCreateWithFlags(&net->trained, hipEventDisableTiming));
+    GFX_HIP(hipEventRecord(net->trained, stream));
+    net->inferDirty = true;
     if (lossOnCPU) {
         GFX_HIP(hipStreamSynchronize(stream));
         GFX_HIP(hipMemcpy(lossOnCPU, net->lossSum.p, sizeof(float), hipMemcpyDeviceToHost));

@@ -1405,7 +1405,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     // which now overlap.  The NEE queue head alternates between two words so that the extension trace can zero the one the bounce kernel
     // appends to while the NEE trace still reads the other.
     const bool overlap = ctx.tune.ptOverlap != 0;
-    if (overlap && !ctx.auxStream) GFX_HIP(hipStreamCreateWithFlags(&ctx.auxStream, hipStreamNonBlocking));   // (restir.hip's block sorts run there too)
+    if (overlap && !ctx.auxStream) GFX_HIP(hipStreamCreateWithFlags(&ctx.auxStream, hipStreamNonBlocking));
     if (overlap && !ctx.auxFork) {
         GFX_HIP(hipEventCreateWithFlags(&ctx.auxFork, hipEventDisableTiming));
         GFX_HIP(hipEventCreateWithFlags(&ctx.auxJoin, hipEventDisableTiming));

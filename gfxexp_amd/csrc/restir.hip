@@ -903,13 +903,14 @@ void block_order_begin(Context& ctx, hipStream_t stream, int which, uint32_t blo
 void block_order_end(Context& ctx, hipStream_t stream, int which, uint32_t blocks, uint32_t* cost) {
     if (!cost) return;
     Context::BlockOrder& bo = ctx.blockOrders[which];
-    if (!ctx.auxStream) GFX_HIP(hipStreamCreateWithFlags(&ctx.auxStream, hipStreamNonBlocking));
+    // a stream of their own: behind the path tracers' NEE traces on auxStream a sort would finish late and hold up the next launch that waits for it
+    if (!ctx.orderStream) GFX_HIP(hipStreamCreateWithFlags(&ctx.orderStream, hipStreamNonBlocking));
     if (!bo.counted) { GFX_HIP(hipEventCreateWithFlags(&bo.counted, hipEventDisableTiming)); GFX_HIP(hipEventCreateWithFlags(&bo.ordered, hipEventDisableTiming)); }
     GFX_HIP(hipEventRecord(bo.counted, stream));
-    GFX_HIP(hipStreamWaitEvent(ctx.auxStream, bo.counted, 0));
-    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx.auxStream, cost, blocks, bo.order.as<uint32_t>());
+    GFX_HIP(hipStreamWaitEvent(ctx.orderStream, bo.counted, 0));
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx.orderStream, cost, blocks, bo.order.as<uint32_t>());
     GFX_HIP(hipGetLastError());
-    GFX_HIP(hipEventRecord(bo.ordered, ctx.auxStream));
+    GFX_HIP(hipEventRecord(bo.ordered, ctx.orderStream));
     bo.valid = true;
 }
 

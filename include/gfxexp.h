@@ -10,6 +10,11 @@
  * (the reference throws std::runtime_error from CUDADRV_CHECK, utils/cuda_util.cpp:58-69).
  * Everything is asynchronous with respect to `stream` (a hipStream_t passed as void*), and a
  * gfx_ctx is not thread-safe (same as the reference: one host thread, restir_di_main.cpp:1705).
+ * A context also owns ONE set of library streams and events behind the launches (the second stream the path tracers' NEE traces
+ * run on with its fork / join events, the stream of the block-order sorts, the scratch sets of the traversal): the launches of
+ * one context (gfx_pt_launch, gfx_restir_launch*) are to be issued from one host thread, and renderers that run concurrently on
+ * different streams take a context each (as the band renderers of tests/ and tools/ do).  With gfx_counters_enable the
+ * per-launch diagnostics are those of the calling stream's order only when "pt_overlap" is 0.
  */
 #ifndef GFXEXP_H
 #define GFXEXP_H
@@ -479,10 +484,17 @@ int gfx_nrc_num_params(gfx_ctx* ctx, uint64_t handle, uint32_t* outCount);
 int gfx_nrc_set_params(gfx_ctx* ctx, uint64_t handle, const float* hostParams, uint32_t count);
 int gfx_nrc_get_params(gfx_ctx* ctx, uint64_t handle, int which, float* hostOut, uint32_t count);
 /* The device images gfx_nrc_infer reads: which = 0 the packed bf16 MLP fragments, 1 the packed bf16 hash grid (null / 0 for
- * the triangle-wave encoding); brought up to date with the trained (EMA) weights by this call and by gfx_nrc_infer -- in stream order
- * after the last gfx_nrc_train, on that call's stream -- not after every training step (a frame trains four steps and infers once).
+ * the triangle-wave encoding).  They are brought up to date with the trained (EMA) weights when somebody asks -- this call, its _async
+ * form, gfx_nrc_infer -- not after every training step (a frame trains four steps and infers once); whoever packs them first waits, on its
+ * stream, for an event gfx_nrc_train records behind its optimizer, so no ordering between the caller's streams is assumed and no stream
+ * handle of an earlier call is kept.  gfx_nrc_inference_image has no stream to order with: it packs on a library-owned stream and
+ * returns when the images are complete (a host wait for the last training step if the images were stale).  The pointers stay valid for the
+ * network's lifetime, the CONTENTS are rewritten by the next refresh after a training step -- a caller that caches the pointers must
+ * order its reads before that (e.g. call one of these functions again after training).
+ * gfx_nrc_inference_image_async: the same, packed on `stream`; the caller uses the images in `stream` order, no host wait.
  * A process that does not train (a band renderer other than rank 0, gfxh_nrc_set_exchange) receives these bytes from the one that does. */
 int gfx_nrc_inference_image(gfx_ctx* ctx, uint64_t handle, int which, void** dPtr, uint64_t* bytes);
+int gfx_nrc_inference_image_async(gfx_ctx* ctx, void* stream, uint64_t handle, int which, void** dPtr, uint64_t* bytes);
 
 /* Blocking device-to-host copy of library- or caller-owned device memory (TypedBuffer::read,
  * utils/cuda_util.h; used for pick info at restir_di_main.cpp:2010). */

@@ -295,8 +295,15 @@ int gfxh_frame_step_exchange_desc(const gfxh_restir_config* cfg, const gfxh_fram
  * builds BVH and light distributions for the uploaded scene. */
 int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir** out);
 void gfxh_restir_destroy(gfxh_restir* r);
-/* One frame: light-instance distribution, G-buffer, initial(+temporal) RIS, spatial passes, shading. */
+/* One frame: light-instance distribution, G-buffer, initial(+temporal) RIS, spatial passes, shading.
+ * Frame pipelining: the G-buffer pass of this frame may run on a private stream underneath the passes of the
+ * PREVIOUS frame that are still queued on `stream`.  It rewrites the albedo / normal accumulation buffers (single-buffered running
+ * means) and this frame's G-buffer half: work the caller queued on its own stream after the previous gfxh_restir_render_frame returned
+ * -- a denoiser, a read-back of those buffers -- is NOT ordered before that pass unless the caller says where it ends:
+ * gfxh_restir_outputs_consumed(r, stream) records that point (an event on `stream`) and the next frame's G-buffer pass waits for it.
+ * The beauty buffer is only written by passes on `stream` and needs no such call.  GFX_SERIAL_FRAMES=1 switches the pipelining off. */
 int gfxh_restir_render_frame(gfxh_restir* r, void* stream);
+int gfxh_restir_outputs_consumed(gfxh_restir* r, void* stream);
 /* Restart the sequence (newSequence, restir_di_main.cpp:2311). */
 int gfxh_restir_reset(gfxh_restir* r);
 /* "-env-texture": upload a lat-long float4 environment map (host pointer) + its importance map and
@@ -349,8 +356,11 @@ typedef struct gfxh_nrc_config {
 void gfxh_nrc_default_config(gfxh_nrc_config* cfg, uint32_t width, uint32_t height);
 int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out);
 void gfxh_nrc_destroy(gfxh_nrc* r);
-/* lossOut (optional): the loss of the fourth training step (main:2363). */
+/* lossOut (optional): the loss of the fourth training step (main:2363).  The G-buffer pass is pipelined as in gfxh_restir_render_frame:
+ * gfxh_nrc_outputs_consumed(r, stream) marks the point on `stream` behind which the caller no longer reads the albedo / normal
+ * accumulation buffers of the previous frame. */
 int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut);
+int gfxh_nrc_outputs_consumed(gfxh_nrc* r, void* stream);
 /* Row-band split of the NRC frame over the GPUs of a node (no reference counterpart; one process per GPU, `rank` of them).
  * Every rank path-traces, infers and accumulates its own rows; the training records of all bands are gathered in rank order
  * (GFXH_EXCHANGE_GATHER_RECORDS: 68 B per record, <= 2^17 records), every rank shuffles the same batch, RANK 0 runs the four

@@ -111,6 +111,61 @@ def test_level_staged_inference_equals_the_in_place_kernel(built_lib, hidden, n)
 
 
 @pytest.mark.gpu
+def test_inference_images_follow_the_training_through_an_event(built_lib):
+    """gfx_nrc_train on one stream, then the packed inference images asked for on ANOTHER stream the caller never ordered after the
+    training stream (gfx_nrc_inference_image_async) and, after more training, with no stream at all (gfx_nrc_inference_image: packed on a
+    library stream, complete on return): both hold the weights AFTER the training steps -- the hash-grid image equals the bf16 pairs of
+    the EMA parameters read back after a device-wide synchronisation."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(3)
+    x = _inputs(rng, 4096)
+    y = _targets(x)
+    ctx = api.Context(0)
+    net = api.NeuralRadianceCache(ctx, N.POS_HASHGRID, 2)
+    _, grid_off, total = N.layout(N.POS_HASHGRID, 2)
+    dx, dt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    train_stream, other = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def bf16_pairs(params):
+        g = np.ascontiguousarray(params[grid_off:], np.float32).view(np.uint32).astype(np.uint64)
+        b = ((g + 0x7FFF + ((g >> 16) & 1)) >> 16).astype(np.uint32)
+        return (b[0::2] | (b[1::2] << 16)).astype(np.uint32)
+
+    before = bf16_pairs(net.get_params(1))
+    for how in ("other-stream", "no-stream"):
+        for _ in range(3):
+            net.train(dx.data_ptr(), dt.data_ptr(), 4096, stream=train_stream.cuda_stream)
+        ptr, nbytes = C.c_void_p(), C.c_uint64()
+        if how == "other-stream":
+            ctx._check(api.lib().gfx_nrc_inference_image_async(ctx.h, C.c_void_p(other.cuda_stream), C.c_uint64(net.h), C.c_int(1), C.byref(ptr), C.byref(nbytes)))
+            got = _copy_device(ptr.value, nbytes.value, other)
+        else:
+            ptr.value, nbytes.value = ctx.nrc_inference_image(net.h, 1)
+            got = _copy_device(ptr.value, nbytes.value, None)
+        want = bf16_pairs(net.get_params(1))              # (synchronises the device)
+        assert nbytes.value == 4 * want.size
+        assert not np.array_equal(want, before), "the training moved nothing"
+        assert np.array_equal(got.view(np.uint32), want), f"{how}: the image was packed before the training steps had finished"
+        before = want
+    net.close()
+    ctx.close()
+
+
+def _copy_device(ptr, nbytes, stream):
+    """Device bytes -> host WITHOUT a device-wide synchronisation in front: a plain copy on `stream` (or on a fresh stream)."""
+    import torch
+    from bench import _device_view
+    s = stream if stream is not None else torch.cuda.Stream()
+    host = torch.empty(nbytes // 4, dtype=torch.float32).pin_memory()
+    with torch.cuda.stream(s):
+        host.copy_(_device_view(ptr, nbytes // 4), non_blocking=True)
+    s.synchronize()
+    return host.numpy().view(np.uint8).copy()
+
+
+@pytest.mark.gpu
 def test_batch_size_must_be_a_multiple_of_128(built_lib):
     import torch
     ctx = api.Context(0)
