@@ -65,6 +65,9 @@ struct gfxh_nrc {
     hipEvent_t evConsumed = nullptr;          // gfxh_nrc_outputs_consumed: the caller's reads of the albedo / normal accumulators are behind this event
     bool consumedPending = false;
     bool trainPending = false, overlapTraining = true;
+    // band split: every rank trains its own copy of the network on the gathered batch (training is reproducible bit for bit, nrc.hip
+    // k_nrc_grid_scatter, so the copies stay identical); GFX_NRC_TRAIN_ON_RANK0=1: rank 0 trains and broadcasts its inference images (rounds 3-4)
+    bool trainOnRank0 = false;
     // band renderer (gfxh_nrc_set_exchange)
     gfxh_exchange_fn exchange = nullptr; void* exchangeUser = nullptr; int rank = 0;
     uint32_t gatherCounts[2] = { 0, 0 };
@@ -220,6 +223,8 @@ int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out) {
     {
         const char* e = std::getenv("GFX_NRC_SERIAL_TRAINING");   // debugging aid: train on the caller's stream
         r->overlapTraining = !(e && e[0] == '1');
+        const char* e0 = std::getenv("GFX_NRC_TRAIN_ON_RANK0");
+        r->trainOnRank0 = e0 && e0[0] == '1';
         // non-blocking: the caller's stream may be the legacy default stream, which would serialise a blocking one
         const char* sf = std::getenv("GFX_SERIAL_FRAMES");   // debugging aid: everything on the caller's stream
         r->pipelineFrames = !(sf && sf[0] == '1');
@@ -380,13 +385,14 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
         NRC_GFX(gfx_pt_launch(ctx, stream, GFX_PT_NRC_SHUFFLE, W, H, cfg.maxPathLength, 0, 0));
         constexpr uint32_t batchSize = kNumTrainingDataPerFrame / 4;                 // main:2350
         void* ts = stream;
-        const bool overlap = r->overlapTraining && !band;
+        const bool rank0Trains = band && r->trainOnRank0;
+        const bool overlap = r->overlapTraining && !rank0Trains;     // (the broadcast of rank 0's images has to follow the training on the caller's stream)
         if (overlap) {
             NRC_HIP(hipEventRecord(r->evData, static_cast<hipStream_t>(stream)));
             NRC_HIP(hipStreamWaitEvent(r->trainStream, r->evData, 0));
             ts = r->trainStream;
         }
-        if (!band || r->rank == 0) {
+        if (!rank0Trains || r->rank == 0) {
             for (uint32_t step = 0; step < 4; ++step) {
                 const char* q = static_cast<const char*>(r->np.trainRadianceQueryBuffer[1]) + 56ull * step * batchSize;
                 const char* t = static_cast<const char*>(r->np.trainTargetBuffer[1]) + 12ull * step * batchSize;
@@ -398,7 +404,7 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
             NRC_HIP(hipEventRecord(r->evTrained, r->trainStream));
             r->trainPending = true;
         }
-        if (band) {   // rank 0's freshly packed inference images -> everyone
+        if (rank0Trains) {   // rank 0's freshly packed inference images -> everyone
             gfxh_exchange_desc d; std::memset(&d, 0, sizeof(d));
             d.kind = GFXH_EXCHANGE_BROADCAST;
             for (int which = 0; which < 2; ++which) {

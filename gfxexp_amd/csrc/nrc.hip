@@ -804,28 +804,49 @@ extern "C" int gfx_debug_nrc_profile(unsigned long long* out64, int reset) {
 #endif
 
 // ---------------------------------------------------------------- hash-grid gradient: one level table per block, in LDS
-// grid (numChunks, 16 levels) x 256 threads; dynamic LDS = the level's entries x 4 B.  partials: [numChunks][all entries] packed fp16 pairs.
-constexpr int kScatterBlock = 256;
+// grid (numChunks, 16 levels) x 256 threads; dynamic LDS = the level's entries x 4 B + a staging area of kScatterBatch records x 20 B.
+// partials: [numChunks][all entries] packed fp16 pairs.
+// The sum is made in a DEFINED order since round 5: the block's four waves copy a batch of records (the level's two deltas and the
+// position) into the staging area, coalesced; then ONE wave adds them to the table, 64 records per step in record order, corner 0 .. 7 of
+// all 64 after one another -- LDS atomics of one wave execute in program order and the lanes of one instruction that meet in an entry are
+// served in a fixed order, so the fp16 sums no longer depend on how four waves happened to interleave.  Two runs of a training step
+// from the same state give the same parameters bit for bit (tests/test_gpu_nrc_net.py), which is what lets every rank of a band-split
+// NRC frame train its own copy of the network on the gathered batch instead of waiting for rank 0's (nrc_driver.cpp).  The adding wave's
+// part is ~3 us per block next to the 128-KiB table it zeroes and writes out; the step's time does not change.
+constexpr int kScatterBlock = 256, kScatterBatch = 1024;
 __global__ __launch_bounds__(kScatterBlock) void k_nrc_grid_scatter(NrcDev d, const float* __restrict__ inputs, const float2* __restrict__ gridDelta,
-                                                                    uint32_t numData, uint32_t chunkRecords, uint32_t totalEntries, uint32_t* __restrict__ partials) {
+                                                                    uint32_t numData, uint32_t chunkRecords, uint32_t totalEntries, uint32_t tableWords,
+                                                                    uint32_t* __restrict__ partials) {
     extern __shared__ uint32_t ldsTable[];
+    float* stage = reinterpret_cast<float*>(ldsTable + tableWords);          // [5][kScatterBatch]: delta.x, delta.y, position
     const NrcLevel lv = d.levels[blockIdx.y];
     for (uint32_t e = threadIdx.x; e < lv.entries; e += kScatterBlock) ldsTable[e] = 0u;
-    __syncthreads();
     const uint32_t begin = blockIdx.x * chunkRecords, end = min(begin + chunkRecords, numData);
-    for (uint32_t r = begin + threadIdx.x; r < end; r += kScatterBlock) {
-        const float2 dl = gridDelta[static_cast<size_t>(blockIdx.y) * numData + r];
-        if (dl.x == 0.0f && dl.y == 0.0f) continue;
-        const float* x = inputs + static_cast<size_t>(r) * kNrcIn;
-        uint32_t idx[8]; float w[8];
-        grid_corners(lv, x[0], x[1], x[2], idx, w);
+    for (uint32_t batch = begin; batch < end; batch += kScatterBatch) {
+        const uint32_t count = min(static_cast<uint32_t>(kScatterBatch), end - batch);
+        __syncthreads();                                   // the table is zero / the previous batch has been added
+        for (uint32_t i = threadIdx.x; i < count; i += kScatterBlock) {
+            const float2 dl = gridDelta[static_cast<size_t>(blockIdx.y) * numData + batch + i];
+            const float* x = inputs + static_cast<size_t>(batch + i) * kNrcIn;
+            stage[i] = dl.x; stage[kScatterBatch + i] = dl.y;
+            stage[2 * kScatterBatch + i] = x[0]; stage[3 * kScatterBatch + i] = x[1]; stage[4 * kScatterBatch + i] = x[2];
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            for (uint32_t i = threadIdx.x; i < count; i += 64) {     // record order: 64 consecutive records per step
+                const float dx = stage[i], dy = stage[kScatterBatch + i];
+                if (dx == 0.0f && dy == 0.0f) continue;
+                uint32_t idx[8]; float w[8];
+                grid_corners(lv, stage[2 * kScatterBatch + i], stage[3 * kScatterBatch + i], stage[4 * kScatterBatch + i], idx, w);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            f16x2 v;
-            v.x = static_cast<_Float16>(fmin2(fmax2(w[c] * dl.x, -65504.0f), 65504.0f));
-            v.y = static_cast<_Float16>(fmin2(fmax2(w[c] * dl.y, -65504.0f), 65504.0f));
-            typedef __attribute__((address_space(3))) f16x2* LdsF16x2;
-            (void)__builtin_amdgcn_ds_atomic_fadd_v2f16((LdsF16x2)(ldsTable + (idx[c] - lv.offset)), v);
+                for (int c = 0; c < 8; ++c) {
+                    f16x2 v;
+                    v.x = static_cast<_Float16>(fmin2(fmax2(w[c] * dx, -65504.0f), 65504.0f));
+                    v.y = static_cast<_Float16>(fmin2(fmax2(w[c] * dy, -65504.0f), 65504.0f));
+                    typedef __attribute__((address_space(3))) f16x2* LdsF16x2;
+                    (void)__builtin_amdgcn_ds_atomic_fadd_v2f16((LdsF16x2)(ldsTable + (idx[c] - lv.offset)), v);
+                }
+            }
         }
     }
     __syncthreads();
@@ -1123,14 +1144,14 @@ void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     if (ldsTables) {
         uint32_t maxEntries = 0;
         for (int l = 0; l < kHashLevels; ++l) maxEntries = std::max(maxEntries, net->d.levels[l].entries);
-        const size_t scatterLds = sizeof(uint32_t) * maxEntries;
+        const size_t scatterLds = sizeof(uint32_t) * maxEntries + 5 * sizeof(float) * kScatterBatch;
         if (scatterLds > net->scatterLdsConfigured) {
             GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(scatterLds)));
             net->scatterLdsConfigured = scatterLds;
         }
         ScopedKernelTimer timer(ctx, stream, "nrc_grid_scatter");
         hipLaunchKernelGGL(k_nrc_grid_scatter, dim3(numChunks, kHashLevels), dim3(kScatterBlock), scatterLds, stream, net->d, dInputs, net->gridDelta.as<float2>(),
-                           numData, chunkRecords, totalEntries, net->gridPartials.as<uint32_t>());
+                           numData, chunkRecords, totalEntries, maxEntries, net->gridPartials.as<uint32_t>());
         GFX_HIP(hipGetLastError());
     }
     // Adam (beta1 0.9, beta2 0.99, l2_reg 1e-6) inside EMA(0.99): network_interface.cu:53-64, 91, 118

@@ -363,10 +363,12 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut);
 int gfxh_nrc_outputs_consumed(gfxh_nrc* r, void* stream);
 /* Row-band split of the NRC frame over the GPUs of a node (no reference counterpart; one process per GPU, `rank` of them).
  * Every rank path-traces, infers and accumulates its own rows; the training records of all bands are gathered in rank order
- * (GFXH_EXCHANGE_GATHER_RECORDS: 68 B per record, <= 2^17 records), every rank shuffles the same batch, RANK 0 runs the four
- * training steps and its inference images (gfx_nrc_inference_image: 20 KB + 2 MB) are broadcast (GFXH_EXCHANGE_BROADCAST), so
- * all ranks infer the next frame with identical weights; the tile size adapts to the global record count; the HDR bands are
- * gathered like gfxh_restir's.  Training is not overlapped with the next frame in this mode. */
+ * (GFXH_EXCHANGE_GATHER_RECORDS: 68 B per record, <= 2^17 records), every rank shuffles the same batch and EVERY rank runs the four
+ * training steps on its own copy of the network, on its training stream underneath the next frame like the whole-frame renderer: a
+ * training step is reproducible bit for bit (nrc.hip k_nrc_grid_scatter: the hash-grid gradient is summed in a defined order), so the
+ * copies stay identical and nothing but records and HDR bands crosses the links.  (GFX_NRC_TRAIN_ON_RANK0=1 keeps the scheme of rounds
+ * 3-4: rank 0 trains on the caller's stream and its inference images -- gfx_nrc_inference_image_async: 20 KB + 2 MB -- are broadcast,
+ * GFXH_EXCHANGE_BROADCAST.)  The tile size adapts to the global record count; the HDR bands are gathered like gfxh_restir's. */
 int gfxh_nrc_set_exchange(gfxh_nrc* r, gfxh_exchange_fn fn, void* user, int rank);
 /* Scene::updateASs of an animated frame: rebuild the renderer's BVH in place after gfx_instance_set_transform. */
 int gfxh_nrc_rebuild_accel(gfxh_nrc* r, void* stream);

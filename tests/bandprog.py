@@ -73,10 +73,12 @@ def small_config(W, H, renderer, band=(0, 0), radius=5.0, passes=2, neighbors=3)
 
 class OracleNrcBandRenderer:
     """gfxh_nrc_render_frame's band sequence (csrc/host/nrc_driver.cpp) with the oracle as the kernels and oracle/nrc_net.py as
-    the network: path tracing / inference / accumulation on the band, records gathered in rank order, rank 0 trains, the
-    inference parameters are broadcast.  band = (0, 0) and exchange = None: the whole-frame loop."""
+    the network: path tracing / inference / accumulation on the band, records gathered in rank order, every rank trains its own copy
+    of the network on the gathered batch (train_on_rank0: rank 0 trains, the inference parameters are broadcast -- the driver's
+    GFX_NRC_TRAIN_ON_RANK0=1).  band = (0, 0) and exchange = None: the whole-frame loop."""
 
-    def __init__(self, osc, hs, W, H, band=(0, 0), rank=0, exchange=None, max_len=3):
+    def __init__(self, osc, hs, W, H, band=(0, 0), rank=0, exchange=None, max_len=3, train_on_rank0=False):
+        self.train_on_rank0 = train_on_rank0
         from oracle import nrc_net as N
         self.N = N
         self.osc, self.W, self.H, self.band, self.rank, self.exchange, self.max_len = osc, W, H, band, rank, exchange, max_len
@@ -127,15 +129,17 @@ class OracleNrcBandRenderer:
             self.exchange(0, d)
             a[f"nrc_num_{b}"][0] = self.counts[0]
         self.osc.pt_launch(s, f, api.PT_NRC_SHUFFLE, self.max_len)
-        if not banded or self.rank == 0:
+        rank0_trains = banded and self.train_on_rank0
+        if not rank0_trains or self.rank == 0:
             for step in range(4):
                 sl = slice(step * 16384, (step + 1) * 16384)
                 self.last_loss = self.net.train(a["nrc_trainq_1"][sl], a["nrc_traint_1"][sl])
-        if banded:
+        if rank0_trains:
             d = self._desc(api.EXCHANGE_BROADCAST)
             d.numBuffers = 1
             d.buffers[0].base, d.buffers[0].bytesPerPixel, d.buffers[0].numPlanes, d.buffers[0].planeStride = self.net.ema.ctypes.data, 1, 1, self.net.ema.nbytes
             self.exchange(0, d)
+        if banded:
             d = self._desc(api.EXCHANGE_GATHER_BANDS)
             d.numBuffers = 1
             d.buffers[0].base, d.buffers[0].bytesPerPixel, d.buffers[0].numPlanes, d.buffers[0].planeStride = pb.beauty.ctypes.data, 16, 1, 16 * n

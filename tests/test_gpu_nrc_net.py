@@ -111,6 +111,38 @@ def test_level_staged_inference_equals_the_in_place_kernel(built_lib, hidden, n)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hidden,records", [(2, 16384), (5, 4096)])
+def test_training_is_reproducible_bit_for_bit(built_lib, hidden, records):
+    """Four training steps from the same parameters on the same records, in two contexts, three times over: parameters, Adam moments
+    and EMA weights are the same BITS every time -- the dW partials are summed in a fixed order and the hash-grid gradient is added to
+    its LDS tables by one wave in record order (k_nrc_grid_scatter), so nothing depends on how waves interleave.  Half of the records
+    sit in one small cell so that many of them meet in the same table entries.  (What a band-split NRC frame relies on: every rank
+    trains its own copy on the gathered batch and all copies stay identical, gfxh_nrc_set_exchange.)"""
+    import torch
+    rng = np.random.default_rng(17)
+    x = _inputs(rng, records)
+    x[: records // 2, :3] = 0.4 + 0.002 * rng.random((records // 2, 3), dtype=np.float32)      # a crowd in one cell of the coarse levels
+    y = _targets(x)
+    p = _random_params(rng, N.POS_HASHGRID, hidden)
+    runs = []
+    for _ in range(3):
+        ctx = api.Context(0)
+        net = api.NeuralRadianceCache(ctx, N.POS_HASHGRID, hidden)
+        net.set_params(p)
+        dx, dt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        for _ in range(4):
+            net.train(dx.data_ptr(), dt.data_ptr(), records)
+        runs.append([net.get_params(which).view(np.uint32).copy() for which in range(4)])
+        net.close()
+        ctx.close()
+    assert not np.array_equal(runs[0][0], p.view(np.uint32)), "the training moved nothing"
+    for k in (1, 2):
+        for which, name in enumerate(("parameters", "EMA", "Adam m", "Adam v")):
+            bad = np.count_nonzero(runs[0][which] != runs[k][which])
+            assert bad == 0, f"run {k}: {bad} of {runs[0][which].size} {name} differ from run 0"
+
+
+@pytest.mark.gpu
 def test_inference_images_follow_the_training_through_an_event(built_lib):
     """gfx_nrc_train on one stream, then the packed inference images asked for on ANOTHER stream the caller never ordered after the
     training stream (gfx_nrc_inference_image_async) and, after more training, with no stream at all (gfx_nrc_inference_image: packed on a

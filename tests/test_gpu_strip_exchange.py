@@ -154,13 +154,31 @@ def test_rccl_exchange_single_rank(built_lib):
 
 
 @pytest.mark.gpu
-def test_three_band_nrc_renderers(built_lib):
+@pytest.mark.parametrize("train_on_rank0", [False, True])
+def test_three_band_nrc_renderers(built_lib, monkeypatch, train_on_rank0):
     """NRC band renderers (gfxh_nrc_set_exchange) on one GPU: frame 0 -- initial weights everywhere -- is bit-identical to the
-    whole-frame renderer and the gathered record count is the whole frame's; after rank 0 trained and broadcast, every rank
-    holds the same inference images bit for bit; frame 1 (weights trained on the same records in another order) agrees with
-    the whole-frame renderer to the training's own noise."""
+    whole-frame renderer and the gathered record count is the whole frame's; then EVERY rank trains its own copy of the network on
+    the gathered batch (the training step is reproducible bit for bit) and all ranks hold the same parameters, Adam moments, EMA
+    weights and inference images bit for bit (train_on_rank0: the scheme of rounds 3-4 -- rank 0 trains, its inference images are
+    broadcast -- behind GFX_NRC_TRAIN_ON_RANK0=1: the images agree, the other ranks' parameters stay untrained); frame 1 (weights
+    trained on the same records in another order than the whole-frame renderer's) agrees with the whole-frame renderer to that
+    difference, and every rank gathers the same frame."""
+    import ctypes as C
     import torch
     from tests import loopback
+    monkeypatch.setenv("GFX_NRC_TRAIN_ON_RANK0", "1" if train_on_rank0 else "0")
+
+    def all_params(ctx, r):
+        L = api.lib()
+        net = r.network()
+        count = C.c_uint32()
+        ctx._check(L.gfx_nrc_num_params(ctx.h, C.c_uint64(net), C.byref(count)))
+        out = []
+        for which in range(4):
+            a = np.zeros(count.value, np.float32)
+            ctx._check(L.gfx_nrc_get_params(ctx.h, C.c_uint64(net), C.c_int(which), a.ctypes.data_as(C.c_void_p), count))
+            out.append(a.view(np.uint32))
+        return out
     hs = util.bunny_scene()
     cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
 
@@ -204,6 +222,15 @@ def test_three_band_nrc_renderers(built_lib):
     for rank in range(1, WORLD):
         for which in (0, 1):
             assert np.array_equal(images[rank][which], images[0][which]), (rank, which)
+    params = [all_params(ctx, r) for ctx, r in made]
+    fresh_params = None
+    for rank in range(1, WORLD):
+        for which, name in enumerate(("parameters", "EMA weights", "Adam m", "Adam v")):
+            same = np.array_equal(params[rank][which], params[0][which])
+            if not train_on_rank0:
+                assert same, f"rank {rank}: {name} differ from rank 0's after the same four training steps"
+            elif name == "parameters":
+                assert not same, "GFX_NRC_TRAIN_ON_RANK0: only rank 0 trains"
     ctx0, fresh = make((0, 0))           # an untrained network: the broadcast images are NOT the initial ones
     p0, n0 = ctx0.nrc_inference_image(fresh.network(), 1)
     assert not np.array_equal(ctx0.read_device(p0, n0), images[1][1])

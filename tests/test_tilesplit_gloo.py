@@ -405,17 +405,17 @@ def test_partition_check_is_the_same_verdict_on_every_rank(built_lib):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# NRC band renderers: records gathered in rank order, rank 0 trains, inference parameters broadcast
+# NRC band renderers: records gathered in rank order, every rank trains its own copy (or: rank 0 trains, inference parameters broadcast)
 # ---------------------------------------------------------------------------------------------------------------------
 NRC_FRAMES = 2
 
 
-def _nrc_run(band, rank, exchange, threads, H=H):
+def _nrc_run(band, rank, exchange, threads, H=H, train_on_rank0=False):
     from gfxexp_amd import api
     from tests import bandprog, util
     hs = util.bunny_scene()
     osc = util.feed_oracle(hs, threads=threads)
-    r = bandprog.OracleNrcBandRenderer(osc, hs, W, H, band=band, rank=rank, exchange=exchange)
+    r = bandprog.OracleNrcBandRenderer(osc, hs, W, H, band=band, rank=rank, exchange=exchange, train_on_rank0=train_on_rank0)
     cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
     for _ in range(NRC_FRAMES):
         r.render_frame(cam)
@@ -426,25 +426,26 @@ def _nrc_run(band, rank, exchange, threads, H=H):
             "batchq": r.nb.a["nrc_trainq_1"][:1 << 16], "batcht": r.nb.a["nrc_traint_1"][:1 << 16], "rng": r.pb.rng}
 
 
-def _nrc_worker(rank, world, port, out_dir):
+def _nrc_worker(rank, world, port, out_dir, train_on_rank0):
     import torch.distributed as dist
     from gfxexp_amd import tilesplit
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     H = HEIGHTS[world]
     band = tilesplit.band_for_rank(H, world, rank)
     ex = tilesplit.StripExchange(dist, rank, world, H, tilesplit.host_view)
-    out = _nrc_run(band, rank, ex, threads=2, H=H)
+    out = _nrc_run(band, rank, ex, threads=2, H=H, train_on_rank0=train_on_rank0)
     ex.finish()
     np.savez(os.path.join(out_dir, f"nrc_{rank}.npz"), band=np.array(band), **out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_nrc_band_split_is_bit_exact(built_lib, world):
+@pytest.mark.parametrize("world,train_on_rank0", [(2, False), (3, False), (2, True)])
+def test_nrc_band_split_is_bit_exact(built_lib, world, train_on_rank0):
     """The CPU oracle allocates training records in pixel order, so the bands' records concatenated in rank order ARE the
-    single-process records: the gathered batch, the trained parameters and both frames are bit-identical.  Three ranks:
-    unequal bands (24 + 16 + 16 rows), so the record gather pads to the largest count of three different ones."""
+    single-process records: the gathered batch, the trained parameters and both frames are bit-identical -- with every rank training
+    its own copy of the network on the gathered batch (the default) and with rank 0 training and broadcasting (train_on_rank0).  Three
+    ranks: unequal bands (24 + 16 + 16 rows), so the record gather pads to the largest count of three different ones."""
     import torch.multiprocessing as mp
     from tests import util
     H = HEIGHTS[world]
@@ -452,7 +453,7 @@ def test_nrc_band_split_is_bit_exact(built_lib, world):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_nrc_worker, args=(world, port, out_dir), nprocs=world, join=True)
+        mp.spawn(_nrc_worker, args=(world, port, out_dir, train_on_rank0), nprocs=world, join=True)
         got = [dict(np.load(os.path.join(out_dir, f"nrc_{r}.npz"))) for r in range(world)]
     want = _nrc_run((0, 0), 0, None, threads=4, H=H)
     assert want["num"][0] > 100 and np.abs(want["beauty"][:, :3]).sum() > 0
