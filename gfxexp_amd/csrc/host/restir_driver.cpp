@@ -382,12 +382,20 @@ int gfxh_restir_set_env(gfxh_restir* r, float* texels, uint32_t w, uint32_t h, f
     err |= up(&sp.envRowIntegrals, rowInt.data(), 4 * rowInt.size());
     err |= up(&sp.envTopPDF, topPDF.data(), 4 * topPDF.size());
     err |= up(&sp.envTopCDF, topCDF.data(), 4 * topCDF.size());
-    sp.envRowGuide = nullptr; sp.envTopGuide = nullptr;
+    sp.envRowGuide = nullptr; sp.envTopGuide = nullptr; sp.envRowTable = nullptr;
     {
         std::vector<uint16_t> rowGuide(n), topGuide(h);
         if (gfxh_env_build_guides(rowCDF.data(), topCDF.data(), w, h, rowGuide.data(), topGuide.data())) {
             err |= up(&sp.envRowGuide, rowGuide.data(), 2 * rowGuide.size());
             err |= up(&sp.envTopGuide, topGuide.data(), 2 * topGuide.size());
+            // the rows interleaved (cdf, pdf, guide, texel per record): what a light sample on the map reads, in two or three sectors
+            // (GFX_ENV_ROW_TABLE=0: the separate arrays, for A/B runs)
+            const char* e = std::getenv("GFX_ENV_ROW_TABLE");
+            if (!(e && e[0] == '0')) {
+            std::vector<uint32_t> table(8 * static_cast<size_t>(h) * (w + 1));
+            gfxh_env_build_row_table(texels, rowPDF.data(), rowCDF.data(), rowGuide.data(), w, h, table.data());
+            err |= up(&sp.envRowTable, table.data(), 4 * table.size());
+            }
         }
     }
     if (err) return 1;

@@ -1032,6 +1032,24 @@ int gfxh_env_build_guides(const float* rowCDF, const float* topCDF, uint32_t w, 
     return 1;
 }
 
+void gfxh_env_build_row_table(const float* texels, const float* rowPDF, const float* rowCDF, const uint16_t* rowGuide, uint32_t w, uint32_t h, void* outRecords) {
+    // record (row, i) of 32 bytes: {cdf, pdf, guide, r | g, b, 0, 0} (shading.hip.h EnvRowRec); i = w: the row's final CDF value alone
+    uint32_t* out = static_cast<uint32_t*>(outRecords);
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t i = 0; i <= w; ++i) {
+            uint32_t* rec = out + 8 * (static_cast<size_t>(y) * (w + 1) + i);
+            rec[0] = bits(rowCDF[static_cast<size_t>(y) * (w + 1) + i]);
+            for (int k = 1; k < 8; ++k) rec[k] = 0u;
+            if (i < w) {
+                const float* t = texels + 4 * (static_cast<size_t>(y) * w + i);
+                rec[1] = bits(rowPDF[static_cast<size_t>(y) * w + i]);
+                rec[2] = rowGuide[static_cast<size_t>(y) * w + i];
+                rec[3] = bits(t[0]); rec[4] = bits(t[1]); rec[5] = bits(t[2]);
+            }
+        }
+}
+
 void gfxh_env_make_sky(uint32_t w, uint32_t h, float sunElevationDeg, float sunAzimuthDeg, float sunRadiance, float* texels) {
     const float d2r = 3.14159265358979323846f / 180.0f;
     const float se = sunElevationDeg * d2r, sa = sunAzimuthDeg * d2r;

@@ -442,15 +442,32 @@ struct LightSample {
 // gather) is read with the texels, not before.
 struct PendingEmittance { uint32_t tex; uint32_t rec; float bcA, bcB, bcC; };
 
+// One texel of the environment map as the row searches want it (gfx_restir_static_params::envRowTable, gfxh_env_build_row_table): the
+// conditional CDF / PDF entry of the texel's column, the row guide's entry and the texel itself in ONE 32-byte record, w + 1 records per
+// row (the last holds the row's final CDF value).  A light sample on the map is a guided search in a row picked at random out of h: with
+// five separate arrays (texels 32 MB, PDFs 8 MB, CDFs 8 MB, guide 4 MB for the 2048 x 1024 map of configs[4]) every step of it was a
+// 64-byte sector of its own from HBM -- 8.2 GB per candidate pass, 4.9 TB/s: that pass ran at the memory system's rate
+// (profiles/r05_experiments.txt 5).  Interleaved, the guide pair, the probes and the final (cdf, cdf', pdf, texel) of a sample lie in the
+// two or three sectors around the texel it ends on.  Same values, same arithmetic: same samples bit for bit.
+struct EnvRowRec { float cdf, pdf; uint32_t guide; float r, g, b; uint32_t pad0, pad1; };
+static_assert(sizeof(EnvRowRec) == 32, "two records per 64-byte sector");
+
 struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
     const float4* texels;
     const float* rowPDF; const float* rowCDF; const float* topPDF; const float* topCDF;
     const uint16_t* rowGuide; const uint16_t* topGuide;   // optional guide tables (gfxh_env_build_guides), or null
+    const EnvRowRec* rowTable;                            // optional interleaved rows (gfxh_env_build_row_table; needs the guides), or null
     int32_t w, h;
     GFX_DEV bool present() const { return texels != nullptr; }
+    GFX_DEV const EnvRowRec* table_row(uint32_t row) const { return rowTable + static_cast<size_t>(row) * (static_cast<uint32_t>(w) + 1u); }
     GFX_DEV f3 fetch(float u, float v) const { // nearest texel (the build's tex2DLod contract)
         uint32_t x = f2u_sat(u * w); if (x > static_cast<uint32_t>(w - 1)) x = w - 1;
         uint32_t y = f2u_sat(v * h); if (y > static_cast<uint32_t>(h - 1)) y = h - 1;
+        if (rowTable) {
+            const float4 t = reinterpret_cast<const float4*>(table_row(y) + x)[1];     // (b | pad) of the record's second half; r, g sit in the first
+            const float4 s = reinterpret_cast<const float4*>(table_row(y) + x)[0];
+            return f3(s.w, t.x, t.y);
+        }
         const float4 t = texels[static_cast<size_t>(y) * w + x];
         return f3(t.x, t.y, t.z);
     }
@@ -478,17 +495,35 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
         p = pdf[idx];
         return (idx + t) / n;
     }
+    // sample1d with the guide over one row of the interleaved table: the same search on the same values
+    static GFX_DEV float sample1d_row(const EnvRowRec* row, uint32_t n, float u, float& p) {
+        const uint32_t k = min(n - 1u, static_cast<uint32_t>(u * static_cast<float>(n)));
+        int hi = static_cast<int>(row[k].guide);
+        int lo = k ? static_cast<int>(row[k - 1].guide) : 0;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (row[mid].cdf <= u) lo = mid;
+            else hi = mid - 1;
+        }
+        const int idx = lo;
+        const float2 here = *reinterpret_cast<const float2*>(row + idx);      // (cdf, pdf) of the column
+        const float t = (u - here.x) / (row[idx + 1].cdf - here.x);
+        p = here.y;
+        return (idx + t) / n;
+    }
     GFX_DEV float evaluate_pdf(float d0, float d1) const { // common_shared.h:344-348, 380-383
         uint32_t row = f2u_sat(d1 * h); if (row > static_cast<uint32_t>(h - 1)) row = h - 1;
         uint32_t col = f2u_sat(d0 * w); if (col > static_cast<uint32_t>(w - 1)) col = w - 1;
+        if (rowTable) return topPDF[row] * table_row(row)[col].pdf;
         return topPDF[row] * rowPDF[static_cast<size_t>(row) * w + col];
     }
     GFX_DEV void sample(float u0, float u1, float& d0, float& d1, float& p) const { // common_shared.h:372-379
         float topP;
         d1 = sample1d(topPDF, topCDF, h, u1, topP, topGuide);
         uint32_t row = f2u_sat(d1 * h); if (row > static_cast<uint32_t>(h - 1)) row = h - 1;
-        d0 = sample1d(rowPDF + static_cast<size_t>(row) * w, rowCDF + static_cast<size_t>(row) * (w + 1), w, u0, p,
-                      rowGuide ? rowGuide + static_cast<size_t>(row) * w : nullptr);
+        if (rowTable) d0 = sample1d_row(table_row(row), w, u0, p);
+        else d0 = sample1d(rowPDF + static_cast<size_t>(row) * w, rowCDF + static_cast<size_t>(row) * (w + 1), w, u0, p,
+                           rowGuide ? rowGuide + static_cast<size_t>(row) * w : nullptr);
         p *= topP;
     }
 };

@@ -245,6 +245,11 @@ typedef struct gfx_restir_static_params {
      * of envW (envH) equal cells of [0,1). */
     const void* envRowGuide;
     const void* envTopGuide;
+    /* Optional: the rows of the map with everything a light sample on it reads in one place (gfxh_env_build_row_table; NULL = the
+     * separate arrays above, same results): envH x (envW + 1) records of 32 bytes {float cdf, pdf; uint32 guide; float r, g, b; 8 B
+     * unused} -- record (row, i) = envRowCDF[row * (envW + 1) + i], envRowPDF[row * envW + i], envRowGuide[row * envW + i] and texel
+     * (i, row) (zero where i = envW has none).  A sample then touches two or three 64-byte sectors instead of six or seven. */
+    const void* envRowTable;
 } gfx_restir_static_params;
 
 /* restir_di/restir_di_shared.h:241-281 PerFramePipelineLaunchParameters. */

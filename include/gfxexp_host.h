@@ -119,6 +119,10 @@ int gfxh_env_build_importance(float* texels4, uint32_t w, uint32_t h, float* row
  * the samplers' log2(n)-step searches become a table lookup plus a one- or two-entry bracket search with identical
  * results.  Returns 1 when the tables are usable (every CDF monotone, w and h <= 65536), 0 otherwise (pass NULL). */
 int gfxh_env_build_guides(const float* rowCDF, const float* topCDF, uint32_t w, uint32_t h, uint16_t* rowGuide, uint16_t* topGuide);
+/* gfx_restir_static_params::envRowTable: the rows of the map interleaved -- h x (w + 1) records of 32 bytes {cdf, pdf, guide, r, g, b, 0, 0}
+ * from the (clamped) texels, the conditional PDFs / CDFs and a usable row guide (gfxh_env_build_guides returned 1).  outRecords: 32 x h x
+ * (w + 1) bytes.  Same samples as with the separate arrays; a third of the memory traffic per sample. */
+void gfxh_env_build_row_table(const float* texels4, const float* rowPDF, const float* rowCDF, const uint16_t* rowGuide, uint32_t w, uint32_t h, void* outRecords);
 /* Synthetic lat-long sky (gradient + sun disc) used as the stand-in environment map. */
 void gfxh_env_make_sky(uint32_t w, uint32_t h, float sunElevationDeg, float sunAzimuthDeg, float sunRadiance, float* texels4);
 

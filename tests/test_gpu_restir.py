@@ -28,7 +28,7 @@ def default_camera(scene_kind, width, height):
 
 def run_sequence_both(hs, width, height, frames=2, renderer=api.RENDERER_BIASED, scene_kind="bunny",
                       low_discrepancy=True, reuse_visibility=True, camera=None, stop_after=None, threads=None,
-                      env=None, env_power=1.0, env_rotation=0.0, animate=None, tunables=None):
+                      env=None, env_power=1.0, env_rotation=0.0, animate=None, tunables=None, env_tables="interleaved"):
     """Run `frames` frames with the sequencing of restir_di_main.cpp:2311-2493 on the GPU (through
     the C ABI) and in the oracle, comparing all buffers after every pass.  Returns a list of
     mismatch descriptions (empty = bit-identical)."""
@@ -48,6 +48,9 @@ def run_sequence_both(hs, width, height, frames=2, renderer=api.RENDERER_BIASED,
     if env is not None:
         pb_gpu_init.set_env(*env)
         pb_cpu.set_env(*env, oracle_side=True)
+        # what the GPU searches: the interleaved rows (gfx_restir_static_params::envRowTable), the separate arrays with guide tables, or the plain arrays
+        pb_gpu_init.use_env_row_table = env_tables == "interleaved"
+        pb_gpu_init.use_env_guides = env_tables != "plain"
     dev = util.DeviceBuffers(pb_gpu_init)
     s_gpu = dev.static_params()
     s_cpu = pb_cpu.host_static_params()
@@ -268,14 +271,17 @@ def test_halo_band_renderer_refuses_a_frame_after_the_camera_moved(built_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env_tables", ["interleaved", "guided", "plain"])
 @pytest.mark.parametrize("renderer", [api.RENDERER_BIASED, api.RENDERER_UNBIASED])
-def test_environment_light_sequence_bit_exact(built_lib, renderer):
+def test_environment_light_sequence_bit_exact(built_lib, renderer, env_tables):
     """BASELINE config 5 ingredients: environment light (importance-sampled lat-long map, 25 % of the
-    candidates) + area lights, unbiased and biased estimators."""
+    candidates) + area lights, unbiased and biased estimators -- with the map's rows interleaved into 32-byte records (envRowTable:
+    CDF, PDF, guide and texel of a column side by side), as separate arrays with guide tables, and as the plain arrays with the
+    reference's binary searches: the same samples bit for bit."""
     w, h = 64, 32
     sky = api.env_make_sky(w, h)
     diffs = run_sequence_both(util.bunny_scene(), 128, 80, frames=2, renderer=renderer, env=(sky, w, h),
-                              env_power=0.7, env_rotation=0.6)
+                              env_power=0.7, env_rotation=0.6, env_tables=env_tables)
     assert not diffs, "\n".join(diffs)
     beauty = run_sequence_both.last_beauty
     bg = run_sequence_both.last_gb0["instSlot"] == 0xFFFFFFFF

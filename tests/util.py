@@ -224,6 +224,8 @@ class DeviceBuffers:
             if pb.env.get("guidesUsable") and getattr(pb, "use_env_guides", True):
                 for k in ("rowGuide", "topGuide"):      # uint16 tables (torch has no uint16: ship the bytes)
                     self.env_t[k] = torch.from_numpy(pb.env[k].view(np.uint8).reshape(-1).copy()).cuda()
+                if "rowTable" in pb.env and getattr(pb, "use_env_row_table", True):      # the interleaved rows (gfx_restir_static_params::envRowTable)
+                    self.env_t["rowTable"] = torch.from_numpy(pb.env["rowTable"].view(np.uint8).reshape(-1).copy()).cuda()
 
     def static_params(self):
         pb, t = self.pb, self.t
@@ -248,6 +250,8 @@ class DeviceBuffers:
             s.envTopPDF = et["topPDF"].data_ptr(); s.envTopCDF = et["topCDF"].data_ptr(); s.envTopIntegral = e["topIntegral"]
             if "rowGuide" in et:
                 s.envRowGuide = et["rowGuide"].data_ptr(); s.envTopGuide = et["topGuide"].data_ptr()
+            if "rowTable" in et:
+                s.envRowTable = et["rowTable"].data_ptr()
         return s
 
     def download(self):
