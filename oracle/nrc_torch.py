@@ -145,3 +145,44 @@ class Model:
         value = self.loss(x, target)
         value.backward()
         return float(value.detach()), self.flat.grad.detach().clone()
+
+
+class Trainer:
+    """The training loop of the cache in plain fp32 with autograd gradients: Adam (beta1 0.9, beta2 0.99, L2 regularisation 1e-6 folded into the
+    gradient of the MLP weights, hash-grid entries with an exactly zero gradient left alone, epsilon 1e-15 for the hash-grid configuration
+    and 1e-8 otherwise -- network_interface.cu:53-64, 91, 118) and the debiased EMA (0.99) of the weights.  No bf16, no fp16 gradient sums,
+    no loss scaling: what the kernels' precision contract is measured against over a whole training run (tests/test_gpu_nrc_net.py
+    test_loss_curve_against_fp32_training, tools/nrc_loss_curves.py)."""
+
+    def __init__(self, flat_params, pos_enc=HASHGRID, hidden_layers=2, learning_rate=1e-2, device="cpu"):
+        self.model = Model(flat_params, pos_enc, hidden_layers, device)
+        self.lr, self.beta1, self.beta2, self.l2, self.decay = learning_rate, 0.9, 0.99, 1e-6, 0.99
+        self.eps = 1e-15 if pos_enc == HASHGRID else 1e-8
+        p = self.model.flat
+        self.m, self.v = torch.zeros_like(p), torch.zeros_like(p)
+        self.ema = p.detach().clone()
+        self.step = 0
+
+    def train(self, x, target):
+        """One step; returns the loss the step started from."""
+        mdl = self.model
+        value, grad = mdl.loss_and_gradient(x, target)
+        self.step += 1
+        t = self.step
+        with torch.no_grad():
+            p = mdl.flat
+            is_grid = torch.zeros_like(p, dtype=torch.bool)
+            is_grid[mdl.mlp_params:] = True
+            active = ~(is_grid & (grad == 0))
+            grad = torch.where(is_grid, grad, grad + self.l2 * p)
+            self.m = torch.where(active, self.beta1 * self.m + (1 - self.beta1) * grad, self.m)
+            self.v = torch.where(active, self.beta2 * self.v + (1 - self.beta2) * grad * grad, self.v)
+            lr_t = self.lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+            p -= torch.where(active, lr_t * self.m / (torch.sqrt(self.v) + self.eps), torch.zeros_like(p))
+            self.ema = ((1 - self.decay) * p + self.decay * (1.0 - self.decay ** (t - 1)) * self.ema) / (1.0 - self.decay ** t)
+        return value
+
+    def infer(self, x):
+        """Predictions with the EMA weights (what gfx_nrc_infer uses)."""
+        with torch.no_grad():
+            return Model(self.ema, self.model.pos_enc, self.model.hidden_layers, self.model.device).forward(x).cpu().numpy()
