@@ -768,6 +768,21 @@ __global__ __launch_bounds__(kBlock) void k_shade_prepare(RestirArgs a) {
     }
 }
 
+// GFX_RESTIR_SPATIAL_BIASED_AND_SHADING at full size: the pixel's last spatial pass and the set-up of its shading in one kernel -- the thread
+// that wrote the pixel's entry of the other reservoir forms the shading terms from it, instead of a second per-pixel launch reading the
+// pixel's G-buffer, material textures and reservoir again (the shadow ray keeps k_trace, whose refill is worth more than a launch at this
+// size: profiles/r04_experiments.txt 19).
+__global__ __launch_bounds__(kBlock) void k_spatial_shade_prepare(RestirArgs a) {
+    const PixelId px = pixel_of_thread(a.px);
+    spatial_reuse<false>(a, px);
+    const ShadeState st = shade_prepare(a, px, (a.curRes + 1) % 2);
+    const uint32_t slot = emit_ray_at_slot(px, st.want, st.ro, st.rd, 0.0f, st.tmax, a);
+    if (px.valid) {
+        a.shadeScratch[2 * px.p] = make_float4(st.contribution.x, st.contribution.y, st.contribution.z, bits2f(slot));
+        a.shadeScratch[2 * px.p + 1] = make_float4(st.direct.x, st.direct.y, st.direct.z, st.recPDF);
+    }
+}
+
 // contribution += recPDFEstimate * directCont; running mean (optix_restir_di_kernels.cu:619-636).  `occluded`: the final shadow ray
 // found an occluder (false when the pixel had no ray).
 GFX_DEV void shade_finish(const RestirArgs& a, const PixelId& px, f3 contribution, f3 direct, float recPDF, bool occluded) {
@@ -1090,7 +1105,12 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         const size_t frameSlots = static_cast<size_t>(make_pixel_grid(ctx, width, 0, height).launchBlocks) * kBlock;
         const uint32_t numSlots = a.px.launchBlocks * kBlock;
         ctx.gbRayOrg.reserve(16 * frameSlots); ctx.gbRayDir.reserve(16 * frameSlots);
-        ctx.gbRayHits.reserve(sizeof(gfx_hit) * frameSlots);
+        if (sizeof(gfx_hit) * frameSlots > ctx.gbRayHits.bytes) {
+            // the first frame finds "no triangle" in every slot's temporal hint, not whatever the allocation held (a stale index
+            // costs a triangle test and moves the work counters, never the result)
+            ctx.gbRayHits.reserve(sizeof(gfx_hit) * frameSlots);
+            GFX_HIP(hipMemsetAsync(ctx.gbRayHits.p, 0xFF, ctx.gbRayHits.bytes, stream));
+        }
         a.rayOrg = ctx.gbRayOrg.as<float4>(); a.rayDir = ctx.gbRayDir.as<float4>();
         a.hits = ctx.gbRayHits.as<gfx_hit>();
         // primary rays are coherent (neighbouring lanes walk nearly the same nodes, the temporal hint ends most of them early): the
@@ -1201,11 +1221,8 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
             block_order_end(1, a.px.launchBlocks, cost);
             break;
         }
-        if (pass == GFX_RESTIR_SPATIAL_BIASED_AND_SHADING) {
-            launch_pixels(ctx, stream, "spatial_biased", k_spatial<false>, a);
-            a.curRes = (a.curRes + 1) % 2;           // the shading pass reads what the spatial pass wrote
-        }
-        launch_pixels(ctx, stream, "shade_prepare", k_shade_prepare, a);
+        if (pass == GFX_RESTIR_SPATIAL_BIASED_AND_SHADING) launch_pixels(ctx, stream, "spatial_shade_prepare", k_spatial_shade_prepare, a);
+        else launch_pixels(ctx, stream, "shade_prepare", k_shade_prepare, a);
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, a.px.launchBlocks * kBlock, false, ctx.rayOut.p);   // one entry per launch slot (emit_ray_at_slot)
         launch_pixels(ctx, stream, "shade_finish", k_shade_finish, a);
         break;

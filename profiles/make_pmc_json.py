@@ -20,7 +20,7 @@ import sys
 
 KERNELS = {"k_trace_any": "k_trace<true, false>", "k_trace_closest": "k_trace<false, false>",
            "k_initial_candidates": "k_initial_candidates<", "k_initial_candidates_pooled": "k_initial_candidates_pooled<", "k_spatial": "k_spatial<false>", "k_temporal": "k_temporal<1>",
-           "k_shade_prepare": "k_shade_prepare", "k_gbuffer_resolve": "k_gbuffer_resolve", "k_gbuffer_fused": "k_gbuffer_fused",
+           "k_shade_prepare": "k_shade_prepare(", "k_spatial_shade_prepare": "k_spatial_shade_prepare", "k_gbuffer_resolve": "k_gbuffer_resolve", "k_gbuffer_fused": "k_gbuffer_fused",
            "k_pt_fused": "k_pt_fused<", "k_spatial_unbiased": "k_spatial<true>", "k_spatial_mis_finish": "k_spatial_mis_finish", "k_temporal_unbiased": "k_temporal<2>",
            "k_initial_fused": "k_initial_fused<", "k_shading_fused": "k_shading_fused<"}
 
