@@ -452,6 +452,28 @@ struct PendingEmittance { uint32_t tex; uint32_t rec; float bcA, bcB, bcC; };
 struct EnvRowRec { float cdf, pdf; uint32_t guide; float r, g, b; uint32_t pad0, pad1; };
 static_assert(sizeof(EnvRowRec) == 32, "two records per 64-byte sector");
 
+// The largest index of [lo, hi] whose CDF value is <= u (cdfAt(lo) <= u is known; the CDF is monotone): what the bisection of
+// DiscreteDistribution / RegularConstantContinuousDistribution1D::sample returns, found with PIVOTS probes per dependent round trip
+// instead of one.  A guide bracket is 0-2 entries wide for nearly every sample, but a map with a sun in it has rows in which a few guide
+// cells cover a hundred dim texels each: one lane of a wave lands there in every other iteration, and the wave waited for its
+// seven to eleven dependent loads (profiles/r05_experiments.txt 5).  Narrows [lo, hi] until at most three entries are left.
+template <int PIVOTS, typename CdfAt>
+GFX_DEV void narrow_bracket(CdfAt cdfAt, float u, int& lo, int& hi) {
+    while (hi - lo > 2) {
+        const int span = hi - lo;
+        int piv[PIVOTS]; float c[PIVOTS];
+#pragma unroll
+        for (int j = 0; j < PIVOTS; ++j) { piv[j] = lo + ((span * (j + 1)) / (PIVOTS + 1)); c[j] = cdfAt(piv[j]); }
+        int nlo = lo, nhi = hi;
+#pragma unroll
+        for (int j = 0; j < PIVOTS; ++j) {
+            if (c[j] <= u) nlo = max(nlo, piv[j]);
+            else nhi = min(nhi, piv[j] - 1);
+        }
+        lo = nlo; hi = nhi;
+    }
+}
+
 struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
     const float4* texels;
     const float* rowPDF; const float* rowCDF; const float* topPDF; const float* topCDF;
@@ -479,6 +501,7 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
             const uint32_t k = min(n - 1u, static_cast<uint32_t>(u * static_cast<float>(n)));
             int hi = guide[k];
             int lo = k ? guide[k - 1] : 0;
+            narrow_bracket<3>([&](int i) { return cdf[i]; }, u, lo, hi);     // wide brackets: three probes per round trip
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (cdf[mid] <= u) lo = mid;
@@ -495,19 +518,30 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
         p = pdf[idx];
         return (idx + t) / n;
     }
-    // sample1d with the guide over one row of the interleaved table: the same search on the same values
+    // sample1d with the guide over one row of the interleaved table: the same search on the same values.  A light sample on the map is a
+    // chain of dependent loads from a table far larger than the L2s (guide pair -> probes -> the column's entries), and a wave's eight
+    // environment candidates are eight such chains one after the other: when the guide's bracket is at most three columns wide -- the usual
+    // case -- the columns it can end on are loaded TOGETHER right after the guide pair (they share two or three sectors) and the search
+    // finishes in registers: two dependent round trips per row instead of three or four.  The column found is the one the bisection
+    // finds (the largest index of the bracket whose CDF value is <= u; the builder verified that the CDF is monotone).
     static GFX_DEV float sample1d_row(const EnvRowRec* row, uint32_t n, float u, float& p) {
         const uint32_t k = min(n - 1u, static_cast<uint32_t>(u * static_cast<float>(n)));
         int hi = static_cast<int>(row[k].guide);
         int lo = k ? static_cast<int>(row[k - 1].guide) : 0;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (row[mid].cdf <= u) lo = mid;
-            else hi = mid - 1;
+        float2 here; float next;
+        int idx;
+        narrow_bracket<7>([&](int i) { return row[i].cdf; }, u, lo, hi);  // wide brackets (dim stretches of a row with a sun in it): seven probes per round trip
+        {
+            const int last = static_cast<int>(n);                       // record n holds the row's final CDF value
+            const float2 c0 = *reinterpret_cast<const float2*>(row + lo);
+            const float2 c1 = *reinterpret_cast<const float2*>(row + min(lo + 1, last));
+            const float2 c2 = *reinterpret_cast<const float2*>(row + min(lo + 2, last));
+            const float c3 = row[min(lo + 3, last)].cdf;
+            idx = lo; here = c0; next = c1.x;
+            if (hi >= lo + 1 && c1.x <= u) { idx = lo + 1; here = c1; next = c2.x; }
+            if (hi >= lo + 2 && c2.x <= u) { idx = lo + 2; here = c2; next = c3; }
         }
-        const int idx = lo;
-        const float2 here = *reinterpret_cast<const float2*>(row + idx);      // (cdf, pdf) of the column
-        const float t = (u - here.x) / (row[idx + 1].cdf - here.x);
+        const float t = (u - here.x) / (next - here.x);
         p = here.y;
         return (idx + t) / n;
     }

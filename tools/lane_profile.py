@@ -34,11 +34,16 @@ def main():
     hs.upload(ctx)
     accel = ctx.accel_build()
     ctx.lights_build_static()
-    dev = util.DeviceBuffers(util.PixelBuffers(W, H))
+    pb = util.PixelBuffers(W, H)
+    env = "--env" in sys.argv                  # configs[4]: 2048 x 1024 sky + sun environment map, a quarter of the candidates sample it
+    if env:
+        pb.set_env(api.env_make_sky(2048, 1024), 2048, 1024)
+        pb.use_env_row_table = "--no-row-table" not in sys.argv
+    dev = util.DeviceBuffers(pb)
     cam = api.make_camera(W, H, pos=(1.5, 2.2, 52.0), pitch=4.0, yaw=181.5)
     stream = torch.cuda.current_stream().cuda_stream
     f = util.frame_params(api.GfxRestirFrameParams, api.GfxCamera, W, H, cam, travHandle=accel, frameIndex=0, bufferIndex=0, resetFlowBuffer=1,
-                          enableBumpMapping=int(textured))
+                          enableBumpMapping=int(textured), enableEnvLight=int(env), envLightPowerCoeff=0.6, envLightRotation=0.4)
     ctx.lights_build_instances(stream)
     ctx.restir_set_params(dev.static_params(), f, 0, 0, stream)
     ctx.restir_launch(api.PASS_SETUP_GBUFFERS, W, H, stream)
