@@ -507,112 +507,161 @@ GFX_DEV void spatial_neighbor(const RestirArgs& a, Pcg32& rng, uint32_t nIdx, in
 
 // optix_restir_di_kernels.cu:303-547.  UNBIASED: combines, then emits the MIS-denominator rays.
 // EVERY thread of the block must call the UNBIASED form (its ray queue reservation is a block-wide operation).
+// What the combination of a pixel's own reservoir with its neighbours' leaves (the first half of the pass)
+struct SpatialSelection {
+    bool surface;
+    ShadingPoint sp;
+    Pcg32 rng;
+    Reservoir combined;
+    float selectedTarget;
+    int32_t selectedNeighborIndex;      // UNBIASED: which neighbour's sample was selected last, -1 = the pixel's own
+    uint32_t selfStreamLength;
+};
 template <bool UNBIASED>
-GFX_DEV void spatial_reuse(const RestirArgs& a, const PixelId& px) {
+GFX_DEV void spatial_select(const RestirArgs& a, const PixelId& px, const Camera& cam, SpatialSelection& s) {
     const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
     const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     const uint32_t numNb = a.f.numSpatialNeighbors;
-    bool surface = false;
-    if (px.valid) surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
+    s.surface = false;
+    if (px.valid) s.surface = static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[p].x != 0xFFFFFFFFu;
     const int x = px.x, y = px.y;
-    const uint32_t srcRes = a.curRes, dstRes = (a.curRes + 1) % 2;
-    const Camera cam = load_camera(a.f.camera);
-
-    ShadingPoint sp;
-    Pcg32 rng; rng.state = 0;
-    Reservoir combined;
-    combined.reset();
-    float selectedTarget = 0.0f;
-    int32_t selectedNeighborIndex = -1;
-    uint32_t selfStreamLength = 0;
-    uint64_t* rngBuf = static_cast<uint64_t*>(a.s.rngBuffer);
-    if (surface) {
-        make_shading_point(a, bufIdx, p, cam.pos, false, sp);
-        rng.state = rngBuf[p];
+    const uint32_t srcRes = a.curRes;
+    s.rng.state = 0;
+    s.combined.reset();
+    s.selectedTarget = 0.0f;
+    s.selectedNeighborIndex = -1;
+    s.selfStreamLength = 0;
+    const uint64_t* rngBuf = static_cast<const uint64_t*>(a.s.rngBuffer);
+    if (s.surface) {
+        make_shading_point(a, bufIdx, p, cam.pos, false, s.sp);
+        s.rng.state = rngBuf[p];
         const Reservoir self = load_reservoir(a.s.reservoirBuffer[srcRes], numPixels, p);
         const float2 selfInfo = static_cast<const float2*>(a.s.reservoirInfoBuffer[srcRes])[p];
-        if (selfInfo.x > 0.0f) { combined = self; selectedTarget = selfInfo.y; }
-        selfStreamLength = self.streamLength;
+        if (selfInfo.x > 0.0f) { s.combined = self; s.selectedTarget = selfInfo.y; }
+        s.selfStreamLength = self.streamLength;
         uint32_t combinedStreamLength = self.streamLength;
         for (uint32_t nIdx = 0; nIdx < numNb; ++nIdx) {
             int nbx, nby;
-            spatial_neighbor(a, rng, nIdx, x, y, nbx, nby);
-            const bool accepted = test_neighbor(a, !UNBIASED, bufIdx, nbx, nby, sp.dist, sp.frame.n, cam.pos) && (nbx != x || nby != y);
+            spatial_neighbor(a, s.rng, nIdx, x, y, nbx, nby);
+            const bool accepted = test_neighbor(a, !UNBIASED, bufIdx, nbx, nby, s.sp.dist, s.sp.frame.n, cam.pos) && (nbx != x || nby != y);
             if (accepted) {
                 const size_t np = static_cast<size_t>(nby) * a.s.imageSizeX + nbx;
                 const Reservoir neighbor = load_reservoir(a.s.reservoirBuffer[srcRes], numPixels, np);
                 const float2 nbInfo = static_cast<const float2*>(a.s.reservoirInfoBuffer[srcRes])[np];
-                const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, neighbor.sample);
+                const f3 cont = direct_lighting(s.sp.pos, s.sp.vOutLocal, s.sp.frame, s.sp.bsdf, neighbor.sample);
                 const float target = target_weight(cont);
                 const uint32_t nbStreamLength = neighbor.streamLength;
                 const float weight = target * nbInfo.x * nbStreamLength;
-                if (combined.update(neighbor.sample, weight, rng.uniform())) {
-                    selectedTarget = target;
-                    if (UNBIASED) selectedNeighborIndex = static_cast<int32_t>(nIdx);
+                if (s.combined.update(neighbor.sample, weight, s.rng.uniform())) {
+                    s.selectedTarget = target;
+                    if (UNBIASED) s.selectedNeighborIndex = static_cast<int32_t>(nIdx);
                 }
                 combinedStreamLength += nbStreamLength;
             }
         }
-        combined.streamLength = combinedStreamLength;
+        s.combined.streamLength = combinedStreamLength;
     }
+}
+// MIS term k of the unbiased pass (0 = the pixel itself, 1 + nIdx = neighbour nIdx): the target density of the selected sample there, that
+// pixel's stream length, and the visibility ray the term needs.  Terms are formed in the order k = 0, 1, ...: a neighbour term draws its
+// position from the pixel's stream (random-neighbour mode).
+struct MisTerm { float target; uint32_t streamLength; bool want, evaluated; f3 ro, rd; float tmax; };
+GFX_DEV MisTerm spatial_mis_term(const RestirArgs& a, const PixelId& px, SpatialSelection& s, const Camera& prevCam, uint32_t k) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const uint32_t bufIdx = a.f.bufferIndex;
+    const bool needMis = s.surface && s.selectedTarget > 0.0f;
+    const LightSample selected = s.combined.sample;
+    MisTerm t; t.target = 0.0f; t.streamLength = 0; t.want = false; t.evaluated = false; t.ro = f3(0.0f); t.rd = f3(0.0f); t.tmax = 0;
+    if (k == 0) {
+        t.streamLength = s.selfStreamLength; t.evaluated = true;
+        if (needMis) {
+            const f3 cont = direct_lighting(s.sp.pos, s.sp.vOutLocal, s.sp.frame, s.sp.bsdf, selected);
+            t.target = target_weight(cont);
+            if (a.f.reuseVisibility && t.target > 0.0f) {
+                const ShadowRay sr = shadow_ray(s.sp.pos, selected);
+                t.want = true; t.ro = s.sp.pos; t.rd = sr.dir; t.tmax = sr.tmax;
+            }
+        }
+        return t;
+    }
+    if (needMis) {
+        const int x = px.x, y = px.y;
+        int nbx, nby;
+        spatial_neighbor(a, s.rng, k - 1, x, y, nbx, nby);
+        const bool accepted = (nbx >= 0 && nbx < a.s.imageSizeX && nby >= 0 && nby < a.s.imageSizeY) && (nbx != x || nby != y);
+        if (accepted) {
+            const size_t np = static_cast<size_t>(nby) * a.s.imageSizeX + nbx;
+            if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[np].x != 0xFFFFFFFFu) {
+                ShadingPoint nsp;
+                make_shading_point(a, bufIdx, np, prevCam.pos, true, nsp);   // prevCamera as in the reference (:487)
+                const Reservoir neighbor = load_reservoir(a.s.reservoirBuffer[a.curRes], numPixels, np);
+                const f3 cont = direct_lighting(nsp.pos, nsp.vOutLocal, nsp.frame, nsp.bsdf, selected);
+                t.target = target_weight(cont);
+                t.streamLength = neighbor.streamLength;
+                t.evaluated = true;
+                if (a.f.reuseVisibility && t.target > 0.0f) {
+                    const ShadowRay sr = shadow_ray(nsp.pos, selected);
+                    t.want = true; t.ro = nsp.pos; t.rd = sr.dir; t.tmax = sr.tmax;
+                }
+            }
+        }
+    }
+    return t;
+}
+// The MIS weight of the unbiased pass as its terms come in (optix_restir_di_kernels.cu:413-546): term k with its ray's answer
+struct MisSum {
+    float numWeight, denomWeight; bool visibility;
+    GFX_DEV void begin() { numWeight = 0.0f; denomWeight = 0.0f; visibility = true; }
+    GFX_DEV void add(const RestirArgs& a, uint32_t k, float target, uint32_t streamLength, bool evaluated, bool occluded, int32_t selectedNeighborIndex) {
+        if (k == 0) {
+            float targetSelf = target;
+            if (occluded) targetSelf = 0.0f;
+            if (a.f.reuseVisibility) visibility = targetSelf > 0.0f;
+            numWeight = targetSelf;
+            denomWeight = targetSelf * streamLength;
+            return;
+        }
+        if (!evaluated) return;                  // out of bounds / self / background: the reference `continue`s
+        float nbTarget = target;
+        if (occluded) nbTarget = 0.0f;
+        denomWeight += nbTarget * streamLength;
+        if (static_cast<int32_t>(k - 1) == selectedNeighborIndex) numWeight = nbTarget;
+    }
+    GFX_DEV float weight(const RestirArgs& a) const {
+        float w = numWeight / denomWeight;
+        if (a.f.reuseVisibility && !visibility) w = 0.0f;
+        return w;
+    }
+};
+template <bool UNBIASED>
+GFX_DEV void spatial_reuse(const RestirArgs& a, const PixelId& px) {
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const size_t p = px.p;
+    const uint32_t numNb = a.f.numSpatialNeighbors;
+    const uint32_t dstRes = (a.curRes + 1) % 2;
+    const Camera cam = load_camera(a.f.camera);
+    uint64_t* rngBuf = static_cast<uint64_t*>(a.s.rngBuffer);
+    SpatialSelection sel;
+    spatial_select<UNBIASED>(a, px, cam, sel);
+    const bool surface = sel.surface;
+    Reservoir& combined = sel.combined;
 
     if (!UNBIASED) {
         if (!surface) return;
         const float weightForEstimate = 1.0f / combined.streamLength;
-        float recPDF = weightForEstimate * combined.sumWeights / selectedTarget;
-        float target = selectedTarget;
+        float recPDF = weightForEstimate * combined.sumWeights / sel.selectedTarget;
+        float target = sel.selectedTarget;
         if (!is_finite(recPDF)) { recPDF = 0.0f; target = 0.0f; }
-        rngBuf[p] = rng.state;
+        rngBuf[p] = sel.rng.state;
         store_reservoir(a.s.reservoirBuffer[dstRes], numPixels, p, combined);
         static_cast<float2*>(a.s.reservoirInfoBuffer[dstRes])[p] = make_float2(recPDF, target);
         return;
     }
 
     // ---- unbiased: targets of the selected sample at self and at every neighbour, rays where needed
-    const bool needMis = surface && selectedTarget > 0.0f;
-    const LightSample selected = combined.sample;
     SpatialSlot* slots = a.spatialScratch + (px.valid ? p * (numNb + 1) : 0);
     const Camera prevCam = load_camera(a.f.prevCamera);
-    // MIS term k (0 = self, 1 + nIdx = neighbour): target density, stream length, and the visibility ray it needs
-    struct MisTerm { float target; uint32_t streamLength; bool want, evaluated; f3 ro, rd; float tmax; };
-    auto self_term = [&]() {
-        MisTerm t; t.target = 0.0f; t.streamLength = selfStreamLength; t.want = false; t.evaluated = true; t.ro = f3(0.0f); t.rd = f3(0.0f); t.tmax = 0;
-        if (needMis) {
-            const f3 cont = direct_lighting(sp.pos, sp.vOutLocal, sp.frame, sp.bsdf, selected);
-            t.target = target_weight(cont);
-            if (a.f.reuseVisibility && t.target > 0.0f) {
-                const ShadowRay sr = shadow_ray(sp.pos, selected);
-                t.want = true; t.ro = sp.pos; t.rd = sr.dir; t.tmax = sr.tmax;
-            }
-        }
-        return t;
-    };
-    auto neighbor_term = [&](uint32_t nIdx) {
-        MisTerm t; t.target = 0.0f; t.streamLength = 0; t.want = false; t.evaluated = false; t.ro = f3(0.0f); t.rd = f3(0.0f); t.tmax = 0;
-        if (needMis) {
-            int nbx, nby;
-            spatial_neighbor(a, rng, nIdx, x, y, nbx, nby);
-            const bool accepted = (nbx >= 0 && nbx < a.s.imageSizeX && nby >= 0 && nby < a.s.imageSizeY) && (nbx != x || nby != y);
-            if (accepted) {
-                const size_t np = static_cast<size_t>(nby) * a.s.imageSizeX + nbx;
-                if (static_cast<const uint4*>(a.s.gbuffer0[bufIdx])[np].x != 0xFFFFFFFFu) {
-                    ShadingPoint nsp;
-                    make_shading_point(a, bufIdx, np, prevCam.pos, true, nsp);   // prevCamera as in the reference (:487)
-                    const Reservoir neighbor = load_reservoir(a.s.reservoirBuffer[srcRes], numPixels, np);
-                    const f3 cont = direct_lighting(nsp.pos, nsp.vOutLocal, nsp.frame, nsp.bsdf, selected);
-                    t.target = target_weight(cont);
-                    t.streamLength = neighbor.streamLength;
-                    t.evaluated = true;
-                    if (a.f.reuseVisibility && t.target > 0.0f) {
-                        const ShadowRay sr = shadow_ray(nsp.pos, selected);
-                        t.want = true; t.ro = nsp.pos; t.rd = sr.dir; t.tmax = sr.tmax;
-                    }
-                }
-            }
-        }
-        return t;
-    };
     auto store_term = [&](uint32_t k, const MisTerm& t, uint32_t slot) {
         if (!t.evaluated) slot = kSlotSkipped;   // out of bounds / self / background: the reference `continue`s
         if (px.valid) { SpatialSlot s; s.targetDensity = t.target; s.streamLength = t.streamLength; s.raySlot = slot; slots[k] = s; }
@@ -623,8 +672,7 @@ GFX_DEV void spatial_reuse(const RestirArgs& a, const PixelId& px) {
         bool want[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
-            if (k == 0) terms[k] = self_term();
-            else if (static_cast<uint32_t>(k) <= numNb) terms[k] = neighbor_term(static_cast<uint32_t>(k) - 1);
+            if (static_cast<uint32_t>(k) <= numNb) terms[k] = spatial_mis_term(a, px, sel, prevCam, static_cast<uint32_t>(k));
             else { terms[k].want = false; terms[k].evaluated = false; }
             want[k] = terms[k].want;
         }
@@ -639,22 +687,23 @@ GFX_DEV void spatial_reuse(const RestirArgs& a, const PixelId& px) {
     }
     else {
         {
-            const MisTerm t = self_term();
+            const MisTerm t = spatial_mis_term(a, px, sel, prevCam, 0u);
             store_term(0, t, emit_ray(t.want, t.ro, t.rd, 0.0f, t.tmax, a));
         }
-        for (uint32_t nIdx = 0; nIdx < numNb; ++nIdx) {
-            const MisTerm t = neighbor_term(nIdx);
-            store_term(1 + nIdx, t, emit_ray(t.want, t.ro, t.rd, 0.0f, t.tmax, a));
+        for (uint32_t k = 1; k <= numNb; ++k) {
+            const MisTerm t = spatial_mis_term(a, px, sel, prevCam, k);
+            store_term(k, t, emit_ray(t.want, t.ro, t.rd, 0.0f, t.tmax, a));
         }
     }
     if (!surface) return;
-    rngBuf[p] = rng.state;
+    rngBuf[p] = sel.rng.state;
     store_reservoir(a.s.reservoirBuffer[dstRes], numPixels, p, combined);
     // stash (selectedNeighborIndex, selectedTarget) for the finishing kernel
-    static_cast<float2*>(a.s.reservoirInfoBuffer[dstRes])[p] = make_float2(bits2f(static_cast<uint32_t>(selectedNeighborIndex)), selectedTarget);
+    static_cast<float2*>(a.s.reservoirInfoBuffer[dstRes])[p] = make_float2(bits2f(static_cast<uint32_t>(sel.selectedNeighborIndex)), sel.selectedTarget);
 }
+// (four waves per SIMD for both forms: the unbiased one sits at the 128-register boundary)
 template <bool UNBIASED>
-__global__ __launch_bounds__(kBlock) void k_spatial(RestirArgs a) { spatial_reuse<UNBIASED>(a, pixel_of_thread(a.px)); }
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_spatial(RestirArgs a) { spatial_reuse<UNBIASED>(a, pixel_of_thread(a.px)); }
 
 // MIS weights of the unbiased spatial pass once the rays are back: optix_restir_di_kernels.cu:413-546
 __global__ __launch_bounds__(kBlock) void k_spatial_mis_finish(RestirArgs a) {
@@ -675,26 +724,14 @@ __global__ __launch_bounds__(kBlock) void k_spatial_mis_finish(RestirArgs a) {
 
     float weightForEstimate = 0.0f;
     if (selectedTarget > 0.0f) {
-        bool visibility = true;
-        float numWeight, denomWeight;
-        {
-            const SpatialSlot s = slots[0];
-            float targetSelf = s.targetDensity;
-            if (s.raySlot != GFX_INVALID_SLOT && a.occluded[s.raySlot]) targetSelf = 0.0f;
-            if (a.f.reuseVisibility) visibility = targetSelf > 0.0f;
-            numWeight = targetSelf;
-            denomWeight = targetSelf * s.streamLength;
+        MisSum sum;
+        sum.begin();
+        for (uint32_t k = 0; k <= numNb; ++k) {
+            const SpatialSlot s = slots[k];
+            const bool rayed = s.raySlot != GFX_INVALID_SLOT && s.raySlot != kSlotSkipped;
+            sum.add(a, k, s.targetDensity, s.streamLength, s.raySlot != kSlotSkipped, rayed && a.occluded[s.raySlot] != 0u, selectedNeighborIndex);
         }
-        for (uint32_t nIdx = 0; nIdx < numNb; ++nIdx) {
-            const SpatialSlot s = slots[1 + nIdx];
-            if (s.raySlot == kSlotSkipped) continue;
-            float nbTarget = s.targetDensity;
-            if (s.raySlot != GFX_INVALID_SLOT && a.occluded[s.raySlot]) nbTarget = 0.0f;
-            denomWeight += nbTarget * s.streamLength;
-            if (static_cast<int32_t>(nIdx) == selectedNeighborIndex) numWeight = nbTarget;
-        }
-        weightForEstimate = numWeight / denomWeight;
-        if (a.f.reuseVisibility && !visibility) weightForEstimate = 0.0f;
+        weightForEstimate = sum.weight(a);
     }
     float recPDF = weightForEstimate * sumWeights / selectedTarget;
     float target = selectedTarget;
@@ -948,6 +985,42 @@ __global__ __launch_bounds__(kBlock) void k_shading_fused(RestirArgs a, DevAccel
     if (px.valid) shade_finish(a, px, st.contribution, st.direct, st.recPDF, st.want && h.tri != GFX_INVALID_SLOT);
 }
 
+// GFX_RESTIR_SPATIAL_UNBIASED as ONE kernel for band-sized launches (the pass of BASELINE configs[4], the configuration the 8-GPU line is
+// quoted on): combine, then per MIS term -- the pixel itself, then its neighbours, in the order the three-kernel form queues them -- form
+// the term, trace its visibility ray inside the wave, add it to the MIS sum; no ray queue, no per-term scratch, no finishing kernel.  Up to
+// 1 + numSpatialNeighbors rays per pixel toward ONE light sample from nearby surface points.
+__global__ __launch_bounds__(kBlock) void k_spatial_unbiased_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap) {
+    __shared__ uint2 ldsStack[kLdsStackDepth * kBlock];
+    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);
+    const PixelId px = pixel_of_thread(a.px);
+    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
+    const uint32_t numNb = a.f.numSpatialNeighbors;
+    const Camera cam = load_camera(a.f.camera);
+    SpatialSelection sel;
+    spatial_select<true>(a, px, cam, sel);
+    const Camera prevCam = load_camera(a.f.prevCamera);
+    MisSum sum;
+    sum.begin();
+    uint2* mySpill = spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * spillCap;
+    for (uint32_t k = 0; k <= numNb; ++k) {              // the same trip count in every lane
+        const MisTerm t = spatial_mis_term(a, px, sel, prevCam, k);
+        const RayHit h = trace_wave_local<true>(accel, t.want, t.ro, t.rd, 0.0f, t.tmax, ldsStack + tid, kBlock, mySpill, spillCap, waveBuf, lane);
+        sum.add(a, k, t.target, t.streamLength, t.evaluated, t.want && h.tri != GFX_INVALID_SLOT, sel.selectedNeighborIndex);
+    }
+    if (!sel.surface) return;
+    const size_t p = px.p;
+    const uint32_t dstRes = (a.curRes + 1) % 2;
+    const float weightForEstimate = sel.selectedTarget > 0.0f ? sum.weight(a) : 0.0f;
+    float recPDF = weightForEstimate * sel.combined.sumWeights / sel.selectedTarget;
+    float target = sel.selectedTarget;
+    if (!is_finite(recPDF)) { recPDF = 0.0f; target = 0.0f; }
+    static_cast<uint64_t*>(a.s.rngBuffer)[p] = sel.rng.state;
+    store_reservoir(a.s.reservoirBuffer[dstRes], numPixels, p, sel.combined);
+    static_cast<float2*>(a.s.reservoirInfoBuffer[dstRes])[p] = make_float2(recPDF, target);
+}
+
 #ifdef GFX_LANE_PROFILE   // experiment builds only (gm_math.hip.h GFX_PROF, tools/lane_profile.py)
 extern "C" int gfx_debug_lane_profile(unsigned long long* out64, int reset) {
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_laneProfile), sizeof(g_laneProfile)) != hipSuccess) return 1;
@@ -1199,6 +1272,14 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         launch_pixels(ctx, stream, "spatial_biased", k_spatial<false>, a);
         break;
     case GFX_RESTIR_SPATIAL_UNBIASED:
+        if (fused) {
+            ctx.spill.reserve(fusedSpillBytes);
+            ScopedKernelTimer timer(ctx, stream, "spatial_unbiased_fused");
+            hipLaunchKernelGGL(k_spatial_unbiased_fused, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a, ctx.accels[ctx.restir.f.travHandle - 1]->dev(),
+                               ctx.spill.as<uint2>(), spillCap);
+            GFX_HIP(hipGetLastError());
+            break;
+        }
         reset_queue();
         launch_pixels(ctx, stream, "spatial_unbiased_select", k_spatial<true>, a);
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);

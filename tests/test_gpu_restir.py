@@ -146,6 +146,20 @@ def test_lanes_per_pixel_of_the_candidate_pass_change_nothing(built_lib, split, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [1, 2])
+@pytest.mark.parametrize("low_discrepancy", [True, False])
+def test_unbiased_spatial_pass_as_three_kernels_and_as_one(built_lib, fuse, low_discrepancy):
+    """GFX_RESTIR_SPATIAL_UNBIASED (the estimator of BASELINE configs[4]): select + MIS rays into the queue, k_trace, finishing kernel
+    (fuse_passes 1: what a full-HD frame runs) or k_spatial_unbiased_fused (2: combine, then term by term form it, trace its ray inside
+    the wave, add it to the MIS sum -- what a rank's band runs).  Street scene with an environment map, three frames, Halton-disk and
+    random neighbours (the MIS terms then draw their positions from the pixel's stream, in term order): every buffer after every pass."""
+    sky = api.env_make_sky(64, 32)
+    diffs = run_sequence_both(util.small_street(), 160, 96, frames=3, renderer=api.RENDERER_UNBIASED, scene_kind="street",
+                              env=(sky, 64, 32), env_rotation=0.4, low_discrepancy=low_discrepancy, tunables={"fuse_passes": fuse})
+    assert not diffs, "\n".join(diffs[:12])
+
+
+@pytest.mark.gpu
 def test_street_sequence_bit_exact(built_lib):
     diffs = run_sequence_both(util.small_street(), 192, 108, frames=2, renderer=api.RENDERER_BIASED, scene_kind="street")
     assert not diffs, "\n".join(diffs)
