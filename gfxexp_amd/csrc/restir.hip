@@ -985,42 +985,6 @@ __global__ __launch_bounds__(kBlock) void k_shading_fused(RestirArgs a, DevAccel
     if (px.valid) shade_finish(a, px, st.contribution, st.direct, st.recPDF, st.want && h.tri != GFX_INVALID_SLOT);
 }
 
-// GFX_RESTIR_SPATIAL_UNBIASED as ONE kernel for band-sized launches (the pass of BASELINE configs[4], the configuration the 8-GPU line is
-// quoted on): combine, then per MIS term -- the pixel itself, then its neighbours, in the order the three-kernel form queues them -- form
-// the term, trace its visibility ray inside the wave, add it to the MIS sum; no ray queue, no per-term scratch, no finishing kernel.  Up to
-// 1 + numSpatialNeighbors rays per pixel toward ONE light sample from nearby surface points.
-__global__ __launch_bounds__(kBlock) void k_spatial_unbiased_fused(RestirArgs a, DevAccel accel, uint2* spill, int spillCap) {
-    __shared__ uint2 ldsStack[kLdsStackDepth * kBlock];
-    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kBlock / 64) * 256];
-    const int tid = threadIdx.x, lane = tid & 63;
-    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);
-    const PixelId px = pixel_of_thread(a.px);
-    const size_t numPixels = static_cast<size_t>(a.s.imageSizeX) * a.s.imageSizeY;
-    const uint32_t numNb = a.f.numSpatialNeighbors;
-    const Camera cam = load_camera(a.f.camera);
-    SpatialSelection sel;
-    spatial_select<true>(a, px, cam, sel);
-    const Camera prevCam = load_camera(a.f.prevCamera);
-    MisSum sum;
-    sum.begin();
-    uint2* mySpill = spill + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * spillCap;
-    for (uint32_t k = 0; k <= numNb; ++k) {              // the same trip count in every lane
-        const MisTerm t = spatial_mis_term(a, px, sel, prevCam, k);
-        const RayHit h = trace_wave_local<true>(accel, t.want, t.ro, t.rd, 0.0f, t.tmax, ldsStack + tid, kBlock, mySpill, spillCap, waveBuf, lane);
-        sum.add(a, k, t.target, t.streamLength, t.evaluated, t.want && h.tri != GFX_INVALID_SLOT, sel.selectedNeighborIndex);
-    }
-    if (!sel.surface) return;
-    const size_t p = px.p;
-    const uint32_t dstRes = (a.curRes + 1) % 2;
-    const float weightForEstimate = sel.selectedTarget > 0.0f ? sum.weight(a) : 0.0f;
-    float recPDF = weightForEstimate * sel.combined.sumWeights / sel.selectedTarget;
-    float target = sel.selectedTarget;
-    if (!is_finite(recPDF)) { recPDF = 0.0f; target = 0.0f; }
-    static_cast<uint64_t*>(a.s.rngBuffer)[p] = sel.rng.state;
-    store_reservoir(a.s.reservoirBuffer[dstRes], numPixels, p, sel.combined);
-    static_cast<float2*>(a.s.reservoirInfoBuffer[dstRes])[p] = make_float2(recPDF, target);
-}
-
 #ifdef GFX_LANE_PROFILE   // experiment builds only (gm_math.hip.h GFX_PROF, tools/lane_profile.py)
 extern "C" int gfx_debug_lane_profile(unsigned long long* out64, int reset) {
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_laneProfile), sizeof(g_laneProfile)) != hipSuccess) return 1;
@@ -1272,14 +1236,8 @@ void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, u
         launch_pixels(ctx, stream, "spatial_biased", k_spatial<false>, a);
         break;
     case GFX_RESTIR_SPATIAL_UNBIASED:
-        if (fused) {
-            ctx.spill.reserve(fusedSpillBytes);
-            ScopedKernelTimer timer(ctx, stream, "spatial_unbiased_fused");
-            hipLaunchKernelGGL(k_spatial_unbiased_fused, dim3(a.px.launchBlocks), dim3(kBlock), 0, stream, a, ctx.accels[ctx.restir.f.travHandle - 1]->dev(),
-                               ctx.spill.as<uint2>(), spillCap);
-            GFX_HIP(hipGetLastError());
-            break;
-        }
+        // (one kernel per band -- combine, then form / trace / add the MIS terms one after the other inside the wave -- was built and measured
+        // slower at every band size: up to four rays per pixel are what k_trace's refill is good at; profiles/r05_experiments.txt 9)
         reset_queue();
         launch_pixels(ctx, stream, "spatial_unbiased_select", k_spatial<true>, a);
         trace_queue(ctx, stream, a, GFX_TRACE_ANY, 0, true, ctx.rayOut.p);

@@ -148,11 +148,12 @@ def test_lanes_per_pixel_of_the_candidate_pass_change_nothing(built_lib, split, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fuse", [1, 2])
 @pytest.mark.parametrize("low_discrepancy", [True, False])
-def test_unbiased_spatial_pass_as_three_kernels_and_as_one(built_lib, fuse, low_discrepancy):
-    """GFX_RESTIR_SPATIAL_UNBIASED (the estimator of BASELINE configs[4]): select + MIS rays into the queue, k_trace, finishing kernel
-    (fuse_passes 1: what a full-HD frame runs) or k_spatial_unbiased_fused (2: combine, then term by term form it, trace its ray inside
-    the wave, add it to the MIS sum -- what a rank's band runs).  Street scene with an environment map, three frames, Halton-disk and
-    random neighbours (the MIS terms then draw their positions from the pixel's stream, in term order): every buffer after every pass."""
+def test_unbiased_estimator_with_the_ray_passes_fused_and_not(built_lib, fuse, low_discrepancy):
+    """The estimator of BASELINE configs[4] (unbiased: MIS-weighted temporal pass, spatial pass with up to four MIS rays per pixel) with the
+    G-buffer / candidate / shading passes as three kernels each (fuse_passes 1: what a full-HD frame runs) or one (2: what a rank's band
+    runs; the unbiased spatial pass keeps its select / k_trace / finish form at every size).  Street scene with an environment map, three
+    frames, Halton-disk and random neighbours (the MIS terms then draw their positions from the pixel's stream, in term order): every
+    buffer after every pass."""
     sky = api.env_make_sky(64, 32)
     diffs = run_sequence_both(util.small_street(), 160, 96, frames=3, renderer=api.RENDERER_UNBIASED, scene_kind="street",
                               env=(sky, 64, 32), env_rotation=0.4, low_discrepancy=low_discrepancy, tunables={"fuse_passes": fuse})
