@@ -166,11 +166,10 @@ struct Context {
     // trace of the same bounce (pathtrace.hip); auxFork / auxJoin order the two streams
     DevBuf auxSpill, auxCounters;
     // fused ReSTIR kernels (restir.hip): step counts per block of the last launch and the block order made from them, for one launch shape
-    // ([0] k_initial_fused, [1] k_shading_fused, [2] k_gbuffer_fused, [3] k_initial_candidates, [4] k_pt_fused).  k_order_blocks runs on orderStream behind the launch that wrote the costs (`counted`);
+    // ([0] k_initial_fused, [1] k_shading_fused, [2] k_gbuffer_fused, [3] k_initial_candidates, [4] k_pt_fused).  k_order_blocks runs on auxStream behind the launch that wrote the costs (`counted`);
     // the next launch of that kind waits for `ordered`.
     struct BlockOrder { DevBuf cost, order; uint64_t key = 0; uint32_t blocks = 0; bool valid = false; hipEvent_t counted = nullptr, ordered = nullptr; } blockOrders[5];
     hipStream_t auxStream = nullptr;
-    hipStream_t orderStream = nullptr;       // k_order_blocks (restir.hip block_order_end)
     hipEvent_t auxFork = nullptr, auxJoin = nullptr;
     // path tracer scratch (pathtrace.hip)
     DevBuf ptPending, ptExtOrg, ptExtDir, ptExtOwner, ptState;

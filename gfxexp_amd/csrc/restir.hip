@@ -955,14 +955,18 @@ void block_order_begin(Context& ctx, hipStream_t stream, int which, uint32_t blo
 void block_order_end(Context& ctx, hipStream_t stream, int which, uint32_t blocks, uint32_t* cost) {
     if (!cost) return;
     Context::BlockOrder& bo = ctx.blockOrders[which];
-    // a stream of their own: behind the path tracers' NEE traces on auxStream a sort would finish late and hold up the next launch that waits for it
-    if (!ctx.orderStream) GFX_HIP(hipStreamCreateWithFlags(&ctx.orderStream, hipStreamNonBlocking));
+    // On the context's ONE side stream, which the path tracers' NEE traces also use (pathtrace.hip).  A stream of their own for these
+    // 10-us sorts was tried in round 5 and cost the NRC frame 0.4 ms: HIP multiplexes its streams onto four hardware queues, a fifth
+    // stream moves the side stream onto the caller's queue (whichever streams were created first keep a queue to themselves), and the
+    // NEE trace then no longer runs beside the extension trace (profiles/r05_experiments.txt 10).  A sort queued behind a frame's NEE
+    // traces is still done long before the next frame's launch waits for it.
+    if (!ctx.auxStream) GFX_HIP(hipStreamCreateWithFlags(&ctx.auxStream, hipStreamNonBlocking));
     if (!bo.counted) { GFX_HIP(hipEventCreateWithFlags(&bo.counted, hipEventDisableTiming)); GFX_HIP(hipEventCreateWithFlags(&bo.ordered, hipEventDisableTiming)); }
     GFX_HIP(hipEventRecord(bo.counted, stream));
-    GFX_HIP(hipStreamWaitEvent(ctx.orderStream, bo.counted, 0));
-    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx.orderStream, cost, blocks, bo.order.as<uint32_t>());
+    GFX_HIP(hipStreamWaitEvent(ctx.auxStream, bo.counted, 0));
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx.auxStream, cost, blocks, bo.order.as<uint32_t>());
     GFX_HIP(hipGetLastError());
-    GFX_HIP(hipEventRecord(bo.ordered, ctx.orderStream));
+    GFX_HIP(hipEventRecord(bo.ordered, ctx.auxStream));
     bo.valid = true;
 }
 

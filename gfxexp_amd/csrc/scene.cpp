@@ -27,7 +27,6 @@ Context::~Context() {
     if (auxFork) (void)hipEventDestroy(auxFork);
     if (auxJoin) (void)hipEventDestroy(auxJoin);
     if (auxStream) (void)hipStreamDestroy(auxStream);
-    if (orderStream) (void)hipStreamDestroy(orderStream);
 }
 
 DevScene Context::devScene() const {

@@ -10,8 +10,8 @@
  * (the reference throws std::runtime_error from CUDADRV_CHECK, utils/cuda_util.cpp:58-69).
  * Everything is asynchronous with respect to `stream` (a hipStream_t passed as void*), and a
  * gfx_ctx is not thread-safe (same as the reference: one host thread, restir_di_main.cpp:1705).
- * A context also owns ONE set of library streams and events behind the launches (the second stream the path tracers' NEE traces
- * run on with its fork / join events, the stream of the block-order sorts, the scratch sets of the traversal): the launches of
+ * A context also owns ONE set of library streams and events behind the launches (the side stream the path tracers' NEE traces and the
+ * block-order sorts run on, with its fork / join events, and the scratch sets of the traversal): the launches of
  * one context (gfx_pt_launch, gfx_restir_launch*) are to be issued from one host thread, and renderers that run concurrently on
  * different streams take a context each (as the band renderers of tests/ and tools/ do).  With gfx_counters_enable the
  * per-launch diagnostics are those of the calling stream's order only when "pt_overlap" is 0.
