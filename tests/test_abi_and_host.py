@@ -167,3 +167,35 @@ def test_image_headers_with_absurd_dimensions_are_refused(built_lib, tmp_path):
     assert s.load_texture(str(ok)) == 1
     big = np.zeros(4, np.uint8)
     assert api.lib().gfxh_scene_add_texture(s.h, C.c_uint32(20000), C.c_uint32(2), C.c_uint32(api.TEX_RGBA8_UNORM), big.ctypes.data_as(C.c_void_p)) == 0
+
+
+def test_counter_files_carry_the_hash_of_the_sources_they_were_measured_on(tmp_path, monkeypatch):
+    """bench.py prints, next to every figure it takes from a committed counter file, which commit and which kernel sources the file
+    belongs to and whether those are the running library's (roofline.pmc_head / pmc_matches_sources): profiles/make_pmc_json.py and
+    bench.py hash gfxexp_amd/csrc the same way, a stale or foreign file shows as a mismatch, a file without provenance as None."""
+    import importlib.util
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    spec = importlib.util.spec_from_file_location("make_pmc_json", os.path.join(root, "profiles", "make_pmc_json.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    sha = bench.sources_sha16()
+    assert len(sha) == 16 and sha == mk.sources_sha16()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "ok.json").write_text(json.dumps({"sources_sha16": sha, "git_head": "abc123", "kernels": {"k_trace_any": {}}}))
+    (prof / "stale.json").write_text(json.dumps({"sources_sha16": "0" * 16, "git_head": "def456", "kernels": {}}))
+    (prof / "old.json").write_text(json.dumps({"kernels": {}}))
+    monkeypatch.setattr(bench, "_profile_value", lambda name, key: json.load(open(prof / name)).get(key))
+    ok = bench._pmc_provenance("profiles/ok.json")
+    assert ok["pmc_matches_sources"] is True and ok["pmc_head"] == "abc123" and ok["run_sources_sha16"] == sha
+    stale = bench._pmc_provenance("profiles/stale.json")
+    assert stale["pmc_matches_sources"] is False and stale["pmc_head"] == "def456"
+    assert bench._pmc_provenance("profiles/old.json")["pmc_matches_sources"] is None
+    assert bench._pmc_provenance(None) == {"pmc_head": None, "pmc_sources_sha16": None, "pmc_matches_sources": None}
+    # every BASELINE configuration has a counter-file slot, newest round first
+    assert set(bench.PMC_FILES) == {1, 2, 4, "animate"} and bench.PMC_FILES[2][0].startswith("r05_")
