@@ -52,11 +52,27 @@ struct NrcDev {
     NrcLevel levels[kHashLevels];
 };
 
-GFX_DEV uint32_t to_bf16_bits(float x) {            // round to nearest even
-    const uint32_t u = f2bits(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+// fp32 -> bf16, round to nearest even: gfx950's v_cvt_pk_bf16_f32 converts two values per instruction (the integer form
+// (u + 0x7FFF + lsb) >> 16 costs four per value; same bits for every finite input, NaNs stay NaNs).
+typedef float NrcF2 __attribute__((ext_vector_type(2)));
+typedef __bf16 NrcBf2 __attribute__((ext_vector_type(2)));
+GFX_DEV uint32_t pack_bf16x2(float lo, float hi) {
+    const NrcF2 v = { lo, hi };
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, NrcBf2));
 }
+GFX_DEV uint32_t to_bf16_bits(float x) { return pack_bf16x2(x, 0.0f) & 0xFFFFu; }
 GFX_DEV float from_bf16_bits(uint32_t b) { return bits2f(b << 16); }
+GFX_DEV float bf16_lo(uint32_t pair) { return bits2f(pair << 16); }
+GFX_DEV float bf16_hi(uint32_t pair) { return bits2f(pair & 0xFFFF0000u); }
+// The level's two features of one query: trilinear blend of the 8 corner entries (bf16 pairs), fused multiply-adds in corner order.
+GFX_DEV void blend_corners(const uint32_t e[8], const float w[8], float& a0, float& a1) {
+    a0 = w[0] * bf16_lo(e[0]); a1 = w[0] * bf16_hi(e[0]);
+#pragma unroll
+    for (int c = 1; c < 8; ++c) {
+        a0 = __builtin_fmaf(w[c], bf16_lo(e[c]), a0);
+        a1 = __builtin_fmaf(w[c], bf16_hi(e[c]), a1);
+    }
+}
 GFX_HOSTDEV inline int nrc_feature_of_slot(int s, int h, int i) { return 16 * s + 8 * (i >> 2) + 4 * h + (i & 3); }
 
 // ---------------------------------------------------------------- weight packing
@@ -98,7 +114,7 @@ __global__ void k_nrc_pack(NrcDev d, const float* __restrict__ params, uint16_t*
         const uint32_t entries = (d.total - d.gridOff) / 2;
         for (uint32_t e = t; e < entries; e += gridDim.x * blockDim.x) {
             const float a = params[d.gridOff + 2 * e], b = params[d.gridOff + 2 * e + 1];
-            gridOut[e] = to_bf16_bits(a) | (to_bf16_bits(b) << 16);
+            gridOut[e] = pack_bf16x2(a, b);
         }
     }
 }
@@ -111,13 +127,27 @@ GFX_DEV float quartic_cdf(float x, float invRadius) {
     const float v = (15.0f / 16.0f) * u * (1 - (2.0f / 3.0f) * u2 + (1.0f / 5.0f) * u4) + 0.5f;
     return fmin2(fmax2(v, 0.0f), 1.0f);
 }
+// One-blob encoding, 4 bins, quartic kernel of radius 1/4, wrapped: cdf(b) = Q(b/4 - x) + Q(b/4 - x - 1) + Q(b/4 - x + 1), feature b = cdf(b + 1) - cdf(b).
+// For x in [0, 1] -- every encoded input is: normalised direction angles, roughness -- ten of the fifteen kernel integrals sit on the
+// clamp: Q(b/4 - x - 1) is 0 unless b = 4, where it is Q(-x); Q(b/4 - x + 1) is 1 unless b = 0, where it is Q(1 - x).  A lane in range takes
+// the five-integral form, a lane out of range (NaN included) the fifteen-integral form -- a branch no lane of a wave normally enters; a
+// query's features do not depend on the queries it shares a wave with.  The two forms agree to 2.4e-7 (the polynomial reaches the clamp to
+// within an ulp of 1/2, not exactly), four orders of magnitude under the bf16 rounding of the features.
 GFX_DEV void oneblob4(float x, float out[4]) {
+    float q[5], below[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, above[5] = { 0.0f, 1.0f, 1.0f, 1.0f, 1.0f };
+#pragma unroll
+    for (int b = 0; b <= 4; ++b) q[b] = quartic_cdf(b * 0.25f - x, 4.0f);
+    below[4] = q[0]; above[0] = q[4];
+    if (!(x >= 0.0f && x <= 1.0f)) {
+#pragma unroll
+        for (int b = 0; b <= 4; ++b) {
+            const float left = b * 0.25f;
+            below[b] = quartic_cdf(left - x - 1.0f, 4.0f); above[b] = quartic_cdf(left - x + 1.0f, 4.0f);
+        }
+    }
     float cdf[5];
 #pragma unroll
-    for (int b = 0; b <= 4; ++b) {
-        const float left = b * 0.25f;
-        cdf[b] = quartic_cdf(left - x, 4.0f) + quartic_cdf(left - x - 1.0f, 4.0f) + quartic_cdf(left - x + 1.0f, 4.0f);
-    }
+    for (int b = 0; b <= 4; ++b) cdf[b] = q[b] + below[b] + above[b];
 #pragma unroll
     for (int b = 0; b < 4; ++b) out[b] = cdf[b + 1] - cdf[b];
 }
@@ -208,13 +238,7 @@ GFX_DEV void encode_half(const NrcDev& d, const uint32_t* __restrict__ grid, con
                 uint32_t idx[8]; float w[8]; uint32_t e[8];
                 grid_corners(lv, x[0], x[1], x[2], idx, w);
                 gather_corners(grid, idx, e);
-                float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    a0 = a0 + w[c] * from_bf16_bits(e[c] & 0xFFFFu);
-                    a1 = a1 + w[c] * from_bf16_bits(e[c] >> 16);
-                }
-                v[2 * k] = a0; v[2 * k + 1] = a1;
+                blend_corners(e, w, v[2 * k], v[2 * k + 1]);
             }
         }
         else encode_plain_group(d.posEnc == 1 ? 32 : 3 * kTriFreqs, x, f0, v);
@@ -225,10 +249,10 @@ GFX_DEV void encode_half(const NrcDev& d, const uint32_t* __restrict__ grid, con
 
 GFX_DEV uint4 pack8(const float v[8]) {
     uint4 r;
-    r.x = to_bf16_bits(v[0]) | (to_bf16_bits(v[1]) << 16);
-    r.y = to_bf16_bits(v[2]) | (to_bf16_bits(v[3]) << 16);
-    r.z = to_bf16_bits(v[4]) | (to_bf16_bits(v[5]) << 16);
-    r.w = to_bf16_bits(v[6]) | (to_bf16_bits(v[7]) << 16);
+    r.x = pack_bf16x2(v[0], v[1]);
+    r.y = pack_bf16x2(v[2], v[3]);
+    r.z = pack_bf16x2(v[4], v[5]);
+    r.w = pack_bf16x2(v[6], v[7]);
     return r;
 }
 GFX_DEV void unpack8(uint4 p, float v[8]) {
@@ -345,7 +369,7 @@ __global__ __launch_bounds__(kInferBlock) __attribute__((amdgpu_waves_per_eu(GFX
 // k_nrc_infer above gathers 128 four-byte table entries per query through the vector-memory path: 270 M L1 fills of a 64-byte sector
 // each per full-HD batch, 0.89 TCP requests per CU and clock -- that, not the matrix pipe (MFMA busy 3 %), is what it runs at
 // (profiles/r04_nrc_pmc.txt).  A level's table is at most 2^15 entries x (2 x bf16) = 128 KiB and a CU has 160 KiB of LDS, so a large
-// batch is encoded level-synchronously instead: one persistent 8-wave block per CU; per pass it owns 8 x kStagedTiles tiles of 64
+// batch is encoded level-synchronously instead: one persistent 12-wave block per CU; per pass it owns 12 x kStagedTiles tiles of 64
 // queries; for each of the 16 levels the block copies the level's table into LDS with global->LDS DMA (coalesced, 2 MB of L2 reads per
 // pass and CU) and every lane computes the level's two features of ONE query of each of its wave's tiles -- eight ds_read_b32 per
 // corner set, no L1 fill, no 64-byte sector per 4-byte corner -- packs them to the bf16 pair the MFMA operand wants and hands the
@@ -355,38 +379,74 @@ __global__ __launch_bounds__(kInferBlock) __attribute__((amdgpu_waves_per_eu(GFX
 // k_nrc_infer's body per tile: one-blob / identity features, the layers, the output.  Per query the same operations in the same order as
 // k_nrc_infer: the outputs are bit-equal (tests/test_gpu_nrc_net.py).  Small batches (the training tiles' suffix queries) keep k_nrc_infer:
 // a pass costs 2 MB of table copies whatever it encodes.
-constexpr int kStagedBlock = 512;                        // 8 waves, 2 per SIMD
-constexpr int kStagedTiles = 8;                          // tiles per wave and pass: 8 x 8 x 64 = 4 096 queries per pass and CU
+// Waves per SIMD against queries per pass (the operand registers of a pass are the budget; a pass pays 16 table copies of ~2 us whatever it
+// encodes): 8 waves x 8 tiles 0.340 ms per 2.1 M queries, 12 x 5 0.327 (42 spilled registers), 12 x 4 0.277, 16 x 3 0.272 (50 spilled),
+// 16 x 4 0.358 (90 spilled), 4 x 16 0.522 (profiles/r05_experiments.txt 4): both phases wait on latencies that two waves per SIMD do not cover.
+#ifndef GFX_NRC_STAGED_BLOCK
+#define GFX_NRC_STAGED_BLOCK 768    // 12 waves, 3 per SIMD (170 registers each)
+#define GFX_NRC_STAGED_TILES 4      // tiles per wave and pass: 12 x 4 x 64 = 3 072 queries per pass and CU
+#endif
+constexpr int kStagedBlock = GFX_NRC_STAGED_BLOCK;
+constexpr int kStagedTiles = GFX_NRC_STAGED_TILES;
 constexpr uint32_t kStagedTableBytes = 4u << kLog2Hashmap;
 GFX_DEV uint32_t staged_word(const uint4& v, int w) { return w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w; }
 GFX_DEV void staged_set_word(uint4& v, int w, uint32_t x) { if (w == 0) v.x = x; else if (w == 1) v.y = x; else if (w == 2) v.z = x; else v.w = x; }
+// Byte offsets into the LDS copy of a level's table + trilinear weights of the 8 corners: grid_corners_t's indices (without the level
+// offset) times four, the weights in its order.  Power-of-two tables only need the low log2(entries) + 2 bits of the scaled index, so the
+// products are 24-bit multiplies by the constant times four (v_mul_u32_u24 is a full-rate instruction, v_mul_lo_u32 a quarter-rate one),
+// nothing is shifted per corner, and the mask merges into the last xor (v_bitop3).
+template <int DENSE, int POW2>
+GFX_DEV void staged_corners(const NrcLevel& lv, float px, float py, float pz, uint32_t off[8], float w[8]) {
+    if (POW2 != 1) {
+        grid_corners_t<DENSE, POW2>(lv, px, py, pz, off, w);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) off[c] <<= 2;
+        return;
+    }
+    const float x = px * lv.scale + 0.5f, y = py * lv.scale + 0.5f, z = pz * lv.scale + 0.5f;
+    const float bx = floorf(x), by = floorf(y), bz = floorf(z);
+    const float fx = x - bx, fy = y - by, fz = z - bz;
+    const uint32_t ix = static_cast<uint32_t>(static_cast<int32_t>(bx));
+    const uint32_t iy = static_cast<uint32_t>(static_cast<int32_t>(by));
+    const uint32_t iz = static_cast<uint32_t>(static_cast<int32_t>(bz));
+    const uint32_t mask = (lv.entries - 1u) << 2;
+    const uint32_t sy = (DENSE == 1 ? lv.res << 2 : 2654435761u << 2) & 0xFFFFFFu;
+    const uint32_t sz = (DENSE == 1 ? (lv.res * lv.res) << 2 : 805459861u << 2) & 0xFFFFFFu;
+    uint32_t tx[2], ty[2], tz[2];
+    tx[0] = ix << 2; tx[1] = tx[0] + 4u;
+    ty[0] = __umul24(iy, sy); ty[1] = ty[0] + sy;
+    tz[0] = __umul24(iz, sz); tz[1] = tz[0] + sz;
+    const float wx[2] = { 1 - fx, fx }, wy[2] = { 1 - fy, fy }, wz[2] = { 1 - fz, fz };
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ox = c & 1, oy = (c >> 1) & 1, oz = (c >> 2) & 1;
+        off[c] = (DENSE == 1 ? tx[ox] + ty[oy] + tz[oz] : tx[ox] ^ ty[oy] ^ tz[oz]) & mask;
+        w[c] = wx[ox] * wy[oy] * wz[oz];
+    }
+}
 // One level for the wave's kStagedTiles tiles: the level's two features of query `lane` of every tile out of the LDS copy of the table,
 // as the bf16 pair of the operand layout, for the lane that owns it (half hL: queries n and 32 + n of the tile).
 template <int DENSE, int POW2>
 GFX_DEV void staged_level(const NrcLevel& lv, const uint32_t* ldsTable, const float (&px)[kStagedTiles], const float (&py)[kStagedTiles], const float (&pz)[kStagedTiles],
-                          int h, int hL, uint32_t (&w0)[kStagedTiles], uint32_t (&w1)[kStagedTiles]) {
+                          int h, int hL, bool lastSlotUsed, uint32_t (&w0)[kStagedTiles], uint32_t (&w1)[kStagedTiles]) {
 #pragma unroll
     for (int t = 0; t < kStagedTiles; ++t) {
-        uint32_t idx[8]; float w[8]; uint32_t e[8];
-        grid_corners_t<DENSE, POW2>(lv, px[t], py[t], pz[t], idx, w);
+        if (t == kStagedTiles - 1 && !lastSlotUsed) continue;             // wave-uniform
+        uint32_t off[8]; float w[8]; uint32_t e[8];
+        staged_corners<DENSE, POW2>(lv, px[t], py[t], pz[t], off, w);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) e[c] = ldsTable[idx[c]];
-        float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            a0 = a0 + w[c] * from_bf16_bits(e[c] & 0xFFFFu);
-            a1 = a1 + w[c] * from_bf16_bits(e[c] >> 16);
-        }
-        const uint32_t mine = to_bf16_bits(a0) | (to_bf16_bits(a1) << 16);       // query `lane` of the tile
-        const uint32_t partner = static_cast<uint32_t>(__shfl_xor(static_cast<int>(mine), 32));   // query `lane ^ 32`
-        if (h == hL) {
-            // this lane owns queries n (tile half 0: computed by lane n) and 32 + n (half 1: computed by lane 32 + n)
-            w0[t] = h ? partner : mine;
-            w1[t] = h ? mine : partner;
-        }
+        for (int c = 0; c < 8; ++c) e[c] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ldsTable) + off[c]);
+        float a0, a1;
+        blend_corners(e, w, a0, a1);
+        // query `lane` of the tile holds the pair; the lane that owns it in the operand layout is lane n of the tile's half: queries n
+        // (computed by lane n) and 32 + n (computed by lane 32 + n).  v_permlane32_swap: first = {lanes 0 .. 31 their own, lanes 32 .. 63 that
+        // of lane - 32} = query n for (n, h); second = {lanes 0 .. 31 that of lane + 32, lanes 32 .. 63 their own} = query 32 + n
+        const uint32_t mine = pack_bf16x2(a0, a1);
+        const auto both = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+        if (h == hL) { w0[t] = both[0]; w1[t] = both[1]; }
     }
 }
-__global__ __launch_bounds__(kStagedBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(kStagedBlock) __attribute__((amdgpu_waves_per_eu(kStagedBlock / 256, kStagedBlock / 256)))
 void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_t* __restrict__ grid, const float* __restrict__ inputs,
                         uint32_t numDataArg, const uint32_t* __restrict__ numDataPtr, float* __restrict__ predictions) {
     extern __shared__ __attribute__((aligned(16))) uint4 ldsAll[];         // kStagedTableBytes: a level's table, then weights + staging
@@ -394,18 +454,25 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t numTiles = (numData + 63) / 64;
-    constexpr uint32_t kTilesPerPass = (kStagedBlock / 64) * kStagedTiles;
-    const uint32_t numPasses = (numTiles + kTilesPerPass - 1) / kTilesPerPass;
+    // Passes of equal size: the batch is cut into gridDim.x x rounds passes of `passTiles` <= 12 x kStagedTiles tiles (a batch of 2.1 M
+    // queries: 3 rounds of 43 tiles on every CU instead of 3 rounds of 48 on 181 CUs and 2 on the rest); inside a pass tile k belongs to
+    // wave k mod 12, slot k / 12, so only a wave's last slot can be empty.
+    constexpr uint32_t kWaves = kStagedBlock / 64, kTilesPerPass = kWaves * kStagedTiles;
+    const uint32_t rounds = (numTiles + gridDim.x * kTilesPerPass - 1) / (gridDim.x * kTilesPerPass);
+    const uint32_t numPasses = gridDim.x * rounds;
+    const uint32_t passTiles = (numTiles + numPasses - 1) / numPasses;
     const uint32_t fwdElems = d.numHidden * kMatFwdElems + kOutFwdElems;
     const uint32_t* ldsTable = reinterpret_cast<const uint32_t*>(ldsAll);
-    for (uint32_t pass = blockIdx.x; pass < numPasses; pass += gridDim.x) {
-        const uint32_t tile0 = pass * kTilesPerPass + wave * kStagedTiles;
+    for (uint32_t pass = blockIdx.x; pass < numPasses && pass * passTiles < numTiles; pass += gridDim.x) {
+        const uint32_t tile0 = pass * passTiles + wave, tileEnd = min((pass + 1) * passTiles, numTiles);   // slot t: tile0 + t * kWaves
+        const bool lastSlotUsed = tile0 + (kStagedTiles - 1) * kWaves < tileEnd;                              // wave-uniform
         // the position of query `lane` of each tile (inputs are [14] per query: three strided loads)
         float px[kStagedTiles], py[kStagedTiles], pz[kStagedTiles];
 #pragma unroll
         for (int t = 0; t < kStagedTiles; ++t) {
-            const size_t col = static_cast<size_t>(tile0 + t) * 64 + lane;
-            const bool ok = col < numData;
+            const uint32_t tile = tile0 + t * kWaves;
+            const size_t col = static_cast<size_t>(tile) * 64 + lane;
+            const bool ok = tile < tileEnd && col < numData;
             px[t] = ok ? inputs[col * kNrcIn] : 0.0f; py[t] = ok ? inputs[col * kNrcIn + 1] : 0.0f; pz[t] = ok ? inputs[col * kNrcIn + 2] : 0.0f;
         }
         uint4 hb[kStagedTiles][2][2];                       // [tile][nt][s]: K steps 0 and 1 of the B operand = the 16 hash-grid features of this half
@@ -442,9 +509,9 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
                 // (the kind of the level decides the index arithmetic once for all queries: a mask for the power-of-two tables of the
                 // reference's configuration, hashed or dense; anything else takes the general form)
                 const bool dense = static_cast<unsigned long long>(lv.res) * lv.res * lv.res <= lv.entries, pow2 = (lv.entries & (lv.entries - 1)) == 0;
-                if (pow2 && !dense) staged_level<0, 1>(lv, ldsTable, px, py, pz, h, hL, w0, w1);
-                else if (pow2) staged_level<1, 1>(lv, ldsTable, px, py, pz, h, hL, w0, w1);
-                else staged_level<-1, -1>(lv, ldsTable, px, py, pz, h, hL, w0, w1);
+                if (pow2 && !dense) staged_level<0, 1>(lv, ldsTable, px, py, pz, h, hL, lastSlotUsed, w0, w1);
+                else if (pow2) staged_level<1, 1>(lv, ldsTable, px, py, pz, h, hL, lastSlotUsed, w0, w1);
+                else staged_level<-1, -1>(lv, ldsTable, px, py, pz, h, hL, lastSlotUsed, w0, w1);
             }
             switch (pos) {                                  // block-uniform
 #define GFX_STAGED_CASE(P) case P: _Pragma("unroll") for (int t = 0; t < kStagedTiles; ++t) { \
@@ -461,8 +528,8 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
         const uint4* ldsW = ldsAll;
         float* ldsX = reinterpret_cast<float*>(ldsAll + fwdElems / 8) + wave * (64 * kNrcIn);
         for (int t = 0; t < kStagedTiles; ++t) {           // not unrolled: the tile in turn is hb[0], the others move up behind it
-            const uint32_t tile = tile0 + t;
-            if (tile < numTiles) {                          // wave-uniform
+            const uint32_t tile = tile0 + t * kWaves;
+            if (tile < tileEnd) {                           // wave-uniform
             {
                 const size_t base = static_cast<size_t>(tile) * 64 * kNrcIn;
                 const size_t limit = static_cast<size_t>(numData) * kNrcIn;
@@ -1076,7 +1143,7 @@ void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     const int numCUs = ctx.numCUs;
     const uint32_t numTiles = numData / 64;
     // A large hash-grid batch is encoded level by level out of LDS copies of the level tables (k_nrc_infer_staged): worth it when every CU
-    // gets at least one pass of 4 096 queries ("nrc_staged_infer": 0 by batch size, 1 never, 2 always)
+    // gets at least one pass of 3 072 queries ("nrc_staged_infer": 0 by batch size, 1 never, 2 always)
     const uint32_t stagedPasses = (numTiles + (kStagedBlock / 64) * kStagedTiles - 1) / ((kStagedBlock / 64) * kStagedTiles);
     const bool staged = net->d.posEnc == 1 && ctx.tune.nrcStagedInfer != 1 && (ctx.tune.nrcStagedInfer == 2 || stagedPasses >= static_cast<uint32_t>(numCUs));
     if (staged) {

@@ -533,7 +533,7 @@ int gfx_timing_collect(gfx_ctx* ctx, char names[][48], float* totalMs, uint32_t*
  *                               pixel's candidates round robin and the reservoir is formed as the sequential loop forms it; 0 (default)
  *                               = by launch size: 4 when the launch fills the GPU's wave slots at most ~1.5 times (a row band of an
  *                               8-way split frame), else 1 (GFX_CANDIDATE_SPLIT)
- *   "nrc_staged_infer" 0|1|2    gfx_nrc_infer with the hash-grid encoding: 0 (default) a batch that gives every CU at least one pass of 4 096 queries is
+ *   "nrc_staged_infer" 0|1|2    gfx_nrc_infer with the hash-grid encoding: 0 (default) a batch that gives every CU at least one pass of 3 072 queries is
  *                               encoded level by level out of LDS copies of the level tables (one persistent block per CU; same predictions bit for
  *                               bit), smaller batches gather from the tables in place; 1 never, 2 always (GFX_NRC_STAGED_INFER)
  * The same knobs are read once from the environment by gfx_ctx_create (GFX_PIXEL_MAP, GFX_SUPER_X, GFX_SUPER_Y,

@@ -152,6 +152,14 @@ def test_border_window_of_the_full_frame_matches_the_oracle(built_lib, where):
         _window_of_the_full_frame("configs[2]: biased", "textured", inner=BORDER_WINDOWS[where](), workload_window=False)
 
 
+@pytest.mark.parametrize("config", ["configs[2]: biased", "configs[4]: unbiased + 2048x1024 environment map"])
+def test_every_pixel_of_the_full_frame_matches_the_oracle(built_lib, config):
+    """No window: all 2 073 600 pixels of two frames of the bench workload (the textured street), every buffer after every
+    pass.  The oracle renders a pass over its host's cores (OpenMP over pixels); on the 128-thread GPU box a frame of it
+    takes a few seconds, which is what ReGIR's whole-frame comparison already relies on."""
+    _window_of_the_full_frame(config, "textured", inner=(0, 0, W, H), frames=2)
+
+
 def _animation(frame):
     """bench.py --animate: the reference command line's moving rectangle light (restir_di_main.cpp:7-12) at 60 frames per second and
     the slowly orbiting camera, as bench.py applies them before frame `frame`."""
@@ -214,6 +222,8 @@ def _window_of_the_full_frame(config, workload, inner=None, frames=2, animated=F
     accel = ctx.accel_build()
     ctx.lights_build_static()
     osc = util.feed_oracle(hs)
+    if (inner[2] - inner[0]) * (inner[3] - inner[1]) > 256 * 256:
+        osc.set_threads(osc.L.orc_max_threads())   # a whole frame: every host thread (the results do not depend on the count)
     cam = api.make_camera(W, H, **CAM)
     ocam = util.copy_struct(O.GfxCamera, cam)
     pb_init, pb_cpu = util.PixelBuffers(W, H), util.PixelBuffers(W, H)
