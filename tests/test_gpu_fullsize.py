@@ -1,8 +1,11 @@
-"""-m gpu: BASELINE configs[2] at its full size (1920x1080, the 2.5 M-triangle street stand-in of bench.py).
+"""-m gpu: the BASELINE configurations at their full size (1920x1080, the 2.5 M-triangle street stand-in of bench.py).
 
-The CPU oracle cannot render the whole frame in seconds, so parity at this size is established by
-  * an oracle run restricted to a window of the frame (plus the margin the reuse passes read), compared
-    bit for bit with the same pixels of the full-frame GPU run after every pass of two frames, and
+Parity at this size is established by
+  * whole frames (test_every_pixel_*): on the GPU box's 128 host threads the oracle renders a 1920x1080 pass in seconds, so
+    every pixel of every buffer is compared after every pass of two (animated: three) frames for configs[2], configs[4], the
+    animated workload, the rearchitected set, the path tracer and the NRC render side (textured street);
+  * an oracle run restricted to a window of the frame (plus the margin the reuse passes read), compared bit for bit with the
+    same pixels of the full-frame GPU run after every pass -- the other workloads (plain, cluttered), 3840x2160, border windows;
   * properties that do not depend on the size: run-to-run determinism (ray-queue slots are handed out by
     atomics in a different order every run), pipelined == serial frame loop, band split == full frame.
 """
@@ -160,6 +163,13 @@ def test_every_pixel_of_the_full_frame_matches_the_oracle(built_lib, config):
     _window_of_the_full_frame(config, "textured", inner=(0, 0, W, H), frames=2)
 
 
+def test_every_pixel_of_the_animated_full_frame_matches_the_oracle(built_lib):
+    """`bench.py --animate` without a window: the moving rectangle light in the animated subtree (rebuilt every frame on both
+    sides) and the orbiting camera, three frames, every pixel of every buffer after every pass -- temporal reuse through motion
+    vectors, the temporal hint of the traversal and the previous camera, frame-wide."""
+    _window_of_the_full_frame("configs[2]: biased", "textured", inner=(0, 0, W, H), frames=3, animated=True, workload_window=False)
+
+
 def _animation(frame):
     """bench.py --animate: the reference command line's moving rectangle light (restir_di_main.cpp:7-12) at 60 frames per second and
     the slowly orbiting camera, as bench.py applies them before frame `frame`."""
@@ -212,7 +222,8 @@ def _window_of_the_full_frame(config, workload, inner=None, frames=2, animated=F
     light_slot = None
     if animated:
         light_slot = hs.add_instance(hs.add_rectangle(1.5, 1.5, (60, 60, 60)), _animation(0)[0])
-        inner = _window_lit_by_the_moving_light(hs, light_slot)
+        if inner is None:
+            inner = _window_lit_by_the_moving_light(hs, light_slot)
     if inner is None:
         inner = _choose_window(workload, hs)
     ctx = api.Context(0)
@@ -295,7 +306,7 @@ def _window_of_the_full_frame(config, workload, inner=None, frames=2, animated=F
             b = np.ascontiguousarray(_pick(want[key], mask, n)).view(np.uint8)
             if not np.array_equal(a, b):
                 diffs.append(f"frame {frame}: {key}: {np.count_nonzero(a != b)} bytes differ inside the window")
-        if animated and frame > 0:
+        if animated and frame > 0 and inner != (0, 0, W, H):
             # the margins assume |motion vector| <= `motion` inside the region the oracle rendered; and the window does see motion
             big = grow(inner, pads[frame])
             mv = np.nan_to_num(np.asarray(pb_cpu.gb1[frame % 2]).view(np.float32).reshape(H, W, 2)[big[1]:big[3], big[0]:big[2]])
@@ -307,7 +318,7 @@ def _window_of_the_full_frame(config, workload, inner=None, frames=2, animated=F
     if workload_window:
         assert beauty.mean() > 1e-4                                  # the window is lit, not background
         _assert_window_shows_the_workload(workload, hs, pb_cpu.gb0[(frames - 1) % 2], pb_cpu.gb3[(frames - 1) % 2], inner)
-    if animated:
+    if animated and inner != (0, 0, W, H):
         # the moving light lights the window (60 W/m2 sr over 1.5 x 1.5 m, a few metres above the ground)
         assert beauty.mean() > 1e-2, "the window is not lit by the moving light"
         gb0 = pb_cpu.gb0[(frames - 1) % 2]["instSlot"].reshape(H, W)
@@ -396,13 +407,16 @@ def test_rearchitected_window_of_the_full_frame_matches_the_oracle(built_lib, un
         _rearchitected_window(unbiased, workload)
 
 
-def _rearchitected_window(unbiased, workload):
+def _rearchitected_window(unbiased, workload, whole=False):
     """Rearchitected ReSTIR at 1920x1080 on the bench scene: the 131072 pre-sampled lights are compared in full, the
     per-pixel passes on an 8-aligned window plus a 48-pixel margin (frame 1's temporal and spatiotemporal
-    neighbours lie within 20 pixels of a pixel; frame 0 reads no neighbour)."""
+    neighbours lie within 20 pixels of a pixel; frame 0 reads no neighbour) -- or, `whole`, on every pixel."""
     import torch
     hs = _scene(workload)
-    inner = _choose_window(workload, hs) if workload != "plain" else (896, 560, 976, 600)
+    if whole:
+        inner = (48, 48, W - 48, H - 48)               # region = the frame; `inner` is widened to it below
+    else:
+        inner = _choose_window(workload, hs) if workload != "plain" else (896, 560, 976, 600)
     ctx = api.Context(0)
     hs.upload(ctx)
     accel = ctx.accel_build()
@@ -415,6 +429,8 @@ def _rearchitected_window(unbiased, workload):
     s_gpu, s_cpu = dev.static_params(), pb_cpu.host_static_params()
     stream = torch.cuda.current_stream().cuda_stream
     region = (inner[0] - 48, inner[1] - 48, inner[2] + 48, inner[3] + 48)
+    if whole:
+        inner = region
     mask = _window_mask(*inner)
     n = W * H
     diffs = []
@@ -444,6 +460,32 @@ def _rearchitected_window(unbiased, workload):
             if not np.array_equal(a, b):
                 diffs.append(f"frame {frame}: {key}: {np.count_nonzero(a != b)} bytes differ inside the window")
     assert not diffs, "\n".join(diffs)
+
+
+@pytest.mark.parametrize("unbiased", [False, True])
+def test_every_pixel_of_the_rearchitected_full_frame_matches_the_oracle(built_lib, unbiased):
+    """The rearchitected set without a window: all 2 073 600 pixels of two frames of the textured street."""
+    with util.frame_overrides(enableBumpMapping=1), util.every_host_thread():
+        _rearchitected_window(unbiased, "textured", whole=True)
+
+
+def test_every_pixel_of_the_path_traced_full_frame_matches_the_oracle(built_lib):
+    """The path tracer (max path length 5, jittered) without a window: every pixel of two accumulated frames of the textured
+    street at 1920x1080 -- the big-launch path of k_pt_fused / the wavefront queues."""
+    from tests.test_gpu_pathtrace import run_pt_both
+    with util.frame_overrides(enableBumpMapping=1), util.every_host_thread():
+        diffs = run_pt_both(_scene("textured"), W, H, frames=2, max_len=5, jitter=1, camera=api.make_camera(W, H, **CAM))
+    assert not diffs, "\n".join(diffs[:16])
+
+
+def test_every_pixel_of_the_nrc_full_frame_matches_the_oracle(built_lib):
+    """BASELINE configs[3]'s render side without a window: tile / training-path selection, the NRC path tracer, radiance
+    queries, terminal infos and the training chains (canonical form: the record indices come out of an unordered atomic counter)
+    of two frames of the textured street at 1920x1080, frame 1's adaptive tile size from each side's own frame-0 record count."""
+    from tests.test_gpu_nrc_render import run_nrc_both
+    with util.frame_overrides(enableBumpMapping=1), util.every_host_thread():
+        diffs = run_nrc_both(_scene("textured"), W, H, frames=2, max_len=5, camera=api.make_camera(W, H, **CAM))
+    assert not diffs, "\n".join(diffs[:16])
 
 
 @pytest.mark.parametrize("workload", ["plain", "textured"])

@@ -1,6 +1,7 @@
 """Helpers shared by the tests: build the same scene in the product (gfxexp_amd, through the C ABI)
 and in the CPU oracle, allocate ReSTIR pixel buffers on either side, compare buffers."""
 import ctypes as C
+import contextlib
 import os
 
 import numpy as np
@@ -18,10 +19,26 @@ def to_oracle_material(m):
     return om
 
 
+_oracle_threads_override = [None]
+
+
+@contextlib.contextmanager
+def every_host_thread():
+    """Oracle scenes fed inside the block run their passes on every host thread, whatever the caller asked for (whole frames at
+    1920x1080; the oracle's results do not depend on the thread count -- tests/test_oracle_*.py)."""
+    _oracle_threads_override[0] = "max"
+    try:
+        yield
+    finally:
+        _oracle_threads_override[0] = None
+
+
 def feed_oracle(host_scene, threads=None, brute_force=False, config=None, library=None):
     """Push every array of a HostScene into an OracleScene (same slots, same order).  `library`: another build of the
     oracle sources (O.lib_fast(), bench.py's speed-mode CPU baseline); default = the parity build."""
     osc = O.OracleScene(threads=threads, library=library)
+    if _oracle_threads_override[0] == "max":
+        osc.set_threads(osc.L.orc_max_threads())
     for slot, w, h, fmt, data in host_scene.textures():
         osc.set_texture(slot, w, h, fmt, data)
     for i, m in enumerate(host_scene.materials()):
