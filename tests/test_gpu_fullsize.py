@@ -155,19 +155,22 @@ def test_border_window_of_the_full_frame_matches_the_oracle(built_lib, where):
         _window_of_the_full_frame("configs[2]: biased", "textured", inner=BORDER_WINDOWS[where](), workload_window=False)
 
 
-@pytest.mark.parametrize("config", ["configs[2]: biased", "configs[4]: unbiased + 2048x1024 environment map"])
-def test_every_pixel_of_the_full_frame_matches_the_oracle(built_lib, config):
-    """No window: all 2 073 600 pixels of two frames of the bench workload (the textured street), every buffer after every
-    pass.  The oracle renders a pass over its host's cores (OpenMP over pixels); on the 128-thread GPU box a frame of it
-    takes a few seconds, which is what ReGIR's whole-frame comparison already relies on."""
-    _window_of_the_full_frame(config, "textured", inner=(0, 0, W, H), frames=2)
+@pytest.mark.parametrize("config,workload", [("configs[2]: biased", "textured"), ("configs[2]: biased", "plain"), ("configs[2]: biased", "cluttered"),
+                                             ("configs[4]: unbiased + 2048x1024 environment map", "textured")])
+def test_every_pixel_of_the_full_frame_matches_the_oracle(built_lib, config, workload):
+    """No window: all 2 073 600 pixels of two frames of the bench workloads (the textured street = the default; --plain;
+    --cluttered), every buffer after every pass.  The oracle renders a pass over its host's cores (OpenMP over pixels); on
+    the 128-thread GPU box a frame of it takes a few seconds, which is what ReGIR's whole-frame comparison already relies on."""
+    with util.frame_overrides(enableBumpMapping=WORKLOADS[workload]["bump"]):
+        _window_of_the_full_frame(config, workload, inner=(0, 0, W, H), frames=2)
 
 
 def test_every_pixel_of_the_animated_full_frame_matches_the_oracle(built_lib):
     """`bench.py --animate` without a window: the moving rectangle light in the animated subtree (rebuilt every frame on both
     sides) and the orbiting camera, three frames, every pixel of every buffer after every pass -- temporal reuse through motion
     vectors, the temporal hint of the traversal and the previous camera, frame-wide."""
-    _window_of_the_full_frame("configs[2]: biased", "textured", inner=(0, 0, W, H), frames=3, animated=True, workload_window=False)
+    with util.frame_overrides(enableBumpMapping=1):
+        _window_of_the_full_frame("configs[2]: biased", "textured", inner=(0, 0, W, H), frames=3, animated=True, workload_window=False)
 
 
 def _animation(frame):
