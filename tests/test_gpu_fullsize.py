@@ -235,9 +235,11 @@ def _window_of_the_full_frame(config, workload, inner=None, frames=2, animated=F
         ctx.instance_set_dynamic(light_slot)
     accel = ctx.accel_build()
     ctx.lights_build_static()
-    osc = util.feed_oracle(hs)
     if (inner[2] - inner[0]) * (inner[3] - inner[1]) > 256 * 256:
-        osc.set_threads(osc.L.orc_max_threads())   # a whole frame: every host thread (the results do not depend on the count)
+        with util.every_host_thread():              # a whole frame: every host thread (the results do not depend on the count)
+            osc = util.feed_oracle(hs)
+    else:
+        osc = util.feed_oracle(hs)
     cam = api.make_camera(W, H, **CAM)
     ocam = util.copy_struct(O.GfxCamera, cam)
     pb_init, pb_cpu = util.PixelBuffers(W, H), util.PixelBuffers(W, H)

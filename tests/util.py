@@ -26,6 +26,9 @@ _oracle_threads_override = [None]
 def every_host_thread():
     """Oracle scenes fed inside the block run their passes on every host thread, whatever the caller asked for (whole frames at
     1920x1080; the oracle's results do not depend on the thread count -- tests/test_oracle_*.py)."""
+    import pytest
+    if (os.cpu_count() or 1) < 32:
+        pytest.skip("a whole 1920x1080 frame on the oracle wants a many-core host (the GPU boxes have 128 threads); the window tests cover the same passes")
     _oracle_threads_override[0] = "max"
     try:
         yield
