@@ -393,7 +393,7 @@ GFX_DEV uint32_t staged_word(const uint4& v, int w) { return w == 0 ? v.x : w ==
 GFX_DEV void staged_set_word(uint4& v, int w, uint32_t x) { if (w == 0) v.x = x; else if (w == 1) v.y = x; else if (w == 2) v.z = x; else v.w = x; }
 // Byte offsets into the LDS copy of a level's table + trilinear weights of the 8 corners: grid_corners_t's indices (without the level
 // offset) times four, the weights in its order.  Power-of-two tables only need the low log2(entries) + 2 bits of the scaled index, so the
-// products are 24-bit multiplies by the constant times four (v_mul_u32_u24 is a full-rate instruction, v_mul_lo_u32 a quarter-rate one),
+// products are multiplies by the constant times four (v_mul_u32_u24; v_mul_lo_u32 issues at the same 4.2 cycles on gfx950, valu_rate.hip),
 // nothing is shifted per corner, and the mask merges into the last xor (v_bitop3).
 template <int DENSE, int POW2>
 GFX_DEV void staged_corners(const NrcLevel& lv, float px, float py, float pz, uint32_t off[8], float w[8]) {

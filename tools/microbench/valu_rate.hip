@@ -61,6 +61,20 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b)
         } else if (KIND == 14) {  // v_pk_max_f16 / v_pk_min_f16 / v_pk_fma_f16: a slab test on packed halves
             asm volatile(REP16("v_pk_fma_f16 %1, %4, %5, %6\n v_pk_max_f16 %2, %2, %1\n v_pk_fma_f16 %0, %4, %6, %5\n v_pk_min_f16 %3, %3, %0\n")
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(u), "v"(a), "v"(b));
+        } else if (KIND == 15) {  // 32-bit integer multiplies: the 64-bit LCG step of PCG32 is built from these
+            asm volatile(REP16("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4\n")
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(u));
+        } else if (KIND == 16) {
+            asm volatile(REP16("v_mul_hi_u32 %0, %0, %4\n v_mul_hi_u32 %1, %1, %4\n v_mul_hi_u32 %2, %2, %4\n v_mul_hi_u32 %3, %3, %4\n")
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(u));
+        } else if (KIND == 17) {  // 24-bit multiplies
+            asm volatile(REP16("v_mul_u32_u24 %0, %0, %4\n v_mad_u32_u24 %1, %1, %4, %0\n v_mul_hi_u32_u24 %2, %2, %4\n v_mad_u32_u24 %3, %3, %4, %2\n")
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(u));
+        } else if (KIND == 18) {  // 32 x 32 + 64 -> 64
+            unsigned long long w0 = u, w1 = u + 1, w2 = u + 2, w3 = u + 3;
+            asm volatile(REP16("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3\n")
+                         : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(u), "v"(a) : "vcc");
+            u += (unsigned)(w0 + w1 + w2 + w3);
         }
     }
     out[blockIdx.x * 64 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (float)u;
@@ -104,5 +118,9 @@ int main() {
     run<12>("cvt_f32_f16", d, p.multiProcessorCount, ghz);
     run<13>("fma_max_fma_min", d, p.multiProcessorCount, ghz);
     run<14>("pk_fma_max_min_f16", d, p.multiProcessorCount, ghz);
+    run<15>("mul_lo_u32", d, p.multiProcessorCount, ghz);
+    run<16>("mul_hi_u32", d, p.multiProcessorCount, ghz);
+    run<17>("mul_u32_u24_mad_u32_u24_mul_hi_u32_u24", d, p.multiProcessorCount, ghz);
+    run<18>("mad_u64_u32", d, p.multiProcessorCount, ghz);
     return 0;
 }
