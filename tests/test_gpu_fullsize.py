@@ -3,9 +3,9 @@
 Parity at this size is established by
   * whole frames (test_every_pixel_*): on the GPU box's 128 host threads the oracle renders a 1920x1080 pass in seconds, so
     every pixel of every buffer is compared after every pass of two (animated: three) frames for configs[2], configs[4], the
-    animated workload, the rearchitected set, the path tracer and the NRC render side (textured street);
+    animated workload, the rearchitected set, the path tracer and the NRC render side (textured street), and for a 3840x2160 frame;
   * an oracle run restricted to a window of the frame (plus the margin the reuse passes read), compared bit for bit with the
-    same pixels of the full-frame GPU run after every pass -- the other workloads (plain, cluttered), 3840x2160, border windows;
+    same pixels of the full-frame GPU run after every pass -- configs[4] on the other workloads, border windows, the quick form;
   * properties that do not depend on the size: run-to-run determinism (ray-queue slots are handed out by
     atomics in a different order every run), pipelined == serial frame loop, band split == full frame.
 """
@@ -142,6 +142,17 @@ def test_window_of_a_3840x2160_frame_matches_the_oracle(built_lib, monkeypatch, 
 
 # Windows that are NOT where the workload's defining geometry is: the frame's corner and edges (the reuse margins are clipped by the
 # image there, launch slots of padded 16 x 16 blocks / XCD supertiles lie next to them) in other supertiles than the chosen window.
+def test_every_pixel_of_a_3840x2160_frame_matches_the_oracle(built_lib, monkeypatch):
+    """Four times BASELINE's pixels without a window: all 8 294 400 pixels of two frames of the textured street (launch sizes,
+    ray-queue capacities and the supertile grid of a 4K frame; the oracle needs ~20 s a frame on 128 threads)."""
+    import sys
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, "W", 3840)
+    monkeypatch.setattr(mod, "H", 2160)
+    with util.frame_overrides(enableBumpMapping=1):
+        _window_of_the_full_frame("configs[2]: biased", "textured", inner=(0, 0, 3840, 2160), frames=2)
+
+
 BORDER_WINDOWS = {"bottom-left corner": lambda: (0, H - 40, 80, H),
                   "right edge": lambda: (W - 80, 600 * H // 1080 // 8 * 8, W, 600 * H // 1080 // 8 * 8 + 40),
                   "top edge, left of centre": lambda: (640 * W // 1920 // 8 * 8, 0, 640 * W // 1920 // 8 * 8 + 80, 40)}
