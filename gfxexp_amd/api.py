@@ -259,10 +259,10 @@ HOST_ABI_SYMBOLS = [
     "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
     "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_band_rows", "gfxh_restir_check_partition", "gfxh_restir_check_bands", "gfxh_balance_bands", "gfxh_restir_frame_program", "gfxh_frame_step_exchange_desc",
     "gfxh_rccl_unique_id", "gfxh_rccl_create", "gfxh_rccl_destroy", "gfxh_rccl_exchange", "gfxh_rccl_last_error", "gfxh_restir_create",
-    "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_build_row_table", "gfxh_env_make_sky", "gfxh_restir_set_env",
+    "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_build_row_table", "gfxh_env_upload", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_outputs_consumed", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
-    "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_outputs_consumed", "gfxh_nrc_set_exchange", "gfxh_nrc_rebuild_accel", "gfxh_nrc_beauty_buffer",
+    "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_outputs_consumed", "gfxh_nrc_set_exchange", "gfxh_nrc_rebuild_accel", "gfxh_nrc_set_env", "gfxh_nrc_beauty_buffer",
     "gfxh_nrc_network", "gfxh_nrc_stats", "gfxh_save_image_sdr", "gfxh_save_image_hdr", "gfxh_tonemap_sdr",
 ]
 
@@ -814,6 +814,11 @@ class NrcRenderer:
     def rebuild_accel(self, stream=0):
         if self.L.gfxh_nrc_rebuild_accel(self.h, C.c_void_p(stream)):
             raise GfxError("gfxh_nrc_rebuild_accel: " + self.L.gfxh_nrc_last_error().decode())
+
+    def set_env(self, texels, w, h, power_coeff=1.0, rotation=0.0):
+        t = np.ascontiguousarray(texels, np.float32)
+        if self.L.gfxh_nrc_set_env(self.h, _p(t), C.c_uint32(w), C.c_uint32(h), C.c_float(power_coeff), C.c_float(rotation)):
+            raise GfxError("gfxh_nrc_set_env: " + self.L.gfxh_nrc_last_error().decode())
 
     def render_frame(self, stream=0, want_loss=False):
         loss = C.c_float(0.0)

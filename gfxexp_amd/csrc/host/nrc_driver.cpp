@@ -39,6 +39,7 @@ struct gfxh_nrc {
     uint64_t accel = 0, network = 0;
     uint32_t frameIndex = 0, numAccumFrames = 0;
     bool viewMoved = false;      // an instance moved since the last frame: accumulation restarts
+    float envPowerCoeff = 1.0f, envRotation = 0.0f;       // gfxh_nrc_set_env
     std::mt19937 perFrameRng{ 72139121 };                  // main:1602
     gfx_camera prevCamera;
     uint32_t lastNumTrainingData = 0, lastTileSize[2] = { 8, 8 }, lastNumInferenceQueries = 0;
@@ -261,8 +262,8 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
     fp.travHandle = r->accel; fp.numAccumFrames = r->numAccumFrames; fp.frameIndex = frameIndex;
     fp.prevCamera = frameIndex == 0 ? cfg.camera : r->prevCamera;
     fp.camera = cfg.camera;
-    fp.envLightPowerCoeff = 1.0f; fp.envLightRotation = 0.0f;
-    fp.bufferIndex = bufferIndex; fp.resetFlowBuffer = newSequence; fp.enableJittering = 0; fp.enableEnvLight = 0; fp.enableBumpMapping = cfg.enableBumpMapping; fp.useSolidAngleSampling = 0;
+    fp.envLightPowerCoeff = r->envPowerCoeff; fp.envLightRotation = r->envRotation;
+    fp.bufferIndex = bufferIndex; fp.resetFlowBuffer = newSequence; fp.enableJittering = 0; fp.enableEnvLight = r->sp.envLightTexture != nullptr; fp.enableBumpMapping = cfg.enableBumpMapping; fp.useSolidAngleSampling = 0;
     r->np.radianceScale = cfg.radianceScale;
     r->np.preprocessOffsetToSelectUnbiasedTile = static_cast<uint32_t>(r->perFrameRng());   // main:2276-2277
     r->np.preprocessOffsetToSelectTrainingPath = static_cast<uint32_t>(r->perFrameRng());
@@ -445,6 +446,19 @@ int gfxh_nrc_rebuild_accel(gfxh_nrc* r, void* stream) {
     return 0;
 }
 void* gfxh_nrc_beauty_buffer(gfxh_nrc* r) { return r->sp.beautyAccumBuffer; }
+int gfxh_nrc_set_env(gfxh_nrc* r, float* texels, uint32_t w, uint32_t h, float powerCoeff, float rotation) {
+    // frames in flight may still read the tables this call replaces: wait for them (the old tables stay allocated until destroy)
+    NRC_HIP(hipDeviceSynchronize());
+    void* allocations[GFXH_ENV_MAX_ALLOCATIONS];
+    uint32_t numAllocations = 0;
+    const int err = gfxh_env_upload(texels, w, h, &r->sp, allocations, &numAllocations);
+    for (uint32_t i = 0; i < numAllocations; ++i) r->allocations.push_back(allocations[i]);
+    if (err) { g_nrcError = std::string("gfxh_env_upload: ") + gfxh_restir_last_error(); return 1; }
+    r->envPowerCoeff = powerCoeff; r->envRotation = rotation;
+    r->viewMoved = true;
+    return 0;
+}
+
 uint64_t gfxh_nrc_network(gfxh_nrc* r) {
     if (r->trainStream) (void)hipStreamSynchronize(r->trainStream);   // whoever asks for the network sees it trained
     return r->network;

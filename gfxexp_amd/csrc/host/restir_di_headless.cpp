@@ -99,6 +99,16 @@ struct Options {
     std::exit(EXIT_FAILURE);
 }
 
+// "-env-texture" (restir_di_main.cpp:1188-1197): a float lat-long image through the scene builder's image loader
+void load_env_texture(const std::string& path, std::vector<float>& texels4, uint32_t& w, uint32_t& h) {
+    gfxh_scene* tmp = gfxh_scene_create();
+    const uint32_t slot = gfxh_scene_load_texture(tmp, path.c_str(), GFX_TEX_RGBA8_SRGB);
+    uint32_t format = 0; const void* texels = nullptr;
+    if (!slot || gfxh_scene_get_texture(tmp, slot, &w, &h, &format, &texels) || format != GFX_TEX_RGBA32F) fail("-env-texture wants a float image (.pfm):", path.c_str());
+    texels4.assign(static_cast<const float*>(texels), static_cast<const float*>(texels) + 4ull * w * h);
+    gfxh_scene_destroy(tmp);
+}
+
 bool apply_rotation(const char* arg, const char* prefix, double deg, Quat* ori) {
     const std::string a = arg, p = prefix;
     int axis;
@@ -338,7 +348,6 @@ int main(int argc, const char* argv[]) {
     if (o.nrc) {
         // neural_radiance_caching_main.cpp: NeuralRadianceCache::initialize(g_positionEncoding, g_numHiddenLayers, g_learningRate)
         // (:1198), the frame loop :2225-2370 behind gfxh_nrc_render_frame
-        if (!o.envTexture.empty()) fail("-env-texture is not wired to the headless NRC renderer", nullptr);
         gfxh_nrc_config cfg;
         gfxh_nrc_default_config(&cfg, o.width, o.height);
         cfg.positionEncoding = o.positionEncoding; cfg.numHiddenLayers = o.numHiddenLayers; cfg.learningRate = o.learningRate;
@@ -351,6 +360,11 @@ int main(int argc, const char* argv[]) {
         for (int k = 0; k < 9; ++k) cfg.camera.orientation[k] = static_cast<float>(camM[k]);
         for (int k = 0; k < 3; ++k) { cfg.sceneAabbMin[k] = bounds[k]; cfg.sceneAabbMax[k] = bounds[3 + k]; }   // scene.initialSceneAabb (:1139)
         if (gfxh_nrc_create(ctx, &cfg, &nrc)) fail("gfxh_nrc_create:", gfxh_nrc_last_error());
+        if (!o.envTexture.empty()) {
+            std::vector<float> env; uint32_t w = 0, h = 0;
+            load_env_texture(o.envTexture, env, w, h);
+            if (gfxh_nrc_set_env(nrc, env.data(), w, h, 1.0f, 0.0f)) fail("gfxh_nrc_set_env:", gfxh_nrc_last_error());
+        }
         float loss = 0.0f;
         for (uint32_t frame = 0; frame < o.frames; ++frame) {
             if (o.animate && frame > 0 && !controllers.empty()) {
@@ -378,13 +392,9 @@ int main(int argc, const char* argv[]) {
     for (int k = 0; k < 3; ++k) { cfg.regirAabbMin[k] = bounds[k]; cfg.regirAabbMax[k] = bounds[3 + k]; }
     if (gfxh_restir_create(ctx, &cfg, &renderer)) fail("gfxh_restir_create:", gfxh_restir_last_error());
     if (!o.envTexture.empty()) {
-        gfxh_scene* tmp = gfxh_scene_create();
-        const uint32_t slot = gfxh_scene_load_texture(tmp, o.envTexture.c_str(), GFX_TEX_RGBA8_SRGB);
-        uint32_t w = 0, h = 0, format = 0; const void* texels = nullptr;
-        if (!slot || gfxh_scene_get_texture(tmp, slot, &w, &h, &format, &texels) || format != GFX_TEX_RGBA32F) fail("-env-texture wants a float image (.pfm):", o.envTexture.c_str());
-        std::vector<float> copy(static_cast<const float*>(texels), static_cast<const float*>(texels) + 4ull * w * h);
-        if (gfxh_restir_set_env(renderer, copy.data(), w, h, 1.0f, 0.0f)) fail("gfxh_restir_set_env:", gfxh_restir_last_error());
-        gfxh_scene_destroy(tmp);
+        std::vector<float> env; uint32_t w = 0, h = 0;
+        load_env_texture(o.envTexture, env, w, h);
+        if (gfxh_restir_set_env(renderer, env.data(), w, h, 1.0f, 0.0f)) fail("gfxh_restir_set_env:", gfxh_restir_last_error());
     }
     for (uint32_t frame = 0; frame < o.frames; ++frame) {
         if (o.animate && frame > 0 && !controllers.empty()) {

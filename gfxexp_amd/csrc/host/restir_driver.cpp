@@ -362,15 +362,18 @@ int gfxh_restir_band_plan(gfxh_restir* r, gfxh_band_plan* out) {
 
 int gfxh_restir_reset(gfxh_restir* r) { r->resetRequested = true; return 0; }
 
-int gfxh_restir_set_env(gfxh_restir* r, float* texels, uint32_t w, uint32_t h, float powerCoeff, float rotation) {
+int gfxh_env_upload(float* texels, uint32_t w, uint32_t h, gfx_restir_static_params* spOut, void** allocations, uint32_t* numAllocations) {
     const size_t n = static_cast<size_t>(w) * h;
     std::vector<float> rowPDF(n), rowCDF(static_cast<size_t>(h) * (w + 1)), rowInt(h), topPDF(h), topCDF(h + 1);
     float topIntegral = 0;
     gfxh_env_build_importance(texels, w, h, rowPDF.data(), rowCDF.data(), rowInt.data(), topPDF.data(), topCDF.data(), &topIntegral);
-    gfx_restir_static_params& sp = r->sp;
+    gfx_restir_static_params& sp = *spOut;
+    *numAllocations = 0;
     auto up = [&](const void** dst, const void* src, size_t bytes) {
         void* p = nullptr;
-        if (alloc_dev(r, &p, bytes, false)) return 1;
+        if (*numAllocations >= GFXH_ENV_MAX_ALLOCATIONS) return 1;
+        if (!hip_ok(hipMalloc(&p, bytes), "hipMalloc (environment map)")) return 1;
+        allocations[(*numAllocations)++] = p;
         if (!hip_ok(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice), "upload env")) return 1;
         *dst = p;
         return 0;
@@ -392,14 +395,23 @@ int gfxh_restir_set_env(gfxh_restir* r, float* texels, uint32_t w, uint32_t h, f
             // (GFX_ENV_ROW_TABLE=0: the separate arrays, for A/B runs)
             const char* e = std::getenv("GFX_ENV_ROW_TABLE");
             if (!(e && e[0] == '0')) {
-            std::vector<uint32_t> table(8 * static_cast<size_t>(h) * (w + 1));
-            gfxh_env_build_row_table(texels, rowPDF.data(), rowCDF.data(), rowGuide.data(), w, h, table.data());
-            err |= up(&sp.envRowTable, table.data(), 4 * table.size());
+                std::vector<uint32_t> table(8 * static_cast<size_t>(h) * (w + 1));
+                gfxh_env_build_row_table(texels, rowPDF.data(), rowCDF.data(), rowGuide.data(), w, h, table.data());
+                err |= up(&sp.envRowTable, table.data(), 4 * table.size());
             }
         }
     }
     if (err) return 1;
     sp.envWidth = static_cast<int32_t>(w); sp.envHeight = static_cast<int32_t>(h); sp.envTopIntegral = topIntegral;
+    return 0;
+}
+
+int gfxh_restir_set_env(gfxh_restir* r, float* texels, uint32_t w, uint32_t h, float powerCoeff, float rotation) {
+    void* allocations[GFXH_ENV_MAX_ALLOCATIONS];
+    uint32_t numAllocations = 0;
+    const int err = gfxh_env_upload(texels, w, h, &r->sp, allocations, &numAllocations);
+    for (uint32_t i = 0; i < numAllocations; ++i) r->allocations.push_back(allocations[i]);   // freed with the renderer
+    if (err) return 1;
     r->envPowerCoeff = powerCoeff; r->envRotation = rotation;
     r->resetRequested = true;
     return 0;

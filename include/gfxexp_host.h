@@ -123,6 +123,12 @@ int gfxh_env_build_guides(const float* rowCDF, const float* topCDF, uint32_t w, 
  * from the (clamped) texels, the conditional PDFs / CDFs and a usable row guide (gfxh_env_build_guides returned 1).  outRecords: 32 x h x
  * (w + 1) bytes.  Same samples as with the separate arrays; a third of the memory traffic per sample. */
 void gfxh_env_build_row_table(const float* texels4, const float* rowPDF, const float* rowCDF, const uint16_t* rowGuide, uint32_t w, uint32_t h, void* outRecords);
+/* The device side of "-env-texture" (restir_di_main.cpp:1188-1197, common_host.cpp:204-357) in one call, for the renderers below and for
+ * callers that fill gfx_restir_static_params themselves: the importance tables, guides and row table of a lat-long float4 map (the three
+ * functions above) are built, map and tables uploaded, and the env* fields of `sp` set.  Synchronous.  The device allocations it made
+ * (at most GFXH_ENV_MAX_ALLOCATIONS, also on failure) are returned for the caller to hipFree once no launch reads `sp` any more. */
+#define GFXH_ENV_MAX_ALLOCATIONS 9
+int gfxh_env_upload(float* texels4, uint32_t w, uint32_t h, gfx_restir_static_params* sp, void** allocations, uint32_t* numAllocations);
 /* Synthetic lat-long sky (gradient + sun disc) used as the stand-in environment map. */
 void gfxh_env_make_sky(uint32_t w, uint32_t h, float sunElevationDeg, float sunAzimuthDeg, float sunRadiance, float* texels4);
 
@@ -376,6 +382,10 @@ int gfxh_nrc_outputs_consumed(gfxh_nrc* r, void* stream);
 int gfxh_nrc_set_exchange(gfxh_nrc* r, gfxh_exchange_fn fn, void* user, int rank);
 /* Scene::updateASs of an animated frame: rebuild the renderer's BVH in place after gfx_instance_set_transform. */
 int gfxh_nrc_rebuild_accel(gfxh_nrc* r, void* stream);
+/* "-env-texture" of the NRC sample (neural_radiance_caching_main.cpp: the same option and loader as restir_di_main.cpp:1188-1197): as
+ * gfxh_restir_set_env.  Paths that leave the scene pick the map up, next-event estimation samples it with probability 0.25; the
+ * accumulation restarts. */
+int gfxh_nrc_set_env(gfxh_nrc* r, float* texels4, uint32_t w, uint32_t h, float powerCoeff, float rotation);
 void* gfxh_nrc_beauty_buffer(gfxh_nrc* r);
 uint64_t gfxh_nrc_network(gfxh_nrc* r);
 int gfxh_nrc_stats(gfxh_nrc* r, uint32_t* numTrainingData, uint32_t tileSize[2], uint32_t* numInferenceQueries);

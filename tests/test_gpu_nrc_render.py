@@ -311,3 +311,50 @@ def test_nrc_render_with_restir_nee_on_the_street_with_env_light(built_lib):
     cam = api.make_camera(96, 64, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0)
     diffs = run_nrc_both(util.small_street(), 96, 64, 2, 5, env=(sky, w, h), camera=cam, restir=True)
     assert not diffs, "\n".join(diffs[:12])
+
+
+@pytest.mark.gpu
+def test_headless_nrc_renderer_with_an_environment_map(built_lib):
+    """gfxh_nrc_set_env ("-env-texture" of the NRC sample): a pixel whose primary ray leaves the scene shows the map exactly as the
+    baseline path tracer's renderer shows it (same bits); with training off and maxPathLength 2 the picture is the first vertex's direct
+    light in both renderers -- area lights + the map, the map sampled with probability 0.25 -- so the accumulated means agree (6 %);
+    and the map adds light."""
+    import torch
+    hs = util.bunny_scene()
+    W, H = 160, 96
+    ew, eh = 256, 128
+    sky = api.env_make_sky(ew, eh)
+    cam = api.make_camera(W, H, pos=(1.5, 5.0, 14.0), pitch=-4.0, yaw=186.0)      # looks up a little: the top rows see the sky
+
+    def image(kind, frames, accumulate, env=True):
+        ctx = api.Context(0)
+        hs.upload(ctx)
+        if kind == "nrc":
+            cfg = api.NrcRenderer.default_config(W, H, hs.bounds())
+            cfg.neeSampler, cfg.train = api.NRC_NEE_LIGHTS, 0
+        else:
+            cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_PATH_TRACE)
+        cfg.camera, cfg.maxPathLength, cfg.enableAccumulation = cam, 2, int(accumulate)
+        r = api.NrcRenderer(ctx, cfg) if kind == "nrc" else api.RestirRenderer(ctx, cfg)
+        if env:
+            r.set_env(sky.copy(), ew, eh, 0.7, 0.3)
+        for _ in range(frames):
+            r.render_frame()
+        if kind == "nrc":
+            r.network()
+        torch.cuda.synchronize()
+        out = ctx.read_device(r.beauty_ptr(), W * H * 16).view(np.float32).reshape(H, W, 4)[..., :3].copy()
+        r.close()
+        ctx.close()
+        return out
+
+    one_nrc, one_pt, one_dark = image("nrc", 1, False), image("pt", 1, False), image("nrc", 1, False, env=False)
+    same = (one_nrc.view(np.uint32) == one_pt.view(np.uint32)).all(axis=-1)
+    lit_by_the_map = same & (one_nrc != one_dark).any(axis=-1)
+    assert lit_by_the_map.sum() > 0.02 * W * H, lit_by_the_map.sum()       # the sky pixels, bit for bit what the path tracer's renderer shows
+    assert lit_by_the_map[: H // 8].mean() > 0.5                              # ... and they are where the sky is
+    mean_nrc, mean_pt, mean_dark = image("nrc", 64, True), image("pt", 64, True), image("nrc", 64, True, env=False)
+    assert np.isfinite(mean_nrc).all()
+    surface = ~lit_by_the_map
+    assert abs(mean_nrc[surface].mean() - mean_pt[surface].mean()) < 0.06 * mean_pt[surface].mean(), (mean_nrc[surface].mean(), mean_pt[surface].mean())
+    assert mean_nrc[surface].mean() > 1.1 * mean_dark[surface].mean(), (mean_nrc[surface].mean(), mean_dark[surface].mean())

@@ -264,3 +264,59 @@ def test_cli_nrc_renderer_matches_the_python_driver(built_lib, tmp_path, encodin
     assert np.isfinite(got3).all()
     assert abs(got3.mean() - want3.mean()) < 0.02 * want3.mean()
     assert not np.array_equal(got3, _read_pfm(out))                    # the cache is being trained: the picture moves
+
+
+def _write_pfm(path, rgb):
+    """rgb: (H, W, 3) float32, top row first (PFM stores bottom-up, little-endian when the scale is negative)."""
+    h, w = rgb.shape[:2]
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
+        f.write(np.ascontiguousarray(rgb[::-1], "<f4").tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("renderer", ["restir-unbiased", "nrc"])
+def test_cli_env_texture(built_lib, tmp_path, renderer):
+    """-env-texture (restir_di_main.cpp:1188-1197; the NRC sample takes the same option): a float lat-long image through the scene
+    builder's loader into gfxh_restir_set_env / gfxh_nrc_set_env.  Frame 0 of the command line is bit-identical to the renderer driven
+    through the bindings with the texels the same loader returns, and differs from the frame without the map."""
+    import torch
+    W, H = 160, 96
+    ew, eh = 128, 64
+    sky = api.env_make_sky(ew, eh).reshape(eh, ew, 4)
+    env_path = str(tmp_path / "sky.pfm")
+    _write_pfm(env_path, sky[..., :3])
+    opts = ["-size", W, H, "-renderer", renderer, "-frames", 1]
+    out, out_dark = str(tmp_path / "env.pfm"), str(tmp_path / "dark.pfm")
+    d = _run(_scene_args() + opts + ["-env-texture", env_path, "-out", out])
+    _run(_scene_args() + opts + ["-out", out_dark])
+
+    tmp = api.HostScene()
+    tmp.load_texture(env_path)
+    (_, w, h, fmt, data), = tmp.textures()
+    assert (w, h, fmt) == (ew, eh, api.TEX_RGBA32F)
+    texels = data.view(np.float32).copy()
+    ctx = api.Context(0)
+    hs = _python_scene()
+    hs.upload(ctx)
+    cam = api.make_camera(W, H, (1.5, 5.0, 14.0))
+    for k in range(9):
+        cam.orientation[k] = d["camera_orientation"][k]
+    if renderer == "nrc":
+        cfg = api.NrcRenderer.default_config(W, H, hs.bounds())
+        cfg.camera = cam
+        r = api.NrcRenderer(ctx, cfg)
+    else:
+        cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_UNBIASED)
+        cfg.camera = cam
+        r = api.RestirRenderer(ctx, cfg)
+    r.set_env(texels, ew, eh, 1.0, 0.0)
+    r.render_frame()
+    if renderer == "nrc":
+        r.network()
+    torch.cuda.synchronize()
+    want = ctx.read_device(r.beauty_ptr(), W * H * 16).view(np.float32).reshape(H, W, 4)[..., :3]
+    got = _read_pfm(out)
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+    assert got.mean() > 1.05 * _read_pfm(out_dark).mean()
+    r.close()
