@@ -291,12 +291,17 @@ bool decode_image(const std::string& path, Image& img, std::string& err) {
         ++at;
         const uint32_t ch = d[1] == 'F' ? 3 : 1;
         if (w > kMaxTextureDim || h > kMaxTextureDim) { err = "image larger than 16384 x 16384: " + path; return false; }
-        if (scale >= 0 || !w || !h || d.size() < at + 4ull * w * h * ch) { err = "unsupported PFM (little-endian only)"; return false; }
+        if (scale == 0 || !w || !h || d.size() < at + 4ull * w * h * ch) { err = "truncated or malformed PFM: " + path; return false; }
+        const bool bigEndian = scale > 0;      // the sign of the scale line is the byte order of the samples
         img.w = w; img.h = h; img.isFloat = true; img.rgba32f.resize(4ull * w * h);
         for (uint32_t y = 0; y < h; ++y)   // PFM rows run bottom to top
             for (uint32_t x = 0; x < w; ++x) {
                 float px[3] = { 0, 0, 0 };
-                std::memcpy(px, d.data() + at + 4ull * ch * (static_cast<size_t>(h - 1 - y) * w + x), 4ull * ch);
+                unsigned char raw[12];
+                std::memcpy(raw, d.data() + at + 4ull * ch * (static_cast<size_t>(h - 1 - y) * w + x), 4ull * ch);
+                if (bigEndian)
+                    for (uint32_t c = 0; c < ch; ++c) { std::swap(raw[4 * c], raw[4 * c + 3]); std::swap(raw[4 * c + 1], raw[4 * c + 2]); }
+                std::memcpy(px, raw, 4ull * ch);
                 float* o = img.rgba32f.data() + 4ull * (static_cast<size_t>(y) * w + x);
                 o[0] = px[0]; o[1] = ch == 3 ? px[1] : px[0]; o[2] = ch == 3 ? px[2] : px[0]; o[3] = 1.0f;
             }

@@ -218,3 +218,101 @@ def test_headers_mips_and_the_way_into_the_host_loader(built_lib, tmp_path):
     (s, w, h, f, texels), = [t for t in hs.textures() if t[0] == slot]
     assert (w, h, f) == (8, 8, api.TEX_RGBA8_UNORM)
     assert np.array_equal(texels.reshape(8, 8, 4), img0)
+
+
+# ---------------------------------------------------------------- PNG
+def _png_chunk(kind, body):
+    import zlib
+    return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+
+
+def _png(rows, w, h, depth, ctype, filters, palette=None, trns=None):
+    """A PNG file from already packed sample rows (bytes per row), the row filters applied here -- the forward direction of the
+    specification's five filters, written independently of the converter's reconstruction."""
+    import zlib
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, channels * depth // 8)
+    out = bytearray()
+    prev = bytes(len(rows[0]))
+    for y, row in enumerate(rows):
+        ft = filters[y % len(filters)]
+        enc = bytearray(len(row))
+        for i, x in enumerate(row):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0:
+                pred = 0
+            elif ft == 1:
+                pred = a
+            elif ft == 2:
+                pred = b
+            elif ft == 3:
+                pred = (a + b) // 2
+            else:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if pa <= pb and pa <= pc else b if pb <= pc else c
+            enc[i] = (x - pred) & 255
+        out += bytes([ft]) + enc
+        prev = row
+    comp = zlib.compress(bytes(out), 6)
+    data = b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        data += _png_chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        data += _png_chunk(b"tRNS", bytes(trns))
+    half = len(comp) // 2                                     # two IDAT chunks: the stream may be split anywhere
+    return data + _png_chunk(b"IDAT", comp[:half]) + _png_chunk(b"IDAT", comp[half:]) + _png_chunk(b"IEND", b"")
+
+
+def test_png_every_colour_type_and_filter():
+    rng = np.random.default_rng(11)
+    w, h = 13, 10
+    filters = [0, 1, 2, 3, 4, 4, 3, 1]
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    # RGBA 8, RGB 8, grey 8, grey + alpha 8
+    img, _ = D.decode_png(_png([bytes(r) for r in rgba.reshape(h, -1)], w, h, 8, 6, filters))
+    assert np.array_equal(img, rgba)
+    img, _ = D.decode_png(_png([bytes(r) for r in rgba[..., :3].reshape(h, -1)], w, h, 8, 2, filters))
+    assert np.array_equal(img[..., :3], rgba[..., :3]) and np.all(img[..., 3] == 255)
+    img, _ = D.decode_png(_png([bytes(r) for r in rgba[..., 0]], w, h, 8, 0, filters))
+    assert np.array_equal(img[..., 0], rgba[..., 0]) and np.array_equal(img[..., 1], img[..., 0]) and np.array_equal(img[..., 2], img[..., 0])
+    img, _ = D.decode_png(_png([bytes(r) for r in rgba[..., :2].reshape(h, -1)], w, h, 8, 4, filters))
+    assert np.array_equal(img[..., 0], rgba[..., 0]) and np.array_equal(img[..., 3], rgba[..., 1])
+    # RGB 16: the high byte of every big-endian sample
+    wide = rng.integers(0, 65536, (h, w, 3), dtype=np.uint16)
+    img, _ = D.decode_png(_png([r.astype(">u2").tobytes() for r in wide.reshape(h, -1)], w, h, 16, 2, filters))
+    assert np.array_equal(img[..., :3], (wide >> 8).astype(np.uint8))
+    # palette, 4 bits per index, with tRNS for the first three entries
+    palette = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, (h, w), dtype=np.uint8)
+    packed = []
+    for r in idx:
+        padded = np.concatenate([r, np.zeros((-len(r)) % 2, np.uint8)])
+        packed.append(bytes((padded[0::2] << 4) | padded[1::2]))
+    img, _ = D.decode_png(_png(packed, w, h, 4, 3, filters, palette=palette.reshape(-1), trns=[0, 128, 200]))
+    assert np.array_equal(img[..., :3], palette[idx])
+    assert np.array_equal(img[..., 3], np.array([0, 128, 200] + [255] * 13, np.uint8)[idx])
+    # grey, 1 bit per pixel
+    bits = rng.integers(0, 2, (h, w), dtype=np.uint8)
+    img, _ = D.decode_png(_png([bytes(np.packbits(r)) for r in bits], w, h, 1, 0, filters))
+    assert np.array_equal(img[..., 0], bits * 255)
+    with pytest.raises(ValueError):
+        D.decode_png(b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 6, 0, 0, 1)) + _png_chunk(b"IEND", b""))   # Adam7
+
+
+def test_png_through_the_converter_and_the_host_loader(tmp_path, built_lib):
+    from gfxexp_amd import api
+    rng = np.random.default_rng(12)
+    w, h = 24, 16
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    src, dst = str(tmp_path / "albedo.png"), str(tmp_path / "albedo.tga")
+    with open(src, "wb") as f:
+        f.write(_png([bytes(r) for r in rgba.reshape(h, -1)], w, h, 8, 6, [4, 1, 3, 2, 0]))
+    assert D.main([src, dst]) == 0
+    s = api.HostScene()
+    slot = s.load_texture(dst, api.TEX_RGBA8_UNORM)
+    (_, tw, th, fmt, data), = [t for t in s.textures() if t[0] == slot]
+    assert (tw, th, fmt) == (w, h, api.TEX_RGBA8_UNORM) and np.array_equal(data.reshape(h, w, 4), rgba)
+    assert D.main(["--dir", str(tmp_path)]) == 0                  # the directory form takes .png as it takes .dds

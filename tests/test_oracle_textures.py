@@ -110,6 +110,8 @@ def _write_images(tmp, rgb, grey, hdr):
         f.write(b"P5 %d %d 255\n" % (w, h) + grey.tobytes())
     with open(os.path.join(tmp, "h.pfm"), "wb") as f:
         f.write(b"PF\n%d %d\n-1.0\n" % (w, h) + hdr[::-1].astype("<f4").tobytes())
+    with open(os.path.join(tmp, "hb.pfm"), "wb") as f:      # a positive scale line: big-endian samples
+        f.write(b"PF\n%d %d\n1.0\n" % (w, h) + hdr[::-1].astype(">f4").tobytes())
     row = (3 * w + 3) & ~3
     with open(os.path.join(tmp, "b.bmp"), "wb") as f:
         f.write(b"BM" + struct.pack("<IHHI", 54 + row * h, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, row * h, 0, 0, 0, 0))
@@ -143,6 +145,9 @@ def test_host_image_decoders_and_mtl_maps(tmp_path, built_lib):
     tw, th, fmt, data = tex[slots["g.pgm"]]
     assert fmt == api.TEX_R8_UNORM and np.array_equal(data.reshape(h, w), grey)
     tw, th, fmt, data = tex[slots["h.pfm"]]
+    assert fmt == api.TEX_RGBA32F and np.array_equal(data.view(F).reshape(h, w, 4)[..., :3], hdr)
+    big = s.load_texture(os.path.join(tmp, "hb.pfm"), api.TEX_RGBA8_SRGB)
+    _, tw, th, fmt, data = [t for t in s.textures() if t[0] == big][0]
     assert fmt == api.TEX_RGBA32F and np.array_equal(data.view(F).reshape(h, w, 4)[..., :3], hdr)
     with pytest.raises(api.GfxError):
         s.load_texture(os.path.join(tmp, "missing.png"))

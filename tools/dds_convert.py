@@ -9,11 +9,16 @@ are decoded once, offline: BC1, BC2, BC3 (RGBA), BC4 (one channel), BC5 (two cha
 Output by extension: .tga (RGBA8, what `gfxh_scene_load_texture` reads with alpha), .ppm (RGB8), .pgm (first channel).
 sRGB variants decode to the same bytes (the loader applies the sRGB table according to how the material uses the texture).
 
-    python tools/dds_convert.py in.dds out.tga [--mip 0] [--dir DIR: convert every .dds under DIR next to itself as .tga]
+    python tools/dds_convert.py in.dds out.tga [--mip 0] [--dir DIR: convert every .dds / .png under DIR next to itself as .tga]
+
+PNG (the other format the reference's assets use, read there through stb_image / assimp: common/common_host.cpp:1246-1313) converts the
+same way: `python tools/dds_convert.py in.png out.tga`.  Non-interlaced files of every colour type (grey, RGB, palette with tRNS,
+grey + alpha, RGBA) and bit depth (1 / 2 / 4 / 8 / 16: 16-bit samples keep their high byte); zlib comes with Python.
 """
 import os
 import struct
 import sys
+import zlib
 
 import numpy as np
 
@@ -238,6 +243,105 @@ def decode(data, mip=0):
     return _blocks_to_image(tex, w, h), fmt
 
 
+def decode_png(data):
+    """(H, W, 4) uint8 RGBA of a non-interlaced PNG file (PNG specification, ISO/IEC 15948: chunks, the five row filters, the colour types)."""
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG file")
+    at, idat, palette, trns, ihdr = 8, [], None, None, None
+    while at + 8 <= len(data):
+        n, kind = struct.unpack_from(">I4s", data, at)
+        body = data[at + 8:at + 8 + n]
+        at += 12 + n
+        if kind == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif kind == b"PLTE":
+            palette = np.frombuffer(body, np.uint8).reshape(-1, 3)
+        elif kind == b"tRNS":
+            trns = np.frombuffer(body, np.uint8)
+        elif kind == b"IDAT":
+            idat.append(body)
+        elif kind == b"IEND":
+            break
+    if ihdr is None:
+        raise ValueError("PNG without IHDR")
+    w, h, depth, ctype, _, _, interlace = ihdr
+    if interlace:
+        raise ValueError("interlaced PNG is not handled")
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}.get(ctype)
+    if channels is None or depth not in (1, 2, 4, 8, 16) or (ctype == 3 and palette is None):
+        raise ValueError("PNG colour type %d / depth %d is not handled" % (ctype, depth))
+    bpp = max(1, channels * depth // 8)                      # filter distance in bytes
+    stride = (w * channels * depth + 7) // 8
+    raw = zlib.decompress(b"".join(idat))
+    if len(raw) < h * (stride + 1):
+        raise ValueError("truncated PNG data")
+    rows = np.zeros((h, stride), np.uint8)
+    prev = bytearray(stride)
+    for y in range(h):
+        ft = raw[y * (stride + 1)]
+        cur = bytearray(raw[y * (stride + 1) + 1:(y + 1) * (stride + 1)])
+        if ft == 1:                                             # Sub
+            for i in range(bpp, stride):
+                cur[i] = (cur[i] + cur[i - bpp]) & 255
+        elif ft == 2:                                           # Up
+            cur = bytearray(((np.frombuffer(bytes(cur), np.uint8).astype(np.uint16) + np.frombuffer(bytes(prev), np.uint8)) & 255).astype(np.uint8).tobytes())
+        elif ft == 3:                                           # Average
+            for i in range(stride):
+                left = cur[i - bpp] if i >= bpp else 0
+                cur[i] = (cur[i] + ((left + prev[i]) >> 1)) & 255
+        elif ft == 4:                                           # Paeth
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                cur[i] = (cur[i] + (a if pa <= pb and pa <= pc else b if pb <= pc else c)) & 255
+        elif ft != 0:
+            raise ValueError("PNG row filter %d does not exist" % ft)
+        rows[y] = np.frombuffer(bytes(cur), np.uint8)
+        prev = cur
+    if depth == 16:
+        samples = rows.reshape(h, w * channels, 2)[:, :, 0]     # big-endian: the high byte
+    elif depth == 8:
+        samples = rows
+    else:                                                       # 1 / 2 / 4 bits, most significant first
+        bits = np.unpackbits(rows, axis=1)[:, :w * channels * depth].reshape(h, w * channels, depth)
+        samples = (bits * (1 << np.arange(depth - 1, -1, -1, dtype=np.uint16))).sum(-1).astype(np.uint16)
+        if ctype != 3:
+            samples = samples * 255 // ((1 << depth) - 1)       # grey levels scale to 0 .. 255
+        samples = samples.astype(np.uint8)
+    samples = samples.reshape(h, w, channels)
+    img = np.full((h, w, 4), 255, np.uint8)
+    if ctype == 0:
+        img[..., :3] = samples
+        if trns is not None and len(trns) >= 2 and depth <= 8:
+            img[..., 3] = np.where(samples[..., 0] == (int(trns[1]) * 255 // ((1 << depth) - 1) if depth < 8 else trns[1]), 0, 255)
+    elif ctype == 2:
+        img[..., :3] = samples
+        if trns is not None and len(trns) >= 6 and depth == 8:
+            img[..., 3] = np.where((samples == trns[1:6:2]).all(-1), 0, 255)
+    elif ctype == 3:
+        idx = samples[..., 0].astype(np.int64)
+        if idx.max(initial=0) >= len(palette):
+            raise ValueError("PNG palette index out of range")
+        img[..., :3] = palette[idx]
+        if trns is not None:
+            alpha = np.full(len(palette), 255, np.uint8)
+            alpha[:len(trns)] = trns[:len(palette)]
+            img[..., 3] = alpha[idx]
+    elif ctype == 4:
+        img[..., :3] = samples[..., :1]
+        img[..., 3] = samples[..., 1]
+    else:
+        img[...] = samples
+    return img, "PNG %d-bit colour type %d" % (depth, ctype)
+
+
+def decode_any(data, mip=0):
+    return decode_png(data) if data[:4] == b"\x89PNG" else decode(data, mip)
+
+
 def write_image(path, img):
     h, w = img.shape[:2]
     ext = os.path.splitext(path)[1].lower()
@@ -259,10 +363,10 @@ def main(argv):
         root = argv[argv.index("--dir") + 1]
         for dp, _, fns in os.walk(root):
             for fn in sorted(fns):
-                if fn.lower().endswith(".dds"):
+                if fn.lower().endswith((".dds", ".png")):
                     src = os.path.join(dp, fn)
                     try:
-                        img, fmt = decode(open(src, "rb").read(), mip)
+                        img, fmt = decode_any(open(src, "rb").read(), mip)
                         write_image(os.path.splitext(src)[0] + ".tga", img)
                         print("%s: %s %dx%d" % (src, fmt, img.shape[1], img.shape[0]))
                     except ValueError as e:
@@ -271,7 +375,7 @@ def main(argv):
     if len(argv) < 2:
         print(__doc__)
         return 1
-    img, fmt = decode(open(argv[0], "rb").read(), mip)
+    img, fmt = decode_any(open(argv[0], "rb").read(), mip)
     write_image(argv[1], img)
     print("%s: %s %dx%d -> %s" % (argv[0], fmt, img.shape[1], img.shape[0], argv[1]))
     return 0
