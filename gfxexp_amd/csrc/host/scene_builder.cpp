@@ -540,6 +540,36 @@ static uint32_t load_obj_impl(gfxh_scene* s, const char* path, int simplePbr) {
                 g.t.push_back(vi);
             }
         }
+        // aiProcess_CalcTangentSpace (common_host.cpp:2163, 2346-2368: texCoord0Dir = aiMesh->mTangents when the mesh has texture
+        // coordinates, the frame built from the normal otherwise): the tangent of a vertex is the direction in which u grows, dP/du of
+        // its triangles -- (e1 dv2 - e2 dv1) / (du1 dv2 - du2 dv1), unchanged by the v flip above --, summed over the triangles that
+        // share the vertex, made orthogonal to the normal.  Triangles without texture coordinates or with a degenerate mapping
+        // contribute nothing; a vertex nothing contributed to keeps the frame built from its normal.
+        {
+            std::vector<V3> sum(g.v.size(), V3{ 0, 0, 0 });
+            for (size_t f = 0; f + 2 < cs.size(); f += 3) {
+                if (cs[f].t < 0 || cs[f + 1].t < 0 || cs[f + 2].t < 0) continue;
+                const uint32_t i0 = g.t[f], i1 = g.t[f + 1], i2 = g.t[f + 2];
+                const V3 e1 = pos[cs[f + 1].v] - pos[cs[f].v], e2 = pos[cs[f + 2].v] - pos[cs[f].v];
+                const double du1 = static_cast<double>(uv[cs[f + 1].t].first) - uv[cs[f].t].first, du2 = static_cast<double>(uv[cs[f + 2].t].first) - uv[cs[f].t].first;
+                const double dv1 = -(static_cast<double>(uv[cs[f + 1].t].second) - uv[cs[f].t].second), dv2 = -(static_cast<double>(uv[cs[f + 2].t].second) - uv[cs[f].t].second);
+                const double det = du1 * dv2 - du2 * dv1;
+                if (!(std::fabs(det) > 1e-20)) continue;
+                V3 t = { static_cast<float>((e1.x * dv2 - e2.x * dv1) / det), static_cast<float>((e1.y * dv2 - e2.y * dv1) / det), static_cast<float>((e1.z * dv2 - e2.z * dv1) / det) };
+                const float len = std::sqrt(t.x * t.x + t.y * t.y + t.z * t.z);
+                if (!(len > 0.0f) || !std::isfinite(len)) continue;
+                t = { t.x / len, t.y / len, t.z / len };
+                for (uint32_t i : { i0, i1, i2 }) sum[i] = sum[i] + t;
+            }
+            for (size_t i = 0; i < g.v.size(); ++i) {
+                const V3 n = { g.v[i].normal[0], g.v[i].normal[1], g.v[i].normal[2] };
+                const float d = sum[i].x * n.x + sum[i].y * n.y + sum[i].z * n.z;
+                const V3 t = { sum[i].x - n.x * d, sum[i].y - n.y * d, sum[i].z - n.z * d };
+                const float len = std::sqrt(t.x * t.x + t.y * t.y + t.z * t.z);
+                if (!(len > 1e-6f) || !std::isfinite(len)) continue;
+                g.v[i].texCoord0Dir[0] = t.x / len; g.v[i].texCoord0Dir[1] = t.y / len; g.v[i].texCoord0Dir[2] = t.z / len;
+            }
+        }
         s->geoms.push_back(std::move(g));
         geomSlots.push_back(static_cast<uint32_t>(s->geoms.size() - 1));
     }

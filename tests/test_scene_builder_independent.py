@@ -178,3 +178,61 @@ def test_simple_pbr_convention(built_lib, synthetic):
     assert m.bsdfType == 2
     np.testing.assert_allclose(list(m.a), [srgb_immediate(0.2)] * 3, rtol=2e-6)
     np.testing.assert_allclose(list(m.b), [int(255 * np.float32(x)) / 255.0 for x in (0.9, 0.6, 0.3)], rtol=1e-6)
+
+
+def test_tangents_follow_the_texture_coordinates(built_lib, tmp_path):
+    """aiProcess_CalcTangentSpace (common_host.cpp:2163, 2346-2368): a vertex with texture coordinates carries dP/du as texCoord0Dir --
+    the axis a normal map's red channel tilts the normal along -- not the frame made up from the normal.  Planar quads whose u axis
+    runs along +x, along +z and along -x (mirrored), and one without texture coordinates, which keeps the made-up frame."""
+    quads = {"u_along_x": [(0, 0), (1, 0), (1, 1), (0, 1)], "u_along_z": [(0, 0), (0, 1), (1, 1), (1, 0)], "u_mirrored": [(1, 0), (0, 0), (0, 1), (1, 1)]}
+    want = {"u_along_x": (1, 0, 0), "u_along_z": (0, 0, 1), "u_mirrored": (-1, 0, 0)}
+    lines, nv, nt = ["vn 0 1 0"], 0, 0
+    for k, (name, uvs) in enumerate(quads.items()):
+        x0 = 3.0 * k
+        for (x, z) in [(0, 0), (2, 0), (2, 2), (0, 2)]:
+            lines.append("v %g 0 %g" % (x0 + x, z))
+        for (u, v) in uvs:
+            lines.append("vt %g %g" % (u, v))
+        lines.append("usemtl " + name)
+        # counter-clockwise seen from +y: (0,0) (0,2) (2,2) (2,0) -> corners 1 4 3 2
+        lines.append("f %d/%d/1 %d/%d/1 %d/%d/1 %d/%d/1" % (nv + 1, nt + 1, nv + 4, nt + 4, nv + 3, nt + 3, nv + 2, nt + 2))
+        nv += 4; nt += 4
+    for (x, z) in [(20, 0), (22, 0), (22, 2), (20, 2)]:
+        lines.append("v %g 0 %g" % (x, z))
+    lines += ["usemtl no_uv", "f %d//1 %d//1 %d//1 %d//1" % (nv + 1, nv + 4, nv + 3, nv + 2)]
+    p = tmp_path / "quads.obj"
+    p.write_text("\n".join(lines) + "\n")
+    hs = api.HostScene()
+    hs.load_obj(str(p))
+    geoms = hs.geoms()
+    assert len(geoms) == 4
+    for gi, name in enumerate(list(quads) + ["no_uv"]):
+        v, t, _ = geoms[gi]
+        tt = v["texCoord0Dir"].astype(np.float64)
+        assert np.abs(np.linalg.norm(tt, axis=1) - 1).max() < 1e-6 and np.abs(tt[:, 1]).max() < 1e-6      # unit, in the quad's plane
+        if name in want:
+            assert np.abs(tt - np.asarray(want[name], np.float64)).max() < 1e-6, (name, tt)
+    # a curved mesh with texture coordinates: the vertex tangents lie on the side of their triangles' dP/du
+    path = os.path.join(ASSETS, "teapot.obj")
+    order, mats, _ = read_obj(path)
+    hs = api.HostScene()
+    hs.load_obj(path)
+    checked = agree = 0
+    for gi, name in enumerate(order):
+        v, t, _ = hs.geoms()[gi]
+        P, T, N = expected_soup(mats[name])
+        if T is None or not np.isfinite(np.asarray(T, np.float64)).all():
+            continue
+        P3, T3 = np.asarray(P, np.float64).reshape(-1, 3, 3), np.asarray(T, np.float64).reshape(-1, 3, 2)
+        e1, e2 = P3[:, 1] - P3[:, 0], P3[:, 2] - P3[:, 0]
+        d1, d2 = T3[:, 1] - T3[:, 0], T3[:, 2] - T3[:, 0]
+        det = d1[:, 0] * d2[:, 1] - d2[:, 0] * d1[:, 1]
+        ok = np.abs(det) > 1e-12
+        dpdu = (e1 * d2[:, 1:2] - e2 * d1[:, 1:2]) / np.where(ok, det, 1.0)[:, None]
+        tri = np.asarray(t, np.int64).reshape(-1, 3)
+        tt = v["texCoord0Dir"].astype(np.float64)
+        for k in range(3):
+            dots = (tt[tri[ok, k]] * dpdu[ok]).sum(1)
+            checked += len(dots); agree += int((dots > 0).sum())
+    if checked:
+        assert agree > 0.9 * checked, (agree, checked)
