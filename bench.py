@@ -209,13 +209,25 @@ def main():
         raise SystemExit(f"--config {args.config} is a single-GPU configuration in BASELINE.json")
     if world > 1 and args.animate and args.exchange == "rccl":
         raise SystemExit("--animate --gpus N runs over the torch.distributed exchange (--exchange torch)")
+    # GFX_BENCH_ONE_GPU=1: every rank on device 0, collectives staged through host memory over gloo (tilesplit.HostStaged) -- a functional
+    # check of the multi-rank frame loop on a one-GPU box (RCCL refuses two ranks on a device); its numbers mean nothing
+    one_gpu = world > 1 and os.environ.get("GFX_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            from gfxexp_amd import tilesplit
+            if args.exchange == "rccl":
+                raise SystemExit("GFX_BENCH_ONE_GPU=1 runs over the torch.distributed exchange (--exchange torch)")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist = tilesplit.HostStaged(dist)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     result = run_config(args, rank, local_rank, world, dist)
     # Every other BASELINE configuration under the same clock as the headline (the driver runs this file once): a short run of each after
     # the headline measurement, reported inside the one line.  The headline's own fields are untouched.
@@ -416,7 +428,7 @@ def run_config(args, rank, local_rank, world, dist):
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32" if args.config != 3 else "f32 path tracing + bf16 MFMA network (fp32 accumulate, fp32 master weights)", "data": "synthetic",
         "config": {"workload": workload,
-                   "width": W, "height": H, "spp": 1, "parallelism": f"row-bands x{world}" if world > 1 else "single GPU",
+                   "width": W, "height": H, "spp": 1, "parallelism": (f"row-bands x{world}" + (" on ONE device, host-staged gloo (GFX_BENCH_ONE_GPU: a functional check, not a measurement)" if os.environ.get("GFX_BENCH_ONE_GPU") == "1" else "")) if world > 1 else "single GPU",
                    "bands": bands,
                    "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]} if accel_stats else None,
                    "light_table": ctx.lights_table_info()},

@@ -263,6 +263,79 @@ class StripExchange:
                 frame[rs * row_bytes:re * row_bytes].copy_(recv[r * slab:r * slab + (re - rs) * row_bytes])
 
 
+class HostStaged:
+    """torch.distributed (gloo) with every CUDA tensor staged through host memory, behind the handful of calls StripExchange and
+    bench.py make.  RCCL refuses two ranks on one device, so this is how the multi-rank frame loop (band partition, cost balancing,
+    strip exchange between the passes, band gather, max-over-ranks timing) is exercised end to end on a ONE-GPU box:
+    `GFX_BENCH_ONE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` puts every rank on device 0.
+    A functional check (tests/test_gpu_strip_exchange.py), not a transport to measure: every call drains the device first."""
+
+    class _Op:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Done:
+        def wait(self):
+            pass
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def isend(self, *a, **k):      # only ever used as tags of P2POp
+        raise NotImplementedError
+
+    def irecv(self, *a, **k):
+        raise NotImplementedError
+
+    def P2POp(self, op, tensor, peer):
+        return HostStaged._Op("send" if op == self.isend else "recv", tensor, peer)
+
+    def batch_isend_irecv(self, ops):
+        import torch
+        torch.cuda.synchronize()
+        pending = []
+        for o in ops:
+            if o.op == "send":
+                h = o.tensor.cpu()
+                pending.append((self._d.isend(h, o.peer), None, h))
+            else:
+                h = torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
+                pending.append((self._d.irecv(h, o.peer), o.tensor, h))
+
+        class _Req:
+            def wait(self_inner):
+                for work, dst, h in pending:
+                    work.wait()
+                    if dst is not None:
+                        dst.copy_(h)
+        return [_Req()]
+
+    def all_reduce(self, t, op=None, async_op=False):
+        h = t.cpu()
+        self._d.all_reduce(h, op=op if op is not None else self.ReduceOp.SUM)
+        t.copy_(h)
+        return HostStaged._Done()
+
+    def all_gather_into_tensor(self, out, inp, async_op=False):
+        import torch
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        self._d.all_gather_into_tensor(ho, inp.cpu())
+        out.copy_(ho)
+        return HostStaged._Done()
+
+    def broadcast(self, t, src=0):
+        h = t.cpu()
+        self._d.broadcast(h, src=src)
+        t.copy_(h)
+
+    def barrier(self):
+        self._d.barrier()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+
 def host_view(ptr, nbytes):
     """Flat uint8 torch tensor over host memory at `ptr` (the oracle's numpy buffers in the CPU tests)."""
     import ctypes

@@ -302,3 +302,29 @@ def test_cpp_rccl_callback_drives_a_band_renderer(built_lib):
     finally:
         torch.cuda.synchronize()
         L.gfxh_rccl_destroy(comm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [[], ["--config", "4"], ["--animate"]])
+def test_bench_frame_loop_with_two_ranks_on_one_gpu(built_lib, flags):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on a one-GPU box: GFX_BENCH_ONE_GPU=1
+    puts both ranks on device 0 and stages the collectives through host memory over gloo (tilesplit.HostStaged; RCCL refuses two ranks
+    on a device).  Everything else is the multi-GPU path: band partition, the cost-balancing rounds that re-create the band renderers,
+    strip exchange between the passes, asynchronous band gather + finish(), barrier / max-over-ranks timing, one JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GFX_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    port = 29600 + (os.getpid() + len(flags) * 7) % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--mse-ref-spp", "0", "--cpu-sample", "0"] + flags
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints, rank 1 does not
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["ms_per_step"] > 0
+    assert "row-bands x2" in d["config"]["parallelism"] and d["config"]["bands"] is not None and len(d["config"]["bands"]) == 2
+    assert d["config"]["bands"][0][0] == 0 and d["config"]["bands"][0][1] == d["config"]["bands"][1][0] and d["config"]["bands"][1][1] == d["config"]["height"]
