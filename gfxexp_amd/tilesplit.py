@@ -293,7 +293,8 @@ class HostStaged:
 
     def batch_isend_irecv(self, ops):
         import torch
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         pending = []
         for o in ops:
             if o.op == "send":

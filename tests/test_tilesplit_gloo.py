@@ -191,10 +191,12 @@ def _state(r):
     return out
 
 
-def _strip_worker(rank, world, port, out_dir, case_names, custom_bands=None):
+def _strip_worker(rank, world, port, out_dir, case_names, custom_bands=None, host_staged=False):
     import torch.distributed as dist
     from gfxexp_amd import tilesplit
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    if host_staged:        # the adapter bench.py's GFX_BENCH_ONE_GPU mode puts between StripExchange and gloo
+        dist = tilesplit.HostStaged(dist)
     height = HEIGHTS[world]
     band = custom_bands[rank] if custom_bands else tilesplit.band_for_rank(height, world, rank)
     for case in STRIP_CASES:
@@ -211,13 +213,13 @@ def _strip_worker(rank, world, port, out_dir, case_names, custom_bands=None):
     dist.destroy_process_group()
 
 
-def _spawn_strip_runs(world, case_names, custom_bands=None):
+def _spawn_strip_runs(world, case_names, custom_bands=None, host_staged=False):
     import torch.multiprocessing as mp
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_strip_worker, args=(world, port, out_dir, case_names, custom_bands), nprocs=world, join=True)
+        mp.spawn(_strip_worker, args=(world, port, out_dir, case_names, custom_bands, host_staged), nprocs=world, join=True)
         return {(c, r): dict(np.load(os.path.join(out_dir, f"{c}_{r}.npz"))) for c in case_names for r in range(world)}
 
 
@@ -256,6 +258,18 @@ def test_three_rank_strip_exchange_with_unequal_bands_is_bit_exact(strip_runs_wo
 # a partition that is not the default one (what gfxh_balance_bands hands bench.py): the short band first
 CUSTOM_BANDS_WORLD3 = [(0, 16), (16, 40), (40, 56)]
 CUSTOM_CASES = ["biased_moving", "rearch_unbiased_moving"]
+
+
+@pytest.fixture(scope="module")
+def strip_runs_host_staged(built_lib):
+    return _spawn_strip_runs(3, WORLD4_CASES, host_staged=True)
+
+
+@pytest.mark.parametrize("case", [c for c in STRIP_CASES if c[0] in WORLD4_CASES], ids=WORLD4_CASES)
+def test_three_rank_strip_exchange_through_the_host_staged_adapter(strip_runs_host_staged, case):
+    """tilesplit.HostStaged (the transport of `GFX_BENCH_ONE_GPU=1 bench.py --gpus N`, N ranks on one device) between StripExchange
+    and gloo: the same frames as the direct transport -- strips, the counter all-reduce, synchronous and asynchronous band gathers."""
+    _check_strip_runs(strip_runs_host_staged, case, 3)
 
 
 @pytest.fixture(scope="module")
