@@ -300,6 +300,12 @@ def test_png_every_colour_type_and_filter():
     assert np.array_equal(img[..., 0], bits * 255)
     with pytest.raises(ValueError):
         D.decode_png(b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 6, 0, 0, 1)) + _png_chunk(b"IEND", b""))   # Adam7
+    good = _png([bytes(r) for r in rgba.reshape(h, -1)], w, h, 8, 6, filters)
+    at = good.index(b"IDAT") + 12
+    with pytest.raises(ValueError):
+        D.decode_png(good[:at] + bytes(8) + good[at + 8:])                  # a damaged deflate stream is a ValueError, not a crash of --dir
+    with pytest.raises(ValueError):
+        D.decode_png(good[:40])                                             # truncated after the header: no image data
 
 
 def test_png_through_the_converter_and_the_host_loader(tmp_path, built_lib):

@@ -272,7 +272,10 @@ def decode_png(data):
         raise ValueError("PNG colour type %d / depth %d is not handled" % (ctype, depth))
     bpp = max(1, channels * depth // 8)                      # filter distance in bytes
     stride = (w * channels * depth + 7) // 8
-    raw = zlib.decompress(b"".join(idat))
+    try:
+        raw = zlib.decompress(b"".join(idat))
+    except zlib.error as e:
+        raise ValueError("corrupt PNG data (%s)" % e)
     if len(raw) < h * (stride + 1):
         raise ValueError("truncated PNG data")
     rows = np.zeros((h, stride), np.uint8)
