@@ -67,19 +67,17 @@ PMC_FILES = {2: ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json"), 1: ("r05_pmc_c
 
 
 def sources_sha16():
-    """A hash of the kernel sources this run's library was built from (gfxexp_amd/csrc: *.hip, *.h, *.cpp, sorted by path): the committed
+    """A hash of the kernel sources this run's library was built from (gfxexp_amd/csrc/*.hip and *.h, sorted by name): the committed
     counter files carry the same hash of the tree they were measured on (profiles/make_pmc_json.py), so a counter file that no longer
     belongs to the kernels shows in the line (`pmc_matches_sources`)."""
     import hashlib
     h = hashlib.sha256()
     root = os.path.join(ROOT, "gfxexp_amd", "csrc")
-    for dp, dn, fns in sorted(os.walk(root)):
-        dn.sort()
-        for fn in sorted(fns):
-            if fn.endswith((".hip", ".h", ".cpp")):
-                h.update(os.path.relpath(os.path.join(dp, fn), root).encode())
-                with open(os.path.join(dp, fn), "rb") as f:
-                    h.update(f.read())
+    for fn in sorted(os.listdir(root)):          # the kernels and the headers they include; not capi.cpp / scene.cpp / host/ (host code)
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            with open(os.path.join(root, fn), "rb") as f:
+                h.update(f.read())
     return h.hexdigest()[:16]
 
 

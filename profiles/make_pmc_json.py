@@ -31,13 +31,11 @@ def sources_sha16():
     import os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gfxexp_amd", "csrc")
     h = hashlib.sha256()
-    for dp, dn, fns in sorted(os.walk(root)):
-        dn.sort()
-        for fn in sorted(fns):
-            if fn.endswith((".hip", ".h", ".cpp")):
-                h.update(os.path.relpath(os.path.join(dp, fn), root).encode())
-                with open(os.path.join(dp, fn), "rb") as f:
-                    h.update(f.read())
+    for fn in sorted(os.listdir(root)):          # the kernels and the headers they include; not capi.cpp / scene.cpp / host/ (host code)
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            with open(os.path.join(root, fn), "rb") as f:
+                h.update(f.read())
     return h.hexdigest()[:16]
 
 
