@@ -11,7 +11,7 @@
 //       -frames 64 -size 1920 1080 -out frame.exr
 //
 // Scene options (same names, same arity, same accumulate-until-"-inst" state machine as parseCommandline):
-//   -cam-pos x y z   -cam-roll|-cam-pitch|-cam-yaw deg   -brightness b   -env-texture file.pfm
+//   -cam-pos x y z   -cam-roll|-cam-pitch|-cam-yaw deg   -brightness b   -env-texture file.exr|.pfm
 //   -name n   -emittance r g b   -rect-emitter-tex file   -obj path preScale trad|simple_pbr   -rectangle dimX dimZ
 //   -begin-pos|-end-pos x y z   -begin-roll|pitch|yaw  -end-roll|pitch|yaw deg   -begin-scale|-end-scale s   -freq f   -time t
 //   -inst n
@@ -24,7 +24,7 @@
 //   and, headless: -max-path-length n (5; 0 = unlimited, :1860-1861)   -no-train   -log10-radiance-scale s (0, :2240)
 //   -nee lights|regir|restir (lights): next-event estimation from the emitter distributions (the reference), from the ReGIR grid, or --
 //        at the first path vertex -- from the pixel's ReSTIR DI reservoir (the two halves of README.md:80-81)
-// Textures are read by the host decoders of scene_builder.cpp (PPM / PGM / PFM / BMP / TGA); DDS / PNG / JPEG assets have to be
+// Textures are read by the host decoders of scene_builder.cpp (PPM / PGM / PFM / BMP / TGA, OpenEXR); DDS / PNG / JPEG assets have to be
 // decoded offline (the image has no image libraries).
 #include <cmath>
 #include <cstdio>
@@ -104,7 +104,7 @@ void load_env_texture(const std::string& path, std::vector<float>& texels4, uint
     gfxh_scene* tmp = gfxh_scene_create();
     const uint32_t slot = gfxh_scene_load_texture(tmp, path.c_str(), GFX_TEX_RGBA8_SRGB);
     uint32_t format = 0; const void* texels = nullptr;
-    if (!slot || gfxh_scene_get_texture(tmp, slot, &w, &h, &format, &texels) || format != GFX_TEX_RGBA32F) fail("-env-texture wants a float image (.pfm):", path.c_str());
+    if (!slot || gfxh_scene_get_texture(tmp, slot, &w, &h, &format, &texels) || format != GFX_TEX_RGBA32F) fail("-env-texture wants a float image (.exr as the reference reads it, or .pfm):", path.c_str());
     texels4.assign(static_cast<const float*>(texels), static_cast<const float*>(texels) + 4ull * w * h);
     gfxh_scene_destroy(tmp);
 }

@@ -259,11 +259,254 @@ bool pnm_token(const std::vector<uint8_t>& d, size_t& at, std::string& tok) {
     while (at < d.size() && !std::isspace(d[at])) tok.push_back(static_cast<char>(d[at++]));
     return !tok.empty();
 }
-// Uncompressed formats only (no third-party decoders in this build): binary PPM / PGM (8 bit), PFM, BMP 24 / 32 bit,
-// TGA types 2 / 3 (24 / 32 / 8 bit).  BC-compressed DDS files of the original assets are decoded offline.
+// ---- OpenEXR (the format the reference reads "-env-texture" from: loadEnvTexture -> tinyexr LoadEXR, common_host.cpp:2674): single-part
+// scanline files, channels R G B A (or Y) stored as HALF / FLOAT / UINT, compression NONE, RLE, ZIPS, ZIP -- what OpenEXR's own tools and
+// most exporters write by default besides PIZ, which this reader names and refuses.  The file layout follows the OpenEXR file-layout
+// document (magic, version, attribute list, chunk offset table, chunks of 1 / 16 scanlines each stored channel by channel in
+// alphabetical order); ZIP / RLE chunks are a zlib stream (RFC 1950 / 1951, inflated below) or run lengths over the chunk's bytes
+// after a byte-delta predictor and an even / odd byte split.
+struct BitReader {
+    const uint8_t* p; size_t n, at = 0; uint32_t acc = 0; int have = 0; bool bad = false;
+    uint32_t bits(int k) {
+        while (have < k) { if (at >= n) { bad = true; return 0; } acc |= static_cast<uint32_t>(p[at++]) << have; have += 8; }
+        const uint32_t v = acc & ((k == 32) ? 0xFFFFFFFFu : ((1u << k) - 1u));
+        acc = k >= 32 ? 0 : acc >> k; have -= k;
+        return v;
+    }
+};
+struct Huffman { uint16_t count[16]; uint16_t symbol[288]; };
+void build_huffman(Huffman& h, const uint8_t* lengths, int n) {
+    std::memset(h.count, 0, sizeof(h.count));
+    for (int i = 0; i < n; ++i) ++h.count[lengths[i]];
+    h.count[0] = 0;
+    uint16_t offs[16]; offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = static_cast<uint16_t>(offs[l] + h.count[l]);
+    for (int i = 0; i < n; ++i) if (lengths[i]) h.symbol[offs[lengths[i]]++] = static_cast<uint16_t>(i);
+}
+int decode_symbol(BitReader& br, const Huffman& h) {       // canonical code, one bit at a time (RFC 1951 3.2.2)
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code |= static_cast<int>(br.bits(1));
+        if (br.bad) return -1;
+        const int count = h.count[len];
+        if (code - count < first) return h.symbol[index + (code - first)];
+        index += count; first += count; first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+// zlib stream -> exactly `want` bytes; false on any malformed input
+bool inflate_zlib(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t want) {
+    static const uint16_t lenBase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+    static const uint16_t lenExtra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+    static const uint16_t distBase[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+    static const uint16_t distExtra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+    if (n < 2 || (src[0] & 0x0F) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) return false;
+    BitReader br{ src + 2, n - 2 };
+    out.clear(); out.reserve(want);
+    for (bool last = false; !last;) {
+        last = br.bits(1) != 0;
+        const uint32_t type = br.bits(2);
+        if (br.bad) return false;
+        if (type == 0) {
+            br.acc = 0; br.have = 0;                                   // to the next byte boundary
+            if (br.at + 4 > br.n) return false;
+            const uint32_t len = br.p[br.at] | (br.p[br.at + 1] << 8), nlen = br.p[br.at + 2] | (br.p[br.at + 3] << 8);
+            br.at += 4;
+            if ((len ^ 0xFFFFu) != nlen || br.at + len > br.n || out.size() + len > want) return false;
+            out.insert(out.end(), br.p + br.at, br.p + br.at + len);
+            br.at += len;
+            continue;
+        }
+        if (type == 3) return false;
+        Huffman lit, dist;
+        uint8_t lengths[320];
+        if (type == 1) {
+            for (int i = 0; i < 144; ++i) lengths[i] = 8;
+            for (int i = 144; i < 256; ++i) lengths[i] = 9;
+            for (int i = 256; i < 280; ++i) lengths[i] = 7;
+            for (int i = 280; i < 288; ++i) lengths[i] = 8;
+            build_huffman(lit, lengths, 288);
+            for (int i = 0; i < 30; ++i) lengths[i] = 5;
+            build_huffman(dist, lengths, 30);
+        }
+        else {
+            static const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+            const int nlen = static_cast<int>(br.bits(5)) + 257, ndist = static_cast<int>(br.bits(5)) + 1, ncode = static_cast<int>(br.bits(4)) + 4;
+            if (br.bad || nlen > 286 || ndist > 30) return false;
+            uint8_t cl[19] = { 0 };
+            for (int i = 0; i < ncode; ++i) cl[order[i]] = static_cast<uint8_t>(br.bits(3));
+            Huffman lc;
+            build_huffman(lc, cl, 19);
+            int i = 0;
+            while (i < nlen + ndist) {
+                const int sym = decode_symbol(br, lc);
+                if (sym < 0) return false;
+                if (sym < 16) { lengths[i++] = static_cast<uint8_t>(sym); continue; }
+                int rep, val = 0;
+                if (sym == 16) { if (i == 0) return false; val = lengths[i - 1]; rep = 3 + static_cast<int>(br.bits(2)); }
+                else if (sym == 17) rep = 3 + static_cast<int>(br.bits(3));
+                else rep = 11 + static_cast<int>(br.bits(7));
+                if (br.bad || i + rep > nlen + ndist) return false;
+                while (rep--) lengths[i++] = static_cast<uint8_t>(val);
+            }
+            if (lengths[256] == 0) return false;
+            build_huffman(lit, lengths, nlen);
+            build_huffman(dist, lengths + nlen, ndist);
+        }
+        for (;;) {
+            const int sym = decode_symbol(br, lit);
+            if (sym < 0) return false;
+            if (sym < 256) { if (out.size() >= want) return false; out.push_back(static_cast<uint8_t>(sym)); continue; }
+            if (sym == 256) break;
+            if (sym > 285) return false;
+            const uint32_t len = lenBase[sym - 257] + br.bits(lenExtra[sym - 257]);
+            const int ds = decode_symbol(br, dist);
+            if (ds < 0 || ds > 29) return false;
+            const uint32_t d = distBase[ds] + br.bits(distExtra[ds]);
+            if (br.bad || d > out.size() || out.size() + len > want) return false;
+            for (uint32_t k = 0; k < len; ++k) out.push_back(out[out.size() - d]);
+        }
+    }
+    return out.size() == want;
+}
+inline float half_to_float(uint16_t h) {
+    const uint32_t sign = static_cast<uint32_t>(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else { int shift = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; ++shift; } bits = sign | ((113u - shift) << 23) | ((mm & 0x3FFu) << 13); }
+    }
+    else if (e == 31) bits = sign | 0x7F800000u | (m << 13);
+    else bits = sign | ((e + 112u) << 23) | (m << 13);
+    float f; std::memcpy(&f, &bits, 4);
+    return f;
+}
+bool decode_exr(const std::vector<uint8_t>& d, const std::string& path, Image& img, std::string& err) {
+    auto fail = [&](const std::string& what) { err = "EXR: " + what + ": " + path; return false; };
+    size_t at = 8;
+    const uint32_t version = d[4] | (d[5] << 8) | (d[6] << 16) | (static_cast<uint32_t>(d[7]) << 24);
+    if ((version & 0xFFu) != 2u) return fail("unknown file version");
+    if (version & 0x1A00u) return fail("tiled, deep and multi-part files are not read (single-part scanline only)");
+    struct Channel { std::string name; int type; };
+    std::vector<Channel> channels;
+    int compression = -1;
+    int32_t win[4] = { 0, 0, -1, -1 };
+    bool haveWindow = false;
+    auto rd_i32 = [&](size_t o) { int32_t v; std::memcpy(&v, d.data() + o, 4); return v; };
+    for (;;) {
+        if (at >= d.size()) return fail("truncated header");
+        if (d[at] == 0) { ++at; break; }
+        std::string name, type;
+        while (at < d.size() && d[at]) name.push_back(static_cast<char>(d[at++]));
+        ++at;
+        while (at < d.size() && d[at]) type.push_back(static_cast<char>(d[at++]));
+        ++at;
+        if (at + 4 > d.size()) return fail("truncated header");
+        const int32_t size = rd_i32(at); at += 4;
+        if (size < 0 || at + static_cast<size_t>(size) > d.size()) return fail("truncated header");
+        if (name == "channels") {
+            size_t c = at;
+            const size_t end = at + size;
+            while (c < end && d[c]) {
+                Channel ch;
+                while (c < end && d[c]) ch.name.push_back(static_cast<char>(d[c++]));
+                ++c;
+                if (c + 16 > end) return fail("truncated channel list");
+                ch.type = rd_i32(c);
+                if (rd_i32(c + 8) != 1 || rd_i32(c + 12) != 1) return fail("subsampled channels are not read");
+                if (ch.type < 0 || ch.type > 2) return fail("unknown pixel type");
+                c += 16;
+                channels.push_back(ch);
+            }
+        }
+        else if (name == "compression" && size == 1) compression = d[at];
+        else if (name == "dataWindow" && size == 16) { for (int k = 0; k < 4; ++k) win[k] = rd_i32(at + 4 * k); haveWindow = true; }
+        at += size;
+    }
+    if (channels.empty() || !haveWindow || compression < 0) return fail("header without channels / dataWindow / compression");
+    static const char* names[] = { "NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB" };
+    if (compression > 3) return fail(std::string("compression ") + (compression < 10 ? names[compression] : "?") + " is not read (NONE, RLE, ZIPS, ZIP are; re-save the file)");
+    const int64_t w64 = static_cast<int64_t>(win[2]) - win[0] + 1, h64 = static_cast<int64_t>(win[3]) - win[1] + 1;
+    if (w64 <= 0 || h64 <= 0 || w64 > kMaxTextureDim || h64 > kMaxTextureDim) return fail("image larger than 16384 x 16384 or empty");
+    const uint32_t w = static_cast<uint32_t>(w64), h = static_cast<uint32_t>(h64);
+    const uint32_t linesPerChunk = compression == 3 ? 16u : 1u;
+    const uint32_t numChunks = (h + linesPerChunk - 1) / linesPerChunk;
+    if (at + 8ull * numChunks > d.size()) return fail("truncated offset table");
+    size_t lineBytes = 0;
+    for (const Channel& c : channels) lineBytes += (c.type == 1 ? 2ull : 4ull) * w;
+    // which file channel feeds which of R G B A (a lone Y feeds R, G and B)
+    int src[4] = { -1, -1, -1, -1 };
+    for (size_t c = 0; c < channels.size(); ++c) {
+        const std::string& nm = channels[c].name;
+        if (nm == "R") src[0] = static_cast<int>(c); else if (nm == "G") src[1] = static_cast<int>(c);
+        else if (nm == "B") src[2] = static_cast<int>(c); else if (nm == "A") src[3] = static_cast<int>(c);
+    }
+    if (src[0] < 0 && src[1] < 0 && src[2] < 0)
+        for (size_t c = 0; c < channels.size(); ++c) if (channels[c].name == "Y") src[0] = src[1] = src[2] = static_cast<int>(c);
+    if (src[0] < 0 && src[1] < 0 && src[2] < 0) return fail("no R, G, B or Y channel");
+    img.w = w; img.h = h; img.isFloat = true; img.rgba32f.assign(4ull * w * h, 0.0f);
+    for (size_t i = 0; i < static_cast<size_t>(w) * h; ++i) img.rgba32f[4 * i + 3] = 1.0f;
+    std::vector<uint8_t> raw, tmp;
+    for (uint32_t k = 0; k < numChunks; ++k) {
+        uint64_t off; std::memcpy(&off, d.data() + at + 8ull * k, 8);
+        if (off + 8 > d.size()) return fail("chunk offset outside the file");
+        const int32_t y0 = rd_i32(off), size = rd_i32(off + 4);
+        const int64_t row0 = static_cast<int64_t>(y0) - win[1];
+        if (size < 0 || off + 8 + static_cast<uint64_t>(size) > d.size() || row0 < 0 || row0 >= h) return fail("malformed chunk");
+        const uint32_t lines = std::min<uint32_t>(linesPerChunk, h - static_cast<uint32_t>(row0));
+        const size_t want = lineBytes * lines;
+        const uint8_t* body = d.data() + off + 8;
+        if (compression == 0 || static_cast<size_t>(size) == want) {       // a chunk that did not shrink is stored as it is
+            if (static_cast<size_t>(size) != want) return fail("chunk of the wrong size");
+            raw.assign(body, body + want);
+        }
+        else {
+            if (compression == 1) {                                           // run lengths: n < 0 -> -n literal bytes, else n + 1 copies of the next
+                tmp.clear();
+                size_t i = 0;
+                while (i < static_cast<size_t>(size)) {
+                    const int n = static_cast<int8_t>(body[i++]);
+                    if (n < 0) { if (i + static_cast<size_t>(-n) > static_cast<size_t>(size)) return fail("malformed RLE chunk"); tmp.insert(tmp.end(), body + i, body + i - n); i += static_cast<size_t>(-n); }
+                    else { if (i >= static_cast<size_t>(size)) return fail("malformed RLE chunk"); tmp.insert(tmp.end(), static_cast<size_t>(n) + 1, body[i++]); }
+                    if (tmp.size() > want) return fail("malformed RLE chunk");
+                }
+                if (tmp.size() != want) return fail("malformed RLE chunk");
+            }
+            else if (!inflate_zlib(body, static_cast<size_t>(size), tmp, want)) return fail("malformed ZIP chunk");
+            for (size_t i = 1; i < want; ++i) tmp[i] = static_cast<uint8_t>(tmp[i - 1] + tmp[i] - 128);      // byte-delta predictor
+            raw.resize(want);
+            const size_t half = (want + 1) / 2;
+            for (size_t i = 0; i < want; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];              // even bytes first, then odd
+        }
+        for (uint32_t l = 0; l < lines; ++l) {
+            const uint8_t* line = raw.data() + lineBytes * l;
+            float* out = img.rgba32f.data() + 4ull * (static_cast<size_t>(row0) + l) * w;
+            size_t chOff = 0;
+            for (size_t c = 0; c < channels.size(); ++c) {
+                const int type = channels[c].type;
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    if (src[k4] != static_cast<int>(c)) continue;
+                    for (uint32_t x = 0; x < w; ++x) {
+                        float v;
+                        if (type == 1) { uint16_t hv; std::memcpy(&hv, line + chOff + 2ull * x, 2); v = half_to_float(hv); }
+                        else if (type == 2) std::memcpy(&v, line + chOff + 4ull * x, 4);
+                        else { uint32_t u; std::memcpy(&u, line + chOff + 4ull * x, 4); v = static_cast<float>(u); }
+                        out[4ull * x + k4] = v;
+                    }
+                }
+                chOff += (type == 1 ? 2ull : 4ull) * w;
+            }
+        }
+    }
+    return true;
+}
+
+// Uncompressed formats (no third-party decoders in this build): binary PPM / PGM (8 bit), PFM, BMP 24 / 32 bit, TGA types 2 / 3
+// (24 / 32 / 8 bit) -- and OpenEXR above.  BC-compressed DDS and PNG files of the original assets are decoded offline (tools/dds_convert.py).
 bool decode_image(const std::string& path, Image& img, std::string& err) {
     std::vector<uint8_t> d;
     if (!read_file(path, d)) { err = "cannot read " + path; return false; }
+    if (d.size() >= 8 && d[0] == 0x76 && d[1] == 0x2f && d[2] == 0x31 && d[3] == 0x01) return decode_exr(d, path, img, err);
     if (d.size() >= 2 && d[0] == 'P' && (d[1] == '6' || d[1] == '5')) {
         size_t at = 2; std::string t;
         uint32_t vals[3];
@@ -347,7 +590,7 @@ bool decode_image(const std::string& path, Image& img, std::string& err) {
             }
         return true;
     }
-    err = "unsupported image format (PPM / PGM / PFM / BMP / TGA, uncompressed): " + path;
+    err = "unsupported image format (PPM / PGM / PFM / BMP / TGA uncompressed, EXR): " + path;
     return false;
 }
 } // namespace
