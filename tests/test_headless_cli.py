@@ -275,8 +275,8 @@ def _write_pfm(path, rgb):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("renderer", ["restir-unbiased", "nrc"])
-def test_cli_env_texture(built_lib, tmp_path, renderer):
+@pytest.mark.parametrize("renderer,kind", [("restir-unbiased", "pfm"), ("nrc", "pfm"), ("restir-unbiased", "exr")])
+def test_cli_env_texture(built_lib, tmp_path, renderer, kind):
     """-env-texture (restir_di_main.cpp:1188-1197; the NRC sample takes the same option): a float lat-long image through the scene
     builder's loader into gfxh_restir_set_env / gfxh_nrc_set_env.  Frame 0 of the command line is bit-identical to the renderer driven
     through the bindings with the texels the same loader returns, and differs from the frame without the map."""
@@ -284,8 +284,11 @@ def test_cli_env_texture(built_lib, tmp_path, renderer):
     W, H = 160, 96
     ew, eh = 128, 64
     sky = api.env_make_sky(ew, eh).reshape(eh, ew, 4)
-    env_path = str(tmp_path / "sky.pfm")
-    _write_pfm(env_path, sky[..., :3])
+    env_path = str(tmp_path / ("sky." + kind))
+    if kind == "pfm":
+        _write_pfm(env_path, sky[..., :3])
+    else:                                              # OpenEXR, what the reference's loadEnvTexture reads (common_host.cpp:2674)
+        api.save_image_hdr(env_path, sky.reshape(-1, 4), ew, eh, 1.0)
     opts = ["-size", W, H, "-renderer", renderer, "-frames", 1]
     out, out_dark = str(tmp_path / "env.pfm"), str(tmp_path / "dark.pfm")
     d = _run(_scene_args() + opts + ["-env-texture", env_path, "-out", out])
