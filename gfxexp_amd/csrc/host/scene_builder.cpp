@@ -695,7 +695,7 @@ static uint32_t load_obj_impl(gfxh_scene* s, const char* path, int simplePbr) {
         if (k == "v") { V3 p; ss >> p.x >> p.y >> p.z; pos.push_back(p); }
         else if (k == "vn") { V3 p; ss >> p.x >> p.y >> p.z; nrm.push_back(p); }
         else if (k == "vt") { float a = 0, b = 0; ss >> a >> b; uv.push_back({ a, b }); }
-        else if (k == "mtllib") { std::string f; ss >> f; parse_mtl(f); }
+        else if (k == "mtllib") { std::string f; while (ss >> f) parse_mtl(f); }      // "mtllib a.mtl b.mtl": every library named
         else if (k == "usemtl") { ss >> curMat; }
         else if (k == "f") {
             std::vector<Corner> cs;

@@ -236,3 +236,20 @@ def test_tangents_follow_the_texture_coordinates(built_lib, tmp_path):
             checked += len(dots); agree += int((dots > 0).sum())
     if checked:
         assert agree > 0.9 * checked, (agree, checked)
+
+
+def test_windows_line_ends_backslashes_and_two_material_libraries(built_lib, tmp_path):
+    """What exported OBJ files look like in practice: CRLF line ends, a texture path written with backslashes, `mtllib` naming two files."""
+    (tmp_path / "tex").mkdir()
+    (tmp_path / "tex" / "albedo.ppm").write_bytes(b"P6\n2 2\n255\n" + bytes(range(12)))
+    (tmp_path / "a.mtl").write_bytes(b"newmtl red\r\nKd 1 0 0\r\nmap_Kd tex\\albedo.ppm\r\n")
+    (tmp_path / "b.mtl").write_bytes(b"newmtl blue\r\nKd 0 0 1\r\n")
+    (tmp_path / "q.obj").write_bytes(b"mtllib a.mtl b.mtl\r\nv 0 0 0\r\nv 1 0 0\r\nv 1 1 0\r\nv 0 1 0\r\nvt 0 0\r\nvt 1 0\r\nvt 1 1\r\nvt 0 1\r\n"
+                                     b"usemtl red\r\nf 1/1 2/2 3/3\r\nusemtl blue\r\nf 1/1 3/3 4/4\r\n")
+    hs = api.HostScene()
+    hs.load_obj(str(tmp_path / "q.obj"))
+    geoms, mats = hs.geoms(), hs.materials()
+    assert len(geoms) == 2
+    red, blue = mats[geoms[0][2]], mats[geoms[1][2]]
+    assert list(red.a) == [1.0, 0.0, 0.0] and red.texA == 1                  # the texture was found behind the backslash path
+    assert list(blue.a) == [0.0, 0.0, 1.0] and blue.texA == 0                # the second library was read
