@@ -449,10 +449,10 @@ bool decode_exr(const std::vector<uint8_t>& d, const std::string& path, Image& i
     std::vector<uint8_t> raw, tmp;
     for (uint32_t k = 0; k < numChunks; ++k) {
         uint64_t off; std::memcpy(&off, d.data() + at + 8ull * k, 8);
-        if (off + 8 > d.size()) return fail("chunk offset outside the file");
+        if (off > d.size() || d.size() - off < 8) return fail("chunk offset outside the file");            // (no off + 8: the field is untrusted)
         const int32_t y0 = rd_i32(off), size = rd_i32(off + 4);
         const int64_t row0 = static_cast<int64_t>(y0) - win[1];
-        if (size < 0 || off + 8 + static_cast<uint64_t>(size) > d.size() || row0 < 0 || row0 >= h) return fail("malformed chunk");
+        if (size < 0 || static_cast<uint64_t>(size) > d.size() - off - 8 || row0 < 0 || row0 >= h) return fail("malformed chunk");
         const uint32_t lines = std::min<uint32_t>(linesPerChunk, h - static_cast<uint32_t>(row0));
         const size_t want = lineBytes * lines;
         const uint8_t* body = d.data() + off + 8;

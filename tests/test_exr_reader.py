@@ -204,6 +204,13 @@ def test_what_the_reader_refuses(built_lib, tmp_path):
         p.write_bytes(data)
         with pytest.raises(api.GfxError, match=what):
             s.load_texture(str(p))
+    wild = bytearray(_exr({"R": (HALF, r)}, NONE))
+    table = bytes(wild).index(b"screenWindowWidth") + len("screenWindowWidth") + 1 + len("float") + 1 + 4 + 4 + 1
+    struct.pack_into("<Q", wild, table, 0xFFFFFFFFFFFFFFFC)      # a chunk offset that wraps when eight is added to it
+    p = tmp_path / "wild.exr"
+    p.write_bytes(bytes(wild))
+    with pytest.raises(api.GfxError, match="offset"):
+        s.load_texture(str(p))
     good = bytearray(_exr({"R": (HALF, np.tile(np.arange(16, dtype=np.float16), (16, 1)))}, ZIP))
     good[-20] ^= 0x5A                                         # a damaged deflate stream
     p = tmp_path / "damaged.exr"
