@@ -155,8 +155,10 @@ def parse():
                     help="N > 1 with the torch.distributed exchange: rounds of cost-balancing the row bands during the warm-up (each round: "
                          "4 frames, all-gather of the ranks' frame times, gfxh_balance_bands, band renderers re-created); 0 = equal bands")
     ap.add_argument("--plain", action="store_true", help="constant-colour materials (the round-1 workload) instead of the textured street")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "rccl"],
-                    help="N > 1: strip-exchange callback -- tilesplit.StripExchange over torch.distributed (default) or the C++ gfxh_rccl_exchange")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "torch", "rccl"],
+                    help="N > 1: strip-exchange transport -- rccl: the C++ gfxh_rccl_exchange (no Python between the passes, one communicator per lane); "
+                         "torch: tilesplit.StripExchange over torch.distributed; auto (default): rccl when librccl loads on every rank, else torch")
+    ap.add_argument("--sync-gather", action="store_true", help="N > 1: the HDR band gather on the frame's own stream instead of the gather lane underneath the next frame")
     ap.add_argument("--cluttered", action="store_true", help="secondary workload: + 70 trees of 6 000 leaf cards, cables, railings (depth complexity)")
     ap.add_argument("--bump", type=int, default=1, help="enableBumpMapping (normal maps) for the textured workload")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4], help="BASELINE.json configs[] index (0-based); 2 = the metric's configuration")
@@ -165,6 +167,7 @@ def parse():
                     help="default run only (configs[2], static, textured, one GPU): afterwards measure configs[1], [3], [4] and --animate for --other-steps "
                          "steps each (5 warm-up frames) and report them inside the one JSON line as `other_configs` (0 = skip)")
     ap.add_argument("--other-steps", type=int, default=20)
+    ap.add_argument("--other-timeout", type=float, default=240.0, help="seconds each other-configs child process may take before it is killed (the headline stands on its own)")
     return ap.parse_args()
 
 
@@ -194,9 +197,58 @@ def orbit_camera(api, W, H, frame):
 ANIMATE_MAX_MOTION_ROWS = 24
 
 
+def _respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU, rendezvous on
+    127.0.0.1) and become that launcher, so the command works in either shape."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: the only mode the host driver supports (RCCL across processes)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+OTHER_CONFIGS = (("configs[1]", ["--config", "1"]), ("configs[3]", ["--config", "3"]), ("configs[4]", ["--config", "4"]), ("configs[2] --animate", ["--animate"]),
+                 ("configs[2] --cluttered", ["--cluttered"]))
+
+
+def _other_configs(args):
+    """Every other BASELINE configuration (and the secondary workloads of configs[2]) under the same clock as the headline: a short run
+    of each in a CHILD process with a time limit, after the headline measurement is complete -- a hang or a crash in one of them costs
+    that entry, never the line.  Each child is this file with --other-configs 0."""
+    import subprocess
+    others = {}
+    for name, flags in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.other_steps), "--warmup", "5", "--mse-ref-spp", "0",
+               "--cpu-sample", "0", "--other-configs", "0"] + flags
+        t0 = time.perf_counter()
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=args.other_timeout)
+            line = next((l for l in reversed(out.stdout.splitlines()) if l.startswith("{")), None)
+            if out.returncode != 0 or line is None:
+                others[name] = {"error": "exit code %d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:])}
+                continue
+            r = json.loads(line)
+            roof = r.get("roofline") or {}
+            others[name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
+                            "workload": r["config"]["workload"], "width": r["config"]["width"], "height": r["config"]["height"],
+                            "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_nominal_hbm", "frac_hbm_counter", "traffic", "avg_launch_ms", "valu",
+                                                                "pmc_head", "pmc_matches_sources", "infer_ms_per_frame") if k in roof},
+                            "kernels_ms_per_frame": r.get("kernels_ms_per_frame"), "seconds": round(time.perf_counter() - t0, 1)}
+        except subprocess.TimeoutExpired:
+            others[name] = {"error": "killed after %.0f s (--other-timeout)" % args.other_timeout}
+        except Exception as e:               # the headline stands on its own
+            others[name] = {"error": repr(e)[:300]}
+    return others
+
+
 def main():
     args = parse()
-    import copy
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn_under_torchrun(args)            # does not return
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -205,13 +257,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1 and args.config in (1, 3):
         raise SystemExit(f"--config {args.config} is a single-GPU configuration in BASELINE.json")
-    if world > 1 and args.animate and args.exchange == "rccl":
-        raise SystemExit("--animate --gpus N runs over the torch.distributed exchange (--exchange torch)")
     # GFX_BENCH_ONE_GPU=1: every rank on device 0, collectives staged through host memory over gloo (tilesplit.HostStaged) -- a functional
     # check of the multi-rank frame loop on a one-GPU box (RCCL refuses two ranks on a device); its numbers mean nothing
     one_gpu = world > 1 and os.environ.get("GFX_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but this box has {torch.cuda.device_count()} GPU(s) (GFX_BENCH_ONE_GPU=1 runs the ranks on one device as a functional check)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -222,34 +274,19 @@ def main():
             from gfxexp_amd import tilesplit
             if args.exchange == "rccl":
                 raise SystemExit("GFX_BENCH_ONE_GPU=1 runs over the torch.distributed exchange (--exchange torch)")
+            args.exchange = "torch"
             dist.init_process_group("gloo", rank=rank, world_size=world)
             dist = tilesplit.HostStaged(dist)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     result = run_config(args, rank, local_rank, world, dist)
-    # Every other BASELINE configuration under the same clock as the headline (the driver runs this file once): a short run of each after
-    # the headline measurement, reported inside the one line.  The headline's own fields are untouched.
     if rank == 0 and world == 1 and args.other_configs and args.config == 2 and not (args.animate or args.plain or args.cluttered):
-        others = {}
-        for name, over in (("configs[1]", {"config": 1}), ("configs[3]", {"config": 3}), ("configs[4]", {"config": 4}), ("configs[2] --animate", {"animate": True})):
-            a2 = copy.copy(args)
-            a2.steps, a2.warmup, a2.mse_ref_spp, a2.cpu_sample = args.other_steps, 5, 0, "0"
-            for k, v in over.items():
-                setattr(a2, k, v)
-            t0 = time.perf_counter()
-            try:
-                r = run_config(a2, rank, local_rank, world, dist)
-                roof = r.get("roofline") or {}
-                others[name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
-                                "workload": r["config"]["workload"], "width": r["config"]["width"], "height": r["config"]["height"],
-                                "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_nominal_hbm", "avg_launch_ms", "valu",
-                                                                    "pmc_head", "pmc_matches_sources", "infer_ms_per_frame") if k in roof},
-                                "kernels_ms_per_frame": r.get("kernels_ms_per_frame"), "seconds": round(time.perf_counter() - t0, 1)}
-            except Exception as e:               # the headline stands on its own
-                others[name] = {"error": repr(e)[:300]}
-        result["other_configs"] = others
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        result["other_configs"] = _other_configs(args)
     if rank == 0:
         print(json.dumps(result))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -323,64 +360,81 @@ def run_config(args, rank, local_rank, world, dist):
     stream = torch.cuda.current_stream().cuda_stream
 
     exchange = None
+    transport = None
     if world > 1:
-        # strip exchange: every pass runs on the band only; the rows the next pass reads across the seams travel between
-        # the passes (G-buffers once, reservoirs before each spatial pass), the HDR bands are all-gathered asynchronously
-        if args.exchange == "rccl":
-            # no Python between the passes: the C++ callback issues ncclSend / ncclRecv / ncclAllGather on the renderer's stream.
-            # Its communicator id comes from rank 0 over the torch process group.
-            L = api.lib()
-            ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                raw = (C.c_uint8 * 128)()
-                if L.gfxh_rccl_unique_id(raw):
-                    raise SystemExit("gfxh_rccl_unique_id failed")
-                ident.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-            dist.broadcast(ident, src=0)
-            raw = (C.c_uint8 * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
-            comm = C.c_void_p()
-            L.gfxh_rccl_last_error.restype = C.c_char_p
-            if L.gfxh_rccl_create(raw, C.c_int(rank), C.c_int(world), C.c_uint32(H), C.byref(comm)):
-                raise SystemExit("gfxh_rccl_create: " + L.gfxh_rccl_last_error().decode())
-            api.check_partition(cfg, world, 0)          # the same verdict on every rank, before the first collective
-            L.gfxh_restir_set_exchange(renderer.h, C.cast(L.gfxh_rccl_exchange, C.c_void_p), comm, C.c_uint32(0))
+        # strip exchange: every pass runs on the band only; the rows the next pass reads across the seams travel between the passes --
+        # the G-buffer strips on the G-buffer lane behind the pipelined G-buffer pass, the reservoir strips on the frame's stream before
+        # each spatial pass -- and the HDR bands are all-gathered on the gather lane underneath the next frame (gfxexp_host.h gfxh_lane)
+        motion_rows = ANIMATE_MAX_MOTION_ROWS if args.animate else 0       # static camera and scene: no motion rows
+        L = api.lib()
+        L.gfxh_rccl_last_error.restype = C.c_char_p
+        use_rccl = args.exchange in ("auto", "rccl")
+        ids = None
+        if use_rccl:
+            # rank 0 draws one ncclUniqueId per lane (this also answers whether librccl loads here); the verdict and the ids go to every
+            # rank over the torch process group, so the ranks choose the same transport before anyone enters ncclCommInitRank
+            ok = torch.ones(1, dtype=torch.int32, device="cuda")
+            buf = torch.zeros(128 * api.NUM_LANES, dtype=torch.uint8, device="cuda")
+            try:
+                mine = api.RcclExchange.unique_ids(api.NUM_LANES)
+                if rank == 0:
+                    buf.copy_(torch.frombuffer(bytearray(mine), dtype=torch.uint8))
+            except api.GfxError as e:
+                ok.zero_()
+                if rank == 0:
+                    sys.stderr.write("bench: librccl does not load (%s)\n" % e)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            dist.broadcast(buf, src=0)
+            use_rccl = bool(ok.item())
+            ids = bytes(buf.cpu().numpy().tobytes())
+            if not use_rccl and args.exchange == "rccl":
+                raise SystemExit("--exchange rccl: librccl does not load on every rank")
 
-            class _Done:
-                def finish(self):
-                    pass
-            exchange = _Done()
-        else:
-            exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda", async_gather=True)
-            motion_rows = ANIMATE_MAX_MOTION_ROWS if args.animate else 0       # static camera and scene: no motion rows
-            renderer.set_exchange(exchange, motion_rows)
-            # Equal rows are not equal work (sky rows are cheap).  Each round: time this rank's band over a few frames, all-gather
-            # the times, cut the frame where gfxh_balance_bands says (the same call with the same numbers on every rank) and start
-            # over with band renderers for the new rows -- all inside the untimed warm-up; the timed frames use the final partition.
-            for _ in range(max(0, args.balance_bands)):
-                for _ in range(2):
-                    renderer.render_frame(stream)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(4):
-                    renderer.render_frame(stream)
-                e1.record()
-                torch.cuda.synchronize()
-                mine = torch.tensor([e0.elapsed_time(e1) / 4], dtype=torch.float32, device="cuda")
-                times = torch.zeros(world, dtype=torch.float32, device="cuda")
-                dist.all_gather_into_tensor(times, mine)
-                new_bands = api.balance_bands(H, bands, [float(t) for t in times.cpu()], min_rows=24)
-                exchange.finish()
-                if new_bands == bands:
-                    break
-                bands = new_bands
-                renderer.close()
-                cfg.rowBegin, cfg.rowEnd = bands[rank]
-                renderer = api.RestirRenderer(ctx, cfg)
-                if args.config == 4:
-                    renderer.set_env(sky, 2048, 1024, 0.6, 0.4)
-                exchange = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda", async_gather=True, bands=bands)
-                renderer.set_exchange(exchange, motion_rows)
+        one_gpu = os.environ.get("GFX_BENCH_ONE_GPU") == "1"
+        rccl_ex = api.RcclExchange(ids, rank, world, H) if use_rccl else None    # the communicators: made once (an ncclUniqueId serves one ncclCommInitRank)
+
+        def install(r, bands_now):
+            """The transport for one band renderer (re-installed when the bands are re-cut)."""
+            if use_rccl:
+                api.check_bands(cfg, bands_now, motion_rows)                      # the same verdict on every rank, before the first collective
+                rccl_ex.set_bands(bands_now)
+                rccl_ex.install(r, motion_rows)                                   # no Python between the passes
+                ex = rccl_ex
+            else:
+                groups = {} if one_gpu else tilesplit.make_lane_groups(dist)
+                ex = tilesplit.StripExchange(dist, rank, world, H, tilesplit.device_bytes, device="cuda", bands=bands_now, lane_groups=groups)
+                r.set_exchange(ex, motion_rows)
+            r.set_async_gather(not args.sync_gather)
+            return ex
+        transport = "gfxh_rccl_exchange (C++, %d communicators)" % api.NUM_LANES if use_rccl else "tilesplit.StripExchange (torch.distributed)"
+        exchange = install(renderer, bands)
+        # Equal rows are not equal work (sky rows are cheap).  Each round: time this rank's band over a few frames, all-gather
+        # the times, cut the frame where gfxh_balance_bands says (the same call with the same numbers on every rank) and start
+        # over with band renderers for the new rows -- all inside the untimed warm-up; the timed frames use the final partition.
+        for _ in range(max(0, args.balance_bands)):
+            for _ in range(2):
+                renderer.render_frame(stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                renderer.render_frame(stream)
+            e1.record()
+            renderer.finish_gather(stream)
+            torch.cuda.synchronize()
+            mine = torch.tensor([e0.elapsed_time(e1) / 4], dtype=torch.float32, device="cuda")
+            times = torch.zeros(world, dtype=torch.float32, device="cuda")
+            dist.all_gather_into_tensor(times, mine)
+            new_bands = api.balance_bands(H, bands, [float(t) for t in times.cpu()], min_rows=24)
+            if new_bands == bands:
+                break
+            bands = new_bands
+            renderer.close()
+            cfg.rowBegin, cfg.rowEnd = bands[rank]
+            renderer = api.RestirRenderer(ctx, cfg)
+            if args.config == 4:
+                renderer.set_env(sky, 2048, 1024, 0.6, 0.4)
+            exchange = install(renderer, bands)
 
     frame_no = [0]
 
@@ -409,7 +463,7 @@ def run_config(args, rank, local_rank, world, dist):
     for _ in range(args.steps):
         frame()
     if exchange is not None:
-        exchange.finish()                             # the last frame's bands are in place on every rank
+        renderer.finish_gather(stream)                # the last frame's bands are in place on every rank
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -427,7 +481,7 @@ def run_config(args, rank, local_rank, world, dist):
         "vs_baseline": None, "dtype": "f32" if args.config != 3 else "f32 path tracing + bf16 MFMA network (fp32 accumulate, fp32 master weights)", "data": "synthetic",
         "config": {"workload": workload,
                    "width": W, "height": H, "spp": 1, "parallelism": (f"row-bands x{world}" + (" on ONE device, host-staged gloo (GFX_BENCH_ONE_GPU: a functional check, not a measurement)" if os.environ.get("GFX_BENCH_ONE_GPU") == "1" else "")) if world > 1 else "single GPU",
-                   "bands": bands,
+                   "bands": bands, "exchange": transport, "band_gather": (None if world == 1 else "caller's stream" if args.sync_gather else "gather lane, underneath the next frame"),
                    "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]} if accel_stats else None,
                    "light_table": ctx.lights_table_info()},
         "setup_s": round(setup_s, 2),

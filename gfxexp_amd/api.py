@@ -136,7 +136,7 @@ class GfxhRestirConfig(C.Structure):
 class GfxhFrameStep(C.Structure):
     _fields_ = [("op", C.c_uint32), ("pass_", C.c_uint32), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32),
                 ("currentReservoirIndex", C.c_uint32), ("spatialNeighborBaseIndex", C.c_uint32),
-                ("exchangeRows", C.c_uint32), ("buffers", C.c_uint32), ("reservoirIndex", C.c_uint32)]
+                ("exchangeRows", C.c_uint32), ("buffers", C.c_uint32), ("reservoirIndex", C.c_uint32), ("lane", C.c_uint32)]
 
 
 class GfxhExchangeBuffer(C.Structure):
@@ -144,7 +144,7 @@ class GfxhExchangeBuffer(C.Structure):
 
 
 class GfxhExchangeDesc(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("stage", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+    _fields_ = [("kind", C.c_uint32), ("stage", C.c_uint32), ("lane", C.c_uint32), ("reserved", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
                 ("bandBegin", C.c_uint32), ("bandEnd", C.c_uint32),
                 ("sendAbove", C.c_uint32 * 2), ("recvAbove", C.c_uint32 * 2), ("sendBelow", C.c_uint32 * 2), ("recvBelow", C.c_uint32 * 2),
                 ("numBuffers", C.c_uint32), ("buffers", GfxhExchangeBuffer * 8),
@@ -153,7 +153,9 @@ class GfxhExchangeDesc(C.Structure):
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(GfxhExchangeDesc))
 EXCHANGE_STRIPS, EXCHANGE_ALLREDUCE_SUM_U32, EXCHANGE_GATHER_BANDS, EXCHANGE_GATHER_RECORDS, EXCHANGE_BROADCAST = 0, 1, 2, 3, 4
-STEP_RESTIR_PASS, STEP_PT_PASS, STEP_EXCHANGE_STRIPS, STEP_ALLREDUCE_CELL_ACCESSES, STEP_GATHER_BANDS, STEP_PREV_GBUFFER_RELEASED = range(6)
+(STEP_RESTIR_PASS, STEP_PT_PASS, STEP_EXCHANGE_STRIPS, STEP_ALLREDUCE_CELL_ACCESSES, STEP_GATHER_BANDS, STEP_PREV_GBUFFER_RELEASED,
+ STEP_WAIT_GBUFFER_STRIPS, STEP_WAIT_PREVIOUS_GATHER) = range(8)
+LANE_MAIN, LANE_GBUFFER, LANE_GATHER, NUM_LANES = 0, 1, 2, 3
 BUF_GBUFFERS, BUF_RESERVOIRS, BUF_SAMPLE_VISIBILITY = 1, 2, 4
 
 
@@ -178,6 +180,73 @@ def exchange_desc(cfg, step, step_index, static_params, regir_params, buffer_ind
     if rc:
         raise GfxError("gfxh_frame_step_exchange_desc: not an exchange step, or the strip is taller than the band")
     return d
+
+
+def abi_layout():
+    """gfxh_abi_entry: {struct: {"size": sizeof, "fields": [(name, offset, size), ...]}} as the library's compiler laid the
+    structs of include/gfxexp.h and include/gfxexp_host.h out."""
+    L = lib()
+    out = {}
+    for i in range(L.gfxh_abi_num_entries()):
+        sn, fn = C.c_char_p(), C.c_char_p()
+        off, size = C.c_uint64(), C.c_uint64()
+        L.gfxh_abi_entry(C.c_uint32(i), C.byref(sn), C.byref(fn), C.byref(off), C.byref(size))
+        e = out.setdefault(sn.value.decode(), {"size": None, "fields": []})
+        if fn.value is None:
+            e["size"] = size.value
+        else:
+            e["fields"].append((fn.value.decode(), off.value, size.value))
+    return out
+
+
+# which ctypes class mirrors which C struct (tests/test_abi_and_host.py checks every one against abi_layout())
+def abi_mirrors():
+    return {"gfx_material": GfxMaterial, "gfx_camera": GfxCamera, "gfx_restir_static_params": GfxRestirStaticParams,
+            "gfx_restir_frame_params": GfxRestirFrameParams, "gfx_regir_params": GfxRegirParams, "gfx_nrc_params": GfxNrcParams,
+            "gfxh_street_params": GfxhStreetParams, "gfxh_restir_config": GfxhRestirConfig, "gfxh_frame_step": GfxhFrameStep,
+            "gfxh_exchange_buffer": GfxhExchangeBuffer, "gfxh_exchange_desc": GfxhExchangeDesc, "gfxh_band_plan": GfxhBandPlan,
+            "gfxh_nrc_config": GfxhNrcConfig, "gfxh_sdr_config": GfxhSdrConfig}
+
+
+class RcclExchange:
+    """gfxh_rccl: the C++ exchange callback over RCCL (csrc/host/rccl_exchange.cpp), one communicator per lane.  `ids` = the
+    bytes of `lanes` ncclUniqueIds from unique_ids() on rank 0, distributed by the caller."""
+
+    @staticmethod
+    def unique_ids(lanes=NUM_LANES):
+        L = lib()
+        L.gfxh_rccl_last_error.restype = C.c_char_p
+        raw = (C.c_uint8 * (128 * lanes))()
+        for k in range(lanes):
+            if L.gfxh_rccl_unique_id(C.byref(raw, 128 * k)):
+                raise GfxError("gfxh_rccl_unique_id: " + L.gfxh_rccl_last_error().decode())
+        return bytes(raw)
+
+    def __init__(self, ids, rank, world, height, bands=None):
+        self.L = lib()
+        self.L.gfxh_rccl_last_error.restype = C.c_char_p
+        self.rank, self.world = rank, world
+        lanes = len(ids) // 128
+        raw = (C.c_uint8 * len(ids)).from_buffer_copy(ids)
+        h = C.c_void_p()
+        if self.L.gfxh_rccl_create_lanes(raw, C.c_uint32(lanes), C.c_int(rank), C.c_int(world), C.c_uint32(height), C.byref(h)):
+            raise GfxError("gfxh_rccl_create_lanes: " + self.L.gfxh_rccl_last_error().decode())
+        self.h = h
+        if bands is not None:
+            self.set_bands(bands)
+
+    def set_bands(self, bands):
+        begins = (C.c_uint32 * (len(bands) + 1))(*([b for b, _ in bands] + [bands[-1][1]]))
+        if self.L.gfxh_rccl_set_bands(self.h, begins):
+            raise GfxError("gfxh_rccl_set_bands: " + self.L.gfxh_rccl_last_error().decode())
+
+    def install(self, renderer, max_motion_rows=0):
+        renderer.set_exchange_native(self.L.gfxh_rccl_exchange, self.h, max_motion_rows)
+
+    def close(self):
+        if self.h:
+            self.L.gfxh_rccl_destroy(self.h)
+            self.h = None
 
 
 def band_rows(height, world, rank):
@@ -258,7 +327,8 @@ HOST_ABI_SYMBOLS = [
     "gfxh_scene_bounds", "gfxh_scene_upload", "gfxh_make_transform", "gfxh_make_orientation",
     "gfxh_seed_rng_states", "gfxh_spatial_neighbor_deltas", "gfxh_restir_default_config", "gfxh_band_plan_compute",
     "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_band_rows", "gfxh_restir_check_partition", "gfxh_restir_check_bands", "gfxh_balance_bands", "gfxh_restir_frame_program", "gfxh_frame_step_exchange_desc",
-    "gfxh_rccl_unique_id", "gfxh_rccl_create", "gfxh_rccl_destroy", "gfxh_rccl_exchange", "gfxh_rccl_last_error", "gfxh_restir_create",
+    "gfxh_rccl_unique_id", "gfxh_rccl_create", "gfxh_rccl_create_lanes", "gfxh_rccl_set_bands", "gfxh_rccl_destroy", "gfxh_rccl_exchange", "gfxh_rccl_last_error", "gfxh_restir_create",
+    "gfxh_restir_set_async_gather", "gfxh_restir_finish_gather", "gfxh_abi_layout", "gfxh_abi_num_entries", "gfxh_abi_entry",
     "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_build_row_table", "gfxh_env_upload", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_outputs_consumed", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
@@ -826,6 +896,11 @@ class NrcRenderer:
             raise GfxError("gfxh_nrc_render_frame: " + self.L.gfxh_nrc_last_error().decode())
         return loss.value if want_loss else None
 
+    def outputs_consumed(self, stream=0):
+        """gfxh_nrc_outputs_consumed: as RestirRenderer.outputs_consumed."""
+        if self.L.gfxh_nrc_outputs_consumed(self.h, C.c_void_p(stream)):
+            raise GfxError("gfxh_nrc_outputs_consumed: " + self.L.gfxh_nrc_last_error().decode())
+
     def beauty_ptr(self):
         return self.L.gfxh_nrc_beauty_buffer(self.h)
 
@@ -892,9 +967,29 @@ class RestirRenderer:
         self._exchange_cb = EXCHANGE_FN(thunk)     # keep the trampoline alive
         self.L.gfxh_restir_set_exchange(self.h, self._exchange_cb, None, C.c_uint32(max_motion_rows))
 
+    def set_exchange_native(self, fn_ptr, user, max_motion_rows=0):
+        """Install a native exchange callback (gfxh_rccl_exchange with its gfxh_rccl*): no Python between the passes."""
+        self._exchange_cb = None
+        self.L.gfxh_restir_set_exchange(self.h, C.cast(fn_ptr, C.c_void_p), user, C.c_uint32(max_motion_rows))
+
+    def set_async_gather(self, enable=True):
+        """The band gather on the renderer's gather stream underneath the next frame; finish_gather() before reading other ranks' rows."""
+        if self.L.gfxh_restir_set_async_gather(self.h, C.c_int(int(enable))):
+            raise GfxError("gfxh_restir_set_async_gather: " + self.L.gfxh_restir_last_error().decode())
+
+    def finish_gather(self, stream=0):
+        if self.L.gfxh_restir_finish_gather(self.h, C.c_void_p(stream)):
+            raise GfxError("gfxh_restir_finish_gather: " + self.L.gfxh_restir_last_error().decode())
+
     def render_frame(self, stream=0):
         if self.L.gfxh_restir_render_frame(self.h, C.c_void_p(stream)):
             raise GfxError("gfxh_restir_render_frame: " + self.L.gfxh_restir_last_error().decode())
+
+    def outputs_consumed(self, stream=0):
+        """gfxh_restir_outputs_consumed: `stream` has passed its reads of the albedo / normal accumulators of the last frame (a
+        denoiser, a read-back); the next frame's pipelined G-buffer pass, which rewrites them, waits for this point."""
+        if self.L.gfxh_restir_outputs_consumed(self.h, C.c_void_p(stream)):
+            raise GfxError("gfxh_restir_outputs_consumed: " + self.L.gfxh_restir_last_error().decode())
 
     def reset(self):
         self.L.gfxh_restir_reset(self.h)

@@ -20,7 +20,7 @@ CLI = os.path.join(HERE, "restir_di_headless")       # host/restir_di_headless.c
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = ["capi.cpp", "scene.cpp", "lights.hip", "lbvh.hip", "trace.hip", "restir.hip", "pathtrace.hip", "nrc.hip", "textures.hip", "diag.hip",
-           "host/scene_builder.cpp", "host/restir_driver.cpp", "host/nrc_driver.cpp", "host/rccl_exchange.cpp"]
+           "host/scene_builder.cpp", "host/restir_driver.cpp", "host/nrc_driver.cpp", "host/rccl_exchange.cpp", "host/abi_layout.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(HERE, "..", "include")]

@@ -71,7 +71,12 @@ thread_local std::string g_rcclError;
 } // namespace
 
 struct gfxh_rccl {
-    ncclComm_t comm = nullptr;
+    // one communicator per lane of the renderer (gfxexp_host.h gfxh_lane) when created with gfxh_rccl_create_lanes: operations of
+    // different lanes are enqueued on different streams and must not queue behind each other inside one communicator; with a single
+    // communicator (gfxh_rccl_create) every lane shares it and the operations run in issue order
+    ncclComm_t comms[GFXH_NUM_LANES] = { nullptr, nullptr, nullptr };
+    uint32_t numComms = 0;
+    ncclComm_t lane(uint32_t l) const { return comms[l < numComms ? l : 0]; }
     int rank = 0, world = 1;
     std::vector<uint32_t> bandBegin, bandEnd;   // of every rank: whole 8-row tiles, remainder spread from rank 0
     void* staging = nullptr; size_t stagingBytes = 0;
@@ -89,9 +94,10 @@ int gfxh_rccl_unique_id(void* id128) {
     return 0;
 }
 
-int gfxh_rccl_create(const void* id128, int rank, int world, uint32_t height, gfxh_rccl** out) {
+int gfxh_rccl_create_lanes(const void* ids, uint32_t numLanes, int rank, int world, uint32_t height, gfxh_rccl** out) {
     *out = nullptr;
     if (!g_rccl.load(g_rcclError)) return 1;
+    if (numLanes < 1 || numLanes > GFXH_NUM_LANES) { g_rcclError = "gfxh_rccl_create_lanes: 1 to " + std::to_string(GFXH_NUM_LANES) + " communicators"; return 1; }
     gfxh_rccl* c = new gfxh_rccl();
     if (world < 1 || rank < 0 || rank >= world) { g_rcclError = "gfxh_rccl_create: rank outside the world"; delete c; return 1; }
     c->rank = rank; c->world = world;
@@ -104,15 +110,33 @@ int gfxh_rccl_create(const void* id128, int rank, int world, uint32_t height, gf
         }
         c->bandBegin.push_back(b); c->bandEnd.push_back(e);
     }
-    ncclUniqueId id; std::memcpy(&id, id128, sizeof(id));
-    if (g_rccl.CommInitRank(&c->comm, world, id, rank)) { g_rcclError = "ncclCommInitRank failed"; delete c; return 1; }
+    for (uint32_t l = 0; l < numLanes; ++l) {
+        ncclUniqueId id; std::memcpy(&id, static_cast<const char*>(ids) + sizeof(id) * l, sizeof(id));
+        if (g_rccl.CommInitRank(&c->comms[l], world, id, rank)) {
+            g_rcclError = "ncclCommInitRank failed (lane " + std::to_string(l) + ")";
+            gfxh_rccl_destroy(c); return 1;
+        }
+        c->numComms = l + 1;
+    }
     *out = c;
+    return 0;
+}
+
+int gfxh_rccl_create(const void* id128, int rank, int world, uint32_t height, gfxh_rccl** out) {
+    return gfxh_rccl_create_lanes(id128, 1, rank, world, height, out);
+}
+
+int gfxh_rccl_set_bands(gfxh_rccl* c, const uint32_t* bandBegin) {
+    if (!c || !bandBegin) { g_rcclError = "gfxh_rccl_set_bands: null argument"; return 1; }
+    for (int r = 0; r < c->world; ++r)
+        if (bandBegin[r + 1] <= bandBegin[r] || (r == 0 && bandBegin[0] != 0)) { g_rcclError = "gfxh_rccl_set_bands: the partition must ascend from row 0"; return 1; }
+    for (int r = 0; r < c->world; ++r) { c->bandBegin[r] = bandBegin[r]; c->bandEnd[r] = bandBegin[r + 1]; }
     return 0;
 }
 
 void gfxh_rccl_destroy(gfxh_rccl* c) {
     if (!c) return;
-    if (c->comm) g_rccl.CommDestroy(c->comm);
+    for (uint32_t l = 0; l < c->numComms; ++l) if (c->comms[l]) g_rccl.CommDestroy(c->comms[l]);
     if (c->staging) (void)hipFree(c->staging);
     delete c;
 }
@@ -121,8 +145,9 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
     gfxh_rccl* c = static_cast<gfxh_rccl*>(user);
     hipStream_t stream = static_cast<hipStream_t>(streamPtr);
     int err = 0;
+    struct { ncclComm_t comm; } lane = { c->lane(d->lane) };   // the communicator of the lane `stream` belongs to
     if (d->kind == GFXH_EXCHANGE_ALLREDUCE_SUM_U32)
-        return g_rccl.AllReduce(d->counters, d->counters, d->numCounters, kNcclUint32, kNcclSum, c->comm, stream) ? 1 : 0;
+        return g_rccl.AllReduce(d->counters, d->counters, d->numCounters, kNcclUint32, kNcclSum, lane.comm, stream) ? 1 : 0;
     if (d->kind == GFXH_EXCHANGE_STRIPS) {
         err |= g_rccl.GroupStart();
         for (uint32_t k = 0; k < d->numBuffers; ++k) {
@@ -132,12 +157,12 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
                 char* base = static_cast<char*>(b.base) + plane * b.planeStride;
                 auto rows = [&](const uint32_t r[2]) { return static_cast<size_t>(r[1] - r[0]) * rowBytes; };
                 if (c->rank > 0) {
-                    if (rows(d->sendAbove)) err |= g_rccl.Send(base + d->sendAbove[0] * rowBytes, rows(d->sendAbove), kNcclUint8, c->rank - 1, c->comm, stream);
-                    if (rows(d->recvAbove)) err |= g_rccl.Recv(base + d->recvAbove[0] * rowBytes, rows(d->recvAbove), kNcclUint8, c->rank - 1, c->comm, stream);
+                    if (rows(d->sendAbove)) err |= g_rccl.Send(base + d->sendAbove[0] * rowBytes, rows(d->sendAbove), kNcclUint8, c->rank - 1, lane.comm, stream);
+                    if (rows(d->recvAbove)) err |= g_rccl.Recv(base + d->recvAbove[0] * rowBytes, rows(d->recvAbove), kNcclUint8, c->rank - 1, lane.comm, stream);
                 }
                 if (c->rank + 1 < c->world) {
-                    if (rows(d->sendBelow)) err |= g_rccl.Send(base + d->sendBelow[0] * rowBytes, rows(d->sendBelow), kNcclUint8, c->rank + 1, c->comm, stream);
-                    if (rows(d->recvBelow)) err |= g_rccl.Recv(base + d->recvBelow[0] * rowBytes, rows(d->recvBelow), kNcclUint8, c->rank + 1, c->comm, stream);
+                    if (rows(d->sendBelow)) err |= g_rccl.Send(base + d->sendBelow[0] * rowBytes, rows(d->sendBelow), kNcclUint8, c->rank + 1, lane.comm, stream);
+                    if (rows(d->recvBelow)) err |= g_rccl.Recv(base + d->recvBelow[0] * rowBytes, rows(d->recvBelow), kNcclUint8, c->rank + 1, lane.comm, stream);
                 }
             }
         }
@@ -149,7 +174,7 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
         // have its rows gathered into the wrong place
         if (d->bandBegin != c->bandBegin[c->rank] || d->bandEnd != c->bandEnd[c->rank]) {
             g_rcclError = "gfxh_rccl_exchange: the renderer's band [" + std::to_string(d->bandBegin) + ", " + std::to_string(d->bandEnd) + ") is not rank " +
-                          std::to_string(c->rank) + "'s band [" + std::to_string(c->bandBegin[c->rank]) + ", " + std::to_string(c->bandEnd[c->rank]) + ") of gfxh_band_rows";
+                          std::to_string(c->rank) + "'s band [" + std::to_string(c->bandBegin[c->rank]) + ", " + std::to_string(c->bandEnd[c->rank]) + ") of gfxh_band_rows / gfxh_rccl_set_bands";
             return 1;
         }
         const gfxh_exchange_buffer& b = d->buffers[0];
@@ -167,7 +192,7 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
         char* own = static_cast<char*>(c->staging) + slab * c->rank;
         if (hipMemcpyAsync(own, frame + c->bandBegin[c->rank] * rowBytes, (c->bandEnd[c->rank] - c->bandBegin[c->rank]) * rowBytes,
                            hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
-        if (g_rccl.AllGather(own, c->staging, slab, kNcclUint8, c->comm, stream)) return 1;
+        if (g_rccl.AllGather(own, c->staging, slab, kNcclUint8, lane.comm, stream)) return 1;
         for (int r = 0; r < c->world; ++r) {
             if (r == c->rank) continue;
             if (hipMemcpyAsync(frame + c->bandBegin[r] * rowBytes, static_cast<char*>(c->staging) + slab * r,
@@ -177,7 +202,7 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
     }
     if (d->kind == GFXH_EXCHANGE_BROADCAST) {
         for (uint32_t k = 0; k < d->numBuffers; ++k)
-            if (g_rccl.Broadcast(d->buffers[k].base, d->buffers[k].base, d->buffers[k].planeStride, kNcclUint8, 0, c->comm, stream)) return 1;
+            if (g_rccl.Broadcast(d->buffers[k].base, d->buffers[k].base, d->buffers[k].planeStride, kNcclUint8, 0, lane.comm, stream)) return 1;
         return 0;
     }
     if (d->kind == GFXH_EXCHANGE_GATHER_RECORDS) {
@@ -196,7 +221,7 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
         }
         uint32_t* dCounts = static_cast<uint32_t*>(c->staging);
         if (hipMemcpyAsync(dCounts + c->world + c->rank, &hostCounts[0], 4, hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
-        if (g_rccl.AllGather(dCounts + c->world + c->rank, dCounts, 1, kNcclUint32, c->comm, stream)) return 1;
+        if (g_rccl.AllGather(dCounts + c->world + c->rank, dCounts, 1, kNcclUint32, lane.comm, stream)) return 1;
         std::vector<uint32_t> counts(c->world);
         if (hipMemcpyAsync(counts.data(), dCounts, 4 * c->world, hipMemcpyDeviceToHost, stream) != hipSuccess) return 1;
         if (hipStreamSynchronize(stream) != hipSuccess) return 1;
@@ -215,7 +240,7 @@ int gfxh_rccl_exchange(void* user, void* streamPtr, const gfxh_exchange_desc* d)
             char* slabs = static_cast<char*>(c->staging) + headBytes;
             char* base = static_cast<char*>(d->buffers[k].base);
             if (hipMemcpyAsync(slabs + slab * c->rank, base, rec * counts[c->rank], hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
-            if (g_rccl.AllGather(slabs + slab * c->rank, slabs, slab, kNcclUint8, c->comm, stream)) return 1;
+            if (g_rccl.AllGather(slabs + slab * c->rank, slabs, slab, kNcclUint8, lane.comm, stream)) return 1;
             size_t at = 0;
             for (int r = 0; r < c->world; ++r) {
                 if (counts[r] && hipMemcpyAsync(base + at * rec, slabs + slab * r, rec * counts[r], hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;

@@ -55,6 +55,13 @@ struct gfxh_restir {
     void* exchangeUser = nullptr;
     uint32_t maxMotionRows = 0;
     bool viewMoved = false;     // the camera or an instance moved since the last frame (accumulation restarts; band seams need motion rows)
+    // lanes of a band renderer (gfxexp_host.h gfxh_lane): the G-buffer strips travel on gbStream behind the pass that made them
+    // (evGbStrips: they have arrived), the HDR bands on gatherStream underneath the next frame (evBandDone: the frame's last pass is
+    // queued; evGather: the gather has finished)
+    hipEvent_t evGbStrips = nullptr, evBandDone = nullptr, evGather = nullptr;
+    hipStream_t gatherStream = nullptr;
+    bool asyncGather = false, gatherPending = false, gbStripsPending = false;
+    bool stripsOnGbLane = true;   // GFX_GB_STRIPS_ON_MAIN=1 (A/B runs): the G-buffer strips on the caller's stream ahead of the candidate pass, as rounds 2-5 issued them
 };
 
 extern "C" {
@@ -202,9 +209,15 @@ int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir*
     {
         const char* e = std::getenv("GFX_SERIAL_FRAMES");   // debugging aid: everything on the caller's stream
         r->pipelineFrames = !(e && e[0] == '1');
+        const char* m = std::getenv("GFX_GB_STRIPS_ON_MAIN");
+        r->stripsOnGbLane = !(m && m[0] == '1');
         if (!hip_ok(hipStreamCreateWithFlags(&r->gbStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
             !hip_ok(hipEventCreateWithFlags(&r->evPrevRead, hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&r->evGbuffer, hipEventDisableTiming), "hipEventCreate")) {
+            !hip_ok(hipEventCreateWithFlags(&r->evGbuffer, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evGbStrips, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evBandDone, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evGather, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipStreamCreateWithFlags(&r->gatherStream, hipStreamNonBlocking), "hipStreamCreateWithFlags")) {
             gfxh_restir_destroy(r);
             return 1;
         }
@@ -219,7 +232,11 @@ void gfxh_restir_destroy(gfxh_restir* r) {
     if (r->evPrevRead) (void)hipEventDestroy(r->evPrevRead);
     if (r->evConsumed) (void)hipEventDestroy(r->evConsumed);
     if (r->evGbuffer) (void)hipEventDestroy(r->evGbuffer);
+    if (r->evGbStrips) (void)hipEventDestroy(r->evGbStrips);
+    if (r->evBandDone) (void)hipEventDestroy(r->evBandDone);
+    if (r->evGather) (void)hipEventDestroy(r->evGather);
     if (r->gbStream) (void)hipStreamDestroy(r->gbStream);
+    if (r->gatherStream) (void)hipStreamDestroy(r->gatherStream);
     for (void* p : r->allocations) (void)hipFree(p);
     delete r;
 }
@@ -236,6 +253,18 @@ int gfxh_strip_rows(uint32_t height, uint32_t bandBegin, uint32_t bandEnd, uint3
 
 int gfxh_restir_set_exchange(gfxh_restir* r, gfxh_exchange_fn fn, void* user, uint32_t maxMotionRows) {
     r->exchange = fn; r->exchangeUser = user; r->maxMotionRows = maxMotionRows;
+    return 0;
+}
+
+int gfxh_restir_set_async_gather(gfxh_restir* r, int enable) {
+    if (!r) { g_driverError = "gfxh_restir_set_async_gather: null renderer"; return 1; }
+    r->asyncGather = enable != 0;
+    return 0;
+}
+
+int gfxh_restir_finish_gather(gfxh_restir* r, void* stream) {
+    if (!r) { g_driverError = "gfxh_restir_finish_gather: null renderer"; return 1; }
+    if (r->gatherPending && !hip_ok(hipStreamWaitEvent(static_cast<hipStream_t>(stream), r->evGather, 0), "hipStreamWaitEvent")) return 1;
     return 0;
 }
 
@@ -468,21 +497,25 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
     int tooTall = 0;
     uint32_t currentReservoirIndex = (lastReservoirIndex + 1) % 2;  // :2352
     uint32_t baseIndex = lastSpatialNeighborBaseIndex;
-    auto push = [&](uint32_t op, uint32_t pass, uint32_t rb, uint32_t re) -> gfxh_frame_step* {
+    auto push = [&](uint32_t op, uint32_t pass, uint32_t rb, uint32_t re, uint32_t lane = GFXH_LANE_MAIN) -> gfxh_frame_step* {
         if (n >= capacity) return nullptr;
         gfxh_frame_step& st = steps[n++];
         std::memset(&st, 0, sizeof(st));
-        st.op = op; st.pass = pass; st.rowBegin = rb; st.rowEnd = re;
+        st.op = op; st.pass = pass; st.rowBegin = rb; st.rowEnd = re; st.lane = lane;
         st.currentReservoirIndex = currentReservoirIndex; st.spatialNeighborBaseIndex = baseIndex;
         return &st;
     };
-    auto exchange = [&](uint32_t rows, uint32_t buffers, uint32_t reservoirIndex) {
-        if (!strips || rows == 0) return;
+    auto exchange = [&](uint32_t rows, uint32_t buffers, uint32_t reservoirIndex, uint32_t lane = GFXH_LANE_MAIN) {
+        if (!strips || rows == 0) return false;
         gfxh_exchange_desc d;
         if (gfxh_strip_rows(cfg.height, plan.bandBegin, plan.bandEnd, rows, &d)) tooTall = 1;
-        if (gfxh_frame_step* st = push(GFXH_STEP_EXCHANGE_STRIPS, 0, 0, 0)) { st->exchangeRows = rows; st->buffers = buffers; st->reservoirIndex = reservoirIndex; }
+        if (gfxh_frame_step* st = push(GFXH_STEP_EXCHANGE_STRIPS, 0, 0, 0, lane)) { st->exchangeRows = rows; st->buffers = buffers; st->reservoirIndex = reservoirIndex; }
+        return true;
     };
-    auto gather = [&]() { if (strips) push(GFXH_STEP_GATHER_BANDS, 0, plan.bandBegin, plan.bandEnd); };
+    // the all-gather of the HDR bands runs on its own lane underneath the next frame; the pass that writes the beauty buffer
+    // waits for the previous frame's gather first (it has read the band by then)
+    auto beauty_writer = [&]() { if (strips) push(GFXH_STEP_WAIT_PREVIOUS_GATHER, 0, 0, 0); };
+    auto gather = [&]() { if (strips) push(GFXH_STEP_GATHER_BANDS, 0, plan.bandBegin, plan.bandEnd, GFXH_LANE_GATHER); };
     const uint32_t motion = maxMotionRows;
 
     if (cfg.renderer == GFXH_PATH_TRACE_REGIR) {
@@ -490,9 +523,10 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
         // last-access update.  The grid lives in world space: every rank builds all of it (same slot RNGs, same access
         // history) and traces its own rows; the per-cell access counters are summed over the ranks before they age the cells.
         const uint32_t rb = strips ? plan.bandBegin : 0, re = strips ? plan.bandEnd : 0;
-        push(GFXH_STEP_PT_PASS, GFX_PT_SETUP_GBUFFERS, rb, re);
+        push(GFXH_STEP_PT_PASS, GFX_PT_SETUP_GBUFFERS, rb, re, GFXH_LANE_GBUFFER);
         push(GFXH_STEP_PREV_GBUFFER_RELEASED, 0, 0, 0);
         push(GFXH_STEP_PT_PASS, (cfg.regirEnableTemporalReuse && !newSequence) ? GFX_PT_REGIR_BUILD_CELL_RESERVOIRS_TEMPORAL : GFX_PT_REGIR_BUILD_CELL_RESERVOIRS, 0, 0);
+        beauty_writer();
         push(GFXH_STEP_PT_PASS, GFX_PT_PATH_TRACE_REGIR, rb, re);
         if (strips) push(GFXH_STEP_ALLREDUCE_CELL_ACCESSES, 0, 0, 0);
         push(GFXH_STEP_PT_PASS, GFX_PT_REGIR_UPDATE_LAST_ACCESS, 0, 0);
@@ -500,8 +534,9 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
     }
     else if (cfg.renderer == GFXH_PATH_TRACE_BASELINE) {
         // path_tracing_main.cpp:2068-2093: G-buffer pipeline, then pathTraceBaseline.  Paths never read a neighbour's pixel state.
-        push(GFXH_STEP_PT_PASS, GFX_PT_SETUP_GBUFFERS, plan.bandBegin, whole ? 0 : plan.bandEnd);
+        push(GFXH_STEP_PT_PASS, GFX_PT_SETUP_GBUFFERS, plan.bandBegin, whole ? 0 : plan.bandEnd, GFXH_LANE_GBUFFER);
         push(GFXH_STEP_PREV_GBUFFER_RELEASED, 0, 0, 0);
+        beauty_writer();
         push(GFXH_STEP_PT_PASS, GFX_PT_PATH_TRACE_BASELINE, plan.bandBegin, whole ? 0 : plan.bandEnd);
         gather();
     }
@@ -510,13 +545,14 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
         // per-pixel passes run on the band.  A band without an exchange callback renders the whole frame (its halo
         // would need the previous frame's state of other ranks).
         const uint32_t rb = strips ? plan.bandBegin : 0, re = strips ? plan.bandEnd : 0;
-        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SETUP_GBUFFERS, rb, re);                       // :2366-2367
+        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SETUP_GBUFFERS, rb, re, GFXH_LANE_GBUFFER);    // :2366-2367
         const bool T = cfg.enableTemporalReuse && !newSequence, S = cfg.enableSpatialReuse && !newSequence;
         const int k = (T && S) ? 3 : T ? 1 : S ? 2 : 0;
         const uint32_t trace = GFX_RESTIR_TRACE_SHADOW_RAYS + (k == 0 ? 0 : k + (useUnbiasedEstimator ? 3 : 0));
         push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_LIGHT_PRESAMPLING, 0, 0);
         push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_PER_PIXEL_RIS, rb, re);
         push(GFXH_STEP_RESTIR_PASS, trace, rb, re);
+        beauty_writer();
         push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SHADE_AND_RESAMPLE + k, rb, re);
         push(GFXH_STEP_PREV_GBUFFER_RELEASED, 0, 0, 0);   // shadeAndResample reads the previous G-buffer and sample visibility
         // everything the next frame reads as "the previous frame" around a pixel: its temporal neighbour (motion) and
@@ -528,9 +564,12 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
         ++baseIndex;                                                                           // :2486
     }
     else {
-        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SETUP_GBUFFERS, plan.gbufferRows[0], whole ? 0 : plan.gbufferRows[1]);   // :2366-2367
-        // strip mode: the G-buffer rows the spatial passes (radius) and the next frame's temporal pass (motion) read
-        exchange(std::max(cfg.enableSpatialReuse ? radiusRows : 0u, cfg.enableTemporalReuse ? motion : 0u), GFXH_BUF_GBUFFERS, 0);
+        push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SETUP_GBUFFERS, plan.gbufferRows[0], whole ? 0 : plan.gbufferRows[1], GFXH_LANE_GBUFFER);   // :2366-2367
+        // strip mode: the G-buffer rows the spatial passes (radius) and the next frame's temporal pass (motion) read.  They travel on
+        // the G-buffer lane right behind the pass: the candidate + temporal pass of THIS frame reads no neighbour's current G-buffer
+        // (the temporal reprojection reads the PREVIOUS frame's, whose strips arrived a frame ago), so only the first spatial pass
+        // -- or, without one, the end of the frame -- waits for them
+        bool gbStripsInFlight = exchange(std::max(cfg.enableSpatialReuse ? radiusRows : 0u, cfg.enableTemporalReuse ? motion : 0u), GFXH_BUF_GBUFFERS, 0, GFXH_LANE_GBUFFER);
         uint32_t entry = GFX_RESTIR_INITIAL_RIS;                                               // :2378-2384
         if (cfg.enableTemporalReuse && !newSequence)
             entry = useUnbiasedEstimator ? GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED : GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED;
@@ -543,20 +582,27 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
             for (uint32_t i = 0; i < cfg.numSpatialReusePasses; ++i) {
                 // strip mode: the reservoirs this pass resamples from, radius rows either side of the band
                 exchange(radiusRows, GFXH_BUF_RESERVOIRS, currentReservoirIndex);
+                if (gbStripsInFlight) { push(GFXH_STEP_WAIT_GBUFFER_STRIPS, 0, 0, 0); gbStripsInFlight = false; }
                 baseIndex = base0 + cfg.numSpatialNeighbors * i;
                 // the last biased pass and the shading pass (:2418-2420) as one step where they cover the same rows (not the halo
                 // scheme, whose spatial passes run over the halo too): one kernel for a band-sized launch (include/gfxexp.h)
                 const bool last = i + 1 == cfg.numSpatialReusePasses;
                 shadingIssued = last && !useUnbiasedEstimator && plan.spatialRows[i][0] == plan.shadingRows[0] && plan.spatialRows[i][1] == plan.shadingRows[1];
+                if (shadingIssued) beauty_writer();
                 push(GFXH_STEP_RESTIR_PASS, shadingIssued ? static_cast<uint32_t>(GFX_RESTIR_SPATIAL_BIASED_AND_SHADING) : spatial,
                      plan.spatialRows[i][0], whole ? 0 : plan.spatialRows[i][1]);
                 currentReservoirIndex = (currentReservoirIndex + 1) % 2;
             }
             baseIndex = base0 + cfg.numSpatialNeighbors * cfg.numSpatialReusePasses;
         }
-        if (!shadingIssued) push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SHADING, plan.shadingRows[0], whole ? 0 : plan.shadingRows[1]);   // :2418-2420
+        if (!shadingIssued) {
+            beauty_writer();
+            push(GFXH_STEP_RESTIR_PASS, GFX_RESTIR_SHADING, plan.shadingRows[0], whole ? 0 : plan.shadingRows[1]);   // :2418-2420
+        }
         // strip mode: the final reservoirs the next frame's temporal pass reads across the seams
         if (cfg.enableTemporalReuse) exchange(motion, GFXH_BUF_RESERVOIRS, currentReservoirIndex);
+        // no spatial pass waited for the G-buffer strips: the next frame's temporal pass is their first reader
+        if (gbStripsInFlight) push(GFXH_STEP_WAIT_GBUFFER_STRIPS, 0, 0, 0);
         gather();
     }
     *numSteps = n;
@@ -573,7 +619,7 @@ int gfxh_frame_step_exchange_desc(const gfxh_restir_config* cfg, const gfxh_fram
     std::memset(&d, 0, sizeof(d));
     const uint32_t W = cfg->width, H = cfg->height;
     const size_t numPixelsAll = static_cast<size_t>(W) * H;
-    d.stage = stepIndex; d.width = W; d.height = H;
+    d.stage = stepIndex; d.width = W; d.height = H; d.lane = st->lane;
     d.bandBegin = cfg->rowBegin; d.bandEnd = cfg->rowEnd;
     auto add = [&](void* base, uint32_t bytesPerPixel, uint32_t planes) {
         gfxh_exchange_buffer& b = d.buffers[d.numBuffers++];
@@ -697,43 +743,65 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     // whole frame: profiles/r03_band_compute_bound.json.)  The halo-recompute scheme stays serial.
     hipStream_t main = static_cast<hipStream_t>(stream);
     const bool pipelined = r->pipelineFrames && !cfg.enableJittering && (wholeFrame || strips);
+    const bool asyncGather = strips && r->asyncGather && r->pipelineFrames;
     if (cfg.renderer == GFXH_PATH_TRACE_REGIR) DRV_GFX(gfx_regir_set_params(ctx, &r->regir));
+    bool gbWaited = false;      // main has been made to wait for this frame's G-buffer pass
+    auto lane_stream = [&](uint32_t lane) -> hipStream_t {
+        return lane == GFXH_LANE_GBUFFER ? (pipelined ? r->gbStream : main) : lane == GFXH_LANE_GATHER ? (asyncGather ? r->gatherStream : main) : main;
+    };
+    auto exchange_stream = [&](const gfxh_frame_step& st) -> hipStream_t {
+        if (st.op == GFXH_STEP_EXCHANGE_STRIPS && st.lane == GFXH_LANE_GBUFFER && !r->stripsOnGbLane) return main;
+        return lane_stream(st.lane);
+    };
     for (uint32_t k = 0; k < numSteps; ++k) {
         const gfxh_frame_step& st = steps[k];
         switch (st.op) {
         case GFXH_STEP_RESTIR_PASS:
         case GFXH_STEP_PT_PASS: {
-            hipStream_t s = main;
-            const bool gb = (st.op == GFXH_STEP_RESTIR_PASS && st.pass == GFX_RESTIR_SETUP_GBUFFERS) || (st.op == GFXH_STEP_PT_PASS && st.pass == GFX_PT_SETUP_GBUFFERS);
+            hipStream_t s = lane_stream(st.lane);
+            const bool gb = st.lane == GFXH_LANE_GBUFFER;
             if (gb && pipelined) {
-                s = r->gbStream;
                 if (r->prevReadPending) DRV_HIP(hipStreamWaitEvent(s, r->evPrevRead, 0));
                 else { DRV_HIP(hipEventRecord(r->evPrevRead, main)); DRV_HIP(hipStreamWaitEvent(s, r->evPrevRead, 0)); }   // first frame: after whatever the caller queued
                 if (r->consumedPending) { DRV_HIP(hipStreamWaitEvent(s, r->evConsumed, 0)); r->consumedPending = false; }   // gfxh_restir_outputs_consumed
             }
+            if (!gb && pipelined && !gbWaited) { DRV_HIP(hipStreamWaitEvent(main, r->evGbuffer, 0)); gbWaited = true; }
             DRV_GFX(gfx_restir_set_params(ctx, s, &r->sp, &fp, st.currentReservoirIndex, st.spatialNeighborBaseIndex));
             if (st.op == GFXH_STEP_PT_PASS) DRV_GFX(gfx_pt_launch(ctx, s, static_cast<int>(st.pass), W, H, cfg.maxPathLength, st.rowBegin, st.rowEnd));
             else DRV_GFX(gfx_restir_launch_rows(ctx, s, static_cast<int>(st.pass), W, H, st.rowBegin, st.rowEnd));
-            if (gb && pipelined) {
-                DRV_HIP(hipEventRecord(r->evGbuffer, s));
-                DRV_HIP(hipStreamWaitEvent(main, r->evGbuffer, 0));
-            }
+            if (gb && pipelined) DRV_HIP(hipEventRecord(r->evGbuffer, s));
             break;
         }
         case GFXH_STEP_PREV_GBUFFER_RELEASED:   // the frame has queued its last pass that reads the previous frame's G-buffer
             if (pipelined) { DRV_HIP(hipEventRecord(r->evPrevRead, main)); r->prevReadPending = true; }
+            break;
+        case GFXH_STEP_WAIT_GBUFFER_STRIPS:
+            if (pipelined && r->gbStripsPending) { DRV_HIP(hipStreamWaitEvent(main, r->evGbStrips, 0)); r->gbStripsPending = false; }
+            break;
+        case GFXH_STEP_WAIT_PREVIOUS_GATHER:
+            if (r->gatherPending) { DRV_HIP(hipStreamWaitEvent(main, r->evGather, 0)); r->gatherPending = false; }
             break;
         case GFXH_STEP_EXCHANGE_STRIPS:
         case GFXH_STEP_ALLREDUCE_CELL_ACCESSES:
         case GFXH_STEP_GATHER_BANDS: {
             gfxh_exchange_desc d;
             gfxh_frame_step_exchange_desc(&cfg, &st, k, &r->sp, cfg.renderer == GFXH_PATH_TRACE_REGIR ? &r->regir : nullptr, bufferIndex, &d);
-            if (r->exchange(r->exchangeUser, stream, &d)) { g_driverError = "gfxh_restir_render_frame: the exchange callback failed"; return 1; }
+            hipStream_t s = exchange_stream(st);
+            if (s == main) d.lane = GFXH_LANE_MAIN;            // the lane the exchange actually runs on (its communicator)
+            if (s == main && pipelined && !gbWaited) { DRV_HIP(hipStreamWaitEvent(main, r->evGbuffer, 0)); gbWaited = true; }
+            if (st.op == GFXH_STEP_GATHER_BANDS && s != main) {       // behind the frame's last pass
+                DRV_HIP(hipEventRecord(r->evBandDone, main));
+                DRV_HIP(hipStreamWaitEvent(s, r->evBandDone, 0));
+            }
+            if (r->exchange(r->exchangeUser, s, &d)) { g_driverError = "gfxh_restir_render_frame: the exchange callback failed"; return 1; }
+            if (st.op == GFXH_STEP_GATHER_BANDS && s != main) { DRV_HIP(hipEventRecord(r->evGather, s)); r->gatherPending = true; }
+            if (st.op == GFXH_STEP_EXCHANGE_STRIPS && s != main) { DRV_HIP(hipEventRecord(r->evGbStrips, s)); r->gbStripsPending = true; }
             break;
         }
         default: break;
         }
     }
+    if (pipelined && !gbWaited) DRV_HIP(hipStreamWaitEvent(main, r->evGbuffer, 0));   // a program without a pass on the main lane
 #undef DRV_GFX
     r->lastReservoirIndex = newLastRes;                                                        // :2493
     r->lastSpatialNeighborBaseIndex = newLastBase;

@@ -143,11 +143,16 @@ class StripExchange:
                     collective is left running underneath the next frame's kernels and the received bands are put into the
                     frame at the NEXT gather -- until then the other ranks' rows are one frame old -- or by finish(), which
                     a caller in this mode must invoke (with the renderer's stream current) before it reads the frame.
+    Lanes (gfxexp_host.h gfxh_lane): the driver hands every exchange the stream of the lane it belongs to -- the G-buffer strips on
+    the renderer's G-buffer stream, the band gather (gfxh_restir_set_async_gather) on its gather stream.  On a device the callback
+    makes that stream torch's current stream for the call (the collective is ordered with it), and `lane_groups` = {lane: process
+    group} (make_lane_groups) gives each lane its own communicator so that the lanes do not queue behind each other.
     The C++ twin is gfxh_rccl_exchange (csrc/host/rccl_exchange.cpp); both consume the same descriptors."""
 
-    def __init__(self, dist, rank, world, height, view, device="cpu", async_gather=False, bands=None):
+    def __init__(self, dist, rank, world, height, view, device="cpu", async_gather=False, bands=None, lane_groups=None):
         self.dist, self.rank, self.world, self.device = dist, rank, world, device
         self.async_gather = bool(async_gather)
+        self.lane_groups = dict(lane_groups or {})
         self._view, self._views = view, {}
         # `bands`: an explicit partition [(begin, end)] per rank (cost-balanced bands, api.balance_bands) instead of the equal one;
         # every rank must pass the same list.  RestirRenderer.set_exchange then checks THAT partition (api.check_bands).
@@ -166,12 +171,22 @@ class StripExchange:
         return t
 
     def __call__(self, stream, d):
+        import torch
+        if self.device != "cpu" and stream:
+            # the lane's stream (a raw hipStream_t from the driver) is torch's current stream for the call
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))):
+                return self._exchange(d)
+        return self._exchange(d)
+
+    def _exchange(self, d):
         from gfxexp_amd import api
         import torch
         dist = self.dist
+        group = self.lane_groups.get(int(d.lane))
+        kw = {"group": group} if group is not None else {}
         if d.kind == api.EXCHANGE_ALLREDUCE_SUM_U32:
             t = self.view(d.counters, 4 * d.numCounters).view(torch.int32)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, **kw)
             return
         if d.kind == api.EXCHANGE_STRIPS:
             ops = []
@@ -187,11 +202,11 @@ class StripExchange:
                     if self.rank > 0:
                         for t, op in ((rows(d.sendAbove), dist.isend), (rows(d.recvAbove), dist.irecv)):
                             if t is not None:
-                                ops.append(dist.P2POp(op, t, self.rank - 1))
+                                ops.append(dist.P2POp(op, t, self.rank - 1, **kw))
                     if self.rank < self.world - 1:
                         for t, op in ((rows(d.sendBelow), dist.isend), (rows(d.recvBelow), dist.irecv)):
                             if t is not None:
-                                ops.append(dist.P2POp(op, t, self.rank + 1))
+                                ops.append(dist.P2POp(op, t, self.rank + 1, **kw))
             self.bytes_moved += sum(op.tensor.numel() for op in ops)
             if ops:
                 for req in dist.batch_isend_irecv(ops):
@@ -210,7 +225,7 @@ class StripExchange:
             s0, e0 = self.bands[self.rank]
             frame = self.view(b.base, row_bytes * d.height)
             send[:(e0 - s0) * row_bytes].copy_(frame[s0 * row_bytes:e0 * row_bytes])
-            work = dist.all_gather_into_tensor(recv, send, async_op=True)
+            work = dist.all_gather_into_tensor(recv, send, async_op=True, **kw)
             self._pending = (work, frame, row_bytes, slab)
             if not self.async_gather:
                 self.finish()
@@ -221,7 +236,7 @@ class StripExchange:
             counts_host = (ctypes.c_uint32 * 2).from_address(d.counters)
             mine = int(counts_host[0])
             counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
-            dist.all_gather_into_tensor(counts, torch.tensor([mine], dtype=torch.int64, device=self.device))
+            dist.all_gather_into_tensor(counts, torch.tensor([mine], dtype=torch.int64, device=self.device), **kw)
             counts = [int(c) for c in counts.cpu()]
             total = sum(counts)
             if total > d.numCounters:
@@ -235,7 +250,7 @@ class StripExchange:
                 recv = torch.zeros(most * rec * self.world, dtype=torch.uint8, device=self.device)
                 whole = self.view(d.buffers[k].base, d.numCounters * rec)
                 send[:mine * rec].copy_(whole[:mine * rec])
-                dist.all_gather_into_tensor(recv, send)
+                dist.all_gather_into_tensor(recv, send, **kw)
                 at = 0
                 for r, c in enumerate(counts):
                     whole[at * rec:(at + c) * rec].copy_(recv[r * most * rec:r * most * rec + c * rec])
@@ -245,7 +260,7 @@ class StripExchange:
             return
         if d.kind == api.EXCHANGE_BROADCAST:
             for k in range(d.numBuffers):
-                dist.broadcast(self.view(d.buffers[k].base, d.buffers[k].planeStride), src=0)
+                dist.broadcast(self.view(d.buffers[k].base, d.buffers[k].planeStride), src=0, **kw)
             return
         raise ValueError("unknown exchange kind %d" % d.kind)
 
@@ -261,6 +276,12 @@ class StripExchange:
         for r, (rs, re) in enumerate(self.bands):
             if r != self.rank:
                 frame[rs * row_bytes:re * row_bytes].copy_(recv[r * slab:r * slab + (re - rs) * row_bytes])
+
+
+def make_lane_groups(dist, lanes=(1, 2)):
+    """One extra process group (= one more RCCL communicator and stream) per lane beyond MAIN; every rank must call this at the same
+    point.  {lane: group} for StripExchange(lane_groups=...)."""
+    return {int(lane): dist.new_group() for lane in lanes}
 
 
 class HostStaged:
@@ -288,7 +309,7 @@ class HostStaged:
     def irecv(self, *a, **k):
         raise NotImplementedError
 
-    def P2POp(self, op, tensor, peer):
+    def P2POp(self, op, tensor, peer, group=None):
         return HostStaged._Op("send" if op == self.isend else "recv", tensor, peer)
 
     def batch_isend_irecv(self, ops):
@@ -312,20 +333,20 @@ class HostStaged:
                         dst.copy_(h)
         return [_Req()]
 
-    def all_reduce(self, t, op=None, async_op=False):
+    def all_reduce(self, t, op=None, async_op=False, group=None):
         h = t.cpu()
         self._d.all_reduce(h, op=op if op is not None else self.ReduceOp.SUM)
         t.copy_(h)
         return HostStaged._Done()
 
-    def all_gather_into_tensor(self, out, inp, async_op=False):
+    def all_gather_into_tensor(self, out, inp, async_op=False, group=None):
         import torch
         ho = torch.empty(out.shape, dtype=out.dtype)
         self._d.all_gather_into_tensor(ho, inp.cpu())
         out.copy_(ho)
         return HostStaged._Done()
 
-    def broadcast(self, t, src=0):
+    def broadcast(self, t, src=0, group=None):
         h = t.cpu()
         self._d.broadcast(h, src=src)
         t.copy_(h)

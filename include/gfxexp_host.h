@@ -224,9 +224,21 @@ typedef struct gfxh_exchange_buffer {
     uint32_t numPlanes;       /* reservoirs: 3 planes of 16 B */
     uint64_t planeStride;     /* bytes between planes */
 } gfxh_exchange_buffer;
+/* The streams of a renderer ("lanes").  A band renderer issues every exchange on the lane whose work it belongs to, so that an
+ * exchange never waits behind kernels it does not depend on and nothing waits for an exchange it does not read:
+ *   MAIN     the caller's stream: the reuse passes and the reservoir strips between them
+ *   GBUFFER  the renderer's G-buffer stream: the G-buffer pass of frame N + 1 runs underneath frame N's reuse passes, and so does
+ *            the exchange of its strips (the candidate pass reads no neighbour's G-buffer; only the spatial passes wait for them)
+ *   GATHER   the renderer's gather stream: the all-gather of the HDR bands runs underneath the NEXT frame (nothing of that frame
+ *            reads other ranks' pixels; its shading pass waits for the gather to have read the band it overwrites)
+ * A transport that keeps one communicator per lane (gfxh_rccl_create_lanes; a process group per lane in tilesplit.StripExchange)
+ * lets the three run concurrently; with one communicator they still run, in issue order. */
+enum gfxh_lane { GFXH_LANE_MAIN = 0, GFXH_LANE_GBUFFER = 1, GFXH_LANE_GATHER = 2, GFXH_NUM_LANES = 3 };
 typedef struct gfxh_exchange_desc {
     uint32_t kind;                       /* enum gfxh_exchange_kind */
     uint32_t stage;                      /* ordinal of the exchange point inside the frame (diagnostics) */
+    uint32_t lane;                       /* enum gfxh_lane: `stream` of the callback is that lane's stream */
+    uint32_t reserved;
     uint32_t width, height;
     uint32_t bandBegin, bandEnd;
     uint32_t sendAbove[2], recvAbove[2], sendBelow[2], recvBelow[2];   /* STRIPS: row ranges [begin, end) */
@@ -236,6 +248,13 @@ typedef struct gfxh_exchange_desc {
 } gfxh_exchange_desc;
 typedef int (*gfxh_exchange_fn)(void* user, void* stream, const gfxh_exchange_desc* desc);
 int gfxh_restir_set_exchange(gfxh_restir* r, gfxh_exchange_fn fn, void* user, uint32_t maxMotionRows);
+/* The all-gather of the HDR bands on the renderer's gather stream, underneath the next frame (lane GATHER above).  Off (the default):
+ * the gather is issued on the caller's stream and the frame buffer holds every rank's rows of THIS frame when that stream has passed
+ * gfxh_restir_render_frame's work.  On: other ranks' rows arrive while the next frame renders; a reader of the whole frame first calls
+ * gfxh_restir_finish_gather(r, stream), which makes `stream` wait for the outstanding gather (a bench loop calls it once, after the
+ * last frame). */
+int gfxh_restir_set_async_gather(gfxh_restir* r, int enable);
+int gfxh_restir_finish_gather(gfxh_restir* r, void* stream);
 /* Row ranges of a strip exchange of `rows` rows for the band [bandBegin, bandEnd) of a frame of `height` rows, into
  * the send* / recv* members of `out` (nothing is sent above row 0 / below the last row).  Returns 1 when `rows`
  * exceeds the band height of this rank: the strip would have to come from a rank further away. */
@@ -262,12 +281,19 @@ int gfxh_balance_bands(uint32_t height, uint32_t world, const uint32_t* bandBegi
                        uint32_t* bandBeginOut);
 /* An exchange callback over RCCL for C++ host programs (librccl is loaded with dlopen on first use; one process per
  * GPU).  Create with the ncclUniqueId bytes rank 0 obtained from gfxh_rccl_unique_id and distributed its own way.  It exchanges
- * the DEFAULT partition (gfxh_band_rows): gfxh_rccl_create fails when that leaves a rank without a band (more ranks than 8-row
- * tiles), and a renderer whose band is not its rank's default one -- the cost-balanced bands of gfxh_balance_bands -- is refused
- * at the first gather; those partitions go through a caller-supplied exchange (tilesplit.StripExchange(bands=...)). */
+ * the DEFAULT partition (gfxh_band_rows) unless gfxh_rccl_set_bands names another: gfxh_rccl_create fails when the default leaves a
+ * rank without a band (more ranks than 8-row tiles), and a renderer whose band is not its rank's band of the partition in force is
+ * refused at the first gather. */
 typedef struct gfxh_rccl gfxh_rccl;
 int gfxh_rccl_unique_id(void* id128);
 int gfxh_rccl_create(const void* id128, int rank, int world, uint32_t height, gfxh_rccl** out);
+/* One communicator per lane (enum gfxh_lane): `ids` = numLanes x 128 bytes, each from its own gfxh_rccl_unique_id call on rank 0
+ * (1 <= numLanes <= GFXH_NUM_LANES; a lane beyond numLanes shares communicator 0).  With three, the G-buffer strips, the reservoir
+ * strips and the band gather never queue behind each other. */
+int gfxh_rccl_create_lanes(const void* ids, uint32_t numLanes, int rank, int world, uint32_t height, gfxh_rccl** out);
+/* Another partition than gfxh_band_rows' (the cost-balanced bands of gfxh_balance_bands): bandBegin = world + 1 ascending rows from 0
+ * to the image height, the same on every rank.  The renderers' cfg.rowBegin / rowEnd must be this partition's. */
+int gfxh_rccl_set_bands(gfxh_rccl* c, const uint32_t* bandBegin);
 void gfxh_rccl_destroy(gfxh_rccl* c);
 int gfxh_rccl_exchange(void* user /* gfxh_rccl* */, void* stream, const gfxh_exchange_desc* desc);
 const char* gfxh_rccl_last_error(void);
@@ -281,7 +307,9 @@ enum gfxh_step_op {
     GFXH_STEP_EXCHANGE_STRIPS = 2,        /* exchangeRows rows of `buffers` (reservoirs: those of reservoirIndex) */
     GFXH_STEP_ALLREDUCE_CELL_ACCESSES = 3,
     GFXH_STEP_GATHER_BANDS = 4,
-    GFXH_STEP_PREV_GBUFFER_RELEASED = 5   /* the frame no longer reads the previous frame's G-buffer (frame pipelining) */
+    GFXH_STEP_PREV_GBUFFER_RELEASED = 5,  /* the frame no longer reads the previous frame's G-buffer (frame pipelining) */
+    GFXH_STEP_WAIT_GBUFFER_STRIPS = 6,    /* the next pass reads the neighbours' G-buffer rows: MAIN waits for the exchange issued on GBUFFER */
+    GFXH_STEP_WAIT_PREVIOUS_GATHER = 7    /* the next pass overwrites the HDR band the previous frame's gather (lane GATHER) sends */
 };
 enum gfxh_exchange_buffers { GFXH_BUF_GBUFFERS = 1 /* GBuffer 0, 2, 3 of the frame */, GFXH_BUF_RESERVOIRS = 2 /* + ReservoirInfo */, GFXH_BUF_SAMPLE_VISIBILITY = 4 };
 typedef struct gfxh_frame_step {
@@ -289,6 +317,7 @@ typedef struct gfxh_frame_step {
     uint32_t rowBegin, rowEnd;                                 /* 0, 0 = all rows */
     uint32_t currentReservoirIndex, spatialNeighborBaseIndex;  /* launch parameters in force for a pass */
     uint32_t exchangeRows, buffers, reservoirIndex;            /* GFXH_STEP_EXCHANGE_STRIPS */
+    uint32_t lane;                                             /* enum gfxh_lane the step is issued on (a program run in list order, as the CPU tests do, is one valid schedule) */
 } gfxh_frame_step;
 int gfxh_restir_frame_program(const gfxh_restir_config* cfg, int stripMode, uint32_t maxMotionRows, int newSequence,
                               uint32_t lastReservoirIndex, uint32_t lastSpatialNeighborBaseIndex, uint32_t useUnbiasedEstimator,
@@ -405,6 +434,15 @@ int gfxh_save_image_sdr(const char* path, uint32_t width, uint32_t height, const
 int gfxh_save_image_hdr(const char* path, uint32_t width, uint32_t height, float brightnessScale, const float* rgba, int flipY);
 /* The 8-bit pixels gfxh_save_image_sdr would write (R | G << 8 | B << 16 | A << 24, common_host.cpp:2886-2890). */
 void gfxh_tonemap_sdr(uint32_t width, uint32_t height, const float* rgba, const gfxh_sdr_config* cfg, uint32_t* out);
+
+/* ---- the ABI as the compiler sees it -------------------------------------------------------------------------------
+ * Layout of every struct of gfxexp.h / gfxexp_host.h in the library as built: a binding that mirrors the structs by hand
+ * (ctypes, cgo, JNI) asserts itself against these instead of against a second hand-written copy.  gfxh_abi_layout: fieldName NULL
+ * -> sizeof(struct) in *size (offset 0); otherwise offsetof / sizeof of the field.  Returns 1 for an unknown struct or field.
+ * gfxh_abi_entry enumerates the table (a struct's own entry has fieldName NULL and precedes its fields, in declaration order). */
+int gfxh_abi_layout(const char* structName, const char* fieldName, uint64_t* offset, uint64_t* size);
+uint32_t gfxh_abi_num_entries(void);
+int gfxh_abi_entry(uint32_t index, const char** structName, const char** fieldName, uint64_t* offset, uint64_t* size);
 
 #ifdef __cplusplus
 }

@@ -29,13 +29,52 @@ def test_every_declared_symbol_is_exported(built_lib):
     assert built_lib.gfx_version().decode().endswith("gfx950")
 
 
-def test_struct_layouts_match_between_product_and_oracle_bindings():
+def test_ctypes_mirrors_match_the_compiled_headers(built_lib):
+    """Every ctypes class of api.py against sizeof / offsetof of the struct it mirrors AS COMPILED into libgfxexp.so
+    (gfxh_abi_layout, csrc/host/abi_layout.cpp): same field names in the same order, same offsets and sizes, same total size.
+    A one-field edit of include/gfxexp.h or include/gfxexp_host.h fails here by struct and field name."""
+    layout = api.abi_layout()
+    mirrors = api.abi_mirrors()
+    assert set(mirrors) <= set(layout)
+    for name, cls in mirrors.items():
+        want = layout[name]
+        got = [(f[0].rstrip("_"), getattr(cls, f[0]).offset, getattr(cls, f[0]).size) for f in cls._fields_]
+        assert got == want["fields"], f"{name}: api.py {cls.__name__} differs from the header: {[g for g, w in zip(got, want['fields']) if g != w][:3] or (len(got), len(want['fields']))}"
+        assert C.sizeof(cls) == want["size"], f"{name}: sizeof {C.sizeof(cls)} in api.py, {want['size']} in the library"
+    # the numpy record types of the G-buffer / hit / vertex arrays
+    for name, dt in (("gfx_vertex", api.VERTEX_DTYPE), ("gfx_gbuffer0", api.GBUFFER0_DTYPE), ("gfx_gbuffer2", api.GBUFFER2_DTYPE),
+                     ("gfx_gbuffer3", api.GBUFFER3_DTYPE), ("gfx_hit", api.HIT_DTYPE), ("gfx_tri_ids", api.TRI_IDS_DTYPE)):
+        want = layout[name]
+        assert dt.itemsize == want["size"], name
+        assert [(n, dt.fields[n][1], dt.fields[n][0].itemsize) for n in dt.names] == want["fields"], name
+    # the lookup form, and its failure modes
+    off, size = C.c_uint64(), C.c_uint64()
+    assert built_lib.gfxh_abi_layout(b"gfxh_exchange_desc", b"lane", C.byref(off), C.byref(size)) == 0 and (off.value, size.value) == (8, 4)
+    assert built_lib.gfxh_abi_layout(b"gfx_material", None, C.byref(off), C.byref(size)) == 0 and size.value == 80
+    assert built_lib.gfxh_abi_layout(b"gfx_material", b"no_such_field", C.byref(off), C.byref(size)) == 1
+    assert built_lib.gfxh_abi_layout(b"no_such_struct", None, C.byref(off), C.byref(size)) == 1
+
+
+def test_a_drifted_mirror_is_caught_by_name(built_lib):
+    """The check above does catch a one-field drift: a copy of GfxhFrameStep without its last field, and one with two fields swapped."""
+    layout = api.abi_layout()["gfxh_frame_step"]
+
+    class Short(C.Structure):
+        _fields_ = api.GfxhFrameStep._fields_[:-1]
+
+    class Swapped(C.Structure):
+        _fields_ = [api.GfxhFrameStep._fields_[1], api.GfxhFrameStep._fields_[0]] + api.GfxhFrameStep._fields_[2:]
+    assert C.sizeof(Short) != layout["size"]
+    got = [(f[0].rstrip("_"), getattr(Swapped, f[0]).offset, getattr(Swapped, f[0]).size) for f in Swapped._fields_]
+    assert got != layout["fields"] and C.sizeof(Swapped) == layout["size"]
+
+
+def test_oracle_bindings_mirror_the_same_structs():
+    """The checker's own ctypes classes (oracle/oracle.py, over liboracle.so's copies of the structs) keep the product's layout."""
     for a, b in ((api.GfxMaterial, O.GfxMaterial), (api.GfxCamera, O.GfxCamera),
                  (api.GfxRestirStaticParams, O.GfxRestirStaticParams), (api.GfxRestirFrameParams, O.GfxRestirFrameParams)):
         assert C.sizeof(a) == C.sizeof(b)
         assert [f[0] for f in a._fields_] == [f[0] for f in b._fields_]
-    assert C.sizeof(api.GfxMaterial) == 80 and api.VERTEX_DTYPE.itemsize == 44
-    assert api.GBUFFER0_DTYPE.itemsize == 16 and api.GBUFFER2_DTYPE.itemsize == 16 and api.GBUFFER3_DTYPE.itemsize == 16
 
 
 def test_context_creation_fails_loudly_without_gpu(built_lib):

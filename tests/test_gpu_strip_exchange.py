@@ -2,6 +2,8 @@
 bit.  Three bands on one GPU, one host thread each, exchanging through tests/loopback.py: the C++ frame loop, its
 exchange descriptors and the band-limited kernels are the production code; only the transport differs from the RCCL
 callbacks (whose descriptor handling the world-2 gloo tests cover: tests/test_tilesplit_gloo.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -328,3 +330,16 @@ def test_bench_frame_loop_with_two_ranks_on_one_gpu(built_lib, flags):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["ms_per_step"] > 0
     assert "row-bands x2" in d["config"]["parallelism"] and d["config"]["bands"] is not None and len(d["config"]["bands"]) == 2
     assert d["config"]["bands"][0][0] == 0 and d["config"]["bands"][0][1] == d["config"]["bands"][1][0] and d["config"]["bands"][1][1] == d["config"]["height"]
+
+
+@pytest.mark.gpu
+def test_lane_schedules_compute_the_same_frames(built_lib):
+    """G-buffer strips on the G-buffer lane, band gather on the gather lane, injected latency: bit-identical to the one-stream schedule
+    (tests/lane_schedule_check.py, its own process: it names the mirror librccl stand-in)."""
+    import subprocess
+    import sys
+    from tests.native import build as native_build
+    native_build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "lane_schedule_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
