@@ -483,11 +483,15 @@ def run_config(args, rank, local_rank, world, dist):
                    "width": W, "height": H, "spp": 1, "parallelism": (f"row-bands x{world}" + (" on ONE device, host-staged gloo (GFX_BENCH_ONE_GPU: a functional check, not a measurement)" if os.environ.get("GFX_BENCH_ONE_GPU") == "1" else "")) if world > 1 else "single GPU",
                    "bands": bands, "exchange": transport, "band_gather": (None if world == 1 else "caller's stream" if args.sync_gather else "gather lane, underneath the next frame"),
                    "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]} if accel_stats else None,
-                   "light_table": ctx.lights_table_info()},
+                   "light_table": ctx.lights_table_info(),
+                   # scene.setupLightInstDistribution runs every frame in the reference (restir_di_main.cpp:2303-2309); here the call is made
+                   # every frame and returns early while no instance has moved (lights.hip: instDistValid) -- same values, about 0.04 ms not spent
+                   "light_inst_distribution": "rebuilt every frame (an emitter instance moves)" if args.animate else "cached (static scene): built once, the per-frame call returns early"},
         "setup_s": round(setup_s, 2),
     }
 
     if rank == 0 and world == 1:
+        result["gpu_bvh_build_ms"] = gpu_bvh_build_ms(ctx, stream)
         if not args.no_roofline:
             ctx.tunable_set("pt_overlap", 0)          # per-kernel durations: kernels that share the GPU with another stream read longer than they are
             if args.config == 3:
@@ -511,6 +515,7 @@ def run_config(args, rank, local_rank, world, dist):
         if args.cpu_sample not in ("0", ""):
             if args.config in (2, 4) and not args.animate:
                 result["cpu_baseline"] = cpu_baseline(hs, cam, args.cpu_sample, W, H, unbiased=args.config == 4, env=(sky, 2048, 1024, 0.6, 0.4) if args.config == 4 else None)
+                result["cpu_baseline"]["gpu_bvh_build_ms"] = result["gpu_bvh_build_ms"]      # beside builds.*.bvh_build_s (the CPU SAH build, seconds)
             elif args.config == 1:
                 result["cpu_baseline"] = cpu_baseline_path_tracer(hs, cam, W, H)
             else:
@@ -519,6 +524,21 @@ def run_config(args, rank, local_rank, world, dist):
     renderer.close()
     ctx.close()
     return result
+
+
+def gpu_bvh_build_ms(ctx, stream):
+    """The HIP LBVH -> SAH-DP BVH8 build of the uploaded scene (csrc/lbvh.hip), the GPU side of SURVEY 8(d)'s "CPU SAH vs HIP LBVH build
+    times side by side": wall time of gfx_accel_build into a NEW handle, host-paired (synchronise, build, synchronise) -- the first
+    build of the run also allocates the builder's scratch, the following ones are what a rebuild costs."""
+    import torch
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.accel_build(stream)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    return {"first_ms": round(times[0], 3), "warm_ms": round(min(times[1:]), 3), "how": "gfx_accel_build into a new handle, host-paired wall time; warm = best of two with the builder's scratch allocated"}
 
 
 def roofline(ctx, renderer, stream, steps, W, H, config=2, animate=False):
@@ -615,6 +635,10 @@ def roofline(ctx, renderer, stream, steps, W, H, config=2, animate=False):
             "frac_of_peak_measured_read_only": round(achieved / peak_read_only, 4) if peak_read_only else None,
             "valu": valu,
             "traffic": traffic,
+            # the three fractions of the 8 TB/s HBM roof side by side: `frac_nominal_hbm` prices the algorithmic bytes (every node and triangle
+            # fetch as if it came from HBM), `frac_hbm_counter` the bytes the memory-side counters saw (the BVH is served from L2 / Infinity
+            # Cache), `frac` the figure that binds (VALU issue x lanes carrying a ray)
+            "frac_hbm_counter": round(traffic / (trav_ms / max(trav_launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
             "traffic_source": (traffic_file + ": HBM bytes per launch by PMC (FETCH_SIZE / WRITE_SIZE passes of this configuration's bench command), mean over the k_trace<any> launches") if traffic_file else None,
             "node_visits_per_ray": {"primary": round(nodes_per_primary, 3),
                                     "shadow": round(c["any"]["nodeFetches"] / max(1, rays_any), 3),

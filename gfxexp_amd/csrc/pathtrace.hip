@@ -717,6 +717,85 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel,
     *beauty = make_float4(result.x, result.y, result.z, 1.0f);
 }
 
+// k_pt_fused with path regeneration.  In k_pt_fused a lane whose path has ended idles until the longest path of its wave has: 0.30
+// lanes per instruction on the 512 x 512 bunny frame (profiles/r05_pmc_config1.json: most pixels miss or end after one or two vertices,
+// a few run to the length limit).  Here the launch is the waves the GPU holds at once, and a lane whose path has ended writes its pixel
+// and draws the next launch slot from a ticket counter (one wave-aggregated atomic per refill), takes that pixel's first vertex from
+// the G-buffer and joins the wave's next trace: the wave keeps full lanes until the ticket runs out.  A pixel's path is the same
+// sequence of operations on the same RNG stream whichever lane runs it and whenever: the frame is bit-identical to k_pt_fused's.
+// Baseline path tracer only (the ReGIR tracer merges its cell-access atomics across lanes that are at the same vertex).
+__global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel, uint2* spill, int spillCap, uint32_t maxPathLength,
+                                                       uint32_t* __restrict__ ticket, uint32_t numSlots) {
+    __shared__ uint2 ldsStack[kLdsStackDepth * kPtBlock];
+    __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kPtBlock / 64) * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint2* stackLds = ldsStack + tid;
+    uint2* stackSpill = spill + (static_cast<size_t>(blockIdx.x) * kPtBlock + tid) * spillCap;
+    PixelId px; px.p = 0; px.x = 0; px.y = 0; px.slot = 0; px.valid = false;
+    PtPath path;
+    reset_vertex_out(path.o);
+    path.alpha = f3(0.0f); path.contribution = f3(0.0f); path.dirPDensity = 0.0f; path.rng.state = 0; path.pos = f3(0.0f);
+    bool active = false, rngMoved = false, exhausted = false;
+    uint32_t pathLength = 2;
+    for (;;) {
+        if (!exhausted) {                                       // wave-uniform
+            const unsigned long long need = __ballot(!active);
+            if (need != 0ull) {
+                const uint32_t count = static_cast<uint32_t>(__popcll(need));
+                uint32_t base = 0;
+                if (lane == __builtin_ctzll(need)) base = atomicAdd(ticket, count);
+                base = __shfl(base, __builtin_ctzll(need));
+                if (!active) {
+                    const uint32_t slot = base + static_cast<uint32_t>(__popcll(need & ((1ull << lane) - 1ull)));
+                    if (slot < numSlots) {
+                        px = pixel_of_block_thread(a.px, slot >> 8, slot & 255u);      // (kPtBlock = 256 slots per launch block)
+                        rngMoved = pt_first_vertex<false>(a, px, path);
+                        pathLength = 2;
+                        active = true;
+                    }
+                }
+                exhausted = base + count >= numSlots;
+            }
+        }
+        if (__ballot(active) == 0ull) break;
+        const bool nee = active && path.o.wantNee;
+        const RayHit shadow = trace_wave_local<true>(accel, nee, path.o.neeFromOrg ? path.o.neeOrg : path.pos, path.o.neeDir, 0.0f, path.o.neeTmax,
+                                                     stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane);
+        if (nee) {                                              // k_pt_apply_nee
+            f3 add = path.o.pending;
+            if (shadow.tri != GFX_INVALID_SLOT) add = add * 0.0f;
+            path.contribution = path.contribution + add;
+        }
+        bool done = active && !path.o.wantExt;
+        const bool extend = active && path.o.wantExt;
+        if (__ballot(extend) != 0ull) {
+            const f3 rayOrg = path.pos, rayDir = path.o.extDir;
+            const RayHit hit = trace_wave_local<false>(accel, extend, rayOrg, rayDir, 0.0f, 3.402823466e+38f, stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane);
+            if (extend) {
+                gfx_hit h; h.dist = hit.t; h.bcB = hit.bcB; h.bcC = hit.bcC; h.triIndex = hit.tri;
+                const bool lastVertex = pathLength >= maxPathLength;
+                if (pt_next_vertex<false>(a, true, h, rayOrg, rayDir, nullptr, path, lastVertex ? 1 : 0, pathLength + 1 >= maxPathLength ? 1 : 0) & kPtHitSurface) rngMoved = true;
+                if (lastVertex) done = true;
+                ++pathLength;
+            }
+        }
+        if (done) {
+            if (px.valid) {
+                const size_t p = px.p;
+                if (rngMoved) static_cast<uint64_t*>(a.s.rngBuffer)[p] = path.rng.state;
+                float4* beauty = static_cast<float4*>(a.s.beautyAccumBuffer) + p;      // k_pt_finish
+                f3 prev(0.0f);
+                if (a.f.numAccumFrames > 0) { const float4 bb = *beauty; prev = f3(bb.x, bb.y, bb.z); }
+                const float curWeight = 1.0f / (1 + a.f.numAccumFrames);
+                const f3 result = (1 - curWeight) * prev + curWeight * path.contribution;
+                *beauty = make_float4(result.x, result.y, result.z, 1.0f);
+            }
+            active = false;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- neural radiance caching (render side)
 // neural_radiance_caching/gpu_kernels/optix_pathtracing_kernels.cu + nrc_setup_kernels.cu on the
 // same wavefront pipeline.  Training-record indices come from one wave-aggregated atomicAdd per
@@ -1395,7 +1474,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
     if (nrc) { ctx.nrcState.reserve(32 * numPixels); ctx.neeTrainIdx.reserve(4 * numPixels); }
     ctx.smallCounters.reserve(kSmallCountersBytes);
     uint32_t* counters = ctx.smallCounters.as<uint32_t>() + 8;   // [0] nee (even bounces), [1] ext ping, [2] ext pong, [3] nee (odd bounces)
-    GFX_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream));
+    GFX_HIP(hipMemsetAsync(counters, 0, 5 * sizeof(uint32_t), stream));   // [4]: the slot ticket of k_pt_regen
     uint32_t* const neeCounts[2] = { counters, counters + 3 };
 
     // The NEE trace of a bounce (any-hit) and the kernel that applies its result touch the NEE queue, the occlusion words and the
@@ -1462,6 +1541,17 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         const bool small = launchWaves <= waveSlots + waveSlots / 2;
         if (!nrc && !ctx.countersEnabled && spillBytes <= (size_t(1) << 30) && (ctx.tune.fusePasses == 2 || (ctx.tune.fusePasses == 0 && small))) {
             ctx.spill.reserve(spillBytes);
+            // Path regeneration (k_pt_regen): when the launch is more blocks than the GPU holds at once, launch what it holds and let the
+            // lanes draw pixels until none are left ("pt_regen": resident blocks per CU, 0 = off)
+            const uint32_t regenBlocks = static_cast<uint32_t>(ctx.tune.ptRegen) * static_cast<uint32_t>(ctx.numCUs);
+            if (!regir && ctx.tune.ptRegen > 0 && a.px.launchBlocks > regenBlocks) {
+                a.px.order = nullptr;
+                ScopedKernelTimer timer(ctx, stream, "pt_regen");
+                hipLaunchKernelGGL(k_pt_regen, dim3(regenBlocks), dim3(kPtBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap, maxPathLength,
+                                   counters + 4, a.px.launchBlocks * static_cast<uint32_t>(kPtBlock));
+                GFX_HIP(hipGetLastError());
+                return;
+            }
             // 159 VGPRs: three blocks per CU are resident, so a 512 x 512 frame (1 024 blocks) is already more than one round
             const uint32_t* order = nullptr;
             uint32_t* cost = nullptr;

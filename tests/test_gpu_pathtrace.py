@@ -9,11 +9,13 @@ from oracle import oracle as O
 from tests import util
 
 
-def run_pt_both(hs, width, height, frames=2, max_len=5, camera=None, env=None, jitter=0, env_rotation=0.0, rows=None, fuse=None):
+def run_pt_both(hs, width, height, frames=2, max_len=5, camera=None, env=None, jitter=0, env_rotation=0.0, rows=None, fuse=None, regen=None):
     import torch
     ctx = api.Context(0)
     if fuse is not None:
         ctx.tunable_set("fuse_passes", fuse)
+    if regen is not None:
+        ctx.tunable_set("pt_regen", regen)
     hs.upload(ctx)
     accel = ctx.accel_build()
     ctx.lights_build_static()
@@ -63,6 +65,19 @@ def test_wavefront_and_one_kernel_forms_of_the_path_tracer(built_lib, fuse):
     sky = api.env_make_sky(64, 32)
     diffs = run_pt_both(util.small_street(), 160, 96, frames=3, max_len=6, camera=api.make_camera(160, 96, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0),
                         env=(sky, 64, 32), env_rotation=0.4, fuse=fuse)
+    assert not diffs, "\n".join(diffs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regen,max_len", [(1, 6), (1, 1), (2, 3), (0, 6)])
+def test_path_regeneration_changes_no_pixel(built_lib, regen, max_len):
+    """k_pt_regen: a launch of `regen` blocks per CU whose lanes draw pixels from a ticket until none are left (what configs[1] runs),
+    against the oracle -- 352 x 256 is more blocks than one (two) per CU, so lanes do regenerate; regen 0 keeps k_pt_fused covered.
+    Street scene with an environment map, accumulation over three frames; path length 1 = the forced single extension."""
+    sky = api.env_make_sky(64, 32)
+    w, h = (352, 256) if regen < 2 else (640, 400)
+    diffs = run_pt_both(util.small_street(), w, h, frames=3, max_len=max_len, camera=api.make_camera(w, h, pos=(2.0, 5.0, 26.0), pitch=6.0, yaw=184.0),
+                        env=(sky, 64, 32), env_rotation=0.4, fuse=2, regen=regen)
     assert not diffs, "\n".join(diffs)
 
 
