@@ -136,7 +136,8 @@ class GfxhRestirConfig(C.Structure):
 class GfxhFrameStep(C.Structure):
     _fields_ = [("op", C.c_uint32), ("pass_", C.c_uint32), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32),
                 ("currentReservoirIndex", C.c_uint32), ("spatialNeighborBaseIndex", C.c_uint32),
-                ("exchangeRows", C.c_uint32), ("buffers", C.c_uint32), ("reservoirIndex", C.c_uint32), ("lane", C.c_uint32)]
+                ("exchangeRows", C.c_uint32), ("buffers", C.c_uint32), ("reservoirIndex", C.c_uint32), ("lane", C.c_uint32),
+                ("gapBegin", C.c_uint32), ("gapEnd", C.c_uint32)]
 
 
 class GfxhExchangeBuffer(C.Structure):
@@ -154,8 +155,8 @@ class GfxhExchangeDesc(C.Structure):
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(GfxhExchangeDesc))
 EXCHANGE_STRIPS, EXCHANGE_ALLREDUCE_SUM_U32, EXCHANGE_GATHER_BANDS, EXCHANGE_GATHER_RECORDS, EXCHANGE_BROADCAST = 0, 1, 2, 3, 4
 (STEP_RESTIR_PASS, STEP_PT_PASS, STEP_EXCHANGE_STRIPS, STEP_ALLREDUCE_CELL_ACCESSES, STEP_GATHER_BANDS, STEP_PREV_GBUFFER_RELEASED,
- STEP_WAIT_GBUFFER_STRIPS, STEP_WAIT_PREVIOUS_GATHER) = range(8)
-LANE_MAIN, LANE_GBUFFER, LANE_GATHER, NUM_LANES = 0, 1, 2, 3
+ STEP_WAIT_GBUFFER_STRIPS, STEP_WAIT_PREVIOUS_GATHER, STEP_WAIT_SEAM_STRIPS) = range(9)
+LANE_MAIN, LANE_GBUFFER, LANE_GATHER, LANE_SEAM, NUM_LANES = 0, 1, 2, 3, 4
 BUF_GBUFFERS, BUF_RESERVOIRS, BUF_SAMPLE_VISIBILITY = 1, 2, 4
 
 
@@ -313,7 +314,7 @@ C_ABI_SYMBOLS = [
     "gfx_accel_build",
     "gfx_accel_set_max_leaf", "gfx_accel_stats", "gfx_accel_tri_ids", "gfx_lights_build_static",
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_lights_table_info", "gfx_trace", "gfx_trace_counted", "gfx_restir_set_params", "gfx_restir_copy_to_linear", "gfx_visualize", "gfx_restir_launch",
-    "gfx_restir_launch_rows", "gfx_pt_launch", "gfx_regir_set_params",
+    "gfx_restir_launch_rows", "gfx_restir_launch_rows_gap", "gfx_pt_launch", "gfx_regir_set_params",
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_infer_indirect", "gfx_nrc_query_count_ptr", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
     "gfx_nrc_get_params", "gfx_nrc_inference_image", "gfx_nrc_inference_image_async", "gfx_nrc_set_render_params",
     "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read", "gfx_trace_diag_read",
@@ -716,6 +717,10 @@ class Context:
     def restir_launch_rows(self, pass_id, width, height, row_begin, row_end, stream=0):
         self._check(self.L.gfx_restir_launch_rows(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height),
                                                   C.c_uint32(row_begin), C.c_uint32(row_end)))
+
+    def restir_launch_rows_gap(self, pass_id, width, height, row_begin, row_end, gap_begin, gap_end, stream=0):
+        self._check(self.L.gfx_restir_launch_rows_gap(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height),
+                                                      C.c_uint32(row_begin), C.c_uint32(row_end), C.c_uint32(gap_begin), C.c_uint32(gap_end)))
 
     def restir_launch(self, pass_id, width, height, stream=0):
         self._check(self.L.gfx_restir_launch(self.h, C.c_void_p(stream), C.c_int(pass_id), C.c_uint32(width), C.c_uint32(height)))

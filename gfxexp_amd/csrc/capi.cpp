@@ -360,6 +360,14 @@ int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint
     GFX_CATCH(ctx)
 }
 
+int gfx_restir_launch_rows_gap(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd,
+                               uint32_t gapBegin, uint32_t gapEnd) {
+    GFX_TRY(ctx)
+    if (rowBegin == 0 && rowEnd == 0) rowEnd = height;
+    restir_launch(ctx->c, static_cast<hipStream_t>(stream), pass, width, height, rowBegin, rowEnd, gapBegin, gapEnd);
+    GFX_CATCH(ctx)
+}
+
 int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {
     GFX_TRY(ctx)
     if (rowBegin == 0 && rowEnd == 0) rowEnd = height;   // 0, 0 = every row, as in gfx_pt_launch

@@ -69,7 +69,7 @@ const Field kFields[] = {
     F(gfxh_exchange_desc, sendBelow), F(gfxh_exchange_desc, recvBelow), F(gfxh_exchange_desc, numBuffers), F(gfxh_exchange_desc, buffers), F(gfxh_exchange_desc, counters),
     F(gfxh_exchange_desc, numCounters),
     S(gfxh_frame_step), F(gfxh_frame_step, op), F(gfxh_frame_step, pass), F(gfxh_frame_step, rowBegin), F(gfxh_frame_step, rowEnd), F(gfxh_frame_step, currentReservoirIndex),
-    F(gfxh_frame_step, spatialNeighborBaseIndex), F(gfxh_frame_step, exchangeRows), F(gfxh_frame_step, buffers), F(gfxh_frame_step, reservoirIndex), F(gfxh_frame_step, lane),
+    F(gfxh_frame_step, spatialNeighborBaseIndex), F(gfxh_frame_step, exchangeRows), F(gfxh_frame_step, buffers), F(gfxh_frame_step, reservoirIndex), F(gfxh_frame_step, lane), F(gfxh_frame_step, gapBegin), F(gfxh_frame_step, gapEnd),
     S(gfxh_nrc_config), F(gfxh_nrc_config, width), F(gfxh_nrc_config, height), F(gfxh_nrc_config, positionEncoding), F(gfxh_nrc_config, numHiddenLayers), F(gfxh_nrc_config, learningRate),
     F(gfxh_nrc_config, maxPathLength), F(gfxh_nrc_config, radianceScale), F(gfxh_nrc_config, train), F(gfxh_nrc_config, enableAccumulation), F(gfxh_nrc_config, camera),
     F(gfxh_nrc_config, sceneAabbMin), F(gfxh_nrc_config, sceneAabbMax), F(gfxh_nrc_config, rowBegin), F(gfxh_nrc_config, rowEnd), F(gfxh_nrc_config, neeSampler),

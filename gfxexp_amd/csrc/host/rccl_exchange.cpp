@@ -74,7 +74,7 @@ struct gfxh_rccl {
     // one communicator per lane of the renderer (gfxexp_host.h gfxh_lane) when created with gfxh_rccl_create_lanes: operations of
     // different lanes are enqueued on different streams and must not queue behind each other inside one communicator; with a single
     // communicator (gfxh_rccl_create) every lane shares it and the operations run in issue order
-    ncclComm_t comms[GFXH_NUM_LANES] = { nullptr, nullptr, nullptr };
+    ncclComm_t comms[GFXH_NUM_LANES] = { nullptr, nullptr, nullptr, nullptr };
     uint32_t numComms = 0;
     ncclComm_t lane(uint32_t l) const { return comms[l < numComms ? l : 0]; }
     int rank = 0, world = 1;

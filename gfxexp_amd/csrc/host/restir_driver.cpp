@@ -58,8 +58,9 @@ struct gfxh_restir {
     // lanes of a band renderer (gfxexp_host.h gfxh_lane): the G-buffer strips travel on gbStream behind the pass that made them
     // (evGbStrips: they have arrived), the HDR bands on gatherStream underneath the next frame (evBandDone: the frame's last pass is
     // queued; evGather: the gather has finished)
-    hipEvent_t evGbStrips = nullptr, evBandDone = nullptr, evGather = nullptr;
-    hipStream_t gatherStream = nullptr;
+    hipEvent_t evGbStrips = nullptr, evBandDone = nullptr, evGather = nullptr, evSeamRows = nullptr, evSeamStrips = nullptr;
+    hipStream_t gatherStream = nullptr, seamStream = nullptr;
+    bool seamStripsPending = false, seamFirst = true;   // GFX_SEAM_FIRST=0: every spatial pass in one launch (stripMode 1)
     bool asyncGather = false, gatherPending = false, gbStripsPending = false;
     bool stripsOnGbLane = true;   // GFX_GB_STRIPS_ON_MAIN=1 (A/B runs): the G-buffer strips on the caller's stream ahead of the candidate pass, as rounds 2-5 issued them
 };
@@ -211,12 +212,17 @@ int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir*
         r->pipelineFrames = !(e && e[0] == '1');
         const char* m = std::getenv("GFX_GB_STRIPS_ON_MAIN");
         r->stripsOnGbLane = !(m && m[0] == '1');
+        const char* sf = std::getenv("GFX_SEAM_FIRST");
+        r->seamFirst = !(sf && sf[0] == '0');
         if (!hip_ok(hipStreamCreateWithFlags(&r->gbStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
             !hip_ok(hipEventCreateWithFlags(&r->evPrevRead, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&r->evGbuffer, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&r->evGbStrips, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&r->evBandDone, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&r->evGather, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evSeamRows, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evSeamStrips, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipStreamCreateWithFlags(&r->seamStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
             !hip_ok(hipStreamCreateWithFlags(&r->gatherStream, hipStreamNonBlocking), "hipStreamCreateWithFlags")) {
             gfxh_restir_destroy(r);
             return 1;
@@ -237,6 +243,9 @@ void gfxh_restir_destroy(gfxh_restir* r) {
     if (r->evGather) (void)hipEventDestroy(r->evGather);
     if (r->gbStream) (void)hipStreamDestroy(r->gbStream);
     if (r->gatherStream) (void)hipStreamDestroy(r->gatherStream);
+    if (r->seamStream) (void)hipStreamDestroy(r->seamStream);
+    if (r->evSeamRows) (void)hipEventDestroy(r->evSeamRows);
+    if (r->evSeamStrips) (void)hipEventDestroy(r->evSeamStrips);
     for (void* p : r->allocations) (void)hipFree(p);
     delete r;
 }
@@ -484,6 +493,7 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
     const gfxh_restir_config& cfg = *cfgp;
     const bool whole = cfg.rowBegin == 0 && cfg.rowEnd == 0;
     const bool strips = stripMode && !whole;
+    const bool seamFirst = strips && stripMode >= 2;
     const uint32_t passes = cfg.enableSpatialReuse ? cfg.numSpatialReusePasses : 0;
     const uint32_t radiusRows = static_cast<uint32_t>(std::ceil(cfg.spatialNeighborRadius));
     gfxh_band_plan plan;
@@ -579,9 +589,11 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
         if (cfg.enableSpatialReuse) {                                                          // :2393-2411
             const uint32_t spatial = useUnbiasedEstimator ? GFX_RESTIR_SPATIAL_UNBIASED : GFX_RESTIR_SPATIAL_BIASED;
             const uint32_t base0 = baseIndex;
+            bool seamStripsInFlight = false;   // the reservoirs the pass in turn reads across the seams travel on lane SEAM (issued inside the pass before it)
             for (uint32_t i = 0; i < cfg.numSpatialReusePasses; ++i) {
                 // strip mode: the reservoirs this pass resamples from, radius rows either side of the band
-                exchange(radiusRows, GFXH_BUF_RESERVOIRS, currentReservoirIndex);
+                if (seamStripsInFlight) { push(GFXH_STEP_WAIT_SEAM_STRIPS, 0, 0, 0); seamStripsInFlight = false; }
+                else exchange(radiusRows, GFXH_BUF_RESERVOIRS, currentReservoirIndex);
                 if (gbStripsInFlight) { push(GFXH_STEP_WAIT_GBUFFER_STRIPS, 0, 0, 0); gbStripsInFlight = false; }
                 baseIndex = base0 + cfg.numSpatialNeighbors * i;
                 // the last biased pass and the shading pass (:2418-2420) as one step where they cover the same rows (not the halo
@@ -589,6 +601,20 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
                 const bool last = i + 1 == cfg.numSpatialReusePasses;
                 shadingIssued = last && !useUnbiasedEstimator && plan.spatialRows[i][0] == plan.shadingRows[0] && plan.spatialRows[i][1] == plan.shadingRows[1];
                 if (shadingIssued) beauty_writer();
+                // Seam rows first: a biased pass that another pass follows writes the rows its neighbours read next -- the first and the last
+                // `radius` rows of the band -- in a launch of its own, their exchange goes out on lane SEAM, and the interior rows follow on
+                // the frame's stream underneath it.  (A per-pixel kernel: which launch computes a pixel changes nothing.)
+                const uint32_t seamAbove = plan.bandBegin > 0 ? radiusRows : 0u, seamBelow = plan.bandEnd < cfg.height ? radiusRows : 0u;
+                const bool split = seamFirst && !last && !useUnbiasedEstimator && (seamAbove + seamBelow) > 0 &&
+                                   plan.bandEnd - plan.bandBegin > seamAbove + seamBelow;
+                if (split) {
+                    const uint32_t gb = plan.bandBegin + seamAbove, ge = plan.bandEnd - seamBelow;
+                    if (gfxh_frame_step* st = push(GFXH_STEP_RESTIR_PASS, spatial, plan.bandBegin, plan.bandEnd)) { st->gapBegin = gb; st->gapEnd = ge; }
+                    exchange(radiusRows, GFXH_BUF_RESERVOIRS, (currentReservoirIndex + 1) % 2, GFXH_LANE_SEAM);
+                    seamStripsInFlight = true;
+                    push(GFXH_STEP_RESTIR_PASS, spatial, gb, ge);
+                }
+                else
                 push(GFXH_STEP_RESTIR_PASS, shadingIssued ? static_cast<uint32_t>(GFX_RESTIR_SPATIAL_BIASED_AND_SHADING) : spatial,
                      plan.spatialRows[i][0], whole ? 0 : plan.spatialRows[i][1]);
                 currentReservoirIndex = (currentReservoirIndex + 1) % 2;
@@ -697,7 +723,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     }
     gfxh_frame_step steps[64];
     uint32_t numSteps = 0, newLastRes = 0, newLastBase = 0;
-    if (gfxh_restir_frame_program(&cfg, strips ? 1 : 0, r->maxMotionRows, newSequence ? 1 : 0, r->lastReservoirIndex, r->lastSpatialNeighborBaseIndex,
+    if (gfxh_restir_frame_program(&cfg, strips ? (r->seamFirst && r->pipelineFrames ? 2 : 1) : 0, r->maxMotionRows, newSequence ? 1 : 0, r->lastReservoirIndex, r->lastSpatialNeighborBaseIndex,
                                   useUnbiased, steps, 64, &numSteps, &newLastRes, &newLastBase)) {
         g_driverError = "gfxh_restir_render_frame: the exchange strip is taller than the band (fewer ranks or a smaller radius; "
                         "gfxh_restir_check_partition decides this for all ranks at once)";
@@ -747,7 +773,8 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     if (cfg.renderer == GFXH_PATH_TRACE_REGIR) DRV_GFX(gfx_regir_set_params(ctx, &r->regir));
     bool gbWaited = false;      // main has been made to wait for this frame's G-buffer pass
     auto lane_stream = [&](uint32_t lane) -> hipStream_t {
-        return lane == GFXH_LANE_GBUFFER ? (pipelined ? r->gbStream : main) : lane == GFXH_LANE_GATHER ? (asyncGather ? r->gatherStream : main) : main;
+        return lane == GFXH_LANE_GBUFFER ? (pipelined ? r->gbStream : main) : lane == GFXH_LANE_GATHER ? (asyncGather ? r->gatherStream : main)
+             : lane == GFXH_LANE_SEAM ? (pipelined ? r->seamStream : main) : main;
     };
     auto exchange_stream = [&](const gfxh_frame_step& st) -> hipStream_t {
         if (st.op == GFXH_STEP_EXCHANGE_STRIPS && st.lane == GFXH_LANE_GBUFFER && !r->stripsOnGbLane) return main;
@@ -768,6 +795,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
             if (!gb && pipelined && !gbWaited) { DRV_HIP(hipStreamWaitEvent(main, r->evGbuffer, 0)); gbWaited = true; }
             DRV_GFX(gfx_restir_set_params(ctx, s, &r->sp, &fp, st.currentReservoirIndex, st.spatialNeighborBaseIndex));
             if (st.op == GFXH_STEP_PT_PASS) DRV_GFX(gfx_pt_launch(ctx, s, static_cast<int>(st.pass), W, H, cfg.maxPathLength, st.rowBegin, st.rowEnd));
+            else if (st.gapEnd > st.gapBegin) DRV_GFX(gfx_restir_launch_rows_gap(ctx, s, static_cast<int>(st.pass), W, H, st.rowBegin, st.rowEnd, st.gapBegin, st.gapEnd));
             else DRV_GFX(gfx_restir_launch_rows(ctx, s, static_cast<int>(st.pass), W, H, st.rowBegin, st.rowEnd));
             if (gb && pipelined) DRV_HIP(hipEventRecord(r->evGbuffer, s));
             break;
@@ -777,6 +805,9 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
             break;
         case GFXH_STEP_WAIT_GBUFFER_STRIPS:
             if (pipelined && r->gbStripsPending) { DRV_HIP(hipStreamWaitEvent(main, r->evGbStrips, 0)); r->gbStripsPending = false; }
+            break;
+        case GFXH_STEP_WAIT_SEAM_STRIPS:
+            if (r->seamStripsPending) { DRV_HIP(hipStreamWaitEvent(main, r->evSeamStrips, 0)); r->seamStripsPending = false; }
             break;
         case GFXH_STEP_WAIT_PREVIOUS_GATHER:
             if (r->gatherPending) { DRV_HIP(hipStreamWaitEvent(main, r->evGather, 0)); r->gatherPending = false; }
@@ -793,9 +824,15 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
                 DRV_HIP(hipEventRecord(r->evBandDone, main));
                 DRV_HIP(hipStreamWaitEvent(s, r->evBandDone, 0));
             }
+            const bool seam = st.op == GFXH_STEP_EXCHANGE_STRIPS && st.lane == GFXH_LANE_SEAM && s != main;
+            if (seam) {                                                // behind the seam rows the frame's stream has just queued
+                DRV_HIP(hipEventRecord(r->evSeamRows, main));
+                DRV_HIP(hipStreamWaitEvent(s, r->evSeamRows, 0));
+            }
             if (r->exchange(r->exchangeUser, s, &d)) { g_driverError = "gfxh_restir_render_frame: the exchange callback failed"; return 1; }
             if (st.op == GFXH_STEP_GATHER_BANDS && s != main) { DRV_HIP(hipEventRecord(r->evGather, s)); r->gatherPending = true; }
-            if (st.op == GFXH_STEP_EXCHANGE_STRIPS && s != main) { DRV_HIP(hipEventRecord(r->evGbStrips, s)); r->gbStripsPending = true; }
+            if (seam) { DRV_HIP(hipEventRecord(r->evSeamStrips, s)); r->seamStripsPending = true; }
+            else if (st.op == GFXH_STEP_EXCHANGE_STRIPS && s != main) { DRV_HIP(hipEventRecord(r->evGbStrips, s)); r->gbStripsPending = true; }
             break;
         }
         default: break;

@@ -251,7 +251,7 @@ void light_matrices_upload(Context& ctx, hipStream_t stream);
 void lights_build_static(Context& ctx, hipStream_t stream);
 void lights_build_instances(Context& ctx, hipStream_t stream, uint32_t bufferIndex);
 // ---- restir.hip
-void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd);
+void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd, uint32_t gapBegin = 0, uint32_t gapEnd = 0);
 void restir_copy_to_linear(Context& ctx, hipStream_t stream, void* color, void* albedo, void* normal, void* motion);
 void restir_visualize(Context& ctx, hipStream_t stream, const void* linearBuffer, int bufferType, float mvOffset, float mvScale, uint32_t width, uint32_t height, void* out);
 // ---- nrc.hip

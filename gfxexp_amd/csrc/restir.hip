@@ -998,7 +998,7 @@ extern "C" int gfx_debug_lane_profile(unsigned long long* out64, int reset) {
 #endif
 
 // ---------------------------------------------------------------- host sequencing
-static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd, bool rearch) {
+static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd, bool rearch, uint32_t gapBegin = 0, uint32_t gapEnd = 0) {
     const RestirParams& rp = ctx.restir;
     if (!rp.valid) throw HipError("gfx_restir_launch: gfx_restir_set_params has not been called");
     if (static_cast<uint32_t>(rp.s.imageSizeX) != width || static_cast<uint32_t>(rp.s.imageSizeY) != height)
@@ -1035,7 +1035,8 @@ static RestirArgs make_args(Context& ctx, uint32_t width, uint32_t height, uint3
         a.rearchSlots = ctx.rearchSlots.as<uint32_t>();
     }
     if (rowEnd > height || rowBegin > rowEnd) throw HipError("gfx_restir_launch_rows: row range outside the image");
-    a.px = make_pixel_grid(ctx, width, rowBegin, rowEnd);
+    if (gapEnd > gapBegin && (gapBegin < rowBegin || gapEnd > rowEnd)) throw HipError("gfx_restir_launch_rows_gap: the gap lies outside the rows");
+    a.px = make_pixel_grid(ctx, width, rowBegin, rowEnd, gapBegin, gapEnd);
     return a;
 }
 
@@ -1112,10 +1113,12 @@ void restir_visualize(Context& ctx, hipStream_t stream, const void* linearBuffer
     GFX_HIP(hipGetLastError());
 }
 
-void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd) {
+void restir_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width, uint32_t height, uint32_t rowBegin, uint32_t rowEnd, uint32_t gapBegin, uint32_t gapEnd) {
     const bool rearch = pass >= GFX_RESTIR_LIGHT_PRESAMPLING && pass <= GFX_RESTIR_SHADE_AND_RESAMPLE_SPATIOTEMPORAL;
-    RestirArgs a = make_args(ctx, width, height, rowBegin, rowEnd, rearch);
-    if (rowEnd == rowBegin) return;
+    // a gap (gfx_restir_launch_rows_gap) is for the pass a band renderer splits around its exchange: the biased spatial pass, a plain per-pixel kernel
+    if (gapEnd > gapBegin && pass != GFX_RESTIR_SPATIAL_BIASED) throw HipError("gfx_restir_launch_rows_gap: only GFX_RESTIR_SPATIAL_BIASED takes a gap");
+    RestirArgs a = make_args(ctx, width, height, rowBegin, rowEnd, rearch, gapBegin, gapEnd);
+    if (rowEnd == rowBegin || a.px.launchBlocks == 0) return;
     auto reset_queue = [&]() { GFX_HIP(hipMemsetAsync(a.rayCount, 0, sizeof(uint32_t), stream)); };
     // A launch of up to about half a full-HD frame (a row band of a multi-GPU frame) runs each of the three ray passes as ONE kernel
     // (k_*_fused above); a larger one keeps the persistent k_trace with its refill between two per-pixel kernels (band of 8 / 4 / 2 /

@@ -32,6 +32,7 @@ struct SpatialSlot {            // per (pixel, k): k = 0 self, 1..N neighbours (
 // `slot` is the thread's index in the launch: dense per-launch arrays (primary rays, their hits) use it.
 struct PixelGrid {
     uint32_t width, rowBegin, rowEnd;
+    uint32_t gapBegin, gapRows;         // rows [gapBegin, gapBegin + gapRows) inside [rowBegin, rowEnd) are left out (the interior of a band whose seam rows run first); 0 rows = none
     uint32_t mode;
     uint32_t blocksX, blocksY;          // 16 x 16-pixel blocks covering the rows
     uint32_t superShiftX, superShiftY;  // log2 of the supertile size in blocks
@@ -46,6 +47,7 @@ GFX_DEV PixelId pixel_of_block_thread(const PixelGrid& g, uint32_t block, uint32
     r.slot = block * 256u + tid;
     if (g.mode == 0) {
         r.p = static_cast<size_t>(g.rowBegin) * g.width + r.slot;
+        if (g.gapRows && r.p >= static_cast<size_t>(g.gapBegin) * g.width) r.p += static_cast<size_t>(g.gapRows) * g.width;
         r.valid = r.p < static_cast<size_t>(g.rowEnd) * g.width;
         r.x = static_cast<int>(r.p % g.width); r.y = static_cast<int>(r.p / g.width);
         return r;
@@ -62,7 +64,8 @@ GFX_DEV PixelId pixel_of_block_thread(const PixelGrid& g, uint32_t block, uint32
     }
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const uint32_t x = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t y = g.rowBegin + by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    uint32_t y = g.rowBegin + by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    if (g.gapRows && y >= g.gapBegin) y += g.gapRows;
     r.valid = bx < g.blocksX && by < g.blocksY && x < g.width && y < g.rowEnd;
     r.x = static_cast<int>(x); r.y = static_cast<int>(y);
     r.p = r.valid ? static_cast<size_t>(y) * g.width + x : 0;
@@ -74,12 +77,13 @@ GFX_DEV uint32_t launch_block(const PixelGrid& g) { return g.order ? g.order[blo
 GFX_DEV PixelId pixel_of_thread(const PixelGrid& g) { return pixel_of_block_thread(g, launch_block(g), threadIdx.x); }
 
 // host side: the grid of a per-pixel launch over rows [rowBegin, rowEnd) (Context::pixelMap* = the mode, internal.h)
-inline PixelGrid make_pixel_grid(const Context& ctx, uint32_t width, uint32_t rowBegin, uint32_t rowEnd) {
+inline PixelGrid make_pixel_grid(const Context& ctx, uint32_t width, uint32_t rowBegin, uint32_t rowEnd, uint32_t gapBegin = 0, uint32_t gapEnd = 0) {
     PixelGrid g;
     g.width = width; g.rowBegin = rowBegin; g.rowEnd = rowEnd;
+    g.gapBegin = gapBegin; g.gapRows = gapEnd > gapBegin ? gapEnd - gapBegin : 0u;
     g.order = nullptr;
     g.mode = static_cast<uint32_t>(ctx.tune.pixelMap);
-    const uint32_t rows = rowEnd - rowBegin;
+    const uint32_t rows = rowEnd - rowBegin - g.gapRows;
     g.blocksX = (width + 15u) / 16u; g.blocksY = (rows + 15u) / 16u;
     g.superShiftX = static_cast<uint32_t>(ctx.tune.superShiftX); g.superShiftY = static_cast<uint32_t>(ctx.tune.superShiftY);
     g.supersX = (g.blocksX + (1u << g.superShiftX) - 1u) >> g.superShiftX;

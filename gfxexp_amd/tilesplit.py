@@ -278,7 +278,7 @@ class StripExchange:
                 frame[rs * row_bytes:re * row_bytes].copy_(recv[r * slab:r * slab + (re - rs) * row_bytes])
 
 
-def make_lane_groups(dist, lanes=(1, 2)):
+def make_lane_groups(dist, lanes=(1, 2, 3)):
     """One extra process group (= one more RCCL communicator and stream) per lane beyond MAIN; every rank must call this at the same
     point.  {lane: group} for StripExchange(lane_groups=...)."""
     return {int(lane): dist.new_group() for lane in lanes}

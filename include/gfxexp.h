@@ -332,6 +332,11 @@ int gfx_restir_launch(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint
  * full-frame size and indexing.  rowBegin == rowEnd == 0 -> every row. */
 int gfx_restir_launch_rows(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height,
                            uint32_t rowBegin, uint32_t rowEnd);
+/* Rows [rowBegin, gapBegin) and [gapEnd, rowEnd) in ONE launch: the seam rows of a band (what the neighbours' next pass reads), which
+ * a band renderer runs ahead of the interior [gapBegin, gapEnd) so that their exchange overlaps the interior (gfxexp_host.h, lane
+ * SEAM).  GFX_RESTIR_SPATIAL_BIASED only (a per-pixel kernel: which launch computes a pixel changes nothing). */
+int gfx_restir_launch_rows_gap(gfx_ctx* ctx, void* stream, int pass, uint32_t width, uint32_t height,
+                               uint32_t rowBegin, uint32_t rowEnd, uint32_t gapBegin, uint32_t gapEnd);
 
 /* Output chain (restir_di/gpu_kernels/copy_buffers.cu:6-80; host calls restir_di_main.cpp:2497-2571).
  * gfx_restir_copy_to_linear = copyToLinearBuffers: beauty / albedo / normal accumulation buffers (normal normalised

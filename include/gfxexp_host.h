@@ -231,9 +231,12 @@ typedef struct gfxh_exchange_buffer {
  *            the exchange of its strips (the candidate pass reads no neighbour's G-buffer; only the spatial passes wait for them)
  *   GATHER   the renderer's gather stream: the all-gather of the HDR bands runs underneath the NEXT frame (nothing of that frame
  *            reads other ranks' pixels; its shading pass waits for the gather to have read the band it overwrites)
+ *   SEAM     the renderer's seam stream: a spatial pass that is followed by another one runs its seam rows (the rows the neighbours'
+ *            next pass reads) FIRST, their exchange travels on this lane while the caller's stream runs the interior rows, and only
+ *            the next pass waits for it (stripMode 2 of gfxh_restir_frame_program; the biased estimator's passes)
  * A transport that keeps one communicator per lane (gfxh_rccl_create_lanes; a process group per lane in tilesplit.StripExchange)
  * lets the three run concurrently; with one communicator they still run, in issue order. */
-enum gfxh_lane { GFXH_LANE_MAIN = 0, GFXH_LANE_GBUFFER = 1, GFXH_LANE_GATHER = 2, GFXH_NUM_LANES = 3 };
+enum gfxh_lane { GFXH_LANE_MAIN = 0, GFXH_LANE_GBUFFER = 1, GFXH_LANE_GATHER = 2, GFXH_LANE_SEAM = 3, GFXH_NUM_LANES = 4 };
 typedef struct gfxh_exchange_desc {
     uint32_t kind;                       /* enum gfxh_exchange_kind */
     uint32_t stage;                      /* ordinal of the exchange point inside the frame (diagnostics) */
@@ -288,7 +291,7 @@ typedef struct gfxh_rccl gfxh_rccl;
 int gfxh_rccl_unique_id(void* id128);
 int gfxh_rccl_create(const void* id128, int rank, int world, uint32_t height, gfxh_rccl** out);
 /* One communicator per lane (enum gfxh_lane): `ids` = numLanes x 128 bytes, each from its own gfxh_rccl_unique_id call on rank 0
- * (1 <= numLanes <= GFXH_NUM_LANES; a lane beyond numLanes shares communicator 0).  With three, the G-buffer strips, the reservoir
+ * (1 <= numLanes <= GFXH_NUM_LANES; a lane beyond numLanes shares communicator 0).  With all of them, the G-buffer strips, the seam strips, the reservoir
  * strips and the band gather never queue behind each other. */
 int gfxh_rccl_create_lanes(const void* ids, uint32_t numLanes, int rank, int world, uint32_t height, gfxh_rccl** out);
 /* Another partition than gfxh_band_rows' (the cost-balanced bands of gfxh_balance_bands): bandBegin = world + 1 ascending rows from 0
@@ -309,7 +312,8 @@ enum gfxh_step_op {
     GFXH_STEP_GATHER_BANDS = 4,
     GFXH_STEP_PREV_GBUFFER_RELEASED = 5,  /* the frame no longer reads the previous frame's G-buffer (frame pipelining) */
     GFXH_STEP_WAIT_GBUFFER_STRIPS = 6,    /* the next pass reads the neighbours' G-buffer rows: MAIN waits for the exchange issued on GBUFFER */
-    GFXH_STEP_WAIT_PREVIOUS_GATHER = 7    /* the next pass overwrites the HDR band the previous frame's gather (lane GATHER) sends */
+    GFXH_STEP_WAIT_PREVIOUS_GATHER = 7,   /* the next pass overwrites the HDR band the previous frame's gather (lane GATHER) sends */
+    GFXH_STEP_WAIT_SEAM_STRIPS = 8        /* the next pass reads the strips the exchange on lane SEAM brings: MAIN waits for it */
 };
 enum gfxh_exchange_buffers { GFXH_BUF_GBUFFERS = 1 /* GBuffer 0, 2, 3 of the frame */, GFXH_BUF_RESERVOIRS = 2 /* + ReservoirInfo */, GFXH_BUF_SAMPLE_VISIBILITY = 4 };
 typedef struct gfxh_frame_step {
@@ -318,7 +322,10 @@ typedef struct gfxh_frame_step {
     uint32_t currentReservoirIndex, spatialNeighborBaseIndex;  /* launch parameters in force for a pass */
     uint32_t exchangeRows, buffers, reservoirIndex;            /* GFXH_STEP_EXCHANGE_STRIPS */
     uint32_t lane;                                             /* enum gfxh_lane the step is issued on (a program run in list order, as the CPU tests do, is one valid schedule) */
+    uint32_t gapBegin, gapEnd;                                 /* a pass over rows [rowBegin, gapBegin) + [gapEnd, rowEnd) (gfx_restir_launch_rows_gap); 0, 0 = no gap */
 } gfxh_frame_step;
+/* stripMode: 0 = whole frame / halo recompute, 1 = strip exchange with every pass over the band in one launch, 2 = 1 + seam rows first
+ * (lane SEAM) for the spatial passes that are followed by another pass -- what gfxh_restir_render_frame runs (GFX_SEAM_FIRST=0: 1). */
 int gfxh_restir_frame_program(const gfxh_restir_config* cfg, int stripMode, uint32_t maxMotionRows, int newSequence,
                               uint32_t lastReservoirIndex, uint32_t lastSpatialNeighborBaseIndex, uint32_t useUnbiasedEstimator,
                               gfxh_frame_step* steps, uint32_t capacity, uint32_t* numSteps, uint32_t* newLastReservoirIndex,

@@ -24,6 +24,7 @@ class OracleBandRenderer:
         self.prev_cam = None
         self.exchange = None
         self.max_motion_rows = 0
+        self.strip_mode = 2
         self.log = []
 
     def set_exchange(self, fn, max_motion_rows=0):
@@ -43,12 +44,17 @@ class OracleBandRenderer:
                               useLowDiscrepancyNeighbors=cfg.useLowDiscrepancyNeighbors, reuseVisibility=cfg.reuseVisibility)
         whole = cfg.rowBegin == 0 and cfg.rowEnd == 0
         strips = self.exchange is not None and not whole
-        steps, new_res, new_base = api.frame_program(cfg, strips, self.max_motion_rows, new_sequence, self.last_res, self.last_base, unbiased)
+        # stripMode 2: what gfxh_restir_render_frame runs -- the seam rows of a spatial pass that another pass follows go first
+        steps, new_res, new_base = api.frame_program(cfg, self.strip_mode if strips else 0, self.max_motion_rows, new_sequence, self.last_res, self.last_base, unbiased)
         if self.regir_params is not None:
             self.osc.regir_set_params(self.regir_params)
         for k, st in enumerate(steps):
             rect = None if (st.rowBegin == 0 and st.rowEnd == 0) else (0, st.rowBegin, W, st.rowEnd)
-            if st.op == api.STEP_RESTIR_PASS:
+            if st.op == api.STEP_RESTIR_PASS and st.gapEnd > st.gapBegin:      # rows [rowBegin, gapBegin) + [gapEnd, rowEnd)
+                for rb, re in ((st.rowBegin, st.gapBegin), (st.gapEnd, st.rowEnd)):
+                    if re > rb:
+                        self.osc.restir_launch(self.sp, f, st.currentReservoirIndex, st.spatialNeighborBaseIndex, st.pass_, rect=(0, rb, W, re))
+            elif st.op == api.STEP_RESTIR_PASS:
                 self.osc.restir_launch(self.sp, f, st.currentReservoirIndex, st.spatialNeighborBaseIndex, st.pass_, rect=rect)
             elif st.op == api.STEP_PT_PASS:
                 self.osc.pt_launch(self.sp, f, st.pass_, cfg.maxPathLength, rect=rect)

@@ -6,9 +6,11 @@ Band 2 of 4 and band 4 of 8 of a 640x360 frame render the same sequence three ti
 transfer executes on its stream:
     serial    GFX_SERIAL_FRAMES=1: every pass and every exchange on ONE stream, in program order -- the reference schedule
     round5    the G-buffer pass pipelined, the G-buffer strips on the frame's stream ahead of the candidate pass, gather synchronous
-    lanes     the G-buffer strips on the G-buffer lane behind the pipelined pass, the band gather on the gather lane underneath the
+    noseam    the G-buffer strips on the G-buffer lane behind the pipelined pass, the band gather on the gather lane underneath the
               next frame, with 40 / 150 microseconds of injected latency per strip exchange / gather (so that a missing wait reads rows
               that have not arrived)
+    lanes     + the seam rows of a spatial pass that another pass follows first, their exchange on the seam lane underneath the interior
+              rows (the schedule gfxh_restir_render_frame runs by default)
 Every buffer a later pass or frame reads (G-buffer halves, reservoirs, infos, the RNG states, the HDR frame) must come out bit for bit
 the same: a missing or misplaced event between the lanes shows up as a difference."""
 import ctypes as C
@@ -26,15 +28,17 @@ def render(api, ctx, cfg, rank, world, H, frames, schedule, mirror, ids, moving)
     import torch
     os.environ.pop("GFX_SERIAL_FRAMES", None)
     os.environ["GFX_GB_STRIPS_ON_MAIN"] = "0"
+    os.environ["GFX_SEAM_FIRST"] = "1" if schedule == "lanes" else "0"
     if schedule == "serial":
         os.environ["GFX_SERIAL_FRAMES"] = "1"
     if schedule == "round5":
         os.environ["GFX_GB_STRIPS_ON_MAIN"] = "1"
-    mirror.rccl_mirror_set_latency_us(C.c_float(40.0 if schedule == "lanes" else 0.0), C.c_float(150.0 if schedule == "lanes" else 0.0))
+    injected = schedule in ("lanes", "noseam")
+    mirror.rccl_mirror_set_latency_us(C.c_float(40.0 if injected else 0.0), C.c_float(150.0 if injected else 0.0))
     r = api.RestirRenderer(ctx, cfg)
     ex = api.RcclExchange(ids, rank, world, H)
     ex.install(r, 8 if moving else 0)
-    r.set_async_gather(schedule == "lanes")
+    r.set_async_gather(injected)
     stream = torch.cuda.current_stream().cuda_stream
     for f in range(frames):
         if moving:
@@ -75,7 +79,7 @@ def main():
         cfg.rowBegin, cfg.rowEnd = api.band_rows(H, world, rank)
         ids = api.RcclExchange.unique_ids(api.NUM_LANES)
         want = render(api, ctx, cfg, rank, world, H, frames, "serial", mirror, ids, moving)
-        for schedule in ("round5", "lanes"):
+        for schedule in ("round5", "noseam", "lanes"):
             got = render(api, ctx, cfg, rank, world, H, frames, schedule, mirror, ids, moving)
             for name in want:
                 if not np.array_equal(want[name], got[name]):

@@ -8,9 +8,10 @@
   latency   frame time of that band with a transport of the right shape: gfxh_rccl_exchange over tests/native/librccl_mirror.so
             (the strips a rank would send across a seam come back as the strips it receives, behind a spin kernel of L microseconds
             per exchange point on the exchange's stream; the band gather behind a spin kernel of G microseconds), for L in
-            0 / 30 / 60 / 120 and three schedules: `round5` = every exchange on the frame's stream in program order (G-buffer strips
+            0 / 30 / 60 / 120 and four schedules: `round5` = every exchange on the frame's stream in program order (G-buffer strips
             ahead of the candidate pass, the gather synchronous), `gb_lane` = the G-buffer strips on the G-buffer stream behind the
-            pipelined pass, `lanes` = that + the gather on its own stream underneath the next frame (what bench.py --gpus N runs).
+            pipelined pass, `lanes_noseam` = that + the gather on its own stream underneath the next frame, `lanes` = that + the seam
+            rows of the first biased spatial pass ahead of its interior, their exchange on the seam lane (what bench.py --gpus N runs).
 usage: band_host_overhead.py host|latency [--config4] [--bands 8] [--steps 60]"""
 import ctypes as C
 import json
@@ -41,8 +42,12 @@ class NullDist:
     def irecv(self, *a, **k):
         pass
 
+    class _Op:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
     def P2POp(self, op, tensor, peer, group=None):
-        return (op, tensor, peer)
+        return NullDist._Op(op, tensor, peer)
 
     def batch_isend_irecv(self, ops):
         return [NullDist._Done()]
@@ -94,8 +99,7 @@ def main():
     W, H = 1920, 1080
     stub = os.path.join(ROOT, "tests", "native", "librccl_stub.so" if mode == "host" else "librccl_mirror.so")
     os.environ["GFX_RCCL_LIBRARY"] = stub          # before libgfxexp loads librccl
-    if mode == "latency":
-        os.environ["GFX_GB_STRIPS_ON_MAIN"] = "1" if "--round5" in sys.argv or arg("--schedule", "lanes") == "round5" else "0"
+XX
     import torch
     from gfxexp_amd import api, scenes, tilesplit
     ctx = api.Context(0)
@@ -140,7 +144,7 @@ def main():
         r, cfg = make_renderer(api, scenes, ctx, W, H, band, config4)
         ex = api.RcclExchange(ids, rank, nb, H)
         ex.install(r, 0)
-        r.set_async_gather(schedule == "lanes")
+        r.set_async_gather(schedule in ("lanes", "lanes_noseam"))
         rows = {}
         for lat in (0.0, 30.0, 60.0, 120.0):
             mirror.rccl_mirror_set_latency_us(C.c_float(lat), C.c_float(gather_us if lat > 0 else 0.0))
