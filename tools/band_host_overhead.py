@@ -99,7 +99,10 @@ def main():
     W, H = 1920, 1080
     stub = os.path.join(ROOT, "tests", "native", "librccl_stub.so" if mode == "host" else "librccl_mirror.so")
     os.environ["GFX_RCCL_LIBRARY"] = stub          # before libgfxexp loads librccl
-XX
+    if mode == "latency":
+        sched = arg("--schedule", "lanes")
+        os.environ["GFX_GB_STRIPS_ON_MAIN"] = "1" if sched == "round5" else "0"
+        os.environ["GFX_SEAM_FIRST"] = "1" if sched == "lanes" else "0"
     import torch
     from gfxexp_amd import api, scenes, tilesplit
     ctx = api.Context(0)
