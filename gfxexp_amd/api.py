@@ -65,7 +65,7 @@ class GfxRestirStaticParams(C.Structure):
         ("envLightTexture", C.c_void_p), ("envWidth", C.c_int32), ("envHeight", C.c_int32),
         ("envRowPDF", C.c_void_p), ("envRowCDF", C.c_void_p), ("envRowIntegrals", C.c_void_p),
         ("envTopPDF", C.c_void_p), ("envTopCDF", C.c_void_p), ("envTopIntegral", C.c_float),
-        ("envRowGuide", C.c_void_p), ("envTopGuide", C.c_void_p), ("envRowTable", C.c_void_p),
+        ("envRowGuide", C.c_void_p), ("envTopGuide", C.c_void_p), ("envRowTable", C.c_void_p), ("envRowSketch", C.c_void_p),
     ]
 
 
@@ -330,7 +330,7 @@ HOST_ABI_SYMBOLS = [
     "gfxh_restir_band_plan", "gfxh_restir_set_exchange", "gfxh_strip_rows", "gfxh_band_rows", "gfxh_restir_check_partition", "gfxh_restir_check_bands", "gfxh_balance_bands", "gfxh_restir_frame_program", "gfxh_frame_step_exchange_desc",
     "gfxh_rccl_unique_id", "gfxh_rccl_create", "gfxh_rccl_create_lanes", "gfxh_rccl_set_bands", "gfxh_rccl_destroy", "gfxh_rccl_exchange", "gfxh_rccl_last_error", "gfxh_restir_create",
     "gfxh_restir_set_async_gather", "gfxh_restir_finish_gather", "gfxh_abi_layout", "gfxh_abi_num_entries", "gfxh_abi_entry",
-    "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_build_row_table", "gfxh_env_upload", "gfxh_env_make_sky", "gfxh_restir_set_env",
+    "gfxh_env_build_importance", "gfxh_env_build_guides", "gfxh_env_build_row_table", "gfxh_env_build_row_sketch", "gfxh_env_upload", "gfxh_env_make_sky", "gfxh_restir_set_env",
     "gfxh_restir_destroy", "gfxh_restir_render_frame", "gfxh_restir_outputs_consumed", "gfxh_restir_reset", "gfxh_restir_set_camera", "gfxh_restir_rebuild_accel",
     "gfxh_restir_beauty_buffer", "gfxh_restir_get_params", "gfxh_restir_accel",
     "gfxh_nrc_default_config", "gfxh_nrc_create", "gfxh_nrc_destroy", "gfxh_nrc_render_frame", "gfxh_nrc_outputs_consumed", "gfxh_nrc_set_exchange", "gfxh_nrc_rebuild_accel", "gfxh_nrc_set_env", "gfxh_nrc_beauty_buffer",
@@ -586,9 +586,13 @@ def env_build_importance(texels, w, h):
     out["rowGuide"], out["topGuide"] = np.zeros(h * w, np.uint16), np.zeros(h, np.uint16)
     out["guidesUsable"] = bool(lib().gfxh_env_build_guides(_p(out["rowCDF"]), _p(out["topCDF"]), C.c_uint32(w), C.c_uint32(h),
                                                            _p(out["rowGuide"]), _p(out["topGuide"])))
-    if out["guidesUsable"]:      # the interleaved rows (gfx_restir_static_params::envRowTable)
-        out["rowTable"] = np.zeros(8 * h * (w + 1), np.uint32)
+    if out["guidesUsable"]:      # the interleaved rows (gfx_restir_static_params::envRowTable) and their sketches (envRowSketch)
+        stride = (w + 1 + 3) & ~3
+        out["rowTable"] = np.zeros(8 * h * stride, np.uint32)
         lib().gfxh_env_build_row_table(_p(texels), _p(out["rowPDF"]), _p(out["rowCDF"]), _p(out["rowGuide"]), C.c_uint32(w), C.c_uint32(h), _p(out["rowTable"]))
+        out["rowSketch"] = np.zeros(34 * h, np.uint32)
+        lib().gfxh_env_build_row_sketch.restype = C.c_uint32
+        out["sketchCells"] = int(lib().gfxh_env_build_row_sketch(_p(out["rowCDF"]), C.c_uint32(w), C.c_uint32(h), _p(out["rowSketch"])))
     return out
 
 

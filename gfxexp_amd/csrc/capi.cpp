@@ -63,6 +63,7 @@ int gfx_ctx_create(int device, gfx_ctx** out) {
         t.temporalHints = env_int("GFX_TEMPORAL_HINTS", t.temporalHints, 0, 1);
         t.ptOverlap = env_int("GFX_PT_OVERLAP", t.ptOverlap, 0, 1);
         t.ptRegen = env_int("GFX_PT_REGEN", t.ptRegen, 0, 8);
+        t.ptRegenMin = env_int("GFX_PT_REGEN_MIN", t.ptRegenMin, 1, 64);
         t.candidateSplit = env_int("GFX_CANDIDATE_SPLIT", t.candidateSplit, 0, 4);
         t.fusePasses = env_int("GFX_FUSE_PASSES", t.fusePasses, 0, 2);
         t.blockOrder = env_int("GFX_BLOCK_ORDER", t.blockOrder, 0, 1);
@@ -525,6 +526,7 @@ int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value) {
     else if (n == "trace_batch") t.traceBatch = in(1, 65536);
     else if (n == "pt_overlap") t.ptOverlap = in(0, 1);
     else if (n == "pt_regen") t.ptRegen = in(0, 8);
+    else if (n == "pt_regen_min") t.ptRegenMin = in(1, 64);
     else if (n == "fuse_passes") t.fusePasses = in(0, 2);
     else if (n == "block_order") t.blockOrder = in(0, 1);
     else if (n == "nrc_staged_infer") t.nrcStagedInfer = in(0, 2);

@@ -32,7 +32,7 @@ const Field kFields[] = {
     F(gfx_restir_static_params, lightPreSamplingRngs), F(gfx_restir_static_params, preSampledLights), F(gfx_restir_static_params, envLightTexture),
     F(gfx_restir_static_params, envWidth), F(gfx_restir_static_params, envHeight), F(gfx_restir_static_params, envRowPDF), F(gfx_restir_static_params, envRowCDF),
     F(gfx_restir_static_params, envRowIntegrals), F(gfx_restir_static_params, envTopPDF), F(gfx_restir_static_params, envTopCDF),
-    F(gfx_restir_static_params, envTopIntegral), F(gfx_restir_static_params, envRowGuide), F(gfx_restir_static_params, envTopGuide), F(gfx_restir_static_params, envRowTable),
+    F(gfx_restir_static_params, envTopIntegral), F(gfx_restir_static_params, envRowGuide), F(gfx_restir_static_params, envTopGuide), F(gfx_restir_static_params, envRowTable), F(gfx_restir_static_params, envRowSketch),
     S(gfx_restir_frame_params), F(gfx_restir_frame_params, travHandle), F(gfx_restir_frame_params, numAccumFrames), F(gfx_restir_frame_params, frameIndex),
     F(gfx_restir_frame_params, camera), F(gfx_restir_frame_params, prevCamera), F(gfx_restir_frame_params, envLightPowerCoeff), F(gfx_restir_frame_params, envLightRotation),
     F(gfx_restir_frame_params, spatialNeighborRadius), F(gfx_restir_frame_params, radiusThresholdForSpatialVisReuse), F(gfx_restir_frame_params, log2NumCandidateSamples),

@@ -60,7 +60,10 @@ struct gfxh_restir {
     // queued; evGather: the gather has finished)
     hipEvent_t evGbStrips = nullptr, evBandDone = nullptr, evGather = nullptr, evSeamRows = nullptr, evSeamStrips = nullptr;
     hipStream_t gatherStream = nullptr, seamStream = nullptr;
-    bool seamStripsPending = false, seamFirst = true;   // GFX_SEAM_FIRST=0: every spatial pass in one launch (stripMode 1)
+    // GFX_SEAM_FIRST=1: stripMode 2 (the seam rows of the first biased spatial pass in a launch of their own, their exchange on the seam lane).
+    // Off by default: on one GPU with a transport of the same shape the split costs more than the exchange it hides (the pass is ~50 us at
+    // eight bands: profiles/r06_band_host_overhead.json, r06_experiments.txt 2)
+    bool seamStripsPending = false, seamFirst = false;
     bool asyncGather = false, gatherPending = false, gbStripsPending = false;
     bool stripsOnGbLane = true;   // GFX_GB_STRIPS_ON_MAIN=1 (A/B runs): the G-buffer strips on the caller's stream ahead of the candidate pass, as rounds 2-5 issued them
 };
@@ -213,7 +216,7 @@ int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir*
         const char* m = std::getenv("GFX_GB_STRIPS_ON_MAIN");
         r->stripsOnGbLane = !(m && m[0] == '1');
         const char* sf = std::getenv("GFX_SEAM_FIRST");
-        r->seamFirst = !(sf && sf[0] == '0');
+        r->seamFirst = sf && sf[0] == '1';
         if (!hip_ok(hipStreamCreateWithFlags(&r->gbStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
             !hip_ok(hipEventCreateWithFlags(&r->evPrevRead, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&r->evGbuffer, hipEventDisableTiming), "hipEventCreate") ||
@@ -423,7 +426,7 @@ int gfxh_env_upload(float* texels, uint32_t w, uint32_t h, gfx_restir_static_par
     err |= up(&sp.envRowIntegrals, rowInt.data(), 4 * rowInt.size());
     err |= up(&sp.envTopPDF, topPDF.data(), 4 * topPDF.size());
     err |= up(&sp.envTopCDF, topCDF.data(), 4 * topCDF.size());
-    sp.envRowGuide = nullptr; sp.envTopGuide = nullptr; sp.envRowTable = nullptr;
+    sp.envRowGuide = nullptr; sp.envTopGuide = nullptr; sp.envRowTable = nullptr; sp.envRowSketch = nullptr;
     {
         std::vector<uint16_t> rowGuide(n), topGuide(h);
         if (gfxh_env_build_guides(rowCDF.data(), topCDF.data(), w, h, rowGuide.data(), topGuide.data())) {
@@ -433,9 +436,16 @@ int gfxh_env_upload(float* texels, uint32_t w, uint32_t h, gfx_restir_static_par
             // (GFX_ENV_ROW_TABLE=0: the separate arrays, for A/B runs)
             const char* e = std::getenv("GFX_ENV_ROW_TABLE");
             if (!(e && e[0] == '0')) {
-                std::vector<uint32_t> table(8 * static_cast<size_t>(h) * (w + 1));
+                std::vector<uint32_t> table(8 * static_cast<size_t>(h) * GFX_ENV_ROW_STRIDE(w));
                 gfxh_env_build_row_table(texels, rowPDF.data(), rowCDF.data(), rowGuide.data(), w, h, table.data());
                 err |= up(&sp.envRowTable, table.data(), 4 * table.size());
+                // ... and the rows' inverse-CDF sketches: a sample of a verified cell reads one line of the table (GFX_ENV_ROW_SKETCH=0: the guide)
+                const char* sk = std::getenv("GFX_ENV_ROW_SKETCH");
+                if (!(sk && sk[0] == '0')) {
+                    std::vector<uint32_t> sketch(static_cast<size_t>(h) * GFX_ENV_SKETCH_WORDS);
+                    (void)gfxh_env_build_row_sketch(rowCDF.data(), w, h, sketch.data());
+                    err |= up(&sp.envRowSketch, sketch.data(), 4 * sketch.size());
+                }
             }
         }
     }

@@ -1311,21 +1311,92 @@ int gfxh_env_build_guides(const float* rowCDF, const float* topCDF, uint32_t w, 
 }
 
 void gfxh_env_build_row_table(const float* texels, const float* rowPDF, const float* rowCDF, const uint16_t* rowGuide, uint32_t w, uint32_t h, void* outRecords) {
-    // record (row, i) of 32 bytes: {cdf, pdf, guide, r | g, b, 0, 0} (shading.hip.h EnvRowRec); i = w: the row's final CDF value alone
+    // record (row, i) of 32 bytes: {cdf, pdf, guide, r | g, b, cdf of record i + 1, 0} (shading.hip.h EnvRowRec); i = w: the row's final CDF
+    // value alone; rows GFX_ENV_ROW_STRIDE(w) records apart, so that four consecutive records from a multiple of four are one 128-byte line
     uint32_t* out = static_cast<uint32_t*>(outRecords);
     auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    const size_t stride = GFX_ENV_ROW_STRIDE(w);
     for (uint32_t y = 0; y < h; ++y)
-        for (uint32_t i = 0; i <= w; ++i) {
-            uint32_t* rec = out + 8 * (static_cast<size_t>(y) * (w + 1) + i);
+        for (uint32_t i = 0; i < stride; ++i) {
+            uint32_t* rec = out + 8 * (static_cast<size_t>(y) * stride + i);
+            for (int k = 0; k < 8; ++k) rec[k] = 0u;
+            if (i > w) continue;
             rec[0] = bits(rowCDF[static_cast<size_t>(y) * (w + 1) + i]);
-            for (int k = 1; k < 8; ++k) rec[k] = 0u;
             if (i < w) {
                 const float* t = texels + 4 * (static_cast<size_t>(y) * w + i);
                 rec[1] = bits(rowPDF[static_cast<size_t>(y) * w + i]);
                 rec[2] = rowGuide[static_cast<size_t>(y) * w + i];
                 rec[3] = bits(t[0]); rec[4] = bits(t[1]); rec[5] = bits(t[2]);
+                rec[6] = bits(rowCDF[static_cast<size_t>(y) * (w + 1) + i + 1]);
             }
         }
+}
+
+// The column RegularConstantContinuousDistribution1D::sample's bisection ends on: the largest index of [0, n - 1] whose CDF value is <= u.
+static uint32_t env_column_of(const float* cdf, uint32_t n, float u) {
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (cdf[mid] <= u) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+// What the device predicts for u from a row's knots (shading.hip.h EnvMap::sketch_column: the same operations in the same order; u * 32
+// and the subtraction of the cell index are exact, the rest is one subtraction, one product, one sum).
+static int env_sketch_predict(const float* knots, float u) {
+    const float uk = u * static_cast<float>(GFX_ENV_SKETCH_CELLS);
+    uint32_t k = static_cast<uint32_t>(uk);
+    if (k > GFX_ENV_SKETCH_CELLS - 1u) k = GFX_ENV_SKETCH_CELLS - 1u;
+    const float t = uk - static_cast<float>(k);
+    const float d = knots[k + 1] - knots[k];
+    const float p = knots[k] + t * d;
+    return static_cast<int>(p);
+}
+
+uint32_t gfxh_env_build_row_sketch(const float* rowCDF, uint32_t w, uint32_t h, void* outSketch) {
+    uint32_t* out = static_cast<uint32_t*>(outSketch);
+    const uint32_t K = GFX_ENV_SKETCH_CELLS;
+    uint32_t good = 0;
+    for (uint32_t y = 0; y < h; ++y) {
+        const float* cdf = rowCDF + static_cast<size_t>(y) * (w + 1);
+        float knots[GFX_ENV_SKETCH_CELLS + 1];
+        bool monotone = cdf[0] == 0.0f;
+        for (uint32_t i = 0; i < w && monotone; ++i) monotone = cdf[i] <= cdf[i + 1];
+        for (uint32_t j = 0; j <= K; ++j) {
+            const float u = static_cast<float>(j) / static_cast<float>(K);
+            float pos = static_cast<float>(w);
+            if (j < K && monotone) {
+                const uint32_t c = env_column_of(cdf, w, u);
+                const float width = cdf[c + 1] - cdf[c];
+                const float t = width > 0.0f ? (u - cdf[c]) / width : 0.0f;
+                pos = static_cast<float>(c) + std::min(std::max(t, 0.0f), 1.0f);
+            }
+            knots[j] = pos;
+        }
+        for (uint32_t j = 0; j < K; ++j) if (!(knots[j] <= knots[j + 1])) monotone = false;   // the prediction must not decrease inside a cell
+        uint32_t mask = 0;
+        for (uint32_t k = 0; k < K && monotone; ++k) {
+            // the cell's range of u: [k / K, (k + 1) / K); the columns it reaches; for each the lowest and the highest u of the cell that
+            // ends on it.  The prediction is monotone in u inside a cell (a product and a sum of non-negative terms, correctly rounded), the
+            // column is constant between the two: a test of both ends covers every u in between.
+            const float uLo = static_cast<float>(k) / K, uHi = std::nextafter(static_cast<float>(k + 1) / K, 0.0f);
+            const uint32_t cFirst = env_column_of(cdf, w, uLo), cLast = env_column_of(cdf, w, uHi);
+            bool ok = true;
+            for (uint32_t c = cFirst; c <= cLast && ok; ++c) {
+                if (c != cFirst && !(cdf[c] < cdf[c + 1]) && c != cLast) continue;       // an empty column between two others is never the bisection's answer... unless it is the last of a run
+                float a = std::max(uLo, cdf[c]);
+                float b = c + 1 <= w && cdf[c + 1] <= uHi ? std::nextafter(cdf[c + 1], 0.0f) : uHi;
+                if (!(a <= b)) continue;
+                for (float u : { a, b }) {
+                    if (env_column_of(cdf, w, u) != c) continue;                          // (ties: this u belongs to a later column of equal CDF value, tested there)
+                    const int pred = env_sketch_predict(knots, u);
+                    if (pred < static_cast<int>(c) - 1 || pred > static_cast<int>(c) + 1) ok = false;
+                }
+            }
+            if (ok) { mask |= 1u << k; ++good; }
+        }
+        uint32_t* row = out + static_cast<size_t>(y) * GFX_ENV_SKETCH_WORDS;
+        for (uint32_t j = 0; j <= K; ++j) std::memcpy(row + j, &knots[j], 4);
+        row[K + 1] = mask;
+    }
+    return good;
 }
 
 void gfxh_env_make_sky(uint32_t w, uint32_t h, float sunElevationDeg, float sunAzimuthDeg, float sunRadiance, float* texels) {

@@ -99,6 +99,7 @@ struct Tunables {
     int fusePasses = 0;              // ReSTIR ray passes as one kernel each (restir.hip k_*_fused): 0 = small launches only, 1 never, 2 always
     int nrcStagedInfer = 0;          // k_nrc_infer_staged (hash-grid levels through LDS): 0 = large batches only, 1 never, 2 always (nrc.hip)
     int ptRegen = 3;                 // baseline path tracer, one-kernel form: blocks of 256 per CU of the regenerating launch (pathtrace.hip k_pt_regen); 0 = k_pt_fused
+    int ptRegenMin = 16;             // ... and the idle lanes a wave waits for before it refills (1 = at once)
     int ptOverlap = 1;               // path tracers: the NEE (any-hit) trace + its apply kernel of a bounce run on a second stream underneath
                                      // the extension (closest-hit) trace of the same bounce (pathtrace.hip)
 };

@@ -22,6 +22,7 @@ GFX_DEV EnvMap load_env(const gfx_restir_static_params& s) {
     e.topPDF = static_cast<const float*>(s.envTopPDF); e.topCDF = static_cast<const float*>(s.envTopCDF);
     e.rowGuide = static_cast<const uint16_t*>(s.envRowGuide); e.topGuide = static_cast<const uint16_t*>(s.envTopGuide);
     e.rowTable = static_cast<const EnvRowRec*>(s.envRowTable);
+    e.rowSketch = e.rowTable ? static_cast<const uint32_t*>(s.envRowSketch) : nullptr;
     e.w = s.envWidth; e.h = s.envHeight;
     return e;
 }

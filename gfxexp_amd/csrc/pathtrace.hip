@@ -725,7 +725,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel,
 // sequence of operations on the same RNG stream whichever lane runs it and whenever: the frame is bit-identical to k_pt_fused's.
 // Baseline path tracer only (the ReGIR tracer merges its cell-access atomics across lanes that are at the same vertex).
 __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel, uint2* spill, int spillCap, uint32_t maxPathLength,
-                                                       uint32_t* __restrict__ ticket, uint32_t numSlots) {
+                                                       uint32_t* __restrict__ ticket, uint32_t numSlots, int minRefill) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kPtBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kPtBlock / 64) * 256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -738,27 +738,44 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel,
     path.alpha = f3(0.0f); path.contribution = f3(0.0f); path.dirPDensity = 0.0f; path.rng.state = 0; path.pos = f3(0.0f);
     bool active = false, rngMoved = false, exhausted = false;
     uint32_t pathLength = 2;
-    for (;;) {
-        if (!exhausted) {                                       // wave-uniform
-            const unsigned long long need = __ballot(!active);
-            if (need != 0ull) {
-                const uint32_t count = static_cast<uint32_t>(__popcll(need));
-                uint32_t base = 0;
-                if (lane == __builtin_ctzll(need)) base = atomicAdd(ticket, count);
-                base = __shfl(base, __builtin_ctzll(need));
-                if (!active) {
-                    const uint32_t slot = base + static_cast<uint32_t>(__popcll(need & ((1ull << lane) - 1ull)));
-                    if (slot < numSlots) {
-                        px = pixel_of_block_thread(a.px, slot >> 8, slot & 255u);      // (kPtBlock = 256 slots per launch block)
-                        rngMoved = pt_first_vertex<false>(a, px, path);
-                        pathLength = 2;
-                        active = true;
-                    }
-                }
-                exhausted = base + count >= numSlots;
-            }
+    auto finish = [&]() {                                       // the pixel's RNG state and its running mean (k_pt_finish)
+        if (px.valid) {
+            const size_t p = px.p;
+            if (rngMoved) static_cast<uint64_t*>(a.s.rngBuffer)[p] = path.rng.state;
+            float4* beauty = static_cast<float4*>(a.s.beautyAccumBuffer) + p;
+            f3 prev(0.0f);
+            if (a.f.numAccumFrames > 0) { const float4 bb = *beauty; prev = f3(bb.x, bb.y, bb.z); }
+            const float curWeight = 1.0f / (1 + a.f.numAccumFrames);
+            const f3 result = (1 - curWeight) * prev + curWeight * path.contribution;
+            *beauty = make_float4(result.x, result.y, result.z, 1.0f);
         }
-        if (__ballot(active) == 0ull) break;
+        active = false;
+    };
+    for (;;) {
+        // Refill: when at least `minRefill` lanes are idle (or all of them), the idle lanes draw launch slots -- one wave-aggregated atomic
+        // -- and take their pixel's first vertex from the G-buffer.  A pixel that asks for no ray at all (background, a surface whose
+        // first vertex samples nothing) is finished on the spot and its lane draws again, up to four times per refill.
+        for (int round = 0; round < 4 && !exhausted; ++round) {
+            const unsigned long long need = __ballot(!active);
+            const int idle = __popcll(need);
+            if (idle == 0 || (idle < minRefill && idle < 64 && round == 0)) break;
+            const uint32_t count = static_cast<uint32_t>(idle);
+            uint32_t base = 0;
+            if (lane == __builtin_ctzll(need)) base = atomicAdd(ticket, count);
+            base = __shfl(base, __builtin_ctzll(need));
+            if (!active) {
+                const uint32_t slot = base + static_cast<uint32_t>(__popcll(need & ((1ull << lane) - 1ull)));
+                if (slot < numSlots) {
+                    px = pixel_of_block_thread(a.px, slot >> 8, slot & 255u);      // (kPtBlock = 256 slots per launch block)
+                    rngMoved = pt_first_vertex<false>(a, px, path);
+                    pathLength = 2;
+                    active = true;
+                    if (!path.o.wantNee && !path.o.wantExt) finish();
+                }
+            }
+            exhausted = base + count >= numSlots;
+        }
+        if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
         const bool nee = active && path.o.wantNee;
         const RayHit shadow = trace_wave_local<true>(accel, nee, path.o.neeFromOrg ? path.o.neeOrg : path.pos, path.o.neeDir, 0.0f, path.o.neeTmax,
                                                      stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane);
@@ -780,19 +797,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel,
                 ++pathLength;
             }
         }
-        if (done) {
-            if (px.valid) {
-                const size_t p = px.p;
-                if (rngMoved) static_cast<uint64_t*>(a.s.rngBuffer)[p] = path.rng.state;
-                float4* beauty = static_cast<float4*>(a.s.beautyAccumBuffer) + p;      // k_pt_finish
-                f3 prev(0.0f);
-                if (a.f.numAccumFrames > 0) { const float4 bb = *beauty; prev = f3(bb.x, bb.y, bb.z); }
-                const float curWeight = 1.0f / (1 + a.f.numAccumFrames);
-                const f3 result = (1 - curWeight) * prev + curWeight * path.contribution;
-                *beauty = make_float4(result.x, result.y, result.z, 1.0f);
-            }
-            active = false;
-        }
+        if (done) finish();
     }
 }
 
@@ -1548,7 +1553,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
                 a.px.order = nullptr;
                 ScopedKernelTimer timer(ctx, stream, "pt_regen");
                 hipLaunchKernelGGL(k_pt_regen, dim3(regenBlocks), dim3(kPtBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap, maxPathLength,
-                                   counters + 4, a.px.launchBlocks * static_cast<uint32_t>(kPtBlock));
+                                   counters + 4, a.px.launchBlocks * static_cast<uint32_t>(kPtBlock), ctx.tune.ptRegenMin);
                 GFX_HIP(hipGetLastError());
                 return;
             }

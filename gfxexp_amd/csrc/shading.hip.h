@@ -449,7 +449,7 @@ struct PendingEmittance { uint32_t tex; uint32_t rec; float bcA, bcB, bcC; };
 // 64-byte sector of its own from HBM -- 8.2 GB per candidate pass, 4.9 TB/s: that pass ran at the memory system's rate
 // (profiles/r05_experiments.txt 5).  Interleaved, the guide pair, the probes and the final (cdf, cdf', pdf, texel) of a sample lie in the
 // two or three sectors around the texel it ends on.  Same values, same arithmetic: same samples bit for bit.
-struct EnvRowRec { float cdf, pdf; uint32_t guide; float r, g, b; uint32_t pad0, pad1; };
+struct EnvRowRec { float cdf, pdf; uint32_t guide; float r, g, b; float cdfNext; uint32_t pad1; };
 static_assert(sizeof(EnvRowRec) == 32, "two records per 64-byte sector");
 
 // The largest index of [lo, hi] whose CDF value is <= u (cdfAt(lo) <= u is known; the CDF is monotone): what the bisection of
@@ -479,9 +479,10 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
     const float* rowPDF; const float* rowCDF; const float* topPDF; const float* topCDF;
     const uint16_t* rowGuide; const uint16_t* topGuide;   // optional guide tables (gfxh_env_build_guides), or null
     const EnvRowRec* rowTable;                            // optional interleaved rows (gfxh_env_build_row_table; needs the guides), or null
+    const uint32_t* rowSketch;                            // optional, with rowTable: 33 inverse-CDF knots + a mask of verified cells per row (gfxh_env_build_row_sketch), or null
     int32_t w, h;
     GFX_DEV bool present() const { return texels != nullptr; }
-    GFX_DEV const EnvRowRec* table_row(uint32_t row) const { return rowTable + static_cast<size_t>(row) * (static_cast<uint32_t>(w) + 1u); }
+    GFX_DEV const EnvRowRec* table_row(uint32_t row) const { return rowTable + static_cast<size_t>(row) * GFX_ENV_ROW_STRIDE(w); }
     GFX_DEV f3 fetch(float u, float v) const { // nearest texel (the build's tex2DLod contract)
         uint32_t x = f2u_sat(u * w); if (x > static_cast<uint32_t>(w - 1)) x = w - 1;
         uint32_t y = f2u_sat(v * h); if (y > static_cast<uint32_t>(h - 1)) y = h - 1;
@@ -545,6 +546,40 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
         p = here.y;
         return (idx + t) / n;
     }
+    // sample1d_row without the guide: the row's sketch (33 knots of its inverse CDF, L2-resident) predicts the column to within one -- the
+    // builder verified that for every u of this cell -- so the answer is in the 128-byte line of four records around the prediction, or in
+    // the first / last record of a neighbouring line when the prediction sits on the line's edge: one line of the table per sample
+    // instead of the guide's and the column's.  The column chosen is the largest one whose CDF value is <= u, as the bisection's.
+    static GFX_DEV bool sample1d_row_sketch(const EnvRowRec* row, const uint32_t* sketch, uint32_t n, float u, float& p, float& d0) {
+        const float uk = u * static_cast<float>(GFX_ENV_SKETCH_CELLS);
+        uint32_t k = static_cast<uint32_t>(uk);
+        if (k > GFX_ENV_SKETCH_CELLS - 1u) k = GFX_ENV_SKETCH_CELLS - 1u;
+        if (!((sketch[GFX_ENV_SKETCH_CELLS + 1u] >> k) & 1u)) return false;
+        const float k0 = bits2f(sketch[k]), k1 = bits2f(sketch[k + 1u]);
+        const float t = uk - static_cast<float>(k);
+        const float d = k1 - k0;
+        const float pred = k0 + t * d;
+        int fp = static_cast<int>(pred);
+        fp = fp < 0 ? 0 : (fp > static_cast<int>(n) - 1 ? static_cast<int>(n) - 1 : fp);
+        const int a = fp & ~3;                                       // n is a multiple of four or the last group is padded (GFX_ENV_ROW_STRIDE)
+        float2 c[4]; float nx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[j] = *reinterpret_cast<const float2*>(row + a + j); nx[j] = row[a + j].cdfNext; }
+        int idx = a; float2 here = c[0]; float next = nx[0];
+        const int last = static_cast<int>(n) - 1;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) if (a + j <= last && c[j].x <= u) { idx = a + j; here = c[j]; next = nx[j]; }
+        if (c[0].x > u && a > 0) {                                   // the column before the line (prediction one too high at the line's first record)
+            idx = a - 1; here = *reinterpret_cast<const float2*>(row + idx); next = c[0].x;
+        }
+        else if (idx == a + 3 && a + 4 <= last && next <= u) {       // the column after the line
+            idx = a + 4; here = *reinterpret_cast<const float2*>(row + idx); next = row[idx].cdfNext;
+        }
+        const float tt = (u - here.x) / (next - here.x);
+        p = here.y;
+        d0 = (idx + tt) / n;
+        return true;
+    }
     GFX_DEV float evaluate_pdf(float d0, float d1) const { // common_shared.h:344-348, 380-383
         uint32_t row = f2u_sat(d1 * h); if (row > static_cast<uint32_t>(h - 1)) row = h - 1;
         uint32_t col = f2u_sat(d0 * w); if (col > static_cast<uint32_t>(w - 1)) col = w - 1;
@@ -555,7 +590,10 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
         float topP;
         d1 = sample1d(topPDF, topCDF, h, u1, topP, topGuide);
         uint32_t row = f2u_sat(d1 * h); if (row > static_cast<uint32_t>(h - 1)) row = h - 1;
-        if (rowTable) d0 = sample1d_row(table_row(row), w, u0, p);
+        if (rowTable) {
+            if (!(rowSketch && sample1d_row_sketch(table_row(row), rowSketch + static_cast<size_t>(row) * GFX_ENV_SKETCH_WORDS, w, u0, p, d0)))
+                d0 = sample1d_row(table_row(row), w, u0, p);
+        }
         else d0 = sample1d(rowPDF + static_cast<size_t>(row) * w, rowCDF + static_cast<size_t>(row) * (w + 1), w, u0, p,
                            rowGuide ? rowGuide + static_cast<size_t>(row) * w : nullptr);
         p *= topP;

@@ -248,9 +248,21 @@ typedef struct gfx_restir_static_params {
     /* Optional: the rows of the map with everything a light sample on it reads in one place (gfxh_env_build_row_table; NULL = the
      * separate arrays above, same results): envH x (envW + 1) records of 32 bytes {float cdf, pdf; uint32 guide; float r, g, b; 8 B
      * unused} -- record (row, i) = envRowCDF[row * (envW + 1) + i], envRowPDF[row * envW + i], envRowGuide[row * envW + i] and texel
-     * (i, row) (zero where i = envW has none).  A sample then touches two or three 64-byte sectors instead of six or seven. */
+     * (i, row) (zero where i = envW has none); the seventh word is the NEXT record's cdf.  Rows are GFX_ENV_ROW_STRIDE(envW) records apart
+     * (a multiple of four: groups of four records are 128-byte lines).  A sample then touches two or three 64-byte sectors instead of six
+     * or seven. */
     const void* envRowTable;
+    /* Optional, with envRowTable (gfxh_env_build_row_sketch; NULL = the guide inside the records): per row GFX_ENV_SKETCH_WORDS words --
+     * 33 floats, the row's inverse CDF (in columns) at u = 0, 1/32 .. 1, then a 32-bit mask: bit k set = for every u of [k/32, (k+1)/32)
+     * the linear interpolation of the two knots lands within one column of the column the bisection finds (verified by the builder for
+     * every column of the cell).  A sample of such a cell reads ONE 128-byte line of the row table (the group of four records around the
+     * prediction; a neighbouring line in the few cases the column sits across its edge) instead of the guide's line plus the column's;
+     * the 135 KB of sketches stay in L2.  Cells that fail the test (rows through the sun) keep the guide.  Same column, same sample. */
+    const void* envRowSketch;
 } gfx_restir_static_params;
+#define GFX_ENV_ROW_STRIDE(envW) ((((uint32_t)(envW)) + 1u + 3u) & ~3u)
+#define GFX_ENV_SKETCH_CELLS 32u
+#define GFX_ENV_SKETCH_WORDS 34u
 
 /* restir_di/restir_di_shared.h:241-281 PerFramePipelineLaunchParameters. */
 typedef struct gfx_restir_frame_params {

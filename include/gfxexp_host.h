@@ -119,15 +119,20 @@ int gfxh_env_build_importance(float* texels4, uint32_t w, uint32_t h, float* row
  * the samplers' log2(n)-step searches become a table lookup plus a one- or two-entry bracket search with identical
  * results.  Returns 1 when the tables are usable (every CDF monotone, w and h <= 65536), 0 otherwise (pass NULL). */
 int gfxh_env_build_guides(const float* rowCDF, const float* topCDF, uint32_t w, uint32_t h, uint16_t* rowGuide, uint16_t* topGuide);
-/* gfx_restir_static_params::envRowTable: the rows of the map interleaved -- h x (w + 1) records of 32 bytes {cdf, pdf, guide, r, g, b, 0, 0}
- * from the (clamped) texels, the conditional PDFs / CDFs and a usable row guide (gfxh_env_build_guides returned 1).  outRecords: 32 x h x
- * (w + 1) bytes.  Same samples as with the separate arrays; a third of the memory traffic per sample. */
+/* gfx_restir_static_params::envRowTable: the rows of the map interleaved -- h rows of GFX_ENV_ROW_STRIDE(w) records of 32 bytes
+ * {cdf, pdf, guide, r, g, b, next record's cdf, 0} (records w + 1 .. stride - 1 of a row are zero) from the (clamped) texels, the
+ * conditional PDFs / CDFs and a usable row guide (gfxh_env_build_guides returned 1).  outRecords: 32 x h x GFX_ENV_ROW_STRIDE(w) bytes.
+ * Same samples as with the separate arrays; a third of the memory traffic per sample. */
 void gfxh_env_build_row_table(const float* texels4, const float* rowPDF, const float* rowCDF, const uint16_t* rowGuide, uint32_t w, uint32_t h, void* outRecords);
+/* gfx_restir_static_params::envRowSketch (described there): outSketch = h x GFX_ENV_SKETCH_WORDS 32-bit words.  Returns the number of
+ * cells (of 32 h) whose prediction the builder verified -- for every column that a cell's range of u reaches, at both ends of the
+ * range, with the arithmetic the device uses -- to lie within one column of the bisection's result; the others keep their mask bit clear. */
+uint32_t gfxh_env_build_row_sketch(const float* rowCDF, uint32_t w, uint32_t h, void* outSketch);
 /* The device side of "-env-texture" (restir_di_main.cpp:1188-1197, common_host.cpp:204-357) in one call, for the renderers below and for
  * callers that fill gfx_restir_static_params themselves: the importance tables, guides and row table of a lat-long float4 map (the three
  * functions above) are built, map and tables uploaded, and the env* fields of `sp` set.  Synchronous.  The device allocations it made
  * (at most GFXH_ENV_MAX_ALLOCATIONS, also on failure) are returned for the caller to hipFree once no launch reads `sp` any more. */
-#define GFXH_ENV_MAX_ALLOCATIONS 9
+#define GFXH_ENV_MAX_ALLOCATIONS 10
 int gfxh_env_upload(float* texels4, uint32_t w, uint32_t h, gfx_restir_static_params* sp, void** allocations, uint32_t* numAllocations);
 /* Synthetic lat-long sky (gradient + sun disc) used as the stand-in environment map. */
 void gfxh_env_make_sky(uint32_t w, uint32_t h, float sunElevationDeg, float sunAzimuthDeg, float sunRadiance, float* texels4);
@@ -325,7 +330,8 @@ typedef struct gfxh_frame_step {
     uint32_t gapBegin, gapEnd;                                 /* a pass over rows [rowBegin, gapBegin) + [gapEnd, rowEnd) (gfx_restir_launch_rows_gap); 0, 0 = no gap */
 } gfxh_frame_step;
 /* stripMode: 0 = whole frame / halo recompute, 1 = strip exchange with every pass over the band in one launch, 2 = 1 + seam rows first
- * (lane SEAM) for the spatial passes that are followed by another pass -- what gfxh_restir_render_frame runs (GFX_SEAM_FIRST=0: 1). */
+ * (lane SEAM) for the spatial passes that are followed by another pass.  gfxh_restir_render_frame runs 1; GFX_SEAM_FIRST=1 makes it run 2 (measured
+ * slower on one GPU with a transport of the same shape: profiles/r06_band_host_overhead.json). */
 int gfxh_restir_frame_program(const gfxh_restir_config* cfg, int stripMode, uint32_t maxMotionRows, int newSequence,
                               uint32_t lastReservoirIndex, uint32_t lastSpatialNeighborBaseIndex, uint32_t useUnbiasedEstimator,
                               gfxh_frame_step* steps, uint32_t capacity, uint32_t* numSteps, uint32_t* newLastReservoirIndex,

@@ -53,7 +53,7 @@ class GfxRestirStaticParams(C.Structure):
         ("envLightTexture", C.c_void_p), ("envWidth", C.c_int32), ("envHeight", C.c_int32),
         ("envRowPDF", C.c_void_p), ("envRowCDF", C.c_void_p), ("envRowIntegrals", C.c_void_p),
         ("envTopPDF", C.c_void_p), ("envTopCDF", C.c_void_p), ("envTopIntegral", C.c_float),
-        ("envRowGuide", C.c_void_p), ("envTopGuide", C.c_void_p), ("envRowTable", C.c_void_p),   # accepted and ignored: the oracle always searches the plain arrays
+        ("envRowGuide", C.c_void_p), ("envTopGuide", C.c_void_p), ("envRowTable", C.c_void_p), ("envRowSketch", C.c_void_p),   # accepted and ignored: the oracle always searches the plain arrays
     ]
 
 

@@ -81,3 +81,67 @@ def test_guide_tables_bracket_every_search(built_lib):
     ok = api.lib().gfxh_env_build_guides(e["rowCDF"].ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p), C.c_uint32(w), C.c_uint32(h),
                                          np.zeros(h * w, np.uint16).ctypes.data_as(C.c_void_p), np.zeros(h, np.uint16).ctypes.data_as(C.c_void_p))
     assert ok == 0
+
+
+def _sketch_select(rec_cdf, n, knots, mask, u):
+    """EnvMap::sample1d_row_sketch (shading.hip.h) restated with float32 operations: the column it ends on for u, or -1 when the cell
+    of u is not verified.  rec_cdf: the row's n + 1 CDF values (the cdf / cdfNext words of the records)."""
+    f = np.float32
+    uk = f(u) * f(32.0)
+    k = min(int(uk), 31)
+    if not (int(mask) >> k) & 1:
+        return -1
+    t = f(uk - f(k))
+    d = f(knots[k + 1] - knots[k])
+    pred = f(knots[k] + f(t * d))
+    fp = min(max(int(pred), 0), n - 1)
+    a = fp & ~3
+    last = n - 1
+    idx = a
+    for j in range(1, 4):
+        if a + j <= last and rec_cdf[a + j] <= u:
+            idx = a + j
+    if rec_cdf[a] > u and a > 0:
+        idx = a - 1
+    elif idx == a + 3 and a + 4 <= last and rec_cdf[a + 4] <= u:
+        idx = a + 4
+    return idx
+
+
+def test_row_sketch_predicts_the_bisection_column_in_every_verified_cell(built_lib):
+    """gfxh_env_build_row_sketch: in a cell whose mask bit is set, the device's selection from the line of four records around the
+    prediction (restated above) is the column the reference's bisection ends on -- for random u, for every CDF knot of the row and
+    for the float just below every knot.  Peaked and smooth maps; the record layout (cdfNext, row stride) is checked on the way."""
+    rng = np.random.default_rng(21)
+    for (w, h, sun) in ((256, 128, 5000.0), (512, 64, 400.0), (100, 20, 50.0)):
+        sky = api.env_make_sky(w, h, sun_radiance=sun)
+        e = api.env_build_importance(sky.copy(), w, h)
+        assert e["guidesUsable"] and 0 < e["sketchCells"] <= 32 * h
+        stride = (w + 1 + 3) & ~3
+        table = e["rowTable"].reshape(h, stride, 8)
+        rows = e["rowCDF"].reshape(h, w + 1)
+        sketch = e["rowSketch"].reshape(h, 34)
+        # records: word 0 = cdf, word 6 = the next record's cdf, padding records are zero
+        assert np.array_equal(table[:, :w + 1, 0].view(np.float32), rows)
+        assert np.array_equal(table[:, :w, 6].view(np.float32), rows[:, 1:])
+        assert not table[:, w + 1:, :].any()
+        checked = unverified = 0
+        for y in list(range(0, h, max(1, h // 9))) + [h - 1]:
+            cdf = rows[y]
+            knots, mask = sketch[y, :33].view(np.float32), sketch[y, 33]
+            assert np.all(np.diff(knots) >= 0) or mask == 0
+            us = np.concatenate([rng.random(600).astype(np.float32), cdf[:w], np.nextafter(cdf[1:], np.float32(0))])
+            us = us[(us >= 0) & (us < 1)]
+            want = np.minimum(np.searchsorted(cdf[:w], us, side="right") - 1, w - 1)
+            for u, wnt in zip(us, want):
+                got = _sketch_select(cdf, w, knots, mask, u)
+                if got < 0:
+                    unverified += 1
+                    continue
+                assert got == wnt, (w, h, y, float(u), got, int(wnt))
+                checked += 1
+        assert checked > 2000
+    # the bench's sky (2048 x 1024 in bench.py; a quarter of it here): nearly every cell is verified -- the rows through the sun keep the guide
+    w, h = 1024, 512
+    e = api.env_build_importance(api.env_make_sky(w, h).copy(), w, h)
+    assert e["sketchCells"] >= 0.9 * 32 * h, e["sketchCells"] / (32.0 * h)

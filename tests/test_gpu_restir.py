@@ -49,7 +49,8 @@ def run_sequence_both(hs, width, height, frames=2, renderer=api.RENDERER_BIASED,
         pb_gpu_init.set_env(*env)
         pb_cpu.set_env(*env, oracle_side=True)
         # what the GPU searches: the interleaved rows (gfx_restir_static_params::envRowTable), the separate arrays with guide tables, or the plain arrays
-        pb_gpu_init.use_env_row_table = env_tables == "interleaved"
+        pb_gpu_init.use_env_row_table = env_tables in ("interleaved", "sketch")
+        pb_gpu_init.use_env_row_sketch = env_tables == "sketch"
         pb_gpu_init.use_env_guides = env_tables != "plain"
     dev = util.DeviceBuffers(pb_gpu_init)
     s_gpu = dev.static_params()
@@ -286,13 +287,14 @@ def test_halo_band_renderer_refuses_a_frame_after_the_camera_moved(built_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_tables", ["interleaved", "guided", "plain"])
+@pytest.mark.parametrize("env_tables", ["sketch", "interleaved", "guided", "plain"])
 @pytest.mark.parametrize("renderer", [api.RENDERER_BIASED, api.RENDERER_UNBIASED])
 def test_environment_light_sequence_bit_exact(built_lib, renderer, env_tables):
     """BASELINE config 5 ingredients: environment light (importance-sampled lat-long map, 25 % of the
     candidates) + area lights, unbiased and biased estimators -- with the map's rows interleaved into 32-byte records (envRowTable:
-    CDF, PDF, guide and texel of a column side by side), as separate arrays with guide tables, and as the plain arrays with the
-    reference's binary searches: the same samples bit for bit."""
+    CDF, PDF, guide and texel of a column side by side), with the rows' inverse-CDF sketches on top (envRowSketch: the column predicted
+    to within one, no guide read), as separate arrays with guide tables, and as the plain arrays with the reference's binary searches:
+    the same samples bit for bit."""
     w, h = 64, 32
     sky = api.env_make_sky(w, h)
     diffs = run_sequence_both(util.bunny_scene(), 128, 80, frames=2, renderer=renderer, env=(sky, w, h),

@@ -246,6 +246,8 @@ class DeviceBuffers:
                     self.env_t[k] = torch.from_numpy(pb.env[k].view(np.uint8).reshape(-1).copy()).cuda()
                 if "rowTable" in pb.env and getattr(pb, "use_env_row_table", True):      # the interleaved rows (gfx_restir_static_params::envRowTable)
                     self.env_t["rowTable"] = torch.from_numpy(pb.env["rowTable"].view(np.uint8).reshape(-1).copy()).cuda()
+                    if "rowSketch" in pb.env and getattr(pb, "use_env_row_sketch", True):   # ... and their inverse-CDF sketches (envRowSketch)
+                        self.env_t["rowSketch"] = torch.from_numpy(pb.env["rowSketch"].view(np.uint8).reshape(-1).copy()).cuda()
 
     def static_params(self):
         pb, t = self.pb, self.t
@@ -272,6 +274,8 @@ class DeviceBuffers:
                 s.envRowGuide = et["rowGuide"].data_ptr(); s.envTopGuide = et["topGuide"].data_ptr()
             if "rowTable" in et:
                 s.envRowTable = et["rowTable"].data_ptr()
+            if "rowSketch" in et:
+                s.envRowSketch = et["rowSketch"].data_ptr()
         return s
 
     def download(self):

@@ -1,8 +1,8 @@
 """What the exchanges of a band renderer cost on ONE GPU, as far as one GPU can tell (profiles/r06_band_host_overhead.json).
 
   host      wall time the host spends inside gfxh_restir_render_frame per band frame (band 4 of 8 of the 1920x1080 bench frame), with
-            the production C++ callback gfxh_rccl_exchange over the recording librccl stand-in (tests/native/librccl_stub.so: every
-            RCCL call returns at once) against the torch.distributed callback (tilesplit.StripExchange) over a `dist` whose collectives
+            the production C++ callback gfxh_rccl_exchange over the mirror librccl stand-in at zero latency (tests/native/librccl_mirror.so:
+            a hipMemcpyAsync per received strip, about what a grouped ncclSend / ncclRecv costs the host) against the torch.distributed callback (tilesplit.StripExchange) over a `dist` whose collectives
             return at once -- the Python a frame executes between its passes, without any transport behind it.  The GPU is slower than
             either host, so the launch queue never pushes back: this is enqueue time.
   latency   frame time of that band with a transport of the right shape: gfxh_rccl_exchange over tests/native/librccl_mirror.so
@@ -97,7 +97,7 @@ def main():
     config4 = "--config4" in sys.argv
     nb, steps = int(arg("--bands", "8")), int(arg("--steps", "60"))
     W, H = 1920, 1080
-    stub = os.path.join(ROOT, "tests", "native", "librccl_stub.so" if mode == "host" else "librccl_mirror.so")
+    stub = os.path.join(ROOT, "tests", "native", "librccl_mirror.so")   # (the recording stub moves its all-gather on the host: device pointers over PCIe)
     os.environ["GFX_RCCL_LIBRARY"] = stub          # before libgfxexp loads librccl
     if mode == "latency":
         sched = arg("--schedule", "lanes")
@@ -122,7 +122,7 @@ def main():
         ex.install(r, 0)
         r.set_async_gather(True)
         wall, host = run(r, stream, steps)
-        res["gfxh_rccl_exchange (C++), recording stub"] = {"host_ms_per_frame": round(host, 4), "frame_ms": round(wall, 4)}
+        res["gfxh_rccl_exchange (C++), mirror transport at zero latency"] = {"host_ms_per_frame": round(host, 4), "frame_ms": round(wall, 4)}
         r.close()
         # torch callback over a dist whose collectives return at once
         r, cfg = make_renderer(api, scenes, ctx, W, H, band, config4)
