@@ -316,8 +316,8 @@ C_ABI_SYMBOLS = [
     "gfx_lights_build_instances", "gfx_lights_read", "gfx_lights_table_info", "gfx_trace", "gfx_trace_counted", "gfx_restir_set_params", "gfx_restir_copy_to_linear", "gfx_visualize", "gfx_restir_launch",
     "gfx_restir_launch_rows", "gfx_restir_launch_rows_gap", "gfx_pt_launch", "gfx_regir_set_params",
     "gfx_nrc_create", "gfx_nrc_destroy", "gfx_nrc_infer", "gfx_nrc_infer_indirect", "gfx_nrc_query_count_ptr", "gfx_nrc_train", "gfx_nrc_num_params", "gfx_nrc_set_params",
-    "gfx_nrc_get_params", "gfx_nrc_inference_image", "gfx_nrc_inference_image_async", "gfx_nrc_set_render_params",
-    "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read", "gfx_trace_diag_read",
+    "gfx_nrc_get_params", "gfx_nrc_inference_image", "gfx_nrc_inference_image_async", "gfx_nrc_params_checksum", "gfx_nrc_set_render_params",
+    "gfx_read_device", "gfx_timing_enable", "gfx_timing_collect", "gfx_counters_enable", "gfx_counters_read", "gfx_trace_diag_read", "gfx_pt_diag_read",
     "gfx_tunable_set", "gfx_stream_copy",
 ]
 HOST_ABI_SYMBOLS = [
@@ -779,6 +779,12 @@ class Context:
         self._check(self.L.gfx_trace_diag_read(self.h, c, C.c_int(1 if reset else 0)))
         return dict(iterations=c[0], itemLanes=c[1], drainIterations=c[2], drainItemLanes=c[3],
                     waveCycles=c[4], refillCycles=c[5], fetchCycles=c[6], processCycles=c[7])
+
+    def pt_diag_read(self, reset=True):
+        """gfx_pt_diag_read (tunable "pt_diag"): wave iterations, lanes with a ray, traversal steps, waves, refills of the one-kernel path tracers."""
+        c = (C.c_uint64 * 8)()
+        self._check(self.L.gfx_pt_diag_read(self.h, c, C.c_int(1 if reset else 0)))
+        return dict(iterations=c[0], lanes=c[1], steps=c[2], waves=c[3], refills=c[4])
 
     def counters_read(self, reset=True):
         c = (C.c_uint64 * 8)()

@@ -472,6 +472,13 @@ int gfx_nrc_inference_image_async(gfx_ctx* ctx, void* stream, uint64_t handle, i
     GFX_CATCH(ctx)
 }
 
+int gfx_nrc_params_checksum(gfx_ctx* ctx, void* stream, uint64_t handle, void* dOutU32) {
+    GFX_TRY(ctx)
+    if (!dOutU32) throw HipError("gfx_nrc_params_checksum: null output");
+    nrc_params_checksum(ctx->c, static_cast<hipStream_t>(stream), nrc_of(ctx, handle), static_cast<uint32_t*>(dOutU32));
+    GFX_CATCH(ctx)
+}
+
 int gfx_read_device(gfx_ctx* ctx, const void* dSrc, void* hostDst, size_t bytes) {
     GFX_TRY(ctx)
     GFX_HIP(hipDeviceSynchronize());
@@ -526,6 +533,7 @@ int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value) {
     else if (n == "trace_batch") t.traceBatch = in(1, 65536);
     else if (n == "pt_overlap") t.ptOverlap = in(0, 1);
     else if (n == "pt_regen") t.ptRegen = in(0, 8);
+    else if (n == "pt_diag") t.ptDiag = in(0, 1);
     else if (n == "pt_regen_min") t.ptRegenMin = in(1, 64);
     else if (n == "fuse_passes") t.fusePasses = in(0, 2);
     else if (n == "block_order") t.blockOrder = in(0, 1);
@@ -554,6 +562,17 @@ int gfx_trace_diag_read(gfx_ctx* ctx, uint64_t diag[8], int reset) {
     if (ctx->c.dTraceDiag.p) {
         GFX_HIP(hipMemcpy(diag, ctx->c.dTraceDiag.p, 64, hipMemcpyDeviceToHost));
         if (reset) GFX_HIP(hipMemset(ctx->c.dTraceDiag.p, 0, 64));
+    }
+    GFX_CATCH(ctx)
+}
+
+int gfx_pt_diag_read(gfx_ctx* ctx, uint64_t diag[8], int reset) {
+    GFX_TRY(ctx)
+    GFX_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 8; ++i) diag[i] = 0;
+    if (ctx->c.ptDiag.p) {
+        GFX_HIP(hipMemcpy(diag, ctx->c.ptDiag.p, 64, hipMemcpyDeviceToHost));
+        if (reset) GFX_HIP(hipMemset(ctx->c.ptDiag.p, 0, 64));
     }
     GFX_CATCH(ctx)
 }

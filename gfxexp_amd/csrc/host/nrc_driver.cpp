@@ -36,6 +36,7 @@ struct gfxh_nrc {
     // neeSampler == 2: the ReSTIR DI passes ahead of the tracer -- reservoir ping-pong and neighbour-table index as restir_di_main.cpp:1686, 2402-2411
     uint32_t lastReservoirIndex = 1, lastSpatialNeighborBaseIndex = 0;
     std::vector<void*> allocations;
+    std::vector<void*> envAllocations;        // the environment map's tables (gfxh_nrc_set_env): replaced as a set
     uint64_t accel = 0, network = 0;
     uint32_t frameIndex = 0, numAccumFrames = 0;
     bool viewMoved = false;      // an instance moved since the last frame: accumulation restarts
@@ -69,6 +70,9 @@ struct gfxh_nrc {
     // band split: every rank trains its own copy of the network on the gathered batch (training is reproducible bit for bit, nrc.hip
     // k_nrc_grid_scatter, so the copies stay identical); GFX_NRC_TRAIN_ON_RANK0=1: rank 0 trains and broadcasts its inference images (rounds 3-4)
     bool trainOnRank0 = false;
+    // ... and every kChecksumPeriod-th frame the ranks compare a checksum of the images they infer with (one 8-byte all-reduce): a copy
+    // that has drifted -- an order-dependent gradient sum, a rank that missed a batch -- fails the frame instead of drawing seams
+    void* dChecksum = nullptr;                // device uint32[2]: {checksum, 1}
     // band renderer (gfxh_nrc_set_exchange)
     gfxh_exchange_fn exchange = nullptr; void* exchangeUser = nullptr; int rank = 0;
     uint32_t gatherCounts[2] = { 0, 0 };
@@ -112,6 +116,7 @@ void gfxh_nrc_destroy(gfxh_nrc* r) {
     if (r->gbStream) (void)hipStreamDestroy(r->gbStream);
     if (r->network) (void)gfx_nrc_destroy(r->ctx, r->network);
     for (void* p : r->allocations) (void)hipFree(p);
+    for (void* p : r->envAllocations) (void)hipFree(p);
     delete r;
 }
 
@@ -401,9 +406,33 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
             }
         }
         else if (lossOut) *lossOut = 0.0f;
+        constexpr uint32_t kChecksumPeriod = 16;
+        const bool compare = band && !rank0Trains && (r->frameIndex % kChecksumPeriod) == kChecksumPeriod - 1;
+        uint32_t ownChecksum = 0;
+        if (compare) {
+            if (!r->dChecksum && nrc_alloc(r, &r->dChecksum, 8)) return 1;
+            const uint32_t init[2] = { 0u, 1u };
+            NRC_HIP(hipMemcpyAsync(r->dChecksum, init, 8, hipMemcpyHostToDevice, static_cast<hipStream_t>(ts)));
+            NRC_GFX(gfx_nrc_params_checksum(ctx, ts, r->network, r->dChecksum));
+            NRC_HIP(hipMemcpyAsync(&ownChecksum, r->dChecksum, 4, hipMemcpyDeviceToHost, static_cast<hipStream_t>(ts)));
+        }
         if (overlap) {
             NRC_HIP(hipEventRecord(r->evTrained, r->trainStream));
             r->trainPending = true;
+        }
+        if (compare) {
+            if (overlap) { NRC_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), r->evTrained, 0)); r->trainPending = false; }
+            gfxh_exchange_desc d; std::memset(&d, 0, sizeof(d));
+            d.kind = GFXH_EXCHANGE_ALLREDUCE_SUM_U32; d.counters = r->dChecksum; d.numCounters = 2;
+            if (exchange(d)) return 1;
+            uint32_t sum[2] = { 0u, 0u };
+            NRC_HIP(hipMemcpyAsync(sum, r->dChecksum, 8, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+            NRC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+            if (sum[0] != ownChecksum * sum[1]) {     // (mod 2^32: equal copies sum to world x own)
+                g_nrcError = "gfxh_nrc_render_frame: the ranks' copies of the network have diverged (checksum of the inference images, frame " +
+                             std::to_string(r->frameIndex) + "); GFX_NRC_TRAIN_ON_RANK0=1 trains on rank 0 and broadcasts";
+                return 1;
+            }
         }
         if (rank0Trains) {   // rank 0's freshly packed inference images -> everyone
             gfxh_exchange_desc d; std::memset(&d, 0, sizeof(d));
@@ -437,6 +466,11 @@ int gfxh_nrc_render_frame(gfxh_nrc* r, void* stream, float* lossOut) {
 
 int gfxh_nrc_set_exchange(gfxh_nrc* r, gfxh_exchange_fn fn, void* user, int rank) {
     r->exchange = fn; r->exchangeUser = user; r->rank = rank;
+    // Every rank training its own copy needs a training step that is reproducible bit for bit: the default hash-grid gradient (summed in
+    // LDS tables in a defined order) is; GFX_NRC_GRID_GRAD = f32 | f16atomic sums with global atomics in arrival order, so the copies
+    // would drift apart: those modes train on rank 0 and broadcast.
+    if (const char* e = std::getenv("GFX_NRC_GRID_GRAD"))
+        if (std::strcmp(e, "f32") == 0 || std::strcmp(e, "f16atomic") == 0) r->trainOnRank0 = true;
     return 0;
 }
 
@@ -447,12 +481,14 @@ int gfxh_nrc_rebuild_accel(gfxh_nrc* r, void* stream) {
 }
 void* gfxh_nrc_beauty_buffer(gfxh_nrc* r) { return r->sp.beautyAccumBuffer; }
 int gfxh_nrc_set_env(gfxh_nrc* r, float* texels, uint32_t w, uint32_t h, float powerCoeff, float rotation) {
-    // frames in flight may still read the tables this call replaces: wait for them (the old tables stay allocated until destroy)
+    // frames in flight may still read the tables this call replaces: wait for them, then the previous map's allocations can go
     NRC_HIP(hipDeviceSynchronize());
+    for (void* p : r->envAllocations) (void)hipFree(p);
+    r->envAllocations.clear();
     void* allocations[GFXH_ENV_MAX_ALLOCATIONS];
     uint32_t numAllocations = 0;
     const int err = gfxh_env_upload(texels, w, h, &r->sp, allocations, &numAllocations);
-    for (uint32_t i = 0; i < numAllocations; ++i) r->allocations.push_back(allocations[i]);
+    for (uint32_t i = 0; i < numAllocations; ++i) r->envAllocations.push_back(allocations[i]);
     if (err) { g_nrcError = std::string("gfxh_env_upload: ") + gfxh_restir_last_error(); return 1; }
     r->envPowerCoeff = powerCoeff; r->envRotation = rotation;
     r->viewMoved = true;

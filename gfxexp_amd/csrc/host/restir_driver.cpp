@@ -30,6 +30,7 @@ struct gfxh_restir {
     gfx_restir_static_params sp;
     gfx_restir_frame_params fp;
     std::vector<void*> allocations;
+    std::vector<void*> envAllocations;          // the environment map's tables (gfxh_restir_set_env): replaced as a set
     uint64_t accel = 0;
     uint32_t frameIndex = 0;
     uint32_t lastReservoirIndex = 1;            // restir_di_main.cpp:1686
@@ -250,6 +251,7 @@ void gfxh_restir_destroy(gfxh_restir* r) {
     if (r->evSeamRows) (void)hipEventDestroy(r->evSeamRows);
     if (r->evSeamStrips) (void)hipEventDestroy(r->evSeamStrips);
     for (void* p : r->allocations) (void)hipFree(p);
+    for (void* p : r->envAllocations) (void)hipFree(p);
     delete r;
 }
 
@@ -421,16 +423,15 @@ int gfxh_env_upload(float* texels, uint32_t w, uint32_t h, gfx_restir_static_par
     };
     int err = 0;
     err |= up(&sp.envLightTexture, texels, 16 * n);
-    err |= up(&sp.envRowPDF, rowPDF.data(), 4 * rowPDF.size());
-    err |= up(&sp.envRowCDF, rowCDF.data(), 4 * rowCDF.size());
     err |= up(&sp.envRowIntegrals, rowInt.data(), 4 * rowInt.size());
     err |= up(&sp.envTopPDF, topPDF.data(), 4 * topPDF.size());
     err |= up(&sp.envTopCDF, topCDF.data(), 4 * topCDF.size());
+    sp.envRowPDF = nullptr; sp.envRowCDF = nullptr;
     sp.envRowGuide = nullptr; sp.envTopGuide = nullptr; sp.envRowTable = nullptr; sp.envRowSketch = nullptr;
+    bool haveTable = false;
     {
         std::vector<uint16_t> rowGuide(n), topGuide(h);
         if (gfxh_env_build_guides(rowCDF.data(), topCDF.data(), w, h, rowGuide.data(), topGuide.data())) {
-            err |= up(&sp.envRowGuide, rowGuide.data(), 2 * rowGuide.size());
             err |= up(&sp.envTopGuide, topGuide.data(), 2 * topGuide.size());
             // the rows interleaved (cdf, pdf, guide, texel per record): what a light sample on the map reads, in two or three sectors
             // (GFX_ENV_ROW_TABLE=0: the separate arrays, for A/B runs)
@@ -439,6 +440,7 @@ int gfxh_env_upload(float* texels, uint32_t w, uint32_t h, gfx_restir_static_par
                 std::vector<uint32_t> table(8 * static_cast<size_t>(h) * GFX_ENV_ROW_STRIDE(w));
                 gfxh_env_build_row_table(texels, rowPDF.data(), rowCDF.data(), rowGuide.data(), w, h, table.data());
                 err |= up(&sp.envRowTable, table.data(), 4 * table.size());
+                haveTable = !err;
                 // ... and the rows' inverse-CDF sketches: a sample of a verified cell reads one line of the table (GFX_ENV_ROW_SKETCH=0: the guide)
                 const char* sk = std::getenv("GFX_ENV_ROW_SKETCH");
                 if (!(sk && sk[0] == '0')) {
@@ -447,7 +449,14 @@ int gfxh_env_upload(float* texels, uint32_t w, uint32_t h, gfx_restir_static_par
                     err |= up(&sp.envRowSketch, sketch.data(), 4 * sketch.size());
                 }
             }
+            if (!haveTable) err |= up(&sp.envRowGuide, rowGuide.data(), 2 * rowGuide.size());
         }
+    }
+    // the separate row arrays are what the samplers read WITHOUT the interleaved table; with it they would be 10 bytes per texel of
+    // device memory nothing reads (20 MB at 2048 x 1024, 320 MB at 8192 x 4096)
+    if (!haveTable) {
+        err |= up(&sp.envRowPDF, rowPDF.data(), 4 * rowPDF.size());
+        err |= up(&sp.envRowCDF, rowCDF.data(), 4 * rowCDF.size());
     }
     if (err) return 1;
     sp.envWidth = static_cast<int32_t>(w); sp.envHeight = static_cast<int32_t>(h); sp.envTopIntegral = topIntegral;
@@ -455,10 +464,14 @@ int gfxh_env_upload(float* texels, uint32_t w, uint32_t h, gfx_restir_static_par
 }
 
 int gfxh_restir_set_env(gfxh_restir* r, float* texels, uint32_t w, uint32_t h, float powerCoeff, float rotation) {
+    // frames in flight may still read the tables this call replaces: wait for them, then the previous map's allocations can go
+    DRV_HIP(hipDeviceSynchronize());
+    for (void* p : r->envAllocations) (void)hipFree(p);
+    r->envAllocations.clear();
     void* allocations[GFXH_ENV_MAX_ALLOCATIONS];
     uint32_t numAllocations = 0;
     const int err = gfxh_env_upload(texels, w, h, &r->sp, allocations, &numAllocations);
-    for (uint32_t i = 0; i < numAllocations; ++i) r->allocations.push_back(allocations[i]);   // freed with the renderer
+    for (uint32_t i = 0; i < numAllocations; ++i) r->envAllocations.push_back(allocations[i]);   // freed with the next map or the renderer
     if (err) return 1;
     r->envPowerCoeff = powerCoeff; r->envRotation = rotation;
     r->resetRequested = true;

@@ -6,6 +6,7 @@
 //   rectangle light           createRectangleLight, common_host.cpp:2431-2476
 //   instances                 createInstance, common_host.cpp:2582-2656
 // plus a procedural "street" scene standing in for Bistro Exterior (not present offline).
+#include <new>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -444,7 +445,22 @@ bool decode_exr(const std::vector<uint8_t>& d, const std::string& path, Image& i
     if (src[0] < 0 && src[1] < 0 && src[2] < 0)
         for (size_t c = 0; c < channels.size(); ++c) if (channels[c].name == "Y") src[0] = src[1] = src[2] = static_cast<int>(c);
     if (src[0] < 0 && src[1] < 0 && src[2] < 0) return fail("no R, G, B or Y channel");
-    img.w = w; img.h = h; img.isFloat = true; img.rgba32f.assign(4ull * w * h, 0.0f);
+    // The offset table and the chunk headers are checked BEFORE the 16 w h bytes of the image are asked for: a compressed file has no
+    // size bound of its own, so a crafted header must not be able to make a tiny file allocate gigabytes (and an allocation that still
+    // fails is an error return, not an exception through the extern "C" loader).
+    for (uint32_t k = 0; k < numChunks; ++k) {
+        uint64_t off; std::memcpy(&off, d.data() + at + 8ull * k, 8);
+        if (off > d.size() || d.size() - off < 8) return fail("chunk offset outside the file");
+        const int32_t y0 = rd_i32(off), size = rd_i32(off + 4);
+        const int64_t row0 = static_cast<int64_t>(y0) - win[1];
+        if (size < 0 || static_cast<uint64_t>(size) > d.size() - off - 8 || row0 < 0 || row0 >= h) return fail("malformed chunk");
+        if (row0 % linesPerChunk != 0) return fail("chunk that does not start on a multiple of its line count (it would overlap its neighbours)");
+    }
+    // every scan line costs the file at least a byte or two (ZIP / RLE shrink a constant line by ~1000 : 1 at best)
+    if (static_cast<uint64_t>(lineBytes) * h / 4096u > d.size()) return fail("image far larger than its file can hold");
+    img.w = w; img.h = h; img.isFloat = true;
+    try { img.rgba32f.assign(4ull * w * h, 0.0f); }
+    catch (const std::bad_alloc&) { return fail("out of memory for the image"); }
     for (size_t i = 0; i < static_cast<size_t>(w) * h; ++i) img.rgba32f[4 * i + 3] = 1.0f;
     std::vector<uint8_t> raw, tmp;
     for (uint32_t k = 0; k < numChunks; ++k) {

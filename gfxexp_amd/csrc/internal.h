@@ -98,7 +98,10 @@ struct Tunables {
     int blockOrder = 1;              // k_initial_fused: blocks start by decreasing cost of one frame ago (restir.hip k_order_blocks); 0 = index order
     int fusePasses = 0;              // ReSTIR ray passes as one kernel each (restir.hip k_*_fused): 0 = small launches only, 1 never, 2 always
     int nrcStagedInfer = 0;          // k_nrc_infer_staged (hash-grid levels through LDS): 0 = large batches only, 1 never, 2 always (nrc.hip)
-    int ptRegen = 3;                 // baseline path tracer, one-kernel form: blocks of 256 per CU of the regenerating launch (pathtrace.hip k_pt_regen); 0 = k_pt_fused
+    int ptDiag = 0;                  // one-kernel path tracers count wave iterations and the lanes that held a ray in them (gfx_pt_diag_read)
+    int ptRegen = 0;                 // baseline path tracer, one-kernel form: blocks of 256 per CU of the regenerating launch (pathtrace.hip k_pt_regen); 0 = k_pt_fused
+                                     // (the default: regeneration fills the lanes -- 0.30 -> 0.6 of them hold a ray -- and still takes 17 % longer on the
+                                     // 512 x 512 bunny frame: profiles/r06_experiments.txt 3)
     int ptRegenMin = 16;             // ... and the idle lanes a wave waits for before it refills (1 = at once)
     int ptOverlap = 1;               // path tracers: the NEE (any-hit) trace + its apply kernel of a bounce run on a second stream underneath
                                      // the extension (closest-hit) trace of the same bounce (pathtrace.hip)
@@ -195,6 +198,7 @@ struct Context {
     DevBuf dTraceCounters;     // u64[8]: any-hit launches {nodes, triangles, rays, spills}, closest-hit launches {same}
     bool countersSplit = true; // false while gfx_trace counts into a caller-supplied u64[4]
     DevBuf dTraceDiag;         // u64[8] scheduling diagnostics of counting launches
+    DevBuf ptDiag;             // u64[8] of the one-kernel path tracers ("pt_diag")
     ~Context();
 };
 
@@ -263,6 +267,7 @@ uint32_t nrc_num_params(const NrcNet* net);
 void nrc_set_params(Context& ctx, hipStream_t stream, NrcNet* net, const float* hostParams, uint32_t count);
 void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count);
 void nrc_inference_image(Context& ctx, NrcNet* net, int which, void** dPtr, uint64_t* bytes, hipStream_t stream = nullptr, bool onStream = false);
+void nrc_params_checksum(Context& ctx, hipStream_t stream, NrcNet* net, uint32_t* dOut);
 void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, uint32_t numData, float* dPredictions, const uint32_t* dNumData = nullptr);
 void nrc_train(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInputs, const float* dTargets, uint32_t numData, float* lossOnCPU);
 // ---- pathtrace.hip

@@ -17,6 +17,7 @@
 // which is exactly accumulator register 8 (s & 1) + i of M tile s >> 1.  Activations therefore stay
 // in registers from the encoding to the output with no LDS round trip and no cross-lane traffic;
 // LDS holds the packed bf16 weight fragments (one ds_read_b128 per fragment per lane).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1127,6 +1128,26 @@ void nrc_inference_image(Context& ctx, NrcNet* net, int which, void** dPtr, uint
     if (which == 0) { *dPtr = net->packInferFwd.p; *bytes = 2ull * fwdElems; }
     else if (which == 1) { *dPtr = net->d.posEnc == 1 ? net->gridInfer.p : nullptr; *bytes = net->d.posEnc == 1 ? 2ull * net->gridParams : 0; }
     else throw HipError("gfx_nrc_inference_image: which must be 0 (MLP fragments) or 1 (hash grid)");
+}
+
+// Sum of the 32-bit words of both inference images, added to *dOut (integer adds: any order gives the same sum).
+__global__ __launch_bounds__(256) void k_nrc_words_sum(const uint32_t* __restrict__ words, size_t n, uint32_t* __restrict__ out) {
+    uint32_t acc = 0;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * 256) acc += words[i] * (static_cast<uint32_t>(i) | 1u);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+void nrc_params_checksum(Context& ctx, hipStream_t stream, NrcNet* net, uint32_t* dOut) {
+    for (int which = 0; which < 2; ++which) {
+        void* p = nullptr; uint64_t bytes = 0;
+        nrc_inference_image(ctx, net, which, &p, &bytes, stream, true);
+        if (!p || bytes < 4) continue;
+        const size_t n = bytes / 4;
+        const uint32_t grid = static_cast<uint32_t>(std::min<size_t>((n + 255) / 256, static_cast<size_t>(ctx.numCUs) * 4));
+        hipLaunchKernelGGL(k_nrc_words_sum, dim3(grid), dim3(256), 0, stream, static_cast<const uint32_t*>(p), n, dOut);
+        GFX_HIP(hipGetLastError());
+    }
 }
 
 void nrc_get_params(NrcNet* net, int which, float* hostOut, uint32_t count) {

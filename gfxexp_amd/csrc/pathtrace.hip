@@ -674,7 +674,8 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_finish(PtArgs a) {
 // slowest wave.  A lane whose path has ended idles until its wave's longest path has (no compaction: that is the price, and why large
 // launches keep the wavefront form).
 template <bool REGIR>
-__global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel, uint2* spill, int spillCap, uint32_t maxPathLength, uint32_t* __restrict__ blockCost) {
+__global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel, uint2* spill, int spillCap, uint32_t maxPathLength, uint32_t* __restrict__ blockCost,
+                                                       unsigned long long* __restrict__ diag) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kPtBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kPtBlock / 64) * 256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -683,9 +684,11 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel,
     uint2* stackSpill = spill + (static_cast<size_t>(blockIdx.x) * kPtBlock + tid) * spillCap;
     const PixelId px = pixel_of_thread(a.px);                   // (a.px.order: the blocks whose paths took most steps one frame ago start first)
     uint32_t steps = 0, totalSteps = 0;
+    uint32_t diagIterations = 0, diagLanes = 0;                 // "pt_diag": bounce iterations of the wave, lanes that held a ray in them
     PtPath path;
     bool rngMoved = pt_first_vertex<REGIR>(a, px, path);       // a.pathLength = 1 (set by the host)
     for (uint32_t pathLength = 2;; ++pathLength) {
+        if (diag) { ++diagIterations; diagLanes += static_cast<uint32_t>(__popcll(__ballot(path.o.wantNee || path.o.wantExt))); }
         const RayHit shadow = trace_wave_local<true>(accel, path.o.wantNee, path.o.neeFromOrg ? path.o.neeOrg : path.pos, path.o.neeDir, 0.0f, path.o.neeTmax,
                                                      stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
         totalSteps += steps;
@@ -706,6 +709,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel,
         if (!REGIR && lastVertex) break;
     }
     if (blockCost && lane == 0) atomicMax(blockCost + launch_block(a.px), totalSteps >> 1);    // (<= 255 after the sort's clamp: 510 steps)
+    if (diag && lane == 0) { atomicAdd(diag, diagIterations); atomicAdd(diag + 1, diagLanes); atomicAdd(diag + 2, totalSteps); atomicAdd(diag + 3, 1ull); }
     if (!px.valid) return;
     const size_t p = px.p;
     if (rngMoved) static_cast<uint64_t*>(a.s.rngBuffer)[p] = path.rng.state;
@@ -725,7 +729,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_fused(PtArgs a, DevAccel accel,
 // sequence of operations on the same RNG stream whichever lane runs it and whenever: the frame is bit-identical to k_pt_fused's.
 // Baseline path tracer only (the ReGIR tracer merges its cell-access atomics across lanes that are at the same vertex).
 __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel, uint2* spill, int spillCap, uint32_t maxPathLength,
-                                                       uint32_t* __restrict__ ticket, uint32_t numSlots, int minRefill) {
+                                                       uint32_t* __restrict__ ticket, uint32_t numSlots, int minRefill, unsigned long long* __restrict__ diag) {
     __shared__ uint2 ldsStack[kLdsStackDepth * kPtBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[(kPtBlock / 64) * 256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -738,6 +742,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel,
     path.alpha = f3(0.0f); path.contribution = f3(0.0f); path.dirPDensity = 0.0f; path.rng.state = 0; path.pos = f3(0.0f);
     bool active = false, rngMoved = false, exhausted = false;
     uint32_t pathLength = 2;
+    uint32_t diagIterations = 0, diagLanes = 0, diagSteps = 0, diagRefills = 0, steps = 0;
     auto finish = [&]() {                                       // the pixel's RNG state and its running mean (k_pt_finish)
         if (px.valid) {
             const size_t p = px.p;
@@ -760,6 +765,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel,
             const int idle = __popcll(need);
             if (idle == 0 || (idle < minRefill && idle < 64 && round == 0)) break;
             const uint32_t count = static_cast<uint32_t>(idle);
+            ++diagRefills;
             uint32_t base = 0;
             if (lane == __builtin_ctzll(need)) base = atomicAdd(ticket, count);
             base = __shfl(base, __builtin_ctzll(need));
@@ -776,9 +782,11 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel,
             exhausted = base + count >= numSlots;
         }
         if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
+        if (diag) { ++diagIterations; diagLanes += static_cast<uint32_t>(__popcll(__ballot(active))); }
         const bool nee = active && path.o.wantNee;
         const RayHit shadow = trace_wave_local<true>(accel, nee, path.o.neeFromOrg ? path.o.neeOrg : path.pos, path.o.neeDir, 0.0f, path.o.neeTmax,
-                                                     stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane);
+                                                     stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
+        diagSteps += steps;
         if (nee) {                                              // k_pt_apply_nee
             f3 add = path.o.pending;
             if (shadow.tri != GFX_INVALID_SLOT) add = add * 0.0f;
@@ -788,7 +796,8 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel,
         const bool extend = active && path.o.wantExt;
         if (__ballot(extend) != 0ull) {
             const f3 rayOrg = path.pos, rayDir = path.o.extDir;
-            const RayHit hit = trace_wave_local<false>(accel, extend, rayOrg, rayDir, 0.0f, 3.402823466e+38f, stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane);
+            const RayHit hit = trace_wave_local<false>(accel, extend, rayOrg, rayDir, 0.0f, 3.402823466e+38f, stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
+            diagSteps += steps;
             if (extend) {
                 gfx_hit h; h.dist = hit.t; h.bcB = hit.bcB; h.bcC = hit.bcC; h.triIndex = hit.tri;
                 const bool lastVertex = pathLength >= maxPathLength;
@@ -799,6 +808,7 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel,
         }
         if (done) finish();
     }
+    if (diag && lane == 0) { atomicAdd(diag, diagIterations); atomicAdd(diag + 1, diagLanes); atomicAdd(diag + 2, diagSteps); atomicAdd(diag + 3, 1ull); atomicAdd(diag + 4, diagRefills); }
 }
 
 // ---------------------------------------------------------------- neural radiance caching (render side)
@@ -1546,6 +1556,11 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
         const bool small = launchWaves <= waveSlots + waveSlots / 2;
         if (!nrc && !ctx.countersEnabled && spillBytes <= (size_t(1) << 30) && (ctx.tune.fusePasses == 2 || (ctx.tune.fusePasses == 0 && small))) {
             ctx.spill.reserve(spillBytes);
+            unsigned long long* ptDiag = nullptr;             // "pt_diag": wave iterations / lanes with a ray / traversal steps / waves / refills (gfx_pt_diag_read)
+            if (ctx.tune.ptDiag) {
+                if (!ctx.ptDiag.p) { ctx.ptDiag.reserve(64); GFX_HIP(hipMemsetAsync(ctx.ptDiag.p, 0, 64, stream)); }
+                ptDiag = ctx.ptDiag.as<unsigned long long>();
+            }
             // Path regeneration (k_pt_regen): when the launch is more blocks than the GPU holds at once, launch what it holds and let the
             // lanes draw pixels until none are left ("pt_regen": resident blocks per CU, 0 = off)
             const uint32_t regenBlocks = static_cast<uint32_t>(ctx.tune.ptRegen) * static_cast<uint32_t>(ctx.numCUs);
@@ -1553,7 +1568,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
                 a.px.order = nullptr;
                 ScopedKernelTimer timer(ctx, stream, "pt_regen");
                 hipLaunchKernelGGL(k_pt_regen, dim3(regenBlocks), dim3(kPtBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap, maxPathLength,
-                                   counters + 4, a.px.launchBlocks * static_cast<uint32_t>(kPtBlock), ctx.tune.ptRegenMin);
+                                   counters + 4, a.px.launchBlocks * static_cast<uint32_t>(kPtBlock), ctx.tune.ptRegenMin, ptDiag);
                 GFX_HIP(hipGetLastError());
                 return;
             }
@@ -1565,7 +1580,7 @@ void pathtrace_launch(Context& ctx, hipStream_t stream, int pass, uint32_t width
             a.px.order = order;
             {
                 ScopedKernelTimer timer(ctx, stream, regir ? "pt_regir_fused" : "pt_fused");
-                hipLaunchKernelGGL(regir ? k_pt_fused<true> : k_pt_fused<false>, dim3(a.px.launchBlocks), dim3(kPtBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap, maxPathLength, cost);
+                hipLaunchKernelGGL(regir ? k_pt_fused<true> : k_pt_fused<false>, dim3(a.px.launchBlocks), dim3(kPtBlock), 0, stream, a, accel, ctx.spill.as<uint2>(), spillCap, maxPathLength, cost, ptDiag);
                 GFX_HIP(hipGetLastError());
             }
             block_order_end(ctx, stream, 4, a.px.launchBlocks, cost);

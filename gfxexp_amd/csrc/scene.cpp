@@ -16,7 +16,7 @@ Context::~Context() {
                       &rayOrg, &rayDir, &rayOut, &rayHits, &spill, &gbRayOrg, &gbRayDir, &gbRayHits, &gbSpill, &gbCounters, &auxSpill, &auxCounters, &blockOrders[0].cost, &blockOrders[0].order, &blockOrders[1].cost, &blockOrders[1].order, &blockOrders[2].cost, &blockOrders[2].order, &blockOrders[3].cost, &blockOrders[3].order, &blockOrders[4].cost, &blockOrders[4].order, &pixelRaySlot, &shadeScratch, &spatialScratch, &smallCounters,
                       &bTris, &bBoxes, &bKeys, &bKeysAlt, &bVals, &bValsAlt, &bSortTemp, &bNodesLR, &bParents, &bFlags,
                       &bNodeBoxes, &bRanges, &bQueueA, &bQueueB, &bCounters, &dTraceCounters, &dLightInstIntegral, &dLightInstGuide, &dSpans, &dSpanGuide, &dSpanHeader, &dSpanInstBegin,
-                      &dTraceDiag, &bCosts, &bDec, &bFlatIdx, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
+                      &dTraceDiag, &ptDiag, &bCosts, &bDec, &bFlatIdx, &ptPending, &ptExtOrg, &ptExtDir, &ptExtOwner, &ptState,
                       &rearchSlots, &nrcState, &neeTrainIdx };
     for (NrcNet* net : nrcNets) if (net) nrc_destroy(net);
     for (DevBuf* b : all) b->release();

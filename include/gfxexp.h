@@ -517,6 +517,10 @@ int gfx_nrc_get_params(gfx_ctx* ctx, uint64_t handle, int which, float* hostOut,
  * A process that does not train (a band renderer other than rank 0, gfxh_nrc_set_exchange) receives these bytes from the one that does. */
 int gfx_nrc_inference_image(gfx_ctx* ctx, uint64_t handle, int which, void** dPtr, uint64_t* bytes);
 int gfx_nrc_inference_image_async(gfx_ctx* ctx, void* stream, uint64_t handle, int which, void** dPtr, uint64_t* bytes);
+/* A 32-bit checksum of both inference images (position-weighted word sum, packed on `stream` first if stale) ADDED to the device word
+ * *dOutU32: processes that each train a copy of the network on the same batches (the band-split NRC renderer) compare it to notice a
+ * copy that has drifted (gfxexp_host.h gfxh_nrc_set_exchange). */
+int gfx_nrc_params_checksum(gfx_ctx* ctx, void* stream, uint64_t handle, void* dOutU32);
 
 /* Blocking device-to-host copy of library- or caller-owned device memory (TypedBuffer::read,
  * utils/cuda_util.h; used for pick info at restir_di_main.cpp:2010). */
@@ -566,6 +570,9 @@ int gfx_counters_read(gfx_ctx* ctx, uint64_t counters[8], int reset);
  * the waves, of which [5] in the ray refill (ticket, ray loads, setup), [6] waiting for the item fetch, [7] processing
  * items (the rest: item selection, loop overhead). */
 int gfx_trace_diag_read(gfx_ctx* ctx, uint64_t diag[8], int reset);
+/* The one-kernel path tracers (k_pt_fused, k_pt_regen) with the tunable "pt_diag" set: [0] bounce iterations summed over the waves, [1] lanes
+ * that held a ray in them, [2] traversal steps, [3] waves, [4] refills (k_pt_regen). */
+int gfx_pt_diag_read(gfx_ctx* ctx, uint64_t diag[8], int reset);
 /* Measurement utility ("measure peak with a streaming-copy microbenchmark on the box, don't quote the datasheet"): copies
  * `bytes` (a multiple of 16; both pointers 16-byte aligned, device memory) with 16-byte non-temporal loads and stores per lane, on
  * `stream`; dDst == NULL makes it a read-only pass over dSrc.  bench.py times both with HIP events for roofline.peak_measured /

@@ -26,6 +26,7 @@ std::vector<Op> g_group;
 hipStream_t g_groupStream = nullptr;
 int g_depth = 0;
 float g_stripUs = 0.0f, g_gatherUs = 0.0f;
+bool g_copy = true;   // rccl_mirror_set_copy(0): the calls return at once (what the host spends in the callback, no transport behind it)
 uint64_t g_ops = 0, g_bytes = 0;
 
 __global__ void k_spin(uint64_t ticks) {            // wall_clock64: the constant 100-MHz counter
@@ -38,6 +39,7 @@ void spin(float us, hipStream_t stream) {
 size_t dtype_size(int t) { return t == 3 ? 4 : 1; }   // ncclUint8 = 1, ncclUint32 = 3
 void flush_group() {
     if (g_group.empty()) return;
+    if (!g_copy) { ++g_ops; g_group.clear(); return; }
     spin(g_stripUs, g_groupStream);
     std::vector<bool> used(g_group.size(), false);
     for (size_t i = 0; i < g_group.size(); ++i) {
@@ -79,6 +81,7 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c
     const Comm* c = static_cast<const Comm*>(comm);
     const size_t bytes = count * dtype_size(dtype);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!g_copy) { ++g_ops; return 0; }
     spin(g_gatherUs, s);
     for (int r = 0; r < c->world; ++r) {
         char* dst = static_cast<char*>(recv) + bytes * r;
@@ -90,5 +93,6 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c
 int ncclBroadcast(const void*, void*, size_t, int, int, void*, void* stream) { spin(g_stripUs, static_cast<hipStream_t>(stream)); ++g_ops; return 0; }
 
 void rccl_mirror_set_latency_us(float strips, float gather) { g_stripUs = strips; g_gatherUs = gather; }
+void rccl_mirror_set_copy(int on) { g_copy = on != 0; }
 void rccl_mirror_stats(uint64_t* ops, uint64_t* bytes, int reset) { *ops = g_ops; *bytes = g_bytes; if (reset) { g_ops = 0; g_bytes = 0; } }
 }

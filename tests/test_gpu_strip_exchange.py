@@ -246,6 +246,57 @@ def test_three_band_nrc_renderers(built_lib, monkeypatch, train_on_rank0):
 
 
 @pytest.mark.gpu
+def test_band_nrc_renderers_notice_a_copy_of_the_network_that_drifted(built_lib, monkeypatch):
+    """Every rank of a band-split NRC frame trains its own copy of the network; every 16th frame the ranks compare a checksum of
+    the images they infer with (one 8-byte all-reduce, gfx_nrc_params_checksum).  Sixteen frames of two identical copies pass the
+    comparison; then one rank's parameters are nudged and the next comparison fails the frame on every rank, by name.  And a
+    gradient mode whose sum depends on arrival order (GFX_NRC_GRID_GRAD=f32) makes the band renderers train on rank 0."""
+    import ctypes as C
+    from tests import loopback
+    monkeypatch.setenv("GFX_NRC_TRAIN_ON_RANK0", "0")
+    hs = util.bunny_scene()
+    w, h = 96, 64
+    cam = api.make_camera(w, h, pos=(1.5, 5.0, 14.0), pitch=12.0, yaw=186.0)
+
+    def make(band):
+        ctx = api.Context(0)
+        hs.upload(ctx)
+        cfg = api.NrcRenderer.default_config(w, h, hs.bounds())
+        cfg.camera, cfg.maxPathLength = cam, 3
+        cfg.rowBegin, cfg.rowEnd = band
+        return ctx, api.NrcRenderer(ctx, cfg)
+    bands = tilesplit.band_rows(h, 2)
+    made = [make(b) for b in bands]
+    ex = loopback.LoopbackExchange(2)
+    for rank, (_, r) in enumerate(made):
+        r.set_exchange(ex.callback(rank), rank)
+    loopback.run_bands([r for _, r in made], 16)                       # frame 15 compares: equal copies
+    assert sum(1 for calls in ex.calls for kind, _ in calls if kind == api.EXCHANGE_ALLREDUCE_SUM_U32) == 2
+    ctx1, r1 = made[1]
+    L = api.lib()
+    n = C.c_uint32()
+    ctx1._check(L.gfx_nrc_num_params(ctx1.h, C.c_uint64(r1.network()), C.byref(n)))
+    p = np.zeros(n.value, np.float32)
+    ctx1._check(L.gfx_nrc_get_params(ctx1.h, C.c_uint64(r1.network()), C.c_int(0), p.ctypes.data_as(C.c_void_p), n))
+    p[:64] += np.float32(0.25)
+    ctx1._check(L.gfx_nrc_set_params(ctx1.h, C.c_uint64(r1.network()), p.ctypes.data_as(C.c_void_p), n))
+    loopback.run_bands([r for _, r in made], 15)                       # frames 16 .. 30: no comparison yet
+    with pytest.raises(AssertionError) as e:
+        loopback.run_bands([r for _, r in made], 1)                    # frame 31
+    assert "diverged" in str(e.value)
+    for _, r in made:
+        r.close()
+    # an order-dependent gradient sum: the ranks do not each train
+    monkeypatch.setenv("GFX_NRC_GRID_GRAD", "f32")
+    made = [make(b) for b in bands]
+    ex = loopback.LoopbackExchange(2)
+    for rank, (_, r) in enumerate(made):
+        r.set_exchange(ex.callback(rank), rank)
+    loopback.run_bands([r for _, r in made], 1)
+    assert any(kind == api.EXCHANGE_BROADCAST for kind, _ in ex.calls[1]), "GFX_NRC_GRID_GRAD=f32: rank 0 trains and broadcasts"
+
+
+@pytest.mark.gpu
 def test_strip_exchange_over_torch_nccl_single_rank(built_lib):
     """The code path bench.py --gpus N installs -- tilesplit.StripExchange over torch.distributed's nccl (= RCCL) backend with
     device-memory views -- on a process group of one rank whose band is the whole frame: the strip exchanges have nothing to

@@ -116,14 +116,19 @@ def main():
     ids = api.RcclExchange.unique_ids(api.NUM_LANES)
     if mode == "host":
         res = {}
-        # C++ callback over the recording stub
-        r, cfg = make_renderer(api, scenes, ctx, W, H, band, config4)
-        ex = api.RcclExchange(ids, rank, nb, H)
-        ex.install(r, 0)
-        r.set_async_gather(True)
-        wall, host = run(r, stream, steps)
-        res["gfxh_rccl_exchange (C++), mirror transport at zero latency"] = {"host_ms_per_frame": round(host, 4), "frame_ms": round(wall, 4)}
-        r.close()
+        # C++ callback: with the mirror's device copies behind it (a hipMemcpyAsync per received strip -- more host work than RCCL's one
+        # launch per group), and with the stand-in's calls returning at once (the callback's own code)
+        mirror = C.CDLL(stub)
+        for label, copy in (("gfxh_rccl_exchange (C++), mirror transport at zero latency", 1), ("gfxh_rccl_exchange (C++), null transport", 0)):
+            mirror.rccl_mirror_set_copy(C.c_int(copy))
+            r, cfg = make_renderer(api, scenes, ctx, W, H, band, config4)
+            ex = api.RcclExchange(ids, rank, nb, H)
+            ex.install(r, 0)
+            r.set_async_gather(True)
+            wall, host = run(r, stream, steps)
+            res[label] = {"host_ms_per_frame": round(host, 4), "frame_ms": round(wall, 4)}
+            r.close()
+        mirror.rccl_mirror_set_copy(C.c_int(1))
         # torch callback over a dist whose collectives return at once
         r, cfg = make_renderer(api, scenes, ctx, W, H, band, config4)
         sx = tilesplit.StripExchange(NullDist(), rank, nb, H, tilesplit.device_bytes, device="cuda")
