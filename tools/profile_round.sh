@@ -28,7 +28,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=gpurun_out/$ROUND
 mkdir -p $OUT
 B="python bench.py --steps 6 --warmup 2 --mse-ref-spp 0 --cpu-sample 0 --other-configs 0"
@@ -70,6 +70,14 @@ for step in "$@"; do
                python profiles/make_pmc_json.py --command "$B --config 1 --no-roofline" $OUT/pmc_config1 > $OUT/${ROUND}_pmc_config1.json; head -c 400 $OUT/${ROUND}_pmc_config1.json ;;
     pmcc4)     BFLAGS="--config 4" pmc_passes pmc_config4 GFX_NOOP=1
                python profiles/make_pmc_json.py --command "$B --config 4 --no-roofline" $OUT/pmc_config4 > $OUT/${ROUND}_pmc_config4.json; head -c 400 $OUT/${ROUND}_pmc_config4.json ;;
+    pmcc4ns)   BFLAGS="--config 4" pmc_passes pmc_config4_nosketch GFX_ENV_ROW_SKETCH=0     # round 6: the same without the rows' inverse-CDF sketches (the guide inside the records)
+               python profiles/make_pmc_json.py --command "GFX_ENV_ROW_SKETCH=0 $B --config 4 --no-roofline" $OUT/pmc_config4_nosketch > $OUT/${ROUND}_pmc_config4_nosketch.json; head -c 400 $OUT/${ROUND}_pmc_config4_nosketch.json ;;
+    ptregen)   timeout 600 python tools/pt_regen_diag.py > $OUT/pt_regen.jsonl 2> $OUT/pt_regen.err; cat $OUT/pt_regen.jsonl ;;
+    bandhost)  timeout 300 python tools/band_host_overhead.py host > $OUT/band_host.json 2> $OUT/band_host.err; cat $OUT/band_host.json
+               : > $OUT/band_latency.jsonl
+               for s in round5 gb_lane lanes_noseam lanes; do timeout 300 python tools/band_host_overhead.py latency --schedule $s >> $OUT/band_latency.jsonl 2>> $OUT/band_host.err; done
+               for s in round5 lanes_noseam; do timeout 300 python tools/band_host_overhead.py latency --schedule $s --config4 >> $OUT/band_latency.jsonl 2>> $OUT/band_host.err; done
+               cat $OUT/band_latency.jsonl ;;
     pmca)      BFLAGS="--animate" pmc_passes pmc_animate GFX_NOOP=1
                python profiles/make_pmc_json.py --command "$B --animate --no-roofline" $OUT/pmc_animate > $OUT/${ROUND}_pmc_animate.json; head -c 400 $OUT/${ROUND}_pmc_animate.json ;;
     pmc1)      pmc_passes pmc_map1 GFX_PIXEL_MAP=1 ;;
