@@ -464,7 +464,9 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
     const uint32_t passTiles = (numTiles + numPasses - 1) / numPasses;
     const uint32_t fwdElems = d.numHidden * kMatFwdElems + kOutFwdElems;
     const uint32_t* ldsTable = reinterpret_cast<const uint32_t*>(ldsAll);
+    GFX_CYC_BEGIN          // profiling builds (GFX_LANE_PROFILE, tools/nrc_infer_profile.py): where a wave's cycles go
     for (uint32_t pass = blockIdx.x; pass < numPasses && pass * passTiles < numTiles; pass += gridDim.x) {
+        GFX_CYC(0);        // positions of the pass's queries
         const uint32_t tile0 = pass * passTiles + wave, tileEnd = min((pass + 1) * passTiles, numTiles);   // slot t: tile0 + t * kWaves
         const bool lastSlotUsed = tile0 + (kStagedTiles - 1) * kWaves < tileEnd;                              // wave-uniform
         // the position of query `lane` of each tile (inputs are [14] per query: three strided loads)
@@ -492,7 +494,9 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
             for (int hL = 0; hL < 2; ++hL) {
                 const int L = 4 * (pos >> 1) + (pos & 1) + 2 * hL;
                 NrcLevel lv = d.levels[L];
+                GFX_CYC(1);                                 // waiting for the block's other waves to finish the level before
                 __syncthreads();                            // the table (or the weights / staging area) of before is no longer read
+                GFX_CYC(2);                                 // the level's table: global -> LDS DMA, issued, landed, seen by every wave
                 {
                     const char* src = reinterpret_cast<const char*>(grid + lv.offset);
                     const uint32_t bytes = lv.entries * 4u; // a multiple of 32
@@ -506,6 +510,7 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();
+                GFX_CYC(3);                                 // the level's two features of this wave's queries (index arithmetic, eight ds_read_b32, blend, exchange)
                 lv.offset = 0u;                             // indices into the LDS copy
                 // (the kind of the level decides the index arithmetic once for all queries: a mask for the power-of-two tables of the
                 // reference's configuration, hashed or dense; anything else takes the general form)
@@ -523,6 +528,7 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
             default: break;
             }
         }
+        GFX_CYC(4);                                         // weights into LDS (two barriers)
         __syncthreads();                                    // the last table is no longer read
         for (uint32_t i = threadIdx.x; i < fwdElems / 8; i += kStagedBlock) ldsAll[i] = reinterpret_cast<const uint4*>(fwd)[i];
         __syncthreads();
@@ -531,6 +537,7 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
         for (int t = 0; t < kStagedTiles; ++t) {           // not unrolled: the tile in turn is hb[0], the others move up behind it
             const uint32_t tile = tile0 + t * kWaves;
             if (tile < tileEnd) {                           // wave-uniform
+            GFX_CYC(5);                                     // the tile's inputs through LDS, one-blob / identity features, operands
             {
                 const size_t base = static_cast<size_t>(tile) * 64 * kNrcIn;
                 const size_t limit = static_cast<size_t>(numData) * kNrcIn;
@@ -571,6 +578,7 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
                 b[nt][0] = hb[0][nt][0]; b[nt][1] = hb[0][nt][1];
                 b[nt][2] = pack8(enc); b[nt][3] = pack8(enc + 8);
             }
+            GFX_CYC(6);                                     // the layers (MFMA, ReLU, pack) and the output
             for (int layer = 0; layer < d.numHidden; ++layer) {
                 const uint4* frags = ldsW + layer * (kMatFwdElems / 8);
 #pragma unroll
@@ -603,6 +611,7 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
                 for (int j = 0; j < 4; ++j) hb[k][j >> 1][j & 1] = hb[k + 1][j >> 1][j & 1];
         }
     }
+    GFX_CYC_END;
 }
 
 // ---------------------------------------------------------------- training step
