@@ -590,9 +590,12 @@ def env_build_importance(texels, w, h):
         stride = (w + 1 + 3) & ~3
         out["rowTable"] = np.zeros(8 * h * stride, np.uint32)
         lib().gfxh_env_build_row_table(_p(texels), _p(out["rowPDF"]), _p(out["rowCDF"]), _p(out["rowGuide"]), C.c_uint32(w), C.c_uint32(h), _p(out["rowTable"]))
-        out["rowSketch"] = np.zeros(34 * h, np.uint32)
         lib().gfxh_env_build_row_sketch.restype = C.c_uint32
-        out["sketchCells"] = int(lib().gfxh_env_build_row_sketch(_p(out["rowCDF"]), C.c_uint32(w), C.c_uint32(h), _p(out["rowSketch"])))
+        nrec = C.c_uint32()
+        lib().gfxh_env_build_row_sketch(_p(out["rowCDF"]), C.c_uint32(w), C.c_uint32(h), None, C.c_uint32(0), C.byref(nrec))
+        out["rowSketch"] = np.zeros(36 * nrec.value, np.uint32)       # h row records + the child records of the cells that failed
+        out["sketchCells"] = int(lib().gfxh_env_build_row_sketch(_p(out["rowCDF"]), C.c_uint32(w), C.c_uint32(h), _p(out["rowSketch"]), nrec, C.byref(nrec)))
+        out["sketchRecords"] = nrec.value
     return out
 
 

@@ -444,8 +444,10 @@ int gfxh_env_upload(float* texels, uint32_t w, uint32_t h, gfx_restir_static_par
                 // ... and the rows' inverse-CDF sketches: a sample of a verified cell reads one line of the table (GFX_ENV_ROW_SKETCH=0: the guide)
                 const char* sk = std::getenv("GFX_ENV_ROW_SKETCH");
                 if (!(sk && sk[0] == '0')) {
-                    std::vector<uint32_t> sketch(static_cast<size_t>(h) * GFX_ENV_SKETCH_WORDS);
-                    (void)gfxh_env_build_row_sketch(rowCDF.data(), w, h, sketch.data());
+                    uint32_t numRecords = 0;
+                    (void)gfxh_env_build_row_sketch(rowCDF.data(), w, h, nullptr, 0, &numRecords);
+                    std::vector<uint32_t> sketch(static_cast<size_t>(numRecords) * GFX_ENV_SKETCH_WORDS);
+                    (void)gfxh_env_build_row_sketch(rowCDF.data(), w, h, sketch.data(), numRecords, &numRecords);
                     err |= up(&sp.envRowSketch, sketch.data(), 4 * sketch.size());
                 }
             }

@@ -1354,63 +1354,105 @@ static uint32_t env_column_of(const float* cdf, uint32_t n, float u) {
     while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (cdf[mid] <= u) lo = mid; else hi = mid - 1; }
     return lo;
 }
-// What the device predicts for u from a row's knots (shading.hip.h EnvMap::sketch_column: the same operations in the same order; u * 32
-// and the subtraction of the cell index are exact, the rest is one subtraction, one product, one sum).
-static int env_sketch_predict(const float* knots, float u) {
-    const float uk = u * static_cast<float>(GFX_ENV_SKETCH_CELLS);
-    uint32_t k = static_cast<uint32_t>(uk);
-    if (k > GFX_ENV_SKETCH_CELLS - 1u) k = GFX_ENV_SKETCH_CELLS - 1u;
-    const float t = uk - static_cast<float>(k);
+// The device's interpolation between two knots (shading.hip.h EnvMap::sample1d_row_sketch: the same operations in the same order; the
+// position t inside the cell is exact, the rest is one subtraction, one product, one sum).
+static int env_sketch_interpolate(const float* knots, uint32_t k, float t) {
     const float d = knots[k + 1] - knots[k];
     const float p = knots[k] + t * d;
     return static_cast<int>(p);
 }
-
-uint32_t gfxh_env_build_row_sketch(const float* rowCDF, uint32_t w, uint32_t h, void* outSketch) {
-    uint32_t* out = static_cast<uint32_t*>(outSketch);
+// One sketch record over [uLo, uLo + 32 step): 33 knots of the row's inverse CDF and the mask of the cells whose interpolation is within
+// one column of the bisection's answer for EVERY u of the cell.  `local(u, k, t)`: the cell and the position inside it the device derives
+// for u at this level.  The interpolation is monotone in u inside a cell (a product and a sum of non-negative terms, correctly rounded)
+// and the column is constant between the lowest and the highest u that end on it: testing both ends of every column covers the cell.
+extern "C++" {
+template <typename Local>
+static uint32_t env_sketch_record(const float* cdf, uint32_t w, float uLo, float step, Local local, float knots[GFX_ENV_SKETCH_CELLS + 1]) {
     const uint32_t K = GFX_ENV_SKETCH_CELLS;
-    uint32_t good = 0;
+    for (uint32_t j = 0; j <= K; ++j) {
+        const float u = uLo + static_cast<float>(j) * step;          // exact: powers of two
+        float pos = static_cast<float>(w);
+        if (u < 1.0f) {
+            const uint32_t c = env_column_of(cdf, w, u);
+            const float width = cdf[c + 1] - cdf[c];
+            const float t = width > 0.0f ? (u - cdf[c]) / width : 0.0f;
+            pos = static_cast<float>(c) + std::min(std::max(t, 0.0f), 1.0f);
+        }
+        knots[j] = pos;
+    }
+    for (uint32_t j = 0; j < K; ++j) if (!(knots[j] <= knots[j + 1])) return 0u;   // the prediction must not decrease inside a cell
+    uint32_t mask = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+        const float cLo = uLo + static_cast<float>(k) * step, cHi = std::nextafter(uLo + static_cast<float>(k + 1) * step, 0.0f);
+        const uint32_t cFirst = env_column_of(cdf, w, cLo), cLast = env_column_of(cdf, w, cHi);
+        bool ok = true;
+        for (uint32_t c = cFirst; c <= cLast && ok; ++c) {
+            const float a = std::max(cLo, cdf[c]);
+            const float b = cdf[c + 1] <= cHi ? std::nextafter(cdf[c + 1], 0.0f) : cHi;
+            if (!(a <= b)) continue;                                  // an empty column: never the bisection's answer
+            for (float u : { a, b }) {
+                if (env_column_of(cdf, w, u) != c) continue;          // (ties: this u belongs to a later column of equal CDF value, tested there)
+                uint32_t kk; float t;
+                local(u, kk, t);
+                if (kk != k) { ok = false; break; }                   // (cannot happen: the cell bounds are exact)
+                const int pred = env_sketch_interpolate(knots, kk, t);
+                if (pred < static_cast<int>(c) - 1 || pred > static_cast<int>(c) + 1) ok = false;
+            }
+        }
+        if (ok) mask |= 1u << k;
+    }
+    return mask;
+}
+}   // extern "C++"
+
+uint32_t gfxh_env_build_row_sketch(const float* rowCDF, uint32_t w, uint32_t h, void* outSketch, uint32_t capacityRecords, uint32_t* numRecords) {
+    const uint32_t K = GFX_ENV_SKETCH_CELLS, W = GFX_ENV_SKETCH_WORDS;
+    std::vector<uint32_t> rows(static_cast<size_t>(h) * W, 0u), children;
+    uint32_t good = 0, numChildren = 0;
+    auto cell_of = [](float x, uint32_t& k, float& t) {
+        const uint32_t K = GFX_ENV_SKETCH_CELLS;             // the device's split of a position in [0, 1) into cell and remainder
+        const float xk = x * static_cast<float>(K);
+        k = static_cast<uint32_t>(xk);
+        if (k > K - 1u) k = K - 1u;
+        t = xk - static_cast<float>(k);
+    };
     for (uint32_t y = 0; y < h; ++y) {
         const float* cdf = rowCDF + static_cast<size_t>(y) * (w + 1);
-        float knots[GFX_ENV_SKETCH_CELLS + 1];
         bool monotone = cdf[0] == 0.0f;
         for (uint32_t i = 0; i < w && monotone; ++i) monotone = cdf[i] <= cdf[i + 1];
-        for (uint32_t j = 0; j <= K; ++j) {
-            const float u = static_cast<float>(j) / static_cast<float>(K);
-            float pos = static_cast<float>(w);
-            if (j < K && monotone) {
-                const uint32_t c = env_column_of(cdf, w, u);
-                const float width = cdf[c + 1] - cdf[c];
-                const float t = width > 0.0f ? (u - cdf[c]) / width : 0.0f;
-                pos = static_cast<float>(c) + std::min(std::max(t, 0.0f), 1.0f);
-            }
-            knots[j] = pos;
-        }
-        for (uint32_t j = 0; j < K; ++j) if (!(knots[j] <= knots[j + 1])) monotone = false;   // the prediction must not decrease inside a cell
+        float knots[GFX_ENV_SKETCH_CELLS + 1];
         uint32_t mask = 0;
-        for (uint32_t k = 0; k < K && monotone; ++k) {
-            // the cell's range of u: [k / K, (k + 1) / K); the columns it reaches; for each the lowest and the highest u of the cell that
-            // ends on it.  The prediction is monotone in u inside a cell (a product and a sum of non-negative terms, correctly rounded), the
-            // column is constant between the two: a test of both ends covers every u in between.
-            const float uLo = static_cast<float>(k) / K, uHi = std::nextafter(static_cast<float>(k + 1) / K, 0.0f);
-            const uint32_t cFirst = env_column_of(cdf, w, uLo), cLast = env_column_of(cdf, w, uHi);
-            bool ok = true;
-            for (uint32_t c = cFirst; c <= cLast && ok; ++c) {
-                if (c != cFirst && !(cdf[c] < cdf[c + 1]) && c != cLast) continue;       // an empty column between two others is never the bisection's answer... unless it is the last of a run
-                float a = std::max(uLo, cdf[c]);
-                float b = c + 1 <= w && cdf[c + 1] <= uHi ? std::nextafter(cdf[c + 1], 0.0f) : uHi;
-                if (!(a <= b)) continue;
-                for (float u : { a, b }) {
-                    if (env_column_of(cdf, w, u) != c) continue;                          // (ties: this u belongs to a later column of equal CDF value, tested there)
-                    const int pred = env_sketch_predict(knots, u);
-                    if (pred < static_cast<int>(c) - 1 || pred > static_cast<int>(c) + 1) ok = false;
-                }
+        if (monotone) mask = env_sketch_record(cdf, w, 0.0f, 1.0f / K, [&](float u, uint32_t& k, float& t) { cell_of(u, k, t); }, knots);
+        else for (uint32_t j = 0; j <= K; ++j) knots[j] = 0.0f;
+        uint32_t* row = rows.data() + static_cast<size_t>(y) * W;
+        std::memcpy(row, knots, 4 * (K + 1));
+        row[K + 1] = mask; row[K + 2] = numChildren;
+        for (uint32_t k = 0; k < K; ++k) {
+            if ((mask >> k) & 1u) { ++good; continue; }
+            // a child record for the failing cell: the same at 1/32 of the step (a row whose CDF is not monotone gets empty children: the guide)
+            float sub[GFX_ENV_SKETCH_CELLS + 1];
+            uint32_t subMask = 0;
+            if (monotone) {
+                const uint32_t k1 = k;
+                subMask = env_sketch_record(cdf, w, static_cast<float>(k1) / K, 1.0f / (K * K), [&](float u, uint32_t& kk, float& t) {
+                    uint32_t ka; float ta;
+                    cell_of(u, ka, ta);                              // level 1: ka == k1 for every u of this cell
+                    cell_of(ta, kk, t);                              // level 2: the remainder is the position inside the cell
+                    if (ka != k1) kk = K;                            // (reported as a mismatch)
+                }, sub);
             }
-            if (ok) { mask |= 1u << k; ++good; }
+            else for (uint32_t j = 0; j <= K; ++j) sub[j] = 0.0f;
+            children.resize(children.size() + W, 0u);
+            uint32_t* rec = children.data() + static_cast<size_t>(numChildren) * W;
+            std::memcpy(rec, sub, 4 * (K + 1));
+            rec[K + 1] = subMask;
+            ++numChildren;
         }
-        uint32_t* row = out + static_cast<size_t>(y) * GFX_ENV_SKETCH_WORDS;
-        for (uint32_t j = 0; j <= K; ++j) std::memcpy(row + j, &knots[j], 4);
-        row[K + 1] = mask;
+    }
+    if (numRecords) *numRecords = h + numChildren;
+    if (outSketch && capacityRecords >= h + numChildren) {
+        std::memcpy(outSketch, rows.data(), 4 * rows.size());
+        if (!children.empty()) std::memcpy(static_cast<uint32_t*>(outSketch) + rows.size(), children.data(), 4 * children.size());
     }
     return good;
 }

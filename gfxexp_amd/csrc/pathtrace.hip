@@ -272,17 +272,25 @@ GFX_DEV void reset_vertex_out(PtVertexOut& o) {
 }
 // The first vertex from the G-buffer.  Returns whether the pixel shows a surface (its RNG state moved).  EVERY lane must call
 // (ReGIR merges its cell-access atomics across the wave).
+// A vertex ready to be shaded: what pt_first_setup / pt_next_setup leave for shade_vertex (the path's own state lives in PtPath).
+struct PtSetup {
+    f3 vOutLocal; Frame frame; Bsdf bsdf; bool shade;
+    GFX_DEV PtSetup() : vOutLocal(0.0f), frame(f3(0, 0, 1), f3(1, 0, 0)), shade(false) {}
+};
+// pt_first_vertex up to the shading of the vertex (shade_vertex): the surface point of the pixel from the G-buffer, emission, BSDF.
 template <bool REGIR>
-GFX_DEV bool pt_first_vertex(const PtArgs& a, const PixelId& px, PtPath& path) {
+GFX_DEV bool pt_first_setup(const PtArgs& a, const PixelId& px, PtPath& path, PtSetup& su) {
     const size_t p = px.p;
     const uint32_t bufIdx = a.f.bufferIndex;
     PtVertexOut& o = path.o;
     reset_vertex_out(o);
     f3& pos = path.pos;
     pos = f3(0.0f);
-    f3 vOutLocal(0.0f);
-    Frame frame(f3(0, 0, 1), f3(1, 0, 0));
-    Bsdf bsdf;
+    f3& vOutLocal = su.vOutLocal;
+    vOutLocal = f3(0.0f);
+    Frame& frame = su.frame;
+    frame = Frame(f3(0, 0, 1), f3(1, 0, 0));
+    Bsdf& bsdf = su.bsdf;
     Pcg32& rng = path.rng; rng.state = 0;
     const EnvMap env = load_env(a.s);
     const bool envEnabled = env.present() && a.f.enableEnvLight;
@@ -337,7 +345,16 @@ GFX_DEV bool pt_first_vertex(const PtArgs& a, const PixelId& px, PtPath& path) {
     else if (px.valid && envEnabled) {
         contribution = a.f.envLightPowerCoeff * env.fetch(decode_bc(g0.w & 0xFFFF), decode_bc(g0.w >> 16));
     }
-    shade_vertex<REGIR>(a, surface, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o);
+    su.shade = surface;
+    return surface;
+}
+template <bool REGIR>
+GFX_DEV bool pt_first_vertex(const PtArgs& a, const PixelId& px, PtPath& path) {
+    PtSetup su;
+    const bool surface = pt_first_setup<REGIR>(a, px, path, su);
+    const EnvMap env = load_env(a.s);
+    const bool envEnabled = env.present() && a.f.enableEnvLight;
+    shade_vertex<REGIR>(a, su.shade, env, envEnabled, path.pos, su.vOutLocal, su.frame, su.bsdf, path.rng, path.alpha, path.contribution, path.dirPDensity, path.o);
     return surface;
 }
 template <bool REGIR>
@@ -385,16 +402,20 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_apply_nee(PtArgs a) {
 // Returns kPtHitSurface (the RNG state moved and the whole state changed) | kPtMissAdded (only the contribution changed).
 // EVERY lane must call (ReGIR merges its cell-access atomics across the wave).
 constexpr uint32_t kPtHitSurface = 1u, kPtMissAdded = 2u;
+// pt_next_vertex up to the shading of the vertex: what the extension ray found (implicit light / environment with MIS), Russian roulette, the
+// surface point and its BSDF when the path goes on (su.shade).
 template <bool REGIR>
-GFX_DEV uint32_t pt_next_vertex(const PtArgs& a, bool active, const gfx_hit& h, f3 rayOrg, f3 rayDir, const uint64_t* rngBuf, PtPath& path,
-                                int maxLengthTerminate = -1, int nextMaxLengthTerminate = -1 /* -1: the launch's (a.*) */) {
+GFX_DEV uint32_t pt_next_setup(const PtArgs& a, bool active, const gfx_hit& h, f3 rayOrg, f3 rayDir, const uint64_t* rngBuf, PtPath& path, PtSetup& su,
+                               int maxLengthTerminate = -1) {
     PtVertexOut& o = path.o;
     reset_vertex_out(o);
     f3& pos = path.pos;
     pos = f3(0.0f);
-    f3 vOutLocal(0.0f);
-    Frame frame(f3(0, 0, 1), f3(1, 0, 0));
-    Bsdf bsdf;
+    f3& vOutLocal = su.vOutLocal;
+    vOutLocal = f3(0.0f);
+    Frame& frame = su.frame;
+    frame = Frame(f3(0, 0, 1), f3(1, 0, 0));
+    Bsdf& bsdf = su.bsdf;
     Pcg32& rng = path.rng;
     const EnvMap env = load_env(a.s);
     const bool envEnabled = env.present() && a.f.enableEnvLight;
@@ -499,8 +520,18 @@ GFX_DEV uint32_t pt_next_vertex(const PtArgs& a, bool active, const gfx_hit& h, 
             }
         }
     }
-    shade_vertex<REGIR>(a, shade, env, envEnabled, pos, vOutLocal, frame, bsdf, rng, alpha, contribution, dirPDensity, o, nullptr, nextMaxLengthTerminate);
+    su.shade = shade;
     return (hitSurface ? kPtHitSurface : 0u) | (missAdded ? kPtMissAdded : 0u);
+}
+template <bool REGIR>
+GFX_DEV uint32_t pt_next_vertex(const PtArgs& a, bool active, const gfx_hit& h, f3 rayOrg, f3 rayDir, const uint64_t* rngBuf, PtPath& path,
+                                int maxLengthTerminate = -1, int nextMaxLengthTerminate = -1 /* -1: the launch's (a.*) */) {
+    PtSetup su;
+    const uint32_t what = pt_next_setup<REGIR>(a, active, h, rayOrg, rayDir, rngBuf, path, su, maxLengthTerminate);
+    const EnvMap env = load_env(a.s);
+    const bool envEnabled = env.present() && a.f.enableEnvLight;
+    shade_vertex<REGIR>(a, su.shade, env, envEnabled, path.pos, su.vOutLocal, su.frame, su.bsdf, path.rng, path.alpha, path.contribution, path.dirPDensity, path.o, nullptr, nextMaxLengthTerminate);
+    return what;
 }
 template <bool REGIR>
 __global__ __launch_bounds__(kPtBlock) void k_pt_bounce(PtArgs a) {
@@ -756,10 +787,42 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel,
         }
         active = false;
     };
+    const EnvMap env = load_env(a.s);
+    const bool envEnabled = env.present() && a.f.enableEnvLight;
     for (;;) {
-        // Refill: when at least `minRefill` lanes are idle (or all of them), the idle lanes draw launch slots -- one wave-aggregated atomic
-        // -- and take their pixel's first vertex from the G-buffer.  A pixel that asks for no ray at all (background, a surface whose
-        // first vertex samples nothing) is finished on the spot and its lane draws again, up to four times per refill.
+        // ---- the rays of the vertices the lanes stand on: NEE (any hit), its visibility applied, then the extension (closest hit)
+        PtSetup su;                                             // the vertex a lane shades at the end of this iteration
+        if (__ballot(active) != 0ull) {
+            if (diag) { ++diagIterations; diagLanes += static_cast<uint32_t>(__popcll(__ballot(active))); }
+            const bool nee = active && path.o.wantNee;
+            const RayHit shadow = trace_wave_local<true>(accel, nee, path.o.neeFromOrg ? path.o.neeOrg : path.pos, path.o.neeDir, 0.0f, path.o.neeTmax,
+                                                         stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
+            diagSteps += steps;
+            if (nee) {                                          // k_pt_apply_nee
+                f3 add = path.o.pending;
+                if (shadow.tri != GFX_INVALID_SLOT) add = add * 0.0f;
+                path.contribution = path.contribution + add;
+            }
+            bool done = active && !path.o.wantExt;
+            const bool extend = active && path.o.wantExt;
+            if (__ballot(extend) != 0ull) {
+                const f3 rayOrg = path.pos, rayDir = path.o.extDir;
+                const RayHit hit = trace_wave_local<false>(accel, extend, rayOrg, rayDir, 0.0f, 3.402823466e+38f, stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
+                diagSteps += steps;
+                if (extend) {                                   // what the ray found: implicit light with MIS, Russian roulette, the next surface point
+                    gfx_hit h; h.dist = hit.t; h.bcB = hit.bcB; h.bcC = hit.bcC; h.triIndex = hit.tri;
+                    const bool lastVertex = pathLength >= maxPathLength;
+                    if (pt_next_setup<false>(a, true, h, rayOrg, rayDir, nullptr, path, su, lastVertex ? 1 : 0) & kPtHitSurface) rngMoved = true;
+                    if (lastVertex || !su.shade) done = true;   // (a path that is not shaded asks for no ray: it has ended)
+                    ++pathLength;
+                }
+            }
+            if (done) finish();
+        }
+        // ---- refill: when at least `minRefill` lanes are idle (or all of them), the idle lanes draw launch slots -- one wave-aggregated
+        // atomic -- and set their pixel's first vertex up from the G-buffer.  A pixel without a surface (background) is finished on the spot
+        // and its lane draws again, up to four times per refill.
+#pragma nounroll
         for (int round = 0; round < 4 && !exhausted; ++round) {
             const unsigned long long need = __ballot(!active);
             const int idle = __popcll(need);
@@ -773,40 +836,18 @@ __global__ __launch_bounds__(kPtBlock) void k_pt_regen(PtArgs a, DevAccel accel,
                 const uint32_t slot = base + static_cast<uint32_t>(__popcll(need & ((1ull << lane) - 1ull)));
                 if (slot < numSlots) {
                     px = pixel_of_block_thread(a.px, slot >> 8, slot & 255u);      // (kPtBlock = 256 slots per launch block)
-                    rngMoved = pt_first_vertex<false>(a, px, path);
+                    rngMoved = pt_first_setup<false>(a, px, path, su);
                     pathLength = 2;
                     active = true;
-                    if (!path.o.wantNee && !path.o.wantExt) finish();
+                    if (!su.shade) finish();                    // nothing to shade: no ray will be asked for
                 }
             }
             exhausted = base + count >= numSlots;
         }
         if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
-        if (diag) { ++diagIterations; diagLanes += static_cast<uint32_t>(__popcll(__ballot(active))); }
-        const bool nee = active && path.o.wantNee;
-        const RayHit shadow = trace_wave_local<true>(accel, nee, path.o.neeFromOrg ? path.o.neeOrg : path.pos, path.o.neeDir, 0.0f, path.o.neeTmax,
-                                                     stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
-        diagSteps += steps;
-        if (nee) {                                              // k_pt_apply_nee
-            f3 add = path.o.pending;
-            if (shadow.tri != GFX_INVALID_SLOT) add = add * 0.0f;
-            path.contribution = path.contribution + add;
-        }
-        bool done = active && !path.o.wantExt;
-        const bool extend = active && path.o.wantExt;
-        if (__ballot(extend) != 0ull) {
-            const f3 rayOrg = path.pos, rayDir = path.o.extDir;
-            const RayHit hit = trace_wave_local<false>(accel, extend, rayOrg, rayDir, 0.0f, 3.402823466e+38f, stackLds, kPtBlock, stackSpill, spillCap, waveBuf, lane, 0xFFFFFFFFu, &steps);
-            diagSteps += steps;
-            if (extend) {
-                gfx_hit h; h.dist = hit.t; h.bcB = hit.bcB; h.bcC = hit.bcC; h.triIndex = hit.tri;
-                const bool lastVertex = pathLength >= maxPathLength;
-                if (pt_next_vertex<false>(a, true, h, rayOrg, rayDir, nullptr, path, lastVertex ? 1 : 0, pathLength + 1 >= maxPathLength ? 1 : 0) & kPtHitSurface) rngMoved = true;
-                if (lastVertex) done = true;
-                ++pathLength;
-            }
-        }
-        if (done) finish();
+        // ---- ONE shading step for the wave: the vertices the extension rays reached and the first vertices of the pixels just drawn
+        // (light sample + MIS + BSDF sample: the code a wave executes once per iteration whichever lanes take part)
+        shade_vertex<false>(a, active && su.shade, env, envEnabled, path.pos, su.vOutLocal, su.frame, su.bsdf, path.rng, path.alpha, path.contribution, path.dirPDensity, path.o);
     }
     if (diag && lane == 0) { atomicAdd(diag, diagIterations); atomicAdd(diag + 1, diagLanes); atomicAdd(diag + 2, diagSteps); atomicAdd(diag + 3, 1ull); atomicAdd(diag + 4, diagRefills); }
 }

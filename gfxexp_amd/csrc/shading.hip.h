@@ -550,15 +550,31 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
     // builder verified that for every u of this cell -- so the answer is in the 128-byte line of four records around the prediction, or in
     // the first / last record of a neighbouring line when the prediction sits on the line's edge: one line of the table per sample
     // instead of the guide's and the column's.  The column chosen is the largest one whose CDF value is <= u, as the bisection's.
-    static GFX_DEV bool sample1d_row_sketch(const EnvRowRec* row, const uint32_t* sketch, uint32_t n, float u, float& p, float& d0) {
-        const float uk = u * static_cast<float>(GFX_ENV_SKETCH_CELLS);
-        uint32_t k = static_cast<uint32_t>(uk);
-        if (k > GFX_ENV_SKETCH_CELLS - 1u) k = GFX_ENV_SKETCH_CELLS - 1u;
-        if (!((sketch[GFX_ENV_SKETCH_CELLS + 1u] >> k) & 1u)) return false;
-        const float k0 = bits2f(sketch[k]), k1 = bits2f(sketch[k + 1u]);
-        const float t = uk - static_cast<float>(k);
-        const float d = k1 - k0;
-        const float pred = k0 + t * d;
+    static GFX_DEV bool sample1d_row_sketch(const EnvRowRec* row, const uint32_t* sketch, uint32_t rowIndex, uint32_t numRows, uint32_t n, float u, float& p, float& d0) {
+        // the row's record, then -- in a cell whose interpolation the builder could not verify -- the cell's child record at 1/32 of the step
+        const uint32_t* rec = sketch + static_cast<size_t>(rowIndex) * GFX_ENV_SKETCH_WORDS;
+        float x = u, pred = 0.0f;
+        bool found = false;
+#pragma unroll
+        for (int level = 0; level < 2 && !found; ++level) {
+            const float xk = x * static_cast<float>(GFX_ENV_SKETCH_CELLS);
+            uint32_t k = static_cast<uint32_t>(xk);
+            if (k > GFX_ENV_SKETCH_CELLS - 1u) k = GFX_ENV_SKETCH_CELLS - 1u;
+            const float t = xk - static_cast<float>(k);                  // exact
+            const uint32_t mask = rec[GFX_ENV_SKETCH_CELLS + 1u];
+            if ((mask >> k) & 1u) {
+                const float k0 = bits2f(rec[k]), k1 = bits2f(rec[k + 1u]);
+                const float d = k1 - k0;
+                pred = k0 + t * d;
+                found = true;
+            }
+            else if (level == 0) {
+                const uint32_t child = rec[GFX_ENV_SKETCH_CELLS + 2u] + static_cast<uint32_t>(__popc(~mask & ((1u << k) - 1u)));
+                rec = sketch + static_cast<size_t>(numRows + child) * GFX_ENV_SKETCH_WORDS;
+                x = t;
+            }
+        }
+        if (!found) return false;
         int fp = static_cast<int>(pred);
         fp = fp < 0 ? 0 : (fp > static_cast<int>(n) - 1 ? static_cast<int>(n) - 1 : fp);
         const int a = fp & ~3;                                       // n is a multiple of four or the last group is padded (GFX_ENV_ROW_STRIDE)
@@ -591,7 +607,7 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
         d1 = sample1d(topPDF, topCDF, h, u1, topP, topGuide);
         uint32_t row = f2u_sat(d1 * h); if (row > static_cast<uint32_t>(h - 1)) row = h - 1;
         if (rowTable) {
-            if (!(rowSketch && sample1d_row_sketch(table_row(row), rowSketch + static_cast<size_t>(row) * GFX_ENV_SKETCH_WORDS, w, u0, p, d0)))
+            if (!(rowSketch && sample1d_row_sketch(table_row(row), rowSketch, row, static_cast<uint32_t>(h), w, u0, p, d0)))
                 d0 = sample1d_row(table_row(row), w, u0, p);
         }
         else d0 = sample1d(rowPDF + static_cast<size_t>(row) * w, rowCDF + static_cast<size_t>(row) * (w + 1), w, u0, p,

@@ -252,17 +252,20 @@ typedef struct gfx_restir_static_params {
      * (a multiple of four: groups of four records are 128-byte lines).  A sample then touches two or three 64-byte sectors instead of six
      * or seven. */
     const void* envRowTable;
-    /* Optional, with envRowTable (gfxh_env_build_row_sketch; NULL = the guide inside the records): per row GFX_ENV_SKETCH_WORDS words --
-     * 33 floats, the row's inverse CDF (in columns) at u = 0, 1/32 .. 1, then a 32-bit mask: bit k set = for every u of [k/32, (k+1)/32)
-     * the linear interpolation of the two knots lands within one column of the column the bisection finds (verified by the builder for
-     * every column of the cell).  A sample of such a cell reads ONE 128-byte line of the row table (the group of four records around the
+    /* Optional, with envRowTable (gfxh_env_build_row_sketch; NULL = the guide inside the records): records of GFX_ENV_SKETCH_WORDS words --
+     * 33 floats = an inverse CDF (in columns) at 33 equidistant u, a 32-bit mask, the index of the record's first child record, one unused
+     * word.  Record `row` (0 .. envH - 1) covers u in [0, 1) of that row: mask bit k set = for every u of cell k = [k/32, (k+1)/32) the linear
+     * interpolation of knots k and k + 1 lands within one column of the column the bisection finds (verified by the builder for every
+     * column of the cell, with the device's arithmetic).  A cell that fails has a CHILD record (envH + first child + its rank among the
+     * record's failing cells) that covers the cell's range of u the same way at 1/32 of the step; a sub-cell that fails again keeps the
+     * guide.  A sample of a verified (sub-)cell reads ONE 128-byte line of the row table (the group of four records around the
      * prediction; a neighbouring line in the few cases the column sits across its edge) instead of the guide's line plus the column's;
-     * the 135 KB of sketches stay in L2.  Cells that fail the test (rows through the sun) keep the guide.  Same column, same sample. */
+     * the records (envH + a few hundred) stay in L2.  Same column, same sample. */
     const void* envRowSketch;
 } gfx_restir_static_params;
 #define GFX_ENV_ROW_STRIDE(envW) ((((uint32_t)(envW)) + 1u + 3u) & ~3u)
 #define GFX_ENV_SKETCH_CELLS 32u
-#define GFX_ENV_SKETCH_WORDS 34u
+#define GFX_ENV_SKETCH_WORDS 36u
 
 /* restir_di/restir_di_shared.h:241-281 PerFramePipelineLaunchParameters. */
 typedef struct gfx_restir_frame_params {

@@ -124,10 +124,12 @@ int gfxh_env_build_guides(const float* rowCDF, const float* topCDF, uint32_t w, 
  * conditional PDFs / CDFs and a usable row guide (gfxh_env_build_guides returned 1).  outRecords: 32 x h x GFX_ENV_ROW_STRIDE(w) bytes.
  * Same samples as with the separate arrays; a third of the memory traffic per sample. */
 void gfxh_env_build_row_table(const float* texels4, const float* rowPDF, const float* rowCDF, const uint16_t* rowGuide, uint32_t w, uint32_t h, void* outRecords);
-/* gfx_restir_static_params::envRowSketch (described there): outSketch = h x GFX_ENV_SKETCH_WORDS 32-bit words.  Returns the number of
- * cells (of 32 h) whose prediction the builder verified -- for every column that a cell's range of u reaches, at both ends of the
- * range, with the arithmetic the device uses -- to lie within one column of the bisection's result; the others keep their mask bit clear. */
-uint32_t gfxh_env_build_row_sketch(const float* rowCDF, uint32_t w, uint32_t h, void* outSketch);
+/* gfx_restir_static_params::envRowSketch (described there).  Writes *numRecords = h + the child records the map needs; the records
+ * themselves (GFX_ENV_SKETCH_WORDS 32-bit words each) go to outSketch when it is non-NULL and capacityRecords >= *numRecords (call once
+ * with NULL to size the buffer).  Returns the number of first-level cells (of 32 h) whose prediction the builder verified -- for every
+ * column that a cell's range of u reaches, at both ends of the range, with the arithmetic the device uses -- to lie within one column
+ * of the bisection's result. */
+uint32_t gfxh_env_build_row_sketch(const float* rowCDF, uint32_t w, uint32_t h, void* outSketch, uint32_t capacityRecords, uint32_t* numRecords);
 /* The device side of "-env-texture" (restir_di_main.cpp:1188-1197, common_host.cpp:204-357) in one call, for the renderers below and for
  * callers that fill gfx_restir_static_params themselves: the importance tables, guides and row table of a lat-long float4 map (the three
  * functions above) are built, map and tables uploaded, and the env* fields of `sp` set.  Synchronous.  The device allocations it made

@@ -83,17 +83,29 @@ def test_guide_tables_bracket_every_search(built_lib):
     assert ok == 0
 
 
-def _sketch_select(rec_cdf, n, knots, mask, u):
-    """EnvMap::sample1d_row_sketch (shading.hip.h) restated with float32 operations: the column it ends on for u, or -1 when the cell
-    of u is not verified.  rec_cdf: the row's n + 1 CDF values (the cdf / cdfNext words of the records)."""
+def _sketch_select(rec_cdf, n, sketch, row, h, u):
+    """EnvMap::sample1d_row_sketch (shading.hip.h) restated with float32 operations: the column it ends on for u, or -1 when neither the
+    row's record nor the cell's child record verifies the cell of u.  rec_cdf: the row's n + 1 CDF values (the cdf / cdfNext words of
+    the records); sketch: all records, 36 words each."""
     f = np.float32
-    uk = f(u) * f(32.0)
-    k = min(int(uk), 31)
-    if not (int(mask) >> k) & 1:
+    rec = sketch[row]
+    x = f(u)
+    pred = None
+    for level in range(2):
+        xk = f(x * f(32.0))
+        k = min(int(xk), 31)
+        t = f(xk - f(k))
+        knots, mask = rec[:33].view(np.float32), int(rec[33])
+        if (mask >> k) & 1:
+            d = f(knots[k + 1] - knots[k])
+            pred = f(knots[k] + f(t * d))
+            break
+        if level == 0:
+            child = int(rec[34]) + bin(~mask & ((1 << k) - 1) & 0xFFFFFFFF).count("1")
+            rec = sketch[h + child]
+            x = t
+    if pred is None:
         return -1
-    t = f(uk - f(k))
-    d = f(knots[k + 1] - knots[k])
-    pred = f(knots[k] + f(t * d))
     fp = min(max(int(pred), 0), n - 1)
     a = fp & ~3
     last = n - 1
@@ -120,7 +132,10 @@ def test_row_sketch_predicts_the_bisection_column_in_every_verified_cell(built_l
         stride = (w + 1 + 3) & ~3
         table = e["rowTable"].reshape(h, stride, 8)
         rows = e["rowCDF"].reshape(h, w + 1)
-        sketch = e["rowSketch"].reshape(h, 34)
+        sketch = e["rowSketch"].reshape(-1, 36)
+        assert len(sketch) == e["sketchRecords"] >= h
+        failing = sum(32 - bin(int(m)).count("1") for m in sketch[:h, 33])
+        assert e["sketchRecords"] == h + failing and e["sketchCells"] == 32 * h - failing      # one child record per failing cell
         # records: word 0 = cdf, word 6 = the next record's cdf, padding records are zero
         assert np.array_equal(table[:, :w + 1, 0].view(np.float32), rows)
         assert np.array_equal(table[:, :w, 6].view(np.float32), rows[:, 1:])
@@ -134,14 +149,27 @@ def test_row_sketch_predicts_the_bisection_column_in_every_verified_cell(built_l
             us = us[(us >= 0) & (us < 1)]
             want = np.minimum(np.searchsorted(cdf[:w], us, side="right") - 1, w - 1)
             for u, wnt in zip(us, want):
-                got = _sketch_select(cdf, w, knots, mask, u)
+                got = _sketch_select(cdf, w, sketch, y, h, u)
                 if got < 0:
                     unverified += 1
                     continue
                 assert got == wnt, (w, h, y, float(u), got, int(wnt))
                 checked += 1
         assert checked > 2000
-    # the bench's sky (2048 x 1024 in bench.py; a quarter of it here): nearly every cell is verified -- the rows through the sun keep the guide
+    # the bench's sky (2048 x 1024 in bench.py; a quarter of it here): nearly every first-level cell is verified, and with the child
+    # records fewer than one sample in a hundred falls back to the guide (importance-sampled rows and columns, as the renderer draws them)
     w, h = 1024, 512
     e = api.env_build_importance(api.env_make_sky(w, h).copy(), w, h)
     assert e["sketchCells"] >= 0.9 * 32 * h, e["sketchCells"] / (32.0 * h)
+    sketch = e["rowSketch"].reshape(-1, 36)
+    u1, u0 = rng.random(200000).astype(np.float32), rng.random(200000).astype(np.float32)
+    rows_drawn = np.minimum(np.searchsorted(e["topCDF"][:h], u1, side="right") - 1, h - 1)
+    k1 = np.minimum((u0 * np.float32(32)).astype(np.int64), 31)
+    t1 = (u0 * np.float32(32) - k1.astype(np.float32)).astype(np.float32)
+    ok1 = ((sketch[rows_drawn, 33] >> k1) & 1).astype(bool)
+    below = np.array([bin(~int(m) & ((1 << int(k)) - 1) & 0xFFFFFFFF).count("1") for m, k in zip(sketch[rows_drawn, 33], k1)])
+    child = h + sketch[rows_drawn, 34].astype(np.int64) + below
+    k2 = np.minimum((t1 * np.float32(32)).astype(np.int64), 31)
+    ok2 = ((sketch[np.minimum(child, len(sketch) - 1), 33] >> k2) & 1).astype(bool)
+    fallback = 1.0 - np.mean(ok1 | ok2)
+    assert np.mean(~ok1) > fallback * 4 and fallback < 0.01, (float(np.mean(~ok1)), float(fallback))
