@@ -391,7 +391,23 @@ def run_config(args, rank, local_rank, world, dist):
                 raise SystemExit("--exchange rccl: librccl does not load on every rank")
 
         one_gpu = os.environ.get("GFX_BENCH_ONE_GPU") == "1"
-        rccl_ex = api.RcclExchange(ids, rank, world, H) if use_rccl else None    # the communicators: made once (an ncclUniqueId serves one ncclCommInitRank)
+        rccl_ex = None
+        if use_rccl:
+            # the communicators: made once (an ncclUniqueId serves one ncclCommInitRank).  A failure that every rank sees (a librccl that
+            # refuses the call) sends all of them to the torch.distributed transport together; --exchange rccl makes it an error instead
+            made = torch.ones(1, dtype=torch.int32, device="cuda")
+            try:
+                rccl_ex = api.RcclExchange(ids, rank, world, H)
+            except api.GfxError as e:
+                made.zero_()
+                sys.stderr.write("bench: rank %d: %s\n" % (rank, e))
+            dist.all_reduce(made, op=dist.ReduceOp.MIN)
+            if not bool(made.item()):
+                if args.exchange == "rccl":
+                    raise SystemExit("--exchange rccl: gfxh_rccl_create_lanes failed")
+                if rccl_ex is not None:
+                    rccl_ex.close()
+                rccl_ex, use_rccl = None, False
 
         def install(r, bands_now):
             """The transport for one band renderer (re-installed when the bands are re-cut)."""

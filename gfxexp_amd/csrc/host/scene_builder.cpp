@@ -1426,6 +1426,7 @@ uint32_t gfxh_env_build_row_sketch(const float* rowCDF, uint32_t w, uint32_t h, 
         else for (uint32_t j = 0; j <= K; ++j) knots[j] = 0.0f;
         uint32_t* row = rows.data() + static_cast<size_t>(y) * W;
         std::memcpy(row, knots, 4 * (K + 1));
+        for (uint32_t k = 0; k < K; ++k) if (!((mask >> k) & 1u)) row[k] |= 0x80000000u;   // the sign bit of knot k repeats mask bit k (cleared = verified): one sector per sample
         row[K + 1] = mask; row[K + 2] = numChildren;
         for (uint32_t k = 0; k < K; ++k) {
             if ((mask >> k) & 1u) { ++good; continue; }
@@ -1445,6 +1446,7 @@ uint32_t gfxh_env_build_row_sketch(const float* rowCDF, uint32_t w, uint32_t h, 
             children.resize(children.size() + W, 0u);
             uint32_t* rec = children.data() + static_cast<size_t>(numChildren) * W;
             std::memcpy(rec, sub, 4 * (K + 1));
+            for (uint32_t j = 0; j < K; ++j) if (!((subMask >> j) & 1u)) rec[j] |= 0x80000000u;
             rec[K + 1] = subMask;
             ++numChildren;
         }

@@ -561,14 +561,15 @@ struct EnvMap { // RegularConstantContinuousDistribution2D + lat-long texture
             uint32_t k = static_cast<uint32_t>(xk);
             if (k > GFX_ENV_SKETCH_CELLS - 1u) k = GFX_ENV_SKETCH_CELLS - 1u;
             const float t = xk - static_cast<float>(k);                  // exact
-            const uint32_t mask = rec[GFX_ENV_SKETCH_CELLS + 1u];
-            if ((mask >> k) & 1u) {
-                const float k0 = bits2f(rec[k]), k1 = bits2f(rec[k + 1u]);
+            const uint32_t w0 = rec[k], w1 = rec[k + 1u];               // knot k carries the cell's verdict in its sign bit (set = not verified)
+            if (!(w0 >> 31)) {
+                const float k0 = bits2f(w0), k1 = bits2f(w1 & 0x7FFFFFFFu);
                 const float d = k1 - k0;
                 pred = k0 + t * d;
                 found = true;
             }
             else if (level == 0) {
+                const uint32_t mask = rec[GFX_ENV_SKETCH_CELLS + 1u];
                 const uint32_t child = rec[GFX_ENV_SKETCH_CELLS + 2u] + static_cast<uint32_t>(__popc(~mask & ((1u << k) - 1u)));
                 rec = sketch + static_cast<size_t>(numRows + child) * GFX_ENV_SKETCH_WORDS;
                 x = t;

@@ -256,7 +256,8 @@ typedef struct gfx_restir_static_params {
      * 33 floats = an inverse CDF (in columns) at 33 equidistant u, a 32-bit mask, the index of the record's first child record, one unused
      * word.  Record `row` (0 .. envH - 1) covers u in [0, 1) of that row: mask bit k set = for every u of cell k = [k/32, (k+1)/32) the linear
      * interpolation of knots k and k + 1 lands within one column of the column the bisection finds (verified by the builder for every
-     * column of the cell, with the device's arithmetic).  A cell that fails has a CHILD record (envH + first child + its rank among the
+     * column of the cell, with the device's arithmetic); the sign bit of knot k repeats the verdict (set = failed), so a sample of a
+     * verified cell reads the two knots and nothing else.  A cell that fails has a CHILD record (envH + first child + its rank among the
      * record's failing cells) that covers the cell's range of u the same way at 1/32 of the step; a sub-cell that fails again keeps the
      * guide.  A sample of a verified (sub-)cell reads ONE 128-byte line of the row table (the group of four records around the
      * prediction; a neighbouring line in the few cases the column sits across its edge) instead of the guide's line plus the column's;

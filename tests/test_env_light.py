@@ -95,10 +95,13 @@ def _sketch_select(rec_cdf, n, sketch, row, h, u):
         xk = f(x * f(32.0))
         k = min(int(xk), 31)
         t = f(xk - f(k))
-        knots, mask = rec[:33].view(np.float32), int(rec[33])
-        if (mask >> k) & 1:
-            d = f(knots[k + 1] - knots[k])
-            pred = f(knots[k] + f(t * d))
+        mask = int(rec[33])
+        assert (int(rec[k]) >> 31) == (0 if (mask >> k) & 1 else 1)           # knot k's sign bit repeats the verdict of cell k
+        if not int(rec[k]) >> 31:
+            k0 = rec[k:k + 1].view(np.float32)[0]
+            k1 = (rec[k + 1:k + 2] & np.uint32(0x7FFFFFFF)).view(np.float32)[0]
+            d = f(k1 - k0)
+            pred = f(k0 + f(t * d))
             break
         if level == 0:
             child = int(rec[34]) + bin(~mask & ((1 << k) - 1) & 0xFFFFFFFF).count("1")
@@ -143,7 +146,7 @@ def test_row_sketch_predicts_the_bisection_column_in_every_verified_cell(built_l
         checked = unverified = 0
         for y in list(range(0, h, max(1, h // 9))) + [h - 1]:
             cdf = rows[y]
-            knots, mask = sketch[y, :33].view(np.float32), sketch[y, 33]
+            knots, mask = (sketch[y, :33] & np.uint32(0x7FFFFFFF)).view(np.float32), sketch[y, 33]
             assert np.all(np.diff(knots) >= 0) or mask == 0
             us = np.concatenate([rng.random(600).astype(np.float32), cdf[:w], np.nextafter(cdf[1:], np.float32(0))])
             us = us[(us >= 0) & (us < 1)]
