@@ -441,9 +441,11 @@ int gfxh_env_upload(float* texels, uint32_t w, uint32_t h, gfx_restir_static_par
                 gfxh_env_build_row_table(texels, rowPDF.data(), rowCDF.data(), rowGuide.data(), w, h, table.data());
                 err |= up(&sp.envRowTable, table.data(), 4 * table.size());
                 haveTable = !err;
-                // ... and the rows' inverse-CDF sketches: a sample of a verified cell reads one line of the table (GFX_ENV_ROW_SKETCH=0: the guide)
+                // ... and, with GFX_ENV_ROW_SKETCH=1, the rows' inverse-CDF sketches: a sample of a verified cell reads one line of the table and
+                // no guide.  Off by default: the candidate pass of configs[4] then moves 3.45 GB through the memory-side counters instead of
+                // 5.80 GB and takes 1-3 % LONGER (it runs at the L2s' sector rate and the VALU's, not HBM's: profiles/r06_experiments.txt 4)
                 const char* sk = std::getenv("GFX_ENV_ROW_SKETCH");
-                if (!(sk && sk[0] == '0')) {
+                if (sk && sk[0] == '1') {
                     uint32_t numRecords = 0;
                     (void)gfxh_env_build_row_sketch(rowCDF.data(), w, h, nullptr, 0, &numRecords);
                     std::vector<uint32_t> sketch(static_cast<size_t>(numRecords) * GFX_ENV_SKETCH_WORDS);

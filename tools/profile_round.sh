@@ -70,8 +70,8 @@ for step in "$@"; do
                python profiles/make_pmc_json.py --command "$B --config 1 --no-roofline" $OUT/pmc_config1 > $OUT/${ROUND}_pmc_config1.json; head -c 400 $OUT/${ROUND}_pmc_config1.json ;;
     pmcc4)     BFLAGS="--config 4" pmc_passes pmc_config4 GFX_NOOP=1
                python profiles/make_pmc_json.py --command "$B --config 4 --no-roofline" $OUT/pmc_config4 > $OUT/${ROUND}_pmc_config4.json; head -c 400 $OUT/${ROUND}_pmc_config4.json ;;
-    pmcc4ns)   BFLAGS="--config 4" pmc_passes pmc_config4_nosketch GFX_ENV_ROW_SKETCH=0     # round 6: the same without the rows' inverse-CDF sketches (the guide inside the records)
-               python profiles/make_pmc_json.py --command "GFX_ENV_ROW_SKETCH=0 $B --config 4 --no-roofline" $OUT/pmc_config4_nosketch > $OUT/${ROUND}_pmc_config4_nosketch.json; head -c 400 $OUT/${ROUND}_pmc_config4_nosketch.json ;;
+    pmcc4sk)   BFLAGS="--config 4" pmc_passes pmc_config4_sketch GFX_ENV_ROW_SKETCH=1     # round 6: the same with the rows' inverse-CDF sketches (no guide read in verified cells)
+               python profiles/make_pmc_json.py --command "GFX_ENV_ROW_SKETCH=1 $B --config 4 --no-roofline" $OUT/pmc_config4_sketch > $OUT/${ROUND}_pmc_config4_sketch.json; head -c 400 $OUT/${ROUND}_pmc_config4_sketch.json ;;
     ptregen)   timeout 600 python tools/pt_regen_diag.py > $OUT/pt_regen.jsonl 2> $OUT/pt_regen.err; cat $OUT/pt_regen.jsonl ;;
     bandhost)  timeout 300 python tools/band_host_overhead.py host > $OUT/band_host.json 2> $OUT/band_host.err; cat $OUT/band_host.json
                : > $OUT/band_latency.jsonl
