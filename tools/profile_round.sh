@@ -98,6 +98,8 @@ for step in "$@"; do
     renderers) timeout 900 python tools/bench_renderers.py > $OUT/renderers.jsonl 2> $OUT/renderers.err
                timeout 300 python tools/bench_config4.py >> $OUT/renderers.jsonl 2>> $OUT/renderers.err; cat $OUT/renderers.jsonl ;;
     bands)     timeout 900 python tools/bench_band.py > $OUT/band_compute_bound.json 2> $OUT/band.err; cat $OUT/band_compute_bound.json; tail -3 $OUT/band.err ;;
+    bands4)    timeout 900 python tools/bench_band.py --config4 --modes strips > $OUT/band_compute_bound_config4.json 2>> $OUT/band.err; cat $OUT/band_compute_bound_config4.json ;;
+    nrcprof)   GFX_LIB=$PWD/gfxexp_amd/variants/libgfxexp_laneprof.so timeout 300 python tools/nrc_infer_profile.py > $OUT/nrc_infer_profile.json 2> $OUT/nrc_prof.err; cat $OUT/nrc_infer_profile.json ;;
     l2gather)  hipcc --offload-arch=gfx950 -O3 -w -o /tmp/l2_gather tools/microbench/l2_gather.hip && timeout 120 /tmp/l2_gather | tee $OUT/l2_gather.jsonl ;;
     valurate)  hipcc --offload-arch=gfx950 -O3 -w -o /tmp/valu_rate tools/microbench/valu_rate.hip && timeout 120 /tmp/valu_rate | tee $OUT/valu_rate.jsonl ;;
     whatif)    # (round 3 only: the GFX_WHATIF_* hooks these variants switched were removed from the kernels in round 4)
