@@ -67,7 +67,7 @@ int gfx_ctx_create(int device, gfx_ctx** out) {
         t.candidateSplit = env_int("GFX_CANDIDATE_SPLIT", t.candidateSplit, 0, 4);
         t.fusePasses = env_int("GFX_FUSE_PASSES", t.fusePasses, 0, 2);
         t.blockOrder = env_int("GFX_BLOCK_ORDER", t.blockOrder, 0, 1);
-        t.nrcStagedInfer = env_int("GFX_NRC_STAGED_INFER", t.nrcStagedInfer, 0, 2);
+        t.nrcStagedInfer = env_int("GFX_NRC_STAGED_INFER", t.nrcStagedInfer, 0, 3);
         if (t.candidateSplit == 3) t.candidateSplit = 2;
         ctx->c.dTraceCounters.reserve(64);
         GFX_HIP(hipMemset(ctx->c.dTraceCounters.p, 0, 64));
@@ -537,7 +537,7 @@ int gfx_tunable_set(gfx_ctx* ctx, const char* name, int value) {
     else if (n == "pt_regen_min") t.ptRegenMin = in(1, 64);
     else if (n == "fuse_passes") t.fusePasses = in(0, 2);
     else if (n == "block_order") t.blockOrder = in(0, 1);
-    else if (n == "nrc_staged_infer") t.nrcStagedInfer = in(0, 2);
+    else if (n == "nrc_staged_infer") t.nrcStagedInfer = in(0, 3);
     else if (n == "candidate_split") { if (value == 3) throw HipError("gfx_tunable_set: candidate_split is 0 (automatic), 1, 2 or 4"); t.candidateSplit = in(0, 4); }
     else throw HipError("gfx_tunable_set: unknown tunable " + n);
     GFX_CATCH(ctx)

@@ -97,7 +97,7 @@ struct Tunables {
     int candidateSplit = 0;          // k_initial_candidates: lanes per pixel (1, 2, 4); 0 = by launch size (restir.hip)
     int blockOrder = 1;              // k_initial_fused: blocks start by decreasing cost of one frame ago (restir.hip k_order_blocks); 0 = index order
     int fusePasses = 0;              // ReSTIR ray passes as one kernel each (restir.hip k_*_fused): 0 = small launches only, 1 never, 2 always
-    int nrcStagedInfer = 0;          // k_nrc_infer_staged (hash-grid levels through LDS): 0 = large batches only, 1 never, 2 always (nrc.hip)
+    int nrcStagedInfer = 0;          // k_nrc_infer_staged (hash-grid levels through LDS): 0 = large batches only, 1 never, 2 always, 3 always in the software-pipelined form k_nrc_infer_piped (nrc.hip)
     int ptDiag = 0;                  // one-kernel path tracers count wave iterations and the lanes that held a ray in them (gfx_pt_diag_read)
     int ptRegen = 0;                 // baseline path tracer, one-kernel form: blocks of 256 per CU of the regenerating launch (pathtrace.hip k_pt_regen); 0 = k_pt_fused
                                      // (the default: regeneration fills the lanes -- 0.30 -> 0.6 of them hold a ray -- and still takes 17 % longer on the
@@ -111,6 +111,7 @@ struct Context {
     int device = 0;
     int numCUs = 0;                  // of `device` (gfx_ctx_create)
     Tunables tune;
+    uint32_t nrcInferPipedLds = 0;            // dynamic LDS bytes k_nrc_infer_piped has been enabled for on this device
     bool nrcInferStagedConfigured = false;   // k_nrc_infer_staged has been given its 128 KiB of dynamic LDS on this device
     size_t nrcTrainLdsConfigured = 0; // dynamic LDS bytes k_nrc_train has been enabled for on this device
     std::string lastError;

@@ -614,6 +614,180 @@ void k_nrc_infer_staged(NrcDev d, const uint16_t* __restrict__ fwd, const uint32
     GFX_CYC_END;
 }
 
+// ---------------------------------------------------------------- inference, staged levels + the table-free half under the table copies
+// k_nrc_infer_staged spends a third of a wave's cycles waiting for the level tables (the DMA of a 128-KiB table and its two barriers, sixteen
+// times per pass: every wave of the block waits at the same time and one block fills the CU's LDS) and another third on work that needs no
+// table (one-blob features, the layers, the output) -- profiles/r06_nrc_infer_profile.json.  This kernel runs the second under the first: a
+// software pipeline across passes.  The hash half of a pass's operands is parked in an L2-resident scratch instead of registers (one K step
+// of 4 words per tile half at a time: after the 8th and the 16th level); the table-free half of pass p - 1 is cut into sixteen slices -- tile
+// 0..3 x batch half 0..1 x {one-blob + first layer, remaining layers + output} -- and slice i runs between the DMA issue and the DMA wait of the
+// i-th level of pass p.  A slice's own loads (8 parked words, 11 inputs) are issued BEFORE the DMA instructions: vmcnt retires in order, a
+// load issued behind the DMA would wait for it.  The weights stay in the 32 KiB of LDS the table leaves free (2 hidden layers: 20 KiB; deeper
+// networks keep k_nrc_infer_staged).  Per query the same operations in the same order as k_nrc_infer: bit-equal outputs.
+constexpr uint32_t kPipedWordsPerWave = 2u * kStagedTiles * 2u * 2u * 4u * 64u;    // [pass parity][tile][batch half][K step][word][lane]
+GFX_DEV uint32_t piped_index(uint32_t parity, int t, int nt, int s, int w, int lane) {
+    return ((((parity * kStagedTiles + static_cast<uint32_t>(t)) * 2u + static_cast<uint32_t>(nt)) * 2u + static_cast<uint32_t>(s)) * 4u + static_cast<uint32_t>(w)) * 64u + static_cast<uint32_t>(lane);
+}
+__global__ __launch_bounds__(kStagedBlock) __attribute__((amdgpu_waves_per_eu(kStagedBlock / 256, kStagedBlock / 256)))
+void k_nrc_infer_piped(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_t* __restrict__ grid, const float* __restrict__ inputs,
+                       uint32_t numDataArg, const uint32_t* __restrict__ numDataPtr, float* __restrict__ predictions, uint32_t* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsAll[];         // kStagedTableBytes: a level's table; behind it the weight fragments
+    const uint32_t numData = numDataPtr ? min(*numDataPtr, numDataArg) : numDataArg;
+    const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t numTiles = (numData + 63) / 64;
+    constexpr uint32_t kWaves = kStagedBlock / 64, kTilesPerPass = kWaves * kStagedTiles;
+    const uint32_t rounds = (numTiles + gridDim.x * kTilesPerPass - 1) / (gridDim.x * kTilesPerPass);
+    const uint32_t numPasses = gridDim.x * rounds;
+    const uint32_t passTiles = (numTiles + numPasses - 1) / numPasses;
+    const uint32_t fwdElems = d.numHidden * kMatFwdElems + kOutFwdElems;
+    const uint32_t* ldsTable = reinterpret_cast<const uint32_t*>(ldsAll);
+    uint4* ldsW = ldsAll + kStagedTableBytes / 16;
+    for (uint32_t i = threadIdx.x; i < fwdElems / 8; i += kStagedBlock) ldsW[i] = reinterpret_cast<const uint4*>(fwd)[i];   // (the first level's barriers publish them)
+    uint32_t* park = scratch + static_cast<size_t>(blockIdx.x * kWaves + static_cast<uint32_t>(wave)) * kPipedWordsPerWave;
+    bool havePrev = false;
+    uint32_t prevTile0 = 0, prevTileEnd = 0, parity = 0;
+    for (uint32_t pass = blockIdx.x;; pass += gridDim.x) {
+        const bool valid = pass < numPasses && pass * passTiles < numTiles;   // block-uniform
+        if (!valid && !havePrev) break;
+        const uint32_t tile0 = pass * passTiles + wave, tileEnd = valid ? min((pass + 1) * passTiles, numTiles) : 0u;
+        const bool lastSlotUsed = valid && tile0 + (kStagedTiles - 1) * kWaves < tileEnd;
+        float px[kStagedTiles], py[kStagedTiles], pz[kStagedTiles];
+#pragma unroll
+        for (int t = 0; t < kStagedTiles; ++t) {
+            const uint32_t tile = tile0 + t * kWaves;
+            const size_t col = static_cast<size_t>(tile) * 64 + lane;
+            const bool ok = valid && tile < tileEnd && col < numData;
+            px[t] = ok ? inputs[col * kNrcIn] : 0.0f; py[t] = ok ? inputs[col * kNrcIn + 1] : 0.0f; pz[t] = ok ? inputs[col * kNrcIn + 2] : 0.0f;
+        }
+        uint4 hb[kStagedTiles][2];                            // [tile][batch half]: the K step being filled (four word positions)
+#pragma unroll
+        for (int t = 0; t < kStagedTiles; ++t) { hb[t][0] = make_uint4(0u, 0u, 0u, 0u); hb[t][1] = make_uint4(0u, 0u, 0u, 0u); }
+        uint4 bLive[4] = { make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u) };   // a slice's first-layer output on its way to the second slice
+        for (int pos = 0; pos < 8; ++pos) {
+            uint32_t w0[kStagedTiles], w1[kStagedTiles];
+#pragma unroll
+            for (int t = 0; t < kStagedTiles; ++t) { w0[t] = 0u; w1[t] = 0u; }
+#pragma unroll
+            for (int hL = 0; hL < 2; ++hL) {
+                const int L = 4 * (pos >> 1) + (pos & 1) + 2 * hL;
+                // ---- slice 2 pos + hL of the previous pass: tile st, batch half snt, part 0 (features + first layer) or 1 (the rest)
+                const int li = 2 * pos + hL, st = li >> 2, snt = (li >> 1) & 1, part = li & 1;
+                const uint32_t ptile = prevTile0 + static_cast<uint32_t>(st) * kWaves;
+                const bool slice = havePrev && ptile < prevTileEnd;                 // wave-uniform
+                const uint32_t col = ptile * 64u + 32u * static_cast<uint32_t>(snt) + static_cast<uint32_t>(n);
+                uint4 hp0 = make_uint4(0u, 0u, 0u, 0u), hp1 = hp0;
+                float x[kNrcIn];
+#pragma unroll
+                for (int k = 0; k < kNrcIn; ++k) x[k] = 0.0f;
+                if (slice && part == 0) {                                            // issued ahead of the DMA
+                    const uint32_t pp = parity ^ 1u;
+                    hp0.x = __hip_atomic_load(park + piped_index(pp, st, snt, 0, 0, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hp0.y = __hip_atomic_load(park + piped_index(pp, st, snt, 0, 1, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hp0.z = __hip_atomic_load(park + piped_index(pp, st, snt, 0, 2, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hp0.w = __hip_atomic_load(park + piped_index(pp, st, snt, 0, 3, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hp1.x = __hip_atomic_load(park + piped_index(pp, st, snt, 1, 0, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hp1.y = __hip_atomic_load(park + piped_index(pp, st, snt, 1, 1, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hp1.z = __hip_atomic_load(park + piped_index(pp, st, snt, 1, 2, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hp1.w = __hip_atomic_load(park + piped_index(pp, st, snt, 1, 3, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (col < numData) {
+#pragma unroll
+                        for (int k = 3; k < kNrcIn; ++k) x[k] = inputs[static_cast<size_t>(col) * kNrcIn + k];
+                    }
+                }
+                NrcLevel lv = d.levels[L];
+                __syncthreads();                            // the table of the level before is no longer read
+                if (valid) {
+                    const char* src = reinterpret_cast<const char*>(grid + lv.offset);
+                    const uint32_t bytes = lv.entries * 4u;
+                    for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < bytes; off += (kStagedBlock / 64) * 1024u) {
+                        if (off + static_cast<uint32_t>(lane) * 16u < bytes) {
+                            typedef const __attribute__((address_space(1))) void* GlobalPtr;
+                            typedef __attribute__((address_space(3))) void* LdsPtr;
+                            __builtin_amdgcn_global_load_lds((GlobalPtr)(src + off + lane * 16), (LdsPtr)(reinterpret_cast<char*>(ldsAll) + off), 16, 0, 0);
+                        }
+                    }
+                }
+                if (slice) {
+                    if (part == 0) {
+                        // k_nrc_infer's features 32 .. 63 of this half (one-blob, identity, ones) + the parked hash features, then the first layer
+                        float enc[16];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            float ob[4];
+                            oneblob4(h ? x[4 + 2 * i] : x[3 + 2 * i], ob);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) enc[4 * i + r] = ob[r];
+                        }
+                        {
+                            float ob[4];
+                            oneblob4(x[7], ob);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) enc[8 + r] = h ? x[8 + r] : ob[r];
+                        }
+                        enc[12] = h ? 1.0f : x[12]; enc[13] = h ? 1.0f : x[13]; enc[14] = 1.0f; enc[15] = 1.0f;
+                        uint4 b[4];
+                        b[0] = hp0; b[1] = hp1; b[2] = pack8(enc); b[3] = pack8(enc + 8);
+                        f32x16 acc[2];
+                        layer64(ldsW, lane, b, acc);
+                        relu_to_operand(acc, bLive);
+                    }
+                    else {
+                        for (int layer = 1; layer < d.numHidden; ++layer) {
+                            f32x16 acc[2];
+                            layer64(ldsW + layer * (kMatFwdElems / 8), lane, bLive, acc);
+                            relu_to_operand(acc, bLive);
+                        }
+                        const uint4* fragsOut = ldsW + d.numHidden * (kMatFwdElems / 8);
+                        f32x16 c;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fragsOut[s * 64 + lane]),
+                                                                        __builtin_bit_cast(bf16x8, bLive[s]), c, 0, 0, 0);
+                        if (h == 0 && col < numData) {
+                            float* o = predictions + static_cast<size_t>(col) * kNrcOut;
+                            o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (valid) {
+                    lv.offset = 0u;
+                    const bool dense = static_cast<unsigned long long>(lv.res) * lv.res * lv.res <= lv.entries, pow2 = (lv.entries & (lv.entries - 1)) == 0;
+                    if (pow2 && !dense) staged_level<0, 1>(lv, ldsTable, px, py, pz, h, hL, lastSlotUsed, w0, w1);
+                    else if (pow2) staged_level<1, 1>(lv, ldsTable, px, py, pz, h, hL, lastSlotUsed, w0, w1);
+                    else staged_level<-1, -1>(lv, ldsTable, px, py, pz, h, hL, lastSlotUsed, w0, w1);
+                }
+            }
+            switch (pos & 3) {                              // block-uniform: word position of the K step being filled
+#define GFX_PIPED_CASE(P) case P: _Pragma("unroll") for (int t = 0; t < kStagedTiles; ++t) { \
+                staged_set_word(hb[t][0], (P), w0[t]); staged_set_word(hb[t][1], (P), w1[t]); } break;
+            GFX_PIPED_CASE(0) GFX_PIPED_CASE(1) GFX_PIPED_CASE(2) GFX_PIPED_CASE(3)
+#undef GFX_PIPED_CASE
+            default: break;
+            }
+            if ((pos & 3) == 3) {                           // a K step is complete: park it (coalesced 4-byte planes), start the next
+                if (valid) {
+#pragma unroll
+                    for (int t = 0; t < kStagedTiles; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            park[piped_index(parity, t, nt, pos >> 2, 0, lane)] = hb[t][nt].x; park[piped_index(parity, t, nt, pos >> 2, 1, lane)] = hb[t][nt].y;
+                            park[piped_index(parity, t, nt, pos >> 2, 2, lane)] = hb[t][nt].z; park[piped_index(parity, t, nt, pos >> 2, 3, lane)] = hb[t][nt].w;
+                        }
+                }
+#pragma unroll
+                for (int t = 0; t < kStagedTiles; ++t) { hb[t][0] = make_uint4(0u, 0u, 0u, 0u); hb[t][1] = make_uint4(0u, 0u, 0u, 0u); }
+            }
+        }
+        havePrev = valid; prevTile0 = tile0; prevTileEnd = tileEnd; parity ^= 1u;
+        if (!valid) break;                                  // that was the draining round
+    }
+}
+
 // ---------------------------------------------------------------- training step
 // One wave per block, 64 batch columns per block.  Weight fragments are read straight from the packed
 // global images (each is used once per block); LDS keeps every layer's activations twice: in operand
@@ -1006,6 +1180,7 @@ struct NrcNet {
     uint32_t mlpParams = 0, gridParams = 0;
     DevBuf params, adamM, adamV, ema, gradPartials, gradSum, gridGrad, lossSum, gridDelta, gridPartials;
     DevBuf packTrainFwd, packTrainBwd, packInferFwd, gridTrain, gridInfer;
+    DevBuf pipeScratch;                      // k_nrc_infer_piped: the parked hash operands of a pass (32 KiB per wave)
     uint32_t partialCapacity = 0;
     // the inference images (bf16 fragments + grid of the EMA weights) are packed when somebody asks for them, not after every step:
     // a frame trains four steps and infers once
@@ -1096,7 +1271,7 @@ NrcNet* nrc_create(Context& ctx, int posEnc, uint32_t numHiddenLayers, float lea
 void nrc_destroy(NrcNet* net) {
     if (!net) return;
     DevBuf* all[] = { &net->params, &net->adamM, &net->adamV, &net->ema, &net->gradPartials, &net->gradSum, &net->gridGrad, &net->lossSum, &net->gridDelta, &net->gridPartials,
-                      &net->packTrainFwd, &net->packTrainBwd, &net->packInferFwd, &net->gridTrain, &net->gridInfer };
+                      &net->packTrainFwd, &net->packTrainBwd, &net->packInferFwd, &net->gridTrain, &net->gridInfer, &net->pipeScratch };
     for (DevBuf* b : all) b->release();
     if (net->trained) (void)hipEventDestroy(net->trained);
     if (net->packStream) (void)hipStreamDestroy(net->packStream);
@@ -1175,7 +1350,23 @@ void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     // A large hash-grid batch is encoded level by level out of LDS copies of the level tables (k_nrc_infer_staged): worth it when every CU
     // gets at least one pass of 3 072 queries ("nrc_staged_infer": 0 by batch size, 1 never, 2 always)
     const uint32_t stagedPasses = (numTiles + (kStagedBlock / 64) * kStagedTiles - 1) / ((kStagedBlock / 64) * kStagedTiles);
-    const bool staged = net->d.posEnc == 1 && ctx.tune.nrcStagedInfer != 1 && (ctx.tune.nrcStagedInfer == 2 || stagedPasses >= static_cast<uint32_t>(numCUs));
+    const bool staged = net->d.posEnc == 1 && ctx.tune.nrcStagedInfer != 1 && (ctx.tune.nrcStagedInfer >= 2 || stagedPasses >= static_cast<uint32_t>(numCUs));
+    // "nrc_staged_infer" 3: the software-pipelined form (k_nrc_infer_piped; networks of up to two hidden layers: the weights share the LDS with the table)
+    const bool piped = staged && ctx.tune.nrcStagedInfer == 3 && net->d.numHidden <= 2;
+    if (piped) {
+        const uint32_t lds = kStagedTableBytes + 2u * (net->d.numHidden * kMatFwdElems + kOutFwdElems);
+        const uint32_t blocks = std::min<uint32_t>(stagedPasses, static_cast<uint32_t>(numCUs));
+        if (ctx.nrcInferPipedLds < lds) {
+            GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_infer_piped), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            ctx.nrcInferPipedLds = lds;
+        }
+        net->pipeScratch.reserve(sizeof(uint32_t) * static_cast<size_t>(numCUs) * (kStagedBlock / 64) * kPipedWordsPerWave);
+        ScopedKernelTimer timer(ctx, stream, "nrc_infer");
+        hipLaunchKernelGGL(k_nrc_infer_piped, dim3(blocks), dim3(kStagedBlock), lds, stream, net->d, net->packInferFwd.as<uint16_t>(), net->gridInfer.as<uint32_t>(),
+                           dInputs, numData, dNumData, dPredictions, net->pipeScratch.as<uint32_t>());
+        GFX_HIP(hipGetLastError());
+        return;
+    }
     if (staged) {
         if (!ctx.nrcInferStagedConfigured) {
             GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_infer_staged), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kStagedTableBytes)));

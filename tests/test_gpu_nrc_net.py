@@ -80,7 +80,7 @@ def test_level_staged_inference_equals_the_in_place_kernel(built_lib, hidden, n)
     x = _inputs(rng, n)
     x[:4, :3] = [[0, 0, 0], [1, 1, 1], [0.999999, 0.5, 0.25], [0.5, 0.0, 1.0]]      # grid borders
     outs = {}
-    for mode in (1, 2):
+    for mode in (1, 2, 3):                          # 3: k_nrc_infer_piped, the table-free half of a pass under the next pass's table copies (two hidden layers; deeper: = 2)
         ctx = api.Context(0)
         ctx.tunable_set("nrc_staged_infer", mode)
         net = api.NeuralRadianceCache(ctx, N.POS_HASHGRID, hidden)
@@ -106,6 +106,8 @@ def test_level_staged_inference_equals_the_in_place_kernel(built_lib, hidden, n)
     assert np.isfinite(outs[1]).all() and (outs[1] != -7.0).any()
     diff = outs[1].view(np.uint32) != outs[2].view(np.uint32)
     assert not diff.any(), f"{np.count_nonzero(diff)} of {diff.size} outputs differ between the staged and the in-place kernel (first query {np.argwhere(diff)[0][0]})"
+    diff = outs[1].view(np.uint32) != outs[3].view(np.uint32)
+    assert not diff.any(), f"{np.count_nonzero(diff)} of {diff.size} outputs differ between the pipelined and the in-place kernel (first query {np.argwhere(diff)[0][0]})"
     if n < 10000:
         _check_inference(outs[2], N.NrcNet(N.POS_HASHGRID, hidden, params=p).infer(x))
 
