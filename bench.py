@@ -63,7 +63,8 @@ def _profile_lines(name):
 
 
 # committed counter passes, newest round first (tools/profile_round.sh pmc / pmc1 / pmc4 / pmca -> profiles/make_pmc_json.py), per BASELINE configuration
-PMC_FILES = {2: ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json"), 1: ("r05_pmc_config1.json",), 4: ("r05_pmc_config4.json",), "animate": ("r05_pmc_animate.json",)}
+PMC_FILES = {2: ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json"), 1: ("r06_pmc_config1.json", "r05_pmc_config1.json"), 4: ("r06_pmc_config4.json", "r05_pmc_config4.json"),
+             "animate": ("r06_pmc_animate.json", "r05_pmc_animate.json")}
 
 
 def sources_sha16():
@@ -744,7 +745,7 @@ def roofline_nrc(ctx, renderer, stream, W, H):
     tflops = flop_per_query * queries / max(1e-9, infer_ms / n * 1e-3) / 1e12
     peak = 2500.0
     pmc_txt = None
-    for name in ("r05_nrc_pmc.txt", "r04_nrc_pmc.txt", "r03_nrc_pmc.txt"):
+    for name in ("r06_nrc_pmc.txt", "r05_nrc_pmc.txt", "r04_nrc_pmc.txt"):
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
             pmc_txt = "profiles/" + name
             break

@@ -628,42 +628,120 @@ constexpr uint32_t kPipedWordsPerWave = 2u * kStagedTiles * 2u * 2u * 4u * 64u; 
 GFX_DEV uint32_t piped_index(uint32_t parity, int t, int nt, int s, int w, int lane) {
     return ((((parity * kStagedTiles + static_cast<uint32_t>(t)) * 2u + static_cast<uint32_t>(nt)) * 2u + static_cast<uint32_t>(s)) * 4u + static_cast<uint32_t>(w)) * 64u + static_cast<uint32_t>(lane);
 }
+// One slice of the table-free half of a tile: part 0 = k_nrc_infer's features 32 .. 63 of this lane's half (one-blob, identity, ones) beside the
+// parked hash features, then the first layer (its ReLU-packed output stays in bLive); part 1 = the remaining layers and the output.
+GFX_DEV void piped_slice_features_and_first_layer(const uint4* ldsW, int lane, int h, const uint4& hp0, const uint4& hp1, const float (&x)[kNrcIn], uint4 (&bLive)[4]) {
+    float enc[16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float ob[4];
+        oneblob4(h ? x[4 + 2 * i] : x[3 + 2 * i], ob);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) enc[4 * i + r] = ob[r];
+    }
+    {
+        float ob[4];
+        oneblob4(x[7], ob);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) enc[8 + r] = h ? x[8 + r] : ob[r];
+    }
+    enc[12] = h ? 1.0f : x[12]; enc[13] = h ? 1.0f : x[13]; enc[14] = 1.0f; enc[15] = 1.0f;
+    uint4 b[4];
+    b[0] = hp0; b[1] = hp1; b[2] = pack8(enc); b[3] = pack8(enc + 8);
+    f32x16 acc[2];
+    layer64(ldsW, lane, b, acc);
+    relu_to_operand(acc, bLive);
+}
+GFX_DEV void piped_slice_rest(const NrcDev& d, const uint4* ldsW, int lane, int h, uint4 (&bLive)[4], uint32_t col, uint32_t numData, float* __restrict__ predictions) {
+    for (int layer = 1; layer < d.numHidden; ++layer) {
+        f32x16 acc[2];
+        layer64(ldsW + layer * (kMatFwdElems / 8), lane, bLive, acc);
+        relu_to_operand(acc, bLive);
+    }
+    const uint4* fragsOut = ldsW + d.numHidden * (kMatFwdElems / 8);
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fragsOut[s * 64 + lane]), __builtin_bit_cast(bf16x8, bLive[s]), c, 0, 0, 0);
+    if (h == 0 && col < numData) {
+        float* o = predictions + static_cast<size_t>(col) * kNrcOut;
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+    }
+}
+// The slice's own operands: the two parked K steps of (tile st, batch half snt) and inputs 3 .. 13 of the lane's query -- eleven loads issued
+// as inline assembly, so that the COMPILER does not know they are in flight: it would wait for them with vmcnt(0) at their first use, behind
+// the DMA instructions that are issued after them (it does not count across the blocks of this loop).  piped_slice_loads_wait() is the wait
+// that belongs to them: all but the `dmaBehind` newer instructions (vmcnt retires in order).  Parked words are read past the L1 (sc1): this
+// wave wrote them one pass ago and an L1 line from two passes ago may still be resident.
+typedef float PipedF4 __attribute__((ext_vector_type(4)));
+typedef float PipedF3 __attribute__((ext_vector_type(3)));
+struct PipedLoads { uint32_t p[8]; PipedF4 xa, xb; PipedF3 xc; };
+GFX_DEV void piped_slice_loads(const uint32_t* park, uint32_t parity, int st, int snt, int lane, const float* __restrict__ inputs, uint32_t col, uint32_t numData, PipedLoads& v) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t* src = park + piped_index(parity, st, snt, k >> 2, k & 3, lane);
+        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v.p[k]) : "v"(src) : "memory");
+    }
+    const float* xs = inputs + static_cast<size_t>(col < numData ? col : numData - 1u) * kNrcIn + 3;       // (a column past the batch reads the last query's inputs; its output is not stored)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v.xa) : "v"(xs) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v.xb) : "v"(xs + 4) : "memory");
+    asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(v.xc) : "v"(xs + 8) : "memory");
+}
+#define GFX_STR2(x) #x
+#define GFX_STR(x) GFX_STR2(x)
+template <int DMA_BEHIND>
+GFX_DEV void piped_slice_loads_wait(PipedLoads& v) {
+    asm volatile("s_waitcnt vmcnt(%11)"
+                 : "+v"(v.p[0]), "+v"(v.p[1]), "+v"(v.p[2]), "+v"(v.p[3]), "+v"(v.p[4]), "+v"(v.p[5]), "+v"(v.p[6]), "+v"(v.p[7]), "+v"(v.xa), "+v"(v.xb),
+                   "+v"(v.xc)
+                 : "n"(DMA_BEHIND) : "memory");
+}
+GFX_DEV void piped_unpack(const PipedLoads& v, uint4& hp0, uint4& hp1, float (&x)[kNrcIn]) {
+    hp0 = make_uint4(v.p[0], v.p[1], v.p[2], v.p[3]); hp1 = make_uint4(v.p[4], v.p[5], v.p[6], v.p[7]);
+    x[0] = x[1] = x[2] = 0.0f;
+    x[3] = v.xa.x; x[4] = v.xa.y; x[5] = v.xa.z; x[6] = v.xa.w; x[7] = v.xb.x; x[8] = v.xb.y; x[9] = v.xb.z; x[10] = v.xb.w;
+    x[11] = v.xc[0]; x[12] = v.xc[1]; x[13] = v.xc[2];
+}
 __global__ __launch_bounds__(kStagedBlock) __attribute__((amdgpu_waves_per_eu(kStagedBlock / 256, kStagedBlock / 256)))
 void k_nrc_infer_piped(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_t* __restrict__ grid, const float* __restrict__ inputs,
                        uint32_t numDataArg, const uint32_t* __restrict__ numDataPtr, float* __restrict__ predictions, uint32_t* __restrict__ scratch) {
-    extern __shared__ __attribute__((aligned(16))) uint4 ldsAll[];         // kStagedTableBytes: a level's table; behind it the weight fragments
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsAll[];         // kStagedTableBytes: a level's table
+    // the weight fragments in an LDS object of their own: the compiler must be able to tell a slice's ds_reads from the table the DMA is
+    // filling (reads of the array the DMA writes wait for it: vmcnt(0) before the first of them, and the overlap is gone)
+    __shared__ __attribute__((aligned(16))) uint4 ldsWeights[(2 * kMatFwdElems + kOutFwdElems) / 8];
     const uint32_t numData = numDataPtr ? min(*numDataPtr, numDataArg) : numDataArg;
     const int lane = threadIdx.x & 63, h = lane >> 5, n = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t numTiles = (numData + 63) / 64;
     constexpr uint32_t kWaves = kStagedBlock / 64, kTilesPerPass = kWaves * kStagedTiles;
+    constexpr int kCopiesPerWave = static_cast<int>((kStagedTableBytes / 1024u + kWaves - 1u) / kWaves);    // 1-KiB DMA instructions of a full table per wave
     const uint32_t rounds = (numTiles + gridDim.x * kTilesPerPass - 1) / (gridDim.x * kTilesPerPass);
     const uint32_t numPasses = gridDim.x * rounds;
     const uint32_t passTiles = (numTiles + numPasses - 1) / numPasses;
     const uint32_t fwdElems = d.numHidden * kMatFwdElems + kOutFwdElems;
     const uint32_t* ldsTable = reinterpret_cast<const uint32_t*>(ldsAll);
-    uint4* ldsW = ldsAll + kStagedTableBytes / 16;
+    uint4* ldsW = ldsWeights;
     for (uint32_t i = threadIdx.x; i < fwdElems / 8; i += kStagedBlock) ldsW[i] = reinterpret_cast<const uint4*>(fwd)[i];   // (the first level's barriers publish them)
     uint32_t* park = scratch + static_cast<size_t>(blockIdx.x * kWaves + static_cast<uint32_t>(wave)) * kPipedWordsPerWave;
     bool havePrev = false;
     uint32_t prevTile0 = 0, prevTileEnd = 0, parity = 0;
-    for (uint32_t pass = blockIdx.x;; pass += gridDim.x) {
-        const bool valid = pass < numPasses && pass * passTiles < numTiles;   // block-uniform
-        if (!valid && !havePrev) break;
-        const uint32_t tile0 = pass * passTiles + wave, tileEnd = valid ? min((pass + 1) * passTiles, numTiles) : 0u;
-        const bool lastSlotUsed = valid && tile0 + (kStagedTiles - 1) * kWaves < tileEnd;
+    uint4 bLive[4] = { make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u) };   // a slice's first-layer output on its way to its second part
+    for (uint32_t pass = blockIdx.x; pass < numPasses && pass * passTiles < numTiles; pass += gridDim.x) {
+        const uint32_t tile0 = pass * passTiles + wave, tileEnd = min((pass + 1) * passTiles, numTiles);
+        const bool lastSlotUsed = tile0 + (kStagedTiles - 1) * kWaves < tileEnd;
         float px[kStagedTiles], py[kStagedTiles], pz[kStagedTiles];
 #pragma unroll
         for (int t = 0; t < kStagedTiles; ++t) {
             const uint32_t tile = tile0 + t * kWaves;
             const size_t col = static_cast<size_t>(tile) * 64 + lane;
-            const bool ok = valid && tile < tileEnd && col < numData;
+            const bool ok = tile < tileEnd && col < numData;
             px[t] = ok ? inputs[col * kNrcIn] : 0.0f; py[t] = ok ? inputs[col * kNrcIn + 1] : 0.0f; pz[t] = ok ? inputs[col * kNrcIn + 2] : 0.0f;
         }
         uint4 hb[kStagedTiles][2];                            // [tile][batch half]: the K step being filled (four word positions)
 #pragma unroll
         for (int t = 0; t < kStagedTiles; ++t) { hb[t][0] = make_uint4(0u, 0u, 0u, 0u); hb[t][1] = make_uint4(0u, 0u, 0u, 0u); }
-        uint4 bLive[4] = { make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u) };   // a slice's first-layer output on its way to the second slice
         for (int pos = 0; pos < 8; ++pos) {
             uint32_t w0[kStagedTiles], w1[kStagedTiles];
 #pragma unroll
@@ -671,90 +749,47 @@ void k_nrc_infer_piped(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_
 #pragma unroll
             for (int hL = 0; hL < 2; ++hL) {
                 const int L = 4 * (pos >> 1) + (pos & 1) + 2 * hL;
-                // ---- slice 2 pos + hL of the previous pass: tile st, batch half snt, part 0 (features + first layer) or 1 (the rest)
+                // ---- slice 2 pos + hL of the previous pass: tile st, batch half snt, part 0 or 1; its loads go out ahead of the DMA
                 const int li = 2 * pos + hL, st = li >> 2, snt = (li >> 1) & 1, part = li & 1;
                 const uint32_t ptile = prevTile0 + static_cast<uint32_t>(st) * kWaves;
                 const bool slice = havePrev && ptile < prevTileEnd;                 // wave-uniform
                 const uint32_t col = ptile * 64u + 32u * static_cast<uint32_t>(snt) + static_cast<uint32_t>(n);
-                uint4 hp0 = make_uint4(0u, 0u, 0u, 0u), hp1 = hp0;
-                float x[kNrcIn];
+                PipedLoads pl;
 #pragma unroll
-                for (int k = 0; k < kNrcIn; ++k) x[k] = 0.0f;
-                if (slice && part == 0) {                                            // issued ahead of the DMA
-                    const uint32_t pp = parity ^ 1u;
-                    hp0.x = __hip_atomic_load(park + piped_index(pp, st, snt, 0, 0, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hp0.y = __hip_atomic_load(park + piped_index(pp, st, snt, 0, 1, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hp0.z = __hip_atomic_load(park + piped_index(pp, st, snt, 0, 2, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hp0.w = __hip_atomic_load(park + piped_index(pp, st, snt, 0, 3, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hp1.x = __hip_atomic_load(park + piped_index(pp, st, snt, 1, 0, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hp1.y = __hip_atomic_load(park + piped_index(pp, st, snt, 1, 1, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hp1.z = __hip_atomic_load(park + piped_index(pp, st, snt, 1, 2, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hp1.w = __hip_atomic_load(park + piped_index(pp, st, snt, 1, 3, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (col < numData) {
-#pragma unroll
-                        for (int k = 3; k < kNrcIn; ++k) x[k] = inputs[static_cast<size_t>(col) * kNrcIn + k];
-                    }
-                }
+                for (int k = 0; k < 8; ++k) pl.p[k] = 0u;
+                pl.xa = PipedF4{ 0.0f, 0.0f, 0.0f, 0.0f }; pl.xb = pl.xa; pl.xc = PipedF3{ 0.0f, 0.0f, 0.0f };
+                if (slice && part == 0) piped_slice_loads(park, parity ^ 1u, st, snt, lane, inputs, col, numData, pl);
                 NrcLevel lv = d.levels[L];
-                __syncthreads();                            // the table of the level before is no longer read
-                if (valid) {
+                // the table of the level before is no longer read: every wave's ds_reads of it have returned (their values were used).  A bare
+                // s_barrier, not __syncthreads(): its fence would wait for the slice's loads here, ahead of the DMA they are meant to fly beside
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                {
+                    // the level's table: a FIXED number of 1-KiB DMA instructions per wave (chunks past the table's end re-copy its last chunk:
+                    // the same bytes to the same place), so that the compiler can count them -- the wait for the slice's loads above is then
+                    // "all but the DMA instructions behind them", not "everything"
                     const char* src = reinterpret_cast<const char*>(grid + lv.offset);
-                    const uint32_t bytes = lv.entries * 4u;
-                    for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < bytes; off += (kStagedBlock / 64) * 1024u) {
-                        if (off + static_cast<uint32_t>(lane) * 16u < bytes) {
-                            typedef const __attribute__((address_space(1))) void* GlobalPtr;
-                            typedef __attribute__((address_space(3))) void* LdsPtr;
-                            __builtin_amdgcn_global_load_lds((GlobalPtr)(src + off + lane * 16), (LdsPtr)(reinterpret_cast<char*>(ldsAll) + off), 16, 0, 0);
-                        }
+                    const uint32_t lastChunk = lv.entries * 4u / 1024u - 1u;         // tables are whole KiB (nrc_infer checks before it picks this kernel)
+#pragma unroll
+                    for (int j = 0; j < kCopiesPerWave; ++j) {
+                        const uint32_t chunk = min(static_cast<uint32_t>(wave) + static_cast<uint32_t>(j) * kWaves, lastChunk);
+                        typedef const __attribute__((address_space(1))) void* GlobalPtr;
+                        typedef __attribute__((address_space(3))) void* LdsPtr;
+                        __builtin_amdgcn_global_load_lds((GlobalPtr)(src + chunk * 1024u + lane * 16), (LdsPtr)(reinterpret_cast<char*>(ldsAll) + chunk * 1024u), 16, 0, 0);
                     }
                 }
                 if (slice) {
                     if (part == 0) {
-                        // k_nrc_infer's features 32 .. 63 of this half (one-blob, identity, ones) + the parked hash features, then the first layer
-                        float enc[16];
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            float ob[4];
-                            oneblob4(h ? x[4 + 2 * i] : x[3 + 2 * i], ob);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) enc[4 * i + r] = ob[r];
-                        }
-                        {
-                            float ob[4];
-                            oneblob4(x[7], ob);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) enc[8 + r] = h ? x[8 + r] : ob[r];
-                        }
-                        enc[12] = h ? 1.0f : x[12]; enc[13] = h ? 1.0f : x[13]; enc[14] = 1.0f; enc[15] = 1.0f;
-                        uint4 b[4];
-                        b[0] = hp0; b[1] = hp1; b[2] = pack8(enc); b[3] = pack8(enc + 8);
-                        f32x16 acc[2];
-                        layer64(ldsW, lane, b, acc);
-                        relu_to_operand(acc, bLive);
+                        piped_slice_loads_wait<kCopiesPerWave>(pl);             // the slice's loads have landed; the table's DMA may still be in flight
+                        uint4 hp0, hp1; float x[kNrcIn];
+                        piped_unpack(pl, hp0, hp1, x);
+                        piped_slice_features_and_first_layer(ldsW, lane, h, hp0, hp1, x, bLive);
                     }
-                    else {
-                        for (int layer = 1; layer < d.numHidden; ++layer) {
-                            f32x16 acc[2];
-                            layer64(ldsW + layer * (kMatFwdElems / 8), lane, bLive, acc);
-                            relu_to_operand(acc, bLive);
-                        }
-                        const uint4* fragsOut = ldsW + d.numHidden * (kMatFwdElems / 8);
-                        f32x16 c;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) c[r] = 0.0f;
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fragsOut[s * 64 + lane]),
-                                                                        __builtin_bit_cast(bf16x8, bLive[s]), c, 0, 0, 0);
-                        if (h == 0 && col < numData) {
-                            float* o = predictions + static_cast<size_t>(col) * kNrcOut;
-                            o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
-                        }
-                    }
+                    else piped_slice_rest(d, ldsW, lane, h, bLive, col, numData, predictions);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (valid) {
+                {
                     lv.offset = 0u;
                     const bool dense = static_cast<unsigned long long>(lv.res) * lv.res * lv.res <= lv.entries, pow2 = (lv.entries & (lv.entries - 1)) == 0;
                     if (pow2 && !dense) staged_level<0, 1>(lv, ldsTable, px, py, pz, h, hL, lastSlotUsed, w0, w1);
@@ -770,21 +805,35 @@ void k_nrc_infer_piped(NrcDev d, const uint16_t* __restrict__ fwd, const uint32_
             default: break;
             }
             if ((pos & 3) == 3) {                           // a K step is complete: park it (coalesced 4-byte planes), start the next
-                if (valid) {
 #pragma unroll
-                    for (int t = 0; t < kStagedTiles; ++t)
+                for (int t = 0; t < kStagedTiles; ++t)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            park[piped_index(parity, t, nt, pos >> 2, 0, lane)] = hb[t][nt].x; park[piped_index(parity, t, nt, pos >> 2, 1, lane)] = hb[t][nt].y;
-                            park[piped_index(parity, t, nt, pos >> 2, 2, lane)] = hb[t][nt].z; park[piped_index(parity, t, nt, pos >> 2, 3, lane)] = hb[t][nt].w;
-                        }
-                }
-#pragma unroll
-                for (int t = 0; t < kStagedTiles; ++t) { hb[t][0] = make_uint4(0u, 0u, 0u, 0u); hb[t][1] = make_uint4(0u, 0u, 0u, 0u); }
+                    for (int nt = 0; nt < 2; ++nt) {
+                        park[piped_index(parity, t, nt, pos >> 2, 0, lane)] = hb[t][nt].x; park[piped_index(parity, t, nt, pos >> 2, 1, lane)] = hb[t][nt].y;
+                        park[piped_index(parity, t, nt, pos >> 2, 2, lane)] = hb[t][nt].z; park[piped_index(parity, t, nt, pos >> 2, 3, lane)] = hb[t][nt].w;
+                        hb[t][nt] = make_uint4(0u, 0u, 0u, 0u);
+                    }
             }
         }
-        havePrev = valid; prevTile0 = tile0; prevTileEnd = tileEnd; parity ^= 1u;
-        if (!valid) break;                                  // that was the draining round
+        havePrev = true; prevTile0 = tile0; prevTileEnd = tileEnd; parity ^= 1u;
+    }
+    // ---- the last pass's table-free half: nothing left to run it under
+    if (havePrev) {
+        for (int li = 0; li < 4 * kStagedTiles; ++li) {
+            const int st = li >> 2, snt = (li >> 1) & 1, part = li & 1;
+            const uint32_t ptile = prevTile0 + static_cast<uint32_t>(st) * kWaves;
+            if (ptile >= prevTileEnd) continue;                                      // wave-uniform
+            const uint32_t col = ptile * 64u + 32u * static_cast<uint32_t>(snt) + static_cast<uint32_t>(n);
+            if (part == 0) {
+                PipedLoads pl;
+                piped_slice_loads(park, parity ^ 1u, st, snt, lane, inputs, col, numData, pl);
+                piped_slice_loads_wait<0>(pl);
+                uint4 hp0, hp1; float x[kNrcIn];
+                piped_unpack(pl, hp0, hp1, x);
+                piped_slice_features_and_first_layer(ldsW, lane, h, hp0, hp1, x, bLive);
+            }
+            else piped_slice_rest(d, ldsW, lane, h, bLive, col, numData, predictions);
+        }
     }
 }
 
@@ -1352,9 +1401,11 @@ void nrc_infer(Context& ctx, hipStream_t stream, NrcNet* net, const float* dInpu
     const uint32_t stagedPasses = (numTiles + (kStagedBlock / 64) * kStagedTiles - 1) / ((kStagedBlock / 64) * kStagedTiles);
     const bool staged = net->d.posEnc == 1 && ctx.tune.nrcStagedInfer != 1 && (ctx.tune.nrcStagedInfer >= 2 || stagedPasses >= static_cast<uint32_t>(numCUs));
     // "nrc_staged_infer" 3: the software-pipelined form (k_nrc_infer_piped; networks of up to two hidden layers: the weights share the LDS with the table)
-    const bool piped = staged && ctx.tune.nrcStagedInfer == 3 && net->d.numHidden <= 2;
+    bool wholeKiB = true;
+    for (int l = 0; l < kHashLevels; ++l) wholeKiB = wholeKiB && net->d.levels[l].entries % 256u == 0 && net->d.levels[l].entries >= 256u;
+    const bool piped = staged && ctx.tune.nrcStagedInfer == 3 && net->d.numHidden <= 2 && wholeKiB;
     if (piped) {
-        const uint32_t lds = kStagedTableBytes + 2u * (net->d.numHidden * kMatFwdElems + kOutFwdElems);
+        const uint32_t lds = kStagedTableBytes;              // + 20 KiB of static LDS for the weight fragments
         const uint32_t blocks = std::min<uint32_t>(stagedPasses, static_cast<uint32_t>(numCUs));
         if (ctx.nrcInferPipedLds < lds) {
             GFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nrc_infer_piped), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
