@@ -696,7 +696,7 @@ GFX_DEV void piped_slice_loads_wait(PipedLoads& v) {
     asm volatile("s_waitcnt vmcnt(%11)"
                  : "+v"(v.p[0]), "+v"(v.p[1]), "+v"(v.p[2]), "+v"(v.p[3]), "+v"(v.p[4]), "+v"(v.p[5]), "+v"(v.p[6]), "+v"(v.p[7]), "+v"(v.xa), "+v"(v.xb),
                    "+v"(v.xc)
-                 : "n"(DMA_BEHIND) : "memory");
+                 : "n"(DMA_BEHIND));          // (no "memory" clobber: behind one the compiler waits for the DMA before the slice's first LDS read)
 }
 GFX_DEV void piped_unpack(const PipedLoads& v, uint4& hp0, uint4& hp1, float (&x)[kNrcIn]) {
     hp0 = make_uint4(v.p[0], v.p[1], v.p[2], v.p[3]); hp1 = make_uint4(v.p[4], v.p[5], v.p[6], v.p[7]);
