@@ -26,6 +26,14 @@ constexpr uint32_t kNumTrainingDataPerFrame = 1u << 16;   // neural_radiance_cac
 constexpr uint32_t kTrainBufferSize = 2u << 16;            // :9
 }
 
+
+// Flags of the events that only order kernels of THIS device across streams: no system-scope fence at the record (its cache write-back
+// and invalidation cost the kernels behind it; hip_runtime_api.h hipEventDisableSystemFence).  GFX_EVENT_SYSTEM_FENCE=1: the default flags.
+static unsigned nrc_order_event_flags() {
+    static const unsigned flags = [] { const char* e = std::getenv("GFX_EVENT_SYSTEM_FENCE"); return (e && e[0] == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence); }();
+    return flags;
+}
+
 struct gfxh_nrc {
     gfx_ctx* ctx = nullptr;
     gfxh_nrc_config cfg;
@@ -235,11 +243,11 @@ int gfxh_nrc_create(gfx_ctx* ctx, const gfxh_nrc_config* cfg, gfxh_nrc** out) {
         const char* sf = std::getenv("GFX_SERIAL_FRAMES");   // debugging aid: everything on the caller's stream
         r->pipelineFrames = !(sf && sf[0] == '1');
         if (!nrc_hip_ok(hipStreamCreateWithFlags(&r->gbStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
-            !nrc_hip_ok(hipEventCreateWithFlags(&r->evGb, hipEventDisableTiming), "hipEventCreate") ||
-            !nrc_hip_ok(hipEventCreateWithFlags(&r->evGbFree, hipEventDisableTiming), "hipEventCreate") ||
+            !nrc_hip_ok(hipEventCreateWithFlags(&r->evGb, nrc_order_event_flags()), "hipEventCreate") ||
+            !nrc_hip_ok(hipEventCreateWithFlags(&r->evGbFree, nrc_order_event_flags()), "hipEventCreate") ||
             !nrc_hip_ok(hipStreamCreateWithFlags(&r->trainStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
-            !nrc_hip_ok(hipEventCreateWithFlags(&r->evData, hipEventDisableTiming), "hipEventCreate") ||
-            !nrc_hip_ok(hipEventCreateWithFlags(&r->evTrained, hipEventDisableTiming), "hipEventCreate") ||
+            !nrc_hip_ok(hipEventCreateWithFlags(&r->evData, nrc_order_event_flags()), "hipEventCreate") ||
+            !nrc_hip_ok(hipEventCreateWithFlags(&r->evTrained, nrc_order_event_flags()), "hipEventCreate") ||
             !nrc_hip_ok(hipEventCreateWithFlags(&r->evStats, hipEventDisableTiming), "hipEventCreate") ||
             !nrc_hip_ok(hipHostMalloc(reinterpret_cast<void**>(&r->hostStats), 64, hipHostMallocDefault), "hipHostMalloc")) {
             gfxh_nrc_destroy(r);
@@ -515,7 +523,7 @@ int gfxh_nrc_stats(gfxh_nrc* r, uint32_t* numTrainingData, uint32_t tileSize[2],
 }
 int gfxh_nrc_outputs_consumed(gfxh_nrc* r, void* stream) {
     if (!r) { g_nrcError = "gfxh_nrc_outputs_consumed: null renderer"; return 1; }
-    if (!r->evConsumed) NRC_HIP(hipEventCreateWithFlags(&r->evConsumed, hipEventDisableTiming));
+    if (!r->evConsumed) NRC_HIP(hipEventCreateWithFlags(&r->evConsumed, nrc_order_event_flags()));
     NRC_HIP(hipEventRecord(r->evConsumed, static_cast<hipStream_t>(stream)));
     r->consumedPending = true;
     return 0;

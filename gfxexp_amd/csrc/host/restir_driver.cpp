@@ -22,6 +22,13 @@ bool hip_ok(hipError_t e, const char* what) {
     return false;
 }
 #define DRV_HIP(call) do { if (!hip_ok((call), #call)) return 1; } while (0)
+
+// Flags of the events that only order kernels of THIS device across streams: no system-scope fence at the record (its cache write-back
+// and invalidation cost the kernels behind it; hip_runtime_api.h hipEventDisableSystemFence).  GFX_EVENT_SYSTEM_FENCE=1: the default flags.
+static unsigned order_event_flags() {
+    static const unsigned flags = [] { const char* e = std::getenv("GFX_EVENT_SYSTEM_FENCE"); return (e && e[0] == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence); }();
+    return flags;
+}
 }
 
 struct gfxh_restir {
@@ -219,13 +226,13 @@ int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir*
         const char* sf = std::getenv("GFX_SEAM_FIRST");
         r->seamFirst = sf && sf[0] == '1';
         if (!hip_ok(hipStreamCreateWithFlags(&r->gbStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
-            !hip_ok(hipEventCreateWithFlags(&r->evPrevRead, hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&r->evGbuffer, hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&r->evGbStrips, hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&r->evBandDone, hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&r->evGather, hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&r->evSeamRows, hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&r->evSeamStrips, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evPrevRead, order_event_flags()), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evGbuffer, order_event_flags()), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evGbStrips, order_event_flags()), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evBandDone, order_event_flags()), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evGather, order_event_flags()), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evSeamRows, order_event_flags()), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&r->evSeamStrips, order_event_flags()), "hipEventCreate") ||
             !hip_ok(hipStreamCreateWithFlags(&r->seamStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
             !hip_ok(hipStreamCreateWithFlags(&r->gatherStream, hipStreamNonBlocking), "hipStreamCreateWithFlags")) {
             gfxh_restir_destroy(r);
@@ -877,7 +884,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
 int gfxh_restir_outputs_consumed(gfxh_restir* r, void* stream) {
     if (!r) { g_driverError = "gfxh_restir_outputs_consumed: null renderer"; return 1; }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!r->evConsumed && !hip_ok(hipEventCreateWithFlags(&r->evConsumed, hipEventDisableTiming), "hipEventCreate")) return 1;
+    if (!r->evConsumed && !hip_ok(hipEventCreateWithFlags(&r->evConsumed, order_event_flags()), "hipEventCreate")) return 1;
     if (!hip_ok(hipEventRecord(r->evConsumed, s), "hipEventRecord")) return 1;
     r->consumedPending = true;
     return 0;
