@@ -749,7 +749,8 @@ def roofline_nrc(ctx, renderer, stream, W, H):
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
             pmc_txt = "profiles/" + name
             break
-    roof = {"bound": "mfma (nominal: the kernel is bound by the hash-grid gathers, 128 corner loads per query)", "kernel": "k_nrc_infer (hash-grid encoding + fused 64-wide MLP, v_mfma_f32_32x32x16_bf16)",
+    roof = {"bound": "mfma (nominal: a wave of the kernel spends a third of its cycles on the level-table copies and their barriers, a fifth on the hash features: profiles/r06_nrc_infer_profile.json)",
+            "kernel": "k_nrc_infer_staged (hash-grid levels staged through LDS + fused 64-wide MLP, v_mfma_f32_32x32x16_bf16)",
             "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 5),
             "flop_per_query": flop_per_query, "queries_per_frame": queries, "launches_per_frame": round(infer_calls / n, 2), "avg_launch_ms": round(launch_ms, 4),
             "infer_ms_per_frame": round(infer_ms / n, 4),

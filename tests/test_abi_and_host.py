@@ -237,11 +237,11 @@ def test_counter_files_carry_the_hash_of_the_sources_they_were_measured_on(tmp_p
     assert bench._pmc_provenance("profiles/old.json")["pmc_matches_sources"] is None
     assert bench._pmc_provenance(None) == {"pmc_head": None, "pmc_sources_sha16": None, "pmc_matches_sources": None}
     # every BASELINE configuration has a counter-file slot, newest round first
-    assert set(bench.PMC_FILES) == {1, 2, 4, "animate"} and bench.PMC_FILES[2][0].startswith("r05_")
+    assert set(bench.PMC_FILES) == {1, 2, 4, "animate"} and bench.PMC_FILES[2][0].startswith("r06_")
 
 
 def test_the_committed_bench_line_keeps_the_driver_contract():
-    """profiles/r05_bench_default.json is what `python bench.py` printed on an MI355X at the end of the round: ONE JSON line with the
+    """profiles/r06_bench_default.json is what `python bench.py` printed on an MI355X at the end of the round: ONE JSON line with the
     fields the driver reads, the roofline and cpu_baseline objects of the measurement section, every other BASELINE configuration inside
     it, and counter figures that belong to the kernel sources of this tree."""
     import json
@@ -250,7 +250,7 @@ def test_the_committed_bench_line_keeps_the_driver_contract():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    lines = [ln for ln in open(os.path.join(root, "profiles", "r05_bench_default.json")).read().splitlines() if ln.strip()]
+    lines = [ln for ln in open(os.path.join(root, "profiles", "r06_bench_default.json")).read().splitlines() if ln.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -259,15 +259,18 @@ def test_the_committed_bench_line_keeps_the_driver_contract():
     assert d["unit"] == "Mpaths/s" and "workload" in d["config"] and "configs[2]" in d["config"]["workload"]
     assert abs(d["value"] - d["config"]["width"] * d["config"]["height"] / d["ms_per_step"] / 1e3) < 0.01 * d["value"]      # value and ms_per_step are one measurement
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_bytes_per_launch"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_bytes_per_launch", "frac_nominal_hbm", "frac_hbm_counter"):
         assert key in r, key
+    assert abs(r["frac_hbm_counter"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3      # counter bytes over the live launch time
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1
     assert r["pmc_matches_sources"] is True and r["run_sources_sha16"] == bench.sources_sha16()     # the counters are this tree's
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
-    assert set(d["other_configs"]) == {"configs[1]", "configs[3]", "configs[4]", "configs[2] --animate"}
+    assert set(d["other_configs"]) == {"configs[1]", "configs[3]", "configs[4]", "configs[2] --animate", "configs[2] --cluttered"}
+    assert d["gpu_bvh_build_ms"]["warm_ms"] > 0 and c["gpu_bvh_build_ms"] == d["gpu_bvh_build_ms"] and c["builds"]["parity"]["bvh_build_s"] > 0      # GPU LBVH beside the CPU SAH build
+    assert d["config"]["light_inst_distribution"].startswith("cached")
     for name, o in d["other_configs"].items():
         assert "error" not in o and o["value"] > 0 and o["ms_per_step"] > 0, name
     assert d["mse"]["ref_spp"] == 65536 and d["mse"]["mse"] > 0
