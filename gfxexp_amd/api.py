@@ -157,7 +157,7 @@ EXCHANGE_STRIPS, EXCHANGE_ALLREDUCE_SUM_U32, EXCHANGE_GATHER_BANDS, EXCHANGE_GAT
 (STEP_RESTIR_PASS, STEP_PT_PASS, STEP_EXCHANGE_STRIPS, STEP_ALLREDUCE_CELL_ACCESSES, STEP_GATHER_BANDS, STEP_PREV_GBUFFER_RELEASED,
  STEP_WAIT_GBUFFER_STRIPS, STEP_WAIT_PREVIOUS_GATHER, STEP_WAIT_SEAM_STRIPS) = range(9)
 LANE_MAIN, LANE_GBUFFER, LANE_GATHER, LANE_SEAM, NUM_LANES = 0, 1, 2, 3, 4
-BUF_GBUFFERS, BUF_RESERVOIRS, BUF_SAMPLE_VISIBILITY = 1, 2, 4
+BUF_GBUFFERS, BUF_RESERVOIRS, BUF_SAMPLE_VISIBILITY, BUF_RNG = 1, 2, 4, 8
 
 
 def frame_program(cfg, strip_mode, max_motion_rows, new_sequence, last_res, last_base, unbiased):

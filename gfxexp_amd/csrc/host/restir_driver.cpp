@@ -72,6 +72,7 @@ struct gfxh_restir {
     // Off by default: on one GPU with a transport of the same shape the split costs more than the exchange it hides (the pass is ~50 us at
     // eight bands: profiles/r06_band_host_overhead.json, r06_experiments.txt 2)
     bool seamStripsPending = false, seamFirst = false;
+    int stripMode = 3;          // GFX_STRIP_MODE = 1 | 2 | 3 (gfxh_restir_frame_program): 3 = intermediate spatial passes recomputed on their halo (the default)
     bool asyncGather = false, gatherPending = false, gbStripsPending = false;
     bool stripsOnGbLane = true;   // GFX_GB_STRIPS_ON_MAIN=1 (A/B runs): the G-buffer strips on the caller's stream ahead of the candidate pass, as rounds 2-5 issued them
 };
@@ -225,6 +226,9 @@ int gfxh_restir_create(gfx_ctx* ctx, const gfxh_restir_config* cfg, gfxh_restir*
         r->stripsOnGbLane = !(m && m[0] == '1');
         const char* sf = std::getenv("GFX_SEAM_FIRST");
         r->seamFirst = sf && sf[0] == '1';
+        const char* sm = std::getenv("GFX_STRIP_MODE");
+        if (sm && sm[0] >= '1' && sm[0] <= '3') r->stripMode = sm[0] - '0';
+        if (r->seamFirst) r->stripMode = 2;
         if (!hip_ok(hipStreamCreateWithFlags(&r->gbStream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
             !hip_ok(hipEventCreateWithFlags(&r->evPrevRead, order_event_flags()), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&r->evGbuffer, order_event_flags()), "hipEventCreate") ||
@@ -321,7 +325,7 @@ int gfxh_restir_check_partition(const gfxh_restir_config* cfgp, uint32_t world, 
     for (int newSequence = 0; newSequence < 2; ++newSequence) {
         gfxh_frame_step steps[64];
         uint32_t n = 0, a = 0, c = 0;
-        (void)gfxh_restir_frame_program(&cfg, 1, maxMotionRows, newSequence, 1, 0, unbiased, steps, 64, &n, &a, &c);
+        (void)gfxh_restir_frame_program(&cfg, 3, maxMotionRows, newSequence, 1, 0, unbiased, steps, 64, &n, &a, &c);   // (mode 3 has the tallest strips)
         for (uint32_t k = 0; k < n; ++k) if (steps[k].op == GFXH_STEP_EXCHANGE_STRIPS) tallest = std::max(tallest, steps[k].exchangeRows);
     }
     if (tallest > minBand) {
@@ -340,7 +344,7 @@ static uint32_t tallest_strip(const gfxh_restir_config* cfgp, uint32_t firstBand
     for (int newSequence = 0; newSequence < 2; ++newSequence) {
         gfxh_frame_step steps[64];
         uint32_t n = 0, a = 0, c = 0;
-        (void)gfxh_restir_frame_program(&cfg, 1, maxMotionRows, newSequence, 1, 0, unbiased, steps, 64, &n, &a, &c);
+        (void)gfxh_restir_frame_program(&cfg, 3, maxMotionRows, newSequence, 1, 0, unbiased, steps, 64, &n, &a, &c);   // (mode 3 has the tallest strips)
         for (uint32_t k = 0; k < n; ++k) if (steps[k].op == GFXH_STEP_EXCHANGE_STRIPS) tallest = std::max(tallest, steps[k].exchangeRows);
     }
     return tallest;
@@ -527,15 +531,20 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
     const gfxh_restir_config& cfg = *cfgp;
     const bool whole = cfg.rowBegin == 0 && cfg.rowEnd == 0;
     const bool strips = stripMode && !whole;
-    const bool seamFirst = strips && stripMode >= 2;
+    const bool seamFirst = strips && stripMode == 2;
     const uint32_t passes = cfg.enableSpatialReuse ? cfg.numSpatialReusePasses : 0;
     const uint32_t radiusRows = static_cast<uint32_t>(std::ceil(cfg.spatialNeighborRadius));
     gfxh_band_plan plan;
     gfxh_band_plan_compute(cfg.height, whole ? 0 : cfg.rowBegin, whole ? cfg.height : cfg.rowEnd, radiusRows, passes, 0, &plan);
-    if (strips) {   // every pass on the band only
+    // stripMode 3: the spatial passes that another pass follows are RECOMPUTED on a halo that shrinks by `radius` rows per pass (the plan's
+    // spatialRows), so only the first of them has an exchange in front of it -- radius x passes rows of the candidate pass's reservoirs and of
+    // the pixel RNG states the halo rows' passes draw from -- and the reservoir exchanges between the spatial passes, which sit on the frame's
+    // critical path around a pass of ~50 us, are gone.  A halo row's pass is the owner's computation on the owner's inputs: same bits.
+    const bool recompute = strips && stripMode == 3 && passes >= 2;
+    if (strips) {   // every pass on the band only (mode 3: the spatial passes but the last one also on their halo)
         plan.gbufferRows[0] = plan.initialRows[0] = plan.shadingRows[0] = plan.bandBegin;
         plan.gbufferRows[1] = plan.initialRows[1] = plan.shadingRows[1] = plan.bandEnd;
-        for (int i = 0; i < 8; ++i) { plan.spatialRows[i][0] = plan.bandBegin; plan.spatialRows[i][1] = plan.bandEnd; }
+        if (!recompute) for (int i = 0; i < 8; ++i) { plan.spatialRows[i][0] = plan.bandBegin; plan.spatialRows[i][1] = plan.bandEnd; }
     }
     uint32_t n = 0;
     int tooTall = 0;
@@ -613,7 +622,7 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
         // the G-buffer lane right behind the pass: the candidate + temporal pass of THIS frame reads no neighbour's current G-buffer
         // (the temporal reprojection reads the PREVIOUS frame's, whose strips arrived a frame ago), so only the first spatial pass
         // -- or, without one, the end of the frame -- waits for them
-        bool gbStripsInFlight = exchange(std::max(cfg.enableSpatialReuse ? radiusRows : 0u, cfg.enableTemporalReuse ? motion : 0u), GFXH_BUF_GBUFFERS, 0, GFXH_LANE_GBUFFER);
+        bool gbStripsInFlight = exchange(std::max(cfg.enableSpatialReuse ? radiusRows * (recompute ? passes : 1u) : 0u, cfg.enableTemporalReuse ? motion : 0u), GFXH_BUF_GBUFFERS, 0, GFXH_LANE_GBUFFER);
         uint32_t entry = GFX_RESTIR_INITIAL_RIS;                                               // :2378-2384
         if (cfg.enableTemporalReuse && !newSequence)
             entry = useUnbiasedEstimator ? GFX_RESTIR_INITIAL_AND_TEMPORAL_UNBIASED : GFX_RESTIR_INITIAL_AND_TEMPORAL_BIASED;
@@ -627,6 +636,7 @@ int gfxh_restir_frame_program(const gfxh_restir_config* cfgp, int stripMode, uin
             for (uint32_t i = 0; i < cfg.numSpatialReusePasses; ++i) {
                 // strip mode: the reservoirs this pass resamples from, radius rows either side of the band
                 if (seamStripsInFlight) { push(GFXH_STEP_WAIT_SEAM_STRIPS, 0, 0, 0); seamStripsInFlight = false; }
+                else if (recompute) { if (i == 0) exchange(radiusRows * passes, GFXH_BUF_RESERVOIRS | GFXH_BUF_RNG, currentReservoirIndex); }
                 else exchange(radiusRows, GFXH_BUF_RESERVOIRS, currentReservoirIndex);
                 if (gbStripsInFlight) { push(GFXH_STEP_WAIT_GBUFFER_STRIPS, 0, 0, 0); gbStripsInFlight = false; }
                 baseIndex = base0 + cfg.numSpatialNeighbors * i;
@@ -693,6 +703,7 @@ int gfxh_frame_step_exchange_desc(const gfxh_restir_config* cfg, const gfxh_fram
         if (st->buffers & GFXH_BUF_GBUFFERS) { add(sp->gbuffer0[bufferIndex], 16, 1); add(sp->gbuffer2[bufferIndex], 16, 1); add(sp->gbuffer3[bufferIndex], 16, 1); }
         if (st->buffers & GFXH_BUF_SAMPLE_VISIBILITY) add(sp->sampleVisibilityBuffer[bufferIndex], 4, 1);
         if (st->buffers & GFXH_BUF_RESERVOIRS) { add(sp->reservoirBuffer[st->reservoirIndex], 16, 3); add(sp->reservoirInfoBuffer[st->reservoirIndex], 8, 1); }
+        if (st->buffers & GFXH_BUF_RNG) add(sp->rngBuffer, 8, 1);
         return 0;
     case GFXH_STEP_ALLREDUCE_CELL_ACCESSES:
         if (!regir) return 1;
@@ -757,7 +768,7 @@ int gfxh_restir_render_frame(gfxh_restir* r, void* stream) {
     }
     gfxh_frame_step steps[64];
     uint32_t numSteps = 0, newLastRes = 0, newLastBase = 0;
-    if (gfxh_restir_frame_program(&cfg, strips ? (r->seamFirst && r->pipelineFrames ? 2 : 1) : 0, r->maxMotionRows, newSequence ? 1 : 0, r->lastReservoirIndex, r->lastSpatialNeighborBaseIndex,
+    if (gfxh_restir_frame_program(&cfg, strips ? (r->stripMode == 2 && !r->pipelineFrames ? 1 : r->stripMode) : 0, r->maxMotionRows, newSequence ? 1 : 0, r->lastReservoirIndex, r->lastSpatialNeighborBaseIndex,
                                   useUnbiased, steps, 64, &numSteps, &newLastRes, &newLastBase)) {
         g_driverError = "gfxh_restir_render_frame: the exchange strip is taller than the band (fewer ranks or a smaller radius; "
                         "gfxh_restir_check_partition decides this for all ranks at once)";

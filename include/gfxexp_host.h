@@ -322,7 +322,8 @@ enum gfxh_step_op {
     GFXH_STEP_WAIT_PREVIOUS_GATHER = 7,   /* the next pass overwrites the HDR band the previous frame's gather (lane GATHER) sends */
     GFXH_STEP_WAIT_SEAM_STRIPS = 8        /* the next pass reads the strips the exchange on lane SEAM brings: MAIN waits for it */
 };
-enum gfxh_exchange_buffers { GFXH_BUF_GBUFFERS = 1 /* GBuffer 0, 2, 3 of the frame */, GFXH_BUF_RESERVOIRS = 2 /* + ReservoirInfo */, GFXH_BUF_SAMPLE_VISIBILITY = 4 };
+enum gfxh_exchange_buffers { GFXH_BUF_GBUFFERS = 1 /* GBuffer 0, 2, 3 of the frame */, GFXH_BUF_RESERVOIRS = 2 /* + ReservoirInfo */, GFXH_BUF_SAMPLE_VISIBILITY = 4,
+                             GFXH_BUF_RNG = 8 /* the pixels' PCG32 states (stripMode 3: the halo rows' passes draw from them) */ };
 typedef struct gfxh_frame_step {
     uint32_t op, pass;
     uint32_t rowBegin, rowEnd;                                 /* 0, 0 = all rows */
@@ -331,9 +332,11 @@ typedef struct gfxh_frame_step {
     uint32_t lane;                                             /* enum gfxh_lane the step is issued on (a program run in list order, as the CPU tests do, is one valid schedule) */
     uint32_t gapBegin, gapEnd;                                 /* a pass over rows [rowBegin, gapBegin) + [gapEnd, rowEnd) (gfx_restir_launch_rows_gap); 0, 0 = no gap */
 } gfxh_frame_step;
-/* stripMode: 0 = whole frame / halo recompute, 1 = strip exchange with every pass over the band in one launch, 2 = 1 + seam rows first
- * (lane SEAM) for the spatial passes that are followed by another pass.  gfxh_restir_render_frame runs 1; GFX_SEAM_FIRST=1 makes it run 2 (measured
- * slower on one GPU with a transport of the same shape: profiles/r06_band_host_overhead.json). */
+/* stripMode: 0 = whole frame / halo recompute; 1 = strip exchange, every pass over the band in one launch, reservoirs exchanged before every
+ * spatial pass; 2 = 1 + seam rows first (lane SEAM) for the spatial passes that another pass follows (GFX_SEAM_FIRST=1; measured slower);
+ * 3 = the spatial passes that another pass follows are recomputed on a halo that shrinks by `radius` rows per pass: ONE reservoir exchange per
+ * frame (radius x passes rows of reservoirs, infos and pixel RNG states behind the candidate pass; G-buffer strips as tall) instead of one per
+ * spatial pass -- what gfxh_restir_render_frame runs (GFX_STRIP_MODE=1|2|3); the same frames bit for bit in every mode. */
 int gfxh_restir_frame_program(const gfxh_restir_config* cfg, int stripMode, uint32_t maxMotionRows, int newSequence,
                               uint32_t lastReservoirIndex, uint32_t lastSpatialNeighborBaseIndex, uint32_t useUnbiasedEstimator,
                               gfxh_frame_step* steps, uint32_t capacity, uint32_t* numSteps, uint32_t* newLastReservoirIndex,

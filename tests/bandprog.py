@@ -24,7 +24,7 @@ class OracleBandRenderer:
         self.prev_cam = None
         self.exchange = None
         self.max_motion_rows = 0
-        self.strip_mode = 2
+        self.strip_mode = 3           # what gfxh_restir_render_frame runs by default (GFX_STRIP_MODE)
         self.log = []
 
     def set_exchange(self, fn, max_motion_rows=0):

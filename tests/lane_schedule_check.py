@@ -10,7 +10,9 @@ transfer executes on its stream:
               next frame, with 40 / 150 microseconds of injected latency per strip exchange / gather (so that a missing wait reads rows
               that have not arrived)
     lanes     + the seam rows of a spatial pass that another pass follows first, their exchange on the seam lane underneath the interior
-              rows (the schedule gfxh_restir_render_frame runs by default)
+              rows (stripMode 2, GFX_SEAM_FIRST=1)
+    recompute the lanes with stripMode 3: the spatial pass that another pass follows recomputed on its halo, ONE reservoir exchange per frame
+              (reservoirs + pixel RNG states, radius x passes rows) -- the schedule gfxh_restir_render_frame runs by default
 Every buffer a later pass or frame reads (G-buffer halves, reservoirs, infos, the RNG states, the HDR frame) must come out bit for bit
 the same: a missing or misplaced event between the lanes shows up as a difference."""
 import ctypes as C
@@ -29,11 +31,12 @@ def render(api, ctx, cfg, rank, world, H, frames, schedule, mirror, ids, moving)
     os.environ.pop("GFX_SERIAL_FRAMES", None)
     os.environ["GFX_GB_STRIPS_ON_MAIN"] = "0"
     os.environ["GFX_SEAM_FIRST"] = "1" if schedule == "lanes" else "0"
+    os.environ["GFX_STRIP_MODE"] = "3" if schedule == "recompute" else "1"        # (GFX_SEAM_FIRST=1 makes it 2)
     if schedule == "serial":
         os.environ["GFX_SERIAL_FRAMES"] = "1"
     if schedule == "round5":
         os.environ["GFX_GB_STRIPS_ON_MAIN"] = "1"
-    injected = schedule in ("lanes", "noseam")
+    injected = schedule in ("lanes", "noseam", "recompute")
     mirror.rccl_mirror_set_latency_us(C.c_float(40.0 if injected else 0.0), C.c_float(150.0 if injected else 0.0))
     r = api.RestirRenderer(ctx, cfg)
     ex = api.RcclExchange(ids, rank, world, H)
@@ -79,7 +82,7 @@ def main():
         cfg.rowBegin, cfg.rowEnd = api.band_rows(H, world, rank)
         ids = api.RcclExchange.unique_ids(api.NUM_LANES)
         want = render(api, ctx, cfg, rank, world, H, frames, "serial", mirror, ids, moving)
-        for schedule in ("round5", "noseam", "lanes"):
+        for schedule in ("round5", "noseam", "lanes", "recompute"):
             got = render(api, ctx, cfg, rank, world, H, frames, schedule, mirror, ids, moving)
             for name in want:
                 if not np.array_equal(want[name], got[name]):

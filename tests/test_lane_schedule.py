@@ -59,6 +59,8 @@ def _accesses(st, frame, band, motion):
             names.append("gbuffer%d" % h)
         if st.buffers & api.BUF_RESERVOIRS:
             names.append("reservoir%d" % st.reservoirIndex)
+        if st.buffers & api.BUF_RNG:
+            names.append("rng")
         for name in names:
             out += [(name, r, "r") for r in send] + [(name, r, "w") for r in recv]
     elif st.op == api.STEP_GATHER_BANDS:
@@ -149,8 +151,8 @@ def _check(cfg, motion, strip_mode):
     return nodes, problems
 
 
-@pytest.mark.parametrize("renderer,motion,strip_mode", [(api.RENDERER_BIASED, 0, 2), (api.RENDERER_BIASED, 24, 2), (api.RENDERER_BIASED, 0, 1),
-                                                       (api.RENDERER_UNBIASED, 0, 2), (api.RENDERER_UNBIASED, 16, 2)])
+@pytest.mark.parametrize("renderer,motion,strip_mode", [(api.RENDERER_BIASED, 0, 3), (api.RENDERER_BIASED, 24, 3), (api.RENDERER_BIASED, 0, 2), (api.RENDERER_BIASED, 24, 2),
+                                                       (api.RENDERER_BIASED, 0, 1), (api.RENDERER_UNBIASED, 0, 3), (api.RENDERER_UNBIASED, 16, 3)])
 def test_every_conflicting_access_of_three_frames_is_ordered(built_lib, renderer, motion, strip_mode):
     cfg = api.RestirRenderer.default_config(W, H, renderer)
     nodes, problems = _check(cfg, motion, strip_mode)
@@ -159,6 +161,8 @@ def test_every_conflicting_access_of_three_frames_is_ordered(built_lib, renderer
     assert {api.LANE_MAIN, api.LANE_GBUFFER, api.LANE_GATHER} <= lanes
     if renderer == api.RENDERER_BIASED and strip_mode == 2:
         assert api.LANE_SEAM in lanes          # the first of the two biased spatial passes runs its seam rows first
+    if renderer == api.RENDERER_BIASED and strip_mode == 3:
+        assert sum(1 for _, _, st in nodes if st.op == api.STEP_EXCHANGE_STRIPS and st.lane == api.LANE_MAIN) == 4 * (2 if motion else 1)   # one reservoir exchange per frame (+ the motion rows)
 
 
 def test_the_checker_sees_a_missing_wait(built_lib, monkeypatch):
@@ -173,6 +177,29 @@ def test_the_checker_sees_a_missing_wait(built_lib, monkeypatch):
     monkeypatch.setattr(api, "frame_program", without_wait)
     _, problems = _check(cfg, 0, 2)
     assert problems and any("gbuffer" in p for p in problems)
+
+
+def test_recomputed_passes_leave_one_reservoir_exchange_per_frame(built_lib):
+    """stripMode 3 (what the driver runs): the first of the two biased spatial passes runs on the band +- radius rows, fed by ONE exchange of
+    radius x 2 rows of reservoirs + infos + pixel RNG states behind the candidate pass (G-buffer strips as tall, on the G-buffer lane); the
+    last pass + shading run on the band; nothing is exchanged between the spatial passes."""
+    cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_BIASED)
+    b, e = api.band_rows(H, WORLD, 3)
+    cfg.rowBegin, cfg.rowEnd = b, e
+    steps, _, _ = api.frame_program(cfg, 3, 0, False, 1, 0, False)
+    xs = [s for s in steps if s.op == api.STEP_EXCHANGE_STRIPS]
+    assert [(s.lane, s.exchangeRows, s.buffers) for s in xs] == [(api.LANE_GBUFFER, 2 * RADIUS, api.BUF_GBUFFERS), (api.LANE_MAIN, 2 * RADIUS, api.BUF_RESERVOIRS | api.BUF_RNG)]
+    passes = [(s.pass_, s.rowBegin, s.rowEnd) for s in steps if s.op == api.STEP_RESTIR_PASS]
+    assert passes == [(api.PASS_SETUP_GBUFFERS, b, e), (api.PASS_INITIAL_TEMPORAL_BIASED, b, e), (api.PASS_SPATIAL_BIASED, b - RADIUS, e + RADIUS),
+                      (api.PASS_SPATIAL_BIASED_AND_SHADING, b, e)]
+    order = [s.op for s in steps]
+    assert order.index(api.STEP_WAIT_GBUFFER_STRIPS) < [i for i, s in enumerate(steps) if s.op == api.STEP_RESTIR_PASS and s.pass_ == api.PASS_SPATIAL_BIASED][0]
+    # the unbiased estimator's single pass needs no halo: mode 3 is mode 1 there
+    cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_UNBIASED)
+    cfg.rowBegin, cfg.rowEnd = b, e
+    a = [(s.op, s.pass_, s.rowBegin, s.rowEnd, s.exchangeRows, s.buffers, s.lane) for s in api.frame_program(cfg, 3, 0, False, 1, 0, True)[0]]
+    c = [(s.op, s.pass_, s.rowBegin, s.rowEnd, s.exchangeRows, s.buffers, s.lane) for s in api.frame_program(cfg, 1, 0, False, 1, 0, True)[0]]
+    assert a == c
 
 
 def test_seam_rows_go_first_and_cover_what_the_neighbours_read(built_lib):

@@ -11,7 +11,8 @@
             0 / 30 / 60 / 120 and four schedules: `round5` = every exchange on the frame's stream in program order (G-buffer strips
             ahead of the candidate pass, the gather synchronous), `gb_lane` = the G-buffer strips on the G-buffer stream behind the
             pipelined pass, `lanes_noseam` = that + the gather on its own stream underneath the next frame, `lanes` = that + the seam
-            rows of the first biased spatial pass ahead of its interior, their exchange on the seam lane (what bench.py --gpus N runs).
+            rows of the first biased spatial pass ahead of its interior, their exchange on the seam lane, `recompute` = lanes_noseam with
+            stripMode 3 (the first biased spatial pass recomputed on its halo: one reservoir exchange per frame; what bench.py --gpus N runs).
 usage: band_host_overhead.py host|latency [--config4] [--bands 8] [--steps 60]"""
 import ctypes as C
 import json
@@ -100,9 +101,10 @@ def main():
     stub = os.path.join(ROOT, "tests", "native", "librccl_mirror.so")   # (the recording stub moves its all-gather on the host: device pointers over PCIe)
     os.environ["GFX_RCCL_LIBRARY"] = stub          # before libgfxexp loads librccl
     if mode == "latency":
-        sched = arg("--schedule", "lanes")
+        sched = arg("--schedule", "recompute")
         os.environ["GFX_GB_STRIPS_ON_MAIN"] = "1" if sched == "round5" else "0"
         os.environ["GFX_SEAM_FIRST"] = "1" if sched == "lanes" else "0"
+        os.environ["GFX_STRIP_MODE"] = "3" if sched == "recompute" else "1"
     import torch
     from gfxexp_amd import api, scenes, tilesplit
     ctx = api.Context(0)
@@ -147,12 +149,12 @@ def main():
     else:
         mirror = C.CDLL(stub)
         mirror.rccl_mirror_set_latency_us.argtypes = [C.c_float, C.c_float]
-        schedule = arg("--schedule", "lanes")
+        schedule = arg("--schedule", "recompute")
         gather_us = float(arg("--gather-us", "300"))
         r, cfg = make_renderer(api, scenes, ctx, W, H, band, config4)
         ex = api.RcclExchange(ids, rank, nb, H)
         ex.install(r, 0)
-        r.set_async_gather(schedule in ("lanes", "lanes_noseam"))
+        r.set_async_gather(schedule in ("lanes", "lanes_noseam", "recompute"))
         rows = {}
         for lat in (0.0, 30.0, 60.0, 120.0):
             mirror.rccl_mirror_set_latency_us(C.c_float(lat), C.c_float(gather_us if lat > 0 else 0.0))

@@ -75,8 +75,8 @@ for step in "$@"; do
     ptregen)   timeout 600 python tools/pt_regen_diag.py > $OUT/pt_regen.jsonl 2> $OUT/pt_regen.err; cat $OUT/pt_regen.jsonl ;;
     bandhost)  timeout 300 python tools/band_host_overhead.py host > $OUT/band_host.json 2> $OUT/band_host.err; cat $OUT/band_host.json
                : > $OUT/band_latency.jsonl
-               for s in round5 gb_lane lanes_noseam lanes; do timeout 300 python tools/band_host_overhead.py latency --schedule $s >> $OUT/band_latency.jsonl 2>> $OUT/band_host.err; done
-               for s in round5 lanes_noseam; do timeout 300 python tools/band_host_overhead.py latency --schedule $s --config4 >> $OUT/band_latency.jsonl 2>> $OUT/band_host.err; done
+               for s in round5 gb_lane lanes_noseam lanes recompute; do timeout 300 python tools/band_host_overhead.py latency --schedule $s >> $OUT/band_latency.jsonl 2>> $OUT/band_host.err; done
+               for s in round5 recompute; do timeout 300 python tools/band_host_overhead.py latency --schedule $s --config4 >> $OUT/band_latency.jsonl 2>> $OUT/band_host.err; done
                cat $OUT/band_latency.jsonl ;;
     pmca)      BFLAGS="--animate" pmc_passes pmc_animate GFX_NOOP=1
                python profiles/make_pmc_json.py --command "$B --animate --no-roofline" $OUT/pmc_animate > $OUT/${ROUND}_pmc_animate.json; head -c 400 $OUT/${ROUND}_pmc_animate.json ;;
