@@ -54,6 +54,7 @@ def fake_static_params(api):
         s.gbuffer0[i], s.gbuffer1[i], s.gbuffer2[i], s.gbuffer3[i] = take(16 * n), take(8 * n), take(16 * n), take(16 * n)
         s.reservoirBuffer[i], s.reservoirInfoBuffer[i], s.sampleVisibilityBuffer[i] = take(48 * n), take(8 * n), take(4 * n)
     s.beautyAccumBuffer = take(16 * n)
+    s.rngBuffer = take(8 * n)
     return s
 
 
@@ -104,7 +105,8 @@ def cpu_plan(api, L, stub):
                 cfg = api.RestirRenderer.default_config(W, H, renderer)
                 cfg.rowBegin, cfg.rowEnd = bands[rank]
                 unbiased = renderer in (api.RENDERER_UNBIASED, api.RENDERER_REARCH_UNBIASED)
-                steps, _, _ = api.frame_program(cfg, True, motion, new_sequence, 1, 0, unbiased)
+                # stripMode 3 (what the driver runs: one reservoir exchange of radius x passes rows + RNG states) and 1 (one per spatial pass)
+                steps = api.frame_program(cfg, 3, motion, new_sequence, 1, 0, unbiased)[0] + api.frame_program(cfg, 1, motion, new_sequence, 1, 0, unbiased)[0]
                 log = []
                 for k, st in enumerate(steps):
                     if st.op == api.STEP_EXCHANGE_STRIPS:

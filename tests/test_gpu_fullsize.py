@@ -615,8 +615,8 @@ def test_eight_band_strip_exchange_at_the_bench_configuration(built_lib, config)
         util.assert_same_bits(f"band {rank} gathered HDR frame", got, want)
     assert np.isfinite(want).all() and want[..., :3].mean() > 1e-3
     kinds = [k for k, _ in ex.calls[0]]
-    # G-buffer strips + one reservoir strip per spatial pass (2 biased, 1 unbiased) per frame; one HDR gather per frame
-    assert kinds.count(api.EXCHANGE_STRIPS) == frames * (2 if unbiased else 3) and kinds.count(api.EXCHANGE_GATHER_BANDS) == frames
+    # G-buffer strips + ONE reservoir exchange per frame: the unbiased estimator has one spatial pass, the biased one recomputes its first on the halo (stripMode 3)
+    assert kinds.count(api.EXCHANGE_STRIPS) == frames * 2 and kinds.count(api.EXCHANGE_GATHER_BANDS) == frames
 
 
 def test_regir_at_the_reference_grid_size_matches_the_oracle(built_lib):
