@@ -167,6 +167,8 @@ def parse():
     ap.add_argument("--other-configs", type=int, default=1,
                     help="default run only (configs[2], static, textured, one GPU): afterwards measure configs[1], [3], [4] and --animate for --other-steps "
                          "steps each (5 warm-up frames) and report them inside the one JSON line as `other_configs` (0 = skip)")
+    ap.add_argument("--spawn-timeout", type=float, default=420.0, help="N > 1 without a launcher: seconds the ranks this command starts may take before they are killed")
+    ap.add_argument("--rank-timeout", type=float, default=300.0, help="N > 1: seconds a rank may spend between the start of its warm-up and the end of its timed frames before it reports where it is and exits (0 = no limit)")
     ap.add_argument("--other-steps", type=int, default=20)
     ap.add_argument("--other-timeout", type=float, default=240.0, help="seconds each other-configs child process may take before it is killed (the headline stands on its own)")
     return ap.parse_args()
@@ -200,16 +202,50 @@ ANIMATE_MAX_MOTION_ROWS = 24
 
 def _respawn_under_torchrun(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU, rendezvous on
-    127.0.0.1) and become that launcher, so the command works in either shape."""
+    127.0.0.1), so the command works in either shape.  The ranks run in a process group of their own with a time limit; when they fail
+    or outlast it with the default transport (gfxh_rccl_exchange on its lanes), ONE more attempt is made over the most conservative
+    path -- torch.distributed's own nccl backend, every exchange and the band gather on the frame's stream -- and its line says so."""
+    import signal
     import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    import subprocess
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: the only mode the host driver supports (RCCL across processes)
+
+    def attempt(extra, limit):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, _ = child.communicate(timeout=limit)
+            return child.returncode, out
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)            # the group this call started, nothing else
+            except ProcessLookupError:
+                pass
+            out, _ = child.communicate()
+            return -9, out
+
     sys.stdout.flush()
-    os.execv(sys.executable, cmd)
+    rc, out = attempt([], args.spawn_timeout)
+    line = next((l for l in reversed((out or "").splitlines()) if l.startswith("{")), None)
+    if (rc != 0 or line is None) and args.exchange == "auto" and not args.sync_gather:
+        sys.stderr.write("bench: the %d ranks %s with the default transport; one more attempt with --exchange torch --sync-gather\n"
+                         % (args.gpus, "were killed after %.0f s" % args.spawn_timeout if rc == -9 else "exited with code %d" % rc))
+        rc, out = attempt(["--exchange", "torch", "--sync-gather"], args.spawn_timeout)
+        line = next((l for l in reversed((out or "").splitlines()) if l.startswith("{")), None)
+        if rc == 0 and line is not None:
+            r = json.loads(line)
+            r["config"]["fallback"] = "the default transport (gfxh_rccl_exchange on its lanes) did not finish; this line is the second attempt: --exchange torch --sync-gather"
+            line = json.dumps(r)
+    if line is not None:
+        print(line)
+    else:
+        sys.stdout.write(out or "")
+    sys.stdout.flush()
+    raise SystemExit(0 if (rc == 0 and line is not None) else (rc if rc > 0 else 1))
 
 
 OTHER_CONFIGS = (("configs[1]", ["--config", "1"]), ("configs[3]", ["--config", "3"]), ("configs[4]", ["--config", "4"]), ("configs[2] --animate", ["--animate"]),
@@ -362,6 +398,20 @@ def run_config(args, rank, local_rank, world, dist):
 
     exchange = None
     transport = None
+    stage = ["setup"]
+    watchdog = None
+    if world > 1 and args.rank_timeout > 0:
+        # a collective that never completes (a transport that deadlocks on hardware nobody could test on) must cost the run minutes and
+        # leave a reason, not hang the node: the rank says where it is and exits, and the launcher ends the others
+        import threading
+
+        def expired():
+            sys.stderr.write("bench: rank %d did not finish within %.0f s (--rank-timeout); it is in: %s; transport: %s\n" % (rank, args.rank_timeout, stage[0], transport))
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(args.rank_timeout, expired)
+        watchdog.daemon = True
+        watchdog.start()
     if world > 1:
         # strip exchange: every pass runs on the band only; the rows the next pass reads across the seams travel between the passes --
         # the G-buffer strips on the G-buffer lane behind the pipelined G-buffer pass, the reservoir strips on the frame's stream before
@@ -371,6 +421,7 @@ def run_config(args, rank, local_rank, world, dist):
         L.gfxh_rccl_last_error.restype = C.c_char_p
         use_rccl = args.exchange in ("auto", "rccl")
         ids = None
+        stage[0] = "the transport's setup (ncclUniqueId broadcast, ncclCommInitRank per lane)"
         if use_rccl:
             # rank 0 draws one ncclUniqueId per lane (this also answers whether librccl loads here); the verdict and the ids go to every
             # rank over the torch process group, so the ranks choose the same transport before anyone enters ncclCommInitRank
@@ -425,6 +476,7 @@ def run_config(args, rank, local_rank, world, dist):
             return ex
         transport = "gfxh_rccl_exchange (C++, %d communicators)" % api.NUM_LANES if use_rccl else "tilesplit.StripExchange (torch.distributed)"
         exchange = install(renderer, bands)
+        stage[0] = "band balancing (untimed)"
         # Equal rows are not equal work (sky rows are cheap).  Each round: time this rank's band over a few frames, all-gather
         # the times, cut the frame where gfxh_balance_bands says (the same call with the same numbers on every rank) and start
         # over with band renderers for the new rows -- all inside the untimed warm-up; the timed frames use the final partition.
@@ -473,9 +525,11 @@ def run_config(args, rank, local_rank, world, dist):
         torch.cuda.synchronize()
 
     # frame 0 starts the sequence (no temporal reuse); it is part of the untimed warm-up
+    stage[0] = "warm-up frames"
     for _ in range(max(1, args.warmup)):
         frame()
     barrier()
+    stage[0] = "timed frames"
     t_start = time.perf_counter()
     for _ in range(args.steps):
         frame()
@@ -487,6 +541,8 @@ def run_config(args, rank, local_rank, world, dist):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if watchdog is not None:
+        watchdog.cancel()
     ms_per_step = 1e3 * elapsed / args.steps
     mpaths = W * H * args.steps / elapsed / 1e6
 

@@ -384,6 +384,32 @@ def test_bench_frame_loop_with_two_ranks_on_one_gpu(built_lib, flags):
 
 
 @pytest.mark.gpu
+def test_bench_starts_its_own_ranks_and_survives_a_transport_that_hangs(built_lib):
+    """`python bench.py --gpus 2` with no launcher around it starts the ranks itself and prints their one line; ranks that do not finish
+    (--rank-timeout: every rank reports the stage it is in and exits) get ONE more attempt over the conservative transport, and a run
+    whose both attempts fail ends with an exit code and the reason instead of hanging."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GFX_BENCH_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--mse-ref-spp", "0", "--cpu-sample", "0"]
+    r = subprocess.run(base, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "fallback" not in d["config"]
+    r = subprocess.run(base + ["--rank-timeout", "0.05"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode != 0
+    assert "did not finish within" in r.stderr and "one more attempt with --exchange torch --sync-gather" in r.stderr, r.stderr[-3000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
 def test_lane_schedules_compute_the_same_frames(built_lib):
     """G-buffer strips on the G-buffer lane, band gather on the gather lane, injected latency: bit-identical to the one-stream schedule
     (tests/lane_schedule_check.py, its own process: it names the mirror librccl stand-in)."""
