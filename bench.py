@@ -413,9 +413,10 @@ def run_config(args, rank, local_rank, world, dist):
         watchdog.daemon = True
         watchdog.start()
     if world > 1:
-        # strip exchange: every pass runs on the band only; the rows the next pass reads across the seams travel between the passes --
-        # the G-buffer strips on the G-buffer lane behind the pipelined G-buffer pass, the reservoir strips on the frame's stream before
-        # each spatial pass -- and the HDR bands are all-gathered on the gather lane underneath the next frame (gfxexp_host.h gfxh_lane)
+        # strip exchange: the rows the reuse passes read across the seams travel between the passes -- the G-buffer strips on the G-buffer
+        # lane behind the pipelined G-buffer pass, the reservoir strips once per frame on the frame's stream behind the candidate pass
+        # (the first spatial pass of two is recomputed on its halo: stripMode 3) -- and the HDR bands are all-gathered on the gather lane
+        # underneath the next frame (gfxexp_host.h gfxh_lane)
         motion_rows = ANIMATE_MAX_MOTION_ROWS if args.animate else 0       # static camera and scene: no motion rows
         L = api.lib()
         L.gfxh_rccl_last_error.restype = C.c_char_p

@@ -208,9 +208,11 @@ int gfxh_restir_band_plan(gfxh_restir* r, gfxh_band_plan* out);
  * ncclSend / ncclRecv / ncclAllReduce / ncclAllGather on that stream -- gfxh_rccl_exchange below; bench.py and the
  * gloo tests: torch.distributed).  Per-pixel RNG streams are advanced by their owner only, so nothing else is shared and
  * the result is bit-identical to the single-GPU frame.  Exchange points per frame:
- *   original ReSTIR     G-buffers (16+16+16 B/pixel) after the G-buffer pass, rows max(radius, motion); reservoirs +
- *                       infos (56 B/pixel) before every spatial pass, rows radius; final reservoirs + infos after the
- *                       last reuse pass, rows motion (the next frame's temporal pass)
+ *   original ReSTIR     G-buffers (16+16+16 B/pixel) after the G-buffer pass, rows max(radius x passes, motion); reservoirs +
+ *                       infos + RNG states (64 B/pixel) ONCE behind the candidate pass, rows radius x passes -- the spatial passes
+ *                       another pass follows are recomputed on a halo that shrinks by radius rows per pass (stripMode 3, the
+ *                       default; stripMode 1: reservoirs + infos, 56 B/pixel, before every spatial pass, rows radius); final
+ *                       reservoirs + infos after the last reuse pass, rows motion (the next frame's temporal pass)
  *   rearchitected       everything the next frame reads from "the previous frame" (G-buffers, sample visibility,
  *                       reservoirs, infos: 108 B/pixel) once at the end of the frame, rows radius + motion
  *   ReGIR path tracer   all-reduce(sum) of perCellNumAccesses (one u32 per cell) before the last-access update
