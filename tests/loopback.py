@@ -98,9 +98,8 @@ def run_bands(renderers, frames, before_frame=None):
                     before_frame(frame, rank, r)
                 r.render_frame()
             torch.cuda.synchronize()
-        except BaseException as e:      # a failing band must not leave the others waiting at the barrier forever
+        except BaseException as e:      # collected here and raised by the caller below (the band's thread just ends)
             errors.append((rank, e))
-            raise
     threads = [threading.Thread(target=work, args=(rank, r), daemon=True) for rank, r in enumerate(renderers)]
     for t in threads:
         t.start()
