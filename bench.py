@@ -399,19 +399,22 @@ def run_config(args, rank, local_rank, world, dist):
     exchange = None
     transport = None
     stage = ["setup"]
-    watchdog = None
-    if world > 1 and args.rank_timeout > 0:
-        # a collective that never completes (a transport that deadlocks on hardware nobody could test on) must cost the run minutes and
-        # leave a reason, not hang the node: the rank says where it is and exits, and the launcher ends the others
+    def arm_watchdog(limit):
+        """A collective that never completes (a transport that deadlocks on hardware nobody could test on) must cost the run minutes and
+        leave a reason, not hang the node: the rank says where it is and exits, and the launcher ends the others."""
+        if world == 1 or args.rank_timeout <= 0:
+            return None
         import threading
 
         def expired():
-            sys.stderr.write("bench: rank %d did not finish within %.0f s (--rank-timeout); it is in: %s; transport: %s\n" % (rank, args.rank_timeout, stage[0], transport))
+            sys.stderr.write("bench: rank %d did not finish within %.0f s (--rank-timeout); it is in: %s; transport: %s\n" % (rank, limit, stage[0], transport))
             sys.stderr.flush()
             os._exit(3)
-        watchdog = threading.Timer(args.rank_timeout, expired)
-        watchdog.daemon = True
-        watchdog.start()
+        timer = threading.Timer(limit, expired)
+        timer.daemon = True
+        timer.start()
+        return timer
+    watchdog = arm_watchdog(args.rank_timeout)
     if world > 1:
         # strip exchange: the rows the reuse passes read across the seams travel between the passes -- the G-buffer strips on the G-buffer
         # lane behind the pipelined G-buffer pass, the reservoir strips once per frame on the frame's stream behind the candidate pass
@@ -595,6 +598,33 @@ def run_config(args, rank, local_rank, world, dist):
             else:
                 result["cpu_baseline"] = {"value": None, "unit": "Mpaths/s", "cores": 0, "kind": "port",
                                           "sample": "not timed for this line: see the default line (configs[2], static) for the CPU restatement on this host"}
+    if world > 1:
+        # what the ranks can say about the frame together: rank 0's gathered frame holds every rank's band bit for bit, and the MSE leg
+        import torch
+        stage[0] = "the gathered frame against the ranks' bands"
+        watchdog = arm_watchdog(args.rank_timeout)
+        n_words = W * H * 4
+        frame_words = _device_view(renderer.beauty_ptr(), n_words).view(torch.int32)
+
+        def band_sum(b):
+            return frame_words[b[0] * W * 4: b[1] * W * 4].to(torch.int64).sum().reshape(1)
+        mine = band_sum(bands[rank])
+        every = torch.zeros(world, dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(every, mine)
+        if rank == 0:
+            held = torch.cat([band_sum(b) for b in bands])
+            result["gathered_frame_matches_bands"] = bool(torch.equal(held, every))
+        if watchdog is not None:
+            watchdog.cancel()
+        if args.mse_ref_spp > 0 and args.config == 2 and not args.animate:
+            stage[0] = "the MSE reference (every rank accumulates the reference of its rows)"
+            # (about ref_spp x a band's plain-NEE frame: ~150 s / world at 64k frames; the limit scales with it)
+            watchdog = arm_watchdog(args.rank_timeout + 0.01 * args.mse_ref_spp)
+            m = mse_vs_reference(ctx, hs, renderer, cam, W, H, args.mse_ref_spp, band=tuple(bands[rank]), dist=dist)
+            if rank == 0:
+                result["mse"] = m
+            if watchdog is not None:
+                watchdog.cancel()
     renderer.close()
     ctx.close()
     return result
@@ -819,20 +849,27 @@ def roofline_nrc(ctx, renderer, stream, W, H):
     return roof, per_frame, stats
 
 
-def mse_vs_reference(ctx, hs, renderer, cam, W, H, ref_spp):
+def mse_vs_reference(ctx, hs, renderer, cam, W, H, ref_spp, band=None, dist=None):
     """MSE / relMSE of one 1-spp ReSTIR frame against an fp64 accumulation of `ref_spp` frames of
-    plain RIS/NEE (temporal + spatial reuse off), same scene and camera."""
+    plain RIS/NEE (temporal + spatial reuse off), same scene and camera.
+    N > 1 (`band`, `dist`): the reference estimator reads no other pixel, so every rank accumulates the reference of ITS rows with a band
+    renderer that exchanges nothing -- the same per-pixel RNG streams, hence the same reference image as the one-GPU run's -- holds them
+    against its rows of the timed renderer's last frame, and the sums of squared errors are added over the ranks."""
     import torch
     from gfxexp_amd import api
-    n = W * H
-    test = torch.from_numpy(ctx.read_device(renderer.beauty_ptr(), n * 16).view(np.float32).reshape(n, 4).copy())[:, :3].double()
+    b0, b1 = band if band is not None else (0, H)
+    n = (b1 - b0) * W
+    first = b0 * W                   # pixels are row-major: a band is one contiguous range of the HDR buffer
+    test = torch.from_numpy(ctx.read_device(renderer.beauty_ptr() + first * 16, n * 16).view(np.float32).reshape(n, 4).copy())[:, :3].double()
     cfg = api.RestirRenderer.default_config(W, H, api.RENDERER_UNBIASED)
     cfg.camera = cam
     cfg.enableTemporalReuse = 0
     cfg.enableSpatialReuse = 0
+    if band is not None:
+        cfg.rowBegin, cfg.rowEnd = b0, b1
     ref_r = api.RestirRenderer(ctx, cfg)
     acc = torch.zeros(n * 4, dtype=torch.float64, device="cuda")
-    view = _device_view(ref_r.beauty_ptr(), n * 4)
+    view = _device_view(ref_r.beauty_ptr() + first * 16, n * 4)
     stream = torch.cuda.current_stream().cuda_stream
     t0 = time.perf_counter()
     for _ in range(ref_spp):
@@ -845,10 +882,27 @@ def mse_vs_reference(ctx, hs, renderer, cam, W, H, ref_spp):
     ref_r.close()
     err = (test - ref) ** 2
     err_plain = (one_ref_frame - ref) ** 2
-    return {"mse": float(err.mean()), "rel_mse": float((err / (ref ** 2 + 1e-2)).mean()), "ref_spp": ref_spp,
-            "mse_of_one_reference_frame": float(err_plain.mean()), "rel_mse_of_one_reference_frame": float((err_plain / (ref ** 2 + 1e-2)).mean()),
-            "ref_estimator": "RIS/NEE 32 candidates + visibility, no reuse, fp64 accumulation", "ref_seconds": round(seconds, 1),
-            "note": "the metric names a 64k-spp reference (the default); a smaller --mse-ref-spp reads higher by the reference's own noise"}
+    # sums over this rank's pixels (x 3 channels), then over the ranks: the means are over the whole frame
+    sums = torch.tensor([float(err.sum()), float((err / (ref ** 2 + 1e-2)).sum()), float(err_plain.sum()), float((err_plain / (ref ** 2 + 1e-2)).sum()),
+                         float(err.numel()), seconds], dtype=torch.float64)
+    how = {}
+    if dist is not None:
+        sums = sums.cuda()
+        longest = sums[5:6].clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_reduce(longest, op=dist.ReduceOp.MAX)
+        sums = sums.cpu()
+        seconds = float(longest.item())
+        how = {"how": "every rank accumulated the reference of its own rows (a band renderer without reuse reads no other rank's pixels) and held it against its rows "
+                      "of the last timed frame; squared errors summed over the ranks.  Same per-pixel RNG streams as the one-GPU run: the same reference image"}
+    count = float(sums[4])
+    assert count == 3.0 * W * H, (count, W, H)
+    out = {"mse": float(sums[0] / count), "rel_mse": float(sums[1] / count), "ref_spp": ref_spp,
+           "mse_of_one_reference_frame": float(sums[2] / count), "rel_mse_of_one_reference_frame": float(sums[3] / count),
+           "ref_estimator": "RIS/NEE 32 candidates + visibility, no reuse, fp64 accumulation", "ref_seconds": round(seconds, 1),
+           "note": "the metric names a 64k-spp reference (the default); a smaller --mse-ref-spp reads higher by the reference's own noise"}
+    out.update(how)
+    return out
 
 
 def _device_view(ptr, num_floats):

@@ -396,13 +396,23 @@ def test_bench_starts_its_own_ranks_and_survives_a_transport_that_hangs(built_li
     env = dict(os.environ, GFX_BENCH_ONE_GPU="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--mse-ref-spp", "0", "--cpu-sample", "0"]
-    r = subprocess.run(base, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    tail = ["--steps", "3", "--warmup", "2", "--cpu-sample", "0"]
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mse-ref-spp", "0"] + tail
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mse-ref-spp", "48"] + tail, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "fallback" not in d["config"]
+    # the ranks together: rank 0's gathered frame is the ranks' bands, and the MSE against the reference every rank accumulated for its
+    # rows is the one-GPU run's (same frames, same per-pixel reference streams; fp64 sums in another order)
+    assert d["gathered_frame_matches_bands"] is True
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--mse-ref-spp", "48", "--no-roofline", "--other-configs", "0"] + tail,
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    for key in ("mse", "rel_mse", "mse_of_one_reference_frame"):
+        assert abs(d["mse"][key] - d1["mse"][key]) <= 1e-9 * abs(d1["mse"][key]), (key, d["mse"][key], d1["mse"][key])
     r = subprocess.run(base + ["--rank-timeout", "0.05"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode != 0
     assert "did not finish within" in r.stderr and "one more attempt with --exchange torch --sync-gather" in r.stderr, r.stderr[-3000:]
