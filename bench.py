@@ -152,9 +152,9 @@ def parse():
     ap.add_argument("--mse-ref-spp", type=int, default=65536, help="frames of plain-NEE reference accumulated in fp64 for the MSE figure; the metric names 64k (0 = skip)")
     ap.add_argument("--cpu-sample", type=str, default="480x270", help="resolution of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--balance-bands", type=int, default=0,
-                    help="N > 1 with the torch.distributed exchange: rounds of cost-balancing the row bands during the warm-up (each round: "
-                         "4 frames, all-gather of the ranks' frame times, gfxh_balance_bands, band renderers re-created); 0 = equal bands")
+    ap.add_argument("--balance-bands", type=int, default=2,
+                    help="N > 1: rounds of cost-balancing the row bands during the warm-up (each round: 4 frames of every rank's band alone, "
+                         "all-gather of the times, gfxh_balance_bands, band renderers re-created); 0 = equal bands")
     ap.add_argument("--plain", action="store_true", help="constant-colour materials (the round-1 workload) instead of the textured street")
     ap.add_argument("--exchange", default="auto", choices=["auto", "torch", "rccl"],
                     help="N > 1: strip-exchange transport -- rccl: the C++ gfxh_rccl_exchange (no Python between the passes, one communicator per lane); "
@@ -479,12 +479,20 @@ def run_config(args, rank, local_rank, world, dist):
             r.set_async_gather(not args.sync_gather)
             return ex
         transport = "gfxh_rccl_exchange (C++, %d communicators)" % api.NUM_LANES if use_rccl else "tilesplit.StripExchange (torch.distributed)"
-        exchange = install(renderer, bands)
+        # Equal rows are not equal work (sky rows are cheap).  Each round: time this rank's band ALONE over a few frames -- behind a callback
+        # that moves nothing, because a frame with its exchanges takes as long as the slowest neighbour's and says nothing about this
+        # band's cost (the seam rows then hold stale data: the same amount of work) --, all-gather the times, cut the frame where
+        # gfxh_balance_bands says (the same call with the same numbers on every rank) and start over with a band renderer for the new rows.
+        # All inside the untimed warm-up; the timed frames use the final partition and a renderer that has seen none of this.
         stage[0] = "band balancing (untimed)"
-        # Equal rows are not equal work (sky rows are cheap).  Each round: time this rank's band over a few frames, all-gather
-        # the times, cut the frame where gfxh_balance_bands says (the same call with the same numbers on every rank) and start
-        # over with band renderers for the new rows -- all inside the untimed warm-up; the timed frames use the final partition.
+        strip_rows_needed = 8 * ((int(cfg.spatialNeighborRadius) * max(1, int(cfg.numSpatialReusePasses)) + motion_rows + 7) // 8)
+        balancing = []
+
+        def nothing(stream_, d):
+            return None
         for _ in range(max(0, args.balance_bands)):
+            renderer.set_exchange(nothing, motion_rows)
+            renderer.set_async_gather(False)
             for _ in range(2):
                 renderer.render_frame(stream)
             torch.cuda.synchronize()
@@ -493,21 +501,23 @@ def run_config(args, rank, local_rank, world, dist):
             for _ in range(4):
                 renderer.render_frame(stream)
             e1.record()
-            renderer.finish_gather(stream)
             torch.cuda.synchronize()
             mine = torch.tensor([e0.elapsed_time(e1) / 4], dtype=torch.float32, device="cuda")
             times = torch.zeros(world, dtype=torch.float32, device="cuda")
             dist.all_gather_into_tensor(times, mine)
-            new_bands = api.balance_bands(H, bands, [float(t) for t in times.cpu()], min_rows=24)
-            if new_bands == bands:
-                break
+            band_ms = [float(t) for t in times.cpu()]
+            balancing.append({"bands": [list(b) for b in bands], "band_ms_alone": [round(t, 4) for t in band_ms]})
+            new_bands = api.balance_bands(H, bands, band_ms, min_rows=max(24, strip_rows_needed))
+            changed = new_bands != bands
             bands = new_bands
-            renderer.close()
+            renderer.close()                         # (also when nothing moved: this one's seams have seen no neighbour)
             cfg.rowBegin, cfg.rowEnd = bands[rank]
             renderer = api.RestirRenderer(ctx, cfg)
             if args.config == 4:
                 renderer.set_env(sky, 2048, 1024, 0.6, 0.4)
-            exchange = install(renderer, bands)
+            if not changed:
+                break
+        exchange = install(renderer, bands)
 
     frame_no = [0]
 
@@ -558,7 +568,7 @@ def run_config(args, rank, local_rank, world, dist):
         "vs_baseline": None, "dtype": "f32" if args.config != 3 else "f32 path tracing + bf16 MFMA network (fp32 accumulate, fp32 master weights)", "data": "synthetic",
         "config": {"workload": workload,
                    "width": W, "height": H, "spp": 1, "parallelism": (f"row-bands x{world}" + (" on ONE device, host-staged gloo (GFX_BENCH_ONE_GPU: a functional check, not a measurement)" if os.environ.get("GFX_BENCH_ONE_GPU") == "1" else "")) if world > 1 else "single GPU",
-                   "bands": bands, "exchange": transport, "band_gather": (None if world == 1 else "caller's stream" if args.sync_gather else "gather lane, underneath the next frame"),
+                   "bands": bands, "band_balancing": (balancing if world > 1 else None), "exchange": transport, "band_gather": (None if world == 1 else "caller's stream" if args.sync_gather else "gather lane, underneath the next frame"),
                    "bvh": {"nodes": accel_stats["nodes"], "triangles": accel_stats["triRecords"], "levels": accel_stats["maxDepth"]} if accel_stats else None,
                    "light_table": ctx.lights_table_info(),
                    # scene.setupLightInstDistribution runs every frame in the reference (restir_di_main.cpp:2303-2309); here the call is made

@@ -381,6 +381,11 @@ def test_bench_frame_loop_with_two_ranks_on_one_gpu(built_lib, flags):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["ms_per_step"] > 0
     assert "row-bands x2" in d["config"]["parallelism"] and d["config"]["bands"] is not None and len(d["config"]["bands"]) == 2
     assert d["config"]["bands"][0][0] == 0 and d["config"]["bands"][0][1] == d["config"]["bands"][1][0] and d["config"]["bands"][1][1] == d["config"]["height"]
+    # the default: bands cut by cost (every rank's band timed alone behind a callback that moves nothing, gfxh_balance_bands on the times)
+    rounds = d["config"]["band_balancing"]
+    assert 1 <= len(rounds) <= 2 and all(len(r["band_ms_alone"]) == 2 and min(r["band_ms_alone"]) > 0 for r in rounds)
+    assert rounds[0]["bands"] == [[0, 544], [544, 1080]]
+    assert d["gathered_frame_matches_bands"] is True
 
 
 @pytest.mark.gpu
