@@ -20,6 +20,7 @@
 #                host: python gfxexp_amd/build.py --variant laneprof GFX_LANE_PROFILE)    -> profiles/r03_initial_candidates.txt
 #   renderers    tools/bench_renderers.py + tools/bench_config4.py                      -> profiles/r03_renderers.jsonl
 #   bands        tools/bench_band.py (compute-only bound of N row bands)                -> profiles/r03_band_compute_bound.json
+#   timeline     tools/band_timeline.py (kernel start / end times of one band frame)    -> profiles/r06_band_timeline.json
 #   l2gather     tools/microbench/l2_gather.hip: scattered 64-byte sectors per second out of L2 / Infinity Cache / HBM by table size
 #                                                                                       -> profiles/r03_l2_gather.jsonl
 #   valurate     tools/microbench/valu_rate.hip: wave64 VALU issue rate per SIMD by instruction kind and resident waves
@@ -99,6 +100,10 @@ for step in "$@"; do
                timeout 300 python tools/bench_config4.py >> $OUT/renderers.jsonl 2>> $OUT/renderers.err; cat $OUT/renderers.jsonl ;;
     bands)     timeout 900 python tools/bench_band.py > $OUT/band_compute_bound.json 2> $OUT/band.err; cat $OUT/band_compute_bound.json; tail -3 $OUT/band.err ;;
     bands4)    timeout 900 python tools/bench_band.py --config4 --modes strips > $OUT/band_compute_bound_config4.json 2>> $OUT/band.err; cat $OUT/band_compute_bound_config4.json ;;
+    timeline)  rm -rf $OUT/tl; timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl/c2 -- python tools/band_timeline.py run > /dev/null 2>&1
+               python tools/band_timeline.py read $OUT/tl/c2 > $OUT/band_timeline_c2.json
+               timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl/c4 -- python tools/band_timeline.py run --config4 > /dev/null 2>&1
+               python tools/band_timeline.py read $OUT/tl/c4 > $OUT/band_timeline_c4.json; rm -rf $OUT/tl; cat $OUT/band_timeline_c2.json $OUT/band_timeline_c4.json ;;
     nrcprof)   GFX_LIB=$PWD/gfxexp_amd/variants/libgfxexp_laneprof.so timeout 300 python tools/nrc_infer_profile.py > $OUT/nrc_infer_profile.json 2> $OUT/nrc_prof.err; cat $OUT/nrc_infer_profile.json ;;
     l2gather)  hipcc --offload-arch=gfx950 -O3 -w -o /tmp/l2_gather tools/microbench/l2_gather.hip && timeout 120 /tmp/l2_gather | tee $OUT/l2_gather.jsonl ;;
     valurate)  hipcc --offload-arch=gfx950 -O3 -w -o /tmp/valu_rate tools/microbench/valu_rate.hip && timeout 120 /tmp/valu_rate | tee $OUT/valu_rate.jsonl ;;
