@@ -317,10 +317,35 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     result = run_config(args, rank, local_rank, world, dist)
-    if rank == 0 and world == 1 and args.other_configs and args.config == 2 and not (args.animate or args.plain or args.cluttered):
+    headline_only = args.config == 2 and not (args.animate or args.plain or args.cluttered)
+    if rank == 0 and world == 1 and args.other_configs and headline_only:
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         result["other_configs"] = _other_configs(args)
+    if world > 1 and args.other_configs and headline_only:
+        # N > 1: BASELINE's configs[4] IS the split across the GPUs of the node (unbiased estimator + environment map), so the same ranks
+        # run a short measurement of it after the headline is complete.  The headline must not depend on it: when the ranks do not finish it
+        # in time, every rank's watchdog ends its process with code 0 and rank 0 prints the headline with the reason first.
+        import copy
+        extra = copy.copy(args)
+        extra.config, extra.steps, extra.warmup, extra.mse_ref_spp, extra.cpu_sample = 4, args.other_steps, 5, 0, "0"
+        extra.rank_timeout = min(args.rank_timeout, 150.0) if args.rank_timeout > 0 else 150.0
+
+        def give_up(why):
+            if rank == 0:
+                result["other_configs"] = {"configs[4]": {"error": why}}
+                print(json.dumps(result))
+                sys.stdout.flush()
+            os._exit(0)
+        try:
+            r4 = run_config(extra, rank, local_rank, world, dist, on_timeout=give_up)
+            if rank == 0:
+                result["other_configs"] = {"configs[4]": {"metric": r4["metric"], "value": r4["value"], "unit": r4["unit"], "n_gpus": world, "ms_per_step": r4["ms_per_step"],
+                                                          "steps": r4["steps"], "warmup": r4["warmup"], "workload": r4["config"]["workload"],
+                                                          "bands": r4["config"]["bands"], "band_balancing": r4["config"]["band_balancing"], "exchange": r4["config"]["exchange"],
+                                                          "gathered_frame_matches_bands": r4.get("gathered_frame_matches_bands")}}
+        except BaseException as e:          # this rank alone may have failed: the others end at their watchdogs; no collective after this point
+            give_up("rank %d: %r" % (rank, e))
     if rank == 0:
         print(json.dumps(result))
         sys.stdout.flush()
@@ -329,8 +354,9 @@ def main():
         dist.destroy_process_group()
 
 
-def run_config(args, rank, local_rank, world, dist):
-    """One measurement: scene, renderer, warm-up, the timed steps, and (rank 0, one GPU) the roofline / MSE / CPU legs.  Returns the JSON object."""
+def run_config(args, rank, local_rank, world, dist, on_timeout=None):
+    """One measurement: scene, renderer, warm-up, the timed steps, and (rank 0, one GPU) the roofline / MSE / CPU legs.  Returns the JSON object.
+    on_timeout(reason): what a rank's watchdog does instead of leaving with code 3 (the secondary measurement of an N > 1 run)."""
     import torch
     from gfxexp_amd import api
     from gfxexp_amd import tilesplit
@@ -407,8 +433,11 @@ def run_config(args, rank, local_rank, world, dist):
         import threading
 
         def expired():
-            sys.stderr.write("bench: rank %d did not finish within %.0f s (--rank-timeout); it is in: %s; transport: %s\n" % (rank, limit, stage[0], transport))
+            why = "rank %d did not finish within %.0f s (--rank-timeout); it is in: %s; transport: %s" % (rank, limit, stage[0], transport)
+            sys.stderr.write("bench: %s\n" % why)
             sys.stderr.flush()
+            if on_timeout is not None:
+                on_timeout(why)
             os._exit(3)
         timer = threading.Timer(limit, expired)
         timer.daemon = True

@@ -386,6 +386,13 @@ def test_bench_frame_loop_with_two_ranks_on_one_gpu(built_lib, flags):
     assert 1 <= len(rounds) <= 2 and all(len(r["band_ms_alone"]) == 2 and min(r["band_ms_alone"]) > 0 for r in rounds)
     assert rounds[0]["bands"] == [[0, 544], [544, 1080]]
     assert d["gathered_frame_matches_bands"] is True
+    if not flags:
+        # the headline run also measures BASELINE's configs[4] -- the configuration that IS the split across the node -- on the same ranks
+        c4 = d["other_configs"]["configs[4]"]
+        assert "error" not in c4, c4
+        assert c4["n_gpus"] == 2 and c4["value"] > 0 and "unbiased" in c4["workload"] and c4["gathered_frame_matches_bands"] is True
+    else:
+        assert "other_configs" not in d
 
 
 @pytest.mark.gpu
