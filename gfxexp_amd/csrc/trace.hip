@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
         const unsigned long long idleMask = __ballot(!tr.active);
         const int numIdle = __popcll(idleMask);
         bool newRay = false;
-        float4 rayO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rayD = rayO;
+        float4 rayO, rayD;             // read only under newRay (no default: eight v_mov per wave iteration, a ray refilled or not)
         uint32_t hint = 0xFFFFFFFFu;
         if (!exhausted && numIdle >= a.refillThreshold) {
             // wave-local ticket range: one device atomic buys a batch of rays, bought on demand
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
             ++diagIter; diagLanes += held;
             if (exhausted) { ++diagDrainIter; diagDrainLanes += held; }
         }
-        uint4 link = make_uint4(0u, 0u, 0u, 0u);
+        uint4 link;                    // read only by process_node, i.e. under the condition of its load
         if (code != kItemNone && !(code & kItemTri)) link = reinterpret_cast<const uint4*>(a.accel.links)[code];   // in flight with the item fetch
         uint4 q0, q1, q2, q3;
         const unsigned long long cyc1 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;

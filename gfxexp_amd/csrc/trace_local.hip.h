@@ -46,7 +46,7 @@ GFX_DEV RayHit trace_wave_local(const DevAccel& accel, bool want, f3 org, f3 dir
         ++steps;
         uint32_t code = kItemNone;
         if (tr.active) code = tr.next_item(stack, accel.triItemOffset);      // the first item of a ray is the root (begin's one-child group)
-        uint4 link = make_uint4(0u, 0u, 0u, 0u);
+        uint4 link;                    // read only by process_node, i.e. under the condition of its load (no default: v_mov per iteration)
         if (code != kItemNone && !(code & kItemTri)) link = reinterpret_cast<const uint4*>(accel.links)[code];   // in flight with the item fetch
         uint4 q0, q1, q2, q3;
         fetch_items(code, accel, waveBuf, lane, q0, q1, q2, q3);
