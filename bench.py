@@ -425,6 +425,19 @@ def run_config(args, rank, local_rank, world, dist, on_timeout=None):
     exchange = None
     transport = None
     stage = ["setup"]
+    measured = [None]          # the line once the timed frames are in: what a failure of a LATER leg must not cost
+
+    def leave_with_the_measurement(why):
+        """A leg after the timed frames (the gathered-frame check, the MSE reference) failed or hung on this rank: no collective is safe
+        any more, so rank 0 prints the measurement with the reason and every rank ends its process with code 0."""
+        if on_timeout is not None:
+            on_timeout(why)                  # the secondary measurement of an N > 1 run: the caller prints the headline
+        if rank == 0 and measured[0] is not None:
+            measured[0]["after_the_timed_frames"] = {"error": why}
+            print(json.dumps(measured[0]))
+            sys.stdout.flush()
+        os._exit(0 if measured[0] is not None else 3)
+
     def arm_watchdog(limit):
         """A collective that never completes (a transport that deadlocks on hardware nobody could test on) must cost the run minutes and
         leave a reason, not hang the node: the rank says where it is and exits, and the launcher ends the others."""
@@ -436,6 +449,8 @@ def run_config(args, rank, local_rank, world, dist, on_timeout=None):
             why = "rank %d did not finish within %.0f s (--rank-timeout); it is in: %s; transport: %s" % (rank, limit, stage[0], transport)
             sys.stderr.write("bench: %s\n" % why)
             sys.stderr.flush()
+            if measured[0] is not None:
+                leave_with_the_measurement(why)
             if on_timeout is not None:
                 on_timeout(why)
             os._exit(3)
@@ -638,32 +653,40 @@ def run_config(args, rank, local_rank, world, dist, on_timeout=None):
                 result["cpu_baseline"] = {"value": None, "unit": "Mpaths/s", "cores": 0, "kind": "port",
                                           "sample": "not timed for this line: see the default line (configs[2], static) for the CPU restatement on this host"}
     if world > 1:
-        # what the ranks can say about the frame together: rank 0's gathered frame holds every rank's band bit for bit, and the MSE leg
+        # what the ranks can say about the frame together: rank 0's gathered frame holds every rank's band bit for bit, and the MSE leg.
+        # From here on a failure costs these legs, not the measurement (leave_with_the_measurement).
         import torch
+        measured[0] = result
         stage[0] = "the gathered frame against the ranks' bands"
         watchdog = arm_watchdog(args.rank_timeout)
-        n_words = W * H * 4
-        frame_words = _device_view(renderer.beauty_ptr(), n_words).view(torch.int32)
+        try:
+            if os.environ.get("GFX_BENCH_TEST_FAIL_RANK") == str(rank):          # tests/test_gpu_strip_exchange.py: a rank that dies here
+                raise RuntimeError("injected by GFX_BENCH_TEST_FAIL_RANK")
+            n_words = W * H * 4
+            frame_words = _device_view(renderer.beauty_ptr(), n_words).view(torch.int32)
 
-        def band_sum(b):
-            return frame_words[b[0] * W * 4: b[1] * W * 4].to(torch.int64).sum().reshape(1)
-        mine = band_sum(bands[rank])
-        every = torch.zeros(world, dtype=torch.int64, device="cuda")
-        dist.all_gather_into_tensor(every, mine)
-        if rank == 0:
-            held = torch.cat([band_sum(b) for b in bands])
-            result["gathered_frame_matches_bands"] = bool(torch.equal(held, every))
-        if watchdog is not None:
-            watchdog.cancel()
-        if args.mse_ref_spp > 0 and args.config == 2 and not args.animate:
-            stage[0] = "the MSE reference (every rank accumulates the reference of its rows)"
-            # (about ref_spp x a band's plain-NEE frame: ~150 s / world at 64k frames; the limit scales with it)
-            watchdog = arm_watchdog(args.rank_timeout + 0.01 * args.mse_ref_spp)
-            m = mse_vs_reference(ctx, hs, renderer, cam, W, H, args.mse_ref_spp, band=tuple(bands[rank]), dist=dist)
+            def band_sum(b):
+                return frame_words[b[0] * W * 4: b[1] * W * 4].to(torch.int64).sum().reshape(1)
+            mine = band_sum(bands[rank])
+            every = torch.zeros(world, dtype=torch.int64, device="cuda")
+            dist.all_gather_into_tensor(every, mine)
             if rank == 0:
-                result["mse"] = m
+                held = torch.cat([band_sum(b) for b in bands])
+                result["gathered_frame_matches_bands"] = bool(torch.equal(held, every))
             if watchdog is not None:
                 watchdog.cancel()
+            if args.mse_ref_spp > 0 and args.config == 2 and not args.animate:
+                stage[0] = "the MSE reference (every rank accumulates the reference of its rows)"
+                # (about ref_spp x a band's plain-NEE frame: ~150 s / world at 64k frames; the limit scales with it)
+                watchdog = arm_watchdog(args.rank_timeout + 0.01 * args.mse_ref_spp)
+                m = mse_vs_reference(ctx, hs, renderer, cam, W, H, args.mse_ref_spp, band=tuple(bands[rank]), dist=dist)
+                if rank == 0:
+                    result["mse"] = m
+                if watchdog is not None:
+                    watchdog.cancel()
+        except BaseException as e:           # (this rank alone, perhaps: the others would wait in a collective for ever)
+            leave_with_the_measurement("rank %d: %r" % (rank, e))
+        measured[0] = None
     renderer.close()
     ctx.close()
     return result

@@ -425,6 +425,11 @@ def test_bench_starts_its_own_ranks_and_survives_a_transport_that_hangs(built_li
     d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     for key in ("mse", "rel_mse", "mse_of_one_reference_frame"):
         assert abs(d["mse"][key] - d1["mse"][key]) <= 1e-9 * abs(d1["mse"][key]), (key, d["mse"][key], d1["mse"][key])
+    # a rank that fails AFTER the timed frames (in the gathered-frame check / the MSE leg) costs those legs, not the measurement
+    r = subprocess.run(base + ["--other-configs", "0"], capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, GFX_BENCH_TEST_FAIL_RANK="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "error" in d["after_the_timed_frames"] and "mse" not in d
     r = subprocess.run(base + ["--rank-timeout", "0.05"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode != 0
     assert "did not finish within" in r.stderr and "one more attempt with --exchange torch --sync-gather" in r.stderr, r.stderr[-3000:]
