@@ -220,7 +220,7 @@ class RcclExchange:
         raw = (C.c_uint8 * (128 * lanes))()
         for k in range(lanes):
             if L.gfxh_rccl_unique_id(C.byref(raw, 128 * k)):
-                raise GfxError("gfxh_rccl_unique_id: " + L.gfxh_rccl_last_error().decode())
+                raise GfxError("gfxh_rccl_unique_id: " + L.gfxh_rccl_last_error().decode(errors="replace"))
         return bytes(raw)
 
     def __init__(self, ids, rank, world, height, bands=None):
@@ -231,7 +231,7 @@ class RcclExchange:
         raw = (C.c_uint8 * len(ids)).from_buffer_copy(ids)
         h = C.c_void_p()
         if self.L.gfxh_rccl_create_lanes(raw, C.c_uint32(lanes), C.c_int(rank), C.c_int(world), C.c_uint32(height), C.byref(h)):
-            raise GfxError("gfxh_rccl_create_lanes: " + self.L.gfxh_rccl_last_error().decode())
+            raise GfxError("gfxh_rccl_create_lanes: " + self.L.gfxh_rccl_last_error().decode(errors="replace"))
         self.h = h
         if bands is not None:
             self.set_bands(bands)
@@ -239,7 +239,7 @@ class RcclExchange:
     def set_bands(self, bands):
         begins = (C.c_uint32 * (len(bands) + 1))(*([b for b, _ in bands] + [bands[-1][1]]))
         if self.L.gfxh_rccl_set_bands(self.h, begins):
-            raise GfxError("gfxh_rccl_set_bands: " + self.L.gfxh_rccl_last_error().decode())
+            raise GfxError("gfxh_rccl_set_bands: " + self.L.gfxh_rccl_last_error().decode(errors="replace"))
 
     def install(self, renderer, max_motion_rows=0):
         renderer.set_exchange_native(self.L.gfxh_rccl_exchange, self.h, max_motion_rows)
@@ -262,14 +262,14 @@ def check_partition(cfg, world, max_motion_rows=0):
     """gfxh_restir_check_partition: raises when a strip of this configuration is taller than the smallest band of `world`
     ranks -- the same verdict on every rank, before anyone enters a collective."""
     if lib().gfxh_restir_check_partition(C.byref(cfg), C.c_uint32(world), C.c_uint32(max_motion_rows)):
-        raise GfxError(lib().gfxh_restir_last_error().decode())
+        raise GfxError(lib().gfxh_restir_last_error().decode(errors="replace"))
 
 
 def check_bands(cfg, bands, max_motion_rows=0):
     """gfxh_restir_check_bands: the strip-feasibility verdict for an explicit partition [(begin, end)] (cost-balanced bands)."""
     begins = (C.c_uint32 * (len(bands) + 1))(*([b for b, _ in bands] + [bands[-1][1]]))
     if lib().gfxh_restir_check_bands(C.byref(cfg), C.c_uint32(len(bands)), begins, C.c_uint32(max_motion_rows)):
-        raise GfxError(lib().gfxh_restir_last_error().decode())
+        raise GfxError(lib().gfxh_restir_last_error().decode(errors="replace"))
 
 
 def balance_bands(height, bands, band_ms, min_rows=8):
@@ -411,13 +411,13 @@ class HostScene:
         h, w = t.shape[0], t.shape[1]
         slot = self.L.gfxh_scene_add_texture(self.h, C.c_uint32(w), C.c_uint32(h), C.c_uint32(fmt), _p(t))
         if slot == 0:
-            raise GfxError(self.L.gfxh_last_error().decode())
+            raise GfxError(self.L.gfxh_last_error().decode(errors="replace"))
         return slot
 
     def load_texture(self, path, fmt8=0):
         slot = self.L.gfxh_scene_load_texture(self.h, path.encode(), C.c_uint32(fmt8))
         if slot == 0:
-            raise GfxError(self.L.gfxh_last_error().decode())
+            raise GfxError(self.L.gfxh_last_error().decode(errors="replace"))
         return slot
 
     def textures(self):
@@ -449,14 +449,14 @@ class HostScene:
         if simple_pbr:
             g = self.L.gfxh_scene_load_obj_conv(self.h, path.encode(), C.c_int(1))
             if g == 0xFFFFFFFF:
-                raise GfxError("gfxh_scene_load_obj: " + self.L.gfxh_last_error().decode())
+                raise GfxError("gfxh_scene_load_obj: " + self.L.gfxh_last_error().decode(errors="replace"))
             return g
         return self._load_obj_trad(path)
 
     def _load_obj_trad(self, path):
         g = self.L.gfxh_scene_load_obj(self.h, path.encode())
         if g == GFX_INVALID_SLOT:
-            raise GfxError(self.L.gfxh_last_error().decode())
+            raise GfxError(self.L.gfxh_last_error().decode(errors="replace"))
         return g
 
     def add_rectangle(self, width, depth, emittance):
@@ -464,7 +464,7 @@ class HostScene:
 
     def make_street(self, params):
         if self.L.gfxh_scene_make_street(self.h, C.byref(params)):
-            raise GfxError(self.L.gfxh_last_error().decode())
+            raise GfxError(self.L.gfxh_last_error().decode(errors="replace"))
 
     def counts(self):
         c = (C.c_uint32 * 5)()
@@ -514,7 +514,7 @@ class HostScene:
 
     def upload(self, ctx):
         if self.L.gfxh_scene_upload(self.h, ctx.h):
-            raise GfxError(self.L.gfxh_last_error().decode())
+            raise GfxError(self.L.gfxh_last_error().decode(errors="replace"))
 
 
 def make_transform(scale=1.0, roll=0.0, pitch=0.0, yaw=0.0, pos=(0, 0, 0)):
@@ -561,13 +561,13 @@ def tonemap_sdr(rgba, width, height, cfg):
 def save_image_sdr(path, rgba, width, height, cfg):
     src = np.ascontiguousarray(rgba, np.float32).reshape(-1)
     if lib().gfxh_save_image_sdr(path.encode(), C.c_uint32(width), C.c_uint32(height), _p(src), C.byref(cfg)):
-        raise GfxError(lib().gfxh_last_error().decode())
+        raise GfxError(lib().gfxh_last_error().decode(errors="replace"))
 
 
 def save_image_hdr(path, rgba, width, height, brightness=1.0, flip_y=False):
     src = np.ascontiguousarray(rgba, np.float32).reshape(-1)
     if lib().gfxh_save_image_hdr(path.encode(), C.c_uint32(width), C.c_uint32(height), C.c_float(brightness), _p(src), C.c_int(int(flip_y))):
-        raise GfxError(lib().gfxh_last_error().decode())
+        raise GfxError(lib().gfxh_last_error().decode(errors="replace"))
 
 
 def env_make_sky(w, h, sun_elevation=35.0, sun_azimuth=40.0, sun_radiance=400.0):
@@ -619,7 +619,7 @@ class Context:
         self.L = lib()
         h = C.c_void_p()
         if self.L.gfx_ctx_create(C.c_int(device), C.byref(h)):
-            raise GfxError("gfx_ctx_create: " + self.L.gfx_last_error(None).decode())
+            raise GfxError("gfx_ctx_create: " + self.L.gfx_last_error(None).decode(errors="replace"))
         self.h = h
 
     def close(self):
@@ -635,7 +635,7 @@ class Context:
 
     def _check(self, rc):
         if rc:
-            raise GfxError(self.L.gfx_last_error(self.h).decode())
+            raise GfxError(self.L.gfx_last_error(self.h).decode(errors="replace"))
 
     def instance_set_transform(self, inst_slot, xfm12, normal_matrix9=None):
         """InstanceController::update for one instance (previous matrix kept for the motion vectors).  Rebuild the
@@ -867,7 +867,7 @@ class NrcRenderer:
         self.L.gfxh_nrc_network.restype = C.c_uint64
         h = C.c_void_p()
         if self.L.gfxh_nrc_create(ctx.h, C.byref(cfg), C.byref(h)):
-            raise GfxError("gfxh_nrc_create: " + self.L.gfxh_nrc_last_error().decode())
+            raise GfxError("gfxh_nrc_create: " + self.L.gfxh_nrc_last_error().decode(errors="replace"))
         self.h = h
 
     @staticmethod
@@ -901,23 +901,23 @@ class NrcRenderer:
 
     def rebuild_accel(self, stream=0):
         if self.L.gfxh_nrc_rebuild_accel(self.h, C.c_void_p(stream)):
-            raise GfxError("gfxh_nrc_rebuild_accel: " + self.L.gfxh_nrc_last_error().decode())
+            raise GfxError("gfxh_nrc_rebuild_accel: " + self.L.gfxh_nrc_last_error().decode(errors="replace"))
 
     def set_env(self, texels, w, h, power_coeff=1.0, rotation=0.0):
         t = np.ascontiguousarray(texels, np.float32)
         if self.L.gfxh_nrc_set_env(self.h, _p(t), C.c_uint32(w), C.c_uint32(h), C.c_float(power_coeff), C.c_float(rotation)):
-            raise GfxError("gfxh_nrc_set_env: " + self.L.gfxh_nrc_last_error().decode())
+            raise GfxError("gfxh_nrc_set_env: " + self.L.gfxh_nrc_last_error().decode(errors="replace"))
 
     def render_frame(self, stream=0, want_loss=False):
         loss = C.c_float(0.0)
         if self.L.gfxh_nrc_render_frame(self.h, C.c_void_p(stream), C.byref(loss) if want_loss else None):
-            raise GfxError("gfxh_nrc_render_frame: " + self.L.gfxh_nrc_last_error().decode())
+            raise GfxError("gfxh_nrc_render_frame: " + self.L.gfxh_nrc_last_error().decode(errors="replace"))
         return loss.value if want_loss else None
 
     def outputs_consumed(self, stream=0):
         """gfxh_nrc_outputs_consumed: as RestirRenderer.outputs_consumed."""
         if self.L.gfxh_nrc_outputs_consumed(self.h, C.c_void_p(stream)):
-            raise GfxError("gfxh_nrc_outputs_consumed: " + self.L.gfxh_nrc_last_error().decode())
+            raise GfxError("gfxh_nrc_outputs_consumed: " + self.L.gfxh_nrc_last_error().decode(errors="replace"))
 
     def beauty_ptr(self):
         return self.L.gfxh_nrc_beauty_buffer(self.h)
@@ -938,7 +938,7 @@ class RestirRenderer:
         self.cfg = cfg
         h = C.c_void_p()
         if self.L.gfxh_restir_create(ctx.h, C.byref(cfg), C.byref(h)):
-            raise GfxError("gfxh_restir_create: " + self.L.gfxh_restir_last_error().decode())
+            raise GfxError("gfxh_restir_create: " + self.L.gfxh_restir_last_error().decode(errors="replace"))
         self.h = h
 
     @staticmethod
@@ -993,21 +993,21 @@ class RestirRenderer:
     def set_async_gather(self, enable=True):
         """The band gather on the renderer's gather stream underneath the next frame; finish_gather() before reading other ranks' rows."""
         if self.L.gfxh_restir_set_async_gather(self.h, C.c_int(int(enable))):
-            raise GfxError("gfxh_restir_set_async_gather: " + self.L.gfxh_restir_last_error().decode())
+            raise GfxError("gfxh_restir_set_async_gather: " + self.L.gfxh_restir_last_error().decode(errors="replace"))
 
     def finish_gather(self, stream=0):
         if self.L.gfxh_restir_finish_gather(self.h, C.c_void_p(stream)):
-            raise GfxError("gfxh_restir_finish_gather: " + self.L.gfxh_restir_last_error().decode())
+            raise GfxError("gfxh_restir_finish_gather: " + self.L.gfxh_restir_last_error().decode(errors="replace"))
 
     def render_frame(self, stream=0):
         if self.L.gfxh_restir_render_frame(self.h, C.c_void_p(stream)):
-            raise GfxError("gfxh_restir_render_frame: " + self.L.gfxh_restir_last_error().decode())
+            raise GfxError("gfxh_restir_render_frame: " + self.L.gfxh_restir_last_error().decode(errors="replace"))
 
     def outputs_consumed(self, stream=0):
         """gfxh_restir_outputs_consumed: `stream` has passed its reads of the albedo / normal accumulators of the last frame (a
         denoiser, a read-back); the next frame's pipelined G-buffer pass, which rewrites them, waits for this point."""
         if self.L.gfxh_restir_outputs_consumed(self.h, C.c_void_p(stream)):
-            raise GfxError("gfxh_restir_outputs_consumed: " + self.L.gfxh_restir_last_error().decode())
+            raise GfxError("gfxh_restir_outputs_consumed: " + self.L.gfxh_restir_last_error().decode(errors="replace"))
 
     def reset(self):
         self.L.gfxh_restir_reset(self.h)
@@ -1015,7 +1015,7 @@ class RestirRenderer:
     def set_env(self, texels, w, h, power_coeff=1.0, rotation=0.0):
         t = np.ascontiguousarray(texels, np.float32)
         if self.L.gfxh_restir_set_env(self.h, _p(t), C.c_uint32(w), C.c_uint32(h), C.c_float(power_coeff), C.c_float(rotation)):
-            raise GfxError("gfxh_restir_set_env: " + self.L.gfxh_restir_last_error().decode())
+            raise GfxError("gfxh_restir_set_env: " + self.L.gfxh_restir_last_error().decode(errors="replace"))
 
     def set_camera(self, cam):
         self.L.gfxh_restir_set_camera(self.h, C.byref(cam))
@@ -1023,7 +1023,7 @@ class RestirRenderer:
     def rebuild_accel(self, stream=0):
         """After Context.instance_set_transform: rebuild this renderer's BVH in place (Scene::updateASs)."""
         if self.L.gfxh_restir_rebuild_accel(self.h, C.c_void_p(stream)):
-            raise GfxError("gfxh_restir_rebuild_accel: " + self.L.gfxh_restir_last_error().decode())
+            raise GfxError("gfxh_restir_rebuild_accel: " + self.L.gfxh_restir_last_error().decode(errors="replace"))
 
     def beauty_ptr(self):
         return self.L.gfxh_restir_beauty_buffer(self.h)

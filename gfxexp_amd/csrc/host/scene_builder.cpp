@@ -69,7 +69,13 @@ inline gfx_vertex make_vertex(V3 p, V3 n, V3 t, float u, float v) {
 }
 
 // 8-bit immediate texture value (common_host.cpp:1045-1073) ...
-inline float quantize8(float v) { const uint32_t q = std::min(static_cast<uint32_t>(255 * v), 255u); return q / 255.0f; }
+// The reference converts the float straight to uint32_t -- undefined for a negative or non-finite material constant (an .mtl file is
+// untrusted input); what its x86-64 build does is cvttss2si to 64 bits and keep the low word, which is spelled out here.
+inline uint32_t float_to_u32_like_x86_64(float f) {
+    if (!(f > -9.2e18f && f < 9.2e18f)) return 0u;                 // NaN / outside int64: the "integer indefinite" 0x8000...0, low word 0
+    return static_cast<uint32_t>(static_cast<uint64_t>(static_cast<int64_t>(f)));
+}
+inline float quantize8(float v) { const uint32_t q = std::min(float_to_u32_like_x86_64(255 * v), 255u); return q / 255.0f; }
 // ... read through an sRGB-decoding sampler (basic_types.h:5396-5402 states the formula)
 inline float srgb_degamma(float v) {
     if (v <= 0.04045f) return v / 12.92f;

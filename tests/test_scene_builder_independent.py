@@ -253,3 +253,19 @@ def test_windows_line_ends_backslashes_and_two_material_libraries(built_lib, tmp
     red, blue = mats[geoms[0][2]], mats[geoms[1][2]]
     assert list(red.a) == [1.0, 0.0, 0.0] and red.texA == 1                  # the texture was found behind the backslash path
     assert list(blue.a) == [0.0, 0.0, 1.0] and blue.texA == 0                # the second library was read
+
+
+def test_material_constants_outside_the_unit_interval_are_defined(built_lib, tmp_path):
+    """The reference's 8-bit immediate-texture value is `min<uint32_t>(255 * v, 255)`: undefined for a negative or non-finite constant.
+    The builder spells out what the reference's x86-64 build does (truncate to 64 bits, keep the low word): negative -> 255, NaN -> 0,
+    huge -> 0; and an error message that quotes bytes of the file which are not UTF-8 is still a GfxError."""
+    (tmp_path / "m.mtl").write_bytes(b"newmtl odd\nKd -0.5 nan 1e30\nKs 0.5 2 -1e30\n")
+    (tmp_path / "q.obj").write_bytes(b"mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nusemtl odd\nf 1 2 3\n")
+    hs = api.HostScene()
+    hs.load_obj(str(tmp_path / "q.obj"))
+    m = hs.materials()[hs.geoms()[0][2]]
+    assert list(m.a) == [1.0, 0.0, 0.0], list(m.a)
+    assert 0.2 < m.b[0] < 0.22 and m.b[1] == 1.0 and m.b[2] == 0.0, list(m.b)          # (127 / 255 through the sRGB decode; clamp; low word 0)
+    (tmp_path / "bad.obj").write_bytes(b"mtllib \xa7\xff.mtl\nv 0 0 0\nusemtl \xa7\nf 1 2 9\n")
+    with pytest.raises(api.GfxError):
+        api.HostScene().load_obj(str(tmp_path / "bad.obj"))
