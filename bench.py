@@ -540,18 +540,27 @@ def run_config(args, rank, local_rank, world, dist, on_timeout=None):
             for _ in range(2):
                 renderer.render_frame(stream)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(4):
-                renderer.render_frame(stream)
-            e1.record()
-            torch.cuda.synchronize()
-            mine = torch.tensor([e0.elapsed_time(e1) / 4], dtype=torch.float32, device="cuda")
+            batches = []
+            for _ in range(3):                       # the least disturbed of three batches of four frames
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(4):
+                    renderer.render_frame(stream)
+                e1.record()
+                torch.cuda.synchronize()
+                batches.append(e0.elapsed_time(e1) / 4)
+            mine = torch.tensor([min(batches)], dtype=torch.float32, device="cuda")
             times = torch.zeros(world, dtype=torch.float32, device="cuda")
             dist.all_gather_into_tensor(times, mine)
             band_ms = [float(t) for t in times.cpu()]
             balancing.append({"bands": [list(b) for b in bands], "band_ms_alone": [round(t, 4) for t in band_ms]})
             new_bands = api.balance_bands(H, bands, band_ms, min_rows=max(24, strip_rows_needed))
+            # a cut that leaves a band below 0.7x or above 1.4x its equal share is a measurement gone wrong, not a scene (the sky-heavy
+            # first band of the bench frame is 1.24x, its cheapest 0.82x: profiles/r06_band_compute_bound*.json): the partition stays
+            share = H / world
+            if any(not (0.7 * share <= e - b <= 1.4 * share) for b, e in new_bands):
+                balancing[-1]["rejected"] = [list(b) for b in new_bands]
+                new_bands = bands
             changed = new_bands != bands
             bands = new_bands
             renderer.close()                         # (also when nothing moved: this one's seams have seen no neighbour)
