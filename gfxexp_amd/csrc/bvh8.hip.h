@@ -63,6 +63,16 @@ struct LaneStack {
     }
 };
 
+// max |coordinate| per axis over the tree's planes, from the root node (item 0): |origin_k| + 257 scale_k -- the root's 255 cells and one
+// more either side for the outward rounding of a descendant's own, finer grid.  The same for every ray of a launch (scalar loads).
+GFX_DEV f3 scene_max_abs(const DevAccel& acc) {
+    if (acc.numNodes == 0u) return f3(0.0f);
+    const uint4 n0 = *reinterpret_cast<const uint4*>(acc.nodes);
+    const f3 origin(bits2f(n0.x), bits2f(n0.y), bits2f(n0.z));
+    const f3 scale(bits2f(((n0.w >> 0) & 0xFFu) << 23), bits2f(((n0.w >> 8) & 0xFFu) << 23), bits2f(((n0.w >> 16) & 0xFFu) << 23));
+    return f3(fmaf(257.0f, scale.x, fabsf(origin.x)), fmaf(257.0f, scale.y, fabsf(origin.y)), fmaf(257.0f, scale.z, fabsf(origin.z)));
+}
+
 constexpr uint32_t kItemNone = 0xFFFFFFFFu;   // nothing to fetch
 constexpr uint32_t kItemTri = 0x80000000u;    // item code: bit 31 = triangle record, low bits = index
 
@@ -75,10 +85,14 @@ constexpr uint32_t kItemTri = 0x80000000u;    // item code: bit 31 = triangle re
 // dir_k, B_k = scale_k / dir_k (one fmaf per plane).  The builder guarantees that the fp32 DECODED
 // box origin + q * scale contains the child; the fmaf form differs from that decode by a few
 // roundings, bounded by 1.5 * 2^-22 * |1/dir_k| * (max |plane coordinate| + |org_k|); slabs are
-// widened by 2^-21 of that magnitude, so no box the exact test keeps is ever culled.
+// widened by 2^-21 of that magnitude, so no box the exact test keeps is ever culled.  The magnitude is taken from the ROOT's box
+// (scene_max_abs: every plane of every node lies inside it, give or take a cell of outward rounding): one widening per ray, set up in
+// begin(), instead of six instructions per visited node for the node's own, smaller bound -- 2^-21 of the scene's extent in world units,
+// far below any box that matters.
 struct Traversal {
     f3 org, dir, inv;
-    f3 slackScale, slackOrg;               // 2^-21 |1/dir_k| and 2^-21 |org_k / dir_k|: per-ray factors of the slab widening
+    f3 slack;                              // 2^-21 |1/dir_k| (max |plane coordinate_k| over the tree + |org_k|): the slab widening of this ray
+    f3 orgInv;                             // org_k / dir_k: A_k = fma(origin_k, 1 / dir_k, -orgInv_k), one instruction per axis and node
     float tmin;
     RayHit hit;
     uint2 grp;
@@ -87,15 +101,16 @@ struct Traversal {
     bool xNeg, yNeg, zNeg;                 // the ray travels toward -k: near plane = hi, far plane = lo
     bool active;
 
-    GFX_DEV void begin(f3 o, f3 d, float t0, float t1, LaneStack& stack, bool hasNodes) {
+    GFX_DEV void begin(f3 o, f3 d, float t0, float t1, LaneStack& stack, bool hasNodes, f3 sceneMaxAbs) {
         org = o; dir = d; tmin = t0;
         // |dir_k| below 1e-20 behaves like an axis-parallel ray without producing inf / NaN
         const float dx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
         const float dy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
         const float dz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
         inv = f3(1.0f / dx, 1.0f / dy, 1.0f / dz);
-        slackScale = f3(fabsf(inv.x) * 4.76837158203125e-07f, fabsf(inv.y) * 4.76837158203125e-07f, fabsf(inv.z) * 4.76837158203125e-07f);
-        slackOrg = f3(fabsf(o.x) * slackScale.x, fabsf(o.y) * slackScale.y, fabsf(o.z) * slackScale.z);
+        slack = f3((sceneMaxAbs.x + fabsf(o.x)) * (fabsf(inv.x) * 4.76837158203125e-07f), (sceneMaxAbs.y + fabsf(o.y)) * (fabsf(inv.y) * 4.76837158203125e-07f),
+                   (sceneMaxAbs.z + fabsf(o.z)) * (fabsf(inv.z) * 4.76837158203125e-07f));
+        orgInv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
         hit.t = t1; hit.bcB = 0; hit.bcC = 0; hit.tri = GFX_INVALID_SLOT;
         // octant mask: bit k set when the ray travels toward -k, so (slot ^ oct) ascending = near to far
         oct = (dx < 0 ? 1u : 0u) | (dy < 0 ? 2u : 0u) | (dz < 0 ? 4u : 0u);
@@ -170,13 +185,9 @@ struct Traversal {
         const uint32_t nz[2] = { zNeg ? n3.z : n2.x, zNeg ? n3.w : n2.y }, fz[2] = { zNeg ? n2.x : n3.z, zNeg ? n2.y : n3.w };
 
         const f3 B = scale * inv;
-        const f3 A = (origin - org) * inv;
-        // widening: 2^-21 |1/dir_k| (|origin_k| + 255 scale_k + |org_k|), an upper bound of the magnitude the header
-        // comment asks for (|origin + 255 scale| <= |origin| + 255 scale), two FMAs per axis
-        const f3 slack(fmaf(fmaf(255.0f, scale.x, fabsf(origin.x)), slackScale.x, slackOrg.x),
-                       fmaf(fmaf(255.0f, scale.y, fabsf(origin.y)), slackScale.y, slackOrg.y),
-                       fmaf(fmaf(255.0f, scale.z, fabsf(origin.z)), slackScale.z, slackOrg.z));
-        const f3 An = A - slack, Af = A + slack;
+        // (origin - org) / dir as origin / dir - org / dir: the second rounding is of magnitude 2^-24 |org_k / dir_k|, inside the bound above
+        const f3 A(fmaf(origin.x, inv.x, -orgInv.x), fmaf(origin.y, inv.y, -orgInv.y), fmaf(origin.z, inv.z, -orgInv.z));
+        const f3 An = A - slack, Af = A + slack;     // (the ray's widening: begin())
 
         // branch-free: one bit per SLOT, classified after the loop.  Child s is missed iff tf < tn, i.e. iff the sign bit of
         // tf - tn is set (no NaNs here: every input is finite; tf is never -0: the far planes carry a positive slack and hit.t

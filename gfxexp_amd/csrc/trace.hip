@@ -64,6 +64,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     if (blockIdx.x == 0 && tid < 2 && a.zeroWords[tid]) *a.zeroWords[tid] = 0u;
     const uint32_t n = a.numRaysPtr ? *a.numRaysPtr : a.numRays;
     const bool hasNodes = a.accel.numNodes != 0;
+    const f3 sceneMaxAbs = scene_max_abs(a.accel);
 
     Traversal tr;
     tr.active = false;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
         if (COUNT) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); cycFetch += __builtin_amdgcn_s_memtime() - cyc1; }
         const unsigned long long cyc2 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         if (newRay) {                                           // its origin and direction have arrived with the items
-            tr.begin(f3(rayO.x, rayO.y, rayO.z), f3(rayD.x, rayD.y, rayD.z), rayO.w, rayD.w, stack, hasNodes);
+            tr.begin(f3(rayO.x, rayO.y, rayO.z), f3(rayD.x, rayD.y, rayD.z), rayO.w, rayD.w, stack, hasNodes, sceneMaxAbs);
             tr.grp.y = 0u;                                      // the root (begin's one-child group) is this iteration's item
             if (!hasNodes || !(rayD.w > rayO.w)) {              // empty interval or empty scene: immediate miss
                 tr.active = false;

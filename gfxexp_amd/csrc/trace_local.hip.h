@@ -37,7 +37,7 @@ GFX_DEV RayHit trace_wave_local(const DevAccel& accel, bool want, f3 org, f3 dir
     stack.lds = stackLds; stack.ldsStride = stackStride; stack.spill = stackSpill; stack.sp = 0; stack.spillCap = spillCap;
     const bool hasNodes = accel.numNodes != 0;
     Traversal tr;
-    tr.begin(org, dir, tmin, tmax, stack, hasNodes);
+    tr.begin(org, dir, tmin, tmax, stack, hasNodes, scene_max_abs(accel));
     tr.active = want && hasNodes && tmax > tmin;        // an empty interval or an empty scene: a miss (hit.t = tmax, no triangle)
     TraceCounters cnt = { 0, 0, 0 };
     bool first = true;
