@@ -22,7 +22,12 @@ namespace gfx {
 #ifndef GFX_TRACE_LDS_STACK
 #define GFX_TRACE_LDS_STACK 12         // experiment builds trade stack depth for resident waves (tools/microbench/README)
 #endif
-constexpr int kLdsStackDepth = GFX_TRACE_LDS_STACK;     // entries per lane held in LDS
+constexpr int kLdsStackDepth = GFX_TRACE_LDS_STACK;     // entries per lane held in LDS (the kernels that trace inside a per-pixel kernel)
+// k_trace holds one entry less and, in the 2 KB that frees, the octant table of process_node: 11 x 8 B x 256 + 16 KB of item buffers + 2 KB
+// = 40 KB, the same as a block of k_gbuffer_fused (12 x 8 B x 256 + 16 KB) -- four blocks per CU, and, while the pipelined G-buffer pass
+// shares the GPU with a k_trace launch, a slot either kernel leaves fits a block of the other (with 38.9-KB G-buffer blocks the slots
+// stayed with the G-buffer pass and k_trace ran a quarter short until it ended: +0.12 ms per frame, profiles/r06_experiments.txt 12)
+constexpr int kTraceLdsStackDepth = kLdsStackDepth - 1;
 constexpr int kSpillStackDepth = 64;   // entries per lane in the HBM spill area
 
 struct TraceCounters { uint32_t nodes, tris, spills; };
@@ -52,14 +57,15 @@ GFX_DEV bool ray_triangle(f3 org, f3 dir, float tmin, f3 pA, f3 eAB, f3 eCA, f3 
 struct LaneStack {
     uint2* lds; int ldsStride; uint2* spill; int sp;
     int spillCap;                      // entries of this lane's spill area (kSpillStackDepth in k_trace; sized by the tree's depth in trace_local.hip.h)
+    int ldsDepth;                      // entries of the LDS column (kLdsStackDepth; kTraceLdsStackDepth in k_trace)
     GFX_DEV void push(uint2 e, TraceCounters& cnt, bool count) {
-        if (sp < kLdsStackDepth) lds[sp * ldsStride] = e;
-        else { if (sp - kLdsStackDepth < spillCap) spill[sp - kLdsStackDepth] = e; if (count) ++cnt.spills; }
+        if (sp < ldsDepth) lds[sp * ldsStride] = e;
+        else { if (sp - ldsDepth < spillCap) spill[sp - ldsDepth] = e; if (count) ++cnt.spills; }
         ++sp;
     }
     GFX_DEV uint2 pop() {
         --sp;
-        return sp < kLdsStackDepth ? lds[sp * ldsStride] : spill[sp - kLdsStackDepth];
+        return sp < ldsDepth ? lds[sp * ldsStride] : spill[sp - ldsDepth];
     }
 };
 
@@ -172,8 +178,11 @@ struct Traversal {
     }
 
     // One node (device_types.h Bvh8Node + Bvh8Link): 8 slab tests, leaf hits -> triangle mask, node hits -> group.
+    // octPerm (k_trace): 8 x 256 bytes of LDS, octPerm[oct * 256 + m] = the 8-bit mask m with bit s moved to bit s ^ oct -- one ds_read_u8
+    // instead of the three conditional swaps (15 instructions); null: the swaps.
     template <bool COUNT>
-    GFX_DEV void process_node(uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint4 link, LaneStack& stack, TraceCounters& cnt) {
+    GFX_DEV void process_node(uint4 n0, uint4 n1, uint4 n2, uint4 n3, uint4 link, LaneStack& stack, TraceCounters& cnt,
+                              const __attribute__((address_space(3))) uint8_t* octPerm = nullptr) {
         if (COUNT) ++cnt.nodes;
         const f3 origin(bits2f(n0.x), bits2f(n0.y), bits2f(n0.z));
         const f3 scale(bits2f(bfe(n0.w, 0, 8) << 23), bits2f(bfe(n0.w, 8, 8) << 23), bits2f(bfe(n0.w, 16, 8) << 23));
@@ -212,9 +221,12 @@ struct Traversal {
         // internal children in (slot ^ oct) order: XOR-permute the 8 bit positions with three conditional swaps
         uint32_t nodeHits = hitSlots & imask;
         // (xNeg / yNeg / zNeg are the bits of oct as lane masks the near / far selection above already holds in scalar registers)
-        nodeHits = xNeg ? (((nodeHits & 0x55u) << 1) | ((nodeHits & 0xAAu) >> 1)) : nodeHits;
-        nodeHits = yNeg ? (((nodeHits & 0x33u) << 2) | ((nodeHits & 0xCCu) >> 2)) : nodeHits;
-        nodeHits = zNeg ? (((nodeHits & 0x0Fu) << 4) | ((nodeHits & 0xF0u) >> 4)) : nodeHits;
+        if (octPerm) nodeHits = octPerm[(oct << 8) + nodeHits];
+        else {
+            nodeHits = xNeg ? (((nodeHits & 0x55u) << 1) | ((nodeHits & 0xAAu) >> 1)) : nodeHits;
+            nodeHits = yNeg ? (((nodeHits & 0x33u) << 2) | ((nodeHits & 0xCCu) >> 2)) : nodeHits;
+            nodeHits = zNeg ? (((nodeHits & 0x0Fu) << 4) | ((nodeHits & 0xF0u) >> 4)) : nodeHits;
+        }
         // leaf children: keep the hit slots and the node's leaf-slot set; the rank (= triangle offset) is
         // taken when the triangle is fetched (next_item)
         const uint32_t leafBits = valid & ~imask;

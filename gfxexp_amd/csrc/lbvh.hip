@@ -684,9 +684,9 @@ void lbvh_build(Context& ctx, hipStream_t stream, Accel& out) {
         out.numNodes = rd.nodeEnd; out.staticDepth = rs.depth; out.maxDepth = std::max(rs.depth, rd.depth) + 1;
     }
     // the traversal keeps one stack entry per level it has descended past (bvh8.hip.h LaneStack: LDS + spill area)
-    if (out.maxDepth + 1 > static_cast<uint32_t>(kLdsStackDepth + kSpillStackDepth))
+    if (out.maxDepth + 1 > static_cast<uint32_t>(kTraceLdsStackDepth + kSpillStackDepth))
         throw std::runtime_error("gfx: acceleration structure is " + std::to_string(out.maxDepth) + " levels deep; the traversal stack holds " +
-                                 std::to_string(kLdsStackDepth + kSpillStackDepth) + " entries");
+                                 std::to_string(kTraceLdsStackDepth + kSpillStackDepth) + " entries");
     out.numTris = n;
     hipLaunchKernelGGL(k_tri_ids, dim3((n + 255) / 256), dim3(256), 0, stream, out.trisPtr(), 0u, n, out.triIds.as<gfx_tri_ids>());
     GFX_HIP(hipGetLastError());
@@ -708,9 +708,9 @@ bool lbvh_update_dynamic(Context& ctx, hipStream_t stream, Accel& out) {
     // per-lane spill area by the tree's depth (trace_local.hip.h local_spill_depth; a push past it would be dropped).  The depth never
     // shrinks here, so spill areas sized for an earlier frame stay large enough.
     out.maxDepth = std::max(out.maxDepth, std::max(out.staticDepth, rd.depth) + 1);
-    if (out.maxDepth + 1 > static_cast<uint32_t>(kLdsStackDepth + kSpillStackDepth))
+    if (out.maxDepth + 1 > static_cast<uint32_t>(kTraceLdsStackDepth + kSpillStackDepth))
         throw std::runtime_error("gfx: acceleration structure is " + std::to_string(out.maxDepth) + " levels deep after the update; the traversal stack holds " +
-                                 std::to_string(kLdsStackDepth + kSpillStackDepth) + " entries");
+                                 std::to_string(kTraceLdsStackDepth + kSpillStackDepth) + " entries");
     return true;
 }
 

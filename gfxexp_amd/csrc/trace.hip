@@ -48,10 +48,20 @@ struct TraceArgs {
 #endif
 template <bool ANY_HIT, bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(TraceArgs a) {
-    __shared__ uint2 ldsStack[kLdsStackDepth * kTraceBlock];
+    __shared__ uint2 ldsStack[kTraceLdsStackDepth * kTraceBlock];
     __shared__ __attribute__((aligned(16))) uint4 fetchBuf[kTraceBlock * 4];   // 4 KiB per wave
+    __shared__ uint8_t octPerm[8 * 256];              // bvh8.hip.h process_node: hit masks in (slot ^ octant) order by table
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    for (int i = tid; i < 8 * 256; i += kTraceBlock) {
+        const uint32_t o = static_cast<uint32_t>(i) >> 8;
+        uint32_t m = static_cast<uint32_t>(i) & 0xFFu;
+        if (o & 1u) m = ((m & 0x55u) << 1) | ((m & 0xAAu) >> 1);
+        if (o & 2u) m = ((m & 0x33u) << 2) | ((m & 0xCCu) >> 2);
+        if (o & 4u) m = ((m & 0x0Fu) << 4) | ((m & 0xF0u) >> 4);
+        octPerm[i] = static_cast<uint8_t>(m);
+    }
+    __syncthreads();
     uint4* waveBuf = fetchBuf + 256 * __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, kept scalar
     LaneStack stack;
     stack.lds = ldsStack + tid;
@@ -59,6 +69,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
     stack.spill = a.spill + (static_cast<size_t>(blockIdx.x) * kTraceBlock + tid) * kSpillStackDepth;
     stack.sp = 0;
     stack.spillCap = kSpillStackDepth;
+    stack.ldsDepth = kTraceLdsStackDepth;
     // the other ticket area belongs to the next launch (stream order: nobody reads it while this kernel runs)
     if (blockIdx.x == 0 && tid < static_cast<int>(kTicketCounters)) a.ticketNext[tid * kTicketStride] = 0u;
     if (blockIdx.x == 0 && tid < 2 && a.zeroWords[tid]) *a.zeroWords[tid] = 0u;
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(kTraceBlock, GFX_TRACE_MIN_WAVES) void k_trace(Trac
                 if (!tr.template process_triangle<ANY_HIT, COUNT>((code & 0x7FFFFFFFu) - a.accel.triItemOffset, q0, q1, q2, q3, a.accel.tris, cnt))
                     write_result();                         // any-hit ray found its occluder
             }
-            else tr.template process_node<COUNT>(q0, q1, q2, q3, link, stack, cnt);
+            else tr.template process_node<COUNT>(q0, q1, q2, q3, link, stack, cnt, (const __attribute__((address_space(3))) uint8_t*)octPerm);
         }
         if (!ANY_HIT && newRay && tr.active && hint < a.accel.numTris && tr.triMask == 0u) { tr.triBase = hint; tr.triMask = 0x0101u; }
         if (COUNT) cycProcess += __builtin_amdgcn_s_memtime() - cyc2;

@@ -16,7 +16,7 @@
 namespace gfx {
 
 // Entries of HBM stack spill a lane needs behind its kLdsStackDepth LDS entries for a tree `maxDepth` levels deep (host side; lbvh.hip
-// refuses trees deeper than kLdsStackDepth + kSpillStackDepth - 1): one entry per level below the LDS part, + 1, at least 4.
+// refuses trees deeper than kTraceLdsStackDepth + kSpillStackDepth - 1): one entry per level below the LDS part, + 1, at least 4.
 inline uint32_t local_spill_depth(uint32_t maxDepth) {
     const uint32_t need = maxDepth + 1 > static_cast<uint32_t>(kLdsStackDepth) ? maxDepth + 1 - static_cast<uint32_t>(kLdsStackDepth) : 0u;
     return need + 1 < 4u ? 4u : need + 1;
@@ -34,7 +34,7 @@ template <bool ANY_HIT>
 GFX_DEV RayHit trace_wave_local(const DevAccel& accel, bool want, f3 org, f3 dir, float tmin, float tmax, uint2* stackLds, int stackStride,
                                 uint2* stackSpill, int spillCap, uint4* waveBuf, int lane, uint32_t hint = 0xFFFFFFFFu, uint32_t* waveSteps = nullptr) {
     LaneStack stack;
-    stack.lds = stackLds; stack.ldsStride = stackStride; stack.spill = stackSpill; stack.sp = 0; stack.spillCap = spillCap;
+    stack.lds = stackLds; stack.ldsStride = stackStride; stack.spill = stackSpill; stack.sp = 0; stack.spillCap = spillCap; stack.ldsDepth = kLdsStackDepth;
     const bool hasNodes = accel.numNodes != 0;
     Traversal tr;
     tr.begin(org, dir, tmin, tmax, stack, hasNodes, scene_max_abs(accel));
